@@ -1,0 +1,86 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * C ABI of the CPU restatement of NVlabs/intrinsic3d's shading-optimisation hot path
+ * (fp64, hand-rolled forward-mode duals, Ceres-2.1.0-equivalent LM + CGNR).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * library (include/intrinsic3d_hip.h) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors and cannot be built
+ * in this environment (Ceres 2.1.0 / Eigen / OpenCV / Boost absent), so this restatement is
+ * checked only against finite differences, scipy dense solves and its own invariants.
+ */
+#ifndef I3D_ORACLE_H
+#define I3D_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t iterations, lm_steps;
+    double lambda_g, lambda_r0, lambda_r1, lambda_s0, lambda_s1, lambda_a;
+    int32_t fix_poses, fix_intrinsics, fix_distortion;
+    float occlusion_distance; int32_t num_observations;
+    double thres_shell; int32_t grid_level, rgbd_level;
+    int32_t cg_fixed_iterations;   /* -1 = Ceres' quadratic-model stopping rule */
+    int32_t verbose;
+} orc_opt_config;
+
+typedef struct {
+    int32_t rows[4]; double weight_sum[4]; double type_weight[4];
+    int32_t valid_voxels, num_params, num_rows_reduced;
+    double cost_initial, cost_final; int32_t lm_iterations, successful;
+    int32_t cg_iters[50]; int32_t accepted[50]; int32_t n_attempts; double final_radius; int32_t termination;
+} orc_iter_stats;
+
+typedef struct { int32_t data_rows, reg_rows, subvolumes, lm_iterations, termination; double cost_initial, cost_final; } orc_sh_stats;
+
+/* grid: built the way the reference does it — insert in file order into a Voxel grid, then convert() */
+void*   orc_grid_from_voxels(float voxel_size, int64_t n, const int32_t* keys, const float* sdf, const float* weight, const uint8_t* color);
+int64_t orc_grid_size(void* g);
+float   orc_grid_voxel_size(void* g);
+void    orc_grid_export(void* g, int32_t* keys, double* sdf, double* sdf_refined, double* albedo, float* weight, uint8_t* color);
+void    orc_grid_import(void* g, const double* sdf_refined, const double* albedo, const uint8_t* color);  /* visit order; NULL = keep */
+void    orc_grid_clear_outside_shell(void* g, double thres_shell);
+void*   orc_grid_upsample(void* g);
+void    orc_grid_free(void* g);
+
+void*   orc_frames_create(int32_t K, int32_t levels);
+void    orc_frames_set(void* fr, int32_t f, int32_t lvl, int32_t w, int32_t h, const float* lum, const float* depth, const uint8_t* bgr);
+void    orc_frames_free(void* fr);
+
+int32_t orc_optimize(void* g, void* fr, const orc_opt_config* cfg, double* intr, double* dist, double* poses,
+                     const double* voxel_sh, orc_iter_stats* stats);
+
+/* one residual collection at the current state (no solve); returns an opaque problem handle */
+void*   orc_collect(void* g, void* fr, const orc_opt_config* cfg, const double* intr, const double* dist, const double* poses,
+                    const double* voxel_sh, int32_t iteration);
+void    orc_problem_counts(void* p, int32_t rows[4], double weight_sum[4], double type_weight[4]);
+void    orc_problem_flags(void* p, uint8_t* active, uint8_t* ring_ok, uint8_t* fix_sdf, uint8_t* fix_alb);
+/* Eg rows: centre voxel (visit index), frame, normalised weight, raw residual, 29 raw partials */
+void    orc_problem_eg(void* p, int32_t* v, int32_t* f, double* weight, double* residual, double* J);
+void    orc_problem_reg(void* p, int32_t type, int32_t* v, int32_t* dir, double* weight, double* residual);
+/* gradient J^T r and diag(J^T J) of the scaled problem over GLOBAL parameter ids (2N + 6K + 9), fixed ones = 0; cost */
+double  orc_problem_normal_eq(void* p, const orc_opt_config* cfg, double* gradient, double* jtj_diag, int32_t* is_free);
+/* y = (J^T J) x over global ids with fixed columns removed */
+void    orc_problem_jtj_apply(void* p, const orc_opt_config* cfg, const double* x, double* y);
+void    orc_problem_free(void* p);
+
+int32_t orc_estimate_sh(void* g, float subvolume_size, double lambda_reg, double thres_shell, int32_t cg_fixed_iterations,
+                        int32_t* num_subvolumes, double* sh /* cap*9 */, int32_t* sub_index /* cap*3 */, int32_t cap,
+                        double* voxel_sh /* N*9 or NULL */, uint8_t* voxel_has_sh /* N or NULL */, orc_sh_stats* st);
+
+int32_t orc_recompute_colors(void* g, void* fr, const double* intr, const double* dist, const double* poses,
+                             float occlusion_distance, int32_t num_observations);
+
+/* known-answer probes */
+double  orc_shading_row(int32_t vx, int32_t vy, int32_t vz, const double* sh9, double pyr_scale, double voxel_size,
+                        int32_t w, int32_t h, const float* lum, const double* params29, double* J29 /* may be NULL */);
+void    orc_bicubic(const float* img, int32_t w, int32_t h, double r, double c, double* f, double* dfdr, double* dfdc);
+void    orc_pose_to_mat(const double* pose6, float* R9, float* t3);
+uint64_t orc_hash(int32_t x, int32_t y, int32_t z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,244 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle_i3d.so (the CPU restatement of the reference).  Import this only
+from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never from intrinsic3d_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle_i3d.so")
+
+
+class OptConfig(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("lm_steps", C.c_int32),
+                ("lambda_g", C.c_double), ("lambda_r0", C.c_double), ("lambda_r1", C.c_double),
+                ("lambda_s0", C.c_double), ("lambda_s1", C.c_double), ("lambda_a", C.c_double),
+                ("fix_poses", C.c_int32), ("fix_intrinsics", C.c_int32), ("fix_distortion", C.c_int32),
+                ("occlusion_distance", C.c_float), ("num_observations", C.c_int32),
+                ("thres_shell", C.c_double), ("grid_level", C.c_int32), ("rgbd_level", C.c_int32),
+                ("cg_fixed_iterations", C.c_int32), ("verbose", C.c_int32)]
+
+
+class IterStats(C.Structure):
+    _fields_ = [("rows", C.c_int32 * 4), ("weight_sum", C.c_double * 4), ("type_weight", C.c_double * 4),
+                ("valid_voxels", C.c_int32), ("num_params", C.c_int32), ("num_rows_reduced", C.c_int32),
+                ("cost_initial", C.c_double), ("cost_final", C.c_double), ("lm_iterations", C.c_int32),
+                ("successful", C.c_int32), ("cg_iters", C.c_int32 * 50), ("accepted", C.c_int32 * 50),
+                ("n_attempts", C.c_int32), ("final_radius", C.c_double), ("termination", C.c_int32)]
+
+
+class ShStats(C.Structure):
+    _fields_ = [("data_rows", C.c_int32), ("reg_rows", C.c_int32), ("subvolumes", C.c_int32),
+                ("lm_iterations", C.c_int32), ("termination", C.c_int32),
+                ("cost_initial", C.c_double), ("cost_final", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the restatement with g++ (the checker itself, not the product)."""
+    srcs = [os.path.join(_HERE, "src", f) for f in os.listdir(os.path.join(_HERE, "src"))] + [os.path.join(_HERE, "i3d_oracle.h")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+        L.orc_grid_from_voxels.restype = vp
+        L.orc_grid_from_voxels.argtypes = [f32, i64, vp, vp, vp, vp]
+        L.orc_grid_size.restype = i64; L.orc_grid_size.argtypes = [vp]
+        L.orc_grid_voxel_size.restype = f32; L.orc_grid_voxel_size.argtypes = [vp]
+        L.orc_grid_export.argtypes = [vp] * 7
+        L.orc_grid_import.argtypes = [vp] * 4
+        L.orc_grid_clear_outside_shell.argtypes = [vp, f64]
+        L.orc_grid_upsample.restype = vp; L.orc_grid_upsample.argtypes = [vp]
+        L.orc_grid_free.argtypes = [vp]
+        L.orc_frames_create.restype = vp; L.orc_frames_create.argtypes = [i32, i32]
+        L.orc_frames_set.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+        L.orc_frames_free.argtypes = [vp]
+        L.orc_optimize.restype = i32
+        L.orc_optimize.argtypes = [vp, vp, C.POINTER(OptConfig), vp, vp, vp, vp, vp]
+        L.orc_collect.restype = vp
+        L.orc_collect.argtypes = [vp, vp, C.POINTER(OptConfig), vp, vp, vp, vp, i32]
+        L.orc_problem_counts.argtypes = [vp, vp, vp, vp]
+        L.orc_problem_flags.argtypes = [vp] * 5
+        L.orc_problem_eg.argtypes = [vp] * 6
+        L.orc_problem_reg.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.orc_problem_normal_eq.restype = f64
+        L.orc_problem_normal_eq.argtypes = [vp, C.POINTER(OptConfig), vp, vp, vp]
+        L.orc_problem_jtj_apply.argtypes = [vp, C.POINTER(OptConfig), vp, vp]
+        L.orc_problem_free.argtypes = [vp]
+        L.orc_estimate_sh.restype = i32
+        L.orc_estimate_sh.argtypes = [vp, f32, f64, f64, i32, vp, vp, vp, i32, vp, vp, C.POINTER(ShStats)]
+        L.orc_recompute_colors.restype = i32
+        L.orc_recompute_colors.argtypes = [vp, vp, vp, vp, vp, f32, i32]
+        L.orc_shading_row.restype = f64
+        L.orc_shading_row.argtypes = [i32, i32, i32, vp, f64, f64, i32, i32, vp, vp, vp]
+        L.orc_bicubic.argtypes = [vp, i32, i32, f64, f64, vp, vp, vp]
+        L.orc_pose_to_mat.argtypes = [vp, vp, vp]
+        L.orc_hash.restype = C.c_uint64; L.orc_hash.argtypes = [i32, i32, i32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Grid:
+    """VoxelSBR grid held by the oracle (std::unordered_map with the reference hash)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_voxels(cls, voxel_size, keys, sdf, weight, color):
+        keys = np.ascontiguousarray(keys, np.int32); sdf = np.ascontiguousarray(sdf, np.float32)
+        weight = np.ascontiguousarray(weight, np.float32); color = np.ascontiguousarray(color, np.uint8)
+        return cls(lib().orc_grid_from_voxels(float(voxel_size), keys.shape[0], _p(keys), _p(sdf), _p(weight), _p(color)))
+
+    def __len__(self):
+        return int(lib().orc_grid_size(self.h))
+
+    @property
+    def voxel_size(self):
+        return float(lib().orc_grid_voxel_size(self.h))
+
+    def export(self):
+        n = len(self)
+        out = {"keys": np.zeros((n, 3), np.int32), "sdf": np.zeros(n), "sdf_refined": np.zeros(n), "albedo": np.zeros(n),
+               "weight": np.zeros(n, np.float32), "color": np.zeros((n, 3), np.uint8)}
+        lib().orc_grid_export(self.h, _p(out["keys"]), _p(out["sdf"]), _p(out["sdf_refined"]), _p(out["albedo"]), _p(out["weight"]), _p(out["color"]))
+        out["voxel_size"] = np.float32(self.voxel_size)
+        return out
+
+    def import_fields(self, sdf_refined=None, albedo=None, color=None):
+        a = None if sdf_refined is None else np.ascontiguousarray(sdf_refined, np.float64)
+        b = None if albedo is None else np.ascontiguousarray(albedo, np.float64)
+        c = None if color is None else np.ascontiguousarray(color, np.uint8)
+        lib().orc_grid_import(self.h, _p(a), _p(b), _p(c))
+
+    def clear_outside_shell(self, thres):
+        lib().orc_grid_clear_outside_shell(self.h, float(thres))
+
+    def upsample(self):
+        return Grid(lib().orc_grid_upsample(self.h))
+
+    def free(self):
+        if self.h:
+            lib().orc_grid_free(self.h); self.h = None
+
+
+class Frames:
+    def __init__(self, frames, levels):
+        self.K = len(frames); self.levels = levels
+        self.h = lib().orc_frames_create(self.K, levels)
+        self._keep = []
+        for f, fr in enumerate(frames):
+            for l in range(levels):
+                lum = np.ascontiguousarray(fr["lum"][l], np.float32); dep = np.ascontiguousarray(fr["depth"][l], np.float32)
+                bgr = np.ascontiguousarray(fr["bgr"][l], np.uint8) if fr.get("bgr") is not None else None
+                self._keep += [lum, dep, bgr]
+                lib().orc_frames_set(self.h, f, l, lum.shape[1], lum.shape[0], _p(lum), _p(dep), _p(bgr))
+
+    def free(self):
+        if self.h:
+            lib().orc_frames_free(self.h); self.h = None
+
+
+def estimate_sh(grid: Grid, subvolume_size, lambda_reg, thres_shell, cg_fixed=-1, cap=4096):
+    n = len(grid)
+    S = C.c_int32(0); sh = np.zeros((cap, 9)); idx = np.zeros((cap, 3), np.int32)
+    vsh = np.zeros((n, 9)); has = np.zeros(n, np.uint8); st = ShStats()
+    rc = lib().orc_estimate_sh(grid.h, float(subvolume_size), float(lambda_reg), float(thres_shell), int(cg_fixed),
+                               C.byref(S), _p(sh), _p(idx), cap, _p(vsh), _p(has), C.byref(st))
+    return rc, sh[:S.value].copy(), idx[:S.value].copy(), vsh, has, st
+
+
+def optimize(grid: Grid, frames: Frames, cfg: OptConfig, intr, dist, poses, voxel_sh):
+    intr = np.ascontiguousarray(intr, np.float64).copy(); dist = np.ascontiguousarray(dist, np.float64).copy()
+    poses = np.ascontiguousarray(poses, np.float64).copy(); vsh = np.ascontiguousarray(voxel_sh, np.float64)
+    stats = (IterStats * cfg.iterations)()
+    rc = lib().orc_optimize(grid.h, frames.h, C.byref(cfg), _p(intr), _p(dist), _p(poses), _p(vsh), C.cast(stats, C.c_void_p))
+    return rc, intr, dist, poses, list(stats)
+
+
+class ProblemView:
+    """One residual collection (rows, flags, normal equations) at the grid's current state."""
+
+    def __init__(self, grid: Grid, frames: Frames, cfg: OptConfig, intr, dist, poses, voxel_sh, iteration=0):
+        self.cfg = cfg; self.N = len(grid); self.K = frames.K
+        a = np.ascontiguousarray(intr, np.float64); b = np.ascontiguousarray(dist, np.float64)
+        c = np.ascontiguousarray(poses, np.float64); d = np.ascontiguousarray(voxel_sh, np.float64)
+        self.h = lib().orc_collect(grid.h, frames.h, C.byref(cfg), _p(a), _p(b), _p(c), _p(d), int(iteration))
+        rows = (C.c_int32 * 4)(); ws = (C.c_double * 4)(); tw = (C.c_double * 4)()
+        lib().orc_problem_counts(self.h, C.cast(rows, C.c_void_p), C.cast(ws, C.c_void_p), C.cast(tw, C.c_void_p))
+        self.rows = list(rows); self.weight_sum = list(ws); self.type_weight = list(tw)
+
+    def flags(self):
+        out = [np.zeros(self.N, np.uint8) for _ in range(4)]
+        lib().orc_problem_flags(self.h, *[_p(o) for o in out])
+        return dict(zip(["active", "ring_ok", "fix_sdf", "fix_alb"], out))
+
+    def eg(self, with_jacobian=True):
+        n = self.rows[0]
+        v = np.zeros(n, np.int32); f = np.zeros(n, np.int32); w = np.zeros(n); r = np.zeros(n)
+        J = np.zeros((n, 29)) if with_jacobian else None
+        lib().orc_problem_eg(self.h, _p(v), _p(f), _p(w), _p(r), _p(J))
+        return v, f, w, r, J
+
+    def reg(self, t):
+        n = self.rows[t]
+        v = np.zeros(n, np.int32); d = np.zeros(n, np.int32); w = np.zeros(n); r = np.zeros(n)
+        lib().orc_problem_reg(self.h, t, _p(v), _p(d), _p(w), _p(r))
+        return v, d, w, r
+
+    def normal_eq(self):
+        ng = 2 * self.N + 6 * self.K + 9
+        g = np.zeros(ng); dg = np.zeros(ng); fr = np.zeros(ng, np.int32)
+        cost = lib().orc_problem_normal_eq(self.h, C.byref(self.cfg), _p(g), _p(dg), _p(fr))
+        return cost, g, dg, fr
+
+    def jtj_apply(self, x):
+        x = np.ascontiguousarray(x, np.float64); y = np.zeros_like(x)
+        lib().orc_problem_jtj_apply(self.h, C.byref(self.cfg), _p(x), _p(y))
+        return y
+
+    def free(self):
+        if self.h:
+            lib().orc_problem_free(self.h); self.h = None
+
+
+def shading_row(v, sh9, pyr_scale, voxel_size, lum, params29, jac=True):
+    lum = np.ascontiguousarray(lum, np.float32); sh9 = np.ascontiguousarray(sh9, np.float64)
+    prm = np.ascontiguousarray(params29, np.float64); J = np.zeros(29) if jac else None
+    r = lib().orc_shading_row(int(v[0]), int(v[1]), int(v[2]), _p(sh9), float(pyr_scale), float(voxel_size),
+                              lum.shape[1], lum.shape[0], _p(lum), _p(prm), _p(J))
+    return r, J
+
+
+def bicubic(img, r, c):
+    img = np.ascontiguousarray(img, np.float32)
+    f = C.c_double(); dr = C.c_double(); dc = C.c_double()
+    lib().orc_bicubic(_p(img), img.shape[1], img.shape[0], float(r), float(c), C.byref(f), C.byref(dr), C.byref(dc))
+    return f.value, dr.value, dc.value
+
+
+def pose_to_mat(pose6):
+    p = np.ascontiguousarray(pose6, np.float64); R = np.zeros(9, np.float32); t = np.zeros(3, np.float32)
+    lib().orc_pose_to_mat(_p(p), _p(R), _p(t))
+    return R.reshape(3, 3), t

@@ -1,0 +1,213 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (never linked into the product library).
+// extern "C" surface of the CPU restatement (see ../i3d_oracle.h).
+#include "../i3d_oracle.h"
+#include "lighting.hpp"
+
+using namespace orc;
+
+static OptConfig to_cfg(const orc_opt_config* c) {
+    OptConfig o;
+    o.iterations = c->iterations; o.lm_steps = c->lm_steps; o.lambda_g = c->lambda_g;
+    o.lambda_r0 = c->lambda_r0; o.lambda_r1 = c->lambda_r1; o.lambda_s0 = c->lambda_s0; o.lambda_s1 = c->lambda_s1; o.lambda_a = c->lambda_a;
+    o.fix_poses = c->fix_poses; o.fix_intrinsics = c->fix_intrinsics; o.fix_distortion = c->fix_distortion;
+    o.occlusion_distance = c->occlusion_distance; o.num_observations = c->num_observations;
+    o.thres_shell = c->thres_shell; o.grid_level = c->grid_level; o.rgbd_level = c->rgbd_level;
+    o.cg_fixed_iterations = c->cg_fixed_iterations; o.verbose = c->verbose;
+    return o;
+}
+
+struct ProblemHandle { Problem P; OptConfig cfg; std::vector<double> xg; };
+
+extern "C" {
+
+void* orc_grid_from_voxels(float voxel_size, int64_t n, const int32_t* keys, const float* sdf, const float* weight, const uint8_t* color) {
+    Grid<Voxel> g(voxel_size);                       // SparseVoxelGrid<Voxel>::load order (sparse_voxel_grid.cpp:545-568)
+    for (int64_t i = 0; i < n; ++i) {
+        Voxel v; v.sdf = sdf[i]; v.weight = weight[i];
+        for (int c = 0; c < 3; ++c) v.color[c] = color[3 * i + c];
+        g.setVoxel({keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]}, v);
+    }
+    return convert(g);
+}
+int64_t orc_grid_size(void* g) { return (int64_t)((Grid<VoxelSBR>*)g)->size(); }
+float orc_grid_voxel_size(void* g) { return ((Grid<VoxelSBR>*)g)->voxel_size; }
+void orc_grid_export(void* gp, int32_t* keys, double* sdf, double* sdf_refined, double* albedo, float* weight, uint8_t* color) {
+    auto* g = (Grid<VoxelSBR>*)gp; size_t i = 0;
+    for (auto it = g->data.begin(); it != g->data.end(); ++it, ++i) {
+        if (keys) { keys[3 * i] = it->first.x; keys[3 * i + 1] = it->first.y; keys[3 * i + 2] = it->first.z; }
+        if (sdf) sdf[i] = it->second.sdf;
+        if (sdf_refined) sdf_refined[i] = it->second.sdf_refined;
+        if (albedo) albedo[i] = it->second.albedo;
+        if (weight) weight[i] = it->second.weight;
+        if (color) for (int c = 0; c < 3; ++c) color[3 * i + c] = it->second.color[c];
+    }
+}
+void orc_grid_import(void* gp, const double* sdf_refined, const double* albedo, const uint8_t* color) {
+    auto* g = (Grid<VoxelSBR>*)gp; size_t i = 0;
+    for (auto it = g->data.begin(); it != g->data.end(); ++it, ++i) {
+        if (sdf_refined) it->second.sdf_refined = sdf_refined[i];
+        if (albedo) it->second.albedo = albedo[i];
+        if (color) for (int c = 0; c < 3; ++c) it->second.color[c] = color[3 * i + c];
+    }
+}
+void orc_grid_clear_outside_shell(void* g, double thres) { clear_voxels_outside_thin_shell(*(Grid<VoxelSBR>*)g, thres); }
+void* orc_grid_upsample(void* g) { return upsample(*(Grid<VoxelSBR>*)g); }
+void orc_grid_free(void* g) { delete (Grid<VoxelSBR>*)g; }
+
+void* orc_frames_create(int32_t K, int32_t levels) { auto* f = new Frames; f->K = K; f->levels = levels; f->img.resize((size_t)K * levels); return f; }
+void orc_frames_set(void* fr, int32_t f, int32_t lvl, int32_t w, int32_t h, const float* lum, const float* depth, const uint8_t* bgr) {
+    Image& im = ((Frames*)fr)->img[(size_t)f * ((Frames*)fr)->levels + lvl]; im.w = w; im.h = h; im.lum = lum; im.depth = depth; im.bgr = bgr;
+}
+void orc_frames_free(void* fr) { delete (Frames*)fr; }
+
+int32_t orc_optimize(void* g, void* fr, const orc_opt_config* c, double* intr, double* dist, double* poses,
+                     const double* voxel_sh, orc_iter_stats* stats) {
+    auto* G = (Grid<VoxelSBR>*)g; auto* F = (Frames*)fr; OptConfig cfg = to_cfg(c);
+    CameraIO cam; for (int i = 0; i < 4; ++i) cam.intr[i] = intr[i]; for (int i = 0; i < 5; ++i) cam.dist[i] = dist[i];
+    cam.poses.assign(poses, poses + 6 * F->K);
+    std::vector<double> sh(voxel_sh, voxel_sh + G->size() * 9);
+    std::vector<IterStats> st;
+    const bool ok = optimize(*G, *F, cam, cfg, sh, &st);
+    for (int i = 0; i < 4; ++i) intr[i] = cam.intr[i]; for (int i = 0; i < 5; ++i) dist[i] = cam.dist[i];
+    for (int i = 0; i < 6 * F->K; ++i) poses[i] = cam.poses[i];
+    if (stats) for (size_t i = 0; i < st.size(); ++i) {
+        static_assert(sizeof(orc_iter_stats) == sizeof(IterStats), "stats layout");
+        std::memcpy(&stats[i], &st[i], sizeof(IterStats));
+    }
+    return ok ? 0 : 1;
+}
+
+void* orc_collect(void* g, void* fr, const orc_opt_config* c, const double* intr, const double* dist, const double* poses,
+                  const double* voxel_sh, int32_t iteration) {
+    auto* G = (Grid<VoxelSBR>*)g; auto* F = (Frames*)fr;
+    auto* h = new ProblemHandle; h->cfg = to_cfg(c);
+    CameraIO cam; for (int i = 0; i < 4; ++i) cam.intr[i] = intr[i]; for (int i = 0; i < 5; ++i) cam.dist[i] = dist[i];
+    cam.poses.assign(poses, poses + 6 * F->K);
+    std::vector<double> sh(voxel_sh, voxel_sh + G->size() * 9);
+    h->P.bind(G, F->K);
+    collect_rows(h->P, h->cfg, *F, cam, sh, h->xg);
+    const OptConfig& q = h->cfg;
+    const double lambda[4] = {q.lambda_g, varying_lambda(iteration, q.iterations, q.lambda_r0, q.lambda_r1),
+                              varying_lambda(iteration, q.iterations, q.lambda_s0, q.lambda_s1), q.lambda_a};
+    normalize_weights(h->P, lambda);
+    return h;
+}
+void orc_problem_counts(void* p, int32_t rows[4], double ws[4], double tw[4]) {
+    auto* h = (ProblemHandle*)p;
+    for (int t = 0; t < 4; ++t) { rows[t] = (int)h->P.rows[t].size(); if (ws) ws[t] = h->P.weight_sum[t]; if (tw) tw[t] = h->P.type_weight[t]; }
+}
+void orc_problem_flags(void* p, uint8_t* active, uint8_t* ring_ok, uint8_t* fix_sdf, uint8_t* fix_alb) {
+    auto* h = (ProblemHandle*)p;
+    for (int i = 0; i < h->P.N; ++i) { if (active) active[i] = h->P.active[i]; if (ring_ok) ring_ok[i] = h->P.ringok[i];
+        if (fix_sdf) fix_sdf[i] = h->P.fix_sdf[i]; if (fix_alb) fix_alb[i] = h->P.fix_alb[i]; }
+}
+void orc_problem_eg(void* p, int32_t* v, int32_t* f, double* weight, double* residual, double* J) {
+    auto* h = (ProblemHandle*)p; const auto& rows = h->P.rows[0];
+#pragma omp parallel for schedule(dynamic, 256)
+    for (size_t i = 0; i < rows.size(); ++i) {
+        v[i] = rows[i].v; f[i] = rows[i].f; weight[i] = rows[i].weight;
+        double Jr[P_TOTAL]; residual[i] = eval_row(rows[i], h->xg, J ? Jr : nullptr);
+        if (J) for (int k = 0; k < P_TOTAL; ++k) J[i * P_TOTAL + k] = Jr[k];
+    }
+}
+void orc_problem_reg(void* p, int32_t type, int32_t* v, int32_t* dir, double* weight, double* residual) {
+    auto* h = (ProblemHandle*)p; const auto& rows = h->P.rows[type];
+    for (size_t i = 0; i < rows.size(); ++i) { v[i] = rows[i].v; if (dir) dir[i] = rows[i].dir; weight[i] = rows[i].weight;
+        if (residual) residual[i] = eval_row(rows[i], h->xg, nullptr); }
+}
+double orc_problem_normal_eq(void* p, const orc_opt_config* c, double* gradient, double* jtj_diag, int32_t* is_free) {
+    auto* h = (ProblemHandle*)p; OptConfig cfg = to_cfg(c); const Problem& P = h->P;
+    const int ng = P.num_global();
+    for (int i = 0; i < ng; ++i) { if (gradient) gradient[i] = 0.0; if (jtj_diag) jtj_diag[i] = 0.0; if (is_free) is_free[i] = 0; }
+    double cost = 0.0;
+    for (int t = 0; t < 4; ++t) for (const Row& r : P.rows[t]) {
+        bool any = false; for (int i = 0; i < r.ncols; ++i) if (!is_fixed(P, cfg, r.cols[i])) any = true;
+        if (!any) continue;
+        double Jr[P_TOTAL]; const double raw = eval_row(r, h->xg, Jr);
+        cost += 0.5 * r.weight * raw * raw;
+        for (int i = 0; i < r.ncols; ++i) { const int gid = r.cols[i]; if (is_fixed(P, cfg, gid)) continue;
+            if (is_free) is_free[gid] = 1;
+            if (gradient) gradient[gid] += r.weight * Jr[i] * raw;
+            if (jtj_diag) jtj_diag[gid] += r.weight * Jr[i] * Jr[i]; }
+    }
+    return cost;
+}
+void orc_problem_jtj_apply(void* p, const orc_opt_config* c, const double* x, double* y) {
+    auto* h = (ProblemHandle*)p; OptConfig cfg = to_cfg(c); const Problem& P = h->P;
+    const int ng = P.num_global(); for (int i = 0; i < ng; ++i) y[i] = 0.0;
+    for (int t = 0; t < 4; ++t) for (const Row& r : P.rows[t]) {
+        double Jr[P_TOTAL]; eval_row(r, h->xg, Jr);
+        double s = 0.0; for (int i = 0; i < r.ncols; ++i) if (!is_fixed(P, cfg, r.cols[i])) s += Jr[i] * x[r.cols[i]];
+        s *= r.weight;
+        for (int i = 0; i < r.ncols; ++i) if (!is_fixed(P, cfg, r.cols[i])) y[r.cols[i]] += Jr[i] * s;
+    }
+}
+void orc_problem_free(void* p) { delete (ProblemHandle*)p; }
+
+int32_t orc_estimate_sh(void* g, float subvolume_size, double lambda_reg, double thres_shell, int32_t cg_fixed,
+                        int32_t* num_subvolumes, double* sh, int32_t* sub_index, int32_t cap,
+                        double* voxel_sh, uint8_t* voxel_has, orc_sh_stats* st) {
+    auto* G = (Grid<VoxelSBR>*)g;
+    Lighting L; L.sub.size = subvolume_size; L.lambda_reg = lambda_reg; L.thres_shell = thres_shell; L.weighted = true;
+    ShStats s; std::memset(&s, 0, sizeof(s));
+    const bool ok = L.estimate(*G, &s, cg_fixed, false);
+    if (st) std::memcpy(st, &s, sizeof(s));
+    if (!ok) return 1;
+    const int S = (int)L.sub.count(); *num_subvolumes = S;
+    if (S > cap) return 2;
+    for (int i = 0; i < S; ++i) { for (int j = 0; j < 9; ++j) sh[9 * i + j] = L.sh[9 * (size_t)i + j];
+        if (sub_index) { sub_index[3 * i] = L.sub.indices[i].x; sub_index[3 * i + 1] = L.sub.indices[i].y; sub_index[3 * i + 2] = L.sub.indices[i].z; } }
+    if (voxel_sh) { std::vector<double> out; std::vector<uint8_t> has; L.voxel_sh(*G, out, &has);
+        std::memcpy(voxel_sh, out.data(), out.size() * sizeof(double)); if (voxel_has) std::memcpy(voxel_has, has.data(), has.size()); }
+    return 0;
+}
+
+// intrinsic3d.cpp:381-409 + colorization.cpp:113-189,318-354 (recolourisation at pyramid level 0)
+int32_t orc_recompute_colors(void* g, void* fr, const double* intr, const double* dist, const double* poses,
+                             float occlusion_distance, int32_t num_observations) {
+    auto* G = (Grid<VoxelSBR>*)g; auto* F = (Frames*)fr;
+    Colorizer col; const Image& l0 = F->at(0, 0);
+    col.cam.fx = (float)intr[0]; col.cam.fy = (float)intr[1]; col.cam.cx = (float)intr[2]; col.cam.cy = (float)intr[3];
+    for (int i = 0; i < 5; ++i) col.cam.k[i] = (float)dist[i];
+    col.cam.w = l0.w; col.cam.h = l0.h; col.max_occlusion_distance = occlusion_distance; col.max_num_observations = (size_t)num_observations;
+    std::vector<std::vector<Observation>> obs(G->size());
+    for (int f = 0; f < F->K; ++f) {
+        double Rd[9], td[3]; pose_aa_to_mat(poses + 6 * f, Rd, td);
+        float R[9], t[3]; for (int i = 0; i < 9; ++i) R[i] = (float)Rd[i]; for (int i = 0; i < 3; ++i) t[i] = (float)td[i];
+        size_t vi = 0;
+        for (auto it = G->data.begin(); it != G->data.end(); ++it, ++vi) {
+            float n[3]; surface_normal(*G, it->first, n);
+            if (is_zero3(n)) continue;
+            Observation o = col.compute_observation(*G, it->first, n, R, t, F->at(f, 0));
+            if (o.weight > 0.0f) { o.frame = f; obs[vi].push_back(o); }
+        }
+    }
+    size_t vi = 0;
+    for (auto it = G->data.begin(); it != G->data.end(); ++it, ++vi) {
+        if (obs[vi].empty()) continue;
+        if (col.max_num_observations > 0) Colorizer::filter(obs[vi], col.max_num_observations);
+        float c[3] = {0, 0, 0}, ws = 0.0f; const float sc = 1.0f / 255.0f;
+        for (auto& o : obs[vi]) { for (int k = 0; k < 3; ++k) c[k] += (float)o.color[k] * (o.weight * sc); ws = ws + o.weight; }
+        if (ws > 0.0f) for (int k = 0; k < 3; ++k) c[k] = c[k] * (255.0f / ws);
+        for (int k = 0; k < 3; ++k) it->second.color[k] = (uint8_t)c[k];
+    }
+    return 0;
+}
+
+double orc_shading_row(int32_t vx, int32_t vy, int32_t vz, const double* sh9, double pyr_scale, double voxel_size,
+                       int32_t w, int32_t h, const float* lum, const double* prm, double* J29) {
+    ShadingRowConst k; k.vx = vx; k.vy = vy; k.vz = vz; for (int i = 0; i < 9; ++i) k.sh[i] = sh9[i];
+    k.pyr_scale = pyr_scale; k.voxel_size = voxel_size; k.w = w; k.h = h; k.lum = lum;
+    if (!J29) return shading_residual<double>(k, prm);
+    Jet<P_TOTAL> p[P_TOTAL]; for (int i = 0; i < P_TOTAL; ++i) p[i] = Jet<P_TOTAL>::var(prm[i], i);
+    const Jet<P_TOTAL> r = shading_residual<Jet<P_TOTAL>>(k, p);
+    for (int i = 0; i < P_TOTAL; ++i) J29[i] = r.v[i];
+    return r.a;
+}
+void orc_bicubic(const float* img, int32_t w, int32_t h, double r, double c, double* f, double* dfdr, double* dfdc) { bicubic(img, w, h, r, c, f, dfdr, dfdc); }
+void orc_pose_to_mat(const double* pose6, float* R9, float* t3) {
+    double R[9], t[3]; pose_aa_to_mat(pose6, R, t); for (int i = 0; i < 9; ++i) R9[i] = (float)R[i]; for (int i = 0; i < 3; ++i) t3[i] = (float)t[i];
+}
+uint64_t orc_hash(int32_t x, int32_t y, int32_t z) { return (uint64_t)V3iHash()({x, y, z}); }
+
+}  // extern "C"
