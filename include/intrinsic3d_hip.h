@@ -1,0 +1,157 @@
+/* intrinsic3d_hip.h — C ABI of the MI355X-native (gfx950, HIP) implementation of NVlabs/intrinsic3d's
+ * voxel-SDF shading-optimisation hot path.
+ *
+ * The reference has no FFI layer; the boundary this library replaces is the C++ entry point
+ *
+ *     bool nv::Optimizer::optimize(SDFColorization&, Optimizer::Data&, Optimizer::ImageFormationModel&)
+ *                                   libintrinsic3d/include/nv/refinement/optimizer.h:123-125
+ *                                   libintrinsic3d/src/refinement/optimizer.cpp:109-173
+ *
+ * and its sibling  nv::LightingSVSH::estimate() + computeVoxelShCoeffs()
+ *                                   libintrinsic3d/include/nv/lighting/lighting_svsh.h:52,60
+ *                                   libintrinsic3d/src/lighting/lighting_svsh.cpp:93-110,166-346
+ *
+ * i.e. everything the reference hands to Ceres (nls_solver.cpp:190-367).  Plain pointers and sizes only; no
+ * C++/torch types cross this boundary.  All functions return 0 on success and a non-zero i3d_status otherwise
+ * (the reference's convention is bool + std::cerr, optimizer.cpp:113-114); nothing throws.  One host thread
+ * drives a context.  INTEGRATION.md shows the reference-side shim that binds these entry points.
+ */
+#ifndef INTRINSIC3D_HIP_H
+#define INTRINSIC3D_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct i3d_context i3d_context;
+
+typedef enum {
+    I3D_OK = 0,
+    I3D_ERR_INVALID_ARGUMENT = 1,   /* null grid / iterations < 1 (optimizer.cpp:113-114 returns false) */
+    I3D_ERR_NO_DEVICE = 2,          /* no HIP device: the product path never falls back to the CPU */
+    I3D_ERR_HIP = 3,
+    I3D_ERR_STATE = 4,              /* grid / frames / camera not set */
+    I3D_ERR_CAPACITY = 5,
+    I3D_ERR_COMM = 6
+} i3d_status;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+int  i3d_create(int32_t device_ordinal, i3d_context** out);
+void i3d_destroy(i3d_context* ctx);
+/* last error text of this context (ctx may be NULL for creation errors) */
+const char* i3d_last_error(const i3d_context* ctx);
+const char* i3d_version(void);
+
+/* ---- voxel grid: SparseVoxelGrid<VoxelSBR> (sparse_voxel_grid.h:69-161) as flat arrays ---------------------
+ * Arrays are in the caller's grid->begin()..end() iteration order.  That "visit order" is part of the
+ * reference's result (the albedo-regulariser edge set depends on it, optimizer.cpp:264-279) and is kept as
+ * a per-voxel rank on the device. */
+typedef struct {
+    int64_t        num_voxels;
+    float          voxel_size;     /* SparseVoxelGrid::voxelSize() */
+    float          truncation;     /* SparseVoxelGrid::truncation() = 5*voxel_size (sparse_voxel_grid.cpp:48) */
+    const int32_t* keys;           /* [N][3] voxel coordinates */
+    const double*  sdf;            /* VoxelSBR::sdf          (read-only for the path) */
+    const double*  sdf_refined;    /* VoxelSBR::sdf_refined  (optimised in place)     */
+    const double*  albedo;         /* VoxelSBR::albedo       (optimised in place)     */
+    const float*   weight;         /* VoxelSBR::weight */
+    const uint8_t* color;          /* [N][3] VoxelSBR::color (r,g,b) */
+} i3d_grid_view;
+
+int i3d_set_grid(i3d_context* ctx, const i3d_grid_view* grid);
+/* write-back of the only per-voxel fields the path mutates; either pointer may be NULL */
+int i3d_get_grid(i3d_context* ctx, double* sdf_refined, double* albedo);
+/* overwrite the unknowns / colours of the resident grid (visit order); NULL = keep */
+int i3d_update_grid(i3d_context* ctx, const double* sdf_refined, const double* albedo, const uint8_t* color);
+
+/* ---- keyframes: ImageFormationModel::rgbd_pyr + ShadingCostData (optimizer.h:107-115, shading_cost.h:52-73)
+ * lum/depth/bgr[f*levels + lvl]; float luminance in [0,1] (pyramid.cpp:66-74), float depth in metres (0 = invalid),
+ * optional 8-bit BGR (only needed by i3d_recompute_colors).  Images are copied to the device. */
+int i3d_set_frames(i3d_context* ctx, int32_t num_frames, int32_t levels, const int32_t* widths, const int32_t* heights,
+                   const float* const* lum, const float* const* depth, const uint8_t* const* bgr);
+
+/* ---- camera: intrinsics Vec4 (fx,fy,cx,cy at level 0), distortion Vec5 (k1,k2,k3,p1,p2), poses Vec6[K]
+ * (angle-axis, translation; world->camera) — optimizer.h:109-114 */
+int i3d_set_camera(i3d_context* ctx, const double* intrinsics4, const double* distortion5, const double* poses6k);
+int i3d_get_camera(i3d_context* ctx, double* intrinsics4, double* distortion5, double* poses6k);
+
+/* ---- Optimizer::Data::voxel_sh_coeffs (optimizer.h:96): 9 doubles per voxel, visit order ------------------ */
+int i3d_set_voxel_sh(i3d_context* ctx, const double* voxel_sh);
+int i3d_get_voxel_sh(i3d_context* ctx, double* voxel_sh);
+
+/* ---- Optimizer::Config (optimizer.h:67-84) + the fields of Intrinsic3D::Config / Optimizer::Data the path reads */
+typedef struct {
+    int32_t iterations;            /* outer Gauss-Newton iterations (optimizer.cpp:119) */
+    int32_t lm_steps;              /* max LM attempts per iteration (nls_solver.cpp:300) */
+    double  lambda_g, lambda_r0, lambda_r1, lambda_s0, lambda_s1, lambda_a;
+    int32_t fix_poses, fix_intrinsics, fix_distortion;
+    float   occlusion_distance;    /* SDFColorization::Config::max_occlusion_distance (intrinsic3d.cpp:165) */
+    int32_t num_observations;      /* ...::max_num_observations (intrinsic3d.cpp:166) */
+    double  thres_shell;           /* Optimizer::Data::thres_shell */
+    int32_t grid_level, rgbd_level;
+    /* parity / measurement controls (not in the reference) */
+    int32_t pcg_fixed_iterations;  /* >=0: run exactly this many PCG iterations per LM attempt; -1: Ceres' Q-test */
+    int32_t verbose;
+} i3d_optimizer_config;
+
+void i3d_optimizer_config_default(i3d_optimizer_config* cfg);   /* the reference's struct defaults */
+
+/* per outer iteration: the quantities NLSSolver prints (nls_solver.cpp:57-103) */
+typedef struct {
+    int64_t rows[4];               /* Eg, Er, Es, Ea residual blocks */
+    double  weight_sum[4];         /* per-type sum of row weights before normalisation */
+    double  type_weight[4];        /* lambda_t / weight_sum_t * 1000 (nls_solver.cpp:379-394) */
+    int64_t valid_voxels;          /* "voxels (valid n)" of optimizer.cpp:158 */
+    int64_t free_parameters;
+    double  cost_initial, cost_final;
+    int32_t lm_iterations, successful_steps, termination;   /* termination: 0 no-conv, 1 convergence, 2 first successful step, 3 failure */
+    int32_t pcg_iterations[50];    /* one per LM attempt */
+    int32_t step_accepted[50];
+    int32_t num_attempts;
+    double  final_radius;
+    double  time_add, time_build, time_solve;               /* seconds, the reference's split (nls_solver.cpp:66-67,101) */
+} i3d_iteration_stats;
+
+/* Optimizer::optimize on the resident grid / frames / camera / per-voxel SH.  stats: [cfg->iterations] or NULL. */
+int i3d_optimize(i3d_context* ctx, const i3d_optimizer_config* cfg, i3d_iteration_stats* stats);
+
+/* One-shot drop-in with host buffers (upload, optimize, write back sdf_refined/albedo/camera in place). */
+int i3d_optimize_host(int32_t device_ordinal, const i3d_optimizer_config* cfg, const i3d_grid_view* grid,
+                      double* sdf_refined_io, double* albedo_io,
+                      int32_t num_frames, int32_t levels, const int32_t* widths, const int32_t* heights,
+                      const float* const* lum, const float* const* depth,
+                      double* intrinsics4_io, double* distortion5_io, double* poses6k_io,
+                      const double* voxel_sh, i3d_iteration_stats* stats);
+
+/* ---- LightingSVSH(grid, subvolume_size, lambda_reg, thres_shell, weighted=true)::estimate() followed by
+ * computeVoxelShCoeffs() (intrinsic3d.cpp:255-264).  sh: [cap][9], sub_index: [cap][3] or NULL.  The per-voxel
+ * coefficients stay resident for i3d_optimize (fetch with i3d_get_voxel_sh). */
+typedef struct { int64_t data_rows, reg_rows; int32_t subvolumes, lm_iterations, termination; double cost_initial, cost_final; } i3d_sh_stats;
+int i3d_estimate_sh(i3d_context* ctx, float subvolume_size, double lambda_reg, double thres_shell,
+                    int32_t* num_subvolumes, double* sh, int32_t* sub_index, int32_t cap, i3d_sh_stats* stats);
+
+/* ---- measurement: HIP-event time (ms) and launch count accumulated per kernel family on the context's stream
+ * since the last reset.  names: see i3d_kernel_name(). */
+enum { I3D_K_CLASSIFY = 0, I3D_K_OBSERVE, I3D_K_BUILD, I3D_K_EG_PASS, I3D_K_GATHER, I3D_K_COST, I3D_K_VECTOR, I3D_K_SH, I3D_K_COUNT };
+int i3d_timing_enable(i3d_context* ctx, int32_t on);
+int i3d_timing_get(i3d_context* ctx, double* ms /*[I3D_K_COUNT]*/, int64_t* launches /*[I3D_K_COUNT]*/, int32_t reset);
+const char* i3d_kernel_name(int32_t k);
+/* sizes of the last assembled problem: active voxels, Eg/Er/Es/Ea rows, free parameters */
+int i3d_problem_sizes(i3d_context* ctx, int64_t out[6]);
+
+/* ---- parity probes (tests only): assemble the rows of outer iteration `iteration` without solving and export them.
+ * Arrays are indexed by visit order; slot k in [0, slots).  Any pointer may be NULL. */
+int i3d_debug_assemble(i3d_context* ctx, const i3d_optimizer_config* cfg, int32_t iteration, int32_t* slots_out);
+int i3d_debug_flags(i3d_context* ctx, uint8_t* flags /*[N]: bit0 valid,1 active,2 ring_ok,3 free_sdf,4 free_albedo*/);
+int i3d_debug_eg_rows(i3d_context* ctx, int32_t* frame /*[N][slots], -1 = none*/, float* weight /*[N][slots] normalised*/,
+                      float* residual /*[N][slots]*/, float* jac /*[N][slots][29]*/);
+int i3d_debug_reg_rows(i3d_context* ctx, uint8_t* has_er /*[N]*/, uint8_t* has_es /*[N]*/, float* ea_weight /*[N][6] normalised, 0 = none*/);
+int i3d_debug_neighbors(i3d_context* ctx, int32_t* nbr /*[N][18] visit indices, -1 = missing*/);
+/* gradient S^-1-free: g = J^T W r, diag(J^T W J) and y = J^T W J x over parameter ids [sdf N | albedo N | poses 6K | intr 4 | dist 5], visit order */
+int i3d_debug_normal_eq(i3d_context* ctx, double* gradient, double* jtj_diag, double* cost);
+int i3d_debug_jtj_apply(i3d_context* ctx, const double* x, double* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,265 @@
+"""ctypes binding of libintrinsic3d_hip.so (include/intrinsic3d_hip.h).
+
+Python is only the test / bench harness here: the host side of the product (Optimizer::optimize mirror, LM/PCG
+control, lighting solve) is C++ inside the library.  Loading fails loudly when the HIP library is missing — there is
+no CPU fallback anywhere on the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libintrinsic3d_hip.so")
+
+K_NAMES = ["classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh"]
+
+
+class OptimizerConfig(C.Structure):
+    """Optimizer::Config (optimizer.h:67-84) + the Intrinsic3D::Config / Optimizer::Data fields the path reads."""
+    _fields_ = [("iterations", C.c_int32), ("lm_steps", C.c_int32),
+                ("lambda_g", C.c_double), ("lambda_r0", C.c_double), ("lambda_r1", C.c_double),
+                ("lambda_s0", C.c_double), ("lambda_s1", C.c_double), ("lambda_a", C.c_double),
+                ("fix_poses", C.c_int32), ("fix_intrinsics", C.c_int32), ("fix_distortion", C.c_int32),
+                ("occlusion_distance", C.c_float), ("num_observations", C.c_int32),
+                ("thres_shell", C.c_double), ("grid_level", C.c_int32), ("rgbd_level", C.c_int32),
+                ("pcg_fixed_iterations", C.c_int32), ("verbose", C.c_int32)]
+
+
+class IterationStats(C.Structure):
+    _fields_ = [("rows", C.c_int64 * 4), ("weight_sum", C.c_double * 4), ("type_weight", C.c_double * 4),
+                ("valid_voxels", C.c_int64), ("free_parameters", C.c_int64),
+                ("cost_initial", C.c_double), ("cost_final", C.c_double),
+                ("lm_iterations", C.c_int32), ("successful_steps", C.c_int32), ("termination", C.c_int32),
+                ("pcg_iterations", C.c_int32 * 50), ("step_accepted", C.c_int32 * 50), ("num_attempts", C.c_int32),
+                ("final_radius", C.c_double), ("time_add", C.c_double), ("time_build", C.c_double), ("time_solve", C.c_double)]
+
+
+class ShStats(C.Structure):
+    _fields_ = [("data_rows", C.c_int64), ("reg_rows", C.c_int64), ("subvolumes", C.c_int32), ("lm_iterations", C.c_int32),
+                ("termination", C.c_int32), ("cost_initial", C.c_double), ("cost_final", C.c_double)]
+
+
+class GridView(C.Structure):
+    _fields_ = [("num_voxels", C.c_int64), ("voxel_size", C.c_float), ("truncation", C.c_float),
+                ("keys", C.c_void_p), ("sdf", C.c_void_p), ("sdf_refined", C.c_void_p), ("albedo", C.c_void_p),
+                ("weight", C.c_void_p), ("color", C.c_void_p)]
+
+
+EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_set_grid", "i3d_get_grid", "i3d_update_grid",
+           "i3d_set_frames", "i3d_set_camera", "i3d_get_camera", "i3d_set_voxel_sh", "i3d_get_voxel_sh",
+           "i3d_optimizer_config_default", "i3d_optimize", "i3d_optimize_host", "i3d_estimate_sh",
+           "i3d_timing_enable", "i3d_timing_get", "i3d_kernel_name", "i3d_problem_sizes",
+           "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
+           "i3d_debug_normal_eq", "i3d_debug_jtj_apply"]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C intrinsic3d_amd/csrc` "
+                           "(or __graft_entry__.build()); the product path has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+    L.i3d_create.restype = i32; L.i3d_create.argtypes = [i32, C.POINTER(vp)]
+    L.i3d_destroy.argtypes = [vp]
+    L.i3d_last_error.restype = C.c_char_p; L.i3d_last_error.argtypes = [vp]
+    L.i3d_version.restype = C.c_char_p
+    L.i3d_set_grid.restype = i32; L.i3d_set_grid.argtypes = [vp, C.POINTER(GridView)]
+    L.i3d_get_grid.restype = i32; L.i3d_get_grid.argtypes = [vp, vp, vp]
+    L.i3d_update_grid.restype = i32; L.i3d_update_grid.argtypes = [vp, vp, vp, vp]
+    L.i3d_set_frames.restype = i32; L.i3d_set_frames.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    L.i3d_set_camera.restype = i32; L.i3d_set_camera.argtypes = [vp, vp, vp, vp]
+    L.i3d_get_camera.restype = i32; L.i3d_get_camera.argtypes = [vp, vp, vp, vp]
+    L.i3d_set_voxel_sh.restype = i32; L.i3d_set_voxel_sh.argtypes = [vp, vp]
+    L.i3d_get_voxel_sh.restype = i32; L.i3d_get_voxel_sh.argtypes = [vp, vp]
+    L.i3d_optimizer_config_default.argtypes = [C.POINTER(OptimizerConfig)]
+    L.i3d_optimize.restype = i32; L.i3d_optimize.argtypes = [vp, C.POINTER(OptimizerConfig), vp]
+    L.i3d_estimate_sh.restype = i32
+    L.i3d_estimate_sh.argtypes = [vp, f32, f64, f64, C.POINTER(i32), vp, vp, i32, C.POINTER(ShStats)]
+    L.i3d_timing_enable.restype = i32; L.i3d_timing_enable.argtypes = [vp, i32]
+    L.i3d_timing_get.restype = i32; L.i3d_timing_get.argtypes = [vp, vp, vp, i32]
+    L.i3d_kernel_name.restype = C.c_char_p; L.i3d_kernel_name.argtypes = [i32]
+    L.i3d_problem_sizes.restype = i32; L.i3d_problem_sizes.argtypes = [vp, vp]
+    L.i3d_debug_assemble.restype = i32; L.i3d_debug_assemble.argtypes = [vp, C.POINTER(OptimizerConfig), i32, C.POINTER(i32)]
+    L.i3d_debug_flags.restype = i32; L.i3d_debug_flags.argtypes = [vp, vp]
+    L.i3d_debug_eg_rows.restype = i32; L.i3d_debug_eg_rows.argtypes = [vp, vp, vp, vp, vp]
+    L.i3d_debug_reg_rows.restype = i32; L.i3d_debug_reg_rows.argtypes = [vp, vp, vp, vp]
+    L.i3d_debug_neighbors.restype = i32; L.i3d_debug_neighbors.argtypes = [vp, vp]
+    L.i3d_debug_normal_eq.restype = i32; L.i3d_debug_normal_eq.argtypes = [vp, vp, vp, C.POINTER(f64)]
+    L.i3d_debug_jtj_apply.restype = i32; L.i3d_debug_jtj_apply.argtypes = [vp, vp, vp]
+    _lib = L
+    return L
+
+
+def default_config(**kw) -> OptimizerConfig:
+    cfg = OptimizerConfig()
+    load().i3d_optimizer_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class I3DError(RuntimeError):
+    pass
+
+
+class Context:
+    """One device context (i3d_context)."""
+
+    def __init__(self, device: int = 0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.i3d_create(int(device), C.byref(h))
+        if rc != 0:
+            raise I3DError(f"i3d_create failed ({rc}): {self.L.i3d_last_error(None).decode()}")
+        self.h = h
+        self.N = 0
+        self.K = 0
+        self._keep = []
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise I3DError(f"{what} failed ({rc}): {self.L.i3d_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.i3d_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- uploads -------------------------------------------------------------------------------------------
+    def set_grid(self, voxel_size, keys, sdf, sdf_refined, albedo, weight, color, truncation=None):
+        keys = np.ascontiguousarray(keys, np.int32); sdf = np.ascontiguousarray(sdf, np.float64)
+        sr = np.ascontiguousarray(sdf_refined, np.float64); al = np.ascontiguousarray(albedo, np.float64)
+        w = np.ascontiguousarray(weight, np.float32); col = np.ascontiguousarray(color, np.uint8)
+        gv = GridView(keys.shape[0], float(voxel_size), float(np.float32(voxel_size) * np.float32(5.0)) if truncation is None else float(truncation),
+                      _p(keys), _p(sdf), _p(sr), _p(al), _p(w), _p(col))
+        self._check(self.L.i3d_set_grid(self.h, C.byref(gv)), "i3d_set_grid")
+        self.N = keys.shape[0]
+
+    def set_frames(self, frames, levels):
+        K = len(frames); self.K = K
+        ws = np.array([frames[0]["lum"][l].shape[1] for l in range(levels)], np.int32)
+        hs = np.array([frames[0]["lum"][l].shape[0] for l in range(levels)], np.int32)
+        arr_t = C.c_void_p * (K * levels)
+        lum = arr_t(); dep = arr_t(); bgr = arr_t(); keep = []
+        for f in range(K):
+            for l in range(levels):
+                a = np.ascontiguousarray(frames[f]["lum"][l], np.float32); b = np.ascontiguousarray(frames[f]["depth"][l], np.float32)
+                c = frames[f].get("bgr")
+                c = np.ascontiguousarray(c[l], np.uint8) if c is not None else None
+                keep += [a, b, c]
+                lum[f * levels + l] = a.ctypes.data; dep[f * levels + l] = b.ctypes.data
+                bgr[f * levels + l] = c.ctypes.data if c is not None else None
+        self._check(self.L.i3d_set_frames(self.h, K, levels, _p(ws), _p(hs), C.cast(lum, C.c_void_p), C.cast(dep, C.c_void_p), C.cast(bgr, C.c_void_p)), "i3d_set_frames")
+
+    def set_camera(self, intr, dist, poses):
+        a = np.ascontiguousarray(intr, np.float64); b = np.ascontiguousarray(dist, np.float64); c = np.ascontiguousarray(poses, np.float64)
+        self._check(self.L.i3d_set_camera(self.h, _p(a), _p(b), _p(c)), "i3d_set_camera")
+
+    def get_camera(self):
+        a = np.zeros(4); b = np.zeros(5); c = np.zeros((self.K, 6))
+        self._check(self.L.i3d_get_camera(self.h, _p(a), _p(b), _p(c)), "i3d_get_camera")
+        return a, b, c
+
+    def set_voxel_sh(self, sh):
+        s = np.ascontiguousarray(sh, np.float64)
+        self._check(self.L.i3d_set_voxel_sh(self.h, _p(s)), "i3d_set_voxel_sh")
+
+    def get_voxel_sh(self):
+        s = np.zeros((self.N, 9))
+        self._check(self.L.i3d_get_voxel_sh(self.h, _p(s)), "i3d_get_voxel_sh")
+        return s
+
+    def get_grid(self):
+        a = np.zeros(self.N); b = np.zeros(self.N)
+        self._check(self.L.i3d_get_grid(self.h, _p(a), _p(b)), "i3d_get_grid")
+        return a, b
+
+    def update_grid(self, sdf_refined=None, albedo=None, color=None):
+        a = None if sdf_refined is None else np.ascontiguousarray(sdf_refined, np.float64)
+        b = None if albedo is None else np.ascontiguousarray(albedo, np.float64)
+        c = None if color is None else np.ascontiguousarray(color, np.uint8)
+        self._check(self.L.i3d_update_grid(self.h, _p(a), _p(b), _p(c)), "i3d_update_grid")
+
+    # ---- the path ------------------------------------------------------------------------------------------
+    def optimize(self, cfg: OptimizerConfig):
+        stats = (IterationStats * cfg.iterations)()
+        self._check(self.L.i3d_optimize(self.h, C.byref(cfg), C.cast(stats, C.c_void_p)), "i3d_optimize")
+        return list(stats)
+
+    def estimate_sh(self, subvolume_size, lambda_reg, thres_shell, cap=8192):
+        S = C.c_int32(0); sh = np.zeros((cap, 9)); idx = np.zeros((cap, 3), np.int32); st = ShStats()
+        self._check(self.L.i3d_estimate_sh(self.h, float(subvolume_size), float(lambda_reg), float(thres_shell), C.byref(S), _p(sh), _p(idx), cap, C.byref(st)), "i3d_estimate_sh")
+        return sh[:S.value].copy(), idx[:S.value].copy(), st
+
+    # ---- measurement ---------------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(self.L.i3d_timing_enable(self.h, 1 if on else 0), "i3d_timing_enable")
+
+    def timing_get(self, reset=True):
+        ms = np.zeros(len(K_NAMES)); n = np.zeros(len(K_NAMES), np.int64)
+        self._check(self.L.i3d_timing_get(self.h, _p(ms), _p(n), 1 if reset else 0), "i3d_timing_get")
+        return {k: (ms[i], int(n[i])) for i, k in enumerate(K_NAMES)}
+
+    def problem_sizes(self):
+        o = np.zeros(6, np.int64)
+        self._check(self.L.i3d_problem_sizes(self.h, _p(o)), "i3d_problem_sizes")
+        return dict(zip(["active", "eg", "er", "es", "ea", "free"], [int(x) for x in o]))
+
+    # ---- parity probes -------------------------------------------------------------------------------------
+    def debug_assemble(self, cfg, iteration=0):
+        s = C.c_int32(0)
+        self._check(self.L.i3d_debug_assemble(self.h, C.byref(cfg), int(iteration), C.byref(s)), "i3d_debug_assemble")
+        self.slots = s.value
+        return s.value
+
+    def debug_flags(self):
+        f = np.zeros(self.N, np.uint8)
+        self._check(self.L.i3d_debug_flags(self.h, _p(f)), "i3d_debug_flags")
+        return f
+
+    def debug_eg_rows(self, jac=True):
+        S = self.slots
+        fr = np.zeros((self.N, S), np.int32); w = np.zeros((self.N, S), np.float32); r = np.zeros((self.N, S), np.float32)
+        J = np.zeros((self.N, S, 29), np.float32) if jac else None
+        self._check(self.L.i3d_debug_eg_rows(self.h, _p(fr), _p(w), _p(r), _p(J)), "i3d_debug_eg_rows")
+        return fr, w, r, J
+
+    def debug_reg_rows(self):
+        er = np.zeros(self.N, np.uint8); es = np.zeros(self.N, np.uint8); ea = np.zeros((self.N, 6), np.float32)
+        self._check(self.L.i3d_debug_reg_rows(self.h, _p(er), _p(es), _p(ea)), "i3d_debug_reg_rows")
+        return er, es, ea
+
+    def debug_neighbors(self):
+        nb = np.zeros((self.N, 18), np.int32)
+        self._check(self.L.i3d_debug_neighbors(self.h, _p(nb)), "i3d_debug_neighbors")
+        return nb
+
+    def debug_normal_eq(self):
+        NP = 2 * self.N + 6 * self.K + 9
+        g = np.zeros(NP); d = np.zeros(NP); cost = C.c_double(0)
+        self._check(self.L.i3d_debug_normal_eq(self.h, _p(g), _p(d), C.byref(cost)), "i3d_debug_normal_eq")
+        return g, d, cost.value
+
+    def debug_jtj_apply(self, x):
+        x = np.ascontiguousarray(x, np.float64); y = np.zeros_like(x)
+        self._check(self.L.i3d_debug_jtj_apply(self.h, _p(x), _p(y)), "i3d_debug_jtj_apply")
+        return y

@@ -1,0 +1,91 @@
+// Shared device/host definitions of the gfx950 shading-optimisation path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+namespace i3d {
+
+// ---- neighbour table -------------------------------------------------------------------------------------
+// 18 voxel offsets per voxel.  0..5 is the reference's 1-ring order (sdf/algorithms.cpp:75-91: +x,-x,+y,-y,+z,-z);
+// 6..11 complete the forward stencil of an Eg row (shading_cost.cpp:65-118); 12..17 are their mirrors, used by
+// the gather formulation of J^T (a parameter pulls from the rows whose stencil contains it).
+constexpr int NUM_NBR = 18;
+enum Nbr { NB_PX = 0, NB_MX, NB_PY, NB_MY, NB_PZ, NB_MZ, NB_P2X, NB_P2Y, NB_P2Z, NB_PXY, NB_PXZ, NB_PYZ,
+           NB_M2X, NB_M2Y, NB_M2Z, NB_MXY, NB_MXZ, NB_MYZ };
+__host__ __device__ inline void nbr_offset(int i, int& dx, int& dy, int& dz) {
+    constexpr int8_t O[NUM_NBR][3] = {{1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1},{2,0,0},{0,2,0},{0,0,2},{1,1,0},{1,0,1},{0,1,1},
+                                      {-2,0,0},{0,-2,0},{0,0,-2},{-1,-1,0},{-1,0,-1},{0,-1,-1}};
+    dx = O[i][0]; dy = O[i][1]; dz = O[i][2];
+}
+
+// ---- Eg row parameter slots (shading_cost.cpp:90-129): 10 sdf, 4 albedo, pose 6, intrinsics 4, distortion 5
+constexpr int P_SDF = 0, P_ALB = 10, P_POSE = 14, P_INTR = 20, P_DIST = 24, P_TOTAL = 29, P_VOX = 14;
+// forward neighbour (-1 = the voxel itself) holding the parameter of voxel-slot c (sdf 0..9, albedo 10..13)
+__host__ __device__ inline int slot_fwd_nbr(int c) {
+    constexpr int8_t F[P_VOX] = {-1, NB_PY, NB_P2Y, NB_PYZ, NB_PZ, NB_P2Z, NB_PX, NB_PXY, NB_PXZ, NB_P2X, -1, NB_PX, NB_PY, NB_PZ};
+    return F[c];
+}
+// reverse neighbour: the voxel whose slot c is *this* voxel
+__host__ __device__ inline int slot_rev_nbr(int c) {
+    constexpr int8_t R[P_VOX] = {-1, NB_MY, NB_M2Y, NB_MYZ, NB_MZ, NB_M2Z, NB_MX, NB_MXY, NB_MXZ, NB_M2X, -1, NB_MX, NB_MY, NB_MZ};
+    return R[c];
+}
+
+// ---- per-voxel flag bits (recomputed every outer iteration: the shell test reads sdf_refined, optimizer.cpp:187)
+enum : uint8_t { F_VALID = 1, F_ACTIVE = 2, F_RING = 4, F_FREE_SDF = 8, F_FREE_ALB = 16 };
+
+constexpr int MAX_SLOTS = 8;       // Eg rows kept per voxel (reference default num_observations = 5)
+
+// ---- per-keyframe constants, rebuilt on the host (fp64) once per outer iteration ----------------------------
+struct FrameConst {
+    double R[9], t[3];             // ceres::AngleAxisRotatePoint as a matrix (row-major) + translation
+    double dR[3][9];               // d R / d omega_i
+    float  Rf[9], tf[3];           // math::poseVecAAToMat(...).cast<float>() (math.cpp:151-163) for the observation pass
+    const float* lum; const float* depth; const uint8_t* bgr;
+    int w, h;
+};
+
+// ---- device views ------------------------------------------------------------------------------------------
+struct GridView {
+    int N;                          // stored voxels, in brick-sorted device order
+    float voxel_size, truncation;
+    const int* cx; const int* cy; const int* cz;     // voxel coordinates
+    const int* rank;                // position in the caller's visit order
+    const int* nbr;                 // [NUM_NBR][N] device indices, -1 = not stored
+    const float* weight; const uchar4* color;
+    const double* sdf0;             // VoxelSBR::sdf (fused value, constant)
+    double* x_sdf; double* x_alb;   // master unknowns (fp64)
+    float* f_sdf; float* f_alb;     // fp32 shadows read by the kernels
+    const float* sh;                // [9][N] per-voxel SH coefficients
+    uint8_t* flags;
+    int* aidx;                      // device index -> active index or -1
+};
+
+struct RowView {                    // per active voxel a in [0, A); SoA planes of length Acap
+    int A; int Acap; int slots;
+    const int* alist;               // active index -> device voxel index
+    int* obs_frame; float* obs_w;   // [slots][Acap]
+    float* res; float* roww;        // [slots][Acap]   raw residual; row weight (obs.w * weight_sdf), 0 = no row
+    float* J;                       // [29][slots][Acap] raw partials
+    uint8_t* rowfree;               // [slots][Acap] 1 if the row has at least one free parameter
+    uint8_t* regflags;              // [Acap] bit0 Er row, bit1 Es row, bit2 Es Jacobian is 1 (else 0), bit3 Er row has a free column, bit4 Es free
+    float* ea_w;                    // [6][Acap] chroma weight of the Ea row towards 1-ring neighbour d, 0 = none
+    uint8_t* ea_free;               // [Acap] bit d: Ea row d has a free column
+};
+
+struct OptParams {                  // scalar state of one outer iteration
+    double thres_shell; double lambda_a;
+    double type_w[4];               // lambda_t / sum_t * 1000
+    int K; int level; double pyr_scale; float occlusion; int use_er, use_es, use_ea;
+    double intr[4]; double dist[5];  // level-0 intrinsics, distortion
+    float cam_f[4]; float dist_f[5]; int dist_zero; int w, h;   // float camera of the observation pass (scaled)
+    int fix_poses, fix_intr, fix_dist;
+};
+
+#define I3D_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    std::snprintf(i3d::g_errbuf, sizeof(i3d::g_errbuf), "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); return I3D_ERR_HIP_; } } while (0)
+constexpr int I3D_ERR_HIP_ = 3;
+extern thread_local char g_errbuf[512];
+
+}  // namespace i3d

@@ -1,0 +1,178 @@
+// Voxel-grid kernels: brick-Morton sort keys, field permutation, device hash table + neighbour table,
+// per-iteration voxel classification and active-list compaction.
+//
+// Replaces the std::unordered_map<Vec3i,VoxelSBR> accesses of the reference (sparse_voxel_grid.cpp:166-259:
+// voxel / exists / valid; ~32 hash finds per Eg row, shading_cost.cpp:65-118) by ONE hash build + ONE
+// neighbour-table build per grid; every later kernel reads neighbours through the int32 table.
+#include "kernels.hpp"
+
+namespace i3d {
+
+thread_local char g_errbuf[512] = {0};
+
+static __device__ __host__ inline unsigned long long pack_key(int x, int y, int z) {
+    const unsigned long long B = 1ull << 20;
+    return ((unsigned long long)(x + (long long)B) & 0x1fffffull) | (((unsigned long long)(y + (long long)B) & 0x1fffffull) << 21) |
+           (((unsigned long long)(z + (long long)B) & 0x1fffffull) << 42);
+}
+static __device__ inline unsigned int mix64(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned int)k;
+}
+static __device__ inline unsigned long long spread3(unsigned long long v) {   // 17 bits -> every 3rd bit
+    v &= 0x1ffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+// sort key = Morton code of the 8^3 brick, then x-fastest position inside the brick: neighbouring voxels of the
+// forward stencil land in the same or an adjacent 2 KB run of every SoA plane (L2-resident gathers).
+__global__ void k_sort_keys(int N, const int* __restrict__ kxyz, unsigned long long* __restrict__ keys, int* __restrict__ iota) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int x = kxyz[3 * i] + (1 << 19), y = kxyz[3 * i + 1] + (1 << 19), z = kxyz[3 * i + 2] + (1 << 19);
+    const unsigned long long m = spread3((unsigned)(x >> 3)) | (spread3((unsigned)(y >> 3)) << 1) | (spread3((unsigned)(z >> 3)) << 2);
+    keys[i] = (m << 9) | (unsigned long long)(((z & 7) << 6) | ((y & 7) << 3) | (x & 7));
+    iota[i] = i;
+}
+void launch_sort_keys(hipStream_t st, int N, const int* kxyz, unsigned long long* keys, int* iota) {
+    if (N > 0) k_sort_keys<<<(N + 255) / 256, 256, 0, st>>>(N, kxyz, keys, iota);
+}
+
+__global__ void k_permute(int N, const int* __restrict__ perm, const int* __restrict__ kxyz, const double* __restrict__ sdf,
+                          const double* __restrict__ sdf_ref, const double* __restrict__ alb, const float* __restrict__ w,
+                          const uint8_t* __restrict__ rgb, int* cx, int* cy, int* cz, int* rank, double* sdf0, double* x_sdf,
+                          double* x_alb, float* f_sdf, float* f_alb, float* weight, uchar4* color) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int v = perm[s];
+    cx[s] = kxyz[3 * v]; cy[s] = kxyz[3 * v + 1]; cz[s] = kxyz[3 * v + 2]; rank[s] = v;
+    sdf0[s] = sdf[v]; x_sdf[s] = sdf_ref[v]; x_alb[s] = alb[v];
+    f_sdf[s] = (float)sdf_ref[v]; f_alb[s] = (float)alb[v]; weight[s] = w[v];
+    color[s] = make_uchar4(rgb[3 * v], rgb[3 * v + 1], rgb[3 * v + 2], 0);
+}
+void launch_permute_grid(hipStream_t st, int N, const int* perm, const int* kxyz, const double* sdf, const double* sdf_ref,
+                         const double* alb, const float* w, const uint8_t* rgb, int* cx, int* cy, int* cz, int* rank, double* sdf0,
+                         double* x_sdf, double* x_alb, float* f_sdf, float* f_alb, float* weight, uchar4* color) {
+    if (N > 0) k_permute<<<(N + 255) / 256, 256, 0, st>>>(N, perm, kxyz, sdf, sdf_ref, alb, w, rgb, cx, cy, cz, rank, sdf0, x_sdf, x_alb, f_sdf, f_alb, weight, color);
+}
+
+__global__ void k_hash_build(int N, const int* __restrict__ cx, const int* __restrict__ cy, const int* __restrict__ cz, HashTable t) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const unsigned long long key = pack_key(cx[s], cy[s], cz[s]);
+    unsigned int h = mix64(key) & t.mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&t.keys[h], ~0ull, key);
+        if (prev == ~0ull || prev == key) { t.vals[h] = s; return; }
+        h = (h + 1) & t.mask;
+    }
+}
+void launch_hash_build(hipStream_t st, int N, const int* cx, const int* cy, const int* cz, HashTable t) {
+    if (N > 0) k_hash_build<<<(N + 255) / 256, 256, 0, st>>>(N, cx, cy, cz, t);
+}
+
+static __device__ inline int hash_find(const HashTable& t, int x, int y, int z) {
+    const unsigned long long key = pack_key(x, y, z);
+    unsigned int h = mix64(key) & t.mask;
+    for (;;) {
+        const unsigned long long k = t.keys[h];
+        if (k == key) return t.vals[h];
+        if (k == ~0ull) return -1;
+        h = (h + 1) & t.mask;
+    }
+}
+
+__global__ void k_nbr_build(int N, const int* __restrict__ cx, const int* __restrict__ cy, const int* __restrict__ cz, HashTable t, int* __restrict__ nbr) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int x = cx[s], y = cy[s], z = cz[s];
+#pragma unroll
+    for (int i = 0; i < NUM_NBR; ++i) {
+        int dx, dy, dz; nbr_offset(i, dx, dy, dz);
+        nbr[(size_t)i * N + s] = hash_find(t, x + dx, y + dy, z + dz);
+    }
+}
+void launch_nbr_build(hipStream_t st, int N, const int* cx, const int* cy, const int* cz, HashTable t, int* nbr) {
+    if (N > 0) k_nbr_build<<<(N + 255) / 256, 256, 0, st>>>(N, cx, cy, cz, t, nbr);
+}
+
+// optimizer.cpp:183-193 (valid, shell, normal != 0), :312-361 (fixed sets), operators.cpp:58-77 (float normal)
+__global__ void k_classify(GridView g, OptParams p, int* __restrict__ active_flag) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= g.N) return;
+    const int N = g.N;
+    const bool valid = g.weight[s] > 0.0f;
+    const bool inshell = !(fabs(g.x_sdf[s]) > p.thres_shell);
+    int nb[6]; bool nbv[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) { nb[d] = g.nbr[(size_t)d * N + s]; nbv[d] = nb[d] >= 0 && g.weight[nb[d]] > 0.0f; }
+    const bool ring = nbv[0] && nbv[1] && nbv[2] && nbv[3] && nbv[4] && nbv[5];
+    bool normal_ok = false;
+    if (valid && nbv[NB_PX] && nbv[NB_PY] && nbv[NB_PZ]) {
+        const float s0 = g.f_sdf[s];
+        float nx = g.f_sdf[nb[NB_PX]] - s0, ny = g.f_sdf[nb[NB_PY]] - s0, nz = g.f_sdf[nb[NB_PZ]] - s0;
+        const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        if (len != 0.0f) { nx /= len; ny /= len; nz /= len; }
+        normal_ok = !(fabsf(nx) <= 1e-5f && fabsf(ny) <= 1e-5f && fabsf(nz) <= 1e-5f);
+    }
+    const bool active = valid && inshell && normal_ok;
+    const bool free_sdf = valid && inshell && ring;
+    const bool free_alb = free_sdf && !(p.lambda_a < 0.0);
+    g.flags[s] = (valid ? F_VALID : 0) | (active ? F_ACTIVE : 0) | (ring ? F_RING : 0) | (free_sdf ? F_FREE_SDF : 0) | (free_alb ? F_FREE_ALB : 0);
+    active_flag[s] = active ? 1 : 0;
+}
+void launch_classify(hipStream_t st, GridView g, OptParams p, int* active_flag) {
+    if (g.N > 0) k_classify<<<(g.N + 255) / 256, 256, 0, st>>>(g, p, active_flag);
+}
+
+__global__ void k_compact(int N, const int* __restrict__ flag, const int* __restrict__ scan, int* __restrict__ aidx, int* __restrict__ alist) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    if (flag[s]) { aidx[s] = scan[s]; alist[scan[s]] = s; } else aidx[s] = -1;
+}
+void launch_compact(hipStream_t st, int N, const int* flag, const int* scan, int* aidx, int* alist) {
+    if (N > 0) k_compact<<<(N + 255) / 256, 256, 0, st>>>(N, flag, scan, aidx, alist);
+}
+
+__global__ void k_scatter_sh(int N, const int* __restrict__ rank, const double* __restrict__ shv, float* __restrict__ sh) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const double* src = shv + (size_t)rank[s] * 9;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) sh[(size_t)j * N + s] = (float)src[j];
+}
+void launch_scatter_sh(hipStream_t st, int N, const int* rank, const double* shv, float* sh) {
+    if (N > 0) k_scatter_sh<<<(N + 255) / 256, 256, 0, st>>>(N, rank, shv, sh);
+}
+
+__global__ void k_gather_visit(int N, const int* __restrict__ rank, const double* __restrict__ xs, const double* __restrict__ xa, double* os, double* oa) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int v = rank[s];
+    if (os) os[v] = xs[s];
+    if (oa) oa[v] = xa[s];
+}
+void launch_gather_visit(hipStream_t st, int N, const int* rank, const double* xs, const double* xa, double* os, double* oa) {
+    if (N > 0) k_gather_visit<<<(N + 255) / 256, 256, 0, st>>>(N, rank, xs, xa, os, oa);
+}
+
+__global__ void k_update_fields(int N, const int* __restrict__ rank, const double* sr, const double* al, const uint8_t* rgb,
+                                double* x_sdf, double* x_alb, float* f_sdf, float* f_alb, uchar4* color) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int v = rank[s];
+    if (sr) { x_sdf[s] = sr[v]; f_sdf[s] = (float)sr[v]; }
+    if (al) { x_alb[s] = al[v]; f_alb[s] = (float)al[v]; }
+    if (rgb) color[s] = make_uchar4(rgb[3 * v], rgb[3 * v + 1], rgb[3 * v + 2], 0);
+}
+void launch_update_fields(hipStream_t st, int N, const int* rank, const double* sr, const double* al, const uint8_t* rgb,
+                          double* x_sdf, double* x_alb, float* f_sdf, float* f_alb, uchar4* color) {
+    if (N > 0) k_update_fields<<<(N + 255) / 256, 256, 0, st>>>(N, rank, sr, al, rgb, x_sdf, x_alb, f_sdf, f_alb, color);
+}
+
+}  // namespace i3d

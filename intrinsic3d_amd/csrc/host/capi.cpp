@@ -1,0 +1,115 @@
+// extern "C" entry points that are not pure context plumbing: optimize, one-shot host drop-in, parity probes.
+#include "context.hpp"
+
+using namespace i3d;
+
+extern "C" {
+
+int i3d_optimize(i3d_context* c, const i3d_optimizer_config* cfg, i3d_iteration_stats* stats) {
+    if (!c || !cfg) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_optimize: null argument");
+    return optimize(c, *cfg, stats);
+}
+
+int i3d_optimize_host(int32_t device_ordinal, const i3d_optimizer_config* cfg, const i3d_grid_view* grid,
+                      double* sdf_refined_io, double* albedo_io, int32_t num_frames, int32_t levels, const int32_t* widths,
+                      const int32_t* heights, const float* const* lum, const float* const* depth,
+                      double* intr_io, double* dist_io, double* poses_io, const double* voxel_sh, i3d_iteration_stats* stats) {
+    if (!cfg || !grid || !sdf_refined_io || !albedo_io || !intr_io || !dist_io || !poses_io || !voxel_sh) return I3D_ERR_INVALID_ARGUMENT;
+    i3d_context* c = nullptr;
+    int rc = i3d_create(device_ordinal, &c); if (rc) return rc;
+    i3d_grid_view gv = *grid; gv.sdf_refined = sdf_refined_io; gv.albedo = albedo_io;
+    rc = i3d_set_grid(c, &gv);
+    if (!rc) rc = i3d_set_frames(c, num_frames, levels, widths, heights, lum, depth, nullptr);
+    if (!rc) rc = i3d_set_camera(c, intr_io, dist_io, poses_io);
+    if (!rc) rc = i3d_set_voxel_sh(c, voxel_sh);
+    if (!rc) rc = i3d_optimize(c, cfg, stats);
+    if (!rc) rc = i3d_get_grid(c, sdf_refined_io, albedo_io);
+    if (!rc) rc = i3d_get_camera(c, intr_io, dist_io, poses_io);
+    if (rc) std::fprintf(stderr, "i3d_optimize_host: %s\n", i3d_last_error(c));
+    i3d_destroy(c);
+    return rc;
+}
+
+int i3d_debug_assemble(i3d_context* c, const i3d_optimizer_config* cfg, int32_t iteration, int32_t* slots_out) {
+    if (!c || !cfg) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_debug_assemble: null argument");
+    CTX_HIP(c, hipSetDevice(c->device));
+    OptParams p; i3d_iteration_stats st; std::memset(&st, 0, sizeof(st));
+    int rc = assemble(c, *cfg, iteration, p, &st);
+    if (!rc && slots_out) *slots_out = c->slots;
+    return rc;
+}
+
+int i3d_debug_flags(i3d_context* c, uint8_t* flags) {
+    if (!c || !flags || !c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_debug_flags: no grid");
+    const int N = c->N; std::vector<uint8_t> f(N); std::vector<int> rank(N);
+    CTX_HIP(c, hipMemcpy(f.data(), c->flags.p, N, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(rank.data(), c->rank.p, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+    for (int s = 0; s < N; ++s) flags[rank[s]] = f[s];
+    return I3D_OK;
+}
+
+int i3d_debug_eg_rows(i3d_context* c, int32_t* frame, float* weight, float* residual, float* jac) {
+    if (!c || !c->assembled) return ctx_fail(c, I3D_ERR_STATE, "i3d_debug_eg_rows: not assembled");
+    const int N = c->N, A = c->A, S = c->slots; const size_t Acap = c->Acap;
+    std::vector<int> rank(N), alist(A > 0 ? A : 1), of(Acap * S); std::vector<float> rw(Acap * S), rs(Acap * S), J;
+    CTX_HIP(c, hipMemcpy(rank.data(), c->rank.p, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+    if (A > 0) CTX_HIP(c, hipMemcpy(alist.data(), c->alist.p, sizeof(int) * (size_t)A, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(of.data(), c->obs_frame.p, sizeof(int) * Acap * S, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(rw.data(), c->roww.p, sizeof(float) * Acap * S, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(rs.data(), c->res.p, sizeof(float) * Acap * S, hipMemcpyDeviceToHost));
+    if (jac) { J.resize(Acap * S * P_TOTAL); CTX_HIP(c, hipMemcpy(J.data(), c->J.p, sizeof(float) * Acap * S * P_TOTAL, hipMemcpyDeviceToHost)); }
+    for (size_t i = 0; i < (size_t)N * S; ++i) { if (frame) frame[i] = -1; if (weight) weight[i] = 0.0f; if (residual) residual[i] = 0.0f; }
+    if (jac) std::memset(jac, 0, sizeof(float) * (size_t)N * S * P_TOTAL);
+    const float tw = (float)c->last_params.type_w[0];
+    for (int a = 0; a < A; ++a) {
+        const int v = rank[alist[a]];
+        for (int k = 0; k < S; ++k) {
+            const size_t ka = (size_t)k * Acap + a;
+            if (rw[ka] == 0.0f) continue;
+            const size_t o = (size_t)v * S + k;
+            if (frame) frame[o] = of[ka];
+            if (weight) weight[o] = rw[ka] * tw;
+            if (residual) residual[o] = rs[ka];
+            if (jac) for (int i = 0; i < P_TOTAL; ++i) jac[o * P_TOTAL + i] = J[((size_t)i * S + k) * Acap + a];
+        }
+    }
+    return I3D_OK;
+}
+
+int i3d_debug_reg_rows(i3d_context* c, uint8_t* has_er, uint8_t* has_es, float* ea_weight) {
+    if (!c || !c->assembled) return ctx_fail(c, I3D_ERR_STATE, "i3d_debug_reg_rows: not assembled");
+    const int N = c->N, A = c->A; const size_t Acap = c->Acap;
+    std::vector<int> rank(N), alist(A > 0 ? A : 1); std::vector<uint8_t> rf(Acap); std::vector<float> ew(Acap * 6);
+    CTX_HIP(c, hipMemcpy(rank.data(), c->rank.p, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+    if (A > 0) CTX_HIP(c, hipMemcpy(alist.data(), c->alist.p, sizeof(int) * (size_t)A, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(rf.data(), c->regflags.p, Acap, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(ew.data(), c->ea_w.p, sizeof(float) * Acap * 6, hipMemcpyDeviceToHost));
+    for (int v = 0; v < N; ++v) { if (has_er) has_er[v] = 0; if (has_es) has_es[v] = 0; if (ea_weight) for (int d = 0; d < 6; ++d) ea_weight[(size_t)v * 6 + d] = 0.0f; }
+    const float tw = (float)c->last_params.type_w[3];
+    for (int a = 0; a < A; ++a) {
+        const int v = rank[alist[a]];
+        if (has_er) has_er[v] = rf[a] & 1; if (has_es) has_es[v] = (rf[a] >> 1) & 1;
+        if (ea_weight) for (int d = 0; d < 6; ++d) ea_weight[(size_t)v * 6 + d] = ew[(size_t)d * Acap + a] * tw;
+    }
+    return I3D_OK;
+}
+
+int i3d_debug_neighbors(i3d_context* c, int32_t* nbr) {
+    if (!c || !nbr || !c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_debug_neighbors: no grid");
+    const int N = c->N; std::vector<int> rank(N), t((size_t)NUM_NBR * N);
+    CTX_HIP(c, hipMemcpy(rank.data(), c->rank.p, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(t.data(), c->nbr.p, sizeof(int) * (size_t)NUM_NBR * N, hipMemcpyDeviceToHost));
+    for (int s = 0; s < N; ++s) for (int i = 0; i < NUM_NBR; ++i) { const int n = t[(size_t)i * N + s]; nbr[(size_t)rank[s] * NUM_NBR + i] = n < 0 ? -1 : rank[n]; }
+    return I3D_OK;
+}
+
+int i3d_debug_normal_eq(i3d_context* c, double* gradient, double* jtj_diag, double* cost) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    return normal_eq_debug(c, gradient, jtj_diag, cost);
+}
+int i3d_debug_jtj_apply(i3d_context* c, const double* x, double* y) {
+    if (!c || !x || !y) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_debug_jtj_apply: null pointer");
+    return jtj_apply_debug(c, x, y);
+}
+
+}  // extern "C"

@@ -1,0 +1,327 @@
+// Context lifetime, uploads (grid / keyframes / camera / per-voxel SH), write-back, per-keyframe constants, timing.
+#include "context.hpp"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+
+using namespace i3d;
+
+static thread_local std::string g_create_error;
+
+namespace i3d {
+
+int ctx_fail(i3d_context* c, int code, const std::string& msg) { if (c) c->err = msg; else g_create_error = msg; return code; }
+int ctx_hip(i3d_context* c, hipError_t e, const char* what) {
+    return ctx_fail(c, I3D_ERR_HIP, std::string(what) + " -> " + hipGetErrorString(e));
+}
+
+int ensure_pinned(i3d_context* c, size_t n) {
+    if (n <= c->h_pinned_n) return I3D_OK;
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    c->h_pinned = nullptr; c->h_pinned_n = 0;
+    CTX_HIP(c, hipHostMalloc((void**)&c->h_pinned, n * sizeof(double), hipHostMallocDefault));
+    c->h_pinned_n = n;
+    return I3D_OK;
+}
+
+// ---- timing: one HIP event pair per launch on the context's stream, resolved at flush -------------------------
+void timing_begin(i3d_context* c, int cat) {
+    if (!c->timing.on) return;
+    Timing::Pending p; p.cat = cat;
+    auto get = [&]() { hipEvent_t e; if (!c->timing.pool.empty()) { e = c->timing.pool.back(); c->timing.pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    p.a = get(); p.b = get();
+    (void)hipEventRecord(p.a, c->stream);
+    c->timing.pending.push_back(p);
+}
+void timing_end(i3d_context* c) {
+    if (!c->timing.on || c->timing.pending.empty()) return;
+    (void)hipEventRecord(c->timing.pending.back().b, c->stream);
+}
+void timing_flush(i3d_context* c) {
+    if (c->timing.pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->timing.pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->timing.ms[p.cat] += ms; c->timing.launches[p.cat] += 1; }
+        c->timing.pool.push_back(p.a); c->timing.pool.push_back(p.b);
+    }
+    c->timing.pending.clear();
+}
+
+// ---- per-keyframe constants ------------------------------------------------------------------------------------
+// R(omega) exactly as ceres::AngleAxisRotatePoint applies it [Ceres 2.1.0 rotation.h, not in reference; used at cost.h:84],
+// with its three partial derivatives, by forward-mode duals over omega.
+namespace {
+struct D3 { double a, v[3]; };
+inline D3 mk(double a) { return {a, {0, 0, 0}}; }
+inline D3 operator+(D3 x, D3 y) { return {x.a + y.a, {x.v[0] + y.v[0], x.v[1] + y.v[1], x.v[2] + y.v[2]}}; }
+inline D3 operator-(D3 x, D3 y) { return {x.a - y.a, {x.v[0] - y.v[0], x.v[1] - y.v[1], x.v[2] - y.v[2]}}; }
+inline D3 operator*(D3 x, D3 y) { return {x.a * y.a, {x.a * y.v[0] + x.v[0] * y.a, x.a * y.v[1] + x.v[1] * y.a, x.a * y.v[2] + x.v[2] * y.a}}; }
+inline D3 operator/(D3 x, D3 y) { const double gi = 1.0 / y.a, q = x.a * gi; return {q, {(x.v[0] - q * y.v[0]) * gi, (x.v[1] - q * y.v[1]) * gi, (x.v[2] - q * y.v[2]) * gi}}; }
+inline D3 dsqrt(D3 x) { const double t = std::sqrt(x.a), h = 1.0 / (2.0 * t); return {t, {x.v[0] * h, x.v[1] * h, x.v[2] * h}}; }
+inline D3 dsin(D3 x) { const double c = std::cos(x.a); return {std::sin(x.a), {c * x.v[0], c * x.v[1], c * x.v[2]}}; }
+inline D3 dcos(D3 x) { const double s = -std::sin(x.a); return {std::cos(x.a), {s * x.v[0], s * x.v[1], s * x.v[2]}}; }
+
+void rotate_dual(const double aa[3], const double pt[3], D3 out[3]) {
+    D3 w[3]; for (int i = 0; i < 3; ++i) { w[i] = mk(aa[i]); w[i].v[i] = 1.0; }
+    const D3 p[3] = {mk(pt[0]), mk(pt[1]), mk(pt[2])};
+    const D3 th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (th2.a > std::numeric_limits<double>::epsilon()) {
+        const D3 th = dsqrt(th2), ct = dcos(th), stn = dsin(th), ti = mk(1.0) / th;
+        const D3 k[3] = {w[0] * ti, w[1] * ti, w[2] * ti};
+        const D3 kxp[3] = {k[1] * p[2] - k[2] * p[1], k[2] * p[0] - k[0] * p[2], k[0] * p[1] - k[1] * p[0]};
+        const D3 tmp = (k[0] * p[0] + k[1] * p[1] + k[2] * p[2]) * (mk(1.0) - ct);
+        for (int i = 0; i < 3; ++i) out[i] = p[i] * ct + kxp[i] * stn + k[i] * tmp;
+    } else {
+        const D3 wxp[3] = {w[1] * p[2] - w[2] * p[1], w[2] * p[0] - w[0] * p[2], w[0] * p[1] - w[1] * p[0]};
+        for (int i = 0; i < 3; ++i) out[i] = p[i] + wxp[i];
+    }
+}
+// math::poseVecAAToMat (math.cpp:151-163): Eigen::AngleAxisd(|w|, w/|w|).matrix() [Eigen, not in reference]
+void pose_to_mat_eigen(const double p[6], double R[9]) {
+    const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    const double angle = std::sqrt(n2);
+    double ax[3] = {p[0], p[1], p[2]};
+    if (n2 > 0.0) { ax[0] /= angle; ax[1] /= angle; ax[2] /= angle; }
+    const double s = std::sin(angle), c = std::cos(angle);
+    const double sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+    const double ca[3] = {(1.0 - c) * ax[0], (1.0 - c) * ax[1], (1.0 - c) * ax[2]};
+    double tmp;
+    tmp = ca[0] * ax[1]; R[1] = tmp - sa[2]; R[3] = tmp + sa[2];
+    tmp = ca[0] * ax[2]; R[2] = tmp + sa[1]; R[6] = tmp - sa[1];
+    tmp = ca[1] * ax[2]; R[5] = tmp - sa[0]; R[7] = tmp + sa[0];
+    R[0] = ca[0] * ax[0] + c; R[4] = ca[1] * ax[1] + c; R[8] = ca[2] * ax[2] + c;
+}
+}  // namespace
+
+void build_frame_consts(const i3d_context* c, int level, const double* poses, std::vector<FrameConst>& out) {
+    out.resize(c->K);
+    for (int f = 0; f < c->K; ++f) {
+        FrameConst& fc = out[f];
+        const double* p = poses + 6 * f;
+        for (int col = 0; col < 3; ++col) {         // columns of R and dR/dw_i = rotation of the basis vectors
+            double e[3] = {0, 0, 0}; e[col] = 1.0;
+            D3 o[3]; rotate_dual(p, e, o);
+            for (int row = 0; row < 3; ++row) { fc.R[3 * row + col] = o[row].a; for (int i = 0; i < 3; ++i) fc.dR[i][3 * row + col] = o[row].v[i]; }
+        }
+        for (int i = 0; i < 3; ++i) fc.t[i] = p[3 + i];
+        double Re[9]; pose_to_mat_eigen(p, Re);
+        for (int i = 0; i < 9; ++i) fc.Rf[i] = (float)Re[i];
+        for (int i = 0; i < 3; ++i) fc.tf[i] = (float)p[3 + i];
+        const size_t k = (size_t)f * c->levels + level;
+        fc.lum = c->lum[k].p; fc.depth = c->depth[k].p; fc.bgr = c->bgr[k].p;
+        fc.w = c->fw[level]; fc.h = c->fh[level];
+    }
+}
+
+}  // namespace i3d
+
+i3d::GridView i3d_context::grid_view() const {
+    GridView g;
+    g.N = N; g.voxel_size = voxel_size; g.truncation = truncation;
+    g.cx = cx.p; g.cy = cy.p; g.cz = cz.p; g.rank = rank.p; g.nbr = nbr.p; g.weight = weight.p; g.color = color.p;
+    g.sdf0 = sdf0.p; g.x_sdf = x_sdf.p; g.x_alb = x_alb.p; g.f_sdf = f_sdf.p; g.f_alb = f_alb.p; g.sh = sh.p;
+    g.flags = flags.p; g.aidx = aidx.p;
+    return g;
+}
+i3d::RowView i3d_context::row_view() const {
+    RowView r;
+    r.A = A; r.Acap = Acap; r.slots = slots; r.alist = alist.p; r.obs_frame = obs_frame.p; r.obs_w = obs_w.p;
+    r.res = res.p; r.roww = roww.p; r.J = J.p; r.rowfree = rowfree.p; r.regflags = regflags.p; r.ea_w = ea_w.p; r.ea_free = ea_free.p;
+    return r;
+}
+
+extern "C" {
+
+const char* i3d_version(void) { return "intrinsic3d_hip 0.1 (gfx950)"; }
+const char* i3d_last_error(const i3d_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int i3d_create(int32_t device_ordinal, i3d_context** out) {
+    if (!out) return ctx_fail(nullptr, I3D_ERR_INVALID_ARGUMENT, "i3d_create: null output pointer");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return ctx_fail(nullptr, I3D_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= count) return ctx_fail(nullptr, I3D_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    e = hipSetDevice(device_ordinal);
+    if (e != hipSuccess) return ctx_hip(nullptr, e, "hipSetDevice");
+    auto* c = new i3d_context();
+    c->device = device_ordinal;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return ctx_hip(nullptr, e, "hipStreamCreate"); }
+    *out = c;
+    return I3D_OK;
+}
+
+void i3d_destroy(i3d_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    timing_flush(c);
+    for (auto e : c->timing.pool) (void)hipEventDestroy(e);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int i3d_set_grid(i3d_context* c, const i3d_grid_view* gv) {
+    if (!c || !gv || gv->num_voxels <= 0 || !gv->keys || !gv->sdf || !gv->sdf_refined || !gv->albedo || !gv->weight || !gv->color)
+        return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_grid: null grid or empty voxel list");
+    if (gv->num_voxels > (1ll << 30)) return ctx_fail(c, I3D_ERR_CAPACITY, "i3d_set_grid: more than 2^30 voxels");
+    CTX_HIP(c, hipSetDevice(c->device));
+    const int N = (int)gv->num_voxels;
+    c->N = N; c->voxel_size = gv->voxel_size; c->truncation = gv->truncation; c->have_grid = false; c->have_sh = false; c->assembled = false;
+    hipStream_t st = c->stream;
+    // staging copies of the caller's arrays (visit order)
+    DevBuf<int> kxyz, perm, iota; DevBuf<double> hsdf, hsr, halb; DevBuf<float> hw; DevBuf<uint8_t> hrgb;
+    DevBuf<unsigned long long> skeys, skeys2;
+    CTX_HIP(c, kxyz.alloc((size_t)3 * N)); CTX_HIP(c, perm.alloc(N)); CTX_HIP(c, iota.alloc(N));
+    CTX_HIP(c, hsdf.alloc(N)); CTX_HIP(c, hsr.alloc(N)); CTX_HIP(c, halb.alloc(N)); CTX_HIP(c, hw.alloc(N)); CTX_HIP(c, hrgb.alloc((size_t)3 * N));
+    CTX_HIP(c, skeys.alloc(N)); CTX_HIP(c, skeys2.alloc(N));
+    CTX_HIP(c, hipMemcpyAsync(kxyz.p, gv->keys, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(hsdf.p, gv->sdf, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(hsr.p, gv->sdf_refined, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(halb.p, gv->albedo, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(hw.p, gv->weight, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(hrgb.p, gv->color, (size_t)3 * N, hipMemcpyHostToDevice, st));
+    // brick-Morton sort (device order), then permute every field into SoA planes
+    launch_sort_keys(st, N, kxyz.p, skeys.p, iota.p);
+    size_t tmp_bytes = 0;
+    CTX_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, skeys.p, skeys2.p, iota.p, perm.p, (size_t)N, 0, 64, st));
+    DevBuf<unsigned char> tmp; CTX_HIP(c, tmp.alloc(tmp_bytes));
+    CTX_HIP(c, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, skeys.p, skeys2.p, iota.p, perm.p, (size_t)N, 0, 64, st));
+    CTX_HIP(c, c->cx.alloc(N)); CTX_HIP(c, c->cy.alloc(N)); CTX_HIP(c, c->cz.alloc(N)); CTX_HIP(c, c->rank.alloc(N));
+    CTX_HIP(c, c->sdf0.alloc(N)); CTX_HIP(c, c->x_sdf.alloc(N)); CTX_HIP(c, c->x_alb.alloc(N)); CTX_HIP(c, c->xc_sdf.alloc(N)); CTX_HIP(c, c->xc_alb.alloc(N));
+    CTX_HIP(c, c->f_sdf.alloc(N)); CTX_HIP(c, c->f_alb.alloc(N)); CTX_HIP(c, c->weight.alloc(N)); CTX_HIP(c, c->color.alloc(N));
+    CTX_HIP(c, c->flags.alloc(N)); CTX_HIP(c, c->aidx.alloc(N)); CTX_HIP(c, c->alist.alloc(N)); CTX_HIP(c, c->aflag.alloc(N)); CTX_HIP(c, c->ascan.alloc(N));
+    CTX_HIP(c, c->sh.alloc((size_t)9 * N)); CTX_HIP(c, c->nbr.alloc((size_t)NUM_NBR * N));
+    launch_permute_grid(st, N, perm.p, kxyz.p, hsdf.p, hsr.p, halb.p, hw.p, hrgb.p, c->cx.p, c->cy.p, c->cz.p, c->rank.p, c->sdf0.p,
+                        c->x_sdf.p, c->x_alb.p, c->f_sdf.p, c->f_alb.p, c->weight.p, c->color.p);
+    // device hash (2x load-factor headroom, power of two) + neighbour table
+    unsigned int cap = 1; while (cap < (unsigned int)N * 2u) cap <<= 1;
+    DevBuf<unsigned long long> hkeys; DevBuf<int> hvals;
+    CTX_HIP(c, hkeys.alloc(cap)); CTX_HIP(c, hvals.alloc(cap));
+    CTX_HIP(c, hipMemsetAsync(hkeys.p, 0xff, sizeof(unsigned long long) * (size_t)cap, st));
+    HashTable t{hkeys.p, hvals.p, cap - 1};
+    launch_hash_build(st, N, c->cx.p, c->cy.p, c->cz.p, t);
+    launch_nbr_build(st, N, c->cx.p, c->cy.p, c->cz.p, t, c->nbr.p);
+    CTX_HIP(c, hipMemsetAsync(c->sh.p, 0, sizeof(float) * 9 * (size_t)N, st));
+    size_t sb = 0;
+    CTX_HIP(c, rocprim::exclusive_scan(nullptr, sb, c->aflag.p, c->ascan.p, 0, (size_t)N, rocprim::plus<int>(), st));
+    CTX_HIP(c, c->scan_tmp.alloc(sb ? sb : 1)); c->scan_tmp_bytes = sb;
+    CTX_HIP(c, hipStreamSynchronize(st));
+    CTX_HIP(c, hipGetLastError());
+    c->have_grid = true;
+    return I3D_OK;
+}
+
+int i3d_get_grid(i3d_context* c, double* sdf_refined, double* albedo) {
+    if (!c || !c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_get_grid: no grid");
+    CTX_HIP(c, hipSetDevice(c->device));
+    const int N = c->N;
+    DevBuf<double> a, b; CTX_HIP(c, a.alloc(N)); CTX_HIP(c, b.alloc(N));
+    launch_gather_visit(c->stream, N, c->rank.p, c->x_sdf.p, c->x_alb.p, a.p, b.p);
+    if (sdf_refined) CTX_HIP(c, hipMemcpyAsync(sdf_refined, a.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    if (albedo) CTX_HIP(c, hipMemcpyAsync(albedo, b.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    return I3D_OK;
+}
+
+int i3d_update_grid(i3d_context* c, const double* sdf_refined, const double* albedo, const uint8_t* color) {
+    if (!c || !c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_update_grid: no grid");
+    CTX_HIP(c, hipSetDevice(c->device));
+    const int N = c->N;
+    DevBuf<double> a, b; DevBuf<uint8_t> col;
+    if (sdf_refined) { CTX_HIP(c, a.alloc(N)); CTX_HIP(c, hipMemcpyAsync(a.p, sdf_refined, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, c->stream)); }
+    if (albedo) { CTX_HIP(c, b.alloc(N)); CTX_HIP(c, hipMemcpyAsync(b.p, albedo, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, c->stream)); }
+    if (color) { CTX_HIP(c, col.alloc((size_t)3 * N)); CTX_HIP(c, hipMemcpyAsync(col.p, color, (size_t)3 * N, hipMemcpyHostToDevice, c->stream)); }
+    launch_update_fields(c->stream, N, c->rank.p, a.p, b.p, col.p, c->x_sdf.p, c->x_alb.p, c->f_sdf.p, c->f_alb.p, c->color.p);
+    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    c->assembled = false;
+    return I3D_OK;
+}
+
+int i3d_set_frames(i3d_context* c, int32_t K, int32_t levels, const int32_t* widths, const int32_t* heights,
+                   const float* const* lum, const float* const* depth, const uint8_t* const* bgr) {
+    if (!c || K <= 0 || levels <= 0 || !widths || !heights || !lum || !depth) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_frames: bad arguments");
+    CTX_HIP(c, hipSetDevice(c->device));
+    c->have_frames = false; c->K = K; c->levels = levels;
+    c->fw.assign(widths, widths + levels); c->fh.assign(heights, heights + levels);
+    c->lum.clear(); c->depth.clear(); c->bgr.clear();
+    c->lum.resize((size_t)K * levels); c->depth.resize((size_t)K * levels); c->bgr.resize((size_t)K * levels);
+    for (int f = 0; f < K; ++f) for (int l = 0; l < levels; ++l) {
+        const size_t k = (size_t)f * levels + l, px = (size_t)widths[l] * heights[l];
+        if (!lum[k] || !depth[k]) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_frames: null image");
+        CTX_HIP(c, c->lum[k].alloc(px)); CTX_HIP(c, c->depth[k].alloc(px));
+        CTX_HIP(c, hipMemcpyAsync(c->lum[k].p, lum[k], px * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        CTX_HIP(c, hipMemcpyAsync(c->depth[k].p, depth[k], px * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        if (bgr && bgr[k]) { CTX_HIP(c, c->bgr[k].alloc(px * 3)); CTX_HIP(c, hipMemcpyAsync(c->bgr[k].p, bgr[k], px * 3, hipMemcpyHostToDevice, c->stream)); }
+    }
+    CTX_HIP(c, c->d_frames.alloc(K)); CTX_HIP(c, c->d_frames_cand.alloc(K));
+    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_frames = true;
+    if ((int)c->poses.size() != 6 * K) { c->poses.assign((size_t)6 * K, 0.0); c->have_camera = false; }
+    return I3D_OK;
+}
+
+int i3d_set_camera(i3d_context* c, const double* intr, const double* dist, const double* poses) {
+    if (!c || !intr || !dist || !poses) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_camera: null pointer");
+    if (!c->have_frames) return ctx_fail(c, I3D_ERR_STATE, "i3d_set_camera: set the keyframes first");
+    std::memcpy(c->intr, intr, sizeof(double) * 4); std::memcpy(c->dist, dist, sizeof(double) * 5);
+    c->poses.assign(poses, poses + (size_t)6 * c->K);
+    c->have_camera = true;
+    return I3D_OK;
+}
+int i3d_get_camera(i3d_context* c, double* intr, double* dist, double* poses) {
+    if (!c || !c->have_camera) return ctx_fail(c, I3D_ERR_STATE, "i3d_get_camera: no camera");
+    if (intr) std::memcpy(intr, c->intr, sizeof(double) * 4);
+    if (dist) std::memcpy(dist, c->dist, sizeof(double) * 5);
+    if (poses) std::memcpy(poses, c->poses.data(), sizeof(double) * 6 * (size_t)c->K);
+    return I3D_OK;
+}
+
+int i3d_set_voxel_sh(i3d_context* c, const double* voxel_sh) {
+    if (!c || !voxel_sh) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_voxel_sh: null pointer");
+    if (!c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_set_voxel_sh: no grid");
+    CTX_HIP(c, hipSetDevice(c->device));
+    DevBuf<double> tmp; CTX_HIP(c, tmp.alloc((size_t)9 * c->N));
+    CTX_HIP(c, hipMemcpyAsync(tmp.p, voxel_sh, sizeof(double) * 9 * (size_t)c->N, hipMemcpyHostToDevice, c->stream));
+    launch_scatter_sh(c->stream, c->N, c->rank.p, tmp.p, c->sh.p);
+    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_sh = true;
+    return I3D_OK;
+}
+int i3d_get_voxel_sh(i3d_context* c, double* out) {
+    if (!c || !out) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_get_voxel_sh: null pointer");
+    if (!c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_get_voxel_sh: no grid");
+    CTX_HIP(c, hipSetDevice(c->device));
+    const int N = c->N;
+    std::vector<float> sh((size_t)9 * N); std::vector<int> rank(N);
+    CTX_HIP(c, hipMemcpy(sh.data(), c->sh.p, sizeof(float) * 9 * (size_t)N, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(rank.data(), c->rank.p, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+    for (int s = 0; s < N; ++s) for (int j = 0; j < 9; ++j) out[(size_t)rank[s] * 9 + j] = (double)sh[(size_t)j * N + s];
+    return I3D_OK;
+}
+
+int i3d_timing_enable(i3d_context* c, int32_t on) { if (!c) return I3D_ERR_INVALID_ARGUMENT; timing_flush(c); c->timing.on = on != 0; return I3D_OK; }
+int i3d_timing_get(i3d_context* c, double* ms, int64_t* launches, int32_t reset) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    timing_flush(c);
+    for (int i = 0; i < I3D_K_COUNT; ++i) { if (ms) ms[i] = c->timing.ms[i]; if (launches) launches[i] = c->timing.launches[i]; }
+    if (reset) for (int i = 0; i < I3D_K_COUNT; ++i) { c->timing.ms[i] = 0; c->timing.launches[i] = 0; }
+    return I3D_OK;
+}
+const char* i3d_kernel_name(int32_t k) {
+    static const char* names[I3D_K_COUNT] = {"classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh"};
+    return (k >= 0 && k < I3D_K_COUNT) ? names[k] : "?";
+}
+int i3d_problem_sizes(i3d_context* c, int64_t out[6]) { if (!c || !out) return I3D_ERR_INVALID_ARGUMENT; for (int i = 0; i < 6; ++i) out[i] = c->last_sizes[i]; return I3D_OK; }
+
+void i3d_optimizer_config_default(i3d_optimizer_config* cfg) {     // optimizer.h:69-79, intrinsic3d.h:67-84
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->iterations = 10; cfg->lm_steps = 50; cfg->lambda_g = 0.2; cfg->lambda_r0 = 20.0; cfg->lambda_r1 = 160.0;
+    cfg->lambda_s0 = 10.0; cfg->lambda_s1 = 120.0; cfg->lambda_a = 0.1;
+    cfg->occlusion_distance = 0.02f; cfg->num_observations = 5; cfg->pcg_fixed_iterations = -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// Host-side state of one device context: resident voxel grid, keyframes, camera model, row storage and solver vectors.
+#pragma once
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cmath>
+#include "../device/kernels.hpp"
+#include "../../../include/intrinsic3d_hip.h"
+
+namespace i3d {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count) {          // grow-only
+        if (count <= n && p) return hipSuccess;
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+};
+
+struct Timing {
+    bool on = false;
+    double ms[I3D_K_COUNT] = {0};
+    long long launches[I3D_K_COUNT] = {0};
+    struct Pending { hipEvent_t a, b; int cat; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+}  // namespace i3d
+
+struct i3d_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- grid (device order = brick-Morton sorted) ----
+    int N = 0; float voxel_size = 0, truncation = 0;
+    i3d::DevBuf<int> cx, cy, cz, rank, nbr, aidx, alist, aflag, ascan;
+    i3d::DevBuf<double> sdf0, x_sdf, x_alb, xc_sdf, xc_alb;
+    i3d::DevBuf<float> f_sdf, f_alb, weight, sh;
+    i3d::DevBuf<uchar4> color;
+    i3d::DevBuf<uint8_t> flags;
+    i3d::DevBuf<unsigned char> scan_tmp; size_t scan_tmp_bytes = 0;
+    bool have_grid = false, have_sh = false;
+
+    // ---- keyframes ----
+    int K = 0, levels = 0;
+    std::vector<int> fw, fh;                        // per level
+    std::vector<i3d::DevBuf<float>> lum, depth;     // [K*levels]
+    std::vector<i3d::DevBuf<uint8_t>> bgr;
+    i3d::DevBuf<i3d::FrameConst> d_frames, d_frames_cand;
+    bool have_frames = false;
+
+    // ---- camera (fp64 master copy on the host) ----
+    double intr[4] = {0, 0, 0, 0}, dist[5] = {0, 0, 0, 0, 0};
+    std::vector<double> poses;
+    bool have_camera = false;
+
+    // ---- rows ----
+    int Acap = 0, slots = 0, A = 0;
+    i3d::DevBuf<int> obs_frame; i3d::DevBuf<float> obs_w, res, roww, J, ea_w, C, treg;
+    i3d::DevBuf<uint8_t> rowfree, regflags, ea_free;
+
+    // ---- solver vectors (length NP = 2N + 6K + 9) ----
+    i3d::DevBuf<float> v_mask, v_c, v_S, v_D2, v_Minv, v_b, v_x, v_r, v_p, v_z, v_q, v_u, v_acc, v_tmp;
+    i3d::DevBuf<float> Minv_blocks;
+    i3d::DevBuf<double> d_shared, d_blocks, d_scal, d_xshared, d_xcshared;
+    double* h_pinned = nullptr; size_t h_pinned_n = 0;
+
+    i3d::OptParams last_params; bool assembled = false;
+    long long last_sizes[6] = {0, 0, 0, 0, 0, 0};
+    i3d::Timing timing;
+
+    // views
+    i3d::GridView grid_view() const;
+    i3d::RowView row_view() const;
+};
+
+namespace i3d {
+
+// helpers implemented in context.cpp
+int ctx_fail(i3d_context* c, int code, const std::string& msg);
+int ctx_hip(i3d_context* c, hipError_t e, const char* what);
+#define CTX_HIP(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return i3d::ctx_hip((c), _e, #expr); } while (0)
+void build_frame_consts(const i3d_context* c, int level, const double* poses, std::vector<FrameConst>& out);
+int ensure_pinned(i3d_context* c, size_t n);
+void timing_begin(i3d_context* c, int cat);
+void timing_end(i3d_context* c);
+void timing_flush(i3d_context* c);
+struct TimedScope { i3d_context* c; TimedScope(i3d_context* c_, int cat) : c(c_) { timing_begin(c, cat); } ~TimedScope() { timing_end(c); } };
+
+// solver.cpp
+int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, OptParams& p, i3d_iteration_stats* st);
+int optimize(i3d_context* c, const i3d_optimizer_config& cfg, i3d_iteration_stats* stats);
+int normal_eq_debug(i3d_context* c, double* gradient, double* jtj_diag, double* cost);
+int jtj_apply_debug(i3d_context* c, const double* x, double* y);
+
+// lighting.cpp
+int estimate_sh(i3d_context* c, float subvolume_size, double lambda_reg, double thres_shell, int* num_subvolumes, double* sh,
+                int32_t* sub_index, int cap, i3d_sh_stats* stats);
+
+}  // namespace i3d

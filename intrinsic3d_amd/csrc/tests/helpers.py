@@ -1,0 +1,56 @@
+"""Shared scene set-up for the parity tests: synthetic scene -> oracle grid (reference visit order) -> flat arrays."""
+import numpy as np
+
+from intrinsic3d_amd import synthetic
+
+
+def small_scene(seed=1, radius_vox=16, K=6, width=160, height=120, levels=1, **kw):
+    return synthetic.make_scene(radius_vox=radius_vox, voxel_size=0.004, K=K, width=width, height=height, levels=levels, seed=seed, **kw)
+
+
+def oracle_setup(O, sc, thres_factor=2.0, sh_size=0.05, perturb=True, seed=3):
+    """Returns (grid, frames, arrays, voxel_sh, thres).  Runs the reference's per-level preparation on the oracle:
+    clearVoxelsOutsideThinShell (intrinsic3d.cpp:298-316) and the SVSH estimate (intrinsic3d.cpp:255-264)."""
+    g = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+    fr = O.Frames(sc["frames"], sc["levels"])
+    thres = thres_factor * float(sc["voxel_size"])
+    g.clear_outside_shell(thres)
+    if perturb:      # make sdf_refined != sdf and albedo non-constant so every residual type has a non-trivial Jacobian
+        a = g.export()
+        rng = np.random.default_rng(seed)
+        n = len(g)
+        sr = a["sdf_refined"] + rng.normal(0, 0.02 * float(sc["voxel_size"]), n)
+        al = 0.6 + 0.05 * np.sin(40.0 * a["keys"][:, 0] * float(sc["voxel_size"])) + rng.normal(0, 0.01, n)
+        g.import_fields(sdf_refined=sr, albedo=al)
+    rc, sh, idx, vsh, has, st = O.estimate_sh(g, sh_size, 10.0, thres)
+    assert rc == 0
+    arrays = g.export()
+    return g, fr, arrays, vsh, thres
+
+
+def oracle_cfg(O, thres, **kw):
+    d = dict(iterations=3, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0, lambda_s1=10.0, lambda_a=0.1,
+             fix_poses=0, fix_intrinsics=0, fix_distortion=0, occlusion_distance=0.02, num_observations=5, thres_shell=thres,
+             grid_level=0, rgbd_level=0, cg_fixed_iterations=-1, verbose=0)
+    d.update(kw)
+    return O.OptConfig(**d)
+
+
+def gpu_cfg(ocfg):
+    from intrinsic3d_amd import binding
+    return binding.default_config(
+        iterations=ocfg.iterations, lm_steps=ocfg.lm_steps, lambda_g=ocfg.lambda_g, lambda_r0=ocfg.lambda_r0, lambda_r1=ocfg.lambda_r1,
+        lambda_s0=ocfg.lambda_s0, lambda_s1=ocfg.lambda_s1, lambda_a=ocfg.lambda_a, fix_poses=ocfg.fix_poses,
+        fix_intrinsics=ocfg.fix_intrinsics, fix_distortion=ocfg.fix_distortion, occlusion_distance=ocfg.occlusion_distance,
+        num_observations=ocfg.num_observations, thres_shell=ocfg.thres_shell, grid_level=ocfg.grid_level, rgbd_level=ocfg.rgbd_level,
+        pcg_fixed_iterations=ocfg.cg_fixed_iterations, verbose=ocfg.verbose)
+
+
+def gpu_context(sc, arrays, vsh):
+    from intrinsic3d_amd import binding
+    ctx = binding.Context(0)
+    ctx.set_grid(sc["voxel_size"], arrays["keys"], arrays["sdf"], arrays["sdf_refined"], arrays["albedo"], arrays["weight"], arrays["color"])
+    ctx.set_frames(sc["frames"], sc["levels"])
+    ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
+    ctx.set_voxel_sh(vsh)
+    return ctx

@@ -1,0 +1,125 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): voxel indexing / row structure bit-exact; residuals, Jacobians, SDF / albedo / camera
+within 1e-4 relative.  Jacobians are stored in fp32 on the device, so per-entry checks use rtol 1e-4 with an atol tied
+to the row's largest partial."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(oracle):
+    sc = helpers.small_scene()
+    g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc)
+    ctx = helpers.gpu_context(sc, arrays, vsh)
+    yield dict(O=oracle, sc=sc, g=g, fr=fr, arrays=arrays, vsh=vsh, thres=thres, ctx=ctx)
+    ctx.close()
+
+
+def test_neighbor_table_bit_exact(setup):
+    keys = setup["arrays"]["keys"]
+    index = {tuple(k): i for i, k in enumerate(keys.tolist())}
+    nb = setup["ctx"].debug_neighbors()
+    offs = [(1,0,0),(-1,0,0),(0,1,0),(0,-1,0),(0,0,1),(0,0,-1),(2,0,0),(0,2,0),(0,0,2),(1,1,0),(1,0,1),(0,1,1),
+            (-2,0,0),(0,-2,0),(0,0,-2),(-1,-1,0),(-1,0,-1),(0,-1,-1)]
+    exp = np.full_like(nb, -1)
+    for j, o in enumerate(offs):
+        q = keys + np.array(o, np.int32)
+        exp[:, j] = [index.get(tuple(k), -1) for k in q.tolist()]
+    assert np.array_equal(nb, exp)
+
+
+def _assemble(setup, **kw):
+    O = setup["O"]
+    ocfg = helpers.oracle_cfg(O, setup["thres"], **kw)
+    pv = O.ProblemView(setup["g"], setup["fr"], ocfg, setup["sc"]["intr"], setup["sc"]["dist"], setup["sc"]["poses"], setup["vsh"], 0)
+    ctx = setup["ctx"]
+    ctx.debug_assemble(helpers.gpu_cfg(ocfg), 0)
+    return ocfg, pv, ctx
+
+
+def test_flags_and_row_structure_bit_exact(setup):
+    ocfg, pv, ctx = _assemble(setup)
+    fl = pv.flags(); gf = ctx.debug_flags()
+    assert np.array_equal((gf >> 1) & 1, fl["active"])
+    assert np.array_equal((gf >> 2) & 1, fl["ring_ok"])
+    assert np.array_equal(((gf >> 3) & 1) ^ 1, fl["fix_sdf"])
+    assert np.array_equal(((gf >> 4) & 1) ^ 1, fl["fix_alb"])
+    # Eg rows: same (voxel, frame) set
+    v, f, w, r, _ = pv.eg(with_jacobian=False)
+    gfr, gw, gr, _ = ctx.debug_eg_rows(jac=False)
+    exp = set(zip(v.tolist(), f.tolist()))
+    got = set((int(i), int(gfr[i, k])) for i, k in zip(*np.nonzero(gfr >= 0)))
+    assert got == exp
+    # Er / Es / Ea rows
+    er, es, ea = ctx.debug_reg_rows()
+    v1, _, _, _ = pv.reg(1); v2, _, _, _ = pv.reg(2); v3, d3, w3, _ = pv.reg(3)
+    assert set(np.nonzero(er)[0].tolist()) == set(v1.tolist())
+    assert set(np.nonzero(es)[0].tolist()) == set(v2.tolist())
+    assert set(zip(*[a.tolist() for a in np.nonzero(ea)])) == set(zip(v3.tolist(), d3.tolist()))
+    np.testing.assert_allclose(ea[v3, d3], w3, rtol=2e-6)
+    assert pv.rows == [len(v), len(v1), len(v2), len(v3)]
+    pv.free()
+
+
+def test_eg_residual_and_jacobian(setup):
+    ocfg, pv, ctx = _assemble(setup)
+    v, f, w, r, J = pv.eg(with_jacobian=True)
+    gfr, gw, gr, gJ = ctx.debug_eg_rows(jac=True)
+    slot = np.array([int(np.nonzero(gfr[vi] == fi)[0][0]) for vi, fi in zip(v, f)])
+    np.testing.assert_allclose(gw[v, slot], w, rtol=1e-5)
+    np.testing.assert_allclose(gr[v, slot], r, rtol=1e-4, atol=1e-9)
+    Jg = gJ[v, slot]
+    scale = np.abs(J).max(axis=1, keepdims=True)
+    # per column group: sdf, albedo, pose, intrinsics, distortion
+    for lo, hi in [(0, 10), (10, 14), (14, 20), (20, 24), (24, 29)]:
+        sc = np.abs(J[:, lo:hi]).max(axis=1, keepdims=True) + 1e-30
+        err = np.abs(Jg[:, lo:hi] - J[:, lo:hi]) / sc
+        assert err.max() < 1e-4, (lo, hi, err.max())
+    pv.free()
+
+
+def test_normal_equations(setup):
+    ocfg, pv, ctx = _assemble(setup)
+    cost, g, dg, free = pv.normal_eq()
+    gg, gd, gcost = ctx.debug_normal_eq()
+    assert abs(gcost - cost) <= 1e-5 * cost
+    np.testing.assert_allclose(gd, dg, rtol=2e-4, atol=1e-6 * dg.max())
+    np.testing.assert_allclose(gg, g, rtol=2e-3, atol=2e-5 * np.abs(g).max())
+    rng = np.random.default_rng(0)
+    x = rng.normal(0, 1, g.shape) * free
+    y = pv.jtj_apply(x); gy = ctx.debug_jtj_apply(x)
+    np.testing.assert_allclose(gy, y, rtol=2e-3, atol=2e-5 * np.abs(y).max())
+    pv.free()
+
+
+def test_optimize_matches_oracle(setup):
+    """3 outer iterations, every parameter group free; PCG iteration counts pinned to the oracle's."""
+    O = setup["O"]; sc = setup["sc"]
+    g2 = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+    g2.clear_outside_shell(setup["thres"])
+    a0 = setup["arrays"]
+    g2.import_fields(sdf_refined=a0["sdf_refined"], albedo=a0["albedo"])
+    ocfg = helpers.oracle_cfg(O, setup["thres"], cg_fixed_iterations=5)
+    rc, intr, dist, poses, stats = O.optimize(g2, setup["fr"], ocfg, sc["intr"], sc["dist"], sc["poses"], setup["vsh"])
+    assert rc == 0
+    ref = g2.export()
+    ctx = helpers.gpu_context(sc, a0, setup["vsh"])
+    gst = ctx.optimize(helpers.gpu_cfg(ocfg))
+    sdf, alb = ctx.get_grid(); gi, gd, gp = ctx.get_camera()
+    for so, sg in zip(stats, gst):
+        assert list(so.rows) == list(sg.rows)
+        assert abs(so.cost_initial - sg.cost_initial) <= 1e-4 * so.cost_initial
+        assert abs(so.cost_final - sg.cost_final) <= 1e-4 * so.cost_final
+        assert list(so.accepted[:so.n_attempts]) == list(sg.step_accepted[:sg.num_attempts])
+    dsdf = np.abs(sdf - ref["sdf_refined"]).max(); dalb = np.abs(alb - ref["albedo"]).max()
+    assert dsdf <= 1e-4 * np.abs(ref["sdf_refined"]).max(), dsdf
+    assert dalb <= 1e-4 * np.abs(ref["albedo"]).max(), dalb
+    np.testing.assert_allclose(gi, intr, rtol=1e-4)
+    np.testing.assert_allclose(gp, poses, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gd, dist, rtol=1e-3, atol=1e-4)
+    ctx.close(); g2.free()
