@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — Gauss-Newton iteration throughput of the voxel-SDF shading optimisation (BASELINE.json metric).
+
+A "step" is one outer iteration of Optimizer::optimize (optimizer.cpp:119-170): observation pass + residual/Jacobian
+build + cost-term normalisation + one Levenberg-Marquardt solve (PCG on the normal equations, cost evaluation, step
+acceptance).  The timed region is ONE i3d_optimize call with `--steps` iterations on inputs that are already resident
+in HBM; `--warmup` iterations run in a separate untimed call first.
+
+Workload (config.workload): BASELINE.json configs[3] shrunk to one node's worth of work per rank — a seeded synthetic
+hashed grid of ~8M stored voxels at 1 mm (thin shell around a bumpy sphere, finest-level shell threshold), 200 keyframes
+of 640x480 on a Fibonacci sphere, 0.2 m SH subvolumes, all parameter groups free.  With --gpus N the SAME problem is
+sharded by subvolume bricks across the ranks (strong scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--voxels", type=float, default=8.0e6, help="stored voxels of the synthetic grid")
+    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--voxel-size", type=float, default=0.001)
+    ap.add_argument("--band", type=float, default=3.5, help="stored half-thickness of the shell in voxels")
+    ap.add_argument("--shell", type=float, default=1.0, help="thin-shell factor (thin_shell_factor_final)")
+    ap.add_argument("--subvolume", type=float, default=0.2)
+    ap.add_argument("--cpu-sample", type=float, default=60000, help="stored voxels of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def build_workload(args, log):
+    from intrinsic3d_amd import synthetic
+    t0 = time.time()
+    radius_vox = int(round(np.sqrt(args.voxels / (4.0 * np.pi * 2.0 * args.band))))
+    sc = synthetic.make_scene(radius_vox=radius_vox, voxel_size=args.voxel_size, K=args.frames, width=args.width, height=args.height,
+                              levels=1, band_vox=args.band, seed=args.seed, cam_dist=2.6 * radius_vox * args.voxel_size,
+                              pose_noise=(0.002, 0.0035), lum_noise=0.005, bump_amp_vox=0.5, bump_freq=40.0)
+    log(f"scene: {sc['keys'].shape[0]} voxels, radius {radius_vox} vox, {args.frames} frames {args.width}x{args.height} in {time.time() - t0:.1f}s")
+    return sc
+
+
+def grid_arrays(sc):
+    n = sc["keys"].shape[0]
+    sdf = sc["sdf"].astype(np.float64)
+    return dict(keys=sc["keys"], sdf=sdf, sdf_refined=sdf.copy(), albedo=np.full(n, 0.6), weight=sc["weight"], color=sc["color"])
+
+
+def make_cfg(binding, args, iterations, thres):
+    # shipped data/intrinsic3d.yml values (lambda schedule, 10 iterations, 50 LM steps, 5 observations, 2 cm occlusion)
+    return binding.default_config(iterations=iterations, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0,
+                                  lambda_s1=10.0, lambda_a=0.1, fix_poses=0, fix_intrinsics=0, fix_distortion=0,
+                                  occlusion_distance=0.02, num_observations=5, thres_shell=thres, grid_level=0, rgbd_level=0,
+                                  pcg_fixed_iterations=-1, verbose=0)
+
+
+def cpu_baseline(args, sc, thres, log):
+    """The restated CPU reference (oracle, fp64, 8 OpenMP threads in the solve like options.num_threads = 8) on a bounded
+    spatial sample of the SAME workload: the voxels of a cap of the sphere, same keyframes, same configuration."""
+    from oracle import oracle_py as O
+    O.build()
+    keys = sc["keys"]
+    n_target = int(args.cpu_sample)
+    if n_target <= 0 or keys.shape[0] == 0:
+        return None
+    x = keys[:, 0]
+    cut = np.partition(x, keys.shape[0] - min(n_target, keys.shape[0]))[keys.shape[0] - min(n_target, keys.shape[0])]
+    sel = x >= cut
+    g = O.Grid.from_voxels(sc["voxel_size"], keys[sel], sc["sdf"][sel], sc["weight"][sel], sc["color"][sel])
+    fr = O.Frames(sc["frames"], 1)
+    n = len(g)
+    vsh = np.tile(np.asarray(sc["scene"].sh), (n, 1))
+    iters = 2
+    cfg = O.OptConfig(iterations=iters, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0, lambda_s1=10.0, lambda_a=0.1,
+                      fix_poses=0, fix_intrinsics=0, fix_distortion=0, occlusion_distance=0.02, num_observations=5, thres_shell=thres,
+                      grid_level=0, rgbd_level=0, cg_fixed_iterations=-1, verbose=0)
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    t0 = time.time()
+    rc, _, _, _, stats = O.optimize(g, fr, cfg, sc["intr"], sc["dist"], sc["poses"], vsh)
+    dt = time.time() - t0
+    g.free(); fr.free()
+    if rc != 0:
+        return None
+    sec_per_iter_sample = dt / iters
+    scale = keys.shape[0] / float(n)
+    value = 1.0 / (sec_per_iter_sample * scale)
+    log(f"cpu baseline: {n} voxels, {iters} iterations in {dt:.1f}s -> {sec_per_iter_sample:.2f} s/iter on the sample, x{scale:.1f} voxels")
+    return {"value": value, "unit": "GN iterations/s", "cores": int(os.environ.get("OMP_NUM_THREADS", "8")), "kind": "port",
+            "sample": f"restated CPU reference (Ceres-2.1.0-equivalent, fp64) on a {n}-voxel cap of the same grid with all {sc['K']} keyframes, "
+                      f"{iters} GN iterations in {dt:.1f}s; per-iteration time scaled linearly by the voxel ratio {scale:.1f} to the full workload "
+                      f"(residual collection single-threaded as in the reference, solve on 8 threads)",
+            "seconds_per_iteration_sample": sec_per_iter_sample}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        args.gpus = world
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from intrinsic3d_amd import binding
+    sc = build_workload(args, log)
+    thres = args.shell * float(sc["voxel_size"])
+    arrays = grid_arrays(sc)
+
+    if world > 1:
+        raise SystemExit("multi-GPU sharding is not wired into bench.py yet")
+
+    ctx = binding.Context(local_rank)
+    t0 = time.time()
+    ctx.set_grid(sc["voxel_size"], arrays["keys"], arrays["sdf"], arrays["sdf_refined"], arrays["albedo"], arrays["weight"], arrays["color"])
+    ctx.set_frames(sc["frames"], 1)
+    ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
+    ctx.set_voxel_sh(np.tile(np.asarray(sc["scene"].sh), (arrays["keys"].shape[0], 1)))
+    log(f"upload + hash/neighbour build: {time.time() - t0:.2f}s")
+
+    if args.warmup > 0:
+        ctx.optimize(make_cfg(binding, args, args.warmup, thres))
+    ctx.timing_enable(True); ctx.timing_get(reset=True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    stats = ctx.optimize(make_cfg(binding, args, args.steps, thres))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    timing = ctx.timing_get(reset=True)
+    sizes = ctx.problem_sizes()
+    ctx.timing_enable(False)
+
+    # ---- roofline of the residual/Jacobian kernel (SURVEY.md §8d byte model) and of the PCG operator kernel -------
+    A, Rg, Rr, Rs, Ra = sizes["active"], sizes["eg"], sizes["er"], sizes["es"], sizes["ea"]
+    img_bytes = min(4.0 * args.frames * args.width * args.height, 256.0 * Rg)
+    b_build = 68.0 * A + 132.0 * Rg + 36.0 * Rr + 12.0 * Rs + 16.0 * Ra + img_bytes
+    b_egpass = 124.0 * Rg + (14 + 8 + 2) * 4.0 * A          # J + weight/frame per row; staged sums, regulariser t-values, vector gather per voxel
+    kernels = {}
+    for name, bytes_per_launch in (("build", b_build), ("eg_pass", b_egpass)):
+        ms, n = timing[name]
+        if n > 0:
+            avg = ms / n
+            kernels[name] = {"launches": n, "avg_ms": avg, "algorithmic_GB": bytes_per_launch / 1e9,
+                             "achieved_GBs": bytes_per_launch / 1e9 / (avg * 1e-3)}
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
+    roofline = None
+    if dominant:
+        k = kernels[dominant]
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        try:
+            cpu = cpu_baseline(args, sc, thres, log)
+        except Exception as e:      # the baseline is informative; never let it take the measurement down
+            log(f"cpu baseline failed: {e}")
+
+    if rank == 0:
+        pcg = [int(s.pcg_iterations[i]) for s in stats for i in range(s.num_attempts)]
+        out = {
+            "metric": "Gauss-Newton iterations/s at the finest SDF level", "value": args.steps / dt, "unit": "GN iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic hashed SDF grid, {arrays['keys'].shape[0]} stored voxels @ {args.voxel_size * 1e3:g} mm "
+                                   f"({A} in the thin shell), {args.frames} keyframes {args.width}x{args.height}, {args.subvolume} m SH subvolumes, "
+                                   f"joint SDF+albedo+pose+intrinsics+distortion, 5 observations/voxel (BASELINE.json configs[3] on one node)",
+                       "stored_voxels": int(arrays["keys"].shape[0]), "active_voxels": A, "rows": {"Eg": Rg, "Er": Rr, "Es": Rs, "Ea": Ra},
+                       "free_parameters": sizes["free"], "keyframes": args.frames, "image": [args.width, args.height],
+                       "pcg_iterations_per_step": pcg, "lm_attempts": [int(s.num_attempts) for s in stats]},
+            "roofline": roofline, "kernels": kernels,
+            "kernel_ms_total": {k: v[0] for k, v in timing.items()}, "kernel_launches": {k: v[1] for k, v in timing.items()},
+            "time_split_ms_per_step": {"time_add": float(np.mean([s.time_add for s in stats]) * 1e3), "time_solve": float(np.mean([s.time_solve for s in stats]) * 1e3)},
+            "cost": [float(stats[0].cost_initial), float(stats[-1].cost_final)],
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,27 +149,41 @@ def render_frame(scene: Scene, pose6, intr, w, h, noise_sigma=0.0, rng=None):
 
 
 def shell_voxels(scene: Scene, voxel_size, band_vox, lo, hi, truncation=None):
-    """Enumerate integer voxels in [lo,hi)^3 with |sdf| <= band_vox*voxel_size, slab by slab."""
+    """Enumerate integer voxels in [lo,hi)^3 with |sdf| <= band_vox*voxel_size, slab by slab.
+    A cheap squared-distance prefilter keeps the transcendental sdf evaluation to the candidate annulus."""
     if truncation is None:
         truncation = 5.0 * voxel_size
     band = band_vox * voxel_size
     keys, sdfs = [], []
     xs = np.arange(lo[0], hi[0], dtype=np.int32)
     ys = np.arange(lo[1], hi[1], dtype=np.int32)
-    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    dx2 = (xs.astype(np.float64) * voxel_size - scene.c[0]) ** 2
+    dy2 = (ys.astype(np.float64) * voxel_size - scene.c[1]) ** 2
+    dense = band > 1e6
+    m = band + abs(scene.amp) + voxel_size
+    r_in2 = max(scene.R - m, 0.0) ** 2
+    r_out2 = (scene.R + m) ** 2
     for z in range(lo[2], hi[2]):
         zc = z * voxel_size
-        # quick reject of slabs that cannot touch the band
-        if abs(zc - scene.c[2]) > scene.R + band + abs(scene.amp) + voxel_size:
+        dz2 = (zc - scene.c[2]) ** 2
+        if not dense and dz2 > r_out2:
             continue
-        P = np.stack([X * np.float64(voxel_size), Y * np.float64(voxel_size), np.full(X.shape, zc)], axis=-1)
+        if dense:
+            ix, iy = np.meshgrid(np.arange(xs.size), np.arange(ys.size), indexing="ij")
+            ix = ix.ravel(); iy = iy.ravel()
+        else:
+            d2 = dx2[:, None] + dy2[None, :] + dz2
+            ix, iy = np.nonzero((d2 >= r_in2) & (d2 <= r_out2))
+        if ix.size == 0:
+            continue
+        P = np.stack([xs[ix].astype(np.float64) * voxel_size, ys[iy].astype(np.float64) * voxel_size, np.full(ix.size, zc)], axis=-1)
         s = scene.sdf(P)
-        m = np.abs(s) <= band
-        if not m.any():
+        sel = np.abs(s) <= band
+        if not sel.any():
             continue
-        k = np.stack([X[m], Y[m], np.full(m.sum(), z, dtype=np.int32)], axis=-1)
+        k = np.stack([xs[ix][sel], ys[iy][sel], np.full(int(sel.sum()), z, dtype=np.int32)], axis=-1)
         keys.append(k.astype(np.int32))
-        sdfs.append(np.clip(s[m], -truncation, truncation).astype(np.float32))
+        sdfs.append(np.clip(s[sel], -truncation, truncation).astype(np.float32))
     return np.concatenate(keys), np.concatenate(sdfs)
 
 
