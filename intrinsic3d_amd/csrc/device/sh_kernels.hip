@@ -1,0 +1,196 @@
+// K8/K9 — spatially-varying SH lighting: per-subvolume normal-equation blocks and per-voxel trilinear interpolation.
+//
+// Replaces the data-term assembly of LightingSVSH::estimate (lighting/lighting_svsh.cpp:196-253, SHDataCost :113-146:
+// one AutoDiffCostFunction<1,9> per in-shell voxel) and LightingSVSH::computeVoxelShCoeffs / Subvolumes::interpolate
+// (lighting_svsh.cpp:93-110, subvolumes.cpp:164-205, math.cpp:74-128).
+//
+// The data term of subvolume s is  sum_v w_v (phi_v . l_s - I_v)^2  with phi_v = albedo_v * H(n_v)  (9 SH basis terms),
+// so everything Ceres needs from these rows is the 10x10 Gram block  G_s = sum_v w_v [phi_v; I_v][phi_v; I_v]^T
+// (9x9 normal matrix, 9-vector right-hand side, scalar).  That rank-k update is the one GEMM-shaped piece of the whole
+// path and runs on the matrix cores in fp64:  v_mfma_f64_16x16x4_f64, A = w*[phi;I] padded 10->16, B = [phi;I], 4 voxels
+// per instruction, 16 instructions per 64-voxel wave tile, accumulated in registers across a wave's chunk and flushed with
+// one fp64 atomic per used entry when the subvolume changes.  fp64 because the SH coefficients must match the reference's
+// fp64 solve to 1e-4 and the 9x9 blocks are ill-conditioned when a subvolume sees a narrow range of normals.
+#include "kernels.hpp"
+#include "sh_kernels.hpp"
+
+namespace i3d {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+static __device__ __host__ inline unsigned long long pack3(int x, int y, int z) {
+    const long long B = 1ll << 20;
+    return ((unsigned long long)(x + B) & 0x1fffffull) | (((unsigned long long)(y + B) & 0x1fffffull) << 21) | (((unsigned long long)(z + B) & 0x1fffffull) << 42);
+}
+
+static __device__ inline int lower_bound_u64(const unsigned long long* __restrict__ a, int n, unsigned long long key) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return (lo < n && a[lo] == key) ? lo : -1;
+}
+
+// eligibility of a voxel for the SH data term (lighting_svsh.cpp:203-231) and its subvolume key (subvolumes.cpp:281-295)
+__global__ void __launch_bounds__(256) k_sh_keys(GridView g, ShParams sp, unsigned long long* __restrict__ keys, int* __restrict__ iota) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= g.N) return;
+    const int N = g.N;
+    unsigned long long key = ~0ull;
+    const bool valid = g.weight[s] > 0.0f;
+    const double xs = g.x_sdf[s];
+    if (valid && !(fabs(xs) > sp.thres_shell)) {
+        const int nx = g.nbr[(size_t)NB_PX * N + s], ny = g.nbr[(size_t)NB_PY * N + s], nz = g.nbr[(size_t)NB_PZ * N + s];
+        if (nx >= 0 && ny >= 0 && nz >= 0 && g.weight[nx] > 0.0f && g.weight[ny] > 0.0f && g.weight[nz] > 0.0f) {
+            const float s0 = g.f_sdf[s];
+            const float gx = g.f_sdf[nx] - s0, gy = g.f_sdf[ny] - s0, gz = g.f_sdf[nz] - s0;
+            const float len = sqrtf(gx * gx + gy * gy + gz * gz);
+            const double alb = g.x_alb[s];
+            if (len != 0.0f && !(len != len) && alb != 0.0 && alb == alb) {
+                if (sp.single) key = pack3(0, 0, 0);
+                else {
+                    const float inv = 1.0f / sp.size;
+                    const int ix = (int)floorf(((float)g.cx[s] * g.voxel_size) * inv), iy = (int)floorf(((float)g.cy[s] * g.voxel_size) * inv),
+                              iz = (int)floorf(((float)g.cz[s] * g.voxel_size) * inv);
+                    key = pack3(ix, iy, iz);
+                }
+            }
+        }
+    }
+    keys[s] = key; iota[s] = s;
+}
+
+// every stored voxel's subvolume key (Subvolumes::generate allocates a subvolume for ANY stored voxel, subvolumes.cpp:214-224)
+__global__ void __launch_bounds__(256) k_sh_all_keys(GridView g, ShParams sp, unsigned long long* __restrict__ keys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= g.N) return;
+    const float inv = 1.0f / sp.size;
+    keys[s] = pack3((int)floorf(((float)g.cx[s] * g.voxel_size) * inv), (int)floorf(((float)g.cy[s] * g.voxel_size) * inv),
+                    (int)floorf(((float)g.cz[s] * g.voxel_size) * inv));
+}
+
+// features of one voxel: f[0..8] = albedo * H(n), f[9] = luminance, weight w
+static __device__ inline void sh_features(const GridView& g, int s, double f[10], double& w) {
+    const int N = g.N;
+    const float s0 = g.f_sdf[s];
+    float nx = g.f_sdf[g.nbr[(size_t)NB_PX * N + s]] - s0, ny = g.f_sdf[g.nbr[(size_t)NB_PY * N + s]] - s0, nz = g.f_sdf[g.nbr[(size_t)NB_PZ * N + s]] - s0;
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    if (len != 0.0f) { nx /= len; ny /= len; nz /= len; }
+    const double x = (double)nx, y = (double)ny, z = (double)nz, a = g.x_alb[s];
+    f[0] = a; f[1] = a * y; f[2] = a * z; f[3] = a * x; f[4] = a * (x * y); f[5] = a * (y * z);
+    f[6] = a * ((-(x * x)) - (y * y) + 2.0 * (z * z)); f[7] = a * (x * z); f[8] = a * ((x * x) - (y * y));
+    const uchar4 c = g.color[s];
+    f[9] = (double)((0.299f * (float)c.x + 0.587f * (float)c.y + 0.114f * (float)c.z) / 255.0f);   // intensity(color)/255 (lighting_svsh.cpp:233)
+    const double tr = (double)g.truncation, xs = g.x_sdf[s];
+    w = fmin(fmax(1.0 - fmin(fabs(xs), tr) / tr, 0.01), 1.0);                                       // sdfToWeight (operators.cpp:142-147)
+}
+
+// Gram accumulation over the subvolume-sorted list of eligible voxels.  One wave owns `tiles_per_wave` consecutive 64-voxel tiles.
+__global__ void __launch_bounds__(256) k_sh_gram(GridView g, int M, const int* __restrict__ sorted_vox, const int* __restrict__ sorted_sub,
+                                                 int tiles_per_wave, double* __restrict__ gram /*[S][100]*/, double* __restrict__ wsum) {
+    __shared__ double feat[4][64][17];     // +1 padding: the MFMA operand read walks a column of 4 voxels x 16 features
+    __shared__ double wl[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave_global = blockIdx.x * 4 + wv;
+    const long long first = (long long)wave_global * tiles_per_wave * 64;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    int cur = -1;
+    double wtot = 0.0;
+    auto flush = [&](int sub) {
+        if (sub < 0) return;
+        const int col = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = (lane >> 4) + 4 * r; if (row < 10 && col < 10 && acc[r] != 0.0) atomicAdd(&gram[(size_t)sub * 100 + row * 10 + col], acc[r]); }
+        acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    };
+    for (int t = 0; t < tiles_per_wave; ++t) {
+        const long long i = first + (long long)t * 64 + lane;
+        if (first + (long long)t * 64 >= M) break;
+        int sub = -1; double f[10], w = 0.0;
+        if (i < M) { sub = sorted_sub[i]; sh_features(g, sorted_vox[i], f, w); wtot += w; }
+        else { for (int j = 0; j < 10; ++j) f[j] = 0.0; }
+        const int sub0 = __shfl(sub, 0, 64);
+        const bool uniform = __all(sub == sub0 || sub < 0);
+        if (uniform) {
+            if (sub0 != cur) { flush(cur); cur = sub0; }
+#pragma unroll
+            for (int j = 0; j < 10; ++j) feat[wv][lane][j] = f[j];
+#pragma unroll
+            for (int j = 10; j < 16; ++j) feat[wv][lane][j] = 0.0;
+            wl[wv][lane] = w;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): LDS writes of this wave are visible to its own reads
+#pragma unroll
+            for (int grp = 0; grp < 16; ++grp) {
+                const int vox = 4 * grp + (lane >> 4);
+                const double b = feat[wv][vox][lane & 15];
+                const double a = b * wl[wv][vox];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if (sub >= 0) {
+            // tile straddles a subvolume boundary: scalar rank-1 update straight into memory (rare)
+            for (int r = 0; r < 10; ++r) for (int c2 = 0; c2 < 10; ++c2) atomicAdd(&gram[(size_t)sub * 100 + r * 10 + c2], w * f[r] * f[c2]);
+        }
+    }
+    flush(cur);
+    for (int o = 32; o > 0; o >>= 1) wtot += __shfl_down(wtot, o, 64);
+    if (lane == 0 && wtot != 0.0) atomicAdd(wsum, wtot);
+}
+
+__global__ void __launch_bounds__(256) k_sh_assign(int M, const unsigned long long* __restrict__ sorted_keys, const unsigned long long* __restrict__ uniq, int S, int* __restrict__ sorted_sub) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    sorted_sub[i] = lower_bound_u64(uniq, S, sorted_keys[i]);
+}
+
+// Subvolumes::interpolate (subvolumes.cpp:164-205) + math::interpolationWeights / average (math.cpp:74-128)
+__global__ void __launch_bounds__(256) k_sh_interpolate(GridView g, ShParams sp, const unsigned long long* __restrict__ uniq, int S,
+                                                        const double* __restrict__ sh /*[S][9]*/, float* __restrict__ out /*[9][N]*/) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= g.N) return;
+    const size_t N = g.N;
+    double o[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) o[j] = 0.0;
+    if (g.weight[s] > 0.0f && !(fabs(g.x_sdf[s]) > sp.thres_shell)) {
+        if (sp.single) { for (int j = 0; j < 9; ++j) o[j] = sh[j]; }
+        else {
+            const float inv = 1.0f / sp.size;
+            const float px = ((float)g.cx[s] * g.voxel_size) * inv - 0.5f, py = ((float)g.cy[s] * g.voxel_size) * inv - 0.5f, pz = ((float)g.cz[s] * g.voxel_size) * inv - 0.5f;
+            const int x0 = (int)floorf(px), y0 = (int)floorf(py), z0 = (int)floorf(pz);
+            const float wx = px - (float)x0, wy = py - (float)y0, wz = pz - (float)z0;
+            const int dx[8] = {0, 1, 0, 0, 1, 0, 1, 1}, dy[8] = {0, 0, 1, 0, 1, 1, 0, 1}, dz[8] = {0, 0, 0, 1, 0, 1, 1, 1};
+            const float w8[8] = {(1.0f - wx) * (1.0f - wy) * (1.0f - wz), wx * (1.0f - wy) * (1.0f - wz), (1.0f - wx) * wy * (1.0f - wz), (1.0f - wx) * (1.0f - wy) * wz,
+                                 wx * wy * (1.0f - wz), (1.0f - wx) * wy * wz, wx * (1.0f - wy) * wz, wx * wy * wz};
+            float sum_w = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int id = lower_bound_u64(uniq, S, pack3(x0 + dx[i], y0 + dy[i], z0 + dz[i]));
+                const float w = id >= 0 ? w8[i] : 0.0f;
+                if (w == 0.0f) continue;
+                const double* v = sh + (size_t)id * 9;
+                if (sum_w == 0.0f) { for (int j = 0; j < 9; ++j) o[j] = (double)w * v[j]; }
+                else { for (int j = 0; j < 9; ++j) o[j] += (double)w * v[j]; }
+                sum_w += w;
+            }
+            if (sum_w != 0.0f) { const double sc = (double)(1.0f / sum_w); for (int j = 0; j < 9; ++j) o[j] = o[j] * sc; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) out[(size_t)j * N + s] = (float)o[j];
+}
+
+void launch_sh_keys(hipStream_t st, GridView g, ShParams sp, unsigned long long* keys, int* iota) { if (g.N > 0) k_sh_keys<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, keys, iota); }
+void launch_sh_all_keys(hipStream_t st, GridView g, ShParams sp, unsigned long long* keys) { if (g.N > 0) k_sh_all_keys<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, keys); }
+void launch_sh_assign(hipStream_t st, int M, const unsigned long long* sorted_keys, const unsigned long long* uniq, int S, int* sorted_sub) { if (M > 0) k_sh_assign<<<(M + 255) / 256, 256, 0, st>>>(M, sorted_keys, uniq, S, sorted_sub); }
+void launch_sh_gram(hipStream_t st, GridView g, int M, const int* sorted_vox, const int* sorted_sub, double* gram, double* wsum) {
+    if (M <= 0) return;
+    const int tiles = (M + 63) / 64;
+    int tiles_per_wave = 8;
+    const int waves = (tiles + tiles_per_wave - 1) / tiles_per_wave;
+    k_sh_gram<<<(waves + 3) / 4, 256, 0, st>>>(g, M, sorted_vox, sorted_sub, tiles_per_wave, gram, wsum);
+}
+void launch_sh_interpolate(hipStream_t st, GridView g, ShParams sp, const unsigned long long* uniq, int S, const double* sh, float* out) {
+    if (g.N > 0) k_sh_interpolate<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, uniq, S, sh, out);
+}
+
+}  // namespace i3d

@@ -123,3 +123,22 @@ def test_optimize_matches_oracle(setup):
     np.testing.assert_allclose(gp, poses, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(gd, dist, rtol=5e-3, atol=5e-4)   # k2,k3 are barely observable (r^4, r^6 with r < 0.5): ill-conditioned block
     ctx.close(); g2.free()
+
+
+def test_estimate_sh_matches_oracle(setup):
+    """LightingSVSH::estimate + computeVoxelShCoeffs: fp64 MFMA Gram blocks + host LM vs the oracle's Ceres-equivalent solve."""
+    O = setup["O"]; sc = setup["sc"]; thres = setup["thres"]
+    for size in (0.05, 0.035, 10.0):
+        rc, sh, idx, vsh, has, st = O.estimate_sh(setup["g"], size, 10.0, thres)
+        assert rc == 0
+        ctx = setup["ctx"]
+        gsh, gidx, gst = ctx.estimate_sh(size, 10.0, thres)
+        assert gst.subvolumes == st.subvolumes and gst.data_rows == st.data_rows and gst.reg_rows == st.reg_rows
+        assert gst.lm_iterations == st.lm_iterations
+        order = {tuple(k): i for i, k in enumerate(gidx.tolist())}
+        perm = np.array([order[tuple(k)] for k in idx.tolist()])
+        np.testing.assert_allclose(gsh[perm], sh, rtol=1e-4, atol=1e-7)
+        gv = ctx.get_voxel_sh()
+        m = has.astype(bool)
+        np.testing.assert_allclose(gv[m], vsh[m], rtol=1e-4, atol=1e-6)
+    ctx.set_voxel_sh(setup["vsh"])     # restore the state the other tests expect
