@@ -79,6 +79,14 @@ double  orc_shading_row(int32_t vx, int32_t vy, int32_t vz, const double* sh9, d
 void    orc_bicubic(const float* img, int32_t w, int32_t h, double r, double c, double* f, double* dfdr, double* dfdc);
 void    orc_pose_to_mat(const double* pose6, float* R9, float* t3);
 uint64_t orc_hash(int32_t x, int32_t y, int32_t z);
+/* Ceres-equivalent LM + CGNR on the dense linear least-squares problem min ||A x - b||^2 (A row-major m x n, column blocks given);
+ * returns the number of LM iterations; cg_iters[<=50] receives the PCG iteration count of every attempt */
+int32_t orc_test_lm_dense(int32_t m, int32_t n, int32_t nblocks, const int32_t* block_sizes, const double* A, const double* b, double* x_io,
+                          int32_t max_iterations, int32_t stop_after_first_success, int32_t cg_fixed_iterations, int32_t* cg_iters, double* costs2);
+/* one CGNR solve of (A^T A + diag(D)^2) x = A^T b with the block-Jacobi preconditioner; returns the iteration count */
+int32_t orc_test_cgnr(int32_t m, int32_t n, int32_t nblocks, const int32_t* block_sizes, const double* A, const double* b, const double* D,
+                      int32_t cg_fixed_iterations, double* x_out);
+int32_t orc_round_trunc(float v);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,9 @@ def lib():
         L.orc_bicubic.argtypes = [vp, i32, i32, f64, f64, vp, vp, vp]
         L.orc_pose_to_mat.argtypes = [vp, vp, vp]
         L.orc_hash.restype = C.c_uint64; L.orc_hash.argtypes = [i32, i32, i32]
+        L.orc_round_trunc.restype = i32; L.orc_round_trunc.argtypes = [f32]
+        L.orc_test_lm_dense.restype = i32; L.orc_test_lm_dense.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+        L.orc_test_cgnr.restype = i32; L.orc_test_cgnr.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp]
         _lib = L
     return _lib
 
@@ -242,3 +245,19 @@ def pose_to_mat(pose6):
     p = np.ascontiguousarray(pose6, np.float64); R = np.zeros(9, np.float32); t = np.zeros(3, np.float32)
     lib().orc_pose_to_mat(_p(p), _p(R), _p(t))
     return R.reshape(3, 3), t
+
+
+def test_lm_dense(A, b, block_sizes, x0=None, max_iterations=50, stop_first=False, cg_fixed=-1):
+    A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64); bs = np.ascontiguousarray(block_sizes, np.int32)
+    m, n = A.shape
+    x = np.zeros(n) if x0 is None else np.ascontiguousarray(x0, np.float64).copy()
+    cg = np.zeros(50, np.int32); costs = np.zeros(2)
+    it = lib().orc_test_lm_dense(m, n, len(bs), _p(bs), _p(A), _p(b), _p(x), int(max_iterations), 1 if stop_first else 0, int(cg_fixed), _p(cg), _p(costs))
+    return x, it, cg, costs
+
+
+def test_cgnr(A, b, D, block_sizes, cg_fixed=-1):
+    A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64); D = np.ascontiguousarray(D, np.float64)
+    bs = np.ascontiguousarray(block_sizes, np.int32); m, n = A.shape; x = np.zeros(n)
+    it = lib().orc_test_cgnr(m, n, len(bs), _p(bs), _p(A), _p(b), _p(D), int(cg_fixed), _p(x))
+    return x, it

@@ -209,5 +209,39 @@ void orc_pose_to_mat(const double* pose6, float* R9, float* t3) {
     double R[9], t[3]; pose_aa_to_mat(pose6, R, t); for (int i = 0; i < 9; ++i) R9[i] = (float)R[i]; for (int i = 0; i < 3; ++i) t3[i] = (float)t[i];
 }
 uint64_t orc_hash(int32_t x, int32_t y, int32_t z) { return (uint64_t)V3iHash()({x, y, z}); }
+int32_t orc_round_trunc(float v) { return round_trunc(v); }
+
+static void dense_to_crs(int m, int n, const double* A, CRS& J) {
+    J.rows = m; J.cols = n; J.ptr.assign(m + 1, 0); J.col.clear(); J.val.clear();
+    for (int r = 0; r < m; ++r) { for (int c = 0; c < n; ++c) { J.col.push_back(c); J.val.push_back(A[(size_t)r * n + c]); } J.ptr[r + 1] = (int)J.col.size(); }
+}
+int32_t orc_test_lm_dense(int32_t m, int32_t n, int32_t nblocks, const int32_t* bs, const double* A, const double* b, double* x_io,
+                          int32_t max_it, int32_t stop_first, int32_t cg_fixed, int32_t* cg_iters, double* costs2) {
+    CRS J; dense_to_crs(m, n, A, J);
+    const std::vector<double> Aval = J.val;
+    std::vector<int> bstart, bsize; int o = 0; for (int i = 0; i < nblocks; ++i) { bstart.push_back(o); bsize.push_back(bs[i]); o += bs[i]; }
+    EvalFn eval = [&](const double* x, double* cost, std::vector<double>* res, CRS* Jout) -> bool {
+        res->resize(m); double cs = 0.0;
+        for (int r = 0; r < m; ++r) { double s = -b[r]; for (int c = 0; c < n; ++c) s += A[(size_t)r * n + c] * x[c]; (*res)[r] = s; cs += 0.5 * s * s; }
+        if (Jout) Jout->val = Aval;
+        *cost = cs; return true; };
+    LMOptions lo; lo.max_num_iterations = max_it; lo.stop_after_first_successful_step = stop_first != 0; lo.cg_fixed_iterations = cg_fixed;
+    std::vector<double> x(x_io, x_io + n);
+    LMSummary s = lm_minimize(eval, J, bstart, bsize, x, lo);
+    for (int i = 0; i < n; ++i) x_io[i] = x[i];
+    if (cg_iters) for (size_t i = 0; i < s.cg_iterations.size() && i < 50; ++i) cg_iters[i] = s.cg_iterations[i];
+    if (costs2) { costs2[0] = s.initial_cost; costs2[1] = s.final_cost; }
+    return s.iterations;
+}
+int32_t orc_test_cgnr(int32_t m, int32_t n, int32_t nblocks, const int32_t* bs, const double* A, const double* b, const double* D,
+                      int32_t cg_fixed, double* x_out) {
+    CRS J; dense_to_crs(m, n, A, J);
+    BlockJacobi M; int o = 0, off = 0;
+    std::vector<int> col_block(n);
+    for (int i = 0; i < nblocks; ++i) { M.start.push_back(o); M.size.push_back(bs[i]); M.off.push_back(off); for (int k = 0; k < bs[i]; ++k) col_block[o + k] = i; o += bs[i]; off += bs[i] * bs[i]; }
+    M.inv.assign(off, 0.0); M.update(J, col_block, D);
+    LMOptions lo; lo.cg_fixed_iterations = cg_fixed;
+    return cgnr_solve(J, b, D, M, lo, x_out);
+}
 
 }  // extern "C"

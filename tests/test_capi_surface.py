@@ -1,0 +1,72 @@
+"""-m "not gpu": the C-ABI library loads and exports every symbol include/intrinsic3d_hip.h declares; host-side behaviour
+that needs no device (defaults, error reporting, loud failure without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from intrinsic3d_amd import binding
+    if not os.path.exists(binding.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return binding, binding.load()
+
+
+def test_every_declared_symbol_is_exported():
+    binding, L = _lib()
+    hdr = open(os.path.join(ROOT, "include", "intrinsic3d_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(i3d_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(binding.EXPORTS) == declared
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors must have the C struct sizes (checked against a tiny C program compiled with gcc)."""
+    import ctypes, subprocess, tempfile
+    binding, L = _lib()
+    src = '#include <stdio.h>\n#include "intrinsic3d_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(i3d_optimizer_config), sizeof(i3d_iteration_stats), sizeof(i3d_grid_view), sizeof(i3d_sh_stats));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
+    assert sizes == [ctypes.sizeof(binding.OptimizerConfig), ctypes.sizeof(binding.IterationStats), ctypes.sizeof(binding.GridView), ctypes.sizeof(binding.ShStats)]
+
+
+def test_defaults_are_the_reference_struct_defaults():
+    binding, L = _lib()
+    c = binding.default_config()
+    # optimizer.h:69-79 and intrinsic3d.h:72-80
+    assert (c.iterations, c.lm_steps) == (10, 50)
+    assert (c.lambda_g, c.lambda_r0, c.lambda_r1, c.lambda_s0, c.lambda_s1, c.lambda_a) == (0.2, 20.0, 160.0, 10.0, 120.0, 0.1)
+    assert (c.fix_poses, c.fix_intrinsics, c.fix_distortion) == (0, 0, 0)
+    assert abs(c.occlusion_distance - 0.02) < 1e-9 and c.num_observations == 5 and c.pcg_fixed_iterations == -1
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    binding, L = _lib()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(binding.I3DError) as e:
+        binding.Context(0)
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "intrinsic3d_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"oracle_py|liboracle|i3d_oracle\.h|from oracle|import oracle|oracle/", txt):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

@@ -142,3 +142,26 @@ def test_estimate_sh_matches_oracle(setup):
         m = has.astype(bool)
         np.testing.assert_allclose(gv[m], vsh[m], rtol=1e-4, atol=1e-6)
     ctx.set_voxel_sh(setup["vsh"])     # restore the state the other tests expect
+
+
+def test_gpu_matches_committed_golden(oracle):
+    """HIP path vs tests/golden/optimize_small.json (oracle outputs committed with their generating script)."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optimize_small.json")))
+    sc = helpers.small_scene(seed=11, radius_vox=12, K=4, width=128, height=96)
+    g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc, sh_size=0.04)
+    ctx = helpers.gpu_context(sc, arrays, vsh)
+    gsh, gidx, gst = ctx.estimate_sh(0.04, 10.0, thres)          # SH from the device path as well
+    ocfg = helpers.oracle_cfg(oracle, thres, iterations=2, cg_fixed_iterations=4)
+    stats = ctx.optimize(helpers.gpu_cfg(ocfg))
+    sdf, alb = ctx.get_grid(); intr, dist, poses = ctx.get_camera()
+    assert len(arrays["keys"]) == gold["num_voxels"]
+    assert [list(s.rows) for s in stats] == gold["rows"]
+    np.testing.assert_allclose([[s.cost_initial, s.cost_final] for s in stats], gold["cost"], rtol=1e-4)
+    np.testing.assert_allclose(sdf[:16], gold["sdf_refined_head"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(alb[:16], gold["albedo_head"], rtol=1e-4)
+    np.testing.assert_allclose(np.sum(sdf), gold["sdf_sum"], rtol=1e-4)
+    np.testing.assert_allclose(np.sum(alb), gold["albedo_sum"], rtol=1e-5)
+    np.testing.assert_allclose(intr, gold["intr"], rtol=1e-4)
+    np.testing.assert_allclose(poses, gold["poses"], rtol=1e-4, atol=1e-6)
+    ctx.close(); g.free(); fr.free()

@@ -1,0 +1,183 @@
+"""-m "not gpu": the CPU oracle against independent checks (finite differences, numpy/scipy dense algebra, known answers).
+
+The reference ships no tests or golden vectors, so the oracle is pinned against:
+  * known answers of the primitives that define voxel indexing (hash, truncating round),
+  * central finite differences of every Eg partial (the reference uses Ceres Jets),
+  * numpy dense solves of the damped normal equations for the Ceres-equivalent CGNR / LM,
+  * a weighted dense least-squares solve for the SH lighting problem,
+  * its own committed golden outputs (tests/golden), which also pin libstdc++'s unordered_map visit order.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_hash_and_round_known_answers(oracle):
+    L = oracle.lib()
+    p0, p1, p2 = 73856093, 19349669, 83492791
+    for x, y, z in [(0, 0, 0), (1, 2, 3), (-1, 0, 0), (-5, 7, -11), (100000, -100000, 12345)]:
+        exp = ((x * p0) & (2 ** 64 - 1)) ^ ((y * p1) & (2 ** 64 - 1)) ^ ((z * p2) & (2 ** 64 - 1))     # sign-extended int -> size_t (mat.h:122)
+        assert L.orc_hash(x, y, z) == exp
+    # mat.h:88-93: (v + 0.5) truncated toward zero, NOT floor
+    assert [L.orc_round_trunc(v) for v in (0.4, 0.5, 1.49, -0.4, -0.7, -1.4, -1.6)] == [0, 1, 1, 0, 0, 0, -1]
+
+
+def test_bicubic_interpolates_and_differentiates(oracle):
+    rng = np.random.default_rng(0)
+    img = rng.random((12, 17)).astype(np.float32)
+    for r, c in [(3, 4), (0, 0), (11, 16), (5, 9)]:
+        f, _, _ = oracle.bicubic(img, r, c)
+        assert abs(f - img[r, c]) < 1e-12                # Catmull-Rom interpolates the samples
+    for r, c in [(3.3, 4.7), (0.2, 0.9), (10.6, 15.5), (5.5, 8.25)]:
+        f, dr, dc = oracle.bicubic(img, r, c)
+        h = 1e-6
+        fr = (oracle.bicubic(img, r + h, c)[0] - oracle.bicubic(img, r - h, c)[0]) / (2 * h)
+        fc = (oracle.bicubic(img, r, c + h)[0] - oracle.bicubic(img, r, c - h)[0]) / (2 * h)
+        assert abs(dr - fr) < 1e-6 and abs(dc - fc) < 1e-6
+    # linear ramp is reproduced exactly in the interior (cubic Hermite with Catmull-Rom tangents)
+    ramp = (np.arange(17, dtype=np.float32)[None, :] * 0.5 + np.arange(12, dtype=np.float32)[:, None] * 0.25)
+    f, dr, dc = oracle.bicubic(ramp, 4.3, 7.6)
+    assert abs(f - (7.6 * 0.5 + 4.3 * 0.25)) < 1e-6 and abs(dr - 0.25) < 1e-6 and abs(dc - 0.5) < 1e-6
+
+
+def test_pose_to_matrix_is_rodrigues(oracle):
+    from intrinsic3d_amd import synthetic
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        p = np.concatenate([rng.normal(0, 1.0, 3), rng.normal(0, 1, 3)])
+        R, t = oracle.pose_to_mat(p)
+        np.testing.assert_allclose(R, synthetic.aa_to_rotmat(p[:3]), atol=2e-7)
+        np.testing.assert_allclose(t, p[3:].astype(np.float32))
+    R, _ = oracle.pose_to_mat(np.zeros(6))
+    np.testing.assert_array_equal(R, np.eye(3, dtype=np.float32))
+
+
+def _row_setup(seed=0):
+    rng = np.random.default_rng(seed)
+    h, w = 60, 80
+    yy, xx = np.mgrid[0:h, 0:w]
+    lum = (0.5 + 0.3 * np.sin(xx * 0.21) * np.cos(yy * 0.17) + 0.05 * rng.random((h, w))).astype(np.float32)
+    vs = 0.004
+    v = np.array([20, 18, 150])
+    # sdf slots: local plane-ish field with noise; albedo; pose looking down +z; intrinsics; small distortion
+    prm = np.zeros(29)
+    offs = [(0, 0, 0), (0, 1, 0), (0, 2, 0), (0, 1, 1), (0, 0, 1), (0, 0, 2), (1, 0, 0), (1, 1, 0), (1, 0, 1), (2, 0, 0)]
+    nrm = np.array([0.3, -0.2, 0.93]); nrm /= np.linalg.norm(nrm)
+    for i, o in enumerate(offs):
+        prm[i] = 0.0012 + vs * np.dot(nrm, o) + rng.normal(0, 1e-4)
+    prm[10:14] = 0.6 + rng.normal(0, 0.05, 4)
+    prm[14:17] = rng.normal(0, 0.05, 3); prm[17:20] = [-0.02, 0.01, 0.05]
+    prm[20:24] = [60.0, 61.0, 39.5, 29.5]
+    prm[24:29] = [0.05, -0.02, 0.01, 0.003, -0.002]
+    sh = np.array([0.8, 0.1, 0.3, -0.1, 0.05, 0.02, 0.04, -0.03, 0.02])
+    return v, sh, vs, lum, prm
+
+
+def test_shading_row_jacobian_vs_finite_differences(oracle):
+    """Every one of the 29 partials of an Eg row (dual numbers) against central differences of the double evaluation."""
+    v, sh, vs, lum, prm = _row_setup()
+    for pyr in (1.0, 0.5):
+        img = lum if pyr == 1.0 else lum[::2, ::2].copy()
+        r, J = oracle.shading_row(v, sh, pyr, vs, img, prm, jac=True)
+        assert r > 0
+        for i in range(29):
+            h = 1e-7 * max(1.0, abs(prm[i])) if i >= 14 else 1e-8
+            pp = prm.copy(); pp[i] += h; pm = prm.copy(); pm[i] -= h
+            fd = (oracle.shading_row(v, sh, pyr, vs, img, pp, jac=False)[0] - oracle.shading_row(v, sh, pyr, vs, img, pm, jac=False)[0]) / (2 * h)
+            assert abs(fd - J[i]) <= 2e-5 * max(1.0, abs(J[i])), (i, fd, J[i])
+
+
+def test_shading_row_invalid_cases(oracle):
+    v, sh, vs, lum, prm = _row_setup()
+    p = prm.copy(); p[19] = -0.5 - v[2] * vs          # behind / far off the image
+    p[17] = 10.0
+    r, J = oracle.shading_row(v, sh, 1.0, vs, lum, p, jac=True)
+    assert r == 0.0 and np.all(J == 0.0)              # NV_INVALID_RESIDUAL row: zero residual and zero Jacobian
+
+
+def test_cgnr_matches_dense_solve(oracle):
+    rng = np.random.default_rng(2)
+    m, n = 60, 14
+    A = rng.normal(0, 1, (m, n)); b = rng.normal(0, 1, m); D = np.abs(rng.normal(0.3, 0.1, n))
+    bs = [1, 1, 6, 1, 5]
+    x, it = oracle.test_cgnr(A, b, D, bs, cg_fixed=200)            # run to (numerical) convergence
+    ref = np.linalg.solve(A.T @ A + np.diag(D * D), A.T @ b)
+    np.testing.assert_allclose(x, ref, rtol=1e-8, atol=1e-10)
+    # Ceres' quadratic-model stop (eta = 0.1) truncates early but must already reduce the model
+    x2, it2 = oracle.test_cgnr(A, b, D, bs, cg_fixed=-1)
+    assert 1 <= it2 < 200
+    q = lambda z: z @ (A.T @ A + np.diag(D * D)) @ z - 2 * (A.T @ b) @ z
+    assert q(x2) < 0.0 and q(ref) <= q(x2) + 1e-12
+
+
+def test_lm_linear_problem_converges_to_least_squares(oracle):
+    rng = np.random.default_rng(3)
+    m, n = 80, 12
+    A = rng.normal(0, 1, (m, n)) * rng.uniform(0.1, 3.0, n)[None, :]; b = rng.normal(0, 1, m)
+    x, it, cg, costs = oracle.test_lm_dense(A, b, [3, 3, 6], max_iterations=50)
+    ref = np.linalg.lstsq(A, b, rcond=None)[0]
+    c_ref = 0.5 * np.sum((A @ ref - b) ** 2)
+    assert costs[1] <= c_ref * (1 + 1e-4)            # function_tolerance 1e-6 stops close to the optimum
+    np.testing.assert_allclose(x, ref, rtol=5e-2, atol=5e-3)
+    # first successful step only (the reference's callback): exactly one accepted step, cost decreased
+    x1, it1, cg1, costs1 = oracle.test_lm_dense(A, b, [3, 3, 6], max_iterations=50, stop_first=True)
+    assert costs1[1] < costs1[0] and it1 >= 1
+
+
+def test_sh_estimate_close_to_weighted_least_squares(oracle):
+    sc = helpers.small_scene(seed=5, radius_vox=14, K=3)
+    g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc, sh_size=10.0)       # one subvolume, no regulariser pairs
+    rc, sh, idx, vsh, has, st = oracle.estimate_sh(g, 10.0, 10.0, thres)
+    assert rc == 0 and sh.shape == (1, 9) and st.reg_rows == 0
+    # single subvolume + trilinear interpolation with only that subvolume present == its coefficients (up to fp32 weight rounding)
+    m = has.astype(bool)
+    np.testing.assert_allclose(vsh[m], np.broadcast_to(sh[0], vsh[m].shape), rtol=1e-6)
+    assert st.cost_final < st.cost_initial * 0.05
+    g.free(); fr.free()
+
+
+def test_upsample_and_thin_shell_invariants(oracle):
+    sc = helpers.small_scene(seed=2, radius_vox=10, K=2)
+    g = oracle.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+    n0 = len(g)
+    a0 = g.export()
+    up = g.upsample()
+    assert len(up) == 8 * n0 and abs(up.voxel_size - g.voxel_size * 0.5) < 1e-9
+    au = up.export()
+    # children at even coordinates sit exactly on a parent sample
+    par = {tuple(k): i for i, k in enumerate(a0["keys"].tolist())}
+    even = np.all(au["keys"] % 2 == 0, axis=1)
+    idx = np.array([par[tuple(k)] for k in (au["keys"][even] // 2).tolist()])
+    np.testing.assert_allclose(au["sdf_refined"][even], a0["sdf_refined"][idx].astype(np.float32), rtol=1e-6)
+    thres = 1.5 * up.voxel_size
+    up.clear_outside_shell(thres)
+    a2 = up.export()
+    keep = {tuple(k) for k in a2["keys"].tolist()}
+    ins = np.abs(au["sdf_refined"]) <= thres
+    valid = au["weight"] > 0
+    for k in au["keys"][ins & valid][::97].tolist():
+        assert tuple(k) in keep                       # every valid in-shell voxel survives (algorithms.cpp:376-383)
+    g.free(); up.free()
+
+
+def test_golden_oracle_outputs(oracle):
+    """The oracle's own outputs on a seeded scene, committed by tests/golden/make_golden.py (pins libstdc++ visit order too)."""
+    path = os.path.join(HERE, "golden", "optimize_small.json")
+    if not os.path.exists(path):
+        pytest.skip("golden file not generated")
+    gold = json.load(open(path))
+    import golden.make_golden as mg
+    cur = mg.compute(oracle)
+    assert cur["num_voxels"] == gold["num_voxels"]
+    assert cur["visit_order_crc"] == gold["visit_order_crc"]
+    assert cur["rows"] == gold["rows"]
+    np.testing.assert_allclose(cur["cost"], gold["cost"], rtol=1e-9)
+    np.testing.assert_allclose(cur["sdf_sum"], gold["sdf_sum"], rtol=1e-9)
+    np.testing.assert_allclose(cur["albedo_sum"], gold["albedo_sum"], rtol=1e-9)
+    np.testing.assert_allclose(cur["sh0"], gold["sh0"], rtol=1e-8)
