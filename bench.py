@@ -168,7 +168,7 @@ def main():
     A, Rg, Rr, Rs, Ra = sizes["active"], sizes["eg"], sizes["er"], sizes["es"], sizes["ea"]
     img_bytes = min(4.0 * args.frames * args.width * args.height, 256.0 * Rg)
     b_build = 68.0 * A + 132.0 * Rg + 36.0 * Rr + 12.0 * Rs + 16.0 * Ra + img_bytes
-    b_egpass = 124.0 * Rg + (14 + 8 + 2) * 4.0 * A          # J + weight/frame per row; staged sums, regulariser t-values, vector gather per voxel
+    b_egpass = 132.0 * Rg + (14 + 8 + 2) * 4.0 * A          # 29 partials + 16 B row record; staged sums, regulariser t-values, vector gather per voxel
     kernels = {}
     for name, bytes_per_launch in (("build", b_build), ("eg_pass", b_egpass)):
         ms, n = timing[name]

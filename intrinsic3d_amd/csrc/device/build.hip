@@ -168,9 +168,16 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     double cost = 0.0;
     if (a < r.A) {
-        const int N = g.N, Acap = r.Acap;
+        const int N = g.N; const size_t Acap = r.Acap;
         const int s = r.alist[a];
-        const uint8_t fl = g.flags[s];
+        const uint8_t fl = r.aflags[a];
+        if (!(fl & F_ACTIVE)) {                 // free-only entry: unknowns but no rows
+            if (WITH_J) {
+                r.regflags[a] = 0; r.ea_free[a] = 0; r.nrows[a] = 0;
+                for (int d = 0; d < 6; ++d) r.ea_w[(size_t)d * Acap + a] = 0.0f;
+                for (int k = 0; k < r.slots; ++k) r.rows[row_index(a, k, 7, r.slots)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        } else {
         int idx[P_VOX];
         bool eligible = true;
 #pragma unroll
@@ -230,12 +237,12 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
         }
 
         // ---- Eg rows ---------------------------------------------------------------------------------------
+        const int nin = WITH_J ? r.slots : (int)r.nrows[a];       // candidates: observation slots (assembly) or stored rows (cost)
         bool any_row = false;
         if (WITH_J) { for (int k = 0; k < r.slots; ++k) any_row |= r.obs_w[(size_t)k * Acap + a] > 0.0f; any_row &= eligible; }
-        else { for (int k = 0; k < r.slots; ++k) any_row |= r.roww[(size_t)k * Acap + a] != 0.0f; }
-        if (!any_row) {
-            if (WITH_J) for (int k = 0; k < r.slots; ++k) { r.roww[(size_t)k * Acap + a] = 0.0f; r.res[(size_t)k * Acap + a] = 0.0f; r.rowfree[(size_t)k * Acap + a] = 0; }
-        } else {
+        else any_row = nin > 0;
+        int nout = 0;
+        if (any_row) {
             real sd[10];
 #pragma unroll
             for (int c = 0; c < 10; ++c) sd[c] = g.x_sdf[idx[c]];
@@ -262,12 +269,12 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
             // slot of (s, sx, sy, sz) for each point
             constexpr int PS[4][4] = {{0, 6, 1, 4}, {6, 9, 7, 8}, {1, 7, 2, 3}, {4, 8, 3, 5}};
 
-            for (int k = 0; k < r.slots; ++k) {
+            for (int k = 0; k < nin; ++k) {
                 const size_t ka = (size_t)k * Acap + a;
                 float roww; int f;
                 if (WITH_J) { const float ow = r.obs_w[ka]; f = r.obs_frame[ka]; roww = (ow > 0.0f) ? (float)((double)ow * weight_sdf) : 0.0f; }
-                else { roww = r.roww[ka]; f = r.obs_frame[ka]; if (!r.rowfree[ka]) roww = 0.0f; }
-                if (roww == 0.0f) { if (WITH_J) { r.roww[ka] = 0.0f; r.res[ka] = 0.0f; r.rowfree[ka] = 0; } continue; }
+                else { const float4 m = r.rows[row_index(a, k, 7, r.slots)]; const int fb = __float_as_int(m.z); roww = (fb & ROW_FREE_BIT) ? m.x : 0.0f; f = fb & ~ROW_FREE_BIT; }
+                if (roww == 0.0f) continue;
                 const FrameConst& fc = frames[f];
                 PointFrame pf[4];
                 bool ok = true;
@@ -282,7 +289,7 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
                     else { const real ir = 1.0 / res; c1 = d1 * ir; c2 = d2 * ir; c3 = d3 * ir; }
                 }
                 if (!WITH_J) { if (ok) cost += 0.5 * (double)roww * p.type_w[0] * res * res; continue; }
-                if (!ok) { r.roww[ka] = 0.0f; r.res[ka] = 0.0f; r.rowfree[ka] = 0; continue; }   // dropped at creation (shading_cost.cpp:136-145)
+                if (!ok) continue;                                                 // dropped at creation (shading_cost.cpp:136-145)
                 const real cj[4] = {-(c1 + c2 + c3), c1, c2, c3};
                 real J[P_TOTAL];
 #pragma unroll
@@ -306,11 +313,19 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
                 bool fin = true;
 #pragma unroll
                 for (int i = 0; i < P_TOTAL; ++i) fin = fin && !(isnan(J[i]) || isinf(J[i]));
-                if (!fin) { r.roww[ka] = 0.0f; r.res[ka] = 0.0f; r.rowfree[ka] = 0; continue; }
-                r.roww[ka] = roww; r.res[ka] = (float)res; r.rowfree[ka] = vox_free ? 1 : 0;
+                if (!fin) continue;
+                // rows of a voxel are compacted into its first slots (creation order = ascending observation weight)
 #pragma unroll
-                for (int i = 0; i < P_TOTAL; ++i) r.J[((size_t)i * r.slots + k) * Acap + a] = (float)J[i];
+                for (int gq = 0; gq < 7; ++gq)
+                    r.rows[row_index(a, nout, gq, r.slots)] = make_float4((float)J[4 * gq], (float)J[4 * gq + 1], (float)J[4 * gq + 2], (float)J[4 * gq + 3]);
+                r.rows[row_index(a, nout, 7, r.slots)] = make_float4(roww, (float)res, __int_as_float(f | (vox_free ? ROW_FREE_BIT : 0)), (float)J[28]);
+                ++nout;
             }
+        }
+        if (WITH_J) {
+            r.nrows[a] = (uint8_t)nout;
+            for (int k = nout; k < r.slots; ++k) r.rows[row_index(a, k, 7, r.slots)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
         }
     }
     if (!WITH_J) block_add(cost, cost_out);
@@ -326,19 +341,21 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
 // nls_solver.cpp:379-394 — per-type sums of the row weights (sums[0..3]) and row counts (sums[4..7])
 __global__ void __launch_bounds__(256) k_weight_sums(RowView r, double* sums) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, n0 = 0, n3 = 0;
-    if (a < r.A) {
-        for (int k = 0; k < r.slots; ++k) { const float w = r.roww[(size_t)k * r.Acap + a]; s0 += (double)w; if (w != 0.0f) n0 += 1.0; }
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, n0 = 0, n3 = 0, na = 0;
+    if (a < r.A && (r.aflags[a] & F_ACTIVE)) {
+        na = 1.0;
+        const int nr = r.nrows[a];
+        for (int k = 0; k < nr; ++k) { const float w = r.rows[row_index(a, k, 7, r.slots)].x; s0 += (double)w; if (w != 0.0f) n0 += 1.0; }
         const uint8_t rf = r.regflags[a];
         if (rf & 1) s1 = 1.0;
         if (rf & 2) s2 = 1.0;
         for (int d = 0; d < 6; ++d) { const float w = r.ea_w[(size_t)d * r.Acap + a]; s3 += (double)w; if (w != 0.0f) n3 += 1.0; }
     }
     block_add(s0, sums + 0); block_add(s1, sums + 1); block_add(s2, sums + 2); block_add(s3, sums + 3);
-    block_add(n0, sums + 4); block_add(n3, sums + 7);
+    block_add(n0, sums + 4); block_add(n3, sums + 7); block_add(na, sums + 8);
 }
-void launch_weight_sums(hipStream_t st, RowView r, double* sums8) {
-    if (r.A > 0) k_weight_sums<<<(r.A + 255) / 256, 256, 0, st>>>(r, sums8);
+void launch_weight_sums(hipStream_t st, RowView r, double* sums9) {
+    if (r.A > 0) k_weight_sums<<<(r.A + 255) / 256, 256, 0, st>>>(r, sums9);
 }
 
 }  // namespace i3d

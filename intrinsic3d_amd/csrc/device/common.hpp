@@ -35,7 +35,10 @@ __host__ __device__ inline int slot_rev_nbr(int c) {
 // ---- per-voxel flag bits (recomputed every outer iteration: the shell test reads sdf_refined, optimizer.cpp:187)
 enum : uint8_t { F_VALID = 1, F_ACTIVE = 2, F_RING = 4, F_FREE_SDF = 8, F_FREE_ALB = 16 };
 
-constexpr int MAX_SLOTS = 8;       // Eg rows kept per voxel (reference default num_observations = 5)
+constexpr int MAX_SLOTS = 8;
+constexpr int ROW_PLANES = 8;
+constexpr int ROW_FREE_BIT = 1 << 30;     // set in plane 7 .z when the row has at least one free column
+__host__ __device__ inline size_t row_index(size_t a, int k, int plane, int slots) { return ((((a >> 6) * (size_t)slots + (size_t)k) * ROW_PLANES + (size_t)plane) << 6) + (a & 63); }       // Eg rows kept per voxel (reference default num_observations = 5)
 
 // ---- per-keyframe constants, rebuilt on the host (fp64) once per outer iteration ----------------------------
 struct FrameConst {
@@ -62,16 +65,32 @@ struct GridView {
     int* aidx;                      // device index -> active index or -1
 };
 
-struct RowView {                    // per active voxel a in [0, A); SoA planes of length Acap
+struct RowView {                    // per work-list entry a in [0, A): voxels that are active (own rows) or free (own unknowns)
     int A; int Acap; int slots;
-    const int* alist;               // active index -> device voxel index
-    int* obs_frame; float* obs_w;   // [slots][Acap]
-    float* res; float* roww;        // [slots][Acap]   raw residual; row weight (obs.w * weight_sdf), 0 = no row
-    float* J;                       // [29][slots][Acap] raw partials
-    uint8_t* rowfree;               // [slots][Acap] 1 if the row has at least one free parameter
+    const int* alist;               // list index -> device voxel index (ascending)
+    const uint8_t* aflags;          // voxel flags of the entry
+    const int* anbr;                // [NUM_NBR][Acap] neighbour table in LIST space (-1 = neighbour not in the list => fixed, contributes 0)
+    int* obs_frame; float* obs_w;   // [slots][Acap] observation pass output (ascending weight, 0 = none)
+    // Eg rows of an entry are compacted into its first nrows slots.  A row is 8 float4 = 128 B; rows are stored wave-tiled
+    // (AoSoA): [tile = a/64][slot][plane 0..7][lane = a%64], i.e. one wave reads ONE contiguous 8 KB block per slot.
+    //   planes 0..6: raw partials, columns 0..27 (sdf 0-9, albedo 10-13, pose 14-19, intrinsics 20-23, distortion 24-27)
+    //   plane 7    : x = row weight obs.w*weight_sdf (0 = no row), y = raw residual, z = keyframe | ROW_FREE_BIT (int bits), w = column 28 (p2)
+    float4* rows;
+    uint8_t* nrows;                 // [Acap]
     uint8_t* regflags;              // [Acap] bit0 Er row, bit1 Es row, bit2 Es Jacobian is 1 (else 0), bit3 Er row has a free column, bit4 Es free
     float* ea_w;                    // [6][Acap] chroma weight of the Ea row towards 1-ring neighbour d, 0 = none
     uint8_t* ea_free;               // [Acap] bit d: Ea row d has a free column
+};
+
+// device-resident scalar state of one PCG solve (ConjugateGradientsSolver) — no host round trip inside an iteration
+struct PcgState {
+    double rho, last_rho, pq, alpha, beta;
+    double xbr, xr, d2xx;           // x.(b+r), x.r, sum D^2 x^2 at the last completed iteration
+    double Q0, Q1;
+    int it;                         // completed iterations
+    int done;                       // 0 running, 1 converged (Q-test / fixed count / max), 2 breakdown before the update of this iteration
+    int fixed_iterations;           // >= 0: stop exactly there
+    int max_iterations;
 };
 
 struct OptParams {                  // scalar state of one outer iteration

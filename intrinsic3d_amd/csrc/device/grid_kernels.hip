@@ -124,19 +124,32 @@ __global__ void k_classify(GridView g, OptParams p, int* __restrict__ active_fla
     const bool free_sdf = valid && inshell && ring;
     const bool free_alb = free_sdf && !(p.lambda_a < 0.0);
     g.flags[s] = (valid ? F_VALID : 0) | (active ? F_ACTIVE : 0) | (ring ? F_RING : 0) | (free_sdf ? F_FREE_SDF : 0) | (free_alb ? F_FREE_ALB : 0);
-    active_flag[s] = active ? 1 : 0;
+    active_flag[s] = (active || free_sdf || free_alb) ? 1 : 0;      // work list = voxels that own rows or unknowns
 }
 void launch_classify(hipStream_t st, GridView g, OptParams p, int* active_flag) {
     if (g.N > 0) k_classify<<<(g.N + 255) / 256, 256, 0, st>>>(g, p, active_flag);
 }
 
-__global__ void k_compact(int N, const int* __restrict__ flag, const int* __restrict__ scan, int* __restrict__ aidx, int* __restrict__ alist) {
+__global__ void k_compact(int N, const int* __restrict__ flag, const int* __restrict__ scan, const uint8_t* __restrict__ flags,
+                          int* __restrict__ aidx, int* __restrict__ alist, uint8_t* __restrict__ aflags) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
-    if (flag[s]) { aidx[s] = scan[s]; alist[scan[s]] = s; } else aidx[s] = -1;
+    if (flag[s]) { const int a = scan[s]; aidx[s] = a; alist[a] = s; aflags[a] = flags[s]; } else aidx[s] = -1;
 }
-void launch_compact(hipStream_t st, int N, const int* flag, const int* scan, int* aidx, int* alist) {
-    if (N > 0) k_compact<<<(N + 255) / 256, 256, 0, st>>>(N, flag, scan, aidx, alist);
+void launch_compact(hipStream_t st, int N, const int* flag, const int* scan, const uint8_t* flags, int* aidx, int* alist, uint8_t* aflags) {
+    if (N > 0) k_compact<<<(N + 255) / 256, 256, 0, st>>>(N, flag, scan, flags, aidx, alist, aflags);
+}
+
+// neighbour table of the work list in LIST space: the solver's vectors live there (2A + 6K + 9 entries instead of 2N + ...)
+__global__ void k_anbr(int N, int A, int Acap, const int* __restrict__ alist, const int* __restrict__ nbr, const int* __restrict__ aidx, int* __restrict__ anbr) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    const int s = alist[a];
+#pragma unroll
+    for (int i = 0; i < NUM_NBR; ++i) { const int nb = nbr[(size_t)i * N + s]; anbr[(size_t)i * Acap + a] = nb >= 0 ? aidx[nb] : -1; }
+}
+void launch_anbr(hipStream_t st, int N, int A, int Acap, const int* alist, const int* nbr, const int* aidx, int* anbr) {
+    if (A > 0) k_anbr<<<(A + 255) / 256, 256, 0, st>>>(N, A, Acap, alist, nbr, aidx, anbr);
 }
 
 __global__ void k_scatter_sh(int N, const int* __restrict__ rank, const double* __restrict__ shv, float* __restrict__ sh) {

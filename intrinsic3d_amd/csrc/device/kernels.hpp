@@ -14,7 +14,8 @@ void launch_permute_grid(hipStream_t st, int N, const int* perm, const int* keys
 void launch_hash_build(hipStream_t st, int N, const int* cx, const int* cy, const int* cz, HashTable t);
 void launch_nbr_build(hipStream_t st, int N, const int* cx, const int* cy, const int* cz, HashTable t, int* nbr);
 void launch_classify(hipStream_t st, GridView g, OptParams p, int* active_flag);
-void launch_compact(hipStream_t st, int N, const int* active_flag, const int* active_scan, int* aidx, int* alist);
+void launch_compact(hipStream_t st, int N, const int* active_flag, const int* active_scan, const uint8_t* flags, int* aidx, int* alist, uint8_t* aflags);
+void launch_anbr(hipStream_t st, int N, int A, int Acap, const int* alist, const int* nbr, const int* aidx, int* anbr);
 void launch_scatter_sh(hipStream_t st, int N, const int* rank, const double* sh_visit /*[N][9]*/, float* sh /*[9][N]*/);
 void launch_gather_visit(hipStream_t st, int N, const int* rank, const double* x_sdf, const double* x_alb, double* out_sdf, double* out_alb);
 void launch_update_fields(hipStream_t st, int N, const int* rank, const double* sdf_ref, const double* alb, const uint8_t* rgb,
@@ -27,9 +28,10 @@ void launch_observe(hipStream_t st, GridView g, RowView r, OptParams p, const Fr
 // with_jacobian: fills res/J/roww/rowfree + regulariser flags (assembly).  Otherwise evaluates the cost of the rows
 // already assembled at the state (g.x_sdf, g.x_alb, frames, p) into cost_out (double, accumulated).
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out);
-void launch_weight_sums(hipStream_t st, RowView r, double* sums8 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]) */);
+void launch_weight_sums(hipStream_t st, RowView r, double* sums9 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels */);
 
 // ---- operator.hip -----------------------------------------------------------------------------------------
+// All vectors are in work-list space: NP = 2A + 6K + 9.
 enum PassMode { PASS_GRAD = 0, PASS_JTJP = 1, PASS_COLNORM = 2 };
 struct PassBuffers {
     float* C;            // [14][Acap] per-voxel-row-block column sums
@@ -37,26 +39,31 @@ struct PassBuffers {
     double* shared;      // [6K+9] pose/intr/dist accumulators (zeroed by the caller)
     double* blocks;      // COLNORM only: [21K + 10 + 15] upper triangles of the pose/intr/dist J^T W J blocks
 };
-void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u /*[NP] or null*/, PassBuffers b);
-void launch_gather(hipStream_t st, PassMode mode, GridView g, RowView r, PassBuffers b, float* out /*[2N]*/);
-void launch_shared_finalize(hipStream_t st, int K, OptParams p, const double* shared, float* out_shared /*[6K+9]*/);
+void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u /*[NP] or null*/, PassBuffers b, const PcgState* state);
+void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out /*[2A]*/);
+void launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_out, const PcgState* state);
+void launch_shared_finalize(hipStream_t st, int A, int K, OptParams p, const double* shared, float* out /*[NP]*/, bool tail, const float* S, const float* D2,
+                            const float* v, double* dot_out, const PcgState* state);
 
-// vector helpers (NP = 2N + 6K + 9)
 void launch_fill(hipStream_t st, int n, float* x, float v);
 void launch_fill_d(hipStream_t st, int n, double* x, double v);
 void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* out);                 // out = a*b
 void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* freemask, float* S);          // S = free ? 1/(1+sqrt(c)) : 0
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float inv_radius, float* D2, float* Minv_diag);  // D2 = clamp(c S^2)/radius, Minv = 1/(c S^2 + D2) (free) else 0
-void launch_apply_op_tail(hipStream_t st, int n, const float* S, const float* acc, const float* D2, const float* p, float* q);  // q = S*acc + D2*p
-void launch_axpy(hipStream_t st, int n, float a, const float* x, float* y);                          // y += a x
-void launch_xpay(hipStream_t st, int n, const float* x, float a, float* y);                          // y = x + a y
-void launch_sub(hipStream_t st, int n, const float* a, const float* b, float* out);                  // out = a - b
 void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out /* accumulated */);
-void launch_dot3(hipStream_t st, int n, const float* x, const float* b, const float* r, const float* D2, double* out3);  // x.(b+r), x.r, sum D2 x^2 (accumulated)
-void launch_precond_shared(hipStream_t st, int K, const float* Minv_blocks /*[K*36 + 16 + 25]*/, const float* r_shared, float* z_shared);
-void launch_freemask(hipStream_t st, GridView g, OptParams p, float* mask /*[NP]*/);
-void launch_candidate(hipStream_t st, GridView g, int K, float sign, const float* step, const float* S, const double* x_shared, double* xc_sdf, double* xc_alb,
+void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask /*[NP]*/);
+
+// fused PCG iteration, scalars resident in PcgState
+void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations);
+void launch_pcg_precond(hipStream_t st, int A, int K, const float* Minv, const float* Minv_blocks, const float* r, float* z, PcgState* state);   // z = M^-1 r, rho, beta
+void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state);                  // p = z + beta p, u = S p
+void launch_pcg_scalar2(hipStream_t st, PcgState* state);                                                                                       // alpha = rho / pq
+void launch_pcg_update(hipStream_t st, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, int reset_phase, PcgState* state);
+void launch_pcg_reset_r(hipStream_t st, int n, const float* x, const float* tmp, float* r, const float* b, const float* D2, PcgState* state);
+void launch_pcg_scalar3(hipStream_t st, PcgState* state);                                                                                       // Q-test, bookkeeping
+
+void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* x_shared, double* xc_sdf, double* xc_alb,
                       double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask);
-void launch_accept(hipStream_t st, GridView g, const double* xc_sdf, const double* xc_alb);           // x <- candidate, refresh fp32 shadows
+void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb);           // x <- candidate, refresh fp32 shadows
 
 }  // namespace i3d

@@ -18,6 +18,11 @@ __global__ void __launch_bounds__(256) k_observe(GridView g, RowView r, OptParam
     if (a >= r.A) return;
     const int N = g.N;
     const int s = r.alist[a];
+    if (!(r.aflags[a] & F_ACTIVE)) {          // free-only entry of the work list: owns unknowns but no rows
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) { r.obs_frame[(size_t)i * r.Acap + a] = -1; r.obs_w[(size_t)i * r.Acap + a] = 0.0f; }
+        return;
+    }
     // surface normal exactly as operators.cpp:58-77
     const float s0 = g.f_sdf[s];
     float nx = g.f_sdf[g.nbr[(size_t)NB_PX * N + s]] - s0;

@@ -1,250 +1,341 @@
-// K5/K6 — matrix-free normal-equation operator of the Gauss-Newton / LM step:  y = J^T W J x,  g = J^T W r,
-// diag(J^T W J) and the dense pose / intrinsics / distortion blocks of the block-Jacobi preconditioner.
+// K5/K6 — matrix-free normal-equation operator of the Gauss-Newton / LM step and the fused PCG iteration.
 //
-// Replaces Ceres' BlockSparseMatrix Jacobian + CgnrLinearOperator + BlockJacobiPreconditioner [Ceres 2.1.0, not in
-// /root/reference; selected at nls_solver.cpp:307] for this problem's FIXED row structure:
-//   * Eg rows are stored (29 fp32 partials, [29][slots][A] planes, one coalesced stream per column);
-//   * Er / Es / Ea rows have constant coefficients (volumetric_regularizer.h:59-72, surface_stab_regularizer.h:59-66,
-//     albedo_regularizer.h:59-66) and are never stored — their action is recomputed from per-voxel flags;
-//   * column indices are implicit: a row's voxel columns are the centre voxel's neighbour-table entries.
+// Replaces Ceres' BlockSparseMatrix Jacobian + CgnrLinearOperator + BlockJacobiPreconditioner + ConjugateGradientsSolver
+// [Ceres 2.1.0, not in /root/reference; selected at nls_solver.cpp:307] for this problem's FIXED row structure:
+//   * Eg rows are stored: 29 fp32 partials as 7 float4 planes + 1 float plane per slot ([slot][plane][entry]) so a wave reads
+//     1 KB per load instruction; Er / Es / Ea rows have constant coefficients (volumetric_regularizer.h:59-72,
+//     surface_stab_regularizer.h:59-66, albedo_regularizer.h:59-66) and are never stored;
+//   * column indices are implicit: a row's voxel columns are the centre voxel's neighbour-table entries;
+//   * all solver vectors live in WORK-LIST space (entries = voxels that own rows or unknowns): [sdf A | albedo A | poses 6K |
+//     intrinsics 4 | distortion 5]; a neighbour outside the list is a fixed parameter and contributes 0.
 //
-// J^T is a GATHER, not a scatter: pass 1 (k_eg_pass, one lane per active voxel) reads the voxel's <= slots rows ONCE,
-// forms t = W (J x) per row and immediately the 14 per-voxel column sums  C[c] = sum_k J[c][k] t_k  (all rows of a voxel
-// share the same 14 voxel columns), which go to a staging plane; pass 2 (k_gather, one lane per voxel) pulls the 10+4
-// staged sums of the voxels whose stencil contains it, plus the regulariser terms.  No fp32 atomics on voxel unknowns,
-// deterministic.  Only the 6K+9 shared camera unknowns are reduced with LDS atomics -> one fp64 atomic per block/entry.
+// J^T is a GATHER, not a scatter: pass 1 (k_eg_pass, one lane per entry) reads the entry's rows ONCE, forms t = W (J u) per
+// row and immediately the 14 per-voxel column sums C[c] = sum_k J[c][k] t_k (all rows of a voxel share the same 14 voxel
+// columns) into a staging plane; pass 2 (k_gather) pulls the 10+4 staged sums of the entries whose stencil contains it plus
+// the regulariser terms, applies the Jacobi scaling / LM diagonal and accumulates p.q.  No fp32 atomics on voxel unknowns.
+// The 6K+9 camera columns are reduced through LDS atomics (poses) / wave shuffles (intrinsics, distortion) -> one fp64
+// atomic per block and entry.
+//
+// The PCG scalars (rho, p.q, alpha, beta, Q) never leave the device inside a solve: 1-thread kernels turn the fp64 partial
+// sums into alpha/beta/termination flags, every vector kernel starts with `if (state->done) return`, and the host only polls
+// the state one iteration behind (no pipeline bubble).
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace i3d {
 
-template <int MODE>
-__global__ void __launch_bounds__(256) k_eg_pass(GridView g, RowView r, OptParams p, const float* __restrict__ u, PassBuffers b, int lds_floats) {
-    extern __shared__ float lds[];        // [6K+9] (+ [21K+25] in COLNORM)
-    for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) lds[i] = 0.0f;
+#define GRID_STRIDE(n) const int stride = gridDim.x * blockDim.x; for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += stride)
+static inline int vblocks(int n) { int b = (n + 255) / 256; return b < 1 ? 1 : (b > 2048 ? 2048 : b); }
+
+static __device__ inline void block_add_d(double v, double* dst) {
+    __shared__ double sm[4];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = g.N, Acap = r.Acap, K = p.K;
+    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i]; if (t != 0.0) atomicAdd(dst, t); }
+    __syncthreads();
+}
+
+// ---- pass 1 ---------------------------------------------------------------------------------------------------------
+// Persistent 1024-thread workgroups (one per CU, 16 waves): each walks a contiguous chunk of 1024-entry tiles.  The pose
+// columns are accumulated with LDS atomics; lanes of a wave mostly see the same few keyframes, so same-address atomics are
+// spread over `reps` replicas of the [6K] accumulator (lane % reps) — with 1 workgroup per CU the replicas can take most of the
+// 160 KB LDS (reps = 32 at K = 200: <= 2-way conflicts instead of 64-way).  LDS is zeroed / flushed once per workgroup.
+constexpr int EG_THREADS = 1024;
+
+template <int MODE>
+__global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, OptParams p, const float* __restrict__ u, PassBuffers b,
+                                                        int reps, int tiles_per_block, const PcgState* __restrict__ state) {
+    if (state && state->done) return;
+    extern __shared__ float lds[];        // GRAD/JTJP: [reps][6K] pose accumulators + [9] + JTJP: staged camera part of u [6K+9]; COLNORM: [6K+9] + [21K+25]
+    const int A = r.A, K = p.K; const size_t Acap = r.Acap;
     const int nshared = 6 * K + 9;
+    const int nacc = (MODE == PASS_COLNORM) ? (nshared + 21 * K + 25) : (reps * 6 * K + 9);
+    for (int i = threadIdx.x; i < nacc; i += EG_THREADS) lds[i] = 0.0f;
+    float* upose = lds + nacc;            // JTJP: the 6K+9 camera entries of u (every row reads 6+9 of them)
+    if (MODE == PASS_JTJP) for (int i = threadIdx.x; i < nshared; i += EG_THREADS) upose[i] = u[2 * (size_t)A + i];
+    __syncthreads();
+    float* const cam_acc = lds + ((MODE == PASS_COLNORM) ? 6 * K : reps * 6 * K);
+    float* const pose_acc = lds + ((MODE == PASS_COLNORM) ? 0 : (threadIdx.x & (reps - 1)) * (6 * K));
     float cam9[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
-    if (a < r.A) {
-        const int s = r.alist[a];
-        int idx[P_VOX];
-#pragma unroll
-        for (int c = 0; c < 10; ++c) { const int nb = slot_fwd_nbr(c); idx[c] = nb < 0 ? s : g.nbr[(size_t)nb * N + s]; }
-        idx[10] = idx[0]; idx[11] = idx[6]; idx[12] = idx[1]; idx[13] = idx[4];
-        int ring[6];
-#pragma unroll
-        for (int d = 0; d < 6; ++d) ring[d] = g.nbr[(size_t)d * N + s];
+    const float tw0 = (float)p.type_w[0];
+    const int ntiles = (A + EG_THREADS - 1) / EG_THREADS;
+    const int tile0 = blockIdx.x * tiles_per_block;
 
-        float uv[P_VOX];
+    for (int tile = tile0; tile < tile0 + tiles_per_block && tile < ntiles; ++tile) {
+        const int a = tile * EG_THREADS + threadIdx.x;
+        const bool in = a < A;
+        const uint8_t fl = in ? r.aflags[a] : 0;
+        const int nr = (in && (fl & F_ACTIVE)) ? (int)r.nrows[a] : 0;
+        // wave-uniform row count so that the row loads are unconditional and batched
+        int nr_max = nr;
+        for (int o = 32; o > 0; o >>= 1) nr_max = max(nr_max, __shfl_xor(nr_max, o, 64));
+
         float acc[P_VOX];
 #pragma unroll
         for (int c = 0; c < P_VOX; ++c) acc[c] = 0.0f;
+        float uv[P_VOX];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
-        bool loaded = false;
-        for (int k = 0; k < r.slots; ++k) {
-            const size_t ka = (size_t)k * Acap + a;
-            const float w = r.roww[ka];
-            if (w == 0.0f) continue;
-            const float rho = w * (float)p.type_w[0];
-            const int f = r.obs_frame[ka];
-            float J[P_TOTAL];
+        for (int c = 0; c < P_VOX; ++c) uv[c] = 0.0f;
+        if (MODE == PASS_JTJP && nr > 0) {
 #pragma unroll
-            for (int i = 0; i < P_TOTAL; ++i) J[i] = r.J[((size_t)i * r.slots + k) * Acap + a];
-            if (MODE == PASS_COLNORM) {
+            for (int c = 0; c < P_VOX; ++c) {
+                const int nb = slot_fwd_nbr(c);
+                const int la = nb < 0 ? a : r.anbr[(size_t)nb * Acap + a];
+                uv[c] = la >= 0 ? u[(c < 10 ? 0 : A) + la] : 0.0f;
+            }
+        }
+        const size_t ac = in ? (size_t)a : 0;
+        for (int k = 0; k < nr_max; ++k) {
+            const float4* __restrict__ row = r.rows + row_index(ac, k, 0, r.slots);     // 8 planes, 64 float4 apart: one contiguous 8 KB block per wave
+            float4 j4[7];
 #pragma unroll
-                for (int c = 0; c < P_VOX; ++c) acc[c] += rho * J[c] * J[c];
-                float* bl = lds + nshared;
-                int o = 0;
+            for (int q = 0; q < 7; ++q) j4[q] = row[q * 64];
+            const float4 m = row[7 * 64];
+            if (k < nr && m.x != 0.0f) {
+                const float rho = m.x * tw0;
+                const int f = __float_as_int(m.z) & ~ROW_FREE_BIT;
+                float J[P_TOTAL];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    atomicAdd(&lds[6 * f + i], rho * J[P_POSE + i] * J[P_POSE + i]);
+                for (int q = 0; q < 7; ++q) { J[4 * q] = j4[q].x; J[4 * q + 1] = j4[q].y; J[4 * q + 2] = j4[q].z; J[4 * q + 3] = j4[q].w; }
+                J[28] = m.w;
+                if (MODE == PASS_COLNORM) {
 #pragma unroll
-                    for (int j = i; j < 6; ++j) { atomicAdd(&bl[21 * f + o], rho * J[P_POSE + i] * J[P_POSE + j]); ++o; }
-                }
-                o = 0;
+                    for (int c = 0; c < P_VOX; ++c) acc[c] += rho * J[c] * J[c];
+                    float* bl = lds + nshared;
+                    int o = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    atomicAdd(&lds[6 * K + i], rho * J[P_INTR + i] * J[P_INTR + i]);
+                    for (int i = 0; i < 6; ++i) {
+                        atomicAdd(&lds[6 * f + i], rho * J[P_POSE + i] * J[P_POSE + i]);
 #pragma unroll
-                    for (int j = i; j < 4; ++j) { atomicAdd(&bl[21 * K + o], rho * J[P_INTR + i] * J[P_INTR + j]); ++o; }
-                }
-                o = 0;
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    atomicAdd(&lds[6 * K + 4 + i], rho * J[P_DIST + i] * J[P_DIST + i]);
-#pragma unroll
-                    for (int j = i; j < 5; ++j) { atomicAdd(&bl[21 * K + 10 + o], rho * J[P_DIST + i] * J[P_DIST + j]); ++o; }
-                }
-            } else {
-                float t;
-                if (MODE == PASS_GRAD) t = rho * r.res[ka];
-                else {
-                    if (!loaded) {
-#pragma unroll
-                        for (int c = 0; c < 10; ++c) uv[c] = idx[c] >= 0 ? u[idx[c]] : 0.0f;
-#pragma unroll
-                        for (int c = 10; c < P_VOX; ++c) uv[c] = idx[c] >= 0 ? u[N + idx[c]] : 0.0f;
-                        loaded = true;
+                        for (int j = i; j < 6; ++j) { atomicAdd(&bl[21 * f + o], rho * J[P_POSE + i] * J[P_POSE + j]); ++o; }
                     }
-                    float d = 0.0f;
+                    o = 0;
 #pragma unroll
-                    for (int c = 0; c < P_VOX; ++c) d += J[c] * uv[c];
-                    const float* up = u + 2 * (size_t)N + 6 * f;
+                    for (int i = 0; i < 4; ++i) {
+                        atomicAdd(&lds[6 * K + i], rho * J[P_INTR + i] * J[P_INTR + i]);
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) d += J[P_POSE + i] * up[i];
-                    const float* ui = u + 2 * (size_t)N + 6 * K;
+                        for (int j = i; j < 4; ++j) { atomicAdd(&bl[21 * K + o], rho * J[P_INTR + i] * J[P_INTR + j]); ++o; }
+                    }
+                    o = 0;
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) d += J[P_INTR + i] * ui[i];
-                    t = rho * d;
+                    for (int i = 0; i < 5; ++i) {
+                        atomicAdd(&lds[6 * K + 4 + i], rho * J[P_DIST + i] * J[P_DIST + i]);
+#pragma unroll
+                        for (int j = i; j < 5; ++j) { atomicAdd(&bl[21 * K + 10 + o], rho * J[P_DIST + i] * J[P_DIST + j]); ++o; }
+                    }
+                } else {
+                    float t;
+                    if (MODE == PASS_GRAD) t = rho * m.y;
+                    else {
+                        float d = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < P_VOX; ++c) d += J[c] * uv[c];
+                        const float* up = upose + 6 * f;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) d += J[P_POSE + i] * up[i];
+                        const float* ui = upose + 6 * K;
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) d += J[P_INTR + i] * ui[i];
+                        t = rho * d;
+                    }
+#pragma unroll
+                    for (int c = 0; c < P_VOX; ++c) acc[c] += J[c] * t;
+                    if (!p.fix_poses) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) atomicAdd(&pose_acc[6 * f + i], J[P_POSE + i] * t);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) cam9[i] += J[P_INTR + i] * t;     // intrinsics + distortion: registers across all tiles, reduced once below
                 }
-#pragma unroll
-                for (int c = 0; c < P_VOX; ++c) acc[c] += J[c] * t;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) atomicAdd(&lds[6 * f + i], J[P_POSE + i] * t);
-#pragma unroll
-                for (int i = 0; i < 9; ++i) cam9[i] += J[P_INTR + i] * t;     // intrinsics + distortion: registers, reduced per wave below
             }
         }
+        if (in) {
 #pragma unroll
-        for (int c = 0; c < P_VOX; ++c) b.C[(size_t)c * Acap + a] = acc[c];
-
-        // ---- regulariser rows: tr (Er), ts (Es, Jacobian folded in), ta[6] (Ea) ---------------------------------
-        const uint8_t rf = r.regflags[a];
-        float tr = 0.0f, ts = 0.0f;
-        if (rf & 1) {
-            const float rho = (float)p.type_w[1];
-            if (MODE == PASS_COLNORM) tr = rho;
-            else if (MODE == PASS_GRAD) {
-                const double xs = g.x_sdf[s];
-                const double dxx = g.x_sdf[ring[0]] + g.x_sdf[ring[1]] - 2.0 * xs, dyy = g.x_sdf[ring[2]] + g.x_sdf[ring[3]] - 2.0 * xs,
-                             dzz = g.x_sdf[ring[4]] + g.x_sdf[ring[5]] - 2.0 * xs;
-                tr = rho * (float)(dxx + dyy + dzz);
-            } else {
-                float d = -6.0f * u[s];
+            for (int c = 0; c < P_VOX; ++c) b.C[(size_t)c * Acap + a] = acc[c];
+            // ---- regulariser rows: tr (Er), ts (Es, Jacobian folded in), ta[6] (Ea) ---------------------------------
+            const uint8_t rf = (fl & F_ACTIVE) ? r.regflags[a] : 0;
+            float tr = 0.0f, ts = 0.0f;
+            const int s = r.alist[a];
+            const int N = g.N;
+            if (rf & 1) {
+                const float rho = (float)p.type_w[1];
+                if (MODE == PASS_COLNORM) tr = rho;
+                else if (MODE == PASS_GRAD) {
+                    const double xs = g.x_sdf[s];
+                    double nbv[6];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) d += u[ring[q]];
-                tr = rho * d;
+                    for (int d = 0; d < 6; ++d) nbv[d] = g.x_sdf[g.nbr[(size_t)d * N + s]];
+                    const double dxx = nbv[0] + nbv[1] - 2.0 * xs, dyy = nbv[2] + nbv[3] - 2.0 * xs, dzz = nbv[4] + nbv[5] - 2.0 * xs;
+                    tr = rho * (float)(dxx + dyy + dzz);
+                } else {
+                    float d = -6.0f * u[a];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) { const int la = r.anbr[(size_t)q * Acap + a]; if (la >= 0) d += u[la]; }
+                    tr = rho * d;
+                }
             }
-        }
-        if ((rf & 2) && (rf & 4)) {        // Es row with unit Jacobian (residual != 0, surface_stab_regularizer.h:62-64)
-            const float rho = (float)p.type_w[2];
-            if (MODE == PASS_COLNORM) ts = rho;
-            else if (MODE == PASS_GRAD) ts = rho * (float)(g.x_sdf[s] - g.sdf0[s]);
-            else ts = rho * u[s];
-        }
-        b.treg[a] = tr; b.treg[(size_t)Acap + a] = ts;
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            const float w = r.ea_w[(size_t)d * Acap + a];
-            float ta = 0.0f;
-            if (w != 0.0f) {
-                const float rho = w * (float)p.type_w[3];
-                if (MODE == PASS_COLNORM) ta = rho;
-                else if (MODE == PASS_GRAD) ta = rho * (float)(g.x_alb[s] - g.x_alb[ring[d]]);
-                else ta = rho * (u[N + s] - u[N + ring[d]]);
+            if ((rf & 2) && (rf & 4)) {        // Es row with unit Jacobian (residual != 0, surface_stab_regularizer.h:62-64)
+                const float rho = (float)p.type_w[2];
+                if (MODE == PASS_COLNORM) ts = rho;
+                else if (MODE == PASS_GRAD) ts = rho * (float)(g.x_sdf[s] - g.sdf0[s]);
+                else ts = rho * u[a];
             }
-            b.treg[(size_t)(2 + d) * Acap + a] = ta;
+            b.treg[a] = tr; b.treg[Acap + a] = ts;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                const float w = (fl & F_ACTIVE) ? r.ea_w[(size_t)d * Acap + a] : 0.0f;
+                float ta = 0.0f;
+                if (w != 0.0f) {
+                    const float rho = w * (float)p.type_w[3];
+                    if (MODE == PASS_COLNORM) ta = rho;
+                    else if (MODE == PASS_GRAD) ta = rho * (float)(g.x_alb[s] - g.x_alb[g.nbr[(size_t)d * N + s]]);
+                    else { const int la = r.anbr[(size_t)d * Acap + a]; ta = rho * (u[A + a] - (la >= 0 ? u[A + la] : 0.0f)); }
+                }
+                b.treg[(size_t)(2 + d) * Acap + a] = ta;
+            }
         }
     }
     if (MODE != PASS_COLNORM) {
-        // the 9 intrinsics/distortion columns are shared by every row: wave-shuffle reduction, one LDS atomic per wave
+        // the 9 intrinsics/distortion columns are shared by every row: wave-shuffle reduction, one LDS atomic per wave and column
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             float v = cam9[i];
             for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if ((threadIdx.x & 63) == 0 && v != 0.0f) atomicAdd(&lds[6 * K + i], v);
+            if ((threadIdx.x & 63) == 0 && v != 0.0f) atomicAdd(&cam_acc[i], v);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nshared; i += blockDim.x) { const float v = lds[i]; if (v != 0.0f) atomicAdd(&b.shared[i], (double)v); }
-    if (MODE == PASS_COLNORM)
-        for (int i = threadIdx.x; i < 21 * K + 25; i += blockDim.x) { const float v = lds[nshared + i]; if (v != 0.0f) atomicAdd(&b.blocks[i], (double)v); }
-}
-
-void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u, PassBuffers b) {
-    if (r.A <= 0) return;
-    const int blocks = (r.A + 255) / 256;
-    const int nshared = 6 * p.K + 9;
-    if (mode == PASS_GRAD) k_eg_pass<PASS_GRAD><<<blocks, 256, nshared * sizeof(float), st>>>(g, r, p, u, b, nshared);
-    else if (mode == PASS_JTJP) k_eg_pass<PASS_JTJP><<<blocks, 256, nshared * sizeof(float), st>>>(g, r, p, u, b, nshared);
-    else { const int n = nshared + 21 * p.K + 25; k_eg_pass<PASS_COLNORM><<<blocks, 256, n * sizeof(float), st>>>(g, r, p, u, b, n); }
-}
-
-// pass 2: one lane per stored voxel pulls what the rows contribute to its two unknowns
-template <bool SQUARED>
-__global__ void __launch_bounds__(256) k_gather(GridView g, RowView r, PassBuffers b, float* __restrict__ out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = g.N;
-    if (s >= N) return;
-    const uint8_t fl = g.flags[s];
-    const size_t Acap = r.Acap;
-    float osdf = 0.0f, oalb = 0.0f;
-    if (fl & (F_FREE_SDF | F_FREE_ALB)) {
-        const int as = g.aidx[s];
-        int ringa[6];
-#pragma unroll
-        for (int d = 0; d < 6; ++d) { const int nb = g.nbr[(size_t)d * N + s]; ringa[d] = nb >= 0 ? g.aidx[nb] : -1; }
-        if (fl & F_FREE_SDF) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 10; ++c) {
-                const int rn = slot_rev_nbr(c);
-                int av;
-                if (rn < 0) av = as; else if (rn < 6) av = ringa[rn]; else { const int nb = g.nbr[(size_t)rn * N + s]; av = nb >= 0 ? g.aidx[nb] : -1; }
-                if (av >= 0) acc += b.C[(size_t)c * Acap + av];
-            }
-            if (as >= 0) acc += b.treg[Acap + as] + (SQUARED ? 36.0f : -6.0f) * b.treg[as];
-#pragma unroll
-            for (int d = 0; d < 6; ++d) if (ringa[d] >= 0) acc += b.treg[ringa[d]];
-            osdf = acc;
-        }
-        if (fl & F_FREE_ALB) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int c = 10; c < P_VOX; ++c) {
-                const int rn = slot_rev_nbr(c);
-                const int av = rn < 0 ? as : ringa[rn];
-                if (av >= 0) acc += b.C[(size_t)c * Acap + av];
-            }
-            if (as >= 0) {
-#pragma unroll
-                for (int d = 0; d < 6; ++d) acc += b.treg[(size_t)(2 + d) * Acap + as];
-            }
-#pragma unroll
-            for (int d = 0; d < 6; ++d) if (ringa[d] >= 0) {
-                const float t = b.treg[(size_t)(2 + (d ^ 1)) * Acap + ringa[d]];     // neighbour's edge pointing back at this voxel
-                acc += SQUARED ? t : -t;
-            }
-            oalb = acc;
+    if (MODE == PASS_COLNORM) {
+        for (int i = threadIdx.x; i < nshared; i += EG_THREADS) { const float v = lds[i]; if (v != 0.0f) atomicAdd(&b.shared[i], (double)v); }
+        for (int i = threadIdx.x; i < 21 * K + 25; i += EG_THREADS) { const float v = lds[nshared + i]; if (v != 0.0f) atomicAdd(&b.blocks[i], (double)v); }
+    } else {
+        for (int i = threadIdx.x; i < nshared; i += EG_THREADS) {
+            float v;
+            if (i < 6 * K) { v = 0.0f; for (int q = 0; q < reps; ++q) v += lds[q * 6 * K + i]; }
+            else v = cam_acc[i - 6 * K];
+            if (v != 0.0f) atomicAdd(&b.shared[i], (double)v);
         }
     }
-    out[s] = osdf; out[(size_t)N + s] = oalb;
-}
-void launch_gather(hipStream_t st, PassMode mode, GridView g, RowView r, PassBuffers b, float* out) {
-    if (g.N <= 0) return;
-    const int blocks = (g.N + 255) / 256;
-    if (mode == PASS_COLNORM) k_gather<true><<<blocks, 256, 0, st>>>(g, r, b, out);
-    else k_gather<false><<<blocks, 256, 0, st>>>(g, r, b, out);
 }
 
-__global__ void k_shared_finalize(int K, OptParams p, const double* __restrict__ shared, float* __restrict__ out) {
+void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u, PassBuffers b, const PcgState* state) {
+    if (r.A <= 0) return;
+    static int num_cu = 0;
+    if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    const int ntiles = (r.A + EG_THREADS - 1) / EG_THREADS;
+    const int blocks = ntiles < num_cu ? ntiles : num_cu;                 // one persistent workgroup per CU
+    const int tiles_per_block = (ntiles + blocks - 1) / blocks;
+    const int nshared = 6 * p.K + 9;
+    // replicas of the pose accumulator: the largest power of two that fits ~150 KB of LDS
+    int reps = 32;
+    while (reps > 1 && (size_t)(reps * 6 * p.K + 9 + nshared) * sizeof(float) > 150 * 1024) reps >>= 1;
+    const size_t lds_rep = (size_t)(reps * 6 * p.K + 9 + nshared) * sizeof(float);
+    if (mode == PASS_GRAD) {
+        (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_GRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rep);
+        k_eg_pass<PASS_GRAD><<<blocks, EG_THREADS, lds_rep, st>>>(g, r, p, u, b, reps, tiles_per_block, state);
+    } else if (mode == PASS_JTJP) {
+        (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_JTJP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rep);
+        k_eg_pass<PASS_JTJP><<<blocks, EG_THREADS, lds_rep, st>>>(g, r, p, u, b, reps, tiles_per_block, state);
+    } else {
+        const size_t n = (size_t)(nshared + 21 * p.K + 25) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_COLNORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n);
+        k_eg_pass<PASS_COLNORM><<<blocks, EG_THREADS, n, st>>>(g, r, p, u, b, 1, tiles_per_block, state);
+    }
+}
+
+// ---- pass 2: one lane per work-list entry pulls what the rows contribute to its two unknowns ------------------------------
+// TAIL: out = S*acc + D2*v (the CGNR operator applied to v) and, if dot_out, dot_out += v.out
+template <bool SQUARED, bool TAIL>
+__global__ void __launch_bounds__(256) k_gather(RowView r, PassBuffers b, float* __restrict__ out, const float* __restrict__ S,
+                                                const float* __restrict__ D2, const float* __restrict__ v, double* dot_out,
+                                                const PcgState* __restrict__ state) {
+    if (state && state->done) return;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int A = r.A; const size_t Acap = r.Acap;
+    double dotp = 0.0;
+    if (a < A) {
+        const uint8_t fl = r.aflags[a];
+        float osdf = 0.0f, oalb = 0.0f;
+        if (fl & (F_FREE_SDF | F_FREE_ALB)) {
+            int ringa[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) ringa[d] = r.anbr[(size_t)d * Acap + a];
+            if (fl & F_FREE_SDF) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 10; ++c) {
+                    const int rn = slot_rev_nbr(c);
+                    const int av = rn < 0 ? a : (rn < 6 ? ringa[rn] : r.anbr[(size_t)rn * Acap + a]);
+                    if (av >= 0) acc += b.C[(size_t)c * Acap + av];
+                }
+                acc += b.treg[Acap + a] + (SQUARED ? 36.0f : -6.0f) * b.treg[a];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) if (ringa[d] >= 0) acc += b.treg[ringa[d]];
+                osdf = acc;
+            }
+            if (fl & F_FREE_ALB) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 10; c < P_VOX; ++c) {
+                    const int rn = slot_rev_nbr(c);
+                    const int av = rn < 0 ? a : ringa[rn];
+                    if (av >= 0) acc += b.C[(size_t)c * Acap + av];
+                }
+#pragma unroll
+                for (int d = 0; d < 6; ++d) acc += b.treg[(size_t)(2 + d) * Acap + a];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) if (ringa[d] >= 0) {
+                    const float t = b.treg[(size_t)(2 + (d ^ 1)) * Acap + ringa[d]];     // neighbour's edge pointing back at this entry
+                    acc += SQUARED ? t : -t;
+                }
+                oalb = acc;
+            }
+        }
+        if (TAIL) {
+            const float v0 = v[a], v1 = v[A + a];
+            osdf = S[a] * osdf + D2[a] * v0; oalb = S[A + a] * oalb + D2[A + a] * v1;
+            dotp = (double)v0 * (double)osdf + (double)v1 * (double)oalb;
+        }
+        out[a] = osdf; out[A + a] = oalb;
+    }
+    if (TAIL && dot_out) block_add_d(dotp, dot_out);
+}
+void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out) {
+    if (r.A <= 0) return;
+    const int blocks = (r.A + 255) / 256;
+    if (mode == PASS_COLNORM) k_gather<true, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else k_gather<false, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+void launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_out, const PcgState* state) {
+    if (r.A <= 0) return;
+    k_gather<false, true><<<(r.A + 255) / 256, 256, 0, st>>>(r, b, out, S, D2, v, dot_out, state);
+}
+
+// camera tail of the vectors: out[2A + i] from the fp64 accumulators; TAIL as above
+__global__ void k_shared_finalize(int A, int K, OptParams p, const double* __restrict__ shared, float* __restrict__ out, int tail,
+                                  const float* __restrict__ S, const float* __restrict__ D2, const float* __restrict__ v, double* dot_out,
+                                  const PcgState* __restrict__ state) {
+    if (state && state->done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 6 * K + 9) return;
-    const bool fixed = i < 6 * K ? p.fix_poses : (i < 6 * K + 4 ? p.fix_intr : p.fix_dist);
-    out[i] = fixed ? 0.0f : (float)shared[i];
+    double dotp = 0.0;
+    if (i < 6 * K + 9) {
+        const bool fixed = i < 6 * K ? p.fix_poses : (i < 6 * K + 4 ? p.fix_intr : p.fix_dist);
+        float o = fixed ? 0.0f : (float)shared[i];
+        const size_t j = 2 * (size_t)A + i;
+        if (tail) { const float vv = v[j]; o = S[j] * o + D2[j] * vv; dotp = (double)vv * (double)o; }
+        out[j] = o;
+    }
+    if (tail && dot_out) block_add_d(dotp, dot_out);
 }
-void launch_shared_finalize(hipStream_t st, int K, OptParams p, const double* shared, float* out) {
-    k_shared_finalize<<<(6 * K + 9 + 255) / 256, 256, 0, st>>>(K, p, shared, out);
+void launch_shared_finalize(hipStream_t st, int A, int K, OptParams p, const double* shared, float* out, bool tail, const float* S, const float* D2,
+                            const float* v, double* dot_out, const PcgState* state) {
+    k_shared_finalize<<<(6 * K + 9 + 255) / 256, 256, 0, st>>>(A, K, p, shared, out, tail ? 1 : 0, S, D2, v, dot_out, state);
 }
 
-// ---- vector helpers ----------------------------------------------------------------------------------------
-#define GRID_STRIDE(n) const int stride = gridDim.x * blockDim.x; for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += stride)
-static inline int vblocks(int n) { int b = (n + 255) / 256; return b < 1 ? 1 : (b > 4096 ? 4096 : b); }
-
+// ---- vector helpers -------------------------------------------------------------------------------------------------
 __global__ void k_fill(int n, float* x, float v) { GRID_STRIDE(n) x[i] = v; }
 __global__ void k_fill_d(int n, double* x, double v) { GRID_STRIDE(n) x[i] = v; }
 __global__ void k_mul(int n, const float* a, const float* b, float* o) { GRID_STRIDE(n) o[i] = a[i] * b[i]; }
@@ -258,95 +349,162 @@ __global__ void k_lm_diag(int n, const float* c, const float* S, float inv_radiu
         D2[i] = d2; Minv[i] = 1.0f / (cs + d2);
     }
 }
-__global__ void k_op_tail(int n, const float* S, const float* acc, const float* D2, const float* p, float* q) { GRID_STRIDE(n) q[i] = S[i] * acc[i] + D2[i] * p[i]; }
-__global__ void k_axpy(int n, float a, const float* x, float* y) { GRID_STRIDE(n) y[i] += a * x[i]; }
-__global__ void k_xpay(int n, const float* x, float a, float* y) { GRID_STRIDE(n) y[i] = x[i] + a * y[i]; }
-__global__ void k_sub(int n, const float* a, const float* b, float* o) { GRID_STRIDE(n) o[i] = a[i] - b[i]; }
-
-static __device__ inline void block_add_d(double v, double* dst) {
-    __shared__ double sm[4];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i]; atomicAdd(dst, t); }
-    __syncthreads();
-}
 __global__ void __launch_bounds__(256) k_dot(int n, const float* a, const float* b, double* out) {
     double s = 0.0; GRID_STRIDE(n) s += (double)a[i] * (double)b[i];
     block_add_d(s, out);
 }
-__global__ void __launch_bounds__(256) k_dot3(int n, const float* x, const float* b, const float* r, const float* D2, double* out) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    GRID_STRIDE(n) { const double xi = x[i]; s0 += xi * ((double)b[i] + (double)r[i]); s1 += xi * (double)r[i]; s2 += (double)D2[i] * xi * xi; }
-    block_add_d(s0, out); block_add_d(s1, out + 1); block_add_d(s2, out + 2);
-}
-
 void launch_fill(hipStream_t st, int n, float* x, float v) { if (n > 0) k_fill<<<vblocks(n), 256, 0, st>>>(n, x, v); }
 void launch_fill_d(hipStream_t st, int n, double* x, double v) { if (n > 0) k_fill_d<<<vblocks(n), 256, 0, st>>>(n, x, v); }
 void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* o) { if (n > 0) k_mul<<<vblocks(n), 256, 0, st>>>(n, a, b, o); }
 void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* m, float* S) { if (n > 0) k_scale<<<vblocks(n), 256, 0, st>>>(n, c, m, S); }
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float ir, float* D2, float* Minv) { if (n > 0) k_lm_diag<<<vblocks(n), 256, 0, st>>>(n, c, S, ir, D2, Minv); }
-void launch_apply_op_tail(hipStream_t st, int n, const float* S, const float* acc, const float* D2, const float* p, float* q) { if (n > 0) k_op_tail<<<vblocks(n), 256, 0, st>>>(n, S, acc, D2, p, q); }
-void launch_axpy(hipStream_t st, int n, float a, const float* x, float* y) { if (n > 0) k_axpy<<<vblocks(n), 256, 0, st>>>(n, a, x, y); }
-void launch_xpay(hipStream_t st, int n, const float* x, float a, float* y) { if (n > 0) k_xpay<<<vblocks(n), 256, 0, st>>>(n, x, a, y); }
-void launch_sub(hipStream_t st, int n, const float* a, const float* b, float* o) { if (n > 0) k_sub<<<vblocks(n), 256, 0, st>>>(n, a, b, o); }
 void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out) { if (n > 0) k_dot<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, a, b, out); }
-void launch_dot3(hipStream_t st, int n, const float* x, const float* b, const float* r, const float* D2, double* out3) { if (n > 0) k_dot3<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, x, b, r, D2, out3); }
 
-// z_shared = Minv_block * r_shared for the K 6x6 pose blocks, the 4x4 intrinsics block and the 5x5 distortion block
-__global__ void k_precond_shared(int K, const float* __restrict__ Minv, const float* __restrict__ rs, float* __restrict__ zs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 6 * K + 9) return;
-    int base, n, row; const float* M;
-    if (i < 6 * K) { const int f = i / 6; base = 6 * f; n = 6; row = i - base; M = Minv + 36 * f; }
-    else if (i < 6 * K + 4) { base = 6 * K; n = 4; row = i - base; M = Minv + 36 * K; }
-    else { base = 6 * K + 4; n = 5; row = i - base; M = Minv + 36 * K + 16; }
-    float s = 0.0f;
-    for (int j = 0; j < n; ++j) s += M[row * n + j] * rs[base + j];
-    zs[i] = s;
-}
-void launch_precond_shared(hipStream_t st, int K, const float* Minv, const float* rs, float* zs) {
-    k_precond_shared<<<(6 * K + 9 + 255) / 256, 256, 0, st>>>(K, Minv, rs, zs);
-}
-
-__global__ void k_freemask(GridView g, OptParams p, float* __restrict__ mask) {
-    const int N = g.N, NP = 2 * N + 6 * p.K + 9;
+__global__ void k_freemask(RowView r, OptParams p, float* __restrict__ mask) {
+    const int A = r.A, NP = 2 * A + 6 * p.K + 9;
     GRID_STRIDE(NP) {
         float m;
-        if (i < N) m = (g.flags[i] & F_FREE_SDF) ? 1.0f : 0.0f;
-        else if (i < 2 * N) m = (g.flags[i - N] & F_FREE_ALB) ? 1.0f : 0.0f;
-        else if (i < 2 * N + 6 * p.K) m = p.fix_poses ? 0.0f : 1.0f;
-        else if (i < 2 * N + 6 * p.K + 4) m = p.fix_intr ? 0.0f : 1.0f;
+        if (i < A) m = (r.aflags[i] & F_FREE_SDF) ? 1.0f : 0.0f;
+        else if (i < 2 * A) m = (r.aflags[i - A] & F_FREE_ALB) ? 1.0f : 0.0f;
+        else if (i < 2 * A + 6 * p.K) m = p.fix_poses ? 0.0f : 1.0f;
+        else if (i < 2 * A + 6 * p.K + 4) m = p.fix_intr ? 0.0f : 1.0f;
         else m = p.fix_dist ? 0.0f : 1.0f;
         mask[i] = m;
     }
 }
-void launch_freemask(hipStream_t st, GridView g, OptParams p, float* mask) { k_freemask<<<vblocks(2 * g.N + 6 * p.K + 9), 256, 0, st>>>(g, p, mask); }
+void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask) { k_freemask<<<vblocks(2 * r.A + 6 * p.K + 9), 256, 0, st>>>(r, p, mask); }
 
+// ---- fused PCG iteration (conjugate_gradients_solver.cc) -------------------------------------------------------------
+// (1) z = M^-1 r on the voxel part (1x1 blocks) and rho += r.z ; the camera blocks go through k_pcg_precond_shared
+__global__ void __launch_bounds__(256) k_pcg_precond(int n2, const float* __restrict__ Minv, const float* __restrict__ r, float* __restrict__ z, PcgState* state) {
+    if (state->done) return;
+    double s = 0.0;
+    GRID_STRIDE(n2) { const float ri = r[i], zi = Minv[i] * ri; z[i] = zi; s += (double)ri * (double)zi; }
+    block_add_d(s, &state->rho);
+}
+__global__ void k_pcg_precond_shared(int A, int K, const float* __restrict__ Minv, const float* __restrict__ r, float* __restrict__ z, PcgState* state) {
+    if (state->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double dotp = 0.0;
+    if (i < 6 * K + 9) {
+        int base, n, row; const float* M;
+        if (i < 6 * K) { const int f = i / 6; base = 6 * f; n = 6; row = i - base; M = Minv + 36 * f; }
+        else if (i < 6 * K + 4) { base = 6 * K; n = 4; row = i - base; M = Minv + 36 * K; }
+        else { base = 6 * K + 4; n = 5; row = i - base; M = Minv + 36 * K + 16; }
+        const float* rs = r + 2 * (size_t)A;
+        float s = 0.0f;
+        for (int j = 0; j < n; ++j) s += M[row * n + j] * rs[base + j];
+        z[2 * (size_t)A + i] = s; dotp = (double)rs[i] * (double)s;
+    }
+    block_add_d(dotp, &state->rho);
+}
+// (2) scalar step: validity of rho, beta
+__global__ void k_pcg_scalar1(PcgState* st) {
+    if (st->done) return;
+    const double rho = st->rho;
+    if (rho == 0.0 || isinf(rho) || isnan(rho)) { st->done = 2; return; }
+    if (st->it > 0) { const double beta = rho / st->last_rho; if (beta == 0.0 || isinf(beta) || isnan(beta)) { st->done = 2; return; } st->beta = beta; }
+    else st->beta = 0.0;
+    st->pq = 0.0;
+}
+// (3) p = z + beta p ; u = S p
+__global__ void __launch_bounds__(256) k_pcg_direction(int n, const float* __restrict__ z, float* __restrict__ p, const float* __restrict__ S, float* __restrict__ u, const PcgState* __restrict__ state) {
+    if (state->done) return;
+    const float beta = (float)state->beta; const bool first = state->it == 0;
+    GRID_STRIDE(n) { const float pi = first ? z[i] : z[i] + beta * p[i]; p[i] = pi; u[i] = S[i] * pi; }
+}
+// (4) eg_pass + gather_tail + shared_finalize give q and pq ; scalar step: alpha
+__global__ void k_pcg_scalar2(PcgState* st) {
+    if (st->done) return;
+    const double pq = st->pq;
+    if (!(pq > 0.0) || isinf(pq)) { st->done = 2; return; }
+    const double alpha = st->rho / pq;
+    if (isinf(alpha)) { st->done = 2; return; }
+    st->alpha = alpha; st->xbr = 0.0; st->xr = 0.0; st->d2xx = 0.0;
+}
+// (5) x += alpha p ; r -= alpha q (unless this is a residual-reset iteration) ; partial sums of x.(b+r), x.r, sum D2 x^2
+__global__ void __launch_bounds__(256) k_pcg_update(int n, const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ x, float* __restrict__ r,
+                                                    const float* __restrict__ b, const float* __restrict__ D2, int reset_phase, PcgState* state) {
+    if (state->done) return;
+    const float alpha = (float)state->alpha;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    GRID_STRIDE(n) {
+        const float xi = x[i] + alpha * p[i]; x[i] = xi;
+        if (reset_phase == 0) {
+            const float ri = r[i] - alpha * q[i]; r[i] = ri;
+            const double xd = xi; s0 += xd * ((double)b[i] + (double)ri); s1 += xd * (double)ri; s2 += (double)D2[i] * xd * xd;
+        }
+    }
+    if (reset_phase == 0) { block_add_d(s0, &state->xbr); block_add_d(s1, &state->xr); block_add_d(s2, &state->d2xx); }
+}
+// (5') every residual_reset_period iterations: r = b - A x (A x in tmp), then the same partial sums
+__global__ void __launch_bounds__(256) k_pcg_reset_r(int n, const float* __restrict__ x, const float* __restrict__ tmp, float* __restrict__ r,
+                                                     const float* __restrict__ b, const float* __restrict__ D2, PcgState* state) {
+    if (state->done) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    GRID_STRIDE(n) { const float ri = b[i] - tmp[i]; r[i] = ri; const double xd = x[i]; s0 += xd * ((double)b[i] + (double)ri); s1 += xd * (double)ri; s2 += (double)D2[i] * xd * xd; }
+    block_add_d(s0, &state->xbr); block_add_d(s1, &state->xr); block_add_d(s2, &state->d2xx);
+}
+// (6) scalar step: quadratic-model termination (eta = 0.1), bookkeeping for the next iteration
+__global__ void k_pcg_scalar3(PcgState* st) {
+    if (st->done) return;
+    const int it = st->it + 1;
+    st->it = it;
+    const double Q1 = -st->xbr; st->Q1 = Q1;
+    st->last_rho = st->rho; st->rho = 0.0;
+    if (st->fixed_iterations >= 0) { if (it >= st->fixed_iterations) st->done = 1; st->Q0 = Q1; return; }
+    const double zeta = (double)it * (Q1 - st->Q0) / Q1;
+    if (zeta < 0.1) { st->done = 1; return; }
+    st->Q0 = Q1;
+    if (it >= st->max_iterations) st->done = 1;
+}
+__global__ void k_pcg_init(PcgState* st, int fixed_iterations, int max_iterations) {
+    st->rho = 0.0; st->last_rho = 1.0; st->pq = 0.0; st->alpha = 0.0; st->beta = 0.0; st->xbr = 0.0; st->xr = 0.0; st->d2xx = 0.0;
+    st->Q0 = 0.0; st->Q1 = 0.0; st->it = 0; st->done = (fixed_iterations == 0) ? 1 : 0; st->fixed_iterations = fixed_iterations; st->max_iterations = max_iterations;
+}
+
+void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations) { k_pcg_init<<<1, 1, 0, st>>>(state, fixed_iterations, max_iterations); }
+void launch_pcg_precond(hipStream_t st, int A, int K, const float* Minv, const float* Minv_blocks, const float* r, float* z, PcgState* state) {
+    if (A > 0) k_pcg_precond<<<vblocks(2 * A) > 1024 ? 1024 : vblocks(2 * A), 256, 0, st>>>(2 * A, Minv, r, z, state);
+    k_pcg_precond_shared<<<(6 * K + 9 + 255) / 256, 256, 0, st>>>(A, K, Minv_blocks, r, z, state);
+    k_pcg_scalar1<<<1, 1, 0, st>>>(state);
+}
+void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state) { if (n > 0) k_pcg_direction<<<vblocks(n), 256, 0, st>>>(n, z, p, S, u, state); }
+void launch_pcg_scalar2(hipStream_t st, PcgState* state) { k_pcg_scalar2<<<1, 1, 0, st>>>(state); }
+void launch_pcg_update(hipStream_t st, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, int reset_phase, PcgState* state) {
+    if (n > 0) k_pcg_update<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, p, q, x, r, b, D2, reset_phase, state);
+}
+void launch_pcg_reset_r(hipStream_t st, int n, const float* x, const float* tmp, float* r, const float* b, const float* D2, PcgState* state) {
+    if (n > 0) k_pcg_reset_r<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, x, tmp, r, b, D2, state);
+}
+void launch_pcg_scalar3(hipStream_t st, PcgState* state) { k_pcg_scalar3<<<1, 1, 0, st>>>(state); }
+
+// ---- LM candidate / acceptance ------------------------------------------------------------------------------------------
 // candidate point x + S*step (TrustRegionMinimizer: delta = step .* jacobian_scaling), squared norms of delta and x over the free parameters
-__global__ void __launch_bounds__(256) k_candidate(GridView g, int K, float sign, const float* __restrict__ step, const float* __restrict__ S,
+__global__ void __launch_bounds__(256) k_candidate(GridView g, RowView r, int K, float sign, const float* __restrict__ step, const float* __restrict__ S,
                                                    const double* __restrict__ xsh, double* xc_sdf, double* xc_alb, double* xc_sh,
                                                    double* norms2, const float* __restrict__ mask) {
-    const int N = g.N, NP = 2 * N + 6 * K + 9;
+    const int A = r.A, NP = 2 * A + 6 * K + 9;
     double d2 = 0.0, x2 = 0.0;
     GRID_STRIDE(NP) {
         const double delta = (double)sign * (double)step[i] * (double)S[i];
         double x;
-        if (i < N) { x = g.x_sdf[i]; xc_sdf[i] = x + delta; }
-        else if (i < 2 * N) { x = g.x_alb[i - N]; xc_alb[i - N] = x + delta; }
-        else { x = xsh[i - 2 * N]; xc_sh[i - 2 * N] = x + delta; }
+        if (i < A) { const int s = r.alist[i]; x = g.x_sdf[s]; xc_sdf[s] = x + delta; }
+        else if (i < 2 * A) { const int s = r.alist[i - A]; x = g.x_alb[s]; xc_alb[s] = x + delta; }
+        else { x = xsh[i - 2 * A]; xc_sh[i - 2 * A] = x + delta; }
         if (mask[i] != 0.0f) { d2 += delta * delta; x2 += x * x; }
     }
     block_add_d(d2, norms2); block_add_d(x2, norms2 + 1);
 }
-void launch_candidate(hipStream_t st, GridView g, int K, float sign, const float* step, const float* S, const double* xsh, double* xc_sdf, double* xc_alb,
+void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* xsh, double* xc_sdf, double* xc_alb,
                       double* xc_sh, double* norms2, const float* mask) {
-    int b = vblocks(2 * g.N + 6 * K + 9); if (b > 1024) b = 1024;
-    k_candidate<<<b, 256, 0, st>>>(g, K, sign, step, S, xsh, xc_sdf, xc_alb, xc_sh, norms2, mask);
+    int b = vblocks(2 * r.A + 6 * K + 9); if (b > 1024) b = 1024;
+    k_candidate<<<b, 256, 0, st>>>(g, r, K, sign, step, S, xsh, xc_sdf, xc_alb, xc_sh, norms2, mask);
 }
-__global__ void k_accept(GridView g, const double* __restrict__ xc_sdf, const double* __restrict__ xc_alb) {
-    GRID_STRIDE(g.N) { const double a = xc_sdf[i], b = xc_alb[i]; g.x_sdf[i] = a; g.x_alb[i] = b; g.f_sdf[i] = (float)a; g.f_alb[i] = (float)b; }
+// x <- candidate on the work list (everything else never moves), refresh the fp32 shadows
+__global__ void k_accept(GridView g, RowView r, const double* __restrict__ xc_sdf, const double* __restrict__ xc_alb) {
+    GRID_STRIDE(r.A) { const int s = r.alist[i]; const double a = xc_sdf[s], b = xc_alb[s]; g.x_sdf[s] = a; g.x_alb[s] = b; g.f_sdf[s] = (float)a; g.f_alb[s] = (float)b; }
 }
-void launch_accept(hipStream_t st, GridView g, const double* xc_sdf, const double* xc_alb) { if (g.N > 0) k_accept<<<vblocks(g.N), 256, 0, st>>>(g, xc_sdf, xc_alb); }
+void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb) { if (r.A > 0) k_accept<<<vblocks(r.A), 256, 0, st>>>(g, r, xc_sdf, xc_alb); }
 
 }  // namespace i3d

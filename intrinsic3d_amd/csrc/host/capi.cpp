@@ -51,26 +51,29 @@ int i3d_debug_flags(i3d_context* c, uint8_t* flags) {
 int i3d_debug_eg_rows(i3d_context* c, int32_t* frame, float* weight, float* residual, float* jac) {
     if (!c || !c->assembled) return ctx_fail(c, I3D_ERR_STATE, "i3d_debug_eg_rows: not assembled");
     const int N = c->N, A = c->A, S = c->slots; const size_t Acap = c->Acap;
-    std::vector<int> rank(N), alist(A > 0 ? A : 1), of(Acap * S); std::vector<float> rw(Acap * S), rs(Acap * S), J;
+    const size_t nrow4 = ((Acap + 63) / 64) * 64 * (size_t)S * ROW_PLANES;
+    std::vector<int> rank(N), alist(A > 0 ? A : 1); std::vector<float4> rows(nrow4); std::vector<uint8_t> nr(Acap);
     CTX_HIP(c, hipMemcpy(rank.data(), c->rank.p, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
     if (A > 0) CTX_HIP(c, hipMemcpy(alist.data(), c->alist.p, sizeof(int) * (size_t)A, hipMemcpyDeviceToHost));
-    CTX_HIP(c, hipMemcpy(of.data(), c->obs_frame.p, sizeof(int) * Acap * S, hipMemcpyDeviceToHost));
-    CTX_HIP(c, hipMemcpy(rw.data(), c->roww.p, sizeof(float) * Acap * S, hipMemcpyDeviceToHost));
-    CTX_HIP(c, hipMemcpy(rs.data(), c->res.p, sizeof(float) * Acap * S, hipMemcpyDeviceToHost));
-    if (jac) { J.resize(Acap * S * P_TOTAL); CTX_HIP(c, hipMemcpy(J.data(), c->J.p, sizeof(float) * Acap * S * P_TOTAL, hipMemcpyDeviceToHost)); }
+    CTX_HIP(c, hipMemcpy(rows.data(), c->rows.p, sizeof(float4) * nrow4, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(nr.data(), c->nrows.p, Acap, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < (size_t)N * S; ++i) { if (frame) frame[i] = -1; if (weight) weight[i] = 0.0f; if (residual) residual[i] = 0.0f; }
     if (jac) std::memset(jac, 0, sizeof(float) * (size_t)N * S * P_TOTAL);
     const float tw = (float)c->last_params.type_w[0];
+    std::vector<uint8_t> afl(Acap); CTX_HIP(c, hipMemcpy(afl.data(), c->aflags.p, Acap, hipMemcpyDeviceToHost));
     for (int a = 0; a < A; ++a) {
+        if (!(afl[a] & F_ACTIVE)) continue;
         const int v = rank[alist[a]];
-        for (int k = 0; k < S; ++k) {
-            const size_t ka = (size_t)k * Acap + a;
-            if (rw[ka] == 0.0f) continue;
+        for (int k = 0; k < (int)nr[a]; ++k) {
+            const float4 m = rows[row_index(a, k, 7, S)];
+            if (m.x == 0.0f) continue;
             const size_t o = (size_t)v * S + k;
-            if (frame) frame[o] = of[ka];
-            if (weight) weight[o] = rw[ka] * tw;
-            if (residual) residual[o] = rs[ka];
-            if (jac) for (int i = 0; i < P_TOTAL; ++i) jac[o * P_TOTAL + i] = J[((size_t)i * S + k) * Acap + a];
+            int f; std::memcpy(&f, &m.z, sizeof(int)); f &= ~ROW_FREE_BIT;
+            if (frame) frame[o] = f;
+            if (weight) weight[o] = m.x * tw;
+            if (residual) residual[o] = m.y;
+            if (jac) { for (int q = 0; q < 7; ++q) { const float4 t = rows[row_index(a, k, q, S)]; jac[o * P_TOTAL + 4 * q] = t.x; jac[o * P_TOTAL + 4 * q + 1] = t.y; jac[o * P_TOTAL + 4 * q + 2] = t.z; jac[o * P_TOTAL + 4 * q + 3] = t.w; }
+                       jac[o * P_TOTAL + 28] = m.w; }
         }
     }
     return I3D_OK;
@@ -79,16 +82,19 @@ int i3d_debug_eg_rows(i3d_context* c, int32_t* frame, float* weight, float* resi
 int i3d_debug_reg_rows(i3d_context* c, uint8_t* has_er, uint8_t* has_es, float* ea_weight) {
     if (!c || !c->assembled) return ctx_fail(c, I3D_ERR_STATE, "i3d_debug_reg_rows: not assembled");
     const int N = c->N, A = c->A; const size_t Acap = c->Acap;
-    std::vector<int> rank(N), alist(A > 0 ? A : 1); std::vector<uint8_t> rf(Acap); std::vector<float> ew(Acap * 6);
+    std::vector<int> rank(N), alist(A > 0 ? A : 1); std::vector<uint8_t> rf(Acap), afl(Acap); std::vector<float> ew(Acap * 6);
     CTX_HIP(c, hipMemcpy(rank.data(), c->rank.p, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
     if (A > 0) CTX_HIP(c, hipMemcpy(alist.data(), c->alist.p, sizeof(int) * (size_t)A, hipMemcpyDeviceToHost));
     CTX_HIP(c, hipMemcpy(rf.data(), c->regflags.p, Acap, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(afl.data(), c->aflags.p, Acap, hipMemcpyDeviceToHost));
     CTX_HIP(c, hipMemcpy(ew.data(), c->ea_w.p, sizeof(float) * Acap * 6, hipMemcpyDeviceToHost));
     for (int v = 0; v < N; ++v) { if (has_er) has_er[v] = 0; if (has_es) has_es[v] = 0; if (ea_weight) for (int d = 0; d < 6; ++d) ea_weight[(size_t)v * 6 + d] = 0.0f; }
     const float tw = (float)c->last_params.type_w[3];
     for (int a = 0; a < A; ++a) {
+        if (!(afl[a] & F_ACTIVE)) continue;
         const int v = rank[alist[a]];
-        if (has_er) has_er[v] = rf[a] & 1; if (has_es) has_es[v] = (rf[a] >> 1) & 1;
+        if (has_er) has_er[v] = rf[a] & 1;
+        if (has_es) has_es[v] = (rf[a] >> 1) & 1;
         if (ea_weight) for (int d = 0; d < 6; ++d) ea_weight[(size_t)v * 6 + d] = ew[(size_t)d * Acap + a] * tw;
     }
     return I3D_OK;

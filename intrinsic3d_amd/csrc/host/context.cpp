@@ -125,8 +125,8 @@ i3d::GridView i3d_context::grid_view() const {
 }
 i3d::RowView i3d_context::row_view() const {
     RowView r;
-    r.A = A; r.Acap = Acap; r.slots = slots; r.alist = alist.p; r.obs_frame = obs_frame.p; r.obs_w = obs_w.p;
-    r.res = res.p; r.roww = roww.p; r.J = J.p; r.rowfree = rowfree.p; r.regflags = regflags.p; r.ea_w = ea_w.p; r.ea_free = ea_free.p;
+    r.A = A; r.Acap = Acap; r.slots = slots; r.alist = alist.p; r.aflags = aflags.p; r.anbr = anbr.p; r.obs_frame = obs_frame.p; r.obs_w = obs_w.p;
+    r.rows = rows.p; r.nrows = nrows.p; r.regflags = regflags.p; r.ea_w = ea_w.p; r.ea_free = ea_free.p;
     return r;
 }
 
@@ -159,6 +159,8 @@ void i3d_destroy(i3d_context* c) {
     timing_flush(c);
     for (auto e : c->timing.pool) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_pcg) (void)hipHostFree(c->h_pcg);
+    for (auto e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -196,6 +198,8 @@ int i3d_set_grid(i3d_context* c, const i3d_grid_view* gv) {
     CTX_HIP(c, c->sh.alloc((size_t)9 * N)); CTX_HIP(c, c->nbr.alloc((size_t)NUM_NBR * N));
     launch_permute_grid(st, N, perm.p, kxyz.p, hsdf.p, hsr.p, halb.p, hw.p, hrgb.p, c->cx.p, c->cy.p, c->cz.p, c->rank.p, c->sdf0.p,
                         c->x_sdf.p, c->x_alb.p, c->f_sdf.p, c->f_alb.p, c->weight.p, c->color.p);
+    CTX_HIP(c, hipMemcpyAsync(c->xc_sdf.p, c->x_sdf.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(c->xc_alb.p, c->x_alb.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
     // device hash (2x load-factor headroom, power of two) + neighbour table
     unsigned int cap = 1; while (cap < (unsigned int)N * 2u) cap <<= 1;
     DevBuf<unsigned long long> hkeys; DevBuf<int> hvals;

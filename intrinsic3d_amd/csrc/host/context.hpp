@@ -67,15 +67,17 @@ struct i3d_context {
     std::vector<double> poses;
     bool have_camera = false;
 
-    // ---- rows ----
-    int Acap = 0, slots = 0, A = 0;
-    i3d::DevBuf<int> obs_frame; i3d::DevBuf<float> obs_w, res, roww, J, ea_w, C, treg;
-    i3d::DevBuf<uint8_t> rowfree, regflags, ea_free;
+    // ---- rows (work-list space) ----
+    int Acap = 0, slots = 0, A = 0; long long n_active = 0;
+    i3d::DevBuf<int> obs_frame, anbr; i3d::DevBuf<float> obs_w, ea_w, C, treg;
+    i3d::DevBuf<float4> rows;
+    i3d::DevBuf<uint8_t> aflags, nrows, regflags, ea_free;
 
     // ---- solver vectors (length NP = 2N + 6K + 9) ----
     i3d::DevBuf<float> v_mask, v_c, v_S, v_D2, v_Minv, v_b, v_x, v_r, v_p, v_z, v_q, v_u, v_acc, v_tmp;
     i3d::DevBuf<float> Minv_blocks;
     i3d::DevBuf<double> d_shared, d_blocks, d_scal, d_xshared, d_xcshared;
+    i3d::DevBuf<i3d::PcgState> d_pcg; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};
     double* h_pinned = nullptr; size_t h_pinned_n = 0;
 
     i3d::OptParams last_params; bool assembled = false;
