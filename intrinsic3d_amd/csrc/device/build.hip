@@ -9,127 +9,120 @@
 //
 // Work mapping: one lane per ACTIVE voxel.  Everything that does not depend on the keyframe (4 normals, their
 // projectors, 4 SH shadings and their partials, 4 iso-points) is computed once and shared by the voxel's <= `slots`
-// rows; per-keyframe rotation R and dR/d(omega) come precomputed in FrameConst (wave-uniform loads when neighbouring
-// voxels see the same keyframes, L1/L2 hits otherwise).
+// rows.  Per row the work is split in two phases so that few values are live at once (occupancy):
+//   phase 1 (fp64, the VALUE path): Q = R P + t, projection with distortion, bicubic luminance at the 4 stencil points
+//            -> residual r = ||grad B - grad I||.  fp64 because r is a difference of differences of O(1) quantities and
+//            the reference computes it in fp64 (parity bar 1e-4).
+//   phase 2 (fp32, the DERIVATIVE path): with c_j = d r / d E_j fixed, every partial is linear in per-point terms and is
+//            accumulated point by point; the rotation columns use  d(RP)/d omega = -R [P]x Jr  (Jr per keyframe), so the
+//            per-point work is one cross product instead of three 3x3 products.
+// The 16 bicubic taps of a point are 4 unaligned float4 loads (interior) instead of 16 scalar gathers.
 #include "kernels.hpp"
 
 namespace i3d {
 
-typedef double real;   // value path precision (geometry, projection, spline).  Stored partials are fp32.
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
 
-struct PointShared {   // per stencil point j in {000,100,010,001}
-    real n[3];         // unit normal (or raw gradient if its length is 0, operators.h:79-84)
-    real inv_len;      // 1/|g| or 0 when |g| == 0 (then dn/dg = I)
-    real s;            // sdf at the point
-    real P[3];         // iso-projected world position
-    real Ls;           // l . H(n)
-    real dLs[3];       // d(l.H)/dn
-    real alb;
+struct PointShared {   // per stencil point j in {000,100,010,001}; value path fp64, derivative path fp32
+    double P[3];       // iso-projected world position
+    double B;          // albedo * (l . H(n))
+    float n[3];        // unit normal (or raw gradient if its length is 0, operators.h:79-84)
+    float inv_len;     // 1/|g| or 0 when |g| == 0 (then dn/dg = I)
+    float s;           // sdf at the point
+    float Ls;          // l . H(n)
+    float dLs[3];      // d(l.H)/dn
+    float alb;
 };
 
-static __device__ inline void shared_point(PointShared& q, real s, real sx, real sy, real sz, real alb, const real sh[9],
-                                           int cx, int cy, int cz, real vs) {
-    real g0 = sx - s, g1 = sy - s, g2 = sz - s;
-    const real len = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
-    if (len > 0.0) { q.inv_len = 1.0 / len; g0 /= len; g1 /= len; g2 /= len; } else q.inv_len = 0.0;
-    q.n[0] = g0; q.n[1] = g1; q.n[2] = g2; q.s = s; q.alb = alb;
-    q.P[0] = (real)cx * vs - g0 * s; q.P[1] = (real)cy * vs - g1 * s; q.P[2] = (real)cz * vs - g2 * s;
-    const real nx = g0, ny = g1, nz = g2;
+static __device__ inline void shared_point(PointShared& q, double s, double sx, double sy, double sz, double alb, const float sh[9],
+                                           int cx, int cy, int cz, double vs) {
+    double g0 = sx - s, g1 = sy - s, g2 = sz - s;
+    const double len = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
+    if (len > 0.0) { q.inv_len = (float)(1.0 / len); g0 /= len; g1 /= len; g2 /= len; } else q.inv_len = 0.0f;
+    q.s = (float)s; q.alb = (float)alb;
+    q.P[0] = (double)cx * vs - g0 * s; q.P[1] = (double)cy * vs - g1 * s; q.P[2] = (double)cz * vs - g2 * s;
+    const double nx = g0, ny = g1, nz = g2;
     // shading.h:53-67 basis order: 1, ny, nz, nx, nx*ny, ny*nz, -nx^2-ny^2+2nz^2, nx*nz, nx^2-ny^2
-    q.Ls = sh[0] + sh[1] * ny + sh[2] * nz + sh[3] * nx + sh[4] * (nx * ny) + sh[5] * (ny * nz) +
-           sh[6] * ((-(nx * nx)) - (ny * ny) + 2.0 * (nz * nz)) + sh[7] * (nx * nz) + sh[8] * ((nx * nx) - (ny * ny));
-    q.dLs[0] = sh[3] + sh[4] * ny - 2.0 * sh[6] * nx + sh[7] * nz + 2.0 * sh[8] * nx;
-    q.dLs[1] = sh[1] + sh[4] * nx + sh[5] * nz - 2.0 * sh[6] * ny - 2.0 * sh[8] * ny;
-    q.dLs[2] = sh[2] + sh[5] * ny + 4.0 * sh[6] * nz + sh[7] * nx;
+    const double Ls = (double)sh[0] + (double)sh[1] * ny + (double)sh[2] * nz + (double)sh[3] * nx + (double)sh[4] * (nx * ny) + (double)sh[5] * (ny * nz) +
+                      (double)sh[6] * ((-(nx * nx)) - (ny * ny) + 2.0 * (nz * nz)) + (double)sh[7] * (nx * nz) + (double)sh[8] * ((nx * nx) - (ny * ny));
+    q.B = alb * Ls; q.Ls = (float)Ls;
+    const float fx = (float)nx, fy = (float)ny, fz = (float)nz;
+    q.n[0] = fx; q.n[1] = fy; q.n[2] = fz;
+    q.dLs[0] = sh[3] + sh[4] * fy - 2.0f * sh[6] * fx + sh[7] * fz + 2.0f * sh[8] * fx;
+    q.dLs[1] = sh[1] + sh[4] * fx + sh[5] * fz - 2.0f * sh[6] * fy - 2.0f * sh[8] * fy;
+    q.dLs[2] = sh[2] + sh[5] * fy + 4.0f * sh[6] * fz + sh[7] * fx;
 }
 
 // v -> (I - n n^T) v / |g|   (or v when |g| == 0)
-static __device__ inline void apply_normal_jac(const PointShared& q, const real v[3], real out[3]) {
-    if (q.inv_len == 0.0) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; return; }
-    const real d = q.n[0] * v[0] + q.n[1] * v[1] + q.n[2] * v[2];
+static __device__ inline void apply_normal_jac(const PointShared& q, const float v[3], float out[3]) {
+    if (q.inv_len == 0.0f) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; return; }
+    const float d = q.n[0] * v[0] + q.n[1] * v[1] + q.n[2] * v[2];
     out[0] = (v[0] - q.n[0] * d) * q.inv_len; out[1] = (v[1] - q.n[1] * d) * q.inv_len; out[2] = (v[2] - q.n[2] * d) * q.inv_len;
 }
 
-// [Ceres 2.1.0 cubic_interpolation.h] CubicHermiteSpline value + derivative
-static __device__ inline void hermite(real p0, real p1, real p2, real p3, real x, real& f, real& df) {
-    const real a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3);
-    const real b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3);
-    const real c = 0.5 * (-p0 + p2);
-    f = p1 + x * (c + x * (b + x * a));
-    df = c + x * (2.0 * b + 3.0 * a * x);
+// [Ceres 2.1.0 cubic_interpolation.h] CubicHermiteSpline
+template <class T> static __device__ inline T hermite_val(T p0, T p1, T p2, T p3, T x) {
+    const T a = (T)0.5 * (-p0 + (T)3.0 * p1 - (T)3.0 * p2 + p3);
+    const T b = (T)0.5 * ((T)2.0 * p0 - (T)5.0 * p1 + (T)4.0 * p2 - p3);
+    const T c = (T)0.5 * (-p0 + p2);
+    return p1 + x * (c + x * (b + x * a));
 }
-// BiCubicInterpolator::Evaluate(r = v, c = u) on a clamped Grid2D<float,1> (cost.h:108-127)
-static __device__ inline void bicubic(const float* __restrict__ img, int w, int h, real r, real c, real& f, real& dfdr, real& dfdc) {
+template <class T> static __device__ inline T hermite_der(T p0, T p1, T p2, T p3, T x) {
+    const T a = (T)0.5 * (-p0 + (T)3.0 * p1 - (T)3.0 * p2 + p3);
+    const T b = (T)0.5 * ((T)2.0 * p0 - (T)5.0 * p1 + (T)4.0 * p2 - p3);
+    const T c = (T)0.5 * (-p0 + p2);
+    return c + x * ((T)2.0 * b + (T)3.0 * a * x);
+}
+// BiCubicInterpolator::Evaluate(r = v, c = u) on a clamped Grid2D<float,1> (cost.h:108-127): value in fp64, derivatives in fp32
+template <bool WITH_J>
+static __device__ inline void bicubic(const float* __restrict__ img, int w, int h, double r, double c, double& f, float& dfdr, float& dfdc) {
     const int row = (int)floor(r), col = (int)floor(c);
-    const real xc = c - (real)col, xr = r - (real)row;
-    real fr[4], dc[4];
-    const int c0 = min(max(col - 1, 0), w - 1), c1 = min(max(col, 0), w - 1), c2 = min(max(col + 1, 0), w - 1), c3 = min(max(col + 2, 0), w - 1);
+    const double xc = c - (double)col, xr = r - (double)row;
+    float4 t[4];
+    const bool interior = col >= 1 && col + 2 <= w - 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rr = min(max(row - 1 + i, 0), h - 1);
         const float* line = img + (size_t)rr * w;
-        hermite((real)line[c0], (real)line[c1], (real)line[c2], (real)line[c3], xc, fr[i], dc[i]);
+        if (interior) { const F4U v = *reinterpret_cast<const F4U*>(line + (col - 1)); t[i] = make_float4(v.x, v.y, v.z, v.w); }
+        else t[i] = make_float4(line[min(max(col - 1, 0), w - 1)], line[min(max(col, 0), w - 1)], line[min(max(col + 1, 0), w - 1)], line[min(max(col + 2, 0), w - 1)]);
     }
-    real dummy;
-    hermite(fr[0], fr[1], fr[2], fr[3], xr, f, dfdr);
-    hermite(dc[0], dc[1], dc[2], dc[3], xr, dfdc, dummy);
+    double fr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fr[i] = hermite_val<double>((double)t[i].x, (double)t[i].y, (double)t[i].z, (double)t[i].w, xc);
+    f = hermite_val<double>(fr[0], fr[1], fr[2], fr[3], xr);
+    if (WITH_J) {
+        const float xcf = (float)xc, xrf = (float)xr;
+        dfdr = hermite_der<float>((float)fr[0], (float)fr[1], (float)fr[2], (float)fr[3], xrf);
+        float dc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dc[i] = hermite_der<float>(t[i].x, t[i].y, t[i].z, t[i].w, xcf);
+        dfdc = hermite_val<float>(dc[0], dc[1], dc[2], dc[3], xrf);
+    }
 }
 
-struct PointFrame {     // per (point, keyframe)
-    real lum;
-    real dpose[6];      // d lum / d (omega, t)
-    real M[3];          // d lum / d P (world)
-    real dintr[4];      // d lum / d (fx,fy,cx,cy) level-0 parameters
-    real ddist[5];      // d lum / d (k1,k2,k3,p1,p2)
+struct PointVal {      // what phase 1 leaves for phase 2 (fp32)
+    float x0, y0, iz, dfdr, dfdc;
 };
 
 // camera.h:96-116 (always distorts; y uses the distorted x) + cost.h:80-127.  Returns false if the projection leaves the image.
 template <bool WITH_J>
-static __device__ inline bool eval_point(const PointShared& q, const FrameConst& fc, const OptParams& p, PointFrame& o) {
-    const real X = fc.R[0] * q.P[0] + fc.R[1] * q.P[1] + fc.R[2] * q.P[2] + fc.t[0];
-    const real Y = fc.R[3] * q.P[0] + fc.R[4] * q.P[1] + fc.R[5] * q.P[2] + fc.t[1];
-    const real Z = fc.R[6] * q.P[0] + fc.R[7] * q.P[1] + fc.R[8] * q.P[2] + fc.t[2];
-    const real ps = p.pyr_scale;
-    const real fx = p.intr[0] * ps, fy = p.intr[1] * ps, cxs = p.intr[2] * ps, cys = p.intr[3] * ps;
-    const real iz = 1.0 / Z;
-    const real x0 = X * iz, y0 = Y * iz;
-    const real r2 = x0 * x0 + y0 * y0, r4 = r2 * r2, r6 = r4 * r2;
-    const real k0 = p.dist[0], k1 = p.dist[1], k2 = p.dist[2], k3 = p.dist[3], k4 = p.dist[4];
-    const real dc = 1.0 + k0 * r2 + k1 * r4 + k2 * r6;
-    const real xd = x0 * dc + 2.0 * k3 * x0 * y0 + k4 * (r2 + 2.0 * x0 * x0);
-    const real yd = y0 * dc + 2.0 * k4 * xd * y0 + k3 * (r2 + 2.0 * y0 * y0);
-    const real u = fx * xd + cxs, v = fy * yd + cys;
-    if (u < 0.0 || u > (real)(fc.w - 1) || v < 0.0 || v > (real)(fc.h - 1)) return false;
+static __device__ inline bool eval_point(const double P[3], const double R[9], const double t[3], const float* __restrict__ img, const OptParams& p, double& lum, PointVal& o) {
+    const double X = R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + t[0];
+    const double Y = R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1];
+    const double Z = R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2];
+    const double ps = p.pyr_scale;
+    const double iz = 1.0 / Z;
+    const double x0 = X * iz, y0 = Y * iz;
+    const double r2 = x0 * x0 + y0 * y0, r4 = r2 * r2, r6 = r4 * r2;
+    const double dc = 1.0 + p.dist[0] * r2 + p.dist[1] * r4 + p.dist[2] * r6;
+    const double xd = x0 * dc + 2.0 * p.dist[3] * x0 * y0 + p.dist[4] * (r2 + 2.0 * x0 * x0);
+    const double yd = y0 * dc + 2.0 * p.dist[4] * xd * y0 + p.dist[3] * (r2 + 2.0 * y0 * y0);
+    const double u = (p.intr[0] * ps) * xd + p.intr[2] * ps, v = (p.intr[1] * ps) * yd + p.intr[3] * ps;
+    if (u < 0.0 || u > (double)(p.w - 1) || v < 0.0 || v > (double)(p.h - 1)) return false;
     if (!(u == u) || !(v == v)) return false;      // NaN coordinates: Ceres' comparisons are all false -> in-bounds -> NaN lum -> invalid row
-    real f, dfdr, dfdc;
-    bicubic(fc.lum, fc.w, fc.h, v, u, f, dfdr, dfdc);
-    o.lum = f;
-    if (!WITH_J) return true;
-    const real dcr = k0 + 2.0 * k1 * r2 + 3.0 * k2 * r4;                 // d dc / d r2
-    const real dxd_dx0 = dc + 2.0 * x0 * x0 * dcr + 2.0 * k3 * y0 + 6.0 * k4 * x0;
-    const real dxd_dy0 = 2.0 * x0 * y0 * dcr + 2.0 * k3 * x0 + 2.0 * k4 * y0;
-    const real dyd_dx0 = 2.0 * x0 * y0 * dcr + 2.0 * k4 * y0 * dxd_dx0 + 2.0 * k3 * x0;
-    const real dyd_dy0 = dc + 2.0 * y0 * y0 * dcr + 2.0 * k4 * (xd + y0 * dxd_dy0) + 6.0 * k3 * y0;
-    const real au = dfdc * fx, av = dfdr * fy;
-    const real lx = au * dxd_dx0 + av * dyd_dx0, ly = au * dxd_dy0 + av * dyd_dy0;
-    const real Lq[3] = {lx * iz, ly * iz, -(lx * x0 + ly * y0) * iz};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const real* d = fc.dR[i];
-        const real dX = d[0] * q.P[0] + d[1] * q.P[1] + d[2] * q.P[2];
-        const real dY = d[3] * q.P[0] + d[4] * q.P[1] + d[5] * q.P[2];
-        const real dZ = d[6] * q.P[0] + d[7] * q.P[1] + d[8] * q.P[2];
-        o.dpose[i] = Lq[0] * dX + Lq[1] * dY + Lq[2] * dZ;
-        o.dpose[3 + i] = Lq[i];
-        o.M[i] = Lq[0] * fc.R[i] + Lq[1] * fc.R[3 + i] + Lq[2] * fc.R[6 + i];
-    }
-    o.dintr[0] = dfdc * ps * xd; o.dintr[1] = dfdr * ps * yd; o.dintr[2] = dfdc * ps; o.dintr[3] = dfdr * ps;
-    const real dxk[5] = {x0 * r2, x0 * r4, x0 * r6, 2.0 * x0 * y0, r2 + 2.0 * x0 * x0};
-    const real c2 = 2.0 * k4 * y0;
-    const real dyk[5] = {y0 * r2 + c2 * dxk[0], y0 * r4 + c2 * dxk[1], y0 * r6 + c2 * dxk[2],
-                         c2 * dxk[3] + (r2 + 2.0 * y0 * y0), 2.0 * xd * y0 + c2 * dxk[4]};
-#pragma unroll
-    for (int i = 0; i < 5; ++i) o.ddist[i] = au * dxk[i] + av * dyk[i];
+    bicubic<WITH_J>(img, p.w, p.h, v, u, lum, o.dfdr, o.dfdc);
+    if (WITH_J) { o.x0 = (float)x0; o.y0 = (float)y0; o.iz = (float)iz; }
     return true;
 }
 
@@ -163,8 +156,20 @@ static __device__ inline void block_add(double v, double* dst) {
     __syncthreads();
 }
 
-template <bool WITH_J>
+// FR_LDS: the per-keyframe constants (144 B each) of ALL keyframes are staged in LDS once per workgroup — every row reads
+// R, t (and Jr) of its keyframe, and with them in global memory those wave-divergent gathers keep the texture-address unit busy.
+template <bool WITH_J, bool FR_LDS>
 __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out) {
+    extern __shared__ double frame_lds_raw[];
+    FrameHot* const flds = reinterpret_cast<FrameHot*>(frame_lds_raw);
+    if (FR_LDS) {
+        constexpr int WORDS = sizeof(FrameHot) / 8;
+        for (int i = threadIdx.x; i < p.K * WORDS; i += blockDim.x) {
+            const int f = i / WORDS, w = i - f * WORDS;
+            frame_lds_raw[(size_t)f * WORDS + w] = reinterpret_cast<const double*>(&frames[f].hot)[w];
+        }
+        __syncthreads();
+    }
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     double cost = 0.0;
     if (a < r.A) {
@@ -243,14 +248,14 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
         else any_row = nin > 0;
         int nout = 0;
         if (any_row) {
-            real sd[10];
+            double sd[10];
 #pragma unroll
             for (int c = 0; c < 10; ++c) sd[c] = g.x_sdf[idx[c]];
-            real sh[9];
+            float sh[9];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) sh[j] = (real)g.sh[(size_t)j * N + s];
+            for (int j = 0; j < 9; ++j) sh[j] = g.sh[(size_t)j * N + s];
             const int cx = g.cx[s], cy = g.cy[s], cz = g.cz[s];
-            const real vs = (real)g.voxel_size;
+            const double vs = (double)g.voxel_size;
             PointShared q[4];
             // sdf slots: 0:000 1:010 2:020 3:011 4:001 5:002 6:100 7:110 8:101 9:200 (shading_cost.h:88-97)
             shared_point(q[0], sd[0], sd[6], sd[1], sd[4], g.x_alb[idx[10]], sh, cx, cy, cz, vs);
@@ -268,6 +273,9 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
             const double weight_sdf = sdf_to_weight(xs, (double)g.truncation);
             // slot of (s, sx, sy, sz) for each point
             constexpr int PS[4][4] = {{0, 6, 1, 4}, {6, 9, 7, 8}, {1, 7, 2, 3}, {4, 8, 3, 5}};
+            const float psf = (float)p.pyr_scale;
+            const float fxs = (float)(p.intr[0] * p.pyr_scale), fys = (float)(p.intr[1] * p.pyr_scale);
+            const float k0 = (float)p.dist[0], k1 = (float)p.dist[1], k2 = (float)p.dist[2], k3 = (float)p.dist[3], k4 = (float)p.dist[4];
 
             for (int k = 0; k < nin; ++k) {
                 const size_t ka = (size_t)k * Acap + a;
@@ -275,41 +283,68 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
                 if (WITH_J) { const float ow = r.obs_w[ka]; f = r.obs_frame[ka]; roww = (ow > 0.0f) ? (float)((double)ow * weight_sdf) : 0.0f; }
                 else { const float4 m = r.rows[row_index(a, k, 7, r.slots)]; const int fb = __float_as_int(m.z); roww = (fb & ROW_FREE_BIT) ? m.x : 0.0f; f = fb & ~ROW_FREE_BIT; }
                 if (roww == 0.0f) continue;
-                const FrameConst& fc = frames[f];
-                PointFrame pf[4];
+                const FrameHot& fc = FR_LDS ? flds[f] : frames[f].hot;
+                // ---- phase 1: values (fp64) ----
+                double lum[4]; PointVal pv[4];
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ok = ok && eval_point<WITH_J>(q[j], fc, p, pf[j]);
-                real res = 0.0, c1 = 0, c2 = 0, c3 = 0;
+                for (int j = 0; j < 4; ++j) ok = ok && eval_point<WITH_J>(q[j].P, fc.R, fc.t, fc.lum, p, lum[j], pv[j]);
+                double res = 0.0; float cj[4] = {0, 0, 0, 0};
                 if (ok) {
-                    const real B0 = q[0].alb * q[0].Ls, B1 = q[1].alb * q[1].Ls, B2 = q[2].alb * q[2].Ls, B3 = q[3].alb * q[3].Ls;
-                    const real d1 = (B1 - B0) - (pf[1].lum - pf[0].lum), d2 = (B2 - B0) - (pf[2].lum - pf[0].lum), d3 = (B3 - B0) - (pf[3].lum - pf[0].lum);
+                    const double d1 = (q[1].B - q[0].B) - (lum[1] - lum[0]), d2 = (q[2].B - q[0].B) - (lum[2] - lum[0]), d3 = (q[3].B - q[0].B) - (lum[3] - lum[0]);
                     res = sqrt(d1 * d1 + d2 * d2 + d3 * d3);
                     if (!(res > 0.0) || isinf(res)) { ok = false; res = 0.0; }    // 0, NaN, inf -> NV_INVALID_RESIDUAL (shading_cost.h:186-195)
-                    else { const real ir = 1.0 / res; c1 = d1 * ir; c2 = d2 * ir; c3 = d3 * ir; }
+                    else { const double ir = 1.0 / res; cj[1] = (float)(d1 * ir); cj[2] = (float)(d2 * ir); cj[3] = (float)(d3 * ir); cj[0] = -(float)((d1 + d2 + d3) * ir); }
                 }
                 if (!WITH_J) { if (ok) cost += 0.5 * (double)roww * p.type_w[0] * res * res; continue; }
                 if (!ok) continue;                                                 // dropped at creation (shading_cost.cpp:136-145)
-                const real cj[4] = {-(c1 + c2 + c3), c1, c2, c3};
-                real J[P_TOTAL];
+                // ---- phase 2: partials (fp32), accumulated point by point ----
+                float J[P_TOTAL];
 #pragma unroll
-                for (int i = 0; i < P_TOTAL; ++i) J[i] = 0.0;
+                for (int i = 0; i < P_TOTAL; ++i) J[i] = 0.0f;
+                float Wx = 0.0f, Wy = 0.0f, Wz = 0.0f;                              // sum_j c_j (P_j x M_j): rotation part before Jr
+                const float R0 = (float)fc.R[0], R1 = (float)fc.R[1], R2 = (float)fc.R[2], R3 = (float)fc.R[3], R4 = (float)fc.R[4], R5 = (float)fc.R[5], R6 = (float)fc.R[6], R7 = (float)fc.R[7], R8 = (float)fc.R[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    const float x0 = pv[j].x0, y0 = pv[j].y0, iz = pv[j].iz;
+                    const float r2 = x0 * x0 + y0 * y0, r4 = r2 * r2, r6 = r4 * r2;
+                    const float dc = 1.0f + k0 * r2 + k1 * r4 + k2 * r6;
+                    const float dcr = k0 + 2.0f * k1 * r2 + 3.0f * k2 * r4;          // d dc / d r2
+                    const float xd = x0 * dc + 2.0f * k3 * x0 * y0 + k4 * (r2 + 2.0f * x0 * x0);
+                    const float yd = y0 * dc + 2.0f * k4 * xd * y0 + k3 * (r2 + 2.0f * y0 * y0);
+                    const float dxd_dx0 = dc + 2.0f * x0 * x0 * dcr + 2.0f * k3 * y0 + 6.0f * k4 * x0;
+                    const float dxd_dy0 = 2.0f * x0 * y0 * dcr + 2.0f * k3 * x0 + 2.0f * k4 * y0;
+                    const float dyd_dx0 = 2.0f * x0 * y0 * dcr + 2.0f * k4 * y0 * dxd_dx0 + 2.0f * k3 * x0;
+                    const float dyd_dy0 = dc + 2.0f * y0 * y0 * dcr + 2.0f * k4 * (xd + y0 * dxd_dy0) + 6.0f * k3 * y0;
+                    const float au = pv[j].dfdc * fxs, av = pv[j].dfdr * fys;
+                    const float lx = au * dxd_dx0 + av * dyd_dx0, ly = au * dxd_dy0 + av * dyd_dy0;
+                    const float L0 = lx * iz, L1 = ly * iz, L2 = -(lx * x0 + ly * y0) * iz;      // d lum / d Q
+                    const float M0 = L0 * R0 + L1 * R3 + L2 * R6, M1 = L0 * R1 + L1 * R4 + L2 * R7, M2 = L0 * R2 + L1 * R5 + L2 * R8;   // d lum / d P
+                    const float c = cj[j];
                     // E_j = B_j - lum_j;  dE/dg = alb * N dLs + s * N M,  dE/ds (direct) = M . n
-                    real v[3] = {q[j].alb * q[j].dLs[0] + q[j].s * pf[j].M[0], q[j].alb * q[j].dLs[1] + q[j].s * pf[j].M[1], q[j].alb * q[j].dLs[2] + q[j].s * pf[j].M[2]};
-                    real G[3]; apply_normal_jac(q[j], v, G);
-                    const real direct = pf[j].M[0] * q[j].n[0] + pf[j].M[1] * q[j].n[1] + pf[j].M[2] * q[j].n[2];
-                    J[PS[j][1]] += cj[j] * G[0]; J[PS[j][2]] += cj[j] * G[1]; J[PS[j][3]] += cj[j] * G[2];
-                    J[PS[j][0]] += cj[j] * (direct - (G[0] + G[1] + G[2]));
-                    J[P_ALB + j] = cj[j] * q[j].Ls;
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) J[P_POSE + i] -= cj[j] * pf[j].dpose[i];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) J[P_INTR + i] -= cj[j] * pf[j].dintr[i];
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) J[P_DIST + i] -= cj[j] * pf[j].ddist[i];
+                    const float v[3] = {q[j].alb * q[j].dLs[0] + q[j].s * M0, q[j].alb * q[j].dLs[1] + q[j].s * M1, q[j].alb * q[j].dLs[2] + q[j].s * M2};
+                    float G[3]; apply_normal_jac(q[j], v, G);
+                    const float direct = M0 * q[j].n[0] + M1 * q[j].n[1] + M2 * q[j].n[2];
+                    J[PS[j][1]] += c * G[0]; J[PS[j][2]] += c * G[1]; J[PS[j][3]] += c * G[2];
+                    J[PS[j][0]] += c * (direct - (G[0] + G[1] + G[2]));
+                    J[P_ALB + j] = c * q[j].Ls;
+                    // pose: d lum/d t = L ; d lum/d omega = (P x M)^T Jr
+                    J[P_POSE + 3] -= c * L0; J[P_POSE + 4] -= c * L1; J[P_POSE + 5] -= c * L2;
+                    const float Px = (float)q[j].P[0], Py = (float)q[j].P[1], Pz = (float)q[j].P[2];
+                    Wx += c * (Py * M2 - Pz * M1); Wy += c * (Pz * M0 - Px * M2); Wz += c * (Px * M1 - Py * M0);
+                    J[P_INTR + 0] -= c * pv[j].dfdc * psf * xd; J[P_INTR + 1] -= c * pv[j].dfdr * psf * yd;
+                    J[P_INTR + 2] -= c * pv[j].dfdc * psf;      J[P_INTR + 3] -= c * pv[j].dfdr * psf;
+                    const float dxk0 = x0 * r2, dxk1 = x0 * r4, dxk2 = x0 * r6, dxk3 = 2.0f * x0 * y0, dxk4 = r2 + 2.0f * x0 * x0;
+                    const float c2 = 2.0f * k4 * y0;
+                    J[P_DIST + 0] -= c * (au * dxk0 + av * (y0 * r2 + c2 * dxk0));
+                    J[P_DIST + 1] -= c * (au * dxk1 + av * (y0 * r4 + c2 * dxk1));
+                    J[P_DIST + 2] -= c * (au * dxk2 + av * (y0 * r6 + c2 * dxk2));
+                    J[P_DIST + 3] -= c * (au * dxk3 + av * (c2 * dxk3 + (r2 + 2.0f * y0 * y0)));
+                    J[P_DIST + 4] -= c * (au * dxk4 + av * (2.0f * xd * y0 + c2 * dxk4));
                 }
+                J[P_POSE + 0] = -(Wx * fc.Jr[0] + Wy * fc.Jr[3] + Wz * fc.Jr[6]);
+                J[P_POSE + 1] = -(Wx * fc.Jr[1] + Wy * fc.Jr[4] + Wz * fc.Jr[7]);
+                J[P_POSE + 2] = -(Wx * fc.Jr[2] + Wy * fc.Jr[5] + Wz * fc.Jr[8]);
                 bool fin = true;
 #pragma unroll
                 for (int i = 0; i < P_TOTAL; ++i) fin = fin && !(isnan(J[i]) || isinf(J[i]));
@@ -317,8 +352,8 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
                 // rows of a voxel are compacted into its first slots (creation order = ascending observation weight)
 #pragma unroll
                 for (int gq = 0; gq < 7; ++gq)
-                    r.rows[row_index(a, nout, gq, r.slots)] = make_float4((float)J[4 * gq], (float)J[4 * gq + 1], (float)J[4 * gq + 2], (float)J[4 * gq + 3]);
-                r.rows[row_index(a, nout, 7, r.slots)] = make_float4(roww, (float)res, __int_as_float(f | (vox_free ? ROW_FREE_BIT : 0)), (float)J[28]);
+                    r.rows[row_index(a, nout, gq, r.slots)] = make_float4(J[4 * gq], J[4 * gq + 1], J[4 * gq + 2], J[4 * gq + 3]);
+                r.rows[row_index(a, nout, 7, r.slots)] = make_float4(roww, (float)res, __int_as_float(f | (vox_free ? ROW_FREE_BIT : 0)), J[28]);
                 ++nout;
             }
         }
@@ -334,8 +369,14 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out) {
     if (r.A <= 0) return;
     const int blocks = (r.A + 255) / 256;
-    if (with_jacobian) k_build<true><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
-    else k_build<false><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
+    const size_t lds = (size_t)p.K * sizeof(FrameHot);
+    if (lds <= 48 * 1024) {
+        if (with_jacobian) k_build<true, true><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
+        else k_build<false, true><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
+    } else {
+        if (with_jacobian) k_build<true, false><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
+        else k_build<false, false><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
+    }
 }
 
 // nls_solver.cpp:379-394 — per-type sums of the row weights (sums[0..3]) and row counts (sums[4..7])

@@ -41,11 +41,16 @@ constexpr int ROW_FREE_BIT = 1 << 30;     // set in plane 7 .z when the row has 
 __host__ __device__ inline size_t row_index(size_t a, int k, int plane, int slots) { return ((((a >> 6) * (size_t)slots + (size_t)k) * ROW_PLANES + (size_t)plane) << 6) + (a & 63); }       // Eg rows kept per voxel (reference default num_observations = 5)
 
 // ---- per-keyframe constants, rebuilt on the host (fp64) once per outer iteration ----------------------------
+struct FrameHot {                  // what the build / cost kernels read per row: 144 B, staged in LDS for all keyframes
+    double R[9], t[3];             // ceres::AngleAxisRotatePoint as a matrix (row-major) + translation (value path, fp64)
+    float  Jr[9];                  // right Jacobian of the rotation: d(R P)/d omega_i = -R [P]x Jr e_i, i.e. Jr e_i = vee(R^T dR/d omega_i)
+    int    pad;
+    const float* lum;              // luminance image of the current pyramid level
+};
 struct FrameConst {
-    double R[9], t[3];             // ceres::AngleAxisRotatePoint as a matrix (row-major) + translation
-    double dR[3][9];               // d R / d omega_i
+    FrameHot hot;
     float  Rf[9], tf[3];           // math::poseVecAAToMat(...).cast<float>() (math.cpp:151-163) for the observation pass
-    const float* lum; const float* depth; const uint8_t* bgr;
+    const float* depth; const uint8_t* bgr;
     int w, h;
 };
 

@@ -98,17 +98,24 @@ void build_frame_consts(const i3d_context* c, int level, const double* poses, st
     for (int f = 0; f < c->K; ++f) {
         FrameConst& fc = out[f];
         const double* p = poses + 6 * f;
+        double dR[3][9];
         for (int col = 0; col < 3; ++col) {         // columns of R and dR/dw_i = rotation of the basis vectors
             double e[3] = {0, 0, 0}; e[col] = 1.0;
             D3 o[3]; rotate_dual(p, e, o);
-            for (int row = 0; row < 3; ++row) { fc.R[3 * row + col] = o[row].a; for (int i = 0; i < 3; ++i) fc.dR[i][3 * row + col] = o[row].v[i]; }
+            for (int row = 0; row < 3; ++row) { fc.hot.R[3 * row + col] = o[row].a; for (int i = 0; i < 3; ++i) dR[i][3 * row + col] = o[row].v[i]; }
         }
-        for (int i = 0; i < 3; ++i) fc.t[i] = p[3 + i];
+        for (int i = 0; i < 3; ++i) {               // Jr e_i = vee(R^T dR_i) (skew part; exact for a rotation matrix)
+            double Sk[9];
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double v = 0.0; for (int k = 0; k < 3; ++k) v += fc.hot.R[3 * k + a] * dR[i][3 * k + b]; Sk[3 * a + b] = v; }
+            fc.hot.Jr[0 * 3 + i] = (float)(0.5 * (Sk[7] - Sk[5])); fc.hot.Jr[1 * 3 + i] = (float)(0.5 * (Sk[2] - Sk[6])); fc.hot.Jr[2 * 3 + i] = (float)(0.5 * (Sk[3] - Sk[1]));
+        }
+        for (int i = 0; i < 3; ++i) fc.hot.t[i] = p[3 + i];
+        fc.hot.pad = 0;
         double Re[9]; pose_to_mat_eigen(p, Re);
         for (int i = 0; i < 9; ++i) fc.Rf[i] = (float)Re[i];
         for (int i = 0; i < 3; ++i) fc.tf[i] = (float)p[3 + i];
         const size_t k = (size_t)f * c->levels + level;
-        fc.lum = c->lum[k].p; fc.depth = c->depth[k].p; fc.bgr = c->bgr[k].p;
+        fc.hot.lum = c->lum[k].p; fc.depth = c->depth[k].p; fc.bgr = c->bgr[k].p;
         fc.w = c->fw[level]; fc.h = c->fh[level];
     }
 }
