@@ -135,10 +135,16 @@ def main():
     thres = args.shell * float(sc["voxel_size"])
     arrays = grid_arrays(sc)
 
-    if world > 1:
-        raise SystemExit("multi-GPU sharding is not wired into bench.py yet")
-
     ctx = binding.Context(local_rank)
+    if world > 1:
+        # one process per GPU: RCCL communicator of the library, bootstrapped through torch.distributed (unique id from rank 0)
+        uid = torch.zeros(256, dtype=torch.uint8, device="cuda")
+        n = torch.zeros(1, dtype=torch.int32, device="cuda")
+        if rank == 0:
+            b = binding.Context.comm_unique_id()
+            uid[:len(b)] = torch.tensor(list(b), dtype=torch.uint8, device="cuda"); n[0] = len(b)
+        dist.broadcast(uid, 0); dist.broadcast(n, 0)
+        ctx.comm_init(rank, world, bytes(uid[:int(n.item())].cpu().tolist()))
     t0 = time.time()
     ctx.set_grid(sc["voxel_size"], arrays["keys"], arrays["sdf"], arrays["sdf_refined"], arrays["albedo"], arrays["weight"], arrays["color"])
     ctx.set_frames(sc["frames"], 1)
@@ -196,7 +202,8 @@ def main():
             "metric": "Gauss-Newton iterations/s at the finest SDF level", "value": args.steps / dt, "unit": "GN iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic hashed SDF grid, {arrays['keys'].shape[0]} stored voxels @ {args.voxel_size * 1e3:g} mm "
+            "config": {"parallelism": f"{world} rank(s): replicated voxel state, row work and solver vectors sharded by contiguous work-list ranges, RCCL all-reduce (PCG scalars + camera block) and all-gather (operator input)",
+                       "workload": f"synthetic hashed SDF grid, {arrays['keys'].shape[0]} stored voxels @ {args.voxel_size * 1e3:g} mm "
                                    f"({A} in the thin shell), {args.frames} keyframes {args.width}x{args.height}, {args.subvolume} m SH subvolumes, "
                                    f"joint SDF+albedo+pose+intrinsics+distortion, 5 observations/voxel (BASELINE.json configs[3] on one node)",
                        "stored_voxels": int(arrays["keys"].shape[0]), "active_voxels": A, "rows": {"Eg": Rg, "Er": Rr, "Es": Rs, "Ea": Ra},

@@ -130,6 +130,21 @@ typedef struct { int64_t data_rows, reg_rows; int32_t subvolumes, lm_iterations,
 int i3d_estimate_sh(i3d_context* ctx, float subvolume_size, double lambda_reg, double thres_shell,
                     int32_t* num_subvolumes, double* sh, int32_t* sub_index, int32_t cap, i3d_sh_stats* stats);
 
+/* ---- one process per GPU: the voxel state is replicated, row work / row storage / solver vectors are sharded by contiguous
+ * work-list ranges; RCCL carries the PCG scalars, the camera block and the per-iteration vector exchange.  Call after i3d_create
+ * on every rank with the same unique id (i3d_comm_unique_id on rank 0, broadcast by the launcher, e.g. torch.distributed). */
+int i3d_comm_unique_id(void* out128, int32_t* bytes);
+int i3d_comm_init(i3d_context* ctx, int32_t rank, int32_t world, const void* unique_id, int32_t id_bytes);
+/* single-GPU simulation of W ranks (W host threads, one context each, same device) — test vehicle for the SPMD control flow */
+void* i3d_comm_sim_create(int32_t world);
+void  i3d_comm_sim_destroy(void* shared);
+int   i3d_comm_init_sim(i3d_context* ctx, void* shared, int32_t rank);
+/* host-side view of the sharding plan (no device needed): owned range and vector layout of `rank`, and which work-list entries
+ * it must compute rows for.  anbr: [18][A] neighbour table in work-list space (-1 = none), active: [A]. */
+int   i3d_shard_plan(int32_t A, int32_t world, int32_t rank, const int32_t* anbr, const uint8_t* active,
+                     int32_t* chunk, int32_t* own0, int32_t* own1, uint8_t* in_compute_list /*[A]*/);
+int32_t i3d_shard_vec_index(int32_t a, int32_t chunk, int32_t albedo);
+
 /* ---- measurement: HIP-event time (ms) and launch count accumulated per kernel family on the context's stream
  * since the last reset.  names: see i3d_kernel_name(). */
 enum { I3D_K_CLASSIFY = 0, I3D_K_OBSERVE, I3D_K_BUILD, I3D_K_EG_PASS, I3D_K_GATHER, I3D_K_COST, I3D_K_VECTOR, I3D_K_SH, I3D_K_COUNT };

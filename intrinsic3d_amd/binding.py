@@ -51,6 +51,7 @@ class GridView(C.Structure):
 EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_set_grid", "i3d_get_grid", "i3d_update_grid",
            "i3d_set_frames", "i3d_set_camera", "i3d_get_camera", "i3d_set_voxel_sh", "i3d_get_voxel_sh",
            "i3d_optimizer_config_default", "i3d_optimize", "i3d_optimize_host", "i3d_estimate_sh",
+           "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_timing_enable", "i3d_timing_get", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
            "i3d_debug_normal_eq", "i3d_debug_jtj_apply"]
@@ -84,6 +85,13 @@ def load():
     L.i3d_optimize.restype = i32; L.i3d_optimize.argtypes = [vp, C.POINTER(OptimizerConfig), vp]
     L.i3d_estimate_sh.restype = i32
     L.i3d_estimate_sh.argtypes = [vp, f32, f64, f64, C.POINTER(i32), vp, vp, i32, C.POINTER(ShStats)]
+    L.i3d_comm_unique_id.restype = i32; L.i3d_comm_unique_id.argtypes = [vp, C.POINTER(i32)]
+    L.i3d_comm_init.restype = i32; L.i3d_comm_init.argtypes = [vp, i32, i32, vp, i32]
+    L.i3d_comm_sim_create.restype = vp; L.i3d_comm_sim_create.argtypes = [i32]
+    L.i3d_comm_sim_destroy.argtypes = [vp]
+    L.i3d_comm_init_sim.restype = i32; L.i3d_comm_init_sim.argtypes = [vp, vp, i32]
+    L.i3d_shard_plan.restype = i32; L.i3d_shard_plan.argtypes = [i32, i32, i32, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), vp]
+    L.i3d_shard_vec_index.restype = i32; L.i3d_shard_vec_index.argtypes = [i32, i32, i32]
     L.i3d_timing_enable.restype = i32; L.i3d_timing_enable.argtypes = [vp, i32]
     L.i3d_timing_get.restype = i32; L.i3d_timing_get.argtypes = [vp, vp, vp, i32]
     L.i3d_kernel_name.restype = C.c_char_p; L.i3d_kernel_name.argtypes = [i32]
@@ -199,6 +207,21 @@ class Context:
         c = None if color is None else np.ascontiguousarray(color, np.uint8)
         self._check(self.L.i3d_update_grid(self.h, _p(a), _p(b), _p(c)), "i3d_update_grid")
 
+    # ---- sharding -----------------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(256); n = C.c_int32(0)
+        rc = load().i3d_comm_unique_id(buf, C.byref(n))
+        if rc != 0:
+            raise I3DError(f"i3d_comm_unique_id failed ({rc})")
+        return buf.raw[:n.value]
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        self._check(self.L.i3d_comm_init(self.h, int(rank), int(world), unique_id, len(unique_id)), "i3d_comm_init")
+
+    def comm_init_sim(self, shared, rank: int):
+        self._check(self.L.i3d_comm_init_sim(self.h, shared, int(rank)), "i3d_comm_init_sim")
+
     # ---- the path ------------------------------------------------------------------------------------------
     def optimize(self, cfg: OptimizerConfig):
         stats = (IterationStats * cfg.iterations)()
@@ -263,3 +286,13 @@ class Context:
         x = np.ascontiguousarray(x, np.float64); y = np.zeros_like(x)
         self._check(self.L.i3d_debug_jtj_apply(self.h, _p(x), _p(y)), "i3d_debug_jtj_apply")
         return y
+
+
+def shard_plan(A, world, rank, anbr, active):
+    """Host-side sharding plan (no GPU): returns chunk, own0, own1 and the compute-list mask of `rank`."""
+    anbr = np.ascontiguousarray(anbr, np.int32); active = np.ascontiguousarray(active, np.uint8)
+    ch = C.c_int32(); o0 = C.c_int32(); o1 = C.c_int32(); mask = np.zeros(A, np.uint8)
+    rc = load().i3d_shard_plan(int(A), int(world), int(rank), _p(anbr), _p(active), C.byref(ch), C.byref(o0), C.byref(o1), _p(mask))
+    if rc != 0:
+        raise I3DError(f"i3d_shard_plan failed ({rc})")
+    return ch.value, o0.value, o1.value, mask.astype(bool)

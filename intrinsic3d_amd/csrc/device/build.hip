@@ -170,9 +170,11 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
         }
         __syncthreads();
     }
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = ci < r.nC ? (r.clist ? r.clist[ci] : ci) : -1;      // compute list of this rank (identity when not sharded)
+    const bool owned = a >= r.own0 && a < r.own1;                     // cost / weight sums count every row once: on its owner
     double cost = 0.0;
-    if (a < r.A) {
+    if (a >= 0 && (WITH_J || owned)) {
         const int N = g.N; const size_t Acap = r.Acap;
         const int s = r.alist[a];
         const uint8_t fl = r.aflags[a];
@@ -367,8 +369,8 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
 }
 
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out) {
-    if (r.A <= 0) return;
-    const int blocks = (r.A + 255) / 256;
+    if (r.nC <= 0) return;
+    const int blocks = (r.nC + 255) / 256;
     const size_t lds = (size_t)p.K * sizeof(FrameHot);
     if (lds <= 48 * 1024) {
         if (with_jacobian) k_build<true, true><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
@@ -381,9 +383,9 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
 
 // nls_solver.cpp:379-394 — per-type sums of the row weights (sums[0..3]) and row counts (sums[4..7])
 __global__ void __launch_bounds__(256) k_weight_sums(RowView r, double* sums) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = r.own0 + blockIdx.x * blockDim.x + threadIdx.x;      // owned range only
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0, n0 = 0, n3 = 0, na = 0;
-    if (a < r.A && (r.aflags[a] & F_ACTIVE)) {
+    if (a < r.own1 && a < r.A && (r.aflags[a] & F_ACTIVE)) {
         na = 1.0;
         const int nr = r.nrows[a];
         for (int k = 0; k < nr; ++k) { const float w = r.rows[row_index(a, k, 7, r.slots)].x; s0 += (double)w; if (w != 0.0f) n0 += 1.0; }
@@ -396,7 +398,8 @@ __global__ void __launch_bounds__(256) k_weight_sums(RowView r, double* sums) {
     block_add(n0, sums + 4); block_add(n3, sums + 7); block_add(na, sums + 8);
 }
 void launch_weight_sums(hipStream_t st, RowView r, double* sums9) {
-    if (r.A > 0) k_weight_sums<<<(r.A + 255) / 256, 256, 0, st>>>(r, sums9);
+    const int n = r.own1 - r.own0;
+    if (n > 0) k_weight_sums<<<(n + 255) / 256, 256, 0, st>>>(r, sums9);
 }
 
 }  // namespace i3d

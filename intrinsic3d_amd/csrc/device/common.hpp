@@ -70,8 +70,35 @@ struct GridView {
     int* aidx;                      // device index -> active index or -1
 };
 
+// ---- sharding (one process per GPU) -------------------------------------------------------------------------
+// The voxel state, flags and work list are REPLICATED on every rank (a few hundred bytes per voxel against 288 GB of HBM);
+// what is sharded is the row work + row storage and the solver vectors: rank k OWNS the contiguous work-list range
+// [k*chunk, (k+1)*chunk) and computes rows for its compute list = owned entries + the entries whose rows its owned unknowns pull from.
+// Solver vectors are laid out rank-major so that a rank's slice is contiguous (in-place all-gather):
+//   [ rank0: sdf(chunk) alb(chunk) | rank1: sdf(chunk) alb(chunk) | ... | poses 6K | intrinsics 4 | distortion 5 ]
+// With one rank chunk >= A and this is the plain [sdf A.. | alb A.. | camera] layout.
+__host__ __device__ inline int vec_sdf(int a, int chunk) { const int k = a / chunk; return k * 2 * chunk + (a - k * chunk); }
+__host__ __device__ inline int vec_alb(int a, int chunk) { return vec_sdf(a, chunk) + chunk; }
+
+// does rank [own0, own1) need the rows of work-list entry a?  (owned, or an owned unknown is one of its ring / forward-stencil columns)
+__host__ __device__ inline bool shard_needs_entry(int a, int own0, int own1, bool active, const int* anbr, size_t stride) {
+    if (a >= own0 && a < own1) return true;
+    if (!active) return false;
+    bool need = false;
+    for (int i = 0; i < 12; ++i) { const int la = anbr[(size_t)i * stride + a]; need |= (la >= own0 && la < own1); }   // ring 0..5, forward stencil 0,2,4,6..11
+    return need;
+}
+__host__ __device__ inline void shard_range(int A, int world, int rank, int& chunk, int& own0, int& own1) {
+    chunk = (A + world - 1) / world; if (chunk < 1) chunk = 1;
+    own0 = rank * chunk < A ? rank * chunk : A; own1 = (rank + 1) * chunk < A ? (rank + 1) * chunk : A;
+}
+
 struct RowView {                    // per work-list entry a in [0, A): voxels that are active (own rows) or free (own unknowns)
     int A; int Acap; int slots;
+    int chunk;                      // entries per rank in the vector layout (>= A when not sharded)
+    int world;                      // number of ranks
+    int own0, own1;                 // owned work-list range of this rank
+    const int* clist; int nC;       // compute list (ascending work-list indices), nullptr = identity over [0, A)
     const int* alist;               // list index -> device voxel index (ascending)
     const uint8_t* aflags;          // voxel flags of the entry
     const int* anbr;                // [NUM_NBR][Acap] neighbour table in LIST space (-1 = neighbour not in the list => fixed, contributes 0)

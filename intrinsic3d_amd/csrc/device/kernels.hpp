@@ -42,7 +42,7 @@ struct PassBuffers {
 void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u /*[NP] or null*/, PassBuffers b, const PcgState* state);
 void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out /*[2A]*/);
 void launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_out, const PcgState* state);
-void launch_shared_finalize(hipStream_t st, int A, int K, OptParams p, const double* shared, float* out /*[NP]*/, bool tail, const float* S, const float* D2,
+void launch_shared_finalize(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, float* out /*[NP]*/, bool tail, const float* S, const float* D2,
                             const float* v, double* dot_out, const PcgState* state);
 
 void launch_fill(hipStream_t st, int n, float* x, float v);
@@ -55,9 +55,10 @@ void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask /*[NP]*
 
 // fused PCG iteration, scalars resident in PcgState
 void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations);
-void launch_pcg_precond(hipStream_t st, int A, int K, const float* Minv, const float* Minv_blocks, const float* r, float* z, PcgState* state);   // z = M^-1 r, rho, beta
+void launch_pcg_precond_slice(hipStream_t st, size_t off, int n, const float* Minv, const float* r, float* z, PcgState* state);                    // z = M^-1 r on a slice, partial rho
+void launch_pcg_precond_tail(hipStream_t st, size_t tail_off, int K, const float* Minv_blocks, const float* r, float* z, PcgState* state);    // camera blocks (after the rho reduction), beta
 void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state);                  // p = z + beta p, u = S p
-void launch_pcg_scalar2(hipStream_t st, PcgState* state);                                                                                       // alpha = rho / pq
+void launch_pcg_scalar2(hipStream_t st, PcgState* state, const double* pq_src);                                                                                       // alpha = rho / pq
 void launch_pcg_update(hipStream_t st, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, int reset_phase, PcgState* state);
 void launch_pcg_reset_r(hipStream_t st, int n, const float* x, const float* tmp, float* r, const float* b, const float* D2, PcgState* state);
 void launch_pcg_scalar3(hipStream_t st, PcgState* state);                                                                                       // Q-test, bookkeeping
@@ -65,5 +66,7 @@ void launch_pcg_scalar3(hipStream_t st, PcgState* state);                       
 void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* x_shared, double* xc_sdf, double* xc_alb,
                       double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask);
 void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb);           // x <- candidate, refresh fp32 shadows
+void launch_mark_compute(hipStream_t st, RowView r, int* flag);
+void launch_compact_list(hipStream_t st, int A, const int* flag, const int* scan, int* list);
 
 }  // namespace i3d

@@ -14,8 +14,9 @@ namespace i3d {
 
 template <int SLOTS, bool KEEP_ALL>
 __global__ void __launch_bounds__(256) k_observe(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= r.A) return;
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= r.nC) return;
+    const int a = r.clist ? r.clist[ci] : ci;           // compute list of this rank (identity when not sharded)
     const int N = g.N;
     const int s = r.alist[a];
     if (!(r.aflags[a] & F_ACTIVE)) {          // free-only entry of the work list: owns unknowns but no rows
@@ -100,13 +101,13 @@ __global__ void __launch_bounds__(256) k_observe(GridView g, RowView r, OptParam
 }
 
 template <int S> static void launch_s(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* fr, bool keep_all) {
-    const int blocks = (r.A + 255) / 256;
+    const int blocks = (r.nC + 255) / 256;
     if (keep_all) k_observe<S, true><<<blocks, 256, 0, st>>>(g, r, p, fr);
     else k_observe<S, false><<<blocks, 256, 0, st>>>(g, r, p, fr);
 }
 
 void launch_observe(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames) {
-    if (r.A <= 0) return;
+    if (r.nC <= 0) return;
     const bool keep_all = r.slots >= p.K;
     switch (r.slots) {
         case 1: launch_s<1>(st, g, r, p, frames, keep_all); break;

@@ -53,7 +53,9 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
     const int nacc = (MODE == PASS_COLNORM) ? (nshared + 21 * K + 25) : (reps * 6 * K + 9);
     for (int i = threadIdx.x; i < nacc; i += EG_THREADS) lds[i] = 0.0f;
     float* upose = lds + nacc;            // JTJP: the 6K+9 camera entries of u (every row reads 6+9 of them)
-    if (MODE == PASS_JTJP) for (int i = threadIdx.x; i < nshared; i += EG_THREADS) upose[i] = u[2 * (size_t)A + i];
+    const size_t tail = (size_t)r.world * 2 * (size_t)r.chunk;          // camera part of every solver vector
+    const int chunk = r.chunk;
+    if (MODE == PASS_JTJP) for (int i = threadIdx.x; i < nshared; i += EG_THREADS) upose[i] = u[tail + i];
     __syncthreads();
     float* const cam_acc = lds + ((MODE == PASS_COLNORM) ? 6 * K : reps * 6 * K);
     float* const pose_acc = lds + ((MODE == PASS_COLNORM) ? 0 : (threadIdx.x & (reps - 1)) * (6 * K));
@@ -61,12 +63,15 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
 #pragma unroll
     for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
     const float tw0 = (float)p.type_w[0];
-    const int ntiles = (A + EG_THREADS - 1) / EG_THREADS;
+    const int nC = r.nC;
+    const int ntiles = (nC + EG_THREADS - 1) / EG_THREADS;
     const int tile0 = blockIdx.x * tiles_per_block;
 
     for (int tile = tile0; tile < tile0 + tiles_per_block && tile < ntiles; ++tile) {
-        const int a = tile * EG_THREADS + threadIdx.x;
-        const bool in = a < A;
+        const int ci = tile * EG_THREADS + threadIdx.x;
+        const bool in = ci < nC;
+        const int a = in ? (r.clist ? r.clist[ci] : ci) : 0;         // compute list of this rank (identity when not sharded)
+        const bool owned = in && a >= r.own0 && a < r.own1;           // camera columns are accumulated once: by the row's owner
         const uint8_t fl = in ? r.aflags[a] : 0;
         const int nr = (in && (fl & F_ACTIVE)) ? (int)r.nrows[a] : 0;
         // wave-uniform row count so that the row loads are unconditional and batched
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
             for (int c = 0; c < P_VOX; ++c) {
                 const int nb = slot_fwd_nbr(c);
                 const int la = nb < 0 ? a : r.anbr[(size_t)nb * Acap + a];
-                uv[c] = la >= 0 ? u[(c < 10 ? 0 : A) + la] : 0.0f;
+                uv[c] = la >= 0 ? u[c < 10 ? vec_sdf(la, chunk) : vec_alb(la, chunk)] : 0.0f;
             }
         }
         const size_t ac = in ? (size_t)a : 0;
@@ -104,6 +109,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                 if (MODE == PASS_COLNORM) {
 #pragma unroll
                     for (int c = 0; c < P_VOX; ++c) acc[c] += rho * J[c] * J[c];
+                  if (owned) {
                     float* bl = lds + nshared;
                     int o = 0;
 #pragma unroll
@@ -126,6 +132,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
 #pragma unroll
                         for (int j = i; j < 5; ++j) { atomicAdd(&bl[21 * K + 10 + o], rho * J[P_DIST + i] * J[P_DIST + j]); ++o; }
                     }
+                  }
                 } else {
                     float t;
                     if (MODE == PASS_GRAD) t = rho * m.y;
@@ -143,12 +150,14 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                     }
 #pragma unroll
                     for (int c = 0; c < P_VOX; ++c) acc[c] += J[c] * t;
-                    if (!p.fix_poses) {
+                    if (!p.fix_poses && owned) {
 #pragma unroll
                         for (int i = 0; i < 6; ++i) atomicAdd(&pose_acc[6 * f + i], J[P_POSE + i] * t);
                     }
+                    if (owned) {
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) cam9[i] += J[P_INTR + i] * t;     // intrinsics + distortion: registers across all tiles, reduced once below
+                        for (int i = 0; i < 9; ++i) cam9[i] += J[P_INTR + i] * t;
+                    }     // intrinsics + distortion: registers across all tiles, reduced once below
                 }
             }
         }
@@ -171,9 +180,9 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                     const double dxx = nbv[0] + nbv[1] - 2.0 * xs, dyy = nbv[2] + nbv[3] - 2.0 * xs, dzz = nbv[4] + nbv[5] - 2.0 * xs;
                     tr = rho * (float)(dxx + dyy + dzz);
                 } else {
-                    float d = -6.0f * u[a];
+                    float d = -6.0f * u[vec_sdf(a, chunk)];
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) { const int la = r.anbr[(size_t)q * Acap + a]; if (la >= 0) d += u[la]; }
+                    for (int q = 0; q < 6; ++q) { const int la = r.anbr[(size_t)q * Acap + a]; if (la >= 0) d += u[vec_sdf(la, chunk)]; }
                     tr = rho * d;
                 }
             }
@@ -181,7 +190,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                 const float rho = (float)p.type_w[2];
                 if (MODE == PASS_COLNORM) ts = rho;
                 else if (MODE == PASS_GRAD) ts = rho * (float)(g.x_sdf[s] - g.sdf0[s]);
-                else ts = rho * u[a];
+                else ts = rho * u[vec_sdf(a, chunk)];
             }
             b.treg[a] = tr; b.treg[Acap + a] = ts;
 #pragma unroll
@@ -192,7 +201,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                     const float rho = w * (float)p.type_w[3];
                     if (MODE == PASS_COLNORM) ta = rho;
                     else if (MODE == PASS_GRAD) ta = rho * (float)(g.x_alb[s] - g.x_alb[g.nbr[(size_t)d * N + s]]);
-                    else { const int la = r.anbr[(size_t)d * Acap + a]; ta = rho * (u[A + a] - (la >= 0 ? u[A + la] : 0.0f)); }
+                    else { const int la = r.anbr[(size_t)d * Acap + a]; ta = rho * (u[vec_alb(a, chunk)] - (la >= 0 ? u[vec_alb(la, chunk)] : 0.0f)); }
                 }
                 b.treg[(size_t)(2 + d) * Acap + a] = ta;
             }
@@ -222,10 +231,10 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
 }
 
 void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u, PassBuffers b, const PcgState* state) {
-    if (r.A <= 0) return;
+    if (r.nC <= 0) return;
     static int num_cu = 0;
     if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    const int ntiles = (r.A + EG_THREADS - 1) / EG_THREADS;
+    const int ntiles = (r.nC + EG_THREADS - 1) / EG_THREADS;
     const int blocks = ntiles < num_cu ? ntiles : num_cu;                 // one persistent workgroup per CU
     const int tiles_per_block = (ntiles + blocks - 1) / blocks;
     const int nshared = 6 * p.K + 9;
@@ -253,10 +262,10 @@ __global__ void __launch_bounds__(256) k_gather(RowView r, PassBuffers b, float*
                                                 const float* __restrict__ D2, const float* __restrict__ v, double* dot_out,
                                                 const PcgState* __restrict__ state) {
     if (state && state->done) return;
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = r.own0 + blockIdx.x * blockDim.x + threadIdx.x;       // owned range of this rank
     const int A = r.A; const size_t Acap = r.Acap;
     double dotp = 0.0;
-    if (a < A) {
+    if (a < r.own1 && a < A) {
         const uint8_t fl = r.aflags[a];
         float osdf = 0.0f, oalb = 0.0f;
         if (fl & (F_FREE_SDF | F_FREE_ALB)) {
@@ -294,28 +303,31 @@ __global__ void __launch_bounds__(256) k_gather(RowView r, PassBuffers b, float*
                 oalb = acc;
             }
         }
+        const int js = vec_sdf(a, r.chunk), ja = js + r.chunk;
         if (TAIL) {
-            const float v0 = v[a], v1 = v[A + a];
-            osdf = S[a] * osdf + D2[a] * v0; oalb = S[A + a] * oalb + D2[A + a] * v1;
+            const float v0 = v[js], v1 = v[ja];
+            osdf = S[js] * osdf + D2[js] * v0; oalb = S[ja] * oalb + D2[ja] * v1;
             dotp = (double)v0 * (double)osdf + (double)v1 * (double)oalb;
         }
-        out[a] = osdf; out[A + a] = oalb;
+        out[js] = osdf; out[ja] = oalb;
     }
     if (TAIL && dot_out) block_add_d(dotp, dot_out);
 }
 void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out) {
-    if (r.A <= 0) return;
-    const int blocks = (r.A + 255) / 256;
+    const int n = (r.own1 < r.A ? r.own1 : r.A) - r.own0;
+    if (n <= 0) return;
+    const int blocks = (n + 255) / 256;
     if (mode == PASS_COLNORM) k_gather<true, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, nullptr);
     else k_gather<false, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 void launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_out, const PcgState* state) {
-    if (r.A <= 0) return;
-    k_gather<false, true><<<(r.A + 255) / 256, 256, 0, st>>>(r, b, out, S, D2, v, dot_out, state);
+    const int n = (r.own1 < r.A ? r.own1 : r.A) - r.own0;
+    if (n <= 0) return;
+    k_gather<false, true><<<(n + 255) / 256, 256, 0, st>>>(r, b, out, S, D2, v, dot_out, state);
 }
 
 // camera tail of the vectors: out[2A + i] from the fp64 accumulators; TAIL as above
-__global__ void k_shared_finalize(int A, int K, OptParams p, const double* __restrict__ shared, float* __restrict__ out, int tail,
+__global__ void k_shared_finalize(size_t tail_off, int K, OptParams p, const double* __restrict__ shared, float* __restrict__ out, int tail,
                                   const float* __restrict__ S, const float* __restrict__ D2, const float* __restrict__ v, double* dot_out,
                                   const PcgState* __restrict__ state) {
     if (state && state->done) return;
@@ -324,15 +336,15 @@ __global__ void k_shared_finalize(int A, int K, OptParams p, const double* __res
     if (i < 6 * K + 9) {
         const bool fixed = i < 6 * K ? p.fix_poses : (i < 6 * K + 4 ? p.fix_intr : p.fix_dist);
         float o = fixed ? 0.0f : (float)shared[i];
-        const size_t j = 2 * (size_t)A + i;
+        const size_t j = tail_off + i;
         if (tail) { const float vv = v[j]; o = S[j] * o + D2[j] * vv; dotp = (double)vv * (double)o; }
         out[j] = o;
     }
     if (tail && dot_out) block_add_d(dotp, dot_out);
 }
-void launch_shared_finalize(hipStream_t st, int A, int K, OptParams p, const double* shared, float* out, bool tail, const float* S, const float* D2,
+void launch_shared_finalize(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, float* out, bool tail, const float* S, const float* D2,
                             const float* v, double* dot_out, const PcgState* state) {
-    k_shared_finalize<<<(6 * K + 9 + 255) / 256, 256, 0, st>>>(A, K, p, shared, out, tail ? 1 : 0, S, D2, v, dot_out, state);
+    k_shared_finalize<<<(6 * K + 9 + 255) / 256, 256, 0, st>>>(tail_off, K, p, shared, out, tail ? 1 : 0, S, D2, v, dot_out, state);
 }
 
 // ---- vector helpers -------------------------------------------------------------------------------------------------
@@ -361,18 +373,21 @@ void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float
 void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out) { if (n > 0) k_dot<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, a, b, out); }
 
 __global__ void k_freemask(RowView r, OptParams p, float* __restrict__ mask) {
-    const int A = r.A, NP = 2 * A + 6 * p.K + 9;
+    const int A = r.A, chunk = r.chunk, nv = r.world * 2 * chunk, NP = nv + 6 * p.K + 9;
     GRID_STRIDE(NP) {
         float m;
-        if (i < A) m = (r.aflags[i] & F_FREE_SDF) ? 1.0f : 0.0f;
-        else if (i < 2 * A) m = (r.aflags[i - A] & F_FREE_ALB) ? 1.0f : 0.0f;
-        else if (i < 2 * A + 6 * p.K) m = p.fix_poses ? 0.0f : 1.0f;
-        else if (i < 2 * A + 6 * p.K + 4) m = p.fix_intr ? 0.0f : 1.0f;
+        if (i < nv) {                                   // rank-major layout: [rank][sdf chunk | alb chunk]; padding entries are fixed
+            const int k = i / (2 * chunk), rem = i - k * 2 * chunk;
+            const int a = k * chunk + (rem < chunk ? rem : rem - chunk);
+            m = (a < A && (r.aflags[a] & (rem < chunk ? F_FREE_SDF : F_FREE_ALB))) ? 1.0f : 0.0f;
+        }
+        else if (i < nv + 6 * p.K) m = p.fix_poses ? 0.0f : 1.0f;
+        else if (i < nv + 6 * p.K + 4) m = p.fix_intr ? 0.0f : 1.0f;
         else m = p.fix_dist ? 0.0f : 1.0f;
         mask[i] = m;
     }
 }
-void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask) { k_freemask<<<vblocks(2 * r.A + 6 * p.K + 9), 256, 0, st>>>(r, p, mask); }
+void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask) { k_freemask<<<vblocks(r.world * 2 * r.chunk + 6 * p.K + 9), 256, 0, st>>>(r, p, mask); }
 
 // ---- fused PCG iteration (conjugate_gradients_solver.cc) -------------------------------------------------------------
 // (1) z = M^-1 r on the voxel part (1x1 blocks) and rho += r.z ; the camera blocks go through k_pcg_precond_shared
@@ -382,7 +397,7 @@ __global__ void __launch_bounds__(256) k_pcg_precond(int n2, const float* __rest
     GRID_STRIDE(n2) { const float ri = r[i], zi = Minv[i] * ri; z[i] = zi; s += (double)ri * (double)zi; }
     block_add_d(s, &state->rho);
 }
-__global__ void k_pcg_precond_shared(int A, int K, const float* __restrict__ Minv, const float* __restrict__ r, float* __restrict__ z, PcgState* state) {
+__global__ void k_pcg_precond_shared(size_t tail_off, int K, const float* __restrict__ Minv, const float* __restrict__ r, float* __restrict__ z, PcgState* state) {
     if (state->done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double dotp = 0.0;
@@ -391,10 +406,10 @@ __global__ void k_pcg_precond_shared(int A, int K, const float* __restrict__ Min
         if (i < 6 * K) { const int f = i / 6; base = 6 * f; n = 6; row = i - base; M = Minv + 36 * f; }
         else if (i < 6 * K + 4) { base = 6 * K; n = 4; row = i - base; M = Minv + 36 * K; }
         else { base = 6 * K + 4; n = 5; row = i - base; M = Minv + 36 * K + 16; }
-        const float* rs = r + 2 * (size_t)A;
+        const float* rs = r + tail_off;
         float s = 0.0f;
         for (int j = 0; j < n; ++j) s += M[row * n + j] * rs[base + j];
-        z[2 * (size_t)A + i] = s; dotp = (double)rs[i] * (double)s;
+        z[tail_off + i] = s; dotp = (double)rs[i] * (double)s;
     }
     block_add_d(dotp, &state->rho);
 }
@@ -414,9 +429,9 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int n, const float* __res
     GRID_STRIDE(n) { const float pi = first ? z[i] : z[i] + beta * p[i]; p[i] = pi; u[i] = S[i] * pi; }
 }
 // (4) eg_pass + gather_tail + shared_finalize give q and pq ; scalar step: alpha
-__global__ void k_pcg_scalar2(PcgState* st) {
+__global__ void k_pcg_scalar2(PcgState* st, const double* pq_src) {
     if (st->done) return;
-    const double pq = st->pq;
+    const double pq = pq_src ? *pq_src : st->pq;
     if (!(pq > 0.0) || isinf(pq)) { st->done = 2; return; }
     const double alpha = st->rho / pq;
     if (isinf(alpha)) { st->done = 2; return; }
@@ -464,13 +479,17 @@ __global__ void k_pcg_init(PcgState* st, int fixed_iterations, int max_iteration
 }
 
 void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations) { k_pcg_init<<<1, 1, 0, st>>>(state, fixed_iterations, max_iterations); }
-void launch_pcg_precond(hipStream_t st, int A, int K, const float* Minv, const float* Minv_blocks, const float* r, float* z, PcgState* state) {
-    if (A > 0) k_pcg_precond<<<vblocks(2 * A) > 1024 ? 1024 : vblocks(2 * A), 256, 0, st>>>(2 * A, Minv, r, z, state);
-    k_pcg_precond_shared<<<(6 * K + 9 + 255) / 256, 256, 0, st>>>(A, K, Minv_blocks, r, z, state);
+// voxel part of z = M^-1 r over [off, off+n) (a rank's slice), partial rho
+void launch_pcg_precond_slice(hipStream_t st, size_t off, int n, const float* Minv, const float* r, float* z, PcgState* state) {
+    if (n > 0) k_pcg_precond<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, Minv + off, r + off, z + off, state);
+}
+// camera blocks (replicated on every rank: call AFTER the slice partials have been reduced) + beta
+void launch_pcg_precond_tail(hipStream_t st, size_t tail_off, int K, const float* Minv_blocks, const float* r, float* z, PcgState* state) {
+    k_pcg_precond_shared<<<(6 * K + 9 + 255) / 256, 256, 0, st>>>(tail_off, K, Minv_blocks, r, z, state);
     k_pcg_scalar1<<<1, 1, 0, st>>>(state);
 }
 void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state) { if (n > 0) k_pcg_direction<<<vblocks(n), 256, 0, st>>>(n, z, p, S, u, state); }
-void launch_pcg_scalar2(hipStream_t st, PcgState* state) { k_pcg_scalar2<<<1, 1, 0, st>>>(state); }
+void launch_pcg_scalar2(hipStream_t st, PcgState* state, const double* pq_src) { k_pcg_scalar2<<<1, 1, 0, st>>>(state, pq_src); }
 void launch_pcg_update(hipStream_t st, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, int reset_phase, PcgState* state) {
     if (n > 0) k_pcg_update<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, p, q, x, r, b, D2, reset_phase, state);
 }
@@ -480,25 +499,34 @@ void launch_pcg_reset_r(hipStream_t st, int n, const float* x, const float* tmp,
 void launch_pcg_scalar3(hipStream_t st, PcgState* state) { k_pcg_scalar3<<<1, 1, 0, st>>>(state); }
 
 // ---- LM candidate / acceptance ------------------------------------------------------------------------------------------
-// candidate point x + S*step (TrustRegionMinimizer: delta = step .* jacobian_scaling), squared norms of delta and x over the free parameters
+// candidate point x + S*step (TrustRegionMinimizer: delta = step .* jacobian_scaling), squared norms of delta and x over the free
+// parameters.  Replicated: every rank holds the full step and S vectors (all-gathered) and updates the whole list.
 __global__ void __launch_bounds__(256) k_candidate(GridView g, RowView r, int K, float sign, const float* __restrict__ step, const float* __restrict__ S,
                                                    const double* __restrict__ xsh, double* xc_sdf, double* xc_alb, double* xc_sh,
                                                    double* norms2, const float* __restrict__ mask) {
-    const int A = r.A, NP = 2 * A + 6 * K + 9;
+    const int A = r.A, NS = 6 * K + 9, chunk = r.chunk;
+    const size_t tail = (size_t)r.world * 2 * (size_t)chunk;
     double d2 = 0.0, x2 = 0.0;
-    GRID_STRIDE(NP) {
-        const double delta = (double)sign * (double)step[i] * (double)S[i];
-        double x;
-        if (i < A) { const int s = r.alist[i]; x = g.x_sdf[s]; xc_sdf[s] = x + delta; }
-        else if (i < 2 * A) { const int s = r.alist[i - A]; x = g.x_alb[s]; xc_alb[s] = x + delta; }
-        else { x = xsh[i - 2 * A]; xc_sh[i - 2 * A] = x + delta; }
-        if (mask[i] != 0.0f) { d2 += delta * delta; x2 += x * x; }
+    GRID_STRIDE(A + NS) {
+        if (i < A) {
+            const int s = r.alist[i]; const int js = vec_sdf(i, chunk), ja = js + chunk;
+            const double ds = (double)sign * (double)step[js] * (double)S[js], da = (double)sign * (double)step[ja] * (double)S[ja];
+            const double xs = g.x_sdf[s], xa = g.x_alb[s];
+            xc_sdf[s] = xs + ds; xc_alb[s] = xa + da;
+            if (mask[js] != 0.0f) { d2 += ds * ds; x2 += xs * xs; }
+            if (mask[ja] != 0.0f) { d2 += da * da; x2 += xa * xa; }
+        } else {
+            const int t = i - A; const size_t j = tail + t;
+            const double delta = (double)sign * (double)step[j] * (double)S[j];
+            const double x = xsh[t]; xc_sh[t] = x + delta;
+            if (mask[j] != 0.0f) { d2 += delta * delta; x2 += x * x; }
+        }
     }
     block_add_d(d2, norms2); block_add_d(x2, norms2 + 1);
 }
 void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* xsh, double* xc_sdf, double* xc_alb,
                       double* xc_sh, double* norms2, const float* mask) {
-    int b = vblocks(2 * r.A + 6 * K + 9); if (b > 1024) b = 1024;
+    int b = vblocks(r.A + 6 * K + 9); if (b > 1024) b = 1024;
     k_candidate<<<b, 256, 0, st>>>(g, r, K, sign, step, S, xsh, xc_sdf, xc_alb, xc_sh, norms2, mask);
 }
 // x <- candidate on the work list (everything else never moves), refresh the fp32 shadows
@@ -506,5 +534,18 @@ __global__ void k_accept(GridView g, RowView r, const double* __restrict__ xc_sd
     GRID_STRIDE(r.A) { const int s = r.alist[i]; const double a = xc_sdf[s], b = xc_alb[s]; g.x_sdf[s] = a; g.x_alb[s] = b; g.f_sdf[s] = (float)a; g.f_alb[s] = (float)b; }
 }
 void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb) { if (r.A > 0) k_accept<<<vblocks(r.A), 256, 0, st>>>(g, r, xc_sdf, xc_alb); }
+
+// compute list of a rank: owned entries + every entry whose Eg rows (forward stencil) or regulariser rows (ring) touch an owned entry
+__global__ void k_mark_compute(RowView r, int* __restrict__ flag) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= r.A) return;
+    flag[a] = shard_needs_entry(a, r.own0, r.own1, (r.aflags[a] & F_ACTIVE) != 0, r.anbr, r.Acap) ? 1 : 0;
+}
+void launch_mark_compute(hipStream_t st, RowView r, int* flag) { if (r.A > 0) k_mark_compute<<<(r.A + 255) / 256, 256, 0, st>>>(r, flag); }
+__global__ void k_compact_list(int A, const int* __restrict__ flag, const int* __restrict__ scan, int* __restrict__ list) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < A && flag[a]) list[scan[a]] = a;
+}
+void launch_compact_list(hipStream_t st, int A, const int* flag, const int* scan, int* list) { if (A > 0) k_compact_list<<<(A + 255) / 256, 256, 0, st>>>(A, flag, scan, list); }
 
 }  // namespace i3d

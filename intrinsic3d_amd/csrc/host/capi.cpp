@@ -30,6 +30,39 @@ int i3d_optimize_host(int32_t device_ordinal, const i3d_optimizer_config* cfg, c
     return rc;
 }
 
+int i3d_comm_unique_id(void* out128, int32_t* bytes) {
+    if (!out128 || !bytes) return I3D_ERR_INVALID_ARGUMENT;
+    size_t n = 0; if (rccl_unique_id(out128, &n)) return I3D_ERR_COMM;
+    *bytes = (int32_t)n; return I3D_OK;
+}
+int i3d_comm_init(i3d_context* c, int32_t rank, int32_t world, const void* unique_id, int32_t id_bytes) {
+    if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_comm_init: bad arguments");
+    CTX_HIP(c, hipSetDevice(c->device));
+    char err[256] = {0};
+    Comm* cm = make_rccl_comm(rank, world, unique_id, (size_t)id_bytes, c->stream, err, sizeof(err));
+    if (!cm) return ctx_fail(c, I3D_ERR_COMM, err);
+    delete c->comm; c->comm = cm; c->assembled = false;
+    return I3D_OK;
+}
+void* i3d_comm_sim_create(int32_t world) { return world >= 1 ? sim_create(world) : nullptr; }
+void i3d_comm_sim_destroy(void* shared) { if (shared) sim_destroy((SimShared*)shared); }
+int i3d_comm_init_sim(i3d_context* c, void* shared, int32_t rank) {
+    if (!c || !shared) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_comm_init_sim: bad arguments");
+    delete c->comm; c->comm = make_sim_comm((SimShared*)shared, rank); c->assembled = false;
+    return I3D_OK;
+}
+
+int i3d_shard_plan(int32_t A, int32_t world, int32_t rank, const int32_t* anbr, const uint8_t* active, int32_t* chunk, int32_t* own0,
+                   int32_t* own1, uint8_t* in_compute_list) {
+    if (A < 0 || world < 1 || rank < 0 || rank >= world || !chunk || !own0 || !own1) return I3D_ERR_INVALID_ARGUMENT;
+    int ch, o0, o1; shard_range(A, world, rank, ch, o0, o1);
+    *chunk = ch; *own0 = o0; *own1 = o1;
+    if (in_compute_list && anbr && active)
+        for (int a = 0; a < A; ++a) in_compute_list[a] = shard_needs_entry(a, o0, o1, active[a] != 0, anbr, (size_t)A) ? 1 : 0;
+    return I3D_OK;
+}
+int32_t i3d_shard_vec_index(int32_t a, int32_t chunk, int32_t albedo) { return albedo ? vec_alb(a, chunk) : vec_sdf(a, chunk); }
+
 int i3d_debug_assemble(i3d_context* c, const i3d_optimizer_config* cfg, int32_t iteration, int32_t* slots_out) {
     if (!c || !cfg) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_debug_assemble: null argument");
     CTX_HIP(c, hipSetDevice(c->device));

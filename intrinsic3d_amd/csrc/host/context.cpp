@@ -132,7 +132,8 @@ i3d::GridView i3d_context::grid_view() const {
 }
 i3d::RowView i3d_context::row_view() const {
     RowView r;
-    r.A = A; r.Acap = Acap; r.slots = slots; r.alist = alist.p; r.aflags = aflags.p; r.anbr = anbr.p; r.obs_frame = obs_frame.p; r.obs_w = obs_w.p;
+    r.A = A; r.Acap = Acap; r.slots = slots; r.chunk = chunk; r.world = comm ? comm->world : 1; r.own0 = own0; r.own1 = own1;
+    r.clist = (comm && comm->world > 1) ? clist.p : nullptr; r.nC = nC; r.alist = alist.p; r.aflags = aflags.p; r.anbr = anbr.p; r.obs_frame = obs_frame.p; r.obs_w = obs_w.p;
     r.rows = rows.p; r.nrows = nrows.p; r.regflags = regflags.p; r.ea_w = ea_w.p; r.ea_free = ea_free.p;
     return r;
 }
@@ -168,6 +169,7 @@ void i3d_destroy(i3d_context* c) {
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_pcg) (void)hipHostFree(c->h_pcg);
     for (auto e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
+    delete c->comm;
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

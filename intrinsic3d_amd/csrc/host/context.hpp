@@ -5,6 +5,7 @@
 #include <cstring>
 #include <cmath>
 #include "../device/kernels.hpp"
+#include "comm.hpp"
 #include "../../../include/intrinsic3d_hip.h"
 
 namespace i3d {
@@ -69,6 +70,9 @@ struct i3d_context {
 
     // ---- rows (work-list space) ----
     int Acap = 0, slots = 0, A = 0; long long n_active = 0;
+    // sharding: owned range / compute list of this rank (see common.hpp)
+    i3d::Comm* comm = nullptr; int chunk = 1, own0 = 0, own1 = 0, nC = 0;
+    i3d::DevBuf<int> clist, cflag, cscan;
     i3d::DevBuf<int> obs_frame, anbr; i3d::DevBuf<float> obs_w, ea_w, C, treg;
     i3d::DevBuf<float4> rows;
     i3d::DevBuf<uint8_t> aflags, nrows, regflags, ea_free;

@@ -42,16 +42,33 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->aflags.alloc(Acap)); CTX_HIP(c, c->nrows.alloc(Acap)); CTX_HIP(c, c->anbr.alloc(Acap * NUM_NBR));
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8));
-    const size_t NP = 2 * (size_t)c->N + 6 * (size_t)c->K + 9;
+    const size_t NP = 2 * (size_t)c->N + 2 * 64 + 6 * (size_t)c->K + 9;          // rank-major layout pads every rank's slice to the same chunk
     for (DevBuf<float>* v : {&c->v_mask, &c->v_c, &c->v_S, &c->v_D2, &c->v_Minv, &c->v_b, &c->v_x, &c->v_r, &c->v_p, &c->v_z, &c->v_q, &c->v_u, &c->v_acc, &c->v_tmp})
         CTX_HIP(c, v->alloc(NP));
     CTX_HIP(c, c->Minv_blocks.alloc((size_t)36 * c->K + 16 + 25));
-    CTX_HIP(c, c->d_shared.alloc((size_t)6 * c->K + 9)); CTX_HIP(c, c->d_blocks.alloc((size_t)21 * c->K + 25));
+    CTX_HIP(c, c->d_shared.alloc((size_t)6 * c->K + 9 + 1)); CTX_HIP(c, c->d_blocks.alloc((size_t)21 * c->K + 25));      // +1: p.q partial rides with the camera block
+    CTX_HIP(c, c->clist.alloc(Acap)); CTX_HIP(c, c->cflag.alloc(Acap)); CTX_HIP(c, c->cscan.alloc(Acap));
     CTX_HIP(c, c->d_scal.alloc(32)); CTX_HIP(c, c->d_xshared.alloc((size_t)6 * c->K + 9)); CTX_HIP(c, c->d_xcshared.alloc((size_t)6 * c->K + 9));
     CTX_HIP(c, c->d_pcg.alloc(1));
     if (!c->h_pcg) CTX_HIP(c, hipHostMalloc((void**)&c->h_pcg, 2 * sizeof(PcgState), hipHostMallocDefault));
     for (auto& e : c->pcg_ev) if (!e) CTX_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return ensure_pinned(c, 64 + (size_t)27 * c->K + 64);
+}
+
+struct Layout { int A, K, NS, chunk, world, rank; size_t slice_off, slice_n, tail_off, NP; };
+static Layout layout_of(const i3d_context* c) {
+    Layout L; L.A = c->A; L.K = c->K; L.NS = 6 * c->K + 9; L.chunk = c->chunk; L.world = c->comm ? c->comm->world : 1; L.rank = c->comm ? c->comm->rank : 0;
+    L.slice_n = 2 * (size_t)L.chunk; L.slice_off = (size_t)L.rank * L.slice_n; L.tail_off = (size_t)L.world * L.slice_n; L.NP = L.tail_off + L.NS;
+    return L;
+}
+static bool sharded(const i3d_context* c) { return c->comm && c->comm->world > 1; }
+static int allreduce(i3d_context* c, double* dev, size_t n) {
+    if (!sharded(c)) return I3D_OK;
+    return c->comm->allreduce_sum(dev, n, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-reduce failed") : I3D_OK;
+}
+static int allgather(i3d_context* c, float* vec) {       // every rank contributes its slice of a solver vector
+    if (!sharded(c)) return I3D_OK;
+    return c->comm->allgather(vec, 2 * (size_t)c->chunk, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-gather failed") : I3D_OK;
 }
 
 // read `n` doubles from device memory (after everything queued on the stream)
@@ -83,11 +100,27 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     CTX_HIP(c, hipStreamSynchronize(s));
     c->A = tail[0] + tail[1];
     { TimedScope t(c, I3D_K_CLASSIFY); launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
+    if (!sharded(c)) { c->chunk = c->A > 0 ? c->A : 1; c->own0 = 0; c->own1 = c->A; c->nC = c->A; }
+    else {      // owned range + compute list (every rank derives them from the replicated work list: no communication)
+        const int world = c->comm->world, rank = c->comm->rank;
+        shard_range(c->A, world, rank, c->chunk, c->own0, c->own1); c->nC = 0;
+        RowView r0 = c->row_view();
+        TimedScope t(c, I3D_K_CLASSIFY);
+        launch_mark_compute(s, r0, c->cflag.p);
+        CTX_HIP(c, rocprim::exclusive_scan(c->scan_tmp.p, c->scan_tmp_bytes, c->cflag.p, c->cscan.p, 0, (size_t)c->A, rocprim::plus<int>(), s));
+        launch_compact_list(s, c->A, c->cflag.p, c->cscan.p, c->clist.p);
+        int tl[2] = {0, 0};
+        if (c->A > 0) { CTX_HIP(c, hipMemcpyAsync(&tl[0], c->cscan.p + (c->A - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+                        CTX_HIP(c, hipMemcpyAsync(&tl[1], c->cflag.p + (c->A - 1), sizeof(int), hipMemcpyDeviceToHost, s)); }
+        CTX_HIP(c, hipStreamSynchronize(s));
+        c->nC = tl[0] + tl[1];
+    }
     RowView r = c->row_view();
     { TimedScope t(c, I3D_K_OBSERVE); launch_observe(s, g, r, p, c->d_frames.p); }
     { TimedScope t(c, I3D_K_BUILD); launch_build(s, g, r, p, c->d_frames.p, true, nullptr); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
     { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, c->d_scal.p); }
+    { int rc = allreduce(c, c->d_scal.p, 9); if (rc) return rc; }
     double sums[9]; { int rc = read_doubles(c, c->d_scal.p, 9, sums); if (rc) return rc; }
     sums[5] = sums[1]; sums[6] = sums[2];
     const double lambda[4] = {cfg.lambda_g, varying_lambda(iteration, cfg.iterations, cfg.lambda_r0, cfg.lambda_r1),
@@ -103,19 +136,25 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
 
 // ---- normal-equation pieces (GRAD / COLNORM; the PCG operator is inlined in pcg_solve) ----------------------------------------
 static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const float* u, float* out /*[NP]*/) {
-    hipStream_t s = c->stream; GridView g = c->grid_view(); RowView r = c->row_view();
+    hipStream_t s = c->stream; GridView g = c->grid_view(); RowView r = c->row_view(); const Layout L = layout_of(c);
     PassBuffers b{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
-    CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * (6 * (size_t)c->K + 9), s));
+    CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
     if (mode == PASS_COLNORM) CTX_HIP(c, hipMemsetAsync(c->d_blocks.p, 0, sizeof(double) * (21 * (size_t)c->K + 25), s));
     { TimedScope t(c, I3D_K_EG_PASS); launch_eg_pass(s, mode, g, r, p, u, b, nullptr); }
     { TimedScope t(c, I3D_K_GATHER); launch_gather(s, mode, r, b, out); }
-    { TimedScope t(c, I3D_K_VECTOR); launch_shared_finalize(s, c->A, c->K, p, c->d_shared.p, out, false, nullptr, nullptr, nullptr, nullptr, nullptr); }
+    { int rc = allreduce(c, c->d_shared.p, (size_t)L.NS); if (rc) return rc; }
+    if (mode == PASS_COLNORM) { int rc = allreduce(c, c->d_blocks.p, 21 * (size_t)c->K + 25); if (rc) return rc; }
+    { TimedScope t(c, I3D_K_VECTOR); launch_shared_finalize(s, L.tail_off, c->K, p, c->d_shared.p, out, false, nullptr, nullptr, nullptr, nullptr, nullptr); }
     return I3D_OK;
 }
 
-static int dot(i3d_context* c, int n, const float* a, const float* b, double* out) {
+// a.b over the distributed vector: own slice -> all-reduce -> + the replicated camera tail
+static int dot(i3d_context* c, const float* a, const float* b, double* out) {
+    const Layout L = layout_of(c);
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 4, c->stream));
-    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, n, a, b, c->d_scal.p); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, (int)L.slice_n, a + L.slice_off, b + L.slice_off, c->d_scal.p); }
+    { int rc = allreduce(c, c->d_scal.p, 1); if (rc) return rc; }
+    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, L.NS, a + L.tail_off, b + L.tail_off, c->d_scal.p); }
     return read_doubles(c, c->d_scal.p, 1, out);
 }
 
@@ -164,37 +203,66 @@ static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const F
     if (candidate) { g.x_sdf = c->xc_sdf.p; g.x_alb = c->xc_alb.p; }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 16, 0, sizeof(double), c->stream));
     { TimedScope t(c, I3D_K_COST); launch_build(c->stream, g, c->row_view(), p, frames, false, c->d_scal.p + 16); }
+    { int rc = allreduce(c, c->d_scal.p + 16, 1); if (rc) return rc; }
     return read_doubles(c, c->d_scal.p + 16, 1, cost);
 }
 
 // CGNR (ConjugateGradientsSolver) on (S J^T W J S + D^2) x = b, x0 = 0.  No host synchronisation inside an iteration.
+// Sharded: every rank iterates on its slice of the vectors + the replicated camera tail; per iteration the slice partials of rho,
+// [p.q | camera block] and the three Q sums are all-reduced and the operator input u is all-gathered.
 static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, PcgState* final_state) {
     hipStream_t s = c->stream;
-    const int A = c->A, K = c->K, NP = 2 * A + 6 * K + 9;
+    const Layout L = layout_of(c);
+    const int K = c->K; const bool multi = sharded(c);
     GridView g = c->grid_view(); RowView r = c->row_view();
     PassBuffers pb{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
     PcgState* st = c->d_pcg.p;
-    { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, NP, c->v_x.p, 0.0f); launch_pcg_init(s, st, cfg.pcg_fixed_iterations, 500); }
-    CTX_HIP(c, hipMemcpyAsync(c->v_r.p, c->v_b.p, sizeof(float) * (size_t)NP, hipMemcpyDeviceToDevice, s));
-    auto apply = [&](const float* v, float* out, double* dot_out) -> int {       // out = A v given u = S v already in v_u
-        CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * (6 * (size_t)K + 9), s));
+    double* pq_slot = c->d_shared.p + L.NS;
+    { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, (int)L.NP, c->v_x.p, 0.0f); launch_pcg_init(s, st, cfg.pcg_fixed_iterations, 500); }
+    CTX_HIP(c, hipMemcpyAsync(c->v_r.p, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s));
+    // vector kernels: one launch over [slice | tail] when they are contiguous (single rank), slice then tail otherwise
+    const size_t so = L.slice_off, to = L.tail_off; const int sn = (int)L.slice_n, tn = L.NS;
+    auto apply = [&](const float* v, float* out, bool with_dot) -> int {       // out = A v given u = S v (all-gathered) in v_u
+        { int rc = allgather(c, c->v_u.p); if (rc) return rc; }
+        CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
         { TimedScope t(c, I3D_K_EG_PASS); launch_eg_pass(s, PASS_JTJP, g, r, p, c->v_u.p, pb, st); }
-        { TimedScope t(c, I3D_K_GATHER); launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, dot_out, st); }
-        { TimedScope t(c, I3D_K_VECTOR); launch_shared_finalize(s, A, K, p, c->d_shared.p, out, true, c->v_S.p, c->v_D2.p, v, dot_out, st); }
+        { TimedScope t(c, I3D_K_GATHER); launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, with_dot ? pq_slot : nullptr, st); }
+        { int rc = allreduce(c, c->d_shared.p, (size_t)L.NS + 1); if (rc) return rc; }
+        { TimedScope t(c, I3D_K_VECTOR); launch_shared_finalize(s, to, K, p, c->d_shared.p, out, true, c->v_S.p, c->v_D2.p, v, with_dot ? pq_slot : nullptr, st); }
         return I3D_OK;
     };
     int it = 1;
     for (;; ++it) {
+        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_precond_slice(s, so, sn, c->v_Minv.p, c->v_r.p, c->v_z.p, st); }
+        { int rc = allreduce(c, &st->rho, 1); if (rc) return rc; }
         { TimedScope t(c, I3D_K_VECTOR);
-          launch_pcg_precond(s, A, K, c->v_Minv.p, c->Minv_blocks.p, c->v_r.p, c->v_z.p, st);
-          launch_pcg_direction(s, NP, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, st); }
-        { int rc = apply(c->v_p.p, c->v_q.p, &st->pq); if (rc) return rc; }
+          launch_pcg_precond_tail(s, to, K, c->Minv_blocks.p, c->v_r.p, c->v_z.p, st);
+          if (!multi) launch_pcg_direction(s, sn + tn, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, st);
+          else { launch_pcg_direction(s, sn, c->v_z.p + so, c->v_p.p + so, c->v_S.p + so, c->v_u.p + so, st);
+                 launch_pcg_direction(s, tn, c->v_z.p + to, c->v_p.p + to, c->v_S.p + to, c->v_u.p + to, st); } }
+        { int rc = apply(c->v_p.p, c->v_q.p, true); if (rc) return rc; }
         const bool reset = (it % 10 == 0);                                       // residual_reset_period
-        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_scalar2(s, st); launch_pcg_update(s, NP, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, reset ? 1 : 0, st); }
+        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_scalar2(s, st, pq_slot);
+          if (!multi) launch_pcg_update(s, sn + tn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, reset ? 1 : 0, st);
+          else launch_pcg_update(s, sn, c->v_p.p + so, c->v_q.p + so, c->v_x.p + so, c->v_r.p + so, c->v_b.p + so, c->v_D2.p + so, reset ? 1 : 0, st); }
+        if (multi) {
+            if (!reset) { int rc = allreduce(c, &st->xbr, 3); if (rc) return rc; }
+            TimedScope t(c, I3D_K_VECTOR);
+            launch_pcg_update(s, tn, c->v_p.p + to, c->v_q.p + to, c->v_x.p + to, c->v_r.p + to, c->v_b.p + to, c->v_D2.p + to, reset ? 1 : 0, st);
+        }
         if (reset) {
-            { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, NP, c->v_S.p, c->v_x.p, c->v_u.p); }
-            { int rc = apply(c->v_x.p, c->v_tmp.p, nullptr); if (rc) return rc; }
-            { TimedScope t(c, I3D_K_VECTOR); launch_pcg_reset_r(s, NP, c->v_x.p, c->v_tmp.p, c->v_r.p, c->v_b.p, c->v_D2.p, st); }
+            { TimedScope t(c, I3D_K_VECTOR);
+              if (!multi) launch_mul(s, sn + tn, c->v_S.p, c->v_x.p, c->v_u.p);
+              else { launch_mul(s, sn, c->v_S.p + so, c->v_x.p + so, c->v_u.p + so); launch_mul(s, tn, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); } }
+            { int rc = apply(c->v_x.p, c->v_tmp.p, false); if (rc) return rc; }
+            { TimedScope t(c, I3D_K_VECTOR);
+              if (!multi) launch_pcg_reset_r(s, sn + tn, c->v_x.p, c->v_tmp.p, c->v_r.p, c->v_b.p, c->v_D2.p, st);
+              else launch_pcg_reset_r(s, sn, c->v_x.p + so, c->v_tmp.p + so, c->v_r.p + so, c->v_b.p + so, c->v_D2.p + so, st); }
+            if (multi) {
+                { int rc = allreduce(c, &st->xbr, 3); if (rc) return rc; }
+                TimedScope t(c, I3D_K_VECTOR);
+                launch_pcg_reset_r(s, tn, c->v_x.p + to, c->v_tmp.p + to, c->v_r.p + to, c->v_b.p + to, c->v_D2.p + to, st);
+            }
         }
         { TimedScope t(c, I3D_K_VECTOR); launch_pcg_scalar3(s, st); }
         const int slot = it & 1;
@@ -214,7 +282,8 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
 // NLSSolver::solve on the assembled rows.  Updates the device unknowns and the host camera when a step is accepted.
 static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& p, i3d_iteration_stats* st) {
     hipStream_t s = c->stream;
-    const int N = c->N, A = c->A, K = c->K, NP = 2 * A + 6 * K + 9, NS = 6 * K + 9;
+    const Layout L = layout_of(c);
+    const int N = c->N, K = c->K, NP = (int)L.NP, NS = L.NS;
     GridView g = c->grid_view(); RowView r = c->row_view();
     { TimedScope t(c, I3D_K_VECTOR); launch_freemask(s, r, p, c->v_mask.p); }
     // candidate arrays mirror x outside the work list (fixed parameters are read through them by the cost kernel)
@@ -226,13 +295,14 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     rc = read_doubles(c, c->d_shared.p, NS, sb.c.data()); if (rc) return rc;
     rc = ensure_pinned(c, (size_t)21 * K + 25 + 64); if (rc) return rc;
     rc = read_doubles(c, c->d_blocks.p, (size_t)21 * K + 25, sb.H.data()); if (rc) return rc;
+    { int rc2 = allgather(c, c->v_c.p); if (rc2) return rc2; }     // the candidate point needs S everywhere
     { TimedScope t(c, I3D_K_VECTOR); launch_scale_from_colnorm(s, NP, c->v_c.p, c->v_mask.p, c->v_S.p); }
     // gradient b = S J^T W r and initial cost
     rc = run_pass(c, PASS_GRAD, p, nullptr, c->v_acc.p); if (rc) return rc;
     { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, NP, c->v_S.p, c->v_acc.p, c->v_b.p); }
     double cost = 0.0; rc = eval_cost(c, p, false, c->d_frames.p, &cost); if (rc) return rc;
-    double gmax2 = 0.0; rc = dot(c, NP, c->v_acc.p, c->v_acc.p, &gmax2); if (rc) return rc;
-    double nfree = 0.0; rc = dot(c, NP, c->v_mask.p, c->v_mask.p, &nfree); if (rc) return rc;
+    double gmax2 = 0.0; rc = dot(c, c->v_acc.p, c->v_acc.p, &gmax2); if (rc) return rc;
+    double nfree = 0.0; rc = dot(c, c->v_mask.p, c->v_mask.p, &nfree); if (rc) return rc;
     if (st) { st->cost_initial = cost; st->cost_final = cost; st->free_parameters = (int64_t)(nfree + 0.5); }
     c->last_sizes[5] = (long long)(nfree + 0.5);
     if (c->n_active == 0 || nfree == 0.0) { if (st) st->termination = 1; return I3D_OK; }
@@ -264,7 +334,8 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
             radius *= 0.5; if (st) st->final_radius = radius; continue;
         }
         invalid = 0;
-        // candidate point
+        // candidate point (replicated: every rank needs the whole step)
+        { int rc2 = allgather(c, c->v_x.p); if (rc2) return rc2; }
         CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 4, 0, sizeof(double) * 2, s));
         { TimedScope t(c, I3D_K_VECTOR); launch_candidate(s, g, r, K, -1.0f, c->v_x.p, c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p); }
         double norms[2]; rc = read_doubles(c, c->d_scal.p + 4, 2, norms); if (rc) return rc;
