@@ -130,6 +130,30 @@ typedef struct { int64_t data_rows, reg_rows; int32_t subvolumes, lm_iterations,
 int i3d_estimate_sh(i3d_context* ctx, float subvolume_size, double lambda_reg, double thres_shell,
                     int32_t* num_subvolumes, double* sh, int32_t* sub_index, int32_t cap, i3d_sh_stats* stats);
 
+/* ---- level transitions and the refine schedule (Intrinsic3D::refine, intrinsic3d.cpp:206-409) ------------------------------
+ * i3d_set_grid_from_tsdf_records: SparseVoxelGrid<Voxel>::load (records in file order) + SDFAlgorithms::convert (algorithms.cpp:47-72)
+ * i3d_recompute_colors          : Intrinsic3D::recomputeColors (SDFColorization::add/compute, colorization.cpp:113-189,318-354)
+ * i3d_clear_outside_thin_shell  : SDFAlgorithms::clearVoxelsOutsideThinShell (algorithms.cpp:368-458)
+ * i3d_upsample                  : SDFAlgorithms::upsample (algorithms.cpp:202-235)
+ * The grid stays resident; i3d_grid_info / i3d_export_grid return it in visit order (e.g. inside the refine callback). */
+int i3d_set_grid_from_tsdf_records(i3d_context* ctx, float voxel_size, int64_t n, const int32_t* keys, const float* sdf, const float* weight, const uint8_t* color);
+int i3d_recompute_colors(i3d_context* ctx, float occlusion_distance, int32_t num_observations);
+int i3d_clear_outside_thin_shell(i3d_context* ctx, double thres_shell, int64_t* new_count);
+int i3d_upsample(i3d_context* ctx, int64_t* new_count);
+int i3d_grid_info(i3d_context* ctx, int64_t* num_voxels, float* voxel_size, float* truncation);
+int i3d_export_grid(i3d_context* ctx, int32_t* keys, double* sdf, double* sdf_refined, double* albedo, float* weight, uint8_t* color);
+
+typedef struct {                   /* Intrinsic3D::Config (intrinsic3d.h:67-84), keys of data/intrinsic3d.yml */
+    int32_t num_grid_levels, num_rgbd_levels;
+    double  thin_shell_factor, thin_shell_factor_final;
+    int32_t clear_distant_voxels;
+    float   occlusion_distance; int32_t num_observations;
+    float   subvolume_size_sh; double sh_lambda_reg;
+} i3d_refine_config;
+/* RefinementCallback::onSDFRefined(RefinementInfo) (intrinsic3d.h:94-114) */
+typedef void (*i3d_refine_callback)(void* user, int32_t grid_level, int32_t num_grid_levels, int32_t pyramid_level, int32_t num_pyramid_levels);
+int i3d_refine(i3d_context* ctx, const i3d_refine_config* rcfg, const i3d_optimizer_config* ocfg, i3d_refine_callback cb, void* user);
+
 /* ---- one process per GPU: the voxel state is replicated, row work / row storage / solver vectors are sharded by contiguous
  * work-list ranges; RCCL carries the PCG scalars, the camera block and the per-iteration vector exchange.  Call after i3d_create
  * on every rank with the same unique id (i3d_comm_unique_id on rank 0, broadcast by the launcher, e.g. torch.distributed). */

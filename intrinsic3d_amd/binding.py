@@ -42,6 +42,17 @@ class ShStats(C.Structure):
                 ("termination", C.c_int32), ("cost_initial", C.c_double), ("cost_final", C.c_double)]
 
 
+class RefineConfig(C.Structure):
+    """i3d_refine_config (include/intrinsic3d_hip.h)."""
+    _fields_ = [("num_grid_levels", C.c_int32), ("num_rgbd_levels", C.c_int32),
+                ("thin_shell_factor", C.c_double), ("thin_shell_factor_final", C.c_double),
+                ("clear_distant_voxels", C.c_int32), ("occlusion_distance", C.c_float), ("num_observations", C.c_int32),
+                ("subvolume_size_sh", C.c_float), ("sh_lambda_reg", C.c_double)]
+
+
+REFINE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32)
+
+
 class GridView(C.Structure):
     _fields_ = [("num_voxels", C.c_int64), ("voxel_size", C.c_float), ("truncation", C.c_float),
                 ("keys", C.c_void_p), ("sdf", C.c_void_p), ("sdf_refined", C.c_void_p), ("albedo", C.c_void_p),
@@ -51,6 +62,8 @@ class GridView(C.Structure):
 EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_set_grid", "i3d_get_grid", "i3d_update_grid",
            "i3d_set_frames", "i3d_set_camera", "i3d_get_camera", "i3d_set_voxel_sh", "i3d_get_voxel_sh",
            "i3d_optimizer_config_default", "i3d_optimize", "i3d_optimize_host", "i3d_estimate_sh",
+           "i3d_set_grid_from_tsdf_records", "i3d_recompute_colors", "i3d_clear_outside_thin_shell", "i3d_upsample", "i3d_grid_info",
+           "i3d_export_grid", "i3d_refine",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_timing_enable", "i3d_timing_get", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
@@ -103,6 +116,13 @@ def load():
     L.i3d_debug_neighbors.restype = i32; L.i3d_debug_neighbors.argtypes = [vp, vp]
     L.i3d_debug_normal_eq.restype = i32; L.i3d_debug_normal_eq.argtypes = [vp, vp, vp, C.POINTER(f64)]
     L.i3d_debug_jtj_apply.restype = i32; L.i3d_debug_jtj_apply.argtypes = [vp, vp, vp]
+    L.i3d_set_grid_from_tsdf_records.restype = i32; L.i3d_set_grid_from_tsdf_records.argtypes = [vp, f32, i64, vp, vp, vp, vp]
+    L.i3d_recompute_colors.restype = i32; L.i3d_recompute_colors.argtypes = [vp, f32, i32]
+    L.i3d_clear_outside_thin_shell.restype = i32; L.i3d_clear_outside_thin_shell.argtypes = [vp, f64, C.POINTER(i64)]
+    L.i3d_upsample.restype = i32; L.i3d_upsample.argtypes = [vp, C.POINTER(i64)]
+    L.i3d_grid_info.restype = i32; L.i3d_grid_info.argtypes = [vp, C.POINTER(i64), C.POINTER(f32), C.POINTER(f32)]
+    L.i3d_export_grid.restype = i32; L.i3d_export_grid.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.i3d_refine.restype = i32; L.i3d_refine.argtypes = [vp, C.POINTER(RefineConfig), C.POINTER(OptimizerConfig), REFINE_CALLBACK, vp]
     _lib = L
     return L
 
@@ -206,6 +226,49 @@ class Context:
         b = None if albedo is None else np.ascontiguousarray(albedo, np.float64)
         c = None if color is None else np.ascontiguousarray(color, np.uint8)
         self._check(self.L.i3d_update_grid(self.h, _p(a), _p(b), _p(c)), "i3d_update_grid")
+
+    # ---- level transitions / refine schedule ------------------------------------------------------------
+    def set_grid_from_tsdf_records(self, voxel_size, keys, sdf, weight, color):
+        keys = np.ascontiguousarray(keys, np.int32); sdf = np.ascontiguousarray(sdf, np.float32)
+        weight = np.ascontiguousarray(weight, np.float32); color = np.ascontiguousarray(color, np.uint8)
+        self._check(self.L.i3d_set_grid_from_tsdf_records(self.h, float(voxel_size), len(sdf), _p(keys), _p(sdf), _p(weight), _p(color)),
+                    "i3d_set_grid_from_tsdf_records")
+        self.grid_info()
+
+    def grid_info(self):
+        n = C.c_int64(0); vs = C.c_float(0); tr = C.c_float(0)
+        self._check(self.L.i3d_grid_info(self.h, C.byref(n), C.byref(vs), C.byref(tr)), "i3d_grid_info")
+        self.N = int(n.value)
+        return self.N, float(vs.value), float(tr.value)
+
+    def export_grid(self):
+        N = self.grid_info()[0]
+        out = dict(keys=np.zeros((N, 3), np.int32), sdf=np.zeros(N), sdf_refined=np.zeros(N), albedo=np.zeros(N),
+                   weight=np.zeros(N, np.float32), color=np.zeros((N, 3), np.uint8))
+        self._check(self.L.i3d_export_grid(self.h, _p(out["keys"]), _p(out["sdf"]), _p(out["sdf_refined"]), _p(out["albedo"]), _p(out["weight"]),
+                                           _p(out["color"])), "i3d_export_grid")
+        return out
+
+    def recompute_colors(self, occlusion_distance, num_observations):
+        self._check(self.L.i3d_recompute_colors(self.h, float(occlusion_distance), int(num_observations)), "i3d_recompute_colors")
+
+    def clear_outside_thin_shell(self, thres_shell):
+        n = C.c_int64(0)
+        self._check(self.L.i3d_clear_outside_thin_shell(self.h, float(thres_shell), C.byref(n)), "i3d_clear_outside_thin_shell")
+        self.N = int(n.value)
+        return self.N
+
+    def upsample(self):
+        n = C.c_int64(0)
+        self._check(self.L.i3d_upsample(self.h, C.byref(n)), "i3d_upsample")
+        self.N = int(n.value)
+        return self.N
+
+    def refine(self, rcfg: "RefineConfig", ocfg: OptimizerConfig, callback=None):
+        """Intrinsic3D::refine; callback(grid_level, num_grid_levels, pyramid_level, num_pyramid_levels) may call export_grid()."""
+        cb = REFINE_CALLBACK((lambda user, a, b, c_, d: callback(a, b, c_, d)) if callback else (lambda *a: None))
+        self._check(self.L.i3d_refine(self.h, C.byref(rcfg), C.byref(ocfg), cb, None), "i3d_refine")
+        self.grid_info()
 
     # ---- sharding -----------------------------------------------------------------------------------------
     @staticmethod

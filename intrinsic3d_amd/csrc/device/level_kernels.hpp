@@ -1,0 +1,16 @@
+// Launch wrappers of level_kernels.hip.
+#pragma once
+#include "kernels.hpp"
+
+namespace i3d {
+void launch_recolor(hipStream_t st, GridView g, OptParams p, const FrameConst* frames, int nobs, uchar4* color_out);
+void launch_shell_mark(hipStream_t st, GridView g, double thres, int* keep);
+void launch_shell_crossing(hipStream_t st, GridView g, HashTable t, int* keep);
+void launch_inv_rank(hipStream_t st, int N, const int* rank, int* inv);
+void launch_keep_visit(hipStream_t st, int N, const int* inv, const int* keep_dev, int* keep_visit);
+void launch_export_visit(hipStream_t st, GridView g, const int* inv_rank, const int* keep_dev, const int* scan_visit, int* kxyz, double* sdf, double* sdf_ref,
+                         double* alb, float* w, uint8_t* rgb);
+void launch_upsample(hipStream_t st, GridView g, HashTable t, const int* inv_rank, int* kxyz, double* sdf, double* sdf_ref, double* alb, float* w, uint8_t* rgb);
+void launch_permute_staging(hipStream_t st, long long n, const int* perm, const int* kin, const double* s0, const double* s1, const double* al, const float* w,
+                            const uint8_t* rgb, int* kout, double* o0, double* o1, double* oal, float* ow, uint8_t* orgb);
+}  // namespace i3d

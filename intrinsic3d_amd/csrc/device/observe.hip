@@ -9,6 +9,7 @@
 // fp64 with the same libm the reference uses and arrives in FrameConst::Rf/tf; every lane of a wave reads the same
 // keyframe at the same time, so those loads are wave-uniform (scalar) loads.
 #include "kernels.hpp"
+#include "observe_device.hpp"
 
 namespace i3d {
 
@@ -45,44 +46,8 @@ __global__ void __launch_bounds__(256) k_observe(GridView g, RowView r, OptParam
     const int K = p.K;
     for (int f = 0; f < K; ++f) {
         const FrameConst& fc = frames[f];
-        const float qx = ((fc.Rf[0] * px + fc.Rf[1] * py) + fc.Rf[2] * pz) + fc.tf[0];
-        const float qy = ((fc.Rf[3] * px + fc.Rf[4] * py) + fc.Rf[5] * pz) + fc.tf[1];
-        const float qz = ((fc.Rf[6] * px + fc.Rf[7] * py) + fc.Rf[8] * pz) + fc.tf[2];
-        float x = qx / qz, y = qy / qz;
-        if (!p.dist_zero) {
-            const float r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-            const float dc = 1.0f + p.dist_f[0] * r2 + p.dist_f[1] * r4 + p.dist_f[2] * r6;
-            x = x * dc + 2.0f * p.dist_f[3] * x * y + p.dist_f[4] * (r2 + 2.0f * x * x);
-            y = y * dc + 2.0f * p.dist_f[4] * x * y + p.dist_f[3] * (r2 + 2.0f * y * y);
-        }
-        const float u = p.cam_f[0] * x + p.cam_f[2], v = p.cam_f[1] * y + p.cam_f[3];
-        const int ui = (int)(u + 0.5f), vi = (int)(v + 0.5f);
-        float w = 0.0f;
-        if (!(ui < 0 || ui >= p.w || vi < 0 || vi >= p.h)) {
-            const float d = fc.depth[(size_t)vi * fc.w + ui];
-            bool vis = true;
-            if (p.occlusion > 0.0f) vis = (d > 0.0f) && (fabsf(d - qz) <= p.occlusion);
-            if (vis && d > 0.0f) {
-                const float cnx = (fc.Rf[0] * nx + fc.Rf[1] * ny) + fc.Rf[2] * nz;
-                const float cny = (fc.Rf[3] * nx + fc.Rf[4] * ny) + fc.Rf[5] * nz;
-                const float cnz = (fc.Rf[6] * nx + fc.Rf[7] * ny) + fc.Rf[8] * nz;
-                float wn = 0.0f;
-                if (!(fabsf(cnx) <= 1e-5f && fabsf(cny) <= 1e-5f && fabsf(cnz) <= 1e-5f)) {
-                    const float vsq = qx * qx + qy * qy + qz * qz;
-                    float vx = qx, vy = qy, vz = qz;
-                    if (vsq > 0.0f) { const float l = sqrtf(vsq); vx /= l; vy /= l; vz /= l; }
-                    wn = 1.0f - fabsf((vx * cnx + vy * cny) + vz * cnz);
-                    wn = fmaxf(fminf(wn, 1.0f), 0.0f);
-                    const float div = 1.0f + 2.0f * wn;
-                    wn = fmaxf(1.0f / (div * div * div), 0.001f);
-                }
-                const float dw = fmaxf(fminf(5.0f, d), 0.01f);
-                const float dn = (dw - 0.01f) / (5.0f - 0.01f);
-                float wd = fmaxf(1.0f - dn, 1.0f);
-                wd = fmaxf(fminf(wd, 5.0f), 0.001f);
-                w = wn * wd;
-            }
-        }
+        float uf, vf;
+        const float w = observation_weight(fc, p, px, py, pz, nx, ny, nz, fc.depth, uf, vf);
         if (KEEP_ALL) {                 // n >= #frames: filter() returns before sorting, rows stay in frame order
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i) if (i == f) { bw[i] = (w > 0.0f) ? w : 0.0f; bf[i] = (w > 0.0f) ? f : -1; }

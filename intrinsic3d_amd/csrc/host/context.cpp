@@ -180,52 +180,63 @@ int i3d_set_grid(i3d_context* c, const i3d_grid_view* gv) {
     if (gv->num_voxels > (1ll << 30)) return ctx_fail(c, I3D_ERR_CAPACITY, "i3d_set_grid: more than 2^30 voxels");
     CTX_HIP(c, hipSetDevice(c->device));
     const int N = (int)gv->num_voxels;
-    c->N = N; c->voxel_size = gv->voxel_size; c->truncation = gv->truncation; c->have_grid = false; c->have_sh = false; c->assembled = false;
     hipStream_t st = c->stream;
-    // staging copies of the caller's arrays (visit order)
-    DevBuf<int> kxyz, perm, iota; DevBuf<double> hsdf, hsr, halb; DevBuf<float> hw; DevBuf<uint8_t> hrgb;
-    DevBuf<unsigned long long> skeys, skeys2;
-    CTX_HIP(c, kxyz.alloc((size_t)3 * N)); CTX_HIP(c, perm.alloc(N)); CTX_HIP(c, iota.alloc(N));
-    CTX_HIP(c, hsdf.alloc(N)); CTX_HIP(c, hsr.alloc(N)); CTX_HIP(c, halb.alloc(N)); CTX_HIP(c, hw.alloc(N)); CTX_HIP(c, hrgb.alloc((size_t)3 * N));
-    CTX_HIP(c, skeys.alloc(N)); CTX_HIP(c, skeys2.alloc(N));
-    CTX_HIP(c, hipMemcpyAsync(kxyz.p, gv->keys, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, st));
-    CTX_HIP(c, hipMemcpyAsync(hsdf.p, gv->sdf, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
-    CTX_HIP(c, hipMemcpyAsync(hsr.p, gv->sdf_refined, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
-    CTX_HIP(c, hipMemcpyAsync(halb.p, gv->albedo, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
-    CTX_HIP(c, hipMemcpyAsync(hw.p, gv->weight, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, st));
-    CTX_HIP(c, hipMemcpyAsync(hrgb.p, gv->color, (size_t)3 * N, hipMemcpyHostToDevice, st));
+    GridStaging g;     // staging copies of the caller's arrays (visit order)
+    CTX_HIP(c, g.kxyz.alloc((size_t)3 * N)); CTX_HIP(c, g.sdf.alloc(N)); CTX_HIP(c, g.sdf_ref.alloc(N)); CTX_HIP(c, g.alb.alloc(N)); CTX_HIP(c, g.w.alloc(N)); CTX_HIP(c, g.rgb.alloc((size_t)3 * N));
+    CTX_HIP(c, hipMemcpyAsync(g.kxyz.p, gv->keys, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(g.sdf.p, gv->sdf, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(g.sdf_ref.p, gv->sdf_refined, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(g.alb.p, gv->albedo, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(g.w.p, gv->weight, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(g.rgb.p, gv->color, (size_t)3 * N, hipMemcpyHostToDevice, st));
+    return set_grid_device(c, N, gv->voxel_size, gv->truncation, g);
+}
+
+}  // extern "C"
+
+namespace i3d {
+int set_grid_device(i3d_context* c, int N, float voxel_size, float truncation, GridStaging& g) {
+    c->N = N; c->voxel_size = voxel_size; c->truncation = truncation; c->have_grid = false; c->have_sh = false; c->assembled = false;
+    c->slots = 0;      // row storage is sized by N: force a re-allocation for the new grid
+    hipStream_t st = c->stream;
+    DevBuf<int> perm, iota; DevBuf<unsigned long long> skeys, skeys2;
+    CTX_HIP(c, perm.alloc(N)); CTX_HIP(c, iota.alloc(N)); CTX_HIP(c, skeys.alloc(N)); CTX_HIP(c, skeys2.alloc(N));
     // brick-Morton sort (device order), then permute every field into SoA planes
-    launch_sort_keys(st, N, kxyz.p, skeys.p, iota.p);
+    launch_sort_keys(st, N, g.kxyz.p, skeys.p, iota.p);
     size_t tmp_bytes = 0;
     CTX_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, skeys.p, skeys2.p, iota.p, perm.p, (size_t)N, 0, 64, st));
     DevBuf<unsigned char> tmp; CTX_HIP(c, tmp.alloc(tmp_bytes));
     CTX_HIP(c, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, skeys.p, skeys2.p, iota.p, perm.p, (size_t)N, 0, 64, st));
-    CTX_HIP(c, c->cx.alloc(N)); CTX_HIP(c, c->cy.alloc(N)); CTX_HIP(c, c->cz.alloc(N)); CTX_HIP(c, c->rank.alloc(N));
-    CTX_HIP(c, c->sdf0.alloc(N)); CTX_HIP(c, c->x_sdf.alloc(N)); CTX_HIP(c, c->x_alb.alloc(N)); CTX_HIP(c, c->xc_sdf.alloc(N)); CTX_HIP(c, c->xc_alb.alloc(N));
-    CTX_HIP(c, c->f_sdf.alloc(N)); CTX_HIP(c, c->f_alb.alloc(N)); CTX_HIP(c, c->weight.alloc(N)); CTX_HIP(c, c->color.alloc(N));
-    CTX_HIP(c, c->flags.alloc(N)); CTX_HIP(c, c->aidx.alloc(N)); CTX_HIP(c, c->alist.alloc(N)); CTX_HIP(c, c->aflag.alloc(N)); CTX_HIP(c, c->ascan.alloc(N));
-    CTX_HIP(c, c->sh.alloc((size_t)9 * N)); CTX_HIP(c, c->nbr.alloc((size_t)NUM_NBR * N));
-    launch_permute_grid(st, N, perm.p, kxyz.p, hsdf.p, hsr.p, halb.p, hw.p, hrgb.p, c->cx.p, c->cy.p, c->cz.p, c->rank.p, c->sdf0.p,
+    // grid-sized buffers: release and re-allocate when the voxel count changes (level transitions shrink and grow the grid)
+    auto fit = [&](auto& buf, size_t n) -> hipError_t { if (buf.n != n) buf.release(); return buf.alloc(n); };
+    CTX_HIP(c, fit(c->cx, N)); CTX_HIP(c, fit(c->cy, N)); CTX_HIP(c, fit(c->cz, N)); CTX_HIP(c, fit(c->rank, N));
+    CTX_HIP(c, fit(c->sdf0, N)); CTX_HIP(c, fit(c->x_sdf, N)); CTX_HIP(c, fit(c->x_alb, N)); CTX_HIP(c, fit(c->xc_sdf, N)); CTX_HIP(c, fit(c->xc_alb, N));
+    CTX_HIP(c, fit(c->f_sdf, N)); CTX_HIP(c, fit(c->f_alb, N)); CTX_HIP(c, fit(c->weight, N)); CTX_HIP(c, fit(c->color, N));
+    CTX_HIP(c, fit(c->flags, N)); CTX_HIP(c, fit(c->aidx, N)); CTX_HIP(c, fit(c->alist, N)); CTX_HIP(c, fit(c->aflag, N)); CTX_HIP(c, fit(c->ascan, N));
+    CTX_HIP(c, fit(c->sh, (size_t)9 * N)); CTX_HIP(c, fit(c->nbr, (size_t)NUM_NBR * N));
+    launch_permute_grid(st, N, perm.p, g.kxyz.p, g.sdf.p, g.sdf_ref.p, g.alb.p, g.w.p, g.rgb.p, c->cx.p, c->cy.p, c->cz.p, c->rank.p, c->sdf0.p,
                         c->x_sdf.p, c->x_alb.p, c->f_sdf.p, c->f_alb.p, c->weight.p, c->color.p);
     CTX_HIP(c, hipMemcpyAsync(c->xc_sdf.p, c->x_sdf.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
     CTX_HIP(c, hipMemcpyAsync(c->xc_alb.p, c->x_alb.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
-    // device hash (2x load-factor headroom, power of two) + neighbour table
+    // device hash (2x load-factor headroom, power of two) + neighbour table; the hash stays resident for the level kernels
     unsigned int cap = 1; while (cap < (unsigned int)N * 2u) cap <<= 1;
-    DevBuf<unsigned long long> hkeys; DevBuf<int> hvals;
-    CTX_HIP(c, hkeys.alloc(cap)); CTX_HIP(c, hvals.alloc(cap));
-    CTX_HIP(c, hipMemsetAsync(hkeys.p, 0xff, sizeof(unsigned long long) * (size_t)cap, st));
-    HashTable t{hkeys.p, hvals.p, cap - 1};
+    CTX_HIP(c, fit(c->hkeys, cap)); CTX_HIP(c, fit(c->hvals, cap)); c->hmask = cap - 1;
+    CTX_HIP(c, hipMemsetAsync(c->hkeys.p, 0xff, sizeof(unsigned long long) * (size_t)cap, st));
+    HashTable t{c->hkeys.p, c->hvals.p, cap - 1};
     launch_hash_build(st, N, c->cx.p, c->cy.p, c->cz.p, t);
     launch_nbr_build(st, N, c->cx.p, c->cy.p, c->cz.p, t, c->nbr.p);
     CTX_HIP(c, hipMemsetAsync(c->sh.p, 0, sizeof(float) * 9 * (size_t)N, st));
     size_t sb = 0;
     CTX_HIP(c, rocprim::exclusive_scan(nullptr, sb, c->aflag.p, c->ascan.p, 0, (size_t)N, rocprim::plus<int>(), st));
-    CTX_HIP(c, c->scan_tmp.alloc(sb ? sb : 1)); c->scan_tmp_bytes = sb;
+    c->scan_tmp.release(); CTX_HIP(c, c->scan_tmp.alloc(sb ? sb : 1)); c->scan_tmp_bytes = sb;
     CTX_HIP(c, hipStreamSynchronize(st));
     CTX_HIP(c, hipGetLastError());
     c->have_grid = true;
     return I3D_OK;
 }
+}  // namespace i3d
+
+extern "C" {
 
 int i3d_get_grid(i3d_context* c, double* sdf_refined, double* albedo) {
     if (!c || !c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_get_grid: no grid");

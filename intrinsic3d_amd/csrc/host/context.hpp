@@ -53,6 +53,7 @@ struct i3d_context {
     i3d::DevBuf<uchar4> color;
     i3d::DevBuf<uint8_t> flags;
     i3d::DevBuf<unsigned char> scan_tmp; size_t scan_tmp_bytes = 0;
+    i3d::DevBuf<unsigned long long> hkeys; i3d::DevBuf<int> hvals; unsigned int hmask = 0;     // device hash of the resident grid (kept for the level kernels)
     bool have_grid = false, have_sh = false;
 
     // ---- keyframes ----
@@ -105,6 +106,15 @@ void timing_begin(i3d_context* c, int cat);
 void timing_end(i3d_context* c);
 void timing_flush(i3d_context* c);
 struct TimedScope { i3d_context* c; TimedScope(i3d_context* c_, int cat) : c(c_) { timing_begin(c, cat); } ~TimedScope() { timing_end(c); } };
+
+// context.cpp — (re)build the resident grid from device arrays in visit order
+struct GridStaging { DevBuf<int> kxyz; DevBuf<double> sdf, sdf_ref, alb; DevBuf<float> w; DevBuf<uint8_t> rgb; };
+int set_grid_device(i3d_context* c, int N, float voxel_size, float truncation, GridStaging& st);
+
+// levels.cpp
+int recompute_colors(i3d_context* c, float occlusion_distance, int num_observations);
+int clear_outside_thin_shell(i3d_context* c, double thres_shell, int64_t* new_count);
+int upsample_grid(i3d_context* c, int64_t* new_count);
 
 // solver.cpp
 int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, OptParams& p, i3d_iteration_stats* st);

@@ -1,0 +1,210 @@
+// Host side of the level transitions of Intrinsic3D::refine (refinement/intrinsic3d.cpp:206-409) around the device kernels of
+// level_kernels.hip: recolourisation, thin-shell sparsification, x2 upsampling, and the refine schedule itself.
+//
+// Visit order (SURVEY.md hazard H1).  The reference keeps its voxels in std::unordered_map<Vec3i,...> (hash mat.h:117-124,
+// reserve(64), max_load_factor 0.6: sparse_voxel_grid.cpp:52-53) and several results depend on that container's ITERATION order.
+// Erasing keeps the relative order, so sparsification is a stable filter; upsampling and the initial Voxel -> VoxelSBR conversion
+// build NEW maps, whose iteration order is a property of libstdc++'s container given the insertion sequence.  That order is
+// obtained here by giving the same key sequence to the same standard container (keys only — no voxel payload, no reference code).
+#include "context.hpp"
+#include "../device/level_kernels.hpp"
+#include <rocprim/rocprim.hpp>
+#include <unordered_map>
+
+namespace i3d {
+
+namespace {
+struct Key3 { int x, y, z; bool operator==(const Key3& o) const { return x == o.x && y == o.y && z == o.z; } };
+struct Key3Hash { size_t operator()(const Key3& v) const {      // the reference's std::hash<Vec3i>: int -> size_t sign-extends (mat.h:117-124)
+    return ((size_t)v.x * (size_t)73856093) ^ ((size_t)v.y * (size_t)19349669) ^ ((size_t)v.z * (size_t)83492791); } };
+typedef std::unordered_map<Key3, int, Key3Hash> OrderMap;
+
+// iteration order of a map filled with `keys` (insertion sequence 0..n-1): out[v] = insertion index of the v-th visited key
+void map_iteration_order(const int* keys, size_t n, std::vector<int>& out) {
+    OrderMap m; m.reserve(64); m.max_load_factor(0.6f);
+    for (size_t i = 0; i < n; ++i) m[Key3{keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]}] = (int)i;
+    out.clear(); out.reserve(m.size());
+    for (auto it = m.begin(); it != m.end(); ++it) out.push_back(it->second);
+}
+
+OptParams color_params(const i3d_context* c, float occlusion) {
+    OptParams p; std::memset(&p, 0, sizeof(p));
+    p.K = c->K; p.level = 0; p.pyr_scale = 1.0; p.occlusion = occlusion;
+    bool dz = true;
+    for (int i = 0; i < 4; ++i) { p.intr[i] = c->intr[i]; p.cam_f[i] = (float)c->intr[i]; }          // Camera::setIntrinsics(Vec4) casts to float (camera.cpp:95-98)
+    for (int i = 0; i < 5; ++i) { p.dist[i] = c->dist[i]; p.dist_f[i] = (float)c->dist[i]; if (std::fabs(p.dist_f[i]) > 1e-5f) dz = false; }
+    p.dist_zero = dz ? 1 : 0; p.w = c->fw[0]; p.h = c->fh[0];
+    return p;
+}
+}  // namespace
+
+// Intrinsic3D::recomputeColors (intrinsic3d.cpp:381-409): SDFColorization::add for every keyframe at pyramid level 0, then compute()
+int recompute_colors(i3d_context* c, float occlusion_distance, int num_observations) {
+    if (!c->have_grid || !c->have_frames || !c->have_camera) return ctx_fail(c, I3D_ERR_STATE, "recompute_colors: grid, keyframes and camera must be set");
+    for (auto& b : c->bgr) if (!b.p) return ctx_fail(c, I3D_ERR_STATE, "recompute_colors: keyframes were uploaded without colour images");
+    if (num_observations > MAX_SLOTS || (num_observations <= 0 && c->K > MAX_SLOTS)) return ctx_fail(c, I3D_ERR_CAPACITY, "recompute_colors: more than 8 observations per voxel");
+    CTX_HIP(c, hipSetDevice(c->device));
+    OptParams p = color_params(c, occlusion_distance);
+    std::vector<FrameConst> fc; build_frame_consts(c, 0, c->poses.data(), fc);
+    CTX_HIP(c, hipMemcpyAsync(c->d_frames.p, fc.data(), sizeof(FrameConst) * fc.size(), hipMemcpyHostToDevice, c->stream));
+    { TimedScope t(c, I3D_K_OBSERVE); launch_recolor(c->stream, c->grid_view(), p, c->d_frames.p, num_observations, c->color.p); }
+    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    c->assembled = false;
+    return I3D_OK;
+}
+
+// SDFAlgorithms::clearVoxelsOutsideThinShell (algorithms.cpp:368-458); erase keeps the iteration order of the survivors
+int clear_outside_thin_shell(i3d_context* c, double thres_shell, int64_t* new_count) {
+    if (!c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "clear_outside_thin_shell: no grid");
+    CTX_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream; const int N = c->N;
+    GridView g = c->grid_view(); HashTable t{c->hkeys.p, c->hvals.p, c->hmask};
+    DevBuf<int> keep, inv, keep_v, scan_v;
+    CTX_HIP(c, keep.alloc(N)); CTX_HIP(c, inv.alloc(N)); CTX_HIP(c, keep_v.alloc(N)); CTX_HIP(c, scan_v.alloc(N));
+    CTX_HIP(c, hipMemsetAsync(keep.p, 0, sizeof(int) * (size_t)N, st));
+    launch_shell_mark(st, g, thres_shell, keep.p);
+    launch_shell_crossing(st, g, t, keep.p);
+    launch_inv_rank(st, N, c->rank.p, inv.p);
+    launch_keep_visit(st, N, inv.p, keep.p, keep_v.p);
+    CTX_HIP(c, rocprim::exclusive_scan(c->scan_tmp.p, c->scan_tmp_bytes, keep_v.p, scan_v.p, 0, (size_t)N, rocprim::plus<int>(), st));
+    int tail[2];
+    CTX_HIP(c, hipMemcpyAsync(&tail[0], scan_v.p + (N - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    CTX_HIP(c, hipMemcpyAsync(&tail[1], keep_v.p + (N - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    CTX_HIP(c, hipStreamSynchronize(st));
+    const int M = tail[0] + tail[1];
+    if (new_count) *new_count = M;
+    if (M == N) return I3D_OK;
+    if (M <= 0) return ctx_fail(c, I3D_ERR_STATE, "clear_outside_thin_shell: no voxel left");
+    GridStaging s;
+    CTX_HIP(c, s.kxyz.alloc((size_t)3 * M)); CTX_HIP(c, s.sdf.alloc(M)); CTX_HIP(c, s.sdf_ref.alloc(M)); CTX_HIP(c, s.alb.alloc(M)); CTX_HIP(c, s.w.alloc(M)); CTX_HIP(c, s.rgb.alloc((size_t)3 * M));
+    launch_export_visit(st, g, inv.p, keep.p, scan_v.p, s.kxyz.p, s.sdf.p, s.sdf_ref.p, s.alb.p, s.w.p, s.rgb.p);
+    return set_grid_device(c, M, c->voxel_size, c->truncation, s);
+}
+
+// SDFAlgorithms::upsample (algorithms.cpp:202-235): the new grid has voxel_size/2 and truncation 5*voxel_size/2 (sparse_voxel_grid.cpp:44-49)
+int upsample_grid(i3d_context* c, int64_t* new_count) {
+    if (!c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "upsample_grid: no grid");
+    if ((long long)c->N * 8 > (1ll << 30)) return ctx_fail(c, I3D_ERR_CAPACITY, "upsample_grid: more than 2^30 voxels");
+    CTX_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream; const int N = c->N; const long long M = 8ll * N;
+    GridView g = c->grid_view(); HashTable t{c->hkeys.p, c->hvals.p, c->hmask};
+    DevBuf<int> inv, perm; CTX_HIP(c, inv.alloc(N)); CTX_HIP(c, perm.alloc(M));
+    GridStaging a, b;
+    CTX_HIP(c, a.kxyz.alloc((size_t)3 * M)); CTX_HIP(c, a.sdf.alloc(M)); CTX_HIP(c, a.sdf_ref.alloc(M)); CTX_HIP(c, a.alb.alloc(M)); CTX_HIP(c, a.w.alloc(M)); CTX_HIP(c, a.rgb.alloc((size_t)3 * M));
+    CTX_HIP(c, b.kxyz.alloc((size_t)3 * M)); CTX_HIP(c, b.sdf.alloc(M)); CTX_HIP(c, b.sdf_ref.alloc(M)); CTX_HIP(c, b.alb.alloc(M)); CTX_HIP(c, b.w.alloc(M)); CTX_HIP(c, b.rgb.alloc((size_t)3 * M));
+    launch_inv_rank(st, N, c->rank.p, inv.p);
+    launch_upsample(st, g, t, inv.p, a.kxyz.p, a.sdf.p, a.sdf_ref.p, a.alb.p, a.w.p, a.rgb.p);
+    std::vector<int> keys((size_t)3 * M), order;
+    CTX_HIP(c, hipMemcpyAsync(keys.data(), a.kxyz.p, sizeof(int) * 3 * (size_t)M, hipMemcpyDeviceToHost, st));
+    CTX_HIP(c, hipStreamSynchronize(st));
+    map_iteration_order(keys.data(), (size_t)M, order);
+    if ((long long)order.size() != M) return ctx_fail(c, I3D_ERR_STATE, "upsample_grid: duplicate child keys");
+    CTX_HIP(c, hipMemcpyAsync(perm.p, order.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice, st));
+    launch_permute_staging(st, M, perm.p, a.kxyz.p, a.sdf.p, a.sdf_ref.p, a.alb.p, a.w.p, a.rgb.p, b.kxyz.p, b.sdf.p, b.sdf_ref.p, b.alb.p, b.w.p, b.rgb.p);
+    CTX_HIP(c, hipStreamSynchronize(st));
+    const float vs = c->voxel_size * 0.5f;
+    if (new_count) *new_count = M;
+    return set_grid_device(c, (int)M, vs, vs * 5.0f, b);
+}
+
+}  // namespace i3d
+
+using namespace i3d;
+
+extern "C" {
+
+int i3d_recompute_colors(i3d_context* c, float occlusion_distance, int32_t num_observations) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    return recompute_colors(c, occlusion_distance, num_observations);
+}
+int i3d_clear_outside_thin_shell(i3d_context* c, double thres_shell, int64_t* new_count) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    return clear_outside_thin_shell(c, thres_shell, new_count);
+}
+int i3d_upsample(i3d_context* c, int64_t* new_count) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    return upsample_grid(c, new_count);
+}
+int i3d_grid_info(i3d_context* c, int64_t* num_voxels, float* voxel_size, float* truncation) {
+    if (!c || !c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_grid_info: no grid");
+    if (num_voxels) *num_voxels = c->N; if (voxel_size) *voxel_size = c->voxel_size; if (truncation) *truncation = c->truncation;
+    return I3D_OK;
+}
+int i3d_export_grid(i3d_context* c, int32_t* keys, double* sdf, double* sdf_refined, double* albedo, float* weight, uint8_t* color) {
+    if (!c || !c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_export_grid: no grid");
+    CTX_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream; const int N = c->N;
+    DevBuf<int> inv; GridStaging s;
+    CTX_HIP(c, inv.alloc(N)); CTX_HIP(c, s.kxyz.alloc((size_t)3 * N)); CTX_HIP(c, s.sdf.alloc(N)); CTX_HIP(c, s.sdf_ref.alloc(N)); CTX_HIP(c, s.alb.alloc(N)); CTX_HIP(c, s.w.alloc(N)); CTX_HIP(c, s.rgb.alloc((size_t)3 * N));
+    launch_inv_rank(st, N, c->rank.p, inv.p);
+    launch_export_visit(st, c->grid_view(), inv.p, nullptr, nullptr, s.kxyz.p, s.sdf.p, s.sdf_ref.p, s.alb.p, s.w.p, s.rgb.p);
+    if (keys) CTX_HIP(c, hipMemcpyAsync(keys, s.kxyz.p, sizeof(int) * 3 * (size_t)N, hipMemcpyDeviceToHost, st));
+    if (sdf) CTX_HIP(c, hipMemcpyAsync(sdf, s.sdf.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
+    if (sdf_refined) CTX_HIP(c, hipMemcpyAsync(sdf_refined, s.sdf_ref.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
+    if (albedo) CTX_HIP(c, hipMemcpyAsync(albedo, s.alb.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
+    if (weight) CTX_HIP(c, hipMemcpyAsync(weight, s.w.p, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, st));
+    if (color) CTX_HIP(c, hipMemcpyAsync(color, s.rgb.p, (size_t)3 * N, hipMemcpyDeviceToHost, st));
+    CTX_HIP(c, hipStreamSynchronize(st));
+    return I3D_OK;
+}
+
+// SparseVoxelGrid<Voxel>::load (sparse_voxel_grid.cpp:545-568, records inserted in file order) followed by SDFAlgorithms::convert
+// (algorithms.cpp:47-72: re-insertion in the Voxel map's iteration order, sdf_refined = sdf, albedo = 0.6, then clearInvalidVoxels)
+int i3d_set_grid_from_tsdf_records(i3d_context* c, float voxel_size, int64_t n, const int32_t* keys, const float* sdf, const float* weight, const uint8_t* color) {
+    if (!c || n <= 0 || !keys || !sdf || !weight || !color) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_grid_from_tsdf_records: bad arguments");
+    // map 1: file order -> Voxel map (later records with the same key overwrite the payload, the node keeps its place)
+    OrderMap m1; m1.reserve(64); m1.max_load_factor(0.6f);
+    for (int64_t i = 0; i < n; ++i) m1[Key3{keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]}] = (int)i;
+    std::vector<int> o1; o1.reserve(m1.size());
+    for (auto it = m1.begin(); it != m1.end(); ++it) o1.push_back(it->second);
+    // map 2: VoxelSBR map filled in that order; invalid voxels (weight <= 0) are erased afterwards (order of the rest is unchanged)
+    OrderMap m2; m2.reserve(64); m2.max_load_factor(0.6f);
+    for (int i : o1) m2[Key3{keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2]}] = i;
+    std::vector<int32_t> k; std::vector<double> s, a; std::vector<float> w; std::vector<uint8_t> col;
+    for (auto it = m2.begin(); it != m2.end(); ++it) {
+        const size_t i = (size_t)it->second;
+        if (!(weight[i] > 0.0f)) continue;
+        k.push_back(keys[3 * i]); k.push_back(keys[3 * i + 1]); k.push_back(keys[3 * i + 2]);
+        s.push_back((double)sdf[i]); a.push_back(0.6); w.push_back(weight[i]);
+        col.push_back(color[3 * i]); col.push_back(color[3 * i + 1]); col.push_back(color[3 * i + 2]);
+    }
+    if (w.empty()) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_grid_from_tsdf_records: no valid voxel");
+    i3d_grid_view gv; gv.num_voxels = (int64_t)w.size(); gv.voxel_size = voxel_size; gv.truncation = voxel_size * 5.0f;
+    gv.keys = k.data(); gv.sdf = s.data(); gv.sdf_refined = s.data(); gv.albedo = a.data(); gv.weight = w.data(); gv.color = col.data();
+    return i3d_set_grid(c, &gv);
+}
+
+static double refine_lambda(int it, int n, double l0, double l1) { if (n <= 1) return l0; return l0 + ((l1 - l0) / (double)(n - 1)) * (double)it; }
+
+// Intrinsic3D::refine (intrinsic3d.cpp:206-290) on the resident grid / keyframes / camera
+int i3d_refine(i3d_context* c, const i3d_refine_config* rc, const i3d_optimizer_config* oc, i3d_refine_callback cb, void* user) {
+    if (!c || !rc || !oc) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_refine: null argument");
+    if (!c->have_grid || rc->num_grid_levels <= 0 || rc->num_rgbd_levels <= 0) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_refine: no grid or no levels");   // :208-211
+    if (rc->num_rgbd_levels > c->levels) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_refine: more rgbd levels than uploaded pyramid levels");
+    int rcode = recompute_colors(c, rc->occlusion_distance, rc->num_observations);            // init(): initial SDF recolorization (:196-201)
+    if (rcode) return rcode;
+    const int coarsest = rc->num_grid_levels - 1;
+    for (int gl = coarsest; gl >= 0; --gl) {
+        double factor = rc->thin_shell_factor;                                                 // prepareGridLevel (:298-316)
+        if (rc->thin_shell_factor_final > 0.0) factor = refine_lambda(coarsest - gl, rc->num_grid_levels, rc->thin_shell_factor, rc->thin_shell_factor_final);
+        const double thres = factor * (double)c->voxel_size;
+        if (rc->clear_distant_voxels) { rcode = clear_outside_thin_shell(c, thres, nullptr); if (rcode) return rcode; }
+        for (int pl = rc->num_rgbd_levels - 1; pl >= 0; --pl) {
+            if (pl > 0 && gl < coarsest) continue;                                             // all pyramid levels only on the coarsest grid (:245)
+            i3d_sh_stats shst; int32_t S = 0;
+            rcode = estimate_sh(c, rc->subvolume_size_sh, rc->sh_lambda_reg, thres, &S, nullptr, nullptr, 1 << 30, &shst);
+            if (rcode) break;                                                                  // "lighting estimation not successful": leave the rgbd loop (:257-261)
+            i3d_optimizer_config o = *oc; o.thres_shell = thres; o.grid_level = gl; o.rgbd_level = pl;
+            o.occlusion_distance = rc->occlusion_distance; o.num_observations = rc->num_observations;
+            rcode = optimize(c, o, nullptr);
+            if (rcode && rcode != I3D_ERR_INVALID_ARGUMENT) return rcode;                      // the reference logs a failed optimize and goes on (:273-276)
+            rcode = recompute_colors(c, rc->occlusion_distance, rc->num_observations);         // finishRgbdLevel (:353-378)
+            if (rcode) return rcode;
+            if (cb) cb(user, gl, rc->num_grid_levels, pl, rc->num_rgbd_levels);                // notifyCallbacks -> onSDFRefined (:282)
+        }
+        if (gl > 0) { rcode = upsample_grid(c, nullptr); if (rcode) return rcode; }            // finishGridLevel (:320-333)
+    }
+    return I3D_OK;
+}
+
+}  // extern "C"

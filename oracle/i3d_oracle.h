@@ -72,6 +72,10 @@ int32_t orc_estimate_sh(void* g, float subvolume_size, double lambda_reg, double
 
 int32_t orc_recompute_colors(void* g, void* fr, const double* intr, const double* dist, const double* poses,
                              float occlusion_distance, int32_t num_observations);
+/* Intrinsic3D::refine (intrinsic3d.cpp:206-290); *grid_io is replaced by the upsampled grids */
+int32_t orc_refine(void** grid_io, void* fr, const orc_opt_config* cfg, int32_t num_grid_levels, int32_t num_rgbd_levels,
+                   double thres_shell_factor, double thres_shell_factor_final, int32_t clear_distant_voxels,
+                   float subvolume_size_sh, double sh_lambda_reg, double* intr, double* dist, double* poses, int32_t* levels_done);
 
 /* known-answer probes */
 double  orc_shading_row(int32_t vx, int32_t vy, int32_t vz, const double* sh9, double pyr_scale, double voxel_size,

@@ -86,6 +86,8 @@ def lib():
         L.orc_estimate_sh.argtypes = [vp, f32, f64, f64, i32, vp, vp, vp, i32, vp, vp, C.POINTER(ShStats)]
         L.orc_recompute_colors.restype = i32
         L.orc_recompute_colors.argtypes = [vp, vp, vp, vp, vp, f32, i32]
+        L.orc_refine.restype = i32
+        L.orc_refine.argtypes = [C.POINTER(vp), vp, C.POINTER(OptConfig), i32, i32, f64, f64, i32, f32, f64, vp, vp, vp, C.POINTER(i32)]
         L.orc_shading_row.restype = f64
         L.orc_shading_row.argtypes = [i32, i32, i32, vp, f64, f64, i32, i32, vp, vp, vp]
         L.orc_bicubic.argtypes = [vp, i32, i32, f64, f64, vp, vp, vp]
@@ -161,6 +163,23 @@ class Frames:
     def free(self):
         if self.h:
             lib().orc_frames_free(self.h); self.h = None
+
+
+def recompute_colors(grid: Grid, frames: "Frames", intr, dist, poses, occlusion_distance, num_observations):
+    intr = np.ascontiguousarray(intr, np.float64); dist = np.ascontiguousarray(dist, np.float64); poses = np.ascontiguousarray(poses, np.float64)
+    return lib().orc_recompute_colors(grid.h, frames.h, _p(intr), _p(dist), _p(poses), float(occlusion_distance), int(num_observations))
+
+
+def refine(grid: Grid, frames: "Frames", cfg: "OptConfig", num_grid_levels, num_rgbd_levels, thres_shell_factor, thres_shell_factor_final,
+           clear_distant_voxels, subvolume_size_sh, sh_lambda_reg, intr, dist, poses):
+    """Intrinsic3D::refine on the oracle pieces; `grid` is updated in place (its handle is swapped on upsampling)."""
+    intr = np.array(intr, np.float64); dist = np.array(dist, np.float64); poses = np.array(poses, np.float64)
+    h = C.c_void_p(grid.h); done = C.c_int32(0)
+    rc = lib().orc_refine(C.byref(h), frames.h, C.byref(cfg), int(num_grid_levels), int(num_rgbd_levels), float(thres_shell_factor),
+                          float(thres_shell_factor_final), int(clear_distant_voxels), float(subvolume_size_sh), float(sh_lambda_reg),
+                          _p(intr), _p(dist), _p(poses), C.byref(done))
+    grid.h = h.value
+    return rc, intr, dist, poses, done.value
 
 
 def estimate_sh(grid: Grid, subvolume_size, lambda_reg, thres_shell, cg_fixed=-1, cap=4096):

@@ -194,6 +194,44 @@ int32_t orc_recompute_colors(void* g, void* fr, const double* intr, const double
     return 0;
 }
 
+// intrinsic3d.cpp:206-290 — the double-hierarchical refine schedule over the restated pieces above.
+// *grid_io is replaced when a level is upsampled.  The camera arrays are updated in place.
+int32_t orc_refine(void** grid_io, void* fr, const orc_opt_config* c, int32_t num_grid_levels, int32_t num_rgbd_levels,
+                   double thres_shell_factor, double thres_shell_factor_final, int32_t clear_distant_voxels,
+                   float subvolume_size_sh, double sh_lambda_reg, double* intr, double* dist, double* poses, int32_t* levels_done) {
+    auto* G = (Grid<VoxelSBR>*)*grid_io; auto* F = (Frames*)fr;
+    if (!G || num_grid_levels <= 0 || num_rgbd_levels <= 0) return 1;
+    OptConfig cfg = to_cfg(c);
+    CameraIO cam; for (int i = 0; i < 4; ++i) cam.intr[i] = intr[i]; for (int i = 0; i < 5; ++i) cam.dist[i] = dist[i];
+    cam.poses.assign(poses, poses + 6 * F->K);
+    int done = 0;
+    orc_recompute_colors(G, F, cam.intr, cam.dist, cam.poses.data(), cfg.occlusion_distance, cfg.num_observations);     // init(): :196-201
+    const int coarsest = num_grid_levels - 1;
+    for (int gl = coarsest; gl >= 0; --gl) {
+        double factor = thres_shell_factor;                                                                               // prepareGridLevel :298-316
+        if (thres_shell_factor_final > 0.0) factor = varying_lambda(coarsest - gl, num_grid_levels, thres_shell_factor, thres_shell_factor_final);
+        const double thres = factor * (double)G->voxel_size;
+        if (clear_distant_voxels) clear_voxels_outside_thin_shell(*G, thres);
+        for (int pl = num_rgbd_levels - 1; pl >= 0; --pl) {
+            if (pl > 0 && gl < coarsest) continue;
+            Lighting L; L.sub.size = subvolume_size_sh; L.lambda_reg = sh_lambda_reg; L.thres_shell = thres; L.weighted = true;
+            ShStats ss; std::memset(&ss, 0, sizeof(ss));
+            if (!L.estimate(*G, &ss, cfg.cg_fixed_iterations, false)) break;
+            std::vector<double> vsh; L.voxel_sh(*G, vsh, nullptr);
+            OptConfig o = cfg; o.thres_shell = thres; o.grid_level = gl; o.rgbd_level = pl;
+            optimize(*G, *F, cam, o, vsh, nullptr);
+            orc_recompute_colors(G, F, cam.intr, cam.dist, cam.poses.data(), cfg.occlusion_distance, cfg.num_observations);
+            ++done;
+        }
+        if (gl > 0) { Grid<VoxelSBR>* up = upsample(*G); delete G; G = up; }
+    }
+    *grid_io = G;
+    for (int i = 0; i < 4; ++i) intr[i] = cam.intr[i]; for (int i = 0; i < 5; ++i) dist[i] = cam.dist[i];
+    for (int i = 0; i < 6 * F->K; ++i) poses[i] = cam.poses[i];
+    if (levels_done) *levels_done = done;
+    return 0;
+}
+
 double orc_shading_row(int32_t vx, int32_t vy, int32_t vz, const double* sh9, double pyr_scale, double voxel_size,
                        int32_t w, int32_t h, const float* lum, const double* prm, double* J29) {
     ShadingRowConst k; k.vx = vx; k.vy = vy; k.vz = vz; for (int i = 0; i < 9; ++i) k.sh[i] = sh9[i];
