@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--subvolume", type=float, default=0.2)
     ap.add_argument("--cpu-sample", type=float, default=60000, help="stored voxels of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--pmc-calibrate", action="store_true",
+                    help="also launch a known-size device copy (1 GiB read + 1 GiB write) so that a rocprofv3 --pmc pass over this command "
+                         "can calibrate FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section); see tools/pmc_traffic.py")
     return ap.parse_args()
 
 
@@ -110,6 +113,23 @@ def cpu_baseline(args, sc, thres, log):
             "seconds_per_iteration_sample": sec_per_iter_sample}
 
 
+def pmc_traffic(kernel, eg_rows, active):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json, written by tools/pmc_traffic.py from
+    separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, calibrated on a known-size copy).  Counters cannot
+    be collected inside the timed run, so the figure is only attached when it was measured on the same workload (row count within 1 %; scaled by the row ratio)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        # the row count drifts by ~1e-4 between GN iterations (rows appear / vanish as the surface moves): same workload = within 1 %
+        if abs(d.get("eg_rows", 0) - eg_rows) <= 0.01 * eg_rows and abs(d.get("active_voxels", 0) - active) <= 0.01 * active and kernel in d.get("kernels", {}):
+            best = d["kernels"][kernel]["traffic_bytes_per_launch"] * (eg_rows / float(d["eg_rows"]))
+    return best
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -152,6 +172,11 @@ def main():
     ctx.set_voxel_sh(np.tile(np.asarray(sc["scene"].sh), (arrays["keys"].shape[0], 1)))
     log(f"upload + hash/neighbour build: {time.time() - t0:.2f}s")
 
+    if args.pmc_calibrate:
+        a = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+        for _ in range(3):
+            b = a.clone()          # 16 B/lane vectorised copy: 2^30 B read + 2^30 B written per launch
+        torch.cuda.synchronize(); del a, b
     if args.warmup > 0:
         ctx.optimize(make_cfg(binding, args, args.warmup, thres))
     ctx.timing_enable(True); ctx.timing_get(reset=True)
@@ -187,7 +212,7 @@ def main():
     if dominant:
         k = kernels[dominant]
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None}
+                    "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant, Rg, A)}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
