@@ -58,6 +58,16 @@ __global__ void __launch_bounds__(256) k_observe(GridView g, RowView r, OptParam
                 if (bw[i] > bw[i + 1]) { const float tw = bw[i]; bw[i] = bw[i + 1]; bw[i + 1] = tw; const int tf = bf[i]; bf[i] = bf[i + 1]; bf[i + 1] = tf; }
         }
     }
+    // Slots are stored in ascending KEYFRAME order (empty slots last).  The reference creates a voxel's rows in ascending weight
+    // order, which only permutes terms of sums; with frame order, neighbouring voxels — which mostly pick the same keyframes —
+    // line the same keyframe up in the same slot, so a wave samples one image region and accumulates into one camera block.
+    if (!KEEP_ALL) {
+#pragma unroll
+        for (int pass = 0; pass < SLOTS - 1; ++pass)
+#pragma unroll
+            for (int i = 0; i + 1 < SLOTS - pass; ++i)
+                if ((unsigned)bf[i] > (unsigned)bf[i + 1]) { const float tw = bw[i]; bw[i] = bw[i + 1]; bw[i + 1] = tw; const int tf = bf[i]; bf[i] = bf[i + 1]; bf[i + 1] = tf; }
+    }
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
         r.obs_frame[(size_t)i * r.Acap + a] = bf[i];

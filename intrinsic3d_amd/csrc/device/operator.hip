@@ -43,25 +43,75 @@ static __device__ inline void block_add_d(double v, double* dst) {
 // 160 KB LDS (reps = 32 at K = 200: <= 2-way conflicts instead of 64-way).  LDS is zeroed / flushed once per workgroup.
 constexpr int EG_THREADS = 1024;
 
+// sum of v over the 64 lanes of the wave, returned to every lane: 4 DPP steps inside each row of 16 lanes (pure VALU, no LDS
+// crossbar), then the four row totals through scalar registers
+static __device__ inline float wave_sum(float v) {
+    int x;
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);  v += __int_as_float(x);    // quad_perm [1,0,3,2]
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);  v += __int_as_float(x);    // quad_perm [2,3,0,1]
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true); v += __int_as_float(x);    // row_half_mirror
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true); v += __int_as_float(x);    // row_mirror
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48));
+}
+
+// Camera-block accumulation of one row slot across the wave.  The observation slots are stored in keyframe order, so the lanes of
+// a wave (64 neighbouring voxels) mostly hold the SAME keyframe in a slot: per distinct keyframe the NV values are summed across the
+// wave in registers and one lane issues the LDS atomics (an LDS float atomic costs ~2 cycles PER ACTIVE LANE, measured).  Waves with
+// many distinct keyframes fall back to per-lane atomics into the lane's replica.
+template <int NV>
+static __device__ inline void wave_accumulate(bool valid, int f, const float (&val)[NV], float* lane_acc, float* wave_acc, int stride) {
+    unsigned long long todo = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    for (int round = 0; todo != 0ull; ++round) {
+        if (round == 3) {                                   // > 3 distinct keyframes in this slot of the wave
+            if (valid && ((todo >> lane) & 1ull)) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) atomicAdd(&lane_acc[stride * f + i], val[i]);
+            }
+            break;
+        }
+        const int leader = __ffsll((long long)todo) - 1;
+        const int f0 = __builtin_amdgcn_readlane(f, leader);
+        const bool mine = valid && f == f0;
+        float sum[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum[i] = wave_sum(mine ? val[i] : 0.0f);
+        if (lane == leader) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) atomicAdd(&wave_acc[stride * f0 + i], sum[i]);
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, OptParams p, const float* __restrict__ u, PassBuffers b,
                                                         int reps, int tiles_per_block, const PcgState* __restrict__ state) {
     if (state && state->done) return;
-    extern __shared__ float lds[];        // GRAD/JTJP: [reps][6K] pose accumulators + [9] + JTJP: staged camera part of u [6K+9]; COLNORM: [6K+9] + [21K+25]
+    extern __shared__ float lds[];        // [reps][rs] pose accumulators (6 per keyframe; COLNORM: the 21 block entries) + [NCAM] + JTJP: staged camera part of u [6K+9]
     const int A = r.A, K = p.K; const size_t Acap = r.Acap;
     const int nshared = 6 * K + 9;
-    const int nacc = (MODE == PASS_COLNORM) ? (nshared + 21 * K + 25) : (reps * 6 * K + 9);
+    // replica stride: ODD, so that the replicas of one keyframe's accumulator fall into different LDS banks
+    const int rs = ((MODE == PASS_COLNORM) ? 21 * K : 6 * K) | 1;
+    constexpr int NCAM = (MODE == PASS_COLNORM) ? 34 : 9;       // COLNORM: 9 squared columns + 10 + 15 block entries of intrinsics / distortion
+    const int nacc = reps * rs + NCAM;
     for (int i = threadIdx.x; i < nacc; i += EG_THREADS) lds[i] = 0.0f;
     float* upose = lds + nacc;            // JTJP: the 6K+9 camera entries of u (every row reads 6+9 of them)
     const size_t tail = (size_t)r.world * 2 * (size_t)r.chunk;          // camera part of every solver vector
     const int chunk = r.chunk;
     if (MODE == PASS_JTJP) for (int i = threadIdx.x; i < nshared; i += EG_THREADS) upose[i] = u[tail + i];
     __syncthreads();
-    float* const cam_acc = lds + ((MODE == PASS_COLNORM) ? 6 * K : reps * 6 * K);
-    float* const pose_acc = lds + ((MODE == PASS_COLNORM) ? 0 : (threadIdx.x & (reps - 1)) * (6 * K));
+    float* const cam_acc = lds + reps * rs;
+    float* const pose_acc = lds + (threadIdx.x & (reps - 1)) * rs;            // per-lane replica (fallback path)
+    float* const wave_acc = lds + ((threadIdx.x >> 6) & (reps - 1)) * rs;     // per-wave replica (aggregated path)
     float cam9[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
+    float camb[NCAM];
+#pragma unroll
+    for (int i = 0; i < NCAM; ++i) camb[i] = 0.0f;
     const float tw0 = (float)p.type_w[0];
     const int nC = r.nC;
     const int ntiles = (nC + EG_THREADS - 1) / EG_THREADS;
@@ -99,6 +149,10 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
 #pragma unroll
             for (int q = 0; q < 7; ++q) j4[q] = row[q * 64];
             const float4 m = row[7 * 64];
+            constexpr int NPV = (MODE == PASS_COLNORM) ? 21 : 6;
+            float pv[NPV]; int fsel = 0; bool pvalid = false;
+#pragma unroll
+            for (int i = 0; i < NPV; ++i) pv[i] = 0.0f;
             if (k < nr && m.x != 0.0f) {
                 const float rho = m.x * tw0;
                 const int f = __float_as_int(m.z) & ~ROW_FREE_BIT;
@@ -110,27 +164,26 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
 #pragma unroll
                     for (int c = 0; c < P_VOX; ++c) acc[c] += rho * J[c] * J[c];
                   if (owned) {
-                    float* bl = lds + nshared;
-                    int o = 0;
+                    int o = 0;                                  // upper triangle of this keyframe's 6x6 block
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
-                        atomicAdd(&lds[6 * f + i], rho * J[P_POSE + i] * J[P_POSE + i]);
 #pragma unroll
-                        for (int j = i; j < 6; ++j) { atomicAdd(&bl[21 * f + o], rho * J[P_POSE + i] * J[P_POSE + j]); ++o; }
+                        for (int j = i; j < 6; ++j) { pv[o] = rho * J[P_POSE + i] * J[P_POSE + j]; ++o; }
                     }
-                    o = 0;
+                    fsel = f; pvalid = true;
+                    // intrinsics / distortion blocks are shared by every row: registers, reduced once per workgroup
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) camb[i] += rho * J[P_INTR + i] * J[P_INTR + i];
+                    o = 9;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        atomicAdd(&lds[6 * K + i], rho * J[P_INTR + i] * J[P_INTR + i]);
 #pragma unroll
-                        for (int j = i; j < 4; ++j) { atomicAdd(&bl[21 * K + o], rho * J[P_INTR + i] * J[P_INTR + j]); ++o; }
+                        for (int j = i; j < 4; ++j) { camb[o] += rho * J[P_INTR + i] * J[P_INTR + j]; ++o; }
                     }
-                    o = 0;
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        atomicAdd(&lds[6 * K + 4 + i], rho * J[P_DIST + i] * J[P_DIST + i]);
 #pragma unroll
-                        for (int j = i; j < 5; ++j) { atomicAdd(&bl[21 * K + 10 + o], rho * J[P_DIST + i] * J[P_DIST + j]); ++o; }
+                        for (int j = i; j < 5; ++j) { camb[o] += rho * J[P_DIST + i] * J[P_DIST + j]; ++o; }
                     }
                   }
                 } else {
@@ -152,7 +205,8 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                     for (int c = 0; c < P_VOX; ++c) acc[c] += J[c] * t;
                     if (!p.fix_poses && owned) {
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) atomicAdd(&pose_acc[6 * f + i], J[P_POSE + i] * t);
+                        for (int i = 0; i < 6; ++i) pv[i] = J[P_POSE + i] * t;
+                        fsel = f; pvalid = true;
                     }
                     if (owned) {
 #pragma unroll
@@ -160,6 +214,8 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                     }     // intrinsics + distortion: registers across all tiles, reduced once below
                 }
             }
+            // pose columns of this slot: every lane of the wave takes part (the loop bound nr_max is wave-uniform)
+            wave_accumulate<NPV>(pvalid, fsel, pv, pose_acc, wave_acc, NPV);
         }
         if (in) {
 #pragma unroll
@@ -207,23 +263,32 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
             }
         }
     }
-    if (MODE != PASS_COLNORM) {
-        // the 9 intrinsics/distortion columns are shared by every row: wave-shuffle reduction, one LDS atomic per wave and column
+    // columns shared by every row: wave-shuffle reduction, one LDS atomic per wave and column
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            float v = cam9[i];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if ((threadIdx.x & 63) == 0 && v != 0.0f) atomicAdd(&cam_acc[i], v);
-        }
+    for (int i = 0; i < NCAM; ++i) {
+        float v = (MODE == PASS_COLNORM) ? camb[i] : cam9[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0.0f) atomicAdd(&cam_acc[i], v);
     }
     __syncthreads();
     if (MODE == PASS_COLNORM) {
-        for (int i = threadIdx.x; i < nshared; i += EG_THREADS) { const float v = lds[i]; if (v != 0.0f) atomicAdd(&b.shared[i], (double)v); }
-        for (int i = threadIdx.x; i < 21 * K + 25; i += EG_THREADS) { const float v = lds[nshared + i]; if (v != 0.0f) atomicAdd(&b.blocks[i], (double)v); }
+        for (int i = threadIdx.x; i < 21 * K; i += EG_THREADS) {
+            float v = 0.0f; for (int q = 0; q < reps; ++q) v += lds[q * rs + i];
+            if (v != 0.0f) {
+                atomicAdd(&b.blocks[i], (double)v);
+                const int f = i / 21, o = i - 21 * f;            // diagonal entries of the block are the squared column norms
+                const int di = o == 0 ? 0 : o == 6 ? 1 : o == 11 ? 2 : o == 15 ? 3 : o == 18 ? 4 : o == 20 ? 5 : -1;
+                if (di >= 0) atomicAdd(&b.shared[6 * f + di], (double)v);
+            }
+        }
+        for (int i = threadIdx.x; i < NCAM; i += EG_THREADS) {
+            const float v = cam_acc[i];
+            if (v != 0.0f) atomicAdd(i < 9 ? &b.shared[6 * K + i] : &b.blocks[21 * K + (i - 9)], (double)v);
+        }
     } else {
         for (int i = threadIdx.x; i < nshared; i += EG_THREADS) {
             float v;
-            if (i < 6 * K) { v = 0.0f; for (int q = 0; q < reps; ++q) v += lds[q * 6 * K + i]; }
+            if (i < 6 * K) { v = 0.0f; for (int q = 0; q < reps; ++q) v += lds[q * rs + i]; }
             else v = cam_acc[i - 6 * K];
             if (v != 0.0f) atomicAdd(&b.shared[i], (double)v);
         }
@@ -240,8 +305,9 @@ void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptPar
     const int nshared = 6 * p.K + 9;
     // replicas of the pose accumulator: the largest power of two that fits ~150 KB of LDS
     int reps = 32;
-    while (reps > 1 && (size_t)(reps * 6 * p.K + 9 + nshared) * sizeof(float) > 150 * 1024) reps >>= 1;
-    const size_t lds_rep = (size_t)(reps * 6 * p.K + 9 + nshared) * sizeof(float);
+    const int rs = (6 * p.K) | 1;
+    while (reps > 1 && (size_t)(reps * rs + 9 + nshared) * sizeof(float) > 150 * 1024) reps >>= 1;
+    const size_t lds_rep = (size_t)(reps * rs + 9 + nshared) * sizeof(float);
     if (mode == PASS_GRAD) {
         (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_GRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rep);
         k_eg_pass<PASS_GRAD><<<blocks, EG_THREADS, lds_rep, st>>>(g, r, p, u, b, reps, tiles_per_block, state);
@@ -249,9 +315,12 @@ void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptPar
         (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_JTJP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rep);
         k_eg_pass<PASS_JTJP><<<blocks, EG_THREADS, lds_rep, st>>>(g, r, p, u, b, reps, tiles_per_block, state);
     } else {
-        const size_t n = (size_t)(nshared + 21 * p.K + 25) * sizeof(float);
+        int reps2 = 32;
+        const int rs2 = (21 * p.K) | 1;
+        while (reps2 > 1 && (size_t)(reps2 * rs2 + 34) * sizeof(float) > 150 * 1024) reps2 >>= 1;
+        const size_t n = (size_t)(reps2 * rs2 + 34) * sizeof(float);
         (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_COLNORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n);
-        k_eg_pass<PASS_COLNORM><<<blocks, EG_THREADS, n, st>>>(g, r, p, u, b, 1, tiles_per_block, state);
+        k_eg_pass<PASS_COLNORM><<<blocks, EG_THREADS, n, st>>>(g, r, p, u, b, reps2, tiles_per_block, state);
     }
 }
 
