@@ -18,6 +18,7 @@
 //            per-point work is one cross product instead of three 3x3 products.
 // The 16 bicubic taps of a point are 4 unaligned float4 loads (interior) instead of 16 scalar gathers.
 #include "kernels.hpp"
+#include "reduce_device.hpp"
 
 namespace i3d {
 
@@ -143,17 +144,6 @@ static __device__ inline float chroma_weight(uchar4 c, uchar4 cn) {
     const float one_minus = 1.0f - d;
     // std::max(1-d, 0.01f) keeps a NaN first argument
     return (one_minus < 0.01f) ? 0.01f : one_minus;
-}
-
-// block-level sum of a double into one atomic
-static __device__ inline void block_add(double v, double* dst) {
-    __shared__ double sm[4];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) sm[wv] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i]; if (t != 0.0) atomicAdd(dst, t); }
-    __syncthreads();
 }
 
 // FR_LDS: the per-keyframe constants (144 B each) of ALL keyframes are staged in LDS once per workgroup — every row reads
@@ -365,12 +355,13 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
         }
         }
     }
-    if (!WITH_J) block_add(cost, cost_out);
+    if (!WITH_J) block_partial_d(cost, cost_out, 1, 0);          // per-workgroup partial (no same-address atomics), summed by k_reduce_partials
 }
 
-void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out) {
+void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out, double* scratch) {
     if (r.nC <= 0) return;
     const int blocks = (r.nC + 255) / 256;
+    double* const cost_dst = cost_out; cost_out = scratch;       // the kernels write per-workgroup partials
     const size_t lds = (size_t)p.K * sizeof(FrameHot);
     if (lds <= 48 * 1024) {
         if (with_jacobian) k_build<true, true><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
@@ -379,27 +370,32 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
         if (with_jacobian) k_build<true, false><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
         else k_build<false, false><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
     }
+    if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr);      // cost_dst += sum
 }
 
 // nls_solver.cpp:379-394 — per-type sums of the row weights (sums[0..3]) and row counts (sums[4..7])
-__global__ void __launch_bounds__(256) k_weight_sums(RowView r, double* sums) {
-    const int a = r.own0 + blockIdx.x * blockDim.x + threadIdx.x;      // owned range only
+__global__ void __launch_bounds__(256) k_weight_sums(RowView r, double* partials) {
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0, n0 = 0, n3 = 0, na = 0;
-    if (a < r.own1 && a < r.A && (r.aflags[a] & F_ACTIVE)) {
-        na = 1.0;
+    for (int a = r.own0 + blockIdx.x * blockDim.x + threadIdx.x; a < r.own1 && a < r.A; a += gridDim.x * blockDim.x) {      // owned range only
+        if (!(r.aflags[a] & F_ACTIVE)) continue;
+        na += 1.0;
         const int nr = r.nrows[a];
         for (int k = 0; k < nr; ++k) { const float w = r.rows[row_index(a, k, 7, r.slots)].x; s0 += (double)w; if (w != 0.0f) n0 += 1.0; }
         const uint8_t rf = r.regflags[a];
-        if (rf & 1) s1 = 1.0;
-        if (rf & 2) s2 = 1.0;
+        if (rf & 1) s1 += 1.0;
+        if (rf & 2) s2 += 1.0;
         for (int d = 0; d < 6; ++d) { const float w = r.ea_w[(size_t)d * r.Acap + a]; s3 += (double)w; if (w != 0.0f) n3 += 1.0; }
     }
-    block_add(s0, sums + 0); block_add(s1, sums + 1); block_add(s2, sums + 2); block_add(s3, sums + 3);
-    block_add(n0, sums + 4); block_add(n3, sums + 7); block_add(na, sums + 8);
+    block_partial_d(s0, partials, 9, 0); block_partial_d(s1, partials, 9, 1); block_partial_d(s2, partials, 9, 2); block_partial_d(s3, partials, 9, 3);
+    block_partial_d(n0, partials, 9, 4); block_partial_d(0.0, partials, 9, 5); block_partial_d(0.0, partials, 9, 6); block_partial_d(n3, partials, 9, 7);
+    block_partial_d(na, partials, 9, 8);
 }
-void launch_weight_sums(hipStream_t st, RowView r, double* sums9) {
+void launch_weight_sums(hipStream_t st, RowView r, double* sums9, double* scratch) {
     const int n = r.own1 - r.own0;
-    if (n > 0) k_weight_sums<<<(n + 255) / 256, 256, 0, st>>>(r, sums9);
+    if (n <= 0) return;
+    int blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+    k_weight_sums<<<blocks, 256, 0, st>>>(r, scratch);
+    launch_reduce_partials(st, scratch, blocks, 9, sums9, nullptr);
 }
 
 }  // namespace i3d

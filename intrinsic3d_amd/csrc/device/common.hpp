@@ -90,6 +90,7 @@ __host__ __device__ inline bool shard_needs_entry(int a, int own0, int own1, boo
 }
 __host__ __device__ inline void shard_range(int A, int world, int rank, int& chunk, int& own0, int& own1) {
     chunk = (A + world - 1) / world; if (chunk < 1) chunk = 1;
+    chunk = (chunk + 3) & ~3;       // slices start on 16-byte boundaries (the vector kernels move float4)
     own0 = rank * chunk < A ? rank * chunk : A; own1 = (rank + 1) * chunk < A ? (rank + 1) * chunk : A;
 }
 
@@ -116,6 +117,7 @@ struct RowView {                    // per work-list entry a in [0, A): voxels t
 
 // device-resident scalar state of one PCG solve (ConjugateGradientsSolver) — no host round trip inside an iteration
 struct PcgState {
+    double acc[4];                  // slice partial sums of the iteration in flight: r.z, x.(b+r), x.r, sum D^2 x^2 (one all-reduce when sharded)
     double rho, last_rho, pq, alpha, beta;
     double xbr, xr, d2xx;           // x.(b+r), x.r, sum D^2 x^2 at the last completed iteration
     double Q0, Q1;

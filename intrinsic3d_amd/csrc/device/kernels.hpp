@@ -27,8 +27,9 @@ void launch_observe(hipStream_t st, GridView g, RowView r, OptParams p, const Fr
 // ---- build.hip --------------------------------------------------------------------------------------------
 // with_jacobian: fills res/J/roww/rowfree + regulariser flags (assembly).  Otherwise evaluates the cost of the rows
 // already assembled at the state (g.x_sdf, g.x_alb, frames, p) into cost_out (double, accumulated).
-void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out);
-void launch_weight_sums(hipStream_t st, RowView r, double* sums9 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels */);
+void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out /* accumulated */, double* scratch);
+void launch_weight_sums(hipStream_t st, RowView r, double* sums9 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels */,
+                        double* scratch);
 
 // ---- operator.hip -----------------------------------------------------------------------------------------
 // All vectors are in work-list space: NP = 2A + 6K + 9.
@@ -41,7 +42,9 @@ struct PassBuffers {
 };
 void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u /*[NP] or null*/, PassBuffers b, const PcgState* state);
 void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out /*[2A]*/);
-void launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_out, const PcgState* state);
+int  launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_partials, const PcgState* state);   // returns #partials
+// dst[k] += sum_b partials[b*ncomp + k]: the second stage of every fp64 reduction (no same-address atomics from thousands of workgroups)
+void launch_reduce_partials(hipStream_t st, const double* partials, int nblk, int ncomp, double* dst, const PcgState* state);
 void launch_shared_finalize(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, float* out /*[NP]*/, bool tail, const float* S, const float* D2,
                             const float* v, double* dot_out, const PcgState* state);
 
@@ -50,21 +53,23 @@ void launch_fill_d(hipStream_t st, int n, double* x, double v);
 void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* out);                 // out = a*b
 void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* freemask, float* S);          // S = free ? 1/(1+sqrt(c)) : 0
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float inv_radius, float* D2, float* Minv_diag);  // D2 = clamp(c S^2)/radius, Minv = 1/(c S^2 + D2) (free) else 0
-void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out /* accumulated */);
+void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out /* accumulated */, double* scratch);
 void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask /*[NP]*/);
 
 // fused PCG iteration, scalars resident in PcgState
 void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations);
-void launch_pcg_precond_slice(hipStream_t st, size_t off, int n, const float* Minv, const float* r, float* z, PcgState* state);                    // z = M^-1 r on a slice, partial rho
-void launch_pcg_precond_tail(hipStream_t st, size_t tail_off, int K, const float* Minv_blocks, const float* r, float* z, PcgState* state);    // camera blocks (after the rho reduction), beta
+// mode: 0 init (z, r.z) | 1 x += a p, r -= a q, z, sums | 2 x only | 3 r = b - q(=A x), z, sums      (a rank's slice; off, n multiples of 4)
+int  launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
+                     float* z, double* partials /*[blocks][4]*/, PcgState* state);                               // returns #partials
+void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state);
+void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
+                       const float* D2, float* z, const double* partials, int nblk, PcgState* state);           // camera tail + Q-test + rho, beta
 void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state);                  // p = z + beta p, u = S p
-void launch_pcg_scalar2(hipStream_t st, PcgState* state, const double* pq_src);                                                                                       // alpha = rho / pq
-void launch_pcg_update(hipStream_t st, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, int reset_phase, PcgState* state);
-void launch_pcg_reset_r(hipStream_t st, int n, const float* x, const float* tmp, float* r, const float* b, const float* D2, PcgState* state);
-void launch_pcg_scalar3(hipStream_t st, PcgState* state);                                                                                       // Q-test, bookkeeping
+void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
+                       float* q, const float* S, const float* D2, const float* v, PcgState* state);                                                          // camera tail of q, p.q, alpha
 
 void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* x_shared, double* xc_sdf, double* xc_alb,
-                      double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask);
+                      double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask, double* scratch);
 void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb);           // x <- candidate, refresh fp32 shadows
 void launch_mark_compute(hipStream_t st, RowView r, int* flag);
 void launch_compact_list(hipStream_t st, int A, const int* flag, const int* scan, int* list);

@@ -20,6 +20,7 @@
 // sums into alpha/beta/termination flags, every vector kernel starts with `if (state->done) return`, and the host only polls
 // the state one iteration behind (no pipeline bubble).
 #include "kernels.hpp"
+#include "reduce_device.hpp"
 #include <cstdlib>
 
 namespace i3d {
@@ -27,13 +28,18 @@ namespace i3d {
 #define GRID_STRIDE(n) const int stride = gridDim.x * blockDim.x; for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += stride)
 static inline int vblocks(int n) { int b = (n + 255) / 256; return b < 1 ? 1 : (b > 2048 ? 2048 : b); }
 
-static __device__ inline void block_add_d(double v, double* dst) {
-    __shared__ double sm[4];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i]; if (t != 0.0) atomicAdd(dst, t); }
-    __syncthreads();
+// dst[k] += sum over workgroups of partials[b * ncomp + k]   (one workgroup)
+__global__ void __launch_bounds__(1024) k_reduce_partials(const double* __restrict__ partials, int nblk, int ncomp, double* dst, const PcgState* __restrict__ state) {
+    if (state && state->done) return;
+    for (int k = 0; k < ncomp; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += partials[(size_t)i * ncomp + k];
+        const double t = block_sum_d(s);
+        if (threadIdx.x == 0) dst[k] += t;
+    }
+}
+void launch_reduce_partials(hipStream_t st, const double* partials, int nblk, int ncomp, double* dst, const PcgState* state) {
+    if (nblk > 0) k_reduce_partials<<<1, 1024, 0, st>>>(partials, nblk, ncomp, dst, state);
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------------
@@ -380,7 +386,7 @@ __global__ void __launch_bounds__(256) k_gather(RowView r, PassBuffers b, float*
         }
         out[js] = osdf; out[ja] = oalb;
     }
-    if (TAIL && dot_out) block_add_d(dotp, dot_out);
+    if (TAIL && dot_out) block_partial_d(dotp, dot_out, 1, 0);      // per-workgroup partial of v.out (summed by k_pcg_tail_b / k_reduce_partials)
 }
 void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out) {
     const int n = (r.own1 < r.A ? r.own1 : r.A) - r.own0;
@@ -389,10 +395,12 @@ void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, floa
     if (mode == PASS_COLNORM) k_gather<true, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, nullptr);
     else k_gather<false, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
-void launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_out, const PcgState* state) {
+int launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_partials, const PcgState* state) {
     const int n = (r.own1 < r.A ? r.own1 : r.A) - r.own0;
-    if (n <= 0) return;
-    k_gather<false, true><<<(n + 255) / 256, 256, 0, st>>>(r, b, out, S, D2, v, dot_out, state);
+    if (n <= 0) return 0;
+    const int blocks = (n + 255) / 256;
+    k_gather<false, true><<<blocks, 256, 0, st>>>(r, b, out, S, D2, v, dot_partials, state);
+    return blocks;                       // number of partials written (when dot_partials != nullptr)
 }
 
 // camera tail of the vectors: out[2A + i] from the fp64 accumulators; TAIL as above
@@ -409,7 +417,7 @@ __global__ void k_shared_finalize(size_t tail_off, int K, OptParams p, const dou
         if (tail) { const float vv = v[j]; o = S[j] * o + D2[j] * vv; dotp = (double)vv * (double)o; }
         out[j] = o;
     }
-    if (tail && dot_out) block_add_d(dotp, dot_out);
+    if (tail && dot_out) { const double t = block_sum_d(dotp); if (threadIdx.x == 0 && t != 0.0) atomicAdd(dot_out, t); }     // a handful of workgroups
 }
 void launch_shared_finalize(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, float* out, bool tail, const float* S, const float* D2,
                             const float* v, double* dot_out, const PcgState* state) {
@@ -432,14 +440,19 @@ __global__ void k_lm_diag(int n, const float* c, const float* S, float inv_radiu
 }
 __global__ void __launch_bounds__(256) k_dot(int n, const float* a, const float* b, double* out) {
     double s = 0.0; GRID_STRIDE(n) s += (double)a[i] * (double)b[i];
-    block_add_d(s, out);
+    block_partial_d(s, out, 1, 0);
 }
 void launch_fill(hipStream_t st, int n, float* x, float v) { if (n > 0) k_fill<<<vblocks(n), 256, 0, st>>>(n, x, v); }
 void launch_fill_d(hipStream_t st, int n, double* x, double v) { if (n > 0) k_fill_d<<<vblocks(n), 256, 0, st>>>(n, x, v); }
 void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* o) { if (n > 0) k_mul<<<vblocks(n), 256, 0, st>>>(n, a, b, o); }
 void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* m, float* S) { if (n > 0) k_scale<<<vblocks(n), 256, 0, st>>>(n, c, m, S); }
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float ir, float* D2, float* Minv) { if (n > 0) k_lm_diag<<<vblocks(n), 256, 0, st>>>(n, c, S, ir, D2, Minv); }
-void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out) { if (n > 0) k_dot<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, a, b, out); }
+void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out, double* scratch) {      // out += a.b
+    if (n <= 0) return;
+    const int blocks = vblocks(n) > 1024 ? 1024 : vblocks(n);
+    k_dot<<<blocks, 256, 0, st>>>(n, a, b, scratch);
+    launch_reduce_partials(st, scratch, blocks, 1, out, nullptr);
+}
 
 __global__ void k_freemask(RowView r, OptParams p, float* __restrict__ mask) {
     const int A = r.A, chunk = r.chunk, nv = r.world * 2 * chunk, NP = nv + 6 * p.K + 9;
@@ -459,113 +472,205 @@ __global__ void k_freemask(RowView r, OptParams p, float* __restrict__ mask) {
 void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask) { k_freemask<<<vblocks(r.world * 2 * r.chunk + 6 * p.K + 9), 256, 0, st>>>(r, p, mask); }
 
 // ---- fused PCG iteration (conjugate_gradients_solver.cc) -------------------------------------------------------------
-// (1) z = M^-1 r on the voxel part (1x1 blocks) and rho += r.z ; the camera blocks go through k_pcg_precond_shared
-__global__ void __launch_bounds__(256) k_pcg_precond(int n2, const float* __restrict__ Minv, const float* __restrict__ r, float* __restrict__ z, PcgState* state) {
+// One iteration = 7 launches:  tail_a | direction | (memset) eg_pass | gather | tail_b | step.
+//   k_pcg_step   (a rank's slice of the voxel unknowns, 16 B per lane):  x += alpha p ; r -= alpha q ; z = M^-1 r ; slice partial
+//                sums of r.z, x.(b+r), x.r, sum D^2 x^2 into state->acc[4]  (ONE 4-double all-reduce per iteration when sharded,
+//                issued together with the all-gather of z)
+//   k_pcg_tail_a (camera tail, replicated, one workgroup): same update on the 6K+9 camera unknowns, block-Jacobi z, adds its sums to
+//                the reduced slice sums, then the scalar logic of the iteration boundary: quadratic-model stop test (eta = 0.1) of the
+//                iteration just finished, rho / beta of the next one
+//   k_pcg_direction  p = z + beta p ; u = S p   (over the whole vector when sharded: p is kept replicated, so the operator input
+//                needs no exchange of its own)
+//   k_pcg_tail_b camera tail of q = A p from the reduced fp64 block, p.q, alpha
+enum { STEP_INIT = 0, STEP_NORMAL = 1, STEP_XONLY = 2, STEP_RESET = 3 };
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_pcg_step(int n4, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x, float4* __restrict__ r,
+                                                  const float4* __restrict__ b, const float4* __restrict__ D2, const float4* __restrict__ Minv, float4* __restrict__ z,
+                                                  double* __restrict__ partials, PcgState* state) {
     if (state->done) return;
-    double s = 0.0;
-    GRID_STRIDE(n2) { const float ri = r[i], zi = Minv[i] * ri; z[i] = zi; s += (double)ri * (double)zi; }
-    block_add_d(s, &state->rho);
+    const float alpha = (float)state->alpha;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float xv[4], rv[4];
+        if (MODE == STEP_INIT) { const float4 t = r[i]; rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
+        else {
+            const float4 xo = x[i];
+            xv[0] = xo.x; xv[1] = xo.y; xv[2] = xo.z; xv[3] = xo.w;
+            if (MODE != STEP_RESET) {
+                const float4 pp = p[i];
+                xv[0] += alpha * pp.x; xv[1] += alpha * pp.y; xv[2] += alpha * pp.z; xv[3] += alpha * pp.w;
+                x[i] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            }
+            if (MODE == STEP_XONLY) continue;
+            const float4 qq = q[i];             // q = A p, or (RESET) tmp = A x
+            if (MODE == STEP_NORMAL) { const float4 ro = r[i]; rv[0] = ro.x - alpha * qq.x; rv[1] = ro.y - alpha * qq.y; rv[2] = ro.z - alpha * qq.z; rv[3] = ro.w - alpha * qq.w; }
+            const float4 bb = b[i], dd = D2[i];
+            if (MODE == STEP_RESET) { rv[0] = bb.x - qq.x; rv[1] = bb.y - qq.y; rv[2] = bb.z - qq.z; rv[3] = bb.w - qq.w; }
+            r[i] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const double xd = xv[k]; s1 += xd * ((double)bv[k] + (double)rv[k]); s2 += xd * (double)rv[k]; s3 += (double)dv[k] * xd * xd; }
+        }
+        const float4 mm = Minv[i];
+        const float zv[4] = {mm.x * rv[0], mm.y * rv[1], mm.z * rv[2], mm.w * rv[3]};
+        z[i] = make_float4(zv[0], zv[1], zv[2], zv[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s0 += (double)rv[k] * (double)zv[k];
+    }
+    if (MODE == STEP_XONLY) return;
+    block_partial_d(s0, partials, 4, 0); block_partial_d(s1, partials, 4, 1); block_partial_d(s2, partials, 4, 2); block_partial_d(s3, partials, 4, 3);
 }
-__global__ void k_pcg_precond_shared(size_t tail_off, int K, const float* __restrict__ Minv, const float* __restrict__ r, float* __restrict__ z, PcgState* state) {
+
+// camera tail, x only (residual-reset iterations: x is needed before r = b - A x can be formed)
+__global__ void k_pcg_tail_x(size_t to, int NS, const float* __restrict__ p, float* __restrict__ x, const PcgState* __restrict__ state) {
     if (state->done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double dotp = 0.0;
-    if (i < 6 * K + 9) {
+    const float alpha = (float)state->alpha;
+    for (int i = threadIdx.x; i < NS; i += blockDim.x) x[to + i] += alpha * p[to + i];
+}
+
+__global__ void __launch_bounds__(256) k_pcg_tail_a(int mode, size_t to, int K, const float* __restrict__ Mblk, const float* __restrict__ p, const float* __restrict__ q,
+                                                    float* __restrict__ x, float* __restrict__ r, const float* __restrict__ b, const float* __restrict__ D2,
+                                                    float* __restrict__ z, const double* __restrict__ partials, int nblk, PcgState* st) {
+    if (st->done) return;
+    __shared__ double red[4][4];
+    const int NS = 6 * K + 9;
+    const float alpha = (float)st->alpha;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (mode != STEP_INIT) {
+        for (int i = threadIdx.x; i < NS; i += blockDim.x) {
+            const size_t j = to + i;
+            float xi = x[j], ri;
+            if (mode == STEP_NORMAL) { xi += alpha * p[j]; x[j] = xi; ri = r[j] - alpha * q[j]; }
+            else ri = b[j] - q[j];                                   // RESET: q holds tmp = A x, x was updated by k_pcg_tail_x
+            r[j] = ri;
+            const double xd = xi; s1 += xd * ((double)b[j] + (double)ri); s2 += xd * (double)ri; s3 += (double)D2[j] * xd * xd;
+        }
+    }
+    __syncthreads();                                                 // the whole tail of r is final: the block preconditioner mixes entries
+    for (int i = threadIdx.x; i < NS; i += blockDim.x) {
         int base, n, row; const float* M;
-        if (i < 6 * K) { const int f = i / 6; base = 6 * f; n = 6; row = i - base; M = Minv + 36 * f; }
-        else if (i < 6 * K + 4) { base = 6 * K; n = 4; row = i - base; M = Minv + 36 * K; }
-        else { base = 6 * K + 4; n = 5; row = i - base; M = Minv + 36 * K + 16; }
-        const float* rs = r + tail_off;
+        if (i < 6 * K) { const int f = i / 6; base = 6 * f; n = 6; row = i - base; M = Mblk + 36 * f; }
+        else if (i < 6 * K + 4) { base = 6 * K; n = 4; row = i - base; M = Mblk + 36 * K; }
+        else { base = 6 * K + 4; n = 5; row = i - base; M = Mblk + 36 * K + 16; }
+        const float* rs = r + to;
         float s = 0.0f;
         for (int j = 0; j < n; ++j) s += M[row * n + j] * rs[base + j];
-        z[tail_off + i] = s; dotp = (double)rs[i] * (double)s;
+        z[to + i] = s; s0 += (double)rs[i] * (double)s;
     }
-    block_add_d(dotp, &state->rho);
-}
-// (2) scalar step: validity of rho, beta
-__global__ void k_pcg_scalar1(PcgState* st) {
-    if (st->done) return;
-    const double rho = st->rho;
-    if (rho == 0.0 || isinf(rho) || isnan(rho)) { st->done = 2; return; }
-    if (st->it > 0) { const double beta = rho / st->last_rho; if (beta == 0.0 || isinf(beta) || isnan(beta)) { st->done = 2; return; } st->beta = beta; }
-    else st->beta = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {          // slice sums of k_pcg_step (single rank; sharded ranks reduce + all-reduce them into acc first)
+        s0 += partials[4 * (size_t)i]; s1 += partials[4 * (size_t)i + 1]; s2 += partials[4 * (size_t)i + 2]; s3 += partials[4 * (size_t)i + 3];
+    }
+    double v[4] = {s0, s1, s2, s3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
+    if ((threadIdx.x & 63) == 0) { for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = v[k]; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double tot[4];
+    for (int k = 0; k < 4; ++k) { double t = st->acc[k]; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][k]; tot[k] = t; st->acc[k] = 0.0; }
     st->pq = 0.0;
+    if (mode != STEP_INIT) {                                         // end of iteration it: quadratic-model termination (eta = 0.1)
+        st->xbr = tot[1]; st->xr = tot[2]; st->d2xx = tot[3];
+        const int it = st->it + 1; st->it = it;
+        const double Q1 = -tot[1]; st->Q1 = Q1;
+        if (st->fixed_iterations >= 0) { st->Q0 = Q1; if (it >= st->fixed_iterations) { st->done = 1; return; } }
+        else {
+            const double zeta = (double)it * (Q1 - st->Q0) / Q1;
+            if (zeta < 0.1) { st->done = 1; return; }
+            st->Q0 = Q1;
+            if (it >= st->max_iterations) { st->done = 1; return; }
+        }
+    }
+    // start of the next iteration: rho = r.z, beta
+    const double rho = tot[0];
+    if (rho == 0.0 || isinf(rho) || isnan(rho)) { st->done = 2; return; }
+    if (st->it > 0) { const double beta = rho / st->rho; if (beta == 0.0 || isinf(beta) || isnan(beta)) { st->done = 2; return; } st->beta = beta; }
+    else st->beta = 0.0;
+    st->last_rho = st->rho; st->rho = rho;
 }
-// (3) p = z + beta p ; u = S p
+
+// p = z + beta p ; u = S p
 __global__ void __launch_bounds__(256) k_pcg_direction(int n, const float* __restrict__ z, float* __restrict__ p, const float* __restrict__ S, float* __restrict__ u, const PcgState* __restrict__ state) {
     if (state->done) return;
     const float beta = (float)state->beta; const bool first = state->it == 0;
-    GRID_STRIDE(n) { const float pi = first ? z[i] : z[i] + beta * p[i]; p[i] = pi; u[i] = S[i] * pi; }
+    const int n4 = n >> 2;
+    const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* S4 = reinterpret_cast<const float4*>(S); float4* u4 = reinterpret_cast<float4*>(u);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float4 pi = z4[i];
+        if (!first) { const float4 po = p4[i]; pi.x += beta * po.x; pi.y += beta * po.y; pi.z += beta * po.z; pi.w += beta * po.w; }
+        p4[i] = pi;
+        const float4 sv = S4[i];
+        u4[i] = make_float4(sv.x * pi.x, sv.y * pi.y, sv.z * pi.z, sv.w * pi.w);
+    }
+    for (int i = 4 * n4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {       // the camera tail is not a multiple of 4
+        const float pi = first ? z[i] : z[i] + beta * p[i]; p[i] = pi; u[i] = S[i] * pi;
+    }
 }
-// (4) eg_pass + gather_tail + shared_finalize give q and pq ; scalar step: alpha
-__global__ void k_pcg_scalar2(PcgState* st, const double* pq_src) {
+
+// camera tail of q = (S J^T W J S + D^2) p from the (all-reduced) fp64 camera block, p.q, alpha = rho / p.q
+__global__ void __launch_bounds__(256) k_pcg_tail_b(size_t to, int K, OptParams p, const double* __restrict__ shared, const double* __restrict__ pq_slice,
+                                                    const double* __restrict__ pq_partials, int nblk, float* __restrict__ q, const float* __restrict__ S, const float* __restrict__ D2, const float* __restrict__ v, PcgState* st) {
     if (st->done) return;
-    const double pq = pq_src ? *pq_src : st->pq;
+    __shared__ double red[4];
+    const int NS = 6 * K + 9;
+    double dotp = 0.0;
+    for (int i = threadIdx.x; i < NS; i += blockDim.x) {
+        const bool fixed = i < 6 * K ? p.fix_poses : (i < 6 * K + 4 ? p.fix_intr : p.fix_dist);
+        const size_t j = to + i;
+        const float vv = v[j];
+        const float o = S[j] * (fixed ? 0.0f : (float)shared[i]) + D2[j] * vv;
+        q[j] = o; dotp += (double)vv * (double)o;
+    }
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) dotp += pq_partials[i];       // workgroup partials of the voxel part (k_gather)
+    for (int o = 32; o > 0; o >>= 1) dotp += __shfl_down(dotp, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dotp;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double pq = *pq_slice; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) pq += red[w];
+    st->pq = pq;
     if (!(pq > 0.0) || isinf(pq)) { st->done = 2; return; }
     const double alpha = st->rho / pq;
     if (isinf(alpha)) { st->done = 2; return; }
-    st->alpha = alpha; st->xbr = 0.0; st->xr = 0.0; st->d2xx = 0.0;
+    st->alpha = alpha;
 }
-// (5) x += alpha p ; r -= alpha q (unless this is a residual-reset iteration) ; partial sums of x.(b+r), x.r, sum D2 x^2
-__global__ void __launch_bounds__(256) k_pcg_update(int n, const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ x, float* __restrict__ r,
-                                                    const float* __restrict__ b, const float* __restrict__ D2, int reset_phase, PcgState* state) {
-    if (state->done) return;
-    const float alpha = (float)state->alpha;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    GRID_STRIDE(n) {
-        const float xi = x[i] + alpha * p[i]; x[i] = xi;
-        if (reset_phase == 0) {
-            const float ri = r[i] - alpha * q[i]; r[i] = ri;
-            const double xd = xi; s0 += xd * ((double)b[i] + (double)ri); s1 += xd * (double)ri; s2 += (double)D2[i] * xd * xd;
-        }
-    }
-    if (reset_phase == 0) { block_add_d(s0, &state->xbr); block_add_d(s1, &state->xr); block_add_d(s2, &state->d2xx); }
-}
-// (5') every residual_reset_period iterations: r = b - A x (A x in tmp), then the same partial sums
-__global__ void __launch_bounds__(256) k_pcg_reset_r(int n, const float* __restrict__ x, const float* __restrict__ tmp, float* __restrict__ r,
-                                                     const float* __restrict__ b, const float* __restrict__ D2, PcgState* state) {
-    if (state->done) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    GRID_STRIDE(n) { const float ri = b[i] - tmp[i]; r[i] = ri; const double xd = x[i]; s0 += xd * ((double)b[i] + (double)ri); s1 += xd * (double)ri; s2 += (double)D2[i] * xd * xd; }
-    block_add_d(s0, &state->xbr); block_add_d(s1, &state->xr); block_add_d(s2, &state->d2xx);
-}
-// (6) scalar step: quadratic-model termination (eta = 0.1), bookkeeping for the next iteration
-__global__ void k_pcg_scalar3(PcgState* st) {
-    if (st->done) return;
-    const int it = st->it + 1;
-    st->it = it;
-    const double Q1 = -st->xbr; st->Q1 = Q1;
-    st->last_rho = st->rho; st->rho = 0.0;
-    if (st->fixed_iterations >= 0) { if (it >= st->fixed_iterations) st->done = 1; st->Q0 = Q1; return; }
-    const double zeta = (double)it * (Q1 - st->Q0) / Q1;
-    if (zeta < 0.1) { st->done = 1; return; }
-    st->Q0 = Q1;
-    if (it >= st->max_iterations) st->done = 1;
-}
+
 __global__ void k_pcg_init(PcgState* st, int fixed_iterations, int max_iterations) {
+    for (int k = 0; k < 4; ++k) st->acc[k] = 0.0;
     st->rho = 0.0; st->last_rho = 1.0; st->pq = 0.0; st->alpha = 0.0; st->beta = 0.0; st->xbr = 0.0; st->xr = 0.0; st->d2xx = 0.0;
     st->Q0 = 0.0; st->Q1 = 0.0; st->it = 0; st->done = (fixed_iterations == 0) ? 1 : 0; st->fixed_iterations = fixed_iterations; st->max_iterations = max_iterations;
 }
 
 void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations) { k_pcg_init<<<1, 1, 0, st>>>(state, fixed_iterations, max_iterations); }
-// voxel part of z = M^-1 r over [off, off+n) (a rank's slice), partial rho
-void launch_pcg_precond_slice(hipStream_t st, size_t off, int n, const float* Minv, const float* r, float* z, PcgState* state) {
-    if (n > 0) k_pcg_precond<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, Minv + off, r + off, z + off, state);
+static inline int step_blocks(int n4) { int b = (n4 + 255) / 256; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
+// off and n must be multiples of 4 (the rank-major layout pads every slice to a multiple of 8 floats)
+int launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
+                    float* z, double* partials, PcgState* state) {
+    if (n <= 0) return 0;
+    const int n4 = n >> 2;
+    auto c4 = [off](const float* v) { return reinterpret_cast<const float4*>(v + off); };
+    auto m4 = [off](float* v) { return reinterpret_cast<float4*>(v + off); };
+    switch (mode) {
+        case STEP_INIT:   k_pcg_step<STEP_INIT><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
+        case STEP_NORMAL: k_pcg_step<STEP_NORMAL><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
+        case STEP_XONLY:  k_pcg_step<STEP_XONLY><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
+        default:          k_pcg_step<STEP_RESET><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
+    }
+    return mode == STEP_XONLY ? 0 : step_blocks(n4);      // number of [4]-partials written
 }
-// camera blocks (replicated on every rank: call AFTER the slice partials have been reduced) + beta
-void launch_pcg_precond_tail(hipStream_t st, size_t tail_off, int K, const float* Minv_blocks, const float* r, float* z, PcgState* state) {
-    k_pcg_precond_shared<<<(6 * K + 9 + 255) / 256, 256, 0, st>>>(tail_off, K, Minv_blocks, r, z, state);
-    k_pcg_scalar1<<<1, 1, 0, st>>>(state);
+void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state) { k_pcg_tail_x<<<1, 256, 0, st>>>(tail_off, 6 * K + 9, p, x, state); }
+void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
+                       const float* D2, float* z, const double* partials, int nblk, PcgState* state) {
+    k_pcg_tail_a<<<1, 256, 0, st>>>(mode, tail_off, K, Minv_blocks, p, q, x, r, b, D2, z, partials, nblk, state);
 }
-void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state) { if (n > 0) k_pcg_direction<<<vblocks(n), 256, 0, st>>>(n, z, p, S, u, state); }
-void launch_pcg_scalar2(hipStream_t st, PcgState* state, const double* pq_src) { k_pcg_scalar2<<<1, 1, 0, st>>>(state, pq_src); }
-void launch_pcg_update(hipStream_t st, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, int reset_phase, PcgState* state) {
-    if (n > 0) k_pcg_update<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, p, q, x, r, b, D2, reset_phase, state);
+void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state) {
+    if (n > 0) k_pcg_direction<<<step_blocks(n >> 2), 256, 0, st>>>(n, z, p, S, u, state);
 }
-void launch_pcg_reset_r(hipStream_t st, int n, const float* x, const float* tmp, float* r, const float* b, const float* D2, PcgState* state) {
-    if (n > 0) k_pcg_reset_r<<<vblocks(n) > 1024 ? 1024 : vblocks(n), 256, 0, st>>>(n, x, tmp, r, b, D2, state);
+void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
+                       float* q, const float* S, const float* D2, const float* v, PcgState* state) {
+    k_pcg_tail_b<<<1, 256, 0, st>>>(tail_off, K, p, shared, pq_slice, pq_partials, nblk, q, S, D2, v, state);
 }
-void launch_pcg_scalar3(hipStream_t st, PcgState* state) { k_pcg_scalar3<<<1, 1, 0, st>>>(state); }
 
 // ---- LM candidate / acceptance ------------------------------------------------------------------------------------------
 // candidate point x + S*step (TrustRegionMinimizer: delta = step .* jacobian_scaling), squared norms of delta and x over the free
@@ -591,12 +696,13 @@ __global__ void __launch_bounds__(256) k_candidate(GridView g, RowView r, int K,
             if (mask[j] != 0.0f) { d2 += delta * delta; x2 += x * x; }
         }
     }
-    block_add_d(d2, norms2); block_add_d(x2, norms2 + 1);
+    block_partial_d(d2, norms2, 2, 0); block_partial_d(x2, norms2, 2, 1);
 }
 void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* xsh, double* xc_sdf, double* xc_alb,
-                      double* xc_sh, double* norms2, const float* mask) {
+                      double* xc_sh, double* norms2, const float* mask, double* scratch) {
     int b = vblocks(r.A + 6 * K + 9); if (b > 1024) b = 1024;
-    k_candidate<<<b, 256, 0, st>>>(g, r, K, sign, step, S, xsh, xc_sdf, xc_alb, xc_sh, norms2, mask);
+    k_candidate<<<b, 256, 0, st>>>(g, r, K, sign, step, S, xsh, xc_sdf, xc_alb, xc_sh, scratch, mask);
+    launch_reduce_partials(st, scratch, b, 2, norms2, nullptr);
 }
 // x <- candidate on the work list (everything else never moves), refresh the fp32 shadows
 __global__ void k_accept(GridView g, RowView r, const double* __restrict__ xc_sdf, const double* __restrict__ xc_alb) {

@@ -18,6 +18,13 @@ struct RcclComm : Comm {
     int allgather(float* dev, size_t count, hipStream_t st) override {
         return ncclAllGather(dev + (size_t)rank * count, dev, count, ncclFloat, comm, st) == ncclSuccess ? 0 : 1;
     }
+    int allreduce_allgather(double* red, size_t n, float* vec, size_t count, hipStream_t st) override {      // one grouped launch
+        if (ncclGroupStart() != ncclSuccess) return 1;
+        const ncclResult_t a = ncclAllReduce(red, red, n, ncclDouble, ncclSum, comm, st);
+        const ncclResult_t b = ncclAllGather(vec + (size_t)rank * count, vec, count, ncclFloat, comm, st);
+        const ncclResult_t e = ncclGroupEnd();
+        return (a == ncclSuccess && b == ncclSuccess && e == ncclSuccess) ? 0 : 1;
+    }
 };
 
 int rccl_unique_id(void* out, size_t* bytes) {

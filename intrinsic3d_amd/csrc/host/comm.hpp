@@ -16,6 +16,10 @@ struct Comm {
     virtual int allreduce_sum(double* dev, size_t n, hipStream_t st) = 0;
     // in-place all-gather: every rank owns count floats at dev + rank*count; afterwards all world*count floats are valid everywhere
     virtual int allgather(float* dev, size_t count, hipStream_t st) = 0;
+    // both of the above as one exchange (the PCG iteration boundary: 4 scalars + the preconditioned residual slices)
+    virtual int allreduce_allgather(double* red, size_t n, float* vec, size_t count, hipStream_t st) {
+        const int rc = allreduce_sum(red, n, st); return rc ? rc : allgather(vec, count, st);
+    }
 };
 
 Comm* make_rccl_comm(int rank, int world, const void* unique_id, size_t id_bytes, hipStream_t st, char* err, size_t errlen);

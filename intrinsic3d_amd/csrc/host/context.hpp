@@ -82,7 +82,7 @@ struct i3d_context {
     i3d::DevBuf<float> v_mask, v_c, v_S, v_D2, v_Minv, v_b, v_x, v_r, v_p, v_z, v_q, v_u, v_acc, v_tmp;
     i3d::DevBuf<float> Minv_blocks;
     i3d::DevBuf<double> d_shared, d_blocks, d_scal, d_xshared, d_xcshared;
-    i3d::DevBuf<i3d::PcgState> d_pcg; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};
+    i3d::DevBuf<i3d::PcgState> d_pcg; i3d::DevBuf<double> d_partials; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};
     double* h_pinned = nullptr; size_t h_pinned_n = 0;
 
     i3d::OptParams last_params; bool assembled = false;

@@ -44,12 +44,13 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8));
     const size_t NP = 2 * (size_t)c->N + 2 * 64 + 6 * (size_t)c->K + 9;          // rank-major layout pads every rank's slice to the same chunk
     for (DevBuf<float>* v : {&c->v_mask, &c->v_c, &c->v_S, &c->v_D2, &c->v_Minv, &c->v_b, &c->v_x, &c->v_r, &c->v_p, &c->v_z, &c->v_q, &c->v_u, &c->v_acc, &c->v_tmp})
-        CTX_HIP(c, v->alloc(NP));
+        { const bool fresh = v->n < NP || !v->p; CTX_HIP(c, v->alloc(NP)); if (fresh) CTX_HIP(c, hipMemset(v->p, 0, sizeof(float) * v->n)); }   // padding entries stay finite
     CTX_HIP(c, c->Minv_blocks.alloc((size_t)36 * c->K + 16 + 25));
     CTX_HIP(c, c->d_shared.alloc((size_t)6 * c->K + 9 + 1)); CTX_HIP(c, c->d_blocks.alloc((size_t)21 * c->K + 25));      // +1: p.q partial rides with the camera block
     CTX_HIP(c, c->clist.alloc(Acap)); CTX_HIP(c, c->cflag.alloc(Acap)); CTX_HIP(c, c->cscan.alloc(Acap));
     CTX_HIP(c, c->d_scal.alloc(32)); CTX_HIP(c, c->d_xshared.alloc((size_t)6 * c->K + 9)); CTX_HIP(c, c->d_xcshared.alloc((size_t)6 * c->K + 9));
     CTX_HIP(c, c->d_pcg.alloc(1));
+    CTX_HIP(c, c->d_partials.alloc((Acap / 256 + 2048) * 9));       // per-workgroup partial sums of the fp64 reductions
     if (!c->h_pcg) CTX_HIP(c, hipHostMalloc((void**)&c->h_pcg, 2 * sizeof(PcgState), hipHostMallocDefault));
     for (auto& e : c->pcg_ev) if (!e) CTX_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return ensure_pinned(c, 64 + (size_t)27 * c->K + 64);
@@ -65,6 +66,10 @@ static bool sharded(const i3d_context* c) { return c->comm && c->comm->world > 1
 static int allreduce(i3d_context* c, double* dev, size_t n) {
     if (!sharded(c)) return I3D_OK;
     return c->comm->allreduce_sum(dev, n, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-reduce failed") : I3D_OK;
+}
+static int allreduce_allgather(i3d_context* c, double* red, size_t n, float* vec) {      // one fused exchange per PCG iteration
+    if (!c->comm || c->comm->world <= 1) return I3D_OK;
+    return c->comm->allreduce_allgather(red, n, vec, 2 * (size_t)c->chunk, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-reduce + all-gather failed") : I3D_OK;
 }
 static int allgather(i3d_context* c, float* vec) {       // every rank contributes its slice of a solver vector
     if (!sharded(c)) return I3D_OK;
@@ -100,7 +105,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     CTX_HIP(c, hipStreamSynchronize(s));
     c->A = tail[0] + tail[1];
     { TimedScope t(c, I3D_K_CLASSIFY); launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
-    if (!sharded(c)) { c->chunk = c->A > 0 ? c->A : 1; c->own0 = 0; c->own1 = c->A; c->nC = c->A; }
+    if (!sharded(c)) { shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; }
     else {      // owned range + compute list (every rank derives them from the replicated work list: no communication)
         const int world = c->comm->world, rank = c->comm->rank;
         shard_range(c->A, world, rank, c->chunk, c->own0, c->own1); c->nC = 0;
@@ -117,9 +122,9 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     }
     RowView r = c->row_view();
     { TimedScope t(c, I3D_K_OBSERVE); launch_observe(s, g, r, p, c->d_frames.p); }
-    { TimedScope t(c, I3D_K_BUILD); launch_build(s, g, r, p, c->d_frames.p, true, nullptr); }
+    { TimedScope t(c, I3D_K_BUILD); launch_build(s, g, r, p, c->d_frames.p, true, nullptr, c->d_partials.p); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
-    { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, c->d_scal.p); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, c->d_scal.p, c->d_partials.p); }
     { int rc = allreduce(c, c->d_scal.p, 9); if (rc) return rc; }
     double sums[9]; { int rc = read_doubles(c, c->d_scal.p, 9, sums); if (rc) return rc; }
     sums[5] = sums[1]; sums[6] = sums[2];
@@ -152,9 +157,9 @@ static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const flo
 static int dot(i3d_context* c, const float* a, const float* b, double* out) {
     const Layout L = layout_of(c);
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 4, c->stream));
-    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, (int)L.slice_n, a + L.slice_off, b + L.slice_off, c->d_scal.p); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, (int)L.slice_n, a + L.slice_off, b + L.slice_off, c->d_scal.p, c->d_partials.p); }
     { int rc = allreduce(c, c->d_scal.p, 1); if (rc) return rc; }
-    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, L.NS, a + L.tail_off, b + L.tail_off, c->d_scal.p); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, L.NS, a + L.tail_off, b + L.tail_off, c->d_scal.p, c->d_partials.p); }
     return read_doubles(c, c->d_scal.p, 1, out);
 }
 
@@ -202,7 +207,7 @@ static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const F
     GridView g = c->grid_view();
     if (candidate) { g.x_sdf = c->xc_sdf.p; g.x_alb = c->xc_alb.p; }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 16, 0, sizeof(double), c->stream));
-    { TimedScope t(c, I3D_K_COST); launch_build(c->stream, g, c->row_view(), p, frames, false, c->d_scal.p + 16); }
+    { TimedScope t(c, I3D_K_COST); launch_build(c->stream, g, c->row_view(), p, frames, false, c->d_scal.p + 16, c->d_partials.p); }
     { int rc = allreduce(c, c->d_scal.p + 16, 1); if (rc) return rc; }
     return read_doubles(c, c->d_scal.p + 16, 1, cost);
 }
@@ -218,64 +223,66 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     PassBuffers pb{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
     PcgState* st = c->d_pcg.p;
     double* pq_slot = c->d_shared.p + L.NS;
+    const size_t so = L.slice_off, to = L.tail_off; const int sn = (int)L.slice_n;
     { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, (int)L.NP, c->v_x.p, 0.0f); launch_pcg_init(s, st, cfg.pcg_fixed_iterations, 500); }
     CTX_HIP(c, hipMemcpyAsync(c->v_r.p, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s));
-    // vector kernels: one launch over [slice | tail] when they are contiguous (single rank), slice then tail otherwise
-    const size_t so = L.slice_off, to = L.tail_off; const int sn = (int)L.slice_n, tn = L.NS;
-    auto apply = [&](const float* v, float* out, bool with_dot) -> int {       // out = A v given u = S v (all-gathered) in v_u
-        { int rc = allgather(c, c->v_u.p); if (rc) return rc; }
+    // the operator on the rows of this rank: out(slice) = S J^T W J u + D^2 v, camera block and p.q partial left in d_shared (reduced over ranks)
+    // fp64 partial sums: [0, 4*2048) slice sums of k_pcg_step, then the p.q partials of k_gather
+    double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048;
+    int n_pq = 0, n_step = 0;
+    auto rows_apply = [&](const float* v, float* out, bool with_dot) -> int {
         CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
         { TimedScope t(c, I3D_K_EG_PASS); launch_eg_pass(s, PASS_JTJP, g, r, p, c->v_u.p, pb, st); }
-        { TimedScope t(c, I3D_K_GATHER); launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, with_dot ? pq_slot : nullptr, st); }
-        { int rc = allreduce(c, c->d_shared.p, (size_t)L.NS + 1); if (rc) return rc; }
-        { TimedScope t(c, I3D_K_VECTOR); launch_shared_finalize(s, to, K, p, c->d_shared.p, out, true, c->v_S.p, c->v_D2.p, v, with_dot ? pq_slot : nullptr, st); }
-        return I3D_OK;
+        { TimedScope t(c, I3D_K_GATHER); n_pq = launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, with_dot ? pq_part : nullptr, st); }
+        if (!multi) return I3D_OK;
+        if (with_dot) { launch_reduce_partials(s, pq_part, n_pq, 1, pq_slot, st); n_pq = 0; }      // the p.q partial rides with the camera block
+        return allreduce(c, c->d_shared.p, (size_t)L.NS + 1);
     };
+    { TimedScope t(c, I3D_K_VECTOR);
+      n_step = launch_pcg_step(s, 0 /*init*/, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st); }
+    int tail_mode = 0;
     int it = 1;
     for (;; ++it) {
-        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_precond_slice(s, so, sn, c->v_Minv.p, c->v_r.p, c->v_z.p, st); }
-        { int rc = allreduce(c, &st->rho, 1); if (rc) return rc; }
+        // iteration boundary.  Sharded: ONE message pair — the 4 slice sums (r.z, x.(b+r), x.r, sum D2 x^2) and the slices of z
+        if (multi) { launch_reduce_partials(s, step_part, n_step, 4, st->acc, st); n_step = 0;
+                     int rc = allreduce_allgather(c, st->acc, 4, c->v_z.p); if (rc) return rc; }
         { TimedScope t(c, I3D_K_VECTOR);
-          launch_pcg_precond_tail(s, to, K, c->Minv_blocks.p, c->v_r.p, c->v_z.p, st);
-          if (!multi) launch_pcg_direction(s, sn + tn, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, st);
-          else { launch_pcg_direction(s, sn, c->v_z.p + so, c->v_p.p + so, c->v_S.p + so, c->v_u.p + so, st);
-                 launch_pcg_direction(s, tn, c->v_z.p + to, c->v_p.p + to, c->v_S.p + to, c->v_u.p + to, st); } }
-        { int rc = apply(c->v_p.p, c->v_q.p, true); if (rc) return rc; }
-        const bool reset = (it % 10 == 0);                                       // residual_reset_period
-        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_scalar2(s, st, pq_slot);
-          if (!multi) launch_pcg_update(s, sn + tn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, reset ? 1 : 0, st);
-          else launch_pcg_update(s, sn, c->v_p.p + so, c->v_q.p + so, c->v_x.p + so, c->v_r.p + so, c->v_b.p + so, c->v_D2.p + so, reset ? 1 : 0, st); }
-        if (multi) {
-            if (!reset) { int rc = allreduce(c, &st->xbr, 3); if (rc) return rc; }
-            TimedScope t(c, I3D_K_VECTOR);
-            launch_pcg_update(s, tn, c->v_p.p + to, c->v_q.p + to, c->v_x.p + to, c->v_r.p + to, c->v_b.p + to, c->v_D2.p + to, reset ? 1 : 0, st);
-        }
-        if (reset) {
-            { TimedScope t(c, I3D_K_VECTOR);
-              if (!multi) launch_mul(s, sn + tn, c->v_S.p, c->v_x.p, c->v_u.p);
-              else { launch_mul(s, sn, c->v_S.p + so, c->v_x.p + so, c->v_u.p + so); launch_mul(s, tn, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); } }
-            { int rc = apply(c->v_x.p, c->v_tmp.p, false); if (rc) return rc; }
-            { TimedScope t(c, I3D_K_VECTOR);
-              if (!multi) launch_pcg_reset_r(s, sn + tn, c->v_x.p, c->v_tmp.p, c->v_r.p, c->v_b.p, c->v_D2.p, st);
-              else launch_pcg_reset_r(s, sn, c->v_x.p + so, c->v_tmp.p + so, c->v_r.p + so, c->v_b.p + so, c->v_D2.p + so, st); }
-            if (multi) {
-                { int rc = allreduce(c, &st->xbr, 3); if (rc) return rc; }
-                TimedScope t(c, I3D_K_VECTOR);
-                launch_pcg_reset_r(s, tn, c->v_x.p + to, c->v_tmp.p + to, c->v_r.p + to, c->v_b.p + to, c->v_D2.p + to, st);
-            }
-        }
-        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_scalar3(s, st); }
+          launch_pcg_tail_a(s, tail_mode, to, K, c->Minv_blocks.p, c->v_p.p, tail_mode == 3 ? c->v_tmp.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_z.p,
+                            step_part, n_step, st); }
         const int slot = it & 1;
         CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[slot], st, sizeof(PcgState), hipMemcpyDeviceToHost, s));
         CTX_HIP(c, hipEventRecord(c->pcg_ev[slot], s));
-        if (it >= 2) {                                                           // look at iteration it-1 while iteration it runs
+        { TimedScope t(c, I3D_K_VECTOR);        // p is kept replicated (z was all-gathered), so u = S p needs no exchange
+          if (!multi) launch_pcg_direction(s, sn + L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, st);
+          else launch_pcg_direction(s, (int)L.NP, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, st); }
+        { int rc = rows_apply(c->v_p.p, c->v_q.p, true); if (rc) return rc; }
+        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_tail_b(s, to, K, p, c->d_shared.p, pq_slot, pq_part, n_pq, c->v_q.p, c->v_S.p, c->v_D2.p, c->v_p.p, st); }
+        const bool reset = (it % 10 == 0);                                       // residual_reset_period
+        if (!reset) {
+            TimedScope t(c, I3D_K_VECTOR);
+            n_step = launch_pcg_step(s, 1, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st);
+            tail_mode = 1;
+        } else {                                                                 // r = b - A x instead of r -= alpha q
+            { TimedScope t(c, I3D_K_VECTOR);
+              launch_pcg_step(s, 2, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st);
+              launch_pcg_tail_x(s, to, K, c->v_p.p, c->v_x.p, st);
+              launch_mul(s, sn, c->v_S.p + so, c->v_x.p + so, c->v_u.p + so); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
+            { int rc = allgather(c, c->v_u.p); if (rc) return rc; }
+            { int rc = rows_apply(c->v_x.p, c->v_tmp.p, false); if (rc) return rc; }
+            { TimedScope t(c, I3D_K_VECTOR);
+              launch_shared_finalize(s, to, K, p, c->d_shared.p, c->v_tmp.p, true, c->v_S.p, c->v_D2.p, c->v_x.p, nullptr, st);
+              n_step = launch_pcg_step(s, 3, so, sn, c->v_p.p, c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st); }
+            tail_mode = 3;
+        }
+        if (it >= 2) {                                                           // look at the boundary of pass it-1 while pass it runs
             CTX_HIP(c, hipEventSynchronize(c->pcg_ev[slot ^ 1]));
             if (c->h_pcg[slot ^ 1].done) break;
         }
         if (it > 520) break;
     }
+    CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[0], st, sizeof(PcgState), hipMemcpyDeviceToHost, s));
     CTX_HIP(c, hipStreamSynchronize(s));
-    *final_state = c->h_pcg[it & 1];            // the newest copy (kernels after `done` were no-ops, so it equals the terminal state)
+    *final_state = c->h_pcg[0];                 // kernels after `done` were no-ops, so this is the terminal state
     return I3D_OK;
 }
 
@@ -337,7 +344,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
         // candidate point (replicated: every rank needs the whole step)
         { int rc2 = allgather(c, c->v_x.p); if (rc2) return rc2; }
         CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 4, 0, sizeof(double) * 2, s));
-        { TimedScope t(c, I3D_K_VECTOR); launch_candidate(s, g, r, K, -1.0f, c->v_x.p, c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p); }
+        { TimedScope t(c, I3D_K_VECTOR); launch_candidate(s, g, r, K, -1.0f, c->v_x.p, c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p, c->d_partials.p); }
         double norms[2]; rc = read_doubles(c, c->d_scal.p + 4, 2, norms); if (rc) return rc;
         rc = read_doubles(c, c->d_xcshared.p, NS, xcshared.data()); if (rc) return rc;
         OptParams pc = p;
@@ -405,13 +412,13 @@ static int list_maps(i3d_context* c, std::vector<int>& rank, std::vector<int>& a
     return I3D_OK;
 }
 static int to_visit_order(i3d_context* c, const float* dev_vec, double* out) {
-    const int N = c->N, A = c->A, K = c->K, NS = 6 * K + 9, NP = 2 * A + NS;
+    const int N = c->N, A = c->A, K = c->K, NS = 6 * K + 9, ch = c->chunk, NP = 2 * ch + NS;      // single-rank layout [sdf ch | alb ch | camera]
     std::vector<float> h(NP); std::vector<int> rank, alist;
     CTX_HIP(c, hipMemcpy(h.data(), dev_vec, sizeof(float) * (size_t)NP, hipMemcpyDeviceToHost));
     int rc = list_maps(c, rank, alist); if (rc) return rc;
     for (int i = 0; i < 2 * N + NS; ++i) out[i] = 0.0;
-    for (int a = 0; a < A; ++a) { const int v = rank[alist[a]]; out[v] = h[a]; out[N + v] = h[A + a]; }
-    for (int i = 0; i < NS; ++i) out[2 * N + i] = h[2 * A + i];
+    for (int a = 0; a < A; ++a) { const int v = rank[alist[a]]; out[v] = h[a]; out[N + v] = h[ch + a]; }
+    for (int i = 0; i < NS; ++i) out[2 * N + i] = h[2 * ch + i];
     return I3D_OK;
 }
 
@@ -430,15 +437,15 @@ int normal_eq_debug(i3d_context* c, double* gradient, double* jtj_diag, double* 
 int jtj_apply_debug(i3d_context* c, const double* x, double* y) {
     if (!c->assembled) return ctx_fail(c, I3D_ERR_STATE, "debug: call i3d_debug_assemble first");
     CTX_HIP(c, hipSetDevice(c->device));
-    const int N = c->N, A = c->A, K = c->K, NS = 6 * K + 9, NP = 2 * A + NS;
+    const int N = c->N, A = c->A, K = c->K, NS = 6 * K + 9, ch = c->chunk, NP = 2 * ch + NS;
     OptParams p = c->last_params;
-    std::vector<int> rank, alist; std::vector<float> h(NP), m(NP);
+    std::vector<int> rank, alist; std::vector<float> h(NP, 0.0f), m(NP);
     int rc = list_maps(c, rank, alist); if (rc) return rc;
     launch_freemask(c->stream, c->row_view(), p, c->v_mask.p);
     CTX_HIP(c, hipStreamSynchronize(c->stream));
     CTX_HIP(c, hipMemcpy(m.data(), c->v_mask.p, sizeof(float) * (size_t)NP, hipMemcpyDeviceToHost));
-    for (int a = 0; a < A; ++a) { const int v = rank[alist[a]]; h[a] = (float)x[v] * m[a]; h[A + a] = (float)x[N + v] * m[A + a]; }
-    for (int i = 0; i < NS; ++i) h[2 * A + i] = (float)x[2 * N + i] * m[2 * A + i];
+    for (int a = 0; a < A; ++a) { const int v = rank[alist[a]]; h[a] = (float)x[v] * m[a]; h[ch + a] = (float)x[N + v] * m[ch + a]; }
+    for (int i = 0; i < NS; ++i) h[2 * ch + i] = (float)x[2 * N + i] * m[2 * ch + i];
     CTX_HIP(c, hipMemcpy(c->v_u.p, h.data(), sizeof(float) * (size_t)NP, hipMemcpyHostToDevice));
     rc = run_pass(c, PASS_JTJP, p, c->v_u.p, c->v_acc.p); if (rc) return rc;
     CTX_HIP(c, hipStreamSynchronize(c->stream));
