@@ -22,7 +22,12 @@
 
 namespace i3d {
 
-struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+// 4 consecutive taps of one image row as ONE 16-byte load from a 4-byte aligned address.  The pointer is re-typed to the global
+// address space: it reaches the kernel through a per-keyframe struct staged in LDS, which makes it a FLAT pointer for the compiler,
+// and flat accesses are neither widened nor allowed to be misaligned (64 flat_load_dword per row instead of 16 global_load_dwordx4).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef const __attribute__((address_space(1))) f4u* gf4u_ptr;
+typedef const __attribute__((address_space(1))) float* gf_ptr;
 
 struct PointShared {   // per stencil point j in {000,100,010,001}; value path fp64, derivative path fp32
     double P[3];       // iso-projected world position
@@ -84,8 +89,8 @@ static __device__ inline void bicubic(const float* __restrict__ img, int w, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rr = min(max(row - 1 + i, 0), h - 1);
-        const float* line = img + (size_t)rr * w;
-        if (interior) { const F4U v = *reinterpret_cast<const F4U*>(line + (col - 1)); t[i] = make_float4(v.x, v.y, v.z, v.w); }
+        const gf_ptr line = (gf_ptr)(img + (size_t)rr * w);
+        if (interior) { const f4u v = *(gf4u_ptr)(line + (col - 1)); t[i] = make_float4(v.x, v.y, v.z, v.w); }
         else t[i] = make_float4(line[min(max(col - 1, 0), w - 1)], line[min(max(col, 0), w - 1)], line[min(max(col + 1, 0), w - 1)], line[min(max(col + 2, 0), w - 1)]);
     }
     double fr[4];
