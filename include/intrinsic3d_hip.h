@@ -32,7 +32,8 @@ typedef enum {
     I3D_ERR_HIP = 3,
     I3D_ERR_STATE = 4,              /* grid / frames / camera not set */
     I3D_ERR_CAPACITY = 5,
-    I3D_ERR_COMM = 6
+    I3D_ERR_COMM = 6,
+    I3D_ERR_IO = 7                  /* file missing / truncated (SparseVoxelGrid::load, Camera::load return false) */
 } i3d_status;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
@@ -153,6 +154,24 @@ typedef struct {                   /* Intrinsic3D::Config (intrinsic3d.h:67-84),
 /* RefinementCallback::onSDFRefined(RefinementInfo) (intrinsic3d.h:94-114) */
 typedef void (*i3d_refine_callback)(void* user, int32_t grid_level, int32_t num_grid_levels, int32_t pyramid_level, int32_t num_pyramid_levels);
 int i3d_refine(i3d_context* ctx, const i3d_refine_config* rcfg, const i3d_optimizer_config* ocfg, i3d_refine_callback cb, void* user);
+
+/* ---- on-disk formats either side of the path (host-only; no device needed) -------------------------------------------------
+ * .tsdf: header {f32 voxel_size, f32 truncation, f32 integration_weight_sample, u64 count, f32 max_load_factor} then count records
+ *        {i32 x,y,z; f32 sdf; f32 weight; u8 r,g,b; u8 pad}  (SparseVoxelGrid<Voxel>::save/load, sparse_voxel_grid.cpp:484-569).
+ * VoxelSBR dump: same header, records {i32 x,y,z; f64 sdf; f32 weight; u8 r,g,b,pad; f64 albedo; f64 sdf_refined} (44 bytes).
+ * poses: TUM trajectory lines (Sensor::savePoses, rgbd/sensor.cpp:315-347); intrinsics: Camera::save/load (camera.cpp:202-274).
+ * i3d_config_load_yaml reads the flat `key: "value"` map of data/intrinsic3d.yml into the two config structs. */
+int i3d_tsdf_read_header(const char* path, float* voxel_size, float* truncation, float* integration_weight_sample, uint64_t* count, float* max_load_factor);
+int i3d_tsdf_read_records(const char* path, uint64_t capacity, int32_t* keys, float* sdf, float* weight, uint8_t* color);
+int i3d_tsdf_write(const char* path, float voxel_size, float truncation, float integration_weight_sample, float max_load_factor, uint64_t count,
+                   const int32_t* keys, const float* sdf, const float* weight, const uint8_t* color);
+int i3d_sbr_write(const char* path, float voxel_size, float truncation, float integration_weight_sample, float max_load_factor, uint64_t count,
+                  const int32_t* keys, const double* sdf, const double* sdf_refined, const double* albedo, const float* weight, const uint8_t* color);
+int i3d_sbr_read(const char* path, uint64_t capacity, int32_t* keys, double* sdf, double* sdf_refined, double* albedo, float* weight, uint8_t* color);
+int i3d_write_poses(const char* path, int32_t num_frames, const double* timestamps, const double* poses_world_to_cam /* [K][6] */);
+int i3d_write_intrinsics(const char* path, int32_t width, int32_t height, const double* intr4, const double* dist5);
+int i3d_read_intrinsics(const char* path, int32_t* width, int32_t* height, double* intr4, double* dist5);
+int i3d_config_load_yaml(const char* path, i3d_refine_config* rcfg, i3d_optimizer_config* ocfg);
 
 /* ---- one process per GPU: the voxel state is replicated, row work / row storage / solver vectors are sharded by contiguous
  * work-list ranges; RCCL carries the PCG scalars, the camera block and the per-iteration vector exchange.  Call after i3d_create

@@ -64,6 +64,8 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_optimizer_config_default", "i3d_optimize", "i3d_optimize_host", "i3d_estimate_sh",
            "i3d_set_grid_from_tsdf_records", "i3d_recompute_colors", "i3d_clear_outside_thin_shell", "i3d_upsample", "i3d_grid_info",
            "i3d_export_grid", "i3d_refine",
+           "i3d_tsdf_read_header", "i3d_tsdf_read_records", "i3d_tsdf_write", "i3d_sbr_write", "i3d_sbr_read", "i3d_write_poses",
+           "i3d_write_intrinsics", "i3d_read_intrinsics", "i3d_config_load_yaml",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_timing_enable", "i3d_timing_get", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
@@ -123,6 +125,16 @@ def load():
     L.i3d_grid_info.restype = i32; L.i3d_grid_info.argtypes = [vp, C.POINTER(i64), C.POINTER(f32), C.POINTER(f32)]
     L.i3d_export_grid.restype = i32; L.i3d_export_grid.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.i3d_refine.restype = i32; L.i3d_refine.argtypes = [vp, C.POINTER(RefineConfig), C.POINTER(OptimizerConfig), REFINE_CALLBACK, vp]
+    u64 = C.c_uint64; cp = C.c_char_p
+    L.i3d_tsdf_read_header.restype = i32; L.i3d_tsdf_read_header.argtypes = [cp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(u64), C.POINTER(f32)]
+    L.i3d_tsdf_read_records.restype = i32; L.i3d_tsdf_read_records.argtypes = [cp, u64, vp, vp, vp, vp]
+    L.i3d_tsdf_write.restype = i32; L.i3d_tsdf_write.argtypes = [cp, f32, f32, f32, f32, u64, vp, vp, vp, vp]
+    L.i3d_sbr_write.restype = i32; L.i3d_sbr_write.argtypes = [cp, f32, f32, f32, f32, u64, vp, vp, vp, vp, vp, vp]
+    L.i3d_sbr_read.restype = i32; L.i3d_sbr_read.argtypes = [cp, u64, vp, vp, vp, vp, vp, vp]
+    L.i3d_write_poses.restype = i32; L.i3d_write_poses.argtypes = [cp, i32, vp, vp]
+    L.i3d_write_intrinsics.restype = i32; L.i3d_write_intrinsics.argtypes = [cp, i32, i32, vp, vp]
+    L.i3d_read_intrinsics.restype = i32; L.i3d_read_intrinsics.argtypes = [cp, C.POINTER(i32), C.POINTER(i32), vp, vp]
+    L.i3d_config_load_yaml.restype = i32; L.i3d_config_load_yaml.argtypes = [cp, C.POINTER(RefineConfig), C.POINTER(OptimizerConfig)]
     _lib = L
     return L
 
@@ -359,3 +371,71 @@ def shard_plan(A, world, rank, anbr, active):
     if rc != 0:
         raise I3DError(f"i3d_shard_plan failed ({rc})")
     return ch.value, o0.value, o1.value, mask.astype(bool)
+
+
+# ---- on-disk formats (host-only entry points) -----------------------------------------------------------------------------
+def _io_check(rc, what):
+    if rc != 0:
+        raise I3DError(f"{what} failed ({rc})")
+
+
+def tsdf_read(path):
+    """-> dict(voxel_size, truncation, integration_weight_sample, max_load_factor, keys, sdf, weight, color) in FILE order."""
+    L = load(); p = str(path).encode()
+    vs, tr, iw, ml = C.c_float(), C.c_float(), C.c_float(), C.c_float(); n = C.c_uint64()
+    _io_check(L.i3d_tsdf_read_header(p, C.byref(vs), C.byref(tr), C.byref(iw), C.byref(n), C.byref(ml)), "i3d_tsdf_read_header")
+    N = int(n.value)
+    out = dict(voxel_size=np.float32(vs.value), truncation=np.float32(tr.value), integration_weight_sample=np.float32(iw.value),
+               max_load_factor=np.float32(ml.value), keys=np.zeros((N, 3), np.int32), sdf=np.zeros(N, np.float32),
+               weight=np.zeros(N, np.float32), color=np.zeros((N, 3), np.uint8))
+    _io_check(L.i3d_tsdf_read_records(p, N, _p(out["keys"]), _p(out["sdf"]), _p(out["weight"]), _p(out["color"])), "i3d_tsdf_read_records")
+    return out
+
+
+def tsdf_write(path, voxel_size, keys, sdf, weight, color, truncation=None, integration_weight_sample=0.0, max_load_factor=0.6):
+    keys = np.ascontiguousarray(keys, np.int32); sdf = np.ascontiguousarray(sdf, np.float32)
+    weight = np.ascontiguousarray(weight, np.float32); color = np.ascontiguousarray(color, np.uint8)
+    tr = float(np.float32(voxel_size) * np.float32(5.0)) if truncation is None else float(truncation)
+    _io_check(load().i3d_tsdf_write(str(path).encode(), float(voxel_size), tr, float(integration_weight_sample), float(max_load_factor), len(sdf),
+                                    _p(keys), _p(sdf), _p(weight), _p(color)), "i3d_tsdf_write")
+
+
+def sbr_write(path, voxel_size, grid, truncation=None, integration_weight_sample=0.0, max_load_factor=0.6):
+    """grid: the dict of Context.export_grid() (visit order)."""
+    tr = float(np.float32(voxel_size) * np.float32(5.0)) if truncation is None else float(truncation)
+    g = {k: np.ascontiguousarray(v) for k, v in grid.items() if isinstance(v, np.ndarray)}
+    _io_check(load().i3d_sbr_write(str(path).encode(), float(voxel_size), tr, float(integration_weight_sample), float(max_load_factor), len(g["sdf"]),
+                                   _p(g["keys"]), _p(g["sdf"]), _p(g["sdf_refined"]), _p(g["albedo"]), _p(g["weight"]), _p(g["color"])), "i3d_sbr_write")
+
+
+def sbr_read(path):
+    L = load(); p = str(path).encode()
+    vs = C.c_float(); n = C.c_uint64()
+    _io_check(L.i3d_tsdf_read_header(p, C.byref(vs), None, None, C.byref(n), None), "i3d_tsdf_read_header")
+    N = int(n.value)
+    out = dict(voxel_size=np.float32(vs.value), keys=np.zeros((N, 3), np.int32), sdf=np.zeros(N), sdf_refined=np.zeros(N), albedo=np.zeros(N),
+               weight=np.zeros(N, np.float32), color=np.zeros((N, 3), np.uint8))
+    _io_check(L.i3d_sbr_read(p, N, _p(out["keys"]), _p(out["sdf"]), _p(out["sdf_refined"]), _p(out["albedo"]), _p(out["weight"]), _p(out["color"])), "i3d_sbr_read")
+    return out
+
+
+def write_poses(path, timestamps, poses_world_to_cam):
+    t = np.ascontiguousarray(timestamps, np.float64); p = np.ascontiguousarray(poses_world_to_cam, np.float64).reshape(-1, 6)
+    _io_check(load().i3d_write_poses(str(path).encode(), len(t), _p(t), _p(p)), "i3d_write_poses")
+
+
+def write_intrinsics(path, width, height, intr, dist):
+    a = np.ascontiguousarray(intr, np.float64); d = np.ascontiguousarray(dist, np.float64)
+    _io_check(load().i3d_write_intrinsics(str(path).encode(), int(width), int(height), _p(a), _p(d)), "i3d_write_intrinsics")
+
+
+def read_intrinsics(path):
+    w, h = C.c_int32(), C.c_int32(); a = np.zeros(4); d = np.zeros(5)
+    rc = load().i3d_read_intrinsics(str(path).encode(), C.byref(w), C.byref(h), _p(a), _p(d))
+    return rc == 0, int(w.value), int(h.value), a, d
+
+
+def load_yaml_config(path):
+    rc = RefineConfig(); oc = default_config()
+    _io_check(load().i3d_config_load_yaml(str(path).encode(), C.byref(rc), C.byref(oc)), "i3d_config_load_yaml")
+    return rc, oc
