@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--band", type=float, default=3.5, help="stored half-thickness of the shell in voxels")
     ap.add_argument("--shell", type=float, default=1.0, help="thin-shell factor (thin_shell_factor_final)")
     ap.add_argument("--subvolume", type=float, default=0.2)
-    ap.add_argument("--cpu-sample", type=float, default=60000, help="stored voxels of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=float, default=1.0e6, help="stored voxels of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="also launch a known-size device copy (1 GiB read + 1 GiB write) so that a rocprofv3 --pmc pass over this command "

@@ -529,11 +529,11 @@ __global__ void k_pcg_tail_x(size_t to, int NS, const float* __restrict__ p, flo
     for (int i = threadIdx.x; i < NS; i += blockDim.x) x[to + i] += alpha * p[to + i];
 }
 
-__global__ void __launch_bounds__(256) k_pcg_tail_a(int mode, size_t to, int K, const float* __restrict__ Mblk, const float* __restrict__ p, const float* __restrict__ q,
+__global__ void __launch_bounds__(1024) k_pcg_tail_a(int mode, size_t to, int K, const float* __restrict__ Mblk, const float* __restrict__ p, const float* __restrict__ q,
                                                     float* __restrict__ x, float* __restrict__ r, const float* __restrict__ b, const float* __restrict__ D2,
                                                     float* __restrict__ z, const double* __restrict__ partials, int nblk, PcgState* st) {
     if (st->done) return;
-    __shared__ double red[4][4];
+    __shared__ double red[16][4];
     const int NS = 6 * K + 9;
     const float alpha = (float)st->alpha;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -610,10 +610,10 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int n, const float* __res
 }
 
 // camera tail of q = (S J^T W J S + D^2) p from the (all-reduced) fp64 camera block, p.q, alpha = rho / p.q
-__global__ void __launch_bounds__(256) k_pcg_tail_b(size_t to, int K, OptParams p, const double* __restrict__ shared, const double* __restrict__ pq_slice,
+__global__ void __launch_bounds__(1024) k_pcg_tail_b(size_t to, int K, OptParams p, const double* __restrict__ shared, const double* __restrict__ pq_slice,
                                                     const double* __restrict__ pq_partials, int nblk, float* __restrict__ q, const float* __restrict__ S, const float* __restrict__ D2, const float* __restrict__ v, PcgState* st) {
     if (st->done) return;
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int NS = 6 * K + 9;
     double dotp = 0.0;
     for (int i = threadIdx.x; i < NS; i += blockDim.x) {
@@ -662,14 +662,14 @@ int launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p,
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state) { k_pcg_tail_x<<<1, 256, 0, st>>>(tail_off, 6 * K + 9, p, x, state); }
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
                        const float* D2, float* z, const double* partials, int nblk, PcgState* state) {
-    k_pcg_tail_a<<<1, 256, 0, st>>>(mode, tail_off, K, Minv_blocks, p, q, x, r, b, D2, z, partials, nblk, state);
+    k_pcg_tail_a<<<1, 1024, 0, st>>>(mode, tail_off, K, Minv_blocks, p, q, x, r, b, D2, z, partials, nblk, state);
 }
 void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state) {
     if (n > 0) k_pcg_direction<<<step_blocks(n >> 2), 256, 0, st>>>(n, z, p, S, u, state);
 }
 void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
                        float* q, const float* S, const float* D2, const float* v, PcgState* state) {
-    k_pcg_tail_b<<<1, 256, 0, st>>>(tail_off, K, p, shared, pq_slice, pq_partials, nblk, q, S, D2, v, state);
+    k_pcg_tail_b<<<1, 1024, 0, st>>>(tail_off, K, p, shared, pq_slice, pq_partials, nblk, q, S, D2, v, state);
 }
 
 // ---- LM candidate / acceptance ------------------------------------------------------------------------------------------
