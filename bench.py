@@ -8,8 +8,9 @@ in HBM; `--warmup` iterations run in a separate untimed call first.
 
 Workload (config.workload): BASELINE.json configs[3] shrunk to one node's worth of work per rank — a seeded synthetic
 hashed grid of ~8M stored voxels at 1 mm (thin shell around a bumpy sphere, finest-level shell threshold), 200 keyframes
-of 640x480 on a Fibonacci sphere, 0.2 m SH subvolumes, all parameter groups free.  With --gpus N the SAME problem is
-sharded by subvolume bricks across the ranks (strong scaling).
+of 640x480 on a Fibonacci sphere, spatially-varying SH lighting estimated on the device (i3d_estimate_sh, untimed: it runs once
+per level, not per iteration) on a subvolume lattice of up to 8^3 = 512 cells, all parameter groups free.  With --gpus N the SAME
+problem is sharded across the ranks by contiguous ranges of the brick-ordered work list (strong scaling).
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,7 +42,7 @@ def parse_args():
     ap.add_argument("--voxel-size", type=float, default=0.001)
     ap.add_argument("--band", type=float, default=3.5, help="stored half-thickness of the shell in voxels")
     ap.add_argument("--shell", type=float, default=1.0, help="thin-shell factor (thin_shell_factor_final)")
-    ap.add_argument("--subvolume", type=float, default=0.2)
+    ap.add_argument("--subvolume", type=float, default=0.08, help="SH subvolume size in metres (0.6 m object: 8 cells per axis)")
     ap.add_argument("--cpu-sample", type=float, default=1.0e6, help="stored voxels of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--pmc-calibrate", action="store_true",
@@ -90,7 +91,9 @@ def cpu_baseline(args, sc, thres, log):
     g = O.Grid.from_voxels(sc["voxel_size"], keys[sel], sc["sdf"][sel], sc["weight"][sel], sc["color"][sel])
     fr = O.Frames(sc["frames"], 1)
     n = len(g)
-    vsh = np.tile(np.asarray(sc["scene"].sh), (n, 1))
+    rc_sh, _, _, vsh, _, _ = O.estimate_sh(g, args.subvolume, 10.0, thres)       # same lighting model as the timed run (untimed here too)
+    if rc_sh != 0:
+        vsh = np.tile(np.asarray(sc["scene"].sh), (n, 1))
     iters = 2
     cfg = O.OptConfig(iterations=iters, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0, lambda_s1=10.0, lambda_a=0.1,
                       fix_poses=0, fix_intrinsics=0, fix_distortion=0, occlusion_distance=0.02, num_observations=5, thres_shell=thres,
@@ -169,8 +172,10 @@ def main():
     ctx.set_grid(sc["voxel_size"], arrays["keys"], arrays["sdf"], arrays["sdf_refined"], arrays["albedo"], arrays["weight"], arrays["color"])
     ctx.set_frames(sc["frames"], 1)
     ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
-    ctx.set_voxel_sh(np.tile(np.asarray(sc["scene"].sh), (arrays["keys"].shape[0], 1)))
     log(f"upload + hash/neighbour build: {time.time() - t0:.2f}s")
+    t0 = time.time()
+    sh_sub, _, sh_stats = ctx.estimate_sh(args.subvolume, 10.0, thres)       # LightingSVSH::estimate + computeVoxelShCoeffs (intrinsic3d.cpp:255-264)
+    log(f"SH estimate: {sh_sub.shape[0]} subvolumes, {sh_stats.data_rows} data rows, {sh_stats.lm_iterations} LM iterations in {time.time() - t0:.2f}s")
 
     if args.pmc_calibrate:
         a = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
@@ -229,7 +234,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"parallelism": f"{world} rank(s): replicated voxel state, row work and solver vectors sharded by contiguous work-list ranges, RCCL all-reduce (PCG scalars + camera block) and all-gather (operator input)",
                        "workload": f"synthetic hashed SDF grid, {arrays['keys'].shape[0]} stored voxels @ {args.voxel_size * 1e3:g} mm "
-                                   f"({A} in the thin shell), {args.frames} keyframes {args.width}x{args.height}, {args.subvolume} m SH subvolumes, "
+                                   f"({A} in the thin shell), {args.frames} keyframes {args.width}x{args.height}, {sh_sub.shape[0]} SH subvolumes of {args.subvolume} m (estimated on the device, untimed), "
                                    f"joint SDF+albedo+pose+intrinsics+distortion, 5 observations/voxel (BASELINE.json configs[3] on one node)",
                        "stored_voxels": int(arrays["keys"].shape[0]), "active_voxels": A, "rows": {"Eg": Rg, "Er": Rr, "Es": Rs, "Ea": Ra},
                        "free_parameters": sizes["free"], "keyframes": args.frames, "image": [args.width, args.height],
