@@ -93,6 +93,8 @@ typedef struct {
     /* parity / measurement controls (not in the reference) */
     int32_t pcg_fixed_iterations;  /* >=0: run exactly this many PCG iterations per LM attempt; -1: Ceres' Q-test */
     int32_t verbose;
+    int32_t fix_sdf;               /* extension: every sdf_refined block constant (BASELINE.json configs[0], "albedo-only"); the reference has
+                                      no such switch — Optimizer::fixVoxelParams (optimizer.cpp:312-361) fixes per voxel only */
 } i3d_optimizer_config;
 
 void i3d_optimizer_config_default(i3d_optimizer_config* cfg);   /* the reference's struct defaults */

@@ -133,7 +133,7 @@ struct OptParams {                  // scalar state of one outer iteration
     int K; int level; double pyr_scale; float occlusion; int use_er, use_es, use_ea;
     double intr[4]; double dist[5];  // level-0 intrinsics, distortion
     float cam_f[4]; float dist_f[5]; int dist_zero; int w, h;   // float camera of the observation pass (scaled)
-    int fix_poses, fix_intr, fix_dist;
+    int fix_poses, fix_intr, fix_dist, fix_sdf;
 };
 
 #define I3D_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \

@@ -121,8 +121,9 @@ __global__ void k_classify(GridView g, OptParams p, int* __restrict__ active_fla
         normal_ok = !(fabsf(nx) <= 1e-5f && fabsf(ny) <= 1e-5f && fabsf(nz) <= 1e-5f);
     }
     const bool active = valid && inshell && normal_ok;
-    const bool free_sdf = valid && inshell && ring;
-    const bool free_alb = free_sdf && !(p.lambda_a < 0.0);
+    const bool free_vox = valid && inshell && ring;             // Optimizer::fixVoxelParams (optimizer.cpp:312-361)
+    const bool free_sdf = free_vox && !p.fix_sdf;
+    const bool free_alb = free_vox && !(p.lambda_a < 0.0);
     g.flags[s] = (valid ? F_VALID : 0) | (active ? F_ACTIVE : 0) | (ring ? F_RING : 0) | (free_sdf ? F_FREE_SDF : 0) | (free_alb ? F_FREE_ALB : 0);
     active_flag[s] = (active || free_sdf || free_alb) ? 1 : 0;      // work list = voxels that own rows or unknowns
 }

@@ -25,7 +25,7 @@ static OptParams make_params(const i3d_context* c, const i3d_optimizer_config& c
     for (int i = 0; i < 5; ++i) { p.dist[i] = dist[i]; p.dist_f[i] = (float)dist[i]; if (std::fabs(p.dist_f[i]) > 1e-5f) dz = false; }
     p.dist_zero = dz ? 1 : 0;
     p.w = c->fw[cfg.rgbd_level]; p.h = c->fh[cfg.rgbd_level];
-    p.fix_poses = cfg.fix_poses; p.fix_intr = cfg.fix_intrinsics; p.fix_dist = cfg.fix_distortion;
+    p.fix_poses = cfg.fix_poses; p.fix_intr = cfg.fix_intrinsics; p.fix_dist = cfg.fix_distortion; p.fix_sdf = cfg.fix_sdf;
     return p;
 }
 

@@ -24,6 +24,7 @@ typedef struct {
     double thres_shell; int32_t grid_level, rgbd_level;
     int32_t cg_fixed_iterations;   /* -1 = Ceres' quadratic-model stopping rule */
     int32_t verbose;
+    int32_t fix_sdf;               /* extension mirrored from the product config: all sdf blocks constant */
 } orc_opt_config;
 
 typedef struct {

@@ -22,7 +22,7 @@ namespace orc {
 struct OptConfig {
     int iterations = 10, lm_steps = 50;
     double lambda_g = 0.2, lambda_r0 = 20.0, lambda_r1 = 160.0, lambda_s0 = 10.0, lambda_s1 = 120.0, lambda_a = 0.1;
-    int fix_poses = 0, fix_intrinsics = 0, fix_distortion = 0;
+    int fix_poses = 0, fix_intrinsics = 0, fix_distortion = 0, fix_sdf = 0;
     float occlusion_distance = 0.02f; int num_observations = 5;
     double thres_shell = 0.0; int grid_level = 0, rgbd_level = 0;
     int cg_fixed_iterations = -1;      // parity pinning, -1 = native Ceres stopping rule
@@ -277,6 +277,7 @@ inline void compute_fixed_flags(Problem& P, const OptConfig& cfg) {
         const bool rok = ring_valid(g, P.keys[i]);
         P.ringok[i] = rok;
         if (!rok) { fs = fa = true; }
+        if (cfg.fix_sdf) fs = true;
         P.fix_sdf[i] = fs; P.fix_alb[i] = fa;
     }
 }

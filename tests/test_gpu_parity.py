@@ -216,3 +216,39 @@ def test_sharded_ranks_match_single_rank(setup):
             np.testing.assert_allclose(gd, rd, rtol=5e-3, atol=5e-4)   # k2,k3 barely observable: ill-conditioned block (see test_optimize_matches_oracle)
             c.close()
         L.i3d_comm_sim_destroy(shared)
+
+
+def test_config_c1_dense_albedo_only(oracle):
+    """BASELINE.json configs[0]: dense 64^3 SDF (sphere r = 24 voxels @ 4 mm), ONE keyframe 640x480, ONE global SH volume,
+    albedo-only (sdf and camera blocks constant).  The whole level: sparsify -> SH estimate -> optimize, device vs oracle."""
+    from intrinsic3d_amd import binding, synthetic
+    O = oracle
+    sc = synthetic.make_scene(radius_vox=24, voxel_size=0.004, K=1, width=640, height=480, dense_res=64, seed=11)
+    assert sc["keys"].shape[0] == 64 ** 3
+    thres = 2.0 * float(sc["voxel_size"])
+    g = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"]); fr = O.Frames(sc["frames"], 1)
+    g.clear_outside_shell(thres)
+    rc, osh, _, vsh, _, ost = O.estimate_sh(g, 0.0, 10.0, thres)                 # subvolume_size_sh 0 -> one global volume
+    assert rc == 0 and osh.shape[0] == 1
+    ocfg = helpers.oracle_cfg(O, thres, iterations=3, fix_poses=1, fix_intrinsics=1, fix_distortion=1, fix_sdf=1, num_observations=5)
+    rc, ointr, odist, oposes, ostats = O.optimize(g, fr, ocfg, sc["intr"], sc["dist"], sc["poses"], vsh)
+    assert rc == 0
+    ref = g.export()
+    with binding.Context(0) as ctx:
+        ctx.set_grid_from_tsdf_records(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        ctx.set_frames(sc["frames"], 1); ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
+        n = ctx.clear_outside_thin_shell(thres)
+        assert n == len(g)
+        gsh, _, gst = ctx.estimate_sh(0.0, 10.0, thres)
+        np.testing.assert_allclose(gsh, osh, rtol=1e-4, atol=1e-6)
+        gstats = ctx.optimize(helpers.gpu_cfg(ocfg))
+        out = ctx.export_grid(); gi, gd, gp = ctx.get_camera()
+    assert np.array_equal(out["keys"], ref["keys"])
+    for so, sg in zip(ostats, gstats):
+        assert list(so.rows) == list(sg.rows) and so.rows[0] > 1000
+        assert abs(so.cost_final - sg.cost_final) <= 1e-4 * so.cost_final
+    assert np.array_equal(out["sdf_refined"], ref["sdf_refined"])               # sdf blocks are constant
+    assert np.abs(ref["albedo"] - 0.6).max() > 1e-3                              # the albedo did move
+    assert np.abs(out["albedo"] - ref["albedo"]).max() <= 1e-4 * np.abs(ref["albedo"]).max()
+    assert np.array_equal(gp, np.asarray(sc["poses"], np.float64)) and np.array_equal(gi, np.asarray(sc["intr"], np.float64))
+    g.free(); fr.free()
