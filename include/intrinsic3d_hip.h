@@ -175,6 +175,16 @@ int i3d_write_intrinsics(const char* path, int32_t width, int32_t height, const 
 int i3d_read_intrinsics(const char* path, int32_t* width, int32_t* height, double* intr4, double* dist5);
 int i3d_config_load_yaml(const char* path, i3d_refine_config* rcfg, i3d_optimizer_config* ocfg);
 
+/* ---- mesh export of the resident grid (MarchingCubes<VoxelSBR>::extractSurface, MeshUtil, Mesh::save; SDFVisualization::exportMesh) -----
+ * use_refined_sdf: SDFAlgorithms::applyRefinedSdf before extraction (app_intrinsic3d.cpp:170-172).  color_mode: 0 voxel colour, 1 "albedo"
+ * (visualization.cpp:308-315).  largest_component_only: MeshUtil::removeLooseComponents.  PLY: binary_little_endian, float xyz, uchar rgb,
+ * "uchar int" face lists (mesh.cpp:41-100). */
+int i3d_extract_mesh(i3d_context* ctx, int32_t use_refined_sdf, int32_t color_mode, int32_t largest_component_only, int64_t* num_vertices, int64_t* num_faces);
+int i3d_get_mesh(i3d_context* ctx, float* vertices /*[nv][3]*/, uint8_t* colors /*[nv][3]*/, int32_t* faces /*[nf][3]*/);
+int i3d_export_mesh_ply(i3d_context* ctx, const char* path, int32_t use_refined_sdf, int32_t color_mode, int32_t largest_component_only);
+int i3d_write_ply(const char* path, int64_t num_vertices, const float* vertices, const uint8_t* colors /* may be NULL */, int64_t num_faces, const int32_t* faces);
+int i3d_mc_tables(uint8_t* ntri /*[256]*/, int8_t* tri /*[256][24]*/);      /* the generated triangulation table; returns max triangles per cell */
+
 /* ---- one process per GPU: the voxel state is replicated, row work / row storage / solver vectors are sharded by contiguous
  * work-list ranges; RCCL carries the PCG scalars, the camera block and the per-iteration vector exchange.  Call after i3d_create
  * on every rank with the same unique id (i3d_comm_unique_id on rank 0, broadcast by the launcher, e.g. torch.distributed). */

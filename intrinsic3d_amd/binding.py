@@ -66,6 +66,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_export_grid", "i3d_refine",
            "i3d_tsdf_read_header", "i3d_tsdf_read_records", "i3d_tsdf_write", "i3d_sbr_write", "i3d_sbr_read", "i3d_write_poses",
            "i3d_write_intrinsics", "i3d_read_intrinsics", "i3d_config_load_yaml",
+           "i3d_extract_mesh", "i3d_get_mesh", "i3d_export_mesh_ply", "i3d_write_ply", "i3d_mc_tables",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_timing_enable", "i3d_timing_get", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
@@ -134,6 +135,11 @@ def load():
     L.i3d_write_poses.restype = i32; L.i3d_write_poses.argtypes = [cp, i32, vp, vp]
     L.i3d_write_intrinsics.restype = i32; L.i3d_write_intrinsics.argtypes = [cp, i32, i32, vp, vp]
     L.i3d_read_intrinsics.restype = i32; L.i3d_read_intrinsics.argtypes = [cp, C.POINTER(i32), C.POINTER(i32), vp, vp]
+    L.i3d_extract_mesh.restype = i32; L.i3d_extract_mesh.argtypes = [vp, i32, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.i3d_get_mesh.restype = i32; L.i3d_get_mesh.argtypes = [vp, vp, vp, vp]
+    L.i3d_export_mesh_ply.restype = i32; L.i3d_export_mesh_ply.argtypes = [vp, cp, i32, i32, i32]
+    L.i3d_write_ply.restype = i32; L.i3d_write_ply.argtypes = [cp, i64, vp, vp, i64, vp]
+    L.i3d_mc_tables.restype = i32; L.i3d_mc_tables.argtypes = [vp, vp]
     L.i3d_config_load_yaml.restype = i32; L.i3d_config_load_yaml.argtypes = [cp, C.POINTER(RefineConfig), C.POINTER(OptimizerConfig)]
     _lib = L
     return L
@@ -281,6 +287,17 @@ class Context:
         cb = REFINE_CALLBACK((lambda user, a, b, c_, d: callback(a, b, c_, d)) if callback else (lambda *a: None))
         self._check(self.L.i3d_refine(self.h, C.byref(rcfg), C.byref(ocfg), cb, None), "i3d_refine")
         self.grid_info()
+
+    # ---- mesh export ------------------------------------------------------------------------------------------
+    def extract_mesh(self, use_refined_sdf=True, color_mode=0, largest_component_only=False):
+        nv, nf = C.c_int64(0), C.c_int64(0)
+        self._check(self.L.i3d_extract_mesh(self.h, int(bool(use_refined_sdf)), int(color_mode), int(bool(largest_component_only)), C.byref(nv), C.byref(nf)), "i3d_extract_mesh")
+        v = np.zeros((nv.value, 3), np.float32); c = np.zeros((nv.value, 3), np.uint8); f = np.zeros((nf.value, 3), np.int32)
+        self._check(self.L.i3d_get_mesh(self.h, _p(v), _p(c), _p(f)), "i3d_get_mesh")
+        return v, c, f
+
+    def export_mesh_ply(self, path, use_refined_sdf=True, color_mode=0, largest_component_only=False):
+        self._check(self.L.i3d_export_mesh_ply(self.h, str(path).encode(), int(bool(use_refined_sdf)), int(color_mode), int(bool(largest_component_only))), "i3d_export_mesh_ply")
 
     # ---- sharding -----------------------------------------------------------------------------------------
     @staticmethod
@@ -439,3 +456,15 @@ def load_yaml_config(path):
     rc = RefineConfig(); oc = default_config()
     _io_check(load().i3d_config_load_yaml(str(path).encode(), C.byref(rc), C.byref(oc)), "i3d_config_load_yaml")
     return rc, oc
+
+
+def write_ply(path, vertices, colors, faces):
+    v = np.ascontiguousarray(vertices, np.float32); f = np.ascontiguousarray(faces, np.int32)
+    c = None if colors is None else np.ascontiguousarray(colors, np.uint8)
+    _io_check(load().i3d_write_ply(str(path).encode(), len(v), _p(v), _p(c), len(f), _p(f)), "i3d_write_ply")
+
+
+def mc_tables():
+    ntri = np.zeros(256, np.uint8); tri = np.zeros((256, 24), np.int8)
+    mx = load().i3d_mc_tables(_p(ntri), _p(tri))
+    return ntri, tri, mx

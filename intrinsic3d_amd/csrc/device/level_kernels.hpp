@@ -14,3 +14,10 @@ void launch_upsample(hipStream_t st, GridView g, HashTable t, const int* inv_ran
 void launch_permute_staging(hipStream_t st, long long n, const int* perm, const int* kin, const double* s0, const double* s1, const double* al, const float* w,
                             const uint8_t* rgb, int* kout, double* o0, double* o1, double* oal, float* ow, uint8_t* orgb);
 }  // namespace i3d
+
+namespace i3d {
+// mesh_kernels.hip — marching cubes on the resident grid (one lane per voxel in visit order)
+void launch_mc_count(hipStream_t st, GridView g, HashTable t, const int* inv_rank, int refined, const unsigned char* ntri, int* counts);
+void launch_mc_emit(hipStream_t st, GridView g, HashTable t, const int* inv_rank, int refined, int color_mode, const unsigned char* ntri, const signed char* tri,
+                    int tri_stride, const int* offsets, float* pos, unsigned char* col);
+}  // namespace i3d

@@ -1,0 +1,269 @@
+// Mesh export of the resident grid: MarchingCubes<VoxelSBR>::extractSurface -> merge -> MeshUtil::removeDegenerateFaces
+// [-> MeshUtil::removeLooseComponents] -> Mesh::save  (mesh/marching_cubes.cpp:65-155, mesh/util.cpp:47-200, mesh/mesh.cpp:41-100),
+// as driven by SDFVisualization::exportMesh (sdf/visualization.cpp:167-196).  Triangles are produced on the device
+// (mesh_kernels.hip); unification, cleaning and the PLY stream are host work.
+//
+// Triangulation table.  The reference carries the literal 256-case table of Bourke's "Polygonising a scalar field".  Here the table
+// is GENERATED from the cube's topology when the library is first used: for a configuration, every cube face contributes the
+// segments between its cut edges (an ambiguous face — two diagonal inside corners — isolates the INSIDE corners, a rule that only
+// depends on the face's own corners, so neighbouring cells agree and the surface has no cracks); the segments chain into closed
+// loops; segments are DIRECTED (inside corners on a fixed side seen from outside the cube) so every loop winds counter-clockwise around a
+// normal pointing from the inside (sdf < 0) to the outside; a loop is split into triangles by the
+// first triangulation (fixed enumeration order) none of whose chords lies in a cube face.  Vertices, their interpolation and their unification are exactly the reference's; the split of a polygon into
+// triangles (and hence the face order inside a cell) may differ from the literal table.
+#include "context.hpp"
+#include "../device/level_kernels.hpp"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <fstream>
+#include <numeric>
+#include <unordered_map>
+
+namespace i3d {
+namespace {
+
+constexpr int MC_STRIDE = 24;              // up to 8 triangles per configuration
+struct McTables { unsigned char ntri[256]; signed char tri[256 * MC_STRIDE]; int max_tri; int fallbacks = 0; bool ready = false; };
+
+// cube geometry in the reference's numbering
+const int CORNER[8][3] = {{1, 1, 0}, {1, 0, 0}, {0, 0, 0}, {0, 1, 0}, {1, 1, 1}, {1, 0, 1}, {0, 0, 1}, {0, 1, 1}};
+const int EA[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, EB[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+// faces as corner cycles (any orientation; orientation of the output is fixed geometrically below)
+const int FACE[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {3, 0, 4, 7}};
+
+// two cube edges lie in a common face: a chord between their vertices would lie IN that face, where the neighbouring cell has no
+// matching triangle side (a crack / non-manifold edge); the triangulation of a loop must avoid such chords
+bool edges_share_face(int e1, int e2) {
+    for (int f = 0; f < 6; ++f) {
+        bool in1 = false, in2 = false;
+        for (int i = 0; i < 4; ++i) {
+            const int a = FACE[f][i], b = FACE[f][(i + 1) & 3];
+            if ((EA[e1] == a && EB[e1] == b) || (EA[e1] == b && EB[e1] == a)) in1 = true;
+            if ((EA[e2] == a && EB[e2] == b) || (EA[e2] == b && EB[e2] == a)) in2 = true;
+        }
+        if (in1 && in2) return true;
+    }
+    return false;
+}
+// first triangulation (in a fixed enumeration order) of the polygon poly[lo..hi] whose chords never join two edges of one face;
+// triangles keep the polygon's orientation
+bool triangulate(const std::vector<int>& poly, int lo, int hi, std::vector<int>& tris) {
+    if (hi - lo < 2) return true;
+    for (int k = lo + 1; k < hi; ++k) {
+        if (k > lo + 1 && edges_share_face(poly[lo], poly[k])) continue;
+        if (k < hi - 1 && edges_share_face(poly[k], poly[hi])) continue;
+        const size_t mark = tris.size();
+        tris.push_back(poly[lo]); tris.push_back(poly[k]); tris.push_back(poly[hi]);
+        if (triangulate(poly, lo, k, tris) && triangulate(poly, k, hi, tris)) return true;
+        tris.resize(mark);
+    }
+    return false;
+}
+
+int edge_between(int a, int b) { for (int e = 0; e < 12; ++e) if ((EA[e] == a && EB[e] == b) || (EA[e] == b && EB[e] == a)) return e; return -1; }
+
+void build_tables(McTables& T) {
+    T.max_tri = 0;
+    for (int idx = 0; idx < 256; ++idx) {
+        T.ntri[idx] = 0;
+        for (int k = 0; k < MC_STRIDE; ++k) T.tri[idx * MC_STRIDE + k] = -1;
+        if (idx == 0 || idx == 255) continue;
+        auto inside = [&](int c) { return (idx >> c) & 1; };
+        // DIRECTED segments between cut edges, face by face.  Seen from outside the cube, a segment A -> B keeps the inside corners on
+        // a fixed side:  ((B - A) x n_face) . (inside end - outside end of A's edge) > 0,  which makes every triangle (A, B, interior
+        // vertex) wind counter-clockwise around a normal that points from sdf < 0 to sdf > 0 — the same in every cell.
+        auto mid = [&](int e, double m[3]) { for (int d = 0; d < 3; ++d) m[d] = 0.5 * (CORNER[EA[e]][d] + CORNER[EB[e]][d]); };
+        std::vector<std::pair<int, int>> seg;
+        auto add_seg = [&](int f, int eA, int eB) {
+            double nf[3] = {0, 0, 0};
+            for (int i = 0; i < 4; ++i) for (int d = 0; d < 3; ++d) nf[d] += 0.25 * CORNER[FACE[f][i]][d];
+            for (int d = 0; d < 3; ++d) nf[d] -= 0.5;                                   // outward face normal (face centre - cube centre)
+            double A[3], B[3]; mid(eA, A); mid(eB, B);
+            const int a_in = inside(EA[eA]) ? EA[eA] : EB[eA], a_out = inside(EA[eA]) ? EB[eA] : EA[eA];
+            const double t[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+            const double cr[3] = {t[1] * nf[2] - t[2] * nf[1], t[2] * nf[0] - t[0] * nf[2], t[0] * nf[1] - t[1] * nf[0]};
+            const double dsgn = cr[0] * (CORNER[a_in][0] - CORNER[a_out][0]) + cr[1] * (CORNER[a_in][1] - CORNER[a_out][1]) + cr[2] * (CORNER[a_in][2] - CORNER[a_out][2]);
+            if (dsgn > 0.0) seg.push_back({eA, eB}); else seg.push_back({eB, eA});
+        };
+        for (int f = 0; f < 6; ++f) {
+            int cut[4], ncut = 0;                                   // cut[i]: edge between cycle corners i and i+1
+            for (int i = 0; i < 4; ++i) { const int a = FACE[f][i], b = FACE[f][(i + 1) & 3]; if (inside(a) != inside(b)) cut[ncut++] = i; }
+            if (ncut == 2) add_seg(f, edge_between(FACE[f][cut[0]], FACE[f][(cut[0] + 1) & 3]), edge_between(FACE[f][cut[1]], FACE[f][(cut[1] + 1) & 3]));
+            else if (ncut == 4) {                                   // ambiguous: isolate each inside corner (its two incident edges of this face)
+                for (int i = 0; i < 4; ++i) if (inside(FACE[f][i])) {
+                    const int prev = FACE[f][(i + 3) & 3], next = FACE[f][(i + 1) & 3];
+                    add_seg(f, edge_between(prev, FACE[f][i]), edge_between(FACE[f][i], next));
+                }
+            }
+        }
+        // chain the directed segments into oriented loops (every cut edge has one incoming and one outgoing segment)
+        std::vector<char> used(seg.size(), 0);
+        std::vector<std::vector<int>> loops;
+        for (size_t s0 = 0; s0 < seg.size(); ++s0) {
+            if (used[s0]) continue;
+            std::vector<int> loop; used[s0] = 1; loop.push_back(seg[s0].first); int cur = seg[s0].second;
+            while (cur != loop[0]) {
+                loop.push_back(cur);
+                bool found = false;
+                for (size_t s = 0; s < seg.size() && !found; ++s) if (!used[s] && seg[s].first == cur) { used[s] = 1; cur = seg[s].second; found = true; }
+                if (!found) { T.fallbacks++; break; }
+            }
+            loops.push_back(loop);
+        }
+        // canonical start of each loop / order of the loops, then a triangulation without chords inside cube faces
+        for (auto& L : loops) std::rotate(L.begin(), std::min_element(L.begin(), L.end()), L.end());
+        std::sort(loops.begin(), loops.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a[0] < b[0]; });
+        int nt = 0;
+        for (auto& L : loops) {
+            const int n = (int)L.size();
+            std::vector<int> tris;
+            if (!triangulate(L, 0, n - 1, tris)) { tris.clear(); for (int i = 1; i + 1 < n; ++i) { tris.push_back(L[0]); tris.push_back(L[i]); tris.push_back(L[i + 1]); } T.fallbacks++; }
+            for (size_t i = 0; i < tris.size(); i += 3) { signed char* t = &T.tri[idx * MC_STRIDE + 3 * nt]; t[0] = (signed char)tris[i]; t[1] = (signed char)tris[i + 1]; t[2] = (signed char)tris[i + 2]; ++nt; }
+        }
+        T.ntri[idx] = (unsigned char)nt; T.max_tri = std::max(T.max_tri, nt);
+    }
+    T.ready = true;
+}
+
+const McTables& tables() { static McTables T; if (!T.ready) build_tables(T); return T; }
+
+struct F3 { float x, y, z; bool operator==(const F3& o) const { return std::memcmp(this, &o, sizeof(F3)) == 0 || (x == o.x && y == o.y && z == o.z); } };
+struct F3Hash { size_t operator()(const F3& v) const {
+    auto b = [](float f) { if (f == 0.0f) f = 0.0f; uint32_t u; std::memcpy(&u, &f, 4); return (size_t)u; };       // -0 and +0 are the same key, like operator<
+    return (b(v.x) * 73856093u) ^ (b(v.y) * 19349669u) ^ (b(v.z) * 83492791u); } };
+
+}  // namespace
+
+struct MeshData { std::vector<float> vertices; std::vector<uint8_t> colors; std::vector<int32_t> faces; };
+static thread_local MeshData g_mesh;       // the last extracted mesh of this host thread (i3d_get_mesh)
+
+int extract_mesh(i3d_context* c, int use_refined, int color_mode, int largest_only, MeshData& M, int64_t* raw_triangles) {
+    if (!c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "extract_mesh: no grid");
+    CTX_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream; const int N = c->N;
+    const McTables& T = tables();
+    GridView g = c->grid_view(); HashTable ht{c->hkeys.p, c->hvals.p, c->hmask};
+    DevBuf<int> inv, counts, offs; DevBuf<unsigned char> d_ntri; DevBuf<signed char> d_tri;
+    CTX_HIP(c, inv.alloc(N)); CTX_HIP(c, counts.alloc(N)); CTX_HIP(c, offs.alloc(N)); CTX_HIP(c, d_ntri.alloc(256)); CTX_HIP(c, d_tri.alloc(256 * MC_STRIDE));
+    CTX_HIP(c, hipMemcpyAsync(d_ntri.p, T.ntri, 256, hipMemcpyHostToDevice, st));
+    CTX_HIP(c, hipMemcpyAsync(d_tri.p, T.tri, 256 * MC_STRIDE, hipMemcpyHostToDevice, st));
+    launch_inv_rank(st, N, c->rank.p, inv.p);
+    launch_mc_count(st, g, ht, inv.p, use_refined, d_ntri.p, counts.p);
+    CTX_HIP(c, rocprim::exclusive_scan(c->scan_tmp.p, c->scan_tmp_bytes, counts.p, offs.p, 0, (size_t)N, rocprim::plus<int>(), st));
+    int tail[2];
+    CTX_HIP(c, hipMemcpyAsync(&tail[0], offs.p + (N - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    CTX_HIP(c, hipMemcpyAsync(&tail[1], counts.p + (N - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    CTX_HIP(c, hipStreamSynchronize(st));
+    const size_t nt = (size_t)tail[0] + (size_t)tail[1];
+    if (raw_triangles) *raw_triangles = (int64_t)nt;
+    M.vertices.clear(); M.colors.clear(); M.faces.clear();
+    if (nt == 0) return I3D_OK;                                      // extractMesh returns nullptr
+    DevBuf<float> d_pos; DevBuf<unsigned char> d_col;
+    CTX_HIP(c, d_pos.alloc(nt * 9)); CTX_HIP(c, d_col.alloc(nt * 9));
+    launch_mc_emit(st, g, ht, inv.p, use_refined, color_mode, d_ntri.p, d_tri.p, MC_STRIDE, offs.p, d_pos.p, d_col.p);
+    std::vector<float> pos(nt * 9); std::vector<uint8_t> col(nt * 9);
+    CTX_HIP(c, hipMemcpyAsync(pos.data(), d_pos.p, sizeof(float) * nt * 9, hipMemcpyDeviceToHost, st));
+    CTX_HIP(c, hipMemcpyAsync(col.data(), d_col.p, nt * 9, hipMemcpyDeviceToHost, st));
+    CTX_HIP(c, hipStreamSynchronize(st));
+    // merge(): vertices with the same position are one vertex; index = order of first appearance (marching_cubes.cpp:98-152)
+    std::unordered_map<F3, int, F3Hash> index; index.reserve(nt * 2);
+    std::vector<int32_t> faces; faces.reserve(nt * 3);
+    for (size_t i = 0; i < nt * 3; ++i) {
+        const F3 p{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+        auto it = index.find(p);
+        int id;
+        if (it == index.end()) { id = (int)(M.vertices.size() / 3); index.emplace(p, id);
+            M.vertices.push_back(p.x); M.vertices.push_back(p.y); M.vertices.push_back(p.z);
+            M.colors.push_back(col[3 * i]); M.colors.push_back(col[3 * i + 1]); M.colors.push_back(col[3 * i + 2]); }
+        else id = it->second;
+        faces.push_back(id);
+    }
+    // removeDegenerateFaces (mesh/util.cpp:174-200)
+    std::vector<int32_t> kept; kept.reserve(faces.size());
+    for (size_t f = 0; f < nt; ++f) {
+        const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
+        if (v0 == v1 || v0 == v2 || v1 == v2) continue;
+        const float* a = &M.vertices[3 * (size_t)v0]; const float* b = &M.vertices[3 * (size_t)v1]; const float* cc = &M.vertices[3 * (size_t)v2];
+        const float e0[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]}, e1[3] = {cc[0] - b[0], cc[1] - b[1], cc[2] - b[2]};
+        const float cr[3] = {e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2], e0[0] * e1[1] - e0[1] * e1[0]};
+        const double area = (double)std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+        if (area == 0.0 || std::isnan(area) || std::isinf(area)) continue;
+        kept.push_back(v0); kept.push_back(v1); kept.push_back(v2);
+    }
+    faces.swap(kept);
+    if (largest_only && !faces.empty()) {       // removeLooseComponents (mesh/util.cpp:47-98): faces sharing a vertex position are connected
+        const size_t nf = faces.size() / 3;
+        std::vector<int> parent(nf); std::iota(parent.begin(), parent.end(), 0);
+        auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        std::vector<int> first_face(M.vertices.size() / 3, -1);
+        for (size_t f = 0; f < nf; ++f) for (int k = 0; k < 3; ++k) {
+            const int v = faces[3 * f + k];
+            if (first_face[v] < 0) first_face[v] = (int)f;
+            else { int a = find(first_face[v]), b = find((int)f); if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; } }      // root = smallest face index
+        }
+        std::vector<int> size(nf, 0);
+        for (size_t f = 0; f < nf; ++f) size[find((int)f)]++;
+        // boost numbers components in order of their first face, std::max_element keeps the first maximum
+        int best = -1;
+        for (size_t f = 0; f < nf; ++f) if (parent[f] == (int)f && (best < 0 || size[f] > size[best])) best = (int)f;
+        std::vector<int32_t> out; out.reserve(3 * (size_t)size[best]);
+        for (size_t f = 0; f < nf; ++f) if (find((int)f) == best) { out.push_back(faces[3 * f]); out.push_back(faces[3 * f + 1]); out.push_back(faces[3 * f + 2]); }
+        faces.swap(out);
+    }
+    M.faces.swap(faces);
+    return I3D_OK;
+}
+
+}  // namespace i3d
+
+using namespace i3d;
+
+extern "C" {
+
+// Mesh::save (mesh/mesh.cpp:41-100): binary little-endian PLY, float positions, optional uchar colours, "uchar int" face lists
+int i3d_write_ply(const char* path, int64_t num_vertices, const float* vertices, const uint8_t* colors, int64_t num_faces, const int32_t* faces) {
+    if (!path || num_vertices <= 0 || !vertices || (num_faces > 0 && !faces)) return I3D_ERR_INVALID_ARGUMENT;     // empty meshes are not saved
+    std::ofstream f(path, std::ios::binary); if (!f.is_open()) return I3D_ERR_IO;
+    f << "ply\n" << "format binary_little_endian 1.0\n" << "element vertex " << (int)num_vertices << "\n"
+      << "property float x\n" << "property float y\n" << "property float z\n";
+    if (colors) f << "property uchar red\n" << "property uchar green\n" << "property uchar blue\n";
+    f << "element face " << (int)num_faces << "\n" << "property list uchar int vertex_indices\n" << "end_header\n";
+    for (int64_t i = 0; i < num_vertices; ++i) { f.write((const char*)&vertices[3 * i], 12); if (colors) f.write((const char*)&colors[3 * i], 3); }
+    const unsigned char three = 3;
+    for (int64_t i = 0; i < num_faces; ++i) { f.write((const char*)&three, 1); f.write((const char*)&faces[3 * i], 12); }
+    return f.good() ? I3D_OK : I3D_ERR_IO;
+}
+
+int i3d_extract_mesh(i3d_context* c, int32_t use_refined_sdf, int32_t color_mode, int32_t largest_component_only, int64_t* num_vertices, int64_t* num_faces) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    const int rc = extract_mesh(c, use_refined_sdf, color_mode, largest_component_only, g_mesh, nullptr);
+    if (rc) return rc;
+    if (num_vertices) *num_vertices = (int64_t)(g_mesh.vertices.size() / 3);
+    if (num_faces) *num_faces = (int64_t)(g_mesh.faces.size() / 3);
+    return I3D_OK;
+}
+int i3d_get_mesh(i3d_context* c, float* vertices, uint8_t* colors, int32_t* faces) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    if (vertices) std::memcpy(vertices, g_mesh.vertices.data(), g_mesh.vertices.size() * sizeof(float));
+    if (colors) std::memcpy(colors, g_mesh.colors.data(), g_mesh.colors.size());
+    if (faces) std::memcpy(faces, g_mesh.faces.data(), g_mesh.faces.size() * sizeof(int32_t));
+    return I3D_OK;
+}
+// SDFVisualization::exportMesh for one colour mode: extract (+ largest component) + save
+int i3d_export_mesh_ply(i3d_context* c, const char* path, int32_t use_refined_sdf, int32_t color_mode, int32_t largest_component_only) {
+    if (!c || !path) return I3D_ERR_INVALID_ARGUMENT;
+    MeshData M;
+    const int rc = extract_mesh(c, use_refined_sdf, color_mode, largest_component_only, M, nullptr);
+    if (rc) return rc;
+    if (M.vertices.empty()) return ctx_fail(c, I3D_ERR_STATE, "i3d_export_mesh_ply: mesh could not be generated (no iso-surface)");
+    return i3d_write_ply(path, (int64_t)(M.vertices.size() / 3), M.vertices.data(), M.colors.data(), (int64_t)(M.faces.size() / 3), M.faces.data());
+}
+// the generated triangulation table, for inspection / tests: ntri[256], tri[256][24] (edge ids, -1 padded)
+int i3d_mc_tables(uint8_t* ntri, int8_t* tri) {
+    const McTables& T = tables();
+    if (ntri) std::memcpy(ntri, T.ntri, 256);
+    if (tri) std::memcpy(tri, T.tri, 256 * MC_STRIDE);
+    return T.max_tri + 100 * T.fallbacks;       // fallbacks (a loop without a face-chord-free triangulation) must be 0
+}
+
+}  // extern "C"

