@@ -1,0 +1,115 @@
+"""-m gpu: edge cases of the path, device vs oracle through the C ABI — negative voxel coordinates (hash sign-extension, truncating
+round), constant albedo (lambda_a < 0), fixed camera blocks, "all observations" (num_observations = 0), capacity errors, grids without
+any active voxel, a keyframe that sees nothing."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(O, sc, thres, **cfgkw):
+    from intrinsic3d_amd import binding
+    g = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"]); fr = O.Frames(sc["frames"], sc["levels"])
+    g.clear_outside_shell(thres)
+    rc, _, _, vsh, _, _ = O.estimate_sh(g, 0.05, 10.0, thres)
+    assert rc == 0
+    ocfg = helpers.oracle_cfg(O, thres, iterations=2, cg_fixed_iterations=6, **cfgkw)
+    rc, ointr, odist, oposes, ostats = O.optimize(g, fr, ocfg, sc["intr"], sc["dist"], sc["poses"], vsh)
+    ref = g.export()
+    with binding.Context(0) as ctx:
+        ctx.set_grid_from_tsdf_records(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        ctx.set_frames(sc["frames"], sc["levels"]); ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
+        assert ctx.clear_outside_thin_shell(thres) == len(g)
+        ctx.estimate_sh(0.05, 10.0, thres)
+        gstats = ctx.optimize(helpers.gpu_cfg(ocfg))
+        out = ctx.export_grid(); cam = ctx.get_camera()
+    g.free(); fr.free()
+    return rc, ref, (ointr, odist, oposes), ostats, out, cam, gstats
+
+
+def _check(ref, ostats, out, gstats, tol=1e-4):
+    assert np.array_equal(out["keys"], ref["keys"])
+    for so, sg in zip(ostats, gstats):
+        assert list(so.rows) == list(sg.rows)
+        assert abs(so.cost_final - sg.cost_final) <= tol * max(so.cost_final, 1e-30)
+    assert np.abs(out["sdf_refined"] - ref["sdf_refined"]).max() <= tol * np.abs(ref["sdf_refined"]).max()
+    assert np.abs(out["albedo"] - ref["albedo"]).max() <= tol * np.abs(ref["albedo"]).max()
+
+
+def test_negative_coordinates(oracle):
+    """the same scene translated into the negative octant: keys < 0 exercise the sign-extending hash (mat.h:117-124) in the visit order
+    and the float voxel->world products; the surface must be found by the cameras all the same"""
+    sc = dict(helpers.small_scene(seed=7, radius_vox=9, K=4, width=96, height=72))
+    shift = np.array([-40, -33, -51], np.int32)
+    sc["keys"] = sc["keys"] + shift[None, :]
+    t = shift.astype(np.float64) * float(sc["voxel_size"])
+    poses = np.array(sc["poses"], np.float64)
+    for f in range(len(poses)):                      # world shifted by t: x_cam = R (x_w' - t) + tr  ->  tr' = tr - R t
+        R, _ = oracle.pose_to_mat(poses[f]); poses[f, 3:] = poses[f, 3:] - R.astype(np.float64).reshape(3, 3) @ t
+    sc["poses"] = poses
+    thres = 2.0 * float(sc["voxel_size"])
+    rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres)
+    assert rc == 0 and ostats[0].rows[0] > 500 and (ref["keys"] < 0).all(axis=1).any()
+    _check(ref, ostats, out, gstats)
+
+
+@pytest.mark.parametrize("kw", [dict(lambda_a=-1.0), dict(fix_poses=1, fix_intrinsics=1, fix_distortion=1), dict(num_observations=0),
+                                dict(fix_poses=1, fix_distortion=1, num_observations=2)])
+def test_parameter_group_switches(oracle, kw):
+    sc = helpers.small_scene(seed=8, radius_vox=9, K=4, width=96, height=72)
+    thres = 2.0 * float(sc["voxel_size"])
+    rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres, **kw)
+    assert rc == 0
+    _check(ref, ostats, out, gstats)
+    if kw.get("lambda_a", 0) < 0:
+        assert np.all(out["albedo"] == 0.6) and np.all(ref["albedo"] == 0.6)       # constant albedo: every albedo block fixed, no Ea rows
+        assert gstats[0].rows[3] == 0
+    if kw.get("fix_poses"):
+        assert np.array_equal(cam[2], np.asarray(sc["poses"], np.float64))
+    if kw.get("num_observations", 5) == 2:
+        assert gstats[0].rows[0] <= 2 * ostats[0].valid_voxels                     # at most the 2 best observations per voxel
+
+
+def test_capacity_and_state_errors(oracle):
+    from intrinsic3d_amd import binding
+    sc = helpers.small_scene(seed=9, radius_vox=6, K=10, width=48, height=36)
+    with binding.Context(0) as ctx:
+        with pytest.raises(binding.I3DError):
+            ctx.optimize(binding.default_config(iterations=1))                     # nothing set: state error, not a crash
+        ctx.set_grid_from_tsdf_records(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        ctx.set_frames(sc["frames"], 1); ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
+        ctx.set_voxel_sh(np.tile(np.asarray(sc["scene"].sh), (ctx.N, 1)))
+        with pytest.raises(binding.I3DError):                                      # 10 keyframes, "all observations": > 8 rows per voxel
+            ctx.optimize(binding.default_config(iterations=1, num_observations=0, thres_shell=0.01))
+        with pytest.raises(binding.I3DError):
+            ctx.optimize(binding.default_config(iterations=0, thres_shell=0.01))   # optimizer.cpp:113-114
+        with pytest.raises(binding.I3DError):
+            ctx.optimize(binding.default_config(iterations=1, thres_shell=0.01, rgbd_level=3))
+        with pytest.raises(binding.I3DError):
+            ctx.estimate_sh(0.05, 10.0, 0.0)                                       # LightingSVSH::estimate: thres_shell <= 0
+
+
+def test_no_active_voxel_and_blind_keyframe(oracle):
+    """(1) a shell threshold of ~0 leaves no in-shell voxel: zero rows, nothing moves, no error (the reference logs and continues);
+    (2) a keyframe that looks away contributes no observation and its pose stays put"""
+    from intrinsic3d_amd import binding
+    sc = dict(helpers.small_scene(seed=10, radius_vox=8, K=3, width=96, height=72))
+    with binding.Context(0) as ctx:
+        ctx.set_grid_from_tsdf_records(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        ctx.set_frames(sc["frames"], 1); ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
+        ctx.set_voxel_sh(np.tile(np.asarray(sc["scene"].sh), (ctx.N, 1)))
+        before = ctx.export_grid()
+        st = ctx.optimize(binding.default_config(iterations=2, thres_shell=1e-12))
+        after = ctx.export_grid()
+        assert list(st[0].rows) == [0, 0, 0, 0] and np.array_equal(before["sdf_refined"], after["sdf_refined"]) and np.array_equal(before["albedo"], after["albedo"])
+    poses = np.array(sc["poses"], np.float64)
+    R, _ = oracle.pose_to_mat(poses[1])
+    poses[1, :3] = 0.0; poses[1, 3:] = [0.0, 0.0, -5.0]            # camera 1: identity rotation, everything 5 m behind it
+    sc["poses"] = poses
+    thres = 2.0 * float(sc["voxel_size"])
+    rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres)
+    assert rc == 0
+    _check(ref, ostats, out, gstats)
+    assert np.array_equal(cam[2][1], poses[1]) and np.array_equal(ocam[2][1], poses[1])      # no row touches pose 1: the block never enters the problem
