@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--subvolume", type=float, default=0.08, help="SH subvolume size in metres (0.6 m object: 8 cells per axis)")
     ap.add_argument("--cpu-sample", type=float, default=1.0e6, help="stored voxels of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--pcg-fixed", type=int, default=-1, help="experiments only: pin the PCG iterations per LM attempt (-1 = Ceres' stopping rule)")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="also launch a known-size device copy (1 GiB read + 1 GiB write) so that a rocprofv3 --pmc pass over this command "
                          "can calibrate FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section); see tools/pmc_traffic.py")
@@ -73,7 +74,7 @@ def make_cfg(binding, args, iterations, thres):
     return binding.default_config(iterations=iterations, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0,
                                   lambda_s1=10.0, lambda_a=0.1, fix_poses=0, fix_intrinsics=0, fix_distortion=0,
                                   occlusion_distance=0.02, num_observations=5, thres_shell=thres, grid_level=0, rgbd_level=0,
-                                  pcg_fixed_iterations=-1, verbose=0)
+                                  pcg_fixed_iterations=args.pcg_fixed, verbose=0)
 
 
 def cpu_baseline(args, sc, thres, log):
