@@ -80,6 +80,12 @@ int i3d_get_camera(i3d_context* ctx, double* intrinsics4, double* distortion5, d
 int i3d_set_voxel_sh(i3d_context* ctx, const double* voxel_sh);
 int i3d_get_voxel_sh(i3d_context* ctx, double* voxel_sh);
 
+/* Intrinsic3D::init's Pyramid(num_rgbd_levels, color, depth) per keyframe, built on the device from level-0 colour + depth (already in colour
+ * geometry): float luminance (convertTo 1/255 + BGR2GRAY), cv::pyrDown levels, valid-mean depth levels (rgbd/pyramid.cpp:59-166).
+ * Replaces i3d_set_frames for callers that do not want to build the pyramids with OpenCV. */
+int i3d_set_frames_rgbd(i3d_context* ctx, int32_t num_frames, int32_t levels, int32_t width, int32_t height, const uint8_t* const* bgr, const float* const* depth);
+int i3d_get_frame_image(i3d_context* ctx, int32_t frame, int32_t level, float* lum /* may be NULL */, float* depth /* may be NULL */);
+
 /* ---- Optimizer::Config (optimizer.h:67-84) + the fields of Intrinsic3D::Config / Optimizer::Data the path reads */
 typedef struct {
     int32_t iterations;            /* outer Gauss-Newton iterations (optimizer.cpp:119) */

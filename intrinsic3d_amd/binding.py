@@ -60,7 +60,7 @@ class GridView(C.Structure):
 
 
 EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_set_grid", "i3d_get_grid", "i3d_update_grid",
-           "i3d_set_frames", "i3d_set_camera", "i3d_get_camera", "i3d_set_voxel_sh", "i3d_get_voxel_sh",
+           "i3d_set_frames", "i3d_set_frames_rgbd", "i3d_get_frame_image", "i3d_set_camera", "i3d_get_camera", "i3d_set_voxel_sh", "i3d_get_voxel_sh",
            "i3d_optimizer_config_default", "i3d_optimize", "i3d_optimize_host", "i3d_estimate_sh",
            "i3d_set_grid_from_tsdf_records", "i3d_recompute_colors", "i3d_clear_outside_thin_shell", "i3d_upsample", "i3d_grid_info",
            "i3d_export_grid", "i3d_refine",
@@ -93,6 +93,8 @@ def load():
     L.i3d_get_grid.restype = i32; L.i3d_get_grid.argtypes = [vp, vp, vp]
     L.i3d_update_grid.restype = i32; L.i3d_update_grid.argtypes = [vp, vp, vp, vp]
     L.i3d_set_frames.restype = i32; L.i3d_set_frames.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    L.i3d_set_frames_rgbd.restype = i32; L.i3d_set_frames_rgbd.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    L.i3d_get_frame_image.restype = i32; L.i3d_get_frame_image.argtypes = [vp, i32, i32, vp, vp]
     L.i3d_set_camera.restype = i32; L.i3d_set_camera.argtypes = [vp, vp, vp, vp]
     L.i3d_get_camera.restype = i32; L.i3d_get_camera.argtypes = [vp, vp, vp, vp]
     L.i3d_set_voxel_sh.restype = i32; L.i3d_set_voxel_sh.argtypes = [vp, vp]
@@ -215,6 +217,19 @@ class Context:
                 lum[f * levels + l] = a.ctypes.data; dep[f * levels + l] = b.ctypes.data
                 bgr[f * levels + l] = c.ctypes.data if c is not None else None
         self._check(self.L.i3d_set_frames(self.h, K, levels, _p(ws), _p(hs), C.cast(lum, C.c_void_p), C.cast(dep, C.c_void_p), C.cast(bgr, C.c_void_p)), "i3d_set_frames")
+
+    def set_frames_rgbd(self, bgr_list, depth_list, levels):
+        """level-0 colour (uint8 HxWx3, BGR) + depth (float32 HxW) per keyframe; the pyramids are built on the device"""
+        K = len(bgr_list); h, w = depth_list[0].shape
+        self._keep = [np.ascontiguousarray(b, np.uint8) for b in bgr_list] + [np.ascontiguousarray(d, np.float32) for d in depth_list]
+        pb = (C.c_void_p * K)(*[a.ctypes.data for a in self._keep[:K]]); pd = (C.c_void_p * K)(*[a.ctypes.data for a in self._keep[K:]])
+        self._check(self.L.i3d_set_frames_rgbd(self.h, K, int(levels), int(w), int(h), pb, pd), "i3d_set_frames_rgbd")
+        self.K = K
+
+    def get_frame_image(self, frame, level, w, h):
+        lum = np.zeros((h, w), np.float32); dep = np.zeros((h, w), np.float32)
+        self._check(self.L.i3d_get_frame_image(self.h, int(frame), int(level), _p(lum), _p(dep)), "i3d_get_frame_image")
+        return lum, dep
 
     def set_camera(self, intr, dist, poses):
         a = np.ascontiguousarray(intr, np.float64); b = np.ascontiguousarray(dist, np.float64); c = np.ascontiguousarray(poses, np.float64)

@@ -201,3 +201,42 @@ void launch_permute_staging(hipStream_t st, long long n, const int* perm, const 
     if (n > 0) k_permute_staging<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(n, perm, kin, s0, s1, al, w, rgb, kout, o0, o1, oal, ow, orgb);
 }
 }  // namespace i3d
+
+// ---- keyframe pyramids (Pyramid::create, rgbd/pyramid.cpp:59-166) -------------------------------------------------------------------
+// level 0 luminance: color.convertTo(CV_32FC3, 1/255) then cv::cvtColor(COLOR_BGR2GRAY) on floats  [OpenCV, un-vendored: b*0.114f + g*0.587f +
+// r*0.299f summed left to right]; further levels: cv::pyrDown = separable [1 4 6 4 1] with BORDER_REFLECT_101, horizontal pass first, the
+// 1/256 applied once at the end; depth levels: mean of the valid taps of each 2x2 block (pyramid.cpp:115-143).
+namespace i3d {
+__global__ void __launch_bounds__(256) k_lum_from_bgr(int n, const uint8_t* __restrict__ bgr, float* __restrict__ lum) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = (float)(1.0 / 255.0);
+    const float b = (float)bgr[3 * i] * s, g = (float)bgr[3 * i + 1] * s, r = (float)bgr[3 * i + 2] * s;
+    lum[i] = (b * 0.114f + g * 0.587f) + r * 0.299f;
+}
+static __device__ inline int reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i; return i; }
+__global__ void __launch_bounds__(256) k_pyr_down(int w, int h, const float* __restrict__ src, int ow, int oh, float* __restrict__ dst) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow || y >= oh) return;
+    float row[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float* line = src + (size_t)reflect101(2 * y - 2 + j, h) * w;
+        const float m2 = line[reflect101(2 * x - 2, w)], m1 = line[reflect101(2 * x - 1, w)], c0 = line[reflect101(2 * x, w)],
+                    p1 = line[reflect101(2 * x + 1, w)], p2 = line[reflect101(2 * x + 2, w)];
+        row[j] = ((c0 * 6.0f + (m1 + p1) * 4.0f) + m2) + p2;
+    }
+    dst[(size_t)y * ow + x] = (((row[2] * 6.0f + (row[1] + row[3]) * 4.0f) + row[0]) + row[4]) * (1.0f / 256.0f);
+}
+__global__ void __launch_bounds__(256) k_depth_down(int w, const float* __restrict__ src, int ow, int oh, float* __restrict__ dst) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow || y >= oh) return;
+    int cnt = 0; float sum = 0.0f;
+    const float d0 = src[(size_t)(2 * y) * w + 2 * x], d1 = src[(size_t)(2 * y) * w + 2 * x + 1], d2 = src[(size_t)(2 * y + 1) * w + 2 * x], d3 = src[(size_t)(2 * y + 1) * w + 2 * x + 1];
+    if (d0 > 0.0f) { sum += d0; ++cnt; } if (d1 > 0.0f) { sum += d1; ++cnt; } if (d2 > 0.0f) { sum += d2; ++cnt; } if (d3 > 0.0f) { sum += d3; ++cnt; }
+    dst[(size_t)y * ow + x] = cnt > 0 ? sum / (float)cnt : 0.0f;
+}
+void launch_lum_from_bgr(hipStream_t st, int n, const uint8_t* bgr, float* lum) { if (n > 0) k_lum_from_bgr<<<(n + 255) / 256, 256, 0, st>>>(n, bgr, lum); }
+void launch_pyr_down(hipStream_t st, int w, int h, const float* src, int ow, int oh, float* dst) { if (ow > 0 && oh > 0) k_pyr_down<<<dim3((ow + 255) / 256, oh), 256, 0, st>>>(w, h, src, ow, oh, dst); }
+void launch_depth_down(hipStream_t st, int w, const float* src, int ow, int oh, float* dst) { if (ow > 0 && oh > 0) k_depth_down<<<dim3((ow + 255) / 256, oh), 256, 0, st>>>(w, src, ow, oh, dst); }
+}  // namespace i3d

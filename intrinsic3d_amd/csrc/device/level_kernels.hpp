@@ -21,3 +21,10 @@ void launch_mc_count(hipStream_t st, GridView g, HashTable t, const int* inv_ran
 void launch_mc_emit(hipStream_t st, GridView g, HashTable t, const int* inv_rank, int refined, int color_mode, const unsigned char* ntri, const signed char* tri,
                     int tri_stride, const int* offsets, float* pos, unsigned char* col);
 }  // namespace i3d
+
+namespace i3d {
+// keyframe pyramids (Pyramid::create, rgbd/pyramid.cpp:59-166)
+void launch_lum_from_bgr(hipStream_t st, int n, const uint8_t* bgr, float* lum);
+void launch_pyr_down(hipStream_t st, int w, int h, const float* src, int ow, int oh, float* dst);
+void launch_depth_down(hipStream_t st, int w, const float* src, int ow, int oh, float* dst);
+}  // namespace i3d

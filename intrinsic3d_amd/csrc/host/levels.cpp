@@ -41,7 +41,7 @@ OptParams color_params(const i3d_context* c, float occlusion) {
 // Intrinsic3D::recomputeColors (intrinsic3d.cpp:381-409): SDFColorization::add for every keyframe at pyramid level 0, then compute()
 int recompute_colors(i3d_context* c, float occlusion_distance, int num_observations) {
     if (!c->have_grid || !c->have_frames || !c->have_camera) return ctx_fail(c, I3D_ERR_STATE, "recompute_colors: grid, keyframes and camera must be set");
-    for (auto& b : c->bgr) if (!b.p) return ctx_fail(c, I3D_ERR_STATE, "recompute_colors: keyframes were uploaded without colour images");
+    for (int f = 0; f < c->K; ++f) if (!c->bgr[(size_t)f * c->levels].p) return ctx_fail(c, I3D_ERR_STATE, "recompute_colors: keyframes were uploaded without colour images");
     if (num_observations > MAX_SLOTS || (num_observations <= 0 && c->K > MAX_SLOTS)) return ctx_fail(c, I3D_ERR_CAPACITY, "recompute_colors: more than 8 observations per voxel");
     CTX_HIP(c, hipSetDevice(c->device));
     OptParams p = color_params(c, occlusion_distance);
@@ -124,6 +124,48 @@ int i3d_clear_outside_thin_shell(i3d_context* c, double thres_shell, int64_t* ne
 int i3d_upsample(i3d_context* c, int64_t* new_count) {
     if (!c) return I3D_ERR_INVALID_ARGUMENT;
     return upsample_grid(c, new_count);
+}
+// Intrinsic3D::init's per-keyframe Pyramid(num_rgbd_levels, color, depth) (intrinsic3d.cpp:182-187, rgbd/pyramid.cpp:59-166) on the device:
+// level-0 colour + depth in, float luminance / depth pyramids out (colour is kept at level 0 only: recomputeColors reads nothing else)
+int i3d_set_frames_rgbd(i3d_context* c, int32_t K, int32_t levels, int32_t width, int32_t height, const uint8_t* const* bgr, const float* const* depth) {
+    if (!c || K <= 0 || levels <= 0 || width <= 0 || height <= 0 || !bgr || !depth) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_frames_rgbd: bad arguments");
+    if ((width >> (levels - 1)) < 1 || (height >> (levels - 1)) < 1) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_frames_rgbd: more levels than the image size allows");
+    CTX_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->have_frames = false; c->K = K; c->levels = levels;
+    c->fw.resize(levels); c->fh.resize(levels);
+    for (int l = 0; l < levels; ++l) { c->fw[l] = l ? c->fw[l - 1] / 2 : width; c->fh[l] = l ? c->fh[l - 1] / 2 : height; }
+    c->lum.clear(); c->depth.clear(); c->bgr.clear();
+    c->lum.resize((size_t)K * levels); c->depth.resize((size_t)K * levels); c->bgr.resize((size_t)K * levels);
+    for (int f = 0; f < K; ++f) {
+        if (!bgr[f] || !depth[f]) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_frames_rgbd: null image");
+        const size_t k0 = (size_t)f * levels, px = (size_t)width * height;
+        CTX_HIP(c, c->bgr[k0].alloc(px * 3)); CTX_HIP(c, c->lum[k0].alloc(px)); CTX_HIP(c, c->depth[k0].alloc(px));
+        CTX_HIP(c, hipMemcpyAsync(c->bgr[k0].p, bgr[f], px * 3, hipMemcpyHostToDevice, st));
+        CTX_HIP(c, hipMemcpyAsync(c->depth[k0].p, depth[f], px * sizeof(float), hipMemcpyHostToDevice, st));
+        launch_lum_from_bgr(st, (int)px, c->bgr[k0].p, c->lum[k0].p);
+        for (int l = 1; l < levels; ++l) {
+            const size_t k = k0 + l, n = (size_t)c->fw[l] * c->fh[l];
+            CTX_HIP(c, c->lum[k].alloc(n)); CTX_HIP(c, c->depth[k].alloc(n));
+            launch_pyr_down(st, c->fw[l - 1], c->fh[l - 1], c->lum[k - 1].p, c->fw[l], c->fh[l], c->lum[k].p);
+            launch_depth_down(st, c->fw[l - 1], c->depth[k - 1].p, c->fw[l], c->fh[l], c->depth[k].p);
+        }
+    }
+    CTX_HIP(c, c->d_frames.alloc(K)); CTX_HIP(c, c->d_frames_cand.alloc(K));
+    CTX_HIP(c, hipStreamSynchronize(st));
+    CTX_HIP(c, hipGetLastError());
+    c->have_frames = true;
+    if ((int)c->poses.size() != 6 * K) { c->poses.assign((size_t)6 * K, 0.0); c->have_camera = false; }
+    return I3D_OK;
+}
+// one pyramid image back to the host (parity probe / callers that still want the images)
+int i3d_get_frame_image(i3d_context* c, int32_t frame, int32_t level, float* lum, float* depth) {
+    if (!c || !c->have_frames || frame < 0 || frame >= c->K || level < 0 || level >= c->levels) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_get_frame_image: bad frame / level");
+    const size_t k = (size_t)frame * c->levels + level, n = (size_t)c->fw[level] * c->fh[level];
+    CTX_HIP(c, hipSetDevice(c->device));
+    if (lum) CTX_HIP(c, hipMemcpy(lum, c->lum[k].p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (depth) CTX_HIP(c, hipMemcpy(depth, c->depth[k].p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return I3D_OK;
 }
 int i3d_grid_info(i3d_context* c, int64_t* num_voxels, float* voxel_size, float* truncation) {
     if (!c || !c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "i3d_grid_info: no grid");

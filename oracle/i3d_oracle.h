@@ -71,6 +71,10 @@ int32_t orc_estimate_sh(void* g, float subvolume_size, double lambda_reg, double
                         int32_t* num_subvolumes, double* sh /* cap*9 */, int32_t* sub_index /* cap*3 */, int32_t cap,
                         double* voxel_sh /* N*9 or NULL */, uint8_t* voxel_has_sh /* N or NULL */, orc_sh_stats* st);
 
+/* keyframe pyramids (rgbd/pyramid.cpp:59-166) */
+void    orc_lum_from_bgr(int32_t n, const uint8_t* bgr, float* lum);
+void    orc_pyr_down(int32_t w, int32_t h, const float* src, float* dst /* (w/2)*(h/2) */);
+void    orc_depth_down(int32_t w, int32_t h, const float* src, float* dst);
 int32_t orc_recompute_colors(void* g, void* fr, const double* intr, const double* dist, const double* poses,
                              float occlusion_distance, int32_t num_observations);
 /* Intrinsic3D::refine (intrinsic3d.cpp:206-290); *grid_io is replaced by the upsampled grids */

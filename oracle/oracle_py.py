@@ -165,6 +165,21 @@ class Frames:
             lib().orc_frames_free(self.h); self.h = None
 
 
+def lum_from_bgr(bgr):
+    b = np.ascontiguousarray(bgr, np.uint8); out = np.zeros(b.shape[:2], np.float32)
+    lib().orc_lum_from_bgr(C.c_int32(out.size), _p(b), _p(out)); return out
+
+
+def pyr_down(img):
+    a = np.ascontiguousarray(img, np.float32); h, w = a.shape; out = np.zeros((h // 2, w // 2), np.float32)
+    lib().orc_pyr_down(C.c_int32(w), C.c_int32(h), _p(a), _p(out)); return out
+
+
+def depth_down(img):
+    a = np.ascontiguousarray(img, np.float32); h, w = a.shape; out = np.zeros((h // 2, w // 2), np.float32)
+    lib().orc_depth_down(C.c_int32(w), C.c_int32(h), _p(a), _p(out)); return out
+
+
 def recompute_colors(grid: Grid, frames: "Frames", intr, dist, poses, occlusion_distance, num_observations):
     intr = np.ascontiguousarray(intr, np.float64); dist = np.ascontiguousarray(dist, np.float64); poses = np.ascontiguousarray(poses, np.float64)
     return lib().orc_recompute_colors(grid.h, frames.h, _p(intr), _p(dist), _p(poses), float(occlusion_distance), int(num_observations))

@@ -162,6 +162,37 @@ int32_t orc_estimate_sh(void* g, float subvolume_size, double lambda_reg, double
     return 0;
 }
 
+// rgbd/pyramid.cpp:59-166 — keyframe pyramids.  cv::cvtColor(BGR2GRAY) on floats and cv::pyrDown are OpenCV (un-vendored): restated from
+// their documented kernels — gray = 0.114 b + 0.587 g + 0.299 r; pyrDown = [1 4 6 4 1] x [1 4 6 4 1] / 256, BORDER_REFLECT_101, horizontal
+// pass first, size (w/2, h/2).  PARITY UNPINNED against OpenCV's exact float summation order.
+static int orc_reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i; return i; }
+void orc_lum_from_bgr(int32_t n, const uint8_t* bgr, float* lum) {
+    const float s = (float)(1.0 / 255.0);
+    for (int i = 0; i < n; ++i) { const float b = (float)bgr[3 * i] * s, g = (float)bgr[3 * i + 1] * s, r = (float)bgr[3 * i + 2] * s; lum[i] = (b * 0.114f + g * 0.587f) + r * 0.299f; }
+}
+void orc_pyr_down(int32_t w, int32_t h, const float* src, float* dst) {
+    const int ow = w / 2, oh = h / 2;
+    for (int y = 0; y < oh; ++y) for (int x = 0; x < ow; ++x) {
+        float row[5];
+        for (int j = 0; j < 5; ++j) {
+            const float* line = src + (size_t)orc_reflect101(2 * y - 2 + j, h) * w;
+            const float m2 = line[orc_reflect101(2 * x - 2, w)], m1 = line[orc_reflect101(2 * x - 1, w)], c0 = line[orc_reflect101(2 * x, w)],
+                        p1 = line[orc_reflect101(2 * x + 1, w)], p2 = line[orc_reflect101(2 * x + 2, w)];
+            row[j] = ((c0 * 6.0f + (m1 + p1) * 4.0f) + m2) + p2;
+        }
+        dst[(size_t)y * ow + x] = (((row[2] * 6.0f + (row[1] + row[3]) * 4.0f) + row[0]) + row[4]) * (1.0f / 256.0f);
+    }
+}
+void orc_depth_down(int32_t w, int32_t h, const float* src, float* dst) {       // Pyramid::downsampleDepth (pyramid.cpp:115-143)
+    const int ow = w / 2, oh = h / 2;
+    for (int y = 0; y < oh; ++y) for (int x = 0; x < ow; ++x) {
+        int cnt = 0; float sum = 0.0f;
+        const float d[4] = {src[(size_t)(2 * y) * w + 2 * x], src[(size_t)(2 * y) * w + 2 * x + 1], src[(size_t)(2 * y + 1) * w + 2 * x], src[(size_t)(2 * y + 1) * w + 2 * x + 1]};
+        for (int i = 0; i < 4; ++i) if (d[i] > 0.0f) { sum += d[i]; ++cnt; }
+        dst[(size_t)y * ow + x] = cnt > 0 ? sum / (float)cnt : 0.0f;
+    }
+}
+
 // intrinsic3d.cpp:381-409 + colorization.cpp:113-189,318-354 (recolourisation at pyramid level 0)
 int32_t orc_recompute_colors(void* g, void* fr, const double* intr, const double* dist, const double* poses,
                              float occlusion_distance, int32_t num_observations) {

@@ -152,3 +152,23 @@ def test_refine_two_levels_matches_oracle(oracle, scene, iterations, fix_intrins
     assert np.abs(poses - oposes).max() <= max(1e-5, 3.0 * np.abs(pposes - oposes).max())
     cd = np.abs(out["color"].astype(int) - ref["color"].astype(int))
     assert (cd > 1).mean() < 1e-3                                             # 8-bit truncation of colours computed from ~1e-7-different geometry
+
+
+def test_keyframe_pyramids_on_device_bit_exact(oracle):
+    """Pyramid::create on the device (i3d_set_frames_rgbd): luminance from 8-bit BGR, pyrDown levels, valid-mean depth levels == oracle, bit for bit"""
+    from intrinsic3d_amd import binding
+    rng = np.random.default_rng(4)
+    K, W, H, L = 3, 101, 75, 3                     # odd sizes: the (w/2, h/2) floor and the reflected borders are exercised
+    bgr = [rng.integers(0, 256, (H, W, 3)).astype(np.uint8) for _ in range(K)]
+    dep = []
+    for _ in range(K):
+        d = rng.uniform(0.4, 3.0, (H, W)).astype(np.float32); d[rng.uniform(size=d.shape) < 0.25] = 0.0; dep.append(d)
+    with binding.Context(0) as ctx:
+        ctx.set_frames_rgbd(bgr, dep, L)
+        for f in range(K):
+            lum_ref = oracle.lum_from_bgr(bgr[f]); dep_ref = dep[f]; w, h = W, H
+            for l in range(L):
+                lum, d = ctx.get_frame_image(f, l, w, h)
+                assert np.array_equal(lum, lum_ref), (f, l, np.abs(lum - lum_ref).max())
+                assert np.array_equal(d, dep_ref), (f, l)
+                lum_ref = oracle.pyr_down(lum_ref); dep_ref = oracle.depth_down(dep_ref); w //= 2; h //= 2

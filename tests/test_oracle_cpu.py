@@ -181,3 +181,21 @@ def test_golden_oracle_outputs(oracle):
     np.testing.assert_allclose(cur["sdf_sum"], gold["sdf_sum"], rtol=1e-9)
     np.testing.assert_allclose(cur["albedo_sum"], gold["albedo_sum"], rtol=1e-9)
     np.testing.assert_allclose(cur["sh0"], gold["sh0"], rtol=1e-8)
+
+
+def test_pyramid_restatement_against_numpy(oracle):
+    """luminance / pyrDown / depth pyramid of the oracle vs an independent numpy formulation (separable float32 convolution with reflected
+    borders; valid-mean of 2x2 blocks)"""
+    from intrinsic3d_amd import synthetic
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (37, 50, 3)).astype(np.uint8)
+    lum = oracle.lum_from_bgr(bgr)
+    ref = (bgr[..., 0].astype(np.float64) * 0.114 + bgr[..., 1].astype(np.float64) * 0.587 + bgr[..., 2].astype(np.float64) * 0.299) / 255.0
+    np.testing.assert_allclose(lum, ref, rtol=0, atol=2e-7)
+    img = rng.uniform(0, 1, (37, 50)).astype(np.float32)
+    np.testing.assert_allclose(oracle.pyr_down(img), synthetic.pyr_down(img), rtol=0, atol=3e-7)       # same kernel, different summation order
+    assert oracle.pyr_down(img).shape == (18, 25)
+    d = rng.uniform(0.5, 2.0, (36, 50)).astype(np.float32); d[rng.uniform(size=d.shape) < 0.3] = 0.0
+    assert np.array_equal(oracle.depth_down(d), synthetic.depth_down(d))
+    const = np.full((20, 24), 0.37, np.float32)
+    np.testing.assert_allclose(oracle.pyr_down(const), 0.37, rtol=0, atol=1e-7)                          # the kernel sums to 1, borders reflected
