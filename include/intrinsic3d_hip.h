@@ -208,9 +208,13 @@ int32_t i3d_shard_vec_index(int32_t a, int32_t chunk, int32_t albedo);
 
 /* ---- measurement: HIP-event time (ms) and launch count accumulated per kernel family on the context's stream
  * since the last reset.  names: see i3d_kernel_name(). */
-enum { I3D_K_CLASSIFY = 0, I3D_K_OBSERVE, I3D_K_BUILD, I3D_K_EG_PASS, I3D_K_GATHER, I3D_K_COST, I3D_K_VECTOR, I3D_K_SH, I3D_K_COUNT };
+enum { I3D_K_CLASSIFY = 0, I3D_K_OBSERVE, I3D_K_BUILD, I3D_K_EG_PASS /* J^T W J p passes of the PCG */, I3D_K_GATHER, I3D_K_COST, I3D_K_VECTOR, I3D_K_SH,
+       I3D_K_EG_AUX /* gradient and column-norm passes over the rows */, I3D_K_COUNT };
 int i3d_timing_enable(i3d_context* ctx, int32_t on);
 int i3d_timing_get(i3d_context* ctx, double* ms /*[I3D_K_COUNT]*/, int64_t* launches /*[I3D_K_COUNT]*/, int32_t reset);
+/* the same restricted to launches that did work: PCG launches queued behind the device-side convergence flag return at once (~4 us) and
+ * would flatter an average; a launch counts when it lasted >= 25 % of the longest launch of its category */
+int i3d_timing_get_work(i3d_context* ctx, double* ms /*[I3D_K_COUNT]*/, int64_t* launches /*[I3D_K_COUNT]*/);
 const char* i3d_kernel_name(int32_t k);
 /* sizes of the last assembled problem: active voxels, Eg/Er/Es/Ea rows, free parameters */
 int i3d_problem_sizes(i3d_context* ctx, int64_t out[6]);

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libintrinsic3d_hip.so")
 
-K_NAMES = ["classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh"]
+K_NAMES = ["classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh", "eg_aux"]
 
 
 class OptimizerConfig(C.Structure):
@@ -68,7 +68,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_write_intrinsics", "i3d_read_intrinsics", "i3d_config_load_yaml",
            "i3d_extract_mesh", "i3d_get_mesh", "i3d_export_mesh_ply", "i3d_write_ply", "i3d_mc_tables",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
-           "i3d_timing_enable", "i3d_timing_get", "i3d_kernel_name", "i3d_problem_sizes",
+           "i3d_timing_enable", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
            "i3d_debug_normal_eq", "i3d_debug_jtj_apply"]
 
@@ -112,6 +112,7 @@ def load():
     L.i3d_shard_vec_index.restype = i32; L.i3d_shard_vec_index.argtypes = [i32, i32, i32]
     L.i3d_timing_enable.restype = i32; L.i3d_timing_enable.argtypes = [vp, i32]
     L.i3d_timing_get.restype = i32; L.i3d_timing_get.argtypes = [vp, vp, vp, i32]
+    L.i3d_timing_get_work.restype = i32; L.i3d_timing_get_work.argtypes = [vp, vp, vp]
     L.i3d_kernel_name.restype = C.c_char_p; L.i3d_kernel_name.argtypes = [i32]
     L.i3d_problem_sizes.restype = i32; L.i3d_problem_sizes.argtypes = [vp, vp]
     L.i3d_debug_assemble.restype = i32; L.i3d_debug_assemble.argtypes = [vp, C.POINTER(OptimizerConfig), i32, C.POINTER(i32)]
@@ -343,6 +344,12 @@ class Context:
     # ---- measurement ---------------------------------------------------------------------------------------
     def timing_enable(self, on=True):
         self._check(self.L.i3d_timing_enable(self.h, 1 if on else 0), "i3d_timing_enable")
+
+    def timing_get_work(self):
+        """like timing_get (no reset), restricted to launches that did work (>= 25 % of the category's longest launch)"""
+        ms = np.zeros(len(K_NAMES)); n = np.zeros(len(K_NAMES), np.int64)
+        self._check(self.L.i3d_timing_get_work(self.h, _p(ms), _p(n)), "i3d_timing_get_work")
+        return {k: (ms[i], int(n[i])) for i, k in enumerate(K_NAMES)}
 
     def timing_get(self, reset=True):
         ms = np.zeros(len(K_NAMES)); n = np.zeros(len(K_NAMES), np.int64)

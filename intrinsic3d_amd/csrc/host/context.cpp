@@ -41,7 +41,7 @@ void timing_flush(i3d_context* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->timing.pending) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->timing.ms[p.cat] += ms; c->timing.launches[p.cat] += 1; }
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->timing.ms[p.cat] += ms; c->timing.launches[p.cat] += 1; c->timing.each[p.cat].push_back(ms); }
         c->timing.pool.push_back(p.a); c->timing.pool.push_back(p.b);
     }
     c->timing.pending.clear();
@@ -331,11 +331,22 @@ int i3d_timing_get(i3d_context* c, double* ms, int64_t* launches, int32_t reset)
     if (!c) return I3D_ERR_INVALID_ARGUMENT;
     timing_flush(c);
     for (int i = 0; i < I3D_K_COUNT; ++i) { if (ms) ms[i] = c->timing.ms[i]; if (launches) launches[i] = c->timing.launches[i]; }
-    if (reset) for (int i = 0; i < I3D_K_COUNT; ++i) { c->timing.ms[i] = 0; c->timing.launches[i] = 0; }
+    if (reset) for (int i = 0; i < I3D_K_COUNT; ++i) { c->timing.ms[i] = 0; c->timing.launches[i] = 0; c->timing.each[i].clear(); }
+    return I3D_OK;
+}
+int i3d_timing_get_work(i3d_context* c, double* ms, int64_t* launches) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    timing_flush(c);
+    for (int i = 0; i < I3D_K_COUNT; ++i) {
+        float mx = 0.0f; for (float v : c->timing.each[i]) mx = std::max(mx, v);
+        double s = 0.0; int64_t n = 0;
+        for (float v : c->timing.each[i]) if (v >= 0.25f * mx) { s += v; ++n; }
+        if (ms) ms[i] = s; if (launches) launches[i] = n;
+    }
     return I3D_OK;
 }
 const char* i3d_kernel_name(int32_t k) {
-    static const char* names[I3D_K_COUNT] = {"classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh"};
+    static const char* names[I3D_K_COUNT] = {"classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh", "eg_aux"};
     return (k >= 0 && k < I3D_K_COUNT) ? names[k] : "?";
 }
 int i3d_problem_sizes(i3d_context* c, int64_t out[6]) { if (!c || !out) return I3D_ERR_INVALID_ARGUMENT; for (int i = 0; i < 6; ++i) out[i] = c->last_sizes[i]; return I3D_OK; }

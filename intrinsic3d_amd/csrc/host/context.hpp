@@ -33,6 +33,7 @@ struct Timing {
     bool on = false;
     double ms[I3D_K_COUNT] = {0};
     long long launches[I3D_K_COUNT] = {0};
+    std::vector<float> each[I3D_K_COUNT];          // every launch duration (for the work-only average)
     struct Pending { hipEvent_t a, b; int cat; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;

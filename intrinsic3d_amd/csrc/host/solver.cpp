@@ -145,7 +145,7 @@ static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const flo
     PassBuffers b{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
     CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
     if (mode == PASS_COLNORM) CTX_HIP(c, hipMemsetAsync(c->d_blocks.p, 0, sizeof(double) * (21 * (size_t)c->K + 25), s));
-    { TimedScope t(c, I3D_K_EG_PASS); launch_eg_pass(s, mode, g, r, p, u, b, nullptr); }
+    { TimedScope t(c, mode == PASS_JTJP ? I3D_K_EG_PASS : I3D_K_EG_AUX); launch_eg_pass(s, mode, g, r, p, u, b, nullptr); }
     { TimedScope t(c, I3D_K_GATHER); launch_gather(s, mode, r, b, out); }
     { int rc = allreduce(c, c->d_shared.p, (size_t)L.NS); if (rc) return rc; }
     if (mode == PASS_COLNORM) { int rc = allreduce(c, c->d_blocks.p, 21 * (size_t)c->K + 25); if (rc) return rc; }
