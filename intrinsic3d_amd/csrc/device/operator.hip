@@ -301,6 +301,160 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
     }
 }
 
+// ---- the PCG operator pass: k_eg_pass<PASS_JTJP> specialised for memory-level parallelism --------------------------------------
+// Same arithmetic as k_eg_pass<PASS_JTJP>.  Differences: the 14 operator-input values of the lane's voxel are parked in LDS instead of
+// registers, which makes room for TWO row blocks in flight per lane: the loads of slot k+1 are issued before slot k is consumed.
+// (The pass is bound by memory round trips: 16 / 12 / 8 waves per CU run 0.42 / 0.46 / 0.56 ms; a second row in flight per wave acts
+// like twice the waves without the registers for them.)
+__global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, OptParams p, const float* __restrict__ u, PassBuffers b,
+                                                        int reps, int tiles_per_block, const PcgState* __restrict__ state) {
+    if (state && state->done) return;
+    extern __shared__ float lds[];        // [reps][rs] pose accumulators | [9] | camera part of u [6K+9] | uv [14][EG_THREADS]
+    const int K = p.K; const size_t Acap = r.Acap;
+    const int nshared = 6 * K + 9;
+    const int rs = (6 * K) | 1;
+    const int nacc = reps * rs + 9;
+    for (int i = threadIdx.x; i < nacc; i += EG_THREADS) lds[i] = 0.0f;
+    float* const upose = lds + nacc;
+    float* const uvl = upose + nshared + threadIdx.x;                    // this lane's column of the [14][EG_THREADS] staging
+    const size_t tail = (size_t)r.world * 2 * (size_t)r.chunk;
+    const int chunk = r.chunk;
+    for (int i = threadIdx.x; i < nshared; i += EG_THREADS) upose[i] = u[tail + i];
+    __syncthreads();
+    float* const cam_acc = lds + reps * rs;
+    float* const pose_acc = lds + (threadIdx.x & (reps - 1)) * rs;
+    float* const wave_acc = lds + ((threadIdx.x >> 6) & (reps - 1)) * rs;
+    float cam9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
+    const float tw0 = (float)p.type_w[0];
+    const int nC = r.nC;
+    const int ntiles = (nC + EG_THREADS - 1) / EG_THREADS;
+    const int tile0 = blockIdx.x * tiles_per_block;
+    const float* const ui = upose + 6 * K;
+
+    for (int tile = tile0; tile < tile0 + tiles_per_block && tile < ntiles; ++tile) {
+        const int ci = tile * EG_THREADS + threadIdx.x;
+        const bool in = ci < nC;
+        const int a = in ? (r.clist ? r.clist[ci] : ci) : 0;
+        const bool owned = in && a >= r.own0 && a < r.own1;
+        const uint8_t fl = in ? r.aflags[a] : 0;
+        const int nr = (in && (fl & F_ACTIVE)) ? (int)r.nrows[a] : 0;
+        int nr_max = nr;
+        for (int o = 32; o > 0; o >>= 1) nr_max = max(nr_max, __shfl_xor(nr_max, o, 64));
+        const size_t ac = in ? (size_t)a : 0;
+        // first row block on its way before anything else of the tile is touched
+        float4 rwA[8], rwB[8];
+        if (nr_max > 0) { const float4* __restrict__ row = r.rows + row_index(ac, 0, 0, r.slots);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+        // operator input at the 14 stencil unknowns of the voxel -> LDS (0 where the neighbour is not in the list = fixed parameter)
+        if (in) {
+#pragma unroll
+            for (int c = 0; c < P_VOX; ++c) {
+                const int nb = slot_fwd_nbr(c);
+                const int la = nb < 0 ? a : r.anbr[(size_t)nb * Acap + a];
+                uvl[c * EG_THREADS] = la >= 0 ? u[c < 10 ? vec_sdf(la, chunk) : vec_alb(la, chunk)] : 0.0f;
+            }
+        }
+        if (nr_max > 1) { const float4* __restrict__ row = r.rows + row_index(ac, 1, 0, r.slots);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+        // ---- regulariser rows: tr (Er), ts (Es, Jacobian folded in), ta[6] (Ea).  They do not depend on the Eg rows: computed HERE, while
+        //      the first two row blocks are in flight, so their index / vector gathers cost no round trip of their own ----
+        if (in) {
+            const uint8_t rf = (fl & F_ACTIVE) ? r.regflags[a] : 0;
+            // the +x,+y,+z ring values are already staged (sdf slots 6,1,4 / albedo slots 11,12,13; 0 when outside the list); only -x,-y,-z are fetched
+            const float us = uvl[0], ua = uvl[10 * EG_THREADS];
+            float rs_[6], ra_[6];
+            rs_[0] = uvl[6 * EG_THREADS]; rs_[2] = uvl[1 * EG_THREADS]; rs_[4] = uvl[4 * EG_THREADS];
+            ra_[0] = uvl[11 * EG_THREADS]; ra_[2] = uvl[12 * EG_THREADS]; ra_[4] = uvl[13 * EG_THREADS];
+#pragma unroll
+            for (int q = 1; q < 6; q += 2) {
+                const int la = (rf || (fl & F_ACTIVE)) ? r.anbr[(size_t)q * Acap + a] : -1;
+                rs_[q] = la >= 0 ? u[vec_sdf(la, chunk)] : 0.0f; ra_[q] = la >= 0 ? u[vec_alb(la, chunk)] : 0.0f;
+            }
+            float tr = 0.0f, ts = 0.0f;
+            if (rf & 1) tr = (float)p.type_w[1] * (((((((-6.0f * us) + rs_[0]) + rs_[1]) + rs_[2]) + rs_[3]) + rs_[4]) + rs_[5]);
+            if ((rf & 2) && (rf & 4)) ts = (float)p.type_w[2] * us;
+            b.treg[a] = tr; b.treg[Acap + a] = ts;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                const float w = (fl & F_ACTIVE) ? r.ea_w[(size_t)d * Acap + a] : 0.0f;
+                b.treg[(size_t)(2 + d) * Acap + a] = (w != 0.0f) ? w * (float)p.type_w[3] * (ua - ra_[d]) : 0.0f;
+            }
+        }
+        float acc[P_VOX];
+#pragma unroll
+        for (int c = 0; c < P_VOX; ++c) acc[c] = 0.0f;
+
+        auto consume = [&](const float4 (&rw)[8], int k) {
+            const float4 m = rw[7];
+            float pv[6]; int fsel = 0; bool pvalid = false;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pv[i] = 0.0f;
+            if (k < nr && m.x != 0.0f) {
+                const float rho = m.x * tw0;
+                const int f = __float_as_int(m.z) & ~ROW_FREE_BIT;
+                float J[P_TOTAL];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { J[4 * q] = rw[q].x; J[4 * q + 1] = rw[q].y; J[4 * q + 2] = rw[q].z; J[4 * q + 3] = rw[q].w; }
+                J[28] = m.w;
+                float d = 0.0f;
+#pragma unroll
+                for (int c = 0; c < P_VOX; ++c) d += J[c] * uvl[c * EG_THREADS];
+                const float* up = upose + 6 * f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d += J[P_POSE + i] * up[i];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) d += J[P_INTR + i] * ui[i];
+                const float t = rho * d;
+#pragma unroll
+                for (int c = 0; c < P_VOX; ++c) acc[c] += J[c] * t;
+                if (!p.fix_poses && owned) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pv[i] = J[P_POSE + i] * t;
+                    fsel = f; pvalid = true;
+                }
+                if (owned) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) cam9[i] += J[P_INTR + i] * t;
+                }
+            }
+            wave_accumulate<6>(pvalid, fsel, pv, pose_acc, wave_acc, 6);
+        };
+        for (int k = 0; k < nr_max; k += 2) {                 // slot k is in rwA, slot k+1 (if any) in rwB; a buffer is refilled as soon as it is consumed
+            consume(rwA, k);
+            if (k + 2 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 2, 0, r.slots);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+            if (k + 1 < nr_max) {
+                consume(rwB, k + 1);
+                if (k + 3 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 3, 0, r.slots);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+            }
+        }
+        if (in) {
+#pragma unroll
+            for (int c = 0; c < P_VOX; ++c) b.C[(size_t)c * Acap + a] = acc[c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        float v = cam9[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0.0f) atomicAdd(&cam_acc[i], v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nshared; i += EG_THREADS) {
+        float v;
+        if (i < 6 * K) { v = 0.0f; for (int q = 0; q < reps; ++q) v += lds[q * rs + i]; }
+        else v = cam_acc[i - 6 * K];
+        if (v != 0.0f) atomicAdd(&b.shared[i], (double)v);
+    }
+}
+
 void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u, PassBuffers b, const PcgState* state) {
     if (r.nC <= 0) return;
     static int num_cu = 0;
@@ -318,8 +472,11 @@ void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptPar
         (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_GRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rep);
         k_eg_pass<PASS_GRAD><<<blocks, EG_THREADS, lds_rep, st>>>(g, r, p, u, b, reps, tiles_per_block, state);
     } else if (mode == PASS_JTJP) {
-        (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_JTJP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rep);
-        k_eg_pass<PASS_JTJP><<<blocks, EG_THREADS, lds_rep, st>>>(g, r, p, u, b, reps, tiles_per_block, state);
+        int rj = 8;                                        // replicas only serve the rare > 3-keyframe fallback; LDS goes to the uv staging
+        while (rj > 1 && (size_t)(rj * rs + 9 + nshared + P_VOX * EG_THREADS) * sizeof(float) > 150 * 1024) rj >>= 1;
+        const size_t lds_j = (size_t)(rj * rs + 9 + nshared + P_VOX * EG_THREADS) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)k_eg_jtjp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_j);
+        k_eg_jtjp<<<blocks, EG_THREADS, lds_j, st>>>(g, r, p, u, b, rj, tiles_per_block, state);
     } else {
         int reps2 = 32;
         const int rs2 = (21 * p.K) | 1;
