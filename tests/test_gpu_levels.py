@@ -172,3 +172,46 @@ def test_keyframe_pyramids_on_device_bit_exact(oracle):
                 assert np.array_equal(lum, lum_ref), (f, l, np.abs(lum - lum_ref).max())
                 assert np.array_equal(d, dep_ref), (f, l)
                 lum_ref = oracle.pyr_down(lum_ref); dep_ref = oracle.depth_down(dep_ref); w //= 2; h //= 2
+
+
+def test_refine_sharded_ranks_match_single_rank(oracle, scene):
+    """the whole refine schedule under the SPMD path (2 ranks simulated by 2 host threads on one GPU): level transitions, lighting and
+    recolourisation run replicated, the optimisation sharded; every rank must end with the single-rank grid"""
+    import threading
+    from intrinsic3d_amd import binding
+    sc = scene
+    ocfg = helpers.oracle_cfg(oracle, 0.0, iterations=1, lm_steps=20, fix_distortion=1, cg_fixed_iterations=8)
+    rc = binding.RefineConfig(num_grid_levels=2, num_rgbd_levels=2, thin_shell_factor=2.0, thin_shell_factor_final=1.0, clear_distant_voxels=1,
+                              occlusion_distance=0.02, num_observations=5, subvolume_size_sh=0.05, sh_lambda_reg=10.0)
+
+    def make():
+        c = binding.Context(0)
+        c.set_grid_from_tsdf_records(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        c.set_frames(sc["frames"], sc["levels"]); c.set_camera(sc["intr"], sc["dist"], sc["poses"])
+        return c
+    ref = make(); ref.refine(rc, helpers.gpu_cfg(ocfg)); want = ref.export_grid(); wcam = ref.get_camera(); ref.close()
+    L = binding.load(); W = 2
+    shared = L.i3d_comm_sim_create(W)
+    ctxs = [make() for _ in range(W)]
+    for r, c in enumerate(ctxs):
+        c.comm_init_sim(shared, r)
+    err = [None] * W
+
+    def run(r):
+        try:
+            ctxs[r].refine(rc, helpers.gpu_cfg(ocfg))
+        except Exception as e:
+            err[r] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    [t.start() for t in th]; [t.join(timeout=300) for t in th]
+    assert not any(t.is_alive() for t in th), "sharded refine hung"
+    assert all(e is None for e in err), err
+    for c in ctxs:
+        got = c.export_grid(); cam = c.get_camera()
+        assert np.array_equal(got["keys"], want["keys"]) and np.array_equal(got["weight"], want["weight"])
+        smax = np.abs(want["sdf_refined"]).max()
+        assert np.abs(got["sdf_refined"] - want["sdf_refined"]).max() <= 1e-4 * smax
+        assert np.abs(got["albedo"] - want["albedo"]).max() <= 1e-4
+        np.testing.assert_allclose(cam[0], wcam[0], rtol=1e-5); np.testing.assert_allclose(cam[2], wcam[2], rtol=1e-4, atol=1e-6)
+        c.close()
+    L.i3d_comm_sim_destroy(shared)
