@@ -2,23 +2,25 @@
 //
 // Replaces Ceres' BlockSparseMatrix Jacobian + CgnrLinearOperator + BlockJacobiPreconditioner + ConjugateGradientsSolver
 // [Ceres 2.1.0, not in /root/reference; selected at nls_solver.cpp:307] for this problem's FIXED row structure:
-//   * Eg rows are stored: 29 fp32 partials as 7 float4 planes + 1 float plane per slot ([slot][plane][entry]) so a wave reads
-//     1 KB per load instruction; Er / Es / Ea rows have constant coefficients (volumetric_regularizer.h:59-72,
+//   * Eg rows are stored wave-tiled (common.hpp row_index: [tile of 64 entries][slot][8 float4 planes][lane], 128 B per row), so a wave
+//     reads one contiguous 8 KB block per slot; Er / Es / Ea rows have constant coefficients (volumetric_regularizer.h:59-72,
 //     surface_stab_regularizer.h:59-66, albedo_regularizer.h:59-66) and are never stored;
 //   * column indices are implicit: a row's voxel columns are the centre voxel's neighbour-table entries;
 //   * all solver vectors live in WORK-LIST space (entries = voxels that own rows or unknowns): [sdf A | albedo A | poses 6K |
 //     intrinsics 4 | distortion 5]; a neighbour outside the list is a fixed parameter and contributes 0.
 //
-// J^T is a GATHER, not a scatter: pass 1 (k_eg_pass, one lane per entry) reads the entry's rows ONCE, forms t = W (J u) per
+// J^T is a GATHER, not a scatter: pass 1 (k_eg_jtjp for the PCG operator, k_eg_pass<GRAD|COLNORM> for the gradient and the column
+// norms; one lane per entry) reads the entry's rows ONCE, forms t = W (J u) per
 // row and immediately the 14 per-voxel column sums C[c] = sum_k J[c][k] t_k (all rows of a voxel share the same 14 voxel
 // columns) into a staging plane; pass 2 (k_gather) pulls the 10+4 staged sums of the entries whose stencil contains it plus
 // the regulariser terms, applies the Jacobi scaling / LM diagonal and accumulates p.q.  No fp32 atomics on voxel unknowns.
-// The 6K+9 camera columns are reduced through LDS atomics (poses) / wave shuffles (intrinsics, distortion) -> one fp64
-// atomic per block and entry.
+// The 6K+9 camera columns: poses are summed across the wave per distinct keyframe (slots are keyframe-ordered) and one lane issues the
+// LDS atomics; intrinsics / distortion accumulate in registers; each workgroup then adds its totals with one fp64 atomic per entry.
+// Every other fp64 reduction goes through per-workgroup partials (reduce_device.hpp) — no same-address atomics from thousands of workgroups.
 //
-// The PCG scalars (rho, p.q, alpha, beta, Q) never leave the device inside a solve: 1-thread kernels turn the fp64 partial
-// sums into alpha/beta/termination flags, every vector kernel starts with `if (state->done) return`, and the host only polls
-// the state one iteration behind (no pipeline bubble).
+// The PCG scalars (rho, p.q, alpha, beta, Q) never leave the device inside a solve: the two camera-tail kernels turn the fp64 partial
+// sums into alpha / beta / termination flags, every kernel of the iteration starts with `if (state->done) return`, and the host only
+// polls the state one pass behind (no pipeline bubble).
 #include "kernels.hpp"
 #include "reduce_device.hpp"
 #include <cstdlib>
@@ -44,9 +46,8 @@ void launch_reduce_partials(hipStream_t st, const double* partials, int nblk, in
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------------
 // Persistent 1024-thread workgroups (one per CU, 16 waves): each walks a contiguous chunk of 1024-entry tiles.  The pose
-// columns are accumulated with LDS atomics; lanes of a wave mostly see the same few keyframes, so same-address atomics are
-// spread over `reps` replicas of the [6K] accumulator (lane % reps) — with 1 workgroup per CU the replicas can take most of the
-// 160 KB LDS (reps = 32 at K = 200: <= 2-way conflicts instead of 64-way).  LDS is zeroed / flushed once per workgroup.
+// columns are accumulated in LDS: aggregated per wave and keyframe (wave_accumulate), with `reps` replicas of the [6K] accumulator
+// (odd stride: different banks) for the rare slots that hold more than 3 keyframes.  LDS is zeroed / flushed once per workgroup.
 constexpr int EG_THREADS = 1024;
 
 // sum of v over the 64 lanes of the wave, returned to every lane: 4 DPP steps inside each row of 16 lanes (pure VALU, no LDS
