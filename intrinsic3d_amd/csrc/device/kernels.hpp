@@ -63,7 +63,8 @@ int  launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p
                      float* z, double* partials /*[blocks][4]*/, PcgState* state);                               // returns #partials
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state);
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
-                       const float* D2, float* z, const double* partials, int nblk, PcgState* state);           // camera tail + Q-test + rho, beta
+                       const float* D2, float* z, const double* partials, int nblk, PcgState* state,           // camera tail + Q-test + rho, beta;
+                       double* shared_zero, int nzero, int* host_flags, int seq);                              // zeroes the camera accumulator, publishes (seq, done) to pinned memory
 void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state);                  // p = z + beta p, u = S p
 void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
                        float* q, const float* S, const float* D2, const float* v, PcgState* state);                                                          // camera tail of q, p.q, alpha

@@ -689,8 +689,13 @@ __global__ void k_pcg_tail_x(size_t to, int NS, const float* __restrict__ p, flo
 
 __global__ void __launch_bounds__(1024) k_pcg_tail_a(int mode, size_t to, int K, const float* __restrict__ Mblk, const float* __restrict__ p, const float* __restrict__ q,
                                                     float* __restrict__ x, float* __restrict__ r, const float* __restrict__ b, const float* __restrict__ D2,
-                                                    float* __restrict__ z, const double* __restrict__ partials, int nblk, PcgState* st) {
-    if (st->done) return;
+                                                    float* __restrict__ z, const double* __restrict__ partials, int nblk, PcgState* st,
+                                                    double* __restrict__ shared_zero, int nzero, int* host_flags, int seq) {
+    // (seq, done) goes to a 2-slot ring in pinned host memory: the host polls it instead of queueing a copy + event per pass
+    auto publish = [&]() { if (host_flags) { __hip_atomic_store(&host_flags[2 * (seq & 1) + 1], st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                             __hip_atomic_store(&host_flags[2 * (seq & 1)], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); } };
+    if (st->done) { if (threadIdx.x == 0) publish(); return; }
+    for (int i = threadIdx.x; i < nzero; i += blockDim.x) shared_zero[i] = 0.0;      // camera block + p.q slot of the pass that starts here
     __shared__ double red[16][4];
     const int NS = 6 * K + 9;
     const float alpha = (float)st->alpha;
@@ -728,24 +733,28 @@ __global__ void __launch_bounds__(1024) k_pcg_tail_a(int mode, size_t to, int K,
     double tot[4];
     for (int k = 0; k < 4; ++k) { double t = st->acc[k]; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][k]; tot[k] = t; st->acc[k] = 0.0; }
     st->pq = 0.0;
+    bool stop = false;
     if (mode != STEP_INIT) {                                         // end of iteration it: quadratic-model termination (eta = 0.1)
         st->xbr = tot[1]; st->xr = tot[2]; st->d2xx = tot[3];
         const int it = st->it + 1; st->it = it;
         const double Q1 = -tot[1]; st->Q1 = Q1;
-        if (st->fixed_iterations >= 0) { st->Q0 = Q1; if (it >= st->fixed_iterations) { st->done = 1; return; } }
+        if (st->fixed_iterations >= 0) { st->Q0 = Q1; if (it >= st->fixed_iterations) { st->done = 1; stop = true; } }
         else {
             const double zeta = (double)it * (Q1 - st->Q0) / Q1;
-            if (zeta < 0.1) { st->done = 1; return; }
-            st->Q0 = Q1;
-            if (it >= st->max_iterations) { st->done = 1; return; }
+            if (zeta < 0.1) { st->done = 1; stop = true; }
+            else { st->Q0 = Q1; if (it >= st->max_iterations) { st->done = 1; stop = true; } }
         }
     }
-    // start of the next iteration: rho = r.z, beta
-    const double rho = tot[0];
-    if (rho == 0.0 || isinf(rho) || isnan(rho)) { st->done = 2; return; }
-    if (st->it > 0) { const double beta = rho / st->rho; if (beta == 0.0 || isinf(beta) || isnan(beta)) { st->done = 2; return; } st->beta = beta; }
-    else st->beta = 0.0;
-    st->last_rho = st->rho; st->rho = rho;
+    if (!stop) {                                                     // start of the next iteration: rho = r.z, beta
+        const double rho = tot[0];
+        if (rho == 0.0 || isinf(rho) || isnan(rho)) { st->done = 2; stop = true; }
+        else {
+            if (st->it > 0) { const double beta = rho / st->rho; if (beta == 0.0 || isinf(beta) || isnan(beta)) { st->done = 2; stop = true; } else st->beta = beta; }
+            else st->beta = 0.0;
+            if (!stop) { st->last_rho = st->rho; st->rho = rho; }
+        }
+    }
+    publish();
 }
 
 // p = z + beta p ; u = S p
@@ -819,8 +828,8 @@ int launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p,
 }
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state) { k_pcg_tail_x<<<1, 256, 0, st>>>(tail_off, 6 * K + 9, p, x, state); }
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
-                       const float* D2, float* z, const double* partials, int nblk, PcgState* state) {
-    k_pcg_tail_a<<<1, 1024, 0, st>>>(mode, tail_off, K, Minv_blocks, p, q, x, r, b, D2, z, partials, nblk, state);
+                       const float* D2, float* z, const double* partials, int nblk, PcgState* state, double* shared_zero, int nzero, int* host_flags, int seq) {
+    k_pcg_tail_a<<<1, 1024, 0, st>>>(mode, tail_off, K, Minv_blocks, p, q, x, r, b, D2, z, partials, nblk, state, shared_zero, nzero, host_flags, seq);
 }
 void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state) {
     if (n > 0) k_pcg_direction<<<step_blocks(n >> 2), 256, 0, st>>>(n, z, p, S, u, state);

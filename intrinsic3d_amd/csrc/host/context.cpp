@@ -168,6 +168,7 @@ void i3d_destroy(i3d_context* c) {
     for (auto e : c->timing.pool) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_pcg) (void)hipHostFree(c->h_pcg);
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
     for (auto e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
     delete c->comm;
     if (c->stream) (void)hipStreamDestroy(c->stream);

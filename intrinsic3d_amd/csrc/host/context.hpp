@@ -84,6 +84,7 @@ struct i3d_context {
     i3d::DevBuf<float> Minv_blocks;
     i3d::DevBuf<double> d_shared, d_blocks, d_scal, d_xshared, d_xcshared;
     i3d::DevBuf<i3d::PcgState> d_pcg; i3d::DevBuf<double> d_partials; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};
+    int* h_flags = nullptr; int* d_flags = nullptr; int pcg_seq = 0;      // pinned (seq, done) ring written by k_pcg_tail_a, polled by the host
     double* h_pinned = nullptr; size_t h_pinned_n = 0;
 
     i3d::OptParams last_params; bool assembled = false;

@@ -53,6 +53,9 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->d_partials.alloc((Acap / 256 + 2048) * 9));       // per-workgroup partial sums of the fp64 reductions
     if (!c->h_pcg) CTX_HIP(c, hipHostMalloc((void**)&c->h_pcg, 2 * sizeof(PcgState), hipHostMallocDefault));
     for (auto& e : c->pcg_ev) if (!e) CTX_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!c->h_flags) { CTX_HIP(c, hipHostMalloc((void**)&c->h_flags, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+                       for (int i = 0; i < 16; ++i) c->h_flags[i] = -1;
+                       CTX_HIP(c, hipHostGetDevicePointer((void**)&c->d_flags, c->h_flags, 0)); }
     return ensure_pinned(c, 64 + (size_t)27 * c->K + 64);
 }
 
@@ -230,8 +233,8 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     // fp64 partial sums: [0, 4*2048) slice sums of k_pcg_step, then the p.q partials of k_gather
     double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048;
     int n_pq = 0, n_step = 0;
-    auto rows_apply = [&](const float* v, float* out, bool with_dot) -> int {
-        CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
+    auto rows_apply = [&](const float* v, float* out, bool with_dot, bool zero_first) -> int {
+        if (zero_first) CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));      // (the pass boundary kernel zeroes it otherwise)
         { TimedScope t(c, I3D_K_EG_PASS); launch_eg_pass(s, PASS_JTJP, g, r, p, c->v_u.p, pb, st); }
         { TimedScope t(c, I3D_K_GATHER); n_pq = launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, with_dot ? pq_part : nullptr, st); }
         if (!multi) return I3D_OK;
@@ -241,6 +244,7 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     { TimedScope t(c, I3D_K_VECTOR);
       n_step = launch_pcg_step(s, 0 /*init*/, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st); }
     int tail_mode = 0;
+    const int seq0 = c->pcg_seq;               // pass numbers are unique across solves: a stale ring entry can never match
     int it = 1;
     for (;; ++it) {
         // iteration boundary.  Sharded: ONE message pair — the 4 slice sums (r.z, x.(b+r), x.r, sum D2 x^2) and the slices of z
@@ -248,14 +252,11 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
                      int rc = allreduce_allgather(c, st->acc, 4, c->v_z.p); if (rc) return rc; }
         { TimedScope t(c, I3D_K_VECTOR);
           launch_pcg_tail_a(s, tail_mode, to, K, c->Minv_blocks.p, c->v_p.p, tail_mode == 3 ? c->v_tmp.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_z.p,
-                            step_part, n_step, st); }
-        const int slot = it & 1;
-        CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[slot], st, sizeof(PcgState), hipMemcpyDeviceToHost, s));
-        CTX_HIP(c, hipEventRecord(c->pcg_ev[slot], s));
+                            step_part, n_step, st, c->d_shared.p, L.NS + 1, c->d_flags, seq0 + it); }
         { TimedScope t(c, I3D_K_VECTOR);        // p is kept replicated (z was all-gathered), so u = S p needs no exchange
           if (!multi) launch_pcg_direction(s, sn + L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, st);
           else launch_pcg_direction(s, (int)L.NP, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, st); }
-        { int rc = rows_apply(c->v_p.p, c->v_q.p, true); if (rc) return rc; }
+        { int rc = rows_apply(c->v_p.p, c->v_q.p, true, false); if (rc) return rc; }
         { TimedScope t(c, I3D_K_VECTOR); launch_pcg_tail_b(s, to, K, p, c->d_shared.p, pq_slot, pq_part, n_pq, c->v_q.p, c->v_S.p, c->v_D2.p, c->v_p.p, st); }
         const bool reset = (it % 10 == 0);                                       // residual_reset_period
         if (!reset) {
@@ -268,18 +269,23 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
               launch_pcg_tail_x(s, to, K, c->v_p.p, c->v_x.p, st);
               launch_mul(s, sn, c->v_S.p + so, c->v_x.p + so, c->v_u.p + so); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
             { int rc = allgather(c, c->v_u.p); if (rc) return rc; }
-            { int rc = rows_apply(c->v_x.p, c->v_tmp.p, false); if (rc) return rc; }
+            { int rc = rows_apply(c->v_x.p, c->v_tmp.p, false, true); if (rc) return rc; }
             { TimedScope t(c, I3D_K_VECTOR);
               launch_shared_finalize(s, to, K, p, c->d_shared.p, c->v_tmp.p, true, c->v_S.p, c->v_D2.p, c->v_x.p, nullptr, st);
               n_step = launch_pcg_step(s, 3, so, sn, c->v_p.p, c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st); }
             tail_mode = 3;
         }
         if (it >= 2) {                                                           // look at the boundary of pass it-1 while pass it runs
-            CTX_HIP(c, hipEventSynchronize(c->pcg_ev[slot ^ 1]));
-            if (c->h_pcg[slot ^ 1].done) break;
+            const int want = seq0 + it - 1; volatile int* ring = c->h_flags + 2 * (want & 1);
+            const double t_wait = now_s();
+            while (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) {
+                if (now_s() - t_wait > 30.0) { CTX_HIP(c, hipStreamSynchronize(s)); if (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) return ctx_fail(c, I3D_ERR_HIP, "pcg_solve: the device stopped publishing its state"); }
+            }
+            if (__atomic_load_n((int*)&ring[1], __ATOMIC_ACQUIRE)) break;
         }
         if (it > 520) break;
     }
+    c->pcg_seq = seq0 + it + 1;
     CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[0], st, sizeof(PcgState), hipMemcpyDeviceToHost, s));
     CTX_HIP(c, hipStreamSynchronize(s));
     *final_state = c->h_pcg[0];                 // kernels after `done` were no-ops, so this is the terminal state
