@@ -207,6 +207,8 @@ def main():
     img_bytes = min(4.0 * args.frames * args.width * args.height, 256.0 * Rg)
     b_build = 68.0 * A + 132.0 * Rg + 36.0 * Rr + 12.0 * Rs + 16.0 * Ra + img_bytes
     b_egpass = 132.0 * Rg + (14 + 8 + 2) * 4.0 * A          # 29 partials + 16 B row record; staged sums, regulariser t-values, vector gather per voxel
+    if world > 1:                                           # a rank streams its own share of the rows (its halo rows are not counted: conservative)
+        b_build /= world; b_egpass /= world
     kernels = {}
     for name, bytes_per_launch in (("build", b_build), ("eg_pass", b_egpass)):
         ms, n = timing_work[name]
