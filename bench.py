@@ -221,7 +221,7 @@ def main():
     if dominant:
         k = kernels[dominant]
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant, Rg, A)}
+                    "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant, Rg, A) if world == 1 else None}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
