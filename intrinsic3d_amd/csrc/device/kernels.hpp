@@ -42,7 +42,8 @@ struct PassBuffers {
 };
 void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u /*[NP] or null*/, PassBuffers b, const PcgState* state);
 void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out /*[2A]*/);
-int  launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_partials, const PcgState* state);   // returns #partials
+int  launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_partials /* or, dot_atomic: the sum itself */,
+                        bool dot_atomic, const PcgState* state);   // returns #partials
 // dst[k] += sum_b partials[b*ncomp + k]: the second stage of every fp64 reduction (no same-address atomics from thousands of workgroups)
 void launch_reduce_partials(hipStream_t st, const double* partials, int nblk, int ncomp, double* dst, const PcgState* state);
 void launch_shared_finalize(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, float* out /*[NP]*/, bool tail, const float* S, const float* D2,

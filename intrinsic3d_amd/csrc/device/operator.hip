@@ -492,7 +492,7 @@ void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptPar
 // TAIL: out = S*acc + D2*v (the CGNR operator applied to v) and, if dot_out, dot_out += v.out
 template <bool SQUARED, bool TAIL>
 __global__ void __launch_bounds__(256) k_gather(RowView r, PassBuffers b, float* __restrict__ out, const float* __restrict__ S,
-                                                const float* __restrict__ D2, const float* __restrict__ v, double* dot_out,
+                                                const float* __restrict__ D2, const float* __restrict__ v, double* dot_out, int dot_atomic,
                                                 const PcgState* __restrict__ state) {
     if (state && state->done) return;
     const int a = r.own0 + blockIdx.x * blockDim.x + threadIdx.x;       // owned range of this rank
@@ -544,20 +544,24 @@ __global__ void __launch_bounds__(256) k_gather(RowView r, PassBuffers b, float*
         }
         out[js] = osdf; out[ja] = oalb;
     }
-    if (TAIL && dot_out) block_partial_d(dotp, dot_out, 1, 0);      // per-workgroup partial of v.out (summed by k_pcg_tail_b / k_reduce_partials)
+    if (TAIL && dot_out) {
+        if (!dot_atomic) block_partial_d(dotp, dot_out, 1, 0);      // per-workgroup partial of v.out (summed by k_pcg_tail_b)
+        else { const double t = block_sum_d(dotp); if (threadIdx.x == 0 && t != 0.0) atomicAdd(dot_out, t); }     // sharded: ~1/world of the workgroups, no extra dispatch
+    }
 }
 void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out) {
     const int n = (r.own1 < r.A ? r.own1 : r.A) - r.own0;
     if (n <= 0) return;
     const int blocks = (n + 255) / 256;
-    if (mode == PASS_COLNORM) k_gather<true, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else k_gather<false, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (mode == PASS_COLNORM) k_gather<true, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+    else k_gather<false, false><<<blocks, 256, 0, st>>>(r, b, out, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
 }
-int launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_partials, const PcgState* state) {
+int launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_partials, bool dot_atomic,
+                       const PcgState* state) {
     const int n = (r.own1 < r.A ? r.own1 : r.A) - r.own0;
     if (n <= 0) return 0;
     const int blocks = (n + 255) / 256;
-    k_gather<false, true><<<blocks, 256, 0, st>>>(r, b, out, S, D2, v, dot_partials, state);
+    k_gather<false, true><<<blocks, 256, 0, st>>>(r, b, out, S, D2, v, dot_partials, dot_atomic ? 1 : 0, state);
     return blocks;                       // number of partials written (when dot_partials != nullptr)
 }
 
@@ -645,7 +649,7 @@ enum { STEP_INIT = 0, STEP_NORMAL = 1, STEP_XONLY = 2, STEP_RESET = 3 };
 template <int MODE>
 __global__ void __launch_bounds__(256) k_pcg_step(int n4, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x, float4* __restrict__ r,
                                                   const float4* __restrict__ b, const float4* __restrict__ D2, const float4* __restrict__ Minv, float4* __restrict__ z,
-                                                  double* __restrict__ partials, PcgState* state) {
+                                                  double* __restrict__ partials /* nullptr: add to state->acc directly (sharded) */, PcgState* state) {
     if (state->done) return;
     const float alpha = (float)state->alpha;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -677,7 +681,11 @@ __global__ void __launch_bounds__(256) k_pcg_step(int n4, const float4* __restri
         for (int k = 0; k < 4; ++k) s0 += (double)rv[k] * (double)zv[k];
     }
     if (MODE == STEP_XONLY) return;
-    block_partial_d(s0, partials, 4, 0); block_partial_d(s1, partials, 4, 1); block_partial_d(s2, partials, 4, 2); block_partial_d(s3, partials, 4, 3);
+    if (partials) { block_partial_d(s0, partials, 4, 0); block_partial_d(s1, partials, 4, 1); block_partial_d(s2, partials, 4, 2); block_partial_d(s3, partials, 4, 3); }
+    else {
+        const double t0 = block_sum_d(s0), t1 = block_sum_d(s1), t2 = block_sum_d(s2), t3 = block_sum_d(s3);
+        if (threadIdx.x == 0) { atomicAdd(&state->acc[0], t0); if (MODE != STEP_INIT) { atomicAdd(&state->acc[1], t1); atomicAdd(&state->acc[2], t2); atomicAdd(&state->acc[3], t3); } }
+    }
 }
 
 // camera tail, x only (residual-reset iterations: x is needed before r = b - A x can be formed)
@@ -824,7 +832,7 @@ int launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p,
         case STEP_XONLY:  k_pcg_step<STEP_XONLY><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
         default:          k_pcg_step<STEP_RESET><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
     }
-    return mode == STEP_XONLY ? 0 : step_blocks(n4);      // number of [4]-partials written
+    return (mode == STEP_XONLY || !partials) ? 0 : step_blocks(n4);      // number of [4]-partials written
 }
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state) { k_pcg_tail_x<<<1, 256, 0, st>>>(tail_off, 6 * K + 9, p, x, state); }
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,

@@ -236,20 +236,20 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     auto rows_apply = [&](const float* v, float* out, bool with_dot, bool zero_first) -> int {
         if (zero_first) CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));      // (the pass boundary kernel zeroes it otherwise)
         { TimedScope t(c, I3D_K_EG_PASS); launch_eg_pass(s, PASS_JTJP, g, r, p, c->v_u.p, pb, st); }
-        { TimedScope t(c, I3D_K_GATHER); n_pq = launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, with_dot ? pq_part : nullptr, st); }
+        // sharded: the rank's p.q partial is accumulated straight into the slot that rides with the camera block (few workgroups per rank)
+        { TimedScope t(c, I3D_K_GATHER); n_pq = launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, with_dot ? (multi ? pq_slot : pq_part) : nullptr, multi, st); }
         if (!multi) return I3D_OK;
-        if (with_dot) { launch_reduce_partials(s, pq_part, n_pq, 1, pq_slot, st); n_pq = 0; }      // the p.q partial rides with the camera block
+        n_pq = 0;
         return allreduce(c, c->d_shared.p, (size_t)L.NS + 1);
     };
     { TimedScope t(c, I3D_K_VECTOR);
-      n_step = launch_pcg_step(s, 0 /*init*/, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st); }
+      n_step = launch_pcg_step(s, 0 /*init*/, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, multi ? nullptr : step_part, st); }
     int tail_mode = 0;
     const int seq0 = c->pcg_seq;               // pass numbers are unique across solves: a stale ring entry can never match
     int it = 1;
     for (;; ++it) {
         // iteration boundary.  Sharded: ONE message pair — the 4 slice sums (r.z, x.(b+r), x.r, sum D2 x^2) and the slices of z
-        if (multi) { launch_reduce_partials(s, step_part, n_step, 4, st->acc, st); n_step = 0;
-                     int rc = allreduce_allgather(c, st->acc, 4, c->v_z.p); if (rc) return rc; }
+        if (multi) { int rc = allreduce_allgather(c, st->acc, 4, c->v_z.p); if (rc) return rc; }      // (sharded k_pcg_step adds into acc directly)
         { TimedScope t(c, I3D_K_VECTOR);
           launch_pcg_tail_a(s, tail_mode, to, K, c->Minv_blocks.p, c->v_p.p, tail_mode == 3 ? c->v_tmp.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_z.p,
                             step_part, n_step, st, c->d_shared.p, L.NS + 1, c->d_flags, seq0 + it); }
@@ -261,18 +261,18 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
         const bool reset = (it % 10 == 0);                                       // residual_reset_period
         if (!reset) {
             TimedScope t(c, I3D_K_VECTOR);
-            n_step = launch_pcg_step(s, 1, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st);
+            n_step = launch_pcg_step(s, 1, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, multi ? nullptr : step_part, st);
             tail_mode = 1;
         } else {                                                                 // r = b - A x instead of r -= alpha q
             { TimedScope t(c, I3D_K_VECTOR);
-              launch_pcg_step(s, 2, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st);
+              launch_pcg_step(s, 2, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, multi ? nullptr : step_part, st);
               launch_pcg_tail_x(s, to, K, c->v_p.p, c->v_x.p, st);
               launch_mul(s, sn, c->v_S.p + so, c->v_x.p + so, c->v_u.p + so); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
             { int rc = allgather(c, c->v_u.p); if (rc) return rc; }
             { int rc = rows_apply(c->v_x.p, c->v_tmp.p, false, true); if (rc) return rc; }
             { TimedScope t(c, I3D_K_VECTOR);
               launch_shared_finalize(s, to, K, p, c->d_shared.p, c->v_tmp.p, true, c->v_S.p, c->v_D2.p, c->v_x.p, nullptr, st);
-              n_step = launch_pcg_step(s, 3, so, sn, c->v_p.p, c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, step_part, st); }
+              n_step = launch_pcg_step(s, 3, so, sn, c->v_p.p, c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, multi ? nullptr : step_part, st); }
             tail_mode = 3;
         }
         if (it >= 2) {                                                           // look at the boundary of pass it-1 while pass it runs
