@@ -101,6 +101,8 @@ def load():
     L.i3d_get_voxel_sh.restype = i32; L.i3d_get_voxel_sh.argtypes = [vp, vp]
     L.i3d_optimizer_config_default.argtypes = [C.POINTER(OptimizerConfig)]
     L.i3d_optimize.restype = i32; L.i3d_optimize.argtypes = [vp, C.POINTER(OptimizerConfig), vp]
+    L.i3d_optimize_host.restype = i32
+    L.i3d_optimize_host.argtypes = [i32, C.POINTER(OptimizerConfig), C.POINTER(GridView), vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.i3d_estimate_sh.restype = i32
     L.i3d_estimate_sh.argtypes = [vp, f32, f64, f64, C.POINTER(i32), vp, vp, i32, C.POINTER(ShStats)]
     L.i3d_comm_unique_id.restype = i32; L.i3d_comm_unique_id.argtypes = [vp, C.POINTER(i32)]
@@ -490,3 +492,27 @@ def mc_tables():
     ntri = np.zeros(256, np.uint8); tri = np.zeros((256, 24), np.int8)
     mx = load().i3d_mc_tables(_p(ntri), _p(tri))
     return ntri, tri, mx
+
+
+def optimize_host(cfg, voxel_size, keys, sdf, sdf_refined, albedo, weight, color, frames, levels, intr, dist, poses, voxel_sh, device=0):
+    """i3d_optimize_host: the one-call form of Optimizer::optimize (host arrays in, unknowns written back in place).  Returns
+    (sdf_refined, albedo, intr, dist, poses, stats)."""
+    L = load()
+    keys = np.ascontiguousarray(keys, np.int32); sdf = np.ascontiguousarray(sdf, np.float64)
+    sr = np.array(sdf_refined, np.float64); al = np.array(albedo, np.float64)
+    w = np.ascontiguousarray(weight, np.float32); col = np.ascontiguousarray(color, np.uint8)
+    gv = GridView(keys.shape[0], float(voxel_size), float(np.float32(voxel_size) * np.float32(5.0)), _p(keys), _p(sdf), _p(sr), _p(al), _p(w), _p(col))
+    K = len(frames)
+    ws = np.array([frames[0]["lum"][l].shape[1] for l in range(levels)], np.int32); hs = np.array([frames[0]["lum"][l].shape[0] for l in range(levels)], np.int32)
+    arr_t = C.c_void_p * (K * levels); lum = arr_t(); dep = arr_t(); keep = []
+    for f in range(K):
+        for l in range(levels):
+            a = np.ascontiguousarray(frames[f]["lum"][l], np.float32); b = np.ascontiguousarray(frames[f]["depth"][l], np.float32); keep += [a, b]
+            lum[f * levels + l] = a.ctypes.data; dep[f * levels + l] = b.ctypes.data
+    i4 = np.array(intr, np.float64); d5 = np.array(dist, np.float64); p6 = np.array(poses, np.float64); sh = np.ascontiguousarray(voxel_sh, np.float64)
+    stats = (IterationStats * cfg.iterations)()
+    rc = L.i3d_optimize_host(int(device), C.byref(cfg), C.byref(gv), _p(sr), _p(al), K, int(levels), _p(ws), _p(hs), C.cast(lum, C.c_void_p), C.cast(dep, C.c_void_p),
+                             _p(i4), _p(d5), _p(p6), _p(sh), C.cast(stats, C.c_void_p))
+    if rc != 0:
+        raise I3DError(f"i3d_optimize_host failed ({rc})")
+    return sr, al, i4, d5, p6, list(stats)

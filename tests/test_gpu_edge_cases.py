@@ -113,3 +113,21 @@ def test_no_active_voxel_and_blind_keyframe(oracle):
     assert rc == 0
     _check(ref, ostats, out, gstats)
     assert np.array_equal(cam[2][1], poses[1]) and np.array_equal(ocam[2][1], poses[1])      # no row touches pose 1: the block never enters the problem
+
+
+def test_one_call_host_entry_point_matches_resident_path(oracle):
+    """i3d_optimize_host (the shim of INTEGRATION.md: host arrays in, unknowns written back) == the resident context path"""
+    from intrinsic3d_amd import binding
+    sc = helpers.small_scene(seed=12, radius_vox=9, K=4, width=96, height=72)
+    g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc)
+    cfg = helpers.gpu_cfg(helpers.oracle_cfg(oracle, thres, iterations=2, cg_fixed_iterations=6))
+    ctx = helpers.gpu_context(sc, arrays, vsh)
+    st1 = ctx.optimize(cfg); sdf1, alb1 = ctx.get_grid(); i1, d1, p1 = ctx.get_camera(); ctx.close()
+    sdf2, alb2, i2, d2, p2, st2 = binding.optimize_host(cfg, sc["voxel_size"], arrays["keys"], arrays["sdf"], arrays["sdf_refined"], arrays["albedo"], arrays["weight"],
+                                                        arrays["color"], sc["frames"], sc["levels"], sc["intr"], sc["dist"], sc["poses"], vsh)
+    assert [list(s.rows) for s in st1] == [list(s.rows) for s in st2]
+    smax = np.abs(sdf1).max()
+    assert np.abs(sdf1 - sdf2).max() <= 5e-5 * smax and np.abs(alb1 - alb2).max() <= 5e-5
+    np.testing.assert_allclose(i2, i1, rtol=5e-5); np.testing.assert_allclose(p2, p1, rtol=1e-4, atol=1e-6)
+    assert np.abs(sdf2 - arrays["sdf_refined"]).max() > 0                       # the unknowns did move and were written back
+    g.free(); fr.free()
