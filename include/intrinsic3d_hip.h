@@ -85,6 +85,9 @@ int i3d_get_voxel_sh(i3d_context* ctx, double* voxel_sh);
  * Replaces i3d_set_frames for callers that do not want to build the pyramids with OpenCV. */
 int i3d_set_frames_rgbd(i3d_context* ctx, int32_t num_frames, int32_t levels, int32_t width, int32_t height, const uint8_t* const* bgr, const float* const* depth);
 int i3d_get_frame_image(i3d_context* ctx, int32_t frame, int32_t level, float* lum /* may be NULL */, float* depth /* may be NULL */);
+/* resizeDepth (rgbd/processing.cpp:129-181): a depth image resampled into the colour camera's geometry; intrinsics = {fx, fy, cx, cy} */
+int i3d_resize_depth(int32_t device_ordinal, int32_t in_w, int32_t in_h, const float* depth_in, const float* in_intr4, int32_t out_w, int32_t out_h,
+                     const float* out_intr4, float* depth_out);
 
 /* ---- Optimizer::Config (optimizer.h:67-84) + the fields of Intrinsic3D::Config / Optimizer::Data the path reads */
 typedef struct {

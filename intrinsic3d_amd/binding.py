@@ -60,7 +60,7 @@ class GridView(C.Structure):
 
 
 EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_set_grid", "i3d_get_grid", "i3d_update_grid",
-           "i3d_set_frames", "i3d_set_frames_rgbd", "i3d_get_frame_image", "i3d_set_camera", "i3d_get_camera", "i3d_set_voxel_sh", "i3d_get_voxel_sh",
+           "i3d_set_frames", "i3d_set_frames_rgbd", "i3d_get_frame_image", "i3d_resize_depth", "i3d_set_camera", "i3d_get_camera", "i3d_set_voxel_sh", "i3d_get_voxel_sh",
            "i3d_optimizer_config_default", "i3d_optimize", "i3d_optimize_host", "i3d_estimate_sh",
            "i3d_set_grid_from_tsdf_records", "i3d_recompute_colors", "i3d_clear_outside_thin_shell", "i3d_upsample", "i3d_grid_info",
            "i3d_export_grid", "i3d_refine",
@@ -94,6 +94,7 @@ def load():
     L.i3d_update_grid.restype = i32; L.i3d_update_grid.argtypes = [vp, vp, vp, vp]
     L.i3d_set_frames.restype = i32; L.i3d_set_frames.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     L.i3d_set_frames_rgbd.restype = i32; L.i3d_set_frames_rgbd.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    L.i3d_resize_depth.restype = i32; L.i3d_resize_depth.argtypes = [i32, i32, i32, vp, vp, i32, i32, vp, vp]
     L.i3d_get_frame_image.restype = i32; L.i3d_get_frame_image.argtypes = [vp, i32, i32, vp, vp]
     L.i3d_set_camera.restype = i32; L.i3d_set_camera.argtypes = [vp, vp, vp, vp]
     L.i3d_get_camera.restype = i32; L.i3d_get_camera.argtypes = [vp, vp, vp, vp]
@@ -516,3 +517,10 @@ def optimize_host(cfg, voxel_size, keys, sdf, sdf_refined, albedo, weight, color
     if rc != 0:
         raise I3DError(f"i3d_optimize_host failed ({rc})")
     return sr, al, i4, d5, p6, list(stats)
+
+
+def resize_depth(depth, in_intr, out_w, out_h, out_intr, device=0):
+    d = np.ascontiguousarray(depth, np.float32); a = np.ascontiguousarray(in_intr, np.float32); b = np.ascontiguousarray(out_intr, np.float32)
+    out = np.zeros((out_h, out_w), np.float32)
+    _io_check(load().i3d_resize_depth(int(device), d.shape[1], d.shape[0], _p(d), _p(a), int(out_w), int(out_h), _p(b), _p(out)), "i3d_resize_depth")
+    return out

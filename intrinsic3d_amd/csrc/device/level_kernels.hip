@@ -240,3 +240,36 @@ void launch_lum_from_bgr(hipStream_t st, int n, const uint8_t* bgr, float* lum) 
 void launch_pyr_down(hipStream_t st, int w, int h, const float* src, int ow, int oh, float* dst) { if (ow > 0 && oh > 0) k_pyr_down<<<dim3((ow + 255) / 256, oh), 256, 0, st>>>(w, h, src, ow, oh, dst); }
 void launch_depth_down(hipStream_t st, int w, const float* src, int ow, int oh, float* dst) { if (ow > 0 && oh > 0) k_depth_down<<<dim3((ow + 255) / 256, oh), 256, 0, st>>>(w, src, ow, oh, dst); }
 }  // namespace i3d
+
+// resizeDepth (rgbd/processing.cpp:129-181): depth image resampled into the colour camera's geometry (pinhole to pinhole at z = 1,
+// pixel test on round-half-up coordinates, bilinear lookup with out-of-image taps dropped and the weights renormalised: interpolate<float>,
+// processing.cpp:236-283); pixels whose lookup is exactly 0 stay 0.
+namespace i3d {
+__global__ void __launch_bounds__(256) k_resize_depth(int iw, int ih, const float* __restrict__ din, float in_fx, float in_fy, float in_cx, float in_cy,
+                                                      int ow, int oh, float out_fx_inv, float out_fy_inv, float out_cx, float out_cy, float* __restrict__ dout) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow || y >= oh) return;
+    const float x0n = ((float)x - out_cx) * out_fx_inv, y0n = ((float)y - out_cy) * out_fy_inv;
+    const float px = (in_fx * x0n / 1.0f) + in_cx, py = (in_fy * y0n / 1.0f) + in_cy;
+    const int pxi = (int)(px + 0.5f), pyi = (int)(py + 0.5f);
+    float out = 0.0f;
+    if (!(pxi < 0 || pyi < 0 || pxi >= iw || pyi >= ih)) {
+        const int x0 = (int)floorf(px), y0 = (int)floorf(py), x1 = x0 + 1, y1 = y0 + 1;
+        float x1w = px - (float)x0, y1w = py - (float)y0, x0w = 1.0f - x1w, y0w = 1.0f - y1w;
+        if (x0 < 0 || x0 >= iw) x0w = 0.0f; if (x1 < 0 || x1 >= iw) x1w = 0.0f; if (y0 < 0 || y0 >= ih) y0w = 0.0f; if (y1 < 0 || y1 >= ih) y1w = 0.0f;
+        const float w00 = x0w * y0w, w10 = x1w * y0w, w01 = x0w * y1w, w11 = x1w * y1w;
+        const float sw = ((w00 + w10) + w01) + w11;
+        float sum = 0.0f;
+        if (w00 > 0.0f) sum += din[(size_t)y0 * iw + x0] * w00;
+        if (w01 > 0.0f) sum += din[(size_t)y1 * iw + x0] * w01;
+        if (w10 > 0.0f) sum += din[(size_t)y0 * iw + x1] * w10;
+        if (w11 > 0.0f) sum += din[(size_t)y1 * iw + x1] * w11;
+        if (sw > 0.0f) out = sum / sw;
+    }
+    dout[(size_t)y * ow + x] = out;
+}
+void launch_resize_depth(hipStream_t st, int iw, int ih, const float* din, const float in_intr[4], int ow, int oh, const float out_intr[4], float* dout) {
+    if (ow > 0 && oh > 0) k_resize_depth<<<dim3((ow + 255) / 256, oh), 256, 0, st>>>(iw, ih, din, in_intr[0], in_intr[1], in_intr[2], in_intr[3], ow, oh,
+                                                                                      1.0f / out_intr[0], 1.0f / out_intr[1], out_intr[2], out_intr[3], dout);
+}
+}  // namespace i3d

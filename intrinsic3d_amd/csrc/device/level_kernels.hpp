@@ -28,3 +28,6 @@ void launch_lum_from_bgr(hipStream_t st, int n, const uint8_t* bgr, float* lum);
 void launch_pyr_down(hipStream_t st, int w, int h, const float* src, int ow, int oh, float* dst);
 void launch_depth_down(hipStream_t st, int w, const float* src, int ow, int oh, float* dst);
 }  // namespace i3d
+namespace i3d {
+void launch_resize_depth(hipStream_t st, int iw, int ih, const float* din, const float in_intr[4], int ow, int oh, const float out_intr[4], float* dout);
+}

@@ -158,6 +158,21 @@ int i3d_set_frames_rgbd(i3d_context* c, int32_t K, int32_t levels, int32_t width
     if ((int)c->poses.size() != 6 * K) { c->poses.assign((size_t)6 * K, 0.0); c->have_camera = false; }
     return I3D_OK;
 }
+// resizeDepth(depth camera, depth, colour camera) (rgbd/processing.cpp:129-181), called per keyframe by Intrinsic3D::init (intrinsic3d.cpp:182-184)
+// before the pyramid is built; intrinsics are (fx, fy, cx, cy) as floats.  Same size in and out: a plain copy, like the reference.
+int i3d_resize_depth(int32_t device_ordinal, int32_t in_w, int32_t in_h, const float* depth_in, const float* in_intr, int32_t out_w, int32_t out_h,
+                     const float* out_intr, float* depth_out) {
+    if (!depth_in || !depth_out || !in_intr || !out_intr || in_w <= 0 || in_h <= 0 || out_w <= 0 || out_h <= 0) return I3D_ERR_INVALID_ARGUMENT;
+    if (in_w == out_w && in_h == out_h) { std::memcpy(depth_out, depth_in, sizeof(float) * (size_t)in_w * in_h); return I3D_OK; }
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || device_ordinal < 0 || device_ordinal >= ndev) return I3D_ERR_NO_DEVICE;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return I3D_ERR_HIP;
+    DevBuf<float> a, b;
+    if (a.alloc((size_t)in_w * in_h) != hipSuccess || b.alloc((size_t)out_w * out_h) != hipSuccess) return I3D_ERR_HIP;
+    if (hipMemcpy(a.p, depth_in, sizeof(float) * (size_t)in_w * in_h, hipMemcpyHostToDevice) != hipSuccess) return I3D_ERR_HIP;
+    launch_resize_depth(nullptr, in_w, in_h, a.p, in_intr, out_w, out_h, out_intr, b.p);
+    if (hipMemcpy(depth_out, b.p, sizeof(float) * (size_t)out_w * out_h, hipMemcpyDeviceToHost) != hipSuccess) return I3D_ERR_HIP;
+    return hipGetLastError() == hipSuccess ? I3D_OK : I3D_ERR_HIP;
+}
 // one pyramid image back to the host (parity probe / callers that still want the images)
 int i3d_get_frame_image(i3d_context* c, int32_t frame, int32_t level, float* lum, float* depth) {
     if (!c || !c->have_frames || frame < 0 || frame >= c->K || level < 0 || level >= c->levels) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_get_frame_image: bad frame / level");

@@ -74,6 +74,7 @@ int32_t orc_estimate_sh(void* g, float subvolume_size, double lambda_reg, double
 /* keyframe pyramids (rgbd/pyramid.cpp:59-166) */
 void    orc_lum_from_bgr(int32_t n, const uint8_t* bgr, float* lum);
 void    orc_pyr_down(int32_t w, int32_t h, const float* src, float* dst /* (w/2)*(h/2) */);
+void    orc_resize_depth(int32_t iw, int32_t ih, const float* din, const float* in_intr4, int32_t ow, int32_t oh, const float* out_intr4, float* dout);
 void    orc_depth_down(int32_t w, int32_t h, const float* src, float* dst);
 int32_t orc_recompute_colors(void* g, void* fr, const double* intr, const double* dist, const double* poses,
                              float occlusion_distance, int32_t num_observations);

@@ -180,6 +180,12 @@ def depth_down(img):
     lib().orc_depth_down(C.c_int32(w), C.c_int32(h), _p(a), _p(out)); return out
 
 
+def resize_depth(depth, in_intr, out_w, out_h, out_intr):
+    d = np.ascontiguousarray(depth, np.float32); a = np.ascontiguousarray(in_intr, np.float32); b = np.ascontiguousarray(out_intr, np.float32)
+    out = np.zeros((out_h, out_w), np.float32)
+    lib().orc_resize_depth(C.c_int32(d.shape[1]), C.c_int32(d.shape[0]), _p(d), _p(a), C.c_int32(out_w), C.c_int32(out_h), _p(b), _p(out)); return out
+
+
 def recompute_colors(grid: Grid, frames: "Frames", intr, dist, poses, occlusion_distance, num_observations):
     intr = np.ascontiguousarray(intr, np.float64); dist = np.ascontiguousarray(dist, np.float64); poses = np.ascontiguousarray(poses, np.float64)
     return lib().orc_recompute_colors(grid.h, frames.h, _p(intr), _p(dist), _p(poses), float(occlusion_distance), int(num_observations))

@@ -193,6 +193,32 @@ void orc_depth_down(int32_t w, int32_t h, const float* src, float* dst) {       
     }
 }
 
+// rgbd/processing.cpp:129-181 + interpolate<float> :236-283
+void orc_resize_depth(int32_t iw, int32_t ih, const float* din, const float* in_intr, int32_t ow, int32_t oh, const float* out_intr, float* dout) {
+    const float in_fx = in_intr[0], in_fy = in_intr[1], in_cx = in_intr[2], in_cy = in_intr[3];
+    const float out_cx = out_intr[2], out_cy = out_intr[3], out_fx_inv = 1.0f / out_intr[0], out_fy_inv = 1.0f / out_intr[1];
+    for (int y = 0; y < oh; ++y) for (int x = 0; x < ow; ++x) {
+        dout[(size_t)y * ow + x] = 0.0f;
+        const float x0n = ((float)x - out_cx) * out_fx_inv, y0n = ((float)y - out_cy) * out_fy_inv;
+        const float px = (in_fx * x0n / 1.0f) + in_cx, py = (in_fy * y0n / 1.0f) + in_cy;
+        const int pxi = (int)(px + 0.5f), pyi = (int)(py + 0.5f);
+        if (pxi < 0 || pyi < 0 || pxi >= iw || pyi >= ih) continue;
+        const int x0 = (int)std::floor(px), y0 = (int)std::floor(py), x1 = x0 + 1, y1 = y0 + 1;
+        float x1w = px - (float)x0, y1w = py - (float)y0, x0w = 1.0f - x1w, y0w = 1.0f - y1w;
+        if (x0 < 0 || x0 >= iw) x0w = 0.0f; if (x1 < 0 || x1 >= iw) x1w = 0.0f; if (y0 < 0 || y0 >= ih) y0w = 0.0f; if (y1 < 0 || y1 >= ih) y1w = 0.0f;
+        const float w00 = x0w * y0w, w10 = x1w * y0w, w01 = x0w * y1w, w11 = x1w * y1w;
+        const float sw = w00 + w10 + w01 + w11;
+        float sum = 0.0f;
+        if (w00 > 0.0f) sum += din[(size_t)y0 * iw + x0] * w00;
+        if (w01 > 0.0f) sum += din[(size_t)y1 * iw + x0] * w01;
+        if (w10 > 0.0f) sum += din[(size_t)y0 * iw + x1] * w10;
+        if (w11 > 0.0f) sum += din[(size_t)y1 * iw + x1] * w11;
+        const float d = sw > 0.0f ? sum / sw : 0.0f;
+        if (d == 0.0f) continue;
+        dout[(size_t)y * ow + x] = d;
+    }
+}
+
 // intrinsic3d.cpp:381-409 + colorization.cpp:113-189,318-354 (recolourisation at pyramid level 0)
 int32_t orc_recompute_colors(void* g, void* fr, const double* intr, const double* dist, const double* poses,
                              float occlusion_distance, int32_t num_observations) {

@@ -223,3 +223,15 @@ def test_refine_sharded_ranks_match_single_rank(oracle, scene):
         assert np.array_equal(cam[0], wcam[0]); np.testing.assert_allclose(cam[2], wcam[2], rtol=1e-3, atol=1e-5)
         c.close()
     L.i3d_comm_sim_destroy(shared)
+
+
+def test_resize_depth_bit_exact(oracle):
+    """resizeDepth: a 320x240 depth image (holes, zero border) into a 640x480 colour camera with different intrinsics, and a 2x down case"""
+    from intrinsic3d_amd import binding
+    rng = np.random.default_rng(6)
+    d = rng.uniform(0.5, 3.0, (240, 320)).astype(np.float32); d[rng.uniform(size=d.shape) < 0.2] = 0.0
+    for (ow, oh, oi) in ((640, 480, [525.0, 524.0, 319.5, 239.5]), (160, 120, [131.0, 131.5, 80.2, 59.1]), (700, 500, [400.0, 400.0, 350.0, 250.0])):
+        ii = [262.5, 262.0, 159.5, 119.5]
+        got = binding.resize_depth(d, ii, ow, oh, oi); ref = oracle.resize_depth(d, ii, ow, oh, oi)
+        assert (ref > 0).mean() > 0.3 and np.array_equal(got, ref), (ow, oh, np.abs(got - ref).max())
+    assert np.array_equal(binding.resize_depth(d, ii, 320, 240, oi), d)          # same size: clone
