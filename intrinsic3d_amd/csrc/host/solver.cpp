@@ -92,6 +92,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     if (cfg.rgbd_level < 0 || cfg.rgbd_level >= c->levels) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "optimize: rgbd_level outside the uploaded pyramid");
     int slots = (cfg.num_observations <= 0 || cfg.num_observations >= c->K) ? c->K : cfg.num_observations;
     if (slots > MAX_SLOTS) return ctx_fail(c, I3D_ERR_CAPACITY, "optimize: more than 8 observations per voxel requested");
+    if (c->K > 2000) return ctx_fail(c, I3D_ERR_CAPACITY, "optimize: more than 2000 keyframes (the camera accumulators of the operator pass live in 160 KB of LDS)");
     if (c->slots != slots || c->Acap != c->N || !c->rows.p) { int rc = alloc_rows(c, slots); if (rc) return rc; }
     hipStream_t s = c->stream;
     p = make_params(c, cfg, c->intr, c->dist);

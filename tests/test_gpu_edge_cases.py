@@ -131,3 +131,14 @@ def test_one_call_host_entry_point_matches_resident_path(oracle):
     np.testing.assert_allclose(i2, i1, rtol=5e-5); np.testing.assert_allclose(p2, p1, rtol=1e-4, atol=1e-6)
     assert np.abs(sdf2 - arrays["sdf_refined"]).max() > 0                       # the unknowns did move and were written back
     g.free(); fr.free()
+
+
+def test_many_keyframes(oracle):
+    """350 keyframes: the per-keyframe constants no longer fit the build kernel's LDS staging (global path), the operator pass runs with
+    fewer accumulator replicas, and the camera tail of every solver vector is 2109 entries long"""
+    sc = helpers.small_scene(seed=13, radius_vox=7, K=350, width=40, height=30)
+    thres = 2.0 * float(sc["voxel_size"])
+    rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres, fix_intrinsics=1, fix_distortion=1)
+    assert rc == 0 and ostats[0].rows[0] > 1000
+    _check(ref, ostats, out, gstats)
+    np.testing.assert_allclose(cam[2], ocam[2], rtol=1e-4, atol=1e-6)
