@@ -36,6 +36,47 @@ def compute(O):
     return res
 
 
+def _crc(a):
+    return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def level_scene():
+    """the seeded inputs of levels_small.json (shared by the generator, the CPU check and the -m gpu check)"""
+    import helpers
+    sc = dict(helpers.small_scene(seed=17, radius_vox=10, K=5, width=96, height=72, levels=1))
+    rng = np.random.default_rng(3)
+    frames = []
+    for fr in sc["frames"]:
+        g = fr["bgr"][0][..., 0].astype(np.float32)
+        frames.append({"lum": fr["lum"], "depth": fr["depth"], "bgr": [np.stack([0.6 * g, g, 250.0 - 0.4 * g], axis=-1).astype(np.uint8)]})
+    sc["frames"] = frames
+    w = sc["weight"].copy(); w[rng.integers(0, len(w), 30)] = 0.0
+    sc["weight"] = w
+    return sc
+
+
+def compute_levels(O):
+    """CRCs of the byte-exact stages of the level schedule on the oracle: converted visit order, recolourisation, thin shell, x2 upsample,
+    and the keyframe pyramid / depth resampling"""
+    sc = level_scene()
+    g = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"]); fr = O.Frames(sc["frames"], 1)
+    res = {"convert": {"n": len(g), "keys": _crc(g.export()["keys"])}}
+    O.recompute_colors(g, fr, sc["intr"], sc["dist"], sc["poses"], 0.02, 3)
+    res["recolor"] = {"color": _crc(g.export()["color"])}
+    thres = 1.5 * float(sc["voxel_size"])
+    g.clear_outside_shell(thres)
+    a = g.export(); res["thin_shell"] = {"n": len(g), "keys": _crc(a["keys"])}
+    up = g.upsample(); b = up.export()
+    res["upsample"] = {"n": len(up), "keys": _crc(b["keys"]), "weight": _crc(b["weight"]), "sdf": _crc(b["sdf"]), "color": _crc(b["color"]),
+                       "valid": int((b["weight"] > 0).sum())}
+    bgr = sc["frames"][0]["bgr"][0]; dep = sc["frames"][0]["depth"][0]
+    lum = O.lum_from_bgr(bgr)
+    res["pyramid"] = {"lum0": _crc(lum), "lum1": _crc(O.pyr_down(lum)), "lum2": _crc(O.pyr_down(O.pyr_down(lum))), "depth1": _crc(O.depth_down(dep))}
+    res["resize_depth"] = {"crc": _crc(O.resize_depth(dep, [78.75, 78.0, 47.5, 35.5], 160, 120, [131.0, 131.5, 80.2, 59.1]))}
+    g.free(); up.free(); fr.free()
+    return res
+
+
 if __name__ == "__main__":
     from oracle import oracle_py as O
     O.build()
@@ -43,3 +84,7 @@ if __name__ == "__main__":
     with open(os.path.join(HERE, "optimize_small.json"), "w") as f:
         json.dump(r, f, indent=1)
     print("written", r["num_voxels"], r["rows"])
+    r2 = compute_levels(O)
+    with open(os.path.join(HERE, "levels_small.json"), "w") as f:
+        json.dump(r2, f, indent=1)
+    print("written levels", r2["convert"], r2["upsample"]["n"])

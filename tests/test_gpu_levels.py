@@ -235,3 +235,31 @@ def test_resize_depth_bit_exact(oracle):
         got = binding.resize_depth(d, ii, ow, oh, oi); ref = oracle.resize_depth(d, ii, ow, oh, oi)
         assert (ref > 0).mean() > 0.3 and np.array_equal(got, ref), (ow, oh, np.abs(got - ref).max())
     assert np.array_equal(binding.resize_depth(d, ii, 320, 240, oi), d)          # same size: clone
+
+
+def test_device_level_operations_match_committed_golden():
+    """the device path alone against tests/golden/levels_small.json (CRCs of byte-exact stages, generated from the oracle by make_golden.py):
+    needs neither the oracle nor the reference at run time"""
+    import json, os, zlib
+    from intrinsic3d_amd import binding
+    import golden.make_golden as mg
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "levels_small.json")))
+    crc = lambda a: int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+    sc = mg.level_scene()
+    with binding.Context(0) as ctx:
+        ctx.set_grid_from_tsdf_records(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        ctx.set_frames(sc["frames"], 1); ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
+        a = ctx.export_grid()
+        assert {"n": len(a["weight"]), "keys": crc(a["keys"])} == gold["convert"]
+        ctx.recompute_colors(0.02, 3)
+        assert crc(ctx.export_grid()["color"]) == gold["recolor"]["color"]
+        n = ctx.clear_outside_thin_shell(1.5 * float(sc["voxel_size"]))
+        assert {"n": n, "keys": crc(ctx.export_grid()["keys"])} == gold["thin_shell"]
+        n = ctx.upsample(); b = ctx.export_grid()
+        got = {"n": n, "keys": crc(b["keys"]), "weight": crc(b["weight"]), "sdf": crc(b["sdf"]), "color": crc(b["color"]), "valid": int((b["weight"] > 0).sum())}
+        assert got == gold["upsample"]
+        bgr = sc["frames"][0]["bgr"][0]; dep = sc["frames"][0]["depth"][0]; h, w = dep.shape
+        ctx.set_frames_rgbd([bgr], [dep], 3)
+        l0, _ = ctx.get_frame_image(0, 0, w, h); l1, d1 = ctx.get_frame_image(0, 1, w // 2, h // 2); l2, _ = ctx.get_frame_image(0, 2, w // 4, h // 4)
+        assert {"lum0": crc(l0), "lum1": crc(l1), "lum2": crc(l2), "depth1": crc(d1)} == gold["pyramid"]
+    assert crc(binding.resize_depth(dep, [78.75, 78.0, 47.5, 35.5], 160, 120, [131.0, 131.5, 80.2, 59.1])) == gold["resize_depth"]["crc"]

@@ -183,6 +183,13 @@ def test_golden_oracle_outputs(oracle):
     np.testing.assert_allclose(cur["sh0"], gold["sh0"], rtol=1e-8)
 
 
+def test_golden_level_operations(oracle):
+    """byte-exact stages of the level schedule (visit orders, 8-bit colours, upsampled fields, pyramids) vs the committed CRCs"""
+    gold = json.load(open(os.path.join(HERE, "golden", "levels_small.json")))
+    import golden.make_golden as mg
+    assert mg.compute_levels(oracle) == gold
+
+
 def test_pyramid_restatement_against_numpy(oracle):
     """luminance / pyrDown / depth pyramid of the oracle vs an independent numpy formulation (separable float32 convolution with reflected
     borders; valid-mean of 2x2 blocks)"""
