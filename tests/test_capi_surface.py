@@ -32,12 +32,13 @@ def test_struct_layouts_match_header():
     """ctypes mirrors must have the C struct sizes (checked against a tiny C program compiled with gcc)."""
     import ctypes, subprocess, tempfile
     binding, L = _lib()
-    src = '#include <stdio.h>\n#include "intrinsic3d_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(i3d_optimizer_config), sizeof(i3d_iteration_stats), sizeof(i3d_grid_view), sizeof(i3d_sh_stats));return 0;}\n'
+    src = '#include <stdio.h>\n#include "intrinsic3d_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(i3d_optimizer_config), sizeof(i3d_iteration_stats), sizeof(i3d_grid_view), sizeof(i3d_sh_stats), sizeof(i3d_refine_config));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
-    assert sizes == [ctypes.sizeof(binding.OptimizerConfig), ctypes.sizeof(binding.IterationStats), ctypes.sizeof(binding.GridView), ctypes.sizeof(binding.ShStats)]
+    assert sizes == [ctypes.sizeof(binding.OptimizerConfig), ctypes.sizeof(binding.IterationStats), ctypes.sizeof(binding.GridView), ctypes.sizeof(binding.ShStats),
+                     ctypes.sizeof(binding.RefineConfig)]
 
 
 def test_defaults_are_the_reference_struct_defaults():
