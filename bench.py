@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--subvolume", type=float, default=0.08, help="SH subvolume size in metres (0.6 m object: 8 cells per axis)")
     ap.add_argument("--cpu-sample", type=float, default=1.0e6, help="stored voxels of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--all-kernel-timing", action="store_true", help="HIP events around every launch (kernel_ms_total for all categories; ~8 % slower)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="experiments only: no per-launch HIP events (no roofline in the output)")
     ap.add_argument("--pcg-fixed", type=int, default=-1, help="experiments only: pin the PCG iterations per LM attempt (-1 = Ceres' stopping rule)")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="also launch a known-size device copy (1 GiB read + 1 GiB write) so that a rocprofv3 --pmc pass over this command "
@@ -185,7 +187,10 @@ def main():
         torch.cuda.synchronize(); del a, b
     if args.warmup > 0:
         ctx.optimize(make_cfg(binding, args, args.warmup, thres))
-    ctx.timing_enable(True); ctx.timing_get(reset=True)
+    ctx.timing_enable(not args.no_kernel_timing)
+    if not args.all_kernel_timing:
+        ctx.timing_select(["eg_pass", "build"])      # the roofline kernels only: an event pair around EVERY launch costs ~8 % of the wall clock
+    ctx.timing_get(reset=True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -214,6 +214,9 @@ int32_t i3d_shard_vec_index(int32_t a, int32_t chunk, int32_t albedo);
 enum { I3D_K_CLASSIFY = 0, I3D_K_OBSERVE, I3D_K_BUILD, I3D_K_EG_PASS /* J^T W J p passes of the PCG */, I3D_K_GATHER, I3D_K_COST, I3D_K_VECTOR, I3D_K_SH,
        I3D_K_EG_AUX /* gradient and column-norm passes over the rows */, I3D_K_COUNT };
 int i3d_timing_enable(i3d_context* ctx, int32_t on);
+/* restrict the per-launch HIP events to the categories of the mask (bit = 1 << I3D_K_*; default: all).  An event pair around EVERY launch of a
+ * Gauss-Newton iteration (~900 launches) costs ~8 % of its wall clock; bench.py times only what its roofline needs. */
+int i3d_timing_select(i3d_context* ctx, uint32_t category_mask);
 int i3d_timing_get(i3d_context* ctx, double* ms /*[I3D_K_COUNT]*/, int64_t* launches /*[I3D_K_COUNT]*/, int32_t reset);
 /* the same restricted to launches that did work: PCG launches queued behind the device-side convergence flag return at once (~4 us) and
  * would flatter an average; a launch counts when it lasted >= 25 % of the longest launch of its category */

@@ -68,7 +68,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_write_intrinsics", "i3d_read_intrinsics", "i3d_config_load_yaml",
            "i3d_extract_mesh", "i3d_get_mesh", "i3d_export_mesh_ply", "i3d_write_ply", "i3d_mc_tables",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
-           "i3d_timing_enable", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
+           "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
            "i3d_debug_normal_eq", "i3d_debug_jtj_apply"]
 
@@ -114,6 +114,7 @@ def load():
     L.i3d_shard_plan.restype = i32; L.i3d_shard_plan.argtypes = [i32, i32, i32, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), vp]
     L.i3d_shard_vec_index.restype = i32; L.i3d_shard_vec_index.argtypes = [i32, i32, i32]
     L.i3d_timing_enable.restype = i32; L.i3d_timing_enable.argtypes = [vp, i32]
+    L.i3d_timing_select.restype = i32; L.i3d_timing_select.argtypes = [vp, C.c_uint32]
     L.i3d_timing_get.restype = i32; L.i3d_timing_get.argtypes = [vp, vp, vp, i32]
     L.i3d_timing_get_work.restype = i32; L.i3d_timing_get_work.argtypes = [vp, vp, vp]
     L.i3d_kernel_name.restype = C.c_char_p; L.i3d_kernel_name.argtypes = [i32]
@@ -347,6 +348,13 @@ class Context:
     # ---- measurement ---------------------------------------------------------------------------------------
     def timing_enable(self, on=True):
         self._check(self.L.i3d_timing_enable(self.h, 1 if on else 0), "i3d_timing_enable")
+
+    def timing_select(self, names):
+        """HIP events only around the launches of these categories (K_NAMES)"""
+        mask = 0
+        for n in names:
+            mask |= 1 << K_NAMES.index(n)
+        self._check(self.L.i3d_timing_select(self.h, mask), "i3d_timing_select")
 
     def timing_get_work(self):
         """like timing_get (no reset), restricted to launches that did work (>= 25 % of the category's longest launch)"""

@@ -24,16 +24,17 @@ int ensure_pinned(i3d_context* c, size_t n) {
 }
 
 // ---- timing: one HIP event pair per launch on the context's stream, resolved at flush -------------------------
-void timing_begin(i3d_context* c, int cat) {
-    if (!c->timing.on) return;
+bool timing_begin(i3d_context* c, int cat) {
+    if (!c->timing.on || !((c->timing.mask >> cat) & 1u)) return false;
     Timing::Pending p; p.cat = cat;
     auto get = [&]() { hipEvent_t e; if (!c->timing.pool.empty()) { e = c->timing.pool.back(); c->timing.pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
     p.a = get(); p.b = get();
     (void)hipEventRecord(p.a, c->stream);
     c->timing.pending.push_back(p);
+    return true;
 }
 void timing_end(i3d_context* c) {
-    if (!c->timing.on || c->timing.pending.empty()) return;
+    if (c->timing.pending.empty()) return;
     (void)hipEventRecord(c->timing.pending.back().b, c->stream);
 }
 void timing_flush(i3d_context* c) {
@@ -328,6 +329,7 @@ int i3d_get_voxel_sh(i3d_context* c, double* out) {
 }
 
 int i3d_timing_enable(i3d_context* c, int32_t on) { if (!c) return I3D_ERR_INVALID_ARGUMENT; timing_flush(c); c->timing.on = on != 0; return I3D_OK; }
+int i3d_timing_select(i3d_context* c, uint32_t category_mask) { if (!c) return I3D_ERR_INVALID_ARGUMENT; timing_flush(c); c->timing.mask = category_mask; return I3D_OK; }
 int i3d_timing_get(i3d_context* c, double* ms, int64_t* launches, int32_t reset) {
     if (!c) return I3D_ERR_INVALID_ARGUMENT;
     timing_flush(c);

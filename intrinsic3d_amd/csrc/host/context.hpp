@@ -31,6 +31,7 @@ struct DevBuf {
 
 struct Timing {
     bool on = false;
+    unsigned mask = ~0u;                            // categories that get HIP events (an event pair per launch is not free: ~8 % with all of them on)
     double ms[I3D_K_COUNT] = {0};
     long long launches[I3D_K_COUNT] = {0};
     std::vector<float> each[I3D_K_COUNT];          // every launch duration (for the work-only average)
@@ -104,10 +105,10 @@ int ctx_hip(i3d_context* c, hipError_t e, const char* what);
 #define CTX_HIP(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return i3d::ctx_hip((c), _e, #expr); } while (0)
 void build_frame_consts(const i3d_context* c, int level, const double* poses, std::vector<FrameConst>& out);
 int ensure_pinned(i3d_context* c, size_t n);
-void timing_begin(i3d_context* c, int cat);
+bool timing_begin(i3d_context* c, int cat);
 void timing_end(i3d_context* c);
 void timing_flush(i3d_context* c);
-struct TimedScope { i3d_context* c; TimedScope(i3d_context* c_, int cat) : c(c_) { timing_begin(c, cat); } ~TimedScope() { timing_end(c); } };
+struct TimedScope { i3d_context* c; bool active; TimedScope(i3d_context* c_, int cat) : c(c_), active(timing_begin(c_, cat)) {} ~TimedScope() { if (active) timing_end(c); } };
 
 // context.cpp — (re)build the resident grid from device arrays in visit order
 struct GridStaging { DevBuf<int> kxyz; DevBuf<double> sdf, sdf_ref, alb; DevBuf<float> w; DevBuf<uint8_t> rgb; };
