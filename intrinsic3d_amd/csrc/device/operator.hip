@@ -634,7 +634,7 @@ __global__ void k_freemask(RowView r, OptParams p, float* __restrict__ mask) {
 void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask) { k_freemask<<<vblocks(r.world * 2 * r.chunk + 6 * p.K + 9), 256, 0, st>>>(r, p, mask); }
 
 // ---- fused PCG iteration (conjugate_gradients_solver.cc) -------------------------------------------------------------
-// One iteration = 7 launches:  tail_a | direction | (memset) eg_pass | gather | tail_b | step.
+// One iteration = 6 launches:  tail_a | direction | eg_jtjp | gather | tail_b | step.
 //   k_pcg_step   (a rank's slice of the voxel unknowns, 16 B per lane):  x += alpha p ; r -= alpha q ; z = M^-1 r ; slice partial
 //                sums of r.z, x.(b+r), x.r, sum D^2 x^2 into state->acc[4]  (ONE 4-double all-reduce per iteration when sharded,
 //                issued together with the all-gather of z)
