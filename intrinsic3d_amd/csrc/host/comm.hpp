@@ -11,6 +11,7 @@ namespace i3d {
 
 struct Comm {
     int rank = 0, world = 1;
+    bool force = false;        // run the sharded code path (and its collectives) even with one rank: exercises the real RCCL calls on a 1-GPU box
     virtual ~Comm() {}
     // in-place sum over ranks of n doubles in device memory
     virtual int allreduce_sum(double* dev, size_t n, hipStream_t st) = 0;

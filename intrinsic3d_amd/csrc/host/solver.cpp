@@ -65,13 +65,13 @@ static Layout layout_of(const i3d_context* c) {
     L.slice_n = 2 * (size_t)L.chunk; L.slice_off = (size_t)L.rank * L.slice_n; L.tail_off = (size_t)L.world * L.slice_n; L.NP = L.tail_off + L.NS;
     return L;
 }
-static bool sharded(const i3d_context* c) { return c->comm && c->comm->world > 1; }
+static bool sharded(const i3d_context* c) { return c->comm && (c->comm->world > 1 || c->comm->force); }
 static int allreduce(i3d_context* c, double* dev, size_t n) {
     if (!sharded(c)) return I3D_OK;
     return c->comm->allreduce_sum(dev, n, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-reduce failed") : I3D_OK;
 }
 static int allreduce_allgather(i3d_context* c, double* red, size_t n, float* vec) {      // one fused exchange per PCG iteration
-    if (!c->comm || c->comm->world <= 1) return I3D_OK;
+    if (!sharded(c)) return I3D_OK;
     return c->comm->allreduce_allgather(red, n, vec, 2 * (size_t)c->chunk, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-reduce + all-gather failed") : I3D_OK;
 }
 static int allgather(i3d_context* c, float* vec) {       // every rank contributes its slice of a solver vector
