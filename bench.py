@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--subvolume", type=float, default=0.08, help="SH subvolume size in metres (0.6 m object: 8 cells per axis)")
     ap.add_argument("--cpu-sample", type=float, default=1.0e6, help="stored voxels of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="experiments only (1 GPU): run the sharded code path through a real 1-rank RCCL communicator, to see what the collectives' launches cost per PCG pass")
     ap.add_argument("--all-kernel-timing", action="store_true", help="HIP events around every launch (kernel_ms_total for all categories; ~8 % slower)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="experiments only: no per-launch HIP events (no roofline in the output)")
     ap.add_argument("--pcg-fixed", type=int, default=-1, help="experiments only: pin the PCG iterations per LM attempt (-1 = Ceres' stopping rule)")
@@ -162,6 +164,9 @@ def main():
     arrays = grid_arrays(sc)
 
     ctx = binding.Context(local_rank)
+    if world == 1 and args.force_collectives:
+        os.environ["I3D_FORCE_COLLECTIVES"] = "1"
+        ctx.comm_init(0, 1, binding.Context.comm_unique_id())
     if world > 1:
         # one process per GPU: RCCL communicator of the library, bootstrapped through torch.distributed (unique id from rank 0)
         uid = torch.zeros(256, dtype=torch.uint8, device="cuda")
