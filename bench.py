@@ -139,6 +139,23 @@ def pmc_traffic(kernel, eg_rows, active):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): anything native libraries print on fd 1 meanwhile (RCCL prints a version banner when a
+    # communicator is created, partly buffered until exit) goes to stderr; the JSON line is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1); os.dup2(2, 1); RESULT_FD[0] = real_stdout
+    _main()          # fd 1 stays on stderr for the rest of the process: C stdio buffers of native libraries are flushed at exit
+
+
+def _emit(line):
+    """the JSON line goes to the process's real stdout (saved in fd RESULT_FD)"""
+    sys.stdout.flush()
+    os.write(RESULT_FD[0], (line + "\n").encode())
+
+
+RESULT_FD = [1]
+
+
+def _main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
@@ -259,7 +276,7 @@ def main():
             "cost": [float(stats[0].cost_initial), float(stats[-1].cost_final)],
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        _emit(json.dumps(out))
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
