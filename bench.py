@@ -81,7 +81,7 @@ def make_cfg(binding, args, iterations, thres):
                                   pcg_fixed_iterations=args.pcg_fixed, verbose=0)
 
 
-def cpu_baseline(args, sc, thres, log):
+def cpu_baseline(args, sc, thres, log, device=0):
     """The restated CPU reference (oracle, fp64, 8 OpenMP threads in the solve like options.num_threads = 8) on a bounded
     spatial sample of the SAME workload: the voxels of a cap of the sphere, same keyframes, same configuration."""
     from oracle import oracle_py as O
@@ -104,12 +104,29 @@ def cpu_baseline(args, sc, thres, log):
                       fix_poses=0, fix_intrinsics=0, fix_distortion=0, occlusion_distance=0.02, num_observations=5, thres_shell=thres,
                       grid_level=0, rgbd_level=0, cg_fixed_iterations=-1, verbose=0)
     os.environ.setdefault("OMP_NUM_THREADS", "8")
+    before = g.export()
     t0 = time.time()
     rc, _, _, _, stats = O.optimize(g, fr, cfg, sc["intr"], sc["dist"], sc["poses"], vsh)
     dt = time.time() - t0
     g.free(); fr.free()
     if rc != 0:
         return None
+    # checker, not product: the device path on the SAME sample must assemble the same problem (row counts bit-exact, initial cost to fp32
+    # round-off) — the quantities of iteration 0 that do not depend on where an inexact PCG happens to stop
+    parity = None
+    try:
+        from intrinsic3d_amd import binding
+        with binding.Context(device) as c2:
+            c2.set_grid(sc["voxel_size"], before["keys"], before["sdf"], before["sdf_refined"], before["albedo"], before["weight"], before["color"])
+            c2.set_frames(sc["frames"], 1); c2.set_camera(sc["intr"], sc["dist"], sc["poses"]); c2.set_voxel_sh(vsh)
+            gst = c2.optimize(binding.default_config(iterations=1, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0, lambda_s1=10.0,
+                                                     lambda_a=0.1, occlusion_distance=0.02, num_observations=5, thres_shell=thres))
+        parity = {"rows_oracle": [int(x) for x in stats[0].rows], "rows_device": [int(x) for x in gst[0].rows],
+                  "rows_equal": [int(x) for x in stats[0].rows] == [int(x) for x in gst[0].rows],
+                  "cost_initial_rel_diff": abs(gst[0].cost_initial - stats[0].cost_initial) / stats[0].cost_initial}
+        log(f"cpu baseline parity on the sample: rows equal {parity['rows_equal']}, initial cost rel. diff {parity['cost_initial_rel_diff']:.2e}")
+    except Exception as e:
+        log(f"parity check on the sample failed to run: {e}")
     sec_per_iter_sample = dt / iters
     scale = keys.shape[0] / float(n)
     value = 1.0 / (sec_per_iter_sample * scale)
@@ -118,7 +135,7 @@ def cpu_baseline(args, sc, thres, log):
             "sample": f"restated CPU reference (Ceres-2.1.0-equivalent, fp64) on a {n}-voxel cap of the same grid with all {sc['K']} keyframes, "
                       f"{iters} GN iterations in {dt:.1f}s; per-iteration time scaled linearly by the voxel ratio {scale:.1f} to the full workload "
                       f"(residual collection single-threaded as in the reference, solve on 8 threads)",
-            "seconds_per_iteration_sample": sec_per_iter_sample}
+            "seconds_per_iteration_sample": sec_per_iter_sample, "parity_on_sample": parity}
 
 
 def pmc_traffic(kernel, eg_rows, active):
@@ -253,7 +270,7 @@ def _main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         try:
-            cpu = cpu_baseline(args, sc, thres, log)
+            cpu = cpu_baseline(args, sc, thres, log, local_rank)
         except Exception as e:      # the baseline is informative; never let it take the measurement down
             log(f"cpu baseline failed: {e}")
 
