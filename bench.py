@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--subvolume", type=float, default=0.08, help="SH subvolume size in metres (0.6 m object: 8 cells per axis)")
     ap.add_argument("--cpu-sample", type=float, default=1.0e6, help="stored voxels of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--carry-radius", action="store_true",
+                    help="NOT the reference's behaviour (and not the headline): carry the trust-region radius across outer iterations, as nls_solver.cpp:322-323 intends")
     ap.add_argument("--force-collectives", action="store_true",
                     help="experiments only (1 GPU): run the sharded code path through a real 1-rank RCCL communicator, to see what the collectives' launches cost per PCG pass")
     ap.add_argument("--all-kernel-timing", action="store_true", help="HIP events around every launch (kernel_ms_total for all categories; ~8 % slower)")
@@ -78,7 +80,7 @@ def make_cfg(binding, args, iterations, thres):
     return binding.default_config(iterations=iterations, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0,
                                   lambda_s1=10.0, lambda_a=0.1, fix_poses=0, fix_intrinsics=0, fix_distortion=0,
                                   occlusion_distance=0.02, num_observations=5, thres_shell=thres, grid_level=0, rgbd_level=0,
-                                  pcg_fixed_iterations=args.pcg_fixed, verbose=0)
+                                  pcg_fixed_iterations=args.pcg_fixed, verbose=0, carry_trust_radius=1 if args.carry_radius else 0)
 
 
 def cpu_baseline(args, sc, thres, log, device=0):
@@ -287,6 +289,7 @@ def _main():
                        "stored_voxels": int(arrays["keys"].shape[0]), "active_voxels": A, "rows": {"Eg": Rg, "Er": Rr, "Es": Rs, "Ea": Ra},
                        "free_parameters": sizes["free"], "keyframes": args.frames, "image": [args.width, args.height],
                        "pcg_iterations_per_step": pcg, "lm_attempts": [int(s.num_attempts) for s in stats]},
+            "carry_trust_radius": bool(args.carry_radius),
             "roofline": roofline, "kernels": kernels,
             "kernel_ms_total": {k: v[0] for k, v in timing.items()}, "kernel_launches": {k: v[1] for k, v in timing.items()},
             "time_split_ms_per_step": {"time_add": float(np.mean([s.time_add for s in stats]) * 1e3), "time_solve": float(np.mean([s.time_solve for s in stats]) * 1e3)},

@@ -102,6 +102,10 @@ typedef struct {
     /* parity / measurement controls (not in the reference) */
     int32_t pcg_fixed_iterations;  /* >=0: run exactly this many PCG iterations per LM attempt; -1: Ceres' Q-test */
     int32_t verbose;
+    int32_t carry_trust_radius;    /* extension, default 0 = the reference's ACTUAL behaviour.  1: start every outer iteration at the trust-region radius the
+                                      previous one ended with — what nls_solver.cpp:322-323 is written to do but never does (a fresh NLSSolver is
+                                      constructed per iteration, optimizer.cpp:138, so solver_info_ is always empty).  Saves the ~5 rejected LM attempts
+                                      that re-discover the radius every iteration; results then differ from the reference's. */
     int32_t fix_sdf;               /* extension: every sdf_refined block constant (BASELINE.json configs[0], "albedo-only"); the reference has
                                       no such switch — Optimizer::fixVoxelParams (optimizer.cpp:312-361) fixes per voxel only */
 } i3d_optimizer_config;

@@ -294,7 +294,7 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
 }
 
 // NLSSolver::solve on the assembled rows.  Updates the device unknowns and the host camera when a step is accepted.
-static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& p, i3d_iteration_stats* st) {
+static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& p, i3d_iteration_stats* st, double initial_radius) {
     hipStream_t s = c->stream;
     const Layout L = layout_of(c);
     const int N = c->N, K = c->K, NP = (int)L.NP, NS = L.NS;
@@ -328,7 +328,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     for (int i = 0; i < 5; ++i) xshared[6 * K + 4 + i] = c->dist[i];
     CTX_HIP(c, hipMemcpyAsync(c->d_xshared.p, xshared.data(), sizeof(double) * NS, hipMemcpyHostToDevice, s));
 
-    double radius = 1e4, decrease_factor = 2.0;
+    double radius = initial_radius, decrease_factor = 2.0;          // Ceres default 1e4 (initial_trust_region_radius)
     int invalid = 0, attempts = 0;
     if (st) { st->termination = 0; st->final_radius = radius; }
     for (int iter = 1; iter <= cfg.lm_steps; ++iter) {
@@ -390,6 +390,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
 int optimize(i3d_context* c, const i3d_optimizer_config& cfg, i3d_iteration_stats* stats) {
     if (!c->have_grid || cfg.iterations < 1) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "optimize: no grid or iterations < 1");   // optimizer.cpp:113-114
     CTX_HIP(c, hipSetDevice(c->device));
+    double carried_radius = 1e4;
     for (int itr = 0; itr < cfg.iterations; ++itr) {
         i3d_iteration_stats local; std::memset(&local, 0, sizeof(local));
         i3d_iteration_stats* st = stats ? &stats[itr] : &local;
@@ -399,7 +400,8 @@ int optimize(i3d_context* c, const i3d_optimizer_config& cfg, i3d_iteration_stat
         int rc = assemble(c, cfg, itr, p, st); if (rc) return rc;
         const double t1 = now_s();
         st->time_add = t1 - t0;
-        if (c->n_active > 0) { rc = lm_solve(c, cfg, p, st); if (rc) return rc; }
+        if (c->n_active > 0) { rc = lm_solve(c, cfg, p, st, cfg.carry_trust_radius ? carried_radius : 1e4); if (rc) return rc;
+                               if (st->final_radius > 0.0) carried_radius = st->final_radius; }
         const double t2 = now_s();
         st->time_solve = t2 - t1; st->time_build = 0.0;
         if (cfg.verbose) std::printf("[i3d] itr %d rows %lld/%lld/%lld/%lld valid %lld cost %.9e -> %.9e (add %.3f ms, solve %.3f ms)\n", itr,

@@ -25,6 +25,7 @@ typedef struct {
     int32_t cg_fixed_iterations;   /* -1 = Ceres' quadratic-model stopping rule */
     int32_t verbose;
     int32_t fix_sdf;               /* extension mirrored from the product config: all sdf blocks constant */
+    int32_t carry_trust_radius;    /* extension mirrored from the product config */
 } orc_opt_config;
 
 typedef struct {

@@ -22,7 +22,7 @@ class OptConfig(C.Structure):
                 ("fix_poses", C.c_int32), ("fix_intrinsics", C.c_int32), ("fix_distortion", C.c_int32),
                 ("occlusion_distance", C.c_float), ("num_observations", C.c_int32),
                 ("thres_shell", C.c_double), ("grid_level", C.c_int32), ("rgbd_level", C.c_int32),
-                ("cg_fixed_iterations", C.c_int32), ("verbose", C.c_int32), ("fix_sdf", C.c_int32)]
+                ("cg_fixed_iterations", C.c_int32), ("verbose", C.c_int32), ("fix_sdf", C.c_int32), ("carry_trust_radius", C.c_int32)]
 
 
 class IterStats(C.Structure):

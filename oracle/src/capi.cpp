@@ -12,7 +12,7 @@ static OptConfig to_cfg(const orc_opt_config* c) {
     o.fix_poses = c->fix_poses; o.fix_intrinsics = c->fix_intrinsics; o.fix_distortion = c->fix_distortion;
     o.occlusion_distance = c->occlusion_distance; o.num_observations = c->num_observations;
     o.thres_shell = c->thres_shell; o.grid_level = c->grid_level; o.rgbd_level = c->rgbd_level;
-    o.cg_fixed_iterations = c->cg_fixed_iterations; o.verbose = c->verbose; o.fix_sdf = c->fix_sdf;
+    o.cg_fixed_iterations = c->cg_fixed_iterations; o.verbose = c->verbose; o.fix_sdf = c->fix_sdf; o.carry_trust_radius = c->carry_trust_radius;
     return o;
 }
 

@@ -23,6 +23,7 @@ struct OptConfig {
     int iterations = 10, lm_steps = 50;
     double lambda_g = 0.2, lambda_r0 = 20.0, lambda_r1 = 160.0, lambda_s0 = 10.0, lambda_s1 = 120.0, lambda_a = 0.1;
     int fix_poses = 0, fix_intrinsics = 0, fix_distortion = 0, fix_sdf = 0;
+    int carry_trust_radius = 0;        // extension mirrored from the product (what nls_solver.cpp:322-323 intends; dead code in the reference)
     float occlusion_distance = 0.02f; int num_observations = 5;
     double thres_shell = 0.0; int grid_level = 0, rgbd_level = 0;
     int cg_fixed_iterations = -1;      // parity pinning, -1 = native Ceres stopping rule
@@ -397,7 +398,7 @@ inline void write_back(Problem& P, CameraIO& cam, const std::vector<double>& xg)
 }
 
 // Solve the assembled problem (NLSSolver::solve, nls_solver.cpp:296-367)
-inline LMSummary solve_problem(Problem& P, const OptConfig& cfg, std::vector<double>& xg, IterStats* st) {
+inline LMSummary solve_problem(Problem& P, const OptConfig& cfg, std::vector<double>& xg, IterStats* st, double initial_radius = 1e4) {
     Reduced R; build_reduced(P, cfg, R);
     const int n = (int)R.global_of.size(), m = (int)R.rows.size();
     CRS J; J.rows = m; J.cols = n; J.ptr.assign(m + 1, 0);
@@ -423,7 +424,7 @@ inline LMSummary solve_problem(Problem& P, const OptConfig& cfg, std::vector<dou
         double cs = 0.0; for (int r = 0; r < m; ++r) cs += costs[r];    // serial: thread-count independent
         *cost = cs; return true;
     };
-    LMOptions lo; lo.max_num_iterations = cfg.lm_steps; lo.stop_after_first_successful_step = true;
+    LMOptions lo; lo.max_num_iterations = cfg.lm_steps; lo.stop_after_first_successful_step = true; lo.initial_radius = initial_radius;
     lo.cg_fixed_iterations = cfg.cg_fixed_iterations; lo.verbose = cfg.verbose != 0;
     LMSummary s;
     if (n == 0 || m == 0) { s.termination = 1; return s; }
@@ -438,6 +439,7 @@ inline bool optimize(Grid<VoxelSBR>& g, const Frames& fr, CameraIO& cam, const O
                      const std::vector<double>& voxel_sh, std::vector<IterStats>* stats) {
     if (cfg.iterations < 1) return false;
     Problem P; P.bind(&g, fr.K);
+    double carried_radius = 1e4;
     for (int itr = 0; itr < cfg.iterations; ++itr) {
         const double lambda[4] = {cfg.lambda_g, varying_lambda(itr, cfg.iterations, cfg.lambda_r0, cfg.lambda_r1),
                                   varying_lambda(itr, cfg.iterations, cfg.lambda_s0, cfg.lambda_s1), cfg.lambda_a};
@@ -447,7 +449,8 @@ inline bool optimize(Grid<VoxelSBR>& g, const Frames& fr, CameraIO& cam, const O
         st.valid_voxels = P.valid_voxels;
         if (P.valid_voxels > 0) {
             normalize_weights(P, lambda);
-            LMSummary s = solve_problem(P, cfg, xg, &st);
+            LMSummary s = solve_problem(P, cfg, xg, &st, cfg.carry_trust_radius ? carried_radius : 1e4);
+            if (s.final_radius > 0.0) carried_radius = s.final_radius;
             write_back(P, cam, xg);
             st.cost_initial = s.initial_cost; st.cost_final = s.final_cost; st.lm_iterations = s.iterations;
             st.successful = s.successful_steps; st.final_radius = s.final_radius; st.termination = s.termination;

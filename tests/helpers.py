@@ -31,7 +31,7 @@ def oracle_setup(O, sc, thres_factor=2.0, sh_size=0.05, perturb=True, seed=3):
 def oracle_cfg(O, thres, **kw):
     d = dict(iterations=3, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0, lambda_s1=10.0, lambda_a=0.1,
              fix_poses=0, fix_intrinsics=0, fix_distortion=0, occlusion_distance=0.02, num_observations=5, thres_shell=thres,
-             grid_level=0, rgbd_level=0, cg_fixed_iterations=-1, verbose=0, fix_sdf=0)
+             grid_level=0, rgbd_level=0, cg_fixed_iterations=-1, verbose=0, fix_sdf=0, carry_trust_radius=0)
     d.update(kw)
     return O.OptConfig(**d)
 
@@ -43,7 +43,7 @@ def gpu_cfg(ocfg):
         lambda_s0=ocfg.lambda_s0, lambda_s1=ocfg.lambda_s1, lambda_a=ocfg.lambda_a, fix_poses=ocfg.fix_poses,
         fix_intrinsics=ocfg.fix_intrinsics, fix_distortion=ocfg.fix_distortion, occlusion_distance=ocfg.occlusion_distance,
         num_observations=ocfg.num_observations, thres_shell=ocfg.thres_shell, grid_level=ocfg.grid_level, rgbd_level=ocfg.rgbd_level,
-        pcg_fixed_iterations=ocfg.cg_fixed_iterations, verbose=ocfg.verbose, fix_sdf=ocfg.fix_sdf)
+        pcg_fixed_iterations=ocfg.cg_fixed_iterations, verbose=ocfg.verbose, fix_sdf=ocfg.fix_sdf, carry_trust_radius=ocfg.carry_trust_radius)
 
 
 def gpu_context(sc, arrays, vsh):

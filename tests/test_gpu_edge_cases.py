@@ -160,3 +160,16 @@ def test_real_rccl_collectives_with_one_rank(oracle, monkeypatch):
     assert np.abs(s1 - s0).max() <= 5e-5 * np.abs(s0).max() and np.abs(a1 - a0).max() <= 5e-5
     np.testing.assert_allclose(cam1[2], cam0[2], rtol=1e-4, atol=1e-6)
     g.free(); fr.free()
+
+
+def test_carry_trust_radius_extension(oracle):
+    """opt-in extension (what nls_solver.cpp:322-323 intends): the radius survives from one outer iteration to the next, so later iterations
+    need fewer LM attempts; device == oracle with the same switch, and the default still restarts at 1e4"""
+    sc = helpers.small_scene(seed=15, radius_vox=9, K=4, width=96, height=72)
+    thres = 2.0 * float(sc["voxel_size"])
+    rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres, carry_trust_radius=1)
+    assert rc == 0
+    _check(ref, ostats, out, gstats)
+    assert [s.num_attempts for s in gstats] == [s.n_attempts for s in ostats]
+    rc0, ref0, _, ostats0, out0, _, gstats0 = _run_both(oracle, sc, thres)
+    assert gstats[1].num_attempts <= gstats0[1].num_attempts and gstats[0].num_attempts == gstats0[0].num_attempts
