@@ -29,6 +29,7 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef const __attribute__((address_space(1))) f4u* gf4u_ptr;
 typedef const __attribute__((address_space(1))) float* gf_ptr;
 
+constexpr int Q_LDS_STRIDE = 296;      // 4 x 72 B + 8: 8-byte aligned, 74 words -> at most 2-way bank conflicts across a wave
 struct PointShared {   // per stencil point j in {000,100,010,001}; value path fp64, derivative path fp32
     double P[3];       // iso-projected world position
     double B;          // albedo * (l . H(n))
@@ -253,7 +254,10 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
             for (int j = 0; j < 9; ++j) sh[j] = g.sh[(size_t)j * N + s];
             const int cx = g.cx[s], cy = g.cy[s], cz = g.cz[s];
             const double vs = (double)g.voxel_size;
-            PointShared q[4];
+            // WITH_J: the 4 point records (72 B each) live in LDS (one 296-byte slot per lane), not in registers: the Jacobian variant is
+            // register-bound (256 VGPR + AGPR spills = one wave per SIMD) and only reads them field by field
+            PointShared qreg[WITH_J ? 1 : 4];
+            PointShared* q = WITH_J ? reinterpret_cast<PointShared*>(reinterpret_cast<char*>(frame_lds_raw) + (FR_LDS ? (size_t)p.K * sizeof(FrameHot) : 0) + (size_t)threadIdx.x * Q_LDS_STRIDE) : qreg;
             // sdf slots: 0:000 1:010 2:020 3:011 4:001 5:002 6:100 7:110 8:101 9:200 (shading_cost.h:88-97)
             shared_point(q[0], sd[0], sd[6], sd[1], sd[4], g.x_alb[idx[10]], sh, cx, cy, cz, vs);
             shared_point(q[1], sd[6], sd[9], sd[7], sd[8], g.x_alb[idx[11]], sh, cx + 1, cy, cz, vs);
@@ -367,14 +371,14 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
     if (r.nC <= 0) return;
     const int blocks = (r.nC + 255) / 256;
     double* const cost_dst = cost_out; cost_out = scratch;       // the kernels write per-workgroup partials
-    const size_t lds = (size_t)p.K * sizeof(FrameHot);
-    if (lds <= 48 * 1024) {
-        if (with_jacobian) k_build<true, true><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
-        else k_build<false, true><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
-    } else {
-        if (with_jacobian) k_build<true, false><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
-        else k_build<false, false><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
-    }
+    const size_t lds = (size_t)p.K * sizeof(FrameHot), qlds = (size_t)256 * Q_LDS_STRIDE;
+    if (with_jacobian) {
+        // point records in LDS (74 KB per workgroup), per-keyframe constants from global memory: 244 VGPRs, no AGPR spills, TWO workgroups per CU.
+        // (Measured: 2.13 -> 1.45 ms; with the keyframe constants staged in LDS as well only one workgroup fits and nothing is gained.)
+        (void)hipFuncSetAttribute((const void*)k_build<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
+        k_build<true, false><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out);
+    } else if (lds <= 48 * 1024) k_build<false, true><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
+    else k_build<false, false><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
     if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr);      // cost_dst += sum
 }
 
