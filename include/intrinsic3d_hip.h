@@ -187,6 +187,7 @@ int i3d_write_poses(const char* path, int32_t num_frames, const double* timestam
 int i3d_write_intrinsics(const char* path, int32_t width, int32_t height, const double* intr4, const double* dist5);
 int i3d_read_intrinsics(const char* path, int32_t* width, int32_t* height, double* intr4, double* dist5);
 int i3d_config_load_yaml(const char* path, i3d_refine_config* rcfg, i3d_optimizer_config* ocfg);
+int i3d_yaml_get(const char* path, const char* key, char* value, uint64_t capacity);     /* Settings::get<std::string>: any key of a flat yml */
 
 /* ---- mesh export of the resident grid (MarchingCubes<VoxelSBR>::extractSurface, MeshUtil, Mesh::save; SDFVisualization::exportMesh) -----
  * use_refined_sdf: SDFAlgorithms::applyRefinedSdf before extraction (app_intrinsic3d.cpp:170-172).  color_mode: 0 voxel colour, 1 "albedo"
@@ -197,6 +198,35 @@ int i3d_get_mesh(i3d_context* ctx, float* vertices /*[nv][3]*/, uint8_t* colors 
 int i3d_export_mesh_ply(i3d_context* ctx, const char* path, int32_t use_refined_sdf, int32_t color_mode, int32_t largest_component_only);
 int i3d_write_ply(const char* path, int64_t num_vertices, const float* vertices, const uint8_t* colors /* may be NULL */, int64_t num_faces, const int32_t* faces);
 int i3d_mc_tables(uint8_t* ntri /*[256]*/, int8_t* tri /*[256][24]*/);      /* the generated triangulation table; returns max triangles per cell */
+
+/* ---- dataset loader in front of the path.  Host code except i3d_init_frames_from_sensor.
+ * PNG: the layout cv::imdecode(IMREAD_UNCHANGED) returns — interleaved, B,G,R[,A] order, 8-bit or native-endian 16-bit, palette and
+ * 1/2/4-bit images expanded (rgbd/sensor_i3d.cpp:307-327). */
+int i3d_png_info(const uint8_t* data, uint64_t size, int32_t* width, int32_t* height, int32_t* channels, int32_t* bit_depth);
+int i3d_png_decode(const uint8_t* data, uint64_t size, void* pixels, uint64_t capacity_bytes);
+/* Intrinsic3D::init's pose conversion (intrinsic3d.cpp:189-192): camera-to-world Mat4f (row-major) -> world-to-camera Vec6 (angle-axis, t) */
+int i3d_pose_mat_to_vec6(const float* cam_to_world16, double* pose6);
+/* Sensor::create + SensorI3d::init (sensor.cpp:63-96, sensor_i3d.cpp:60-144): `frame-%06d.{color,depth}.png`, `.pose.txt`,
+ * `{depth,color}Intrinsics.txt` of `folder`; max_frames / min_depth / max_depth as in sensor.yml (0 = off) */
+typedef struct i3d_sensor i3d_sensor;
+int  i3d_sensor_open(const char* folder, int32_t max_frames, float min_depth, float max_depth, i3d_sensor** out);
+void i3d_sensor_close(i3d_sensor* s);
+int  i3d_sensor_info(const i3d_sensor* s, int32_t* num_frames, int32_t* num_loaded, int32_t* color_wh /*[2]*/, int32_t* depth_wh /*[2]*/,
+                     float* color_intr4 /* fx fy cx cy */, float* depth_intr4);
+int  i3d_sensor_color(const i3d_sensor* s, int32_t id, uint8_t* bgr /*[h][w][3]*/);          /* Sensor::color */
+int  i3d_sensor_depth(const i3d_sensor* s, int32_t id, float* depth /*[h][w] metres*/);      /* Sensor::depth: decode, 1/1000, thresholdDepth */
+int  i3d_sensor_pose(const i3d_sensor* s, int32_t id, float* cam_to_world16);
+int  i3d_sensor_set_pose(i3d_sensor* s, int32_t id, const float* cam_to_world16);
+int  i3d_sensor_set_pose_vec6(i3d_sensor* s, int32_t id, const double* pose_world_to_cam6);  /* finishRgbdLevel write-back, intrinsic3d.cpp:362-368 */
+int  i3d_sensor_save_poses(const i3d_sensor* s, const char* path);                           /* Sensor::savePoses, sensor.cpp:315-347 */
+/* KeyframeSelection::load / save / selectKeyframes (keyframe_selection.cpp:73-106,139-207); count = lines in the file even if > capacity */
+int i3d_keyframes_load(const char* path, int32_t* window_size, uint64_t capacity, double* scores, uint8_t* is_keyframe, uint64_t* count);
+int i3d_keyframes_save(const char* path, int32_t window_size, uint64_t count, const double* scores, const uint8_t* is_keyframe);
+int i3d_keyframes_select(int32_t window_size, uint64_t count, const double* scores, uint8_t* is_keyframe);
+/* Intrinsic3D::init's keyframe loop (intrinsic3d.cpp:156-193): for every keyframe decode colour + depth, resample the depth into the colour
+ * geometry and build the pyramids on the device, convert the pose; sets the frames and the camera (colour intrinsics, zero distortion) of ctx */
+int i3d_init_frames_from_sensor(i3d_context* ctx, int32_t device_ordinal, const i3d_sensor* s, uint64_t num_flags, const uint8_t* is_keyframe,
+                                int32_t num_rgbd_levels, int32_t frame_capacity, int32_t* frame_ids, int32_t* num_keyframes);
 
 /* ---- one process per GPU: the voxel state is replicated, row work / row storage / solver vectors are sharded by contiguous
  * work-list ranges; RCCL carries the PCG scalars, the camera block and the per-iteration vector exchange.  Call after i3d_create

@@ -65,8 +65,11 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_set_grid_from_tsdf_records", "i3d_recompute_colors", "i3d_clear_outside_thin_shell", "i3d_upsample", "i3d_grid_info",
            "i3d_export_grid", "i3d_refine",
            "i3d_tsdf_read_header", "i3d_tsdf_read_records", "i3d_tsdf_write", "i3d_sbr_write", "i3d_sbr_read", "i3d_write_poses",
-           "i3d_write_intrinsics", "i3d_read_intrinsics", "i3d_config_load_yaml",
+           "i3d_write_intrinsics", "i3d_read_intrinsics", "i3d_config_load_yaml", "i3d_yaml_get",
            "i3d_extract_mesh", "i3d_get_mesh", "i3d_export_mesh_ply", "i3d_write_ply", "i3d_mc_tables",
+           "i3d_png_info", "i3d_png_decode", "i3d_pose_mat_to_vec6", "i3d_sensor_open", "i3d_sensor_close", "i3d_sensor_info", "i3d_sensor_color",
+           "i3d_sensor_depth", "i3d_sensor_pose", "i3d_sensor_set_pose", "i3d_sensor_set_pose_vec6", "i3d_sensor_save_poses",
+           "i3d_keyframes_load", "i3d_keyframes_save", "i3d_keyframes_select", "i3d_init_frames_from_sensor",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
@@ -148,6 +151,24 @@ def load():
     L.i3d_write_ply.restype = i32; L.i3d_write_ply.argtypes = [cp, i64, vp, vp, i64, vp]
     L.i3d_mc_tables.restype = i32; L.i3d_mc_tables.argtypes = [vp, vp]
     L.i3d_config_load_yaml.restype = i32; L.i3d_config_load_yaml.argtypes = [cp, C.POINTER(RefineConfig), C.POINTER(OptimizerConfig)]
+    u64 = C.c_uint64; f32 = C.c_float
+    L.i3d_yaml_get.restype = i32; L.i3d_yaml_get.argtypes = [cp, cp, vp, u64]
+    L.i3d_png_info.restype = i32; L.i3d_png_info.argtypes = [vp, u64, vp, vp, vp, vp]
+    L.i3d_png_decode.restype = i32; L.i3d_png_decode.argtypes = [vp, u64, vp, u64]
+    L.i3d_pose_mat_to_vec6.restype = i32; L.i3d_pose_mat_to_vec6.argtypes = [vp, vp]
+    L.i3d_sensor_open.restype = i32; L.i3d_sensor_open.argtypes = [cp, i32, f32, f32, C.POINTER(vp)]
+    L.i3d_sensor_close.restype = None; L.i3d_sensor_close.argtypes = [vp]
+    L.i3d_sensor_info.restype = i32; L.i3d_sensor_info.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.i3d_sensor_color.restype = i32; L.i3d_sensor_color.argtypes = [vp, i32, vp]
+    L.i3d_sensor_depth.restype = i32; L.i3d_sensor_depth.argtypes = [vp, i32, vp]
+    L.i3d_sensor_pose.restype = i32; L.i3d_sensor_pose.argtypes = [vp, i32, vp]
+    L.i3d_sensor_set_pose.restype = i32; L.i3d_sensor_set_pose.argtypes = [vp, i32, vp]
+    L.i3d_sensor_set_pose_vec6.restype = i32; L.i3d_sensor_set_pose_vec6.argtypes = [vp, i32, vp]
+    L.i3d_sensor_save_poses.restype = i32; L.i3d_sensor_save_poses.argtypes = [vp, cp]
+    L.i3d_keyframes_load.restype = i32; L.i3d_keyframes_load.argtypes = [cp, vp, u64, vp, vp, vp]
+    L.i3d_keyframes_save.restype = i32; L.i3d_keyframes_save.argtypes = [cp, i32, u64, vp, vp]
+    L.i3d_keyframes_select.restype = i32; L.i3d_keyframes_select.argtypes = [i32, u64, vp, vp]
+    L.i3d_init_frames_from_sensor.restype = i32; L.i3d_init_frames_from_sensor.argtypes = [vp, i32, vp, u64, vp, i32, i32, vp, vp]
     _lib = L
     return L
 
@@ -491,6 +512,15 @@ def load_yaml_config(path):
     return rc, oc
 
 
+def yaml_get(path, key, default=None):
+    buf = C.create_string_buffer(4096)
+    rc = load().i3d_yaml_get(str(path).encode(), key.encode(), buf, 4096)
+    if rc == 1 and default is not None:
+        return default
+    _io_check(rc, f"i3d_yaml_get({key})")
+    return buf.value.decode()
+
+
 def write_ply(path, vertices, colors, faces):
     v = np.ascontiguousarray(vertices, np.float32); f = np.ascontiguousarray(faces, np.int32)
     c = None if colors is None else np.ascontiguousarray(colors, np.uint8)
@@ -532,3 +562,90 @@ def resize_depth(depth, in_intr, out_w, out_h, out_intr, device=0):
     out = np.zeros((out_h, out_w), np.float32)
     _io_check(load().i3d_resize_depth(int(device), d.shape[1], d.shape[0], _p(d), _p(a), int(out_w), int(out_h), _p(b), _p(out)), "i3d_resize_depth")
     return out
+
+
+def png_decode(data: bytes):
+    """cv::imdecode(buf, IMREAD_UNCHANGED) for PNG: HxW or HxWxC array (uint8 / uint16), colour in B,G,R[,A] order"""
+    L = load(); buf = np.frombuffer(data, np.uint8)
+    w = C.c_int32(); h = C.c_int32(); ch = C.c_int32(); bd = C.c_int32()
+    _io_check(L.i3d_png_info(_p(buf), buf.size, C.byref(w), C.byref(h), C.byref(ch), C.byref(bd)), "i3d_png_info")
+    out = np.zeros((h.value, w.value, ch.value), np.uint16 if bd.value == 16 else np.uint8)
+    _io_check(L.i3d_png_decode(_p(buf), buf.size, _p(out), out.nbytes), "i3d_png_decode")
+    return out[:, :, 0] if ch.value == 1 else out
+
+
+def pose_mat_to_vec6(cam_to_world):
+    m = np.ascontiguousarray(cam_to_world, np.float32).reshape(16); out = np.zeros(6)
+    _io_check(load().i3d_pose_mat_to_vec6(_p(m), _p(out)), "i3d_pose_mat_to_vec6")
+    return out
+
+
+def keyframes_load(path):
+    """KeyframeSelection::load -> (window_size, scores, is_keyframe)"""
+    L = load(); win = C.c_int32(0); n = C.c_uint64(0)
+    _io_check(L.i3d_keyframes_load(path.encode(), C.byref(win), 0, None, None, C.byref(n)), "i3d_keyframes_load")
+    scores = np.zeros(n.value); kf = np.zeros(n.value, np.uint8)
+    _io_check(L.i3d_keyframes_load(path.encode(), C.byref(win), n.value, _p(scores), _p(kf), C.byref(n)), "i3d_keyframes_load")
+    return win.value, scores, kf.astype(bool)
+
+
+def keyframes_save(path, window_size, scores, is_keyframe):
+    s = np.ascontiguousarray(scores, np.float64); k = np.ascontiguousarray(is_keyframe, np.uint8)
+    _io_check(load().i3d_keyframes_save(path.encode(), int(window_size), s.size, _p(s), _p(k)), "i3d_keyframes_save")
+
+
+def keyframes_select(window_size, scores):
+    s = np.ascontiguousarray(scores, np.float64); k = np.zeros(s.size, np.uint8)
+    _io_check(load().i3d_keyframes_select(int(window_size), s.size, _p(s), _p(k)), "i3d_keyframes_select")
+    return k.astype(bool)
+
+
+class Sensor:
+    """Sensor::create on an Intrinsic3D dataset folder (rgbd/sensor_i3d.cpp); decoding happens on demand, like the reference"""
+
+    def __init__(self, folder, max_frames=0, min_depth=0.0, max_depth=0.0):
+        self.L = load(); self.h = C.c_void_p()
+        _io_check(self.L.i3d_sensor_open(str(folder).encode(), int(max_frames), float(min_depth), float(max_depth), C.byref(self.h)), "i3d_sensor_open")
+        nf = C.c_int32(); nl = C.c_int32(); cwh = np.zeros(2, np.int32); dwh = np.zeros(2, np.int32); ci = np.zeros(4, np.float32); di = np.zeros(4, np.float32)
+        _io_check(self.L.i3d_sensor_info(self.h, C.byref(nf), C.byref(nl), _p(cwh), _p(dwh), _p(ci), _p(di)), "i3d_sensor_info")
+        self.num_frames, self.num_loaded = nf.value, nl.value
+        self.color_size, self.depth_size, self.color_intrinsics, self.depth_intrinsics = tuple(cwh), tuple(dwh), ci, di
+
+    def close(self):
+        if self.h:
+            self.L.i3d_sensor_close(self.h); self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def color(self, i):
+        out = np.zeros((self.color_size[1], self.color_size[0], 3), np.uint8)
+        _io_check(self.L.i3d_sensor_color(self.h, int(i), _p(out)), "i3d_sensor_color"); return out
+
+    def depth(self, i):
+        out = np.zeros((self.depth_size[1], self.depth_size[0]), np.float32)
+        _io_check(self.L.i3d_sensor_depth(self.h, int(i), _p(out)), "i3d_sensor_depth"); return out
+
+    def pose(self, i):
+        out = np.zeros((4, 4), np.float32)
+        _io_check(self.L.i3d_sensor_pose(self.h, int(i), _p(out)), "i3d_sensor_pose"); return out
+
+    def set_pose(self, i, cam_to_world):
+        m = np.ascontiguousarray(cam_to_world, np.float32)
+        _io_check(self.L.i3d_sensor_set_pose(self.h, int(i), _p(m)), "i3d_sensor_set_pose")
+
+    def set_pose_vec6(self, i, pose_world_to_cam):
+        p = np.ascontiguousarray(pose_world_to_cam, np.float64)
+        _io_check(self.L.i3d_sensor_set_pose_vec6(self.h, int(i), _p(p)), "i3d_sensor_set_pose_vec6")
+
+    def save_poses(self, path):
+        _io_check(self.L.i3d_sensor_save_poses(self.h, str(path).encode()), "i3d_sensor_save_poses")
+
+
+def init_frames_from_sensor(ctx: "Context", sensor: Sensor, is_keyframe, levels, device=0):
+    """Intrinsic3D::init's keyframe loop; returns the frame ids of the keyframes (ImageFormationModel::frame_ids)"""
+    kf = np.ascontiguousarray(is_keyframe, np.uint8); ids = np.zeros(max(1, int(kf.sum())), np.int32); nk = C.c_int32(0)
+    rc = ctx.L.i3d_init_frames_from_sensor(ctx.h, int(device), sensor.h, kf.size, _p(kf), int(levels), ids.size, _p(ids), C.byref(nk))
+    ctx._check(rc, "i3d_init_frames_from_sensor")
+    ctx.K = nk.value
+    return ids[:nk.value]

@@ -49,6 +49,19 @@ void pose_to_mat(const double* p, double R[9], double t[3]) {
     R[6] = k[2] * k[0] * v - k[1] * s; R[7] = k[2] * k[1] * v + k[0] * s; R[8] = c + k[2] * k[2] * v;
     t[0] = p[3]; t[1] = p[4]; t[2] = p[5];
 }
+// the flat `key: "value"` map the apps read through cv::FileStorage (data/*.yml): `%YAML:1.0` directive, # comments, quoted scalars
+bool read_flat_yaml(const char* path, std::map<std::string, std::string>& kv) {
+    std::ifstream f(path); if (!f.is_open()) return false;
+    std::string line;
+    auto trim = [](const std::string& s) { const char* ws = " \t\r\n\""; const size_t a = s.find_first_not_of(ws); if (a == std::string::npos) return std::string(); return s.substr(a, s.find_last_not_of(ws) - a + 1); };
+    while (std::getline(f, line)) {
+        const size_t hash = line.find('#'); if (hash != std::string::npos) line.erase(hash);
+        const size_t colon = line.find(':'); if (colon == std::string::npos || line[0] == '%') continue;
+        const std::string k = trim(line.substr(0, colon)), v = trim(line.substr(colon + 1));
+        if (!k.empty()) kv[k] = v;
+    }
+    return true;
+}
 std::string fmt_default(float v) { char b[64]; std::snprintf(b, sizeof(b), "%g", (double)v); return b; }      // operator<<(float): precision 6, %g
 
 }  // namespace
@@ -172,15 +185,8 @@ int i3d_read_intrinsics(const char* path, int32_t* width, int32_t* height, doubl
 // missing keys keep the value already in the structs (call i3d_optimizer_config_default first).
 int i3d_config_load_yaml(const char* path, i3d_refine_config* rc, i3d_optimizer_config* oc) {
     if (!path || !rc || !oc) return I3D_ERR_INVALID_ARGUMENT;
-    std::ifstream f(path); if (!f.is_open()) return I3D_ERR_IO;
-    std::map<std::string, std::string> kv; std::string line;
-    while (std::getline(f, line)) {
-        const size_t hash = line.find('#'); if (hash != std::string::npos) line.erase(hash);
-        const size_t colon = line.find(':'); if (colon == std::string::npos || line[0] == '%') continue;
-        auto trim = [](std::string s) { const char* ws = " \t\r\n\""; const size_t a = s.find_first_not_of(ws); if (a == std::string::npos) return std::string(); return s.substr(a, s.find_last_not_of(ws) - a + 1); };
-        const std::string k = trim(line.substr(0, colon)), v = trim(line.substr(colon + 1));
-        if (!k.empty()) kv[k] = v;
-    }
+    std::map<std::string, std::string> kv;
+    if (!read_flat_yaml(path, kv)) return I3D_ERR_IO;
     auto num = [&](const char* k, double& dst) { auto it = kv.find(k); if (it != kv.end() && !it->second.empty()) dst = std::atof(it->second.c_str()); };
     auto geti = [&](const char* k, int32_t& dst) { double t = dst; num(k, t); dst = (int32_t)t; };
     auto getf = [&](const char* k, float& dst) { double t = dst; num(k, t); dst = (float)t; };
@@ -193,6 +199,18 @@ int i3d_config_load_yaml(const char* path, i3d_refine_config* rc, i3d_optimizer_
     num("lambda_g", oc->lambda_g); num("lambda_r0", oc->lambda_r0); num("lambda_r1", oc->lambda_r1); num("lambda_s0", oc->lambda_s0); num("lambda_s1", oc->lambda_s1);
     num("lambda_a", oc->lambda_a); geti("iterations", oc->iterations); geti("lm_steps", oc->lm_steps);
     geti("fix_poses", oc->fix_poses); geti("fix_intrinsics", oc->fix_intrinsics); geti("fix_distortion", oc->fix_distortion);
+    return I3D_OK;
+}
+
+
+// Settings::get<std::string>(key) (the apps' accessor over cv::FileStorage): the value as text; I3D_ERR_INVALID_ARGUMENT when the key is absent
+int i3d_yaml_get(const char* path, const char* key, char* value, uint64_t capacity) {
+    if (!path || !key || !value || capacity == 0) return I3D_ERR_INVALID_ARGUMENT;
+    std::map<std::string, std::string> kv;
+    if (!read_flat_yaml(path, kv)) return I3D_ERR_IO;
+    const auto it = kv.find(key);
+    if (it == kv.end() || it->second.size() + 1 > capacity) return I3D_ERR_INVALID_ARGUMENT;
+    std::memcpy(value, it->second.c_str(), it->second.size() + 1);
     return I3D_OK;
 }
 
