@@ -228,6 +228,24 @@ int i3d_keyframes_select(int32_t window_size, uint64_t count, const double* scor
 int i3d_init_frames_from_sensor(i3d_context* ctx, int32_t device_ordinal, const i3d_sensor* s, uint64_t num_flags, const uint8_t* is_keyframe,
                                 int32_t num_rgbd_levels, int32_t frame_capacity, int32_t* frame_ids, int32_t* num_keyframes);
 
+/* ---- TSDF fusion, the stage in front of the path: AppFusion::fuseSDF's volume on the device.
+ * i3d_fusion_create    SparseVoxelGrid<Voxel>::create(voxel_size, depth_min, depth_max) + setClipBounds (app_fusion.cpp:121-139); clip6 = {x0,x1,y0,y1,z0,z1},
+ *                      all zero / NULL = no clipping; initial_capacity = expected number of allocated voxels (the table grows when needed)
+ * i3d_fusion_integrate erodeDiscontinuities(depth, erode_window) + computeNormals + SparseVoxelGrid::integrate (alloc + update) of one frame
+ *                      (app_fusion.cpp:152-166, sparse_voxel_grid.cpp:301-467); depth = Sensor::depth (metres, 0 = invalid), pose = camera-to-world
+ * i3d_fusion_finish    SDFAlgorithms::correctSDF(grid, correct_iterations) + clearInvalidVoxels (sdf/algorithms.cpp:260-366); count = saved voxels
+ * i3d_fusion_get/save  the records in the order SparseVoxelGrid::save writes them (the reference's unordered_map iteration order) */
+typedef struct i3d_fusion i3d_fusion;
+int  i3d_fusion_create(int32_t device_ordinal, float voxel_size, float depth_min, float depth_max, const float* clip6, uint64_t initial_capacity, i3d_fusion** out);
+void i3d_fusion_destroy(i3d_fusion* f);
+const char* i3d_fusion_last_error(const i3d_fusion* f);
+int  i3d_fusion_integrate(i3d_fusion* f, int32_t depth_w, int32_t depth_h, const float* depth_intr4, int32_t color_w, int32_t color_h, const float* color_intr4,
+                          const float* depth, const uint8_t* bgr, const float* pose_cam_to_world16, int32_t erode_window);
+int  i3d_fusion_finish(i3d_fusion* f, int32_t correct_iterations, uint64_t* count);
+int  i3d_fusion_info(const i3d_fusion* f, uint64_t* frames, uint64_t* allocated, uint64_t* capacity, int32_t* correct_launches);
+int  i3d_fusion_get(const i3d_fusion* f, int32_t* keys, float* sdf, float* weight, uint8_t* color);
+int  i3d_fusion_save(const i3d_fusion* f, const char* path);
+
 /* ---- one process per GPU: the voxel state is replicated, row work / row storage / solver vectors are sharded by contiguous
  * work-list ranges; RCCL carries the PCG scalars, the camera block and the per-iteration vector exchange.  Call after i3d_create
  * on every rank with the same unique id (i3d_comm_unique_id on rank 0, broadcast by the launcher, e.g. torch.distributed). */

@@ -70,6 +70,8 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_png_info", "i3d_png_decode", "i3d_pose_mat_to_vec6", "i3d_sensor_open", "i3d_sensor_close", "i3d_sensor_info", "i3d_sensor_color",
            "i3d_sensor_depth", "i3d_sensor_pose", "i3d_sensor_set_pose", "i3d_sensor_set_pose_vec6", "i3d_sensor_save_poses",
            "i3d_keyframes_load", "i3d_keyframes_save", "i3d_keyframes_select", "i3d_init_frames_from_sensor",
+           "i3d_fusion_create", "i3d_fusion_destroy", "i3d_fusion_last_error", "i3d_fusion_integrate", "i3d_fusion_finish", "i3d_fusion_info", "i3d_fusion_get",
+           "i3d_fusion_save",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
@@ -152,6 +154,14 @@ def load():
     L.i3d_mc_tables.restype = i32; L.i3d_mc_tables.argtypes = [vp, vp]
     L.i3d_config_load_yaml.restype = i32; L.i3d_config_load_yaml.argtypes = [cp, C.POINTER(RefineConfig), C.POINTER(OptimizerConfig)]
     u64 = C.c_uint64; f32 = C.c_float
+    L.i3d_fusion_create.restype = i32; L.i3d_fusion_create.argtypes = [i32, f32, f32, f32, vp, u64, C.POINTER(vp)]
+    L.i3d_fusion_destroy.restype = None; L.i3d_fusion_destroy.argtypes = [vp]
+    L.i3d_fusion_last_error.restype = C.c_char_p; L.i3d_fusion_last_error.argtypes = [vp]
+    L.i3d_fusion_integrate.restype = i32; L.i3d_fusion_integrate.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32]
+    L.i3d_fusion_finish.restype = i32; L.i3d_fusion_finish.argtypes = [vp, i32, vp]
+    L.i3d_fusion_info.restype = i32; L.i3d_fusion_info.argtypes = [vp, vp, vp, vp, vp]
+    L.i3d_fusion_get.restype = i32; L.i3d_fusion_get.argtypes = [vp, vp, vp, vp, vp]
+    L.i3d_fusion_save.restype = i32; L.i3d_fusion_save.argtypes = [vp, cp]
     L.i3d_yaml_get.restype = i32; L.i3d_yaml_get.argtypes = [cp, cp, vp, u64]
     L.i3d_png_info.restype = i32; L.i3d_png_info.argtypes = [vp, u64, vp, vp, vp, vp]
     L.i3d_png_decode.restype = i32; L.i3d_png_decode.argtypes = [vp, u64, vp, u64]
@@ -649,3 +659,53 @@ def init_frames_from_sensor(ctx: "Context", sensor: Sensor, is_keyframe, levels,
     ctx._check(rc, "i3d_init_frames_from_sensor")
     ctx.K = nk.value
     return ids[:nk.value]
+
+
+class Fusion:
+    """AppFusion::fuseSDF's volume on the device: integrate() per frame, then finish() = correctSDF + clearInvalidVoxels"""
+
+    def __init__(self, voxel_size, depth_min, depth_max, clip=None, initial_capacity=1 << 20, device=0):
+        self.L = load(); self.h = C.c_void_p()
+        c = None if clip is None else np.ascontiguousarray(clip, np.float32)
+        rc = self.L.i3d_fusion_create(int(device), float(voxel_size), float(depth_min), float(depth_max), _p(c) if c is not None else None, int(initial_capacity), C.byref(self.h))
+        if rc != 0:
+            raise I3DError(f"i3d_fusion_create failed ({rc})")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise I3DError(f"{what} failed ({rc}): {self.L.i3d_fusion_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.i3d_fusion_destroy(self.h); self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def integrate(self, depth, dcam, bgr, ccam, pose_c2w, erode_window=2):
+        d = np.ascontiguousarray(depth, np.float32); b = np.ascontiguousarray(bgr, np.uint8)
+        dc = np.ascontiguousarray(dcam, np.float32); cc = np.ascontiguousarray(ccam, np.float32); T = np.ascontiguousarray(pose_c2w, np.float32)
+        self._check(self.L.i3d_fusion_integrate(self.h, d.shape[1], d.shape[0], _p(dc), b.shape[1], b.shape[0], _p(cc), _p(d), _p(b), _p(T), int(erode_window)),
+                    "i3d_fusion_integrate")
+
+    def finish(self, correct_iterations=10):
+        n = C.c_uint64(0)
+        self._check(self.L.i3d_fusion_finish(self.h, int(correct_iterations), C.byref(n)), "i3d_fusion_finish")
+        return n.value
+
+    def info(self):
+        fr = C.c_uint64(); al = C.c_uint64(); cap = C.c_uint64(); cl = C.c_int32()
+        self._check(self.L.i3d_fusion_info(self.h, C.byref(fr), C.byref(al), C.byref(cap), C.byref(cl)), "i3d_fusion_info")
+        return dict(frames=fr.value, allocated=al.value, capacity=cap.value, correct_launches=cl.value)
+
+    def export(self):
+        n = self.finish()
+        keys = np.zeros((n, 3), np.int32); sdf = np.zeros(n, np.float32); w = np.zeros(n, np.float32); col = np.zeros((n, 3), np.uint8)
+        self._check(self.L.i3d_fusion_get(self.h, _p(keys), _p(sdf), _p(w), _p(col)), "i3d_fusion_get")
+        return dict(keys=keys, sdf=sdf, weight=w, color=col)
+
+    def save(self, path):
+        self._check(self.L.i3d_fusion_save(self.h, str(path).encode()), "i3d_fusion_save")

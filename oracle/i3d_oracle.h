@@ -84,6 +84,18 @@ int32_t orc_refine(void** grid_io, void* fr, const orc_opt_config* cfg, int32_t 
                    double thres_shell_factor, double thres_shell_factor_final, int32_t clear_distant_voxels,
                    float subvolume_size_sh, double sh_lambda_reg, double* intr, double* dist, double* poses, int32_t* levels_done);
 
+/* TSDF fusion, the stage in front of the path (sparse_voxel_grid.cpp:301-467, sdf/algorithms.cpp:260-366, app_fusion.cpp:107-200).
+ * cam = {fx, fy, cx, cy}; pose = camera-to-world 4x4 row-major; depth is Sensor::depth (thresholded, not yet eroded). */
+void*   orc_fusion_create(float voxel_size, float depth_min, float depth_max, const float* clip6 /* may be NULL */);
+void    orc_fusion_integrate(void* f, int32_t dw, int32_t dh, const float* dcam4, int32_t cw, int32_t ch, const float* ccam4,
+                             const float* depth, const uint8_t* bgr, const float* pose16, int32_t erode_window);
+void    orc_fusion_finish(void* f, int32_t correct_iterations);            /* correctSDF + clearInvalidVoxels */
+int64_t orc_fusion_size(void* f);
+void    orc_fusion_export(void* f, int32_t* keys, float* sdf, float* weight, uint8_t* color);   /* iteration (= file) order */
+void    orc_fusion_free(void* f);
+void    orc_erode_discontinuities(int32_t w, int32_t h, const float* in, int32_t window, float max_diff, float* out);
+void    orc_compute_normals(int32_t w, int32_t h, const float* cam4, const float* depth, float depth_threshold, float* normals);
+
 /* known-answer probes */
 double  orc_shading_row(int32_t vx, int32_t vy, int32_t vz, const double* sh9, double pyr_scale, double voxel_size,
                         int32_t w, int32_t h, const float* lum, const double* params29, double* J29 /* may be NULL */);

@@ -301,3 +301,42 @@ def test_cgnr(A, b, D, block_sizes, cg_fixed=-1):
     bs = np.ascontiguousarray(block_sizes, np.int32); m, n = A.shape; x = np.zeros(n)
     it = lib().orc_test_cgnr(m, n, len(bs), _p(bs), _p(A), _p(b), _p(D), int(cg_fixed), _p(x))
     return x, it
+
+
+class Fusion:
+    """AppFusion::fuseSDF on the CPU restatement: integrate frames, then finish() = correctSDF + clearInvalidVoxels"""
+
+    def __init__(self, voxel_size, depth_min, depth_max, clip=None):
+        L = lib(); L.orc_fusion_create.restype = C.c_void_p
+        c = None if clip is None else np.ascontiguousarray(clip, np.float32)
+        self.h = C.c_void_p(L.orc_fusion_create(C.c_float(voxel_size), C.c_float(depth_min), C.c_float(depth_max), None if c is None else _p(c)))
+
+    def integrate(self, depth, dcam, bgr, ccam, pose_c2w, erode_window=2):
+        d = np.ascontiguousarray(depth, np.float32); b = np.ascontiguousarray(bgr, np.uint8)
+        dc = np.ascontiguousarray(dcam, np.float32); cc = np.ascontiguousarray(ccam, np.float32); T = np.ascontiguousarray(pose_c2w, np.float32)
+        lib().orc_fusion_integrate(self.h, C.c_int32(d.shape[1]), C.c_int32(d.shape[0]), _p(dc), C.c_int32(b.shape[1]), C.c_int32(b.shape[0]), _p(cc),
+                                   _p(d), _p(b), _p(T), C.c_int32(erode_window))
+
+    def finish(self, correct_iterations=10):
+        lib().orc_fusion_finish(self.h, C.c_int32(correct_iterations))
+
+    def export(self):
+        L = lib(); L.orc_fusion_size.restype = C.c_int64
+        n = L.orc_fusion_size(self.h)
+        keys = np.zeros((n, 3), np.int32); sdf = np.zeros(n, np.float32); w = np.zeros(n, np.float32); col = np.zeros((n, 3), np.uint8)
+        L.orc_fusion_export(self.h, _p(keys), _p(sdf), _p(w), _p(col))
+        return dict(keys=keys, sdf=sdf, weight=w, color=col)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_fusion_free(self.h); self.h = None
+
+
+def erode_discontinuities(depth, window, max_diff=0.5):
+    d = np.ascontiguousarray(depth, np.float32); out = np.zeros_like(d)
+    lib().orc_erode_discontinuities(C.c_int32(d.shape[1]), C.c_int32(d.shape[0]), _p(d), C.c_int32(window), C.c_float(max_diff), _p(out)); return out
+
+
+def compute_normals(depth, cam, thr=0.3):
+    d = np.ascontiguousarray(depth, np.float32); c = np.ascontiguousarray(cam, np.float32); out = np.zeros(d.shape + (3,), np.float32)
+    lib().orc_compute_normals(C.c_int32(d.shape[1]), C.c_int32(d.shape[0]), _p(c), _p(d), C.c_float(thr), _p(out)); return out

@@ -2,6 +2,7 @@
 // extern "C" surface of the CPU restatement (see ../i3d_oracle.h).
 #include "../i3d_oracle.h"
 #include "lighting.hpp"
+#include "fusion.hpp"
 
 using namespace orc;
 
@@ -337,6 +338,37 @@ int32_t orc_test_cgnr(int32_t m, int32_t n, int32_t nblocks, const int32_t* bs, 
     M.inv.assign(off, 0.0); M.update(J, col_block, D);
     LMOptions lo; lo.cg_fixed_iterations = cg_fixed;
     return cgnr_solve(J, b, D, M, lo, x_out);
+}
+
+// ---- TSDF fusion (app_fusion.cpp:107-200)
+void* orc_fusion_create(float voxel_size, float depth_min, float depth_max, const float* clip6) {
+    auto* f = new Fusion(voxel_size, depth_min, depth_max);
+    if (clip6) for (int i = 0; i < 6; ++i) f->clip[i] = clip6[i];
+    return f;
+}
+void orc_fusion_integrate(void* fp, int32_t dw, int32_t dh, const float* dc, int32_t cw, int32_t ch, const float* cc, const float* depth, const uint8_t* bgr,
+                          const float* pose16, int32_t erode_window) {
+    auto* f = (Fusion*)fp;
+    const PinCam dcam{dc[0], dc[1], dc[2], dc[3], dw, dh}, ccam{cc[0], cc[1], cc[2], cc[3], cw, ch};
+    std::vector<float> er((size_t)dw * dh), nrm((size_t)dw * dh * 3);
+    erode_discontinuities(dw, dh, depth, erode_window, 0.5f, er.data());           // processing.h:57 default max_depth_diff
+    compute_normals(dcam, er.data(), 0.3f, nrm.data());                             // processing.h:53 default depth_threshold
+    f->integrate(dcam, ccam, er.data(), bgr, nrm.data(), pose16);
+}
+void orc_fusion_finish(void* fp, int32_t iters) { auto* f = (Fusion*)fp; f->correct_sdf((unsigned)iters); f->clear_invalid(); }
+int64_t orc_fusion_size(void* fp) { return (int64_t)((Fusion*)fp)->grid.size(); }
+void orc_fusion_export(void* fp, int32_t* keys, float* sdf, float* weight, uint8_t* color) {
+    auto& g = ((Fusion*)fp)->grid; size_t i = 0;
+    for (auto it = g.data.begin(); it != g.data.end(); ++it, ++i) {
+        keys[3 * i] = it->first.x; keys[3 * i + 1] = it->first.y; keys[3 * i + 2] = it->first.z;
+        sdf[i] = it->second.sdf; weight[i] = it->second.weight;
+        for (int c = 0; c < 3; ++c) color[3 * i + c] = it->second.color[c];
+    }
+}
+void orc_fusion_free(void* fp) { delete (Fusion*)fp; }
+void orc_erode_discontinuities(int32_t w, int32_t h, const float* in, int32_t window, float max_diff, float* out) { erode_discontinuities(w, h, in, window, max_diff, out); }
+void orc_compute_normals(int32_t w, int32_t h, const float* c, const float* depth, float thr, float* normals) {
+    compute_normals(PinCam{c[0], c[1], c[2], c[3], w, h}, depth, thr, normals);
 }
 
 }  // extern "C"

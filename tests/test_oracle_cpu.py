@@ -206,3 +206,33 @@ def test_pyramid_restatement_against_numpy(oracle):
     assert np.array_equal(oracle.depth_down(d), synthetic.depth_down(d))
     const = np.full((20, 24), 0.37, np.float32)
     np.testing.assert_allclose(oracle.pyr_down(const), 0.37, rtol=0, atol=1e-7)                          # the kernel sums to 1, borders reflected
+
+
+def test_oracle_fusion_reconstructs_the_scene(oracle):
+    """the restated SparseVoxelGrid::integrate / correctSDF / clearInvalidVoxels on rendered frames of the synthetic sphere: the fused
+    projective TSDF agrees with the scene's distance field near the surface, never-seen blocks are removed, colours are averaged"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_dataset import pose_vec_to_cam_to_world
+    from intrinsic3d_amd import synthetic
+    sc = synthetic.make_scene(radius_vox=12, K=6, width=128, height=96, levels=1, seed=3)
+    f = oracle.Fusion(sc["voxel_size"], 0.1, 10.0)
+    for fr, pose in zip(sc["frames"], sc["poses"]):
+        f.integrate(fr["depth"][0], sc["intr"], fr["bgr"][0], sc["intr"], pose_vec_to_cam_to_world(np.asarray(pose, np.float64)), 2)
+    raw = f.export()
+    f.finish(10)
+    vol = f.export()
+    assert len(vol["sdf"]) == int((raw["weight"] > 0).sum()) and (vol["weight"] > 0).all()
+    assert np.array_equal(vol["keys"], raw["keys"][raw["weight"] > 0])                  # erase keeps the order of the survivors
+    truth = {tuple(k): s for k, s in zip(sc["keys"], sc["sdf"])}
+    err = np.array([abs(truth[tuple(k)] - s) for k, s in zip(vol["keys"], vol["sdf"]) if tuple(k) in truth and abs(truth[tuple(k)]) < 2 * sc["voxel_size"]])
+    assert len(err) > 2000 and err.mean() < 0.6 * sc["voxel_size"]
+    assert np.abs(vol["sdf"]).max() <= 5 * np.float32(sc["voxel_size"]) * 1.8            # truncation band (correctSDF may push values past it by a diagonal)
+    assert vol["color"].max() > 100 and (vol["color"][:, 0] == vol["color"][:, 1]).all()   # grey frames -> grey voxels
+    # erosion and normals on a frame: eroded pixels are a subset, normals are unit or zero and face the camera
+    d = sc["frames"][0]["depth"][0]
+    e = oracle.erode_discontinuities(d, 2)
+    assert ((e == 0) | (e == d)).all() and 0 < (e > 0).sum() < (d > 0).sum()
+    n = oracle.compute_normals(e, sc["intr"])
+    ln = np.linalg.norm(n, axis=-1)
+    assert ((ln == 0) | (np.abs(ln - 1) < 1e-5)).all() and (n[..., 2][ln > 0] < 0).mean() > 0.99
