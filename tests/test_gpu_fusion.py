@@ -101,3 +101,31 @@ def test_fusion_errors():
         assert f.finish() == 0 and f.export()["keys"].shape == (0, 3)                    # nothing integrated
         with pytest.raises(B.I3DError):
             f.integrate(np.zeros((4, 4), np.float32), [1, 1, 0, 0], np.zeros((4, 4, 3), np.uint8), [1, 1, 0, 0], np.eye(4, dtype=np.float32))
+
+
+def test_app_fusion_then_app_intrinsic3d(oracle, tmp_path):
+    """the two CLIs back to back on a dataset folder in the reference's layout: app_fusion's volume is byte-identical to the oracle's fusion of
+    the same decoded frames, and app_intrinsic3d refines it"""
+    import subprocess
+    from intrinsic3d_amd import binding as B, synthetic
+    import make_dataset
+    sc = synthetic.make_scene(radius_vox=14, K=6, width=128, height=96, levels=1, seed=9, pose_noise=(0.0005, 0.001), lum_noise=0.003)
+    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=1, rgbd_levels=1, iterations=1)
+    tsdf = tmp_path / "fusion" / f"volume_{float(sc['voxel_size']):g}.tsdf"
+    tsdf.unlink()                                                                     # the analytic volume the writer leaves: app_fusion must produce its own
+    for name in ("app_fusion", "app_intrinsic3d"):
+        assert os.path.exists(os.path.join(ROOT, "apps", name)), f"apps/{name} has not been built (run __graft_entry__.build())"
+    r = subprocess.run([os.path.join(ROOT, "apps", "app_fusion"), "-s", s_yml, "-f", str(tmp_path / "fusion.yml")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "integrating frame 5" in r.stdout, r.stdout + r.stderr
+    vol = B.tsdf_read(str(tsdf))
+    sensor = B.Sensor(tmp_path / "rgbd", 0, 0.1, 10.0)
+    o = oracle.Fusion(sc["voxel_size"], 0.1, 10.0, np.zeros(6, np.float32))
+    for i in range(sensor.num_frames):
+        o.integrate(sensor.depth(i), sensor.depth_intrinsics, sensor.color(i), sensor.color_intrinsics, sensor.pose(i), 2)
+    o.finish(10); ref = o.export()
+    for k in ("keys", "sdf", "weight", "color"):
+        assert np.array_equal(vol[k], ref[k]), k
+    assert (tmp_path / "fusion" / f"mesh_{float(sc['voxel_size']):g}.ply").stat().st_size > 10000
+    r = subprocess.run([os.path.join(ROOT, "apps", "app_intrinsic3d"), "-s", s_yml, "-i", i_yml], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "intrinsic3d" / "mesh_g0_p0_albedo.ply").stat().st_size > 10000 and (tmp_path / "intrinsic3d" / "poses_g0_p0.txt").exists()

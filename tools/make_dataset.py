@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Write a synthetic scene in the reference's on-disk dataset layout, ready for apps/app_intrinsic3d:
 
-    <out>/sensor.yml  <out>/intrinsic3d.yml
+    <out>/sensor.yml  <out>/intrinsic3d.yml  <out>/fusion.yml
     <out>/rgbd/frame-%06d.{color,depth}.png  .pose.txt  colorIntrinsics.txt  depthIntrinsics.txt      (rgbd/sensor_i3d.cpp:184-220)
     <out>/fusion/keyframes.txt  <out>/fusion/volume_<voxel size>.tsdf                                  (what AppKeyframes / AppFusion leave)
 
-    python tools/make_dataset.py --out /tmp/ds --radius 40 --frames 12 && apps/app_intrinsic3d -s /tmp/ds/sensor.yml -i /tmp/ds/intrinsic3d.yml
+    python tools/make_dataset.py --out /tmp/ds --radius 40 --frames 12
+    apps/app_fusion -s /tmp/ds/sensor.yml -f /tmp/ds/fusion.yml            # optional: replaces the analytic volume by one fused from the frames
+    apps/app_intrinsic3d -s /tmp/ds/sensor.yml -i /tmp/ds/intrinsic3d.yml
 """
 import argparse, os, sys
 import numpy as np
@@ -51,6 +53,10 @@ def write_dataset(out, sc, window=1, grid_levels=2, rgbd_levels=2, iterations=2,
     vals.update(cfg)
     with open(os.path.join(out, "intrinsic3d.yml"), "w") as f:
         f.write("%YAML:1.0\n\n# Intrinsic3D config\n" + "".join(f'{k}: "{v}"\n' for k, v in vals.items()))
+    with open(os.path.join(out, "fusion.yml"), "w") as f:                  # data/fusion.yml of the reference; all-zero clip bounds = no clipping
+        f.write('%YAML:1.0\n\n# sdf fusion config\nkeyframes: ""\n' + f'voxel_size: "{float(sc["voxel_size"]):g}"\ndiscont_window_size: "2"\n'
+                + "".join(f'clip_{a}: "0.0"\n' for a in ("x0", "x1", "y0", "y1", "z0", "z1"))
+                + f'output_mesh: "./fusion/mesh_{float(sc["voxel_size"]):g}.ply"\noutput_sdf: "{tsdf}"\n')
     return os.path.join(out, "sensor.yml"), os.path.join(out, "intrinsic3d.yml")
 
 
