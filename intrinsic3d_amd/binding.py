@@ -74,7 +74,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_fusion_save",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
-           "i3d_debug_assemble", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
+           "i3d_debug_assemble", "i3d_debug_map_order", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
            "i3d_debug_normal_eq", "i3d_debug_jtj_apply"]
 
 _lib = None
@@ -162,6 +162,7 @@ def load():
     L.i3d_fusion_info.restype = i32; L.i3d_fusion_info.argtypes = [vp, vp, vp, vp, vp]
     L.i3d_fusion_get.restype = i32; L.i3d_fusion_get.argtypes = [vp, vp, vp, vp, vp]
     L.i3d_fusion_save.restype = i32; L.i3d_fusion_save.argtypes = [vp, cp]
+    L.i3d_debug_map_order.restype = i64; L.i3d_debug_map_order.argtypes = [vp, i64, i32, vp]
     L.i3d_yaml_get.restype = i32; L.i3d_yaml_get.argtypes = [cp, cp, vp, u64]
     L.i3d_png_info.restype = i32; L.i3d_png_info.argtypes = [vp, u64, vp, vp, vp, vp]
     L.i3d_png_decode.restype = i32; L.i3d_png_decode.argtypes = [vp, u64, vp, u64]
@@ -709,3 +710,9 @@ class Fusion:
 
     def save(self, path):
         self._check(self.L.i3d_fusion_save(self.h, str(path).encode()), "i3d_fusion_save")
+
+
+def debug_map_order(keys, mode=0):
+    k = np.ascontiguousarray(keys, np.int32); out = np.zeros(k.shape[0], np.int32)
+    n = load().i3d_debug_map_order(_p(k), k.shape[0], int(mode), _p(out))
+    return out[:n]

@@ -21,6 +21,9 @@ __device__ inline unsigned long long pack_key(int x, int y, int z) {
 __device__ inline void unpack_key(unsigned long long k, int& x, int& y, int& z) {
     x = (int)(k & 0x1FFFFFull) - FUSION_COORD_OFFSET; y = (int)((k >> 21) & 0x1FFFFFull) - FUSION_COORD_OFFSET; z = (int)((k >> 42) & 0x1FFFFFull) - FUSION_COORD_OFFSET;
 }
+// Home slot: a multiplicative hash of the packed key.  (A brick-local layout — 512 contiguous slots per 8x8x8 brick — was measured and
+// rejected: the surface shell fills long runs of such a group, colliding bricks then probe linearly through hundreds of occupied slots,
+// and both allocation and correctSDF became ~40x slower.)
 __device__ inline unsigned long long slot_of(unsigned long long key, unsigned long long mask) { return ((key * 0x9E3779B97F4A7C15ull) >> 17) & mask; }
 __device__ inline long long find_slot(const FusionTable& t, unsigned long long key) {
     unsigned long long s = slot_of(key, t.mask);
@@ -109,6 +112,7 @@ __global__ void k_alloc(FusionTable t, FusionFrame f, FusionCam cam, const float
     const float ray_step = f.voxel_size * 0.25f, inv_vs = 1.0f / f.voxel_size;
     const unsigned long long pixel = (unsigned long long)y * cam.w + x;
     int lx = 0, ly = 0, lz = 0; unsigned step = 0;
+    int qx = 0, qy = 0, qz = 0; bool have_block = false;          // centre of the last 3x3x3 block this lane made sure exists
     for (float d_off = -f.truncation; d_off <= f.truncation; d_off += ray_step, ++step) {
         const float s = d + d_off;
         float pw[3]; xform(f.c2w, pcx * s, pcy * s, pcz * s, pw);
@@ -123,6 +127,8 @@ __global__ void k_alloc(FusionTable t, FusionFrame f, FusionCam cam, const float
         const unsigned long long base = (f.frame << 41) | (pixel << 13) | ((unsigned long long)(step & 0xFF) << 5);
         int blk = 0;
         for (int bz = -1; bz <= 1; ++bz) for (int by = -1; by <= 1; ++by) for (int bx = -1; bx <= 1; ++bx, ++blk) {
+            // a cell of the previous block exists already and carries a rank no larger than this one
+            if (have_block && abs(gx + bx - qx) <= 1 && abs(gy + by - qy) <= 1 && abs(gz + bz - qz) <= 1) continue;
             const unsigned long long key = pack_key(gx + bx, gy + by, gz + bz), my_rank = base | (unsigned long long)blk;
             unsigned long long sl = slot_of(key, t.mask);
             for (;;) {
@@ -136,6 +142,7 @@ __global__ void k_alloc(FusionTable t, FusionFrame f, FusionCam cam, const float
                 sl = (sl + 1) & t.mask;
             }
         }
+        qx = gx; qy = gy; qz = gz; have_block = true;
     }
 }
 
@@ -211,13 +218,14 @@ __global__ void k_positions(long long m, const unsigned int* slot_sorted, const 
 // correctSDF's sweep is an in-place Gauss-Seidel pass in iteration order: voxel v sees the NEW value of neighbours visited before it and
 // the OLD value of the others.  The sequential result is the unique fixed point of  cur[v] = F(v; cur[nb < v], old[nb > v]),  so the
 // kernel is relaunched on `cur` until a launch changes nothing (voxel number k is final after at most k launches; in practice a handful).
-__global__ void k_correct(FusionTable t, long long m, float voxel_size, const unsigned int* __restrict__ visit_slot, const int* __restrict__ pos_of_slot,
-                          float* cur, unsigned char* upd, int* changed) {
-    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (v >= m) return;
-    const unsigned int s = visit_slot[v];
-    if (!(t.weight[s] > 0.0f)) return;
-    int gx, gy, gz; unpack_key(t.keys[s], gx, gy, gz);
+// Lanes walk the table in slot order (a brick's voxels are neighbours in memory), not in visit order.
+__global__ void k_correct(FusionTable t, float voxel_size, const int* __restrict__ pos_of_slot, float* cur, unsigned char* upd, int* changed) {
+    const unsigned long long s = (unsigned long long)blockIdx.x * TPB + threadIdx.x;
+    if (s > t.mask) return;
+    const unsigned long long key = t.keys[s];
+    if (key == FUSION_EMPTY || !(t.weight[s] > 0.0f)) return;
+    const int v = pos_of_slot[s];
+    int gx, gy, gz; unpack_key(key, gx, gy, gz);
     const float cx = (float)gx * voxel_size, cy = (float)gy * voxel_size, cz = (float)gz * voxel_size;
     const float old_f = t.sdf[s];
     const double sdf = (double)old_f, sgn = sdf >= 0.0 ? 1.0 : -1.0;
@@ -234,11 +242,10 @@ __global__ void k_correct(FusionTable t, long long m, float voxel_size, const un
     upd[s] = updated ? 1 : 0;
     if (__float_as_uint(cur[s]) != __float_as_uint(res)) { cur[s] = res; *changed = 1; }
 }
-__global__ void k_commit(FusionTable t, long long m, const unsigned int* visit_slot, const float* cur, const unsigned char* upd, int* has_update) {
-    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (v >= m) return;
-    const unsigned int s = visit_slot[v];
-    if (!(t.weight[s] > 0.0f)) return;
+__global__ void k_commit(FusionTable t, const float* cur, const unsigned char* upd, int* has_update) {
+    const unsigned long long s = (unsigned long long)blockIdx.x * TPB + threadIdx.x;
+    if (s > t.mask) return;
+    if (t.keys[s] == FUSION_EMPTY || !(t.weight[s] > 0.0f)) return;
     if (upd[s]) { t.sdf[s] = cur[s]; t.weight[s] = 1.0f; *has_update = 1; }
 }
 __global__ void k_valid(FusionTable t, long long m, const unsigned int* visit_slot, int* flags) {
@@ -285,11 +292,11 @@ void launch_fusion_keys(hipStream_t st, FusionTable t, long long m, const unsign
 void launch_fusion_positions(hipStream_t st, long long m, const unsigned int* slot_sorted, const int* order, unsigned int* visit_slot, int* pos_of_slot) {
     if (m > 0) hipLaunchKernelGGL(k_positions, blocks(m), TPB, 0, st, m, slot_sorted, order, visit_slot, pos_of_slot);
 }
-void launch_fusion_correct(hipStream_t st, FusionTable t, long long m, float voxel_size, const unsigned int* visit_slot, const int* pos_of_slot, float* cur, unsigned char* upd, int* changed) {
-    if (m > 0) hipLaunchKernelGGL(k_correct, blocks(m), TPB, 0, st, t, m, voxel_size, visit_slot, pos_of_slot, cur, upd, changed);
+void launch_fusion_correct(hipStream_t st, FusionTable t, float voxel_size, const int* pos_of_slot, float* cur, unsigned char* upd, int* changed) {
+    hipLaunchKernelGGL(k_correct, blocks(t.mask + 1), TPB, 0, st, t, voxel_size, pos_of_slot, cur, upd, changed);
 }
-void launch_fusion_commit(hipStream_t st, FusionTable t, long long m, const unsigned int* visit_slot, const float* cur, const unsigned char* upd, int* has_update) {
-    if (m > 0) hipLaunchKernelGGL(k_commit, blocks(m), TPB, 0, st, t, m, visit_slot, cur, upd, has_update);
+void launch_fusion_commit(hipStream_t st, FusionTable t, const float* cur, const unsigned char* upd, int* has_update) {
+    hipLaunchKernelGGL(k_commit, blocks(t.mask + 1), TPB, 0, st, t, cur, upd, has_update);
 }
 void launch_fusion_valid(hipStream_t st, FusionTable t, long long m, const unsigned int* visit_slot, int* flags) {
     if (m > 0) hipLaunchKernelGGL(k_valid, blocks(m), TPB, 0, st, t, m, visit_slot, flags);

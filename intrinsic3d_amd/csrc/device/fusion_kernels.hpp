@@ -35,8 +35,8 @@ void launch_fusion_occupied(hipStream_t st, FusionTable t, int* flags);
 void launch_fusion_gather_rank(hipStream_t st, FusionTable t, const int* flags, const int* offsets, unsigned long long* rank, unsigned int* slot);
 void launch_fusion_keys(hipStream_t st, FusionTable t, long long m, const unsigned int* slot_sorted, int* kxyz);
 void launch_fusion_positions(hipStream_t st, long long m, const unsigned int* slot_sorted, const int* order, unsigned int* visit_slot, int* pos_of_slot);
-void launch_fusion_correct(hipStream_t st, FusionTable t, long long m, float voxel_size, const unsigned int* visit_slot, const int* pos_of_slot, float* cur, unsigned char* upd, int* changed);
-void launch_fusion_commit(hipStream_t st, FusionTable t, long long m, const unsigned int* visit_slot, const float* cur, const unsigned char* upd, int* has_update);
+void launch_fusion_correct(hipStream_t st, FusionTable t, float voxel_size, const int* pos_of_slot, float* cur, unsigned char* upd, int* changed);
+void launch_fusion_commit(hipStream_t st, FusionTable t, const float* cur, const unsigned char* upd, int* has_update);
 void launch_fusion_valid(hipStream_t st, FusionTable t, long long m, const unsigned int* visit_slot, int* flags);
 void launch_fusion_export(hipStream_t st, FusionTable t, long long m, const unsigned int* visit_slot, const int* flags, const int* offsets, int* kxyz, float* sdf, float* weight, uint8_t* rgb);
 

@@ -3,11 +3,12 @@
 //   i3d_fusion_finish    = SDFAlgorithms::correctSDF + clearInvalidVoxels, and the reference's record order
 // Frames are integrated in call order, one allocation launch and one integration launch per frame (fusion_kernels.hip).  The saved
 // volume's record order is the iteration order of the reference's unordered_map; it is reproduced from the order of first insertion
-// (a per-voxel rank kept by the allocation kernel, radix-sorted here) by replaying the insertions into a std::unordered_map of keys with
-// the reference's hash / reserve(64) / max_load_factor(0.6) — the same host replay levels.cpp uses for the level transitions.
+// (a per-voxel rank kept by the allocation kernel, radix-sorted here) by replaying the insertions on the host (map_order.hpp) — the same replay levels.cpp uses for the level
+// transitions.
 #include "../../../include/intrinsic3d_hip.h"
 #include "../device/fusion_kernels.hpp"
 #include "context.hpp"
+#include "map_order.hpp"
 #include <rocprim/rocprim.hpp>
 #include <cmath>
 #include <cstring>
@@ -19,11 +20,6 @@
 using namespace i3d;
 
 namespace {
-
-struct Key3 { int x, y, z; bool operator==(const Key3& o) const { return x == o.x && y == o.y && z == o.z; } };
-struct Key3Hash {                                               // mat.h:117-124
-    size_t operator()(const Key3& v) const { return ((size_t)v.x * 73856093) ^ ((size_t)v.y * 19349669) ^ ((size_t)v.z * 83492791); }
-};
 
 // Matrix4f::inverse(): adjugate over determinant from the 2x2 minors of the row pairs, in float
 void inverse4f(const float* m, float* inv) {
@@ -206,12 +202,7 @@ int i3d_fusion_finish(i3d_fusion* f, int32_t correct_iterations, uint64_t* count
     std::vector<int> hk(3 * m), order; order.reserve(m);
     F_HIP(f, hipMemcpyAsync(hk.data(), kxyz.p, sizeof(int) * 3 * m, hipMemcpyDeviceToHost, st));
     F_HIP(f, hipStreamSynchronize(st));
-    {
-        std::unordered_map<Key3, int, Key3Hash> map; map.reserve(64); map.max_load_factor(0.6f);        // sparse_voxel_grid.cpp:52-53
-        for (size_t i = 0; i < m; ++i) map[Key3{hk[3 * i], hk[3 * i + 1], hk[3 * i + 2]}] = (int)i;
-        if (map.size() != m) return fail(f, I3D_ERR_STATE, "fusion: duplicate keys in the table");
-        for (auto it = map.begin(); it != map.end(); ++it) order.push_back(it->second);
-    }
+    map_iteration_order_replay(hk.data(), (size_t)m, order);                                           // keys of a hash table: distinct by construction
     DevBuf<int> d_order, pos_of_slot; DevBuf<unsigned int> visit_slot;
     F_HIP(f, d_order.alloc(m)); F_HIP(f, pos_of_slot.alloc(cap)); F_HIP(f, visit_slot.alloc(m));
     F_HIP(f, hipMemcpyAsync(d_order.p, order.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
@@ -225,14 +216,14 @@ int i3d_fusion_finish(i3d_fusion* f, int32_t correct_iterations, uint64_t* count
         F_HIP(f, hipMemsetAsync(upd.p, 0, cap, st));
         for (;;) {
             F_HIP(f, hipMemsetAsync(f->d_flag.p, 0, 2 * sizeof(int), st));
-            launch_fusion_correct(st, t, (long long)m, f->voxel_size, visit_slot.p, pos_of_slot.p, cur.p, upd.p, f->d_flag.p);
+            launch_fusion_correct(st, t, f->voxel_size, pos_of_slot.p, cur.p, upd.p, f->d_flag.p);
             int changed = 0;
             F_HIP(f, hipMemcpyAsync(&changed, f->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
             F_HIP(f, hipStreamSynchronize(st));
             ++f->correct_launches;
             if (!changed) break;
         }
-        launch_fusion_commit(st, t, (long long)m, visit_slot.p, cur.p, upd.p, f->d_flag.p + 1);
+        launch_fusion_commit(st, t, cur.p, upd.p, f->d_flag.p + 1);
         int has_update = 0;
         F_HIP(f, hipMemcpyAsync(&has_update, f->d_flag.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
         F_HIP(f, hipStreamSynchronize(st));

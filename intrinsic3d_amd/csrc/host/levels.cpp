@@ -5,27 +5,17 @@
 // reserve(64), max_load_factor 0.6: sparse_voxel_grid.cpp:52-53) and several results depend on that container's ITERATION order.
 // Erasing keeps the relative order, so sparsification is a stable filter; upsampling and the initial Voxel -> VoxelSBR conversion
 // build NEW maps, whose iteration order is a property of libstdc++'s container given the insertion sequence.  That order is
-// obtained here by giving the same key sequence to the same standard container (keys only — no voxel payload, no reference code).
+// obtained by replaying the container's list operations on the same key sequence (map_order.hpp; keys only, no voxel payload).
 #include "context.hpp"
 #include "../device/level_kernels.hpp"
 #include <rocprim/rocprim.hpp>
-#include <unordered_map>
+#include "map_order.hpp"
 
 namespace i3d {
 
 namespace {
-struct Key3 { int x, y, z; bool operator==(const Key3& o) const { return x == o.x && y == o.y && z == o.z; } };
-struct Key3Hash { size_t operator()(const Key3& v) const {      // the reference's std::hash<Vec3i>: int -> size_t sign-extends (mat.h:117-124)
-    return ((size_t)v.x * (size_t)73856093) ^ ((size_t)v.y * (size_t)19349669) ^ ((size_t)v.z * (size_t)83492791); } };
-typedef std::unordered_map<Key3, int, Key3Hash> OrderMap;
-
 // iteration order of a map filled with `keys` (insertion sequence 0..n-1): out[v] = insertion index of the v-th visited key
-void map_iteration_order(const int* keys, size_t n, std::vector<int>& out) {
-    OrderMap m; m.reserve(64); m.max_load_factor(0.6f);
-    for (size_t i = 0; i < n; ++i) m[Key3{keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]}] = (int)i;
-    out.clear(); out.reserve(m.size());
-    for (auto it = m.begin(); it != m.end(); ++it) out.push_back(it->second);
-}
+void map_iteration_order(const int* keys, size_t n, std::vector<int>& out) { map_iteration_order_replay(keys, n, out, false); }
 
 OptParams color_params(const i3d_context* c, float occlusion) {
     OptParams p; std::memset(&p, 0, sizeof(p));
@@ -113,6 +103,15 @@ using namespace i3d;
 
 extern "C" {
 
+// parity probe: the replayed iteration order (mode 0: keys may repeat, 1: caller guarantees distinct keys) or the order of a real
+// std::unordered_map (mode 2); returns the number of visited elements
+int64_t i3d_debug_map_order(const int32_t* keys, int64_t n, int32_t mode, int32_t* order) {
+    if (n < 0 || (n && (!keys || !order))) return -1;
+    std::vector<int> o;
+    if (mode == 2) map_iteration_order_stl(keys, (size_t)n, o); else map_iteration_order_replay(keys, (size_t)n, o, mode == 1);
+    for (size_t i = 0; i < o.size(); ++i) order[i] = o[i];
+    return (int64_t)o.size();
+}
 int i3d_recompute_colors(i3d_context* c, float occlusion_distance, int32_t num_observations) {
     if (!c) return I3D_ERR_INVALID_ARGUMENT;
     return recompute_colors(c, occlusion_distance, num_observations);
@@ -210,16 +209,15 @@ int i3d_export_grid(i3d_context* c, int32_t* keys, double* sdf, double* sdf_refi
 int i3d_set_grid_from_tsdf_records(i3d_context* c, float voxel_size, int64_t n, const int32_t* keys, const float* sdf, const float* weight, const uint8_t* color) {
     if (!c || n <= 0 || !keys || !sdf || !weight || !color) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_grid_from_tsdf_records: bad arguments");
     // map 1: file order -> Voxel map (later records with the same key overwrite the payload, the node keeps its place)
-    OrderMap m1; m1.reserve(64); m1.max_load_factor(0.6f);
-    for (int64_t i = 0; i < n; ++i) m1[Key3{keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]}] = (int)i;
-    std::vector<int> o1; o1.reserve(m1.size());
-    for (auto it = m1.begin(); it != m1.end(); ++it) o1.push_back(it->second);
+    std::vector<int> o1;
+    map_iteration_order_replay(keys, (size_t)n, o1, false);
     // map 2: VoxelSBR map filled in that order; invalid voxels (weight <= 0) are erased afterwards (order of the rest is unchanged)
-    OrderMap m2; m2.reserve(64); m2.max_load_factor(0.6f);
-    for (int i : o1) m2[Key3{keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2]}] = i;
+    std::vector<int> k2(3 * o1.size()), o2;
+    for (size_t v = 0; v < o1.size(); ++v) for (int a = 0; a < 3; ++a) k2[3 * v + a] = keys[3 * (size_t)o1[v] + a];
+    map_iteration_order_replay(k2.data(), o1.size(), o2, true);
     std::vector<int32_t> k; std::vector<double> s, a; std::vector<float> w; std::vector<uint8_t> col;
-    for (auto it = m2.begin(); it != m2.end(); ++it) {
-        const size_t i = (size_t)it->second;
+    for (size_t v = 0; v < o2.size(); ++v) {
+        const size_t i = (size_t)o1[(size_t)o2[v]];
         if (!(weight[i] > 0.0f)) continue;
         k.push_back(keys[3 * i]); k.push_back(keys[3 * i + 1]); k.push_back(keys[3 * i + 2]);
         s.push_back((double)sdf[i]); a.push_back(0.6); w.push_back(weight[i]);

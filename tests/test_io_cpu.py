@@ -176,3 +176,24 @@ def test_write_ply_bytes(tmp_path):
     assert body == b"".join(struct.pack("<fffBBB", *v[i].tolist(), *c[i].tolist()) for i in range(4)) + b"".join(struct.pack("<Biii", 3, *f[i].tolist()) for i in range(2))
     binding.write_ply(tmp_path / "nc.ply", v, None, f)                      # without colours: 12 bytes per vertex
     assert len(open(tmp_path / "nc.ply", "rb").read().split(b"end_header\n", 1)[1]) == 4 * 12 + 2 * 13
+
+
+def test_map_order_replay_matches_the_standard_container():
+    """host/map_order.hpp replays libstdc++'s unordered_map list operations on index arrays; it must visit the elements exactly like a real
+    std::unordered_map with the reference's hash / reserve(64) / max_load_factor(0.6) — at every size around the rehash points, with repeated
+    keys (operator[] overwrites the payload, the node keeps its place) and at a size with many rehashes"""
+    from intrinsic3d_amd import binding as B
+    rng = np.random.default_rng(0)
+    grid = np.stack(np.meshgrid(np.arange(-40, 40), np.arange(-35, 45), np.arange(-3, 60), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    rng.shuffle(grid)
+    for n in list(range(0, 200)) + [1000, 4096, 65537, len(grid)]:
+        k = grid[:n]
+        ref = B.debug_map_order(k, 2)
+        assert len(ref) == n
+        assert np.array_equal(B.debug_map_order(k, 0), ref) and np.array_equal(B.debug_map_order(k, 1), ref), n
+    dup = grid[rng.integers(0, 5000, 30000)]                                  # ~5000 distinct keys, each repeated ~6 times
+    ref = B.debug_map_order(dup, 2)
+    assert len(ref) == len(np.unique(dup, axis=0)) and np.array_equal(B.debug_map_order(dup, 0), ref)
+    # negative coordinates hash through sign extension (mat.h:117-124): the order differs from the one of their absolute values
+    neg = grid[:5000].copy(); neg[:, 0] -= 100
+    assert np.array_equal(B.debug_map_order(neg, 0), B.debug_map_order(neg, 2))
