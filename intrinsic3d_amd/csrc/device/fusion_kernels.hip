@@ -215,38 +215,74 @@ __global__ void k_positions(long long m, const unsigned int* slot_sorted, const 
     visit_slot[v] = s; pos_of_slot[s] = (int)v;
 }
 
-// correctSDF's sweep is an in-place Gauss-Seidel pass in iteration order: voxel v sees the NEW value of neighbours visited before it and
-// the OLD value of the others.  The sequential result is the unique fixed point of  cur[v] = F(v; cur[nb < v], old[nb > v]),  so the
-// kernel is relaunched on `cur` until a launch changes nothing (voxel number k is final after at most k launches; in practice a handful).
-// Lanes walk the table in slot order (a brick's voxels are neighbours in memory), not in visit order.
-__global__ void k_correct(FusionTable t, float voxel_size, const int* __restrict__ pos_of_slot, float* cur, unsigned char* upd, int* changed) {
-    const unsigned long long s = (unsigned long long)blockIdx.x * TPB + threadIdx.x;
-    if (s > t.mask) return;
-    const unsigned long long key = t.keys[s];
-    if (key == FUSION_EMPTY || !(t.weight[s] > 0.0f)) return;
-    const int v = pos_of_slot[s];
-    int gx, gy, gz; unpack_key(key, gx, gy, gz);
-    const float cx = (float)gx * voxel_size, cy = (float)gy * voxel_size, cz = (float)gz * voxel_size;
-    const float old_f = t.sdf[s];
-    const double sdf = (double)old_f, sgn = sdf >= 0.0 ? 1.0 : -1.0;
-    float res = old_f; bool updated = false;
+// ---- correctSDF (sdf/algorithms.cpp:260-331) ----------------------------------------------------------------------------------
+// The sweep is an in-place Gauss-Seidel pass in iteration order: voxel v sees the NEW value of neighbours visited before it and the
+// OLD value of the others.  The sequential result is the unique fixed point of  cur[v] = F(v; cur[nb < v], old[nb > v]),  so k_correct is
+// relaunched on `cur` until a launch changes nothing (voxel number k is final after at most k launches; in practice about ten).
+// Hash probing 26 neighbours per voxel per launch costs 43 ms on 14M voxels (random 64-byte lines); instead the allocated voxels are
+// sorted once by (brick, cell) so that spatial neighbours are neighbours in memory, the 26 neighbour indices are resolved once into a
+// [26][m] table, and every launch is a coalesced read of that table plus short-range gathers.
+__global__ void k_spatial_keys(FusionTable t, long long m, const unsigned int* slots, unsigned long long* skey) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= m) return;
+    const unsigned long long k = t.keys[slots[i]];
+    const unsigned long long x = k & 0x1FFFFFull, y = (k >> 21) & 0x1FFFFFull, z = (k >> 42) & 0x1FFFFFull;
+    skey[i] = ((z >> 3) << 45) | ((y >> 3) << 27) | ((x >> 3) << 9) | ((z & 7) << 6) | ((y & 7) << 3) | (x & 7);
+}
+__global__ void k_compact_init(FusionTable t, long long m, const unsigned int* slot_c, const int* pos_of_slot, int* compact_of_slot, float* c_sdf, int* c_pos,
+                               unsigned char* c_valid, unsigned char* c_touched) {
+    const long long c = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (c >= m) return;
+    const unsigned int s = slot_c[c];
+    compact_of_slot[s] = (int)c; c_sdf[c] = t.sdf[s]; c_pos[c] = pos_of_slot[s]; c_valid[c] = t.weight[s] > 0.0f; c_touched[c] = 0;
+}
+__global__ void k_build_nbr(FusionTable t, long long m, const unsigned int* slot_c, const int* compact_of_slot, const unsigned char* c_valid, int* nbr) {
+    const long long c = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (c >= m) return;
+    int gx, gy, gz; unpack_key(t.keys[slot_c[c]], gx, gy, gz);
+    int n = 0;
     for (int k = -1; k <= 1; ++k) for (int j = -1; j <= 1; ++j) for (int i = -1; i <= 1; ++i) {
         if (k == 0 && j == 0 && i == 0) continue;
-        const long long nb = find_slot(t, pack_key(gx + i, gy + j, gz + k));
-        if (nb < 0 || !(t.weight[nb] > 0.0f)) continue;
-        const double sdf_nb = (double)(pos_of_slot[nb] < v ? cur[nb] : t.sdf[nb]), sgn_nb = sdf_nb >= 0.0 ? 1.0 : -1.0;
+        int out = -1;
+        if (c_valid[c]) {
+            const long long nb = find_slot(t, pack_key(gx + i, gy + j, gz + k));
+            if (nb >= 0) { const int cn = compact_of_slot[nb]; if (c_valid[cn]) out = cn; }
+        }
+        nbr[(long long)n * m + c] = out; ++n;
+    }
+}
+__global__ void k_correct(FusionTable t, long long m, float voxel_size, const unsigned int* __restrict__ slot_c, const int* __restrict__ nbr, const int* __restrict__ c_pos,
+                          const unsigned char* __restrict__ c_valid, const float* __restrict__ c_sdf, float* c_cur, unsigned char* c_upd, int* changed) {
+    const long long c = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (c >= m || !c_valid[c]) return;
+    const int v = c_pos[c];
+    int gx, gy, gz; unpack_key(t.keys[slot_c[c]], gx, gy, gz);
+    const float cx = (float)gx * voxel_size, cy = (float)gy * voxel_size, cz = (float)gz * voxel_size;
+    const float old_f = c_sdf[c];
+    const double sdf = (double)old_f, sgn = sdf >= 0.0 ? 1.0 : -1.0;
+    float res = old_f; bool updated = false; int n = 0;
+    for (int k = -1; k <= 1; ++k) for (int j = -1; j <= 1; ++j) for (int i = -1; i <= 1; ++i) {
+        if (k == 0 && j == 0 && i == 0) continue;
+        const int nb = nbr[(long long)n * m + c]; ++n;
+        if (nb < 0) continue;
+        const double sdf_nb = (double)(c_pos[nb] < v ? c_cur[nb] : c_sdf[nb]), sgn_nb = sdf_nb >= 0.0 ? 1.0 : -1.0;
         const float dx = cx - (float)(gx + i) * voxel_size, dy = cy - (float)(gy + j) * voxel_size, dz = cz - (float)(gz + k) * voxel_size;
         const double dist_nb = sdf_nb + sgn_nb * (double)sqrtf((dx * dx + dy * dy) + dz * dz);
         if (fabs(dist_nb) < fabs(sdf) && sgn == sgn_nb) { res = (float)dist_nb; updated = true; }
     }
-    upd[s] = updated ? 1 : 0;
-    if (__float_as_uint(cur[s]) != __float_as_uint(res)) { cur[s] = res; *changed = 1; }
+    c_upd[c] = updated ? 1 : 0;
+    if (__float_as_uint(c_cur[c]) != __float_as_uint(res)) { c_cur[c] = res; *changed = 1; }
 }
-__global__ void k_commit(FusionTable t, const float* cur, const unsigned char* upd, int* has_update) {
-    const unsigned long long s = (unsigned long long)blockIdx.x * TPB + threadIdx.x;
-    if (s > t.mask) return;
-    if (t.keys[s] == FUSION_EMPTY || !(t.weight[s] > 0.0f)) return;
-    if (upd[s]) { t.sdf[s] = cur[s]; t.weight[s] = 1.0f; *has_update = 1; }
+__global__ void k_commit(long long m, const unsigned char* c_valid, const float* c_cur, const unsigned char* c_upd, float* c_sdf, unsigned char* c_touched, int* has_update) {
+    const long long c = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (c >= m || !c_valid[c]) return;
+    if (c_upd[c]) { c_sdf[c] = c_cur[c]; c_touched[c] = 1; *has_update = 1; }
+}
+__global__ void k_write_back(FusionTable t, long long m, const unsigned int* slot_c, const float* c_sdf, const unsigned char* c_touched) {
+    const long long c = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (c >= m || !c_touched[c]) return;
+    const unsigned int s = slot_c[c];
+    t.sdf[s] = c_sdf[c]; t.weight[s] = 1.0f;
 }
 __global__ void k_valid(FusionTable t, long long m, const unsigned int* visit_slot, int* flags) {
     const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -292,11 +328,25 @@ void launch_fusion_keys(hipStream_t st, FusionTable t, long long m, const unsign
 void launch_fusion_positions(hipStream_t st, long long m, const unsigned int* slot_sorted, const int* order, unsigned int* visit_slot, int* pos_of_slot) {
     if (m > 0) hipLaunchKernelGGL(k_positions, blocks(m), TPB, 0, st, m, slot_sorted, order, visit_slot, pos_of_slot);
 }
-void launch_fusion_correct(hipStream_t st, FusionTable t, float voxel_size, const int* pos_of_slot, float* cur, unsigned char* upd, int* changed) {
-    hipLaunchKernelGGL(k_correct, blocks(t.mask + 1), TPB, 0, st, t, voxel_size, pos_of_slot, cur, upd, changed);
+void launch_fusion_spatial_keys(hipStream_t st, FusionTable t, long long m, const unsigned int* slots, unsigned long long* skey) {
+    if (m > 0) hipLaunchKernelGGL(k_spatial_keys, blocks(m), TPB, 0, st, t, m, slots, skey);
 }
-void launch_fusion_commit(hipStream_t st, FusionTable t, const float* cur, const unsigned char* upd, int* has_update) {
-    hipLaunchKernelGGL(k_commit, blocks(t.mask + 1), TPB, 0, st, t, cur, upd, has_update);
+void launch_fusion_compact_init(hipStream_t st, FusionTable t, long long m, const unsigned int* slot_c, const int* pos_of_slot, int* compact_of_slot, float* c_sdf, int* c_pos,
+                                unsigned char* c_valid, unsigned char* c_touched) {
+    if (m > 0) hipLaunchKernelGGL(k_compact_init, blocks(m), TPB, 0, st, t, m, slot_c, pos_of_slot, compact_of_slot, c_sdf, c_pos, c_valid, c_touched);
+}
+void launch_fusion_build_nbr(hipStream_t st, FusionTable t, long long m, const unsigned int* slot_c, const int* compact_of_slot, const unsigned char* c_valid, int* nbr) {
+    if (m > 0) hipLaunchKernelGGL(k_build_nbr, blocks(m), TPB, 0, st, t, m, slot_c, compact_of_slot, c_valid, nbr);
+}
+void launch_fusion_correct(hipStream_t st, FusionTable t, long long m, float voxel_size, const unsigned int* slot_c, const int* nbr, const int* c_pos, const unsigned char* c_valid,
+                           const float* c_sdf, float* c_cur, unsigned char* c_upd, int* changed) {
+    if (m > 0) hipLaunchKernelGGL(k_correct, blocks(m), TPB, 0, st, t, m, voxel_size, slot_c, nbr, c_pos, c_valid, c_sdf, c_cur, c_upd, changed);
+}
+void launch_fusion_commit(hipStream_t st, long long m, const unsigned char* c_valid, const float* c_cur, const unsigned char* c_upd, float* c_sdf, unsigned char* c_touched, int* has_update) {
+    if (m > 0) hipLaunchKernelGGL(k_commit, blocks(m), TPB, 0, st, m, c_valid, c_cur, c_upd, c_sdf, c_touched, has_update);
+}
+void launch_fusion_write_back(hipStream_t st, FusionTable t, long long m, const unsigned int* slot_c, const float* c_sdf, const unsigned char* c_touched) {
+    if (m > 0) hipLaunchKernelGGL(k_write_back, blocks(m), TPB, 0, st, t, m, slot_c, c_sdf, c_touched);
 }
 void launch_fusion_valid(hipStream_t st, FusionTable t, long long m, const unsigned int* visit_slot, int* flags) {
     if (m > 0) hipLaunchKernelGGL(k_valid, blocks(m), TPB, 0, st, t, m, visit_slot, flags);

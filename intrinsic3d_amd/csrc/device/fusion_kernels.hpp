@@ -35,8 +35,15 @@ void launch_fusion_occupied(hipStream_t st, FusionTable t, int* flags);
 void launch_fusion_gather_rank(hipStream_t st, FusionTable t, const int* flags, const int* offsets, unsigned long long* rank, unsigned int* slot);
 void launch_fusion_keys(hipStream_t st, FusionTable t, long long m, const unsigned int* slot_sorted, int* kxyz);
 void launch_fusion_positions(hipStream_t st, long long m, const unsigned int* slot_sorted, const int* order, unsigned int* visit_slot, int* pos_of_slot);
-void launch_fusion_correct(hipStream_t st, FusionTable t, float voxel_size, const int* pos_of_slot, float* cur, unsigned char* upd, int* changed);
-void launch_fusion_commit(hipStream_t st, FusionTable t, const float* cur, const unsigned char* upd, int* has_update);
+// correctSDF in a spatially sorted compact index space (see fusion_kernels.hip)
+void launch_fusion_spatial_keys(hipStream_t st, FusionTable t, long long m, const unsigned int* slots, unsigned long long* skey);
+void launch_fusion_compact_init(hipStream_t st, FusionTable t, long long m, const unsigned int* slot_c, const int* pos_of_slot, int* compact_of_slot, float* c_sdf, int* c_pos,
+                                unsigned char* c_valid, unsigned char* c_touched);
+void launch_fusion_build_nbr(hipStream_t st, FusionTable t, long long m, const unsigned int* slot_c, const int* compact_of_slot, const unsigned char* c_valid, int* nbr);
+void launch_fusion_correct(hipStream_t st, FusionTable t, long long m, float voxel_size, const unsigned int* slot_c, const int* nbr, const int* c_pos, const unsigned char* c_valid,
+                           const float* c_sdf, float* c_cur, unsigned char* c_upd, int* changed);
+void launch_fusion_commit(hipStream_t st, long long m, const unsigned char* c_valid, const float* c_cur, const unsigned char* c_upd, float* c_sdf, unsigned char* c_touched, int* has_update);
+void launch_fusion_write_back(hipStream_t st, FusionTable t, long long m, const unsigned int* slot_c, const float* c_sdf, const unsigned char* c_touched);
 void launch_fusion_valid(hipStream_t st, FusionTable t, long long m, const unsigned int* visit_slot, int* flags);
 void launch_fusion_export(hipStream_t st, FusionTable t, long long m, const unsigned int* visit_slot, const int* flags, const int* offsets, int* kxyz, float* sdf, float* weight, uint8_t* rgb);
 

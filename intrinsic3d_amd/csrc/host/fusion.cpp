@@ -207,27 +207,41 @@ int i3d_fusion_finish(i3d_fusion* f, int32_t correct_iterations, uint64_t* count
     F_HIP(f, d_order.alloc(m)); F_HIP(f, pos_of_slot.alloc(cap)); F_HIP(f, visit_slot.alloc(m));
     F_HIP(f, hipMemcpyAsync(d_order.p, order.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
     launch_fusion_positions(st, (long long)m, slot1.p, d_order.p, visit_slot.p, pos_of_slot.p);
-    // 3. correctSDF: up to `correct_iterations` in-place sweeps, each evaluated as a fixed point (see k_correct)
-    DevBuf<float> cur; DevBuf<unsigned char> upd;
-    F_HIP(f, cur.alloc(cap)); F_HIP(f, upd.alloc(cap));
-    f->correct_launches = 0;
-    for (int iter = 0; iter < correct_iterations; ++iter) {
-        F_HIP(f, hipMemcpyAsync(cur.p, f->sdf.p, sizeof(float) * cap, hipMemcpyDeviceToDevice, st));
-        F_HIP(f, hipMemsetAsync(upd.p, 0, cap, st));
-        for (;;) {
-            F_HIP(f, hipMemsetAsync(f->d_flag.p, 0, 2 * sizeof(int), st));
-            launch_fusion_correct(st, t, f->voxel_size, pos_of_slot.p, cur.p, upd.p, f->d_flag.p);
-            int changed = 0;
-            F_HIP(f, hipMemcpyAsync(&changed, f->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    // 3. correctSDF: up to `correct_iterations` in-place sweeps, each evaluated as a fixed point (see k_correct), in a spatially sorted
+    //    compact index space with the 26 neighbour indices resolved once
+    if (correct_iterations > 0) {
+        DevBuf<unsigned long long> sk0, sk1; DevBuf<unsigned int> slot_c; DevBuf<int> compact_of_slot, c_pos, nbr; DevBuf<float> c_sdf, c_cur;
+        DevBuf<unsigned char> c_valid, c_touched, c_upd;
+        F_HIP(f, sk0.alloc(m)); F_HIP(f, sk1.alloc(m)); F_HIP(f, slot_c.alloc(m)); F_HIP(f, compact_of_slot.alloc(cap)); F_HIP(f, c_pos.alloc(m));
+        F_HIP(f, nbr.alloc(26 * m)); F_HIP(f, c_sdf.alloc(m)); F_HIP(f, c_cur.alloc(m)); F_HIP(f, c_valid.alloc(m)); F_HIP(f, c_touched.alloc(m)); F_HIP(f, c_upd.alloc(m));
+        launch_fusion_spatial_keys(st, t, (long long)m, slot1.p, sk0.p);
+        bytes = 0;
+        F_HIP(f, rocprim::radix_sort_pairs(nullptr, bytes, sk0.p, sk1.p, slot1.p, slot_c.p, (size_t)m, 0, 64, st));
+        F_HIP(f, tmp.alloc(bytes));
+        F_HIP(f, rocprim::radix_sort_pairs(tmp.p, bytes, sk0.p, sk1.p, slot1.p, slot_c.p, (size_t)m, 0, 64, st));
+        launch_fusion_compact_init(st, t, (long long)m, slot_c.p, pos_of_slot.p, compact_of_slot.p, c_sdf.p, c_pos.p, c_valid.p, c_touched.p);
+        launch_fusion_build_nbr(st, t, (long long)m, slot_c.p, compact_of_slot.p, c_valid.p, nbr.p);
+        f->correct_launches = 0;
+        for (int iter = 0; iter < correct_iterations; ++iter) {
+            F_HIP(f, hipMemcpyAsync(c_cur.p, c_sdf.p, sizeof(float) * m, hipMemcpyDeviceToDevice, st));
+            F_HIP(f, hipMemsetAsync(c_upd.p, 0, m, st));
+            for (;;) {
+                F_HIP(f, hipMemsetAsync(f->d_flag.p, 0, 2 * sizeof(int), st));
+                launch_fusion_correct(st, t, (long long)m, f->voxel_size, slot_c.p, nbr.p, c_pos.p, c_valid.p, c_sdf.p, c_cur.p, c_upd.p, f->d_flag.p);
+                int changed = 0;
+                F_HIP(f, hipMemcpyAsync(&changed, f->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                F_HIP(f, hipStreamSynchronize(st));
+                ++f->correct_launches;
+                if (!changed) break;
+            }
+            launch_fusion_commit(st, (long long)m, c_valid.p, c_cur.p, c_upd.p, c_sdf.p, c_touched.p, f->d_flag.p + 1);
+            int has_update = 0;
+            F_HIP(f, hipMemcpyAsync(&has_update, f->d_flag.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
             F_HIP(f, hipStreamSynchronize(st));
-            ++f->correct_launches;
-            if (!changed) break;
+            if (!has_update) break;
         }
-        launch_fusion_commit(st, t, cur.p, upd.p, f->d_flag.p + 1);
-        int has_update = 0;
-        F_HIP(f, hipMemcpyAsync(&has_update, f->d_flag.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+        launch_fusion_write_back(st, t, (long long)m, slot_c.p, c_sdf.p, c_touched.p);
         F_HIP(f, hipStreamSynchronize(st));
-        if (!has_update) break;
     }
     // 4. clearInvalidVoxels + records in iteration order
     DevBuf<int> vflags, voffs;
