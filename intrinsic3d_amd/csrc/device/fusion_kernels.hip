@@ -45,7 +45,7 @@ __device__ inline bool within(const int* b, int x, int y, int z) { return !(x < 
 __global__ void k_clear(FusionTable t) {
     const unsigned long long i = (unsigned long long)blockIdx.x * TPB + threadIdx.x;
     if (i > t.mask) return;
-    t.keys[i] = FUSION_EMPTY; t.sdf[i] = 0.0f; t.weight[i] = 0.0f; t.color[i] = make_uchar4(0, 0, 0, 0); t.rank[i] = ~0ull;
+    t.keys[i] = FUSION_EMPTY; t.sdf[i] = 0.0f; t.weight[i] = 0.0f; t.color[i] = make_uchar4(0, 0, 0, 0); t.rank[i] = ~0ull; t.crank[i] = ~0ull;
 }
 __global__ void k_rehash(FusionTable src, FusionTable dst) {
     const unsigned long long i = (unsigned long long)blockIdx.x * TPB + threadIdx.x;
@@ -57,7 +57,7 @@ __global__ void k_rehash(FusionTable src, FusionTable dst) {
         if (atomicCAS(&dst.keys[s], FUSION_EMPTY, key) == FUSION_EMPTY) break;       // keys are unique in src
         s = (s + 1) & dst.mask;
     }
-    dst.sdf[s] = src.sdf[i]; dst.weight[s] = src.weight[i]; dst.color[s] = src.color[i]; dst.rank[s] = src.rank[i];
+    dst.sdf[s] = src.sdf[i]; dst.weight[s] = src.weight[i]; dst.color[s] = src.color[i]; dst.rank[s] = src.rank[i]; dst.crank[s] = src.crank[i];
 }
 
 __global__ void k_erode(int w, int h, const float* __restrict__ in, int window, float max_diff, float* __restrict__ out) {
@@ -100,50 +100,86 @@ __global__ void k_normals(FusionCam c, const float* __restrict__ depth, float th
     float* o = &normals[((size_t)y * c.w + x) * 3]; o[0] = n[0]; o[1] = n[1]; o[2] = n[2];
 }
 
-// one lane per depth pixel: march the ray through the truncation band and make sure the 3x3x3 block around every voxel it enters
-// exists.  Idempotent (insert-if-absent + atomicMin on the rank), so a launch that ran out of table space is simply repeated after growth.
-__global__ void k_alloc(FusionTable t, FusionFrame f, FusionCam cam, const float* __restrict__ depth, unsigned long long limit,
-                        unsigned long long* count, int* overflow) {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= cam.w || y >= cam.h) return;
-    const float d = depth[(size_t)y * cam.w + x];
-    if (d == 0.0f) return;
-    const float pcx = 1.0f * (((float)x - cam.cx) / cam.fx), pcy = 1.0f * (((float)y - cam.cy) / cam.fy), pcz = 1.0f;     // unproject2(x, y, 1)
-    const float ray_step = f.voxel_size * 0.25f, inv_vs = 1.0f / f.voxel_size;
-    const unsigned long long pixel = (unsigned long long)y * cam.w + x;
-    int lx = 0, ly = 0, lz = 0; unsigned step = 0;
-    int qx = 0, qy = 0, qz = 0; bool have_block = false;          // centre of the last 3x3x3 block this lane made sure exists
-    for (float d_off = -f.truncation; d_off <= f.truncation; d_off += ray_step, ++step) {
-        const float s = d + d_off;
-        float pw[3]; xform(f.c2w, pcx * s, pcy * s, pcz * s, pw);
-        const int gx = round_trunc(pw[0] * inv_vs), gy = round_trunc(pw[1] * inv_vs), gz = round_trunc(pw[2] * inv_vs);
-        if (gx == lx && gy == ly && gz == lz) continue;
-        lx = gx; ly = gy; lz = gz;
-        if (!within(f.bounds, gx, gy, gz)) continue;
-        if (f.use_clip) {
-            const float wx = (float)gx * f.voxel_size, wy = (float)gy * f.voxel_size, wz = (float)gz * f.voxel_size;
-            if (wx < f.clip[0] || wx > f.clip[1] || wy < f.clip[2] || wy > f.clip[3] || wz < f.clip[4] || wz > f.clip[5]) continue;
+// Allocation (SparseVoxelGrid::alloc) in two launches per frame.
+// The reference walks every depth pixel's ray through the truncation band and inserts the 3x3x3 block around every voxel the ray enters —
+// 27 map probes per ray sample, ~3.4e8 per VGA frame, nearly all of them finding the voxel present.  Here
+//   1. k_alloc_centres (one lane per pixel) only records the CENTRE voxels: it makes sure the centre exists and keeps, per centre, the rank
+//      of its first visit in the reference's sequential order (frame, pixel, ray step) with atomicMin — one probe per ray sample;
+//   2. k_alloc_blocks (one lane per table slot) expands the block of every centre that has not been expanded in an earlier frame.
+// A cell is first inserted by the earliest visit whose block covers it, and for one centre the earliest visit is its first, so the
+// insertion rank of a new cell is  min over the centres c around it of (first visit of c, index of the cell in c's block)  — exactly
+// what the atomicMin over the expanding centres computes.  A centre expanded once never needs expanding again (its cells exist):
+// crank = 0 marks it, ~0 = never a centre, anything else = pending first-visit rank.  Both launches are idempotent, so a launch that
+// ran out of table space is simply repeated after growth.
+// `fresh` counts the cells this lane created; the lanes of a wave add their totals to the global counter with ONE atomic at the end of
+// the kernel (a same-address atomic per new voxel — ~1e6 per frame — serialises at ~10 ns each and was 3/4 of the allocation time).
+__device__ inline bool insert_cell(const FusionTable& t, unsigned long long key, unsigned long long my_rank, unsigned long long limit, const unsigned long long* count,
+                                   unsigned& fresh, int* overflow, unsigned long long* slot_out) {
+    unsigned long long sl = slot_of(key, t.mask);
+    for (unsigned long long probes = 0; probes <= t.mask; ++probes) {
+        unsigned long long k = t.keys[sl];
+        if (k == FUSION_EMPTY) {
+            if (*count + fresh >= limit) break;                                   // the counter lags by what the waves in flight have not yet added: the
+            k = atomicCAS(&t.keys[sl], FUSION_EMPTY, key);                        // probe bound above keeps a table that filled up meanwhile from spinning
+            if (k == FUSION_EMPTY) { ++fresh; k = key; }
         }
-        const unsigned long long base = (f.frame << 41) | (pixel << 13) | ((unsigned long long)(step & 0xFF) << 5);
-        int blk = 0;
-        for (int bz = -1; bz <= 1; ++bz) for (int by = -1; by <= 1; ++by) for (int bx = -1; bx <= 1; ++bx, ++blk) {
-            // a cell of the previous block exists already and carries a rank no larger than this one
-            if (have_block && abs(gx + bx - qx) <= 1 && abs(gy + by - qy) <= 1 && abs(gz + bz - qz) <= 1) continue;
-            const unsigned long long key = pack_key(gx + bx, gy + by, gz + bz), my_rank = base | (unsigned long long)blk;
-            unsigned long long sl = slot_of(key, t.mask);
-            for (;;) {
-                unsigned long long k = t.keys[sl];
-                if (k == FUSION_EMPTY) {
-                    if (*count >= limit) { *overflow = 1; return; }
-                    k = atomicCAS(&t.keys[sl], FUSION_EMPTY, key);
-                    if (k == FUSION_EMPTY) { atomicAdd(count, 1ull); k = key; }
-                }
-                if (k == key) { if (my_rank < t.rank[sl]) atomicMin(&t.rank[sl], my_rank); break; }
-                sl = (sl + 1) & t.mask;
-            }
-        }
-        qx = gx; qy = gy; qz = gz; have_block = true;
+        if (k == key) { if (my_rank < t.rank[sl]) atomicMin(&t.rank[sl], my_rank); *slot_out = sl; return true; }
+        sl = (sl + 1) & t.mask;
     }
+    *overflow = 1;
+    return false;
+}
+__device__ inline void add_fresh(unsigned fresh, unsigned long long* count) {     // every lane of the wave must call this
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fresh += __shfl_down(fresh, off);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(count, (unsigned long long)fresh);
+}
+__global__ void k_alloc_centres(FusionTable t, FusionFrame f, FusionCam cam, const float* __restrict__ depth, unsigned long long limit,
+                                unsigned long long* count, int* overflow) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    unsigned fresh = 0;
+    const float d = (x < cam.w && y < cam.h) ? depth[(size_t)y * cam.w + x] : 0.0f;
+    if (d != 0.0f) {
+        const float pcx = 1.0f * (((float)x - cam.cx) / cam.fx), pcy = 1.0f * (((float)y - cam.cy) / cam.fy), pcz = 1.0f;     // unproject2(x, y, 1)
+        const float ray_step = f.voxel_size * 0.25f, inv_vs = 1.0f / f.voxel_size;
+        const unsigned long long pixel = (unsigned long long)y * cam.w + x;
+        int lx = 0, ly = 0, lz = 0; unsigned step = 0;
+        for (float d_off = -f.truncation; d_off <= f.truncation; d_off += ray_step, ++step) {
+            const float s = d + d_off;
+            float pw[3]; xform(f.c2w, pcx * s, pcy * s, pcz * s, pw);
+            const int gx = round_trunc(pw[0] * inv_vs), gy = round_trunc(pw[1] * inv_vs), gz = round_trunc(pw[2] * inv_vs);
+            if (gx == lx && gy == ly && gz == lz) continue;
+            lx = gx; ly = gy; lz = gz;
+            if (!within(f.bounds, gx, gy, gz)) continue;
+            if (f.use_clip) {
+                const float wx = (float)gx * f.voxel_size, wy = (float)gy * f.voxel_size, wz = (float)gz * f.voxel_size;
+                if (wx < f.clip[0] || wx > f.clip[1] || wy < f.clip[2] || wy > f.clip[3] || wz < f.clip[4] || wz > f.clip[5]) continue;
+            }
+            const unsigned long long visit = (f.frame << 41) | (pixel << 13) | ((unsigned long long)(step & 0xFF) << 5);
+            unsigned long long sl;
+            if (!insert_cell(t, pack_key(gx, gy, gz), visit | 13ull, limit, count, fresh, overflow, &sl)) break;      // the centre is cell 13 of its own block
+            const unsigned long long pending = visit | 31ull;                                                       // never 0, never a cell rank
+            const unsigned long long c = t.crank[sl];
+            if (c != 0ull && pending < c) atomicMin(&t.crank[sl], pending);
+        }
+    }
+    add_fresh(fresh, count);
+}
+__global__ void k_alloc_blocks(FusionTable t, unsigned long long limit, unsigned long long* count, int* overflow) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * TPB + threadIdx.x;
+    unsigned fresh = 0;
+    const unsigned long long c = i <= t.mask ? t.crank[i] : 0ull;
+    if (c != 0ull && c != ~0ull) {
+        int gx, gy, gz; unpack_key(t.keys[i], gx, gy, gz);
+        const unsigned long long visit = c & ~31ull;
+        int blk = 0; bool ok = true;
+        for (int bz = -1; bz <= 1 && ok; ++bz) for (int by = -1; by <= 1 && ok; ++by) for (int bx = -1; bx <= 1 && ok; ++bx, ++blk) {
+            unsigned long long sl;
+            ok = insert_cell(t, pack_key(gx + bx, gy + by, gz + bz), visit | (unsigned long long)blk, limit, count, fresh, overflow, &sl);
+        }
+        if (ok) t.crank[i] = 0ull;
+    }
+    add_fresh(fresh, count);
 }
 
 // one lane per table slot: the running weighted mean of one frame (sparse_voxel_grid.cpp:315-395)
@@ -313,7 +349,8 @@ void launch_normals(hipStream_t st, FusionCam cam, const float* depth, float thr
     hipLaunchKernelGGL(k_normals, image_grid(cam.w, cam.h), TPB, 0, st, cam, depth, thr, normals);
 }
 void launch_fusion_alloc(hipStream_t st, FusionTable t, FusionFrame f, FusionCam cam, const float* depth, unsigned long long limit, unsigned long long* count, int* overflow) {
-    hipLaunchKernelGGL(k_alloc, image_grid(cam.w, cam.h), TPB, 0, st, t, f, cam, depth, limit, count, overflow);
+    hipLaunchKernelGGL(k_alloc_centres, image_grid(cam.w, cam.h), TPB, 0, st, t, f, cam, depth, limit, count, overflow);
+    hipLaunchKernelGGL(k_alloc_blocks, blocks(t.mask + 1), TPB, 0, st, t, limit, count, overflow);
 }
 void launch_fusion_integrate(hipStream_t st, FusionTable t, FusionFrame f, FusionCam dcam, FusionCam ccam, const float* depth, const float* normals, const uint8_t* bgr) {
     hipLaunchKernelGGL(k_integrate, blocks(t.mask + 1), TPB, 0, st, t, f, dcam, ccam, depth, normals, bgr);

@@ -13,6 +13,7 @@ struct FusionTable {                                         // slot-indexed SoA
     unsigned long long* keys;                                // packed (x, y, z) or FUSION_EMPTY
     float* sdf; float* weight; uchar4* color;                // Voxel (sparse_voxel_grid.h:56-62), colour as R,G,B
     unsigned long long* rank;                                // (frame, pixel, ray step, block index) of the FIRST insertion in the reference's sequential order
+    unsigned long long* crank;                               // centre state: ~0 never a block centre, 0 block expanded, else rank of the first visit (pending)
     unsigned long long mask;                                 // capacity - 1
 };
 struct FusionCam { float fx, fy, cx, cy; int w, h; };

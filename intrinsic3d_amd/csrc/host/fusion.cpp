@@ -45,14 +45,14 @@ struct i3d_fusion {
     float voxel_size = 0, truncation = 0, depth_min = 0, depth_max = 0, weight_sample = 10.0f;      // sparse_voxel_grid.cpp:44-51
     float clip[6] = {0, 0, 0, 0, 0, 0}; bool use_clip = false;
     unsigned long long capacity = 0, frames = 0;
-    DevBuf<unsigned long long> keys, rank; DevBuf<float> sdf, weight; DevBuf<uchar4> color;
+    DevBuf<unsigned long long> keys, rank, crank; DevBuf<float> sdf, weight; DevBuf<uchar4> color;
     DevBuf<unsigned long long> d_count; DevBuf<int> d_flag;
     DevBuf<float> d_depth_raw, d_depth, d_normals; DevBuf<uint8_t> d_bgr;
     // result of finish()
     bool finished = false; std::vector<int32_t> out_keys; std::vector<float> out_sdf, out_weight; std::vector<uint8_t> out_color;
     unsigned long long allocated = 0; int correct_launches = 0;
     std::string error;
-    FusionTable table() { return FusionTable{keys.p, sdf.p, weight.p, color.p, rank.p, capacity - 1}; }
+    FusionTable table() { return FusionTable{keys.p, sdf.p, weight.p, color.p, rank.p, crank.p, capacity - 1}; }
 };
 
 namespace {
@@ -60,20 +60,20 @@ namespace {
 int fail(i3d_fusion* f, int code, const std::string& msg) { if (f) f->error = msg; return code; }
 #define F_HIP(f, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(f, I3D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
-int alloc_table(i3d_fusion* f, unsigned long long cap, DevBuf<unsigned long long>& keys, DevBuf<unsigned long long>& rank, DevBuf<float>& sdf, DevBuf<float>& weight,
-                DevBuf<uchar4>& color) {
-    F_HIP(f, keys.alloc(cap)); F_HIP(f, rank.alloc(cap)); F_HIP(f, sdf.alloc(cap)); F_HIP(f, weight.alloc(cap)); F_HIP(f, color.alloc(cap));
-    launch_fusion_clear(f->stream, FusionTable{keys.p, sdf.p, weight.p, color.p, rank.p, cap - 1});
+int alloc_table(i3d_fusion* f, unsigned long long cap, DevBuf<unsigned long long>& keys, DevBuf<unsigned long long>& rank, DevBuf<unsigned long long>& crank,
+                DevBuf<float>& sdf, DevBuf<float>& weight, DevBuf<uchar4>& color) {
+    F_HIP(f, keys.alloc(cap)); F_HIP(f, rank.alloc(cap)); F_HIP(f, crank.alloc(cap)); F_HIP(f, sdf.alloc(cap)); F_HIP(f, weight.alloc(cap)); F_HIP(f, color.alloc(cap));
+    launch_fusion_clear(f->stream, FusionTable{keys.p, sdf.p, weight.p, color.p, rank.p, crank.p, cap - 1});
     return I3D_OK;
 }
 int grow(i3d_fusion* f) {
     if (f->capacity >= (1ull << 31)) return fail(f, I3D_ERR_CAPACITY, "fusion: more than 2^31 table slots");
-    DevBuf<unsigned long long> keys, rank; DevBuf<float> sdf, weight; DevBuf<uchar4> color;
+    DevBuf<unsigned long long> keys, rank, crank; DevBuf<float> sdf, weight; DevBuf<uchar4> color;
     const unsigned long long cap = f->capacity * 2;
-    const int rc = alloc_table(f, cap, keys, rank, sdf, weight, color); if (rc) return rc;
-    launch_fusion_rehash(f->stream, f->table(), FusionTable{keys.p, sdf.p, weight.p, color.p, rank.p, cap - 1});
+    const int rc = alloc_table(f, cap, keys, rank, crank, sdf, weight, color); if (rc) return rc;
+    launch_fusion_rehash(f->stream, f->table(), FusionTable{keys.p, sdf.p, weight.p, color.p, rank.p, crank.p, cap - 1});
     F_HIP(f, hipStreamSynchronize(f->stream));
-    f->keys = std::move(keys); f->rank = std::move(rank); f->sdf = std::move(sdf); f->weight = std::move(weight); f->color = std::move(color);
+    f->keys = std::move(keys); f->rank = std::move(rank); f->crank = std::move(crank); f->sdf = std::move(sdf); f->weight = std::move(weight); f->color = std::move(color);
     f->capacity = cap;
     return I3D_OK;
 }
@@ -111,11 +111,11 @@ int i3d_fusion_create(int32_t device_ordinal, float voxel_size, float depth_min,
     i3d_fusion* f = new i3d_fusion();
     f->device = device_ordinal; f->voxel_size = voxel_size; f->truncation = voxel_size * 5.0f; f->depth_min = depth_min; f->depth_max = depth_max;
     if (clip6) { float n = 0.0f; for (int i = 0; i < 6; ++i) { f->clip[i] = clip6[i]; n += clip6[i] * clip6[i]; } f->use_clip = std::sqrt(n) > 0.0f; }
-    unsigned long long cap = 1ull << 16;
+    unsigned long long cap = 1ull << 12;
     while (cap < initial_capacity * 2 && cap < (1ull << 31)) cap <<= 1;
     f->capacity = cap;
     if (hipStreamCreate(&f->stream) != hipSuccess) { delete f; return I3D_ERR_HIP; }
-    int rc = alloc_table(f, cap, f->keys, f->rank, f->sdf, f->weight, f->color);
+    int rc = alloc_table(f, cap, f->keys, f->rank, f->crank, f->sdf, f->weight, f->color);
     if (rc == I3D_OK && (f->d_count.alloc(1) != hipSuccess || f->d_flag.alloc(2) != hipSuccess)) rc = I3D_ERR_HIP;
     if (rc == I3D_OK && hipMemsetAsync(f->d_count.p, 0, sizeof(unsigned long long), f->stream) != hipSuccess) rc = I3D_ERR_HIP;
     if (rc == I3D_OK && hipStreamSynchronize(f->stream) != hipSuccess) rc = I3D_ERR_HIP;

@@ -39,13 +39,13 @@ def test_fusion_matches_oracle_bit_exact(oracle):
     sc, frames = _frames(noise=0.0015)
     intr = sc["intr"].astype(np.float32)
     o = oracle.Fusion(sc["voxel_size"], 0.1, 10.0)
-    with B.Fusion(sc["voxel_size"], 0.1, 10.0, initial_capacity=1 << 12) as f:          # small table: the growth path runs several times
+    with B.Fusion(sc["voxel_size"], 0.1, 10.0, initial_capacity=1 << 10) as f:          # 4096-slot table: it has to grow four times
         for d, bgr, T in frames:
             o.integrate(d, intr, bgr, intr, T, 2); f.integrate(d, intr, bgr, intr, T, 2)
         raw_o = o.export()
         o.finish(10); n = f.finish(10)
         ref = o.export(); got = f.export(); info = f.info()
-    assert info["frames"] == len(frames) and info["allocated"] == len(raw_o["sdf"]) and info["capacity"] > (1 << 13)
+    assert info["frames"] == len(frames) and info["allocated"] == len(raw_o["sdf"]) and info["capacity"] >= (1 << 16)
     assert n == len(ref["sdf"]) and 5000 < n < info["allocated"]                         # clearInvalidVoxels removed the never-seen blocks
     assert (ref["weight"] == 1.0).sum() > 100, "correctSDF did not touch anything: the sweep emulation is not exercised"
     _same(got, ref)
