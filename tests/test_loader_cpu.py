@@ -247,3 +247,27 @@ def test_sensor_folder(tmp_path):
     assert B.Sensor(tmp_path / "rgbd").num_frames == 3
     with pytest.raises(B.I3DError):
         B.Sensor("")
+
+
+def test_yaml_get_and_cli_usage(tmp_path):
+    """Settings::get<std::string> over the reference's flat yml files, and the argument handling of the two CLIs (no device needed)"""
+    import os, subprocess
+    yml = tmp_path / "sensor.yml"
+    yml.write_text('%YAML:1.0\n\n# rgbd sensor config\n# ------------------\n\n# dataset file/folder \ndataset: "./rgbd/"\nmax_frames: "0"\n# minimum depth\nmin_depth: "0.1"\nempty: ""\n')
+    assert B.yaml_get(yml, "dataset") == "./rgbd/" and B.yaml_get(yml, "min_depth") == "0.1" and B.yaml_get(yml, "empty") == ""
+    assert B.yaml_get(yml, "missing", default="7") == "7"
+    with pytest.raises(B.I3DError):
+        B.yaml_get(yml, "missing")
+    with pytest.raises(B.I3DError):
+        B.yaml_get(tmp_path / "nope.yml", "dataset")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for app, flag in (("app_intrinsic3d", "-i"), ("app_fusion", "-f")):
+        exe = os.path.join(root, "apps", app)
+        if not os.path.exists(exe):
+            pytest.skip("apps not built")
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "usage" in r.stderr
+        r = subprocess.run([exe, "-s", str(yml)], capture_output=True, text=True)                  # second config missing
+        assert r.returncode == 2
+        r = subprocess.run([exe, f"--sensor={yml}", flag, str(yml)], capture_output=True, text=True)   # no frames in ./rgbd/: Sensor::create fails
+        assert r.returncode == 1 and "RGB-D sensor could not be initialized" in r.stderr
