@@ -77,6 +77,32 @@ def compute_levels(O):
     return res
 
 
+def fusion_frames():
+    """the seeded frames of fusion_small.json: (depth, bgr, camera-to-world pose) per frame + intrinsics + voxel size"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "tools"))
+    from make_dataset import pose_vec_to_cam_to_world
+    import helpers
+    sc = helpers.small_scene(seed=21, radius_vox=11, K=5, width=96, height=72, levels=1)
+    rng = np.random.default_rng(5)
+    frames = []
+    for fr, pose in zip(sc["frames"], sc["poses"]):
+        d = fr["depth"][0].copy(); d[d > 0] += rng.normal(0, 0.001, int((d > 0).sum())).astype(np.float32)
+        g = fr["bgr"][0][..., 0]
+        frames.append((d, np.stack([g // 2, g, 255 - g // 3], axis=-1).astype(np.uint8), pose_vec_to_cam_to_world(np.asarray(pose, np.float64)).astype(np.float32)))
+    return frames, sc["intr"].astype(np.float32), float(sc["voxel_size"])
+
+
+def compute_fusion(O):
+    """CRCs of the fused volume (AppFusion::fuseSDF: integrate x5, correctSDF, clearInvalidVoxels) in record order"""
+    frames, intr, vs = fusion_frames()
+    f = O.Fusion(vs, 0.1, 10.0)
+    for d, bgr, T in frames:
+        f.integrate(d, intr, bgr, intr, T, 2)
+    raw = f.export(); f.finish(10); v = f.export()
+    return {"allocated": len(raw["sdf"]), "saved": len(v["sdf"]), "keys": _crc(v["keys"]), "sdf": _crc(v["sdf"]), "weight": _crc(v["weight"]), "color": _crc(v["color"]),
+            "corrected": int((v["weight"] == 1.0).sum())}
+
+
 if __name__ == "__main__":
     from oracle import oracle_py as O
     O.build()
@@ -88,3 +114,7 @@ if __name__ == "__main__":
     with open(os.path.join(HERE, "levels_small.json"), "w") as f:
         json.dump(r2, f, indent=1)
     print("written levels", r2["convert"], r2["upsample"]["n"])
+    r3 = compute_fusion(O)
+    with open(os.path.join(HERE, "fusion_small.json"), "w") as f:
+        json.dump(r3, f, indent=1)
+    print("written fusion", r3)

@@ -129,3 +129,21 @@ def test_app_fusion_then_app_intrinsic3d(oracle, tmp_path):
     r = subprocess.run([os.path.join(ROOT, "apps", "app_intrinsic3d"), "-s", s_yml, "-i", i_yml], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "intrinsic3d" / "mesh_g0_p0_albedo.ply").stat().st_size > 10000 and (tmp_path / "intrinsic3d" / "poses_g0_p0.txt").exists()
+
+
+def test_device_fusion_matches_committed_golden():
+    """the device path alone against tests/golden/fusion_small.json (CRCs generated from the oracle by make_golden.py): needs neither the oracle
+    nor the reference at run time"""
+    import json, zlib
+    from intrinsic3d_amd import binding as B
+    import golden.make_golden as mg
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fusion_small.json")))
+    crc = lambda a: int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+    frames, intr, vs = mg.fusion_frames()
+    with B.Fusion(vs, 0.1, 10.0, initial_capacity=1 << 14) as f:
+        for d, bgr, T in frames:
+            f.integrate(d, intr, bgr, intr, T, 2)
+        v = f.export(); info = f.info()
+    got = {"allocated": info["allocated"], "saved": len(v["sdf"]), "keys": crc(v["keys"]), "sdf": crc(v["sdf"]), "weight": crc(v["weight"]), "color": crc(v["color"]),
+           "corrected": int((v["weight"] == 1.0).sum())}
+    assert got == gold

@@ -190,6 +190,13 @@ def test_golden_level_operations(oracle):
     assert mg.compute_levels(oracle) == gold
 
 
+def test_golden_fusion(oracle):
+    """the fused volume of five seeded frames (integrate, correctSDF, clearInvalidVoxels; record order) vs the committed CRCs"""
+    gold = json.load(open(os.path.join(HERE, "golden", "fusion_small.json")))
+    import golden.make_golden as mg
+    assert mg.compute_fusion(oracle) == gold
+
+
 def test_pyramid_restatement_against_numpy(oracle):
     """luminance / pyrDown / depth pyramid of the oracle vs an independent numpy formulation (separable float32 convolution with reflected
     borders; valid-mean of 2x2 blocks)"""
