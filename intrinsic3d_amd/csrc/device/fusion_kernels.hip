@@ -109,8 +109,8 @@ __global__ void k_normals(FusionCam c, const float* __restrict__ depth, float th
 // A cell is first inserted by the earliest visit whose block covers it, and for one centre the earliest visit is its first, so the
 // insertion rank of a new cell is  min over the centres c around it of (first visit of c, index of the cell in c's block)  — exactly
 // what the atomicMin over the expanding centres computes.  A centre expanded once never needs expanding again (its cells exist):
-// crank = 0 marks it, ~0 = never a centre, anything else = pending first-visit rank.  Both launches are idempotent, so a launch that
-// ran out of table space is simply repeated after growth.
+// crank = 0 marks it, ~0 = never a centre, anything else = pending first-visit rank.  Both launches are idempotent, so a frame whose
+// allocation ran out of table space is simply repeated after growth (the blocks launch does nothing when the centres launch overflowed).
 // `fresh` counts the cells this lane created; the lanes of a wave add their totals to the global counter with ONE atomic at the end of
 // the kernel (a same-address atomic per new voxel — ~1e6 per frame — serialises at ~10 ns each and was 3/4 of the allocation time).
 __device__ inline bool insert_cell(const FusionTable& t, unsigned long long key, unsigned long long my_rank, unsigned long long limit, const unsigned long long* count,
@@ -168,7 +168,9 @@ __global__ void k_alloc_centres(FusionTable t, FusionFrame f, FusionCam cam, con
 __global__ void k_alloc_blocks(FusionTable t, unsigned long long limit, unsigned long long* count, int* overflow) {
     const unsigned long long i = (unsigned long long)blockIdx.x * TPB + threadIdx.x;
     unsigned fresh = 0;
-    const unsigned long long c = i <= t.mask ? t.crank[i] : 0ull;
+    // a centre may only be expanded once its first-visit rank is final: if k_alloc_centres ran out of space, some lanes stopped early and a
+    // pending rank may not be the minimum yet — leave everything pending for the repeat after growth
+    const unsigned long long c = (i <= t.mask && !*overflow) ? t.crank[i] : 0ull;
     if (c != 0ull && c != ~0ull) {
         int gx, gy, gz; unpack_key(t.keys[i], gx, gy, gz);
         const unsigned long long visit = c & ~31ull;

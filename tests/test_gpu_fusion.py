@@ -147,3 +147,22 @@ def test_device_fusion_matches_committed_golden():
     got = {"allocated": info["allocated"], "saved": len(v["sdf"]), "keys": crc(v["keys"]), "sdf": crc(v["sdf"]), "weight": crc(v["weight"]), "color": crc(v["color"]),
            "corrected": int((v["weight"] == 1.0).sum())}
     assert got == gold
+
+
+def test_fusion_degenerate_frames(oracle):
+    """frames that allocate nothing (all-zero depth, everything outside the clip box), a frustum whose far plane lies in front of the object,
+    and a 4096-slot table that has to grow in the middle of a frame's allocation (which must then be repeated without changing the order of
+    first insertion): the volume must equal the oracle's"""
+    from intrinsic3d_amd import binding as B
+    sc, frames = _frames(seed=6, K=3, radius=10, w=96, h=72)
+    intr = sc["intr"].astype(np.float32)
+    d0, bgr0, T0 = frames[0]
+    far_clip = np.array([50, 51, 50, 51, 50, 51], np.float32)
+    for clip, dmax in ((None, 10.0), (far_clip, 10.0), (None, 0.2)):                  # dmax 0.2 m: the object lies outside the frustum bounds
+        o = oracle.Fusion(sc["voxel_size"], 0.1, dmax, clip)
+        with B.Fusion(sc["voxel_size"], 0.1, dmax, clip, initial_capacity=1 << 10) as f:
+            for d, bgr, T in ((np.zeros_like(d0), bgr0, T0), (d0, bgr0, T0), (frames[1][0], frames[1][1], frames[1][2]), (np.zeros_like(d0), bgr0, T0)):
+                o.integrate(d, intr, bgr, intr, T, 1); f.integrate(d, intr, bgr, intr, T, 1)
+            o.finish(2); f.finish(2); ref = o.export(); got = f.export()
+        _same(got, ref)
+        assert (len(ref["sdf"]) > 1000) == (clip is None)                  # the frustum bounds are rounded to whole METRES (sparse_voxel_grid.cpp:587-588): dmax 0.2 cuts nothing here
