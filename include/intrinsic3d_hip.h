@@ -223,6 +223,8 @@ int  i3d_sensor_save_poses(const i3d_sensor* s, const char* path);              
 int i3d_keyframes_load(const char* path, int32_t* window_size, uint64_t capacity, double* scores, uint8_t* is_keyframe, uint64_t* count);
 int i3d_keyframes_save(const char* path, int32_t window_size, uint64_t count, const double* scores, const uint8_t* is_keyframe);
 int i3d_keyframes_select(int32_t window_size, uint64_t count, const double* scores, uint8_t* is_keyframe);
+/* KeyframeSelection::estimateBlur (keyframe_selection.cpp:219-311): blur metric of one colour (B,G,R) or grey 8-bit image; 1 = sharp */
+int i3d_blur_score(const uint8_t* image, int32_t width, int32_t height, int32_t channels, double* score);
 /* Intrinsic3D::init's keyframe loop (intrinsic3d.cpp:156-193): for every keyframe decode colour + depth, resample the depth into the colour
  * geometry and build the pyramids on the device, convert the pose; sets the frames and the camera (colour intrinsics, zero distortion) of ctx */
 int i3d_init_frames_from_sensor(i3d_context* ctx, int32_t device_ordinal, const i3d_sensor* s, uint64_t num_flags, const uint8_t* is_keyframe,

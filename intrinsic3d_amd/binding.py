@@ -69,7 +69,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_extract_mesh", "i3d_get_mesh", "i3d_export_mesh_ply", "i3d_write_ply", "i3d_mc_tables",
            "i3d_png_info", "i3d_png_decode", "i3d_pose_mat_to_vec6", "i3d_sensor_open", "i3d_sensor_close", "i3d_sensor_info", "i3d_sensor_color",
            "i3d_sensor_depth", "i3d_sensor_pose", "i3d_sensor_set_pose", "i3d_sensor_set_pose_vec6", "i3d_sensor_save_poses",
-           "i3d_keyframes_load", "i3d_keyframes_save", "i3d_keyframes_select", "i3d_init_frames_from_sensor",
+           "i3d_keyframes_load", "i3d_keyframes_save", "i3d_keyframes_select", "i3d_blur_score", "i3d_init_frames_from_sensor",
            "i3d_fusion_create", "i3d_fusion_destroy", "i3d_fusion_last_error", "i3d_fusion_integrate", "i3d_fusion_finish", "i3d_fusion_info", "i3d_fusion_get",
            "i3d_fusion_save",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
@@ -163,6 +163,7 @@ def load():
     L.i3d_fusion_get.restype = i32; L.i3d_fusion_get.argtypes = [vp, vp, vp, vp, vp]
     L.i3d_fusion_save.restype = i32; L.i3d_fusion_save.argtypes = [vp, cp]
     L.i3d_debug_map_order.restype = i64; L.i3d_debug_map_order.argtypes = [vp, i64, i32, vp]
+    L.i3d_blur_score.restype = i32; L.i3d_blur_score.argtypes = [vp, i32, i32, i32, vp]
     L.i3d_yaml_get.restype = i32; L.i3d_yaml_get.argtypes = [cp, cp, vp, u64]
     L.i3d_png_info.restype = i32; L.i3d_png_info.argtypes = [vp, u64, vp, vp, vp, vp]
     L.i3d_png_decode.restype = i32; L.i3d_png_decode.argtypes = [vp, u64, vp, u64]
@@ -716,3 +717,10 @@ def debug_map_order(keys, mode=0):
     k = np.ascontiguousarray(keys, np.int32); out = np.zeros(k.shape[0], np.int32)
     n = load().i3d_debug_map_order(_p(k), k.shape[0], int(mode), _p(out))
     return out[:n]
+
+
+def blur_score(image):
+    """KeyframeSelection::estimateBlur of an HxW (grey) or HxWx3 (B,G,R) uint8 image"""
+    a = np.ascontiguousarray(image, np.uint8); out = C.c_double(0)
+    _io_check(load().i3d_blur_score(_p(a), a.shape[1], a.shape[0], 1 if a.ndim == 2 else a.shape[2], C.byref(out)), "i3d_blur_score")
+    return out.value

@@ -10,6 +10,7 @@
 // layout imdecode produces (BGR[A] order, 16-bit kept, palette/low-bit-depth expanded).
 #include "../../../include/intrinsic3d_hip.h"
 #include <zlib.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -440,6 +441,38 @@ int i3d_keyframes_select(int32_t window_size, uint64_t count, const double* scor
         for (uint64_t i = beg; i < end; ++i) if (scores[i] > best) { best = scores[i]; arg = i; }
         for (uint64_t i = beg; i < end; ++i) is_keyframe[i] = (i == arg);
     }
+    return I3D_OK;
+}
+
+// KeyframeSelection::estimateBlur / estimateBlurCrete (keyframe_selection.cpp:219-311): the no-reference perceptual blur metric of Crete et
+// al. 2007 on the grey image in [0,1]; 1.0 = sharp, 0.0 = blurred.  8-bit BGR -> grey with cv::cvtColor's fixed-point weights
+// (R 4899, G 9617, B 1868, >> 14 with rounding); the 9-tap box filters use BORDER_REFLECT_101 like cv::filter2D's default.
+int i3d_blur_score(const uint8_t* image, int32_t width, int32_t height, int32_t channels, double* score) {
+    if (!image || !score || width <= 0 || height <= 0) return I3D_ERR_INVALID_ARGUMENT;
+    *score = 0.0;
+    if (channels != 1 && channels != 3) return I3D_OK;                              // estimateBlur returns 0.0 for other layouts
+    const int w = width, h = height; const size_t n = (size_t)w * h;
+    std::vector<float> g(n), bv(n), bh(n);
+    const float s255 = (float)(1.0 / 255.0);
+    for (size_t i = 0; i < n; ++i) {
+        const int v = channels == 1 ? image[i] : (image[3 * i] * 1868 + image[3 * i + 1] * 9617 + image[3 * i + 2] * 4899 + (1 << 13)) >> 14;
+        g[i] = (float)v * s255;
+    }
+    auto refl = [](int p, int len) { if (len == 1) return 0; while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p; return p; };
+    const float k9 = (float)(1.0 / 9.0);
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        float sv = 0.0f, sh = 0.0f;
+        for (int k = -4; k <= 4; ++k) { sv += k9 * g[(size_t)refl(y + k, h) * w + x]; sh += k9 * g[(size_t)y * w + refl(x + k, w)]; }
+        bv[(size_t)y * w + x] = sv; bh[(size_t)y * w + x] = sh;
+    }
+    double s_f_ver = 0, s_v_ver = 0, s_f_hor = 0, s_v_hor = 0;
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        const size_t i = (size_t)y * w + x;
+        if (y >= 1) { const float df = std::fabs(g[i] - g[i - w]), db = std::fabs(bv[i] - bv[i - w]); s_f_ver += df; s_v_ver += std::max(0.0f, df - db); }
+        if (x >= 1) { const float df = std::fabs(g[i] - g[i - 1]), db = std::fabs(bh[i] - bh[i - 1]); s_f_hor += df; s_v_hor += std::max(0.0f, df - db); }
+    }
+    const double b_ver = (s_f_ver - s_v_ver) / s_f_ver, b_hor = (s_f_hor - s_v_hor) / s_f_hor;
+    *score = 1.0 - std::max(b_ver, b_hor);
     return I3D_OK;
 }
 

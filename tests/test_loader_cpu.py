@@ -271,3 +271,49 @@ def test_yaml_get_and_cli_usage(tmp_path):
         assert r.returncode == 2
         r = subprocess.run([exe, f"--sensor={yml}", flag, str(yml)], capture_output=True, text=True)   # no frames in ./rgbd/: Sensor::create fails
         assert r.returncode == 1 and "RGB-D sensor could not be initialized" in r.stderr
+
+
+def test_blur_score_and_app_keyframes(tmp_path):
+    """KeyframeSelection::estimateBlur (Crete et al. 2007) against a numpy/scipy formulation, and apps/app_keyframes end to end (host only)"""
+    import os, subprocess, sys
+    from scipy.ndimage import correlate1d, gaussian_filter
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:120, 0:160]
+    sharp = ((np.sin(xx * 0.9) * np.cos(yy * 0.7) > 0) * 200 + rng.integers(0, 40, xx.shape)).astype(np.uint8)
+    bgr = np.stack([sharp, np.roll(sharp, 3, 1), np.roll(sharp, 5, 0)], -1)
+
+    def crete(img_bgr):
+        b, g, r = (img_bgr[..., c].astype(np.int64) for c in range(3))
+        grey = ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.float32) * np.float32(1.0 / 255.0)
+        k = np.full(9, np.float32(1.0 / 9.0), np.float32)
+        bv = correlate1d(grey, k, axis=0, mode="mirror"); bh = correlate1d(grey, k, axis=1, mode="mirror")
+        dfv = np.abs(np.diff(grey, axis=0)); dbv = np.abs(np.diff(bv, axis=0)); dfh = np.abs(np.diff(grey, axis=1)); dbh = np.abs(np.diff(bh, axis=1))
+        sfv, svv = dfv.sum(dtype=np.float64), np.maximum(0, dfv - dbv).sum(dtype=np.float64)
+        sfh, svh = dfh.sum(dtype=np.float64), np.maximum(0, dfh - dbh).sum(dtype=np.float64)
+        return 1.0 - max((sfv - svv) / sfv, (sfh - svh) / sfh)
+
+    s_sharp = B.blur_score(bgr)
+    assert abs(s_sharp - crete(bgr)) < 1e-5
+    soft = np.stack([gaussian_filter(bgr[..., c].astype(np.float32), 2.0) for c in range(3)], -1).astype(np.uint8)
+    s_soft = B.blur_score(soft)
+    assert abs(s_soft - crete(soft)) < 1e-5 and 0.0 < s_soft < s_sharp <= 1.0
+    assert abs(B.blur_score(sharp) - B.blur_score(np.stack([sharp] * 3, -1))) < 1e-3          # grey input skips cvtColor; same image up to its rounding
+    # the CLI: scores of all frames, the sharpest of every window of 3 is the keyframe
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "apps", "app_keyframes")
+    if not os.path.exists(exe):
+        pytest.skip("apps not built")
+    _make_dataset(tmp_path / "rgbd", 7, rng)
+    for i in (1, 5):                                                                           # blur two frames: they must not be selected
+        p = tmp_path / "rgbd" / f"frame-{i:06d}.color.png"
+        im = np.asarray(Image.open(p)).astype(np.float32)
+        Image.fromarray(np.stack([gaussian_filter(im[..., c], 1.5) for c in range(3)], -1).astype(np.uint8)).save(p)
+    (tmp_path / "sensor.yml").write_text('%YAML:1.0\ndataset: "./rgbd/"\nmax_frames: "0"\nmin_depth: "0.1"\nmax_depth: "2.0"\n')
+    (tmp_path / "keyframes.yml").write_text('%YAML:1.0\nwindow_size: "3"\nfilename: "./fusion/keyframes.txt"\nshow_keyframes: "0"\n')
+    r = subprocess.run([exe, "-s", str(tmp_path / "sensor.yml"), "-k", str(tmp_path / "keyframes.yml")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    win, scores, kf = B.keyframes_load(str(tmp_path / "fusion" / "keyframes.txt"))
+    s = B.Sensor(tmp_path / "rgbd")
+    want = np.array([B.blur_score(s.color(i)) for i in range(7)])
+    assert win == 3 and np.allclose(scores, want, atol=1e-6) and np.array_equal(kf, B.keyframes_select(3, want))
+    assert kf.sum() == 3 and not kf[1] and not kf[5] and kf[6]

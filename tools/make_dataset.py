@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Write a synthetic scene in the reference's on-disk dataset layout, ready for apps/app_intrinsic3d:
 
-    <out>/sensor.yml  <out>/intrinsic3d.yml  <out>/fusion.yml
+    <out>/sensor.yml  <out>/intrinsic3d.yml  <out>/fusion.yml  <out>/keyframes.yml
     <out>/rgbd/frame-%06d.{color,depth}.png  .pose.txt  colorIntrinsics.txt  depthIntrinsics.txt      (rgbd/sensor_i3d.cpp:184-220)
     <out>/fusion/keyframes.txt  <out>/fusion/volume_<voxel size>.tsdf                                  (what AppKeyframes / AppFusion leave)
 
     python tools/make_dataset.py --out /tmp/ds --radius 40 --frames 12
+    apps/app_keyframes -s /tmp/ds/sensor.yml -k /tmp/ds/keyframes.yml      # optional: re-selects the keyframes by blur score (host only)
     apps/app_fusion -s /tmp/ds/sensor.yml -f /tmp/ds/fusion.yml            # optional: replaces the analytic volume by one fused from the frames
     apps/app_intrinsic3d -s /tmp/ds/sensor.yml -i /tmp/ds/intrinsic3d.yml
 """
@@ -57,6 +58,8 @@ def write_dataset(out, sc, window=1, grid_levels=2, rgbd_levels=2, iterations=2,
         f.write('%YAML:1.0\n\n# sdf fusion config\nkeyframes: ""\n' + f'voxel_size: "{float(sc["voxel_size"]):g}"\ndiscont_window_size: "2"\n'
                 + "".join(f'clip_{a}: "0.0"\n' for a in ("x0", "x1", "y0", "y1", "z0", "z1"))
                 + f'output_mesh: "./fusion/mesh_{float(sc["voxel_size"]):g}.ply"\noutput_sdf: "{tsdf}"\n')
+    with open(os.path.join(out, "keyframes.yml"), "w") as f:               # data/keyframes.yml of the reference
+        f.write(f'%YAML:1.0\n\n# keyframe selection config\nwindow_size: "{window}"\nfilename: "./fusion/keyframes.txt"\nshow_keyframes: "0"\n')
     return os.path.join(out, "sensor.yml"), os.path.join(out, "intrinsic3d.yml")
 
 
