@@ -104,7 +104,7 @@ def test_fusion_errors():
 
 
 def test_app_fusion_then_app_intrinsic3d(oracle, tmp_path):
-    """the two CLIs back to back on a dataset folder in the reference's layout: app_fusion's volume is byte-identical to the oracle's fusion of
+    """the three CLIs back to back (keyframes -> fusion -> refinement) on a dataset folder in the reference's layout: app_fusion's volume is byte-identical to the oracle's fusion of
     the same decoded frames, and app_intrinsic3d refines it"""
     import subprocess
     from intrinsic3d_amd import binding as B, synthetic
@@ -113,8 +113,11 @@ def test_app_fusion_then_app_intrinsic3d(oracle, tmp_path):
     s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=1, rgbd_levels=1, iterations=1)
     tsdf = tmp_path / "fusion" / f"volume_{float(sc['voxel_size']):g}.tsdf"
     tsdf.unlink()                                                                     # the analytic volume the writer leaves: app_fusion must produce its own
-    for name in ("app_fusion", "app_intrinsic3d"):
+    for name in ("app_keyframes", "app_fusion", "app_intrinsic3d"):
         assert os.path.exists(os.path.join(ROOT, "apps", name)), f"apps/{name} has not been built (run __graft_entry__.build())"
+    (tmp_path / "fusion" / "keyframes.txt").unlink()                                  # ... and app_keyframes the keyframe list (window 1: every frame)
+    r = subprocess.run([os.path.join(ROOT, "apps", "app_keyframes"), "-s", s_yml, "-k", str(tmp_path / "keyframes.yml")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and B.keyframes_load(str(tmp_path / "fusion" / "keyframes.txt"))[2].all(), r.stdout + r.stderr
     r = subprocess.run([os.path.join(ROOT, "apps", "app_fusion"), "-s", s_yml, "-f", str(tmp_path / "fusion.yml")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "integrating frame 5" in r.stdout, r.stdout + r.stderr
     vol = B.tsdf_read(str(tsdf))
