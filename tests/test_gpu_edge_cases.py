@@ -127,8 +127,9 @@ def test_one_call_host_entry_point_matches_resident_path(oracle):
                                                         arrays["color"], sc["frames"], sc["levels"], sc["intr"], sc["dist"], sc["poses"], vsh)
     assert [list(s.rows) for s in st1] == [list(s.rows) for s in st2]
     smax = np.abs(sdf1).max()
-    assert np.abs(sdf1 - sdf2).max() <= 5e-5 * smax and np.abs(alb1 - alb2).max() <= 5e-5
-    np.testing.assert_allclose(i2, i1, rtol=5e-5); np.testing.assert_allclose(p2, p1, rtol=1e-4, atol=1e-6)
+    # two device runs of the same problem: they differ by the summation order of the fp32 atomics (north-star tolerance)
+    assert np.abs(sdf1 - sdf2).max() <= 1e-4 * smax and np.abs(alb1 - alb2).max() <= 1e-4
+    np.testing.assert_allclose(i2, i1, rtol=1e-4); np.testing.assert_allclose(p2, p1, rtol=1e-4, atol=1e-6)
     assert np.abs(sdf2 - arrays["sdf_refined"]).max() > 0                       # the unknowns did move and were written back
     g.free(); fr.free()
 
@@ -157,7 +158,7 @@ def test_real_rccl_collectives_with_one_rank(oracle, monkeypatch):
     ctx.comm_init(0, 1, binding.Context.comm_unique_id())
     st1 = ctx.optimize(cfg); s1, a1 = ctx.get_grid(); cam1 = ctx.get_camera(); ctx.close()
     assert [list(s.rows) for s in st0] == [list(s.rows) for s in st1]
-    assert np.abs(s1 - s0).max() <= 5e-5 * np.abs(s0).max() and np.abs(a1 - a0).max() <= 5e-5
+    assert np.abs(s1 - s0).max() <= 1e-4 * np.abs(s0).max() and np.abs(a1 - a0).max() <= 1e-4
     np.testing.assert_allclose(cam1[2], cam0[2], rtol=1e-4, atol=1e-6)
     g.free(); fr.free()
 

@@ -207,12 +207,12 @@ def test_sharded_ranks_match_single_rank(setup):
                 assert list(s1.rows) == list(s2.rows) and s1.valid_voxels == s2.valid_voxels and s1.free_parameters == s2.free_parameters
                 # iteration 0 starts from identical state: only the fp64 summation order differs; later ones inherit the fp32 PCG round-off
                 # (fp32 atomics inside the operator make the PCG round-off run-to-run variable; the bar is the north-star 1e-4)
-                assert abs(s1.cost_initial - s2.cost_initial) <= (1e-12 if k == 0 else 5e-5) * s1.cost_initial
-                assert abs(s1.cost_final - s2.cost_final) <= 5e-5 * s1.cost_final
+                assert abs(s1.cost_initial - s2.cost_initial) <= (1e-12 if k == 0 else 1e-4) * s1.cost_initial
+                assert abs(s1.cost_final - s2.cost_final) <= 1e-4 * s1.cost_final
                 assert list(s1.step_accepted[:s1.num_attempts]) == list(s2.step_accepted[:s2.num_attempts])
-            assert np.abs(sdf - rsdf).max() <= 5e-5 * np.abs(rsdf).max()      # fp32 PCG round-off, different partial-sum order
-            assert np.abs(alb - ralb).max() <= 5e-5 * np.abs(ralb).max()
-            np.testing.assert_allclose(gi, ri, rtol=5e-5); np.testing.assert_allclose(gp, rp, rtol=5e-5, atol=1e-6)
+            assert np.abs(sdf - rsdf).max() <= 1e-4 * np.abs(rsdf).max()      # fp32 PCG round-off, different partial-sum order
+            assert np.abs(alb - ralb).max() <= 1e-4 * np.abs(ralb).max()
+            np.testing.assert_allclose(gi, ri, rtol=1e-4); np.testing.assert_allclose(gp, rp, rtol=1e-4, atol=1e-6)
             np.testing.assert_allclose(gd, rd, rtol=5e-3, atol=5e-4)   # k2,k3 barely observable: ill-conditioned block (see test_optimize_matches_oracle)
             c.close()
         L.i3d_comm_sim_destroy(shared)
@@ -302,7 +302,7 @@ def test_multi_tile_problem_matches_oracle(oracle):
     assert not any(t.is_alive() for t in th) and all(e is None for e in err), err
     for c in ctxs:
         s2, a2 = c.get_grid()
-        assert np.abs(s2 - sdf).max() <= 5e-5 * np.abs(sdf).max() and np.abs(a2 - alb).max() <= 5e-5
+        assert np.abs(s2 - sdf).max() <= 1e-4 * np.abs(sdf).max() and np.abs(a2 - alb).max() <= 1e-4
         c.close()
     L.i3d_comm_sim_destroy(shared)
     g.free(); fr.free()
