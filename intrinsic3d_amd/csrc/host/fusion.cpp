@@ -187,8 +187,8 @@ int i3d_fusion_finish(i3d_fusion* f, int32_t correct_iterations, uint64_t* count
     F_HIP(f, hipStreamSynchronize(st));
     f->allocated = m;
     if (m > 0x7FFFFFFFull) return fail(f, I3D_ERR_CAPACITY, "fusion: more than 2^31 voxels");
-    f->finished = true; f->out_keys.clear(); f->out_sdf.clear(); f->out_weight.clear(); f->out_color.clear();
-    if (m == 0) { if (count) *count = 0; return I3D_OK; }
+    f->out_keys.clear(); f->out_sdf.clear(); f->out_weight.clear(); f->out_color.clear();
+    if (m == 0) { f->finished = true; if (count) *count = 0; return I3D_OK; }
     DevBuf<unsigned long long> rank0, rank1; DevBuf<unsigned int> slot0, slot1;
     F_HIP(f, rank0.alloc(m)); F_HIP(f, rank1.alloc(m)); F_HIP(f, slot0.alloc(m)); F_HIP(f, slot1.alloc(m));
     launch_fusion_gather_rank(st, t, flags.p, offs.p, rank0.p, slot0.p);
@@ -267,6 +267,7 @@ int i3d_fusion_finish(i3d_fusion* f, int32_t correct_iterations, uint64_t* count
         F_HIP(f, hipMemcpyAsync(f->out_color.data(), oc.p, 3 * nv, hipMemcpyDeviceToHost, st));
         F_HIP(f, hipStreamSynchronize(st));
     }
+    f->finished = true;                                  // only now: a failed finish can be diagnosed (i3d_fusion_last_error) and is not mistaken for an empty volume
     if (count) *count = nv;
     return I3D_OK;
 }
