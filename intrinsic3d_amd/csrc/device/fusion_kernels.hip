@@ -27,12 +27,13 @@ __device__ inline void unpack_key(unsigned long long k, int& x, int& y, int& z) 
 __device__ inline unsigned long long slot_of(unsigned long long key, unsigned long long mask) { return ((key * 0x9E3779B97F4A7C15ull) >> 17) & mask; }
 __device__ inline long long find_slot(const FusionTable& t, unsigned long long key) {
     unsigned long long s = slot_of(key, t.mask);
-    for (;;) {
+    for (unsigned long long probes = 0; probes <= t.mask; ++probes) {      // bounded: a completely full table has no empty slot to stop at
         const unsigned long long k = t.keys[s];
         if (k == key) return (long long)s;
         if (k == FUSION_EMPTY) return -1;
         s = (s + 1) & t.mask;
     }
+    return -1;
 }
 __device__ inline int round_trunc(float v) { return (int)(v + 0.5f); }                                   // mat.h:90
 __device__ inline void xform(const float* T, float px, float py, float pz, float q[3]) {

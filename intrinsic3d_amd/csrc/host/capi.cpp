@@ -43,14 +43,14 @@ int i3d_comm_init(i3d_context* c, int32_t rank, int32_t world, const void* uniqu
     Comm* cm = make_rccl_comm(rank, world, unique_id, (size_t)id_bytes, c->stream, err, sizeof(err));
     if (!cm) return ctx_fail(c, I3D_ERR_COMM, err);
     { const char* e = std::getenv("I3D_FORCE_COLLECTIVES"); cm->force = e && e[0] == '1'; }      // test hook: sharded path with a 1-rank communicator
-    delete c->comm; c->comm = cm; c->assembled = false;
+    delete c->comm; c->comm = cm; c->assembled = false; c->slots = 0;      // solver vectors are sized for the world: re-derive storage
     return I3D_OK;
 }
 void* i3d_comm_sim_create(int32_t world) { return world >= 1 ? sim_create(world) : nullptr; }
 void i3d_comm_sim_destroy(void* shared) { if (shared) sim_destroy((SimShared*)shared); }
 int i3d_comm_init_sim(i3d_context* c, void* shared, int32_t rank) {
     if (!c || !shared) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_comm_init_sim: bad arguments");
-    delete c->comm; c->comm = make_sim_comm((SimShared*)shared, rank); c->assembled = false;
+    delete c->comm; c->comm = make_sim_comm((SimShared*)shared, rank); c->assembled = false; c->slots = 0;
     return I3D_OK;
 }
 

@@ -49,7 +49,8 @@ struct i3d_fusion {
     DevBuf<unsigned long long> d_count; DevBuf<int> d_flag;
     DevBuf<float> d_depth_raw, d_depth, d_normals; DevBuf<uint8_t> d_bgr;
     // result of finish()
-    bool finished = false; std::vector<int32_t> out_keys; std::vector<float> out_sdf, out_weight; std::vector<uint8_t> out_color;
+    bool finished = false, corrected = false;      // corrected: correctSDF has been written into the table (finish is not re-runnable past that point)
+    std::vector<int32_t> out_keys; std::vector<float> out_sdf, out_weight; std::vector<uint8_t> out_color;
     unsigned long long allocated = 0; int correct_launches = 0;
     std::string error;
     FusionTable table() { return FusionTable{keys.p, sdf.p, weight.p, color.p, rank.p, crank.p, capacity - 1}; }
@@ -136,7 +137,7 @@ int i3d_fusion_integrate(i3d_fusion* f, int32_t dw, int32_t dh, const float* dca
                          const float* pose16, int32_t erode_window) {
     if (!f) return I3D_ERR_INVALID_ARGUMENT;
     if (dw <= 0 || dh <= 0 || cw <= 0 || ch <= 0 || !dcam4 || !ccam4 || !depth || !bgr || !pose16) return fail(f, I3D_ERR_INVALID_ARGUMENT, "i3d_fusion_integrate: bad arguments");
-    if (f->finished) return fail(f, I3D_ERR_STATE, "i3d_fusion_integrate: the volume has been finished");
+    if (f->finished || f->corrected) return fail(f, I3D_ERR_STATE, "i3d_fusion_integrate: the volume has been finished (or a finish failed after correcting the table)");
     F_HIP(f, hipSetDevice(f->device));
     hipStream_t st = f->stream;
     const size_t dn = (size_t)dw * dh, cn = (size_t)cw * ch;
@@ -160,8 +161,14 @@ int i3d_fusion_integrate(i3d_fusion* f, int32_t dw, int32_t dh, const float* dca
         int overflow = 0;
         F_HIP(f, hipMemcpyAsync(&overflow, f->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
         F_HIP(f, hipStreamSynchronize(st));
-        if (!overflow) break;
-        const int rc = grow(f); if (rc) return rc;
+        if (overflow) { const int rc = grow(f); if (rc) return rc; continue; }
+        // the in-kernel load test lags by the inserts of the waves in flight: keep the load factor of the finished frame below 0.6 as well
+        unsigned long long have = 0;
+        F_HIP(f, hipMemcpyAsync(&have, f->d_count.p, sizeof(have), hipMemcpyDeviceToHost, st));
+        F_HIP(f, hipStreamSynchronize(st));
+        if ((double)have <= 0.6 * (double)f->capacity) break;
+        const int rc = grow(f); if (rc) return rc;         // rehash only: every cell of this frame already exists
+        break;
     }
     launch_fusion_integrate(st, f->table(), fr, dcam, ccam, f->d_depth.p, f->d_normals.p, f->d_bgr.p);
     F_HIP(f, hipStreamSynchronize(st));                                                              // the host buffers may be reused by the caller
@@ -172,6 +179,7 @@ int i3d_fusion_integrate(i3d_fusion* f, int32_t dw, int32_t dh, const float* dca
 int i3d_fusion_finish(i3d_fusion* f, int32_t correct_iterations, uint64_t* count) {
     if (!f) return I3D_ERR_INVALID_ARGUMENT;
     if (f->finished) { if (count) *count = f->out_sdf.size(); return I3D_OK; }
+    if (f->corrected) return fail(f, I3D_ERR_STATE, "i3d_fusion_finish: an earlier finish failed after correctSDF had been written into the table; the volume cannot be finished twice");
     F_HIP(f, hipSetDevice(f->device));
     hipStream_t st = f->stream; FusionTable t = f->table();
     const unsigned long long cap = f->capacity;
@@ -240,6 +248,7 @@ int i3d_fusion_finish(i3d_fusion* f, int32_t correct_iterations, uint64_t* count
             F_HIP(f, hipStreamSynchronize(st));
             if (!has_update) break;
         }
+        f->corrected = true;                              // from here on the table holds corrected values: a retry would correct them twice
         launch_fusion_write_back(st, t, (long long)m, slot_c.p, c_sdf.p, c_touched.p);
         F_HIP(f, hipStreamSynchronize(st));
     }

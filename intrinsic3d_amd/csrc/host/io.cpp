@@ -55,8 +55,10 @@ bool read_flat_yaml(const char* path, std::map<std::string, std::string>& kv) {
     std::string line;
     auto trim = [](const std::string& s) { const char* ws = " \t\r\n\""; const size_t a = s.find_first_not_of(ws); if (a == std::string::npos) return std::string(); return s.substr(a, s.find_last_not_of(ws) - a + 1); };
     while (std::getline(f, line)) {
-        const size_t hash = line.find('#'); if (hash != std::string::npos) line.erase(hash);
-        const size_t colon = line.find(':'); if (colon == std::string::npos || line[0] == '%') continue;
+        bool quoted = false; size_t hash = std::string::npos;          // '#' starts a comment only outside a quoted value (paths may contain it)
+        for (size_t i = 0; i < line.size(); ++i) { if (line[i] == '"') quoted = !quoted; else if (line[i] == '#' && !quoted) { hash = i; break; } }
+        if (hash != std::string::npos) line.erase(hash);
+        const size_t colon = line.find(':'); if (colon == std::string::npos || line.empty() || line[0] == '%') continue;
         const std::string k = trim(line.substr(0, colon)), v = trim(line.substr(colon + 1));
         if (!k.empty()) kv[k] = v;
     }

@@ -132,6 +132,7 @@ int i3d_set_frames_rgbd(i3d_context* c, int32_t K, int32_t levels, int32_t width
     CTX_HIP(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->have_frames = false; c->K = K; c->levels = levels;
+    c->slots = 0; c->assembled = false;            // K sizes the camera blocks and solver vectors: force alloc_rows() to run again
     c->fw.resize(levels); c->fh.resize(levels);
     for (int l = 0; l < levels; ++l) { c->fw[l] = l ? c->fw[l - 1] / 2 : width; c->fh[l] = l ? c->fh[l - 1] / 2 : height; }
     c->lum.clear(); c->depth.clear(); c->bgr.clear();

@@ -61,7 +61,7 @@ bool unfilter(uint8_t* raw, size_t rows, size_t rowbytes, size_t bpp) {
     return true;
 }
 
-int png_decode(const uint8_t* d, size_t n, PngImage& out, bool header_only) {
+static int png_decode_impl(const uint8_t* d, size_t n, PngImage& out, bool header_only) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     if (!d || n < 8 + 25 || std::memcmp(d, sig, 8) != 0) return I3D_ERR_IO;
     PngHeader hd; bool have_ihdr = false, have_end = false;
@@ -109,11 +109,16 @@ int png_decode(const uint8_t* d, size_t n, PngImage& out, bool header_only) {
         const size_t pw = pass_dim(hd.w, passes[p].xs, passes[p].dx), ph = pass_dim(hd.h, passes[p].ys, passes[p].dy);
         if (pw && ph) total += ph * (1 + (pw * bits + 7) / 8);
     }
+    // a deflate stream expands at most ~1032:1: an IHDR that promises more pixels than the IDAT data can hold is corrupt (and would
+    // otherwise size the buffers below from attacker-controlled dimensions)
+    // (zlib's avail_in / avail_out are 32-bit: larger streams are refused rather than truncated)
+    if (total >= ((size_t)1 << 31) || idat.size() >= ((size_t)1 << 31) || total / 1100 > idat.size() + 64) return I3D_ERR_IO;
     std::vector<uint8_t> raw(total);
     z_stream zs; std::memset(&zs, 0, sizeof(zs));
     if (inflateInit(&zs) != Z_OK) return I3D_ERR_IO;
     zs.next_in = idat.data(); zs.avail_in = (uInt)idat.size(); zs.next_out = raw.data(); zs.avail_out = (uInt)raw.size();
-    const int zr = inflate(&zs, Z_FINISH); const size_t got = zs.total_out; inflateEnd(&zs);
+    const int zr = inflate(&zs, Z_FINISH);
+    const size_t got = zs.total_out; inflateEnd(&zs);
     if ((zr != Z_STREAM_END && zr != Z_OK && zr != Z_BUF_ERROR) || got != total) return I3D_ERR_IO;
 
     // samples of every pixel at file depth
@@ -261,6 +266,11 @@ struct i3d_sensor {
     std::vector<float> poses;                              // 16 per stored frame, camera-to-world, row-major
     bool stored(int id) const { return id >= 0 && id < num_frames && (size_t)id < depth_png.size(); }
 };
+
+// no exception may cross the C ABI: allocation failures on hostile dimensions become an I/O error
+int png_decode(const uint8_t* d, size_t n, PngImage& out, bool header_only) {
+    try { return png_decode_impl(d, n, out, header_only); } catch (const std::exception&) { return I3D_ERR_IO; }
+}
 
 extern "C" {
 
