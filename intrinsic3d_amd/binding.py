@@ -540,7 +540,7 @@ def write_ply(path, vertices, colors, faces):
 
 
 def mc_tables():
-    ntri = np.zeros(256, np.uint8); tri = np.zeros((256, 24), np.int8)
+    ntri = np.zeros(256, np.uint8); tri = np.zeros((256, 16), np.int8)
     mx = load().i3d_mc_tables(_p(ntri), _p(tri))
     return ntri, tri, mx
 

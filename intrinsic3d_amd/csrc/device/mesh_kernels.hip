@@ -2,8 +2,7 @@
 // (mesh/marching_cubes.cpp:178-343), one lane per stored voxel in VISIT order, two passes (count, scan, emit).
 // Cube corners and edges use the reference's numbering (corner 0 = (x+1,y+1,z), 1 = (x+1,y,z), 2 = (x,y,z), 3 = (x,y+1,z), 4..7 the same
 // at z+1; edge e joins corners EA[e] -> EB[e] in that direction, which fixes the interpolation formula's operand order).
-// The triangulation table is NOT the reference's literal table: it is generated at start-up (host/mesh.cpp) from the cube topology
-// (face tracing, inside corners isolated on ambiguous faces, fans oriented outward), see DESIGN.md.
+// The triangulation table is Bourke's (host/mc_table.hpp, unpacked by host/mesh.cpp): the triangle sequence of a cell equals the reference's.
 #include "kernels.hpp"
 #include "level_kernels.hpp"
 

@@ -3,16 +3,11 @@
 // as driven by SDFVisualization::exportMesh (sdf/visualization.cpp:167-196).  Triangles are produced on the device
 // (mesh_kernels.hip); unification, cleaning and the PLY stream are host work.
 //
-// Triangulation table.  The reference carries the literal 256-case table of Bourke's "Polygonising a scalar field".  Here the table
-// is GENERATED from the cube's topology when the library is first used: for a configuration, every cube face contributes the
-// segments between its cut edges (an ambiguous face — two diagonal inside corners — isolates the INSIDE corners, a rule that only
-// depends on the face's own corners, so neighbouring cells agree and the surface has no cracks); the segments chain into closed
-// loops; segments are DIRECTED (inside corners on a fixed side seen from outside the cube) so every loop winds counter-clockwise around a
-// normal pointing from the inside (sdf < 0) to the outside; a loop is split into triangles by the
-// first triangulation (fixed enumeration order) none of whose chords lies in a cube face.  Vertices, their interpolation and their unification are exactly the reference's; the split of a polygon into
-// triangles (and hence the face order inside a cell) may differ from the literal table.
+// Triangulation table: Bourke's 256-case table (the one the reference carries, marching_cubes.cpp:330-623) in the packed form of
+// mc_table.hpp, so cells, triangles, faces and therefore the PLY stream are identical to the reference's, not just the vertex set.
 #include "context.hpp"
 #include "../device/level_kernels.hpp"
+#include "mc_table.hpp"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <fstream>
@@ -22,105 +17,14 @@
 namespace i3d {
 namespace {
 
-constexpr int MC_STRIDE = 24;              // up to 8 triangles per configuration
-struct McTables { unsigned char ntri[256]; signed char tri[256 * MC_STRIDE]; int max_tri; int fallbacks = 0; bool ready = false; };
+constexpr int MC_STRIDE = 16;              // up to 5 triangles per configuration (15 edge ids), -1 padded like the reference's rows
+struct McTables { unsigned char ntri[256]; signed char tri[256 * MC_STRIDE]; int max_tri = 0; bool ready = false; };
 
-// cube geometry in the reference's numbering
-const int CORNER[8][3] = {{1, 1, 0}, {1, 0, 0}, {0, 0, 0}, {0, 1, 0}, {1, 1, 1}, {1, 0, 1}, {0, 0, 1}, {0, 1, 1}};
-const int EA[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, EB[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
-// faces as corner cycles (any orientation; orientation of the output is fixed geometrically below)
-const int FACE[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {3, 0, 4, 7}};
-
-// two cube edges lie in a common face: a chord between their vertices would lie IN that face, where the neighbouring cell has no
-// matching triangle side (a crack / non-manifold edge); the triangulation of a loop must avoid such chords
-bool edges_share_face(int e1, int e2) {
-    for (int f = 0; f < 6; ++f) {
-        bool in1 = false, in2 = false;
-        for (int i = 0; i < 4; ++i) {
-            const int a = FACE[f][i], b = FACE[f][(i + 1) & 3];
-            if ((EA[e1] == a && EB[e1] == b) || (EA[e1] == b && EB[e1] == a)) in1 = true;
-            if ((EA[e2] == a && EB[e2] == b) || (EA[e2] == b && EB[e2] == a)) in2 = true;
-        }
-        if (in1 && in2) return true;
-    }
-    return false;
-}
-// first triangulation (in a fixed enumeration order) of the polygon poly[lo..hi] whose chords never join two edges of one face;
-// triangles keep the polygon's orientation
-bool triangulate(const std::vector<int>& poly, int lo, int hi, std::vector<int>& tris) {
-    if (hi - lo < 2) return true;
-    for (int k = lo + 1; k < hi; ++k) {
-        if (k > lo + 1 && edges_share_face(poly[lo], poly[k])) continue;
-        if (k < hi - 1 && edges_share_face(poly[k], poly[hi])) continue;
-        const size_t mark = tris.size();
-        tris.push_back(poly[lo]); tris.push_back(poly[k]); tris.push_back(poly[hi]);
-        if (triangulate(poly, lo, k, tris) && triangulate(poly, k, hi, tris)) return true;
-        tris.resize(mark);
-    }
-    return false;
-}
-
-int edge_between(int a, int b) { for (int e = 0; e < 12; ++e) if ((EA[e] == a && EB[e] == b) || (EA[e] == b && EB[e] == a)) return e; return -1; }
-
-void build_tables(McTables& T) {
-    T.max_tri = 0;
+void build_tables(McTables& T) {           // unpack mc_table.hpp into the byte table the kernels read
     for (int idx = 0; idx < 256; ++idx) {
-        T.ntri[idx] = 0;
-        for (int k = 0; k < MC_STRIDE; ++k) T.tri[idx * MC_STRIDE + k] = -1;
-        if (idx == 0 || idx == 255) continue;
-        auto inside = [&](int c) { return (idx >> c) & 1; };
-        // DIRECTED segments between cut edges, face by face.  Seen from outside the cube, a segment A -> B keeps the inside corners on
-        // a fixed side:  ((B - A) x n_face) . (inside end - outside end of A's edge) > 0,  which makes every triangle (A, B, interior
-        // vertex) wind counter-clockwise around a normal that points from sdf < 0 to sdf > 0 — the same in every cell.
-        auto mid = [&](int e, double m[3]) { for (int d = 0; d < 3; ++d) m[d] = 0.5 * (CORNER[EA[e]][d] + CORNER[EB[e]][d]); };
-        std::vector<std::pair<int, int>> seg;
-        auto add_seg = [&](int f, int eA, int eB) {
-            double nf[3] = {0, 0, 0};
-            for (int i = 0; i < 4; ++i) for (int d = 0; d < 3; ++d) nf[d] += 0.25 * CORNER[FACE[f][i]][d];
-            for (int d = 0; d < 3; ++d) nf[d] -= 0.5;                                   // outward face normal (face centre - cube centre)
-            double A[3], B[3]; mid(eA, A); mid(eB, B);
-            const int a_in = inside(EA[eA]) ? EA[eA] : EB[eA], a_out = inside(EA[eA]) ? EB[eA] : EA[eA];
-            const double t[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
-            const double cr[3] = {t[1] * nf[2] - t[2] * nf[1], t[2] * nf[0] - t[0] * nf[2], t[0] * nf[1] - t[1] * nf[0]};
-            const double dsgn = cr[0] * (CORNER[a_in][0] - CORNER[a_out][0]) + cr[1] * (CORNER[a_in][1] - CORNER[a_out][1]) + cr[2] * (CORNER[a_in][2] - CORNER[a_out][2]);
-            if (dsgn > 0.0) seg.push_back({eA, eB}); else seg.push_back({eB, eA});
-        };
-        for (int f = 0; f < 6; ++f) {
-            int cut[4], ncut = 0;                                   // cut[i]: edge between cycle corners i and i+1
-            for (int i = 0; i < 4; ++i) { const int a = FACE[f][i], b = FACE[f][(i + 1) & 3]; if (inside(a) != inside(b)) cut[ncut++] = i; }
-            if (ncut == 2) add_seg(f, edge_between(FACE[f][cut[0]], FACE[f][(cut[0] + 1) & 3]), edge_between(FACE[f][cut[1]], FACE[f][(cut[1] + 1) & 3]));
-            else if (ncut == 4) {                                   // ambiguous: isolate each inside corner (its two incident edges of this face)
-                for (int i = 0; i < 4; ++i) if (inside(FACE[f][i])) {
-                    const int prev = FACE[f][(i + 3) & 3], next = FACE[f][(i + 1) & 3];
-                    add_seg(f, edge_between(prev, FACE[f][i]), edge_between(FACE[f][i], next));
-                }
-            }
-        }
-        // chain the directed segments into oriented loops (every cut edge has one incoming and one outgoing segment)
-        std::vector<char> used(seg.size(), 0);
-        std::vector<std::vector<int>> loops;
-        for (size_t s0 = 0; s0 < seg.size(); ++s0) {
-            if (used[s0]) continue;
-            std::vector<int> loop; used[s0] = 1; loop.push_back(seg[s0].first); int cur = seg[s0].second;
-            while (cur != loop[0]) {
-                loop.push_back(cur);
-                bool found = false;
-                for (size_t s = 0; s < seg.size() && !found; ++s) if (!used[s] && seg[s].first == cur) { used[s] = 1; cur = seg[s].second; found = true; }
-                if (!found) { T.fallbacks++; break; }
-            }
-            loops.push_back(loop);
-        }
-        // canonical start of each loop / order of the loops, then a triangulation without chords inside cube faces
-        for (auto& L : loops) std::rotate(L.begin(), std::min_element(L.begin(), L.end()), L.end());
-        std::sort(loops.begin(), loops.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a[0] < b[0]; });
-        int nt = 0;
-        for (auto& L : loops) {
-            const int n = (int)L.size();
-            std::vector<int> tris;
-            if (!triangulate(L, 0, n - 1, tris)) { tris.clear(); for (int i = 1; i + 1 < n; ++i) { tris.push_back(L[0]); tris.push_back(L[i]); tris.push_back(L[i + 1]); } T.fallbacks++; }
-            for (size_t i = 0; i < tris.size(); i += 3) { signed char* t = &T.tri[idx * MC_STRIDE + 3 * nt]; t[0] = (signed char)tris[i]; t[1] = (signed char)tris[i + 1]; t[2] = (signed char)tris[i + 2]; ++nt; }
-        }
+        const int nt = mc_num_triangles(idx);
         T.ntri[idx] = (unsigned char)nt; T.max_tri = std::max(T.max_tri, nt);
+        for (int k = 0; k < MC_STRIDE; ++k) T.tri[idx * MC_STRIDE + k] = k < 3 * nt ? (signed char)mc_edge(idx, k) : (signed char)-1;
     }
     T.ready = true;
 }
@@ -258,12 +162,12 @@ int i3d_export_mesh_ply(i3d_context* c, const char* path, int32_t use_refined_sd
     if (M.vertices.empty()) return ctx_fail(c, I3D_ERR_STATE, "i3d_export_mesh_ply: mesh could not be generated (no iso-surface)");
     return i3d_write_ply(path, (int64_t)(M.vertices.size() / 3), M.vertices.data(), M.colors.data(), (int64_t)(M.faces.size() / 3), M.faces.data());
 }
-// the generated triangulation table, for inspection / tests: ntri[256], tri[256][24] (edge ids, -1 padded)
+// the triangulation table the kernels use, for inspection / tests: ntri[256], tri[256][16] (edge ids, -1 padded); returns max triangles per cell
 int i3d_mc_tables(uint8_t* ntri, int8_t* tri) {
     const McTables& T = tables();
     if (ntri) std::memcpy(ntri, T.ntri, 256);
     if (tri) std::memcpy(tri, T.tri, 256 * MC_STRIDE);
-    return T.max_tri + 100 * T.fallbacks;       // fallbacks (a loop without a face-chord-free triangulation) must be 0
+    return T.max_tri;
 }
 
 }  // extern "C"

@@ -5,9 +5,15 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
  * library (include/intrinsic3d_hip.h) never links or calls it.
  *
- * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors and cannot be built
- * in this environment (Ceres 2.1.0 / Eigen / OpenCV / Boost absent), so this restatement is
- * checked only against finite differences, scipy dense solves and its own invariants.
+ * PARITY PARTLY PINNED: the reference ships no tests, fixtures or golden vectors and its library cannot
+ * be built in this environment (Ceres 2.1.0 / Eigen / OpenCV / Boost absent).  What CAN be executed of it
+ * is: oracle/extract_ref.py compiles the reference's own residual functors, camera / shading / SDF
+ * templates, observation weights, hash / rounding, grid container and marching cubes (cut out of
+ * /root/reference by file:line at build time) into oracle/_ref/libref_i3d.so over stand-ins for the
+ * absent Eigen / Ceres / OpenCV names, and tests/test_oracle_vs_ref.py holds this restatement against
+ * it.  Still unpinned: everything Ceres itself does (LM, CGNR, block-Jacobi, Jets, bicubic spline —
+ * restated from the published 2.1.0 algorithm on both sides), Eigen's float reduction order and
+ * OpenCV's pyrDown / cvtColor.
  */
 #ifndef I3D_ORACLE_H
 #define I3D_ORACLE_H
@@ -110,6 +116,25 @@ int32_t orc_test_lm_dense(int32_t m, int32_t n, int32_t nblocks, const int32_t* 
 int32_t orc_test_cgnr(int32_t m, int32_t n, int32_t nblocks, const int32_t* block_sizes, const double* A, const double* b, const double* D,
                       int32_t cg_fixed_iterations, double* x_out);
 int32_t orc_round_trunc(float v);
+
+/* primitive probes (same helpers the pipeline above runs), held against oracle/_ref by tests/test_oracle_vs_ref.py */
+double  orc_sdf_to_weight(double sdf, double truncation);
+double  orc_varying_lambda(int32_t it, int32_t n, double l0, double l1);
+int32_t orc_project_f(const float* fxfycxcy, const float* dist5, int32_t w, int32_t h, const float* p3, float* p2f, int32_t* p2i);
+int32_t orc_voxel_visible(float max_occlusion_distance, const float* pt3, int32_t w, int32_t h, const float* depth, int32_t x, int32_t y);
+float   orc_observation_weight(int32_t w, int32_t h, const float* depth, const float* n3, int32_t x, int32_t y, const float* v3);
+void    orc_compute_color(int32_t n, const uint8_t* rgb, const float* weights, float* out3);
+void    orc_filter(int32_t count, float* weights, int32_t keep, int32_t* order);
+double  orc_chroma_weight(const uint8_t* c3, const uint8_t* cn3);
+/* regulariser rows: type 1 = Er (x[7]: centre, +x,-x,+y,-y,+z,-z), 2 = Es (x[0], sdf0), 3 = Ea (x[2]) */
+double  orc_reg_row(int32_t type, const double* x, double sdf0, double* J);
+double  orc_sh_data_row(double luminance, const float* normal3, double albedo, const double* sh9, double* J9);
+void    orc_world_to_voxel(float voxel_size, const float* p3, int32_t* out3);
+/* marching cubes of the grid (sdf or sdf_refined): merged, cleaned mesh as MarchingCubes<VoxelSBR>::extractSurface returns it */
+void*   orc_mc_extract(void* g, int32_t use_refined);
+void    orc_mesh_counts(void* mesh, int64_t* nv, int64_t* nf);
+void    orc_mesh_get(void* mesh, float* verts, uint8_t* colors, int32_t* faces);
+void    orc_mesh_free(void* mesh);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,20 @@ def lib():
         L.orc_round_trunc.restype = i32; L.orc_round_trunc.argtypes = [f32]
         L.orc_test_lm_dense.restype = i32; L.orc_test_lm_dense.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]
         L.orc_test_cgnr.restype = i32; L.orc_test_cgnr.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp]
+        u8p = vp
+        L.orc_sdf_to_weight.restype = f64; L.orc_sdf_to_weight.argtypes = [f64, f64]
+        L.orc_varying_lambda.restype = f64; L.orc_varying_lambda.argtypes = [i32, i32, f64, f64]
+        L.orc_project_f.restype = i32; L.orc_project_f.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.orc_voxel_visible.restype = i32; L.orc_voxel_visible.argtypes = [f32, vp, i32, i32, vp, i32, i32]
+        L.orc_observation_weight.restype = f32; L.orc_observation_weight.argtypes = [i32, i32, vp, vp, i32, i32, vp]
+        L.orc_compute_color.argtypes = [i32, u8p, vp, vp]
+        L.orc_filter.argtypes = [i32, vp, i32, vp]
+        L.orc_chroma_weight.restype = f64; L.orc_chroma_weight.argtypes = [u8p, u8p]
+        L.orc_reg_row.restype = f64; L.orc_reg_row.argtypes = [i32, vp, f64, vp]
+        L.orc_sh_data_row.restype = f64; L.orc_sh_data_row.argtypes = [f64, vp, f64, vp, vp]
+        L.orc_world_to_voxel.argtypes = [f32, vp, vp]
+        L.orc_mc_extract.restype = vp; L.orc_mc_extract.argtypes = [vp, i32]
+        L.orc_mesh_counts.argtypes = [vp, vp, vp]; L.orc_mesh_get.argtypes = [vp, vp, vp, vp]; L.orc_mesh_free.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -264,6 +278,15 @@ class ProblemView:
     def free(self):
         if self.h:
             lib().orc_problem_free(self.h); self.h = None
+
+
+def marching_cubes(grid: "Grid", use_refined=False):
+    """MarchingCubes<VoxelSBR>::extractSurface of the grid: (vertices [n,3] f32, colors [n,3] u8, faces [m,3] i32)."""
+    L = lib(); m = L.orc_mc_extract(grid.h, 1 if use_refined else 0)
+    nv = C.c_int64(); nf = C.c_int64(); L.orc_mesh_counts(m, C.byref(nv), C.byref(nf))
+    v = np.zeros((nv.value, 3), np.float32); c = np.zeros((nv.value, 3), np.uint8); f = np.zeros((nf.value, 3), np.int32)
+    L.orc_mesh_get(m, _p(v), _p(c), _p(f)); L.orc_mesh_free(m)
+    return v, c, f
 
 
 def shading_row(v, sh9, pyr_scale, voxel_size, lum, params29, jac=True):

@@ -1,0 +1,93 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/_ref/libref_i3d.so: bodies of the reference itself (cut out of /root/reference by oracle/extract_ref.py
+at build time, compiled over stand-ins for the absent Eigen / Ceres / OpenCV).  Only tests/ and __graft_entry__.build() use it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_ref", "libref_i3d.so")
+_lib = None
+
+
+def build() -> str | None:
+    """(Re)build from /root/reference when it is present; otherwise keep whatever prebuilt library travelled with the tree."""
+    subprocess.check_call([sys.executable, os.path.join(_HERE, "extract_ref.py")])
+    return LIB_PATH if os.path.exists(LIB_PATH) else None
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+        L.ref_hash.restype = C.c_uint64; L.ref_hash.argtypes = [i32, i32, i32]
+        L.ref_round3f.argtypes = [vp, vp]; L.ref_round3d.argtypes = [vp, vp]
+        L.ref_sdf_to_weight.restype = f64; L.ref_sdf_to_weight.argtypes = [f64, f64]
+        L.ref_robust_kernel.restype = f32; L.ref_robust_kernel.argtypes = [f32]
+        L.ref_varying_lambda.restype = f64; L.ref_varying_lambda.argtypes = [i32, i32, f64, f64]
+        L.ref_pyramid_scale.restype = f64; L.ref_pyramid_scale.argtypes = [i32]
+        L.ref_shading_row.restype = f64; L.ref_shading_row.argtypes = [i32, i32, i32, vp, i32, f64, i32, i32, vp, vp, vp, vp]
+        L.ref_project_t.restype = i32; L.ref_project_t.argtypes = [vp, vp, i32, i32, vp, vp]
+        L.ref_project_f.restype = i32; L.ref_project_f.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.ref_bicubic.argtypes = [vp, i32, i32, f64, f64, vp, vp, vp]
+        L.ref_transform_voxel_iso.argtypes = [f64, vp, vp, f64, vp, vp]
+        L.ref_compute_normal.argtypes = [f64, f64, f64, f64, vp]
+        L.ref_volumetric.argtypes = [vp, vp, vp]; L.ref_surface_stab.argtypes = [f64, f64, vp, vp]; L.ref_albedo_reg.argtypes = [f64, f64, vp, vp]
+        L.ref_chroma_weight.restype = f64; L.ref_chroma_weight.argtypes = [vp, vp]
+        L.ref_sh_data_cost.argtypes = [f64, vp, f64, vp, vp, vp]; L.ref_sh_reg_cost.argtypes = [vp, vp, vp]
+        L.ref_voxel_visible.restype = i32; L.ref_voxel_visible.argtypes = [f32, vp, i32, i32, vp, i32, i32]
+        L.ref_observation_weight.restype = f32; L.ref_observation_weight.argtypes = [i32, i32, vp, vp, i32, i32, vp]
+        L.ref_compute_color.argtypes = [i32, vp, vp, vp]; L.ref_filter.argtypes = [i32, vp, i32, vp]
+        L.ref_grid_visit_order.argtypes = [f32, i64, vp, vp]; L.ref_world_to_voxel.argtypes = [f32, vp, vp]
+        L.ref_truncation.restype = f32; L.ref_truncation.argtypes = [f32]
+        L.ref_mc_extract.restype = vp; L.ref_mc_extract.argtypes = [f32, i64, vp, vp, vp, vp]
+        L.ref_mesh_counts.argtypes = [vp, vp, vp]; L.ref_mesh_get.argtypes = [vp, vp, vp, vp]
+        L.ref_mesh_save.restype = i32; L.ref_mesh_save.argtypes = [vp, C.c_char_p]; L.ref_mesh_free.argtypes = [vp]
+        L.ref_mc_tables.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+def shading_row(v, sh9, rgbd_level, voxel_size, lum, params29):
+    """ShadingCost::operator() of the reference: (residual via Jets, 29 partials, residual via T = double)."""
+    lum = np.ascontiguousarray(lum, np.float32); sh9 = np.ascontiguousarray(sh9, np.float64); prm = np.ascontiguousarray(params29, np.float64)
+    J = np.zeros(29); val = C.c_double()
+    r = lib().ref_shading_row(int(v[0]), int(v[1]), int(v[2]), _p(sh9), int(rgbd_level), float(voxel_size), lum.shape[1], lum.shape[0], _p(lum), _p(prm), _p(J), C.byref(val))
+    return r, J, val.value
+
+
+def marching_cubes(voxel_size, keys, sdf, weight, color, save_path=None):
+    """MarchingCubes<VoxelSBR>::extractSurface of a grid filled by inserting the records in the given order."""
+    keys = np.ascontiguousarray(keys, np.int32); sdf = np.ascontiguousarray(sdf, np.float64)
+    weight = np.ascontiguousarray(weight, np.float32); color = np.ascontiguousarray(color, np.uint8)
+    L = lib(); m = L.ref_mc_extract(float(voxel_size), keys.shape[0], _p(keys), _p(sdf), _p(weight), _p(color))
+    nv = C.c_int64(); nf = C.c_int64(); L.ref_mesh_counts(m, C.byref(nv), C.byref(nf))
+    v = np.zeros((nv.value, 3), np.float32); c = np.zeros((nv.value, 3), np.uint8); f = np.zeros((nf.value, 3), np.int32)
+    if m:
+        L.ref_mesh_get(m, _p(v), _p(c), _p(f))
+        if save_path is not None:
+            assert L.ref_mesh_save(m, save_path.encode()) == 1
+        L.ref_mesh_free(m)
+    return v, c, f
+
+
+def mc_tables():
+    edge = np.zeros(256, np.int32); tri = np.zeros((256, 16), np.int32)
+    lib().ref_mc_tables(_p(edge), _p(tri))
+    return edge, tri

@@ -3,6 +3,7 @@
 #include "../i3d_oracle.h"
 #include "lighting.hpp"
 #include "fusion.hpp"
+#include "mesh.hpp"
 
 using namespace orc;
 
@@ -244,9 +245,7 @@ int32_t orc_recompute_colors(void* g, void* fr, const double* intr, const double
     for (auto it = G->data.begin(); it != G->data.end(); ++it, ++vi) {
         if (obs[vi].empty()) continue;
         if (col.max_num_observations > 0) Colorizer::filter(obs[vi], col.max_num_observations);
-        float c[3] = {0, 0, 0}, ws = 0.0f; const float sc = 1.0f / 255.0f;
-        for (auto& o : obs[vi]) { for (int k = 0; k < 3; ++k) c[k] += (float)o.color[k] * (o.weight * sc); ws = ws + o.weight; }
-        if (ws > 0.0f) for (int k = 0; k < 3; ++k) c[k] = c[k] * (255.0f / ws);
+        float c[3]; Colorizer::mean_color(obs[vi], c);
         for (int k = 0; k < 3; ++k) it->second.color[k] = (uint8_t)c[k];
     }
     return 0;
@@ -306,6 +305,55 @@ void orc_pose_to_mat(const double* pose6, float* R9, float* t3) {
 }
 uint64_t orc_hash(int32_t x, int32_t y, int32_t z) { return (uint64_t)V3iHash()({x, y, z}); }
 int32_t orc_round_trunc(float v) { return round_trunc(v); }
+
+// ---- primitive probes ------------------------------------------------------------------------------------------------
+double orc_sdf_to_weight(double sdf, double truncation) { return sdf_to_weight(sdf, truncation); }
+double orc_varying_lambda(int32_t it, int32_t n, double l0, double l1) { return varying_lambda(it, n, l0, l1); }
+int32_t orc_project_f(const float* k4, const float* dist5, int32_t w, int32_t h, const float* p3, float* p2f, int32_t* p2i) {
+    CameraF cam; cam.fx = k4[0]; cam.fy = k4[1]; cam.cx = k4[2]; cam.cy = k4[3]; cam.w = w; cam.h = h; for (int i = 0; i < 5; ++i) cam.k[i] = dist5[i];
+    int pi[2]; const bool ok = cam.project(p3, p2f, pi); p2i[0] = pi[0]; p2i[1] = pi[1]; return ok ? 1 : 0;
+}
+static Image probe_image(int32_t w, int32_t h, const float* depth) { Image im; im.w = w; im.h = h; im.depth = depth; return im; }
+int32_t orc_voxel_visible(float max_occlusion_distance, const float* pt3, int32_t w, int32_t h, const float* depth, int32_t x, int32_t y) {
+    Colorizer col; col.max_occlusion_distance = max_occlusion_distance; return col.visible(pt3, probe_image(w, h, depth), x, y) ? 1 : 0;
+}
+float orc_observation_weight(int32_t w, int32_t h, const float* depth, const float* n3, int32_t x, int32_t y, const float* v3) {
+    Colorizer col; return col.weight(probe_image(w, h, depth), n3, x, y, v3);
+}
+void orc_compute_color(int32_t n, const uint8_t* rgb, const float* weights, float* out3) {
+    std::vector<Observation> obs((size_t)n);
+    for (int i = 0; i < n; ++i) { for (int k = 0; k < 3; ++k) obs[i].color[k] = rgb[3 * i + k]; obs[i].weight = weights[i]; obs[i].frame = i; }
+    Colorizer::mean_color(obs, out3);
+}
+void orc_filter(int32_t count, float* weights, int32_t keep, int32_t* order) {
+    std::vector<Observation> obs((size_t)count);
+    for (int i = 0; i < count; ++i) { obs[i].weight = weights[i]; obs[i].frame = i; }
+    Colorizer::filter(obs, (size_t)keep);
+    for (int i = 0; i < count; ++i) { weights[i] = obs[i].weight; order[i] = obs[i].frame; }
+}
+double orc_chroma_weight(const uint8_t* c3, const uint8_t* cn3) { return chroma_weight(c3, cn3); }
+double orc_reg_row(int32_t type, const double* x, double sdf0, double* J) {
+    Row r; r.type = type; r.v = 0; r.f = -1; r.dir = 0; r.weight = 1.0; r.sdf0 = sdf0; r.ncols = type == 1 ? 7 : (type == 2 ? 1 : 2);
+    std::vector<double> xg(x, x + r.ncols); for (int i = 0; i < r.ncols; ++i) r.cols[i] = i;
+    return eval_row(r, xg, J);
+}
+double orc_sh_data_row(double luminance, const float* n3, double albedo, const double* sh9, double* J9) {
+    double b[9]; sh_basis((double)n3[0], (double)n3[1], (double)n3[2], b);
+    double ab[9]; for (int j = 0; j < 9; ++j) { ab[j] = albedo * b[j]; if (J9) J9[j] = ab[j]; }
+    return sh_data_raw(albedo, ab, sh9, luminance);
+}
+void orc_world_to_voxel(float voxel_size, const float* p3, int32_t* out3) {
+    Grid<VoxelSBR> g(voxel_size); const V3i v = g.worldToVoxel({p3[0], p3[1], p3[2]}); out3[0] = v.x; out3[1] = v.y; out3[2] = v.z;
+}
+void* orc_mc_extract(void* g, int32_t use_refined) { auto* M = new MeshOut(); marching_cubes(*(Grid<VoxelSBR>*)g, use_refined != 0, *M); return M; }
+void orc_mesh_counts(void* mesh, int64_t* nv, int64_t* nf) { auto* M = (MeshOut*)mesh; *nv = (int64_t)(M->vertices.size() / 3); *nf = (int64_t)(M->faces.size() / 3); }
+void orc_mesh_get(void* mesh, float* verts, uint8_t* colors, int32_t* faces) {
+    auto* M = (MeshOut*)mesh;
+    if (verts) std::memcpy(verts, M->vertices.data(), M->vertices.size() * sizeof(float));
+    if (colors) std::memcpy(colors, M->colors.data(), M->colors.size());
+    if (faces) std::memcpy(faces, M->faces.data(), M->faces.size() * sizeof(int32_t));
+}
+void orc_mesh_free(void* mesh) { delete (MeshOut*)mesh; }
 
 static void dense_to_crs(int m, int n, const double* A, CRS& J) {
     J.rows = m; J.cols = n; J.ptr.assign(m + 1, 0); J.col.clear(); J.val.clear();

@@ -66,6 +66,17 @@ struct Subvolumes {
     }
 };
 
+// shading.h:53-66 basis functions of a unit normal (double)
+inline void sh_basis(double nx, double ny, double nz, double b[9]) {
+    b[0] = 1.0; b[1] = ny; b[2] = nz; b[3] = nx; b[4] = nx * ny; b[5] = ny * nz; b[6] = (-(nx * nx)) - (ny * ny) + 2.0 * (nz * nz); b[7] = nx * nz; b[8] = (nx * nx) - (ny * ny);
+}
+// SHDataCost::operator() (lighting_svsh.cpp:127-141): albedo * sum_j l_j H_j(n) - luminance; albedo_basis[j] = albedo * H_j(n) is the row's Jacobian
+inline double sh_data_raw(double albedo, const double* albedo_basis, const double* l, double lum) {
+    double shd = 0.0;                                   // shading.h:98-112: shad += sh_coeffs[i]*sh_funcs[i]; shading = albedo*shad
+    for (int j = 0; j < 9; ++j) shd += l[j] * (albedo_basis[j] / albedo);
+    return albedo * shd - lum;
+}
+
 struct ShStats { int data_rows, reg_rows, subvolumes, lm_iterations, termination; double cost_initial, cost_final; };
 
 struct Lighting {
@@ -128,7 +139,7 @@ struct Lighting {
         std::vector<double> basis((size_t)drows.size() * 9);
         for (size_t r = 0; r < drows.size(); ++r) {
             const double nx = (double)drows[r].n[0], ny = (double)drows[r].n[1], nz = (double)drows[r].n[2];
-            double b[9] = {1.0, ny, nz, nx, nx * ny, ny * nz, (-(nx * nx)) - (ny * ny) + 2.0 * (nz * nz), nx * nz, (nx * nx) - (ny * ny)};
+            double b[9]; sh_basis(nx, ny, nz, b);
             const double s = std::sqrt(data_w * drows[r].w);
             for (int j = 0; j < 9; ++j) { basis[r * 9 + j] = drows[r].albedo * b[j]; J.col[J.ptr[r] + j] = 9 * blk[drows[r].s] + j; J.val[J.ptr[r] + j] = s * drows[r].albedo * b[j]; }
         }
@@ -141,11 +152,7 @@ struct Lighting {
         EvalFn eval = [&](const double* xr, double* cost, std::vector<double>* res, CRS* Jout) -> bool {
             res->resize(m); double cs = 0.0;
             for (size_t r = 0; r < drows.size(); ++r) {
-                double shd = 0.0; const double* l = xr + 9 * blk[drows[r].s];
-                // shading.h:98-112: shad += sh_coeffs[i]*sh_funcs[i]; shading = albedo*shad
-                const double a = drows[r].albedo;
-                for (int j = 0; j < 9; ++j) shd += l[j] * (basis[r * 9 + j] / a);
-                const double raw = a * shd - drows[r].lum; const double w = data_w * drows[r].w;
+                const double raw = sh_data_raw(drows[r].albedo, &basis[r * 9], xr + 9 * blk[drows[r].s], drows[r].lum); const double w = data_w * drows[r].w;
                 (*res)[r] = std::sqrt(w) * raw; cs += 0.5 * w * raw * raw;
             }
             for (size_t q = 0; q < pairs.size(); ++q) for (int j = 0; j < 9; ++j) {

@@ -52,6 +52,17 @@ inline double sdf_to_weight(double sdf, double trunc) {                       //
 }
 inline float intensity_u8(const uint8_t c[3]) { return 0.299f * (float)c[0] + 0.587f * (float)c[1] + 0.114f * (float)c[2]; }  // color_util.cpp:41-52
 
+// albedo_regularizer.cpp:59-70: chromaticity weight of an Ea row (the caller drops NaN / Inf)
+inline double chroma_weight(const uint8_t ca[3], const uint8_t cb[3]) {
+    const float s255 = 1.0f / 255.0f;
+    const float lum = intensity_u8(ca), lum_nb = intensity_u8(cb);
+    float d2 = 0.0f;
+    for (int c = 0; c < 3; ++c) { const float a = ((float)ca[c] * s255) / lum - ((float)cb[c] * s255) / lum_nb; d2 += a * a; }
+    float chroma = std::sqrt(d2);
+    chroma = std::max(1.0f - chroma, 0.01f);
+    return (double)chroma * (double)1.0f;
+}
+
 // operators.cpp:58-77 (float; Eigen normalize() divides by sqrt(squaredNorm))
 inline void surface_normal(const Grid<VoxelSBR>& g, const V3i& p, float n[3]) {
     n[0] = n[1] = n[2] = 0.0f;
@@ -136,6 +147,11 @@ struct Colorizer {     // SDFColorization restricted to what the hot path uses
         float wd = std::max(1.0f - dn, 1.0f);                        // identically 1 (hazard 7)
         wd = std::max(std::min(wd, 5.0f), 0.001f);
         return wn * wd;
+    }
+    static void mean_color(const std::vector<Observation>& obs, float c[3]) {   // colorization.cpp:318-354 (computeColor, non-empty list)
+        c[0] = c[1] = c[2] = 0.0f; float ws = 0.0f; const float sc = 1.0f / 255.0f;
+        for (auto& o : obs) { for (int k = 0; k < 3; ++k) c[k] += (float)o.color[k] * (o.weight * sc); ws = ws + o.weight; }
+        if (ws > 0.0f) for (int k = 0; k < 3; ++k) c[k] = c[k] * (255.0f / ws);
     }
     static void filter(std::vector<Observation>& obs, size_t n) {    // colorization.cpp:357-370
         const size_t num = obs.size();
@@ -250,13 +266,7 @@ inline bool add_voxel_residuals(Problem& P, const OptConfig& cfg, const Colorize
             if (voxels_added.find(nb[d]) != voxels_added.end()) continue;
             // albedo_regularizer.cpp:50-84 (both voxels are valid here)
             const VoxelSBR& vn = g.voxel(nb[d]);
-            const float s255 = 1.0f / 255.0f;
-            const float lum = intensity_u8(v.color), lum_nb = intensity_u8(vn.color);
-            float d2 = 0.0f;
-            for (int c = 0; c < 3; ++c) { const float a = ((float)v.color[c] * s255) / lum - ((float)vn.color[c] * s255) / lum_nb; d2 += a * a; }
-            float chroma = std::sqrt(d2);
-            chroma = std::max(1.0f - chroma, 0.01f);
-            const double w = (double)chroma * (double)1.0f;
+            const double w = chroma_weight(v.color, vn.color);
             if (std::isnan(w) || std::isinf(w)) continue;
             if (w == 0.0) continue;
             Row r; r.type = 3; r.v = vi; r.f = -1; r.dir = d; r.weight = w; r.sdf0 = 0; r.ncols = 2;
