@@ -60,15 +60,35 @@ void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask /*[NP]*
 // fused PCG iteration, scalars resident in PcgState
 void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations);
 // mode: 0 init (z, r.z) | 1 x += a p, r -= a q, z, sums | 2 x only | 3 r = b - q(=A x), z, sums      (a rank's slice; off, n multiples of 4)
+// S_for_inline_q != nullptr: `q` holds the raw accumulators of the tiled operator pass and q = S acc + D2 v is formed inside the kernel
 int  launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
-                     float* z, double* partials /*[blocks][4]*/, PcgState* state);                               // returns #partials
+                     float* z, const float* S_for_inline_q, double* partials /*[blocks][4]*/, PcgState* state);                               // returns #partials
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state);
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
                        const float* D2, float* z, const double* partials, int nblk, PcgState* state,           // camera tail + Q-test + rho, beta;
                        double* shared_zero, int nzero, int* host_flags, int seq);                              // zeroes the camera accumulator, publishes (seq, done) to pinned memory
-void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state);                  // p = z + beta p, u = S p
+int  launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const float* D2, double* d2_partials /* or null */,
+                          const PcgState* state);                  // p = z + beta p, u = S p; returns the number of D^2 p^2 partials written
 void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
+                       const double* pq_partials2, int nblk2, bool rowwise,
                        float* q, const float* S, const float* D2, const float* v, PcgState* state);                                                          // camera tail of q, p.q, alpha
+// ---- tile_pass.hip: the LDS-tiled operator pass of the PCG (single rank) ----------------------------------------------------------
+struct TilePlan {                   // built once per outer iteration by launch_tile_plan
+    unsigned* lnbr;                 // [9][Acap] local slots (uint16 pairs): 12 stencil neighbours read + 6 further in-tile sources
+    float* eaw_sym;                 // [6][Acap] symmetric albedo-edge weights (pull form of the Ea rows)
+    int* halo_idx; int* halo_cnt;   // [tiles][HMAX] foreign entries a tile's stencils reach (sorted, INT_MAX padded), [tiles] their number
+    int* iota; int* ext_e; int* ext_pos;   // [tiles * HMAX] (entry, halo slot) pairs sorted by entry
+    float* qh;                      // [tiles * HMAX][2] halo accumulators of one pass
+    int* overflow;                  // device flag: a halo did not fit -> use the untiled pass
+};
+int    tile_plan_tiles(int A);
+int    tile_plan_hmax();
+size_t tile_plan_temp_bytes(int ntiles);
+hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, size_t temp_bytes);
+void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t);        // after launch_build (reads the Ea weights it wrote)
+// qacc[2 chunk] = J^T W J u on the voxel unknowns (raw), camera block added into `shared` (fp64), row-wise p.q partials; returns their number
+int  launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials /* or null */,
+                    const PcgState* state);
 
 void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* x_shared, double* xc_sdf, double* xc_alb,
                       double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask, double* scratch);

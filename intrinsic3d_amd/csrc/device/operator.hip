@@ -23,6 +23,7 @@
 // polls the state one pass behind (no pipeline bubble).
 #include "kernels.hpp"
 #include "reduce_device.hpp"
+#include "wave_ops.hpp"
 #include <cstdlib>
 
 namespace i3d {
@@ -49,49 +50,6 @@ void launch_reduce_partials(hipStream_t st, const double* partials, int nblk, in
 // columns are accumulated in LDS: aggregated per wave and keyframe (wave_accumulate), with `reps` replicas of the [6K] accumulator
 // (odd stride: different banks) for the rare slots that hold more than 3 keyframes.  LDS is zeroed / flushed once per workgroup.
 constexpr int EG_THREADS = 1024;
-
-// sum of v over the 64 lanes of the wave, returned to every lane: 4 DPP steps inside each row of 16 lanes (pure VALU, no LDS
-// crossbar), then the four row totals through scalar registers
-static __device__ inline float wave_sum(float v) {
-    int x;
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);  v += __int_as_float(x);    // quad_perm [1,0,3,2]
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);  v += __int_as_float(x);    // quad_perm [2,3,0,1]
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true); v += __int_as_float(x);    // row_half_mirror
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true); v += __int_as_float(x);    // row_mirror
-    const int b = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16)) +
-           __int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48));
-}
-
-// Camera-block accumulation of one row slot across the wave.  The observation slots are stored in keyframe order, so the lanes of
-// a wave (64 neighbouring voxels) mostly hold the SAME keyframe in a slot: per distinct keyframe the NV values are summed across the
-// wave in registers and one lane issues the LDS atomics (an LDS float atomic costs ~2 cycles PER ACTIVE LANE, measured).  Waves with
-// many distinct keyframes fall back to per-lane atomics into the lane's replica.
-template <int NV>
-static __device__ inline void wave_accumulate(bool valid, int f, const float (&val)[NV], float* lane_acc, float* wave_acc, int stride) {
-    unsigned long long todo = __ballot(valid);
-    const int lane = threadIdx.x & 63;
-    for (int round = 0; todo != 0ull; ++round) {
-        if (round == 3) {                                   // > 3 distinct keyframes in this slot of the wave
-            if (valid && ((todo >> lane) & 1ull)) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) atomicAdd(&lane_acc[stride * f + i], val[i]);
-            }
-            break;
-        }
-        const int leader = __ffsll((long long)todo) - 1;
-        const int f0 = __builtin_amdgcn_readlane(f, leader);
-        const bool mine = valid && f == f0;
-        float sum[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) sum[i] = wave_sum(mine ? val[i] : 0.0f);
-        if (lane == leader) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) atomicAdd(&wave_acc[stride * f0 + i], sum[i]);
-        }
-        todo &= ~__ballot(mine);
-    }
-}
 
 template <int MODE>
 __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, OptParams p, const float* __restrict__ u, PassBuffers b,
@@ -456,6 +414,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
     }
 }
 
+
 void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u, PassBuffers b, const PcgState* state) {
     if (r.nC <= 0) return;
     static int num_cu = 0;
@@ -646,10 +605,12 @@ void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask) { k_fr
 //   k_pcg_tail_b camera tail of q = A p from the reduced fp64 block, p.q, alpha
 enum { STEP_INIT = 0, STEP_NORMAL = 1, STEP_XONLY = 2, STEP_RESET = 3 };
 
-template <int MODE>
+// QINLINE: `q` holds the raw operator accumulators J^T W J u of the tiled pass (k_eg_tile + k_ext_gather); the vector q = S acc + D^2 v
+// (v = p, or x for the residual reset) is formed here instead of being written and read back.
+template <int MODE, bool QINLINE>
 __global__ void __launch_bounds__(256) k_pcg_step(int n4, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x, float4* __restrict__ r,
                                                   const float4* __restrict__ b, const float4* __restrict__ D2, const float4* __restrict__ Minv, float4* __restrict__ z,
-                                                  double* __restrict__ partials /* nullptr: add to state->acc directly (sharded) */, PcgState* state) {
+                                                  const float4* __restrict__ S, double* __restrict__ partials /* nullptr: add to state->acc directly (sharded) */, PcgState* state) {
     if (state->done) return;
     const float alpha = (float)state->alpha;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -665,9 +626,14 @@ __global__ void __launch_bounds__(256) k_pcg_step(int n4, const float4* __restri
                 x[i] = make_float4(xv[0], xv[1], xv[2], xv[3]);
             }
             if (MODE == STEP_XONLY) continue;
-            const float4 qq = q[i];             // q = A p, or (RESET) tmp = A x
-            if (MODE == STEP_NORMAL) { const float4 ro = r[i]; rv[0] = ro.x - alpha * qq.x; rv[1] = ro.y - alpha * qq.y; rv[2] = ro.z - alpha * qq.z; rv[3] = ro.w - alpha * qq.w; }
+            float4 qq = q[i];                   // q = A p, or (RESET) tmp = A x
             const float4 bb = b[i], dd = D2[i];
+            if (QINLINE) {
+                const float4 sv = S[i];
+                if (MODE == STEP_NORMAL) { const float4 pp = p[i]; qq = make_float4(sv.x * qq.x + dd.x * pp.x, sv.y * qq.y + dd.y * pp.y, sv.z * qq.z + dd.z * pp.z, sv.w * qq.w + dd.w * pp.w); }
+                else qq = make_float4(sv.x * qq.x + dd.x * xv[0], sv.y * qq.y + dd.y * xv[1], sv.z * qq.z + dd.z * xv[2], sv.w * qq.w + dd.w * xv[3]);
+            }
+            if (MODE == STEP_NORMAL) { const float4 ro = r[i]; rv[0] = ro.x - alpha * qq.x; rv[1] = ro.y - alpha * qq.y; rv[2] = ro.z - alpha * qq.z; rv[3] = ro.w - alpha * qq.w; }
             if (MODE == STEP_RESET) { rv[0] = bb.x - qq.x; rv[1] = bb.y - qq.y; rv[2] = bb.z - qq.z; rv[3] = bb.w - qq.w; }
             r[i] = make_float4(rv[0], rv[1], rv[2], rv[3]);
             const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w};
@@ -765,28 +731,35 @@ __global__ void __launch_bounds__(1024) k_pcg_tail_a(int mode, size_t to, int K,
     publish();
 }
 
-// p = z + beta p ; u = S p
-__global__ void __launch_bounds__(256) k_pcg_direction(int n, const float* __restrict__ z, float* __restrict__ p, const float* __restrict__ S, float* __restrict__ u, const PcgState* __restrict__ state) {
+// p = z + beta p ; u = S p ; d2_partials (optional): per-workgroup sums of D^2 p^2 (the diagonal part of p.q, see k_eg_tile)
+__global__ void __launch_bounds__(256) k_pcg_direction(int n, const float* __restrict__ z, float* __restrict__ p, const float* __restrict__ S, float* __restrict__ u,
+                                                       const float* __restrict__ D2, double* __restrict__ d2_partials, const PcgState* __restrict__ state) {
     if (state->done) return;
     const float beta = (float)state->beta; const bool first = state->it == 0;
     const int n4 = n >> 2;
     const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
     const float4* S4 = reinterpret_cast<const float4*>(S); float4* u4 = reinterpret_cast<float4*>(u);
+    const float4* D4 = reinterpret_cast<const float4*>(D2);
+    double d2 = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
         float4 pi = z4[i];
         if (!first) { const float4 po = p4[i]; pi.x += beta * po.x; pi.y += beta * po.y; pi.z += beta * po.z; pi.w += beta * po.w; }
         p4[i] = pi;
         const float4 sv = S4[i];
         u4[i] = make_float4(sv.x * pi.x, sv.y * pi.y, sv.z * pi.z, sv.w * pi.w);
+        if (d2_partials) { const float4 dd = D4[i]; d2 += (double)dd.x * (double)pi.x * (double)pi.x + (double)dd.y * (double)pi.y * (double)pi.y + (double)dd.z * (double)pi.z * (double)pi.z + (double)dd.w * (double)pi.w * (double)pi.w; }
     }
     for (int i = 4 * n4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {       // the camera tail is not a multiple of 4
         const float pi = first ? z[i] : z[i] + beta * p[i]; p[i] = pi; u[i] = S[i] * pi;
+        if (d2_partials) d2 += (double)D2[i] * (double)pi * (double)pi;
     }
+    if (d2_partials) block_partial_d(d2, d2_partials, 1, 0);
 }
 
 // camera tail of q = (S J^T W J S + D^2) p from the (all-reduced) fp64 camera block, p.q, alpha = rho / p.q
 __global__ void __launch_bounds__(1024) k_pcg_tail_b(size_t to, int K, OptParams p, const double* __restrict__ shared, const double* __restrict__ pq_slice,
-                                                    const double* __restrict__ pq_partials, int nblk, float* __restrict__ q, const float* __restrict__ S, const float* __restrict__ D2, const float* __restrict__ v, PcgState* st) {
+                                                    const double* __restrict__ pq_partials, int nblk, const double* __restrict__ pq_partials2, int nblk2, int rowwise,
+                                                    float* __restrict__ q, const float* __restrict__ S, const float* __restrict__ D2, const float* __restrict__ v, PcgState* st) {
     if (st->done) return;
     __shared__ double red[16];
     const int NS = 6 * K + 9;
@@ -796,9 +769,11 @@ __global__ void __launch_bounds__(1024) k_pcg_tail_b(size_t to, int K, OptParams
         const size_t j = to + i;
         const float vv = v[j];
         const float o = S[j] * (fixed ? 0.0f : (float)shared[i]) + D2[j] * vv;
-        q[j] = o; dotp += (double)vv * (double)o;
+        q[j] = o;
+        if (!rowwise) dotp += (double)vv * (double)o;      // rowwise: p.q = sum_rows t (J u) [partials] + sum D^2 p^2 [partials2], camera columns included in both
     }
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) dotp += pq_partials[i];       // workgroup partials of the voxel part (k_gather)
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) dotp += pq_partials[i];       // workgroup partials of the voxel part (k_gather) / of the rows (k_eg_tile)
+    for (int i = threadIdx.x; i < nblk2; i += blockDim.x) dotp += pq_partials2[i];     // workgroup partials of sum D^2 p^2 (k_pcg_direction)
     for (int o = 32; o > 0; o >>= 1) dotp += __shfl_down(dotp, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dotp;
     __syncthreads();
@@ -821,17 +796,20 @@ void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int 
 static inline int step_blocks(int n4) { int b = (n4 + 255) / 256; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
 // off and n must be multiples of 4 (the rank-major layout pads every slice to a multiple of 8 floats)
 int launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
-                    float* z, double* partials, PcgState* state) {
+                    float* z, const float* S_for_inline_q, double* partials, PcgState* state) {
     if (n <= 0) return 0;
     const int n4 = n >> 2;
-    auto c4 = [off](const float* v) { return reinterpret_cast<const float4*>(v + off); };
+    auto c4 = [off](const float* v) { return reinterpret_cast<const float4*>(v ? v + off : nullptr); };
     auto m4 = [off](float* v) { return reinterpret_cast<float4*>(v + off); };
+    const float* S = S_for_inline_q;
+#define I3D_STEP(MODE, QI) k_pcg_step<MODE, QI><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), c4(S), partials, state)
     switch (mode) {
-        case STEP_INIT:   k_pcg_step<STEP_INIT><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
-        case STEP_NORMAL: k_pcg_step<STEP_NORMAL><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
-        case STEP_XONLY:  k_pcg_step<STEP_XONLY><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
-        default:          k_pcg_step<STEP_RESET><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), partials, state); break;
+        case STEP_INIT:   I3D_STEP(STEP_INIT, false); break;
+        case STEP_NORMAL: if (S) I3D_STEP(STEP_NORMAL, true); else I3D_STEP(STEP_NORMAL, false); break;
+        case STEP_XONLY:  I3D_STEP(STEP_XONLY, false); break;
+        default:          if (S) I3D_STEP(STEP_RESET, true); else I3D_STEP(STEP_RESET, false); break;
     }
+#undef I3D_STEP
     return (mode == STEP_XONLY || !partials) ? 0 : step_blocks(n4);      // number of [4]-partials written
 }
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state) { k_pcg_tail_x<<<1, 256, 0, st>>>(tail_off, 6 * K + 9, p, x, state); }
@@ -839,12 +817,15 @@ void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const f
                        const float* D2, float* z, const double* partials, int nblk, PcgState* state, double* shared_zero, int nzero, int* host_flags, int seq) {
     k_pcg_tail_a<<<1, 1024, 0, st>>>(mode, tail_off, K, Minv_blocks, p, q, x, r, b, D2, z, partials, nblk, state, shared_zero, nzero, host_flags, seq);
 }
-void launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const PcgState* state) {
-    if (n > 0) k_pcg_direction<<<step_blocks(n >> 2), 256, 0, st>>>(n, z, p, S, u, state);
+int launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const float* D2, double* d2_partials, const PcgState* state) {
+    if (n <= 0) return 0;
+    const int blocks = step_blocks(n >> 2);
+    k_pcg_direction<<<blocks, 256, 0, st>>>(n, z, p, S, u, D2, d2_partials, state);
+    return d2_partials ? blocks : 0;
 }
 void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
-                       float* q, const float* S, const float* D2, const float* v, PcgState* state) {
-    k_pcg_tail_b<<<1, 1024, 0, st>>>(tail_off, K, p, shared, pq_slice, pq_partials, nblk, q, S, D2, v, state);
+                       const double* pq_partials2, int nblk2, bool rowwise, float* q, const float* S, const float* D2, const float* v, PcgState* state) {
+    k_pcg_tail_b<<<1, 1024, 0, st>>>(tail_off, K, p, shared, pq_slice, pq_partials, nblk, pq_partials2, nblk2, rowwise ? 1 : 0, q, S, D2, v, state);
 }
 
 // ---- LM candidate / acceptance ------------------------------------------------------------------------------------------

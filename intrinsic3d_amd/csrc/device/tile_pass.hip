@@ -1,0 +1,484 @@
+// K6 — the PCG operator pass q = J^T W J u, LDS-tiled (single-rank layout: list space == vector space).
+//
+// The work list is brick-Morton ordered, so 1024 consecutive entries (a TILE) are a compact patch of the surface shell: ~85-90 % of what
+// a voxel's rows read from / contribute to lies in the same patch, the rest in a HALO of a few hundred entries of neighbouring patches.
+// Once per outer iteration k_tile_plan gives every tile its halo (sorted list of the foreign entries its stencils reach) and every entry
+// the LOCAL slots of its 12 stencil neighbours (9 forward slots of the Eg stencil + the -x,-y,-z ring entries; uint16: 0..1023 own tile,
+// 1024.. halo, TP_ZSLOT = not in the list -> fixed parameter, reads 0 / contributions dropped).  The pass itself then never gathers or
+// scatters through global memory:
+//   * the operator input u of tile + halo is staged in LDS once per tile (coalesced for the tile, one gather per halo entry);
+//   * a lane (= voxel, <= `slots` rows) reads its stencil values from LDS, forms t = W (J u) per row and PUSHES J^T t and the
+//     regulariser terms into LDS accumulators (ds_add_f32; distinct lanes hit distinct voxels: conflict-free);
+//   * the tile's totals leave with one coalesced store per unknown (qacc), the halo's with one coalesced store per halo slot (qh), and
+//     k_halo_fold adds the halo sums to their owners (sorted (entry, slot) pairs, built once per outer iteration).
+// All index / flag loads of an entry are issued BEFORE its first two row blocks and nothing in the entry's prologue touches global memory
+// after them, so the row stream is never drained by an s_waitcnt on a younger gather (the in-order vmcnt was what held the first
+// version of this pass, and k_eg_jtjp, at 0.40 ms against the 0.235 ms of the bare row stream).
+// p.q needs no pass over q: p.(S J^T W J S p) = sum over rows of t (J u), accumulated here row by row (sum D^2 p^2: k_pcg_direction).
+#include <cstring>
+#include <cstdlib>
+#include <climits>
+#include "kernels.hpp"
+#include "reduce_device.hpp"
+#include "wave_ops.hpp"
+#include <rocprim/rocprim.hpp>
+
+namespace i3d {
+
+constexpr int TP_PLAN_LIST = 1024;              // capacity of a tile's halo list (plan kernel sorts this many keys)
+// the 12 stencil neighbours an entry READS (operator input): sdf slots 1..9 of the Eg row (shading_cost.cpp:90-129), then -x, -y, -z;
+// the 6 further entries whose Eg stencil contains it (the others are -x,-y,-z again): pulled from when they are in the same tile
+__device__ __host__ inline int tp_dir(int j) {
+    constexpr int8_t D[18] = {NB_PY, NB_P2Y, NB_PYZ, NB_PZ, NB_P2Z, NB_PX, NB_PXY, NB_PXZ, NB_P2X, NB_MX, NB_MY, NB_MZ,
+                              NB_M2Y, NB_MYZ, NB_M2Z, NB_MXY, NB_MXZ, NB_M2X};
+    return D[j];
+}
+
+// ---- plan (once per outer iteration) ----------------------------------------------------------------------------------------------
+// One workgroup per tile of T entries: hash set of the foreign entries its FORWARD stencils / rings reach -> compact -> bitonic sort
+// (deterministic slot numbers, coalescing-friendly staging) -> local slots by binary search.  lnbr[0..5]: the 12 read slots (uint16 pairs:
+// 0..T-1 own tile, T.. halo, zslot = not a list entry); lnbr[6..8]: the 6 extra reverse slots, own tile or zslot (foreign sources reach
+// the entry through THEIR tile's halo accumulators).  halo_idx is padded with INT_MAX (those keys sort behind every real pair).
+__global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, unsigned* __restrict__ lnbr, int* __restrict__ halo_idx, int* __restrict__ halo_cnt,
+                                                    int* __restrict__ overflow) {
+    __shared__ int hkeys[4096];
+    __shared__ int hlist[TP_PLAN_LIST];
+    __shared__ int cnt;
+    const int tile = blockIdx.x, base = tile * T, a = base + threadIdx.x;
+    const bool in = (int)threadIdx.x < T && a < r.A;
+    const int zslot = T + hmax;
+    for (int i = threadIdx.x; i < 4096; i += 1024) hkeys[i] = -1;
+    hlist[threadIdx.x] = INT_MAX;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int la[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+        la[j] = in ? r.anbr[(size_t)tp_dir(j) * r.Acap + a] : -1;
+        if (j < 12 && la[j] >= 0 && (unsigned)(la[j] - base) >= (unsigned)T) {
+            unsigned h = ((unsigned)la[j] * 2654435761u) >> 20;                 // 12 bits
+            for (int probes = 0; probes < 4096; ++probes) {
+                const int k = atomicCAS(&hkeys[h], -1, la[j]);
+                if (k == -1 || k == la[j]) break;
+                h = (h + 1) & 4095u;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 1024) if (hkeys[i] >= 0) { const int pos = atomicAdd(&cnt, 1); if (pos < TP_PLAN_LIST) hlist[pos] = hkeys[i]; }
+    __syncthreads();
+    const int H = cnt;
+    if (H > hmax) { if (threadIdx.x == 0) { *overflow = 1; halo_cnt[tile] = 0; } return; }      // the caller falls back to the untiled pass
+    for (int k = 2; k <= TP_PLAN_LIST; k <<= 1)                                     // bitonic sort, ascending (INT_MAX padding ends up last)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int i = threadIdx.x, ixj = i ^ j;
+            if (ixj > i) { const int x = hlist[i], y = hlist[ixj]; const bool up = (i & k) == 0; if ((x > y) == up) { hlist[i] = y; hlist[ixj] = x; } }
+            __syncthreads();
+        }
+    if ((int)threadIdx.x < hmax) halo_idx[(size_t)tile * hmax + threadIdx.x] = hlist[threadIdx.x];
+    if (threadIdx.x == 0) halo_cnt[tile] = H;
+    if (!in) return;
+    unsigned short ls[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+        int slot = zslot;
+        if (la[j] >= 0) {
+            const unsigned off = (unsigned)(la[j] - base);
+            if (off < (unsigned)T) slot = (int)off;
+            else if (j < 12) { int lo = 0, hi = H - 1; while (lo < hi) { const int mid = (lo + hi) >> 1; if (hlist[mid] < la[j]) lo = mid + 1; else hi = mid; } slot = T + lo; }
+        }
+        ls[j] = (unsigned short)slot;
+    }
+#pragma unroll
+    for (int w = 0; w < 9; ++w) lnbr[(size_t)w * r.Acap + a] = (unsigned)ls[2 * w] | ((unsigned)ls[2 * w + 1] << 16);
+}
+
+// symmetric albedo-edge weights: the Ea row of the edge (a, neighbour d) is created once, by whichever voxel is visited first
+// (optimizer.cpp:259-279), so ea_w[d][a] is non-zero on one side only.  With w_sym[d][a] = ea_w[d][a] + ea_w[d^1][nb_d(a)] the Ea part of
+// J^T W J u is a pure PULL: q_alb[a] = rho sum_d w_sym[d][a] (u_a - u_nb(d)) — no contribution has to be pushed to a neighbour.
+__global__ void __launch_bounds__(256) k_eaw_sym(RowView r, float* __restrict__ eaw_sym) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= r.A) return;
+    const bool act = (r.aflags[a] & F_ACTIVE) != 0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        float w = act ? r.ea_w[(size_t)d * r.Acap + a] : 0.0f;
+        const int nb = r.anbr[(size_t)d * r.Acap + a];
+        if (nb >= 0 && (r.aflags[nb] & F_ACTIVE)) w += r.ea_w[(size_t)(d ^ 1) * r.Acap + nb];
+        eaw_sym[(size_t)d * r.Acap + a] = w;
+    }
+}
+
+// ---- the pass ---------------------------------------------------------------------------------------------------------------------
+static __device__ inline void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <int NW> static __device__ inline int unpack16(const unsigned (&w)[NW], int j) { return (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu); }
+
+// T lanes = T entries per tile.  SLOTS > 0: the row loop is unrolled for exactly that many observation slots and EVERY slot is requested
+// (unused slots of a voxel are skipped per lane): straight-line code whose s_waitcnt the compiler can count exactly — with a run-time
+// trip count and conditional refills it falls back to vmcnt(0) at the loop header, which drains the block meant to stay in flight.
+// LDS float atomics cost ~70 cycles per wave instruction on gfx950 (measured: 14 ds_add_f32 per row doubled the kernel time), so the
+// J^T accumulation inside the tile is a PULL from lane-private column sums staged in LDS; only what lands in the halo is pushed.
+// wave_accumulate (wave_ops.hpp) on the kernel's own LDS array by integer offset.  wave_off is wave-uniform (a scalar register); the
+// per-lane replica offset of the rare fallback is recomputed there, and lanes are tracked by a flag instead of a 64-bit lane mask: nothing
+// of this helper lives in vector registers across the row loop.
+template <int NV>
+static __device__ inline void wave_accumulate_lds(bool valid, int f, const float (&val)[NV], float* lds, int reps, int rs, int wave_off, int stride) {
+    bool pending = valid;
+    unsigned long long todo = __ballot(pending);
+    for (int round = 0; todo != 0ull; ++round) {
+        if (round == 3) {                                   // > 3 distinct keyframes in this slot of the wave
+            if (pending) {
+                const int lane_off = (threadIdx.x & (reps - 1)) * rs;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) lds_add(&lds[lane_off + stride * f + i], val[i]);
+            }
+            break;
+        }
+        const int leader = __ffsll((long long)todo) - 1;
+        const int f0 = __builtin_amdgcn_readlane(f, leader);
+        const bool mine = pending && f == f0;
+        float sum[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum[i] = wave_sum(mine ? val[i] : 0.0f);
+        if ((int)(threadIdx.x & 63) == leader) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) lds_add(&lds[wave_off + stride * f0 + i], sum[i]);
+        }
+        pending = pending && !mine;
+        todo = __ballot(pending);
+    }
+}
+
+// T lanes = T entries per tile.  SLOTS > 0: the row loop is unrolled for exactly that many observation slots and EVERY slot is requested
+// (unused slots of a voxel are skipped per lane): straight-line code whose s_waitcnt the compiler can count exactly — with a run-time
+// trip count and conditional refills it falls back to vmcnt(0) at the loop header, which drains the block meant to stay in flight.
+// LDS float atomics cost ~70 cycles per wave instruction on gfx950 (measured: 14 ds_add_f32 per row doubled the kernel time), so the
+// J^T accumulation inside the tile is a PULL from lane-private column sums staged in LDS; only what lands in the halo is pushed.
+// wave_accumulate (wave_ops.hpp) on the kernel's own LDS array by integer offset
+template <int NV>
+static __device__ inline void wave_accumulate_lds(bool valid, int f, const float (&val)[NV], float* lds, int lane_off, int wave_off, int stride) {
+    unsigned long long todo = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    for (int round = 0; todo != 0ull; ++round) {
+        if (round == 3) {                                   // > 3 distinct keyframes in this slot of the wave
+            if (valid && ((todo >> lane) & 1ull)) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) lds_add(&lds[lane_off + stride * f + i], val[i]);
+            }
+            break;
+        }
+        const int leader = __ffsll((long long)todo) - 1;
+        const int f0 = __builtin_amdgcn_readlane(f, leader);
+        const bool mine = valid && f == f0;
+        float sum[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum[i] = wave_sum(mine ? val[i] : 0.0f);
+        if (lane == leader) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) lds_add(&lds[wave_off + stride * f0 + i], sum[i]);
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
+template <int T, int HMAX, int SLOTS>
+__global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowView r, OptParams p, const float* __restrict__ u, const unsigned* __restrict__ lnbr,
+                                                        const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx, const int* __restrict__ halo_cnt,
+                                                        double* __restrict__ shared, float* __restrict__ qacc, float* __restrict__ qh, double* __restrict__ pq_partials,
+                                                        int reps, int tiles_per_block, const PcgState* __restrict__ state) {
+    if (state && state->done) return;
+    constexpr int ZSLOT = T + HMAX, NSLOT = ZSLOT + 1;
+    extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T]
+    const int K = p.K; const size_t Acap = r.Acap; const int A = r.A, chunk = r.chunk;
+    const int nshared = 6 * K + 9;
+    const int rs = (6 * K) | 1;
+    const int nacc = reps * rs + 9;
+    const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
+    for (int i = threadIdx.x; i < nacc; i += T) lds[i] = 0.0f;
+    // every LDS access below is lds[<integer offset>]: pointers derived from `lds` and handed to helpers degrade to 64-bit generic pointers
+    // (flat instructions, two registers each — they were what spilled inside the row loop)
+#define upose (lds + o_upose)
+#define u_s (lds + o_u)                                                        /* operator input: sdf / albedo unknowns by local slot */
+#define u_a (lds + o_u + NSLOT)
+#define qh_s (lds + o_u + 2 * NSLOT)                                           /* halo accumulators */
+#define qh_a (lds + o_u + 2 * NSLOT + HMAX)
+#define tr_l (lds + o_u + 2 * NSLOT + 2 * HMAX)                                /* Er row value of every tile entry (+ a zero at index T) */
+#define C_l (lds + o_u + 2 * NSLOT + 2 * HMAX + T + 4)                         /* [12][T] column sums of the tile's Eg rows (slots 1..9, 11..13), lane-private until the pull */
+    const size_t tail = 2 * (size_t)chunk;
+    for (int i = threadIdx.x; i < nshared; i += T) upose[i] = u[tail + i];
+    const int o_cam = reps * rs;
+    const int o_wave_acc = __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) & (reps - 1)) * rs);       // wave-uniform: a scalar
+    float cam9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
+    const float tw0 = (float)p.type_w[0], tw1 = (float)p.type_w[1], tw2 = (float)p.type_w[2], tw3 = (float)p.type_w[3];
+    const int ntiles = (A + T - 1) / T;
+    const int tile0 = blockIdx.x * tiles_per_block;
+#define ui (lds + o_upose + 6 * K)
+    const int i = threadIdx.x;
+    double pq = 0.0;
+
+    for (int tile = tile0; tile < tile0 + tiles_per_block && tile < ntiles; ++tile) {
+        const int base = tile * T, a = base + i;
+        const bool in = a < A;
+        const size_t ac = in ? (size_t)a : 0;
+        const int H = halo_cnt[tile];
+        // everything the entry needs besides its rows is requested first (older than the row loads: waiting for it does not drain them)
+        const float us = in ? u[a] : 0.0f, ua = in ? u[chunk + a] : 0.0f;
+        const uint8_t fl = in ? r.aflags[ac] : 0;
+        const int nr_ld = r.nrows[ac];
+        const uint8_t rf_ld = r.regflags[ac];
+        unsigned ln[6];
+#pragma unroll
+        for (int w = 0; w < 6; ++w) ln[w] = lnbr[(size_t)w * Acap + ac];
+        float hs[(HMAX + T - 1) / T], ha[(HMAX + T - 1) / T];
+#pragma unroll
+        for (int q = 0; q < (HMAX + T - 1) / T; ++q) {
+            const int hq = i + q * T; hs[q] = 0.0f; ha[q] = 0.0f;
+            if (hq < H) { const int e = halo_idx[(size_t)tile * HMAX + hq]; hs[q] = u[e]; ha[q] = u[chunk + e]; }
+        }
+        float4 rwA[8], rwB[8];
+        { const float4* __restrict__ row = r.rows + row_index(ac, 0, 0, r.slots);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+        if (SLOTS > 1 || (SLOTS == 0 && r.slots > 1)) { const float4* __restrict__ row = r.rows + row_index(ac, 1, 0, r.slots);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+        // ---- stage the operator input of tile + halo, clear the accumulators ----
+        u_s[i] = us; u_a[i] = ua;
+#pragma unroll
+        for (int q = 0; q < (HMAX + T - 1) / T; ++q) { const int hq = i + q * T; if (hq < HMAX) { u_s[T + hq] = hs[q]; u_a[T + hq] = ha[q]; qh_s[hq] = 0.0f; qh_a[hq] = 0.0f; } }
+        if (i == 0) { u_s[ZSLOT] = 0.0f; u_a[ZSLOT] = 0.0f; tr_l[T] = 0.0f; }
+#pragma unroll
+        for (int c = 0; c < 12; ++c) C_l[c * T + i] = 0.0f;
+        const bool active = in && (fl & F_ACTIVE);
+        const int nr = active ? nr_ld : 0;
+        const uint8_t rf = active ? rf_ld : 0;
+        if (!in) { for (int w = 0; w < 6; ++w) ln[w] = (unsigned)ZSLOT | ((unsigned)ZSLOT << 16); }
+        __syncthreads();
+        // local slots: sdf stencil slot c (1..9) = unpack16(ln, c - 1); +x,+y,+z = 5,0,3; -x,-y,-z = 9,10,11
+        const int sx = unpack16(ln, 5), sy = unpack16(ln, 0), sz = unpack16(ln, 3), mx = unpack16(ln, 9), my = unpack16(ln, 10), mz = unpack16(ln, 11);
+        float self_s = 0.0f, self_a = 0.0f;
+        // ---- regulariser rows (constant coefficients), while the first two row blocks are in flight ----
+        {
+            const int rg[6] = {sx, mx, sy, my, sz, mz};                    // ring order +x,-x,+y,-y,+z,-z
+            float tr = 0.0f;
+            if (rf & 1) {
+                const float lap = ((((((-6.0f * us) + u_s[rg[0]]) + u_s[rg[1]]) + u_s[rg[2]]) + u_s[rg[3]]) + u_s[rg[4]]) + u_s[rg[5]];
+                tr = tw1 * lap; pq += (double)(tr * lap);
+                self_s += -6.0f * tr;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles
+            }
+            tr_l[i] = tr;
+            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * us; pq += (double)(ts * us); self_s += ts; }
+        }
+#define Cme (C_l + i)
+        float pq_rows = 0.0f;
+        int nr_max = nr;
+        if (SLOTS == 0) { for (int o = 32; o > 0; o >>= 1) nr_max = max(nr_max, __shfl_xor(nr_max, o, 64)); }
+        // one row: t = W (J u), J^T t added to the lane's own column sums in LDS (plain read-modify-write: the slots are private to the lane)
+        auto consume = [&](const float4 (&rw)[8], int k) {
+            const float4 m = rw[7];
+            float pv[6]; int fsel = 0; bool pvalid = false;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) pv[q] = 0.0f;
+            if (k < nr && m.x != 0.0f) {
+                const float rho = m.x * tw0;
+                const int f = __float_as_int(m.z) & ~ROW_FREE_BIT;
+                float J[P_TOTAL];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { J[4 * q] = rw[q].x; J[4 * q + 1] = rw[q].y; J[4 * q + 2] = rw[q].z; J[4 * q + 3] = rw[q].w; }
+                J[28] = m.w;
+                float d = J[0] * us + J[10] * ua;
+#pragma unroll
+                for (int c = 1; c < 10; ++c) d += J[c] * u_s[unpack16(ln, c - 1)];
+                d += J[11] * u_a[sx] + J[12] * u_a[sy] + J[13] * u_a[sz];
+                const int o_up = o_upose + 6 * f;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) d += J[P_POSE + q] * lds[o_up + q];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) d += J[P_INTR + q] * ui[q];
+                const float t = rho * d;
+                pq_rows += t * d;
+                self_s += J[0] * t; self_a += J[10] * t;
+#pragma unroll
+                for (int c = 1; c < 10; ++c) Cme[(c - 1) * T] += J[c] * t;
+                Cme[9 * T] += J[11] * t; Cme[10 * T] += J[12] * t; Cme[11 * T] += J[13] * t;
+                if (!p.fix_poses) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) pv[q] = J[P_POSE + q] * t;
+                    fsel = f; pvalid = true;
+                }
+#pragma unroll
+                for (int q = 0; q < 9; ++q) cam9[q] += J[P_INTR + q] * t;
+            }
+            wave_accumulate_lds<6>(pvalid, fsel, pv, lds, reps, rs, o_wave_acc, 6);
+        };
+        if (SLOTS > 0) {
+#pragma unroll
+            for (int k = 0; k < SLOTS; k += 2) {               // slot k is in rwA, slot k+1 (if any) in rwB; a buffer is refilled as soon as it is consumed
+                consume(rwA, k);
+                if (k + 2 < SLOTS) { const float4* __restrict__ row = r.rows + row_index(ac, k + 2, 0, SLOTS);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+                if (k + 1 < SLOTS) {
+                    consume(rwB, k + 1);
+                    if (k + 3 < SLOTS) { const float4* __restrict__ row = r.rows + row_index(ac, k + 3, 0, SLOTS);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+                }
+            }
+        } else {
+            for (int k = 0; k < nr_max; k += 2) {
+                consume(rwA, k);
+                if (k + 2 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 2, 0, r.slots);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+                if (k + 1 < nr_max) {
+                    consume(rwB, k + 1);
+                    if (k + 3 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 3, 0, r.slots);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+                }
+            }
+        }
+        pq += (double)pq_rows;
+        // what the pull phase needs in addition (requested now, used behind the barrier): the 6 further reverse slots, the symmetric Ea weights
+        unsigned lr[3];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) lr[w] = lnbr[(size_t)(6 + w) * Acap + ac];
+        float eaw[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) eaw[d] = eaw_sym[(size_t)d * Acap + ac];
+        // ---- what lands in the halo is pushed (few lanes: the tile's outer shell) ----
+        if (nr > 0) {
+#pragma unroll
+            for (int c = 1; c < 10; ++c) { const int sl = unpack16(ln, c - 1); if (sl >= T && sl != ZSLOT) lds_add(&qh_s[sl - T], Cme[(c - 1) * T]); }
+            if (sx >= T && sx != ZSLOT) lds_add(&qh_a[sx - T], Cme[9 * T]);
+            if (sy >= T && sy != ZSLOT) lds_add(&qh_a[sy - T], Cme[10 * T]);
+            if (sz >= T && sz != ZSLOT) lds_add(&qh_a[sz - T], Cme[11 * T]);
+        }
+        __syncthreads();
+        // ---- pull: every entry collects the column sums of the tile entries whose stencil contains it ----
+        if (in) {
+            // reverse entries: slot c of entry e is this entry <=> e = this entry's neighbour in the mirrored direction
+            // c: 1 -y, 2 -2y, 3 -y-z, 4 -z, 5 -2z, 6 -x, 7 -x-y, 8 -x-z, 9 -2x; albedo 11 -x, 12 -y, 13 -z
+            const int r2y = unpack16(lr, 0), ryz = unpack16(lr, 1), r2z = unpack16(lr, 2), rxy = unpack16(lr, 3), rxz = unpack16(lr, 4), r2x = unpack16(lr, 5);
+            auto pull = [&](int col, int slot) { return slot < T ? C_l[col * T + slot] : 0.0f; };
+            float qs = self_s, qa = self_a;
+            qs += pull(0, my) + pull(1, r2y) + pull(2, ryz) + pull(3, mz) + pull(4, r2z) + pull(5, mx) + pull(6, rxy) + pull(7, rxz) + pull(8, r2x);
+            qa += pull(9, mx) + pull(10, my) + pull(11, mz);
+            const int rg[6] = {sx, mx, sy, my, sz, mz};
+#pragma unroll
+            for (int d = 0; d < 6; ++d) qs += tr_l[rg[d] < T ? rg[d] : T];
+            // Ea rows in pull form (k_eaw_sym): rho sum_d w_sym[d] (u_a - u_nb(d))
+            float ea = 0.0f, eq = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) { const float diff = ua - u_a[rg[d]]; const float t = eaw[d] * diff; ea += t; eq += (rg[d] == ZSLOT ? 1.0f : 0.5f) * t * diff; }
+            qa += tw3 * ea; pq += (double)(tw3 * eq);                 // an edge whose other voxel is a list entry is seen from both sides
+            qacc[a] = qs; qacc[chunk + a] = qa;
+        }
+#pragma unroll
+        for (int q = 0; q < (HMAX + T - 1) / T; ++q) { const int hq = i + q * T; if (hq < H) { const size_t o = (size_t)tile * HMAX + hq; qh[2 * o] = qh_s[hq]; qh[2 * o + 1] = qh_a[hq]; } }
+        __syncthreads();       // the staging of the next tile rewrites u / C / tr slots other lanes are still pulling from
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        float v = cam9[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0.0f) lds_add(&lds[o_cam + q], v);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nshared; q += T) {
+        float v;
+        if (q < 6 * K) { v = 0.0f; for (int rp = 0; rp < reps; ++rp) v += lds[rp * rs + q]; }
+        else v = lds[o_cam + q - 6 * K];
+        if (v != 0.0f) atomicAdd(&shared[q], (double)v);
+    }
+    if (pq_partials) block_partial_d(pq, pq_partials, 1, 0);
+#undef upose
+#undef u_s
+#undef u_a
+#undef qh_s
+#undef qh_a
+#undef tr_l
+#undef C_l
+#undef ui
+#undef Cme
+}
+
+// halo sums -> owners.  (ext_e, ext_pos): the (entry, halo slot) pairs of all tiles sorted by entry (INT_MAX padding last); the lane at the
+// head of an entry's run adds the run (a handful of slots: the tiles around the entry) in its fixed order.
+__global__ void __launch_bounds__(256) k_halo_fold(int n, const int* __restrict__ ext_e, const int* __restrict__ ext_pos, const float* __restrict__ qh,
+                                                   float* __restrict__ qacc, int chunk, const PcgState* __restrict__ state) {
+    if (state && state->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = ext_e[i];
+    if (e == INT_MAX || (i > 0 && ext_e[i - 1] == e)) return;
+    float s = 0.0f, al = 0.0f;
+    for (int j = i; j < n && ext_e[j] == e; ++j) { const float2 v = reinterpret_cast<const float2*>(qh)[ext_pos[j]]; s += v.x; al += v.y; }
+    qacc[e] += s; qacc[chunk + e] += al;
+}
+
+__global__ void k_iota(int n, int* __restrict__ x) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) x[i] = i; }
+
+// tile geometry: T entries per tile / workgroup, HMAX halo slots.  512 (two workgroups per CU, 57 KB of LDS each) unless the environment says 1024.
+static int tp_T() { static int t = 0; if (!t) { const char* e = std::getenv("I3D_EGT_TILE"); t = (e && std::atoi(e) == 1024) ? 1024 : 512; } return t; }
+static int tp_H() { return tp_T() == 1024 ? 1024 : 768; }
+int tile_plan_tiles(int A) { return (A + tp_T() - 1) / tp_T(); }
+int tile_plan_hmax() { return tp_H(); }
+size_t tile_plan_temp_bytes(int ntiles) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr, (size_t)ntiles * tp_H(), 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+// returns hipSuccess or the first error; *overflow (device int, zeroed here) = 1 when a tile's halo does not fit
+hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, size_t temp_bytes) {
+    const int ntiles = tile_plan_tiles(r.A);
+    if (ntiles <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(t.overflow, 0, sizeof(int), st); if (e != hipSuccess) return e;
+    k_tile_plan<<<ntiles, 1024, 0, st>>>(r, tp_T(), tp_H(), t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
+    const int n = ntiles * tp_H();
+    k_iota<<<(n + 255) / 256, 256, 0, st>>>(n, t.iota);
+    return rocprim::radix_sort_pairs(temp, temp_bytes, (const int*)t.halo_idx, t.ext_e, (const int*)t.iota, t.ext_pos, (size_t)n, 0, 32, st);
+}
+
+// after the build kernel has written the Ea weights of this outer iteration
+void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t) { if (r.A > 0) k_eaw_sym<<<(r.A + 255) / 256, 256, 0, st>>>(r, t.eaw_sym); }
+
+template <int T, int HMAX>
+static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state, int num_cu) {
+    const int ntiles = (r.A + T - 1) / T;
+    const int nshared = 6 * p.K + 9, rs = (6 * p.K) | 1;
+    auto lds_bytes = [&](int reps) { const int nacc = reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
+                                     return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T) * sizeof(float); };
+    const size_t budget = (T == 512 ? 78 : 158) * 1024;
+    int reps = 4;                                            // replicas only serve the rare > 3-keyframe fallback of wave_accumulate
+    while (reps > 1 && lds_bytes(reps) > budget) reps >>= 1;
+    const size_t lds = lds_bytes(reps);
+    int per_cu = (T == 512 && lds <= budget) ? 2 : 1;
+    { static int knob = -1; if (knob < 0) { const char* e = std::getenv("I3D_EGT_WG_PER_CU"); knob = e ? std::atoi(e) : 0; } if (knob > 0) per_cu = knob; }
+    const int blocks = ntiles < per_cu * num_cu ? ntiles : per_cu * num_cu;
+    const int tiles_per_block = (ntiles + blocks - 1) / blocks;
+#define I3D_EGT(SL) do { (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        k_eg_tile<T, HMAX, SL><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, state); } while (0)
+    if (r.slots == 5) I3D_EGT(5);                             // the shipped num_observations (data/intrinsic3d.yml)
+    else I3D_EGT(0);
+#undef I3D_EGT
+    const int n = ntiles * HMAX;
+    k_halo_fold<<<(n + 255) / 256, 256, 0, st>>>(n, t.ext_e, t.ext_pos, t.qh, qacc, r.chunk, state);
+    return blocks;                                           // number of p.q partials written
+}
+
+int launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state) {
+    if (r.A <= 0) return 0;
+    static int num_cu = 0;
+    if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    if (tp_T() == 1024) return launch_eg_tile_t<1024, 1024>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
+    return launch_eg_tile_t<512, 768>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
+}
+
+}  // namespace i3d

@@ -79,9 +79,13 @@ struct i3d_context {
     i3d::DevBuf<int> obs_frame, anbr; i3d::DevBuf<float> obs_w, ea_w, C, treg;
     i3d::DevBuf<float4> rows;
     i3d::DevBuf<uint8_t> aflags, nrows, regflags, ea_free;
+    // tiled operator pass (tile_pass.hip): plan of the current work list
+    i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw;
+    i3d::DevBuf<unsigned char> tp_temp; bool tile_ok = false;
+    i3d::TilePlan tile_plan() const { return i3d::TilePlan{tp_lnbr.p, tp_eaw.p, tp_halo_idx.p, tp_halo_cnt.p, tp_iota.p, tp_ext_e.p, tp_ext_pos.p, tp_qh.p, tp_overflow.p}; }
 
     // ---- solver vectors (length NP = 2N + 6K + 9) ----
-    i3d::DevBuf<float> v_mask, v_c, v_S, v_D2, v_Minv, v_b, v_x, v_r, v_p, v_z, v_q, v_u, v_acc, v_tmp;
+    i3d::DevBuf<float> v_mask, v_c, v_S, v_D2, v_Minv, v_b, v_x, v_r, v_p, v_z, v_q, v_u, v_acc, v_tmp, v_qacc;
     i3d::DevBuf<float> Minv_blocks;
     i3d::DevBuf<double> d_shared, d_blocks, d_scal, d_xshared, d_xcshared;
     i3d::DevBuf<i3d::PcgState> d_pcg; i3d::DevBuf<double> d_partials; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};

@@ -42,8 +42,12 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->aflags.alloc(Acap)); CTX_HIP(c, c->nrows.alloc(Acap)); CTX_HIP(c, c->anbr.alloc(Acap * NUM_NBR));
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8));
+    { const size_t nt = (size_t)tile_plan_tiles((int)Acap), nh = nt * (size_t)tile_plan_hmax();
+      CTX_HIP(c, c->tp_lnbr.alloc(Acap * 9)); CTX_HIP(c, c->tp_eaw.alloc(Acap * 6)); CTX_HIP(c, c->tp_halo_idx.alloc(nh)); CTX_HIP(c, c->tp_halo_cnt.alloc(nt)); CTX_HIP(c, c->tp_iota.alloc(nh));
+      CTX_HIP(c, c->tp_ext_e.alloc(nh)); CTX_HIP(c, c->tp_ext_pos.alloc(nh)); CTX_HIP(c, c->tp_qh.alloc(2 * nh)); CTX_HIP(c, c->tp_overflow.alloc(1));
+      CTX_HIP(c, c->tp_temp.alloc(tile_plan_temp_bytes((int)nt))); }
     const size_t NP = 2 * (size_t)c->N + 2 * 64 + 6 * (size_t)c->K + 9;          // rank-major layout pads every rank's slice to the same chunk
-    for (DevBuf<float>* v : {&c->v_mask, &c->v_c, &c->v_S, &c->v_D2, &c->v_Minv, &c->v_b, &c->v_x, &c->v_r, &c->v_p, &c->v_z, &c->v_q, &c->v_u, &c->v_acc, &c->v_tmp})
+    for (DevBuf<float>* v : {&c->v_mask, &c->v_c, &c->v_S, &c->v_D2, &c->v_Minv, &c->v_b, &c->v_x, &c->v_r, &c->v_p, &c->v_z, &c->v_q, &c->v_u, &c->v_acc, &c->v_tmp, &c->v_qacc})
         { const bool fresh = v->n < NP || !v->p; CTX_HIP(c, v->alloc(NP)); if (fresh) CTX_HIP(c, hipMemset(v->p, 0, sizeof(float) * v->n)); }   // padding entries stay finite
     CTX_HIP(c, c->Minv_blocks.alloc((size_t)36 * c->K + 16 + 25));
     CTX_HIP(c, c->d_shared.alloc((size_t)6 * c->K + 9 + 1)); CTX_HIP(c, c->d_blocks.alloc((size_t)21 * c->K + 25));      // +1: p.q partial rides with the camera block
@@ -109,7 +113,10 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     CTX_HIP(c, hipStreamSynchronize(s));
     c->A = tail[0] + tail[1];
     { TimedScope t(c, I3D_K_CLASSIFY); launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
-    if (!sharded(c)) { shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; }
+    c->tile_ok = false;
+    if (!sharded(c)) { shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A;
+                       RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
+                       CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n)); }
     else {      // owned range + compute list (every rank derives them from the replicated work list: no communication)
         const int world = c->comm->world, rank = c->comm->rank;
         shard_range(c->A, world, rank, c->chunk, c->own0, c->own1); c->nC = 0;
@@ -127,10 +134,15 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     RowView r = c->row_view();
     { TimedScope t(c, I3D_K_OBSERVE); launch_observe(s, g, r, p, c->d_frames.p); }
     { TimedScope t(c, I3D_K_BUILD); launch_build(s, g, r, p, c->d_frames.p, true, nullptr, c->d_partials.p); }
+    if (!sharded(c)) { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan()); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
     { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, c->d_scal.p, c->d_partials.p); }
     { int rc = allreduce(c, c->d_scal.p, 9); if (rc) return rc; }
+    int tp_over = 1;
+    if (!sharded(c)) CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
     double sums[9]; { int rc = read_doubles(c, c->d_scal.p, 9, sums); if (rc) return rc; }
+    c->tile_ok = !sharded(c) && tp_over == 0;       // a halo that does not fit (pathological grids) -> the untiled operator pass
+    { const char* e = std::getenv("I3D_NO_TILE"); if (e && e[0] == '1') c->tile_ok = false; }      // tests of the fallback (k_eg_jtjp + k_gather)
     sums[5] = sums[1]; sums[6] = sums[2];
     const double lambda[4] = {cfg.lambda_g, varying_lambda(iteration, cfg.iterations, cfg.lambda_r0, cfg.lambda_r1),
                               varying_lambda(iteration, cfg.iterations, cfg.lambda_s0, cfg.lambda_s1), cfg.lambda_a};
@@ -149,8 +161,13 @@ static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const flo
     PassBuffers b{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
     CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
     if (mode == PASS_COLNORM) CTX_HIP(c, hipMemsetAsync(c->d_blocks.p, 0, sizeof(double) * (21 * (size_t)c->K + 25), s));
-    { TimedScope t(c, mode == PASS_JTJP ? I3D_K_EG_PASS : I3D_K_EG_AUX); launch_eg_pass(s, mode, g, r, p, u, b, nullptr); }
-    { TimedScope t(c, I3D_K_GATHER); launch_gather(s, mode, r, b, out); }
+    if (mode == PASS_JTJP && c->tile_ok) {        // the PCG's tiled operator pass (raw accumulators straight into `out`)
+        { TimedScope t(c, I3D_K_EG_PASS); launch_eg_tile(s, r, p, u, c->tile_plan(), c->d_shared.p, out, nullptr, nullptr); }
+        { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, 2 * c->chunk, c->v_mask.p, out, out); }      // the raw accumulators also cover fixed unknowns (the PCG multiplies them by S = 0)
+    } else {
+        { TimedScope t(c, mode == PASS_JTJP ? I3D_K_EG_PASS : I3D_K_EG_AUX); launch_eg_pass(s, mode, g, r, p, u, b, nullptr); }
+        { TimedScope t(c, I3D_K_GATHER); launch_gather(s, mode, r, b, out); }
+    }
     { int rc = allreduce(c, c->d_shared.p, (size_t)L.NS); if (rc) return rc; }
     if (mode == PASS_COLNORM) { int rc = allreduce(c, c->d_blocks.p, 21 * (size_t)c->K + 25); if (rc) return rc; }
     { TimedScope t(c, I3D_K_VECTOR); launch_shared_finalize(s, L.tail_off, c->K, p, c->d_shared.p, out, false, nullptr, nullptr, nullptr, nullptr, nullptr); }
@@ -222,7 +239,7 @@ static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const F
 static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, PcgState* final_state) {
     hipStream_t s = c->stream;
     const Layout L = layout_of(c);
-    const int K = c->K; const bool multi = sharded(c);
+    const int K = c->K; const bool multi = sharded(c), tiled = !multi && c->tile_ok;
     GridView g = c->grid_view(); RowView r = c->row_view();
     PassBuffers pb{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
     PcgState* st = c->d_pcg.p;
@@ -230,21 +247,30 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     const size_t so = L.slice_off, to = L.tail_off; const int sn = (int)L.slice_n;
     { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, (int)L.NP, c->v_x.p, 0.0f); launch_pcg_init(s, st, cfg.pcg_fixed_iterations, 500); }
     CTX_HIP(c, hipMemcpyAsync(c->v_r.p, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s));
-    // the operator on the rows of this rank: out(slice) = S J^T W J u + D^2 v, camera block and p.q partial left in d_shared (reduced over ranks)
-    // fp64 partial sums: [0, 4*2048) slice sums of k_pcg_step, then the p.q partials of k_gather
-    double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048;
-    int n_pq = 0, n_step = 0;
+    // fp64 partial sums: [0, 4*2048) slice sums of k_pcg_step, then the p.q partials of the operator pass, then the D^2 p^2 partials of k_pcg_direction
+    double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048; double* const d2_part = pq_part + 1024;
+    int n_pq = 0, n_step = 0, n_d2 = 0;
+    // Single rank: the LDS-tiled pass leaves the raw accumulators J^T W J u in v_qacc (camera block in d_shared, p.q partials row by row); the
+    // vector q = S acc + D^2 v is formed inside k_pcg_step.  Sharded: the rank's rows through k_eg_jtjp + k_gather on its compute list:
+    // out(slice) = S J^T W J u + D^2 v, camera block and p.q partial left in d_shared (reduced over ranks).
     auto rows_apply = [&](const float* v, float* out, bool with_dot, bool zero_first) -> int {
         if (zero_first) CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));      // (the pass boundary kernel zeroes it otherwise)
+        if (tiled) {
+            TimedScope t(c, I3D_K_EG_PASS);
+            n_pq = launch_eg_tile(s, r, p, c->v_u.p, c->tile_plan(), c->d_shared.p, c->v_qacc.p, with_dot ? pq_part : nullptr, st);
+            if (!with_dot) n_pq = 0;
+            return I3D_OK;
+        }
         { TimedScope t(c, I3D_K_EG_PASS); launch_eg_pass(s, PASS_JTJP, g, r, p, c->v_u.p, pb, st); }
         // sharded: the rank's p.q partial is accumulated straight into the slot that rides with the camera block (few workgroups per rank)
         { TimedScope t(c, I3D_K_GATHER); n_pq = launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, with_dot ? (multi ? pq_slot : pq_part) : nullptr, multi, st); }
-        if (!multi) return I3D_OK;
+        if (!multi) { if (!with_dot) n_pq = 0; return I3D_OK; }
         n_pq = 0;
         return allreduce(c, c->d_shared.p, (size_t)L.NS + 1);
     };
+    const float* const Sq = tiled ? c->v_S.p : nullptr;          // tiled pass: k_pcg_step forms q from the accumulators
     { TimedScope t(c, I3D_K_VECTOR);
-      n_step = launch_pcg_step(s, 0 /*init*/, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, multi ? nullptr : step_part, st); }
+      n_step = launch_pcg_step(s, 0 /*init*/, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, multi ? nullptr : step_part, st); }
     int tail_mode = 0;
     const int seq0 = c->pcg_seq;               // pass numbers are unique across solves: a stale ring entry can never match
     int it = 1;
@@ -255,25 +281,25 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
           launch_pcg_tail_a(s, tail_mode, to, K, c->Minv_blocks.p, c->v_p.p, tail_mode == 3 ? c->v_tmp.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_z.p,
                             step_part, n_step, st, c->d_shared.p, L.NS + 1, c->d_flags, seq0 + it); }
         { TimedScope t(c, I3D_K_VECTOR);        // p is kept replicated (z was all-gathered), so u = S p needs no exchange
-          if (!multi) launch_pcg_direction(s, sn + L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, st);
-          else launch_pcg_direction(s, (int)L.NP, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, st); }
+          if (!multi) n_d2 = launch_pcg_direction(s, sn + L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, tiled ? d2_part : nullptr, st);
+          else launch_pcg_direction(s, (int)L.NP, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, nullptr, nullptr, st); }
         { int rc = rows_apply(c->v_p.p, c->v_q.p, true, false); if (rc) return rc; }
-        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_tail_b(s, to, K, p, c->d_shared.p, pq_slot, pq_part, n_pq, c->v_q.p, c->v_S.p, c->v_D2.p, c->v_p.p, st); }
+        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_tail_b(s, to, K, p, c->d_shared.p, pq_slot, pq_part, n_pq, d2_part, tiled ? n_d2 : 0, tiled, c->v_q.p, c->v_S.p, c->v_D2.p, c->v_p.p, st); }
         const bool reset = (it % 10 == 0);                                       // residual_reset_period
         if (!reset) {
             TimedScope t(c, I3D_K_VECTOR);
-            n_step = launch_pcg_step(s, 1, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, multi ? nullptr : step_part, st);
+            n_step = launch_pcg_step(s, 1, so, sn, c->v_p.p, tiled ? c->v_qacc.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, multi ? nullptr : step_part, st);
             tail_mode = 1;
         } else {                                                                 // r = b - A x instead of r -= alpha q
             { TimedScope t(c, I3D_K_VECTOR);
-              launch_pcg_step(s, 2, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, multi ? nullptr : step_part, st);
+              launch_pcg_step(s, 2, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, multi ? nullptr : step_part, st);
               launch_pcg_tail_x(s, to, K, c->v_p.p, c->v_x.p, st);
               launch_mul(s, sn, c->v_S.p + so, c->v_x.p + so, c->v_u.p + so); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
             { int rc = allgather(c, c->v_u.p); if (rc) return rc; }
             { int rc = rows_apply(c->v_x.p, c->v_tmp.p, false, true); if (rc) return rc; }
             { TimedScope t(c, I3D_K_VECTOR);
               launch_shared_finalize(s, to, K, p, c->d_shared.p, c->v_tmp.p, true, c->v_S.p, c->v_D2.p, c->v_x.p, nullptr, st);
-              n_step = launch_pcg_step(s, 3, so, sn, c->v_p.p, c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, multi ? nullptr : step_part, st); }
+              n_step = launch_pcg_step(s, 3, so, sn, c->v_p.p, tiled ? c->v_qacc.p : c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, multi ? nullptr : step_part, st); }
             tail_mode = 3;
         }
         if (it >= 2) {                                                           // look at the boundary of pass it-1 while pass it runs

@@ -163,6 +163,19 @@ def test_real_rccl_collectives_with_one_rank(oracle, monkeypatch):
     g.free(); fr.free()
 
 
+def test_untiled_operator_fallback(oracle, monkeypatch):
+    """the PCG operator without the LDS tile plan (what a grid whose tile halos do not fit falls back to; I3D_NO_TILE=1 forces it):
+    k_eg_jtjp + k_gather give the same answer as the tiled pass and the oracle"""
+    sc = helpers.small_scene(seed=16, radius_vox=9, K=4, width=96, height=72)
+    thres = 2.0 * float(sc["voxel_size"])
+    rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres)
+    monkeypatch.setenv("I3D_NO_TILE", "1")
+    rc2, ref2, _, ostats2, out2, cam2, gstats2 = _run_both(oracle, sc, thres)
+    assert rc == 0 and rc2 == 0
+    _check(ref2, ostats2, out2, gstats2)
+    assert np.abs(out2["sdf_refined"] - out["sdf_refined"]).max() <= 1e-4 * np.abs(out["sdf_refined"]).max() and np.abs(out2["albedo"] - out["albedo"]).max() <= 1e-4
+
+
 def test_carry_trust_radius_extension(oracle):
     """opt-in extension (what nls_solver.cpp:322-323 intends): the radius survives from one outer iteration to the next, so later iterations
     need fewer LM attempts; device == oracle with the same switch, and the default still restarts at 1e4"""
