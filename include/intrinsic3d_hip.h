@@ -248,9 +248,11 @@ int  i3d_fusion_info(const i3d_fusion* f, uint64_t* frames, uint64_t* allocated,
 int  i3d_fusion_get(const i3d_fusion* f, int32_t* keys, float* sdf, float* weight, uint8_t* color);
 int  i3d_fusion_save(const i3d_fusion* f, const char* path);
 
-/* ---- one process per GPU: the voxel state is replicated, row work / row storage / solver vectors are sharded by contiguous
- * work-list ranges; RCCL carries the PCG scalars, the camera block and the per-iteration vector exchange.  Call after i3d_create
- * on every rank with the same unique id (i3d_comm_unique_id on rank 0, broadcast by the launcher, e.g. torch.distributed). */
+/* ---- one process per GPU: the voxel state is replicated; row work / row storage / solver vectors are sharded by contiguous, tile-aligned
+ * ranges of the brick-ordered work list (compact regions of the surface).  A rank builds rows for its range + a thin rim of ghost entries;
+ * per PCG pass it pushes the operator input of the rim to its neighbours (peer to peer) and joins ONE small all-reduce [camera block | p.q]
+ * (RCCL) plus the 4 iteration scalars.  Call after i3d_create on every rank with the same unique id (i3d_comm_unique_id on rank 0,
+ * broadcast by the launcher, e.g. torch.distributed). */
 int i3d_comm_unique_id(void* out128, int32_t* bytes);
 int i3d_comm_init(i3d_context* ctx, int32_t rank, int32_t world, const void* unique_id, int32_t id_bytes);
 /* single-GPU simulation of W ranks (W host threads, one context each, same device) — test vehicle for the SPMD control flow */
@@ -262,6 +264,12 @@ int   i3d_comm_init_sim(i3d_context* ctx, void* shared, int32_t rank);
 int   i3d_shard_plan(int32_t A, int32_t world, int32_t rank, const int32_t* anbr, const uint8_t* active,
                      int32_t* chunk, int32_t* own0, int32_t* own1, uint8_t* in_compute_list /*[A]*/);
 int32_t i3d_shard_vec_index(int32_t a, int32_t chunk, int32_t albedo);
+/* need[e] bit k: rank k's rows read the unknowns of work-list entry e, which it does not own (what Comm::push_halo moves once per PCG pass) */
+int   i3d_shard_need(int32_t A, int32_t world, const int32_t* anbr /*[18][A]*/, const uint8_t* active /*[A]*/, uint64_t* need /*[A]*/);
+/* traffic log of the sharded path since i3d_comm_init: halo exchanges (calls, bytes this rank sent), all-reduces (calls, bytes), and the
+ * plan of the last outer iteration (rim entries sent / received per pass, foreign tiles with ghost entries, compute-list length) */
+int   i3d_comm_stats(i3d_context* ctx, int64_t* halo_calls, int64_t* halo_bytes_sent, int64_t* reduce_calls, int64_t* reduce_bytes,
+                     int32_t* halo_entries_send, int32_t* halo_entries_recv, int32_t* ghost_tiles, int32_t* compute_list);
 
 /* ---- measurement: HIP-event time (ms) and launch count accumulated per kernel family on the context's stream
  * since the last reset.  names: see i3d_kernel_name(). */

@@ -71,7 +71,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_sensor_depth", "i3d_sensor_pose", "i3d_sensor_set_pose", "i3d_sensor_set_pose_vec6", "i3d_sensor_save_poses",
            "i3d_keyframes_load", "i3d_keyframes_save", "i3d_keyframes_select", "i3d_blur_score", "i3d_init_frames_from_sensor",
            "i3d_fusion_create", "i3d_fusion_destroy", "i3d_fusion_last_error", "i3d_fusion_integrate", "i3d_fusion_finish", "i3d_fusion_info", "i3d_fusion_get",
-           "i3d_fusion_save",
+           "i3d_fusion_save", "i3d_shard_need", "i3d_comm_stats",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_map_order", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
@@ -118,6 +118,8 @@ def load():
     L.i3d_comm_init_sim.restype = i32; L.i3d_comm_init_sim.argtypes = [vp, vp, i32]
     L.i3d_shard_plan.restype = i32; L.i3d_shard_plan.argtypes = [i32, i32, i32, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), vp]
     L.i3d_shard_vec_index.restype = i32; L.i3d_shard_vec_index.argtypes = [i32, i32, i32]
+    L.i3d_shard_need.restype = i32; L.i3d_shard_need.argtypes = [i32, i32, vp, vp, vp]
+    L.i3d_comm_stats.restype = i32; L.i3d_comm_stats.argtypes = [vp] * 9
     L.i3d_timing_enable.restype = i32; L.i3d_timing_enable.argtypes = [vp, i32]
     L.i3d_timing_select.restype = i32; L.i3d_timing_select.argtypes = [vp, C.c_uint32]
     L.i3d_timing_get.restype = i32; L.i3d_timing_get.argtypes = [vp, vp, vp, i32]
@@ -364,6 +366,12 @@ class Context:
     def comm_init(self, rank: int, world: int, unique_id: bytes):
         self._check(self.L.i3d_comm_init(self.h, int(rank), int(world), unique_id, len(unique_id)), "i3d_comm_init")
 
+    def comm_stats(self):
+        """traffic log of the sharded path: dict(halo_calls, halo_bytes_sent, reduce_calls, reduce_bytes, halo_send, halo_recv, ghost_tiles, compute_list)"""
+        a = [C.c_int64() for _ in range(4)]; b = [C.c_int32() for _ in range(4)]
+        self._check(self.L.i3d_comm_stats(self.h, *[C.byref(x) for x in a], *[C.byref(x) for x in b]), "i3d_comm_stats")
+        return dict(zip(["halo_calls", "halo_bytes_sent", "reduce_calls", "reduce_bytes", "halo_send", "halo_recv", "ghost_tiles", "compute_list"], [x.value for x in a + b]))
+
     def comm_init_sim(self, shared, rank: int):
         self._check(self.L.i3d_comm_init_sim(self.h, shared, int(rank)), "i3d_comm_init_sim")
 
@@ -444,6 +452,15 @@ class Context:
         x = np.ascontiguousarray(x, np.float64); y = np.zeros_like(x)
         self._check(self.L.i3d_debug_jtj_apply(self.h, _p(x), _p(y)), "i3d_debug_jtj_apply")
         return y
+
+
+def shard_need(A, world, anbr, active):
+    """need[e] bit k: rank k's rows read entry e, which it does not own (host statement of the device plan)."""
+    anbr = np.ascontiguousarray(anbr, np.int32); active = np.ascontiguousarray(active, np.uint8); need = np.zeros(A, np.uint64)
+    rc = load().i3d_shard_need(int(A), int(world), _p(anbr), _p(active), _p(need))
+    if rc != 0:
+        raise I3DError(f"i3d_shard_need failed ({rc})")
+    return need
 
 
 def shard_plan(A, world, rank, anbr, active):

@@ -71,14 +71,18 @@ struct GridView {
 };
 
 // ---- sharding (one process per GPU) -------------------------------------------------------------------------
-// The voxel state, flags and work list are REPLICATED on every rank (a few hundred bytes per voxel against 288 GB of HBM);
-// what is sharded is the row work + row storage and the solver vectors: rank k OWNS the contiguous work-list range
-// [k*chunk, (k+1)*chunk) and computes rows for its compute list = owned entries + the entries whose rows its owned unknowns pull from.
-// Solver vectors are laid out rank-major so that a rank's slice is contiguous (in-place all-gather):
-//   [ rank0: sdf(chunk) alb(chunk) | rank1: sdf(chunk) alb(chunk) | ... | poses 6K | intrinsics 4 | distortion 5 ]
-// With one rank chunk >= A and this is the plain [sdf A.. | alb A.. | camera] layout.
-__host__ __device__ inline int vec_sdf(int a, int chunk) { const int k = a / chunk; return k * 2 * chunk + (a - k * chunk); }
-__host__ __device__ inline int vec_alb(int a, int chunk) { return vec_sdf(a, chunk) + chunk; }
+// The voxel state, flags and work list are REPLICATED on every rank (a few hundred bytes per voxel against 288 GB of HBM); what is sharded
+// is the row work + row storage and the solver vectors.  The work list is brick-Morton ordered, so a contiguous range of it is a compact
+// region of the surface; rank k OWNS the range [k*slice, (k+1)*slice), slice a multiple of SHARD_ALIGN entries (whole tiles of the
+// operator pass, tile_pass.hip = whole groups of bricks).  It builds rows for its compute list = owned entries + the GHOST entries of other
+// ranks whose rows touch an owned unknown (a 1-2 voxel rim, ~2 % at 8 ranks of 8 M voxels), so everything that lands on an owned unknown is
+// computed locally and nothing has to be returned to an owner.  What a rank needs from others is the operator input on the rim its rows
+// READ (ghosts and their forward stencils): pushed by the owners once per PCG pass (Comm::push_halo), peer to peer.
+// Every solver vector has the SAME global layout on every rank:  [ sdf: chunk | albedo: chunk | poses 6K | intrinsics 4 | distortion 5 ],
+// chunk = world * slice >= A; a rank keeps its two owned segments (and the halo values pushed to it) up to date, the camera tail is replicated.
+constexpr int SHARD_ALIGN = 1024;
+__host__ __device__ inline int vec_sdf(int a, int) { return a; }
+__host__ __device__ inline int vec_alb(int a, int chunk) { return chunk + a; }
 
 // does rank [own0, own1) need the rows of work-list entry a?  (owned, or an owned unknown is one of its ring / forward-stencil columns)
 __host__ __device__ inline bool shard_needs_entry(int a, int own0, int own1, bool active, const int* anbr, size_t stride) {
@@ -88,15 +92,23 @@ __host__ __device__ inline bool shard_needs_entry(int a, int own0, int own1, boo
     for (int i = 0; i < 12; ++i) { const int la = anbr[(size_t)i * stride + a]; need |= (la >= own0 && la < own1); }   // ring 0..5, forward stencil 0,2,4,6..11
     return need;
 }
+// which ranks hold the rows of ACTIVE entry a (its owner and the owners of its 12 ring / forward-stencil columns); col[12] = those columns
+__host__ __device__ inline unsigned long long shard_entry_ranks(int a, int slice, const int* anbr, size_t stride, int col[12], bool& interior) {
+    const int o = a / slice;
+    unsigned long long ranks = 1ull << o; interior = true;
+    for (int i = 0; i < 12; ++i) { col[i] = anbr[(size_t)i * stride + a]; if (col[i] >= 0) { const int k = col[i] / slice; ranks |= 1ull << k; interior &= k == o; } }
+    return ranks;
+}
 __host__ __device__ inline void shard_range(int A, int world, int rank, int& chunk, int& own0, int& own1) {
-    chunk = (A + world - 1) / world; if (chunk < 1) chunk = 1;
-    chunk = (chunk + 3) & ~3;       // slices start on 16-byte boundaries (the vector kernels move float4)
-    own0 = rank * chunk < A ? rank * chunk : A; own1 = (rank + 1) * chunk < A ? (rank + 1) * chunk : A;
+    const int tiles = (A + SHARD_ALIGN - 1) / SHARD_ALIGN, per_rank = tiles > 0 ? (tiles + world - 1) / world : 1;
+    const int slice = per_rank * SHARD_ALIGN;
+    chunk = world * slice;
+    own0 = rank * slice < A ? rank * slice : A; own1 = (rank + 1) * slice < A ? (rank + 1) * slice : A;
 }
 
 struct RowView {                    // per work-list entry a in [0, A): voxels that are active (own rows) or free (own unknowns)
     int A; int Acap; int slots;
-    int chunk;                      // entries per rank in the vector layout (>= A when not sharded)
+    int chunk;                      // length of the sdf / albedo part of every solver vector (>= A, see the layout above)
     int world;                      // number of ranks
     int own0, own1;                 // owned work-list range of this rank
     const int* clist; int nC;       // compute list (ascending work-list indices), nullptr = identity over [0, A)

@@ -34,6 +34,8 @@ void launch_weight_sums(hipStream_t st, RowView r, double* sums9 /* accumulated:
 // ---- operator.hip -----------------------------------------------------------------------------------------
 // All vectors are in work-list space: NP = 2A + 6K + 9.
 enum PassMode { PASS_GRAD = 0, PASS_JTJP = 1, PASS_COLNORM = 2 };
+// a rank's slice of a solver vector: [off0, off0 + n) of the sdf part and [off1, off1 + n) of the albedo part (n, offsets multiples of 4)
+struct Seg2 { size_t off0, off1; int n; };
 struct PassBuffers {
     float* C;            // [14][Acap] per-voxel-row-block column sums
     float* treg;         // [8][Acap]  tr, ts, ta[6]
@@ -55,20 +57,22 @@ void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* ou
 void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* freemask, float* S);          // S = free ? 1/(1+sqrt(c)) : 0
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float inv_radius, float* D2, float* Minv_diag);  // D2 = clamp(c S^2)/radius, Minv = 1/(c S^2 + D2) (free) else 0
 void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out /* accumulated */, double* scratch);
+void launch_dot2(hipStream_t st, Seg2 sg, const float* a, const float* b, double* out /* accumulated */, double* scratch);
+void launch_mul2(hipStream_t st, Seg2 sg, const float* a, const float* b, float* out);
 void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask /*[NP]*/);
 
 // fused PCG iteration, scalars resident in PcgState
 void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations);
 // mode: 0 init (z, r.z) | 1 x += a p, r -= a q, z, sums | 2 x only | 3 r = b - q(=A x), z, sums      (a rank's slice; off, n multiples of 4)
 // S_for_inline_q != nullptr: `q` holds the raw accumulators of the tiled operator pass and q = S acc + D2 v is formed inside the kernel
-int  launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
+int  launch_pcg_step(hipStream_t st, int mode, Seg2 sg, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
                      float* z, const float* S_for_inline_q, double* partials /*[blocks][4]*/, PcgState* state);                               // returns #partials
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state);
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
                        const float* D2, float* z, const double* partials, int nblk, PcgState* state,           // camera tail + Q-test + rho, beta;
                        double* shared_zero, int nzero, int* host_flags, int seq);                              // zeroes the camera accumulator, publishes (seq, done) to pinned memory
-int  launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const float* D2, double* d2_partials /* or null */,
-                          const PcgState* state);                  // p = z + beta p, u = S p; returns the number of D^2 p^2 partials written
+int  launch_pcg_direction(hipStream_t st, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2,
+                          double* d2_partials /* or null */, const PcgState* state);   // p = z + beta p, u = S p (slice + ntail tail entries); returns the number of D^2 p^2 partials
 void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
                        const double* pq_partials2, int nblk2, bool rowwise,
                        float* q, const float* S, const float* D2, const float* v, PcgState* state);                                                          // camera tail of q, p.q, alpha
@@ -80,15 +84,25 @@ struct TilePlan {                   // built once per outer iteration by launch_
     int* iota; int* ext_e; int* ext_pos;   // [tiles * HMAX] (entry, halo slot) pairs sorted by entry
     float* qh;                      // [tiles * HMAX][2] halo accumulators of one pass
     int* overflow;                  // device flag: a halo did not fit -> use the untiled pass
+    int tile_first, ntiles_own;     // tiles this rank owns (all of them when not sharded)
+    const int* ghost_tiles; int n_ghost;   // sharded: foreign tiles that hold ghost entries of this rank's compute list
 };
+int    tile_plan_T();
 int    tile_plan_tiles(int A);
 int    tile_plan_hmax();
 size_t tile_plan_temp_bytes(int ntiles);
 hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, size_t temp_bytes);
-void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t);        // after launch_build (reads the Ea weights it wrote)
+void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t, const int* cflag /* sharded: compute-list flags, else null */);   // after launch_build (reads the Ea weights it wrote)
 // qacc[2 chunk] = J^T W J u on the voxel unknowns (raw), camera block added into `shared` (fp64), row-wise p.q partials; returns their number
 int  launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials /* or null */,
                     const PcgState* state);
+
+// ---- shard_kernels.hip: the sharding plan of one outer iteration ----------------------------------------------------------------
+void launch_need_mask(hipStream_t st, RowView r, int slice, unsigned long long* need /* [A], zeroed */);
+void launch_halo_items(hipStream_t st, int A, int slice, int me, const unsigned long long* need, unsigned long long* items, int* count /* zeroed */, int cap);
+void launch_tile_flags(hipStream_t st, int A, int T, const int* cflag, int* tileflag /* zeroed */);
+size_t halo_sort_temp_bytes(int cap);
+hipError_t launch_halo_sort(hipStream_t st, void* temp, size_t temp_bytes, const unsigned long long* in, unsigned long long* out, int n);
 
 void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* x_shared, double* xc_sdf, double* xc_alb,
                       double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask, double* scratch);

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
     const int nacc = reps * rs + NCAM;
     for (int i = threadIdx.x; i < nacc; i += EG_THREADS) lds[i] = 0.0f;
     float* upose = lds + nacc;            // JTJP: the 6K+9 camera entries of u (every row reads 6+9 of them)
-    const size_t tail = (size_t)r.world * 2 * (size_t)r.chunk;          // camera part of every solver vector
+    const size_t tail = 2 * (size_t)r.chunk;          // camera part of every solver vector
     const int chunk = r.chunk;
     if (MODE == PASS_JTJP) for (int i = threadIdx.x; i < nshared; i += EG_THREADS) upose[i] = u[tail + i];
     __syncthreads();
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
     for (int i = threadIdx.x; i < nacc; i += EG_THREADS) lds[i] = 0.0f;
     float* const upose = lds + nacc;
     float* const uvl = upose + nshared + threadIdx.x;                    // this lane's column of the [14][EG_THREADS] staging
-    const size_t tail = (size_t)r.world * 2 * (size_t)r.chunk;
+    const size_t tail = 2 * (size_t)r.chunk;
     const int chunk = r.chunk;
     for (int i = threadIdx.x; i < nshared; i += EG_THREADS) upose[i] = u[tail + i];
     __syncthreads();
@@ -549,6 +549,7 @@ void launch_shared_finalize(hipStream_t st, size_t tail_off, int K, OptParams p,
 __global__ void k_fill(int n, float* x, float v) { GRID_STRIDE(n) x[i] = v; }
 __global__ void k_fill_d(int n, double* x, double v) { GRID_STRIDE(n) x[i] = v; }
 __global__ void k_mul(int n, const float* a, const float* b, float* o) { GRID_STRIDE(n) o[i] = a[i] * b[i]; }
+__global__ void k_mul2(int n, size_t seg, const float* a, const float* b, float* o) { GRID_STRIDE(2 * n) { const size_t j = i < n ? (size_t)i : (size_t)(i - n) + seg; o[j] = a[j] * b[j]; } }
 __global__ void k_scale(int n, const float* c, const float* m, float* S) { GRID_STRIDE(n) S[i] = m[i] != 0.0f ? 1.0f / (1.0f + sqrtf(c[i])) : 0.0f; }
 __global__ void k_lm_diag(int n, const float* c, const float* S, float inv_radius, float* D2, float* Minv) {
     GRID_STRIDE(n) {
@@ -563,11 +564,24 @@ __global__ void __launch_bounds__(256) k_dot(int n, const float* a, const float*
     double s = 0.0; GRID_STRIDE(n) s += (double)a[i] * (double)b[i];
     block_partial_d(s, out, 1, 0);
 }
+__global__ void __launch_bounds__(256) k_dot2(int n, size_t seg, const float* a, const float* b, double* out) {
+    double s = 0.0; GRID_STRIDE(2 * n) { const size_t j = i < n ? (size_t)i : (size_t)(i - n) + seg; s += (double)a[j] * (double)b[j]; }
+    block_partial_d(s, out, 1, 0);
+}
 void launch_fill(hipStream_t st, int n, float* x, float v) { if (n > 0) k_fill<<<vblocks(n), 256, 0, st>>>(n, x, v); }
 void launch_fill_d(hipStream_t st, int n, double* x, double v) { if (n > 0) k_fill_d<<<vblocks(n), 256, 0, st>>>(n, x, v); }
 void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* o) { if (n > 0) k_mul<<<vblocks(n), 256, 0, st>>>(n, a, b, o); }
+void launch_mul2(hipStream_t st, Seg2 sg, const float* a, const float* b, float* o) {
+    if (sg.n > 0) k_mul2<<<vblocks(2 * sg.n), 256, 0, st>>>(sg.n, sg.off1 - sg.off0, a + sg.off0, b + sg.off0, o + sg.off0);
+}
 void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* m, float* S) { if (n > 0) k_scale<<<vblocks(n), 256, 0, st>>>(n, c, m, S); }
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float ir, float* D2, float* Minv) { if (n > 0) k_lm_diag<<<vblocks(n), 256, 0, st>>>(n, c, S, ir, D2, Minv); }
+void launch_dot2(hipStream_t st, Seg2 sg, const float* a, const float* b, double* out, double* scratch) {      // out += a.b over both segments
+    if (sg.n <= 0) return;
+    const int blocks = vblocks(2 * sg.n) > 1024 ? 1024 : vblocks(2 * sg.n);
+    k_dot2<<<blocks, 256, 0, st>>>(sg.n, sg.off1 - sg.off0, a + sg.off0, b + sg.off0, scratch);
+    launch_reduce_partials(st, scratch, blocks, 1, out, nullptr);
+}
 void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out, double* scratch) {      // out += a.b
     if (n <= 0) return;
     const int blocks = vblocks(n) > 1024 ? 1024 : vblocks(n);
@@ -576,13 +590,12 @@ void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* o
 }
 
 __global__ void k_freemask(RowView r, OptParams p, float* __restrict__ mask) {
-    const int A = r.A, chunk = r.chunk, nv = r.world * 2 * chunk, NP = nv + 6 * p.K + 9;
+    const int A = r.A, chunk = r.chunk, nv = 2 * chunk, NP = nv + 6 * p.K + 9;
     GRID_STRIDE(NP) {
         float m;
-        if (i < nv) {                                   // rank-major layout: [rank][sdf chunk | alb chunk]; padding entries are fixed
-            const int k = i / (2 * chunk), rem = i - k * 2 * chunk;
-            const int a = k * chunk + (rem < chunk ? rem : rem - chunk);
-            m = (a < A && (r.aflags[a] & (rem < chunk ? F_FREE_SDF : F_FREE_ALB))) ? 1.0f : 0.0f;
+        if (i < nv) {                                   // [sdf chunk | alb chunk]; padding entries are fixed
+            const int a = i < chunk ? i : i - chunk;
+            m = (a < A && (r.aflags[a] & (i < chunk ? F_FREE_SDF : F_FREE_ALB))) ? 1.0f : 0.0f;
         }
         else if (i < nv + 6 * p.K) m = p.fix_poses ? 0.0f : 1.0f;
         else if (i < nv + 6 * p.K + 4) m = p.fix_intr ? 0.0f : 1.0f;
@@ -590,7 +603,7 @@ __global__ void k_freemask(RowView r, OptParams p, float* __restrict__ mask) {
         mask[i] = m;
     }
 }
-void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask) { k_freemask<<<vblocks(r.world * 2 * r.chunk + 6 * p.K + 9), 256, 0, st>>>(r, p, mask); }
+void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask) { k_freemask<<<vblocks(2 * r.chunk + 6 * p.K + 9), 256, 0, st>>>(r, p, mask); }
 
 // ---- fused PCG iteration (conjugate_gradients_solver.cc) -------------------------------------------------------------
 // One iteration = 6 launches:  tail_a | direction | eg_jtjp | gather | tail_b | step.
@@ -608,13 +621,14 @@ enum { STEP_INIT = 0, STEP_NORMAL = 1, STEP_XONLY = 2, STEP_RESET = 3 };
 // QINLINE: `q` holds the raw operator accumulators J^T W J u of the tiled pass (k_eg_tile + k_ext_gather); the vector q = S acc + D^2 v
 // (v = p, or x for the residual reset) is formed here instead of being written and read back.
 template <int MODE, bool QINLINE>
-__global__ void __launch_bounds__(256) k_pcg_step(int n4, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x, float4* __restrict__ r,
+__global__ void __launch_bounds__(256) k_pcg_step(int n4, int seg4 /* float4 distance between the sdf and the albedo segment */, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x, float4* __restrict__ r,
                                                   const float4* __restrict__ b, const float4* __restrict__ D2, const float4* __restrict__ Minv, float4* __restrict__ z,
                                                   const float4* __restrict__ S, double* __restrict__ partials /* nullptr: add to state->acc directly (sharded) */, PcgState* state) {
     if (state->done) return;
     const float alpha = (float)state->alpha;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < 2 * n4; j += gridDim.x * blockDim.x) {
+        const int i = j < n4 ? j : j - n4 + seg4;          // a rank's slice = one segment of the sdf part + the same segment of the albedo part
         float xv[4], rv[4];
         if (MODE == STEP_INIT) { const float4 t = r[i]; rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
         else {
@@ -731,17 +745,18 @@ __global__ void __launch_bounds__(1024) k_pcg_tail_a(int mode, size_t to, int K,
     publish();
 }
 
-// p = z + beta p ; u = S p ; d2_partials (optional): per-workgroup sums of D^2 p^2 (the diagonal part of p.q, see k_eg_tile)
-__global__ void __launch_bounds__(256) k_pcg_direction(int n, const float* __restrict__ z, float* __restrict__ p, const float* __restrict__ S, float* __restrict__ u,
-                                                       const float* __restrict__ D2, double* __restrict__ d2_partials, const PcgState* __restrict__ state) {
+// p = z + beta p ; u = S p over the two segments of a slice (+ `ntail` trailing scalars at `tail_off`: the camera tail, when it is
+// handled here); d2_partials (optional): per-workgroup sums of D^2 p^2 (the diagonal part of p.q, see tile_pass.hip)
+__global__ void __launch_bounds__(256) k_pcg_direction(int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p, const float* __restrict__ S,
+                                                       float* __restrict__ u, const float* __restrict__ D2, double* __restrict__ d2_partials, const PcgState* __restrict__ state) {
     if (state->done) return;
     const float beta = (float)state->beta; const bool first = state->it == 0;
-    const int n4 = n >> 2;
     const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
     const float4* S4 = reinterpret_cast<const float4*>(S); float4* u4 = reinterpret_cast<float4*>(u);
     const float4* D4 = reinterpret_cast<const float4*>(D2);
     double d2 = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < 2 * n4; j += gridDim.x * blockDim.x) {
+        const int i = j < n4 ? j : j - n4 + seg4;
         float4 pi = z4[i];
         if (!first) { const float4 po = p4[i]; pi.x += beta * po.x; pi.y += beta * po.y; pi.z += beta * po.z; pi.w += beta * po.w; }
         p4[i] = pi;
@@ -749,9 +764,9 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int n, const float* __res
         u4[i] = make_float4(sv.x * pi.x, sv.y * pi.y, sv.z * pi.z, sv.w * pi.w);
         if (d2_partials) { const float4 dd = D4[i]; d2 += (double)dd.x * (double)pi.x * (double)pi.x + (double)dd.y * (double)pi.y * (double)pi.y + (double)dd.z * (double)pi.z * (double)pi.z + (double)dd.w * (double)pi.w * (double)pi.w; }
     }
-    for (int i = 4 * n4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {       // the camera tail is not a multiple of 4
-        const float pi = first ? z[i] : z[i] + beta * p[i]; p[i] = pi; u[i] = S[i] * pi;
-        if (d2_partials) d2 += (double)D2[i] * (double)pi * (double)pi;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntail; t += gridDim.x * blockDim.x) {
+        const size_t i = tail_rel + t;
+        const float pi = first ? z[i] : z[i] + beta * p[i]; p[i] = pi; u[i] = S[i] * pi;      // (the tail's D^2 p^2 is added by k_pcg_tail_b: it is replicated when sharded)
     }
     if (d2_partials) block_partial_d(d2, d2_partials, 1, 0);
 }
@@ -770,7 +785,8 @@ __global__ void __launch_bounds__(1024) k_pcg_tail_b(size_t to, int K, OptParams
         const float vv = v[j];
         const float o = S[j] * (fixed ? 0.0f : (float)shared[i]) + D2[j] * vv;
         q[j] = o;
-        if (!rowwise) dotp += (double)vv * (double)o;      // rowwise: p.q = sum_rows t (J u) [partials] + sum D^2 p^2 [partials2], camera columns included in both
+        if (!rowwise) dotp += (double)vv * (double)o;      // rowwise: p.q = sum_rows t (J u) [partials, camera columns included] + sum D^2 p^2 [partials2: voxel part; camera part here]
+        else dotp += (double)D2[j] * (double)vv * (double)vv;
     }
     for (int i = threadIdx.x; i < nblk; i += blockDim.x) dotp += pq_partials[i];       // workgroup partials of the voxel part (k_gather) / of the rows (k_eg_tile)
     for (int i = threadIdx.x; i < nblk2; i += blockDim.x) dotp += pq_partials2[i];     // workgroup partials of sum D^2 p^2 (k_pcg_direction)
@@ -795,14 +811,16 @@ __global__ void k_pcg_init(PcgState* st, int fixed_iterations, int max_iteration
 void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations) { k_pcg_init<<<1, 1, 0, st>>>(state, fixed_iterations, max_iterations); }
 static inline int step_blocks(int n4) { int b = (n4 + 255) / 256; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
 // off and n must be multiples of 4 (the rank-major layout pads every slice to a multiple of 8 floats)
-int launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
+int launch_pcg_step(hipStream_t st, int mode, Seg2 sg, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
                     float* z, const float* S_for_inline_q, double* partials, PcgState* state) {
-    if (n <= 0) return 0;
-    const int n4 = n >> 2;
+    if (sg.n <= 0) return 0;
+    const int n4 = sg.n >> 2, seg4 = (int)((sg.off1 - sg.off0) >> 2);
+    const size_t off = sg.off0;
     auto c4 = [off](const float* v) { return reinterpret_cast<const float4*>(v ? v + off : nullptr); };
     auto m4 = [off](float* v) { return reinterpret_cast<float4*>(v + off); };
     const float* S = S_for_inline_q;
-#define I3D_STEP(MODE, QI) k_pcg_step<MODE, QI><<<step_blocks(n4), 256, 0, st>>>(n4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), c4(S), partials, state)
+    const int blocks = step_blocks(2 * n4);
+#define I3D_STEP(MODE, QI) k_pcg_step<MODE, QI><<<blocks, 256, 0, st>>>(n4, seg4, c4(p), c4(q), m4(x), m4(r), c4(b), c4(D2), c4(Minv), m4(z), c4(S), partials, state)
     switch (mode) {
         case STEP_INIT:   I3D_STEP(STEP_INIT, false); break;
         case STEP_NORMAL: if (S) I3D_STEP(STEP_NORMAL, true); else I3D_STEP(STEP_NORMAL, false); break;
@@ -810,17 +828,20 @@ int launch_pcg_step(hipStream_t st, int mode, size_t off, int n, const float* p,
         default:          if (S) I3D_STEP(STEP_RESET, true); else I3D_STEP(STEP_RESET, false); break;
     }
 #undef I3D_STEP
-    return (mode == STEP_XONLY || !partials) ? 0 : step_blocks(n4);      // number of [4]-partials written
+    return (mode == STEP_XONLY || !partials) ? 0 : blocks;      // number of [4]-partials written
 }
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state) { k_pcg_tail_x<<<1, 256, 0, st>>>(tail_off, 6 * K + 9, p, x, state); }
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
                        const float* D2, float* z, const double* partials, int nblk, PcgState* state, double* shared_zero, int nzero, int* host_flags, int seq) {
     k_pcg_tail_a<<<1, 1024, 0, st>>>(mode, tail_off, K, Minv_blocks, p, q, x, r, b, D2, z, partials, nblk, state, shared_zero, nzero, host_flags, seq);
 }
-int launch_pcg_direction(hipStream_t st, int n, const float* z, float* p, const float* S, float* u, const float* D2, double* d2_partials, const PcgState* state) {
-    if (n <= 0) return 0;
-    const int blocks = step_blocks(n >> 2);
-    k_pcg_direction<<<blocks, 256, 0, st>>>(n, z, p, S, u, D2, d2_partials, state);
+int launch_pcg_direction(hipStream_t st, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, double* d2_partials,
+                         const PcgState* state) {
+    if (sg.n <= 0 && ntail <= 0) return 0;
+    const int n4 = sg.n >> 2, seg4 = (int)((sg.off1 - sg.off0) >> 2);
+    const int blocks = step_blocks(2 * n4 > 0 ? 2 * n4 : 1);
+    const size_t o = sg.off0;
+    k_pcg_direction<<<blocks, 256, 0, st>>>(n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, d2_partials, state);
     return d2_partials ? blocks : 0;
 }
 void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
@@ -835,7 +856,7 @@ __global__ void __launch_bounds__(256) k_candidate(GridView g, RowView r, int K,
                                                    const double* __restrict__ xsh, double* xc_sdf, double* xc_alb, double* xc_sh,
                                                    double* norms2, const float* __restrict__ mask) {
     const int A = r.A, NS = 6 * K + 9, chunk = r.chunk;
-    const size_t tail = (size_t)r.world * 2 * (size_t)chunk;
+    const size_t tail = 2 * (size_t)chunk;
     double d2 = 0.0, x2 = 0.0;
     GRID_STRIDE(A + NS) {
         if (i < A) {
@@ -865,6 +886,18 @@ __global__ void k_accept(GridView g, RowView r, const double* __restrict__ xc_sd
     GRID_STRIDE(r.A) { const int s = r.alist[i]; const double a = xc_sdf[s], b = xc_alb[s]; g.x_sdf[s] = a; g.x_alb[s] = b; g.f_sdf[s] = (float)a; g.f_alb[s] = (float)b; }
 }
 void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb) { if (r.A > 0) k_accept<<<vblocks(r.A), 256, 0, st>>>(g, r, xc_sdf, xc_alb); }
+
+// halo exchange of the operator input (Comm::push_halo): gather the rim values a peer needs / scatter what the peers sent
+__global__ void k_halo_pack(int n, const int* __restrict__ idx, const float* __restrict__ vec, int chunk, float* __restrict__ buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int e = idx[i]; buf[2 * (size_t)i] = vec[e]; buf[2 * (size_t)i + 1] = vec[(size_t)chunk + e]; }
+}
+__global__ void k_halo_unpack(int n, const int* __restrict__ idx, const float* __restrict__ buf, int chunk, float* __restrict__ vec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int e = idx[i]; vec[e] = buf[2 * (size_t)i]; vec[(size_t)chunk + e] = buf[2 * (size_t)i + 1]; }
+}
+void launch_halo_pack(hipStream_t st, int n, const int* idx, const float* vec, int chunk, float* buf) { if (n > 0) k_halo_pack<<<(n + 255) / 256, 256, 0, st>>>(n, idx, vec, chunk, buf); }
+void launch_halo_unpack(hipStream_t st, int n, const int* idx, const float* buf, int chunk, float* vec) { if (n > 0) k_halo_unpack<<<(n + 255) / 256, 256, 0, st>>>(n, idx, buf, chunk, vec); }
 
 // compute list of a rank: owned entries + every entry whose Eg rows (forward stencil) or regulariser rows (ring) touch an owned entry
 __global__ void k_mark_compute(RowView r, int* __restrict__ flag) {

@@ -25,7 +25,8 @@
 
 namespace i3d {
 
-constexpr int TP_PLAN_LIST = 1024;              // capacity of a tile's halo list (plan kernel sorts this many keys)
+constexpr int TP_PLAN_LIST = 2048;              // capacity of a tile's halo list (the plan kernel sorts this many keys, two per thread)
+constexpr int TP_NONE = 0x7f7f7f7f;             // padding of halo_idx (a byte pattern, so that a memset clears the tiles a rank does not run)
 // the 12 stencil neighbours an entry READS (operator input): sdf slots 1..9 of the Eg row (shading_cost.cpp:90-129), then -x, -y, -z;
 // the 6 further entries whose Eg stencil contains it (the others are -x,-y,-z again): pulled from when they are in the same tile
 __device__ __host__ inline int tp_dir(int j) {
@@ -36,19 +37,20 @@ __device__ __host__ inline int tp_dir(int j) {
 
 // ---- plan (once per outer iteration) ----------------------------------------------------------------------------------------------
 // One workgroup per tile of T entries: hash set of the foreign entries its FORWARD stencils / rings reach -> compact -> bitonic sort
-// (deterministic slot numbers, coalescing-friendly staging) -> local slots by binary search.  lnbr[0..5]: the 12 read slots (uint16 pairs:
+// (deterministic slot numbers, coalescing-friendly staging) -> local slots by binary search.  Sharded: a rank plans the tiles it runs
+// (its own range + the foreign tiles that hold ghost entries); the others keep halo_cnt = 0 and padding.  lnbr[0..5]: the 12 read slots (uint16 pairs:
 // 0..T-1 own tile, T.. halo, zslot = not a list entry); lnbr[6..8]: the 6 extra reverse slots, own tile or zslot (foreign sources reach
-// the entry through THEIR tile's halo accumulators).  halo_idx is padded with INT_MAX (those keys sort behind every real pair).
-__global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, unsigned* __restrict__ lnbr, int* __restrict__ halo_idx, int* __restrict__ halo_cnt,
-                                                    int* __restrict__ overflow) {
+// the entry through THEIR tile's halo accumulators).  halo_idx is padded with TP_NONE (those keys sort behind every real pair).
+__global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, int tile_first, const int* __restrict__ tile_list, unsigned* __restrict__ lnbr,
+                                                    int* __restrict__ halo_idx, int* __restrict__ halo_cnt, int* __restrict__ overflow) {
     __shared__ int hkeys[4096];
     __shared__ int hlist[TP_PLAN_LIST];
     __shared__ int cnt;
-    const int tile = blockIdx.x, base = tile * T, a = base + threadIdx.x;
+    const int tile = tile_list ? tile_list[blockIdx.x] : tile_first + (int)blockIdx.x, base = tile * T, a = base + threadIdx.x;
     const bool in = (int)threadIdx.x < T && a < r.A;
     const int zslot = T + hmax;
     for (int i = threadIdx.x; i < 4096; i += 1024) hkeys[i] = -1;
-    hlist[threadIdx.x] = INT_MAX;
+    hlist[threadIdx.x] = TP_NONE; hlist[threadIdx.x + 1024] = TP_NONE;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     int la[18];
@@ -69,13 +71,16 @@ __global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, 
     __syncthreads();
     const int H = cnt;
     if (H > hmax) { if (threadIdx.x == 0) { *overflow = 1; halo_cnt[tile] = 0; } return; }      // the caller falls back to the untiled pass
-    for (int k = 2; k <= TP_PLAN_LIST; k <<= 1)                                     // bitonic sort, ascending (INT_MAX padding ends up last)
+    for (int k = 2; k <= TP_PLAN_LIST; k <<= 1)                                     // bitonic sort, ascending (the padding ends up last)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const int i = threadIdx.x, ixj = i ^ j;
-            if (ixj > i) { const int x = hlist[i], y = hlist[ixj]; const bool up = (i & k) == 0; if ((x > y) == up) { hlist[i] = y; hlist[ixj] = x; } }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int i = threadIdx.x + half * 1024, ixj = i ^ j;
+                if (ixj > i) { const int x = hlist[i], y = hlist[ixj]; const bool up = (i & k) == 0; if ((x > y) == up) { hlist[i] = y; hlist[ixj] = x; } }
+            }
             __syncthreads();
         }
-    if ((int)threadIdx.x < hmax) halo_idx[(size_t)tile * hmax + threadIdx.x] = hlist[threadIdx.x];
+    for (int i = threadIdx.x; i < hmax; i += 1024) halo_idx[(size_t)tile * hmax + i] = hlist[i];
     if (threadIdx.x == 0) halo_cnt[tile] = H;
     if (!in) return;
     unsigned short ls[18];
@@ -96,15 +101,15 @@ __global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, 
 // symmetric albedo-edge weights: the Ea row of the edge (a, neighbour d) is created once, by whichever voxel is visited first
 // (optimizer.cpp:259-279), so ea_w[d][a] is non-zero on one side only.  With w_sym[d][a] = ea_w[d][a] + ea_w[d^1][nb_d(a)] the Ea part of
 // J^T W J u is a pure PULL: q_alb[a] = rho sum_d w_sym[d][a] (u_a - u_nb(d)) — no contribution has to be pushed to a neighbour.
-__global__ void __launch_bounds__(256) k_eaw_sym(RowView r, float* __restrict__ eaw_sym) {
+__global__ void __launch_bounds__(256) k_eaw_sym(RowView r, const int* __restrict__ cflag /* sharded: 1 = rows built on this rank */, float* __restrict__ eaw_sym) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= r.A) return;
-    const bool act = (r.aflags[a] & F_ACTIVE) != 0;
+    const bool act = (r.aflags[a] & F_ACTIVE) != 0 && (!cflag || cflag[a]);
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
         float w = act ? r.ea_w[(size_t)d * r.Acap + a] : 0.0f;
         const int nb = r.anbr[(size_t)d * r.Acap + a];
-        if (nb >= 0 && (r.aflags[nb] & F_ACTIVE)) w += r.ea_w[(size_t)(d ^ 1) * r.Acap + nb];
+        if (nb >= 0 && (r.aflags[nb] & F_ACTIVE) && (!cflag || cflag[nb])) w += r.ea_w[(size_t)(d ^ 1) * r.Acap + nb];
         eaw_sym[(size_t)d * r.Acap + a] = w;
     }
 }
@@ -185,7 +190,7 @@ template <int T, int HMAX, int SLOTS>
 __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowView r, OptParams p, const float* __restrict__ u, const unsigned* __restrict__ lnbr,
                                                         const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx, const int* __restrict__ halo_cnt,
                                                         double* __restrict__ shared, float* __restrict__ qacc, float* __restrict__ qh, double* __restrict__ pq_partials,
-                                                        int reps, int tiles_per_block, const PcgState* __restrict__ state) {
+                                                        int reps, int tiles_per_block, int tile_first, const int* __restrict__ tile_list, int ntl, const PcgState* __restrict__ state) {
     if (state && state->done) return;
     constexpr int ZSLOT = T + HMAX, NSLOT = ZSLOT + 1;
     extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T]
@@ -212,15 +217,16 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
 #pragma unroll
     for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
     const float tw0 = (float)p.type_w[0], tw1 = (float)p.type_w[1], tw2 = (float)p.type_w[2], tw3 = (float)p.type_w[3];
-    const int ntiles = (A + T - 1) / T;
     const int tile0 = blockIdx.x * tiles_per_block;
 #define ui (lds + o_upose + 6 * K)
     const int i = threadIdx.x;
     double pq = 0.0;
 
-    for (int tile = tile0; tile < tile0 + tiles_per_block && tile < ntiles; ++tile) {
+    for (int tk = tile0; tk < tile0 + tiles_per_block && tk < ntl; ++tk) {
+        const int tile = tile_list ? tile_list[tk] : tile_first + tk;
         const int base = tile * T, a = base + i;
         const bool in = a < A;
+        const bool owned = a >= r.own0 && a < r.own1;          // p.q and the camera block count a row once: on the rank that owns its voxel
         const size_t ac = in ? (size_t)a : 0;
         const int H = halo_cnt[tile];
         // everything the entry needs besides its rows is requested first (older than the row loads: waiting for it does not drain them)
@@ -265,13 +271,13 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
             float tr = 0.0f;
             if (rf & 1) {
                 const float lap = ((((((-6.0f * us) + u_s[rg[0]]) + u_s[rg[1]]) + u_s[rg[2]]) + u_s[rg[3]]) + u_s[rg[4]]) + u_s[rg[5]];
-                tr = tw1 * lap; pq += (double)(tr * lap);
+                tr = tw1 * lap; if (owned) pq += (double)(tr * lap);
                 self_s += -6.0f * tr;
 #pragma unroll
                 for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles
             }
             tr_l[i] = tr;
-            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * us; pq += (double)(ts * us); self_s += ts; }
+            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * us; if (owned) pq += (double)(ts * us); self_s += ts; }
         }
 #define Cme (C_l + i)
         float pq_rows = 0.0f;
@@ -305,13 +311,15 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
 #pragma unroll
                 for (int c = 1; c < 10; ++c) Cme[(c - 1) * T] += J[c] * t;
                 Cme[9 * T] += J[11] * t; Cme[10 * T] += J[12] * t; Cme[11 * T] += J[13] * t;
-                if (!p.fix_poses) {
+                if (!p.fix_poses && owned) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q) pv[q] = J[P_POSE + q] * t;
                     fsel = f; pvalid = true;
                 }
+                if (owned) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) cam9[q] += J[P_INTR + q] * t;
+                    for (int q = 0; q < 9; ++q) cam9[q] += J[P_INTR + q] * t;
+                }
             }
             wave_accumulate_lds<6>(pvalid, fsel, pv, lds, reps, rs, o_wave_acc, 6);
         };
@@ -343,7 +351,7 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
                 }
             }
         }
-        pq += (double)pq_rows;
+        if (owned) pq += (double)pq_rows;
         // what the pull phase needs in addition (requested now, used behind the barrier): the 6 further reverse slots, the symmetric Ea weights
         unsigned lr[3];
 #pragma unroll
@@ -376,7 +384,7 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
             float ea = 0.0f, eq = 0.0f;
 #pragma unroll
             for (int d = 0; d < 6; ++d) { const float diff = ua - u_a[rg[d]]; const float t = eaw[d] * diff; ea += t; eq += (rg[d] == ZSLOT ? 1.0f : 0.5f) * t * diff; }
-            qa += tw3 * ea; pq += (double)(tw3 * eq);                 // an edge whose other voxel is a list entry is seen from both sides
+            qa += tw3 * ea; if (owned) pq += (double)(tw3 * eq);      // an edge whose other voxel is a list entry is seen from both sides (by their owners)
             qacc[a] = qs; qacc[chunk + a] = qa;
         }
 #pragma unroll
@@ -408,7 +416,7 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
 #undef Cme
 }
 
-// halo sums -> owners.  (ext_e, ext_pos): the (entry, halo slot) pairs of all tiles sorted by entry (INT_MAX padding last); the lane at the
+// halo sums -> owners.  (ext_e, ext_pos): the (entry, halo slot) pairs of all tiles sorted by entry (padding last); the lane at the
 // head of an entry's run adds the run (a handful of slots: the tiles around the entry) in its fixed order.
 __global__ void __launch_bounds__(256) k_halo_fold(int n, const int* __restrict__ ext_e, const int* __restrict__ ext_pos, const float* __restrict__ qh,
                                                    float* __restrict__ qacc, int chunk, const PcgState* __restrict__ state) {
@@ -416,7 +424,7 @@ __global__ void __launch_bounds__(256) k_halo_fold(int n, const int* __restrict_
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int e = ext_e[i];
-    if (e == INT_MAX || (i > 0 && ext_e[i - 1] == e)) return;
+    if (e >= TP_NONE || (i > 0 && ext_e[i - 1] == e)) return;
     float s = 0.0f, al = 0.0f;
     for (int j = i; j < n && ext_e[j] == e; ++j) { const float2 v = reinterpret_cast<const float2*>(qh)[ext_pos[j]]; s += v.x; al += v.y; }
     qacc[e] += s; qacc[chunk + e] += al;
@@ -426,7 +434,7 @@ __global__ void k_iota(int n, int* __restrict__ x) { const int i = blockIdx.x * 
 
 // tile geometry: T entries per tile / workgroup, HMAX halo slots.  512 (two workgroups per CU, 57 KB of LDS each) unless the environment says 1024.
 static int tp_T() { static int t = 0; if (!t) { const char* e = std::getenv("I3D_EGT_TILE"); t = (e && std::atoi(e) == 1024) ? 1024 : 512; } return t; }
-static int tp_H() { return tp_T() == 1024 ? 1024 : 768; }
+static int tp_H() { return tp_T() == 1024 ? 2048 : 1536; }
 int tile_plan_tiles(int A) { return (A + tp_T() - 1) / tp_T(); }
 int tile_plan_hmax() { return tp_H(); }
 size_t tile_plan_temp_bytes(int ntiles) {
@@ -435,50 +443,64 @@ size_t tile_plan_temp_bytes(int ntiles) {
     return bytes;
 }
 
-// returns hipSuccess or the first error; *overflow (device int, zeroed here) = 1 when a tile's halo does not fit
+// returns hipSuccess or the first error; *overflow (device int, zeroed here) = 1 when a tile's halo does not fit.
+// Plans the tiles [tile_first, tile_first + ntiles_own) and the n_ghost tiles of t.ghost_tiles; every other tile keeps an empty halo.
 hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, size_t temp_bytes) {
     const int ntiles = tile_plan_tiles(r.A);
     if (ntiles <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(t.overflow, 0, sizeof(int), st); if (e != hipSuccess) return e;
-    k_tile_plan<<<ntiles, 1024, 0, st>>>(r, tp_T(), tp_H(), t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
     const int n = ntiles * tp_H();
+    const bool all = t.tile_first == 0 && t.ntiles_own >= ntiles;
+    if (!all) { e = hipMemsetAsync(t.halo_idx, 0x7f, sizeof(int) * (size_t)n, st); if (e != hipSuccess) return e;
+                e = hipMemsetAsync(t.halo_cnt, 0, sizeof(int) * (size_t)ntiles, st); if (e != hipSuccess) return e; }
+    if (t.ntiles_own > 0) k_tile_plan<<<t.ntiles_own, 1024, 0, st>>>(r, tp_T(), tp_H(), t.tile_first, nullptr, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
+    if (t.n_ghost > 0) k_tile_plan<<<t.n_ghost, 1024, 0, st>>>(r, tp_T(), tp_H(), 0, t.ghost_tiles, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
     k_iota<<<(n + 255) / 256, 256, 0, st>>>(n, t.iota);
     return rocprim::radix_sort_pairs(temp, temp_bytes, (const int*)t.halo_idx, t.ext_e, (const int*)t.iota, t.ext_pos, (size_t)n, 0, 32, st);
 }
 
 // after the build kernel has written the Ea weights of this outer iteration
-void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t) { if (r.A > 0) k_eaw_sym<<<(r.A + 255) / 256, 256, 0, st>>>(r, t.eaw_sym); }
+void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t, const int* cflag) { if (r.A > 0) k_eaw_sym<<<(r.A + 255) / 256, 256, 0, st>>>(r, cflag, t.eaw_sym); }
 
 template <int T, int HMAX>
 static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state, int num_cu) {
-    const int ntiles = (r.A + T - 1) / T;
     const int nshared = 6 * p.K + 9, rs = (6 * p.K) | 1;
     auto lds_bytes = [&](int reps) { const int nacc = reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
                                      return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T) * sizeof(float); };
-    const size_t budget = (T == 512 ? 78 : 158) * 1024;
+    const size_t budget = (T == 512 ? 79 : 158) * 1024;
     int reps = 4;                                            // replicas only serve the rare > 3-keyframe fallback of wave_accumulate
     while (reps > 1 && lds_bytes(reps) > budget) reps >>= 1;
     const size_t lds = lds_bytes(reps);
     int per_cu = (T == 512 && lds <= budget) ? 2 : 1;
     { static int knob = -1; if (knob < 0) { const char* e = std::getenv("I3D_EGT_WG_PER_CU"); knob = e ? std::atoi(e) : 0; } if (knob > 0) per_cu = knob; }
-    const int blocks = ntiles < per_cu * num_cu ? ntiles : per_cu * num_cu;
-    const int tiles_per_block = (ntiles + blocks - 1) / blocks;
+    // tiles in units of T: the plan counts tiles of tp_T() == T
+    int written = 0;
+    auto run = [&](int ntl, int tile_first, const int* tile_list, bool unrolled) {
+        if (ntl <= 0) return;
+        const int blocks = ntl < per_cu * num_cu ? ntl : per_cu * num_cu;
+        const int tiles_per_block = (ntl + blocks - 1) / blocks;
+        double* pqp = pq_partials ? pq_partials + written : nullptr;
 #define I3D_EGT(SL) do { (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        k_eg_tile<T, HMAX, SL><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, state); } while (0)
-    if (r.slots == 5) I3D_EGT(5);                             // the shipped num_observations (data/intrinsic3d.yml)
-    else I3D_EGT(0);
+        k_eg_tile<T, HMAX, SL><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pqp, reps, tiles_per_block, tile_first, tile_list, ntl, state); } while (0)
+        if (unrolled && r.slots == 5) I3D_EGT(5);             // the shipped num_observations (data/intrinsic3d.yml)
+        else I3D_EGT(0);
 #undef I3D_EGT
-    const int n = ntiles * HMAX;
+        written += blocks;
+    };
+    run(t.ntiles_own, t.tile_first, nullptr, true);
+    run(t.n_ghost, 0, t.ghost_tiles, false);                  // foreign tiles: a few ghost rows each, run-time row loop (no rows are fetched for the other lanes)
+    const int n = tile_plan_tiles(r.A) * HMAX;
     k_halo_fold<<<(n + 255) / 256, 256, 0, st>>>(n, t.ext_e, t.ext_pos, t.qh, qacc, r.chunk, state);
-    return blocks;                                           // number of p.q partials written
+    return written;                                          // number of p.q partials written
 }
 
 int launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state) {
     if (r.A <= 0) return 0;
     static int num_cu = 0;
     if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    if (tp_T() == 1024) return launch_eg_tile_t<1024, 1024>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
-    return launch_eg_tile_t<512, 768>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
+    if (tp_T() == 1024) return launch_eg_tile_t<1024, 2048>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
+    return launch_eg_tile_t<512, 1536>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
 }
+int tile_plan_T() { return tp_T(); }
 
 }  // namespace i3d

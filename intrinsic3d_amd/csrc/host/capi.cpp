@@ -64,6 +64,33 @@ int i3d_shard_plan(int32_t A, int32_t world, int32_t rank, const int32_t* anbr, 
     return I3D_OK;
 }
 int32_t i3d_shard_vec_index(int32_t a, int32_t chunk, int32_t albedo) { return albedo ? vec_alb(a, chunk) : vec_sdf(a, chunk); }
+// need[e] bit k: rank k's rows read the unknowns of entry e and it does not own e — the host statement of k_need_mask (shard_kernels.hip)
+int i3d_shard_need(int32_t A, int32_t world, const int32_t* anbr, const uint8_t* active, uint64_t* need) {
+    if (A < 0 || world < 1 || world > 64 || !anbr || !active || !need) return I3D_ERR_INVALID_ARGUMENT;
+    int chunk, o0, o1; shard_range(A, world, 0, chunk, o0, o1);
+    const int slice = chunk / world;
+    for (int a = 0; a < A; ++a) need[a] = 0;
+    for (int a = 0; a < A; ++a) {
+        if (!active[a]) continue;
+        int col[12]; bool interior;
+        const unsigned long long ranks = shard_entry_ranks(a, slice, anbr, (size_t)A, col, interior);
+        if (interior) continue;
+        for (int k = 0; k < world; ++k) if ((ranks >> k) & 1ull) {
+            if (a / slice != k) need[a] |= 1ull << k;
+            for (int i = 0; i < 12; ++i) if (col[i] >= 0 && col[i] / slice != k) need[col[i]] |= 1ull << k;
+        }
+    }
+    return I3D_OK;
+}
+int i3d_comm_stats(i3d_context* c, int64_t* halo_calls, int64_t* halo_bytes_sent, int64_t* reduce_calls, int64_t* reduce_bytes, int32_t* halo_entries_send, int32_t* halo_entries_recv,
+                   int32_t* ghost_tiles, int32_t* compute_list) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    if (halo_calls) *halo_calls = c->comm ? c->comm->halo_calls : 0; if (halo_bytes_sent) *halo_bytes_sent = c->comm ? c->comm->halo_bytes_sent : 0;
+    if (reduce_calls) *reduce_calls = c->comm ? c->comm->reduce_calls : 0; if (reduce_bytes) *reduce_bytes = c->comm ? c->comm->reduce_bytes : 0;
+    if (halo_entries_send) *halo_entries_send = c->halo.n_send; if (halo_entries_recv) *halo_entries_recv = c->halo.n_recv;
+    if (ghost_tiles) *ghost_tiles = c->n_ghost_tiles; if (compute_list) *compute_list = c->nC;
+    return I3D_OK;
+}
 
 int i3d_debug_assemble(i3d_context* c, const i3d_optimizer_config* cfg, int32_t iteration, int32_t* slots_out) {
     if (!c || !cfg) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_debug_assemble: null argument");

@@ -13,17 +13,27 @@ struct RcclComm : Comm {
     ncclComm_t comm = nullptr;
     ~RcclComm() override { if (comm) ncclCommDestroy(comm); }
     int allreduce_sum(double* dev, size_t n, hipStream_t st) override {
+        ++reduce_calls; reduce_bytes += 8ll * (long long)n;
         return ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm, st) == ncclSuccess ? 0 : 1;
     }
     int allgather(float* dev, size_t count, hipStream_t st) override {
         return ncclAllGather(dev + (size_t)rank * count, dev, count, ncclFloat, comm, st) == ncclSuccess ? 0 : 1;
     }
-    int allreduce_allgather(double* red, size_t n, float* vec, size_t count, hipStream_t st) override {      // one grouped launch
+    // neighbours only: one grouped launch of sends / receives of the packed rim values (a few tens of KB per pair)
+    int push_halo(float* vec, const HaloPlan& h, hipStream_t st) override {
+        ++halo_calls; halo_bytes_sent += 8ll * h.n_send;
+        if (h.n_send == 0 && h.n_recv == 0) return 0;
+        launch_halo_pack(st, h.n_send, h.d_send_idx, vec, h.chunk, h.d_send_buf);
         if (ncclGroupStart() != ncclSuccess) return 1;
-        const ncclResult_t a = ncclAllReduce(red, red, n, ncclDouble, ncclSum, comm, st);
-        const ncclResult_t b = ncclAllGather(vec + (size_t)rank * count, vec, count, ncclFloat, comm, st);
-        const ncclResult_t e = ncclGroupEnd();
-        return (a == ncclSuccess && b == ncclSuccess && e == ncclSuccess) ? 0 : 1;
+        bool ok = true;
+        for (int k = 0; k < world; ++k) {
+            if (k == rank) continue;
+            if (h.send_cnt[k] > 0) ok &= ncclSend(h.d_send_buf + 2 * (size_t)h.send_off[k], 2 * (size_t)h.send_cnt[k], ncclFloat, k, comm, st) == ncclSuccess;
+            if (h.recv_cnt[k] > 0) ok &= ncclRecv(h.d_recv_buf + 2 * (size_t)h.recv_off[k], 2 * (size_t)h.recv_cnt[k], ncclFloat, k, comm, st) == ncclSuccess;
+        }
+        if (ncclGroupEnd() != ncclSuccess || !ok) return 1;
+        launch_halo_unpack(st, h.n_recv, h.d_recv_idx, h.d_recv_buf, h.chunk, vec);
+        return 0;
     }
 };
 
@@ -49,6 +59,7 @@ struct SimShared {
     std::mutex m; std::condition_variable cv;
     int arrived = 0; long generation = 0;
     std::vector<void*> ptr; std::vector<double> sum;
+    std::vector<const HaloPlan*> halo;
     void barrier() {
         std::unique_lock<std::mutex> lk(m);
         const long gen = generation;
@@ -56,12 +67,13 @@ struct SimShared {
         else cv.wait(lk, [&] { return generation != gen; });
     }
 };
-SimShared* sim_create(int world) { auto* s = new SimShared; s->world = world; s->ptr.assign(world, nullptr); return s; }
+SimShared* sim_create(int world) { auto* s = new SimShared; s->world = world; s->ptr.assign(world, nullptr); s->halo.assign(world, nullptr); return s; }
 void sim_destroy(SimShared* s) { delete s; }
 
 struct SimComm : Comm {
     SimShared* sh = nullptr;
     int allreduce_sum(double* dev, size_t n, hipStream_t st) override {
+        ++reduce_calls; reduce_bytes += 8ll * (long long)n;
         if (hipStreamSynchronize(st) != hipSuccess) return 1;
         std::vector<double> mine(n);
         if (hipMemcpy(mine.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return 1;
@@ -84,6 +96,24 @@ struct SimComm : Comm {
             if (hipMemcpy(dev + (size_t)k * count, src, count * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) return 1;
         }
         sh->barrier();
+        return 0;
+    }
+    // same device, one process: every rank packs, then copies what the peers packed for it
+    int push_halo(float* vec, const HaloPlan& h, hipStream_t st) override {
+        ++halo_calls; halo_bytes_sent += 8ll * h.n_send;
+        launch_halo_pack(st, h.n_send, h.d_send_idx, vec, h.chunk, h.d_send_buf);
+        if (hipStreamSynchronize(st) != hipSuccess) return 1;
+        sh->halo[rank] = &h;
+        sh->barrier();
+        for (int k = 0; k < world; ++k) {
+            if (k == rank || h.recv_cnt[k] == 0) continue;
+            const HaloPlan* pk = sh->halo[k];
+            if (pk->send_cnt[rank] != h.recv_cnt[k]) return 1;                  // the two ends of a pair disagree about their list
+            if (hipMemcpy(h.d_recv_buf + 2 * (size_t)h.recv_off[k], pk->d_send_buf + 2 * (size_t)pk->send_off[rank], sizeof(float) * 2 * (size_t)h.recv_cnt[k],
+                          hipMemcpyDeviceToDevice) != hipSuccess) return 1;
+        }
+        sh->barrier();
+        launch_halo_unpack(st, h.n_recv, h.d_recv_idx, h.d_recv_buf, h.chunk, vec);
         return 0;
     }
 };

@@ -6,22 +6,37 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <vector>
 
 namespace i3d {
+
+// What a rank exchanges with its neighbours once per PCG pass: the operator input on the rim its rows read (common.hpp, sharding).
+// Built once per outer iteration, identically on both ends of every pair (every rank derives it from the replicated work list):
+// send_idx[send_off[k] .. +send_cnt[k]) = work-list entries this rank OWNS and rank k needs, ascending; recv_idx likewise for what it needs of k.
+struct HaloPlan {
+    int world = 1, chunk = 0;
+    std::vector<int> send_cnt, send_off, recv_cnt, recv_off;      // per peer (entries; every entry carries its sdf and its albedo value)
+    const int* d_send_idx = nullptr; const int* d_recv_idx = nullptr;
+    float* d_send_buf = nullptr; float* d_recv_buf = nullptr;     // 2 floats per entry
+    int n_send = 0, n_recv = 0;
+};
 
 struct Comm {
     int rank = 0, world = 1;
     bool force = false;        // run the sharded code path (and its collectives) even with one rank: exercises the real RCCL calls on a 1-GPU box
+    long long halo_bytes_sent = 0, halo_calls = 0, reduce_calls = 0, reduce_bytes = 0;      // traffic log (i3d_comm_stats)
     virtual ~Comm() {}
     // in-place sum over ranks of n doubles in device memory
     virtual int allreduce_sum(double* dev, size_t n, hipStream_t st) = 0;
-    // in-place all-gather: every rank owns count floats at dev + rank*count; afterwards all world*count floats are valid everywhere
+    // in-place all-gather of one part of a solver vector: every rank owns count floats at dev + rank*count
     virtual int allgather(float* dev, size_t count, hipStream_t st) = 0;
-    // both of the above as one exchange (the PCG iteration boundary: 4 scalars + the preconditioned residual slices)
-    virtual int allreduce_allgather(double* red, size_t n, float* vec, size_t count, hipStream_t st) {
-        const int rc = allreduce_sum(red, n, st); return rc ? rc : allgather(vec, count, st);
-    }
+    // vec[e], vec[chunk + e] of the entries in the send lists -> the same positions of the peers' copies of vec (their recv lists)
+    virtual int push_halo(float* vec, const HaloPlan& h, hipStream_t st) = 0;
 };
+
+// pack / unpack kernels of the halo exchange (operator.hip)
+void launch_halo_pack(hipStream_t st, int n, const int* idx, const float* vec, int chunk, float* buf);
+void launch_halo_unpack(hipStream_t st, int n, const int* idx, const float* buf, int chunk, float* vec);
 
 Comm* make_rccl_comm(int rank, int world, const void* unique_id, size_t id_bytes, hipStream_t st, char* err, size_t errlen);
 int   rccl_unique_id(void* out, size_t* bytes);

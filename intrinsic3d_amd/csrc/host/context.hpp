@@ -76,13 +76,22 @@ struct i3d_context {
     // sharding: owned range / compute list of this rank (see common.hpp)
     i3d::Comm* comm = nullptr; int chunk = 1, own0 = 0, own1 = 0, nC = 0;
     i3d::DevBuf<int> clist, cflag, cscan;
+    // halo exchange plan of the current work list (shard_kernels.hip) and the foreign tiles with ghost entries
+    i3d::HaloPlan halo; i3d::DevBuf<unsigned long long> need_mask, halo_items, halo_sorted; i3d::DevBuf<int> halo_count, halo_send_idx, halo_recv_idx, tile_flag, ghost_tiles;
+    i3d::DevBuf<float> halo_send_buf, halo_recv_buf; i3d::DevBuf<unsigned char> halo_temp; int n_ghost_tiles = 0, slice = 0;
     i3d::DevBuf<int> obs_frame, anbr; i3d::DevBuf<float> obs_w, ea_w, C, treg;
     i3d::DevBuf<float4> rows;
     i3d::DevBuf<uint8_t> aflags, nrows, regflags, ea_free;
     // tiled operator pass (tile_pass.hip): plan of the current work list
     i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw;
     i3d::DevBuf<unsigned char> tp_temp; bool tile_ok = false;
-    i3d::TilePlan tile_plan() const { return i3d::TilePlan{tp_lnbr.p, tp_eaw.p, tp_halo_idx.p, tp_halo_cnt.p, tp_iota.p, tp_ext_e.p, tp_ext_pos.p, tp_qh.p, tp_overflow.p}; }
+    i3d::TilePlan tile_plan() const {
+        const int T = i3d::tile_plan_T();
+        const bool sh = comm && (comm->world > 1 || comm->force);
+        const int t0 = sh ? own0 / T : 0, t1 = sh ? (own1 + T - 1) / T : i3d::tile_plan_tiles(A);
+        return i3d::TilePlan{tp_lnbr.p, tp_eaw.p, tp_halo_idx.p, tp_halo_cnt.p, tp_iota.p, tp_ext_e.p, tp_ext_pos.p, tp_qh.p, tp_overflow.p, t0, t1 > t0 ? t1 - t0 : 0,
+                             ghost_tiles.p, sh ? n_ghost_tiles : 0};
+    }
 
     // ---- solver vectors (length NP = 2N + 6K + 9) ----
     i3d::DevBuf<float> v_mask, v_c, v_S, v_D2, v_Minv, v_b, v_x, v_r, v_p, v_z, v_q, v_u, v_acc, v_tmp, v_qacc;

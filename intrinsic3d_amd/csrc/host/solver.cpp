@@ -34,6 +34,8 @@ static double varying_lambda(int it, int n, double l0, double l1) {        // co
     return l0 + ((l1 - l0) / (double)(n - 1)) * (double)it;
 }
 
+constexpr int HALO_CAP = 1 << 20;      // (direction, peer, entry) items of a rank's halo plan
+
 static int alloc_rows(i3d_context* c, int slots) {
     const size_t Acap = (size_t)c->N;
     c->Acap = (int)Acap; c->slots = slots;
@@ -46,12 +48,20 @@ static int alloc_rows(i3d_context* c, int slots) {
       CTX_HIP(c, c->tp_lnbr.alloc(Acap * 9)); CTX_HIP(c, c->tp_eaw.alloc(Acap * 6)); CTX_HIP(c, c->tp_halo_idx.alloc(nh)); CTX_HIP(c, c->tp_halo_cnt.alloc(nt)); CTX_HIP(c, c->tp_iota.alloc(nh));
       CTX_HIP(c, c->tp_ext_e.alloc(nh)); CTX_HIP(c, c->tp_ext_pos.alloc(nh)); CTX_HIP(c, c->tp_qh.alloc(2 * nh)); CTX_HIP(c, c->tp_overflow.alloc(1));
       CTX_HIP(c, c->tp_temp.alloc(tile_plan_temp_bytes((int)nt))); }
-    const size_t NP = 2 * (size_t)c->N + 2 * 64 + 6 * (size_t)c->K + 9;          // rank-major layout pads every rank's slice to the same chunk
+    const int world_a = c->comm ? c->comm->world : 1;
+    const size_t NP = 2 * ((size_t)c->N + (size_t)SHARD_ALIGN * (world_a + 1)) + 6 * (size_t)c->K + 9;      // chunk = world * slice >= A, slice a multiple of SHARD_ALIGN
     for (DevBuf<float>* v : {&c->v_mask, &c->v_c, &c->v_S, &c->v_D2, &c->v_Minv, &c->v_b, &c->v_x, &c->v_r, &c->v_p, &c->v_z, &c->v_q, &c->v_u, &c->v_acc, &c->v_tmp, &c->v_qacc})
         { const bool fresh = v->n < NP || !v->p; CTX_HIP(c, v->alloc(NP)); if (fresh) CTX_HIP(c, hipMemset(v->p, 0, sizeof(float) * v->n)); }   // padding entries stay finite
     CTX_HIP(c, c->Minv_blocks.alloc((size_t)36 * c->K + 16 + 25));
     CTX_HIP(c, c->d_shared.alloc((size_t)6 * c->K + 9 + 1)); CTX_HIP(c, c->d_blocks.alloc((size_t)21 * c->K + 25));      // +1: p.q partial rides with the camera block
     CTX_HIP(c, c->clist.alloc(Acap)); CTX_HIP(c, c->cflag.alloc(Acap)); CTX_HIP(c, c->cscan.alloc(Acap));
+    if (c->comm) {      // sharding plan storage (small: the rim of a rank is a few percent of what it owns)
+        const size_t cap = HALO_CAP;
+        CTX_HIP(c, c->need_mask.alloc(Acap)); CTX_HIP(c, c->halo_items.alloc(cap)); CTX_HIP(c, c->halo_sorted.alloc(cap)); CTX_HIP(c, c->halo_count.alloc(1));
+        CTX_HIP(c, c->halo_send_idx.alloc(cap)); CTX_HIP(c, c->halo_recv_idx.alloc(cap)); CTX_HIP(c, c->halo_send_buf.alloc(2 * cap)); CTX_HIP(c, c->halo_recv_buf.alloc(2 * cap));
+        CTX_HIP(c, c->halo_temp.alloc(halo_sort_temp_bytes((int)cap)));
+        const size_t nt = (size_t)tile_plan_tiles((int)Acap) + 1; CTX_HIP(c, c->tile_flag.alloc(nt)); CTX_HIP(c, c->ghost_tiles.alloc(nt));
+    }
     CTX_HIP(c, c->d_scal.alloc(32)); CTX_HIP(c, c->d_xshared.alloc((size_t)6 * c->K + 9)); CTX_HIP(c, c->d_xcshared.alloc((size_t)6 * c->K + 9));
     CTX_HIP(c, c->d_pcg.alloc(1));
     CTX_HIP(c, c->d_partials.alloc((Acap / 256 + 2048) * 9));       // per-workgroup partial sums of the fp64 reductions
@@ -63,10 +73,13 @@ static int alloc_rows(i3d_context* c, int slots) {
     return ensure_pinned(c, 64 + (size_t)27 * c->K + 64);
 }
 
-struct Layout { int A, K, NS, chunk, world, rank; size_t slice_off, slice_n, tail_off, NP; };
+// vector layout (common.hpp): [sdf chunk | albedo chunk | camera tail]; a rank's slice = the same segment of both parts
+struct Layout { int A, K, NS, chunk, world, rank, slice; Seg2 own; size_t tail_off, NP; };
 static Layout layout_of(const i3d_context* c) {
     Layout L; L.A = c->A; L.K = c->K; L.NS = 6 * c->K + 9; L.chunk = c->chunk; L.world = c->comm ? c->comm->world : 1; L.rank = c->comm ? c->comm->rank : 0;
-    L.slice_n = 2 * (size_t)L.chunk; L.slice_off = (size_t)L.rank * L.slice_n; L.tail_off = (size_t)L.world * L.slice_n; L.NP = L.tail_off + L.NS;
+    L.slice = L.chunk / L.world;
+    L.own = Seg2{(size_t)L.rank * L.slice, (size_t)L.chunk + (size_t)L.rank * L.slice, L.slice};
+    L.tail_off = 2 * (size_t)L.chunk; L.NP = L.tail_off + L.NS;
     return L;
 }
 static bool sharded(const i3d_context* c) { return c->comm && (c->comm->world > 1 || c->comm->force); }
@@ -74,13 +87,70 @@ static int allreduce(i3d_context* c, double* dev, size_t n) {
     if (!sharded(c)) return I3D_OK;
     return c->comm->allreduce_sum(dev, n, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-reduce failed") : I3D_OK;
 }
-static int allreduce_allgather(i3d_context* c, double* red, size_t n, float* vec) {      // one fused exchange per PCG iteration
+static int allgather(i3d_context* c, float* vec) {       // every rank contributes its two segments of a solver vector
     if (!sharded(c)) return I3D_OK;
-    return c->comm->allreduce_allgather(red, n, vec, 2 * (size_t)c->chunk, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-reduce + all-gather failed") : I3D_OK;
+    const size_t slice = (size_t)(c->chunk / c->comm->world);
+    if (c->comm->allgather(vec, slice, c->stream) || c->comm->allgather(vec + c->chunk, slice, c->stream)) return ctx_fail(c, I3D_ERR_COMM, "all-gather failed");
+    return I3D_OK;
 }
-static int allgather(i3d_context* c, float* vec) {       // every rank contributes its slice of a solver vector
+static int push_halo(i3d_context* c, float* vec) {       // the rim of the operator input (common.hpp: sharding)
     if (!sharded(c)) return I3D_OK;
-    return c->comm->allgather(vec, 2 * (size_t)c->chunk, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-gather failed") : I3D_OK;
+    return c->comm->push_halo(vec, c->halo, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "halo exchange failed") : I3D_OK;
+}
+
+// the sharding plan of this outer iteration: compute list, halo lists, ghost tiles — derived from the replicated work list, no communication
+static int shard_plan(i3d_context* c) {
+    hipStream_t s = c->stream;
+    const int world = c->comm->world, rank = c->comm->rank;
+    if (world > 64) return ctx_fail(c, I3D_ERR_CAPACITY, "sharding: more than 64 ranks");
+    shard_range(c->A, world, rank, c->chunk, c->own0, c->own1); c->nC = 0; c->slice = c->chunk / world;
+    RowView r0 = c->row_view();
+    TimedScope t(c, I3D_K_CLASSIFY);
+    launch_mark_compute(s, r0, c->cflag.p);
+    CTX_HIP(c, rocprim::exclusive_scan(c->scan_tmp.p, c->scan_tmp_bytes, c->cflag.p, c->cscan.p, 0, (size_t)c->A, rocprim::plus<int>(), s));
+    launch_compact_list(s, c->A, c->cflag.p, c->cscan.p, c->clist.p);
+    const int T = tile_plan_T(), ntiles = tile_plan_tiles(c->A);
+    CTX_HIP(c, hipMemsetAsync(c->need_mask.p, 0, sizeof(unsigned long long) * (size_t)c->A, s));
+    CTX_HIP(c, hipMemsetAsync(c->halo_count.p, 0, sizeof(int), s));
+    CTX_HIP(c, hipMemsetAsync(c->tile_flag.p, 0, sizeof(int) * (size_t)(ntiles + 1), s));
+    launch_need_mask(s, r0, c->slice, c->need_mask.p);
+    launch_halo_items(s, c->A, c->slice, rank, c->need_mask.p, c->halo_items.p, c->halo_count.p, HALO_CAP);
+    launch_tile_flags(s, c->A, T, c->cflag.p, c->tile_flag.p);
+    int tl[2] = {0, 0}, nitems = 0;
+    if (c->A > 0) { CTX_HIP(c, hipMemcpyAsync(&tl[0], c->cscan.p + (c->A - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+                    CTX_HIP(c, hipMemcpyAsync(&tl[1], c->cflag.p + (c->A - 1), sizeof(int), hipMemcpyDeviceToHost, s)); }
+    CTX_HIP(c, hipMemcpyAsync(&nitems, c->halo_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    std::vector<int> tf((size_t)ntiles + 1, 0);
+    CTX_HIP(c, hipMemcpyAsync(tf.data(), c->tile_flag.p, sizeof(int) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
+    CTX_HIP(c, hipStreamSynchronize(s));
+    c->nC = tl[0] + tl[1];
+    if (nitems > HALO_CAP) return ctx_fail(c, I3D_ERR_CAPACITY, "sharding: the halo plan does not fit its buffers");
+    // ghost tiles: foreign tiles that hold compute-list entries
+    std::vector<int> ghosts; const int t0 = c->own0 / T, t1 = (c->own1 + T - 1) / T;
+    for (int i = 0; i < ntiles; ++i) if (tf[i] && (i < t0 || i >= t1)) ghosts.push_back(i);
+    c->n_ghost_tiles = (int)ghosts.size();
+    if (!ghosts.empty()) CTX_HIP(c, hipMemcpyAsync(c->ghost_tiles.p, ghosts.data(), sizeof(int) * ghosts.size(), hipMemcpyHostToDevice, s));
+    // halo lists: items sorted by (direction, peer, entry) -> per-peer runs
+    HaloPlan& h = c->halo; h.world = world; h.chunk = c->chunk;
+    h.send_cnt.assign(world, 0); h.send_off.assign(world, 0); h.recv_cnt.assign(world, 0); h.recv_off.assign(world, 0); h.n_send = h.n_recv = 0;
+    std::vector<unsigned long long> items((size_t)nitems);
+    if (nitems > 0) {
+        CTX_HIP(c, launch_halo_sort(s, c->halo_temp.p, c->halo_temp.n, c->halo_items.p, c->halo_sorted.p, nitems));
+        CTX_HIP(c, hipMemcpyAsync(items.data(), c->halo_sorted.p, sizeof(unsigned long long) * (size_t)nitems, hipMemcpyDeviceToHost, s));
+        CTX_HIP(c, hipStreamSynchronize(s));
+    }
+    std::vector<int> sidx, ridx;
+    for (unsigned long long it : items) {
+        const int dir = (int)(it >> 40) & 1, peer = (int)((it >> 32) & 0xFF), e = (int)(it & 0xFFFFFFFFull);
+        if (dir == 0) { if (h.send_cnt[peer]++ == 0) h.send_off[peer] = (int)sidx.size(); sidx.push_back(e); }
+        else          { if (h.recv_cnt[peer]++ == 0) h.recv_off[peer] = (int)ridx.size(); ridx.push_back(e); }
+    }
+    h.n_send = (int)sidx.size(); h.n_recv = (int)ridx.size();
+    if (h.n_send) CTX_HIP(c, hipMemcpyAsync(c->halo_send_idx.p, sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice, s));
+    if (h.n_recv) CTX_HIP(c, hipMemcpyAsync(c->halo_recv_idx.p, ridx.data(), sizeof(int) * ridx.size(), hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipStreamSynchronize(s));                  // (the host vectors above go out of scope)
+    h.d_send_idx = c->halo_send_idx.p; h.d_recv_idx = c->halo_recv_idx.p; h.d_send_buf = c->halo_send_buf.p; h.d_recv_buf = c->halo_recv_buf.p;
+    return I3D_OK;
 }
 
 // read `n` doubles from device memory (after everything queued on the stream)
@@ -114,34 +184,27 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     c->A = tail[0] + tail[1];
     { TimedScope t(c, I3D_K_CLASSIFY); launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
     c->tile_ok = false;
-    if (!sharded(c)) { shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A;
-                       RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
-                       CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n)); }
-    else {      // owned range + compute list (every rank derives them from the replicated work list: no communication)
-        const int world = c->comm->world, rank = c->comm->rank;
-        shard_range(c->A, world, rank, c->chunk, c->own0, c->own1); c->nC = 0;
-        RowView r0 = c->row_view();
-        TimedScope t(c, I3D_K_CLASSIFY);
-        launch_mark_compute(s, r0, c->cflag.p);
-        CTX_HIP(c, rocprim::exclusive_scan(c->scan_tmp.p, c->scan_tmp_bytes, c->cflag.p, c->cscan.p, 0, (size_t)c->A, rocprim::plus<int>(), s));
-        launch_compact_list(s, c->A, c->cflag.p, c->cscan.p, c->clist.p);
-        int tl[2] = {0, 0};
-        if (c->A > 0) { CTX_HIP(c, hipMemcpyAsync(&tl[0], c->cscan.p + (c->A - 1), sizeof(int), hipMemcpyDeviceToHost, s));
-                        CTX_HIP(c, hipMemcpyAsync(&tl[1], c->cflag.p + (c->A - 1), sizeof(int), hipMemcpyDeviceToHost, s)); }
-        CTX_HIP(c, hipStreamSynchronize(s));
-        c->nC = tl[0] + tl[1];
+    if (!sharded(c)) { shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; c->slice = c->chunk; }
+    else {      // owned range + compute list + halo lists + ghost tiles (every rank derives them from the replicated work list: no communication)
+        int rc = shard_plan(c); if (rc) return rc;
+        // rows are only built on the compute list: everything else on the tiles this rank runs must be inert
+        CTX_HIP(c, hipMemsetAsync(c->nrows.p, 0, (size_t)c->A, s)); CTX_HIP(c, hipMemsetAsync(c->regflags.p, 0, (size_t)c->A, s));
     }
+    { RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
+      CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n)); }
     RowView r = c->row_view();
     { TimedScope t(c, I3D_K_OBSERVE); launch_observe(s, g, r, p, c->d_frames.p); }
     { TimedScope t(c, I3D_K_BUILD); launch_build(s, g, r, p, c->d_frames.p, true, nullptr, c->d_partials.p); }
-    if (!sharded(c)) { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan()); }
+    { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan(), sharded(c) ? c->cflag.p : nullptr); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
     { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, c->d_scal.p, c->d_partials.p); }
     { int rc = allreduce(c, c->d_scal.p, 9); if (rc) return rc; }
     int tp_over = 1;
-    if (!sharded(c)) CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
     double sums[9]; { int rc = read_doubles(c, c->d_scal.p, 9, sums); if (rc) return rc; }
-    c->tile_ok = !sharded(c) && tp_over == 0;       // a halo that does not fit (pathological grids) -> the untiled operator pass
+    c->tile_ok = tp_over == 0;       // a halo that does not fit (pathological grids) -> the untiled operator pass (single rank only)
+    if (!sharded(c) && !c->tile_ok) std::fprintf(stderr, "[i3d] operator pass: a tile's halo does not fit, using the untiled pass (k_eg_jtjp + k_gather)\n");
+    if (sharded(c) && !c->tile_ok) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: a tile of the operator pass reaches more foreign entries than its halo holds");
     { const char* e = std::getenv("I3D_NO_TILE"); if (e && e[0] == '1') c->tile_ok = false; }      // tests of the fallback (k_eg_jtjp + k_gather)
     sums[5] = sums[1]; sums[6] = sums[2];
     const double lambda[4] = {cfg.lambda_g, varying_lambda(iteration, cfg.iterations, cfg.lambda_r0, cfg.lambda_r1),
@@ -161,7 +224,7 @@ static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const flo
     PassBuffers b{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
     CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
     if (mode == PASS_COLNORM) CTX_HIP(c, hipMemsetAsync(c->d_blocks.p, 0, sizeof(double) * (21 * (size_t)c->K + 25), s));
-    if (mode == PASS_JTJP && c->tile_ok) {        // the PCG's tiled operator pass (raw accumulators straight into `out`)
+    if (mode == PASS_JTJP && c->tile_ok && !sharded(c)) {        // the PCG's tiled operator pass (raw accumulators straight into `out`)
         { TimedScope t(c, I3D_K_EG_PASS); launch_eg_tile(s, r, p, u, c->tile_plan(), c->d_shared.p, out, nullptr, nullptr); }
         { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, 2 * c->chunk, c->v_mask.p, out, out); }      // the raw accumulators also cover fixed unknowns (the PCG multiplies them by S = 0)
     } else {
@@ -178,7 +241,7 @@ static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const flo
 static int dot(i3d_context* c, const float* a, const float* b, double* out) {
     const Layout L = layout_of(c);
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 4, c->stream));
-    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, (int)L.slice_n, a + L.slice_off, b + L.slice_off, c->d_scal.p, c->d_partials.p); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_dot2(c->stream, L.own, a, b, c->d_scal.p, c->d_partials.p); }
     { int rc = allreduce(c, c->d_scal.p, 1); if (rc) return rc; }
     { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, L.NS, a + L.tail_off, b + L.tail_off, c->d_scal.p, c->d_partials.p); }
     return read_doubles(c, c->d_scal.p, 1, out);
@@ -234,72 +297,76 @@ static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const F
 }
 
 // CGNR (ConjugateGradientsSolver) on (S J^T W J S + D^2) x = b, x0 = 0.  No host synchronisation inside an iteration.
-// Sharded: every rank iterates on its slice of the vectors + the replicated camera tail; per iteration the slice partials of rho,
-// [p.q | camera block] and the three Q sums are all-reduced and the operator input u is all-gathered.
+// Sharded (one process per GPU): a rank iterates on its two owned segments of every vector + the replicated camera tail.  Per pass:
+//   * ONE neighbour exchange: the operator input u = S p on the rim the rank's rows read (Comm::push_halo, a few tens of KB per pair);
+//   * ONE small all-reduce after the operator: [camera block 6K+9 | p.q] (fp64);
+//   * ONE all-reduce of the 4 iteration scalars (r.z, x.(b+r), x.r, sum D^2 x^2) at the iteration boundary.
+// No vector is gathered: everything that lands on an owned unknown is computed from rows the rank holds itself (owned + ghost entries).
 static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, PcgState* final_state) {
     hipStream_t s = c->stream;
     const Layout L = layout_of(c);
-    const int K = c->K; const bool multi = sharded(c), tiled = !multi && c->tile_ok;
+    const int K = c->K; const bool multi = sharded(c), tiled = c->tile_ok;
     GridView g = c->grid_view(); RowView r = c->row_view();
     PassBuffers pb{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
     PcgState* st = c->d_pcg.p;
     double* pq_slot = c->d_shared.p + L.NS;
-    const size_t so = L.slice_off, to = L.tail_off; const int sn = (int)L.slice_n;
+    const size_t to = L.tail_off; const Seg2 own = L.own;
     { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, (int)L.NP, c->v_x.p, 0.0f); launch_pcg_init(s, st, cfg.pcg_fixed_iterations, 500); }
     CTX_HIP(c, hipMemcpyAsync(c->v_r.p, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s));
     // fp64 partial sums: [0, 4*2048) slice sums of k_pcg_step, then the p.q partials of the operator pass, then the D^2 p^2 partials of k_pcg_direction
     double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048; double* const d2_part = pq_part + 1024;
     int n_pq = 0, n_step = 0, n_d2 = 0;
-    // Single rank: the LDS-tiled pass leaves the raw accumulators J^T W J u in v_qacc (camera block in d_shared, p.q partials row by row); the
-    // vector q = S acc + D^2 v is formed inside k_pcg_step.  Sharded: the rank's rows through k_eg_jtjp + k_gather on its compute list:
-    // out(slice) = S J^T W J u + D^2 v, camera block and p.q partial left in d_shared (reduced over ranks).
+    // The operator on the rows of this rank.  Tiled (tile_pass.hip): raw accumulators J^T W J u in v_qacc (camera block in d_shared, p.q partials
+    // row by row); the vector q = S acc + D^2 v is formed inside k_pcg_step.  Untiled fallback (single rank): k_eg_jtjp + k_gather -> out.
     auto rows_apply = [&](const float* v, float* out, bool with_dot, bool zero_first) -> int {
         if (zero_first) CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));      // (the pass boundary kernel zeroes it otherwise)
+        if (multi) { int rc = push_halo(c, c->v_u.p); if (rc) return rc; }
         if (tiled) {
-            TimedScope t(c, I3D_K_EG_PASS);
-            n_pq = launch_eg_tile(s, r, p, c->v_u.p, c->tile_plan(), c->d_shared.p, c->v_qacc.p, with_dot ? pq_part : nullptr, st);
+            { TimedScope t(c, I3D_K_EG_PASS);
+              n_pq = launch_eg_tile(s, r, p, c->v_u.p, c->tile_plan(), c->d_shared.p, c->v_qacc.p, with_dot ? pq_part : nullptr, st); }
             if (!with_dot) n_pq = 0;
-            return I3D_OK;
+            if (!multi) return I3D_OK;
+            // the rank's p.q (rows + D^2 p^2 of its slice) rides with the camera block
+            if (with_dot) { TimedScope t(c, I3D_K_VECTOR); launch_reduce_partials(s, pq_part, n_pq, 1, pq_slot, st); launch_reduce_partials(s, d2_part, n_d2, 1, pq_slot, st); }
+            n_pq = 0;
+            return allreduce(c, c->d_shared.p, (size_t)L.NS + 1);
         }
         { TimedScope t(c, I3D_K_EG_PASS); launch_eg_pass(s, PASS_JTJP, g, r, p, c->v_u.p, pb, st); }
-        // sharded: the rank's p.q partial is accumulated straight into the slot that rides with the camera block (few workgroups per rank)
-        { TimedScope t(c, I3D_K_GATHER); n_pq = launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, with_dot ? (multi ? pq_slot : pq_part) : nullptr, multi, st); }
-        if (!multi) { if (!with_dot) n_pq = 0; return I3D_OK; }
-        n_pq = 0;
-        return allreduce(c, c->d_shared.p, (size_t)L.NS + 1);
+        { TimedScope t(c, I3D_K_GATHER); n_pq = launch_gather_tail(s, r, pb, out, c->v_S.p, c->v_D2.p, v, with_dot ? pq_part : nullptr, false, st); }
+        if (!with_dot) n_pq = 0;
+        return I3D_OK;
     };
     const float* const Sq = tiled ? c->v_S.p : nullptr;          // tiled pass: k_pcg_step forms q from the accumulators
     { TimedScope t(c, I3D_K_VECTOR);
-      n_step = launch_pcg_step(s, 0 /*init*/, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, multi ? nullptr : step_part, st); }
+      n_step = launch_pcg_step(s, 0 /*init*/, own, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, multi ? nullptr : step_part, st); }
     int tail_mode = 0;
     const int seq0 = c->pcg_seq;               // pass numbers are unique across solves: a stale ring entry can never match
     int it = 1;
     for (;; ++it) {
-        // iteration boundary.  Sharded: ONE message pair — the 4 slice sums (r.z, x.(b+r), x.r, sum D2 x^2) and the slices of z
-        if (multi) { int rc = allreduce_allgather(c, st->acc, 4, c->v_z.p); if (rc) return rc; }      // (sharded k_pcg_step adds into acc directly)
+        // iteration boundary.  Sharded: the 4 slice sums (r.z, x.(b+r), x.r, sum D2 x^2) are all-reduced (sharded k_pcg_step adds into acc directly)
+        if (multi) { int rc = allreduce(c, st->acc, 4); if (rc) return rc; }
         { TimedScope t(c, I3D_K_VECTOR);
           launch_pcg_tail_a(s, tail_mode, to, K, c->Minv_blocks.p, c->v_p.p, tail_mode == 3 ? c->v_tmp.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_z.p,
                             step_part, n_step, st, c->d_shared.p, L.NS + 1, c->d_flags, seq0 + it); }
-        { TimedScope t(c, I3D_K_VECTOR);        // p is kept replicated (z was all-gathered), so u = S p needs no exchange
-          if (!multi) n_d2 = launch_pcg_direction(s, sn + L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, tiled ? d2_part : nullptr, st);
-          else launch_pcg_direction(s, (int)L.NP, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, nullptr, nullptr, st); }
+        { TimedScope t(c, I3D_K_VECTOR);        // p = z + beta p, u = S p on the owned segments and the (replicated) camera tail; sharded: D^2 p^2 of the tail is added by k_pcg_tail_b
+          n_d2 = launch_pcg_direction(s, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, tiled ? d2_part : nullptr, st); }
         { int rc = rows_apply(c->v_p.p, c->v_q.p, true, false); if (rc) return rc; }
-        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_tail_b(s, to, K, p, c->d_shared.p, pq_slot, pq_part, n_pq, d2_part, tiled ? n_d2 : 0, tiled, c->v_q.p, c->v_S.p, c->v_D2.p, c->v_p.p, st); }
+        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_tail_b(s, to, K, p, c->d_shared.p, pq_slot, pq_part, n_pq, d2_part, (tiled && !multi) ? n_d2 : 0, tiled,
+                                                           c->v_q.p, c->v_S.p, c->v_D2.p, c->v_p.p, st); }
         const bool reset = (it % 10 == 0);                                       // residual_reset_period
         if (!reset) {
             TimedScope t(c, I3D_K_VECTOR);
-            n_step = launch_pcg_step(s, 1, so, sn, c->v_p.p, tiled ? c->v_qacc.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, multi ? nullptr : step_part, st);
+            n_step = launch_pcg_step(s, 1, own, c->v_p.p, tiled ? c->v_qacc.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, multi ? nullptr : step_part, st);
             tail_mode = 1;
         } else {                                                                 // r = b - A x instead of r -= alpha q
             { TimedScope t(c, I3D_K_VECTOR);
-              launch_pcg_step(s, 2, so, sn, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, multi ? nullptr : step_part, st);
+              launch_pcg_step(s, 2, own, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, multi ? nullptr : step_part, st);
               launch_pcg_tail_x(s, to, K, c->v_p.p, c->v_x.p, st);
-              launch_mul(s, sn, c->v_S.p + so, c->v_x.p + so, c->v_u.p + so); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
-            { int rc = allgather(c, c->v_u.p); if (rc) return rc; }
+              launch_mul2(s, own, c->v_S.p, c->v_x.p, c->v_u.p); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
             { int rc = rows_apply(c->v_x.p, c->v_tmp.p, false, true); if (rc) return rc; }
             { TimedScope t(c, I3D_K_VECTOR);
               launch_shared_finalize(s, to, K, p, c->d_shared.p, c->v_tmp.p, true, c->v_S.p, c->v_D2.p, c->v_x.p, nullptr, st);
-              n_step = launch_pcg_step(s, 3, so, sn, c->v_p.p, tiled ? c->v_qacc.p : c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, multi ? nullptr : step_part, st); }
+              n_step = launch_pcg_step(s, 3, own, c->v_p.p, tiled ? c->v_qacc.p : c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, multi ? nullptr : step_part, st); }
             tail_mode = 3;
         }
         if (it >= 2) {                                                           // look at the boundary of pass it-1 while pass it runs

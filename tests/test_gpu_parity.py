@@ -175,8 +175,9 @@ def test_gpu_matches_committed_golden(oracle):
 
 
 def test_sharded_ranks_match_single_rank(setup):
-    """The SPMD path (owned ranges, compute lists, rank-major vectors, reduced PCG scalars / camera block, gathered operator input)
-    with W ranks simulated by W host threads on ONE GPU (i3d_comm_init_sim) must reproduce the single-rank result."""
+    """The SPMD path (tile-aligned owned ranges, compute lists with ghost entries, ghost tiles of the operator pass, rim exchange of the
+    operator input, reduced PCG scalars / camera block) with W ranks simulated by W host threads on ONE GPU (i3d_comm_init_sim) must
+    reproduce the single-rank result.  (The scene's work list spans a dozen ownership tiles: W = 8 leaves some ranks without rows.)"""
     import threading
     from intrinsic3d_amd import binding
     O = setup["O"]; sc = setup["sc"]; a0 = setup["arrays"]; vsh = setup["vsh"]
@@ -185,7 +186,7 @@ def test_sharded_ranks_match_single_rank(setup):
     ref = helpers.gpu_context(sc, a0, vsh)
     rst = ref.optimize(cfg); rsdf, ralb = ref.get_grid(); ri, rd, rp = ref.get_camera(); ref.close()
     L = binding.load()
-    for W in (2, 3):
+    for W in (2, 3, 8):
         shared = L.i3d_comm_sim_create(W)
         ctxs = [helpers.gpu_context(sc, a0, vsh) for _ in range(W)]
         for r, c in enumerate(ctxs):
@@ -282,27 +283,38 @@ def test_multi_tile_problem_matches_oracle(oracle):
     assert np.abs(sdf - ref["sdf_refined"]).max() <= 1e-4 * np.abs(ref["sdf_refined"]).max()
     assert np.abs(alb - ref["albedo"]).max() <= 1e-4 * np.abs(ref["albedo"]).max()
     np.testing.assert_allclose(gi, ointr, rtol=1e-4); np.testing.assert_allclose(gp, oposes, rtol=1e-4, atol=1e-6)
-    # the same problem under the SPMD path (2 simulated ranks): owned ranges of ~0.3 M entries, halo rows, rank-major vectors
+    # the same problem under the SPMD path (2 and 8 simulated ranks): owned ranges of ~0.3 M / ~75 k entries, ghost rows, ghost tiles, rim exchange
     import threading
     from intrinsic3d_amd import binding
-    L = binding.load(); W = 2
-    shared = L.i3d_comm_sim_create(W)
-    ctxs = [helpers.gpu_context(sc, arrays, vsh) for _ in range(W)]
-    for r, c in enumerate(ctxs):
-        c.comm_init_sim(shared, r)
-    err = [None] * W
+    L = binding.load()
+    for W in (2, 8):
+        shared = L.i3d_comm_sim_create(W)
+        ctxs = [helpers.gpu_context(sc, arrays, vsh) for _ in range(W)]
+        for r, c in enumerate(ctxs):
+            c.comm_init_sim(shared, r)
+        err = [None] * W
 
-    def run(r):
-        try:
-            ctxs[r].optimize(helpers.gpu_cfg(ocfg))
-        except Exception as e:
-            err[r] = e
-    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
-    [t.start() for t in th]; [t.join(timeout=300) for t in th]
-    assert not any(t.is_alive() for t in th) and all(e is None for e in err), err
-    for c in ctxs:
-        s2, a2 = c.get_grid()
-        assert np.abs(s2 - sdf).max() <= 1e-4 * np.abs(sdf).max() and np.abs(a2 - alb).max() <= 1e-4
-        c.close()
-    L.i3d_comm_sim_destroy(shared)
+        def run(r):
+            try:
+                ctxs[r].optimize(helpers.gpu_cfg(ocfg))
+            except Exception as e:
+                err[r] = e
+        th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+        [t.start() for t in th]; [t.join(timeout=300) for t in th]
+        assert not any(t.is_alive() for t in th) and all(e is None for e in err), err
+        A = sizes["active"]
+        for r, c in enumerate(ctxs):
+            s2, a2 = c.get_grid()
+            assert np.abs(s2 - sdf).max() <= 1e-4 * np.abs(sdf).max() and np.abs(a2 - alb).max() <= 1e-4
+            cs = c.comm_stats()
+            # what a rank exchanges per PCG pass is its RIM, never a vector: 8 bytes per rim entry (a 5-voxel-thick shell cut into 8 patches of
+            # ~125 x 125 voxels here: ~16 % of what a rank owns; ~5 % for the 1-mm bench shell at 8 ranks)
+            assert 0 < cs["halo_send"] < 0.25 * A / W and 0 < cs["halo_recv"] < 0.25 * A / W, cs
+            assert cs["compute_list"] < 1.25 * A / W + 2048, cs                     # owned + ghost entries
+            assert cs["halo_bytes_sent"] == 8 * cs["halo_send"] * cs["halo_calls"] and cs["halo_calls"] > 0
+            if r == 0:
+                print(f"W={W}: rank 0 owns ~{A // W} entries, compute list {cs['compute_list']}, rim sent/received per pass {cs['halo_send']}/{cs['halo_recv']} entries "
+                      f"({8 * cs['halo_send']} B), ghost tiles {cs['ghost_tiles']}, all-reduce bytes per call {cs['reduce_bytes'] // max(cs['reduce_calls'], 1)}")
+            c.close()
+        L.i3d_comm_sim_destroy(shared)
     g.free(); fr.free()

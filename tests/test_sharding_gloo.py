@@ -1,10 +1,15 @@
 """-m "not gpu": the N>1 protocol of the sharded PCG operator with real collectives (gloo, world_size 2 and 3, CPU).
 
-Every rank holds the replicated problem structure, asks the library's host-side planner (i3d_shard_plan, the same inline
-functions the device kernels use) for its owned work-list range, rank-major vector layout and compute list, evaluates
-y = J^T W J x ONLY from the rows of its compute list (rows come from the CPU oracle), keeps ONLY the outputs of the unknowns it
-owns, counts the camera columns ONLY on a row's owner, all-reduces the camera block and all-gathers the slices — exactly what
-host/solver.cpp does around k_eg_pass / k_gather with RCCL.  The assembled result must equal the oracle's global product."""
+Every rank holds the replicated problem structure and asks the library's host-side planner (i3d_shard_plan / i3d_shard_need, the same
+inline functions the device plan uses) for its owned tile-aligned range, its compute list (owned + ghost entries) and the NEED sets.
+Then one operator application exactly as host/solver.cpp + Comm run it:
+  1. every rank holds the operator input u ONLY on the unknowns it owns — everything else is poisoned with NaN;
+  2. the owners push the rim values their neighbours need (point-to-point: here all_to_all of (index, value) lists) — if the need
+     sets were too small, a NaN would reach a row;
+  3. y = J^T W J u from the rows of the compute list (rows come from the CPU oracle), kept ONLY on owned unknowns; the camera columns and
+     p.q counted ONLY on a row's owner;
+  4. ONE all-reduce of [camera block | p.q]; nothing else is exchanged — no vector is gathered (the check below assembles the owned
+     segments only to compare with the oracle's global product)."""
 import os
 import sys
 
@@ -49,40 +54,59 @@ def _worker(rank, world, port, q):
             nb = np.array([index.get((k[0] + o[0], k[1] + o[1], k[2] + o[2]), -1) for k in keys[wl].tolist()])
             anbr[j] = np.where(nb >= 0, lidx[np.maximum(nb, 0)], -1)
         chunk, own0, own1, comp = binding.shard_plan(A, world, rank, anbr, active[wl])
-        L = binding.load()
-        vs = lambda a: L.i3d_shard_vec_index(int(a), chunk, 0)
-        va = lambda a: L.i3d_shard_vec_index(int(a), chunk, 1)
-        tail = world * 2 * chunk
-        # a random vector on the free unknowns, in the rank-major layout (replicated input, like the all-gathered u)
+        need = binding.shard_need(A, world, anbr, active[wl])
+        slice_ = chunk // world
+        assert own0 == min(rank * slice_, A) and slice_ % 1024 == 0 and chunk >= A
+        tail = 2 * chunk
+        vs = lambda a: int(a)
+        va = lambda a: chunk + int(a)
         rng = np.random.default_rng(7)
         xg = rng.normal(0, 1, 2 * N + NS)
         is_free = np.concatenate([free_s, free_a, np.full(6 * K, cfg.fix_poses == 0), np.full(4, cfg.fix_intrinsics == 0), np.full(5, cfg.fix_distortion == 0)])
         cost, grad, diag, touched = pv.normal_eq()
         xg = xg * is_free
-        u = np.zeros(tail + NS)
-        for a in range(A):
+        # 1. the operator input: owned segments + replicated camera tail; everything else is NaN
+        u = np.full(tail + NS, np.nan)
+        for a in range(own0, own1):
             u[vs(a)] = xg[wl[a]]; u[va(a)] = xg[N + wl[a]]
         u[tail:] = xg[2 * N:]
+        # 2. the rim exchange: owner -> every rank whose rows read the entry
+        send = [[] for _ in range(world)]
+        for a in range(own0, own1):
+            m = int(need[a])
+            for k in range(world):
+                if k != rank and (m >> k) & 1:
+                    send[k].append((a, u[vs(a)], u[va(a)]))
+        recv = [None] * world
+        dist.all_to_all_single  # (gloo has no variable all_to_all for objects: use all_gather_object of the per-destination lists)
+        allsend = [None] * world
+        dist.all_gather_object(allsend, send)
+        n_recv = 0
+        for k in range(world):
+            if k == rank: continue
+            for a, us_, ua_ in allsend[k][rank]:
+                assert (int(need[a]) >> rank) & 1 and not (own0 <= a < own1)
+                u[vs(a)] = us_; u[va(a)] = ua_; n_recv += 1
+        n_send = sum(len(x) for x in send)
 
-        def col_vec(v_idx):        # list-space vector position of voxel v_idx's sdf unknown (or None when outside the list = fixed)
-            a = lidx[v_idx]
-            return None if a < 0 else int(a)
-
-        y_slice = np.zeros(tail + NS); cam = np.zeros(NS)
+        y_slice = np.zeros(tail + NS); cam = np.zeros(NS + 1)
         owned = lambda a: own0 <= a < own1
 
         def add_row(centre_a, cols, coefs, w, cam_cols=None, cam_coefs=None):
-            # cols: vector positions (or None); t = w * (J . u); outputs only on owned unknowns; camera only on the owner of the row
+            # cols: vector positions (or None); t = w * (J . u); outputs only on owned unknowns; camera + p.q only on the owner of the row
             d = sum(c * u[p] for p, c in zip(cols, coefs) if p is not None)
             if cam_cols is not None:
                 d += sum(c * u[tail + p] for p, c in zip(cam_cols, cam_coefs))
+            assert d == d, "a row read an operator-input value that was neither owned nor pushed (need set too small)"
             t = w * d
             for p, c, a_of in zip(cols, coefs, row_entries):
                 if p is not None and owned(a_of):
                     y_slice[p] += c * t
-            if cam_cols is not None and owned(centre_a):
-                for p, c in zip(cam_cols, cam_coefs):
-                    cam[p] += c * t
+            if owned(centre_a):
+                cam[NS] += t * d                                 # p.q row by row (tile_pass.hip)
+                if cam_cols is not None:
+                    for p, c in zip(cam_cols, cam_coefs):
+                        cam[p] += c * t
 
         v, f, w, r, J = pv.eg(True)
         for i in range(len(v)):
@@ -95,7 +119,7 @@ def _worker(rank, world, port, q):
             row_entries = ent
             cam_cols = list(range(6 * f[i], 6 * f[i] + 6)) + list(range(6 * K, 6 * K + 9))
             add_row(ca, cols, J[i, :14], w[i], cam_cols, J[i, 14:])
-        for t_id, coefs_fn in ((1, None), (2, None), (3, None)):
+        for t_id in (1, 2, 3):
             vv, dd, ww, rr = pv.reg(t_id)
             for i in range(len(vv)):
                 ca = lidx[vv[i]]
@@ -119,20 +143,27 @@ def _worker(rank, world, port, q):
         for a in range(A):
             maskv[vs(a)] = free_s[wl[a]]; maskv[va(a)] = free_a[wl[a]]
         maskv[tail:] = is_free[2 * N:]
-        # the exchange: camera block all-reduced, slices all-gathered
+        # 4. the ONE collective of the pass: [camera block | p.q]
         cam_t = torch.from_numpy(cam); dist.all_reduce(cam_t)
-        sl = torch.from_numpy(y_slice[rank * 2 * chunk:(rank + 1) * 2 * chunk].copy())
-        parts = [torch.zeros_like(sl) for _ in range(world)]
-        dist.all_gather(parts, sl)
-        y = np.concatenate([p.numpy() for p in parts] + [cam_t.numpy()]) * maskv
-        # reference: the oracle's global product (u already carries zeros on fixed unknowns because x was masked)
+        # (test only) assemble the owned segments to compare with the oracle's global product
+        seg = np.zeros(2 * slice_)
+        seg[:slice_] = y_slice[rank * slice_:(rank + 1) * slice_]; seg[slice_:] = y_slice[chunk + rank * slice_:chunk + (rank + 1) * slice_]
+        parts = [torch.zeros(2 * slice_, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(seg))
+        y = np.zeros(tail + NS)
+        for k2 in range(world):
+            pk = parts[k2].numpy(); y[k2 * slice_:(k2 + 1) * slice_] = pk[:slice_]; y[chunk + k2 * slice_:chunk + (k2 + 1) * slice_] = pk[slice_:]
+        y[tail:] = cam_t.numpy()[:NS]
+        y *= maskv
         yref_g = pv.jtj_apply(xg)
         yref = np.zeros(tail + NS)
         for a in range(A):
             yref[vs(a)] = yref_g[wl[a]]; yref[va(a)] = yref_g[N + wl[a]]
         yref[tail:] = yref_g[2 * N:]
         err = np.abs(y - yref).max() / (np.abs(yref).max() + 1e-30)
-        q.put((rank, float(err), int(comp.sum()), int(own1 - own0), A))
+        pq_ref = float(xg @ yref_g)
+        err_pq = abs(float(cam_t.numpy()[NS]) - pq_ref) / abs(pq_ref)
+        q.put((rank, float(err), int(comp.sum()), int(own1 - own0), A, n_send, n_recv, float(err_pq)))
     finally:
         dist.destroy_process_group()
 
@@ -150,6 +181,8 @@ def test_sharded_operator_protocol_gloo(world):
     res = sorted(q.get(timeout=5) for _ in range(world))
     A = res[0][4]
     assert sum(r[3] for r in res) == A                       # owned ranges partition the work list
-    for rank, err, ncomp, nown, _ in res:
-        assert err < 1e-12, (rank, err)
-        assert nown <= ncomp < A                              # compute list = owned + a halo, not everything
+    assert sum(r[5] for r in res) == sum(r[6] for r in res)  # everything pushed is received
+    for rank, err, ncomp, nown, _, n_send, n_recv, err_pq in res:
+        assert err < 1e-12 and err_pq < 1e-12, (rank, err, err_pq)
+        assert nown <= ncomp <= A
+    assert all(r[3] > 0 for r in res) and sum(r[5] for r in res) > 0, res      # every rank owns a range and rim values do travel
