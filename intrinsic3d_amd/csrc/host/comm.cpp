@@ -1,4 +1,6 @@
 #include "comm.hpp"
+#include "p2p.hpp"
+#include <cstdlib>
 #include <rccl/rccl.h>
 #include <condition_variable>
 #include <cstdio>
@@ -8,12 +10,19 @@
 
 namespace i3d {
 
+constexpr int P2P_RED_CAP = 6 * 2000 + 16;      // the camera block of the largest supported keyframe count + p.q
+constexpr int P2P_HALO_CAP = 1 << 17;           // rim entries per pair and pass
+
 // ---- RCCL -------------------------------------------------------------------------------------------------------------
 struct RcclComm : Comm {
     ncclComm_t comm = nullptr;
-    ~RcclComm() override { if (comm) ncclCommDestroy(comm); }
+    P2PEngine p2p; bool use_p2p = false;       // peer-to-peer mailboxes for the per-pass exchanges (verified at start-up, else RCCL carries them too)
+    ~RcclComm() override { p2p.destroy(); if (comm) ncclCommDestroy(comm); }
+    int plan_changed(const HaloPlan& h, hipStream_t st) override { return use_p2p ? p2p.set_halo_lists(h, st) : 0; }
+    int health(hipStream_t st) override { return use_p2p ? p2p.check(st) : 0; }
     int allreduce_sum(double* dev, size_t n, hipStream_t st) override {
         ++reduce_calls; reduce_bytes += 8ll * (long long)n;
+        if (use_p2p && (int)n <= p2p.L.red_cap) return p2p.allreduce(dev, n, st);
         return ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm, st) == ncclSuccess ? 0 : 1;
     }
     int allgather(float* dev, size_t count, hipStream_t st) override {
@@ -22,6 +31,7 @@ struct RcclComm : Comm {
     // neighbours only: one grouped launch of sends / receives of the packed rim values (a few tens of KB per pair)
     int push_halo(float* vec, const HaloPlan& h, hipStream_t st) override {
         ++halo_calls; halo_bytes_sent += 8ll * h.n_send;
+        if (use_p2p) return p2p.push_halo(vec, h, st);
         if (h.n_send == 0 && h.n_recv == 0) return 0;
         launch_halo_pack(st, h.n_send, h.d_send_idx, vec, h.chunk, h.d_send_buf);
         if (ncclGroupStart() != ncclSuccess) return 1;
@@ -44,12 +54,56 @@ int rccl_unique_id(void* out, size_t* bytes) {
     return 0;
 }
 
-Comm* make_rccl_comm(int rank, int world, const void* unique_id, size_t id_bytes, hipStream_t, char* err, size_t errlen) {
+// Mailboxes for the per-pass exchanges: created on every rank, IPC handles all-gathered through RCCL, then verified with real exchanges
+// (known sums, bounded waits).  All ranks take the same decision (all-reduced); anything short of a clean pass leaves RCCL in charge.
+static bool bootstrap_p2p(RcclComm* c, hipStream_t st) {
+    { const char* e = std::getenv("I3D_TRANSPORT"); if (e && std::strcmp(e, "rccl") == 0) return false; }
+    bool ok = c->p2p.create(c->rank, c->world, P2P_RED_CAP, P2P_HALO_CAP) == 0;
+    unsigned char* d_handles = nullptr; double* d_test = nullptr;
+    ok = ok && hipMalloc((void**)&d_handles, 64 * (size_t)c->world) == hipSuccess && hipMalloc((void**)&d_test, sizeof(double) * 64) == hipSuccess;
+    unsigned char mine[64] = {0};
+    if (ok) ok = c->p2p.export_handle(mine) == 0;
+    if (ok) ok = hipMemcpy(d_handles + 64 * (size_t)c->rank, mine, 64, hipMemcpyHostToDevice) == hipSuccess;
+    // every rank must take part in the collectives below even if it failed locally (ok is agreed on at the end)
+    std::vector<unsigned char> all(64 * (size_t)c->world, 0);
+    if (d_handles) {
+        (void)ncclAllGather(d_handles + 64 * (size_t)c->rank, d_handles, 64, ncclUint8, c->comm, st);
+        (void)hipStreamSynchronize(st);
+        ok = ok && hipMemcpy(all.data(), d_handles, all.size(), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (ok && c->world > 1) ok = c->p2p.attach_ipc(all.data()) == 0;
+    if (ok && c->world == 1) c->p2p.ready = true;
+    // agree that everyone has mapped everyone before the first peer store
+    double flag = ok ? 1.0 : 0.0;
+    if (d_test) { (void)hipMemcpy(d_test, &flag, sizeof(double), hipMemcpyHostToDevice); (void)ncclAllReduce(d_test, d_test, 1, ncclDouble, ncclMin, c->comm, st); (void)hipStreamSynchronize(st);
+                  (void)hipMemcpy(&flag, d_test, sizeof(double), hipMemcpyDeviceToHost); }
+    ok = ok && flag == 1.0;
+    if (ok) {        // self-test: 8 all-reduces of rank-dependent vectors
+        for (int rep = 0; rep < 8 && ok; ++rep) {
+            double v[64]; for (int i = 0; i < 64; ++i) v[i] = (double)(c->rank + 1) * (i + 1) + rep;
+            ok = hipMemcpy(d_test, v, sizeof(v), hipMemcpyHostToDevice) == hipSuccess && c->p2p.allreduce(d_test, 64, st) == 0 && c->p2p.check(st) == 0
+                 && hipMemcpy(v, d_test, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess;
+            const double tri = 0.5 * c->world * (c->world + 1);
+            for (int i = 0; i < 64 && ok; ++i) ok = v[i] == tri * (i + 1) + (double)rep * c->world;
+        }
+        flag = ok ? 1.0 : 0.0;
+        (void)hipMemcpy(d_test, &flag, sizeof(double), hipMemcpyHostToDevice); (void)ncclAllReduce(d_test, d_test, 1, ncclDouble, ncclMin, c->comm, st); (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(&flag, d_test, sizeof(double), hipMemcpyDeviceToHost);
+        ok = flag == 1.0;
+    }
+    if (d_handles) (void)hipFree(d_handles); if (d_test) (void)hipFree(d_test);
+    if (!ok) c->p2p.destroy();
+    return ok;
+}
+
+Comm* make_rccl_comm(int rank, int world, const void* unique_id, size_t id_bytes, hipStream_t st, char* err, size_t errlen) {
     if (id_bytes != sizeof(ncclUniqueId)) { std::snprintf(err, errlen, "RCCL unique id has %zu bytes, expected %zu", id_bytes, sizeof(ncclUniqueId)); return nullptr; }
     ncclUniqueId id; std::memcpy(&id, unique_id, sizeof(id));
     auto* c = new RcclComm; c->rank = rank; c->world = world;
     const ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) { std::snprintf(err, errlen, "ncclCommInitRank: %s", ncclGetErrorString(r)); c->comm = nullptr; delete c; return nullptr; }
+    c->use_p2p = bootstrap_p2p(c, st);
+    c->transport = c->use_p2p ? "p2p-mailbox (per-pass exchanges) + rccl" : "rccl";
     return c;
 }
 
@@ -60,6 +114,7 @@ struct SimShared {
     int arrived = 0; long generation = 0;
     std::vector<void*> ptr; std::vector<double> sum;
     std::vector<const HaloPlan*> halo;
+    std::vector<unsigned char*> mailbox;      // P2P mode: every rank's mailbox (same process: plain pointers)
     void barrier() {
         std::unique_lock<std::mutex> lk(m);
         const long gen = generation;
@@ -67,13 +122,26 @@ struct SimShared {
         else cv.wait(lk, [&] { return generation != gen; });
     }
 };
-SimShared* sim_create(int world) { auto* s = new SimShared; s->world = world; s->ptr.assign(world, nullptr); s->halo.assign(world, nullptr); return s; }
+SimShared* sim_create(int world) { auto* s = new SimShared; s->world = world; s->ptr.assign(world, nullptr); s->halo.assign(world, nullptr); s->mailbox.assign(world, nullptr); return s; }
 void sim_destroy(SimShared* s) { delete s; }
 
 struct SimComm : Comm {
     SimShared* sh = nullptr;
+    P2PEngine p2p; bool use_p2p = false, want_p2p = false, attached = false;      // I3D_SIM_P2P=1: the per-pass exchanges through the mailbox kernels (<= 4 ranks: one hardware queue per spinning rank)
+    ~SimComm() override { p2p.destroy(); }
+    void attach() {        // first collective of every rank (they run concurrently): all mailboxes are registered by now
+        if (attached) return; attached = true;
+        sh->barrier();
+        bool all = want_p2p; for (int k = 0; k < world; ++k) all = all && sh->mailbox[k] != nullptr;
+        if (all) { for (int k = 0; k < world; ++k) p2p.attach_pointer(k, sh->mailbox[k]); p2p.ready = true; use_p2p = true; transport = "p2p-mailbox (rank simulation)"; }
+        sh->barrier();
+    }
+    int plan_changed(const HaloPlan& h, hipStream_t st) override { attach(); return use_p2p ? p2p.set_halo_lists(h, st) : 0; }
+    int health(hipStream_t st) override { return use_p2p ? p2p.check(st) : 0; }
     int allreduce_sum(double* dev, size_t n, hipStream_t st) override {
         ++reduce_calls; reduce_bytes += 8ll * (long long)n;
+        attach();
+        if (use_p2p && (int)n <= p2p.L.red_cap) return p2p.allreduce(dev, n, st);
         if (hipStreamSynchronize(st) != hipSuccess) return 1;
         std::vector<double> mine(n);
         if (hipMemcpy(mine.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return 1;
@@ -101,6 +169,8 @@ struct SimComm : Comm {
     // same device, one process: every rank packs, then copies what the peers packed for it
     int push_halo(float* vec, const HaloPlan& h, hipStream_t st) override {
         ++halo_calls; halo_bytes_sent += 8ll * h.n_send;
+        attach();
+        if (use_p2p) return p2p.push_halo(vec, h, st);
         launch_halo_pack(st, h.n_send, h.d_send_idx, vec, h.chunk, h.d_send_buf);
         if (hipStreamSynchronize(st) != hipSuccess) return 1;
         sh->halo[rank] = &h;
@@ -117,6 +187,14 @@ struct SimComm : Comm {
         return 0;
     }
 };
-Comm* make_sim_comm(SimShared* s, int rank) { auto* c = new SimComm; c->sh = s; c->rank = rank; c->world = s->world; return c; }
+Comm* make_sim_comm(SimShared* s, int rank) {
+    auto* c = new SimComm; c->sh = s; c->rank = rank; c->world = s->world; c->transport = "host-mediated (rank simulation)";
+    const char* e = std::getenv("I3D_SIM_P2P");
+    if (e && e[0] == '1' && s->world <= 4) {      // mailboxes are registered here; the peers are attached at the first collective (all ranks are running by then)
+        c->want_p2p = c->p2p.create(rank, s->world, P2P_RED_CAP, P2P_HALO_CAP) == 0;
+        std::lock_guard<std::mutex> lk(s->m); s->mailbox[rank] = c->want_p2p ? c->p2p.mailbox : nullptr;
+    }
+    return c;
+}
 
 }  // namespace i3d

@@ -32,6 +32,11 @@ struct Comm {
     virtual int allgather(float* dev, size_t count, hipStream_t st) = 0;
     // vec[e], vec[chunk + e] of the entries in the send lists -> the same positions of the peers' copies of vec (their recv lists)
     virtual int push_halo(float* vec, const HaloPlan& h, hipStream_t st) = 0;
+    // called once per outer iteration after the halo plan changed; 0 = ok
+    virtual int plan_changed(const HaloPlan&, hipStream_t) { return 0; }
+    // 0 = healthy; non-zero after a peer-to-peer wait timed out (synchronises the stream)
+    virtual int health(hipStream_t) { return 0; }
+    const char* transport = "";      // what carries the per-pass exchanges (for logs / bench)
 };
 
 // pack / unpack kernels of the halo exchange (operator.hip)

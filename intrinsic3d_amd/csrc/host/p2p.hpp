@@ -1,0 +1,34 @@
+// Peer-to-peer mailbox transport of the per-pass exchanges of the sharded PCG (see p2p.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include "comm.hpp"
+
+namespace i3d {
+
+constexpr int P2P_MAX_RANKS = 64;
+
+struct P2PLayout { int world, red_cap, halo_cap; size_t off_red, off_halo, bytes; };
+P2PLayout p2p_layout(int world, int red_cap /* doubles per all-reduce */, int halo_cap /* rim entries per pair */);
+
+struct P2PEngine {
+    int rank = 0, world = 1; bool ready = false;
+    P2PLayout L{};
+    unsigned char* mailbox = nullptr;                 // this rank's mailbox (fine-grained device memory)
+    unsigned char* peer[P2P_MAX_RANKS] = {nullptr};   // every rank's mailbox as seen from this device (peer[rank] == mailbox)
+    bool opened[P2P_MAX_RANKS] = {false};
+    int* d_err = nullptr; int* d_lists = nullptr;
+    unsigned long long epoch_red = 0, epoch_halo = 0;
+
+    int  create(int rank, int world, int red_cap, int halo_cap);
+    int  export_handle(void* out64);                  // hipIpcMemHandle_t of the mailbox
+    int  attach_ipc(const void* handles);             // world x 64 bytes, in rank order (one process per GPU)
+    void attach_pointer(int k, unsigned char* p);     // same process (rank simulation)
+    void destroy();
+    int  allreduce(double* dev, size_t n, hipStream_t st);
+    int  set_halo_lists(const HaloPlan& h, hipStream_t st);
+    int  push_halo(float* vec, const HaloPlan& h, hipStream_t st);
+    int  check(hipStream_t st);                       // 1 if a spin timed out
+};
+
+}  // namespace i3d

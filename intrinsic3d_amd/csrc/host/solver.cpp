@@ -150,6 +150,7 @@ static int shard_plan(i3d_context* c) {
     if (h.n_recv) CTX_HIP(c, hipMemcpyAsync(c->halo_recv_idx.p, ridx.data(), sizeof(int) * ridx.size(), hipMemcpyHostToDevice, s));
     CTX_HIP(c, hipStreamSynchronize(s));                  // (the host vectors above go out of scope)
     h.d_send_idx = c->halo_send_idx.p; h.d_recv_idx = c->halo_recv_idx.p; h.d_send_buf = c->halo_send_buf.p; h.d_recv_buf = c->halo_recv_buf.p;
+    if (c->comm->plan_changed(h, s)) return ctx_fail(c, I3D_ERR_CAPACITY, "sharding: the rim of a rank pair exceeds the peer-to-peer mailbox");
     return I3D_OK;
 }
 
@@ -383,6 +384,7 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[0], st, sizeof(PcgState), hipMemcpyDeviceToHost, s));
     CTX_HIP(c, hipStreamSynchronize(s));
     *final_state = c->h_pcg[0];                 // kernels after `done` were no-ops, so this is the terminal state
+    if (multi && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "pcg_solve: a peer-to-peer exchange timed out (a rank stopped taking part)");
     return I3D_OK;
 }
 

@@ -163,6 +163,44 @@ def test_real_rccl_collectives_with_one_rank(oracle, monkeypatch):
     g.free(); fr.free()
 
 
+def test_sharded_ranks_over_peer_to_peer_mailboxes(oracle, monkeypatch):
+    """the per-pass exchanges of the sharded PCG through the mailbox kernels (host/p2p.cpp: peer stores + epoch flags, no host in the loop) with
+    2 and 3 ranks simulated by host threads on ONE GPU (I3D_SIM_P2P=1): same answer as one rank, and no wait timed out"""
+    import threading
+    from intrinsic3d_amd import binding
+    sc = helpers.small_scene(seed=17, radius_vox=16, K=4, width=96, height=72)
+    g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc)
+    cfg = helpers.gpu_cfg(helpers.oracle_cfg(oracle, thres, iterations=2, cg_fixed_iterations=12))
+    ref = helpers.gpu_context(sc, arrays, vsh); st0 = ref.optimize(cfg); s0, a0 = ref.get_grid(); cam0 = ref.get_camera(); ref.close()
+    monkeypatch.setenv("I3D_SIM_P2P", "1")
+    L = binding.load()
+    for W in (2, 3):
+        shared = L.i3d_comm_sim_create(W)
+        ctxs = [helpers.gpu_context(sc, arrays, vsh) for _ in range(W)]
+        for r, c in enumerate(ctxs):
+            c.comm_init_sim(shared, r)
+        err = [None] * W; out = [None] * W
+
+        def run(r):
+            try:
+                out[r] = ctxs[r].optimize(cfg)
+            except Exception as e:
+                err[r] = e
+        th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+        [t.start() for t in th]; [t.join(timeout=120) for t in th]
+        assert not any(t.is_alive() for t in th), "a rank hung"
+        assert all(e is None for e in err), err
+        for r, c in enumerate(ctxs):
+            s1, a1 = c.get_grid(); cam1 = c.get_camera()
+            assert [list(x.rows) for x in out[r]] == [list(x.rows) for x in st0]
+            assert np.abs(s1 - s0).max() <= 1e-4 * np.abs(s0).max() and np.abs(a1 - a0).max() <= 1e-4
+            np.testing.assert_allclose(cam1[2], cam0[2], rtol=1e-4, atol=1e-6)
+            cs = c.comm_stats(); assert cs["halo_calls"] > 0 and cs["halo_send"] > 0
+            c.close()
+        L.i3d_comm_sim_destroy(shared)
+    g.free(); fr.free()
+
+
 def test_untiled_operator_fallback(oracle, monkeypatch):
     """the PCG operator without the LDS tile plan (what a grid whose tile halos do not fit falls back to; I3D_NO_TILE=1 forces it):
     k_eg_jtjp + k_gather give the same answer as the tiled pass and the oracle"""
