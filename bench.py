@@ -3,14 +3,16 @@
 
 A "step" is one outer iteration of Optimizer::optimize (optimizer.cpp:119-170): observation pass + residual/Jacobian
 build + cost-term normalisation + one Levenberg-Marquardt solve (PCG on the normal equations, cost evaluation, step
-acceptance).  The timed region is ONE i3d_optimize call with `--steps` iterations on inputs that are already resident
-in HBM; `--warmup` iterations run in a separate untimed call first.
+acceptance).  The timed region is a sequence of i3d_optimize calls of (up to) 10 iterations each — the reference's own
+call shape, lambda schedule included (intrinsic3d.yml: iterations 10) — that together run `--steps` iterations on inputs
+that are already resident in HBM; `--warmup` iterations run in a separate untimed call first.
 
 Workload (config.workload): BASELINE.json configs[3] shrunk to one node's worth of work per rank — a seeded synthetic
 hashed grid of ~8M stored voxels at 1 mm (thin shell around a bumpy sphere, finest-level shell threshold), 200 keyframes
 of 640x480 on a Fibonacci sphere, spatially-varying SH lighting estimated on the device (i3d_estimate_sh, untimed: it runs once
-per level, not per iteration) on a subvolume lattice of up to 8^3 = 512 cells, all parameter groups free.  With --gpus N the SAME
-problem is sharded across the ranks by contiguous ranges of the brick-ordered work list (strong scaling).
+per level, not per iteration) on the ~512 subvolumes of 0.06 m the shell touches, all parameter groups free.  With --gpus N the SAME
+problem is sharded across the ranks (strong scaling): tile-aligned ownership of the brick-ordered work list, rows of a thin rim
+recomputed as ghosts, per PCG pass one neighbour exchange of the operator input on the rim + one small all-reduce.
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNEL_TAG = "r02-quad-build"  # bumped when k_build<true> / k_eg_tile change materially: PMC traffic files of older kernels are not attached
 
 
 def parse_args():
@@ -42,13 +45,13 @@ def parse_args():
     ap.add_argument("--voxel-size", type=float, default=0.001)
     ap.add_argument("--band", type=float, default=3.5, help="stored half-thickness of the shell in voxels")
     ap.add_argument("--shell", type=float, default=1.0, help="thin-shell factor (thin_shell_factor_final)")
-    ap.add_argument("--subvolume", type=float, default=0.08, help="SH subvolume size in metres (0.6 m object: 8 cells per axis)")
+    ap.add_argument("--subvolume", type=float, default=0.06, help="SH subvolume size in metres (chosen so that the shell of the 0.6 m object touches ~512 subvolumes, BASELINE.json configs[3])")
     ap.add_argument("--cpu-sample", type=float, default=1.0e6, help="stored voxels of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--carry-radius", action="store_true",
                     help="NOT the reference's behaviour (and not the headline): carry the trust-region radius across outer iterations, as nls_solver.cpp:322-323 intends")
     ap.add_argument("--force-collectives", action="store_true",
-                    help="experiments only (1 GPU): run the sharded code path through a real 1-rank RCCL communicator, to see what the collectives' launches cost per PCG pass")
+                    help="experiments only (1 GPU): run the sharded code path through a real 1-rank communicator, to see what the exchange launches cost per PCG pass (comm_us_per_pass)")
     ap.add_argument("--all-kernel-timing", action="store_true", help="HIP events around every launch (kernel_ms_total for all categories; ~8 % slower)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="experiments only: no per-launch HIP events (no roofline in the output)")
     ap.add_argument("--pcg-fixed", type=int, default=-1, help="experiments only: pin the PCG iterations per LM attempt (-1 = Ceres' stopping rule)")
@@ -73,6 +76,9 @@ def grid_arrays(sc):
     n = sc["keys"].shape[0]
     sdf = sc["sdf"].astype(np.float64)
     return dict(keys=sc["keys"], sdf=sdf, sdf_refined=sdf.copy(), albedo=np.full(n, 0.6), weight=sc["weight"], color=sc["color"])
+
+
+CALL_ITERATIONS = 10          # Optimizer::optimize runs `iterations: 10` per call (intrinsic3d.yml); the lambda schedule spans ONE call
 
 
 def make_cfg(binding, args, iterations, thres):
@@ -106,37 +112,55 @@ def cpu_baseline(args, sc, thres, log, device=0):
                       fix_poses=0, fix_intrinsics=0, fix_distortion=0, occlusion_distance=0.02, num_observations=5, thres_shell=thres,
                       grid_level=0, rgbd_level=0, cg_fixed_iterations=-1, verbose=0)
     os.environ.setdefault("OMP_NUM_THREADS", "8")
+    threads = int(os.environ["OMP_NUM_THREADS"])
     before = g.export()
     t0 = time.time()
-    rc, _, _, _, stats = O.optimize(g, fr, cfg, sc["intr"], sc["dist"], sc["poses"], vsh)
+    rc, o_intr, o_dist, o_poses, stats = O.optimize(g, fr, cfg, sc["intr"], sc["dist"], sc["poses"], vsh)
     dt = time.time() - t0
+    after = g.export() if rc == 0 else None
     g.free(); fr.free()
     if rc != 0:
         return None
-    # checker, not product: the device path on the SAME sample must assemble the same problem (row counts bit-exact, initial cost to fp32
-    # round-off) — the quantities of iteration 0 that do not depend on where an inexact PCG happens to stop
+    # checker, not product: the device path on the SAME sample, same two iterations (native PCG stop, all groups free) — the problem it
+    # assembles (row counts), the cost before and after every iteration, and the fields / camera it ends with
     parity = None
     try:
         from intrinsic3d_amd import binding
         with binding.Context(device) as c2:
             c2.set_grid(sc["voxel_size"], before["keys"], before["sdf"], before["sdf_refined"], before["albedo"], before["weight"], before["color"])
             c2.set_frames(sc["frames"], 1); c2.set_camera(sc["intr"], sc["dist"], sc["poses"]); c2.set_voxel_sh(vsh)
-            gst = c2.optimize(binding.default_config(iterations=1, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0, lambda_s1=10.0,
+            gst = c2.optimize(binding.default_config(iterations=iters, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0, lambda_s1=10.0,
                                                      lambda_a=0.1, occlusion_distance=0.02, num_observations=5, thres_shell=thres))
-        parity = {"rows_oracle": [int(x) for x in stats[0].rows], "rows_device": [int(x) for x in gst[0].rows],
+            d_sdf, d_alb = c2.get_grid(); d_intr, d_dist, d_poses = c2.get_camera()
+
+        def rel_l2(dev, ref, start):          # error of the accumulated update, not of the state it is added to
+            den = float(np.linalg.norm(ref - start)); return float(np.linalg.norm(dev - ref)) / den if den > 0 else float(np.linalg.norm(dev - ref))
+        parity = {"iterations": iters,
+                  "rows_oracle": [[int(x) for x in st.rows] for st in stats], "rows_device": [[int(x) for x in st.rows] for st in gst],
                   "rows_equal": [int(x) for x in stats[0].rows] == [int(x) for x in gst[0].rows],
-                  "cost_initial_rel_diff": abs(gst[0].cost_initial - stats[0].cost_initial) / stats[0].cost_initial}
-        log(f"cpu baseline parity on the sample: rows equal {parity['rows_equal']}, initial cost rel. diff {parity['cost_initial_rel_diff']:.2e}")
+                  "cost_initial_rel_diff": abs(gst[0].cost_initial - stats[0].cost_initial) / stats[0].cost_initial,
+                  "cost_final_rel_diff": [abs(a.cost_final - b.cost_final) / b.cost_final for a, b in zip(gst, stats)],
+                  "lm_attempts": {"oracle": [int(st.n_attempts) for st in stats], "device": [int(st.num_attempts) for st in gst]},
+                  "pcg_iterations": {"oracle": [[int(x) for x in st.cg_iters[:st.n_attempts]] for st in stats],
+                                     "device": [[int(x) for x in st.pcg_iterations[:st.num_attempts]] for st in gst]},
+                  "sdf_update_rel_l2_err": rel_l2(d_sdf, after["sdf_refined"], before["sdf_refined"]),
+                  "albedo_update_rel_l2_err": rel_l2(d_alb, after["albedo"], before["albedo"]),
+                  "sdf_max_rel_err": float(np.abs(d_sdf - after["sdf_refined"]).max() / np.abs(after["sdf_refined"]).max()),
+                  "albedo_max_rel_err": float(np.abs(d_alb - after["albedo"]).max() / np.abs(after["albedo"]).max()),
+                  "poses_max_abs_err": float(np.abs(np.asarray(d_poses) - np.asarray(o_poses)).max()),
+                  "intrinsics_max_rel_err": float(np.abs((np.asarray(d_intr) - np.asarray(o_intr)) / np.asarray(o_intr)).max())}
+        log(f"cpu baseline parity on the sample: rows equal {parity['rows_equal']}, cost rel. diff initial {parity['cost_initial_rel_diff']:.2e} "
+            f"final {parity['cost_final_rel_diff']}, update rel. L2 err sdf {parity['sdf_update_rel_l2_err']:.2e} albedo {parity['albedo_update_rel_l2_err']:.2e}")
     except Exception as e:
         log(f"parity check on the sample failed to run: {e}")
     sec_per_iter_sample = dt / iters
     scale = keys.shape[0] / float(n)
     value = 1.0 / (sec_per_iter_sample * scale)
     log(f"cpu baseline: {n} voxels, {iters} iterations in {dt:.1f}s -> {sec_per_iter_sample:.2f} s/iter on the sample, x{scale:.1f} voxels")
-    return {"value": value, "unit": "GN iterations/s", "cores": int(os.environ.get("OMP_NUM_THREADS", "8")), "kind": "port",
+    return {"value": value, "unit": "GN iterations/s", "cores": os.cpu_count(), "threads": threads, "kind": "port",
             "sample": f"restated CPU reference (Ceres-2.1.0-equivalent, fp64) on a {n}-voxel cap of the same grid with all {sc['K']} keyframes, "
                       f"{iters} GN iterations in {dt:.1f}s; per-iteration time scaled linearly by the voxel ratio {scale:.1f} to the full workload "
-                      f"(residual collection single-threaded as in the reference, solve on 8 threads)",
+                      f"(residual collection single-threaded as in the reference, solve on {threads} threads like options.num_threads = 8; the host has {os.cpu_count()} cores)",
             "seconds_per_iteration_sample": sec_per_iter_sample, "parity_on_sample": parity}
 
 
@@ -152,6 +176,8 @@ def pmc_traffic(kernel, eg_rows, active):
         except Exception:
             continue
         # the row count drifts by ~1e-4 between GN iterations (rows appear / vanish as the surface moves): same workload = within 1 %
+        if d.get("kernel_tag") != KERNEL_TAG:
+            continue
         if abs(d.get("eg_rows", 0) - eg_rows) <= 0.01 * eg_rows and abs(d.get("active_voxels", 0) - active) <= 0.01 * active and kernel in d.get("kernels", {}):
             best = d["kernels"][kernel]["traffic_bytes_per_launch"] * (eg_rows / float(d["eg_rows"]))
     return best
@@ -229,14 +255,18 @@ def _main():
     if args.warmup > 0:
         ctx.optimize(make_cfg(binding, args, args.warmup, thres))
     ctx.timing_enable(not args.no_kernel_timing)
+    sharded_run = world > 1 or args.force_collectives
     if not args.all_kernel_timing:
-        ctx.timing_select(["eg_pass", "build"])      # the roofline kernels only: an event pair around EVERY launch costs ~8 % of the wall clock
+        # the roofline kernels only: an event pair around EVERY launch costs ~8 % of the wall clock (+ the exchange launches when sharded)
+        ctx.timing_select(["eg_pass", "build"] + (["comm"] if sharded_run else []))
     ctx.timing_get(reset=True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    stats = ctx.optimize(make_cfg(binding, args, args.steps, thres))
+    stats = []
+    while len(stats) < args.steps:          # the reference's call shape: 10 iterations per Optimizer::optimize, lambda schedule per call
+        stats += ctx.optimize(make_cfg(binding, args, min(CALL_ITERATIONS, args.steps - len(stats)), thres))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -248,26 +278,47 @@ def _main():
     sizes = ctx.problem_sizes()
     ctx.timing_enable(False)
 
-    # ---- roofline of the residual/Jacobian kernel (SURVEY.md §8d byte model) and of the PCG operator kernel -------
+    comm_stats = ctx.comm_stats() if sharded_run else None
+    transport = ctx.comm_transport() if sharded_run else ""
+
+    # ---- roofline of the residual/Jacobian kernel and of the PCG operator kernel, both on SURVEY.md §8(d)'s byte model ----
+    # build (K2+K3):   68 A + 132 Rg + 36 Rr + 12 Rs + 16 Ra + B_img
+    # operator (K6):   4 nnz, nnz = 29 Rg + 7 Rr + Rs + 2 Ra  — §8(d)'s fused single-pass J^T J p ("4 nnz + 12*4 n" is the whole PCG iteration;
+    #                  the 48 n of vector passes belong to the vector kernels, not to this one)
+    # `design_GB` beside it is what THIS implementation must move per launch by construction: 128 B per stored Eg row (29 partials, rho, frame,
+    # padding to 8 x 16 B) + per work-list entry the operator input 8, flags 6, local stencil slots 36, symmetric Ea weights 24, accumulators out 8
+    # + ~20 B per tile-halo slot (~1 per entry); Er / Es rows are not stored (constant coefficients), so their 4 nnz bytes are never read.
     A, Rg, Rr, Rs, Ra = sizes["active"], sizes["eg"], sizes["er"], sizes["es"], sizes["ea"]
+    nnz = 29.0 * Rg + 7.0 * Rr + Rs + 2.0 * Ra
     img_bytes = min(4.0 * args.frames * args.width * args.height, 256.0 * Rg)
     b_build = 68.0 * A + 132.0 * Rg + 36.0 * Rr + 12.0 * Rs + 16.0 * Ra + img_bytes
-    b_egpass = 132.0 * Rg + (14 + 8 + 2) * 4.0 * A          # 29 partials + 16 B row record; staged sums, regulariser t-values, vector gather per voxel
-    if world > 1:                                           # a rank streams its own share of the rows (its halo rows are not counted: conservative)
-        b_build /= world; b_egpass /= world
+    b_egpass = 4.0 * nnz
+    d_build = b_build
+    d_egpass = 128.0 * Rg + (8 + 6 + 36 + 24 + 8 + 20) * float(A)
+    if world > 1:                                           # a rank streams its own share of the rows (its ghost rows are not counted: conservative)
+        b_build /= world; b_egpass /= world; d_build /= world; d_egpass /= world
     kernels = {}
-    for name, bytes_per_launch in (("build", b_build), ("eg_pass", b_egpass)):
+    for name, bytes_per_launch, design in (("build", b_build, d_build), ("eg_pass", b_egpass, d_egpass)):
         ms, n = timing_work[name]
         if n > 0:
             avg = ms / n                     # HIP events around each launch on the library's stream, no-op launches excluded
             kernels[name] = {"launches": n, "launches_incl_noop": timing[name][1], "avg_ms": avg, "algorithmic_GB": bytes_per_launch / 1e9,
-                             "achieved_GBs": bytes_per_launch / 1e9 / (avg * 1e-3)}
+                             "design_GB": design / 1e9, "achieved_GBs": bytes_per_launch / 1e9 / (avg * 1e-3)}
+
+    def roof(name):
+        if name not in kernels:
+            return None
+        k = kernels[name]
+        return {"kernel": {"build": "k_build<true>", "eg_pass": "k_eg_tile"}[name], "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(name, Rg, A) if world == 1 else None}
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
-    roofline = None
-    if dominant:
-        k = kernels[dominant]
-        roofline = {"kernel": dominant, "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant, Rg, A) if world == 1 else None}
+    roofline = roof(dominant) if dominant else None
+    roofline_build = roof("build")           # the kernel the north star names, whichever one dominates
+    comm = None
+    if sharded_run:
+        ms, n = timing["comm"]; passes = max(1, timing["eg_pass"][1])
+        comm = {"transport": transport, "launch_ms_total": ms, "launches": n, "operator_passes": passes, "comm_us_per_pass": 1e3 * ms / passes,
+                "stats_rank0": comm_stats}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
@@ -282,15 +333,18 @@ def _main():
             "metric": "Gauss-Newton iterations/s at the finest SDF level", "value": args.steps / dt, "unit": "GN iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"parallelism": f"{world} rank(s): replicated voxel state, row work and solver vectors sharded by contiguous work-list ranges, RCCL all-reduce (PCG scalars + camera block) and all-gather (operator input)",
+            "config": {"parallelism": f"{world} rank(s), one per GPU: replicated voxel state; tile-aligned ownership of the brick-ordered work list, rim rows recomputed as ghosts; "
+                                       f"per PCG pass one neighbour exchange of the operator input on the rim + one all-reduce [camera block | p.q] + one of 4 scalars"
+                                       + (f" over {transport}" if transport else ""),
                        "workload": f"synthetic hashed SDF grid, {arrays['keys'].shape[0]} stored voxels @ {args.voxel_size * 1e3:g} mm "
                                    f"({A} in the thin shell), {args.frames} keyframes {args.width}x{args.height}, {sh_sub.shape[0]} SH subvolumes of {args.subvolume} m (estimated on the device, untimed), "
                                    f"joint SDF+albedo+pose+intrinsics+distortion, 5 observations/voxel (BASELINE.json configs[3] on one node)",
                        "stored_voxels": int(arrays["keys"].shape[0]), "active_voxels": A, "rows": {"Eg": Rg, "Er": Rr, "Es": Rs, "Ea": Ra},
                        "free_parameters": sizes["free"], "keyframes": args.frames, "image": [args.width, args.height],
                        "pcg_iterations_per_step": pcg, "lm_attempts": [int(s.num_attempts) for s in stats]},
-            "carry_trust_radius": bool(args.carry_radius),
-            "roofline": roofline, "kernels": kernels,
+            "carry_trust_radius": bool(args.carry_radius), "kernel_tag": KERNEL_TAG,
+            "optimize_calls": (args.steps + CALL_ITERATIONS - 1) // CALL_ITERATIONS, "iterations_per_call": min(CALL_ITERATIONS, args.steps),
+            "roofline": roofline, "roofline_build": roofline_build, "kernels": kernels, "comm": comm,
             "kernel_ms_total": {k: v[0] for k, v in timing.items()}, "kernel_launches": {k: v[1] for k, v in timing.items()},
             "time_split_ms_per_step": {"time_add": float(np.mean([s.time_add for s in stats]) * 1e3), "time_solve": float(np.mean([s.time_solve for s in stats]) * 1e3)},
             "cost": [float(stats[0].cost_initial), float(stats[-1].cost_final)],

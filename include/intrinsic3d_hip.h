@@ -270,11 +270,14 @@ int   i3d_shard_need(int32_t A, int32_t world, const int32_t* anbr /*[18][A]*/, 
  * plan of the last outer iteration (rim entries sent / received per pass, foreign tiles with ghost entries, compute-list length) */
 int   i3d_comm_stats(i3d_context* ctx, int64_t* halo_calls, int64_t* halo_bytes_sent, int64_t* reduce_calls, int64_t* reduce_bytes,
                      int32_t* halo_entries_send, int32_t* halo_entries_recv, int32_t* ghost_tiles, int32_t* compute_list);
+/* what carries the per-pass exchanges: "p2p-mailbox" (peer-to-peer stores over xGMI), "rccl" (fallback), "sim-*" (1-GPU rank simulation), "" without a communicator */
+const char* i3d_comm_transport(i3d_context* ctx);
 
 /* ---- measurement: HIP-event time (ms) and launch count accumulated per kernel family on the context's stream
  * since the last reset.  names: see i3d_kernel_name(). */
 enum { I3D_K_CLASSIFY = 0, I3D_K_OBSERVE, I3D_K_BUILD, I3D_K_EG_PASS /* J^T W J p passes of the PCG */, I3D_K_GATHER, I3D_K_COST, I3D_K_VECTOR, I3D_K_SH,
-       I3D_K_EG_AUX /* gradient and column-norm passes over the rows */, I3D_K_COUNT };
+       I3D_K_EG_AUX /* gradient and column-norm passes over the rows */,
+       I3D_K_COMM /* sharded runs: halo push, all-reduce, all-gather launches (GPU time incl. waiting for the peers) */, I3D_K_COUNT };
 int i3d_timing_enable(i3d_context* ctx, int32_t on);
 /* restrict the per-launch HIP events to the categories of the mask (bit = 1 << I3D_K_*; default: all).  An event pair around EVERY launch of a
  * Gauss-Newton iteration (~900 launches) costs ~8 % of its wall clock; bench.py times only what its roofline needs. */

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libintrinsic3d_hip.so")
 
-K_NAMES = ["classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh", "eg_aux"]
+K_NAMES = ["classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh", "eg_aux", "comm"]
 
 
 class OptimizerConfig(C.Structure):
@@ -73,7 +73,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_fusion_create", "i3d_fusion_destroy", "i3d_fusion_last_error", "i3d_fusion_integrate", "i3d_fusion_finish", "i3d_fusion_info", "i3d_fusion_get",
            "i3d_fusion_save", "i3d_shard_need", "i3d_comm_stats",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
-           "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
+           "i3d_comm_transport", "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_map_order", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
            "i3d_debug_normal_eq", "i3d_debug_jtj_apply"]
 
@@ -125,6 +125,7 @@ def load():
     L.i3d_timing_get.restype = i32; L.i3d_timing_get.argtypes = [vp, vp, vp, i32]
     L.i3d_timing_get_work.restype = i32; L.i3d_timing_get_work.argtypes = [vp, vp, vp]
     L.i3d_kernel_name.restype = C.c_char_p; L.i3d_kernel_name.argtypes = [i32]
+    L.i3d_comm_transport.restype = C.c_char_p; L.i3d_comm_transport.argtypes = [vp]
     L.i3d_problem_sizes.restype = i32; L.i3d_problem_sizes.argtypes = [vp, vp]
     L.i3d_debug_assemble.restype = i32; L.i3d_debug_assemble.argtypes = [vp, C.POINTER(OptimizerConfig), i32, C.POINTER(i32)]
     L.i3d_debug_flags.restype = i32; L.i3d_debug_flags.argtypes = [vp, vp]
@@ -371,6 +372,9 @@ class Context:
         a = [C.c_int64() for _ in range(4)]; b = [C.c_int32() for _ in range(4)]
         self._check(self.L.i3d_comm_stats(self.h, *[C.byref(x) for x in a], *[C.byref(x) for x in b]), "i3d_comm_stats")
         return dict(zip(["halo_calls", "halo_bytes_sent", "reduce_calls", "reduce_bytes", "halo_send", "halo_recv", "ghost_tiles", "compute_list"], [x.value for x in a + b]))
+
+    def comm_transport(self) -> str:
+        return (self.L.i3d_comm_transport(self.h) or b"").decode()
 
     def comm_init_sim(self, shared, rank: int):
         self._check(self.L.i3d_comm_init_sim(self.h, shared, int(rank)), "i3d_comm_init_sim")

@@ -17,6 +17,7 @@
 //            accumulated point by point; the rotation columns use  d(RP)/d omega = -R [P]x Jr  (Jr per keyframe), so the
 //            per-point work is one cross product instead of three 3x3 products.
 // The 16 bicubic taps of a point are 4 unaligned float4 loads (interior) instead of 16 scalar gathers.
+#include <cstdlib>
 #include "kernels.hpp"
 #include "reduce_device.hpp"
 
@@ -80,20 +81,26 @@ template <class T> static __device__ inline T hermite_der(T p0, T p1, T p2, T p3
     const T c = (T)0.5 * (-p0 + p2);
     return c + x * ((T)2.0 * b + (T)3.0 * a * x);
 }
-// BiCubicInterpolator::Evaluate(r = v, c = u) on a clamped Grid2D<float,1> (cost.h:108-127): value in fp64, derivatives in fp32
-template <bool WITH_J>
-static __device__ inline void bicubic(const float* __restrict__ img, int w, int h, double r, double c, double& f, float& dfdr, float& dfdc) {
+// BiCubicInterpolator::Evaluate(r = v, c = u) on a clamped Grid2D<float,1> (cost.h:108-127): value in fp64, derivatives in fp32.
+// Split in two so that the tap loads of ALL four stencil points of a row are in flight together (one memory round trip per row instead of
+// four dependent ones: the kernel runs two waves per SIMD and is latency-bound, not issue-bound): bicubic_taps only issues the 4 x 16 B
+// loads, bicubic_eval consumes them.
+struct Taps { float4 t[4]; double xc, xr; };
+static __device__ inline void bicubic_taps(const float* __restrict__ img, int w, int h, double r, double c, Taps& o) {
     const int row = (int)floor(r), col = (int)floor(c);
-    const double xc = c - (double)col, xr = r - (double)row;
-    float4 t[4];
+    o.xc = c - (double)col; o.xr = r - (double)row;
     const bool interior = col >= 1 && col + 2 <= w - 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rr = min(max(row - 1 + i, 0), h - 1);
         const gf_ptr line = (gf_ptr)(img + (size_t)rr * w);
-        if (interior) { const f4u v = *(gf4u_ptr)(line + (col - 1)); t[i] = make_float4(v.x, v.y, v.z, v.w); }
-        else t[i] = make_float4(line[min(max(col - 1, 0), w - 1)], line[min(max(col, 0), w - 1)], line[min(max(col + 1, 0), w - 1)], line[min(max(col + 2, 0), w - 1)]);
+        if (interior) { const f4u v = *(gf4u_ptr)(line + (col - 1)); o.t[i] = make_float4(v.x, v.y, v.z, v.w); }
+        else o.t[i] = make_float4(line[min(max(col - 1, 0), w - 1)], line[min(max(col, 0), w - 1)], line[min(max(col + 1, 0), w - 1)], line[min(max(col + 2, 0), w - 1)]);
     }
+}
+template <bool WITH_J>
+static __device__ inline void bicubic_eval(const Taps& k, double& f, float& dfdr, float& dfdc) {
+    const float4* t = k.t; const double xc = k.xc, xr = k.xr;
     double fr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fr[i] = hermite_val<double>((double)t[i].x, (double)t[i].y, (double)t[i].z, (double)t[i].w, xc);
@@ -112,9 +119,9 @@ struct PointVal {      // what phase 1 leaves for phase 2 (fp32)
     float x0, y0, iz, dfdr, dfdc;
 };
 
-// camera.h:96-116 (always distorts; y uses the distorted x) + cost.h:80-127.  Returns false if the projection leaves the image.
+// camera.h:96-116 (always distorts; y uses the distorted x) + cost.h:80-127: pixel coordinates (u, v) of P.  Returns false if the projection leaves the image.
 template <bool WITH_J>
-static __device__ inline bool eval_point(const double P[3], const double R[9], const double t[3], const float* __restrict__ img, const OptParams& p, double& lum, PointVal& o) {
+static __device__ inline bool project_point(const double P[3], const double R[9], const double t[3], const OptParams& p, double& u, double& v, PointVal& o) {
     const double X = R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + t[0];
     const double Y = R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1];
     const double Z = R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2];
@@ -125,11 +132,10 @@ static __device__ inline bool eval_point(const double P[3], const double R[9], c
     const double dc = 1.0 + p.dist[0] * r2 + p.dist[1] * r4 + p.dist[2] * r6;
     const double xd = x0 * dc + 2.0 * p.dist[3] * x0 * y0 + p.dist[4] * (r2 + 2.0 * x0 * x0);
     const double yd = y0 * dc + 2.0 * p.dist[4] * xd * y0 + p.dist[3] * (r2 + 2.0 * y0 * y0);
-    const double u = (p.intr[0] * ps) * xd + p.intr[2] * ps, v = (p.intr[1] * ps) * yd + p.intr[3] * ps;
+    u = (p.intr[0] * ps) * xd + p.intr[2] * ps; v = (p.intr[1] * ps) * yd + p.intr[3] * ps;
+    if (WITH_J) { o.x0 = (float)x0; o.y0 = (float)y0; o.iz = (float)iz; }
     if (u < 0.0 || u > (double)(p.w - 1) || v < 0.0 || v > (double)(p.h - 1)) return false;
     if (!(u == u) || !(v == v)) return false;      // NaN coordinates: Ceres' comparisons are all false -> in-bounds -> NaN lum -> invalid row
-    bicubic<WITH_J>(img, p.w, p.h, v, u, lum, o.dfdr, o.dfdc);
-    if (WITH_J) { o.x0 = (float)x0; o.y0 = (float)y0; o.iz = (float)iz; }
     return true;
 }
 
@@ -154,8 +160,8 @@ static __device__ inline float chroma_weight(uchar4 c, uchar4 cn) {
 
 // FR_LDS: the per-keyframe constants (144 B each) of ALL keyframes are staged in LDS once per workgroup — every row reads
 // R, t (and Jr) of its keyframe, and with them in global memory those wave-divergent gathers keep the texture-address unit busy.
-template <bool WITH_J, bool FR_LDS>
-__global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out) {
+template <bool WITH_J, bool FR_LDS, int BATCH>
+__global__ void __launch_bounds__(256, WITH_J ? 2 : (BATCH == 4 ? 3 : 4)) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out) {
     extern __shared__ double frame_lds_raw[];
     FrameHot* const flds = reinterpret_cast<FrameHot*>(frame_lds_raw);
     if (FR_LDS) {
@@ -284,12 +290,26 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
                 if (WITH_J) { const float ow = r.obs_w[ka]; f = r.obs_frame[ka]; roww = (ow > 0.0f) ? (float)((double)ow * weight_sdf) : 0.0f; }
                 else { const float4 m = r.rows[row_index(a, k, 7, r.slots)]; const int fb = __float_as_int(m.z); roww = (fb & ROW_FREE_BIT) ? m.x : 0.0f; f = fb & ~ROW_FREE_BIT; }
                 if (roww == 0.0f) continue;
+                if (p.dbg & 1) f = 0;               // experiment: every lane reads the same keyframe
                 const FrameHot& fc = FR_LDS ? flds[f] : frames[f].hot;
                 // ---- phase 1: values (fp64) ----
                 double lum[4]; PointVal pv[4];
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ok = ok && eval_point<WITH_J>(q[j].P, fc.R, fc.t, fc.lum, p, lum[j], pv[j]);
+                for (int j0 = 0; j0 < 4; j0 += BATCH) {
+                    if (!ok) break;             // a row with a point outside the image is dropped (cost.h:100-105)
+                    double pu[BATCH], pw[BATCH];
+#pragma unroll
+                    for (int j = 0; j < BATCH; ++j) ok = project_point<WITH_J>(q[j0 + j].P, fc.R, fc.t, p, pu[j], pw[j], pv[j0 + j]) && ok;
+                    if (p.dbg & 2) { for (int j = 0; j < BATCH; ++j) { pu[j] = 100.25 + j0 + j; pw[j] = 100.25; } ok = true; }      // experiment: coherent tap addresses
+                    if (ok) {
+                        Taps tp[BATCH];
+#pragma unroll
+                        for (int j = 0; j < BATCH; ++j) bicubic_taps(fc.lum, p.w, p.h, pw[j], pu[j], tp[j]);
+#pragma unroll
+                        for (int j = 0; j < BATCH; ++j) bicubic_eval<WITH_J>(tp[j], lum[j0 + j], pv[j0 + j].dfdr, pv[j0 + j].dfdc);
+                    }
+                }
                 double res = 0.0; float cj[4] = {0, 0, 0, 0};
                 if (ok) {
                     const double d1 = (q[1].B - q[0].B) - (lum[1] - lum[0]), d2 = (q[2].B - q[0].B) - (lum[2] - lum[0]), d3 = (q[3].B - q[0].B) - (lum[3] - lum[0]);
@@ -351,6 +371,7 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
                 for (int i = 0; i < P_TOTAL; ++i) fin = fin && !(isnan(J[i]) || isinf(J[i]));
                 if (!fin) continue;
                 // rows of a voxel are compacted into its first slots (creation order = ascending observation weight)
+                if (p.dbg & 4) { if (J[3] == 12345.0f) r.rows[0] = make_float4(J[0], J[1], J[2], J[5]); ++nout; continue; }      // experiment: no row stores
 #pragma unroll
                 for (int gq = 0; gq < 7; ++gq)
                     r.rows[row_index(a, nout, gq, r.slots)] = make_float4(J[4 * gq], J[4 * gq + 1], J[4 * gq + 2], J[4 * gq + 3]);
@@ -367,18 +388,28 @@ __global__ void __launch_bounds__(256) k_build(GridView g, RowView r, OptParams 
     if (!WITH_J) block_partial_d(cost, cost_out, 1, 0);          // per-workgroup partial (no same-address atomics), summed by k_reduce_partials
 }
 
+static int env_batch(const char* name, int dflt) { const char* e = std::getenv(name); const int v = e ? std::atoi(e) : dflt; return (v == 1 || v == 2 || v == 4) ? v : dflt; }
+
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out, double* scratch) {
     if (r.nC <= 0) return;
     const int blocks = (r.nC + 255) / 256;
     double* const cost_dst = cost_out; cost_out = scratch;       // the kernels write per-workgroup partials
     const size_t lds = (size_t)p.K * sizeof(FrameHot), qlds = (size_t)256 * Q_LDS_STRIDE;
+    // BATCH: the tap loads of how many stencil points of a row are in flight together (experiments: I3D_BUILD_BATCH / I3D_COST_BATCH = 1, 2, 4)
+    { static const int dbg = []() { const char* e = std::getenv("I3D_BUILD_DBG"); return e ? std::atoi(e) : 0; }(); p.dbg = dbg; }
+    static const int bj = env_batch("I3D_BUILD_BATCH", 2), bc = env_batch("I3D_COST_BATCH", 4);
     if (with_jacobian) {
-        // point records in LDS (74 KB per workgroup), per-keyframe constants from global memory: 244 VGPRs, no AGPR spills, TWO workgroups per CU.
+        // point records in LDS (74 KB per workgroup), per-keyframe constants from global memory: <= 256 VGPRs, TWO workgroups per CU.
         // (Measured: 2.13 -> 1.45 ms; with the keyframe constants staged in LDS as well only one workgroup fits and nothing is gained.)
-        (void)hipFuncSetAttribute((const void*)k_build<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
-        k_build<true, false><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out);
-    } else if (lds <= 48 * 1024) k_build<false, true><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
-    else k_build<false, false><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
+#define I3D_BJ(B) do { (void)hipFuncSetAttribute((const void*)k_build<true, false, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds); \
+                       k_build<true, false, B><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out); } while (0)
+        if (bj == 4) I3D_BJ(4); else if (bj == 2) I3D_BJ(2); else I3D_BJ(1);
+#undef I3D_BJ
+    } else if (lds <= 48 * 1024) {
+        if (bc == 4) k_build<false, true, 4><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
+        else if (bc == 2) k_build<false, true, 2><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
+        else k_build<false, true, 1><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
+    } else k_build<false, false, 2><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
     if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr);      // cost_dst += sum
 }
 

@@ -96,6 +96,7 @@ void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t, const int* cflag /* s
 // qacc[2 chunk] = J^T W J u on the voxel unknowns (raw), camera block added into `shared` (fp64), row-wise p.q partials; returns their number
 int  launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials /* or null */,
                     const PcgState* state);
+void launch_halo_fold(hipStream_t st, RowView r, TilePlan t, float* qacc, const PcgState* state);
 
 // ---- shard_kernels.hip: the sharding plan of one outer iteration ----------------------------------------------------------------
 void launch_need_mask(hipStream_t st, RowView r, int slice, unsigned long long* need /* [A], zeroed */);

@@ -489,8 +489,6 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
     };
     run(t.ntiles_own, t.tile_first, nullptr, true);
     run(t.n_ghost, 0, t.ghost_tiles, false);                  // foreign tiles: a few ghost rows each, run-time row loop (no rows are fetched for the other lanes)
-    const int n = tile_plan_tiles(r.A) * HMAX;
-    k_halo_fold<<<(n + 255) / 256, 256, 0, st>>>(n, t.ext_e, t.ext_pos, t.qh, qacc, r.chunk, state);
     return written;                                          // number of p.q partials written
 }
 
@@ -500,6 +498,12 @@ int launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TileP
     if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     if (tp_T() == 1024) return launch_eg_tile_t<1024, 2048>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
     return launch_eg_tile_t<512, 1536>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
+}
+// halo accumulators of all tiles -> the per-entry accumulators (sorted by target entry at plan time; timed as its own category)
+void launch_halo_fold(hipStream_t st, RowView r, TilePlan t, float* qacc, const PcgState* state) {
+    if (r.A <= 0) return;
+    const int n = tile_plan_tiles(r.A) * tp_H();
+    k_halo_fold<<<(n + 255) / 256, 256, 0, st>>>(n, t.ext_e, t.ext_pos, t.qh, qacc, r.chunk, state);
 }
 int tile_plan_T() { return tp_T(); }
 

@@ -92,6 +92,8 @@ int i3d_comm_stats(i3d_context* c, int64_t* halo_calls, int64_t* halo_bytes_sent
     return I3D_OK;
 }
 
+const char* i3d_comm_transport(i3d_context* c) { return (c && c->comm) ? c->comm->transport : ""; }
+
 int i3d_debug_assemble(i3d_context* c, const i3d_optimizer_config* cfg, int32_t iteration, int32_t* slots_out) {
     if (!c || !cfg) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_debug_assemble: null argument");
     CTX_HIP(c, hipSetDevice(c->device));

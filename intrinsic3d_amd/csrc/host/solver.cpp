@@ -85,16 +85,19 @@ static Layout layout_of(const i3d_context* c) {
 static bool sharded(const i3d_context* c) { return c->comm && (c->comm->world > 1 || c->comm->force); }
 static int allreduce(i3d_context* c, double* dev, size_t n) {
     if (!sharded(c)) return I3D_OK;
+    TimedScope t(c, I3D_K_COMM);
     return c->comm->allreduce_sum(dev, n, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "all-reduce failed") : I3D_OK;
 }
 static int allgather(i3d_context* c, float* vec) {       // every rank contributes its two segments of a solver vector
     if (!sharded(c)) return I3D_OK;
     const size_t slice = (size_t)(c->chunk / c->comm->world);
+    TimedScope t(c, I3D_K_COMM);
     if (c->comm->allgather(vec, slice, c->stream) || c->comm->allgather(vec + c->chunk, slice, c->stream)) return ctx_fail(c, I3D_ERR_COMM, "all-gather failed");
     return I3D_OK;
 }
 static int push_halo(i3d_context* c, float* vec) {       // the rim of the operator input (common.hpp: sharding)
     if (!sharded(c)) return I3D_OK;
+    TimedScope t(c, I3D_K_COMM);
     return c->comm->push_halo(vec, c->halo, c->stream) ? ctx_fail(c, I3D_ERR_COMM, "halo exchange failed") : I3D_OK;
 }
 
@@ -227,6 +230,7 @@ static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const flo
     if (mode == PASS_COLNORM) CTX_HIP(c, hipMemsetAsync(c->d_blocks.p, 0, sizeof(double) * (21 * (size_t)c->K + 25), s));
     if (mode == PASS_JTJP && c->tile_ok && !sharded(c)) {        // the PCG's tiled operator pass (raw accumulators straight into `out`)
         { TimedScope t(c, I3D_K_EG_PASS); launch_eg_tile(s, r, p, u, c->tile_plan(), c->d_shared.p, out, nullptr, nullptr); }
+        { TimedScope t(c, I3D_K_GATHER); launch_halo_fold(s, r, c->tile_plan(), out, nullptr); }
         { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, 2 * c->chunk, c->v_mask.p, out, out); }      // the raw accumulators also cover fixed unknowns (the PCG multiplies them by S = 0)
     } else {
         { TimedScope t(c, mode == PASS_JTJP ? I3D_K_EG_PASS : I3D_K_EG_AUX); launch_eg_pass(s, mode, g, r, p, u, b, nullptr); }
@@ -325,6 +329,7 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
         if (tiled) {
             { TimedScope t(c, I3D_K_EG_PASS);
               n_pq = launch_eg_tile(s, r, p, c->v_u.p, c->tile_plan(), c->d_shared.p, c->v_qacc.p, with_dot ? pq_part : nullptr, st); }
+            { TimedScope t(c, I3D_K_GATHER); launch_halo_fold(s, r, c->tile_plan(), c->v_qacc.p, st); }
             if (!with_dot) n_pq = 0;
             if (!multi) return I3D_OK;
             // the rank's p.q (rows + D^2 p^2 of its slice) rides with the camera block

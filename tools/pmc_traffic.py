@@ -3,15 +3,16 @@
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --pmc-calibrate
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --pmc-calibrate
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/bench_pmc.json profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/bench_pmc.json profiles/r02_pmc_traffic.json
 
 Calibration (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x and WRITE_SIZE is
 uncalibrated): bench.py --pmc-calibrate launches a device copy of exactly 2^30 B; the raw counter of that kernel gives the factor
-bytes-per-count for 16 B/lane streaming accesses, which is what the row streams of k_eg_pass / k_build are.  Both the raw counter
+bytes-per-count for 16 B/lane streaming accesses, which is what the row streams of k_eg_tile / k_build are.  Both the raw counter
 means and the factors are written out so the correction can be audited."""
 import collections, csv, glob, json, re, sys
 
-KERNELS = {"eg_pass": r"k_eg_jtjp|k_eg_pass<1>", "eg_pass_gradient": r"k_eg_pass<0>", "eg_pass_diag": r"k_eg_pass<2>", "gather": r"k_gather<false, true>",
+KERNELS = {"eg_pass": r"k_eg_tile", "halo_fold": r"k_halo_fold", "pcg_step": r"k_pcg_step", "pcg_direction": r"k_pcg_direction",
+           "eg_pass_untiled": r"k_eg_jtjp|k_eg_pass<1>", "eg_pass_gradient": r"k_eg_pass<0>", "eg_pass_diag": r"k_eg_pass<2>", "gather": r"k_gather<false, true>",
            "build": r"k_build<true", "cost": r"k_build<false", "observe": r"k_observe", "copy_1GiB": r"(elementwise|vectorized|copy).*"}
 COPY_BYTES = float(1 << 30)
 
@@ -57,7 +58,7 @@ def main():
            "calibration": {"copy_bytes": COPY_BYTES, "FETCH_SIZE_raw_of_copy": cf, "WRITE_SIZE_raw_of_copy": cw,
                            "bytes_per_FETCH_SIZE_count": f_read, "bytes_per_WRITE_SIZE_count": f_write,
                            "note": "factor measured on a 16 B/lane streaming copy of 2^30 B; applied to every kernel below"},
-           "eg_rows": bench["config"]["rows"]["Eg"], "active_voxels": bench["config"]["active_voxels"], "kernels": {}}
+           "kernel_tag": bench.get("kernel_tag"), "eg_rows": bench["config"]["rows"]["Eg"], "active_voxels": bench["config"]["active_voxels"], "kernels": {}}
     for name, pat in KERNELS.items():
         if name == "copy_1GiB":
             continue
