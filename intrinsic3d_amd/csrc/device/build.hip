@@ -17,7 +17,6 @@
 //            accumulated point by point; the rotation columns use  d(RP)/d omega = -R [P]x Jr  (Jr per keyframe), so the
 //            per-point work is one cross product instead of three 3x3 products.
 // The 16 bicubic taps of a point are 4 unaligned float4 loads (interior) instead of 16 scalar gathers.
-#include <cstdlib>
 #include "kernels.hpp"
 #include "reduce_device.hpp"
 
@@ -161,7 +160,7 @@ static __device__ inline float chroma_weight(uchar4 c, uchar4 cn) {
 // FR_LDS: the per-keyframe constants (144 B each) of ALL keyframes are staged in LDS once per workgroup — every row reads
 // R, t (and Jr) of its keyframe, and with them in global memory those wave-divergent gathers keep the texture-address unit busy.
 template <bool WITH_J, bool FR_LDS, int BATCH>
-__global__ void __launch_bounds__(256, WITH_J ? 2 : (BATCH == 4 ? 3 : 4)) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out) {
+__global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out) {
     extern __shared__ double frame_lds_raw[];
     FrameHot* const flds = reinterpret_cast<FrameHot*>(frame_lds_raw);
     if (FR_LDS) {
@@ -290,7 +289,6 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : (BATCH == 4 ? 3 : 4)) k_buil
                 if (WITH_J) { const float ow = r.obs_w[ka]; f = r.obs_frame[ka]; roww = (ow > 0.0f) ? (float)((double)ow * weight_sdf) : 0.0f; }
                 else { const float4 m = r.rows[row_index(a, k, 7, r.slots)]; const int fb = __float_as_int(m.z); roww = (fb & ROW_FREE_BIT) ? m.x : 0.0f; f = fb & ~ROW_FREE_BIT; }
                 if (roww == 0.0f) continue;
-                if (p.dbg & 1) f = 0;               // experiment: every lane reads the same keyframe
                 const FrameHot& fc = FR_LDS ? flds[f] : frames[f].hot;
                 // ---- phase 1: values (fp64) ----
                 double lum[4]; PointVal pv[4];
@@ -301,7 +299,6 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : (BATCH == 4 ? 3 : 4)) k_buil
                     double pu[BATCH], pw[BATCH];
 #pragma unroll
                     for (int j = 0; j < BATCH; ++j) ok = project_point<WITH_J>(q[j0 + j].P, fc.R, fc.t, p, pu[j], pw[j], pv[j0 + j]) && ok;
-                    if (p.dbg & 2) { for (int j = 0; j < BATCH; ++j) { pu[j] = 100.25 + j0 + j; pw[j] = 100.25; } ok = true; }      // experiment: coherent tap addresses
                     if (ok) {
                         Taps tp[BATCH];
 #pragma unroll
@@ -371,7 +368,6 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : (BATCH == 4 ? 3 : 4)) k_buil
                 for (int i = 0; i < P_TOTAL; ++i) fin = fin && !(isnan(J[i]) || isinf(J[i]));
                 if (!fin) continue;
                 // rows of a voxel are compacted into its first slots (creation order = ascending observation weight)
-                if (p.dbg & 4) { if (J[3] == 12345.0f) r.rows[0] = make_float4(J[0], J[1], J[2], J[5]); ++nout; continue; }      // experiment: no row stores
 #pragma unroll
                 for (int gq = 0; gq < 7; ++gq)
                     r.rows[row_index(a, nout, gq, r.slots)] = make_float4(J[4 * gq], J[4 * gq + 1], J[4 * gq + 2], J[4 * gq + 3]);
@@ -388,28 +384,18 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : (BATCH == 4 ? 3 : 4)) k_buil
     if (!WITH_J) block_partial_d(cost, cost_out, 1, 0);          // per-workgroup partial (no same-address atomics), summed by k_reduce_partials
 }
 
-static int env_batch(const char* name, int dflt) { const char* e = std::getenv(name); const int v = e ? std::atoi(e) : dflt; return (v == 1 || v == 2 || v == 4) ? v : dflt; }
-
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out, double* scratch) {
     if (r.nC <= 0) return;
     const int blocks = (r.nC + 255) / 256;
     double* const cost_dst = cost_out; cost_out = scratch;       // the kernels write per-workgroup partials
     const size_t lds = (size_t)p.K * sizeof(FrameHot), qlds = (size_t)256 * Q_LDS_STRIDE;
-    // BATCH: the tap loads of how many stencil points of a row are in flight together (experiments: I3D_BUILD_BATCH / I3D_COST_BATCH = 1, 2, 4)
-    { static const int dbg = []() { const char* e = std::getenv("I3D_BUILD_DBG"); return e ? std::atoi(e) : 0; }(); p.dbg = dbg; }
-    static const int bj = env_batch("I3D_BUILD_BATCH", 2), bc = env_batch("I3D_COST_BATCH", 4);
     if (with_jacobian) {
-        // point records in LDS (74 KB per workgroup), per-keyframe constants from global memory: <= 256 VGPRs, TWO workgroups per CU.
+        // point records in LDS (74 KB per workgroup), per-keyframe constants from global memory: 247 VGPRs, no spills, TWO workgroups per CU.
         // (Measured: 2.13 -> 1.45 ms; with the keyframe constants staged in LDS as well only one workgroup fits and nothing is gained.)
-#define I3D_BJ(B) do { (void)hipFuncSetAttribute((const void*)k_build<true, false, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds); \
-                       k_build<true, false, B><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out); } while (0)
-        if (bj == 4) I3D_BJ(4); else if (bj == 2) I3D_BJ(2); else I3D_BJ(1);
-#undef I3D_BJ
-    } else if (lds <= 48 * 1024) {
-        if (bc == 4) k_build<false, true, 4><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
-        else if (bc == 2) k_build<false, true, 2><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
-        else k_build<false, true, 1><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
-    } else k_build<false, false, 2><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
+        (void)hipFuncSetAttribute((const void*)k_build<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
+        k_build<true, false, 2><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out);
+    } else if (lds <= 48 * 1024) k_build<false, true, 2><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);
+    else k_build<false, false, 2><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
     if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr);      // cost_dst += sum
 }
 

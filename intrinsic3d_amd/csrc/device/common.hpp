@@ -146,7 +146,6 @@ struct OptParams {                  // scalar state of one outer iteration
     double intr[4]; double dist[5];  // level-0 intrinsics, distortion
     float cam_f[4]; float dist_f[5]; int dist_zero; int w, h;   // float camera of the observation pass (scaled)
     int fix_poses, fix_intr, fix_dist, fix_sdf;
-    int dbg;                        // experiments only (I3D_BUILD_DBG, build.hip): 0 in every product run
 };
 
 #define I3D_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \

@@ -1,6 +1,7 @@
 // Launch wrappers of the gfx950 kernels (definitions in *.hip).  All launches go to the given stream.
 #pragma once
 #include "common.hpp"
+#include "p2p_device.hpp"
 
 namespace i3d {
 
@@ -70,12 +71,13 @@ int  launch_pcg_step(hipStream_t st, int mode, Seg2 sg, const float* p, const fl
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state);
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
                        const float* D2, float* z, const double* partials, int nblk, PcgState* state,           // camera tail + Q-test + rho, beta;
-                       double* shared_zero, int nzero, int* host_flags, int seq);                              // zeroes the camera accumulator, publishes (seq, done) to pinned memory
+                       double* shared_zero, int nzero, int* host_flags, int seq,                               // zeroes the camera accumulator, publishes (seq, done) to pinned memory
+                       const P2PDev& pd);                                                                      // pd.on: sum the slice sums over the ranks in the kernel (p2p_device.hpp)
 int  launch_pcg_direction(hipStream_t st, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2,
                           double* d2_partials /* or null */, const PcgState* state);   // p = z + beta p, u = S p (slice + ntail tail entries); returns the number of D^2 p^2 partials
-void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
+void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, double* shared, const double* pq_slice, const double* pq_partials, int nblk,
                        const double* pq_partials2, int nblk2, bool rowwise,
-                       float* q, const float* S, const float* D2, const float* v, PcgState* state);                                                          // camera tail of q, p.q, alpha
+                       float* q, const float* S, const float* D2, const float* v, PcgState* state, const P2PDev& pd);                                        // camera tail of q, p.q, alpha (pd.on: [camera block | p.q] summed over the ranks in the kernel)
 // ---- tile_pass.hip: the LDS-tiled operator pass of the PCG (single rank) ----------------------------------------------------------
 struct TilePlan {                   // built once per outer iteration by launch_tile_plan
     unsigned* lnbr;                 // [9][Acap] local slots (uint16 pairs): 12 stencil neighbours read + 6 further in-tile sources

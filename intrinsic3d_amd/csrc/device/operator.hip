@@ -678,13 +678,25 @@ __global__ void k_pcg_tail_x(size_t to, int NS, const float* __restrict__ p, flo
 __global__ void __launch_bounds__(1024) k_pcg_tail_a(int mode, size_t to, int K, const float* __restrict__ Mblk, const float* __restrict__ p, const float* __restrict__ q,
                                                     float* __restrict__ x, float* __restrict__ r, const float* __restrict__ b, const float* __restrict__ D2,
                                                     float* __restrict__ z, const double* __restrict__ partials, int nblk, PcgState* st,
-                                                    double* __restrict__ shared_zero, int nzero, int* host_flags, int seq) {
+                                                    double* __restrict__ shared_zero, int nzero, int* host_flags, int seq, P2PDev pd) {
     // (seq, done) goes to a 2-slot ring in pinned host memory: the host polls it instead of queueing a copy + event per pass
     auto publish = [&]() { if (host_flags) { __hip_atomic_store(&host_flags[2 * (seq & 1) + 1], st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                              __hip_atomic_store(&host_flags[2 * (seq & 1)], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); } };
-    if (st->done) { if (threadIdx.x == 0) publish(); return; }
+    if (st->done) { if (threadIdx.x == 0) publish(); return; }        // (the same decision on every rank: the scalars are replicated bit for bit)
     for (int i = threadIdx.x; i < nzero; i += blockDim.x) shared_zero[i] = 0.0;      // camera block + p.q slot of the pass that starts here
     __shared__ double red[16][4];
+    if (pd.on) {        // sharded, peer-to-peer transport: this rank's slice sums -> acc, summed over the ranks right here (no reduction launches)
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < nblk; i += blockDim.x) { for (int k = 0; k < 4; ++k) v[k] += partials[4 * (size_t)i + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
+        if ((threadIdx.x & 63) == 0) { for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = v[k]; }
+        __syncthreads();
+        if (threadIdx.x < 4) { double t = st->acc[threadIdx.x]; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][threadIdx.x]; st->acc[threadIdx.x] = t; }
+        __syncthreads();
+        p2p_allreduce_wg(pd, st->acc, 4);
+        nblk = 0;
+    }
     const int NS = 6 * K + 9;
     const float alpha = (float)st->alpha;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -772,12 +784,24 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int n4, int seg4, size_t 
 }
 
 // camera tail of q = (S J^T W J S + D^2) p from the (all-reduced) fp64 camera block, p.q, alpha = rho / p.q
-__global__ void __launch_bounds__(1024) k_pcg_tail_b(size_t to, int K, OptParams p, const double* __restrict__ shared, const double* __restrict__ pq_slice,
+__global__ void __launch_bounds__(1024) k_pcg_tail_b(size_t to, int K, OptParams p, double* shared, const double* pq_slice,
                                                     const double* __restrict__ pq_partials, int nblk, const double* __restrict__ pq_partials2, int nblk2, int rowwise,
-                                                    float* __restrict__ q, const float* __restrict__ S, const float* __restrict__ D2, const float* __restrict__ v, PcgState* st) {
+                                                    float* __restrict__ q, const float* __restrict__ S, const float* __restrict__ D2, const float* __restrict__ v, PcgState* st, P2PDev pd) {
     if (st->done) return;
     __shared__ double red[16];
     const int NS = 6 * K + 9;
+    if (pd.on) {        // sharded, peer-to-peer transport: this rank's p.q (rows + D^2 p^2 of its slice) joins the camera block, [6K+9 | p.q] is summed over the ranks here
+        double d = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += blockDim.x) d += pq_partials[i];
+        for (int i = threadIdx.x; i < nblk2; i += blockDim.x) d += pq_partials2[i];
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) { double t = shared[NS]; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w]; shared[NS] = t; }
+        __syncthreads();
+        p2p_allreduce_wg(pd, shared, NS + 1);
+        nblk = 0; nblk2 = 0;
+    }
     double dotp = 0.0;
     for (int i = threadIdx.x; i < NS; i += blockDim.x) {
         const bool fixed = i < 6 * K ? p.fix_poses : (i < 6 * K + 4 ? p.fix_intr : p.fix_dist);
@@ -809,7 +833,7 @@ __global__ void k_pcg_init(PcgState* st, int fixed_iterations, int max_iteration
 }
 
 void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations) { k_pcg_init<<<1, 1, 0, st>>>(state, fixed_iterations, max_iterations); }
-static inline int step_blocks(int n4) { int b = (n4 + 255) / 256; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
+static inline int step_blocks(int n4) { int b = (n4 + 255) / 256; return b < 1 ? 1 : (b > 2048 ? 2048 : b); }      // 64 VGPRs: 8 waves per SIMD = 2048 workgroups of 256 in flight
 // off and n must be multiples of 4 (the rank-major layout pads every slice to a multiple of 8 floats)
 int launch_pcg_step(hipStream_t st, int mode, Seg2 sg, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
                     float* z, const float* S_for_inline_q, double* partials, PcgState* state) {
@@ -832,8 +856,8 @@ int launch_pcg_step(hipStream_t st, int mode, Seg2 sg, const float* p, const flo
 }
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state) { k_pcg_tail_x<<<1, 256, 0, st>>>(tail_off, 6 * K + 9, p, x, state); }
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
-                       const float* D2, float* z, const double* partials, int nblk, PcgState* state, double* shared_zero, int nzero, int* host_flags, int seq) {
-    k_pcg_tail_a<<<1, 1024, 0, st>>>(mode, tail_off, K, Minv_blocks, p, q, x, r, b, D2, z, partials, nblk, state, shared_zero, nzero, host_flags, seq);
+                       const float* D2, float* z, const double* partials, int nblk, PcgState* state, double* shared_zero, int nzero, int* host_flags, int seq, const P2PDev& pd) {
+    k_pcg_tail_a<<<1, 1024, 0, st>>>(mode, tail_off, K, Minv_blocks, p, q, x, r, b, D2, z, partials, nblk, state, shared_zero, nzero, host_flags, seq, pd);
 }
 int launch_pcg_direction(hipStream_t st, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, double* d2_partials,
                          const PcgState* state) {
@@ -844,9 +868,9 @@ int launch_pcg_direction(hipStream_t st, Seg2 sg, size_t tail_off, int ntail, co
     k_pcg_direction<<<blocks, 256, 0, st>>>(n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, d2_partials, state);
     return d2_partials ? blocks : 0;
 }
-void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, const double* pq_slice, const double* pq_partials, int nblk,
-                       const double* pq_partials2, int nblk2, bool rowwise, float* q, const float* S, const float* D2, const float* v, PcgState* state) {
-    k_pcg_tail_b<<<1, 1024, 0, st>>>(tail_off, K, p, shared, pq_slice, pq_partials, nblk, pq_partials2, nblk2, rowwise ? 1 : 0, q, S, D2, v, state);
+void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, double* shared, const double* pq_slice, const double* pq_partials, int nblk,
+                       const double* pq_partials2, int nblk2, bool rowwise, float* q, const float* S, const float* D2, const float* v, PcgState* state, const P2PDev& pd) {
+    k_pcg_tail_b<<<1, 1024, 0, st>>>(tail_off, K, p, shared, pq_slice, pq_partials, nblk, pq_partials2, nblk2, rowwise ? 1 : 0, q, S, D2, v, state, pd);
 }
 
 // ---- LM candidate / acceptance ------------------------------------------------------------------------------------------

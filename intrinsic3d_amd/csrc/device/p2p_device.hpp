@@ -1,0 +1,72 @@
+// Device side of the peer-to-peer mailbox transport (host/p2p.cpp): the all-reduce of a few doubles as a function a SINGLE-WORKGROUP
+// kernel can call in the middle of its own work.  The PCG's boundary kernels (k_pcg_tail_a / k_pcg_tail_b, operator.hip) are such kernels:
+// with the exchange inside them a sharded pass has no separate reduction launches at all (every tiny launch costs 5-10 us of GPU timeline,
+// as much as a rank's share of the operator at 8 GPUs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+namespace i3d {
+
+constexpr int P2P_MAX_RANKS = 64;
+constexpr unsigned long long P2P_SPIN_LIMIT = 4000000000ull;       // ~2 s of s_memtime ticks
+
+struct P2PLayout { int world, red_cap, halo_cap; size_t off_red, off_halo, bytes; };
+struct PeerPtrs { unsigned char* m[P2P_MAX_RANKS]; };             // every rank's mailbox as seen from this device
+// handle passed BY VALUE to kernels; on == 0: no transport (the kernel behaves as on a single rank)
+struct P2PDev { int on, me; P2PLayout L; int* err; unsigned long long* epoch_red /* device counter of the all-reduces performed so far */; PeerPtrs peers; };
+
+// Mailbox words are SELF-VALIDATING (the "LL" idea of the collective libraries): every 8-byte word carries 4 bytes of payload and the low 32
+// bits of the exchange's epoch, written by ONE 8-byte store and polled by 8-byte loads.  An 8-byte store is atomic, so a reader that sees the
+// epoch sees the payload: no release fence (at agent / system scope that is a write-back of the whole L2, microseconds on every exchange), no
+// separate flag and no acquire fence (an L2 invalidate) — the latency of an exchange is one store crossing the link plus the poll.
+static __device__ inline unsigned long long* p2p_red_words(unsigned char* mb, const P2PLayout& L, int par, int sender) { return reinterpret_cast<unsigned long long*>(mb + L.off_red) + ((size_t)par * L.world + sender) * 2 * L.red_cap; }
+static __device__ inline unsigned long long* p2p_halo_words(unsigned char* mb, const P2PLayout& L, int par, int sender) { return reinterpret_cast<unsigned long long*>(mb + L.off_halo) + ((size_t)par * L.world + sender) * 2 * L.halo_cap; }
+static __device__ inline void p2p_put(unsigned long long* w, unsigned payload, unsigned epoch32) {
+    __hip_atomic_store(w, ((unsigned long long)epoch32 << 32) | (unsigned long long)payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// bounded wait for the word of this epoch; a timeout latches *err (the host turns it into I3D_ERR_COMM) and returns 0
+static __device__ inline unsigned p2p_get(unsigned long long* w, unsigned epoch32, int* err) {
+    unsigned long long x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)(x >> 32) == epoch32) return (unsigned)x;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(x >> 32) == epoch32) return (unsigned)x;
+        if (__builtin_readcyclecounter() - t0 > P2P_SPIN_LIMIT) { atomicExch(err, 1); return 0u; }
+    }
+}
+
+// dev[0..n) <- sum over ranks in rank order (bit-identical on every rank).  Called by ALL threads of a single-workgroup kernel; n <= L.red_cap.
+// The epoch is a DEVICE counter advanced by every exchange actually performed: ranks that skip the same exchanges (a solve that has
+// converged skips its remaining boundary kernels on every rank alike) stay in step, and two consecutive exchanges always use the two
+// different parity buffers (a rank cannot run two exchanges ahead of a peer: it needs that peer's contribution to the one in between, and the
+// peer sends that only after it has consumed this one).  Epoch 0 is never used (the mailbox starts zeroed).
+static __device__ inline void p2p_allreduce_wg(const P2PDev& d, double* dev, int n) {
+    __shared__ unsigned long long epoch_s;
+    if (threadIdx.x == 0) { unsigned long long e = *d.epoch_red + 1; if ((unsigned)e == 0u) ++e; epoch_s = e; }
+    __syncthreads();
+    const unsigned long long epoch = epoch_s;
+    const unsigned e32 = (unsigned)epoch;
+    const int par = (int)(epoch & 1ull), W = d.L.world, me = d.me;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double x = dev[i];
+        const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+        for (int k = 0; k < W; ++k) { unsigned long long* dst = p2p_red_words(d.peers.m[k], d.L, par, me); p2p_put(&dst[2 * i], lo, e32); p2p_put(&dst[2 * i + 1], hi, e32); }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double s = 0.0;
+        for (int j = 0; j < W; ++j) {
+            unsigned long long* src = p2p_red_words(d.peers.m[me], d.L, par, j);
+            const unsigned lo = p2p_get(&src[2 * i], e32, d.err), hi = p2p_get(&src[2 * i + 1], e32, d.err);
+            s += __hiloint2double((int)hi, (int)lo);
+        }
+        dev[i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *d.epoch_red = epoch;
+    __syncthreads();
+}
+
+}  // namespace i3d

@@ -20,6 +20,7 @@ struct RcclComm : Comm {
     ~RcclComm() override { p2p.destroy(); if (comm) ncclCommDestroy(comm); }
     int plan_changed(const HaloPlan& h, hipStream_t st) override { return use_p2p ? p2p.set_halo_lists(h, st) : 0; }
     int health(hipStream_t st) override { return use_p2p ? p2p.check(st) : 0; }
+    bool device_reduce(P2PDev* dev) override { if (!use_p2p) return false; *dev = p2p.device(); return true; }
     int allreduce_sum(double* dev, size_t n, hipStream_t st) override {
         ++reduce_calls; reduce_bytes += 8ll * (long long)n;
         if (use_p2p && (int)n <= p2p.L.red_cap) return p2p.allreduce(dev, n, st);
@@ -138,6 +139,7 @@ struct SimComm : Comm {
     }
     int plan_changed(const HaloPlan& h, hipStream_t st) override { attach(); return use_p2p ? p2p.set_halo_lists(h, st) : 0; }
     int health(hipStream_t st) override { return use_p2p ? p2p.check(st) : 0; }
+    bool device_reduce(P2PDev* dev) override { attach(); if (!use_p2p) return false; *dev = p2p.device(); return true; }
     int allreduce_sum(double* dev, size_t n, hipStream_t st) override {
         ++reduce_calls; reduce_bytes += 8ll * (long long)n;
         attach();

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <vector>
+#include "../device/p2p_device.hpp"
 
 namespace i3d {
 
@@ -32,6 +33,9 @@ struct Comm {
     virtual int allgather(float* dev, size_t count, hipStream_t st) = 0;
     // vec[e], vec[chunk + e] of the entries in the send lists -> the same positions of the peers' copies of vec (their recv lists)
     virtual int push_halo(float* vec, const HaloPlan& h, hipStream_t st) = 0;
+    // true: all-reduces of a few doubles can run INSIDE single-workgroup kernels (p2p_allreduce_wg with *dev); the caller logs them with count_reduce
+    virtual bool device_reduce(P2PDev* dev) { (void)dev; return false; }
+    void count_reduce(size_t n) { ++reduce_calls; reduce_bytes += 8ll * (long long)n; }
     // called once per outer iteration after the halo plan changed; 0 = ok
     virtual int plan_changed(const HaloPlan&, hipStream_t) { return 0; }
     // 0 = healthy; non-zero after a peer-to-peer wait timed out (synchronises the stream)

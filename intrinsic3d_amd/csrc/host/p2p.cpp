@@ -1,13 +1,15 @@
 // Peer-to-peer mailbox transport for what the sharded PCG exchanges every pass (comm.hpp): the small fp64 all-reduce
 // [camera block | p.q] / [4 iteration scalars] and the rim of the operator input.  xGMI is point to point and fully connected
 // inside a node, and both messages are latency-bound (10 KB / a few tens of KB per pair): instead of a collective library's
-// kernels (~40 us per launch here) every rank STORES its contribution straight into a mailbox in each peer's HBM, publishes an
-// epoch flag, waits for the peers' flags and consumes — one single-workgroup kernel per exchange, no host involvement.
+// kernels (~40 us per launch here) every rank STORES its contribution straight into a mailbox in each peer's HBM and polls its
+// own mailbox for the peers' — no host involvement, and for the reductions not even a kernel of their own (p2p_device.hpp:
+// p2p_allreduce_wg runs inside the PCG's boundary kernels).
 //   * mailbox memory is fine-grained (uncached in the consumer's L2), mapped into the peers by HIP IPC (one process per GPU) or
 //     shared by pointer (rank simulation on one GPU);
-//   * publish = system-scope release fence + relaxed system-scope flag store per peer; consume = relaxed polling of the own
-//     flags, one system-scope acquire fence, then plain loads (MI355X_MICROARCH.md, inter-workgroup visibility — system instead
-//     of agent scope because the producer is another device);
+//   * every 8-byte mailbox word carries 4 payload bytes + the low 32 bits of the exchange's epoch and is written by one atomic
+//     8-byte system-scope store / read by 8-byte system-scope loads: a word that shows the epoch shows the payload.  No fences —
+//     a release fence at agent or system scope writes back the whole L2 and an acquire invalidates it, microseconds per exchange
+//     (measured on one GPU: 9.7 us for the fenced flag protocol as a kernel of its own);
 //   * two buffers by epoch parity: a rank cannot run two exchanges ahead of a peer (it needs that peer's contribution to the
 //     exchange in between), so the buffer of epoch e is free again when e + 2 is written;
 //   * the sum runs over the ranks in rank order on every rank: all ranks hold bit-identical results (the replicated camera
@@ -19,81 +21,41 @@
 
 namespace i3d {
 
-constexpr unsigned long long P2P_SPIN_LIMIT = 4000000000ull;       // ~2 s of s_memtime ticks
-
-struct PeerPtrs { unsigned char* m[P2P_MAX_RANKS]; };
-
-static __device__ inline unsigned long long* red_flag(unsigned char* mb, int par, int sender) { return reinterpret_cast<unsigned long long*>(mb) + par * P2P_MAX_RANKS + sender; }
-static __device__ inline unsigned long long* halo_flag(unsigned char* mb, int par, int sender) { return reinterpret_cast<unsigned long long*>(mb) + (2 + par) * P2P_MAX_RANKS + sender; }
-static __device__ inline double* red_in(unsigned char* mb, const P2PLayout& L, int par, int sender) { return reinterpret_cast<double*>(mb + L.off_red) + ((size_t)par * L.world + sender) * L.red_cap; }
-static __device__ inline float* halo_in(unsigned char* mb, const P2PLayout& L, int par, int sender) { return reinterpret_cast<float*>(mb + L.off_halo) + ((size_t)par * L.world + sender) * 2 * L.halo_cap; }
-
-static __device__ inline bool wait_flag(unsigned long long* f, unsigned long long epoch, int* err) {
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-        __builtin_amdgcn_s_sleep(2);
-        if (__builtin_readcyclecounter() - t0 > P2P_SPIN_LIMIT) { atomicExch(err, 1); return false; }
-    }
-    return true;
-}
-
 // dev[0..n) <- sum over ranks, in rank order
-__global__ void __launch_bounds__(1024) k_p2p_allreduce(double* __restrict__ dev, int n, int me, P2PLayout L, PeerPtrs peers, unsigned long long epoch, int* err) {
-    const int par = (int)(epoch & 1ull), W = L.world;
-    for (int k = 0; k < W; ++k) {
-        double* dst = red_in(peers.m[k], L, par, me);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(&dst[i], dev[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
-    __syncthreads();
-    if ((int)threadIdx.x < W) __hip_atomic_store(red_flag(peers.m[threadIdx.x], par, me), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((int)threadIdx.x < W) wait_flag(red_flag(peers.m[me], par, threadIdx.x), epoch, err);
-    __syncthreads();
-    __threadfence_system();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        double s = 0.0;
-        for (int j = 0; j < W; ++j) s += __hip_atomic_load(&red_in(peers.m[me], L, par, j)[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        dev[i] = s;
-    }
-}
+__global__ void __launch_bounds__(1024) k_p2p_allreduce(double* __restrict__ dev, int n, P2PDev d) { p2p_allreduce_wg(d, dev, n); }
 
 // rim of the operator input: vec[e], vec[chunk + e] of this rank's send list -> the peers' mailboxes; their values for this rank -> vec
 __global__ void __launch_bounds__(1024) k_p2p_halo(float* __restrict__ vec, int chunk, int me, P2PLayout L, PeerPtrs peers, unsigned long long epoch,
                                                    const int* __restrict__ send_idx, const int* __restrict__ send_off, const int* __restrict__ send_cnt,
                                                    const int* __restrict__ recv_idx, const int* __restrict__ recv_off, const int* __restrict__ recv_cnt, int* err) {
     const int par = (int)(epoch & 1ull), W = L.world;
+    const unsigned e32 = (unsigned)epoch;
     for (int k = 0; k < W; ++k) {
         const int cnt = send_cnt[k]; if (k == me || cnt == 0) continue;
-        const int off = send_off[k]; float* dst = halo_in(peers.m[k], L, par, me);
+        const int off = send_off[k]; unsigned long long* dst = p2p_halo_words(peers.m[k], L, par, me);
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
             const int e = send_idx[off + i];
-            __hip_atomic_store(&dst[2 * i], vec[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&dst[2 * i + 1], vec[(size_t)chunk + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            p2p_put(&dst[2 * i], __float_as_uint(vec[e]), e32);
+            p2p_put(&dst[2 * i + 1], __float_as_uint(vec[(size_t)chunk + e]), e32);
         }
     }
-    __threadfence_system();
-    __syncthreads();
-    if ((int)threadIdx.x < W && (int)threadIdx.x != me && send_cnt[threadIdx.x] > 0)
-        __hip_atomic_store(halo_flag(peers.m[threadIdx.x], par, me), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((int)threadIdx.x < W && (int)threadIdx.x != me && recv_cnt[threadIdx.x] > 0) wait_flag(halo_flag(peers.m[me], par, threadIdx.x), epoch, err);
-    __syncthreads();
-    __threadfence_system();
     for (int k = 0; k < W; ++k) {
         const int cnt = recv_cnt[k]; if (k == me || cnt == 0) continue;
-        const int off = recv_off[k]; const float* src = halo_in(peers.m[me], L, par, k);
+        const int off = recv_off[k]; unsigned long long* src = p2p_halo_words(peers.m[me], L, par, k);
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
             const int e = recv_idx[off + i];
-            vec[e] = __hip_atomic_load(&src[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            vec[(size_t)chunk + e] = __hip_atomic_load(&src[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            vec[e] = __uint_as_float(p2p_get(&src[2 * i], e32, err));
+            vec[(size_t)chunk + e] = __uint_as_float(p2p_get(&src[2 * i + 1], e32, err));
         }
     }
 }
 
 P2PLayout p2p_layout(int world, int red_cap, int halo_cap) {
     P2PLayout L; L.world = world; L.red_cap = red_cap; L.halo_cap = halo_cap;
-    L.off_red = 4 * P2P_MAX_RANKS * sizeof(unsigned long long);
-    L.off_halo = L.off_red + (size_t)2 * world * red_cap * sizeof(double);
-    L.bytes = L.off_halo + (size_t)2 * world * 2 * halo_cap * sizeof(float);
+    // [2 parities][world senders][2 words per double]  |  [2 parities][world senders][2 words per rim entry (sdf, albedo)]
+    L.off_red = 0;
+    L.off_halo = L.off_red + (size_t)2 * world * 2 * red_cap * sizeof(unsigned long long);
+    L.bytes = L.off_halo + (size_t)2 * world * 2 * halo_cap * sizeof(unsigned long long);
     return L;
 }
 
@@ -106,6 +68,7 @@ int P2PEngine::create(int rank_, int world_, int red_cap, int halo_cap) {
     if (hipMemset(mailbox, 0, L.bytes) != hipSuccess) return 1;
     if (hipMalloc((void**)&d_err, sizeof(int)) != hipSuccess || hipMemset(d_err, 0, sizeof(int)) != hipSuccess) return 1;
     if (hipMalloc((void**)&d_lists, sizeof(int) * 4 * P2P_MAX_RANKS) != hipSuccess) return 1;
+    if (hipMalloc((void**)&d_epoch_red, sizeof(unsigned long long)) != hipSuccess || hipMemset(d_epoch_red, 0, sizeof(unsigned long long)) != hipSuccess) return 1;
     for (int k = 0; k < P2P_MAX_RANKS; ++k) peer[k] = nullptr;
     peer[rank] = mailbox;
     return 0;
@@ -124,16 +87,17 @@ int P2PEngine::attach_ipc(const void* handles /* world x 64 bytes */) {
 void P2PEngine::attach_pointer(int k, unsigned char* p) { peer[k] = p; }
 void P2PEngine::destroy() {
     for (int k = 0; k < P2P_MAX_RANKS; ++k) if (opened[k] && peer[k]) { (void)hipIpcCloseMemHandle(peer[k]); opened[k] = false; }
-    if (mailbox) (void)hipFree(mailbox); if (d_err) (void)hipFree(d_err); if (d_lists) (void)hipFree(d_lists);
-    mailbox = nullptr; d_err = nullptr; d_lists = nullptr; ready = false;
+    if (mailbox) (void)hipFree(mailbox); if (d_err) (void)hipFree(d_err); if (d_lists) (void)hipFree(d_lists); if (d_epoch_red) (void)hipFree(d_epoch_red);
+    mailbox = nullptr; d_err = nullptr; d_lists = nullptr; d_epoch_red = nullptr; ready = false;
 }
 
 static PeerPtrs ptrs_of(const P2PEngine& e) { PeerPtrs p; for (int k = 0; k < P2P_MAX_RANKS; ++k) p.m[k] = e.peer[k]; return p; }
 
+P2PDev P2PEngine::device() const { P2PDev d; d.on = ready ? 1 : 0; d.me = rank; d.L = L; d.err = d_err; d.epoch_red = d_epoch_red; d.peers = ptrs_of(*this); return d; }
+
 int P2PEngine::allreduce(double* dev, size_t n, hipStream_t st) {
     if ((int)n > L.red_cap) return 1;
-    ++epoch_red;
-    k_p2p_allreduce<<<1, 1024, 0, st>>>(dev, (int)n, rank, L, ptrs_of(*this), epoch_red, d_err);
+    k_p2p_allreduce<<<1, 1024, 0, st>>>(dev, (int)n, device());
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int P2PEngine::set_halo_lists(const HaloPlan& h, hipStream_t st) {      // once per outer iteration
@@ -144,7 +108,7 @@ int P2PEngine::set_halo_lists(const HaloPlan& h, hipStream_t st) {      // once 
     return hipStreamSynchronize(st) == hipSuccess ? 0 : 1;
 }
 int P2PEngine::push_halo(float* vec, const HaloPlan& h, hipStream_t st) {
-    ++epoch_halo;
+    ++epoch_halo; if ((unsigned)epoch_halo == 0u) ++epoch_halo;
     k_p2p_halo<<<1, 1024, 0, st>>>(vec, h.chunk, rank, L, ptrs_of(*this), epoch_halo, h.d_send_idx, d_lists, d_lists + P2P_MAX_RANKS, h.d_recv_idx, d_lists + 2 * P2P_MAX_RANKS,
                                    d_lists + 3 * P2P_MAX_RANKS, d_err);
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -3,12 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include "comm.hpp"
+#include "../device/p2p_device.hpp"
 
 namespace i3d {
 
-constexpr int P2P_MAX_RANKS = 64;
-
-struct P2PLayout { int world, red_cap, halo_cap; size_t off_red, off_halo, bytes; };
 P2PLayout p2p_layout(int world, int red_cap /* doubles per all-reduce */, int halo_cap /* rim entries per pair */);
 
 struct P2PEngine {
@@ -18,13 +16,15 @@ struct P2PEngine {
     unsigned char* peer[P2P_MAX_RANKS] = {nullptr};   // every rank's mailbox as seen from this device (peer[rank] == mailbox)
     bool opened[P2P_MAX_RANKS] = {false};
     int* d_err = nullptr; int* d_lists = nullptr;
-    unsigned long long epoch_red = 0, epoch_halo = 0;
+    unsigned long long* d_epoch_red = nullptr;        // all-reduces performed so far (device counter, see p2p_device.hpp)
+    unsigned long long epoch_halo = 0;
 
     int  create(int rank, int world, int red_cap, int halo_cap);
     int  export_handle(void* out64);                  // hipIpcMemHandle_t of the mailbox
     int  attach_ipc(const void* handles);             // world x 64 bytes, in rank order (one process per GPU)
     void attach_pointer(int k, unsigned char* p);     // same process (rank simulation)
     void destroy();
+    P2PDev device() const;                            // handle for kernels that reduce in place (p2p_allreduce_wg)
     int  allreduce(double* dev, size_t n, hipStream_t st);
     int  set_halo_lists(const HaloPlan& h, hipStream_t st);
     int  push_halo(float* vec, const HaloPlan& h, hipStream_t st);

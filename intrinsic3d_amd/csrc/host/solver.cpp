@@ -321,6 +321,11 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     // fp64 partial sums: [0, 4*2048) slice sums of k_pcg_step, then the p.q partials of the operator pass, then the D^2 p^2 partials of k_pcg_direction
     double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048; double* const d2_part = pq_part + 1024;
     int n_pq = 0, n_step = 0, n_d2 = 0;
+    // Sharded over the peer-to-peer transport: the two reductions of a pass run INSIDE the boundary kernels (k_pcg_tail_a / k_pcg_tail_b), a pass
+    // has no reduction launches of its own.  Any other transport: separate all-reduce launches around the same kernels (pd.on = 0).
+    P2PDev pd; std::memset(&pd, 0, sizeof(pd));
+    const bool fused = multi && tiled && c->comm->device_reduce(&pd) && L.NS + 1 <= pd.L.red_cap;
+    if (!fused) pd.on = 0;
     // The operator on the rows of this rank.  Tiled (tile_pass.hip): raw accumulators J^T W J u in v_qacc (camera block in d_shared, p.q partials
     // row by row); the vector q = S acc + D^2 v is formed inside k_pcg_step.  Untiled fallback (single rank): k_eg_jtjp + k_gather -> out.
     auto rows_apply = [&](const float* v, float* out, bool with_dot, bool zero_first) -> int {
@@ -331,7 +336,7 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
               n_pq = launch_eg_tile(s, r, p, c->v_u.p, c->tile_plan(), c->d_shared.p, c->v_qacc.p, with_dot ? pq_part : nullptr, st); }
             { TimedScope t(c, I3D_K_GATHER); launch_halo_fold(s, r, c->tile_plan(), c->v_qacc.p, st); }
             if (!with_dot) n_pq = 0;
-            if (!multi) return I3D_OK;
+            if (!multi || (fused && with_dot)) return I3D_OK;      // fused: k_pcg_tail_b adds the partials and sums [camera block | p.q] over the ranks
             // the rank's p.q (rows + D^2 p^2 of its slice) rides with the camera block
             if (with_dot) { TimedScope t(c, I3D_K_VECTOR); launch_reduce_partials(s, pq_part, n_pq, 1, pq_slot, st); launch_reduce_partials(s, d2_part, n_d2, 1, pq_slot, st); }
             n_pq = 0;
@@ -342,37 +347,44 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
         if (!with_dot) n_pq = 0;
         return I3D_OK;
     };
+    // sharded: the slice sums of k_pcg_step go into acc (one small launch: thousands of workgroups adding into four doubles serialise at the L2,
+    // measured 71 vs 32 us for the step kernel), which is all-reduced at the iteration boundary; single rank: k_pcg_tail_a adds the partials itself
+    auto fold_step = [&]() { if (multi && !fused) { launch_reduce_partials(s, step_part, n_step, 4, st->acc, st); n_step = 0; } };
     const float* const Sq = tiled ? c->v_S.p : nullptr;          // tiled pass: k_pcg_step forms q from the accumulators
     { TimedScope t(c, I3D_K_VECTOR);
-      n_step = launch_pcg_step(s, 0 /*init*/, own, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, multi ? nullptr : step_part, st); }
+      n_step = launch_pcg_step(s, 0 /*init*/, own, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, step_part, st);
+      fold_step(); }
     int tail_mode = 0;
     const int seq0 = c->pcg_seq;               // pass numbers are unique across solves: a stale ring entry can never match
     int it = 1;
     for (;; ++it) {
         // iteration boundary.  Sharded: the 4 slice sums (r.z, x.(b+r), x.r, sum D2 x^2) are all-reduced (sharded k_pcg_step adds into acc directly)
-        if (multi) { int rc = allreduce(c, st->acc, 4); if (rc) return rc; }
+        if (multi && !fused) { int rc = allreduce(c, st->acc, 4); if (rc) return rc; }
+        if (fused) { c->comm->count_reduce(4); c->comm->count_reduce((size_t)L.NS + 1); }
         { TimedScope t(c, I3D_K_VECTOR);
           launch_pcg_tail_a(s, tail_mode, to, K, c->Minv_blocks.p, c->v_p.p, tail_mode == 3 ? c->v_tmp.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_z.p,
-                            step_part, n_step, st, c->d_shared.p, L.NS + 1, c->d_flags, seq0 + it); }
+                            step_part, n_step, st, c->d_shared.p, L.NS + 1, c->d_flags, seq0 + it, pd); }
         { TimedScope t(c, I3D_K_VECTOR);        // p = z + beta p, u = S p on the owned segments and the (replicated) camera tail; sharded: D^2 p^2 of the tail is added by k_pcg_tail_b
           n_d2 = launch_pcg_direction(s, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, tiled ? d2_part : nullptr, st); }
         { int rc = rows_apply(c->v_p.p, c->v_q.p, true, false); if (rc) return rc; }
-        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_tail_b(s, to, K, p, c->d_shared.p, pq_slot, pq_part, n_pq, d2_part, (tiled && !multi) ? n_d2 : 0, tiled,
-                                                           c->v_q.p, c->v_S.p, c->v_D2.p, c->v_p.p, st); }
+        { TimedScope t(c, I3D_K_VECTOR); launch_pcg_tail_b(s, to, K, p, c->d_shared.p, pq_slot, pq_part, n_pq, d2_part, (tiled && (!multi || fused)) ? n_d2 : 0, tiled,
+                                                           c->v_q.p, c->v_S.p, c->v_D2.p, c->v_p.p, st, pd); }
         const bool reset = (it % 10 == 0);                                       // residual_reset_period
         if (!reset) {
             TimedScope t(c, I3D_K_VECTOR);
-            n_step = launch_pcg_step(s, 1, own, c->v_p.p, tiled ? c->v_qacc.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, multi ? nullptr : step_part, st);
+            n_step = launch_pcg_step(s, 1, own, c->v_p.p, tiled ? c->v_qacc.p : c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, step_part, st);
+            fold_step();
             tail_mode = 1;
         } else {                                                                 // r = b - A x instead of r -= alpha q
             { TimedScope t(c, I3D_K_VECTOR);
-              launch_pcg_step(s, 2, own, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, multi ? nullptr : step_part, st);
+              launch_pcg_step(s, 2, own, c->v_p.p, c->v_q.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, nullptr, step_part, st);
               launch_pcg_tail_x(s, to, K, c->v_p.p, c->v_x.p, st);
               launch_mul2(s, own, c->v_S.p, c->v_x.p, c->v_u.p); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
             { int rc = rows_apply(c->v_x.p, c->v_tmp.p, false, true); if (rc) return rc; }
             { TimedScope t(c, I3D_K_VECTOR);
               launch_shared_finalize(s, to, K, p, c->d_shared.p, c->v_tmp.p, true, c->v_S.p, c->v_D2.p, c->v_x.p, nullptr, st);
-              n_step = launch_pcg_step(s, 3, own, c->v_p.p, tiled ? c->v_qacc.p : c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, multi ? nullptr : step_part, st); }
+              n_step = launch_pcg_step(s, 3, own, c->v_p.p, tiled ? c->v_qacc.p : c->v_tmp.p, c->v_x.p, c->v_r.p, c->v_b.p, c->v_D2.p, c->v_Minv.p, c->v_z.p, Sq, step_part, st);
+              fold_step(); }
             tail_mode = 3;
         }
         if (it >= 2) {                                                           // look at the boundary of pass it-1 while pass it runs
