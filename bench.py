@@ -316,9 +316,12 @@ def _main():
     roofline_build = roof("build")           # the kernel the north star names, whichever one dominates
     comm = None
     if sharded_run:
+        # HIP events around the exchange launches that still are launches of their own (the rim push; with RCCL also the all-reduces).  Over the
+        # peer-to-peer transport the two reductions of a pass run INSIDE the PCG's boundary kernels, so the whole price of the sharded path on one
+        # GPU is the difference of ms_per_step between a plain run and a --force-collectives run (profiles/README.md quotes both).
         ms, n = timing["comm"]; passes = max(1, timing["eg_pass"][1])
-        comm = {"transport": transport, "launch_ms_total": ms, "launches": n, "operator_passes": passes, "comm_us_per_pass": 1e3 * ms / passes,
-                "stats_rank0": comm_stats}
+        comm = {"transport": transport, "separate_launch_ms_total": ms, "separate_launches": n, "operator_passes": passes,
+                "separate_launch_us_per_pass": 1e3 * ms / passes, "stats_rank0": comm_stats}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:

@@ -79,14 +79,46 @@ static bool bootstrap_p2p(RcclComm* c, hipStream_t st) {
     if (d_test) { (void)hipMemcpy(d_test, &flag, sizeof(double), hipMemcpyHostToDevice); (void)ncclAllReduce(d_test, d_test, 1, ncclDouble, ncclMin, c->comm, st); (void)hipStreamSynchronize(st);
                   (void)hipMemcpy(&flag, d_test, sizeof(double), hipMemcpyDeviceToHost); }
     ok = ok && flag == 1.0;
-    if (ok) {        // self-test: 8 all-reduces of rank-dependent vectors
-        for (int rep = 0; rep < 8 && ok; ++rep) {
-            double v[64]; for (int i = 0; i < 64; ++i) v[i] = (double)(c->rank + 1) * (i + 1) + rep;
-            ok = hipMemcpy(d_test, v, sizeof(v), hipMemcpyHostToDevice) == hipSuccess && c->p2p.allreduce(d_test, 64, st) == 0 && c->p2p.check(st) == 0
-                 && hipMemcpy(v, d_test, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok) {        // self-test with real exchanges and bounded waits: small and full-size all-reduces, then rim pushes between every pair
+        const int big = P2P_RED_CAP;
+        double* d_big = nullptr; std::vector<double> hb(big);
+        ok = hipMalloc((void**)&d_big, sizeof(double) * big) == hipSuccess;
+        for (int rep = 0; rep < 12 && ok; ++rep) {
+            const int n = rep < 8 ? 64 : big;
+            for (int i = 0; i < n; ++i) hb[i] = (double)(c->rank + 1) * (i + 1) + rep;
+            ok = hipMemcpy(d_big, hb.data(), sizeof(double) * n, hipMemcpyHostToDevice) == hipSuccess && c->p2p.allreduce(d_big, n, st) == 0 && c->p2p.check(st) == 0
+                 && hipMemcpy(hb.data(), d_big, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
             const double tri = 0.5 * c->world * (c->world + 1);
-            for (int i = 0; i < 64 && ok; ++i) ok = v[i] == tri * (i + 1) + (double)rep * c->world;
+            for (int i = 0; i < n && ok; ++i) ok = hb[i] == tri * (i + 1) + (double)rep * c->world;
         }
+        if (d_big) (void)hipFree(d_big);
+        // rim push: every rank owns entries [0, B) of a test vector and receives the B entries of peer k at [(k + 1) B, (k + 2) B)
+        const int B = 512, W = c->world, chunk = B * (W + 1);
+        HaloPlan h; h.world = W; h.chunk = chunk; h.send_cnt.assign(W, 0); h.send_off.assign(W, 0); h.recv_cnt.assign(W, 0); h.recv_off.assign(W, 0);
+        std::vector<int> sidx, ridx;
+        for (int k = 0; k < W; ++k) if (k != c->rank) {
+            h.send_off[k] = (int)sidx.size(); h.send_cnt[k] = B; for (int i = 0; i < B; ++i) sidx.push_back(i);
+            h.recv_off[k] = (int)ridx.size(); h.recv_cnt[k] = B; for (int i = 0; i < B; ++i) ridx.push_back((k + 1) * B + i);
+        }
+        h.n_send = (int)sidx.size(); h.n_recv = (int)ridx.size();
+        int* d_idx = nullptr; float* d_vec = nullptr;
+        if (ok && W > 1) {
+            std::vector<float> hv(2 * (size_t)chunk);
+            ok = hipMalloc((void**)&d_idx, sizeof(int) * (sidx.size() + ridx.size())) == hipSuccess && hipMalloc((void**)&d_vec, sizeof(float) * hv.size()) == hipSuccess
+                 && hipMemcpy(d_idx, sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice) == hipSuccess
+                 && hipMemcpy(d_idx + sidx.size(), ridx.data(), sizeof(int) * ridx.size(), hipMemcpyHostToDevice) == hipSuccess;
+            h.d_send_idx = d_idx; h.d_recv_idx = d_idx ? d_idx + sidx.size() : nullptr;
+            ok = ok && c->p2p.set_halo_lists(h, st) == 0;
+            for (int rep = 0; rep < 4 && ok; ++rep) {
+                std::fill(hv.begin(), hv.end(), -1.0f);
+                for (int i = 0; i < B; ++i) { hv[i] = (float)(1000 * c->rank + i + rep); hv[(size_t)chunk + i] = -(float)(1000 * c->rank + i + rep); }
+                ok = hipMemcpy(d_vec, hv.data(), sizeof(float) * hv.size(), hipMemcpyHostToDevice) == hipSuccess && c->p2p.push_halo(d_vec, h, st) == 0 && c->p2p.check(st) == 0
+                     && hipMemcpy(hv.data(), d_vec, sizeof(float) * hv.size(), hipMemcpyDeviceToHost) == hipSuccess;
+                for (int k = 0; k < W && ok; ++k) if (k != c->rank) for (int i = 0; i < B && ok; ++i)
+                    ok = hv[(size_t)(k + 1) * B + i] == (float)(1000 * k + i + rep) && hv[(size_t)chunk + (size_t)(k + 1) * B + i] == -(float)(1000 * k + i + rep);
+            }
+        }
+        if (d_idx) (void)hipFree(d_idx); if (d_vec) (void)hipFree(d_vec);
         flag = ok ? 1.0 : 0.0;
         (void)hipMemcpy(d_test, &flag, sizeof(double), hipMemcpyHostToDevice); (void)ncclAllReduce(d_test, d_test, 1, ncclDouble, ncclMin, c->comm, st); (void)hipStreamSynchronize(st);
         (void)hipMemcpy(&flag, d_test, sizeof(double), hipMemcpyDeviceToHost);
