@@ -4,6 +4,14 @@ import numpy as np
 from intrinsic3d_amd import synthetic
 
 
+# The refine schedule chains lighting estimates, joint solves and 8-bit recolourisations over several levels; where the joint geometry + camera
+# problem is so ill-conditioned that the ORACLE ITSELF moves further than 1e-4 when its input poses are perturbed by a few 1e-7 (gauge
+# freedom), fields are held to ENVELOPE_FACTOR x that measured sensitivity of the reference computation instead.  One factor, used by every
+# schedule test (test_gpu_levels.py, test_gpu_configs.py) and quoted in DESIGN.md section 6: the device path adds run-to-run summation-order
+# noise of its own (fp32 atomics), and an envelope from a handful of perturbed re-runs under-estimates the true spread.
+ENVELOPE_FACTOR = 10.0
+
+
 def small_scene(seed=1, radius_vox=16, K=6, width=160, height=120, levels=1, **kw):
     return synthetic.make_scene(radius_vox=radius_vox, voxel_size=0.004, K=K, width=width, height=height, levels=levels, seed=seed, **kw)
 

@@ -1,0 +1,136 @@
+"""-m gpu: the configurations BASELINE.json names, at test size, through the refine schedule (i3d_refine / apps/app_intrinsic3d) against
+oracle.refine (Intrinsic3D::refine, intrinsic3d.cpp:206-350).  configs[0] (C1) is tests/test_gpu_parity.py::test_config_c1_dense_albedo_only.
+
+  C2  single level at 4 mm, fixed camera (poses, intrinsics, distortion), ONE global SH volume
+  C3  3 grid levels (4 -> 2 -> 1 mm) x (3, 1, 1) pyramid levels, poses fixed, joint SDF + albedo + spatially varying SH, on a dataset folder
+      in the reference's layout through apps/app_intrinsic3d and through the same flow in-process
+
+Structure (keys, visit order, weights) must be identical; fields are held to 1e-4 on the 99.9 % quantile and to
+max(1e-4, helpers.ENVELOPE_FACTOR x the oracle's own sensitivity to 1e-7 input perturbations) on the maximum."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_refine(O, sc, frames, levels, ocfg, rc, intr, dist, poses, pose_eps=0.0):
+    g = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+    fr = O.Frames(frames, levels)
+    rcode, ointr, odist, oposes, done = O.refine(g, fr, ocfg, rc.num_grid_levels, rc.num_rgbd_levels, rc.thin_shell_factor, rc.thin_shell_factor_final,
+                                                 rc.clear_distant_voxels, rc.subvolume_size_sh, rc.sh_lambda_reg, intr, dist,
+                                                 np.array(poses, np.float64) * (1.0 + pose_eps))
+    assert rcode == 0
+    ref = g.export(); g.free(); fr.free()
+    return ref, ointr, oposes, done
+
+
+def _check_fields(out, ref, env):
+    assert np.array_equal(out["keys"], ref["keys"]) and np.array_equal(out["weight"], ref["weight"])
+    d_sdf = np.abs(out["sdf_refined"] - ref["sdf_refined"]); d_alb = np.abs(out["albedo"] - ref["albedo"])
+    smax = float(np.abs(ref["sdf_refined"]).max()); amax = float(np.abs(ref["albedo"]).max())
+    assert np.quantile(d_sdf, 0.999) <= 1e-4 * smax, (np.quantile(d_sdf, 0.999), smax)
+    assert np.quantile(d_alb, 0.999) <= 1e-4 * amax, (np.quantile(d_alb, 0.999), amax)
+    assert d_sdf.max() <= max(1e-4 * smax, helpers.ENVELOPE_FACTOR * env["sdf_refined"]), (d_sdf.max(), smax, env)
+    assert d_alb.max() <= max(1e-4 * amax, helpers.ENVELOPE_FACTOR * env["albedo"]), (d_alb.max(), env)
+    cd = np.abs(out["color"].astype(int) - ref["color"].astype(int))
+    assert (cd > 1).mean() < 1e-3                                             # 8-bit truncation of colours computed from ~1e-7-different geometry
+
+
+def _envelope(O, sc, frames, levels, ocfg, rc, intr, dist, poses, ref, eps_list):
+    env = dict(sdf_refined=0.0, albedo=0.0)
+    for eps in eps_list:
+        per, _, _, _ = _oracle_refine(O, sc, frames, levels, ocfg, rc, intr, dist, poses, pose_eps=eps)
+        if per["keys"].shape == ref["keys"].shape and np.array_equal(per["keys"], ref["keys"]):
+            for k in env:
+                env[k] = max(env[k], float(np.abs(per[k] - ref[k]).max()))
+    return env
+
+
+def test_config_c2_single_level_fixed_camera_global_sh(oracle):
+    """BASELINE.json configs[1]: one grid level at 4 mm, one pyramid level, camera fixed, one SH volume for the whole object (a subvolume
+    size larger than the scene: intrinsic3d.yml's `subvolume_size_sh` with a single cell), the shipped lambda schedule."""
+    from intrinsic3d_amd import binding
+    sc = helpers.small_scene(seed=21, radius_vox=14, K=8, width=160, height=120, levels=1, pose_noise=(0.0, 0.0), lum_noise=0.003)
+    ocfg = helpers.oracle_cfg(oracle, 0.0, iterations=3, lm_steps=50, fix_poses=1, fix_intrinsics=1, fix_distortion=1)
+    rc = binding.RefineConfig(num_grid_levels=1, num_rgbd_levels=1, thin_shell_factor=2.0, thin_shell_factor_final=2.0, clear_distant_voxels=1,
+                              occlusion_distance=0.02, num_observations=5, subvolume_size_sh=10.0, sh_lambda_reg=10.0)
+    seen = []
+    with binding.Context(0) as ctx:
+        ctx.set_grid_from_tsdf_records(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        ctx.set_frames(sc["frames"], sc["levels"]); ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
+        ctx.refine(rc, helpers.gpu_cfg(ocfg), callback=lambda gl, ng, pl, npl: seen.append((gl, pl)))
+        out = ctx.export_grid(); intr, dist, poses = ctx.get_camera()
+        sh, _, _ = ctx.estimate_sh(10.0, 10.0, 2.0 * float(sc["voxel_size"]))
+    assert seen == [(0, 0)] and sh.shape[0] == 1                              # one level, ONE SH volume
+    ref, ointr, oposes, done = _oracle_refine(oracle, sc, sc["frames"], 1, ocfg, rc, sc["intr"], sc["dist"], sc["poses"])
+    assert done == 1
+    np.testing.assert_array_equal(intr, ointr); np.testing.assert_array_equal(poses, oposes)          # fixed blocks come back untouched
+    env = _envelope(oracle, sc, sc["frames"], 1, ocfg, rc, sc["intr"], sc["dist"], sc["poses"], ref, ())
+    _check_fields(out, ref, env)                                             # a fixed camera leaves no gauge freedom: plain 1e-4
+    assert np.abs(out["sdf_refined"] - out["sdf"]).max() > 1e-3 * float(sc["voxel_size"])             # the geometry did move
+
+
+def test_config_c3_three_level_schedule_through_the_app(oracle, tmp_path):
+    """BASELINE.json configs[2] at test size: the reference's coarse-to-fine schedule — 3 grid levels, 3 pyramid levels on the coarsest grid and
+    the finest pyramid level on the others (intrinsic3d.cpp:233-247) — with poses fixed and SDF + albedo + SVSH + intrinsics joint.  The dataset
+    folder is in the reference's layout (tools/make_dataset.py); apps/app_intrinsic3d runs it end to end; the same flow in-process is compared
+    with oracle.refine fed with the decoded keyframes."""
+    from intrinsic3d_amd import binding as B, synthetic
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_dataset
+    app = os.path.join(ROOT, "apps", "app_intrinsic3d")
+    assert os.path.exists(app), "apps/app_intrinsic3d has not been built (run __graft_entry__.build())"
+    levels = 3
+    sc = synthetic.make_scene(radius_vox=10, K=6, width=192, height=144, levels=1, seed=33, pose_noise=(0.0, 0.0), lum_noise=0.003, cam_dist=0.2)      # surface beyond sensor.yml's min_depth 0.1 m
+    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=3, rgbd_levels=levels, iterations=2, fix_poses=1, fix_distortion=1,
+                                              subvolume_size_sh=0.05)
+    r = subprocess.run([app, "-s", s_yml, "-i", i_yml], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    outdir = tmp_path / "intrinsic3d"
+    want = [(2, 2), (2, 1), (2, 0), (1, 0), (0, 0)]                           # all pyramid levels only on the coarsest grid
+    assert sorted(p.name for p in outdir.glob("poses_*")) == sorted(f"poses_g{g}_p{p}.txt" for g, p in want)
+    for g, p in want:
+        for name in (f"mesh_g{g}_p{p}.ply", f"mesh_g{g}_p{p}_albedo.ply", f"intrinsics_g{g}_p{p}.txt"):
+            assert (outdir / name).stat().st_size > 0, name
+    ok, w, h, intr_app, dist_app = B.read_intrinsics(str(outdir / "intrinsics_g0_p0.txt"))
+    assert ok and (w, h) == (192, 144)
+
+    # the same flow in-process, and the oracle on the same decoded keyframes
+    sensor = B.Sensor(tmp_path / "rgbd", 0, 0.1, 10.0)
+    _, _, is_kf = B.keyframes_load(str(tmp_path / "fusion" / "keyframes.txt"))
+    rc, oc = B.load_yaml_config(i_yml)
+    assert (rc.num_grid_levels, rc.num_rgbd_levels, oc.fix_poses, oc.fix_intrinsics) == (3, 3, 1, 0)
+    vol = B.tsdf_read(str(tmp_path / "fusion" / f"volume_{float(sc['voxel_size']):g}.tsdf"))
+    seen = []
+    with B.Context(0) as ctx:
+        ctx.set_grid_from_tsdf_records(vol["voxel_size"], vol["keys"], vol["sdf"], vol["weight"], vol["color"])
+        ids = B.init_frames_from_sensor(ctx, sensor, is_kf, levels)
+        intr0, dist0, poses0 = ctx.get_camera()
+        frames = []
+        for k, fid in enumerate(ids):
+            bgr0 = sensor.color(fid)
+            lum, dep, bgr = [], [], []
+            for lvl in range(levels):
+                l, d = ctx.get_frame_image(k, lvl, 192 >> lvl, 144 >> lvl)
+                lum.append(l); dep.append(d); bgr.append(np.ascontiguousarray(bgr0[::1 << lvl, ::1 << lvl]))      # colours are sampled at level 0 only
+            frames.append({"lum": lum, "depth": dep, "bgr": bgr})
+        ctx.refine(rc, oc, callback=lambda gl, ng, pl, npl: seen.append((gl, pl)))
+        out = ctx.export_grid(); intr, dist, poses = ctx.get_camera()
+    assert seen == want
+    assert np.allclose(intr_app, intr, rtol=1e-4)                            # the app and the in-process flow agree (6 significant digits in the file)
+    np.testing.assert_array_equal(poses, poses0)                             # fixed
+    ocfg = helpers.oracle_cfg(oracle, 0.0, iterations=oc.iterations, lm_steps=oc.lm_steps, fix_poses=1, fix_intrinsics=0, fix_distortion=1)
+    vsc = dict(voxel_size=vol["voxel_size"], keys=vol["keys"], sdf=vol["sdf"], weight=vol["weight"], color=vol["color"])
+    ref, ointr, oposes, done = _oracle_refine(oracle, vsc, frames, levels, ocfg, rc, intr0, dist0, poses0)
+    assert done == 5
+    env = _envelope(oracle, vsc, frames, levels, ocfg, rc, intr0, dist0, poses0, ref, (1e-7, -1e-7))
+    _check_fields(out, ref, env)
+    assert np.abs(intr - ointr).max() <= 1e-4 * np.abs(ointr).max(), (intr, ointr)
+    assert float(vol["voxel_size"]) / 4.0 == pytest.approx(0.001)            # 4 mm -> 1 mm

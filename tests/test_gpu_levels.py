@@ -125,8 +125,8 @@ def test_refine_two_levels_matches_oracle(oracle, scene, iterations, fix_intrins
     """Intrinsic3D::refine: 2 grid levels x 2 pyramid levels = 3 lighting + optimize + recolour rounds, one sparsification per level,
     one upsampling.  Structure (keys, order, validity) must be identical.  Fields are held to 1e-4 relative — or, where the joint
     geometry + pose problem is so ill-conditioned (gauge freedom) that the ORACLE ITSELF moves further than that when its input poses
-    are perturbed by a few 1e-7 relative, to 10x that measured sensitivity envelope (five perturbed re-runs) of the reference computation (the device path adds
-    run-to-run summation-order noise of its own through fp32 atomics)."""
+    are perturbed by a few 1e-7 relative, to helpers.ENVELOPE_FACTOR x that measured sensitivity envelope (five perturbed re-runs) of the reference
+    computation."""
     from intrinsic3d_amd import binding
     sc = scene
     ocfg = helpers.oracle_cfg(oracle, 0.0, iterations=iterations, lm_steps=20, fix_distortion=1, fix_intrinsics=fix_intrinsics)
@@ -154,10 +154,10 @@ def test_refine_two_levels_matches_oracle(oracle, scene, iterations, fix_intrins
     assert np.median(d_sdf) <= 1e-5 * smax and np.median(d_alb) <= 1e-5
     assert np.quantile(d_sdf, 0.999) <= max(1e-4 * smax, env["sdf_refined"]) and np.quantile(d_alb, 0.999) <= max(1e-4, env["albedo"])
     # isolated voxels next to a marginal decision (row validity, observation choice) may move further, in the oracle's own perturbed runs too
-    assert d_sdf.max() <= max(1e-4 * smax, 10.0 * env["sdf_refined"], 3e-3 * smax), (d_sdf.max(), smax, env)
-    assert d_alb.max() <= max(1e-4, 10.0 * env["albedo"], 3e-3), (d_alb.max(), env)
-    assert np.abs(intr - ointr).max() <= max(1e-5 * np.abs(ointr).max(), 10.0 * env["intr"])
-    assert np.abs(poses - oposes).max() <= max(1e-5, 10.0 * env["poses"]), (np.abs(poses - oposes).max(), env)
+    assert d_sdf.max() <= max(1e-4 * smax, helpers.ENVELOPE_FACTOR * env["sdf_refined"], 3e-3 * smax), (d_sdf.max(), smax, env)
+    assert d_alb.max() <= max(1e-4, helpers.ENVELOPE_FACTOR * env["albedo"], 3e-3), (d_alb.max(), env)
+    assert np.abs(intr - ointr).max() <= max(1e-5 * np.abs(ointr).max(), helpers.ENVELOPE_FACTOR * env["intr"])
+    assert np.abs(poses - oposes).max() <= max(1e-5, helpers.ENVELOPE_FACTOR * env["poses"]), (np.abs(poses - oposes).max(), env)
     cd = np.abs(out["color"].astype(int) - ref["color"].astype(int))
     assert (cd > 1).mean() < 1e-3                                             # 8-bit truncation of colours computed from ~1e-7-different geometry
 
