@@ -294,7 +294,8 @@ int i3d_problem_sizes(i3d_context* ctx, int64_t out[6]);
  * Arrays are indexed by visit order; slot k in [0, slots).  Any pointer may be NULL. */
 int i3d_debug_assemble(i3d_context* ctx, const i3d_optimizer_config* cfg, int32_t iteration, int32_t* slots_out);
 /* iteration order of the reference's unordered_map<Vec3i,...> after `map[key_i] = i`, i = 0..n-1: mode 0 = the host replay (repeated keys
- * allowed), 1 = the replay for distinct keys, 2 = a real std::unordered_map; returns the number of elements (host only, no device) */
+ * allowed), 1 = the replay for distinct keys, 2 = a real std::unordered_map, 3 = the per-rehash-epoch closed form on the host, 4 = the same on
+ * the current device (what the level transitions and the fusion volume use; distinct keys); returns the number of elements, -1 on error */
 int64_t i3d_debug_map_order(const int32_t* keys, int64_t n, int32_t mode, int32_t* order);
 int i3d_debug_flags(i3d_context* ctx, uint8_t* flags /*[N]: bit0 valid,1 active,2 ring_ok,3 free_sdf,4 free_albedo*/);
 int i3d_debug_eg_rows(i3d_context* ctx, int32_t* frame /*[N][slots], -1 = none*/, float* weight /*[N][slots] normalised*/,

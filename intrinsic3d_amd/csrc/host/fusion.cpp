@@ -3,7 +3,7 @@
 //   i3d_fusion_finish    = SDFAlgorithms::correctSDF + clearInvalidVoxels, and the reference's record order
 // Frames are integrated in call order, one allocation launch and one integration launch per frame (fusion_kernels.hip).  The saved
 // volume's record order is the iteration order of the reference's unordered_map; it is reproduced from the order of first insertion
-// (a per-voxel rank kept by the allocation kernel, radix-sorted here) by replaying the insertions on the host (map_order.hpp) — the same replay levels.cpp uses for the level
+// (a per-voxel rank kept by the allocation kernel, radix-sorted here) by replaying the insertions epoch by epoch on the device (map_order.hip) — the same replay levels.cpp uses for the level
 // transitions.
 #include "../../../include/intrinsic3d_hip.h"
 #include "../device/fusion_kernels.hpp"
@@ -204,16 +204,13 @@ int i3d_fusion_finish(i3d_fusion* f, int32_t correct_iterations, uint64_t* count
     F_HIP(f, rocprim::radix_sort_pairs(nullptr, bytes, rank0.p, rank1.p, slot0.p, slot1.p, (size_t)m, 0, 64, st));
     F_HIP(f, tmp.alloc(bytes));
     F_HIP(f, rocprim::radix_sort_pairs(tmp.p, bytes, rank0.p, rank1.p, slot0.p, slot1.p, (size_t)m, 0, 64, st));
-    // 2. replay the insertions on the host: iteration order of the reference's map
+    // 2. replay the insertions: iteration order of the reference's map
     DevBuf<int> kxyz; F_HIP(f, kxyz.alloc(3 * m));
     launch_fusion_keys(st, t, (long long)m, slot1.p, kxyz.p);
-    std::vector<int> hk(3 * m), order; order.reserve(m);
-    F_HIP(f, hipMemcpyAsync(hk.data(), kxyz.p, sizeof(int) * 3 * m, hipMemcpyDeviceToHost, st));
-    F_HIP(f, hipStreamSynchronize(st));
-    map_iteration_order_replay(hk.data(), (size_t)m, order);                                           // keys of a hash table: distinct by construction
     DevBuf<int> d_order, pos_of_slot; DevBuf<unsigned int> visit_slot;
     F_HIP(f, d_order.alloc(m)); F_HIP(f, pos_of_slot.alloc(cap)); F_HIP(f, visit_slot.alloc(m));
-    F_HIP(f, hipMemcpyAsync(d_order.p, order.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
+    { const std::vector<MapEpoch> ep = map_epochs((size_t)m);                                            // keys of a hash table: distinct by construction
+      F_HIP(f, map_order_device(st, kxyz.p, (size_t)m, ep.data(), (int)ep.size(), d_order.p)); }
     launch_fusion_positions(st, (long long)m, slot1.p, d_order.p, visit_slot.p, pos_of_slot.p);
     // 3. correctSDF: up to `correct_iterations` in-place sweeps, each evaluated as a fixed point (see k_correct), in a spatially sorted
     //    compact index space with the 26 neighbour indices resolved once

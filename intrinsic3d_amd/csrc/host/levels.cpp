@@ -14,9 +14,6 @@
 namespace i3d {
 
 namespace {
-// iteration order of a map filled with `keys` (insertion sequence 0..n-1): out[v] = insertion index of the v-th visited key
-void map_iteration_order(const int* keys, size_t n, std::vector<int>& out) { map_iteration_order_replay(keys, n, out, false); }
-
 OptParams color_params(const i3d_context* c, float occlusion) {
     OptParams p; std::memset(&p, 0, sizeof(p));
     p.K = c->K; p.level = 0; p.pyr_scale = 1.0; p.occlusion = occlusion;
@@ -84,12 +81,9 @@ int upsample_grid(i3d_context* c, int64_t* new_count) {
     CTX_HIP(c, b.kxyz.alloc((size_t)3 * M)); CTX_HIP(c, b.sdf.alloc(M)); CTX_HIP(c, b.sdf_ref.alloc(M)); CTX_HIP(c, b.alb.alloc(M)); CTX_HIP(c, b.w.alloc(M)); CTX_HIP(c, b.rgb.alloc((size_t)3 * M));
     launch_inv_rank(st, N, c->rank.p, inv.p);
     launch_upsample(st, g, t, inv.p, a.kxyz.p, a.sdf.p, a.sdf_ref.p, a.alb.p, a.w.p, a.rgb.p);
-    std::vector<int> keys((size_t)3 * M), order;
-    CTX_HIP(c, hipMemcpyAsync(keys.data(), a.kxyz.p, sizeof(int) * 3 * (size_t)M, hipMemcpyDeviceToHost, st));
-    CTX_HIP(c, hipStreamSynchronize(st));
-    map_iteration_order(keys.data(), (size_t)M, order);
-    if ((long long)order.size() != M) return ctx_fail(c, I3D_ERR_STATE, "upsample_grid: duplicate child keys");
-    CTX_HIP(c, hipMemcpyAsync(perm.p, order.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice, st));
+    // iteration order of the new map, on the device (child keys are distinct: every parent has its own 2x2x2 block)
+    { const std::vector<MapEpoch> ep = map_epochs((size_t)M);
+      CTX_HIP(c, map_order_device(st, a.kxyz.p, (size_t)M, ep.data(), (int)ep.size(), perm.p)); }
     launch_permute_staging(st, M, perm.p, a.kxyz.p, a.sdf.p, a.sdf_ref.p, a.alb.p, a.w.p, a.rgb.p, b.kxyz.p, b.sdf.p, b.sdf_ref.p, b.alb.p, b.w.p, b.rgb.p);
     CTX_HIP(c, hipStreamSynchronize(st));
     const float vs = c->voxel_size * 0.5f;
@@ -108,7 +102,20 @@ extern "C" {
 int64_t i3d_debug_map_order(const int32_t* keys, int64_t n, int32_t mode, int32_t* order) {
     if (n < 0 || (n && (!keys || !order))) return -1;
     std::vector<int> o;
-    if (mode == 2) map_iteration_order_stl(keys, (size_t)n, o); else map_iteration_order_replay(keys, (size_t)n, o, mode == 1);
+    if (mode == 2) map_iteration_order_stl(keys, (size_t)n, o);
+    else if (mode == 3) map_iteration_order_epochs(keys, (size_t)n, o);
+    else if (mode == 4) {                                     // the device path (distinct keys)
+        if (n == 0) return 0;
+        int *dk = nullptr, *dout = nullptr;
+        const std::vector<MapEpoch> ep = map_epochs((size_t)n);
+        bool ok = hipMalloc((void**)&dk, sizeof(int) * 3 * (size_t)n) == hipSuccess && hipMalloc((void**)&dout, sizeof(int) * (size_t)n) == hipSuccess
+                  && hipMemcpy(dk, keys, sizeof(int) * 3 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess
+                  && map_order_device(nullptr, dk, (size_t)n, ep.data(), (int)ep.size(), dout) == hipSuccess
+                  && hipMemcpy(order, dout, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess;
+        if (dk) (void)hipFree(dk); if (dout) (void)hipFree(dout);
+        return ok ? n : -1;
+    }
+    else map_iteration_order_replay(keys, (size_t)n, o, mode == 1);
     for (size_t i = 0; i < o.size(); ++i) order[i] = o[i];
     return (int64_t)o.size();
 }
@@ -213,9 +220,16 @@ int i3d_set_grid_from_tsdf_records(i3d_context* c, float voxel_size, int64_t n, 
     std::vector<int> o1;
     map_iteration_order_replay(keys, (size_t)n, o1, false);
     // map 2: VoxelSBR map filled in that order; invalid voxels (weight <= 0) are erased afterwards (order of the rest is unchanged)
-    std::vector<int> k2(3 * o1.size()), o2;
+    std::vector<int> k2(3 * o1.size()), o2(o1.size());
     for (size_t v = 0; v < o1.size(); ++v) for (int a = 0; a < 3; ++a) k2[3 * v + a] = keys[3 * (size_t)o1[v] + a];
-    map_iteration_order_replay(k2.data(), o1.size(), o2, true);
+    {   // distinct keys now: on the device (map_order.hip)
+        CTX_HIP(c, hipSetDevice(c->device));
+        DevBuf<int> dk, dord; CTX_HIP(c, dk.alloc(k2.size())); CTX_HIP(c, dord.alloc(o1.size()));
+        CTX_HIP(c, hipMemcpyAsync(dk.p, k2.data(), sizeof(int) * k2.size(), hipMemcpyHostToDevice, c->stream));
+        const std::vector<MapEpoch> ep = map_epochs(o1.size());
+        CTX_HIP(c, map_order_device(c->stream, dk.p, o1.size(), ep.data(), (int)ep.size(), dord.p));
+        CTX_HIP(c, hipMemcpy(o2.data(), dord.p, sizeof(int) * o2.size(), hipMemcpyDeviceToHost));
+    }
     std::vector<int32_t> k; std::vector<double> s, a; std::vector<float> w; std::vector<uint8_t> col;
     for (size_t v = 0; v < o2.size(); ++v) {
         const size_t i = (size_t)o1[(size_t)o2[v]];

@@ -10,8 +10,10 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <algorithm>
 #include <unordered_map>
 #include <vector>
+#include "../device/map_order_device.hpp"
 
 namespace i3d {
 
@@ -71,6 +73,45 @@ inline void map_iteration_order_replay(const int* keys, size_t n, std::vector<in
     }
     out.clear(); out.reserve(count);
     for (int p = head; p != -1; p = next[p]) out.push_back(distinct ? p : payload[p]);
+}
+
+// The rehash schedule of n insertions into the reference's map (reserve(64), then max_load_factor 0.6), from libstdc++'s own policy object:
+// epoch k holds bucket count nb and ends when the map has m_end elements (the insertion that triggers a rehash belongs to the NEXT epoch).
+// _M_need_rehash does nothing (and changes nothing) while count + 1 <= _M_next_resize, so only the calls that can do work are made.
+inline std::vector<MapEpoch> map_epochs(size_t n) {
+    std::__detail::_Prime_rehash_policy pol(1.0f);
+    size_t nb = pol._M_next_bkt(std::max<size_t>(pol._M_bkt_for_elements(1), 64));
+    pol = std::__detail::_Prime_rehash_policy(0.6f);
+    std::vector<MapEpoch> ep;
+    size_t i = 0;
+    while (i < n) {
+        const auto grow = pol._M_need_rehash(nb, i, 1);
+        if (grow.first) { ep.push_back(MapEpoch{i, nb}); nb = grow.second; }
+        ++i;
+        if (pol._M_next_resize > i) i = std::min(n, pol._M_next_resize);
+    }
+    ep.push_back(MapEpoch{n, nb});
+    return ep;
+}
+
+// The closed form the device uses (device/map_order.hip), on the host with std::sort: after every rehash epoch the list is the elements sorted by
+// (stamp of the arrival that created their bucket group, own stamp), both descending.  Test-only cross-check of the formulation (distinct keys).
+inline void map_iteration_order_epochs(const int* keys, size_t n, std::vector<int>& out) {
+    const std::vector<MapEpoch> ep = map_epochs(n);
+    std::vector<size_t> code(n); std::vector<int> pos(n, 0), order;
+    for (size_t i = 0; i < n; ++i) code[i] = voxel_hash(keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]);
+    size_t m_prev = 0;
+    for (const MapEpoch& e : ep) {
+        const size_t m = e.m_end;
+        if (m == m_prev) continue;
+        std::vector<int> gmin(e.nb, 0x7f7f7f7f), stamp(m);
+        for (size_t i = 0; i < m; ++i) { stamp[i] = i < m_prev ? pos[i] : (int)i; int& g = gmin[code[i] % e.nb]; g = std::min(g, stamp[i]); }
+        order.resize(m); for (size_t i = 0; i < m; ++i) order[i] = (int)i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { const int ga = gmin[code[a] % e.nb], gb = gmin[code[b] % e.nb]; return ga != gb ? ga > gb : stamp[a] > stamp[b]; });
+        for (size_t r = 0; r < m; ++r) pos[order[r]] = (int)r;
+        m_prev = m;
+    }
+    out = order;
 }
 
 // the same through a real std::unordered_map (used to cross-check the replay)

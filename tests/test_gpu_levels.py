@@ -265,3 +265,16 @@ def test_device_level_operations_match_committed_golden():
         l0, _ = ctx.get_frame_image(0, 0, w, h); l1, d1 = ctx.get_frame_image(0, 1, w // 2, h // 2); l2, _ = ctx.get_frame_image(0, 2, w // 4, h // 4)
         assert {"lum0": crc(l0), "lum1": crc(l1), "lum2": crc(l2), "depth1": crc(d1)} == gold["pyramid"]
     assert crc(binding.resize_depth(dep, [78.75, 78.0, 47.5, 35.5], 160, 120, [131.0, 131.5, 80.2, 59.1])) == gold["resize_depth"]["crc"]
+
+
+def test_map_order_on_the_device_matches_the_standard_container():
+    """device/map_order.hip (one atomicMin + radix sort per rehash epoch) against a real std::unordered_map with the reference's hash,
+    reserve(64) and load factor 0.6: sizes around the first rehash points, a size with ~14 epochs, negative coordinates."""
+    from intrinsic3d_amd import binding as B
+    rng = np.random.default_rng(4)
+    grid = np.stack(np.meshgrid(np.arange(-50, 50), np.arange(-45, 55), np.arange(-3, 77), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    rng.shuffle(grid)
+    for n in [1, 2, 39, 40, 41, 42, 63, 64, 65, 100, 1000, 4096, 65537, 300000, len(grid)]:
+        k = grid[:n]
+        got = B.debug_map_order(k, 4)
+        assert len(got) == n and np.array_equal(got, B.debug_map_order(k, 2)), n

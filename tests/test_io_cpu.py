@@ -191,6 +191,8 @@ def test_map_order_replay_matches_the_standard_container():
         ref = B.debug_map_order(k, 2)
         assert len(ref) == n
         assert np.array_equal(B.debug_map_order(k, 0), ref) and np.array_equal(B.debug_map_order(k, 1), ref), n
+        # the per-epoch closed form the device computes (device/map_order.hip), here on the host: groups and members by descending arrival stamp
+        assert np.array_equal(B.debug_map_order(k, 3), ref), n
     dup = grid[rng.integers(0, 5000, 30000)]                                  # ~5000 distinct keys, each repeated ~6 times
     ref = B.debug_map_order(dup, 2)
     assert len(ref) == len(np.unique(dup, axis=0)) and np.array_equal(B.debug_map_order(dup, 0), ref)
