@@ -154,8 +154,9 @@ def test_refine_two_levels_matches_oracle(oracle, scene, iterations, fix_intrins
     assert np.median(d_sdf) <= 1e-5 * smax and np.median(d_alb) <= 1e-5
     assert np.quantile(d_sdf, 0.999) <= max(1e-4 * smax, env["sdf_refined"]) and np.quantile(d_alb, 0.999) <= max(1e-4, env["albedo"])
     # isolated voxels next to a marginal decision (row validity, observation choice) may move further, in the oracle's own perturbed runs too
-    assert d_sdf.max() <= max(1e-4 * smax, helpers.ENVELOPE_FACTOR * env["sdf_refined"], 3e-3 * smax), (d_sdf.max(), smax, env)
-    assert d_alb.max() <= max(1e-4, helpers.ENVELOPE_FACTOR * env["albedo"], 3e-3), (d_alb.max(), env)
+    print("two-level refine: max |d sdf| / smax", d_sdf.max() / smax, "max |d albedo|", d_alb.max(), "envelope", env, "smax", smax)
+    assert d_sdf.max() <= max(1e-4 * smax, helpers.ENVELOPE_FACTOR * env["sdf_refined"]), (d_sdf.max(), smax, env)
+    assert d_alb.max() <= max(1e-4, helpers.ENVELOPE_FACTOR * env["albedo"]), (d_alb.max(), env)
     assert np.abs(intr - ointr).max() <= max(1e-5 * np.abs(ointr).max(), helpers.ENVELOPE_FACTOR * env["intr"])
     assert np.abs(poses - oposes).max() <= max(1e-5, helpers.ENVELOPE_FACTOR * env["poses"]), (np.abs(poses - oposes).max(), env)
     cd = np.abs(out["color"].astype(int) - ref["color"].astype(int))
