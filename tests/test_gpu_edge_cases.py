@@ -225,3 +225,15 @@ def test_carry_trust_radius_extension(oracle):
     assert [s.num_attempts for s in gstats] == [s.n_attempts for s in ostats]
     rc0, ref0, _, ostats0, out0, _, gstats0 = _run_both(oracle, sc, thres)
     assert gstats[1].num_attempts <= gstats0[1].num_attempts and gstats[0].num_attempts == gstats0[0].num_attempts
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_mailbox_transport_across_processes(world):
+    """tools/p2p_ipc_selftest: the mailbox transport between PROCESSES — IPC handles of the fine-grained mailboxes exchanged over pipes, no
+    RCCL — all-reduces of 4 and 1210 doubles and rim pushes between every pair, 100 rounds, every value checked.  (One device here, so the
+    ranks share it; on a multi-GPU node the same binary puts every rank on its own device.)"""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "p2p_ipc_selftest")
+    assert os.path.exists(exe), "tools/p2p_ipc_selftest has not been built (run __graft_entry__.build())"
+    r = subprocess.run([exe, str(world), "100"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
