@@ -70,7 +70,7 @@ static int alloc_rows(i3d_context* c, int slots) {
     if (!c->h_flags) { CTX_HIP(c, hipHostMalloc((void**)&c->h_flags, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
                        for (int i = 0; i < 16; ++i) c->h_flags[i] = -1;
                        CTX_HIP(c, hipHostGetDevicePointer((void**)&c->d_flags, c->h_flags, 0)); }
-    return ensure_pinned(c, 64 + (size_t)27 * c->K + 64);
+    return ensure_pinned(c, 64 + (size_t)27 * c->K + 64 + (size_t)18 * c->K + 64);      // + staging of the block preconditioner (36K + 41 floats), see lm_solve
 }
 
 // vector layout (common.hpp): [sdf chunk | albedo chunk | camera tail]; a rank's slice = the same segment of both parts
@@ -271,9 +271,14 @@ static bool spd_invert(int n, const double* m, double* inv) {            // Chol
 struct SharedBlocks { std::vector<double> c, H; };     // diag (6K+9) and upper triangles (21K+25) of J^T W J on the camera unknowns
 
 // block-Jacobi inverse of the pose (6x6), intrinsics (4x4) and distortion (5x5) blocks of  S H S + D^2
-static int upload_shared_precond(i3d_context* c, const OptParams& p, const SharedBlocks& sb, double radius) {
+// host part: the damped camera blocks of trust-region radius `radius`, inverted in fp64, into the pinned staging area
+static void prepare_shared_precond(i3d_context* c, const OptParams& p, const SharedBlocks& sb, double radius) {
     const int K = c->K;
-    std::vector<float> Minv((size_t)36 * K + 41, 0.0f);
+    // staged in pinned memory behind the read-back area: the copy is asynchronous, the next writer of this area is the next LM attempt (two
+    // stream synchronisations later)
+    float* const Minv = reinterpret_cast<float*>(c->h_pinned + 64 + (size_t)27 * K + 64);
+    const size_t nM = (size_t)36 * K + 41;
+    std::fill(Minv, Minv + nM, 0.0f);
     auto do_block = [&](int n, const double* cdiag, const double* tri, bool fixed, float* out) {
         if (fixed) return;
         double S[6], M[36], inv[36];
@@ -287,17 +292,22 @@ static int upload_shared_precond(i3d_context* c, const OptParams& p, const Share
     for (int f = 0; f < K; ++f) do_block(6, &sb.c[6 * f], &sb.H[21 * f], p.fix_poses, &Minv[36 * (size_t)f]);
     do_block(4, &sb.c[6 * K], &sb.H[21 * K], p.fix_intr, &Minv[36 * (size_t)K]);
     do_block(5, &sb.c[6 * K + 4], &sb.H[21 * K + 10], p.fix_dist, &Minv[36 * (size_t)K + 16]);
-    CTX_HIP(c, hipMemcpyAsync(c->Minv_blocks.p, Minv.data(), sizeof(float) * Minv.size(), hipMemcpyHostToDevice, c->stream));
-    CTX_HIP(c, hipStreamSynchronize(c->stream));
+}
+static int upload_shared_precond(i3d_context* c) {
+    const size_t nM = (size_t)36 * c->K + 41;
+    CTX_HIP(c, hipMemcpyAsync(c->Minv_blocks.p, reinterpret_cast<float*>(c->h_pinned + 64 + (size_t)27 * c->K + 64), sizeof(float) * nM, hipMemcpyHostToDevice, c->stream));
     return I3D_OK;
 }
 
-static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames, double* cost) {
+static int eval_cost_launch(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames) {
     GridView g = c->grid_view();
     if (candidate) { g.x_sdf = c->xc_sdf.p; g.x_alb = c->xc_alb.p; }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 16, 0, sizeof(double), c->stream));
     { TimedScope t(c, I3D_K_COST); launch_build(c->stream, g, c->row_view(), p, frames, false, c->d_scal.p + 16, c->d_partials.p); }
-    { int rc = allreduce(c, c->d_scal.p + 16, 1); if (rc) return rc; }
+    return allreduce(c, c->d_scal.p + 16, 1);
+}
+static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames, double* cost) {
+    int rc = eval_cost_launch(c, p, candidate, frames); if (rc) return rc;
     return read_doubles(c, c->d_scal.p + 16, 1, cost);
 }
 
@@ -307,7 +317,9 @@ static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const F
 //   * ONE small all-reduce after the operator: [camera block 6K+9 | p.q] (fp64);
 //   * ONE all-reduce of the 4 iteration scalars (r.z, x.(b+r), x.r, sum D^2 x^2) at the iteration boundary.
 // No vector is gathered: everything that lands on an owned unknown is computed from rows the rank holds itself (owned + ghost entries).
-static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, PcgState* final_state) {
+// The terminal state is copied to c->h_pcg[0] on the stream WITHOUT a synchronisation: the caller reads it after its next one (lm_solve queues
+// the candidate point behind the solve and synchronises once for both).
+static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p) {
     hipStream_t s = c->stream;
     const Layout L = layout_of(c);
     const int K = c->K; const bool multi = sharded(c), tiled = c->tile_ok;
@@ -398,10 +410,7 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
         if (it > 520) break;
     }
     c->pcg_seq = seq0 + it + 1;
-    CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[0], st, sizeof(PcgState), hipMemcpyDeviceToHost, s));
-    CTX_HIP(c, hipStreamSynchronize(s));
-    *final_state = c->h_pcg[0];                 // kernels after `done` were no-ops, so this is the terminal state
-    if (multi && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "pcg_solve: a peer-to-peer exchange timed out (a rank stopped taking part)");
+    CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[0], st, sizeof(PcgState), hipMemcpyDeviceToHost, s));      // kernels after `done` were no-ops, so this is the terminal state
     return I3D_OK;
 }
 
@@ -441,14 +450,28 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     CTX_HIP(c, hipMemcpyAsync(c->d_xshared.p, xshared.data(), sizeof(double) * NS, hipMemcpyHostToDevice, s));
 
     double radius = initial_radius, decrease_factor = 2.0;          // Ceres default 1e4 (initial_trust_region_radius)
+    double prepared_radius = -1.0;                                  // radius the staged block preconditioner was computed for
     int invalid = 0, attempts = 0;
     if (st) { st->termination = 0; st->final_radius = radius; }
     for (int iter = 1; iter <= cfg.lm_steps; ++iter) {
         if (radius < 1e-32) { if (st) st->termination = 1; break; }
         if (st) st->lm_iterations = iter;
         { TimedScope t(c, I3D_K_VECTOR); launch_lm_diag(s, NP, c->v_c.p, c->v_S.p, (float)(1.0 / radius), c->v_D2.p, c->v_Minv.p); }
-        rc = upload_shared_precond(c, p, sb, radius); if (rc) return rc;
-        PcgState ps; rc = pcg_solve(c, cfg, p, &ps); if (rc) return rc;
+        if (prepared_radius != radius) { prepare_shared_precond(c, p, sb, radius); prepared_radius = radius; }
+        rc = upload_shared_precond(c); if (rc) return rc;
+        rc = pcg_solve(c, cfg, p); if (rc) return rc;
+        // candidate point (replicated: every rank needs the whole step), queued behind the solve: ONE synchronisation returns the terminal PCG
+        // state, the step / parameter norms and the candidate camera.  (A step the model rejects below costs one wasted candidate kernel.)
+        { int rc2 = allgather(c, c->v_x.p); if (rc2) return rc2; }
+        CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 4, 0, sizeof(double) * 2, s));
+        { TimedScope t(c, I3D_K_VECTOR); launch_candidate(s, g, r, K, -1.0f, c->v_x.p, c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p, c->d_partials.p); }
+        CTX_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_xcshared.p, sizeof(double) * NS, hipMemcpyDeviceToHost, s));
+        CTX_HIP(c, hipMemcpyAsync(c->h_pinned + NS, c->d_scal.p + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+        CTX_HIP(c, hipStreamSynchronize(s));
+        if (sharded(c) && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "pcg_solve: a peer-to-peer exchange timed out (a rank stopped taking part)");
+        const PcgState ps = c->h_pcg[0];
+        const double norms[2] = {c->h_pinned[NS], c->h_pinned[NS + 1]};
+        std::memcpy(xcshared.data(), c->h_pinned, sizeof(double) * NS);
         if (st && attempts < 50) st->pcg_iterations[attempts] = ps.done == 2 ? ps.it + 1 : ps.it;     // Ceres counts the iteration it broke in
         // model_cost_change = -(J s)^T (r + J s / 2) with s = -x  ==  x.(b + r_cg)/2 + sum D^2 x^2 / 2
         const double model_change = 0.5 * ps.xbr + 0.5 * ps.d2xx;
@@ -460,18 +483,15 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
             radius *= 0.5; if (st) st->final_radius = radius; continue;
         }
         invalid = 0;
-        // candidate point (replicated: every rank needs the whole step)
-        { int rc2 = allgather(c, c->v_x.p); if (rc2) return rc2; }
-        CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 4, 0, sizeof(double) * 2, s));
-        { TimedScope t(c, I3D_K_VECTOR); launch_candidate(s, g, r, K, -1.0f, c->v_x.p, c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p, c->d_partials.p); }
-        double norms[2]; rc = read_doubles(c, c->d_scal.p + 4, 2, norms); if (rc) return rc;
-        rc = read_doubles(c, c->d_xcshared.p, NS, xcshared.data()); if (rc) return rc;
         OptParams pc = p;
         for (int i = 0; i < 4; ++i) pc.intr[i] = xcshared[6 * K + i];
         for (int i = 0; i < 5; ++i) pc.dist[i] = xcshared[6 * K + 4 + i];
         std::vector<FrameConst> fcc; build_frame_consts(c, cfg.rgbd_level, xcshared.data(), fcc);
         CTX_HIP(c, hipMemcpyAsync(c->d_frames_cand.p, fcc.data(), sizeof(FrameConst) * fcc.size(), hipMemcpyHostToDevice, s));
-        double cand_cost = 0.0; rc = eval_cost(c, pc, true, c->d_frames_cand.p, &cand_cost); if (rc) return rc;
+        rc = eval_cost_launch(c, pc, true, c->d_frames_cand.p); if (rc) return rc;
+        // while the cost kernel runs: the block preconditioner of the NEXT attempt, should this one be rejected (K Cholesky inversions on the host)
+        { const double next_radius = radius / decrease_factor; prepare_shared_precond(c, p, sb, next_radius); prepared_radius = next_radius; }
+        double cand_cost = 0.0; rc = read_doubles(c, c->d_scal.p + 16, 1, &cand_cost); if (rc) return rc;
         const double step_norm = std::sqrt(norms[0]), x_norm = std::sqrt(norms[1]);
         if (step_norm <= 1e-8 * (x_norm + 1e-8)) { if (st) { if (attempts < 50) st->step_accepted[attempts] = 0; st->termination = 1; } ++attempts; break; }
         const double cost_change = cost - cand_cost;
