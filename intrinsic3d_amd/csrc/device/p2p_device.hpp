@@ -9,7 +9,7 @@
 namespace i3d {
 
 constexpr int P2P_MAX_RANKS = 64;
-constexpr unsigned long long P2P_SPIN_LIMIT = 4000000000ull;       // ~2 s of s_memtime ticks
+constexpr unsigned long long P2P_SPIN_LIMIT = 60000000000ull;      // ~30 s of shader-clock ticks: a peer that is merely late (first launch in a fresh process loads the code object) is not a dead peer
 
 struct P2PLayout { int world, red_cap, halo_cap; size_t off_red, off_halo, bytes; };
 struct PeerPtrs { unsigned char* m[P2P_MAX_RANKS]; };             // every rank's mailbox as seen from this device

@@ -186,11 +186,14 @@ static __device__ inline void wave_accumulate_lds(bool valid, int f, const float
     }
 }
 
-template <int T, int HMAX, int SLOTS>
+// GHOSTS: the tile list continues with foreign tiles that hold this rank's ghost entries (sharded runs).  A template parameter because the
+// extra wave-uniform test costs the unrolled row loop registers: 12 instead of 4 spilled, 363 instead of 344 us on the single-GPU bench.
+template <int T, int HMAX, int SLOTS, bool GHOSTS>
 __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowView r, OptParams p, const float* __restrict__ u, const unsigned* __restrict__ lnbr,
                                                         const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx, const int* __restrict__ halo_cnt,
                                                         double* __restrict__ shared, float* __restrict__ qacc, float* __restrict__ qh, double* __restrict__ pq_partials,
-                                                        int reps, int tiles_per_block, int tile_first, const int* __restrict__ tile_list, int ntl, const PcgState* __restrict__ state) {
+                                                        int reps, int tiles_per_block, int tile_first, int n_own /* tiles [tile_first, +n_own): this rank's own */,
+                                                        const int* __restrict__ ghost_list /* then ntl - n_own foreign tiles holding ghost entries */, int ntl, const PcgState* __restrict__ state) {
     if (state && state->done) return;
     constexpr int ZSLOT = T + HMAX, NSLOT = ZSLOT + 1;
     extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T]
@@ -223,7 +226,8 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
     double pq = 0.0;
 
     for (int tk = tile0; tk < tile0 + tiles_per_block && tk < ntl; ++tk) {
-        const int tile = tile_list ? tile_list[tk] : tile_first + tk;
+        const bool ghost_tile = GHOSTS && tk >= n_own;     // a few ghost rows on the rim of a neighbour's tile: most of its waves have nothing to stream
+        const int tile = ghost_tile ? ghost_list[tk - n_own] : tile_first + tk;
         const int base = tile * T, a = base + i;
         const bool in = a < A;
         const bool owned = a >= r.own0 && a < r.own1;          // p.q and the camera block count a row once: on the rank that owns its voxel
@@ -323,7 +327,9 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
             }
             wave_accumulate_lds<6>(pvalid, fsel, pv, lds, reps, rs, o_wave_acc, 6);
         };
-        if (SLOTS > 0) {
+        if (SLOTS > 0 && ghost_tile && __ballot(nr > 0) == 0ull) {
+            // (wave-uniform, a scalar compare) no row in this wave of a ghost tile: nothing to stream
+        } else if (SLOTS > 0) {
 #pragma unroll
             for (int k = 0; k < SLOTS; k += 2) {               // slot k is in rwA, slot k+1 (if any) in rwB; a buffer is refilled as soon as it is consumed
                 consume(rwA, k);
@@ -475,23 +481,26 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
     { static int knob = -1; if (knob < 0) { const char* e = std::getenv("I3D_EGT_WG_PER_CU"); knob = e ? std::atoi(e) : 0; } if (knob > 0) per_cu = knob; }
     // tiles in units of T: the plan counts tiles of tp_T() == T
     int written = 0;
-    auto run = [&](int ntl, int tile_first, const int* tile_list, bool unrolled) {
-        if (ntl <= 0) return;
-        int blocks = ntl < per_cu * num_cu ? ntl : per_cu * num_cu;
-        int tiles_per_block = (ntl + blocks - 1) / blocks;
-        // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
-        // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
-        if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
-        double* pqp = pq_partials ? pq_partials + written : nullptr;
-#define I3D_EGT(SL) do { (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        k_eg_tile<T, HMAX, SL><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pqp, reps, tiles_per_block, tile_first, tile_list, ntl, state); } while (0)
-        if (unrolled && r.slots == 5) I3D_EGT(5);             // the shipped num_observations (data/intrinsic3d.yml)
-        else I3D_EGT(0);
+    // ONE launch over the rank's own tiles followed by the foreign tiles that hold its ghost entries (the short ghost tiles fill the idle tail of
+    // the last round of own tiles instead of paying a launch and a round of their own)
+    {
+        const int ntl = t.ntiles_own + t.n_ghost;
+        if (ntl > 0) {
+            int blocks = ntl < per_cu * num_cu ? ntl : per_cu * num_cu;
+            int tiles_per_block = (ntl + blocks - 1) / blocks;
+            // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
+            // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
+            if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
+#define I3D_EGT(SL, GH) do { (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, GH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        k_eg_tile<T, HMAX, SL, GH><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
+                                                      t.ghost_tiles, ntl, state); } while (0)
+            const bool gh = t.n_ghost > 0;
+            if (r.slots == 5) { if (gh) I3D_EGT(5, true); else I3D_EGT(5, false); }      // the shipped num_observations (data/intrinsic3d.yml): unrolled row loop
+            else { if (gh) I3D_EGT(0, true); else I3D_EGT(0, false); }
 #undef I3D_EGT
-        written += blocks;
-    };
-    run(t.ntiles_own, t.tile_first, nullptr, true);
-    run(t.n_ghost, 0, t.ghost_tiles, false);                  // foreign tiles: a few ghost rows each, run-time row loop (no rows are fetched for the other lanes)
+            written = blocks;
+        }
+    }
     return written;                                          // number of p.q partials written
 }
 

@@ -21,6 +21,8 @@
 
 namespace i3d {
 
+__global__ void k_p2p_warmup(int* p) { if (p && threadIdx.x == 12345) *p = 0; }
+
 // dev[0..n) <- sum over ranks, in rank order
 __global__ void __launch_bounds__(1024) k_p2p_allreduce(double* __restrict__ dev, int n, P2PDev d) { p2p_allreduce_wg(d, dev, n); }
 
@@ -71,7 +73,10 @@ int P2PEngine::create(int rank_, int world_, int red_cap, int halo_cap) {
     if (hipMalloc((void**)&d_epoch_red, sizeof(unsigned long long)) != hipSuccess || hipMemset(d_epoch_red, 0, sizeof(unsigned long long)) != hipSuccess) return 1;
     for (int k = 0; k < P2P_MAX_RANKS; ++k) peer[k] = nullptr;
     peer[rank] = mailbox;
-    return 0;
+    // the first launch from this library loads its code object (hundreds of ms in a fresh process, more when several ranks start together): do it
+    // here, before any peer can be waiting for this rank inside an exchange
+    k_p2p_warmup<<<1, 64>>>(d_err);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
 }
 int P2PEngine::export_handle(void* out64) { hipIpcMemHandle_t h; if (hipIpcGetMemHandle(&h, mailbox) != hipSuccess) return 1; std::memcpy(out64, &h, sizeof(h)); return 0; }
 int P2PEngine::attach_ipc(const void* handles /* world x 64 bytes */) {

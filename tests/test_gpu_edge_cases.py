@@ -145,10 +145,13 @@ def test_many_keyframes(oracle):
     np.testing.assert_allclose(cam[2], ocam[2], rtol=1e-4, atol=1e-6)
 
 
-def test_real_rccl_collectives_with_one_rank(oracle, monkeypatch):
-    """the sharded code path driven through a REAL 1-rank RCCL communicator (I3D_FORCE_COLLECTIVES=1): in-place all-gather, the grouped
-    all-reduce + all-gather, the camera-block all-reduce — same answer as the plain path"""
+@pytest.mark.parametrize("transport", ["p2p", "rccl"])
+def test_real_rccl_collectives_with_one_rank(oracle, monkeypatch, transport):
+    """the sharded code path driven through a REAL 1-rank RCCL communicator (I3D_FORCE_COLLECTIVES=1) — same answer as the plain path —
+    with the mailbox transport (bootstrap over RCCL, start-up self-test, reductions inside the boundary kernels) and with the RCCL fallback
+    (I3D_TRANSPORT=rccl: grouped send / receive for the rim, ncclAllReduce for the blocks, separate reduction launches)"""
     from intrinsic3d_amd import binding
+    monkeypatch.setenv("I3D_TRANSPORT", transport)
     sc = helpers.small_scene(seed=14, radius_vox=9, K=4, width=96, height=72)
     g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc)
     cfg = helpers.gpu_cfg(helpers.oracle_cfg(oracle, thres, iterations=2, cg_fixed_iterations=12))
@@ -156,6 +159,7 @@ def test_real_rccl_collectives_with_one_rank(oracle, monkeypatch):
     monkeypatch.setenv("I3D_FORCE_COLLECTIVES", "1")
     ctx = helpers.gpu_context(sc, arrays, vsh)
     ctx.comm_init(0, 1, binding.Context.comm_unique_id())
+    assert ctx.comm_transport().startswith("p2p-mailbox" if transport == "p2p" else "rccl")
     st1 = ctx.optimize(cfg); s1, a1 = ctx.get_grid(); cam1 = ctx.get_camera(); ctx.close()
     assert [list(s.rows) for s in st0] == [list(s.rows) for s in st1]
     assert np.abs(s1 - s0).max() <= 1e-4 * np.abs(s0).max() and np.abs(a1 - a0).max() <= 1e-4
