@@ -606,19 +606,18 @@ __global__ void k_freemask(RowView r, OptParams p, float* __restrict__ mask) {
 void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask) { k_freemask<<<vblocks(2 * r.chunk + 6 * p.K + 9), 256, 0, st>>>(r, p, mask); }
 
 // ---- fused PCG iteration (conjugate_gradients_solver.cc) -------------------------------------------------------------
-// One iteration = 6 launches:  tail_a | direction | eg_jtjp | gather | tail_b | step.
-//   k_pcg_step   (a rank's slice of the voxel unknowns, 16 B per lane):  x += alpha p ; r -= alpha q ; z = M^-1 r ; slice partial
-//                sums of r.z, x.(b+r), x.r, sum D^2 x^2 into state->acc[4]  (ONE 4-double all-reduce per iteration when sharded,
-//                issued together with the all-gather of z)
-//   k_pcg_tail_a (camera tail, replicated, one workgroup): same update on the 6K+9 camera unknowns, block-Jacobi z, adds its sums to
-//                the reduced slice sums, then the scalar logic of the iteration boundary: quadratic-model stop test (eta = 0.1) of the
-//                iteration just finished, rho / beta of the next one
-//   k_pcg_direction  p = z + beta p ; u = S p   (over the whole vector when sharded: p is kept replicated, so the operator input
-//                needs no exchange of its own)
-//   k_pcg_tail_b camera tail of q = A p from the reduced fp64 block, p.q, alpha
+// One iteration = 6 launches:  tail_a | direction | eg_tile | halo_fold | tail_b | step   (+ the rim push of the operator input when sharded).
+//   k_pcg_step   (a rank's slice of the voxel unknowns, 16 B per lane):  x += alpha p ; q = S acc + D^2 p ; r -= alpha q ; z = M^-1 r ;
+//                per-workgroup partial sums of r.z, x.(b+r), x.r, sum D^2 x^2
+//   k_pcg_tail_a (camera tail, replicated, one workgroup): adds up the partials (sharded over the mailbox transport: and sums them over the
+//                ranks, p2p_allreduce_wg), the same update on the 6K+9 camera unknowns, block-Jacobi z, then the scalar logic of the iteration
+//                boundary: quadratic-model stop test (eta = 0.1) of the iteration just finished, rho / beta of the next one
+//   k_pcg_direction  p = z + beta p ; u = S p on the rank's slice + the camera tail; partial sums of D^2 p^2
+//   k_pcg_tail_b (one workgroup) p.q from the row and D^2 p^2 partials (sharded: [camera block | p.q] summed over the ranks), camera tail of
+//                q = A p from the fp64 block, alpha
 enum { STEP_INIT = 0, STEP_NORMAL = 1, STEP_XONLY = 2, STEP_RESET = 3 };
 
-// QINLINE: `q` holds the raw operator accumulators J^T W J u of the tiled pass (k_eg_tile + k_ext_gather); the vector q = S acc + D^2 v
+// QINLINE: `q` holds the raw operator accumulators J^T W J u of the tiled pass (k_eg_tile + k_halo_fold); the vector q = S acc + D^2 v
 // (v = p, or x for the residual reset) is formed here instead of being written and read back.
 template <int MODE, bool QINLINE>
 __global__ void __launch_bounds__(256) k_pcg_step(int n4, int seg4 /* float4 distance between the sdf and the albedo segment */, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x, float4* __restrict__ r,

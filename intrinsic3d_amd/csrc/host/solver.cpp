@@ -370,7 +370,8 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     const int seq0 = c->pcg_seq;               // pass numbers are unique across solves: a stale ring entry can never match
     int it = 1;
     for (;; ++it) {
-        // iteration boundary.  Sharded: the 4 slice sums (r.z, x.(b+r), x.r, sum D2 x^2) are all-reduced (sharded k_pcg_step adds into acc directly)
+        // iteration boundary.  Sharded: the 4 slice sums (r.z, x.(b+r), x.r, sum D2 x^2) are summed over the ranks — inside k_pcg_tail_a over the
+        // mailbox transport, by a reduction + all-reduce launch otherwise
         if (multi && !fused) { int rc = allreduce(c, st->acc, 4); if (rc) return rc; }
         if (fused) { c->comm->count_reduce(4); c->comm->count_reduce((size_t)L.NS + 1); }
         { TimedScope t(c, I3D_K_VECTOR);
