@@ -622,7 +622,7 @@ enum { STEP_INIT = 0, STEP_NORMAL = 1, STEP_XONLY = 2, STEP_RESET = 3 };
 template <int MODE, bool QINLINE>
 __global__ void __launch_bounds__(256) k_pcg_step(int n4, int seg4 /* float4 distance between the sdf and the albedo segment */, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x, float4* __restrict__ r,
                                                   const float4* __restrict__ b, const float4* __restrict__ D2, const float4* __restrict__ Minv, float4* __restrict__ z,
-                                                  const float4* __restrict__ S, double* __restrict__ partials /* nullptr: add to state->acc directly (sharded) */, PcgState* state) {
+                                                  const float4* __restrict__ S, double* __restrict__ partials /* [gridDim.x][4] */, PcgState* state) {
     if (state->done) return;
     const float alpha = (float)state->alpha;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -660,11 +660,7 @@ __global__ void __launch_bounds__(256) k_pcg_step(int n4, int seg4 /* float4 dis
         for (int k = 0; k < 4; ++k) s0 += (double)rv[k] * (double)zv[k];
     }
     if (MODE == STEP_XONLY) return;
-    if (partials) { block_partial_d(s0, partials, 4, 0); block_partial_d(s1, partials, 4, 1); block_partial_d(s2, partials, 4, 2); block_partial_d(s3, partials, 4, 3); }
-    else {
-        const double t0 = block_sum_d(s0), t1 = block_sum_d(s1), t2 = block_sum_d(s2), t3 = block_sum_d(s3);
-        if (threadIdx.x == 0) { atomicAdd(&state->acc[0], t0); if (MODE != STEP_INIT) { atomicAdd(&state->acc[1], t1); atomicAdd(&state->acc[2], t2); atomicAdd(&state->acc[3], t3); } }
-    }
+    block_partial_d(s0, partials, 4, 0); block_partial_d(s1, partials, 4, 1); block_partial_d(s2, partials, 4, 2); block_partial_d(s3, partials, 4, 3);
 }
 
 // camera tail, x only (residual-reset iterations: x is needed before r = b - A x can be formed)
@@ -851,7 +847,7 @@ int launch_pcg_step(hipStream_t st, int mode, Seg2 sg, const float* p, const flo
         default:          if (S) I3D_STEP(STEP_RESET, true); else I3D_STEP(STEP_RESET, false); break;
     }
 #undef I3D_STEP
-    return (mode == STEP_XONLY || !partials) ? 0 : blocks;      // number of [4]-partials written
+    return mode == STEP_XONLY ? 0 : blocks;      // number of [4]-partials written
 }
 void launch_pcg_tail_x(hipStream_t st, size_t tail_off, int K, const float* p, float* x, const PcgState* state) { k_pcg_tail_x<<<1, 256, 0, st>>>(tail_off, 6 * K + 9, p, x, state); }
 void launch_pcg_tail_a(hipStream_t st, int mode, size_t tail_off, int K, const float* Minv_blocks, const float* p, const float* q, float* x, float* r, const float* b,
