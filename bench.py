@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_TAG = "r02-tile-pass"  # bumped when k_build<true> / k_eg_tile change materially: PMC traffic files of older kernels are not attached
+KERNEL_TAG = "r02-tile-pass-nt"  # bumped when k_build<true> / k_eg_tile change materially: PMC traffic files of older kernels are not attached
 
 
 def parse_args():

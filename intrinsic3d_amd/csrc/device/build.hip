@@ -22,6 +22,11 @@
 
 namespace i3d {
 
+// The row set (1.46 GB on the bench workload) is written once per outer iteration and read much later: non-temporal stores, so that it does not
+// displace the keyframe images (245 MB, re-read by every wave) and the voxel state from the last-level cache.
+typedef float v4f_row __attribute__((ext_vector_type(4)));
+static __device__ inline void st_row(float4* p, float a, float b, float c, float d) { v4f_row v; v.x = a; v.y = b; v.z = c; v.w = d; __builtin_nontemporal_store(v, reinterpret_cast<v4f_row*>(p)); }
+
 // 4 consecutive taps of one image row as ONE 16-byte load from a 4-byte aligned address.  The pointer is re-typed to the global
 // address space: it reaches the kernel through a per-keyframe struct staged in LDS, which makes it a FLAT pointer for the compiler,
 // and flat accesses are neither widened nor allowed to be misaligned (64 flat_load_dword per row instead of 16 global_load_dwordx4).
@@ -370,8 +375,8 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowVi
                 // rows of a voxel are compacted into its first slots (creation order = ascending observation weight)
 #pragma unroll
                 for (int gq = 0; gq < 7; ++gq)
-                    r.rows[row_index(a, nout, gq, r.slots)] = make_float4(J[4 * gq], J[4 * gq + 1], J[4 * gq + 2], J[4 * gq + 3]);
-                r.rows[row_index(a, nout, 7, r.slots)] = make_float4(roww, (float)res, __int_as_float(f | (vox_free ? ROW_FREE_BIT : 0)), J[28]);
+                    st_row(&r.rows[row_index(a, nout, gq, r.slots)], J[4 * gq], J[4 * gq + 1], J[4 * gq + 2], J[4 * gq + 3]);
+                st_row(&r.rows[row_index(a, nout, 7, r.slots)], roww, (float)res, __int_as_float(f | (vox_free ? ROW_FREE_BIT : 0)), J[28]);
                 ++nout;
             }
         }

@@ -112,8 +112,8 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
             const float4* __restrict__ row = r.rows + row_index(ac, k, 0, r.slots);     // 8 planes, 64 float4 apart: one contiguous 8 KB block per wave
             float4 j4[7];
 #pragma unroll
-            for (int q = 0; q < 7; ++q) j4[q] = row[q * 64];
-            const float4 m = row[7 * 64];
+            for (int q = 0; q < 7; ++q) j4[q] = ld_row(row + q * 64);
+            const float4 m = ld_row(row + 7 * 64);
             constexpr int NPV = (MODE == PASS_COLNORM) ? 21 : 6;
             float pv[NPV]; int fsel = 0; bool pvalid = false;
 #pragma unroll
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
         float4 rwA[8], rwB[8];
         if (nr_max > 0) { const float4* __restrict__ row = r.rows + row_index(ac, 0, 0, r.slots);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+            for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
         // operator input at the 14 stencil unknowns of the voxel -> LDS (0 where the neighbour is not in the list = fixed parameter)
         if (in) {
 #pragma unroll
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
         }
         if (nr_max > 1) { const float4* __restrict__ row = r.rows + row_index(ac, 1, 0, r.slots);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+            for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
         // ---- regulariser rows: tr (Er), ts (Es, Jacobian folded in), ta[6] (Ea).  They do not depend on the Eg rows: computed HERE, while
         //      the first two row blocks are in flight, so their index / vector gathers cost no round trip of their own ----
         if (in) {
@@ -386,12 +386,12 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
             consume(rwA, k);
             if (k + 2 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 2, 0, r.slots);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+                for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
             if (k + 1 < nr_max) {
                 consume(rwB, k + 1);
                 if (k + 3 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 3, 0, r.slots);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+                    for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
             }
         }
         if (in) {

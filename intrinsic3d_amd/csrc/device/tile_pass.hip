@@ -240,20 +240,20 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
         const uint8_t rf_ld = r.regflags[ac];
         unsigned ln[6];
 #pragma unroll
-        for (int w = 0; w < 6; ++w) ln[w] = lnbr[(size_t)w * Acap + ac];
+        for (int w = 0; w < 6; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);      // per-entry plan data: read once per pass, like the rows
         float hs[(HMAX + T - 1) / T], ha[(HMAX + T - 1) / T];
 #pragma unroll
         for (int q = 0; q < (HMAX + T - 1) / T; ++q) {
             const int hq = i + q * T; hs[q] = 0.0f; ha[q] = 0.0f;
-            if (hq < H) { const int e = halo_idx[(size_t)tile * HMAX + hq]; hs[q] = u[e]; ha[q] = u[chunk + e]; }
+            if (hq < H) { const int e = __builtin_nontemporal_load(&halo_idx[(size_t)tile * HMAX + hq]); hs[q] = u[e]; ha[q] = u[chunk + e]; }
         }
         float4 rwA[8], rwB[8];
         { const float4* __restrict__ row = r.rows + row_index(ac, 0, 0, r.slots);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+            for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
         if (SLOTS > 1 || (SLOTS == 0 && r.slots > 1)) { const float4* __restrict__ row = r.rows + row_index(ac, 1, 0, r.slots);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+            for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
         // ---- stage the operator input of tile + halo, clear the accumulators ----
         u_s[i] = us; u_a[i] = ua;
 #pragma unroll
@@ -335,12 +335,12 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
                 consume(rwA, k);
                 if (k + 2 < SLOTS) { const float4* __restrict__ row = r.rows + row_index(ac, k + 2, 0, SLOTS);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+                    for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
                 if (k + 1 < SLOTS) {
                     consume(rwB, k + 1);
                     if (k + 3 < SLOTS) { const float4* __restrict__ row = r.rows + row_index(ac, k + 3, 0, SLOTS);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+                        for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
                 }
             }
         } else {
@@ -348,12 +348,12 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
                 consume(rwA, k);
                 if (k + 2 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 2, 0, r.slots);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) rwA[q] = row[q * 64]; }
+                    for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
                 if (k + 1 < nr_max) {
                     consume(rwB, k + 1);
                     if (k + 3 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 3, 0, r.slots);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) rwB[q] = row[q * 64]; }
+                        for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
                 }
             }
         }
@@ -361,10 +361,10 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
         // what the pull phase needs in addition (requested now, used behind the barrier): the 6 further reverse slots, the symmetric Ea weights
         unsigned lr[3];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) lr[w] = lnbr[(size_t)(6 + w) * Acap + ac];
+        for (int w = 0; w < 3; ++w) lr[w] = __builtin_nontemporal_load(&lnbr[(size_t)(6 + w) * Acap + ac]);
         float eaw[6];
 #pragma unroll
-        for (int d = 0; d < 6; ++d) eaw[d] = eaw_sym[(size_t)d * Acap + ac];
+        for (int d = 0; d < 6; ++d) eaw[d] = __builtin_nontemporal_load(&eaw_sym[(size_t)d * Acap + ac]);
         // ---- what lands in the halo is pushed (few lanes: the tile's outer shell) ----
         if (nr > 0) {
 #pragma unroll
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(256) k_halo_fold(int n, const int* __restrict_
     if (state && state->done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int e = ext_e[i];
+    const int e = ext_e[i];                 // (not non-temporal: the neighbouring lane re-reads it; measured 22 -> 26 us with nt)
     if (e >= TP_NONE || (i > 0 && ext_e[i - 1] == e)) return;
     float s = 0.0f, al = 0.0f;
     for (int j = i; j < n && ext_e[j] == e; ++j) { const float2 v = reinterpret_cast<const float2*>(qh)[ext_pos[j]]; s += v.x; al += v.y; }

@@ -4,6 +4,12 @@
 
 namespace i3d {
 
+// One 16-byte piece of a stored Eg row.  The row set (1.46 GB on the bench workload) is streamed once per pass: NON-TEMPORAL, so that it does not
+// displace the solver vectors and the plan data from the L2 / last-level cache (measured on the operator pass: 316 -> 299 us, and the vector
+// kernels behind it get faster too).
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+static __device__ inline float4 ld_row(const float4* p) { const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+
 // sum of v over the 64 lanes of the wave, returned to every lane: 4 DPP steps inside each row of 16 lanes (pure VALU, no LDS
 // crossbar), then the four row totals through scalar registers
 static __device__ inline float wave_sum(float v) {
