@@ -10,11 +10,12 @@ namespace i3d {
 
 constexpr int P2P_MAX_RANKS = 64;
 constexpr unsigned long long P2P_SPIN_LIMIT = 60000000000ull;      // ~30 s of shader-clock ticks: a peer that is merely late (first launch in a fresh process loads the code object) is not a dead peer
+constexpr unsigned long long P2P_SPIN_LIMIT_SELFTEST = 10000000000ull;   // ~5 s while the start-up self-test decides whether the transport works at all
 
 struct P2PLayout { int world, red_cap, halo_cap; size_t off_red, off_halo, bytes; };
 struct PeerPtrs { unsigned char* m[P2P_MAX_RANKS]; };             // every rank's mailbox as seen from this device
 // handle passed BY VALUE to kernels; on == 0: no transport (the kernel behaves as on a single rank)
-struct P2PDev { int on, me; P2PLayout L; int* err; unsigned long long* epoch_red /* device counter of the all-reduces performed so far */; PeerPtrs peers; };
+struct P2PDev { int on, me; P2PLayout L; int* err; unsigned long long* epoch_red /* device counter of the all-reduces performed so far */; unsigned long long spin_limit; PeerPtrs peers; };
 
 // Mailbox words are SELF-VALIDATING (the "LL" idea of the collective libraries): every 8-byte word carries 4 bytes of payload and the low 32
 // bits of the exchange's epoch, written by ONE 8-byte store and polled by 8-byte loads.  An 8-byte store is atomic, so a reader that sees the
@@ -26,7 +27,7 @@ static __device__ inline void p2p_put(unsigned long long* w, unsigned payload, u
     __hip_atomic_store(w, ((unsigned long long)epoch32 << 32) | (unsigned long long)payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // bounded wait for the word of this epoch; a timeout latches *err (the host turns it into I3D_ERR_COMM) and returns 0
-static __device__ inline unsigned p2p_get(unsigned long long* w, unsigned epoch32, int* err) {
+static __device__ inline unsigned p2p_get(unsigned long long* w, unsigned epoch32, int* err, unsigned long long spin_limit) {
     unsigned long long x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(x >> 32) == epoch32) return (unsigned)x;
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -34,7 +35,8 @@ static __device__ inline unsigned p2p_get(unsigned long long* w, unsigned epoch3
         __builtin_amdgcn_s_sleep(1);
         x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((unsigned)(x >> 32) == epoch32) return (unsigned)x;
-        if (__builtin_readcyclecounter() - t0 > P2P_SPIN_LIMIT) { atomicExch(err, 1); return 0u; }
+        if (__builtin_readcyclecounter() - t0 > spin_limit) { atomicExch(err, 1); return 0u; }
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0u;      // another wait of this rank has already given up: fail fast
     }
 }
 
@@ -59,7 +61,7 @@ static __device__ inline void p2p_allreduce_wg(const P2PDev& d, double* dev, int
         double s = 0.0;
         for (int j = 0; j < W; ++j) {
             unsigned long long* src = p2p_red_words(d.peers.m[me], d.L, par, j);
-            const unsigned lo = p2p_get(&src[2 * i], e32, d.err), hi = p2p_get(&src[2 * i + 1], e32, d.err);
+            const unsigned lo = p2p_get(&src[2 * i], e32, d.err, d.spin_limit), hi = p2p_get(&src[2 * i + 1], e32, d.err, d.spin_limit);
             s += __hiloint2double((int)hi, (int)lo);
         }
         dev[i] = s;

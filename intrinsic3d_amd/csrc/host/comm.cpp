@@ -79,6 +79,7 @@ static bool bootstrap_p2p(RcclComm* c, hipStream_t st) {
     if (d_test) { (void)hipMemcpy(d_test, &flag, sizeof(double), hipMemcpyHostToDevice); (void)ncclAllReduce(d_test, d_test, 1, ncclDouble, ncclMin, c->comm, st); (void)hipStreamSynchronize(st);
                   (void)hipMemcpy(&flag, d_test, sizeof(double), hipMemcpyDeviceToHost); }
     ok = ok && flag == 1.0;
+    c->p2p.spin_limit = P2P_SPIN_LIMIT_SELFTEST;
     if (ok) {        // self-test with real exchanges and bounded waits: small and full-size all-reduces, then rim pushes between every pair
         const int big = P2P_RED_CAP;
         double* d_big = nullptr; std::vector<double> hb(big);
@@ -124,6 +125,7 @@ static bool bootstrap_p2p(RcclComm* c, hipStream_t st) {
         (void)hipMemcpy(&flag, d_test, sizeof(double), hipMemcpyDeviceToHost);
         ok = flag == 1.0;
     }
+    c->p2p.spin_limit = P2P_SPIN_LIMIT;
     if (d_handles) (void)hipFree(d_handles); if (d_test) (void)hipFree(d_test);
     if (!ok) c->p2p.destroy();
     return ok;

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(1024) k_p2p_allreduce(double* __restrict__ dev
 // rim of the operator input: vec[e], vec[chunk + e] of this rank's send list -> the peers' mailboxes; their values for this rank -> vec
 __global__ void __launch_bounds__(1024) k_p2p_halo(float* __restrict__ vec, int chunk, int me, P2PLayout L, PeerPtrs peers, unsigned long long epoch,
                                                    const int* __restrict__ send_idx, const int* __restrict__ send_off, const int* __restrict__ send_cnt,
-                                                   const int* __restrict__ recv_idx, const int* __restrict__ recv_off, const int* __restrict__ recv_cnt, int* err) {
+                                                   const int* __restrict__ recv_idx, const int* __restrict__ recv_off, const int* __restrict__ recv_cnt, int* err, unsigned long long spin_limit) {
     const int par = (int)(epoch & 1ull), W = L.world;
     const unsigned e32 = (unsigned)epoch;
     for (int k = 0; k < W; ++k) {
@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(1024) k_p2p_halo(float* __restrict__ vec, int 
         const int off = recv_off[k]; unsigned long long* src = p2p_halo_words(peers.m[me], L, par, k);
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
             const int e = recv_idx[off + i];
-            vec[e] = __uint_as_float(p2p_get(&src[2 * i], e32, err));
-            vec[(size_t)chunk + e] = __uint_as_float(p2p_get(&src[2 * i + 1], e32, err));
+            vec[e] = __uint_as_float(p2p_get(&src[2 * i], e32, err, spin_limit));
+            vec[(size_t)chunk + e] = __uint_as_float(p2p_get(&src[2 * i + 1], e32, err, spin_limit));
         }
     }
 }
@@ -98,7 +98,7 @@ void P2PEngine::destroy() {
 
 static PeerPtrs ptrs_of(const P2PEngine& e) { PeerPtrs p; for (int k = 0; k < P2P_MAX_RANKS; ++k) p.m[k] = e.peer[k]; return p; }
 
-P2PDev P2PEngine::device() const { P2PDev d; d.on = ready ? 1 : 0; d.me = rank; d.L = L; d.err = d_err; d.epoch_red = d_epoch_red; d.peers = ptrs_of(*this); return d; }
+P2PDev P2PEngine::device() const { P2PDev d; d.on = ready ? 1 : 0; d.me = rank; d.L = L; d.err = d_err; d.epoch_red = d_epoch_red; d.spin_limit = spin_limit; d.peers = ptrs_of(*this); return d; }
 
 int P2PEngine::allreduce(double* dev, size_t n, hipStream_t st) {
     if ((int)n > L.red_cap) return 1;
@@ -115,7 +115,7 @@ int P2PEngine::set_halo_lists(const HaloPlan& h, hipStream_t st) {      // once 
 int P2PEngine::push_halo(float* vec, const HaloPlan& h, hipStream_t st) {
     ++epoch_halo; if ((unsigned)epoch_halo == 0u) ++epoch_halo;
     k_p2p_halo<<<1, 1024, 0, st>>>(vec, h.chunk, rank, L, ptrs_of(*this), epoch_halo, h.d_send_idx, d_lists, d_lists + P2P_MAX_RANKS, h.d_recv_idx, d_lists + 2 * P2P_MAX_RANKS,
-                                   d_lists + 3 * P2P_MAX_RANKS, d_err);
+                                   d_lists + 3 * P2P_MAX_RANKS, d_err, spin_limit);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int P2PEngine::check(hipStream_t st) {      // has any spin timed out?  (synchronises the stream)

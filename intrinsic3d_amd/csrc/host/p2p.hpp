@@ -18,6 +18,7 @@ struct P2PEngine {
     int* d_err = nullptr; int* d_lists = nullptr;
     unsigned long long* d_epoch_red = nullptr;        // all-reduces performed so far (device counter, see p2p_device.hpp)
     unsigned long long epoch_halo = 0;
+    unsigned long long spin_limit = P2P_SPIN_LIMIT;   // bound of every wait (shader-clock ticks)
 
     int  create(int rank, int world, int red_cap, int halo_cap);
     int  export_handle(void* out64);                  // hipIpcMemHandle_t of the mailbox
