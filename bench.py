@@ -242,7 +242,8 @@ def _main():
     ctx.set_grid(sc["voxel_size"], arrays["keys"], arrays["sdf"], arrays["sdf_refined"], arrays["albedo"], arrays["weight"], arrays["color"])
     ctx.set_frames(sc["frames"], 1)
     ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
-    log(f"upload + hash/neighbour build: {time.time() - t0:.2f}s")
+    torch.cuda.synchronize(); t_upload = time.time() - t0
+    log(f"upload + hash/neighbour build: {t_upload:.2f}s")
     t0 = time.time()
     sh_sub, _, sh_stats = ctx.estimate_sh(args.subvolume, 10.0, thres)       # LightingSVSH::estimate + computeVoxelShCoeffs (intrinsic3d.cpp:255-264)
     log(f"SH estimate: {sh_sub.shape[0]} subvolumes, {sh_stats.data_rows} data rows, {sh_stats.lm_iterations} LM iterations in {time.time() - t0:.2f}s")
@@ -273,6 +274,7 @@ def _main():
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    t0 = time.time(); _ = ctx.get_grid(); _ = ctx.get_camera(); t_download = time.time() - t0          # what a host-buffer caller reads back
     timing_work = ctx.timing_get_work()      # launches that did work (PCG launches queued behind the convergence flag return at once)
     timing = ctx.timing_get(reset=True)
     sizes = ctx.problem_sizes()
@@ -351,6 +353,10 @@ def _main():
             "kernel_ms_total": {k: v[0] for k, v in timing.items()}, "kernel_launches": {k: v[1] for k, v in timing.items()},
             "time_split_ms_per_step": {"time_add": float(np.mean([s.time_add for s in stats]) * 1e3), "time_solve": float(np.mean([s.time_solve for s in stats]) * 1e3)},
             "cost": [float(stats[0].cost_initial), float(stats[-1].cost_final)],
+            # the boundary also accepts host buffers (i3d_set_grid / i3d_set_frames / i3d_optimize_host): the same run with the one-off upload
+            # (voxels + keyframe pyramids over PCIe, hash / neighbour-table build) and the read-back of the refined fields counted in.  Never `value`.
+            "host_buffers_inclusive": {"upload_and_grid_build_s": t_upload, "download_s": t_download,
+                                       "iterations_per_s": args.steps / (dt + t_upload + t_download)},
             "cpu_baseline": cpu,
         }
         _emit(json.dumps(out))
