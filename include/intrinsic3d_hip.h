@@ -250,8 +250,8 @@ int  i3d_fusion_save(const i3d_fusion* f, const char* path);
 
 /* ---- one process per GPU: the voxel state is replicated; row work / row storage / solver vectors are sharded by contiguous, tile-aligned
  * ranges of the brick-ordered work list (compact regions of the surface).  A rank builds rows for its range + a thin rim of ghost entries;
- * per PCG pass it pushes the operator input of the rim to its neighbours (peer to peer) and joins ONE small all-reduce [camera block | p.q]
- * (RCCL) plus the 4 iteration scalars.  Call after i3d_create on every rank with the same unique id (i3d_comm_unique_id on rank 0,
+ * per PCG pass it pushes the operator input of the rim to its neighbours and joins ONE small all-reduce [camera block | p.q] plus the 4 iteration
+ * scalars — over peer-to-peer xGMI mailboxes (self-tested at start-up), RCCL as the fallback and for the rare large collectives.  Call after i3d_create on every rank with the same unique id (i3d_comm_unique_id on rank 0,
  * broadcast by the launcher, e.g. torch.distributed). */
 int i3d_comm_unique_id(void* out128, int32_t* bytes);
 int i3d_comm_init(i3d_context* ctx, int32_t rank, int32_t world, const void* unique_id, int32_t id_bytes);
