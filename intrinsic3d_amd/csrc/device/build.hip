@@ -156,7 +156,7 @@ static __device__ inline float chroma_weight(uchar4 c, uchar4 cn) {
     const float a0 = ((float)c.x * s) / lum - ((float)cn.x * s) / lumn;
     const float a1 = ((float)c.y * s) / lum - ((float)cn.y * s) / lumn;
     const float a2 = ((float)c.z * s) / lum - ((float)cn.z * s) / lumn;
-    const float d = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    const float d = sqrtf(a0 * a0 + (a1 * a1 + a2 * a2))      /* Vec3f::norm(): Eigen's halving reduction a0 + (a1 + a2) */;
     const float one_minus = 1.0f - d;
     // std::max(1-d, 0.01f) keeps a NaN first argument
     return (one_minus < 0.01f) ? 0.01f : one_minus;

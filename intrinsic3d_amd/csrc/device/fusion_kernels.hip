@@ -36,9 +36,11 @@ __device__ inline long long find_slot(const FusionTable& t, unsigned long long k
     return -1;
 }
 __device__ inline int round_trunc(float v) { return (int)(v + 0.5f); }                                   // mat.h:90
+// pose.topLeftCorner<3,3>() * p + pose.topRightCorner<3,1>() (sparse_voxel_grid.cpp:328,425,584): a fixed-size Eigen product, every coefficient
+// the halving reduction a0 + (a1 + a2) — pinned against the reference's own integrate / alloc in oracle/_ref (tests/test_ref_pipeline.py)
 __device__ inline void xform(const float* T, float px, float py, float pz, float q[3]) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) q[i] = ((T[4 * i] * px + T[4 * i + 1] * py) + T[4 * i + 2] * pz) + T[4 * i + 3];
+    for (int i = 0; i < 3; ++i) q[i] = (T[4 * i] * px + (T[4 * i + 1] * py + T[4 * i + 2] * pz)) + T[4 * i + 3];
 }
 __device__ inline float robust_kernel(float val) { const float div = 1.0f + 2.0f * val; return 1.0f / (div * div * div); }   // math.cpp:43-47
 __device__ inline bool within(const int* b, int x, int y, int z) { return !(x < b[0] || x > b[1] || y < b[2] || y > b[3] || z < b[4] || z > b[5]); }
@@ -90,10 +92,10 @@ __global__ void k_normals(FusionCam c, const float* __restrict__ depth, float th
         vertex(c, depth, x, y - 1, fx_inv, fy_inv, y0); vertex(c, depth, x, y + 1, fx_inv, fy_inv, y1);
         if (v[2] != 0.0f && x0[2] != 0.0f && x1[2] != 0.0f && y0[2] != 0.0f && y1[2] != 0.0f) {
             const float tx[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]}, ty[3] = {y1[0] - y0[0], y1[1] - y0[1], y1[2] - y0[2]};
-            const float ntx = sqrtf((tx[0] * tx[0] + tx[1] * tx[1]) + tx[2] * tx[2]), nty = sqrtf((ty[0] * ty[0] + ty[1] * ty[1]) + ty[2] * ty[2]);
+            const float ntx = sqrtf(tx[0] * tx[0] + (tx[1] * tx[1] + tx[2] * tx[2])), nty = sqrtf(ty[0] * ty[0] + (ty[1] * ty[1] + ty[2] * ty[2]));
             if (ntx < thr && nty < thr) {
                 n[0] = ty[1] * tx[2] - ty[2] * tx[1]; n[1] = ty[2] * tx[0] - ty[0] * tx[2]; n[2] = ty[0] * tx[1] - ty[1] * tx[0];
-                const float sq = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
+                const float sq = n[0] * n[0] + (n[1] * n[1] + n[2] * n[2]);
                 if (sq > 0.0f) { const float l = sqrtf(sq); n[0] /= l; n[1] /= l; n[2] /= l; }
             }
         }
@@ -206,10 +208,10 @@ __global__ void k_integrate(FusionTable t, FusionFrame f, FusionCam dc, FusionCa
     float wu = 1.0f;
     if (f.weight_sample > 0.0f) {
         const float* n = &normals[((size_t)py * dc.w + px) * 3];
-        const float sq = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+        const float sq = p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]);
         float pn[3] = {p[0], p[1], p[2]};
         if (sq > 0.0f) { const float l = sqrtf(sq); pn[0] /= l; pn[1] /= l; pn[2] /= l; }
-        float wn = 1.0f - fabsf((pn[0] * n[0] + pn[1] * n[1]) + pn[2] * n[2]);
+        float wn = 1.0f - fabsf(pn[0] * n[0] + (pn[1] * n[1] + pn[2] * n[2]));
         wn = fmaxf(fminf(wn, 1.0f), 0.0f);
         wn = fmaxf(f.weight_sample * robust_kernel(wn), 1.0f);
         const float wd = fmaxf(f.weight_sample * robust_kernel(2.0f * fabsf(tsdf) / f.truncation), 1.0f);
@@ -306,7 +308,7 @@ __global__ void k_correct(FusionTable t, long long m, float voxel_size, const un
         if (nb < 0) continue;
         const double sdf_nb = (double)(c_pos[nb] < v ? c_cur[nb] : c_sdf[nb]), sgn_nb = sdf_nb >= 0.0 ? 1.0 : -1.0;
         const float dx = cx - (float)(gx + i) * voxel_size, dy = cy - (float)(gy + j) * voxel_size, dz = cz - (float)(gz + k) * voxel_size;
-        const double dist_nb = sdf_nb + sgn_nb * (double)sqrtf((dx * dx + dy * dy) + dz * dz);
+        const double dist_nb = sdf_nb + sgn_nb * (double)sqrtf(dx * dx + (dy * dy + dz * dz));
         if (fabs(dist_nb) < fabs(sdf) && sgn == sgn_nb) { res = (float)dist_nb; updated = true; }
     }
     c_upd[c] = updated ? 1 : 0;

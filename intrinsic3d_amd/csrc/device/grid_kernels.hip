@@ -116,7 +116,7 @@ __global__ void k_classify(GridView g, OptParams p, int* __restrict__ active_fla
     if (valid && nbv[NB_PX] && nbv[NB_PY] && nbv[NB_PZ]) {
         const float s0 = g.f_sdf[s];
         float nx = g.f_sdf[nb[NB_PX]] - s0, ny = g.f_sdf[nb[NB_PY]] - s0, nz = g.f_sdf[nb[NB_PZ]] - s0;
-        const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        const float len = sqrtf(nx * nx + (ny * ny + nz * nz));
         if (len != 0.0f) { nx /= len; ny /= len; nz /= len; }
         normal_ok = !(fabsf(nx) <= 1e-5f && fabsf(ny) <= 1e-5f && fabsf(nz) <= 1e-5f);
     }

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_recolor(GridView g, OptParams p, const 
     if (!(g.weight[s] > 0.0f) || nbx < 0 || nby < 0 || nbz < 0 || !(g.weight[nbx] > 0.0f) || !(g.weight[nby] > 0.0f) || !(g.weight[nbz] > 0.0f)) return;
     const float s0 = g.f_sdf[s];
     float nx = g.f_sdf[nbx] - s0, ny = g.f_sdf[nby] - s0, nz = g.f_sdf[nbz] - s0;
-    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float len = sqrtf(nx * nx + (ny * ny + nz * nz));
     if (len != 0.0f) { nx /= len; ny /= len; nz /= len; }
     if (fabsf(nx) <= 1e-5f && fabsf(ny) <= 1e-5f && fabsf(nz) <= 1e-5f) return;
     const float px = (float)g.cx[s] * g.voxel_size - nx * s0, py = (float)g.cy[s] * g.voxel_size - ny * s0, pz = (float)g.cz[s] * g.voxel_size - nz * s0;

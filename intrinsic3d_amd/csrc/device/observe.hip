@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) k_observe(GridView g, RowView r, OptParam
     float ny = g.f_sdf[g.nbr[(size_t)NB_PY * N + s]] - s0;
     float nz = g.f_sdf[g.nbr[(size_t)NB_PZ * N + s]] - s0;
     {
-        const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        const float len = sqrtf(nx * nx + (ny * ny + nz * nz));
         if (len != 0.0f) { nx /= len; ny /= len; nz /= len; }
     }
     // voxelCenterToIso (operators.cpp:44-55): voxelToWorld(v) - n * (float)sdf_refined

@@ -33,10 +33,10 @@ static __device__ inline float observation_weight(const FrameConst& fc, const Op
             const float cnz = (fc.Rf[6] * nx + fc.Rf[7] * ny) + fc.Rf[8] * nz;
             float wn = 0.0f;
             if (!(fabsf(cnx) <= 1e-5f && fabsf(cny) <= 1e-5f && fabsf(cnz) <= 1e-5f)) {
-                const float vsq = qx * qx + qy * qy + qz * qz;
+                const float vsq = qx * qx + (qy * qy + qz * qz);          // fixed-size Eigen reductions: a0 + (a1 + a2)
                 float vx = qx, vy = qy, vz = qz;
                 if (vsq > 0.0f) { const float l = sqrtf(vsq); vx /= l; vy /= l; vz /= l; }
-                wn = 1.0f - fabsf((vx * cnx + vy * cny) + vz * cnz);
+                wn = 1.0f - fabsf(vx * cnx + (vy * cny + vz * cnz));
                 wn = fmaxf(fminf(wn, 1.0f), 0.0f);
                 const float div = 1.0f + 2.0f * wn;
                 wn = fmaxf(1.0f / (div * div * div), 0.001f);

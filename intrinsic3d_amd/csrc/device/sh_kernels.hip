@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_sh_keys(GridView g, ShParams sp, unsign
         if (nx >= 0 && ny >= 0 && nz >= 0 && g.weight[nx] > 0.0f && g.weight[ny] > 0.0f && g.weight[nz] > 0.0f) {
             const float s0 = g.f_sdf[s];
             const float gx = g.f_sdf[nx] - s0, gy = g.f_sdf[ny] - s0, gz = g.f_sdf[nz] - s0;
-            const float len = sqrtf(gx * gx + gy * gy + gz * gz);
+            const float len = sqrtf(gx * gx + (gy * gy + gz * gz));
             const double alb = g.x_alb[s];
             if (len != 0.0f && !(len != len) && alb != 0.0 && alb == alb) {
                 if (sp.single) key = pack3(0, 0, 0);
@@ -72,7 +72,7 @@ static __device__ inline void sh_features(const GridView& g, int s, double f[10]
     const int N = g.N;
     const float s0 = g.f_sdf[s];
     float nx = g.f_sdf[g.nbr[(size_t)NB_PX * N + s]] - s0, ny = g.f_sdf[g.nbr[(size_t)NB_PY * N + s]] - s0, nz = g.f_sdf[g.nbr[(size_t)NB_PZ * N + s]] - s0;
-    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float len = sqrtf(nx * nx + (ny * ny + nz * nz));
     if (len != 0.0f) { nx /= len; ny /= len; nz /= len; }
     const double x = (double)nx, y = (double)ny, z = (double)nz, a = g.x_alb[s];
     f[0] = a; f[1] = a * y; f[2] = a * z; f[3] = a * x; f[4] = a * (x * y); f[5] = a * (y * z);

@@ -79,7 +79,7 @@ void rotate_dual(const double aa[3], const double pt[3], D3 out[3]) {
 }
 // math::poseVecAAToMat (math.cpp:151-163): Eigen::AngleAxisd(|w|, w/|w|).matrix() [Eigen, not in reference]
 void pose_to_mat_eigen(const double p[6], double R[9]) {
-    const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    const double n2 = p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]);       // Vec3::norm(): halving reduction
     const double angle = std::sqrt(n2);
     double ax[3] = {p[0], p[1], p[2]};
     if (n2 > 0.0) { ax[0] /= angle; ax[1] /= angle; ax[2] /= angle; }

@@ -91,7 +91,7 @@ void frustum_bounds(const i3d_fusion* f, const FusionCam& cam, const float* pose
         float c[3] = {0, 0, 0};
         if (depth != 0.0f) { const float x = ((float)px[i & 3] - cam.cx) / cam.fx, y = ((float)py[i & 3] - cam.cy) / cam.fy; c[0] = depth * x; c[1] = depth * y; c[2] = depth; }
         for (int a = 0; a < 3; ++a) {
-            const float pt = ((pose[4 * a] * c[0] + pose[4 * a + 1] * c[1]) + pose[4 * a + 2] * c[2]) + pose[4 * a + 3];
+            const float pt = (pose[4 * a] * c[0] + (pose[4 * a + 1] * c[1] + pose[4 * a + 2] * c[2])) + pose[4 * a + 3];    // fixed-size Eigen product: halving reduction
             const int pl = to_voxel((float)(int)std::floor(pt)), pu = to_voxel((float)(int)std::ceil(pt));
             b[2 * a] = std::min(b[2 * a], std::min(pl, pu)); b[2 * a + 1] = std::max(b[2 * a + 1], std::max(pl, pu));
         }

@@ -40,7 +40,7 @@ void rot_to_quat(const float m[9], float q[4] /*x y z w*/) {
 }
 // math::poseVecAAToMat (math.cpp:151-163): angle-axis + translation -> rigid transform (fp64)
 void pose_to_mat(const double* p, double R[9], double t[3]) {
-    const double th = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    const double th = std::sqrt(p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]));
     double k[3] = {0, 0, 0};
     if (th > 0.0) { k[0] = p[0] / th; k[1] = p[1] / th; k[2] = p[2] / th; }
     const double c = std::cos(th), s = std::sin(th), v = 1.0 - c;

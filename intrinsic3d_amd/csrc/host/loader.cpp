@@ -391,7 +391,7 @@ int i3d_sensor_set_pose(i3d_sensor* s, int32_t id, const float* cam_to_world16) 
 // the write-back of Intrinsic3D::finishRgbdLevel (intrinsic3d.cpp:362-368): world->camera vector -> camera-to-world Mat4f
 int i3d_sensor_set_pose_vec6(i3d_sensor* s, int32_t id, const double* p) {
     if (!s || !p) return I3D_ERR_INVALID_ARGUMENT;
-    const double th = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    const double th = std::sqrt(p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]));
     double k[3] = {0, 0, 0}; if (th > 0.0) { k[0] = p[0] / th; k[1] = p[1] / th; k[2] = p[2] / th; }
     const double c = std::cos(th), sn = std::sin(th), v = 1.0 - c;
     const double m[16] = {c + k[0] * k[0] * v, k[0] * k[1] * v - k[2] * sn, k[0] * k[2] * v + k[1] * sn, p[3],

@@ -90,7 +90,7 @@ int extract_mesh(i3d_context* c, int use_refined, int color_mode, int largest_on
         const float* a = &M.vertices[3 * (size_t)v0]; const float* b = &M.vertices[3 * (size_t)v1]; const float* cc = &M.vertices[3 * (size_t)v2];
         const float e0[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]}, e1[3] = {cc[0] - b[0], cc[1] - b[1], cc[2] - b[2]};
         const float cr[3] = {e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2], e0[0] * e1[1] - e0[1] * e1[0]};
-        const double area = (double)std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+        const double area = (double)std::sqrt(cr[0] * cr[0] + (cr[1] * cr[1] + cr[2] * cr[2]));
         if (area == 0.0 || std::isnan(area) || std::isinf(area)) continue;
         kept.push_back(v0); kept.push_back(v1); kept.push_back(v2);
     }

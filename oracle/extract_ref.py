@@ -27,33 +27,23 @@ GEN = os.path.join(OUT, "gen")
 
 # name, file (relative to libintrinsic3d/), first line, last line, token expected in the first line, token expected in the last line
 CHUNKS = [
+    # --- scalar helpers, functors, templates (round 2)
     ("mat_round",            "include/nv/mat.h", 88, 93, "inline Vec2i round(const Vec2f", "inline Vec4i round(const Vec4 "),
+    ("mat_floor_ceil",       "include/nv/mat.h", 95, 107, "inline Vec2i floor(const Vec2f", "inline Vec4i ceil(const Vec4 "),
     ("mat_hash",             "include/nv/mat.h", 114, 125, "template <>", "};"),
     ("grid_voxels",          "include/nv/sparse_voxel_grid.h", 56, 77, "struct Voxel", "};"),
-    ("grid_ctor",            "src/sparse_voxel_grid.cpp", 43, 54, "template <class T>", "}"),
-    ("grid_access",          "src/sparse_voxel_grid.cpp", 165, 297, "template <class T>", "}"),
     ("operators_templates",  "include/nv/sdf/operators.h", 49, 109, "template <typename T>", "}"),
     ("operators_sdf_weight", "src/sdf/operators.cpp", 142, 147, "double sdfToWeight", "}"),
-    ("math_robust_kernel",   "src/math.cpp", 43, 47, "float robustKernel", "}"),
     ("shading_basis",        "include/nv/shading.h", 53, 67, "template <typename T>", "}"),
     ("shading_compute",      "include/nv/shading.h", 73, 112, "template <typename T>", "}"),
     ("shading_graddiff",     "include/nv/shading.h", 128, 148, "template <typename T>", "}"),
     ("camera_t",             "include/nv/camera.h", 92, 126, "template <typename T>", "};"),
-    ("camera_project_f",     "src/camera.cpp", 124, 154, "bool Camera::project(const Vec3f", "}"),
     ("cost_helpers",         "include/nv/refinement/cost.h", 73, 150, "template <typename T>", "}"),
     ("shading_cost_data",    "include/nv/refinement/shading_cost.h", 52, 73, "class ShadingCostData", "};"),
-    ("shading_cost_functor", "include/nv/refinement/shading_cost.h", 85, 198, "template <typename T>", "}"),
-    ("volreg_functor",       "include/nv/refinement/volumetric_regularizer.h", 59, 72, "template <typename T>", "}"),
-    ("stab_functor",         "include/nv/refinement/surface_stab_regularizer.h", 59, 66, "template <typename T>", "}"),
-    ("albedo_functor",       "include/nv/refinement/albedo_regularizer.h", 59, 66, "template <typename T>", "}"),
     ("albedo_chroma",        "src/refinement/albedo_regularizer.cpp", 61, 70, "Vec3f c = v.color", "double w ="),
-    ("color_intensity",      "src/color_util.cpp", 41, 52, "float intensity(unsigned char r", "}"),
-    ("sh_costs",             "src/lighting/lighting_svsh.cpp", 113, 163, "class SHDataCost", "};"),
     ("invalid_residual",     "include/nv/refinement/cost.h", 45, 45, "#define NV_INVALID_RESIDUAL", "#define NV_INVALID_RESIDUAL"),
-    ("colorization_config",  "include/nv/sdf/colorization.h", 91, 98, "struct Config", "};"),
     ("vertex_observation",   "include/nv/sdf/colorization.h", 57, 78, "struct VertexObservation", "};"),
     ("vertex_observation_lt","src/sdf/colorization.cpp", 46, 49, "bool VertexObservation::operator<", "}"),
-    ("colorization_weights", "src/sdf/colorization.cpp", 254, 370, "bool SDFColorization::isVoxelVisible", "}"),
     ("mesh_struct",          "include/nv/mesh.h", 45, 59, "struct Mesh", "};"),
     ("mesh_save",            "src/mesh.cpp", 41, 100, "bool Mesh::save", "}"),
     ("mesh_degenerate",      "src/mesh/util.cpp", 174, 200, "bool removeDegenerateFaces", "}"),
@@ -61,6 +51,57 @@ CHUNKS = [
     ("mc_extract_mesh",      "src/mesh/marching_cubes.cpp", 43, 94, "template <class T>", "}"),
     ("mc_body",              "src/mesh/marching_cubes.cpp", 97, 317, "template <class T>", "}"),
     ("mc_tables",            "src/mesh/marching_cubes.cpp", 330, 623, "template <class T>", "};"),
+    # --- classes and whole implementation files of the hot path (round 3): grid container incl. integrate / alloc, camera, math,
+    #     level transitions, colourisation, the cost-function factories, NLSSolver, Optimizer, Subvolumes, LightingSVSH
+    ("grid_class",           "include/nv/sparse_voxel_grid.h", 84, 161, "template <class T>", "};"),
+    ("grid_impl",            "src/sparse_voxel_grid.cpp", 43, 467, "template <class T>", "}"),
+    ("grid_frustum",         "src/sparse_voxel_grid.cpp", 572, 602, "template <class T>", "}"),
+    ("camera_class",         "include/nv/camera.h", 47, 89, "class Camera", "};"),
+    ("camera_impl",          "src/camera.cpp", 41, 199, "Camera::Camera() :", "}"),
+    ("camera_convert",       "src/camera.cpp", 277, 311, "void Camera::print", "}"),
+    ("math_decl",            "include/nv/math.h", 44, 65, "namespace math", "} // namespace math"),
+    ("math_impl",            "src/math.cpp", 43, 163, "float robustKernel", "}"),
+    ("operators_impl",       "src/sdf/operators.cpp", 45, 77, "Vec3f voxelCenterToIso(const SparseVoxelGrid", "}"),
+    ("algorithms_decl",      "include/nv/sdf/algorithms.h", 44, 69, "namespace SDFAlgorithms", "} // namespace SDFAlgorithms"),
+    ("algorithms_impl",      "src/sdf/algorithms.cpp", 47, 458, "SparseVoxelGrid<VoxelSBR>* convert", "}"),
+    ("color_util_decl",      "include/nv/color_util.h", 46, 57, "float intensity(unsigned char r", "Vec3b randomColor();"),
+    ("color_intensity",      "src/color_util.cpp", 41, 58, "float intensity(unsigned char r", "}"),
+    ("color_random",         "src/color_util.cpp", 83, 114, "Vec3f checkRange", "}"),
+    ("processing_decl",      "include/nv/rgbd/processing.h", 50, 62, "cv::Mat computeVertexMap", "Vec3b interpolateRGB"),
+    ("processing_impl",      "src/rgbd/processing.cpp", 49, 301, "cv::Mat computeVertexMap", "}"),
+    ("pyramid_class",        "include/nv/rgbd/pyramid.h", 47, 69, "class Pyramid", "};"),
+    ("pyramid_ctor",         "src/rgbd/pyramid.cpp", 43, 45, "Pyramid::Pyramid()", "}"),
+    ("pyramid_dtor",         "src/rgbd/pyramid.cpp", 54, 56, "Pyramid::~Pyramid()", "}"),
+    ("pyramid_access",       "src/rgbd/pyramid.cpp", 81, 105, "cv::Mat Pyramid::color", "}"),
+    ("pyramid_depth_down",   "src/rgbd/pyramid.cpp", 116, 141, "cv::Mat Pyramid::downsampleDepth", "}"),
+    ("pyramid_depth_pyr",    "src/rgbd/pyramid.cpp", 155, 166, "std::vector<cv::Mat> Pyramid::createDepthPyramid", "}"),
+    ("colorization_class",   "include/nv/sdf/colorization.h", 87, 136, "class SDFColorization", "};"),
+    ("colorization_impl",    "src/sdf/colorization.cpp", 52, 370, "SDFColorization::SDFColorization(const Camera", "}"),
+    ("shading_decl",         "include/nv/shading.h", 49, 51, "static const int NUM_SPHERICAL_HARMONICS", "Eigen::VectorXf shBasisFunctions"),
+    ("shading_basis_f",      "src/shading.cpp", 43, 58, "Eigen::VectorXf shBasisFunctions", "}"),
+    ("voxel_residual",       "include/nv/refinement/cost.h", 59, 70, "struct VoxelResidual", "};"),
+    ("shading_cost_class",   "include/nv/refinement/shading_cost.h", 76, 204, "class ShadingCost", "};"),
+    ("shading_cost_impl",    "src/refinement/shading_cost.cpp", 46, 150, "ShadingCost::ShadingCost(const Vec3i", "}"),
+    ("volreg_class",         "include/nv/refinement/volumetric_regularizer.h", 51, 76, "class VolumetricRegularizer", "};"),
+    ("volreg_impl",          "src/refinement/volumetric_regularizer.cpp", 42, 78, "VolumetricRegularizer::VolumetricRegularizer()", "}"),
+    ("stab_class",           "include/nv/refinement/surface_stab_regularizer.h", 51, 69, "class SurfaceStabRegularizer", "};"),
+    ("stab_impl",            "src/refinement/surface_stab_regularizer.cpp", 40, 61, "SurfaceStabRegularizer::SurfaceStabRegularizer(double", "}"),
+    ("albedo_class",         "include/nv/refinement/albedo_regularizer.h", 51, 69, "class AlbedoRegularizer", "};"),
+    ("albedo_impl",          "src/refinement/albedo_regularizer.cpp", 40, 84, "AlbedoRegularizer::AlbedoRegularizer()", "}"),
+    ("timer_class",          "include/nv/timer.h", 45, 80, "class Timer", "};"),
+    ("nls_class",            "include/nv/refinement/nls_solver.h", 53, 125, "class NLSSolver", "};"),
+    ("nls_impl",             "src/refinement/nls_solver.cpp", 45, 394, "NLSSolver::ProblemInfo::ProblemInfo()", "}"),
+    ("optimizer_class",      "include/nv/refinement/optimizer.h", 59, 141, "class Optimizer", "};"),
+    ("optimizer_impl",       "src/refinement/optimizer.cpp", 92, 361, "Optimizer::Optimizer(Config cfg)", "}"),
+    ("subvolumes_class",     "include/nv/lighting/subvolumes.h", 47, 91, "class Subvolumes", "};"),
+    ("subvolumes_impl",      "src/lighting/subvolumes.cpp", 43, 304, "Subvolumes::Subvolumes(float size)", "}"),
+    ("svsh_class",           "include/nv/lighting/lighting_svsh.h", 46, 71, "class LightingSVSH", "};"),
+    ("svsh_impl",            "src/lighting/lighting_svsh.cpp", 54, 346, "LightingSVSH::LightingSVSH(const SparseVoxelGrid", "}"),
+    # --- the level schedule itself: Intrinsic3D::refine / prepare* / finish* / recomputeColors (init() is ours: it needs Sensor + OpenCV)
+    ("i3d_class",            "include/nv/refinement/intrinsic3d.h", 59, 155, "class Intrinsic3D", "};"),
+    ("i3d_callback_dtor",    "src/refinement/intrinsic3d.cpp", 53, 55, "Intrinsic3D::RefinementCallback::~RefinementCallback", "}"),
+    ("i3d_ctor",             "src/refinement/intrinsic3d.cpp", 98, 148, "Intrinsic3D::Intrinsic3D(Config cfg", "}"),
+    ("i3d_refine",           "src/refinement/intrinsic3d.cpp", 206, 409, "bool Intrinsic3D::refine", "}"),
 ]
 
 

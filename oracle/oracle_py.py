@@ -51,66 +51,93 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+class _Prefixed:
+    """Attribute proxy over a CDLL: `orc_x` resolves to `<prefix>x`.  oracle/_ref exports the reference's own pipeline under the same shapes
+    with the prefix `ref_` (oracle/ref_py.py: pipeline()), so one harness drives both.  A symbol the library lacks yields a stub that raises."""
+
+    def __init__(self, cdll, prefix):
+        self._cdll = cdll; self._prefix = prefix
+
+    def __getattr__(self, name):
+        real = self._prefix + name[4:] if name.startswith("orc_") else name
+        try:
+            return getattr(self._cdll, real)
+        except AttributeError:
+            return _Missing(real)
+
+
+class _Missing:
+    def __init__(self, name):
+        self._name = name; self.restype = None; self.argtypes = None
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError(f"{self._name} is not exported by this library")
+
+
+def _configure(L):
+    """Declare the C signatures of include i3d_oracle.h on `L` (a _Prefixed proxy)."""
+    vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+    L.orc_grid_from_voxels.restype = vp
+    L.orc_grid_from_voxels.argtypes = [f32, i64, vp, vp, vp, vp]
+    L.orc_grid_size.restype = i64; L.orc_grid_size.argtypes = [vp]
+    L.orc_grid_voxel_size.restype = f32; L.orc_grid_voxel_size.argtypes = [vp]
+    L.orc_grid_export.argtypes = [vp] * 7
+    L.orc_grid_import.argtypes = [vp] * 4
+    L.orc_grid_clear_outside_shell.argtypes = [vp, f64]
+    L.orc_grid_upsample.restype = vp; L.orc_grid_upsample.argtypes = [vp]
+    L.orc_grid_free.argtypes = [vp]
+    L.orc_frames_create.restype = vp; L.orc_frames_create.argtypes = [i32, i32]
+    L.orc_frames_set.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+    L.orc_frames_free.argtypes = [vp]
+    L.orc_optimize.restype = i32
+    L.orc_optimize.argtypes = [vp, vp, C.POINTER(OptConfig), vp, vp, vp, vp, vp]
+    L.orc_collect.restype = vp
+    L.orc_collect.argtypes = [vp, vp, C.POINTER(OptConfig), vp, vp, vp, vp, i32]
+    L.orc_problem_counts.argtypes = [vp, vp, vp, vp]
+    L.orc_problem_flags.argtypes = [vp] * 5
+    L.orc_problem_eg.argtypes = [vp] * 6
+    L.orc_problem_reg.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.orc_problem_normal_eq.restype = f64
+    L.orc_problem_normal_eq.argtypes = [vp, C.POINTER(OptConfig), vp, vp, vp]
+    L.orc_problem_jtj_apply.argtypes = [vp, C.POINTER(OptConfig), vp, vp]
+    L.orc_problem_free.argtypes = [vp]
+    L.orc_estimate_sh.restype = i32
+    L.orc_estimate_sh.argtypes = [vp, f32, f64, f64, i32, vp, vp, vp, i32, vp, vp, C.POINTER(ShStats)]
+    L.orc_recompute_colors.restype = i32
+    L.orc_recompute_colors.argtypes = [vp, vp, vp, vp, vp, f32, i32]
+    L.orc_refine.restype = i32
+    L.orc_refine.argtypes = [C.POINTER(vp), vp, C.POINTER(OptConfig), i32, i32, f64, f64, i32, f32, f64, vp, vp, vp, C.POINTER(i32)]
+    L.orc_shading_row.restype = f64
+    L.orc_shading_row.argtypes = [i32, i32, i32, vp, f64, f64, i32, i32, vp, vp, vp]
+    L.orc_bicubic.argtypes = [vp, i32, i32, f64, f64, vp, vp, vp]
+    L.orc_pose_to_mat.argtypes = [vp, vp, vp]
+    L.orc_hash.restype = C.c_uint64; L.orc_hash.argtypes = [i32, i32, i32]
+    L.orc_round_trunc.restype = i32; L.orc_round_trunc.argtypes = [f32]
+    L.orc_test_lm_dense.restype = i32; L.orc_test_lm_dense.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.orc_test_cgnr.restype = i32; L.orc_test_cgnr.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp]
+    u8p = vp
+    L.orc_sdf_to_weight.restype = f64; L.orc_sdf_to_weight.argtypes = [f64, f64]
+    L.orc_varying_lambda.restype = f64; L.orc_varying_lambda.argtypes = [i32, i32, f64, f64]
+    L.orc_project_f.restype = i32; L.orc_project_f.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.orc_voxel_visible.restype = i32; L.orc_voxel_visible.argtypes = [f32, vp, i32, i32, vp, i32, i32]
+    L.orc_observation_weight.restype = f32; L.orc_observation_weight.argtypes = [i32, i32, vp, vp, i32, i32, vp]
+    L.orc_compute_color.argtypes = [i32, u8p, vp, vp]
+    L.orc_filter.argtypes = [i32, vp, i32, vp]
+    L.orc_chroma_weight.restype = f64; L.orc_chroma_weight.argtypes = [u8p, u8p]
+    L.orc_reg_row.restype = f64; L.orc_reg_row.argtypes = [i32, vp, f64, vp]
+    L.orc_sh_data_row.restype = f64; L.orc_sh_data_row.argtypes = [f64, vp, f64, vp, vp]
+    L.orc_world_to_voxel.argtypes = [f32, vp, vp]
+    L.orc_mc_extract.restype = vp; L.orc_mc_extract.argtypes = [vp, i32]
+    L.orc_mesh_counts.argtypes = [vp, vp, vp]; L.orc_mesh_get.argtypes = [vp, vp, vp, vp]; L.orc_mesh_free.argtypes = [vp]
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
-        vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
-        L.orc_grid_from_voxels.restype = vp
-        L.orc_grid_from_voxels.argtypes = [f32, i64, vp, vp, vp, vp]
-        L.orc_grid_size.restype = i64; L.orc_grid_size.argtypes = [vp]
-        L.orc_grid_voxel_size.restype = f32; L.orc_grid_voxel_size.argtypes = [vp]
-        L.orc_grid_export.argtypes = [vp] * 7
-        L.orc_grid_import.argtypes = [vp] * 4
-        L.orc_grid_clear_outside_shell.argtypes = [vp, f64]
-        L.orc_grid_upsample.restype = vp; L.orc_grid_upsample.argtypes = [vp]
-        L.orc_grid_free.argtypes = [vp]
-        L.orc_frames_create.restype = vp; L.orc_frames_create.argtypes = [i32, i32]
-        L.orc_frames_set.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
-        L.orc_frames_free.argtypes = [vp]
-        L.orc_optimize.restype = i32
-        L.orc_optimize.argtypes = [vp, vp, C.POINTER(OptConfig), vp, vp, vp, vp, vp]
-        L.orc_collect.restype = vp
-        L.orc_collect.argtypes = [vp, vp, C.POINTER(OptConfig), vp, vp, vp, vp, i32]
-        L.orc_problem_counts.argtypes = [vp, vp, vp, vp]
-        L.orc_problem_flags.argtypes = [vp] * 5
-        L.orc_problem_eg.argtypes = [vp] * 6
-        L.orc_problem_reg.argtypes = [vp, i32, vp, vp, vp, vp]
-        L.orc_problem_normal_eq.restype = f64
-        L.orc_problem_normal_eq.argtypes = [vp, C.POINTER(OptConfig), vp, vp, vp]
-        L.orc_problem_jtj_apply.argtypes = [vp, C.POINTER(OptConfig), vp, vp]
-        L.orc_problem_free.argtypes = [vp]
-        L.orc_estimate_sh.restype = i32
-        L.orc_estimate_sh.argtypes = [vp, f32, f64, f64, i32, vp, vp, vp, i32, vp, vp, C.POINTER(ShStats)]
-        L.orc_recompute_colors.restype = i32
-        L.orc_recompute_colors.argtypes = [vp, vp, vp, vp, vp, f32, i32]
-        L.orc_refine.restype = i32
-        L.orc_refine.argtypes = [C.POINTER(vp), vp, C.POINTER(OptConfig), i32, i32, f64, f64, i32, f32, f64, vp, vp, vp, C.POINTER(i32)]
-        L.orc_shading_row.restype = f64
-        L.orc_shading_row.argtypes = [i32, i32, i32, vp, f64, f64, i32, i32, vp, vp, vp]
-        L.orc_bicubic.argtypes = [vp, i32, i32, f64, f64, vp, vp, vp]
-        L.orc_pose_to_mat.argtypes = [vp, vp, vp]
-        L.orc_hash.restype = C.c_uint64; L.orc_hash.argtypes = [i32, i32, i32]
-        L.orc_round_trunc.restype = i32; L.orc_round_trunc.argtypes = [f32]
-        L.orc_test_lm_dense.restype = i32; L.orc_test_lm_dense.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]
-        L.orc_test_cgnr.restype = i32; L.orc_test_cgnr.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp]
-        u8p = vp
-        L.orc_sdf_to_weight.restype = f64; L.orc_sdf_to_weight.argtypes = [f64, f64]
-        L.orc_varying_lambda.restype = f64; L.orc_varying_lambda.argtypes = [i32, i32, f64, f64]
-        L.orc_project_f.restype = i32; L.orc_project_f.argtypes = [vp, vp, i32, i32, vp, vp, vp]
-        L.orc_voxel_visible.restype = i32; L.orc_voxel_visible.argtypes = [f32, vp, i32, i32, vp, i32, i32]
-        L.orc_observation_weight.restype = f32; L.orc_observation_weight.argtypes = [i32, i32, vp, vp, i32, i32, vp]
-        L.orc_compute_color.argtypes = [i32, u8p, vp, vp]
-        L.orc_filter.argtypes = [i32, vp, i32, vp]
-        L.orc_chroma_weight.restype = f64; L.orc_chroma_weight.argtypes = [u8p, u8p]
-        L.orc_reg_row.restype = f64; L.orc_reg_row.argtypes = [i32, vp, f64, vp]
-        L.orc_sh_data_row.restype = f64; L.orc_sh_data_row.argtypes = [f64, vp, f64, vp, vp]
-        L.orc_world_to_voxel.argtypes = [f32, vp, vp]
-        L.orc_mc_extract.restype = vp; L.orc_mc_extract.argtypes = [vp, i32]
-        L.orc_mesh_counts.argtypes = [vp, vp, vp]; L.orc_mesh_get.argtypes = [vp, vp, vp, vp]; L.orc_mesh_free.argtypes = [vp]
-        _lib = L
+        _lib = _configure(_Prefixed(C.CDLL(_LIB_PATH), "orc_"))
     return _lib
 
 

@@ -64,6 +64,24 @@ def lib():
     return _lib
 
 
+_pipeline = None
+
+
+def pipeline():
+    """The reference's own pipeline (Optimizer / NLSSolver / SDFColorization / SDFAlgorithms / Subvolumes / LightingSVSH / SparseVoxelGrid::integrate /
+    Intrinsic3D::refine compiled from /root/reference, ceres::Solve = oracle/ref_shim/mini_ceres_solver.hpp) behind the SAME Python classes as the oracle:
+    a second instance of oracle_py whose library handle maps orc_* onto this library's ref_* exports.  `R = ref_py.pipeline(); R.Grid.from_voxels(...)`."""
+    global _pipeline
+    if _pipeline is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("oracle._ref_pipeline", os.path.join(_HERE, "oracle_py.py"))
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+        mod._lib = mod._configure(mod._Prefixed(C.CDLL(LIB_PATH), "ref_"))
+        mod.build = lambda force=False: LIB_PATH
+        _pipeline = mod
+    return _pipeline
+
+
 def shading_row(v, sh9, rgbd_level, voxel_size, lum, params29):
     """ShadingCost::operator() of the reference: (residual via Jets, 29 partials, residual via T = double)."""
     lum = np.ascontiguousarray(lum, np.float32); sh9 = np.ascontiguousarray(sh9, np.float64); prm = np.ascontiguousarray(params29, np.float64)

@@ -8,6 +8,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <limits>
 
 namespace ceres {
@@ -138,6 +139,6 @@ struct BiCubicInterpolator {
     const Grid& grid_;
 };
 
-struct CostFunction {};      // only named by VoxelResidual (cost.h), never used by the extracted bodies
-
 }  // namespace ceres
+
+#include "mini_ceres_solver.hpp"

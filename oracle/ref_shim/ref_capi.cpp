@@ -15,156 +15,156 @@
 #include <string>
 #include <tuple>
 #include <unordered_map>
+#include <unordered_set>
+#include <cassert>
+#include <ctime>
+#include <limits>
+#include <sstream>
+#include <type_traits>
 #include <vector>
 #include <omp.h>
 #include "mini_eigen.hpp"
+#include "mini_cv.hpp"
 #include "mini_ceres.hpp"
 
 #include "gen/invalid_residual.inc"
 
-namespace cv {                                       // shim: the one cv::Mat operation the extracted bodies use (row-major float image)
-struct Mat {
-    int rows = 0, cols = 0; const float* p = nullptr;
-    template <class T> const T& at(int y, int x) const { return reinterpret_cast<const T*>(p)[(size_t)y * cols + x]; }
-};
-}  // namespace cv
-
 namespace nv {                                       // shim: the typedef names of nv/mat.h:47-86 over the stand-in Matrix
 typedef Eigen::Vector2d Vec2; typedef Eigen::Vector3d Vec3; typedef Eigen::Vector4d Vec4;
 typedef Eigen::Matrix<double, 5, 1> Vec5; typedef Eigen::Matrix<double, 6, 1> Vec6;
+typedef Eigen::Matrix3d Mat3; typedef Eigen::Matrix4d Mat4;
 typedef Eigen::Vector2f Vec2f; typedef Eigen::Vector3f Vec3f; typedef Eigen::Vector4f Vec4f;
 typedef Eigen::Matrix<float, 5, 1> Vec5f; typedef Eigen::Matrix<float, 6, 1> Vec6f;
 typedef Eigen::Matrix3f Mat3f; typedef Eigen::Matrix4f Mat4f;
 typedef Eigen::Vector2i Vec2i; typedef Eigen::Vector3i Vec3i; typedef Eigen::Vector4i Vec4i; typedef Eigen::Matrix<int, 6, 1> Vec6i;
 typedef Eigen::Matrix<unsigned char, 3, 1> Vec3b;
 #include "gen/mat_round.inc"
+#include "gen/mat_floor_ceil.inc"
 }  // namespace nv
 
 namespace std {
 #include "gen/mat_hash.inc"
 }  // namespace std
 
+#define private public                               /* shim: the C ABI below fills / reads private members instead of going through files */
+#define protected public
 namespace nv {
 
+class Settings;                                      // shim: only named by Config::load declarations that are never defined or called
+
 #include "gen/grid_voxels.inc"
-
-template <class T>
-class SparseVoxelGrid {                              // shim: the members of sparse_voxel_grid.h:83-165 whose DEFINITIONS are extracted below
-public:
-    SparseVoxelGrid(float voxel_size, float depth_min, float depth_max);
-    typedef typename std::unordered_map<Vec3i, T, std::hash<Vec3i>>::iterator iterator;
-    typedef typename std::unordered_map<Vec3i, T, std::hash<Vec3i>>::const_iterator const_iterator;
-    iterator begin() { return data_.begin(); }
-    iterator end() { return data_.end(); }
-    const_iterator begin() const { return data_.begin(); }
-    const_iterator end() const { return data_.end(); }
-    float voxelSize() const { return voxel_size_; }
-    float truncation() const { return truncation_; }
-    T& voxel(const Vec3i& voxel_pos); T& voxel(const Vec3f& world_pos); T& voxel(int x, int y, int z);
-    const T& voxel(const Vec3i& voxel_pos) const; const T& voxel(const Vec3f& world_pos) const; const T& voxel(int x, int y, int z) const;
-    Vec3i worldToVoxel(const Vec3f& p) const; Vec3f worldToVoxelFloat(const Vec3f& p) const; Vec3f voxelToWorld(const Vec3i& v) const;
-    bool exists(int x, int y, int z) const; bool exists(const Vec3i& voxel_pos) const;
-    bool valid(int x, int y, int z) const; bool valid(const Vec3i& voxel_pos) const;
-    size_t numVoxels() const; void setVoxel(const Vec3i& voxel_pos, const T& voxel);
-    bool empty() const; void clear(); bool remove(const Vec3i& voxel_pos);
-private:
-    std::unordered_map<Vec3i, T, std::hash<Vec3i>> data_;
-    float voxel_size_, depth_min_, depth_max_, truncation_, integration_weight_sample_;
-    Vec6f clip_bounds_;
-};
-#include "gen/grid_ctor.inc"
-#include "gen/grid_access.inc"
-
+#include "gen/camera_class.inc"
+#include "gen/camera_t.inc"
+#include "gen/grid_class.inc"
+#include "gen/math_decl.inc"
+#include "gen/color_util_decl.inc"
+#include "gen/processing_decl.inc"
 namespace SDFOperators {
 #include "gen/operators_templates.inc"
+}  // namespace SDFOperators
+#include "gen/algorithms_decl.inc"
+
+#include "gen/camera_impl.inc"
+#include "gen/camera_convert.inc"
+namespace math {
+#include "gen/math_impl.inc"
+}  // namespace math
+#include "gen/grid_impl.inc"
+#include "gen/grid_frustum.inc"
+namespace SDFOperators {
+#include "gen/operators_impl.inc"
 #include "gen/operators_sdf_weight.inc"
 }  // namespace SDFOperators
-
-namespace math {
-float robustKernel(float val, float thres = 2.0f);   // shim: the declaration of math.h:47 (default argument)
-#include "gen/math_robust_kernel.inc"
-}  // namespace math
+#include "gen/color_intensity.inc"
+#include "gen/color_random.inc"
+#include "gen/processing_impl.inc"
+#include "gen/pyramid_class.inc"
+#include "gen/pyramid_ctor.inc"
+#include "gen/pyramid_dtor.inc"
+#include "gen/pyramid_access.inc"
+#include "gen/pyramid_depth_down.inc"
+#include "gen/pyramid_depth_pyr.inc"
+namespace SDFAlgorithms {
+#include "gen/algorithms_impl.inc"
+}  // namespace SDFAlgorithms
 
 namespace Shading {
+#include "gen/shading_decl.inc"
 #include "gen/shading_basis.inc"
 #include "gen/shading_compute.inc"
 #include "gen/shading_graddiff.inc"
+#include "gen/shading_basis_f.inc"
 }  // namespace Shading
 
-#include "gen/camera_t.inc"
+#include "gen/vertex_observation.inc"
+#include "gen/vertex_observation_lt.inc"
+#include "gen/colorization_class.inc"
+#include "gen/colorization_impl.inc"
 
-class Camera {                                       // shim: the data members Camera::project reads (camera.h:83-88)
-public:
-    bool project(const Vec3f& pt, Vec2f& pt2f, Vec2i& pt2i) const;
-    Mat3f K_; int width_; int height_; Vec5f dist_coeffs_;
-};
-#include "gen/camera_project_f.inc"
-
-struct VoxelResidual;                                // (named by nothing we extract)
+#include "gen/voxel_residual.inc"
 #include "gen/cost_helpers.inc"
 #include "gen/shading_cost_data.inc"
-
-class ShadingCost {                                  // shim: constructor + members of shading_cost.h:78-83,200-203; operator() is the reference's
-public:
-    ShadingCost(const Vec3i& v_pos, const Eigen::VectorXd& sh_coeffs, const ShadingCostData* data) : v_pos_(v_pos), sh_coeffs_(sh_coeffs), data_(data) {}
-#include "gen/shading_cost_functor.inc"
-private:
-    Vec3i v_pos_;
-    const Eigen::VectorXd& sh_coeffs_;
-    const ShadingCostData* data_;
-};
-
-class VolumetricRegularizer {
-public:
-#include "gen/volreg_functor.inc"
-};
-class SurfaceStabRegularizer {
-public:
-    explicit SurfaceStabRegularizer(double sdf) : sdf_(sdf) {}
-#include "gen/stab_functor.inc"
-private:
-    double sdf_;
-};
-class AlbedoRegularizer {
-public:
-#include "gen/albedo_functor.inc"
-};
-
-#include "gen/color_intensity.inc"
+#include "gen/shading_cost_class.inc"
+#include "gen/shading_cost_impl.inc"
+#include "gen/volreg_class.inc"
+#include "gen/volreg_impl.inc"
+#include "gen/stab_class.inc"
+#include "gen/stab_impl.inc"
+#include "gen/albedo_class.inc"
+#include "gen/albedo_impl.inc"
 static double chroma_weight(const Vec3b& color, const Vec3b& color_nb) {     // shim: the two voxels the extracted lines read
     struct { Vec3b color; } v{color}, v_nb{color_nb};
 #include "gen/albedo_chroma.inc"
     return w;
 }
 
-#include "gen/sh_costs.inc"
+#include "gen/timer_class.inc"
+#include "gen/nls_class.inc"
+#include "gen/nls_impl.inc"
+#include "gen/optimizer_class.inc"
+#include "gen/optimizer_impl.inc"
+#include "gen/subvolumes_class.inc"
+#include "gen/subvolumes_impl.inc"
+#include "gen/svsh_class.inc"
+#include "gen/svsh_impl.inc"
 
-#include "gen/vertex_observation.inc"
-#include "gen/vertex_observation_lt.inc"
-class SDFColorization {                              // shim: declarations of the four member functions extracted below
+// shim: the two collaborators Intrinsic3D holds.  The reference's Sensor reads a dataset folder through OpenCV and its
+// KeyframeSelection a text file; here the C ABI hands the keyframes in directly, so both are inert holders.
+class Sensor {
 public:
-#include "gen/colorization_config.inc"
-    static void filter(std::vector<VertexObservation>& observations, size_t n);
-    bool isVoxelVisible(const Vec3f& pt, const cv::Mat& depth, int x, int y) const;
-    float computeWeight(const cv::Mat& depth, const Vec3f& n, const int x, const int y, const Vec3f& v) const;
-    Vec3f computeColor(const std::vector<VertexObservation>& verts_obs) const;
-    Config cfg_;
+    Camera& colorCamera() { return color_cam_; }
+    void setPose(int, const Mat4f&) {}
+    Camera color_cam_;
 };
-#include "gen/colorization_weights.inc"
+class KeyframeSelection {};
+#include "gen/i3d_class.inc"
+#include "gen/i3d_callback_dtor.inc"
+#include "gen/i3d_ctor.inc"
+#include "gen/i3d_refine.inc"
+// shim for Intrinsic3D::init (intrinsic3d.cpp:151-203): its keyframe loop needs Sensor + cv::pyrDown / cvtColor; image_model_ is
+// filled by the C ABI instead, and what remains is the configuration of the colouriser (:160-166) and the initial recolouring (:196-201)
+bool Intrinsic3D::init() {
+    sdf_colorization_.reset(opt_data_.grid, sensor_->colorCamera());
+    SDFColorization::Config colorizeCfg;
+    colorizeCfg.max_occlusion_distance = cfg_.occlusions_distance;
+    colorizeCfg.max_num_observations = cfg_.num_observations;
+    sdf_colorization_.setConfig(colorizeCfg);
+    return recomputeColors();
+}
 
 #include "gen/mesh_struct.inc"
 #include "gen/mesh_save.inc"
 namespace MeshUtil {
 #include "gen/mesh_degenerate.inc"
 }  // namespace MeshUtil
-#define private public                               /* shim: the tables are private statics; ref_mc_tables() reads them */
 #include "gen/mc_class.inc"
-#undef private
 #include "gen/mc_extract_mesh.inc"
 #include "gen/mc_body.inc"
 #include "gen/mc_tables.inc"
 
 }  // namespace nv
+#undef private
+#undef protected
 
 // ---------------------------------------------------------------------------------------------------------------- C ABI (ours)
 using namespace nv;
@@ -250,17 +250,17 @@ void ref_sh_reg_cost(const double* sh9a, const double* sh9b, double* r9) { SHReg
 
 // observation weights / colours (SDFColorization)
 int32_t ref_voxel_visible(float max_occlusion_distance, const float* pt3, int32_t w, int32_t h, const float* depth, int32_t x, int32_t y) {
-    SDFColorization c; c.cfg_.max_occlusion_distance = max_occlusion_distance; cv::Mat d; d.rows = h; d.cols = w; d.p = depth;
+    Camera cam; SDFColorization c(cam); c.cfg_.max_occlusion_distance = max_occlusion_distance; const cv::Mat d = cv::Mat::wrap(h, w, CV_32FC1, depth);
     return c.isVoxelVisible(Vec3f(pt3[0], pt3[1], pt3[2]), d, x, y) ? 1 : 0;
 }
 float ref_observation_weight(int32_t w, int32_t h, const float* depth, const float* n3, int32_t x, int32_t y, const float* v3) {
-    SDFColorization c; cv::Mat d; d.rows = h; d.cols = w; d.p = depth;
+    Camera cam; SDFColorization c(cam); const cv::Mat d = cv::Mat::wrap(h, w, CV_32FC1, depth);
     return c.computeWeight(d, Vec3f(n3[0], n3[1], n3[2]), x, y, Vec3f(v3[0], v3[1], v3[2]));
 }
 void ref_compute_color(int32_t n, const uint8_t* rgb, const float* weights, float* out3) {
     std::vector<VertexObservation> obs((size_t)n);
     for (int i = 0; i < n; ++i) { obs[i].color = Vec3b(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]); obs[i].weight = weights[i]; obs[i].frame = i; }
-    SDFColorization c; const Vec3f col = c.computeColor(obs); out3[0] = col[0]; out3[1] = col[1]; out3[2] = col[2];
+    Camera cam; SDFColorization c(cam); const Vec3f col = c.computeColor(obs); out3[0] = col[0]; out3[1] = col[1]; out3[2] = col[2];
 }
 // filter: weights in frame order -> weights after keeping the best n (others zeroed), and the frame ids in the sorted order
 void ref_filter(int32_t count, float* weights, int32_t keep, int32_t* order) {
@@ -305,6 +305,356 @@ void ref_mesh_free(void* mesh) { delete (Mesh*)mesh; }
 // the two tables, for the case-by-case check of the product's packed copy
 void ref_mc_tables(int32_t* edge256, int32_t* tri256x16) {
     for (int i = 0; i < 256; ++i) { edge256[i] = MarchingCubes<VoxelSBR>::edge_table_[i]; for (int k = 0; k < 16; ++k) tri256x16[16 * i + k] = MarchingCubes<VoxelSBR>::triangle_table_[i][k]; }
+}
+
+
+// ================================================================================================================================
+// Pipeline level (round 3): the reference's OWN Optimizer / NLSSolver / SDFColorization / SDFAlgorithms / Subvolumes / LightingSVSH /
+// SparseVoxelGrid::integrate / Intrinsic3D::refine, driven through the same C ABI shapes as oracle/i3d_oracle.h (orc_* -> ref_*) so that
+// one Python harness runs both.  ceres::Solve underneath is oracle/ref_shim/mini_ceres_solver.hpp.
+// ================================================================================================================================
+typedef struct {
+    int32_t iterations, lm_steps;
+    double lambda_g, lambda_r0, lambda_r1, lambda_s0, lambda_s1, lambda_a;
+    int32_t fix_poses, fix_intrinsics, fix_distortion;
+    float occlusion_distance; int32_t num_observations;
+    double thres_shell; int32_t grid_level, rgbd_level;
+    int32_t cg_fixed_iterations; int32_t verbose; int32_t fix_sdf; int32_t carry_trust_radius;
+} ref_opt_config;                                    /* = orc_opt_config */
+typedef struct {
+    int32_t rows[4]; double weight_sum[4]; double type_weight[4];
+    int32_t valid_voxels, num_params, num_rows_reduced;
+    double cost_initial, cost_final; int32_t lm_iterations, successful;
+    int32_t cg_iters[50]; int32_t accepted[50]; int32_t n_attempts; double final_radius; int32_t termination;
+} ref_iter_stats;                                    /* = orc_iter_stats */
+typedef struct { int32_t data_rows, reg_rows, subvolumes, lm_iterations, termination; double cost_initial, cost_final; } ref_sh_stats;
+
+}  // extern "C" (helpers below are C++)
+
+namespace {
+
+struct CoutSilencer { std::streambuf* o; std::streambuf* e; CoutSilencer() : o(std::cout.rdbuf(nullptr)), e(std::cerr.rdbuf(nullptr)) {} ~CoutSilencer() { std::cout.rdbuf(o); std::cerr.rdbuf(e); } };
+
+struct RefFrames {                                   // K keyframe pyramids; images are borrowed from the caller
+    int K = 0, levels = 0; std::vector<Pyramid> pyr;
+};
+
+Optimizer::Config to_opt_cfg(const ref_opt_config* c) {
+    Optimizer::Config o; o.iterations = c->iterations; o.lm_steps = c->lm_steps; o.lambda_g = c->lambda_g; o.lambda_r0 = c->lambda_r0; o.lambda_r1 = c->lambda_r1;
+    o.lambda_s0 = c->lambda_s0; o.lambda_s1 = c->lambda_s1; o.lambda_a = c->lambda_a;
+    o.fix_poses = c->fix_poses != 0; o.fix_intrinsics = c->fix_intrinsics != 0; o.fix_distortion = c->fix_distortion != 0; return o;
+}
+
+// global parameter ids as the oracle numbers them: sdf_refined of voxel i (visit order) = i, albedo = N + i, pose f = 2N + 6f.., intrinsics, distortion
+struct ParamIndex {
+    std::unordered_map<const double*, long> id; long N = 0, K = 0;
+    std::vector<Vec3i> keys;
+    void bind(SparseVoxelGrid<VoxelSBR>* g, Optimizer::ImageFormationModel& im) {
+        id.clear(); keys.clear(); N = (long)g->numVoxels(); K = (long)im.poses.size(); id.reserve((size_t)(2 * N + K + 2) * 2);
+        long i = 0; for (auto it = g->begin(); it != g->end(); ++it, ++i) { id[&it->second.sdf_refined] = i; id[&it->second.albedo] = N + i; keys.push_back(it->first); }
+        for (long f = 0; f < K; ++f) id[im.poses[f].data()] = 2 * N + 6 * f;
+        id[im.intrinsics.data()] = 2 * N + 6 * K; id[im.distortion_coeffs.data()] = 2 * N + 6 * K + 4;
+    }
+};
+
+struct SnapRow { int type, v, f, dir; double weight, residual; double J[29]; };
+struct Snapshot { std::vector<SnapRow> rows[4]; std::vector<uint8_t> fix_sdf, fix_alb; long N = 0; };   // flags: 0 free, 1 constant, 2 not in the problem
+
+int row_type(const ceres::CostFunction* c) {
+    if (dynamic_cast<const ceres::DynamicAutoDiffCostFunction<ShadingCost, 4>*>(c)) return 0;
+    if (dynamic_cast<const ceres::AutoDiffCostFunction<VolumetricRegularizer, 1, 1, 1, 1, 1, 1, 1, 1>*>(c)) return 1;
+    if (dynamic_cast<const ceres::AutoDiffCostFunction<SurfaceStabRegularizer, 1, 1>*>(c)) return 2;
+    if (dynamic_cast<const ceres::AutoDiffCostFunction<AlbedoRegularizer, 1, 1, 1>*>(c)) return 3;
+    return -1;
+}
+
+void take_snapshot(const ceres::Problem& P, const ParamIndex& ix, Snapshot* s) {
+    s->N = ix.N; s->fix_sdf.assign((size_t)ix.N, 2); s->fix_alb.assign((size_t)ix.N, 2);
+    for (double* p : P.parameter_order()) { const long g = ix.id.at(p); if (g < ix.N) s->fix_sdf[g] = P.info(p).constant ? 1 : 0; else if (g < 2 * ix.N) s->fix_alb[g - ix.N] = P.info(p).constant ? 1 : 0; }
+    for (const ceres::ResidualBlock& rb : P.blocks()) {
+        SnapRow r; std::memset(&r, 0, sizeof r); r.type = row_type(rb.cost); r.f = -1; r.dir = -1;
+        if (r.type < 0) continue;
+        const long g0 = ix.id.at(rb.params[0]);
+        r.v = (int)(r.type == 3 ? g0 - ix.N : g0);
+        r.weight = static_cast<const ceres::ScaledLoss*>(rb.loss)->scale();
+        std::vector<std::vector<double>> jac(rb.params.size()); std::vector<double*> jp(rb.params.size());
+        const std::vector<int32_t>& sz = rb.cost->parameter_block_sizes();
+        for (size_t i = 0; i < jac.size(); ++i) { jac[i].assign((size_t)sz[i], 0.0); jp[i] = jac[i].data(); }
+        rb.cost->Evaluate(rb.params.data(), &r.residual, r.type == 0 ? jp.data() : nullptr);
+        if (r.type == 0) {
+            r.f = (int)((ix.id.at(rb.params[14]) - 2 * ix.N) / 6);
+            int k = 0; for (size_t i = 0; i < jac.size(); ++i) for (int c = 0; c < sz[i]; ++c) r.J[k++] = jac[i][c];
+        } else if (r.type == 3) {
+            const Vec3i a = ix.keys[(size_t)r.v], b = ix.keys[(size_t)(ix.id.at(rb.params[1]) - ix.N)];
+            const int d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+            r.dir = d[0] == 1 ? 0 : d[0] == -1 ? 1 : d[1] == 1 ? 2 : d[1] == -1 ? 3 : d[2] == 1 ? 4 : 5;
+        }
+        s->rows[r.type].push_back(r);
+    }
+}
+
+struct RefRun {                                      // everything one Optimizer::optimize call of the reference needs
+    Optimizer::Data data; Optimizer::ImageFormationModel im; Camera cam; SDFColorization col;
+    RefRun() : col(cam) {}
+    void setup(SparseVoxelGrid<VoxelSBR>* g, RefFrames* fr, const ref_opt_config* c, const double* intr, const double* dist, const double* poses, const double* voxel_sh) {
+        data.grid = g; data.thres_shell = c->thres_shell; data.grid_level = c->grid_level; data.rgbd_level = c->rgbd_level;
+        const size_t N = g->numVoxels();
+        data.voxel_sh_coeffs.assign(N, Eigen::VectorXd(9));
+        for (size_t i = 0; i < N; ++i) for (int j = 0; j < 9; ++j) data.voxel_sh_coeffs[i][j] = voxel_sh[9 * i + j];
+        for (int i = 0; i < 4; ++i) im.intrinsics[i] = intr[i];
+        for (int i = 0; i < 5; ++i) im.distortion_coeffs[i] = dist[i];
+        im.poses.resize((size_t)fr->K); im.rgbd_pyr = fr->pyr; im.frame_ids.clear();
+        for (int f = 0; f < fr->K; ++f) { for (int j = 0; j < 6; ++j) im.poses[f][j] = poses[6 * f + j]; im.frame_ids.push_back(f); }
+        data.shading_cost_data.clear();                                                     // Intrinsic3D::prepareRgbdLevel (intrinsic3d.cpp:337-350)
+        for (size_t i = 0; i < im.rgbd_pyr.size(); ++i) {
+            cv::Mat lum = im.rgbd_pyr[i].intensity(data.rgbd_level);
+            data.shading_cost_data.push_back(ShadingCostData(data.rgbd_level, static_cast<double>(g->voxelSize()), lum.cols, lum.rows, reinterpret_cast<const float*>(lum.data)));
+        }
+        SDFColorization::Config cc; cc.max_occlusion_distance = c->occlusion_distance; cc.max_num_observations = (size_t)c->num_observations;
+        col.setConfig(cc);
+    }
+};
+
+std::unordered_map<void*, SparseVoxelGrid<Voxel>*>& twins() { static std::unordered_map<void*, SparseVoxelGrid<Voxel>*> t; return t; }
+
+}  // namespace
+
+extern "C" {
+
+void* ref_grid_from_voxels(float voxel_size, int64_t n, const int32_t* keys, const float* sdf, const float* weight, const uint8_t* color) {
+    SparseVoxelGrid<Voxel>* g = SparseVoxelGrid<Voxel>::create(voxel_size);        // records inserted in file order (SparseVoxelGrid::load), then convert()
+    for (int64_t i = 0; i < n; ++i) { Voxel v; v.sdf = sdf[i]; v.weight = weight[i]; v.color = Vec3b(color[3 * i], color[3 * i + 1], color[3 * i + 2]);
+        g->setVoxel(Vec3i(keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]), v); }
+    SparseVoxelGrid<VoxelSBR>* out = SDFAlgorithms::convert(g); twins()[out] = g; return out;     // the Voxel grid is kept: Intrinsic3D::refine starts from it
+}
+int64_t ref_grid_size(void* g) { return (int64_t)((SparseVoxelGrid<VoxelSBR>*)g)->numVoxels(); }
+float ref_grid_voxel_size(void* g) { return ((SparseVoxelGrid<VoxelSBR>*)g)->voxelSize(); }
+void ref_grid_export(void* gp, int32_t* keys, double* sdf, double* sdf_refined, double* albedo, float* weight, uint8_t* color) {
+    auto* g = (SparseVoxelGrid<VoxelSBR>*)gp; size_t i = 0;
+    for (auto it = g->begin(); it != g->end(); ++it, ++i) {
+        if (keys) for (int c = 0; c < 3; ++c) keys[3 * i + c] = it->first[c];
+        if (sdf) sdf[i] = it->second.sdf;
+        if (sdf_refined) sdf_refined[i] = it->second.sdf_refined;
+        if (albedo) albedo[i] = it->second.albedo;
+        if (weight) weight[i] = it->second.weight;
+        if (color) for (int c = 0; c < 3; ++c) color[3 * i + c] = it->second.color[c];
+    }
+}
+void ref_grid_import(void* gp, const double* sdf_refined, const double* albedo, const uint8_t* color) {
+    auto* g = (SparseVoxelGrid<VoxelSBR>*)gp; size_t i = 0;
+    for (auto it = g->begin(); it != g->end(); ++it, ++i) {
+        if (sdf_refined) it->second.sdf_refined = sdf_refined[i];
+        if (albedo) it->second.albedo = albedo[i];
+        if (color) it->second.color = Vec3b(color[3 * i], color[3 * i + 1], color[3 * i + 2]);
+    }
+}
+void ref_grid_clear_outside_shell(void* g, double thres) { SDFAlgorithms::clearVoxelsOutsideThinShell((SparseVoxelGrid<VoxelSBR>*)g, thres); }
+void* ref_grid_upsample(void* g) { return SDFAlgorithms::upsample<VoxelSBR>((SparseVoxelGrid<VoxelSBR>*)g); }
+void ref_grid_free(void* g) { auto it = twins().find(g); if (it != twins().end()) { delete it->second; twins().erase(it); } delete (SparseVoxelGrid<VoxelSBR>*)g; }
+
+void* ref_frames_create(int32_t K, int32_t levels) {
+    auto* f = new RefFrames; f->K = K; f->levels = levels; f->pyr.resize((size_t)K);
+    for (auto& p : f->pyr) { p.color_pyramid_.resize((size_t)levels); p.intensity_pyramid_.resize((size_t)levels); p.depth_pyramid_.resize((size_t)levels); }
+    return f;
+}
+void ref_frames_set(void* fr, int32_t f, int32_t lvl, int32_t w, int32_t h, const float* lum, const float* depth, const uint8_t* bgr) {
+    Pyramid& p = ((RefFrames*)fr)->pyr[(size_t)f];
+    p.intensity_pyramid_[(size_t)lvl] = cv::Mat::wrap(h, w, CV_32FC1, lum); p.depth_pyramid_[(size_t)lvl] = cv::Mat::wrap(h, w, CV_32FC1, depth);
+    p.color_pyramid_[(size_t)lvl] = bgr ? cv::Mat::wrap(h, w, CV_8UC3, bgr) : cv::Mat(h, w, CV_8UC3);
+}
+void ref_frames_free(void* fr) { delete (RefFrames*)fr; }
+
+// Optimizer::optimize of the reference (optimizer.cpp:109-173), every outer iteration: addVoxelResiduals, NLSSolver::buildProblem,
+// fixVoxelParams, NLSSolver::solve -> mini-ceres.  Statistics come from the ceres::Problem / Summary of each iteration.
+int32_t ref_optimize(void* g, void* fr, const ref_opt_config* c, double* intr, double* dist, double* poses, const double* voxel_sh, ref_iter_stats* stats) {
+    CoutSilencer quiet;
+    auto* G = (SparseVoxelGrid<VoxelSBR>*)g; auto* F = (RefFrames*)fr;
+    RefRun run; run.setup(G, F, c, intr, dist, poses, voxel_sh);
+    ParamIndex ix; ix.bind(G, run.im);
+    int call = 0;
+    ceres::hooks() = ceres::SolveHooks(); ceres::hooks().cg_fixed_iterations = c->cg_fixed_iterations;
+    ceres::hooks().on_problem = [&](const ceres::Problem& P) {
+        if (!stats || call >= c->iterations) { ++call; return; }
+        ref_iter_stats& st = stats[call++]; std::memset(&st, 0, sizeof st);
+        Snapshot s; take_snapshot(P, ix, &s);
+        for (int t = 0; t < 4; ++t) st.rows[t] = (int32_t)s.rows[t].size();
+    };
+    struct After : ceres::IterationCallback { ceres::CallbackReturnType operator()(const ceres::IterationSummary&) override { return ceres::SOLVER_CONTINUE; } };
+    ceres::hooks_summary() = [&](const ceres::Solver::Summary& sum) {
+        if (!stats || call < 1 || call > c->iterations) return;
+        ref_iter_stats& st = stats[call - 1];
+        st.cost_initial = sum.initial_cost - sum.fixed_cost; st.cost_final = sum.final_cost - sum.fixed_cost; st.num_params = sum.num_parameters_reduced; st.num_rows_reduced = sum.num_residuals_reduced;
+        st.lm_iterations = (int32_t)sum.iterations.size() - 1; st.successful = sum.num_successful_steps; st.n_attempts = 0;
+        for (size_t i = 1; i < sum.iterations.size() && st.n_attempts < 50; ++i) { st.cg_iters[st.n_attempts] = sum.iterations[i].linear_solver_iterations; st.accepted[st.n_attempts] = sum.iterations[i].step_is_successful ? 1 : 0; ++st.n_attempts; }
+        st.final_radius = sum.iterations.empty() ? 0.0 : sum.iterations.back().trust_region_radius;
+        st.termination = sum.termination_type == ceres::USER_SUCCESS ? 2 : sum.termination_type == ceres::CONVERGENCE ? 1 : sum.termination_type == ceres::NO_CONVERGENCE ? 0 : 3;
+    };
+    Optimizer opt(to_opt_cfg(c));
+    const bool ok = opt.optimize(run.col, run.data, run.im);
+    ceres::hooks() = ceres::SolveHooks(); ceres::hooks_summary() = nullptr;
+    for (int i = 0; i < 4; ++i) intr[i] = run.im.intrinsics[i];
+    for (int i = 0; i < 5; ++i) dist[i] = run.im.distortion_coeffs[i];
+    for (int f = 0; f < F->K; ++f) for (int j = 0; j < 6; ++j) poses[6 * f + j] = run.im.poses[f][j];
+    return ok ? 0 : 1;
+}
+
+// one residual collection (no solve) exactly as outer iteration `iteration` of `cfg->iterations` would assemble it
+void* ref_collect(void* g, void* fr, const ref_opt_config* c, const double* intr, const double* dist, const double* poses, const double* voxel_sh, int32_t iteration) {
+    CoutSilencer quiet;
+    auto* G = (SparseVoxelGrid<VoxelSBR>*)g; auto* F = (RefFrames*)fr;
+    RefRun run; run.setup(G, F, c, intr, dist, poses, voxel_sh);
+    ParamIndex ix; ix.bind(G, run.im);
+    auto* snap = new Snapshot; int call = 0;
+    ceres::hooks() = ceres::SolveHooks(); ceres::hooks().skip_minimize = true;
+    ceres::hooks().on_problem = [&](const ceres::Problem& P) { if (call++ == iteration) take_snapshot(P, ix, snap); };
+    Optimizer opt(to_opt_cfg(c)); opt.optimize(run.col, run.data, run.im);      // nothing moves (skip_minimize): iteration k sees the input state
+    ceres::hooks() = ceres::SolveHooks();
+    snap->N = ix.N;
+    return snap;
+}
+void ref_problem_counts(void* p, int32_t rows[4], double ws[4], double tw[4]) {
+    auto* s = (Snapshot*)p; for (int t = 0; t < 4; ++t) { rows[t] = (int32_t)s->rows[t].size(); if (ws) ws[t] = 0.0; if (tw) tw[t] = 0.0; }
+}
+void ref_problem_flags(void* p, uint8_t* active, uint8_t* ring_ok, uint8_t* fix_sdf, uint8_t* fix_alb) {
+    auto* s = (Snapshot*)p; (void)active; (void)ring_ok;
+    for (long i = 0; i < s->N; ++i) { if (fix_sdf) fix_sdf[i] = s->fix_sdf[(size_t)i]; if (fix_alb) fix_alb[i] = s->fix_alb[(size_t)i]; }
+}
+void ref_problem_eg(void* p, int32_t* v, int32_t* f, double* weight, double* residual, double* J) {
+    auto* s = (Snapshot*)p; const auto& rows = s->rows[0];
+    for (size_t i = 0; i < rows.size(); ++i) { v[i] = rows[i].v; f[i] = rows[i].f; weight[i] = rows[i].weight; residual[i] = rows[i].residual; if (J) for (int k = 0; k < 29; ++k) J[i * 29 + k] = rows[i].J[k]; }
+}
+void ref_problem_reg(void* p, int32_t type, int32_t* v, int32_t* dir, double* weight, double* residual) {
+    auto* s = (Snapshot*)p; const auto& rows = s->rows[type];
+    for (size_t i = 0; i < rows.size(); ++i) { v[i] = rows[i].v; if (dir) dir[i] = rows[i].dir; weight[i] = rows[i].weight; if (residual) residual[i] = rows[i].residual; }
+}
+void ref_problem_free(void* p) { delete (Snapshot*)p; }
+
+// LightingSVSH::estimate + computeVoxelShCoeffs of the reference (lighting_svsh.cpp:83-110,166-346; subvolumes.cpp)
+int32_t ref_estimate_sh(void* g, float subvolume_size, double lambda_reg, double thres_shell, int32_t cg_fixed, int32_t* num_subvolumes, double* sh, int32_t* sub_index, int32_t cap,
+                        double* voxel_sh, uint8_t* voxel_has, ref_sh_stats* st) {
+    CoutSilencer quiet;
+    auto* G = (SparseVoxelGrid<VoxelSBR>*)g;
+    LightingSVSH L(G, subvolume_size, lambda_reg, thres_shell, true);
+    ceres::hooks() = ceres::SolveHooks(); ceres::hooks().cg_fixed_iterations = cg_fixed;
+    if (st) std::memset(st, 0, sizeof *st);
+    ceres::hooks().on_problem = [&](const ceres::Problem& P) { if (!st) return; for (const auto& rb : P.blocks()) { if (rb.cost->num_residuals() == 1) ++st->data_rows; else ++st->reg_rows; } };
+    ceres::hooks_summary() = [&](const ceres::Solver::Summary& sum) { if (!st) return; st->lm_iterations = (int32_t)sum.iterations.size() - 1; st->cost_initial = sum.initial_cost; st->cost_final = sum.final_cost;
+        st->termination = sum.termination_type == ceres::CONVERGENCE ? 1 : sum.termination_type == ceres::NO_CONVERGENCE ? 0 : 3; };
+    const bool ok = L.estimate();
+    ceres::hooks() = ceres::SolveHooks(); ceres::hooks_summary() = nullptr;
+    if (!ok) return 1;
+    const int S = (int)L.subvolumes().count(); *num_subvolumes = S; if (st) st->subvolumes = S;
+    if (S > cap) return 2;
+    const std::vector<Eigen::VectorXd> coeffs = L.shCoeffs();
+    for (int i = 0; i < S; ++i) { for (int j = 0; j < 9; ++j) sh[9 * i + j] = coeffs[(size_t)i][j];
+        if (sub_index) { const Vec3i ix = L.subvolumes().index(i); for (int c = 0; c < 3; ++c) sub_index[3 * i + c] = ix[c]; } }
+    if (voxel_sh) {
+        std::vector<Eigen::VectorXd> vc; L.computeVoxelShCoeffs(vc);
+        for (size_t i = 0; i < vc.size(); ++i) { const bool has = vc[i].size() == 9; if (voxel_has) voxel_has[i] = has ? 1 : 0; for (int j = 0; j < 9; ++j) voxel_sh[9 * i + j] = has ? vc[i][j] : 0.0; }
+    }
+    return 0;
+}
+
+// Intrinsic3D::recomputeColors (intrinsic3d.cpp:381-409) on SDFColorization::add / compute of the reference
+int32_t ref_recompute_colors(void* g, void* fr, const double* intr, const double* dist, const double* poses, float occlusion_distance, int32_t num_observations) {
+    CoutSilencer quiet;
+    auto* G = (SparseVoxelGrid<VoxelSBR>*)g; auto* F = (RefFrames*)fr;
+    Sensor sensor; KeyframeSelection ks;
+    Intrinsic3D::Config cfg; cfg.occlusions_distance = occlusion_distance; cfg.num_observations = (size_t)num_observations; cfg.num_rgbd_levels = F->levels;
+    Intrinsic3D i3d(cfg, Optimizer::Config(), &sensor, &ks);
+    i3d.opt_data_.grid = G; i3d.image_model_.rgbd_pyr = F->pyr; i3d.image_model_.poses.resize((size_t)F->K);
+    for (int i = 0; i < 4; ++i) i3d.image_model_.intrinsics[i] = intr[i];
+    for (int i = 0; i < 5; ++i) i3d.image_model_.distortion_coeffs[i] = dist[i];
+    for (int f = 0; f < F->K; ++f) for (int j = 0; j < 6; ++j) i3d.image_model_.poses[(size_t)f][j] = poses[6 * f + j];
+    SDFColorization::Config cc; cc.max_occlusion_distance = occlusion_distance; cc.max_num_observations = (size_t)num_observations; i3d.sdf_colorization_.setConfig(cc);
+    return i3d.recomputeColors() ? 0 : 1;
+}
+
+// Intrinsic3D::refine (intrinsic3d.cpp:206-290) of the reference on a grid built by ref_grid_from_voxels' Voxel twin; *grid_io receives the final grid
+int32_t ref_refine(void** grid_io, void* fr, const ref_opt_config* c, int32_t num_grid_levels, int32_t num_rgbd_levels, double thres_shell_factor, double thres_shell_factor_final,
+                   int32_t clear_distant_voxels, float subvolume_size_sh, double sh_lambda_reg, double* intr, double* dist, double* poses, int32_t* levels_done) {
+    CoutSilencer quiet;
+    auto* G = (SparseVoxelGrid<VoxelSBR>*)*grid_io; auto* F = (RefFrames*)fr;
+    auto tw = twins().find(G); if (tw == twins().end()) return 3;          // refine() takes the Voxel grid the VoxelSBR grid was converted from
+    SparseVoxelGrid<Voxel>* twin = tw->second;
+    Sensor sensor; KeyframeSelection ks;
+    Intrinsic3D::Config cfg; cfg.num_grid_levels = num_grid_levels; cfg.num_rgbd_levels = num_rgbd_levels; cfg.thres_shell_factor = thres_shell_factor; cfg.thres_shell_factor_final = thres_shell_factor_final;
+    cfg.clear_distant_voxels = clear_distant_voxels != 0; cfg.occlusions_distance = c->occlusion_distance; cfg.num_observations = (size_t)c->num_observations;
+    cfg.subvolume_size_sh = subvolume_size_sh; cfg.sh_est_lambda_reg = sh_lambda_reg;
+    { Vec4 k; for (int i = 0; i < 4; ++i) k[i] = intr[i]; sensor.color_cam_.setIntrinsics(k); cv::Mat l0 = F->pyr[0].intensity(0); sensor.color_cam_.setWidth(l0.cols); sensor.color_cam_.setHeight(l0.rows); }
+    Intrinsic3D i3d(cfg, to_opt_cfg(c), &sensor, &ks);
+    i3d.image_model_.rgbd_pyr = F->pyr; i3d.image_model_.poses.resize((size_t)F->K);
+    for (int i = 0; i < 4; ++i) i3d.image_model_.intrinsics[i] = intr[i];
+    for (int i = 0; i < 5; ++i) i3d.image_model_.distortion_coeffs[i] = dist[i];
+    for (int f = 0; f < F->K; ++f) { for (int j = 0; j < 6; ++j) i3d.image_model_.poses[(size_t)f][j] = poses[6 * f + j]; i3d.image_model_.frame_ids.push_back(f); }
+    struct Keep : Intrinsic3D::RefinementCallback { SparseVoxelGrid<VoxelSBR>* last = nullptr; int n = 0; std::vector<std::tuple<Vec3i, VoxelSBR>> recs; float vs = 0, dmin = 0, dmax = 0;
+        void onSDFRefined(const Intrinsic3D::RefinementInfo& info) override { ++n; recs.clear(); vs = info.grid->voxelSize(); dmin = info.grid->depthMin(); dmax = info.grid->depthMax();
+            for (auto it = info.grid->begin(); it != info.grid->end(); ++it) recs.emplace_back(it->first, it->second); } } keep;
+    i3d.addRefinementCallback(&keep);
+    ceres::hooks() = ceres::SolveHooks(); ceres::hooks().cg_fixed_iterations = c->cg_fixed_iterations;
+    const bool ok = i3d.refine(twin);                // deletes its own VoxelSBR grid at the end (:287); the last callback state is what we return
+    ceres::hooks() = ceres::SolveHooks();
+    twins().erase(G); delete twin; delete G;
+    // the records of the last callback go back through a fresh container filled in that visit order; the caller compares BY KEY
+    SparseVoxelGrid<VoxelSBR>* out = SparseVoxelGrid<VoxelSBR>::create(keep.vs > 0 ? keep.vs : 0.004f, keep.dmin, keep.dmax);
+    for (auto& r : keep.recs) out->setVoxel(std::get<0>(r), std::get<1>(r));
+    *grid_io = out;
+    for (int i = 0; i < 4; ++i) intr[i] = i3d.image_model_.intrinsics[i];
+    for (int i = 0; i < 5; ++i) dist[i] = i3d.image_model_.distortion_coeffs[i];
+    for (int f = 0; f < F->K; ++f) for (int j = 0; j < 6; ++j) poses[6 * f + j] = i3d.image_model_.poses[(size_t)f][j];
+    if (levels_done) *levels_done = keep.n;
+    return ok ? 0 : 1;
+}
+
+// TSDF fusion: AppFusion::fuseSDF's per-frame body (app_fusion.cpp:150-170) on SparseVoxelGrid<Voxel>::integrate / alloc of the reference
+struct RefFusion { SparseVoxelGrid<Voxel>* grid; };
+void* ref_fusion_create(float voxel_size, float depth_min, float depth_max, const float* clip6) {
+    auto* f = new RefFusion; f->grid = SparseVoxelGrid<Voxel>::create(voxel_size, depth_min, depth_max);
+    if (clip6) { Vec6f cb; for (int i = 0; i < 6; ++i) cb[i] = clip6[i]; if (cb.norm() > 0.0f) f->grid->setClipBounds(cb); }
+    return f;
+}
+void ref_fusion_integrate(void* fp, int32_t dw, int32_t dh, const float* dc, int32_t cw, int32_t ch, const float* cc, const float* depth_in, const uint8_t* bgr, const float* pose16, int32_t erode_window) {
+    auto* f = (RefFusion*)fp;
+    auto mk = [](const float* k, int w, int h) { Mat3f K = Mat3f::Identity(); K(0, 0) = k[0]; K(1, 1) = k[1]; K(0, 2) = k[2]; K(1, 2) = k[3]; return Camera(K, w, h); };
+    Camera dcam = mk(dc, dw, dh), ccam = mk(cc, cw, ch);
+    cv::Mat depth = cv::Mat::wrap(dh, dw, CV_32FC1, depth_in); const cv::Mat color = cv::Mat::wrap(ch, cw, CV_8UC3, bgr);
+    if (erode_window > 0) depth = erodeDiscontinuities(depth, erode_window);
+    cv::Mat normals = computeNormals(dcam.intrinsics(), depth);
+    Mat4f pose; for (int r = 0; r < 4; ++r) for (int c2 = 0; c2 < 4; ++c2) pose(r, c2) = pose16[4 * r + c2];
+    f->grid->integrate(dcam, ccam, depth, color, normals, pose);
+}
+void ref_fusion_finish(void* fp, int32_t iters) { auto* f = (RefFusion*)fp; SDFAlgorithms::correctSDF(f->grid, (unsigned)iters); SDFAlgorithms::clearInvalidVoxels(f->grid); }
+int64_t ref_fusion_size(void* fp) { return (int64_t)((RefFusion*)fp)->grid->numVoxels(); }
+void ref_fusion_export(void* fp, int32_t* keys, float* sdf, float* weight, uint8_t* color) {
+    auto* g = ((RefFusion*)fp)->grid; size_t i = 0;
+    for (auto it = g->begin(); it != g->end(); ++it, ++i) { for (int c = 0; c < 3; ++c) { keys[3 * i + c] = it->first[c]; color[3 * i + c] = it->second.color[c]; } sdf[i] = it->second.sdf; weight[i] = it->second.weight; }
+}
+void ref_fusion_free(void* fp) { auto* f = (RefFusion*)fp; delete f->grid; delete f; }
+void ref_erode_discontinuities(int32_t w, int32_t h, const float* in, int32_t window, float max_diff, float* out) {
+    const cv::Mat r = erodeDiscontinuities(cv::Mat::wrap(h, w, CV_32FC1, in), window, max_diff); std::memcpy(out, r.data, (size_t)w * h * 4);
+}
+void ref_compute_normals(int32_t w, int32_t h, const float* c, const float* depth, float thr, float* normals) {
+    Mat3f K = Mat3f::Identity(); K(0, 0) = c[0]; K(1, 1) = c[1]; K(0, 2) = c[2]; K(1, 2) = c[3];
+    const cv::Mat r = computeNormals(K, cv::Mat::wrap(h, w, CV_32FC1, depth), thr); std::memcpy(normals, r.data, (size_t)w * h * 12);
+}
+void ref_resize_depth(int32_t iw, int32_t ih, const float* din, const float* in_intr, int32_t ow, int32_t oh, const float* out_intr, float* dout) {
+    auto mk = [](const float* k, int w, int h) { Mat3f K = Mat3f::Identity(); K(0, 0) = k[0]; K(1, 1) = k[1]; K(0, 2) = k[2]; K(1, 2) = k[3]; return Camera(K, w, h); };
+    const cv::Mat r = resizeDepth(mk(in_intr, iw, ih), cv::Mat::wrap(ih, iw, CV_32FC1, din), mk(out_intr, ow, oh)); std::memcpy(dout, r.data, (size_t)ow * oh * 4);
+}
+void ref_depth_down(int32_t w, int32_t h, const float* src, float* dst) {
+    Pyramid p; const cv::Mat r = p.downsampleDepth(cv::Mat::wrap(h, w, CV_32FC1, src)); std::memcpy(dst, r.data, (size_t)(w / 2) * (h / 2) * 4);
+}
+void ref_pose_to_mat(const double* pose6, float* R9, float* t3) {
+    Vec6 p; for (int i = 0; i < 6; ++i) p[i] = pose6[i];
+    const Mat4f m = math::poseVecAAToMat(p).cast<float>();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R9[3 * r + c] = m(r, c); t3[r] = m(r, 3); }
+}
+void ref_interpolation_weights(const float* pos3, int32_t* coords24, float* weights8) {
+    Vec3i c[8]; math::interpolationWeights(Vec3f(pos3[0], pos3[1], pos3[2]), c, weights8);
+    for (int i = 0; i < 8; ++i) for (int k = 0; k < 3; ++k) coords24[3 * i + k] = c[i][k];
+}
+void ref_surface_normal(void* g, const int32_t* key3, float* n3) {
+    const Vec3f n = SDFOperators::computeSurfaceNormal((SparseVoxelGrid<VoxelSBR>*)g, Vec3i(key3[0], key3[1], key3[2])); n3[0] = n[0]; n3[1] = n[1]; n3[2] = n[2];
 }
 
 }  // extern "C"

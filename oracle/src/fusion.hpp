@@ -36,8 +36,9 @@ inline void inverse4f(const float* m, float* inv) {
     inv[12] = ((-m[4] * c3 + m[5] * c1) - m[6] * c0) * id;    inv[13] = ((m[0] * c3 - m[1] * c1) + m[2] * c0) * id;
     inv[14] = ((-m[12] * s3 + m[13] * s1) - m[14] * s0) * id; inv[15] = ((m[8] * s3 - m[9] * s1) + m[10] * s0) * id;
 }
+// pose.topLeftCorner<3,3>() * p + pose.topRightCorner<3,1>(): a FIXED-SIZE product, every coefficient a halving reduction a0 + (a1 + a2)
 inline void xform(const float* T /*4x4 row-major*/, const float p[3], float q[3]) {
-    for (int i = 0; i < 3; ++i) q[i] = ((T[4 * i] * p[0] + T[4 * i + 1] * p[1]) + T[4 * i + 2] * p[2]) + T[4 * i + 3];
+    for (int i = 0; i < 3; ++i) q[i] = (T[4 * i] * p[0] + (T[4 * i + 1] * p[1] + T[4 * i + 2] * p[2])) + T[4 * i + 3];
 }
 
 // rgbd/processing.cpp:184-232
@@ -74,10 +75,10 @@ inline void compute_normals(const PinCam& cam, const float* depth, float thr, fl
         const float* y0 = &vm[((size_t)(y - 1) * w + x) * 3]; const float* y1 = &vm[((size_t)(y + 1) * w + x) * 3];
         if (x0[2] == 0.0f || x1[2] == 0.0f || y0[2] == 0.0f || y1[2] == 0.0f) continue;
         const float tx[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]}, ty[3] = {y1[0] - y0[0], y1[1] - y0[1], y1[2] - y0[2]};
-        const float ntx = std::sqrt((tx[0] * tx[0] + tx[1] * tx[1]) + tx[2] * tx[2]), nty = std::sqrt((ty[0] * ty[0] + ty[1] * ty[1]) + ty[2] * ty[2]);
+        const float ntx = std::sqrt(tx[0] * tx[0] + (tx[1] * tx[1] + tx[2] * tx[2])), nty = std::sqrt(ty[0] * ty[0] + (ty[1] * ty[1] + ty[2] * ty[2]));
         if (ntx < thr && nty < thr) {
             float n[3] = {ty[1] * tx[2] - ty[2] * tx[1], ty[2] * tx[0] - ty[0] * tx[2], ty[0] * tx[1] - ty[1] * tx[0]};
-            const float sq = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
+            const float sq = n[0] * n[0] + (n[1] * n[1] + n[2] * n[2]);
             if (sq > 0.0f) { const float l = std::sqrt(sq); n[0] /= l; n[1] /= l; n[2] /= l; }
             float* o = &normals[((size_t)y * w + x) * 3]; o[0] = n[0]; o[1] = n[1]; o[2] = n[2];
         }
@@ -165,10 +166,10 @@ struct Fusion {
                 float wn = 1.0f;
                 if (normals) {
                     const float* n = &normals[((size_t)py * dcam.w + px) * 3];
-                    const float sq = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+                    const float sq = p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]);
                     float pn[3] = {p[0], p[1], p[2]};
                     if (sq > 0.0f) { const float l = std::sqrt(sq); pn[0] /= l; pn[1] /= l; pn[2] /= l; }
-                    wn = 1.0f - std::abs((pn[0] * n[0] + pn[1] * n[1]) + pn[2] * n[2]);
+                    wn = 1.0f - std::abs(pn[0] * n[0] + (pn[1] * n[1] + pn[2] * n[2]));
                     wn = std::max(std::min(wn, 1.0f), 0.0f);
                     wn = std::max(iws * robust_kernel(wn), 1.0f);
                 }
@@ -208,7 +209,7 @@ struct Fusion {
                     const Voxel& vn = grid.voxel(nb); const V3f nc = grid.voxelToWorld(nb);
                     const double sdf_nb = vn.sdf, sgn_nb = sdf_nb >= 0.0 ? 1.0 : -1.0;
                     const float dx = vc.x - nc.x, dy = vc.y - nc.y, dz = vc.z - nc.z;
-                    const double dist_nb = sdf_nb + sgn_nb * (double)std::sqrt((dx * dx + dy * dy) + dz * dz);
+                    const double dist_nb = sdf_nb + sgn_nb * (double)std::sqrt(dx * dx + (dy * dy + dz * dz));     // Vec3f::norm(): halving reduction
                     if (std::abs(dist_nb) < std::abs(sdf) && sgn == sgn_nb) { v.sdf = (float)dist_nb; v.weight = 1.0f; has_update = true; }
                 }
             }

@@ -98,7 +98,7 @@ struct Lighting {
             if (!g.valid(p)) continue;
             if (std::abs(v.sdf_refined) > thres_shell) continue;
             float n[3]; surface_normal(g, p, n);
-            const float nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            const float nn = std::sqrt(n[0] * n[0] + (n[1] * n[1] + n[2] * n[2]));
             if (is_zero3(n) || std::isnan(nn)) continue;
             if (v.albedo == 0.0 || std::isnan(v.albedo)) continue;
             const int s = sub.point_to_subvolume(g.voxelToWorld(p));

@@ -56,12 +56,18 @@ inline float intensity_u8(const uint8_t c[3]) { return 0.299f * (float)c[0] + 0.
 inline double chroma_weight(const uint8_t ca[3], const uint8_t cb[3]) {
     const float s255 = 1.0f / 255.0f;
     const float lum = intensity_u8(ca), lum_nb = intensity_u8(cb);
-    float d2 = 0.0f;
-    for (int c = 0; c < 3; ++c) { const float a = ((float)ca[c] * s255) / lum - ((float)cb[c] * s255) / lum_nb; d2 += a * a; }
-    float chroma = std::sqrt(d2);
+    float a[3];
+    for (int c = 0; c < 3; ++c) a[c] = ((float)ca[c] * s255) / lum - ((float)cb[c] * s255) / lum_nb;
+    float chroma = std::sqrt(a[0] * a[0] + (a[1] * a[1] + a[2] * a[2]));          // Vec3f::norm(): halving reduction
     chroma = std::max(1.0f - chroma, 0.01f);
     return (double)chroma * (double)1.0f;
 }
+
+// Eigen reduces a FIXED-SIZE 3-vector sum by halving (Core/Redux.h, redux_novec_unroller<0,3>): a0 + (a1 + a2).  Every dot / norm / fixed 3x3 * 3
+// product of the reference goes through it; run-time sized blocks (`topLeftCorner(3, 3) * p`) go through GEMV instead, which accumulates
+// left to right.  oracle/_ref runs the reference bodies on stand-ins with exactly these two orders and tests/test_ref_pipeline.py holds
+// this file to them bit for bit.
+template <class T> inline T esum3(T a0, T a1, T a2) { return a0 + (a1 + a2); }
 
 // operators.cpp:58-77 (float; Eigen normalize() divides by sqrt(squaredNorm))
 inline void surface_normal(const Grid<VoxelSBR>& g, const V3i& p, float n[3]) {
@@ -72,7 +78,7 @@ inline void surface_normal(const Grid<VoxelSBR>& g, const V3i& p, float n[3]) {
     n[0] = (float)g.voxel(px).sdf_refined - s0;
     n[1] = (float)g.voxel(py).sdf_refined - s0;
     n[2] = (float)g.voxel(pz).sdf_refined - s0;
-    const float sq = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    const float sq = esum3(n[0] * n[0], n[1] * n[1], n[2] * n[2]);
     const float len = std::sqrt(sq);
     if (len != 0.0f) { n[0] /= len; n[1] /= len; n[2] /= len; }
 }
@@ -80,7 +86,7 @@ inline bool is_zero3(const float n[3]) { return std::fabs(n[0]) <= 1e-5f && std:
 
 // math.cpp:151-163 — Eigen::AngleAxisd(norm, normalized).matrix() in double, then cast<float>() at the caller
 inline void pose_aa_to_mat(const double p[6], double R[9], double t[3]) {
-    const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    const double n2 = esum3(p[0] * p[0], p[1] * p[1], p[2] * p[2]);
     const double angle = std::sqrt(n2);
     double ax[3] = {p[0], p[1], p[2]};
     if (n2 > 0.0) { ax[0] /= angle; ax[1] /= angle; ax[2] /= angle; }
@@ -133,10 +139,10 @@ struct Colorizer {     // SDFColorization restricted to what the hot path uses
         if (d <= 0.0f) return 0.0f;
         float wn = 0.0f;
         if (!is_zero3(n)) {
-            const float vsq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+            const float vsq = esum3(v[0] * v[0], v[1] * v[1], v[2] * v[2]);
             float vn[3] = {v[0], v[1], v[2]};
             if (vsq > 0.0f) { const float l = std::sqrt(vsq); vn[0] /= l; vn[1] /= l; vn[2] /= l; }
-            wn = 1.0f - std::abs((vn[0] * n[0] + vn[1] * n[1]) + vn[2] * n[2]);
+            wn = 1.0f - std::abs(esum3(vn[0] * n[0], vn[1] * n[1], vn[2] * n[2]));
             wn = std::max(std::min(wn, 1.0f), 0.0f);
             const float div = 1.0f + 2.0f * wn;                      // math.cpp:43-47, thres = 2
             wn = std::max(1.0f / (div * div * div), 0.001f);

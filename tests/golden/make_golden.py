@@ -1,8 +1,12 @@
-"""Generates tests/golden/optimize_small.json from the CPU oracle (run: python tests/golden/make_golden.py).
+"""Generates tests/golden/*.json BY RUNNING THE REFERENCE'S OWN CODE (run: python tests/golden/make_golden.py in a container that has
+/root/reference).
 
-The reference has no fixtures and cannot be imported or built here, so these goldens pin the ORACLE'S OWN outputs
-(parity unpinned): a change in the restatement, in libstdc++'s unordered_map iteration order or in the
-synthetic generator shows up as a diff.  The -m gpu tests compare the HIP path against the same numbers."""
+The reference ships no fixtures, so these are made here: oracle/_ref compiles the reference's Optimizer / NLSSolver / SDFColorization /
+SDFAlgorithms / Subvolumes / LightingSVSH / SparseVoxelGrid::integrate classes from /root/reference (oracle/extract_ref.py) and
+`ref_py.pipeline()` drives them; the numbers below are what THAT code computes on seeded inputs ("generator": "reference").  The CPU suite
+holds the restated oracle to them, the -m gpu suite the HIP path — on boxes where /root/reference does not exist.  Two sections cannot come
+from the reference because the code behind them is OpenCV's, not the reference's (cv::pyrDown / cvtColor): "pyramid" is the oracle's
+restatement and says so.  Ceres is mini-ceres (oracle/ref_shim/mini_ceres_solver.hpp) under the reference and ceres_like.hpp under the oracle."""
 import json
 import os
 import sys
@@ -36,6 +40,11 @@ def compute(O):
     return res
 
 
+def strip_tags(d):
+    """the goldens without their provenance strings"""
+    return {k: (strip_tags(v) if isinstance(v, dict) else v) for k, v in d.items() if k != "generator"}
+
+
 def _crc(a):
     return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
 
@@ -55,9 +64,10 @@ def level_scene():
     return sc
 
 
-def compute_levels(O):
-    """CRCs of the byte-exact stages of the level schedule on the oracle: converted visit order, recolourisation, thin shell, x2 upsample,
-    and the keyframe pyramid / depth resampling"""
+def compute_levels(O, O_cv=None):
+    """CRCs of the byte-exact stages of the level schedule: converted visit order, recolourisation, thin shell, x2 upsample,
+    and the keyframe pyramid / depth resampling.  O_cv: the module that owns the OpenCV restatements (the oracle) when O is the reference."""
+    O_cv = O_cv or O
     sc = level_scene()
     g = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"]); fr = O.Frames(sc["frames"], 1)
     res = {"convert": {"n": len(g), "keys": _crc(g.export()["keys"])}}
@@ -70,25 +80,35 @@ def compute_levels(O):
     res["upsample"] = {"n": len(up), "keys": _crc(b["keys"]), "weight": _crc(b["weight"]), "sdf": _crc(b["sdf"]), "color": _crc(b["color"]),
                        "valid": int((b["weight"] > 0).sum())}
     bgr = sc["frames"][0]["bgr"][0]; dep = sc["frames"][0]["depth"][0]
-    lum = O.lum_from_bgr(bgr)
-    res["pyramid"] = {"lum0": _crc(lum), "lum1": _crc(O.pyr_down(lum)), "lum2": _crc(O.pyr_down(O.pyr_down(lum))), "depth1": _crc(O.depth_down(dep))}
+    lum = O_cv.lum_from_bgr(bgr)
+    res["pyramid"] = {"lum0": _crc(lum), "lum1": _crc(O_cv.pyr_down(lum)), "lum2": _crc(O_cv.pyr_down(O_cv.pyr_down(lum))), "depth1": _crc(O.depth_down(dep))}
     res["resize_depth"] = {"crc": _crc(O.resize_depth(dep, [78.75, 78.0, 47.5, 35.5], 160, 120, [131.0, 131.5, 80.2, 59.1]))}
     g.free(); up.free(); fr.free()
     return res
 
 
 def fusion_frames():
-    """the seeded frames of fusion_small.json: (depth, bgr, camera-to-world pose) per frame + intrinsics + voxel size"""
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "tools"))
-    from make_dataset import pose_vec_to_cam_to_world
+    """the seeded frames of fusion_small.json: (depth, bgr, camera-to-world pose) per frame + intrinsics + voxel size.  The five cameras look
+    along the coordinate axes: their rotations are signed permutations, so Matrix4f::inverse() (sparse_voxel_grid.cpp:305) is exact whatever
+    operation order Eigen uses for it — the one step of the fusion the reference run cannot pin bit for bit on a general pose."""
     import helpers
+    from intrinsic3d_amd import synthetic
     sc = helpers.small_scene(seed=21, radius_vox=11, K=5, width=96, height=72, levels=1)
     rng = np.random.default_rng(5)
+    scene, intr = sc["scene"], sc["intr"]
+    dist = float(np.linalg.norm(synthetic.aa_to_rotmat(sc["poses"][0][:3]).T @ sc["poses"][0][3:] + sc["center"]))
     frames = []
-    for fr, pose in zip(sc["frames"], sc["poses"]):
-        d = fr["depth"][0].copy(); d[d > 0] += rng.normal(0, 0.001, int((d > 0).sum())).astype(np.float32)
-        g = fr["bgr"][0][..., 0]
-        frames.append((d, np.stack([g // 2, g, 255 - g // 3], axis=-1).astype(np.uint8), pose_vec_to_cam_to_world(np.asarray(pose, np.float64)).astype(np.float32)))
+    for axis in ([1, 0, 0], [-1, 0, 0], [0, 0, 1], [0, 0, -1], [0, 1, 0]):
+        a = np.asarray(axis, np.float64)
+        eye = (sc["center"] + dist * a).astype(np.float32).astype(np.float64)
+        pose = synthetic.look_at_pose(eye, eye - a)
+        Rw2c = np.round(synthetic.aa_to_rotmat(pose[:3]))                      # exactly the signed permutation look_at_pose built
+        T = np.eye(4, dtype=np.float32); T[:3, :3] = Rw2c.T.astype(np.float32); T[:3, 3] = eye.astype(np.float32)
+        pose = np.concatenate([synthetic.rotmat_to_aa(Rw2c), -Rw2c @ eye])
+        lum, d, bgr = synthetic.render_frame(scene, pose, intr, 96, 72)
+        d = d.copy(); d[d > 0] += rng.normal(0, 0.001, int((d > 0).sum())).astype(np.float32)
+        g = bgr[..., 0]
+        frames.append((d, np.stack([g // 2, g, 255 - g // 3], axis=-1).astype(np.uint8), T))
     return frames, sc["intr"].astype(np.float32), float(sc["voxel_size"])
 
 
@@ -104,17 +124,23 @@ def compute_fusion(O):
 
 
 if __name__ == "__main__":
-    from oracle import oracle_py as O
+    from oracle import oracle_py as O, ref_py
     O.build()
-    r = compute(O)
+    if not os.path.isdir("/root/reference"):
+        raise SystemExit("make_golden: /root/reference is not present — the goldens are generated by running the reference's own code")
+    ref_py.build()
+    R = ref_py.pipeline()
+    tag = {"generator": "reference: oracle/_ref (classes compiled from /root/reference) through ref_py.pipeline()"}
+    r = dict(compute(R), **tag)
     with open(os.path.join(HERE, "optimize_small.json"), "w") as f:
         json.dump(r, f, indent=1)
     print("written", r["num_voxels"], r["rows"])
-    r2 = compute_levels(O)
+    r2 = dict(compute_levels(R, O), **tag)
+    r2["pyramid"]["generator"] = "oracle restatement of cv::cvtColor / cv::pyrDown (OpenCV is not reference code)"
     with open(os.path.join(HERE, "levels_small.json"), "w") as f:
         json.dump(r2, f, indent=1)
     print("written levels", r2["convert"], r2["upsample"]["n"])
-    r3 = compute_fusion(O)
+    r3 = dict(compute_fusion(R), **tag)
     with open(os.path.join(HERE, "fusion_small.json"), "w") as f:
         json.dump(r3, f, indent=1)
     print("written fusion", r3)

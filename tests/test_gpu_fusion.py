@@ -135,12 +135,12 @@ def test_app_fusion_then_app_intrinsic3d(oracle, tmp_path):
 
 
 def test_device_fusion_matches_committed_golden():
-    """the device path alone against tests/golden/fusion_small.json (CRCs generated from the oracle by make_golden.py): needs neither the oracle
-    nor the reference at run time"""
+    """the device path alone against tests/golden/fusion_small.json (CRCs generated by make_golden.py FROM THE REFERENCE'S OWN integrate / alloc / correctSDF code, oracle/_ref):
+    needs neither the oracle nor the reference at run time"""
     import json, zlib
     from intrinsic3d_amd import binding as B
     import golden.make_golden as mg
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fusion_small.json")))
+    gold = mg.strip_tags(json.load(open(os.path.join(ROOT, "tests", "golden", "fusion_small.json"))))
     crc = lambda a: int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
     frames, intr, vs = mg.fusion_frames()
     with B.Fusion(vs, 0.1, 10.0, initial_capacity=1 << 14) as f:

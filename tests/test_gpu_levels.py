@@ -241,12 +241,12 @@ def test_resize_depth_bit_exact(oracle):
 
 
 def test_device_level_operations_match_committed_golden():
-    """the device path alone against tests/golden/levels_small.json (CRCs of byte-exact stages, generated from the oracle by make_golden.py):
-    needs neither the oracle nor the reference at run time"""
+    """the device path alone against tests/golden/levels_small.json (CRCs of byte-exact stages, generated by make_golden.py from the REFERENCE'S OWN convert / recolour /
+    thin-shell / upsample / resizeDepth code in oracle/_ref; the OpenCV pyramid CRCs from the oracle): needs neither at run time"""
     import json, os, zlib
     from intrinsic3d_amd import binding
     import golden.make_golden as mg
-    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "levels_small.json")))
+    gold = mg.strip_tags(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "levels_small.json"))))
     crc = lambda a: int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
     sc = mg.level_scene()
     with binding.Context(0) as ctx:

@@ -1,0 +1,262 @@
+"""CPU: the restated oracle against THE REFERENCE'S OWN hot-path code, end to end.
+
+oracle/_ref compiles — besides the functors and primitives of tests/test_oracle_vs_ref.py — the reference's whole classes from /root/reference
+(oracle/extract_ref.py, round-3 chunks): Optimizer::optimize / addVoxelResiduals / buildProblem / fixVoxelParams (optimizer.cpp:92-361), NLSSolver
+(nls_solver.cpp:45-394), SDFColorization incl. collectObservations / computeObservation / add / compute (colorization.cpp:52-370), the cost-function
+factories ShadingCost / VolumetricRegularizer / SurfaceStabRegularizer / AlbedoRegularizer::create, SDFOperators::computeSurfaceNormal, SDFAlgorithms
+(convert, upsample, interpolate, clearVoxelsOutsideThinShell, correctSDF, clearInvalidVoxels; algorithms.cpp:47-458), math.cpp:43-163, Subvolumes
+(subvolumes.cpp:43-304), LightingSVSH::estimate / computeVoxelShCoeffs (lighting_svsh.cpp:54-346), SparseVoxelGrid incl. integrate / alloc
+(sparse_voxel_grid.cpp:43-467,572-602), Camera, rgbd/processing.cpp:49-301 and Intrinsic3D::refine / prepare* / finish* / recomputeColors
+(intrinsic3d.cpp:206-409).  Underneath run stand-ins for Eigen / OpenCV containers and a SECOND, independently written Ceres-2.1.0 LM + CGNR
+(oracle/ref_shim/mini_ceres_solver.hpp).  `ref_py.pipeline()` exposes all of it behind the same Python classes as the oracle, so every test
+below runs one function on both and compares.
+
+What this pins: every order- / structure-critical piece the round-2 review listed as "restated on both sides" — Eg / Er / Es / Ea row sets
+in reference order, the voxels_added edge rule, fixed flags, type weights, residuals and all 29 partials, thin shell + upsample key order and
+fields, subvolume ids + interpolated SH, recolourisation, fusion alloc / integrate / correctSDF record order, and the level schedule.
+What stays unpinned: Ceres itself (two restatements agree), Eigen's 4x4 inverse and OpenCV's pyrDown / cvtColor.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import helpers  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import ref_py
+    if os.path.isdir("/root/reference"):
+        ref_py.build()
+    if not ref_py.available():
+        pytest.skip("oracle/_ref/libref_i3d.so not built (no /root/reference on this box and no prebuilt library in the tree)")
+    return ref_py.pipeline()
+
+
+def _mangled_scene(seed, radius_vox=10, K=4, levels=1):
+    """A scene with what the review asked the row tests to cover: holes, zero-weight voxels, black voxels (NaN chroma weight), negative
+    coordinates (keys shifted by an integer vector, poses compensated) and non-zero lens distortion."""
+    sc = helpers.small_scene(seed=seed, radius_vox=radius_vox, K=K, levels=levels)
+    rng = np.random.default_rng(100 + seed)
+    n = sc["keys"].shape[0]
+    keep = rng.random(n) > 0.04                                        # holes
+    for k in ("keys", "sdf", "weight", "color"):
+        sc[k] = np.ascontiguousarray(sc[k][keep])
+    n = sc["keys"].shape[0]
+    sc["weight"][rng.random(n) < 0.03] = 0.0                           # never-observed voxels inside the shell
+    sc["color"][rng.random(n) < 0.01] = 0                              # black: chroma weight is NaN -> no Ea row (albedo_regularizer.cpp:71-72)
+    off = np.array([-(2 * radius_vox + 9), -7, -(radius_vox + 3)], np.int32)
+    sc["keys"] = np.ascontiguousarray(sc["keys"] + off)
+    from intrinsic3d_amd.synthetic import aa_to_rotmat
+    d = off.astype(np.float64) * float(sc["voxel_size"])
+    for f in range(sc["K"]):
+        sc["poses"][f, 3:] -= aa_to_rotmat(sc["poses"][f, :3]) @ d
+    sc["dist"] = np.array([0.02, -0.01, 0.003, 0.0004, -0.0003])
+    return sc
+
+
+def _setup_upsampled(M, sc, seed=3):
+    """Like helpers.oracle_setup but one level further down the schedule: coarse grid -> thin shell -> x2 upsample -> thin shell.  The upsampled
+    grid holds what a fused volume never does: zero-weight voxels INSIDE the shell (<= 4 valid corners, algorithms.cpp:163-164)."""
+    g0 = M.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+    fr = M.Frames(sc["frames"], sc["levels"])
+    g0.clear_outside_shell(2.0 * float(sc["voxel_size"]))
+    g = g0.upsample(); g0.free()
+    thres = 1.5 * float(g.voxel_size)
+    g.clear_outside_shell(thres)
+    a = g.export(); rng = np.random.default_rng(seed); n = len(g)
+    g.import_fields(sdf_refined=a["sdf_refined"] + rng.normal(0, 0.02 * float(g.voxel_size), n), albedo=0.6 + rng.normal(0, 0.02, n))
+    rc, sh, idx, vsh, has, st = M.estimate_sh(g, 0.05, 10.0, thres)
+    assert rc == 0
+    return g, fr, g.export(), vsh, thres
+
+
+def _both(O, R, sc, upsampled=False, **kw):
+    if upsampled:
+        return _setup_upsampled(O, sc), _setup_upsampled(R, sc)
+    a = helpers.oracle_setup(O, sc, **kw); b = helpers.oracle_setup(R, sc, **kw)
+    return a, b
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_row_assembly_equals_the_reference_code(oracle, R, seed):
+    """optimizer.cpp:176-361 + nls_solver.cpp:172-187,228-235,379-394 executed from the reference vs the oracle: bit for bit."""
+    O = oracle
+    sc = _mangled_scene(seed, radius_vox=7 if seed == 5 else 10)
+    if seed == 5:                                                                    # coarse level first: the rows of an UPSAMPLED grid
+        sc["voxel_size"] = np.float32(2.0 * float(sc["voxel_size"]))
+        sc["keys"] = np.ascontiguousarray(sc["keys"] // 2); _, first = np.unique(sc["keys"], axis=0, return_index=True); first.sort()
+        for k in ("keys", "sdf", "weight", "color"):
+            sc[k] = np.ascontiguousarray(sc[k][first])
+    (go, fo, ao, vsh, thres), (gr, fr, ar, vshr, _) = _both(O, R, sc, upsampled=(seed == 5))
+    for k in ("keys", "sdf", "sdf_refined", "albedo", "weight", "color"):          # convert + thin shell (+ upsample): visit order and fields
+        assert np.array_equal(ao[k], ar[k]), k
+    assert np.abs(vsh - vshr).max() < 1e-9
+    assert (ao["keys"] < 0).any() and ((ao["weight"] == 0).any() or seed != 5)
+    for it in (0, 2):
+        po = O.ProblemView(go, fo, helpers.oracle_cfg(O, thres, iterations=3), sc["intr"], sc["dist"], sc["poses"], vsh, iteration=it)
+        pr = R.ProblemView(gr, fr, helpers.oracle_cfg(R, thres, iterations=3), sc["intr"], sc["dist"], sc["poses"], vsh, iteration=it)
+        assert po.rows == pr.rows and min(po.rows) > 100, (po.rows, pr.rows)
+        vo, f_o, wo, ro, Jo = po.eg(); vr, f_r, wr, rr, Jr = pr.eg()
+        assert np.array_equal(vo, vr) and np.array_equal(f_o, f_r)                  # Eg rows: same (voxel, keyframe) SEQUENCE
+        assert np.array_equal(wo, wr), np.abs(wo - wr).max()                        # obs.weight * sdfToWeight * lambda / sum * 1000, bit-exact
+        assert np.array_equal(ro, rr) and np.array_equal(Jo, Jr)                    # residual + 29 partials (DynamicAutoDiff stride-4 passes)
+        for t in (1, 2, 3):
+            a = po.reg(t); b = pr.reg(t)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), t
+            if t == 3:
+                assert np.array_equal(a[1], b[1])                                   # Ea: the visit-order-dependent edge set (voxels_added rule)
+        flo = po.flags(); flr = pr.flags()                                          # fixVoxelParams; 2 = block not in the reference's problem
+        for k in ("fix_sdf", "fix_alb"):
+            present = flr[k] != 2
+            assert np.array_equal(flo[k][present], flr[k][present]) and present.sum() > 100
+            if k == "fix_sdf":       # an active voxel always owns its Es row; its albedo may be touched by no row at all (no Eg, ring invalid) — then
+                assert not ((~present) & (flo[k] == 0) & (flo["active"] == 1)).any()     # Ceres never sees the block and the oracle keeps a zero column
+        po.free(); pr.free()
+    for h in (go, gr, fo, fr):
+        h.free()
+
+
+def test_optimize_equals_the_reference_code_on_a_second_ceres(oracle, R):
+    """Optimizer::optimize of the reference (3 outer iterations; NLSSolver::solve -> mini-ceres) vs oracle.optimize: same accept / reject
+    sequence and PCG counts, fields to round-off — with Ceres' own PCG stop and with a pinned count; fixed poses as well."""
+    O = oracle
+    sc = _mangled_scene(6)
+    (go, fo, ao, vsh, thres), (gr, fr, _, _, _) = _both(O, R, sc)
+    for kw in (dict(cg_fixed_iterations=-1), dict(cg_fixed_iterations=5, fix_poses=1, fix_distortion=1), dict(cg_fixed_iterations=-1, lambda_a=-1.0)):
+        for g in (go, gr):
+            g.import_fields(sdf_refined=ao["sdf_refined"], albedo=ao["albedo"], color=ao["color"])
+        rc1, io, do, po, so = O.optimize(go, fo, helpers.oracle_cfg(O, thres, iterations=3, **kw), sc["intr"], sc["dist"], sc["poses"], vsh)
+        rc2, ir, dr, pr, sr = R.optimize(gr, fr, helpers.oracle_cfg(R, thres, iterations=3, **kw), sc["intr"], sc["dist"], sc["poses"], vsh)
+        assert rc1 == 0 and rc2 == 0
+        for a, b in zip(so, sr):
+            assert list(a.rows) == list(b.rows) and a.num_params == b.num_params and a.num_rows_reduced == b.num_rows_reduced
+            assert a.n_attempts == b.n_attempts and list(a.cg_iters[:a.n_attempts]) == list(b.cg_iters[:b.n_attempts])
+            assert list(a.accepted[:a.n_attempts]) == list(b.accepted[:b.n_attempts]) and a.termination == b.termination
+            assert abs(a.cost_initial - b.cost_initial) <= 1e-12 * a.cost_initial and abs(a.cost_final - b.cost_final) <= 1e-12 * a.cost_final
+            assert abs(a.final_radius - b.final_radius) <= 1e-9 * a.final_radius
+        eo = go.export(); er = gr.export()
+        moved = np.abs(eo["sdf_refined"] - ao["sdf_refined"]).max()
+        assert moved > 1e-2 * float(sc["voxel_size"])
+        assert np.abs(eo["sdf_refined"] - er["sdf_refined"]).max() <= 1e-9 * moved and np.abs(eo["albedo"] - er["albedo"]).max() <= 1e-10
+        assert np.abs(io - ir).max() <= 1e-9 * np.abs(io).max() and np.abs(do - dr).max() <= 1e-10 and np.abs(po - pr).max() <= 1e-10
+
+
+@pytest.mark.parametrize("seed", [2, 8])
+def test_level_transitions_lighting_and_recolouring_equal_the_reference_code(oracle, R, seed):
+    """recomputeColors, clearVoxelsOutsideThinShell, Subvolumes + LightingSVSH::estimate + computeVoxelShCoeffs, upsample (x2, twice):
+    key ORDER, fields, subvolume ids — bit-exact; SH coefficients to 1e-12 (two LM implementations)."""
+    sc = _mangled_scene(seed, radius_vox=9, levels=2)
+
+    def run(M):
+        g = M.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        fr = M.Frames(sc["frames"], sc["levels"]); out = {}
+        assert M.recompute_colors(g, fr, sc["intr"], sc["dist"], sc["poses"], 0.02, 5) == 0
+        out["recolour"] = g.export()
+        thres = 2.0 * float(sc["voxel_size"])
+        g.clear_outside_shell(thres); out["shell"] = g.export()
+        rng = np.random.default_rng(seed); a = out["shell"]
+        g.import_fields(albedo=0.6 + rng.normal(0, 0.02, len(g)), sdf_refined=a["sdf_refined"] + rng.normal(0, 2e-5, len(g)))
+        rc, sh, idx, vsh, has, st = M.estimate_sh(g, 0.03, 10.0, thres); assert rc == 0
+        out["sh"] = (sh, idx, vsh, has, st.data_rows, st.reg_rows, st.lm_iterations)
+        up = g.upsample(); out["up"] = up.export()
+        up.clear_outside_shell(1.5 * float(up.voxel_size)); out["up_shell"] = up.export()
+        up2 = up.upsample(); out["up2"] = up2.export()
+        for h in (g, up, up2, fr):
+            h.free()
+        return out
+
+    a = run(oracle); b = run(R)
+    for stage in ("recolour", "shell", "up", "up_shell", "up2"):
+        for k in ("keys", "sdf", "sdf_refined", "albedo", "weight", "color"):
+            assert np.array_equal(a[stage][k], b[stage][k]), (stage, k)
+    assert len(a["up2"]["keys"]) > 8 * len(a["up_shell"]["keys"]) - 1 and (a["recolour"]["color"] != sc["color"][:1]).any()
+    sa, sb = a["sh"], b["sh"]
+    assert np.array_equal(sa[1], sb[1]) and len(sa[0]) > 8                              # subvolume ids in map order
+    assert np.array_equal(sa[3], sb[3]) and sa[4:] == sb[4:]                            # in-shell mask; data rows, regulariser rows, LM iterations
+    assert np.abs(sa[0] - sb[0]).max() <= 1e-12 and np.abs(sa[2] - sb[2]).max() <= 1e-12
+
+
+def test_refine_schedule_equals_the_reference_code(oracle, R):
+    """Intrinsic3D::refine (intrinsic3d.cpp:206-290: 2 grid levels x (2, 1) pyramid levels, thin shell, SVSH, optimize, recolourise, upsample)
+    compiled from the reference vs oracle.refine."""
+    sc = helpers.small_scene(seed=5, radius_vox=8, K=4, levels=2)
+
+    def run(M):
+        g = M.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        fr = M.Frames(sc["frames"], sc["levels"])
+        rc, intr, dist, poses, done = M.refine(g, fr, helpers.oracle_cfg(M, 0.0, iterations=2), 2, 2, 2.0, 1.0, 1, 0.03, 10.0, sc["intr"], sc["dist"], sc["poses"])
+        e = g.export(); g.free(); fr.free()
+        o = np.lexsort(e["keys"].T[::-1])                                               # the reference hands its last grid to a callback: compare by key
+        return rc, intr, dist, poses, done, {k: (v[o] if getattr(v, "shape", ())[:1] == e["keys"].shape[:1] else v) for k, v in e.items()}
+
+    a = run(oracle); b = run(R)
+    assert a[0] == 0 and b[0] == 0 and a[4] == b[4] == 3
+    ea, eb = a[5], b[5]
+    for k in ("keys", "sdf", "weight", "color"):
+        assert np.array_equal(ea[k], eb[k]), k
+    assert np.abs(ea["sdf_refined"] - eb["sdf_refined"]).max() <= 1e-10 and np.abs(ea["albedo"] - eb["albedo"]).max() <= 1e-9
+    assert np.abs(a[1] - b[1]).max() <= 1e-8 and np.abs(a[2] - b[2]).max() <= 1e-8 and np.abs(a[3] - b[3]).max() <= 1e-9
+    assert np.abs(ea["sdf_refined"] - ea["sdf"]).max() > 1e-3 * float(ea["voxel_size"])
+
+
+def _fusion_frames(seed, exact):
+    from intrinsic3d_amd import synthetic
+    from make_dataset import pose_vec_to_cam_to_world
+    sc = synthetic.make_scene(radius_vox=10, K=4, width=96, height=72, levels=1, seed=seed)
+    rng = np.random.default_rng(seed); frames = []
+    rots = [np.eye(3), np.array([[0., -1, 0], [1, 0, 0], [0, 0, 1]]), np.array([[1., 0, 0], [0, 0, -1], [0, 1, 0]]), np.array([[0., 0, 1], [0, 1, 0], [-1, 0, 0]])]
+    for i, (fr, pose) in enumerate(zip(sc["frames"], sc["poses"])):
+        d = fr["depth"][0].copy(); d[d > 0] += rng.normal(0, 0.0015, int((d > 0).sum())).astype(np.float32)
+        bgr = fr["bgr"][0].copy(); bgr[..., 0] //= 2
+        T = pose_vec_to_cam_to_world(np.asarray(pose, np.float64)).astype(np.float32)
+        if exact:      # quarter-turn rotations and dyadic translations: Matrix4f::inverse() is exact whatever its operation order
+            T = T.copy(); T[:3, :3] = rots[i % 4].astype(np.float32); T[:3, 3] = np.round(T[:3, 3] * 64) / 64
+        frames.append((d, bgr, T))
+    return sc, frames
+
+
+def test_fusion_equals_the_reference_code(oracle, R):
+    """SparseVoxelGrid<Voxel>::alloc / integrate, correctSDF, clearInvalidVoxels (sparse_voxel_grid.cpp:301-467, algorithms.cpp:260-366) from the
+    reference vs the oracle: record ORDER, sdf, weights, colours bit-exact for poses whose inverse is exact; general poses to 1e-6 (Eigen's 4x4 inverse
+    is unpinned)."""
+    for exact in (True, False):
+        sc, frames = _fusion_frames(9, exact)
+        intr = sc["intr"].astype(np.float32); cintr = intr * np.float32(0.5)
+        out = []
+        for M in (oracle, R):
+            f = M.Fusion(sc["voxel_size"], 0.1, 10.0)
+            for d, bgr, T in frames:
+                f.integrate(d, intr, bgr[::2, ::2].copy(), cintr, T, 2)             # colour camera != depth camera
+            raw = f.export(); f.finish(10); out.append((raw, f.export()))
+        (raw_o, fin_o), (raw_r, fin_r) = out
+        assert len(raw_o["sdf"]) > 3000 and len(fin_o["sdf"]) < len(raw_o["sdf"])
+        for stage, (x, y) in enumerate(((raw_o, raw_r), (fin_o, fin_r))):
+            assert np.array_equal(x["keys"], y["keys"])                                 # first-insertion order -> map order -> file order
+            if exact:
+                for k in ("sdf", "weight", "color"):
+                    assert np.array_equal(x[k], y[k]), k
+            else:    # last-bit differences of the inverted pose; after correctSDF they can flip a '<' between near-equal candidates (2 % allowed)
+                assert np.abs(x["weight"] - y["weight"]).max() <= 1e-4 and (np.abs(x["sdf"] - y["sdf"]) > 1e-6).mean() < (0.02 if stage else 0.002)
+
+
+def test_small_helpers_equal_the_reference_code(oracle, R):
+    """poseVecAAToMat (math.cpp:151-163), erodeDiscontinuities / computeNormals / resizeDepth (processing.cpp:49-232), Pyramid::downsampleDepth."""
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        p = np.concatenate([rng.normal(0, 1.0, 3) * rng.choice([1e-9, 0.3, 2.0]), rng.normal(0, 1, 3)])
+        Ro, to = oracle.pose_to_mat(p); Rr, tr = R.pose_to_mat(p)
+        assert np.array_equal(Ro, Rr) and np.array_equal(to, tr)
+    d = (1.0 + 0.3 * rng.random((60, 80))).astype(np.float32); d[rng.random(d.shape) < 0.1] = 0; d[20:30, 30:50] += 0.8
+    assert np.array_equal(oracle.erode_discontinuities(d, 2, 0.5), R.erode_discontinuities(d, 2, 0.5))
+    cam = np.array([90.0, 91.0, 39.5, 29.5], np.float32)
+    assert np.array_equal(oracle.compute_normals(d, cam, 0.3), R.compute_normals(d, cam, 0.3))
+    assert np.array_equal(oracle.depth_down(d), R.depth_down(d))
+    out_cam = np.array([130.0, 131.0, 63.5, 47.5], np.float32)
+    assert np.array_equal(oracle.resize_depth(d, cam, 128, 96, out_cam), R.resize_depth(d, cam, 128, 96, out_cam))
