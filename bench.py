@@ -183,7 +183,30 @@ def pmc_traffic(kernel, eg_rows, active):
     return best
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves — one process per GPU through
+    torch.distributed.run on 127.0.0.1 — and pass rank 0's JSON line through.  Never silently fewer ranks than asked for."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} visible devices, this box has {have}; refusing to run fewer ranks than asked for", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
+    if "WORLD_SIZE" not in os.environ:
+        pre = argparse.ArgumentParser(add_help=False); pre.add_argument("--gpus", type=int, default=1)
+        n = pre.parse_known_args()[0].gpus
+        if n > 1:
+            sys.exit(spawn_ranks(n))
     # stdout carries exactly ONE line (the JSON): anything native libraries print on fd 1 meanwhile (RCCL prints a version banner when a
     # communicator is created, partly buffered until exit) goes to stderr; the JSON line is written to the saved descriptor
     sys.stdout.flush()
@@ -203,8 +226,11 @@ RESULT_FD = [1]
 def _main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        args.gpus = world
+    if args.gpus != world:
+        if world > 1:
+            args.gpus = world                 # the launcher's world size wins (the driver passes both, consistently)
+        elif args.gpus > 1:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} under a launcher that set WORLD_SIZE=1; refusing to report a 1-rank run as {args.gpus} GPUs")
 
     def log(msg):
         if rank == 0:
