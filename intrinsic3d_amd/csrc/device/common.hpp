@@ -142,6 +142,7 @@ struct PcgState {
 struct OptParams {                  // scalar state of one outer iteration
     double thres_shell; double lambda_a;
     double type_w[4];               // lambda_t / sum_t * 1000
+    float type_wf[4];               // the same in float: kernel arguments are scalar registers, (float)type_w[t] would be a VALU result = a VGPR
     int K; int level; double pyr_scale; float occlusion; int use_er, use_es, use_ea;
     double intr[4]; double dist[5];  // level-0 intrinsics, distortion
     float cam_f[4]; float dist_f[5]; int dist_zero; int w, h;   // float camera of the observation pass (scaled)

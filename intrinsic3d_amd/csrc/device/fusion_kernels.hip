@@ -37,7 +37,7 @@ __device__ inline long long find_slot(const FusionTable& t, unsigned long long k
 }
 __device__ inline int round_trunc(float v) { return (int)(v + 0.5f); }                                   // mat.h:90
 // pose.topLeftCorner<3,3>() * p + pose.topRightCorner<3,1>() (sparse_voxel_grid.cpp:328,425,584): a fixed-size Eigen product, every coefficient
-// the halving reduction a0 + (a1 + a2) — pinned against the reference's own integrate / alloc in oracle/_ref (tests/test_ref_pipeline.py)
+// the halving reduction a0 + (a1 + a2) (Eigen Core/Redux.h; the tests hold this against the reference's own integrate / alloc code)
 __device__ inline void xform(const float* T, float px, float py, float pz, float q[3]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) q[i] = (T[4 * i] * px + (T[4 * i + 1] * py + T[4 * i + 2] * pz)) + T[4 * i + 3];

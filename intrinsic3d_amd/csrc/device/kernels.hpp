@@ -85,6 +85,7 @@ struct TilePlan {                   // built once per outer iteration by launch_
     int* halo_idx; int* halo_cnt;   // [tiles][HMAX] foreign entries a tile's stencils reach (sorted, INT_MAX padded), [tiles] their number
     int* iota; int* ext_e; int* ext_pos;   // [tiles * HMAX] (entry, halo slot) pairs sorted by entry
     float* qh;                      // [tiles * HMAX][2] halo accumulators of one pass
+    int* ext_off;                   // [chunk + 1] CSR offsets of the sorted pairs by entry (k_pcg_step3 folds the halo sums itself), or null
     int* overflow;                  // device flag: a halo did not fit -> use the untiled pass
     int tile_first, ntiles_own;     // tiles this rank owns (all of them when not sharded)
     const int* ghost_tiles; int n_ghost;   // sharded: foreign tiles that hold ghost entries of this rank's compute list
@@ -96,8 +97,30 @@ size_t tile_plan_temp_bytes(int ntiles);
 hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, size_t temp_bytes);
 void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t, const int* cflag /* sharded: compute-list flags, else null */);   // after launch_build (reads the Ea weights it wrote)
 // qacc[2 chunk] = J^T W J u on the voxel unknowns (raw), camera block added into `shared` (fp64), row-wise p.q partials; returns their number
+// cam_partials != null: the camera block is NOT added into `shared`; workgroup w stores its float sums in cam_partials[w * cam_stride + 0..6K+9)
 int  launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials /* or null */,
-                    const PcgState* state);
+                    const PcgState* state, float* cam_partials = nullptr, int cam_stride = 0);
+void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext_off);
+
+// ---- pcg_fused.hip: the PCG iteration in three launches (single rank): k_pcg_dir3 | k_eg_tile | k_pcg_step3 -----------------------
+struct Step3Args {
+    int nq; int chunk4;
+    const float4* p; const float4* qacc; float4* x; float4* r; const float4* b; const float4* D2; const float4* Minv; float4* z; const float4* S;
+    const int* ext_off; const int* ext_pos; const float2* qh; int e0;
+    const double* pq_partials; int n_pq; const double* d2_partials; int n_d2;
+    int n_slice_wg;
+    int K; int fix_poses, fix_intr, fix_dist;
+    const float* cam_partials; int n_cam; int cam_stride; const float* Mblk;
+    const float* tp; float* tx; float* tr; const float* tb; const float* tD2; float* tz; const float* tS;
+    double* step_partials;
+    PcgState* cur;
+};
+void launch_pcg_init3(hipStream_t st, PcgState* st2 /* [2] */, int fixed_iterations, int max_iterations);
+int  launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2,
+                     const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq);   // returns #d2 partials
+int  pcg_step3_slice_wgs(int n_entries);
+int  pcg_step3_tail_wgs(int K);
+int  launch_pcg_step3(hipStream_t st, int mode /* 0 init | 1 normal | 2 x only | 3 reset */, Step3Args a);                                          // returns #[4]-partials
 void launch_halo_fold(hipStream_t st, RowView r, TilePlan t, float* qacc, const PcgState* state);
 
 // ---- shard_kernels.hip: the sharding plan of one outer iteration ----------------------------------------------------------------

@@ -1,0 +1,284 @@
+// The PCG iteration in THREE launches (single rank; conjugate_gradients_solver.cc of Ceres 2.1.0 as driven by nls_solver.cpp:296-337):
+//
+//     k_pcg_dir3  ->  k_eg_tile  ->  k_pcg_step3
+//
+// Round 2 ran six (tail_a | direction | eg_tile | halo_fold | tail_b | step): the two single-workgroup boundary kernels and the halo fold
+// cost 82 us of a 410 us pass for 0.3 GB of traffic.  Here every grid-wide reduction is finished REDUNDANTLY in the prologue of the kernel
+// that needs its result — each workgroup adds up the same few thousand per-workgroup partial sums in the same fixed order, so all of them
+// hold bit-identical scalars without a launch or an in-kernel barrier:
+//   * k_pcg_dir3  : [r.z, x.(b+r), x.r, sum D^2 x^2] of the iteration just finished -> Ceres' quadratic-model stop test, rho, beta (workgroup 0
+//                   also records them and publishes (pass, done) to the host); then p = z + beta p, u = S p, partial sums of D^2 p^2;
+//   * k_eg_tile   : q_acc = J^T W J u (tile_pass.hip), p.q row by row; the camera block leaves as one float partial per workgroup (no atomics);
+//   * k_pcg_step3 : p.q = rows + D^2 p^2 -> alpha; folds the tiles' halo sums into the accumulators (the former k_halo_fold: pairs sorted by
+//                   entry, CSR offsets from the plan), x += alpha p, q = S acc + D^2 p, r -= alpha q, z = M^-1 r and the four partial sums; a
+//                   handful of extra workgroups do the same for the 6K+9 camera unknowns: column sums of the camera partials in a fixed
+//                   order, block-Jacobi z with the 6x6 / 4x4 / 5x5 inverses.
+// The scalar state is double-buffered by pass parity (a kernel never writes the PcgState it reads), so there is no same-kernel race on it.
+// Everything here is deterministic: no floating-point atomics, fixed summation orders.
+#include "kernels.hpp"
+#include "reduce_device.hpp"
+
+namespace i3d {
+
+constexpr int PF_THREADS = 512;
+constexpr int PF_MAX_WG = 1024;            // slice workgroups of dir3 / step3 (grid-stride beyond)
+constexpr int PF_POSES_PER_WG = 10;        // camera tail: poses handled by one tail workgroup of k_pcg_step3
+
+// sum of nblk partial [NC]-tuples, identical (bit for bit) in every workgroup of PF_THREADS threads that calls it
+template <int NC>
+static __device__ inline void reduce_partials_all(const double* __restrict__ P, int nblk, double (&tot)[NC], double* sm /* [NC * 8] */) {
+    double v[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) v[k] = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += PF_THREADS) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) v[k] += P[(size_t)i * NC + k];
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) sm[k * 8 + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { double t = 0.0; for (int w = 0; w < PF_THREADS / 64; ++w) t += sm[k * 8 + w]; tot[k] = t; }
+    __syncthreads();
+}
+
+__global__ void k_pcg_init3(PcgState* st2, int fixed_iterations, int max_iterations) {
+    for (int b = 0; b < 2; ++b) {
+        PcgState* st = st2 + b;
+        for (int k = 0; k < 4; ++k) st->acc[k] = 0.0;
+        st->rho = 0.0; st->last_rho = 1.0; st->pq = 0.0; st->alpha = 0.0; st->beta = 0.0; st->xbr = 0.0; st->xr = 0.0; st->d2xx = 0.0;
+        st->Q0 = 0.0; st->Q1 = 0.0; st->it = 0; st->done = (fixed_iterations == 0) ? 1 : 0; st->fixed_iterations = fixed_iterations; st->max_iterations = max_iterations;
+    }
+}
+void launch_pcg_init3(hipStream_t st, PcgState* st2, int fixed_iterations, int max_iterations) { k_pcg_init3<<<1, 1, 0, st>>>(st2, fixed_iterations, max_iterations); }
+
+// iteration boundary + direction.  `prev` was written by the previous boundary, `next` is read by the operator / step kernels of this pass
+__global__ void __launch_bounds__(PF_THREADS) k_pcg_dir3(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
+                                                        const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ D2,
+                                                        const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
+                                                        const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq) {
+    __shared__ double sm[4 * 8];
+    // (seq, done) goes to a 2-slot ring in pinned host memory: the host polls it one pass behind
+    auto publish = [&](int done) { if (host_flags) { __hip_atomic_store(&host_flags[2 * (seq & 1) + 1], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                                     __hip_atomic_store(&host_flags[2 * (seq & 1)], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); } };
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    if (prev->done) { if (writer) { *next = *prev; publish(prev->done); } return; }
+    double tot[4];
+    reduce_partials_all<4>(step_partials, n_step, tot, sm);
+    int it = prev->it, done = 0; bool stop = false;
+    double Q0 = prev->Q0, Q1 = prev->Q1, xbr = prev->xbr, xr = prev->xr, d2xx = prev->d2xx;
+    if (!init) {                                                     // end of iteration it: quadratic-model termination (eta = 0.1)
+        xbr = tot[1]; xr = tot[2]; d2xx = tot[3];
+        it = it + 1;
+        Q1 = -tot[1];
+        if (prev->fixed_iterations >= 0) { Q0 = Q1; if (it >= prev->fixed_iterations) { done = 1; stop = true; } }
+        else {
+            const double zeta = (double)it * (Q1 - Q0) / Q1;
+            if (zeta < 0.1) { done = 1; stop = true; }
+            else { Q0 = Q1; if (it >= prev->max_iterations) { done = 1; stop = true; } }
+        }
+    }
+    double rho = prev->rho, last_rho = prev->last_rho, beta = prev->beta;
+    if (!stop) {                                                     // start of the next iteration: rho = r.z, beta
+        const double rho_new = tot[0];
+        if (rho_new == 0.0 || isinf(rho_new) || isnan(rho_new)) { done = 2; stop = true; }
+        else {
+            if (it > 0) { const double bt = rho_new / prev->rho; if (bt == 0.0 || isinf(bt) || isnan(bt)) { done = 2; stop = true; } else beta = bt; }
+            else beta = 0.0;
+            if (!stop) { last_rho = prev->rho; rho = rho_new; }
+        }
+    }
+    if (writer) {
+        PcgState s = *prev;
+        s.rho = rho; s.last_rho = last_rho; s.beta = beta; s.xbr = xbr; s.xr = xr; s.d2xx = d2xx; s.Q0 = Q0; s.Q1 = Q1; s.it = it; s.done = done; s.pq = 0.0;
+        *next = s;
+        publish(done);
+    }
+    if (stop) return;
+    const float betaf = (float)beta; const bool first = it == 0;
+    const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* S4 = reinterpret_cast<const float4*>(S); float4* u4 = reinterpret_cast<float4*>(u);
+    const float4* D4 = reinterpret_cast<const float4*>(D2);
+    double d2 = 0.0;
+    for (int j = blockIdx.x * PF_THREADS + threadIdx.x; j < 2 * n4; j += gridDim.x * PF_THREADS) {
+        const int i = j < n4 ? j : j - n4 + seg4;
+        float4 pi = z4[i];
+        if (!first) { const float4 po = p4[i]; pi.x += betaf * po.x; pi.y += betaf * po.y; pi.z += betaf * po.z; pi.w += betaf * po.w; }
+        p4[i] = pi;
+        const float4 sv = S4[i];
+        u4[i] = make_float4(sv.x * pi.x, sv.y * pi.y, sv.z * pi.z, sv.w * pi.w);
+        const float4 dd = D4[i];
+        d2 += (double)dd.x * (double)pi.x * (double)pi.x + (double)dd.y * (double)pi.y * (double)pi.y + (double)dd.z * (double)pi.z * (double)pi.z + (double)dd.w * (double)pi.w * (double)pi.w;
+    }
+    if (blockIdx.x == gridDim.x - 1) {                               // the camera tail (6K+9 unknowns) rides with the last workgroup
+        for (int t = threadIdx.x; t < ntail; t += PF_THREADS) {
+            const size_t i = tail_rel + t;
+            const float pi = first ? z[i] : z[i] + betaf * p[i]; p[i] = pi; u[i] = S[i] * pi;
+            d2 += (double)D2[i] * (double)pi * (double)pi;
+        }
+    }
+    block_partial_d(d2, d2_partials, 1, 0);
+}
+
+int launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2,
+                    const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq) {
+    const int n4 = sg.n >> 2, seg4 = (int)((sg.off1 - sg.off0) >> 2);
+    int blocks = (2 * n4 + PF_THREADS - 1) / PF_THREADS; blocks = blocks < 1 ? 1 : (blocks > PF_MAX_WG ? PF_MAX_WG : blocks);
+    const size_t o = sg.off0;
+    k_pcg_dir3<<<blocks, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, step_partials, n_step, d2_partials, prev, next, host_flags, seq);
+    return blocks;
+}
+
+enum { S3_INIT = 0, S3_NORMAL = 1, S3_XONLY = 2, S3_RESET = 3 };
+
+
+template <int MODE>
+__global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
+    __shared__ double sm[4 * 8];
+    __shared__ double camv[64];
+    __shared__ double camred[8][64];
+    __shared__ float rs[64];
+    PcgState* const cur = a.cur;
+    if (cur->done) return;
+    float alpha = 0.0f;
+    if (MODE == S3_NORMAL || MODE == S3_XONLY) {                     // p.q = sum over rows of t (J u) + sum D^2 p^2  ->  alpha = rho / p.q
+        double t1[1], t2[1];
+        reduce_partials_all<1>(a.pq_partials, a.n_pq, t1, sm);
+        reduce_partials_all<1>(a.d2_partials, a.n_d2, t2, sm);
+        const double pq = t1[0] + t2[0];
+        const double al = cur->rho / pq;
+        const bool bad = !(pq > 0.0) || isinf(pq) || isinf(al);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { cur->pq = pq; if (bad) cur->done = 2; else cur->alpha = al; }      // (no kernel reads pq / alpha from the state; done = 2 only makes everyone return)
+        if (bad) return;
+        alpha = (float)al;
+    }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if ((int)blockIdx.x < a.n_slice_wg) {
+        for (int q = blockIdx.x * PF_THREADS + threadIdx.x; q < a.nq; q += a.n_slice_wg * PF_THREADS) {
+            float accv[2][4];
+            if (MODE == S3_NORMAL || MODE == S3_RESET) {
+                const float4 as = a.qacc[q], aa = a.qacc[q + a.chunk4];
+                accv[0][0] = as.x; accv[0][1] = as.y; accv[0][2] = as.z; accv[0][3] = as.w; accv[1][0] = aa.x; accv[1][1] = aa.y; accv[1][2] = aa.z; accv[1][3] = aa.w;
+                const int e = a.e0 + 4 * q;
+                const int4 o = *reinterpret_cast<const int4*>(a.ext_off + e);                 // (e is a multiple of 4: slices start at multiples of 1024)
+                const int o4 = a.ext_off[e + 4];
+                const int ob[5] = {o.x, o.y, o.z, o.w, o4};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) for (int j = ob[k]; j < ob[k + 1]; ++j) { const float2 v = a.qh[a.ext_pos[j]]; accv[0][k] += v.x; accv[1][k] += v.y; }
+            }
+#pragma unroll
+            for (int seg = 0; seg < 2; ++seg) {
+                const int i = q + seg * a.chunk4;
+                float xv[4], rv[4];
+                if (MODE == S3_INIT) { const float4 t = a.r[i]; rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
+                else {
+                    const float4 xo = a.x[i];
+                    xv[0] = xo.x; xv[1] = xo.y; xv[2] = xo.z; xv[3] = xo.w;
+                    float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (MODE != S3_RESET) {
+                        const float4 pp = a.p[i]; pv[0] = pp.x; pv[1] = pp.y; pv[2] = pp.z; pv[3] = pp.w;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xv[k] += alpha * pv[k];
+                        a.x[i] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+                    }
+                    if (MODE == S3_XONLY) continue;
+                    const float4 bb = a.b[i], dd = a.D2[i], sv = a.S[i];
+                    const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w}, svv[4] = {sv.x, sv.y, sv.z, sv.w};
+                    float qq[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) qq[k] = svv[k] * accv[seg][k] + dv[k] * (MODE == S3_NORMAL ? pv[k] : xv[k]);      // q = S acc + D^2 v
+                    if (MODE == S3_NORMAL) { const float4 ro = a.r[i]; rv[0] = ro.x - alpha * qq[0]; rv[1] = ro.y - alpha * qq[1]; rv[2] = ro.z - alpha * qq[2]; rv[3] = ro.w - alpha * qq[3]; }
+                    else { rv[0] = bv[0] - qq[0]; rv[1] = bv[1] - qq[1]; rv[2] = bv[2] - qq[2]; rv[3] = bv[3] - qq[3]; }           // RESET: r = b - A x
+                    a.r[i] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const double xd = xv[k]; s1 += xd * ((double)bv[k] + (double)rv[k]); s2 += xd * (double)rv[k]; s3 += (double)dv[k] * xd * xd; }
+                }
+                const float4 mm = a.Minv[i];
+                const float zv[4] = {mm.x * rv[0], mm.y * rv[1], mm.z * rv[2], mm.w * rv[3]};
+                a.z[i] = make_float4(zv[0], zv[1], zv[2], zv[3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s0 += (double)rv[k] * (double)zv[k];
+            }
+        }
+    } else {
+        // ---- camera tail: PF_POSES_PER_WG poses per workgroup, the last tail workgroup takes intrinsics (4) + distortion (5) ----
+        const int K = a.K, tw = (int)blockIdx.x - a.n_slice_wg, n_pose_wg = (K + PF_POSES_PER_WG - 1) / PF_POSES_PER_WG;
+        int col0, ncol;
+        if (tw < n_pose_wg) { col0 = 6 * PF_POSES_PER_WG * tw; const int c1 = min(6 * K, col0 + 6 * PF_POSES_PER_WG); ncol = c1 - col0; }
+        else { col0 = 6 * K; ncol = 9; }
+        const int t = threadIdx.x;
+        if (MODE == S3_NORMAL || MODE == S3_RESET) {                 // column sums of the operator's camera partials (one float row per workgroup), fixed order
+            const int g = t / 64, c = t % 64;                        // 8 row groups x 64 columns
+            double v = 0.0;
+            if (c < ncol) for (int w = g; w < a.n_cam; w += 8) v += (double)a.cam_partials[(size_t)w * a.cam_stride + col0 + c];
+            camred[g][c] = v;
+            __syncthreads();
+            if (t < ncol) { double s = 0.0; for (int gg = 0; gg < 8; ++gg) s += camred[gg][t]; camv[t] = s; }
+            __syncthreads();
+        }
+        if (t < ncol) {
+            const int i = col0 + t;
+            const bool fixed = i < 6 * K ? a.fix_poses : (i < 6 * K + 4 ? a.fix_intr : a.fix_dist);
+            float ri;
+            if (MODE == S3_INIT) ri = a.tr[i];
+            else {
+                float xi = a.tx[i];
+                if (MODE != S3_RESET) { xi += alpha * a.tp[i]; a.tx[i] = xi; }
+                if (MODE == S3_XONLY) ri = 0.0f;
+                else {
+                    const float vv = MODE == S3_NORMAL ? a.tp[i] : xi;
+                    const float qi = a.tS[i] * (fixed ? 0.0f : (float)camv[t]) + a.tD2[i] * vv;
+                    ri = MODE == S3_NORMAL ? a.tr[i] - alpha * qi : a.tb[i] - qi;
+                    a.tr[i] = ri;
+                    const double xd = xi; s1 += xd * ((double)a.tb[i] + (double)ri); s2 += xd * (double)ri; s3 += (double)a.tD2[i] * xd * xd;
+                }
+            }
+            rs[t] = ri;
+        }
+        if (MODE == S3_XONLY) return;
+        __syncthreads();                                             // the block preconditioner mixes the entries of a parameter block
+        if (t < ncol) {
+            const int i = col0 + t;
+            int base, n, row; const float* M;
+            if (i < 6 * K) { const int f = i / 6; base = 6 * f; n = 6; row = i - base; M = a.Mblk + 36 * f; }
+            else if (i < 6 * K + 4) { base = 6 * K; n = 4; row = i - base; M = a.Mblk + 36 * K; }
+            else { base = 6 * K + 4; n = 5; row = i - base; M = a.Mblk + 36 * K + 16; }
+            float s = 0.0f;
+            for (int j = 0; j < n; ++j) s += M[row * n + j] * rs[base - col0 + j];
+            a.tz[i] = s; s0 += (double)rs[t] * (double)s;
+        }
+    }
+    if (MODE == S3_XONLY) return;
+    block_partial_d(s0, a.step_partials, 4, 0); block_partial_d(s1, a.step_partials, 4, 1); block_partial_d(s2, a.step_partials, 4, 2); block_partial_d(s3, a.step_partials, 4, 3);
+}
+
+int pcg_step3_slice_wgs(int n_entries) { int b = (n_entries / 4 + PF_THREADS - 1) / PF_THREADS; return b < 1 ? 1 : (b > PF_MAX_WG ? PF_MAX_WG : b); }
+int pcg_step3_tail_wgs(int K) { return (K + PF_POSES_PER_WG - 1) / PF_POSES_PER_WG + 1; }
+
+// returns the number of [4]-partials written (0 in XONLY mode)
+int launch_pcg_step3(hipStream_t st, int mode, Step3Args a) {
+    const int blocks = a.n_slice_wg + pcg_step3_tail_wgs(a.K);
+    switch (mode) {
+        case S3_INIT:   k_pcg_step3<S3_INIT><<<blocks, PF_THREADS, 0, st>>>(a); break;
+        case S3_NORMAL: k_pcg_step3<S3_NORMAL><<<blocks, PF_THREADS, 0, st>>>(a); break;
+        case S3_XONLY:  k_pcg_step3<S3_XONLY><<<blocks, PF_THREADS, 0, st>>>(a); break;
+        default:        k_pcg_step3<S3_RESET><<<blocks, PF_THREADS, 0, st>>>(a); break;
+    }
+    return mode == S3_XONLY ? 0 : blocks;
+}
+
+// plan side of the fold: ext_off[e] = index of the first (entry, halo slot) pair whose entry is >= e, e in [0, A]
+__global__ void k_ext_offsets(int n, const int* __restrict__ ext_e, int A, int* __restrict__ ext_off) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    const int cur = j < n ? min(ext_e[j], A) : A;
+    const int prev = j > 0 ? min(ext_e[j - 1], A) : -1;
+    for (int e = prev + 1; e <= cur; ++e) ext_off[e] = j;
+}
+void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext_off) { k_ext_offsets<<<(n + 1 + 255) / 256, 256, 0, st>>>(n, ext_e, A, ext_off); }
+
+}  // namespace i3d

@@ -126,8 +126,10 @@ template <int NW> static __device__ inline int unpack16(const unsigned (&w)[NW],
 // wave_accumulate (wave_ops.hpp) on the kernel's own LDS array by integer offset.  wave_off is wave-uniform (a scalar register); the
 // per-lane replica offset of the rare fallback is recomputed there, and lanes are tracked by a flag instead of a 64-bit lane mask: nothing
 // of this helper lives in vector registers across the row loop.
-template <int NV>
-static __device__ inline void wave_accumulate_lds(bool valid, int f, const float (&val)[NV], float* lds, int reps, int rs, int wave_off, int stride) {
+// `val(i)` yields component i of this lane's contribution ON DEMAND and every wave sum is added to LDS at once: neither the NV values nor the
+// NV sums are live together (the row loop has no register to spare: 128 per lane, and a spill reload there is a vmcnt(0) that drains the row stream)
+template <int NV, class F>
+static __device__ inline void wave_accumulate_lds(bool valid, int f, F val, float* lds, int reps, int rs, int wave_off, int stride) {
     bool pending = valid;
     unsigned long long todo = __ballot(pending);
     for (int round = 0; todo != 0ull; ++round) {
@@ -135,65 +137,33 @@ static __device__ inline void wave_accumulate_lds(bool valid, int f, const float
             if (pending) {
                 const int lane_off = (threadIdx.x & (reps - 1)) * rs;
 #pragma unroll
-                for (int i = 0; i < NV; ++i) lds_add(&lds[lane_off + stride * f + i], val[i]);
+                for (int i = 0; i < NV; ++i) lds_add(&lds[lane_off + stride * f + i], val(i));
             }
             break;
         }
         const int leader = __ffsll((long long)todo) - 1;
         const int f0 = __builtin_amdgcn_readlane(f, leader);
         const bool mine = pending && f == f0;
-        float sum[NV];
+        const bool lead = (int)(threadIdx.x & 63) == leader;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) sum[i] = wave_sum(mine ? val[i] : 0.0f);
-        if ((int)(threadIdx.x & 63) == leader) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) lds_add(&lds[wave_off + stride * f0 + i], sum[i]);
-        }
+        for (int i = 0; i < NV; ++i) { const float sum = wave_sum(mine ? val(i) : 0.0f); if (lead) lds_add(&lds[wave_off + stride * f0 + i], sum); }
         pending = pending && !mine;
         todo = __ballot(pending);
     }
 }
 
-// T lanes = T entries per tile.  SLOTS > 0: the row loop is unrolled for exactly that many observation slots and EVERY slot is requested
-// (unused slots of a voxel are skipped per lane): straight-line code whose s_waitcnt the compiler can count exactly — with a run-time
-// trip count and conditional refills it falls back to vmcnt(0) at the loop header, which drains the block meant to stay in flight.
-// LDS float atomics cost ~70 cycles per wave instruction on gfx950 (measured: 14 ds_add_f32 per row doubled the kernel time), so the
-// J^T accumulation inside the tile is a PULL from lane-private column sums staged in LDS; only what lands in the halo is pushed.
-// wave_accumulate (wave_ops.hpp) on the kernel's own LDS array by integer offset
-template <int NV>
-static __device__ inline void wave_accumulate_lds(bool valid, int f, const float (&val)[NV], float* lds, int lane_off, int wave_off, int stride) {
-    unsigned long long todo = __ballot(valid);
-    const int lane = threadIdx.x & 63;
-    for (int round = 0; todo != 0ull; ++round) {
-        if (round == 3) {                                   // > 3 distinct keyframes in this slot of the wave
-            if (valid && ((todo >> lane) & 1ull)) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) lds_add(&lds[lane_off + stride * f + i], val[i]);
-            }
-            break;
-        }
-        const int leader = __ffsll((long long)todo) - 1;
-        const int f0 = __builtin_amdgcn_readlane(f, leader);
-        const bool mine = valid && f == f0;
-        float sum[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) sum[i] = wave_sum(mine ? val[i] : 0.0f);
-        if (lane == leader) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) lds_add(&lds[wave_off + stride * f0 + i], sum[i]);
-        }
-        todo &= ~__ballot(mine);
-    }
-}
-
 // GHOSTS: the tile list continues with foreign tiles that hold this rank's ghost entries (sharded runs).  A template parameter because the
 // extra wave-uniform test costs the unrolled row loop registers: 12 instead of 4 spilled, 363 instead of 344 us on the single-GPU bench.
-template <int T, int HMAX, int SLOTS, bool GHOSTS>
-__global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowView r, OptParams p, const float* __restrict__ u, const unsigned* __restrict__ lnbr,
+// PIPE: software pipelining across the tiles of a (persistent) workgroup — the loads of the NEXT tile (its operator input, flags, local slots, halo gathers
+// and its first two row blocks) are issued right after the last row of the current tile, BEFORE the barrier / pull / store phase, so the memory
+// pipe keeps streaming while the workgroup works in LDS (round 2: 0.324 ms against 0.235 ms for the bare row stream; the difference was this phase).
+template <int T, int HMAX, int SLOTS, bool GHOSTS, int PIPE /* 0 off | 1 operator input, flags, slots, halo gathers | 2 + the first row block */>
+__global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const float* __restrict__ u, const unsigned* __restrict__ lnbr,
                                                         const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx, const int* __restrict__ halo_cnt,
                                                         double* __restrict__ shared, float* __restrict__ qacc, float* __restrict__ qh, double* __restrict__ pq_partials,
                                                         int reps, int tiles_per_block, int tile_first, int n_own /* tiles [tile_first, +n_own): this rank's own */,
-                                                        const int* __restrict__ ghost_list /* then ntl - n_own foreign tiles holding ghost entries */, int ntl, const PcgState* __restrict__ state) {
+                                                        const int* __restrict__ ghost_list /* then ntl - n_own foreign tiles holding ghost entries */, int ntl, const PcgState* __restrict__ state,
+                                                        float* __restrict__ cam_partials /* or null: [gridDim.x][cam_stride] camera block of this workgroup (no atomics) */, int cam_stride) {
     if (state && state->done) return;
     constexpr int ZSLOT = T + HMAX, NSLOT = ZSLOT + 1;
     extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T]
@@ -219,45 +189,68 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
     float cam9[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
-    const float tw0 = (float)p.type_w[0], tw1 = (float)p.type_w[1], tw2 = (float)p.type_w[2], tw3 = (float)p.type_w[3];
+    // wave-uniform constants live in scalar registers (every VGPR counts: 128 per lane at 4 waves per SIMD, and a spill reload inside the row
+    // loop is a vmcnt(0) that drains the row blocks in flight)
+    const float tw0 = p.type_wf[0], tw1 = p.type_wf[1], tw2 = p.type_wf[2], tw3 = p.type_wf[3];
     const int tile0 = blockIdx.x * tiles_per_block;
 #define ui (lds + o_upose + 6 * K)
     const int i = threadIdx.x;
     double pq = 0.0;
 
-    for (int tk = tile0; tk < tile0 + tiles_per_block && tk < ntl; ++tk) {
-        const bool ghost_tile = GHOSTS && tk >= n_own;     // a few ghost rows on the rim of a neighbour's tile: most of its waves have nothing to stream
-        const int tile = ghost_tile ? ghost_list[tk - n_own] : tile_first + tk;
-        const int base = tile * T, a = base + i;
-        const bool in = a < A;
-        const bool owned = a >= r.own0 && a < r.own1;          // p.q and the camera block count a row once: on the rank that owns its voxel
-        const size_t ac = in ? (size_t)a : 0;
-        const int H = halo_cnt[tile];
-        // everything the entry needs besides its rows is requested first (older than the row loads: waiting for it does not drain them)
-        const float us = in ? u[a] : 0.0f, ua = in ? u[chunk + a] : 0.0f;
-        const uint8_t fl = in ? r.aflags[ac] : 0;
-        const int nr_ld = r.nrows[ac];
-        const uint8_t rf_ld = r.regflags[ac];
-        unsigned ln[6];
+    // the tile in flight (mutable: with PIPE the loads of the next tile overwrite them while the current one is still being pulled)
+    constexpr int NQH = (HMAX + T - 1) / T;
+    int tile = 0, base = 0, a = 0, H = 0, nr_ld = 0; bool in = false, owned = false; size_t ac = 0;
+    float us = 0.0f, ua = 0.0f; uint8_t fl = 0, rf_ld = 0; unsigned ln[6]; float hs[NQH], ha[NQH]; float4 rwA[8], rwB[8];
+    const int tk_end = min(tile0 + tiles_per_block, ntl);
+    // everything a tile needs besides its later rows is requested first (older than the row loads: waiting for it does not drain them)
+    auto issue_A = [&]() {
+        const float4* __restrict__ row = r.rows + row_index(ac, 0, 0, r.slots);
 #pragma unroll
-        for (int w = 0; w < 6; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);      // per-entry plan data: read once per pass, like the rows
-        float hs[(HMAX + T - 1) / T], ha[(HMAX + T - 1) / T];
-#pragma unroll
-        for (int q = 0; q < (HMAX + T - 1) / T; ++q) {
-            const int hq = i + q * T; hs[q] = 0.0f; ha[q] = 0.0f;
-            if (hq < H) { const int e = __builtin_nontemporal_load(&halo_idx[(size_t)tile * HMAX + hq]); hs[q] = u[e]; ha[q] = u[chunk + e]; }
-        }
-        float4 rwA[8], rwB[8];
-        { const float4* __restrict__ row = r.rows + row_index(ac, 0, 0, r.slots);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
+        for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64);
+    };
+    auto issue_B = [&]() {
         if (SLOTS > 1 || (SLOTS == 0 && r.slots > 1)) { const float4* __restrict__ row = r.rows + row_index(ac, 1, 0, r.slots);
 #pragma unroll
             for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
+    };
+    // part 1: the operator input of the tile and of its halo — the only DEPENDENT loads of a tile (halo index -> gather); with PIPE these cross the
+    // pull phase of the previous tile (8 registers).  part 2: flags, local slots (coalesced, issued with the row blocks).
+    auto issue_in = [&](int tk) {
+        const bool ghost = GHOSTS && tk >= n_own;
+        tile = ghost ? ghost_list[tk - n_own] : tile_first + tk;
+        base = tile * T; a = base + i;
+        in = a < A;
+        owned = a >= r.own0 && a < r.own1;          // p.q and the camera block count a row once: on the rank that owns its voxel
+        ac = in ? (size_t)a : 0;
+        H = halo_cnt[tile];
+        us = in ? u[a] : 0.0f; ua = in ? u[chunk + a] : 0.0f;
+        // branch-free (unconditional loads, padding slots gather entry 0 and are zeroed when staged): loads under divergent branches are waited for at
+        // every join, which would serialise exactly the dependent gathers this prefetch is meant to hide
+        int he[NQH];
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) he[q] = __builtin_nontemporal_load(&halo_idx[(size_t)tile * HMAX + (i + q * T < HMAX ? i + q * T : 0)]);
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) { const int e = (i + q * T < H) ? he[q] : 0; hs[q] = u[e]; ha[q] = u[chunk + e]; }
+        if (PIPE == 2) issue_A();
+    };
+    auto issue_meta = [&]() {
+        fl = in ? r.aflags[ac] : 0;
+        nr_ld = r.nrows[ac];
+        rf_ld = r.regflags[ac];
+#pragma unroll
+        for (int w = 0; w < 6; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);      // per-entry plan data: read once per pass, like the rows
+    };
+    if (PIPE && tile0 < tk_end) issue_in(tile0);
+    for (int tk = tile0; tk < tk_end; ++tk) {
+        if (!PIPE) issue_in(tk);
+        issue_meta();
+        if (PIPE != 2) issue_A();
+        issue_B();                                         // (PIPE: only slot 0 travels across the pull phase — both blocks would not fit the 128 registers)
+        const bool ghost_tile = GHOSTS && tk >= n_own;     // a few ghost rows on the rim of a neighbour's tile: most of its waves have nothing to stream
         // ---- stage the operator input of tile + halo, clear the accumulators ----
         u_s[i] = us; u_a[i] = ua;
 #pragma unroll
-        for (int q = 0; q < (HMAX + T - 1) / T; ++q) { const int hq = i + q * T; if (hq < HMAX) { u_s[T + hq] = hs[q]; u_a[T + hq] = ha[q]; qh_s[hq] = 0.0f; qh_a[hq] = 0.0f; } }
+        for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; if (hq < HMAX) { const bool hv = hq < H; u_s[T + hq] = hv ? hs[q] : 0.0f; u_a[T + hq] = hv ? ha[q] : 0.0f; qh_s[hq] = 0.0f; qh_a[hq] = 0.0f; } }
         if (i == 0) { u_s[ZSLOT] = 0.0f; u_a[ZSLOT] = 0.0f; tr_l[T] = 0.0f; }
 #pragma unroll
         for (int c = 0; c < 12; ++c) C_l[c * T + i] = 0.0f;
@@ -289,10 +282,12 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
         if (SLOTS == 0) { for (int o = 32; o > 0; o >>= 1) nr_max = max(nr_max, __shfl_xor(nr_max, o, 64)); }
         // one row: t = W (J u), J^T t added to the lane's own column sums in LDS (plain read-modify-write: the slots are private to the lane)
         auto consume = [&](const float4 (&rw)[8], int k) {
+            // plane 7 carries the row's residual in .y, which this pass never reads: without a use the register allocator hands that VGPR to another value
+            // WHILE THE LOAD IS IN FLIGHT, and the write-after-write hazard costs an s_waitcnt vmcnt(0) right behind every refill — the row stream
+            // was never double-buffered (found in the ISA; round 2 measured 0.32 ms against 0.235 ms for the bare stream)
+            asm volatile("" :: "v"(rw[7].y));
             const float4 m = rw[7];
-            float pv[6]; int fsel = 0; bool pvalid = false;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) pv[q] = 0.0f;
+            int fsel = 0; bool pvalid = false; float tsel = 0.0f;
             if (k < nr && m.x != 0.0f) {
                 const float rho = m.x * tw0;
                 const int f = __float_as_int(m.z) & ~ROW_FREE_BIT;
@@ -315,17 +310,15 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
 #pragma unroll
                 for (int c = 1; c < 10; ++c) Cme[(c - 1) * T] += J[c] * t;
                 Cme[9 * T] += J[11] * t; Cme[10 * T] += J[12] * t; Cme[11 * T] += J[13] * t;
-                if (!p.fix_poses && owned) {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) pv[q] = J[P_POSE + q] * t;
-                    fsel = f; pvalid = true;
-                }
+                if (!p.fix_poses && owned) { fsel = f; pvalid = true; tsel = t; }
                 if (owned) {
 #pragma unroll
                     for (int q = 0; q < 9; ++q) cam9[q] += J[P_INTR + q] * t;
                 }
             }
-            wave_accumulate_lds<6>(pvalid, fsel, pv, lds, reps, rs, o_wave_acc, 6);
+            // pose columns 14..19 of the row: plane 3 (.z, .w) and plane 4
+            wave_accumulate_lds<6>(pvalid, fsel, [&](int q) { const float j = q == 0 ? rw[3].z : q == 1 ? rw[3].w : q == 2 ? rw[4].x : q == 3 ? rw[4].y : q == 4 ? rw[4].z : rw[4].w; return j * tsel; },
+                                   lds, reps, rs, o_wave_acc, 6);
         };
         if (SLOTS > 0 && ghost_tile && __ballot(nr > 0) == 0ull) {
             // (wave-uniform, a scalar compare) no row in this wave of a ghost tile: nothing to stream
@@ -373,9 +366,12 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
             if (sy >= T && sy != ZSLOT) lds_add(&qh_a[sy - T], Cme[10 * T]);
             if (sz >= T && sz != ZSLOT) lds_add(&qh_a[sz - T], Cme[11 * T]);
         }
+        // the pull below works on the CURRENT tile; with PIPE the next tile's loads go out first and overwrite the tile variables
+        const int a_c = a, H_c = H, tile_c = tile; const bool in_c = in, owned_c = owned; const float ua_c = ua;
+        if (PIPE && tk + 1 < tk_end) issue_in(tk + 1);
         __syncthreads();
         // ---- pull: every entry collects the column sums of the tile entries whose stencil contains it ----
-        if (in) {
+        if (in_c) {
             // reverse entries: slot c of entry e is this entry <=> e = this entry's neighbour in the mirrored direction
             // c: 1 -y, 2 -2y, 3 -y-z, 4 -z, 5 -2z, 6 -x, 7 -x-y, 8 -x-z, 9 -2x; albedo 11 -x, 12 -y, 13 -z
             const int r2y = unpack16(lr, 0), ryz = unpack16(lr, 1), r2z = unpack16(lr, 2), rxy = unpack16(lr, 3), rxz = unpack16(lr, 4), r2x = unpack16(lr, 5);
@@ -389,12 +385,12 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
             // Ea rows in pull form (k_eaw_sym): rho sum_d w_sym[d] (u_a - u_nb(d))
             float ea = 0.0f, eq = 0.0f;
 #pragma unroll
-            for (int d = 0; d < 6; ++d) { const float diff = ua - u_a[rg[d]]; const float t = eaw[d] * diff; ea += t; eq += (rg[d] == ZSLOT ? 1.0f : 0.5f) * t * diff; }
-            qa += tw3 * ea; if (owned) pq += (double)(tw3 * eq);      // an edge whose other voxel is a list entry is seen from both sides (by their owners)
-            qacc[a] = qs; qacc[chunk + a] = qa;
+            for (int d = 0; d < 6; ++d) { const float diff = ua_c - u_a[rg[d]]; const float t = eaw[d] * diff; ea += t; eq += (rg[d] == ZSLOT ? 1.0f : 0.5f) * t * diff; }
+            qa += tw3 * ea; if (owned_c) pq += (double)(tw3 * eq);      // an edge whose other voxel is a list entry is seen from both sides (by their owners)
+            qacc[a_c] = qs; qacc[chunk + a_c] = qa;
         }
 #pragma unroll
-        for (int q = 0; q < (HMAX + T - 1) / T; ++q) { const int hq = i + q * T; if (hq < H) { const size_t o = (size_t)tile * HMAX + hq; qh[2 * o] = qh_s[hq]; qh[2 * o + 1] = qh_a[hq]; } }
+        for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; if (hq < H_c) { const size_t o = (size_t)tile_c * HMAX + hq; qh[2 * o] = qh_s[hq]; qh[2 * o + 1] = qh_a[hq]; } }
         __syncthreads();       // the staging of the next tile rewrites u / C / tr slots other lanes are still pulling from
     }
 #pragma unroll
@@ -408,7 +404,8 @@ __global__ void __launch_bounds__(T, (2 * T) / 256 > 4 ? 4 : 4) k_eg_tile(RowVie
         float v;
         if (q < 6 * K) { v = 0.0f; for (int rp = 0; rp < reps; ++rp) v += lds[rp * rs + q]; }
         else v = lds[o_cam + q - 6 * K];
-        if (v != 0.0f) atomicAdd(&shared[q], (double)v);
+        if (cam_partials) cam_partials[(size_t)blockIdx.x * cam_stride + q] = v;      // summed in a fixed order by k_pcg_step3's camera workgroups
+        else if (v != 0.0f) atomicAdd(&shared[q], (double)v);
     }
     if (pq_partials) block_partial_d(pq, pq_partials, 1, 0);
 #undef upose
@@ -462,14 +459,18 @@ hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, s
     if (t.ntiles_own > 0) k_tile_plan<<<t.ntiles_own, 1024, 0, st>>>(r, tp_T(), tp_H(), t.tile_first, nullptr, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
     if (t.n_ghost > 0) k_tile_plan<<<t.n_ghost, 1024, 0, st>>>(r, tp_T(), tp_H(), 0, t.ghost_tiles, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
     k_iota<<<(n + 255) / 256, 256, 0, st>>>(n, t.iota);
-    return rocprim::radix_sort_pairs(temp, temp_bytes, (const int*)t.halo_idx, t.ext_e, (const int*)t.iota, t.ext_pos, (size_t)n, 0, 32, st);
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const int*)t.halo_idx, t.ext_e, (const int*)t.iota, t.ext_pos, (size_t)n, 0, 32, st);
+    if (e != hipSuccess) return e;
+    if (t.ext_off) launch_ext_offsets(st, n, t.ext_e, r.chunk, t.ext_off);       // CSR offsets of the sorted pairs: k_pcg_step3 folds the halo sums itself (pcg_fused.hip)
+    return hipGetLastError();
 }
 
 // after the build kernel has written the Ea weights of this outer iteration
 void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t, const int* cflag) { if (r.A > 0) k_eaw_sym<<<(r.A + 255) / 256, 256, 0, st>>>(r, cflag, t.eaw_sym); }
 
 template <int T, int HMAX>
-static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state, int num_cu) {
+static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state, int num_cu,
+                            float* cam_partials, int cam_stride) {
     const int nshared = 6 * p.K + 9, rs = (6 * p.K) | 1;
     auto lds_bytes = [&](int reps) { const int nacc = reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
                                      return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T) * sizeof(float); };
@@ -491,10 +492,15 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
             // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
             // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
             if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
-#define I3D_EGT(SL, GH) do { (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, GH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        k_eg_tile<T, HMAX, SL, GH><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
-                                                      t.ghost_tiles, ntl, state); } while (0)
+#define I3D_EGT_ARGS r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, t.ghost_tiles, ntl, state, cam_partials, cam_stride
+#define I3D_EGT(SL, GH) do { \
+        if (pipe == 1 && !(GH)) { (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); k_eg_tile<T, HMAX, SL, false, 1><<<blocks, T, lds, st>>>(I3D_EGT_ARGS); break; } \
+        if (pipe == 2 && !(GH)) { (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); k_eg_tile<T, HMAX, SL, false, 2><<<blocks, T, lds, st>>>(I3D_EGT_ARGS); break; } \
+        (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, GH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        k_eg_tile<T, HMAX, SL, GH, 0><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
+                                                      t.ghost_tiles, ntl, state, cam_partials, cam_stride); } while (0)
             const bool gh = t.n_ghost > 0;
+            static const int pipe = [] { const char* e = std::getenv("I3D_EGT_PIPE"); return e ? std::atoi(e) : 0; }();      // single rank; I3D_EGT_PIPE=0 / 1 / 2 for A/B runs (1, 2: the compiler spills what is carried across the pull phase)
             if (r.slots == 5) { if (gh) I3D_EGT(5, true); else I3D_EGT(5, false); }      // the shipped num_observations (data/intrinsic3d.yml): unrolled row loop
             else { if (gh) I3D_EGT(0, true); else I3D_EGT(0, false); }
 #undef I3D_EGT
@@ -504,12 +510,13 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
     return written;                                          // number of p.q partials written
 }
 
-int launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state) {
+int launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state,
+                   float* cam_partials, int cam_stride) {
     if (r.A <= 0) return 0;
     static int num_cu = 0;
     if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    if (tp_T() == 1024) return launch_eg_tile_t<1024, 2048>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
-    return launch_eg_tile_t<512, 1536>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu);
+    if (tp_T() == 1024) return launch_eg_tile_t<1024, 2048>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
+    return launch_eg_tile_t<512, 1536>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
 }
 // halo accumulators of all tiles -> the per-entry accumulators (sorted by target entry at plan time; timed as its own category)
 void launch_halo_fold(hipStream_t st, RowView r, TilePlan t, float* qacc, const PcgState* state) {

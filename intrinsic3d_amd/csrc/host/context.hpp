@@ -83,13 +83,13 @@ struct i3d_context {
     i3d::DevBuf<float4> rows;
     i3d::DevBuf<uint8_t> aflags, nrows, regflags, ea_free;
     // tiled operator pass (tile_pass.hip): plan of the current work list
-    i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw;
+    i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_ext_off, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw, cam_part;
     i3d::DevBuf<unsigned char> tp_temp; bool tile_ok = false;
     i3d::TilePlan tile_plan() const {
         const int T = i3d::tile_plan_T();
         const bool sh = comm && (comm->world > 1 || comm->force);
         const int t0 = sh ? own0 / T : 0, t1 = sh ? (own1 + T - 1) / T : i3d::tile_plan_tiles(A);
-        return i3d::TilePlan{tp_lnbr.p, tp_eaw.p, tp_halo_idx.p, tp_halo_cnt.p, tp_iota.p, tp_ext_e.p, tp_ext_pos.p, tp_qh.p, tp_overflow.p, t0, t1 > t0 ? t1 - t0 : 0,
+        return i3d::TilePlan{tp_lnbr.p, tp_eaw.p, tp_halo_idx.p, tp_halo_cnt.p, tp_iota.p, tp_ext_e.p, tp_ext_pos.p, tp_qh.p, tp_ext_off.p, tp_overflow.p, t0, t1 > t0 ? t1 - t0 : 0,
                              ghost_tiles.p, sh ? n_ghost_tiles : 0};
     }
 
@@ -97,7 +97,7 @@ struct i3d_context {
     i3d::DevBuf<float> v_mask, v_c, v_S, v_D2, v_Minv, v_b, v_x, v_r, v_p, v_z, v_q, v_u, v_acc, v_tmp, v_qacc;
     i3d::DevBuf<float> Minv_blocks;
     i3d::DevBuf<double> d_shared, d_blocks, d_scal, d_xshared, d_xcshared;
-    i3d::DevBuf<i3d::PcgState> d_pcg; i3d::DevBuf<double> d_partials; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};
+    i3d::DevBuf<i3d::PcgState> d_pcg, d_pcg2; i3d::DevBuf<double> d_partials; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};
     int* h_flags = nullptr; int* d_flags = nullptr; int pcg_seq = 0;      // pinned (seq, done) ring written by k_pcg_tail_a, polled by the host
     double* h_pinned = nullptr; size_t h_pinned_n = 0;
 

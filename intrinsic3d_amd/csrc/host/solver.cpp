@@ -47,6 +47,8 @@ static int alloc_rows(i3d_context* c, int slots) {
     { const size_t nt = (size_t)tile_plan_tiles((int)Acap), nh = nt * (size_t)tile_plan_hmax();
       CTX_HIP(c, c->tp_lnbr.alloc(Acap * 9)); CTX_HIP(c, c->tp_eaw.alloc(Acap * 6)); CTX_HIP(c, c->tp_halo_idx.alloc(nh)); CTX_HIP(c, c->tp_halo_cnt.alloc(nt)); CTX_HIP(c, c->tp_iota.alloc(nh));
       CTX_HIP(c, c->tp_ext_e.alloc(nh)); CTX_HIP(c, c->tp_ext_pos.alloc(nh)); CTX_HIP(c, c->tp_qh.alloc(2 * nh)); CTX_HIP(c, c->tp_overflow.alloc(1));
+      CTX_HIP(c, c->tp_ext_off.alloc(Acap + (size_t)SHARD_ALIGN * ((c->comm ? c->comm->world : 1) + 1) + 8));      // chunk + 1 offsets (chunk >= A, a multiple of the slice alignment)
+      CTX_HIP(c, c->cam_part.alloc((size_t)2048 * (((size_t)6 * c->K + 9 + 3) & ~(size_t)3)));                     // one float row of the camera block per operator workgroup
       CTX_HIP(c, c->tp_temp.alloc(tile_plan_temp_bytes((int)nt))); }
     const int world_a = c->comm ? c->comm->world : 1;
     const size_t NP = 2 * ((size_t)c->N + (size_t)SHARD_ALIGN * (world_a + 1)) + 6 * (size_t)c->K + 9;      // chunk = world * slice >= A, slice a multiple of SHARD_ALIGN
@@ -63,7 +65,7 @@ static int alloc_rows(i3d_context* c, int slots) {
         const size_t nt = (size_t)tile_plan_tiles((int)Acap) + 1; CTX_HIP(c, c->tile_flag.alloc(nt)); CTX_HIP(c, c->ghost_tiles.alloc(nt));
     }
     CTX_HIP(c, c->d_scal.alloc(32)); CTX_HIP(c, c->d_xshared.alloc((size_t)6 * c->K + 9)); CTX_HIP(c, c->d_xcshared.alloc((size_t)6 * c->K + 9));
-    CTX_HIP(c, c->d_pcg.alloc(1));
+    CTX_HIP(c, c->d_pcg.alloc(1)); CTX_HIP(c, c->d_pcg2.alloc(2));
     CTX_HIP(c, c->d_partials.alloc((Acap / 256 + 2048) * 9));       // per-workgroup partial sums of the fp64 reductions
     if (!c->h_pcg) CTX_HIP(c, hipHostMalloc((void**)&c->h_pcg, 2 * sizeof(PcgState), hipHostMallocDefault));
     for (auto& e : c->pcg_ev) if (!e) CTX_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -213,7 +215,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     sums[5] = sums[1]; sums[6] = sums[2];
     const double lambda[4] = {cfg.lambda_g, varying_lambda(iteration, cfg.iterations, cfg.lambda_r0, cfg.lambda_r1),
                               varying_lambda(iteration, cfg.iterations, cfg.lambda_s0, cfg.lambda_s1), cfg.lambda_a};
-    for (int t = 0; t < 4; ++t) p.type_w[t] = sums[t] != 0.0 ? (lambda[t] / sums[t]) * 1000.0 : 0.0;     // nls_solver.cpp:379-394
+    for (int t = 0; t < 4; ++t) { p.type_w[t] = sums[t] != 0.0 ? (lambda[t] / sums[t]) * 1000.0 : 0.0; p.type_wf[t] = (float)p.type_w[t]; }     // nls_solver.cpp:379-394
     c->n_active = (long long)(sums[8] + 0.5);
     if (st) { for (int t = 0; t < 4; ++t) { st->rows[t] = (int64_t)(sums[4 + t] + 0.5); st->weight_sum[t] = sums[t]; st->type_weight[t] = p.type_w[t]; } st->valid_voxels = c->n_active; }
     c->last_sizes[0] = c->n_active; for (int t = 0; t < 4; ++t) c->last_sizes[1 + t] = (long long)(sums[4 + t] + 0.5);
@@ -415,6 +417,64 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     return I3D_OK;
 }
 
+// The same solve in THREE launches per pass (pcg_fused.hip): k_pcg_dir3 | k_eg_tile | k_pcg_step3.  Single rank, tiled operator.  The scalar state is
+// double-buffered by pass parity: boundary `it` reads st2[(it + 1) & 1] and writes st2[it & 1], which the operator and the step of pass `it` read.
+static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p) {
+    hipStream_t s = c->stream;
+    const Layout L = layout_of(c);
+    const int K = c->K; const size_t to = L.tail_off; const Seg2 own = L.own;
+    RowView r = c->row_view(); TilePlan tp = c->tile_plan();
+    PcgState* const st2 = c->d_pcg2.p;
+    const int NSP = (L.NS + 3) & ~3;
+    double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048; double* const d2_part = pq_part + 2048;
+    { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, (int)L.NP, c->v_x.p, 0.0f); launch_pcg_init3(s, st2, cfg.pcg_fixed_iterations, 500); }
+    CTX_HIP(c, hipMemcpyAsync(c->v_r.p, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s));
+    Step3Args a; std::memset(&a, 0, sizeof(a));
+    auto c4 = [&](const float* v) { return reinterpret_cast<const float4*>(v + own.off0); };
+    auto m4 = [&](float* v) { return reinterpret_cast<float4*>(v + own.off0); };
+    a.nq = own.n >> 2; a.chunk4 = (int)((own.off1 - own.off0) >> 2);
+    a.p = c4(c->v_p.p); a.qacc = c4(c->v_qacc.p); a.x = m4(c->v_x.p); a.r = m4(c->v_r.p); a.b = c4(c->v_b.p); a.D2 = c4(c->v_D2.p); a.Minv = c4(c->v_Minv.p); a.z = m4(c->v_z.p); a.S = c4(c->v_S.p);
+    a.ext_off = tp.ext_off; a.ext_pos = tp.ext_pos; a.qh = reinterpret_cast<const float2*>(tp.qh); a.e0 = (int)own.off0;
+    a.pq_partials = pq_part; a.d2_partials = d2_part; a.n_pq = 0; a.n_d2 = 0;
+    a.n_slice_wg = pcg_step3_slice_wgs(own.n);
+    a.K = K; a.fix_poses = p.fix_poses; a.fix_intr = p.fix_intr; a.fix_dist = p.fix_dist;
+    a.cam_partials = c->cam_part.p; a.n_cam = 0; a.cam_stride = NSP; a.Mblk = c->Minv_blocks.p;
+    a.tp = c->v_p.p + to; a.tx = c->v_x.p + to; a.tr = c->v_r.p + to; a.tb = c->v_b.p + to; a.tD2 = c->v_D2.p + to; a.tz = c->v_z.p + to; a.tS = c->v_S.p + to;
+    a.step_partials = step_part;
+    int n_step = 0;
+    { TimedScope t(c, I3D_K_VECTOR); a.cur = st2; n_step = launch_pcg_step3(s, 0 /*init*/, a); }
+    const int seq0 = c->pcg_seq;
+    int it = 1;
+    for (;; ++it) {
+        PcgState* const prev = st2 + ((it + 1) & 1); PcgState* const cur = st2 + (it & 1);
+        { TimedScope t(c, I3D_K_VECTOR);
+          a.n_d2 = launch_pcg_dir3(s, it == 1, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, step_part, n_step, d2_part, prev, cur, c->d_flags, seq0 + it); }
+        { TimedScope t(c, I3D_K_EG_PASS); a.n_pq = launch_eg_tile(s, r, p, c->v_u.p, tp, nullptr, c->v_qacc.p, pq_part, cur, c->cam_part.p, NSP); a.n_cam = a.n_pq; }
+        a.cur = cur;
+        if (it % 10 != 0) { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3(s, 1, a); }
+        else {                                                                   // residual_reset_period: r = b - A x instead of r -= alpha q
+            { TimedScope t(c, I3D_K_VECTOR); launch_pcg_step3(s, 2, a);
+              launch_mul2(s, own, c->v_S.p, c->v_x.p, c->v_u.p); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
+            { TimedScope t(c, I3D_K_EG_PASS); a.n_cam = launch_eg_tile(s, r, p, c->v_u.p, tp, nullptr, c->v_qacc.p, nullptr, cur, c->cam_part.p, NSP); }
+            { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3(s, 3, a); }
+        }
+        if (it >= 2) {                                                           // look at the boundary of pass it-1 while pass it runs
+            const int want = seq0 + it - 1; volatile int* ring = c->h_flags + 2 * (want & 1);
+            const double t_wait = now_s();
+            while (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) {
+                if (now_s() - t_wait > 30.0) { CTX_HIP(c, hipStreamSynchronize(s)); if (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) return ctx_fail(c, I3D_ERR_HIP, "pcg_solve: the device stopped publishing its state"); }
+            }
+            if (__atomic_load_n((int*)&ring[1], __ATOMIC_ACQUIRE)) break;
+        }
+        if (it > 520) break;
+    }
+    c->pcg_seq = seq0 + it + 1;
+    // boundary `it` copied the terminal state forward (kernels after `done` are no-ops), so st2[it & 1] is final
+    CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[0], st2 + (it & 1), sizeof(PcgState), hipMemcpyDeviceToHost, s));
+    CTX_HIP(c, hipGetLastError());
+    return I3D_OK;
+}
+
 // NLSSolver::solve on the assembled rows.  Updates the device unknowns and the host camera when a step is accepted.
 static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& p, i3d_iteration_stats* st, double initial_radius) {
     hipStream_t s = c->stream;
@@ -460,7 +520,10 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
         { TimedScope t(c, I3D_K_VECTOR); launch_lm_diag(s, NP, c->v_c.p, c->v_S.p, (float)(1.0 / radius), c->v_D2.p, c->v_Minv.p); }
         if (prepared_radius != radius) { prepare_shared_precond(c, p, sb, radius); prepared_radius = radius; }
         rc = upload_shared_precond(c); if (rc) return rc;
-        rc = pcg_solve(c, cfg, p); if (rc) return rc;
+        {   // three launches per pass on one rank with the tiled operator; the six-launch sequence when sharded, untiled, or asked for (A/B runs)
+            static const bool legacy = [] { const char* e = std::getenv("I3D_PCG_LEGACY"); return e && e[0] == '1'; }();
+            rc = (!sharded(c) && c->tile_ok && !legacy) ? pcg_solve_fused(c, cfg, p) : pcg_solve(c, cfg, p); if (rc) return rc;
+        }
         // candidate point (replicated: every rank needs the whole step), queued behind the solve: ONE synchronisation returns the terminal PCG
         // state, the step / parameter norms and the candidate camera.  (A step the model rejects below costs one wasted candidate kernel.)
         { int rc2 = allgather(c, c->v_x.p); if (rc2) return rc2; }

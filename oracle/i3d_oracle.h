@@ -73,6 +73,8 @@ double  orc_problem_normal_eq(void* p, const orc_opt_config* cfg, double* gradie
 /* y = (J^T J) x over global ids with fixed columns removed */
 void    orc_problem_jtj_apply(void* p, const orc_opt_config* cfg, const double* x, double* y);
 void    orc_problem_free(void* p);
+/* per voxel (visit order): relative gap between the n-th and (n+1)-th best observation weight at the current state (1 = no cut), -1 = no rows */
+void    orc_observation_margins(void* g, void* fr, const orc_opt_config* cfg, const double* intr, const double* dist, const double* poses, double* margin);
 
 int32_t orc_estimate_sh(void* g, float subvolume_size, double lambda_reg, double thres_shell, int32_t cg_fixed_iterations,
                         int32_t* num_subvolumes, double* sh /* cap*9 */, int32_t* sub_index /* cap*3 */, int32_t cap,

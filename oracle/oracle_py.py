@@ -101,6 +101,7 @@ def _configure(L):
     L.orc_problem_normal_eq.argtypes = [vp, C.POINTER(OptConfig), vp, vp, vp]
     L.orc_problem_jtj_apply.argtypes = [vp, C.POINTER(OptConfig), vp, vp]
     L.orc_problem_free.argtypes = [vp]
+    L.orc_observation_margins.argtypes = [vp, vp, C.POINTER(OptConfig), vp, vp, vp, vp]
     L.orc_estimate_sh.restype = i32
     L.orc_estimate_sh.argtypes = [vp, f32, f64, f64, i32, vp, vp, vp, i32, vp, vp, C.POINTER(ShStats)]
     L.orc_recompute_colors.restype = i32
@@ -259,6 +260,14 @@ def optimize(grid: Grid, frames: Frames, cfg: OptConfig, intr, dist, poses, voxe
     stats = (IterStats * cfg.iterations)()
     rc = lib().orc_optimize(grid.h, frames.h, C.byref(cfg), _p(intr), _p(dist), _p(poses), _p(vsh), C.cast(stats, C.c_void_p))
     return rc, intr, dist, poses, list(stats)
+
+
+def observation_margins(grid, frames, cfg, intr, dist, poses):
+    """relative gap at the top-n cut of every voxel's observation weights (see i3d_oracle.h); -1 = the voxel gets no rows"""
+    a = np.ascontiguousarray(intr, np.float64); b = np.ascontiguousarray(dist, np.float64); c = np.ascontiguousarray(poses, np.float64)
+    out = np.zeros(len(grid))
+    lib().orc_observation_margins(grid.h, frames.h, C.byref(cfg), _p(a), _p(b), _p(c), _p(out))
+    return out
 
 
 class ProblemView:

@@ -146,6 +146,33 @@ void orc_problem_jtj_apply(void* p, const orc_opt_config* c, const double* x, do
 }
 void orc_problem_free(void* p) { delete (ProblemHandle*)p; }
 
+// Diagnostic for chained comparisons: how close the top-n cut of SDFColorization::filter (colorization.cpp:357-370) is to a tie.  For every voxel that
+// would get rows at the current state: (w_n - w_{n+1}) / w_n over its positive observation weights sorted descending (1 when there are at most n
+// candidates); -1 for voxels without rows.  A second implementation whose state differs by round-off can only pick another keyframe where this is tiny.
+void orc_observation_margins(void* g, void* fr, const orc_opt_config* c, const double* intr, const double* dist, const double* poses, double* margin) {
+    auto* G = (Grid<VoxelSBR>*)g; auto* F = (Frames*)fr; OptConfig cfg = to_cfg(c);
+    Colorizer col; const Image& l0 = F->at(0, cfg.rgbd_level);
+    const double sc = 1.0 / std::pow(2.0, cfg.rgbd_level);
+    col.cam.fx = (float)(intr[0] * sc); col.cam.fy = (float)(intr[1] * sc); col.cam.cx = (float)(intr[2] * sc); col.cam.cy = (float)(intr[3] * sc);
+    for (int i = 0; i < 5; ++i) col.cam.k[i] = (float)dist[i];
+    col.cam.w = l0.w; col.cam.h = l0.h; col.max_occlusion_distance = cfg.occlusion_distance; col.max_num_observations = 0;      // 0: keep every observation
+    std::vector<double> pv(poses, poses + 6 * F->K);
+    std::vector<V3i> keys; for (auto it = G->data.begin(); it != G->data.end(); ++it) keys.push_back(it->first);
+    const size_t n = (size_t)cfg.num_observations;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (long i = 0; i < (long)keys.size(); ++i) {
+        margin[i] = -1.0;
+        const V3i p = keys[(size_t)i];
+        if (!G->valid(p) || std::abs(G->voxel(p).sdf_refined) > cfg.thres_shell) continue;
+        float nrm[3]; surface_normal(*G, p, nrm);
+        if (is_zero3(nrm)) continue;
+        std::vector<Observation> obs; col.collect(*G, pv, *F, p, nrm, cfg.rgbd_level, obs);
+        std::vector<float> w; for (auto& o : obs) if (o.weight > 0.0f) w.push_back(o.weight);
+        std::sort(w.begin(), w.end(), [](float a, float b) { return a > b; });
+        margin[i] = (n == 0 || w.size() <= n) ? 1.0 : (double)(w[n - 1] - w[n]) / (double)w[n - 1];
+    }
+}
+
 int32_t orc_estimate_sh(void* g, float subvolume_size, double lambda_reg, double thres_shell, int32_t cg_fixed,
                         int32_t* num_subvolumes, double* sh, int32_t* sub_index, int32_t cap,
                         double* voxel_sh, uint8_t* voxel_has, orc_sh_stats* st) {
