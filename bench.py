@@ -30,7 +30,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_TAG = "r02-tile-pass-nt"  # bumped when k_build<true> / k_eg_tile change materially: PMC traffic files of older kernels are not attached
+KERNEL_TAG = "r03-fused-pcg"     # bumped when k_build<true> / k_eg_tile change materially: PMC traffic / SQ counter files of older kernels are not attached
+# issue cost of a VALU wave-instruction on gfx950 measured with tools/experiments/valu_rate.hip (profiles/r02_valu_rate.txt): cycles per instruction on one SIMD
+VALU_CYCLES = {"f64": 5.4, "f32": 3.0}
+GPU_CLOCK_HZ = 2.4e9; NUM_SIMD = 1024
 
 
 def parse_args():
@@ -164,6 +167,23 @@ def cpu_baseline(args, sc, thres, log, device=0):
             "seconds_per_iteration_sample": sec_per_iter_sample, "parity_on_sample": parity}
 
 
+def sq_valu(kernel, eg_rows):
+    """VALU wave-instructions per launch of `kernel` from the committed SQ-counter pass (profiles/*_sq_counters.json, SQ_INSTS_VALU), same tag / workload rule
+    as pmc_traffic: the issue-time floor of the kernel = instructions x cycles-per-instruction / (SIMDs x clock)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel_tag") != KERNEL_TAG or kernel not in d.get("kernels", {}):
+            continue
+        if abs(d.get("eg_rows", 0) - eg_rows) <= 0.01 * eg_rows:
+            best = dict(d["kernels"][kernel], source=os.path.basename(f))
+    return best
+
+
 def pmc_traffic(kernel, eg_rows, active):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json, written by tools/pmc_traffic.py from
     separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, calibrated on a known-size copy).  Counters cannot
@@ -179,7 +199,7 @@ def pmc_traffic(kernel, eg_rows, active):
         if d.get("kernel_tag") != KERNEL_TAG:
             continue
         if abs(d.get("eg_rows", 0) - eg_rows) <= 0.01 * eg_rows and abs(d.get("active_voxels", 0) - active) <= 0.01 * active and kernel in d.get("kernels", {}):
-            best = d["kernels"][kernel]["traffic_bytes_per_launch"] * (eg_rows / float(d["eg_rows"]))
+            best = (d["kernels"][kernel]["traffic_bytes_per_launch"] * (eg_rows / float(d["eg_rows"])), os.path.basename(f))
     return best
 
 
@@ -301,7 +321,7 @@ def _main():
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     t0 = time.time(); _ = ctx.get_grid(); _ = ctx.get_camera(); t_download = time.time() - t0          # what a host-buffer caller reads back
-    timing_work = ctx.timing_get_work()      # launches that did work (PCG launches queued behind the convergence flag return at once)
+    timing_work = ctx.timing_get_work_ex()   # launches that did work (PCG launches queued behind the convergence flag return at once); + what the upper cut-off removed
     timing = ctx.timing_get(reset=True)
     sizes = ctx.problem_sizes()
     ctx.timing_enable(False)
@@ -327,18 +347,29 @@ def _main():
         b_build /= world; b_egpass /= world; d_build /= world; d_egpass /= world
     kernels = {}
     for name, bytes_per_launch, design in (("build", b_build, d_build), ("eg_pass", b_egpass, d_egpass)):
-        ms, n = timing_work[name]
+        ms, n, slow_ms, slow_n = timing_work[name]
         if n > 0:
             avg = ms / n                     # HIP events around each launch on the library's stream, no-op launches excluded
             kernels[name] = {"launches": n, "launches_incl_noop": timing[name][1], "avg_ms": avg, "algorithmic_GB": bytes_per_launch / 1e9,
-                             "design_GB": design / 1e9, "achieved_GBs": bytes_per_launch / 1e9 / (avg * 1e-3)}
+                             "design_GB": design / 1e9, "achieved_GBs": bytes_per_launch / 1e9 / (avg * 1e-3),
+                             # launches slower than 4x the 90th percentile are not in avg_ms (a launch that straddles a device hiccup); reported, not hidden:
+                             "excluded_slow_launches": slow_n, "excluded_slow_ms": slow_ms, "avg_ms_incl_slow": (ms + slow_ms) / (n + slow_n)}
 
     def roof(name):
         if name not in kernels:
             return None
         k = kernels[name]
-        return {"kernel": {"build": "k_build<true>", "eg_pass": "k_eg_tile"}[name], "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(name, Rg, A) if world == 1 else None}
+        tr = pmc_traffic(name, Rg, A) if world == 1 else None
+        out = {"kernel": {"build": "k_build<true>", "eg_pass": "k_eg_tile"}[name], "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+               "traffic_source": (f"committed PMC passes of this command, profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; not measured in this run)" if tr else None)}
+        sq = sq_valu(name, Rg) if world == 1 else None
+        if sq:      # what actually limits the kernel: issue time of its VALU instructions against the measured launch time
+            issue_ms = (sq["valu_f64"] * VALU_CYCLES["f64"] + (sq["valu"] - sq["valu_f64"]) * VALU_CYCLES["f32"]) / (NUM_SIMD * GPU_CLOCK_HZ) * 1e3
+            out.update(valu_instructions=sq["valu"], valu_issue_ms=issue_ms, valu_frac=issue_ms / k["avg_ms"], valu_source=f"profiles/{sq['source']} (SQ_INSTS_VALU; fp64 share from the ISA)")
+            if out["valu_frac"] > out["frac"]:
+                out["bound"] = "valu-issue"
+        return out
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
     roofline = roof(dominant) if dominant else None
     roofline_build = roof("build")           # the kernel the north star names, whichever one dominates
@@ -370,14 +401,20 @@ def _main():
                        "workload": f"synthetic hashed SDF grid, {arrays['keys'].shape[0]} stored voxels @ {args.voxel_size * 1e3:g} mm "
                                    f"({A} in the thin shell), {args.frames} keyframes {args.width}x{args.height}, {sh_sub.shape[0]} SH subvolumes of {args.subvolume} m (estimated on the device, untimed), "
                                    f"joint SDF+albedo+pose+intrinsics+distortion, 5 observations/voxel (BASELINE.json configs[3] on one node)",
-                       "stored_voxels": int(arrays["keys"].shape[0]), "active_voxels": A, "rows": {"Eg": Rg, "Er": Rr, "Es": Rs, "Ea": Ra},
+                       "stored_voxels": int(arrays["keys"].shape[0]), "active_voxels": A, "active_fraction": A / float(arrays["keys"].shape[0]),
+                       "stored_shell_half_thickness_voxels": args.band,
+                       "note": "SURVEY section 8(d) prices its worked C4 example with every stored voxel active (N_a = 8e6, R_g = 4e7); here the stored band is "
+                               f"{2 * args.band:g} voxels thick and the finest-level thin shell (factor {args.shell:g}) activates {100.0 * A / float(arrays['keys'].shape[0]):.0f} % of it, so one iteration "
+                               f"carries {Rg / 4.0e7:.2f}x the rows of that example (--band 2 stores the 4-voxel shell of section 8(d): profiles/r03_bench_band2.json)",
+                       "rows": {"Eg": Rg, "Er": Rr, "Es": Rs, "Ea": Ra},
                        "free_parameters": sizes["free"], "keyframes": args.frames, "image": [args.width, args.height],
                        "pcg_iterations_per_step": pcg, "lm_attempts": [int(s.num_attempts) for s in stats]},
             "carry_trust_radius": bool(args.carry_radius), "kernel_tag": KERNEL_TAG,
             "optimize_calls": (args.steps + CALL_ITERATIONS - 1) // CALL_ITERATIONS, "iterations_per_call": min(CALL_ITERATIONS, args.steps),
             "roofline": roofline, "roofline_build": roofline_build, "kernels": kernels, "comm": comm,
             "kernel_ms_total": {k: v[0] for k, v in timing.items()}, "kernel_launches": {k: v[1] for k, v in timing.items()},
-            "time_split_ms_per_step": {"time_add": float(np.mean([s.time_add for s in stats]) * 1e3), "time_solve": float(np.mean([s.time_solve for s in stats]) * 1e3)},
+            "time_split_ms_per_step": {"time_add": float(np.mean([s.time_add for s in stats]) * 1e3), "time_build": float(np.mean([s.time_build for s in stats]) * 1e3),
+                                       "time_solve": float(np.mean([s.time_solve for s in stats]) * 1e3)},      # nls_solver.cpp:66-67,101
             "cost": [float(stats[0].cost_initial), float(stats[-1].cost_final)],
             # the boundary also accepts host buffers (i3d_set_grid / i3d_set_frames / i3d_optimize_host): the same run with the one-off upload
             # (voxels + keyframe pyramids over PCIe, hash / neighbour-table build) and the read-back of the refined fields counted in.  Never `value`.

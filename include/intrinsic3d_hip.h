@@ -286,6 +286,9 @@ int i3d_timing_get(i3d_context* ctx, double* ms /*[I3D_K_COUNT]*/, int64_t* laun
 /* the same restricted to launches that did work: PCG launches queued behind the device-side convergence flag return at once (~4 us) and
  * would flatter an average; a launch counts when it lasted >= 25 % of the longest launch of its category */
 int i3d_timing_get_work(i3d_context* ctx, double* ms /*[I3D_K_COUNT]*/, int64_t* launches /*[I3D_K_COUNT]*/);
+/* the same, plus what the upper cut-off removed: launches that lasted more than 4x the 90th percentile of their category (a launch that straddles a
+ * hiccup of the device) — their number and total time, so that a caller can quote them beside the average.  The exchange category is never cut. */
+int i3d_timing_get_work_ex(i3d_context* ctx, double* ms, int64_t* launches, double* slow_ms /*[I3D_K_COUNT]*/, int64_t* slow_launches /*[I3D_K_COUNT]*/);
 const char* i3d_kernel_name(int32_t k);
 /* sizes of the last assembled problem: active voxels, Eg/Er/Es/Ea rows, free parameters */
 int i3d_problem_sizes(i3d_context* ctx, int64_t out[6]);

@@ -73,7 +73,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_fusion_create", "i3d_fusion_destroy", "i3d_fusion_last_error", "i3d_fusion_integrate", "i3d_fusion_finish", "i3d_fusion_info", "i3d_fusion_get",
            "i3d_fusion_save", "i3d_shard_need", "i3d_comm_stats",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
-           "i3d_comm_transport", "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_kernel_name", "i3d_problem_sizes",
+           "i3d_comm_transport", "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_timing_get_work_ex", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_map_order", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
            "i3d_debug_normal_eq", "i3d_debug_jtj_apply"]
 
@@ -124,6 +124,7 @@ def load():
     L.i3d_timing_select.restype = i32; L.i3d_timing_select.argtypes = [vp, C.c_uint32]
     L.i3d_timing_get.restype = i32; L.i3d_timing_get.argtypes = [vp, vp, vp, i32]
     L.i3d_timing_get_work.restype = i32; L.i3d_timing_get_work.argtypes = [vp, vp, vp]
+    L.i3d_timing_get_work_ex.restype = i32; L.i3d_timing_get_work_ex.argtypes = [vp, vp, vp, vp, vp]
     L.i3d_kernel_name.restype = C.c_char_p; L.i3d_kernel_name.argtypes = [i32]
     L.i3d_comm_transport.restype = C.c_char_p; L.i3d_comm_transport.argtypes = [vp]
     L.i3d_problem_sizes.restype = i32; L.i3d_problem_sizes.argtypes = [vp, vp]
@@ -406,6 +407,12 @@ class Context:
         ms = np.zeros(len(K_NAMES)); n = np.zeros(len(K_NAMES), np.int64)
         self._check(self.L.i3d_timing_get_work(self.h, _p(ms), _p(n)), "i3d_timing_get_work")
         return {k: (ms[i], int(n[i])) for i, k in enumerate(K_NAMES)}
+
+    def timing_get_work_ex(self):
+        """timing_get_work plus the launches its upper cut-off (> 4x the 90th percentile) removed: {category: (ms, launches, slow_ms, slow_launches)}"""
+        ms = np.zeros(len(K_NAMES)); n = np.zeros(len(K_NAMES), np.int64); sms = np.zeros(len(K_NAMES)); sn = np.zeros(len(K_NAMES), np.int64)
+        self._check(self.L.i3d_timing_get_work_ex(self.h, _p(ms), _p(n), _p(sms), _p(sn)), "i3d_timing_get_work_ex")
+        return {k: (ms[i], int(n[i]), sms[i], int(sn[i])) for i, k in enumerate(K_NAMES)}
 
     def timing_get(self, reset=True):
         ms = np.zeros(len(K_NAMES)); n = np.zeros(len(K_NAMES), np.int64)

@@ -102,20 +102,36 @@ static __device__ inline void bicubic_taps(const float* __restrict__ img, int w,
         else o.t[i] = make_float4(line[min(max(col - 1, 0), w - 1)], line[min(max(col, 0), w - 1)], line[min(max(col + 1, 0), w - 1)], line[min(max(col + 2, 0), w - 1)]);
     }
 }
+// Catmull-Rom in WEIGHT form.  Ceres evaluates p1 + x (c + x (b + x a)) with a, b, c recombined from the taps for every spline (5 splines per
+// point, ~15 operations each); the same cubic as a weighted sum of the taps shares ONE weight vector per axis between the four row splines and
+// the column spline: f = sum_i wr_i (sum_j wc_j t_ij).  Values differ from the Horner form by fp64 round-off only (1e-16 relative).
+//   w0 = x(-1 + x(2 - x))/2   w1 = 1 + x^2(3x - 5)/2   w2 = x(1 + x(4 - 3x))/2   w3 = x^2(x - 1)/2
+//   w0' = (-1 + x(4 - 3x))/2  w1' = x(9x - 10)/2       w2' = (1 + x(8 - 9x))/2   w3' = x(3x - 2)/2
+template <class T> static __device__ inline void cr_weights(T x, T w[4]) {
+    const T h = (T)0.5, x2 = x * x;
+    w[0] = h * x * ((T)-1.0 + x * ((T)2.0 - x)); w[1] = (T)1.0 + h * x2 * ((T)3.0 * x - (T)5.0);
+    w[2] = h * x * ((T)1.0 + x * ((T)4.0 - (T)3.0 * x)); w[3] = h * x2 * (x - (T)1.0);
+}
+template <class T> static __device__ inline void cr_dweights(T x, T d[4]) {
+    const T h = (T)0.5;
+    d[0] = h * ((T)-1.0 + x * ((T)4.0 - (T)3.0 * x)); d[1] = h * x * ((T)9.0 * x - (T)10.0);
+    d[2] = h * ((T)1.0 + x * ((T)8.0 - (T)9.0 * x)); d[3] = h * x * ((T)3.0 * x - (T)2.0);
+}
 template <bool WITH_J>
 static __device__ inline void bicubic_eval(const Taps& k, double& f, float& dfdr, float& dfdc) {
-    const float4* t = k.t; const double xc = k.xc, xr = k.xr;
+    const float4* t = k.t;
+    double wc[4], wr[4]; cr_weights<double>(k.xc, wc); cr_weights<double>(k.xr, wr);
     double fr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fr[i] = hermite_val<double>((double)t[i].x, (double)t[i].y, (double)t[i].z, (double)t[i].w, xc);
-    f = hermite_val<double>(fr[0], fr[1], fr[2], fr[3], xr);
+    for (int i = 0; i < 4; ++i) fr[i] = wc[0] * (double)t[i].x + wc[1] * (double)t[i].y + wc[2] * (double)t[i].z + wc[3] * (double)t[i].w;
+    f = wr[0] * fr[0] + wr[1] * fr[1] + wr[2] * fr[2] + wr[3] * fr[3];
     if (WITH_J) {
-        const float xcf = (float)xc, xrf = (float)xr;
-        dfdr = hermite_der<float>((float)fr[0], (float)fr[1], (float)fr[2], (float)fr[3], xrf);
-        float dc[4];
+        float dwc[4], dwr[4]; cr_dweights<float>((float)k.xc, dwc); cr_dweights<float>((float)k.xr, dwr);
+        dfdr = dwr[0] * (float)fr[0] + dwr[1] * (float)fr[1] + dwr[2] * (float)fr[2] + dwr[3] * (float)fr[3];
+        float acc = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dc[i] = hermite_der<float>(t[i].x, t[i].y, t[i].z, t[i].w, xcf);
-        dfdc = hermite_val<float>(dc[0], dc[1], dc[2], dc[3], xrf);
+        for (int i = 0; i < 4; ++i) acc += (float)wr[i] * (dwc[0] * t[i].x + dwc[1] * t[i].y + dwc[2] * t[i].z + dwc[3] * t[i].w);
+        dfdc = acc;
     }
 }
 

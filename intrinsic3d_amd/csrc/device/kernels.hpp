@@ -54,6 +54,7 @@ void launch_shared_finalize(hipStream_t st, size_t tail_off, int K, OptParams p,
 
 void launch_fill(hipStream_t st, int n, float* x, float v);
 void launch_fill_d(hipStream_t st, int n, double* x, double v);
+void launch_int_to_double(hipStream_t st, const int* src, double* dst);      // a device flag joins an fp64 all-reduce
 void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* out);                 // out = a*b
 void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* freemask, float* S);          // S = free ? 1/(1+sqrt(c)) : 0
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float inv_radius, float* D2, float* Minv_diag);  // D2 = clamp(c S^2)/radius, Minv = 1/(c S^2 + D2) (free) else 0
@@ -87,12 +88,15 @@ struct TilePlan {                   // built once per outer iteration by launch_
     float* qh;                      // [tiles * HMAX][2] halo accumulators of one pass
     int* ext_off;                   // [chunk + 1] CSR offsets of the sorted pairs by entry (k_pcg_step3 folds the halo sums itself), or null
     int* overflow;                  // device flag: a halo did not fit -> use the untiled pass
+    int T, hmax;                    // geometry of THIS plan: 512 / 1536 (two workgroups per CU) or 1024 / 2048 (the fallback when a tile's halo does not fit)
     int tile_first, ntiles_own;     // tiles this rank owns (all of them when not sharded)
     const int* ghost_tiles; int n_ghost;   // sharded: foreign tiles that hold ghost entries of this rank's compute list
 };
-int    tile_plan_T();
-int    tile_plan_tiles(int A);
+int    tile_plan_T();                      // default geometry (I3D_EGT_TILE): entries per tile
+int    tile_plan_tiles(int A);             // ... tiles of A entries, halo slots per tile
 int    tile_plan_hmax();
+inline int tile_plan_hmax_of(int T) { return T == 1024 ? 2048 : 1536; }
+inline int tile_plan_tiles_of(int A, int T) { return (A + T - 1) / T; }
 size_t tile_plan_temp_bytes(int ntiles);
 hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, size_t temp_bytes);
 void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t, const int* cflag /* sharded: compute-list flags, else null */);   // after launch_build (reads the Ea weights it wrote)

@@ -570,6 +570,8 @@ __global__ void __launch_bounds__(256) k_dot2(int n, size_t seg, const float* a,
 }
 void launch_fill(hipStream_t st, int n, float* x, float v) { if (n > 0) k_fill<<<vblocks(n), 256, 0, st>>>(n, x, v); }
 void launch_fill_d(hipStream_t st, int n, double* x, double v) { if (n > 0) k_fill_d<<<vblocks(n), 256, 0, st>>>(n, x, v); }
+__global__ void k_int_to_double(const int* src, double* dst) { *dst = (double)*src; }
+void launch_int_to_double(hipStream_t st, const int* src, double* dst) { k_int_to_double<<<1, 1, 0, st>>>(src, dst); }
 void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* o) { if (n > 0) k_mul<<<vblocks(n), 256, 0, st>>>(n, a, b, o); }
 void launch_mul2(hipStream_t st, Seg2 sg, const float* a, const float* b, float* o) {
     if (sg.n > 0) k_mul2<<<vblocks(2 * sg.n), 256, 0, st>>>(sg.n, sg.off1 - sg.off0, a + sg.off0, b + sg.off0, o + sg.off0);

@@ -41,7 +41,7 @@ __device__ __host__ inline int tp_dir(int j) {
 // (its own range + the foreign tiles that hold ghost entries); the others keep halo_cnt = 0 and padding.  lnbr[0..5]: the 12 read slots (uint16 pairs:
 // 0..T-1 own tile, T.. halo, zslot = not a list entry); lnbr[6..8]: the 6 extra reverse slots, own tile or zslot (foreign sources reach
 // the entry through THEIR tile's halo accumulators).  halo_idx is padded with TP_NONE (those keys sort behind every real pair).
-__global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, int tile_first, const int* __restrict__ tile_list, unsigned* __restrict__ lnbr,
+__global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, int hlimit /* <= hmax: more halo entries than this = overflow */, int tile_first, const int* __restrict__ tile_list, unsigned* __restrict__ lnbr,
                                                     int* __restrict__ halo_idx, int* __restrict__ halo_cnt, int* __restrict__ overflow) {
     __shared__ int hkeys[4096];
     __shared__ int hlist[TP_PLAN_LIST];
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, 
     for (int i = threadIdx.x; i < 4096; i += 1024) if (hkeys[i] >= 0) { const int pos = atomicAdd(&cnt, 1); if (pos < TP_PLAN_LIST) hlist[pos] = hkeys[i]; }
     __syncthreads();
     const int H = cnt;
-    if (H > hmax) { if (threadIdx.x == 0) { *overflow = 1; halo_cnt[tile] = 0; } return; }      // the caller falls back to the untiled pass
+    if (H > hlimit) { if (threadIdx.x == 0) { *overflow = 1; halo_cnt[tile] = 0; } return; }      // the caller falls back to the untiled pass
     for (int k = 2; k <= TP_PLAN_LIST; k <<= 1)                                     // bitonic sort, ascending (the padding ends up last)
         for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
@@ -449,15 +449,18 @@ size_t tile_plan_temp_bytes(int ntiles) {
 // returns hipSuccess or the first error; *overflow (device int, zeroed here) = 1 when a tile's halo does not fit.
 // Plans the tiles [tile_first, tile_first + ntiles_own) and the n_ghost tiles of t.ghost_tiles; every other tile keeps an empty halo.
 hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, size_t temp_bytes) {
-    const int ntiles = tile_plan_tiles(r.A);
+    const int ntiles = tile_plan_tiles_of(r.A, t.T);
     if (ntiles <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(t.overflow, 0, sizeof(int), st); if (e != hipSuccess) return e;
-    const int n = ntiles * tp_H();
+    const int n = ntiles * t.hmax;
+    // tests of the overflow handling: pretend the 512-entry geometry has fewer halo slots than it has (the 1024-entry fallback is not limited)
+    const int limit512 = [] { const char* s = std::getenv("I3D_EGT_HMAX_LIMIT"); return s ? std::atoi(s) : 0; }();      // (read per plan: tests set it for one run)
+    const int hlimit = (t.T == 512 && limit512 > 0 && limit512 < t.hmax) ? limit512 : t.hmax;
     const bool all = t.tile_first == 0 && t.ntiles_own >= ntiles;
     if (!all) { e = hipMemsetAsync(t.halo_idx, 0x7f, sizeof(int) * (size_t)n, st); if (e != hipSuccess) return e;
                 e = hipMemsetAsync(t.halo_cnt, 0, sizeof(int) * (size_t)ntiles, st); if (e != hipSuccess) return e; }
-    if (t.ntiles_own > 0) k_tile_plan<<<t.ntiles_own, 1024, 0, st>>>(r, tp_T(), tp_H(), t.tile_first, nullptr, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
-    if (t.n_ghost > 0) k_tile_plan<<<t.n_ghost, 1024, 0, st>>>(r, tp_T(), tp_H(), 0, t.ghost_tiles, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
+    if (t.ntiles_own > 0) k_tile_plan<<<t.ntiles_own, 1024, 0, st>>>(r, t.T, t.hmax, hlimit, t.tile_first, nullptr, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
+    if (t.n_ghost > 0) k_tile_plan<<<t.n_ghost, 1024, 0, st>>>(r, t.T, t.hmax, hlimit, 0, t.ghost_tiles, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
     k_iota<<<(n + 255) / 256, 256, 0, st>>>(n, t.iota);
     e = rocprim::radix_sort_pairs(temp, temp_bytes, (const int*)t.halo_idx, t.ext_e, (const int*)t.iota, t.ext_pos, (size_t)n, 0, 32, st);
     if (e != hipSuccess) return e;
@@ -515,13 +518,13 @@ int launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TileP
     if (r.A <= 0) return 0;
     static int num_cu = 0;
     if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    if (tp_T() == 1024) return launch_eg_tile_t<1024, 2048>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
+    if (t.T == 1024) return launch_eg_tile_t<1024, 2048>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
     return launch_eg_tile_t<512, 1536>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
 }
 // halo accumulators of all tiles -> the per-entry accumulators (sorted by target entry at plan time; timed as its own category)
 void launch_halo_fold(hipStream_t st, RowView r, TilePlan t, float* qacc, const PcgState* state) {
     if (r.A <= 0) return;
-    const int n = tile_plan_tiles(r.A) * tp_H();
+    const int n = tile_plan_tiles_of(r.A, t.T) * t.hmax;
     k_halo_fold<<<(n + 255) / 256, 256, 0, st>>>(n, t.ext_e, t.ext_pos, t.qh, qacc, r.chunk, state);
 }
 int tile_plan_T() { return tp_T(); }

@@ -17,8 +17,20 @@ constexpr int P2P_HALO_CAP = 1 << 17;           // rim entries per pair and pass
 struct RcclComm : Comm {
     ncclComm_t comm = nullptr;
     P2PEngine p2p; bool use_p2p = false;       // peer-to-peer mailboxes for the per-pass exchanges (verified at start-up, else RCCL carries them too)
-    ~RcclComm() override { p2p.destroy(); if (comm) ncclCommDestroy(comm); }
-    int plan_changed(const HaloPlan& h, hipStream_t st) override { return use_p2p ? p2p.set_halo_lists(h, st) : 0; }
+    bool halo_rccl = false; double* d_agree = nullptr;      // this outer iteration's rim exceeds a mailbox somewhere: every rank pushes it through RCCL instead
+    ~RcclComm() override { p2p.destroy(); if (d_agree) (void)hipFree(d_agree); if (comm) ncclCommDestroy(comm); }
+    // a rim that does not fit the mailbox of one rank pair is not an error: the ranks agree (max over ranks) and the grouped send / receive path carries
+    // this iteration's rim pushes (HALO_CAP entries instead of P2P_HALO_CAP)
+    int plan_changed(const HaloPlan& h, hipStream_t st) override {
+        if (!use_p2p) return 0;
+        double bad = p2p.set_halo_lists(h, st) != 0 ? 1.0 : 0.0;
+        if (!d_agree && hipMalloc((void**)&d_agree, sizeof(double)) != hipSuccess) return 1;
+        if (hipMemcpyAsync(d_agree, &bad, sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+        if (ncclAllReduce(d_agree, d_agree, 1, ncclDouble, ncclMax, comm, st) != ncclSuccess) return 1;
+        if (hipMemcpyAsync(&bad, d_agree, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+        halo_rccl = bad != 0.0;
+        return 0;
+    }
     int health(hipStream_t st) override { return use_p2p ? p2p.check(st) : 0; }
     bool device_reduce(P2PDev* dev) override { if (!use_p2p) return false; *dev = p2p.device(); return true; }
     int allreduce_sum(double* dev, size_t n, hipStream_t st) override {
@@ -32,7 +44,7 @@ struct RcclComm : Comm {
     // neighbours only: one grouped launch of sends / receives of the packed rim values (a few tens of KB per pair)
     int push_halo(float* vec, const HaloPlan& h, hipStream_t st) override {
         ++halo_calls; halo_bytes_sent += 8ll * h.n_send;
-        if (use_p2p) return p2p.push_halo(vec, h, st);
+        if (use_p2p && !halo_rccl) return p2p.push_halo(vec, h, st);
         if (h.n_send == 0 && h.n_recv == 0) return 0;
         launch_halo_pack(st, h.n_send, h.d_send_idx, vec, h.chunk, h.d_send_buf);
         if (ncclGroupStart() != ncclSuccess) return 1;
@@ -57,27 +69,37 @@ int rccl_unique_id(void* out, size_t* bytes) {
 
 // Mailboxes for the per-pass exchanges: created on every rank, IPC handles all-gathered through RCCL, then verified with real exchanges
 // (known sums, bounded waits).  All ranks take the same decision (all-reduced); anything short of a clean pass leaves RCCL in charge.
-static bool bootstrap_p2p(RcclComm* c, hipStream_t st) {
-    { const char* e = std::getenv("I3D_TRANSPORT"); if (e && std::strcmp(e, "rccl") == 0) return false; }
-    bool ok = c->p2p.create(c->rank, c->world, P2P_RED_CAP, P2P_HALO_CAP) == 0;
+// The mailbox transport is OPT-IN (I3D_TRANSPORT=p2p): it has only ever run with all ranks on one device (same-process simulation, 2-8 processes on
+// one GPU, a forced 1-rank communicator) — until a multi-GPU run of the suite has passed, RCCL carries every exchange by default.
+// *fatal is set when this rank could not even take part in the agreement collectives (scratch allocation): the caller aborts the init instead of
+// letting the ranks issue mismatched collectives.
+static bool bootstrap_p2p(RcclComm* c, hipStream_t st, bool* fatal) {
+    *fatal = false;
+    { const char* e = std::getenv("I3D_TRANSPORT"); if (!e || std::strcmp(e, "p2p") != 0) return false; }      // every rank reads the same environment: no collective is skipped one-sidedly
+    // the scratch of the agreement collectives comes first and unconditionally: every rank issues the all-gather and both min-reductions whatever happens to it locally
     unsigned char* d_handles = nullptr; double* d_test = nullptr;
-    ok = ok && hipMalloc((void**)&d_handles, 64 * (size_t)c->world) == hipSuccess && hipMalloc((void**)&d_test, sizeof(double) * 64) == hipSuccess;
+    if (hipMalloc((void**)&d_handles, 64 * (size_t)c->world) != hipSuccess || hipMalloc((void**)&d_test, sizeof(double) * 64) != hipSuccess) {
+        if (d_handles) (void)hipFree(d_handles);
+        *fatal = true; return false;
+    }
+    (void)hipMemset(d_handles, 0, 64 * (size_t)c->world);
+    bool ok = c->p2p.create(c->rank, c->world, P2P_RED_CAP, P2P_HALO_CAP) == 0;
     unsigned char mine[64] = {0};
     if (ok) ok = c->p2p.export_handle(mine) == 0;
     if (ok) ok = hipMemcpy(d_handles + 64 * (size_t)c->rank, mine, 64, hipMemcpyHostToDevice) == hipSuccess;
     // every rank must take part in the collectives below even if it failed locally (ok is agreed on at the end)
     std::vector<unsigned char> all(64 * (size_t)c->world, 0);
-    if (d_handles) {
-        (void)ncclAllGather(d_handles + 64 * (size_t)c->rank, d_handles, 64, ncclUint8, c->comm, st);
+    {
+        const bool gathered = ncclAllGather(d_handles + 64 * (size_t)c->rank, d_handles, 64, ncclUint8, c->comm, st) == ncclSuccess;
         (void)hipStreamSynchronize(st);
-        ok = ok && hipMemcpy(all.data(), d_handles, all.size(), hipMemcpyDeviceToHost) == hipSuccess;
+        ok = gathered && ok && hipMemcpy(all.data(), d_handles, all.size(), hipMemcpyDeviceToHost) == hipSuccess;
     }
     if (ok && c->world > 1) ok = c->p2p.attach_ipc(all.data()) == 0;
     if (ok && c->world == 1) c->p2p.ready = true;
     // agree that everyone has mapped everyone before the first peer store
     double flag = ok ? 1.0 : 0.0;
-    if (d_test) { (void)hipMemcpy(d_test, &flag, sizeof(double), hipMemcpyHostToDevice); (void)ncclAllReduce(d_test, d_test, 1, ncclDouble, ncclMin, c->comm, st); (void)hipStreamSynchronize(st);
-                  (void)hipMemcpy(&flag, d_test, sizeof(double), hipMemcpyDeviceToHost); }
+    (void)hipMemcpy(d_test, &flag, sizeof(double), hipMemcpyHostToDevice); (void)ncclAllReduce(d_test, d_test, 1, ncclDouble, ncclMin, c->comm, st); (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(&flag, d_test, sizeof(double), hipMemcpyDeviceToHost);
     ok = ok && flag == 1.0;
     c->p2p.spin_limit = P2P_SPIN_LIMIT_SELFTEST;
     if (ok) {        // self-test with real exchanges and bounded waits: small and full-size all-reduces, then rim pushes between every pair
@@ -137,7 +159,9 @@ Comm* make_rccl_comm(int rank, int world, const void* unique_id, size_t id_bytes
     auto* c = new RcclComm; c->rank = rank; c->world = world;
     const ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) { std::snprintf(err, errlen, "ncclCommInitRank: %s", ncclGetErrorString(r)); c->comm = nullptr; delete c; return nullptr; }
-    c->use_p2p = bootstrap_p2p(c, st);
+    bool fatal = false;
+    c->use_p2p = bootstrap_p2p(c, st, &fatal);
+    if (fatal) { std::snprintf(err, errlen, "communicator bootstrap: scratch allocation failed on rank %d", rank); delete c; return nullptr; }
     c->transport = c->use_p2p ? "p2p-mailbox (per-pass exchanges) + rccl" : "rccl";
     return c;
 }

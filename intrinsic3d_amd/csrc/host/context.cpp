@@ -338,7 +338,8 @@ int i3d_timing_get(i3d_context* c, double* ms, int64_t* launches, int32_t reset)
     if (reset) for (int i = 0; i < I3D_K_COUNT; ++i) { c->timing.ms[i] = 0; c->timing.launches[i] = 0; c->timing.each[i].clear(); }
     return I3D_OK;
 }
-int i3d_timing_get_work(i3d_context* c, double* ms, int64_t* launches) {
+int i3d_timing_get_work(i3d_context* c, double* ms, int64_t* launches) { return i3d_timing_get_work_ex(c, ms, launches, nullptr, nullptr); }
+int i3d_timing_get_work_ex(i3d_context* c, double* ms, int64_t* launches, double* slow_ms, int64_t* slow_launches) {
     if (!c) return I3D_ERR_INVALID_ARGUMENT;
     timing_flush(c);
     for (int i = 0; i < I3D_K_COUNT; ++i) {
@@ -346,9 +347,15 @@ int i3d_timing_get_work(i3d_context* c, double* ms, int64_t* launches) {
         // and a launch that straddles a hiccup of the device (seen once: 19.9 ms for a 0.33 ms kernel) is not the kernel's duration either (> 4x)
         std::vector<float> sorted(c->timing.each[i]); std::sort(sorted.begin(), sorted.end());
         const float ref = sorted.empty() ? 0.0f : sorted[(size_t)(0.9 * (double)(sorted.size() - 1))];
-        double s = 0.0; int64_t n = 0;
-        for (float v : c->timing.each[i]) if (v >= 0.25f * ref && v <= 4.0f * ref) { s += v; ++n; }
+        double s = 0.0, slow = 0.0; int64_t n = 0, nslow = 0;
+        const bool waits_for_peers = i == I3D_K_COMM;        // exchange launches mostly WAIT: their spread is the peers', there is no "hiccup" to cut off
+        for (float v : c->timing.each[i]) {
+            if (v < 0.25f * ref) continue;
+            if (v > 4.0f * ref && !waits_for_peers) { slow += v; ++nslow; continue; }
+            s += v; ++n;
+        }
         if (ms) ms[i] = s; if (launches) launches[i] = n;
+        if (slow_ms) slow_ms[i] = slow; if (slow_launches) slow_launches[i] = nslow;      // reported beside the average, never silently dropped
     }
     return I3D_OK;
 }

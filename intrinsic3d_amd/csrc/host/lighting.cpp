@@ -212,11 +212,13 @@ int estimate_sh(i3d_context* c, float subvolume_size, double lambda_reg, double 
     DevBuf<double> d_gram, d_wsum; CTX_HIP(c, d_gram.alloc((size_t)S * 100)); CTX_HIP(c, d_wsum.alloc(1));
     CTX_HIP(c, hipMemsetAsync(d_gram.p, 0, sizeof(double) * (size_t)S * 100, st)); CTX_HIP(c, hipMemsetAsync(d_wsum.p, 0, sizeof(double), st));
     launch_sh_assign(st, (int)M, k1.p, d_sub.p, S, ssub.p);
-    launch_sh_gram(st, g, (int)M, svox.p, ssub.p, d_gram.p, d_wsum.p);
-    // Replicated across ranks, but the Gram blocks are accumulated with fp64 atomics (summation order differs from run to run): every rank
-    // takes the AVERAGE of all ranks' blocks, so the lighting — and with it every replicated row — is bit-identical everywhere.
-    const int world = (c->comm && c->comm->world > 1) ? c->comm->world : 1;
-    if (world > 1) {
+    // Sharded (lighting_svsh.cpp:196-253 is the data term): the subvolume-sorted list of eligible voxels is cut into `world` contiguous
+    // slices, a rank accumulates the Gram blocks of ITS slice only, and one all-reduce (sum) of S x 100 doubles + the weight sum gives every rank the
+    // same totals — the all-reduce hands out one result, so the lighting, and with it every replicated row, is bit-identical on all ranks.
+    const int world = (c->comm && (c->comm->world > 1 || c->comm->force)) ? c->comm->world : 1, me = world > 1 ? c->comm->rank : 0;
+    const long long m0 = (M * me) / world, m1 = (M * (me + 1)) / world;
+    if (m1 > m0) launch_sh_gram(st, g, (int)(m1 - m0), svox.p + m0, ssub.p + m0, d_gram.p, d_wsum.p);
+    if (c->comm && (c->comm->world > 1 || c->comm->force)) {
         if (c->comm->allreduce_sum(d_gram.p, (size_t)S * 100, st) || c->comm->allreduce_sum(d_wsum.p, 1, st)) return ctx_fail(c, I3D_ERR_COMM, "i3d_estimate_sh: all-reduce failed");
     }
     ShSystem sys; sys.S = S; sys.G.resize((size_t)S * 100);
@@ -224,7 +226,6 @@ int estimate_sh(i3d_context* c, float subvolume_size, double lambda_reg, double 
     CTX_HIP(c, hipMemcpyAsync(sys.G.data(), d_gram.p, sizeof(double) * (size_t)S * 100, hipMemcpyDeviceToHost, st));
     CTX_HIP(c, hipMemcpyAsync(&wsum, d_wsum.p, sizeof(double), hipMemcpyDeviceToHost, st));
     CTX_HIP(c, hipStreamSynchronize(st));
-    if (world > 1) { const double inv = 1.0 / (double)world; for (double& v : sys.G) v *= inv; wsum *= inv; }
 
     // ---- neighbour pairs between subvolumes (6-ring, both directions) ----
     auto unpack = [](unsigned long long k, int& x, int& y, int& z) { x = (int)(k & 0x1fffff) - (1 << 20); y = (int)((k >> 21) & 0x1fffff) - (1 << 20); z = (int)((k >> 42) & 0x1fffff) - (1 << 20); };

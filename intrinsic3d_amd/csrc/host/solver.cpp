@@ -44,7 +44,7 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->aflags.alloc(Acap)); CTX_HIP(c, c->nrows.alloc(Acap)); CTX_HIP(c, c->anbr.alloc(Acap * NUM_NBR));
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8));
-    { const size_t nt = (size_t)tile_plan_tiles((int)Acap), nh = nt * (size_t)tile_plan_hmax();
+    { const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512), nh = nt * (size_t)tile_plan_hmax_of(512);        // the 512-entry geometry needs the most slots (3 per entry; 1024: 2)
       CTX_HIP(c, c->tp_lnbr.alloc(Acap * 9)); CTX_HIP(c, c->tp_eaw.alloc(Acap * 6)); CTX_HIP(c, c->tp_halo_idx.alloc(nh)); CTX_HIP(c, c->tp_halo_cnt.alloc(nt)); CTX_HIP(c, c->tp_iota.alloc(nh));
       CTX_HIP(c, c->tp_ext_e.alloc(nh)); CTX_HIP(c, c->tp_ext_pos.alloc(nh)); CTX_HIP(c, c->tp_qh.alloc(2 * nh)); CTX_HIP(c, c->tp_overflow.alloc(1));
       CTX_HIP(c, c->tp_ext_off.alloc(Acap + (size_t)SHARD_ALIGN * ((c->comm ? c->comm->world : 1) + 1) + 8));      // chunk + 1 offsets (chunk >= A, a multiple of the slice alignment)
@@ -62,7 +62,7 @@ static int alloc_rows(i3d_context* c, int slots) {
         CTX_HIP(c, c->need_mask.alloc(Acap)); CTX_HIP(c, c->halo_items.alloc(cap)); CTX_HIP(c, c->halo_sorted.alloc(cap)); CTX_HIP(c, c->halo_count.alloc(1));
         CTX_HIP(c, c->halo_send_idx.alloc(cap)); CTX_HIP(c, c->halo_recv_idx.alloc(cap)); CTX_HIP(c, c->halo_send_buf.alloc(2 * cap)); CTX_HIP(c, c->halo_recv_buf.alloc(2 * cap));
         CTX_HIP(c, c->halo_temp.alloc(halo_sort_temp_bytes((int)cap)));
-        const size_t nt = (size_t)tile_plan_tiles((int)Acap) + 1; CTX_HIP(c, c->tile_flag.alloc(nt)); CTX_HIP(c, c->ghost_tiles.alloc(nt));
+        const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512) + 1; CTX_HIP(c, c->tile_flag.alloc(nt)); CTX_HIP(c, c->ghost_tiles.alloc(nt));
     }
     CTX_HIP(c, c->d_scal.alloc(32)); CTX_HIP(c, c->d_xshared.alloc((size_t)6 * c->K + 9)); CTX_HIP(c, c->d_xcshared.alloc((size_t)6 * c->K + 9));
     CTX_HIP(c, c->d_pcg.alloc(1)); CTX_HIP(c, c->d_pcg2.alloc(2));
@@ -114,7 +114,7 @@ static int shard_plan(i3d_context* c) {
     launch_mark_compute(s, r0, c->cflag.p);
     CTX_HIP(c, rocprim::exclusive_scan(c->scan_tmp.p, c->scan_tmp_bytes, c->cflag.p, c->cscan.p, 0, (size_t)c->A, rocprim::plus<int>(), s));
     launch_compact_list(s, c->A, c->cflag.p, c->cscan.p, c->clist.p);
-    const int T = tile_plan_T(), ntiles = tile_plan_tiles(c->A);
+    const int T = c->plan_T(), ntiles = tile_plan_tiles_of(c->A, T);
     CTX_HIP(c, hipMemsetAsync(c->need_mask.p, 0, sizeof(unsigned long long) * (size_t)c->A, s));
     CTX_HIP(c, hipMemsetAsync(c->halo_count.p, 0, sizeof(int), s));
     CTX_HIP(c, hipMemsetAsync(c->tile_flag.p, 0, sizeof(int) * (size_t)(ntiles + 1), s));
@@ -189,17 +189,36 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     CTX_HIP(c, hipStreamSynchronize(s));
     c->A = tail[0] + tail[1];
     { TimedScope t(c, I3D_K_CLASSIFY); launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
-    c->tile_ok = false;
-    if (!sharded(c)) { shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; c->slice = c->chunk; }
-    else {      // owned range + compute list + halo lists + ghost tiles (every rank derives them from the replicated work list: no communication)
-        int rc = shard_plan(c); if (rc) return rc;
+    c->tile_ok = false; c->tile_T = 0;
+    if (!sharded(c)) {
+        shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; c->slice = c->chunk;
+        RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
+        CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n));
+    } else {
+        // owned range + compute list + halo lists + ghost tiles (every rank derives them from the replicated work list: no communication), then the tile plan.
+        // A sharded run has no untiled operator: when the halo of a 512-entry tile does not fit anywhere (the ranks agree: max over ranks), all of them plan
+        // again with 1024-entry tiles and 2048 halo slots (a third fewer tile boundaries; one workgroup per CU) before anything is built on the plan.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int rc = shard_plan(c); if (rc) return rc;
+            { RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
+              CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n)); }
+            launch_fill_d(s, 1, c->d_scal.p + 20, 0.0); launch_int_to_double(s, c->tp_overflow.p, c->d_scal.p + 20);
+            rc = allreduce(c, c->d_scal.p + 20, 1); if (rc) return rc;
+            double over = 0.0; rc = read_doubles(c, c->d_scal.p + 20, 1, &over); if (rc) return rc;
+            if (over == 0.0) break;
+            if (c->plan_T() == 1024) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: a 1024-entry tile of the operator pass reaches more than 2048 foreign entries");
+            std::fprintf(stderr, "[i3d] sharded operator pass: a 512-entry tile's halo does not fit, planning again with 1024-entry tiles\n");
+            c->tile_T = 1024;
+        }
         // rows are only built on the compute list: everything else on the tiles this rank runs must be inert
         CTX_HIP(c, hipMemsetAsync(c->nrows.p, 0, (size_t)c->A, s)); CTX_HIP(c, hipMemsetAsync(c->regflags.p, 0, (size_t)c->A, s));
     }
-    { RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
-      CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n)); }
     RowView r = c->row_view();
     { TimedScope t(c, I3D_K_OBSERVE); launch_observe(s, g, r, p, c->d_frames.p); }
+    // the reference's three-way split (nls_solver.cpp:66-67,101): time_add = collecting the residuals (addVoxelResiduals: classification, observations),
+    // time_build = buildProblem (cost functions, weight normalisation), time_solve.  One extra synchronisation per outer iteration marks the boundary.
+    CTX_HIP(c, hipStreamSynchronize(s));
+    c->t_add_end = now_s();
     { TimedScope t(c, I3D_K_BUILD); launch_build(s, g, r, p, c->d_frames.p, true, nullptr, c->d_partials.p); }
     { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan(), sharded(c) ? c->cflag.p : nullptr); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
@@ -208,10 +227,11 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     int tp_over = 1;
     CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
     double sums[9]; { int rc = read_doubles(c, c->d_scal.p, 9, sums); if (rc) return rc; }
+    if (sharded(c) && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "assemble: a peer-to-peer exchange timed out (a rank stopped taking part)");
     c->tile_ok = tp_over == 0;       // a halo that does not fit (pathological grids) -> the untiled operator pass (single rank only)
     if (!sharded(c) && !c->tile_ok) std::fprintf(stderr, "[i3d] operator pass: a tile's halo does not fit, using the untiled pass (k_eg_jtjp + k_gather)\n");
-    if (sharded(c) && !c->tile_ok) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: a tile of the operator pass reaches more foreign entries than its halo holds");
-    { const char* e = std::getenv("I3D_NO_TILE"); if (e && e[0] == '1') c->tile_ok = false; }      // tests of the fallback (k_eg_jtjp + k_gather)
+    if (sharded(c) && !c->tile_ok) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: the tile plan overflowed after it had been accepted");      // (cannot happen: agreed on above)
+    if (!sharded(c)) { const char* e = std::getenv("I3D_NO_TILE"); if (e && e[0] == '1') c->tile_ok = false; }      // tests of the single-rank fallback (k_eg_jtjp + k_gather); a sharded run has no untiled pass
     sums[5] = sums[1]; sums[6] = sums[2];
     const double lambda[4] = {cfg.lambda_g, varying_lambda(iteration, cfg.iterations, cfg.lambda_r0, cfg.lambda_r1),
                               varying_lambda(iteration, cfg.iterations, cfg.lambda_s0, cfg.lambda_s1), cfg.lambda_a};
@@ -310,7 +330,9 @@ static int eval_cost_launch(i3d_context* c, const OptParams& p, bool candidate, 
 }
 static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames, double* cost) {
     int rc = eval_cost_launch(c, p, candidate, frames); if (rc) return rc;
-    return read_doubles(c, c->d_scal.p + 16, 1, cost);
+    rc = read_doubles(c, c->d_scal.p + 16, 1, cost); if (rc) return rc;
+    if (sharded(c) && c->comm->health(c->stream)) return ctx_fail(c, I3D_ERR_COMM, "cost evaluation: a peer-to-peer exchange timed out (a rank stopped taking part)");
+    return I3D_OK;
 }
 
 // CGNR (ConjugateGradientsSolver) on (S J^T W J S + D^2) x = b, x0 = 0.  No host synchronisation inside an iteration.
@@ -595,11 +617,11 @@ int optimize(i3d_context* c, const i3d_optimizer_config& cfg, i3d_iteration_stat
         const double t0 = now_s();
         int rc = assemble(c, cfg, itr, p, st); if (rc) return rc;
         const double t1 = now_s();
-        st->time_add = t1 - t0;
+        st->time_add = (c->t_add_end > t0 ? c->t_add_end : t1) - t0; st->time_build = t1 - (c->t_add_end > t0 ? c->t_add_end : t1);
         if (c->n_active > 0) { rc = lm_solve(c, cfg, p, st, cfg.carry_trust_radius ? carried_radius : 1e4); if (rc) return rc;
                                if (st->final_radius > 0.0) carried_radius = st->final_radius; }
         const double t2 = now_s();
-        st->time_solve = t2 - t1; st->time_build = 0.0;
+        st->time_solve = t2 - t1;
         if (cfg.verbose) std::printf("[i3d] itr %d rows %lld/%lld/%lld/%lld valid %lld cost %.9e -> %.9e (add %.3f ms, solve %.3f ms)\n", itr,
                                      (long long)st->rows[0], (long long)st->rows[1], (long long)st->rows[2], (long long)st->rows[3], (long long)st->valid_voxels,
                                      st->cost_initial, st->cost_final, st->time_add * 1e3, st->time_solve * 1e3);

@@ -175,6 +175,50 @@ def test_gpu_matches_committed_golden(oracle):
     ctx.close(); g.free(); fr.free()
 
 
+def _run_sharded(setup, W, cfg):
+    """W simulated ranks (host threads, one GPU) through one optimize call: (contexts, per-rank stats)"""
+    import threading
+    from intrinsic3d_amd import binding
+    sc = setup["sc"]; a0 = setup["arrays"]; vsh = setup["vsh"]
+    L = binding.load()
+    shared = L.i3d_comm_sim_create(W)
+    ctxs = [helpers.gpu_context(sc, a0, vsh) for _ in range(W)]
+    for r, c in enumerate(ctxs):
+        c.comm_init_sim(shared, r)
+    out = [None] * W; err = [None] * W
+
+    def run(r):
+        try:
+            out[r] = ctxs[r].optimize(cfg)
+        except Exception as e:      # surface failures instead of deadlocking the other ranks silently
+            err[r] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    [t.start() for t in th]; [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th), "sharded run hung"
+    assert all(e is None for e in err), err
+    return L, shared, ctxs, out
+
+
+def test_sharded_run_survives_a_tile_halo_that_does_not_fit(setup, monkeypatch, capfd):
+    """A sharded run has no untiled operator pass to fall back to.  When the halo of a 512-entry tile does not fit on ANY rank (forced here: the plan is
+    told that such a tile has 48 halo slots), all ranks agree (max all-reduce of the overflow flag) and plan again with 1024-entry tiles — then the
+    result must be the single-rank one.  Without the knob the same scene runs on 512-entry tiles."""
+    O = setup["O"]
+    cfg = helpers.gpu_cfg(helpers.oracle_cfg(O, setup["thres"], iterations=2, cg_fixed_iterations=12))
+    ref = helpers.gpu_context(setup["sc"], setup["arrays"], setup["vsh"])
+    rst = ref.optimize(cfg); rsdf, ralb = ref.get_grid(); ref.close()
+    monkeypatch.setenv("I3D_EGT_HMAX_LIMIT", "48")
+    L, shared, ctxs, out = _run_sharded(setup, 2, cfg)
+    assert "planning again with 1024-entry tiles" in capfd.readouterr().err
+    for r, c in enumerate(ctxs):
+        sdf, alb = c.get_grid()
+        for s1, s2 in zip(rst, out[r]):
+            assert list(s1.rows) == list(s2.rows) and list(s1.step_accepted[:s1.num_attempts]) == list(s2.step_accepted[:s2.num_attempts])
+        assert np.abs(sdf - rsdf).max() <= 1e-4 * np.abs(rsdf).max() and np.abs(alb - ralb).max() <= 1e-4 * np.abs(ralb).max()
+        c.close()
+    L.i3d_comm_sim_destroy(shared)
+
+
 def test_sharded_ranks_match_single_rank(setup):
     """The SPMD path (tile-aligned owned ranges, compute lists with ghost entries, ghost tiles of the operator pass, rim exchange of the
     operator input, reduced PCG scalars / camera block) with W ranks simulated by W host threads on ONE GPU (i3d_comm_init_sim) must
