@@ -99,6 +99,18 @@ def test_deep_fixed_pcg_matches_oracle(slice_setup):
     assert sum(r[2].n_attempts for r in runs) >= 4             # rejected attempts (radius re-discovery, optimizer.cpp:138) are part of the comparison
 
 
+def test_untiled_fallback_at_bench_depth(slice_setup, monkeypatch):
+    """The round-1 operator (k_eg_jtjp + k_gather, six launches per pass) is what a single rank falls back to when a tile's halo does not fit; it stays in
+    the library for that case only, so it gets the same bar as the tiled pass: 30 PCG iterations per attempt against the fp64 oracle."""
+    monkeypatch.setenv("I3D_NO_TILE", "1")
+    runs = _run_both(slice_setup, 30)
+    for ref, ocam, so, dev, dcam, sg, start in runs:
+        assert list(so.rows) == list(sg.rows)
+        assert list(so.accepted[:so.n_attempts]) == list(sg.step_accepted[:sg.num_attempts])
+        assert list(so.cg_iters[:so.n_attempts]) == list(sg.pcg_iterations[:sg.num_attempts]) == [30] * so.n_attempts
+        _check_fields(ref, ocam, dev, dcam, start)
+
+
 def test_native_pcg_stop_matches_oracle(slice_setup):
     """Ceres' quadratic-model stop (eta = 0.1) decided on the device from fp32 vectors / fp64 reductions vs the fp64 oracle: the
     iteration count of every LM attempt, the accept / reject sequence and the accepted step."""
