@@ -168,7 +168,9 @@ int i3d_write_intrinsics(const char* path, int32_t width, int32_t height, const 
     for (int i = 0; i < 5; ++i) f << fmt_default((float)dist[i]) << (i < 4 ? " " : "\n");
     return f.good() ? I3D_OK : I3D_ERR_IO;
 }
-// Camera::load: returns I3D_ERR_IO when the file cannot be read (the reference then falls back to fx=fy=525, cx=319.5, cy=239.5, zero distortion)
+// Camera::load (camera.cpp:202-243): returns I3D_ERR_IO when the file cannot be read; the outputs then hold what a default-constructed reference Camera holds
+// after its failed load: 640 x 480 (camera.cpp:41-47), fx=fy=525, cx=319.5, cy=239.5, zero distortion.  Stricter than the reference in one respect: a file that
+// opens but ends early is an error here, where the reference's unchecked stream reads report success with stale values in the missing entries.
 int i3d_read_intrinsics(const char* path, int32_t* width, int32_t* height, double* intr, double* dist) {
     if (!path || !intr || !dist) return I3D_ERR_INVALID_ARGUMENT;
     std::ifstream f(path);
@@ -176,7 +178,7 @@ int i3d_read_intrinsics(const char* path, int32_t* width, int32_t* height, doubl
     bool ok = f.is_open() && (bool)(f >> w >> h);
     for (int i = 0; ok && i < 9; ++i) ok = (bool)(f >> K[i]);
     for (int i = 0; ok && i < 5; ++i) ok = (bool)(f >> d[i]);
-    if (!ok) { intr[0] = 525.0; intr[1] = 525.0; intr[2] = 319.5; intr[3] = 239.5; for (int i = 0; i < 5; ++i) dist[i] = 0.0; return I3D_ERR_IO; }
+    if (!ok) { intr[0] = 525.0; intr[1] = 525.0; intr[2] = 319.5; intr[3] = 239.5; for (int i = 0; i < 5; ++i) dist[i] = 0.0; if (width) *width = 640; if (height) *height = 480; return I3D_ERR_IO; }
     if (width) *width = w; if (height) *height = h;
     intr[0] = K[0]; intr[1] = K[4]; intr[2] = K[2]; intr[3] = K[5];
     for (int i = 0; i < 5; ++i) dist[i] = d[i];

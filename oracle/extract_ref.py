@@ -56,9 +56,12 @@ CHUNKS = [
     ("grid_class",           "include/nv/sparse_voxel_grid.h", 84, 161, "template <class T>", "};"),
     ("grid_impl",            "src/sparse_voxel_grid.cpp", 43, 467, "template <class T>", "}"),
     ("grid_frustum",         "src/sparse_voxel_grid.cpp", 572, 602, "template <class T>", "}"),
+    ("grid_save",            "src/sparse_voxel_grid.cpp", 483, 516, "template <class T>", "}"),
+    ("grid_load",            "src/sparse_voxel_grid.cpp", 531, 569, "template <class T>", "}"),
     ("camera_class",         "include/nv/camera.h", 47, 89, "class Camera", "};"),
     ("camera_impl",          "src/camera.cpp", 41, 199, "Camera::Camera() :", "}"),
     ("camera_convert",       "src/camera.cpp", 277, 311, "void Camera::print", "}"),
+    ("camera_load_save",     "src/camera.cpp", 202, 274, "bool Camera::load", "}"),
     ("math_decl",            "include/nv/math.h", 44, 65, "namespace math", "} // namespace math"),
     ("math_impl",            "src/math.cpp", 43, 163, "float robustKernel", "}"),
     ("operators_impl",       "src/sdf/operators.cpp", 45, 77, "Vec3f voxelCenterToIso(const SparseVoxelGrid", "}"),

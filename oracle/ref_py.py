@@ -109,3 +109,54 @@ def mc_tables():
     edge = np.zeros(256, np.int32); tri = np.zeros((256, 16), np.int32)
     lib().ref_mc_tables(_p(edge), _p(tri))
     return edge, tri
+
+
+# --- on-disk formats: the reference's own writers / readers (sparse_voxel_grid.cpp:484-569, camera.cpp:202-274)
+def _raw():
+    L = C.CDLL(LIB_PATH)
+    L.ref_fusion_load.restype = C.c_void_p; L.ref_grid_load.restype = C.c_void_p
+    L.ref_fusion_size.restype = C.c_int64; L.ref_grid_size.restype = C.c_int64
+    vp = C.c_void_p
+    L.ref_fusion_save.argtypes = [vp, C.c_char_p]; L.ref_grid_save.argtypes = [vp, C.c_char_p]; L.ref_fusion_size.argtypes = [vp]; L.ref_fusion_free.argtypes = [vp]
+    L.ref_fusion_export.argtypes = [vp] * 5; L.ref_fusion_header.argtypes = [vp] * 4
+    return L
+
+
+def tsdf_save(fusion, path):
+    """SparseVoxelGrid<Voxel>::save of a `pipeline().Fusion` object's grid"""
+    assert _raw().ref_fusion_save(fusion.h, str(path).encode()) == 1
+
+
+def tsdf_load(path):
+    """SparseVoxelGrid<Voxel>::load, then the records in the loaded container's iteration order + the three header floats; None if the file does not open"""
+    L = _raw(); h = L.ref_fusion_load(str(path).encode())
+    if not h:
+        return None
+    h = C.c_void_p(h); n = int(L.ref_fusion_size(h))
+    keys = np.zeros((n, 3), np.int32); sdf = np.zeros(n, np.float32); w = np.zeros(n, np.float32); col = np.zeros((n, 3), np.uint8)
+    L.ref_fusion_export(h, _p(keys), _p(sdf), _p(w), _p(col))
+    vs = C.c_float(); tr = C.c_float(); iws = C.c_float(); L.ref_fusion_header(h, C.byref(vs), C.byref(tr), C.byref(iws))
+    L.ref_fusion_free(h)
+    return dict(keys=keys, sdf=sdf, weight=w, color=col, voxel_size=np.float32(vs.value), truncation=np.float32(tr.value), integration_weight_sample=np.float32(iws.value))
+
+
+def sbr_save(grid, path):
+    """SparseVoxelGrid<VoxelSBR>::save of a `pipeline().Grid`"""
+    assert _raw().ref_grid_save(grid.h, str(path).encode()) == 1
+
+
+def sbr_load(path):
+    """SparseVoxelGrid<VoxelSBR>::load -> `pipeline().Grid` (None if the file does not open)"""
+    h = _raw().ref_grid_load(str(path).encode())
+    return pipeline().Grid(C.c_void_p(h)) if h else None
+
+
+def camera_save(path, w, h, k4, dist5):
+    k = np.ascontiguousarray(k4, np.float32); d = np.ascontiguousarray(dist5, np.float32)
+    return _raw().ref_camera_save(str(path).encode(), int(w), int(h), _p(k), _p(d)) == 1
+
+
+def camera_load(path):
+    w = C.c_int32(); h = C.c_int32(); k = np.zeros(4, np.float32); d = np.zeros(5, np.float32)
+    ok = _raw().ref_camera_load(str(path).encode(), C.byref(w), C.byref(h), _p(k), _p(d)) == 1
+    return ok, w.value, h.value, k, d

@@ -66,11 +66,14 @@ namespace SDFOperators {
 
 #include "gen/camera_impl.inc"
 #include "gen/camera_convert.inc"
+#include "gen/camera_load_save.inc"
 namespace math {
 #include "gen/math_impl.inc"
 }  // namespace math
 #include "gen/grid_impl.inc"
 #include "gen/grid_frustum.inc"
+#include "gen/grid_save.inc"
+#include "gen/grid_load.inc"
 namespace SDFOperators {
 #include "gen/operators_impl.inc"
 #include "gen/operators_sdf_weight.inc"
@@ -628,6 +631,33 @@ int64_t ref_fusion_size(void* fp) { return (int64_t)((RefFusion*)fp)->grid->numV
 void ref_fusion_export(void* fp, int32_t* keys, float* sdf, float* weight, uint8_t* color) {
     auto* g = ((RefFusion*)fp)->grid; size_t i = 0;
     for (auto it = g->begin(); it != g->end(); ++it, ++i) { for (int c = 0; c < 3; ++c) { keys[3 * i + c] = it->first[c]; color[3 * i + c] = it->second.color[c]; } sdf[i] = it->second.sdf; weight[i] = it->second.weight; }
+}
+/* on-disk formats, the reference's own writers / readers (sparse_voxel_grid.cpp:484-569, camera.cpp:202-274) */
+int32_t ref_fusion_save(void* fp, const char* path) { return ((RefFusion*)fp)->grid->save(path) ? 1 : 0; }
+void* ref_fusion_load(const char* path) {
+    auto* f = new RefFusion; f->grid = SparseVoxelGrid<Voxel>::create(0.004f, 0.1f, 5.0f);
+    if (!f->grid->load(path)) { delete f->grid; delete f; return nullptr; }
+    return f;
+}
+void ref_fusion_header(void* fp, float* voxel_size, float* truncation, float* integration_weight_sample) {
+    auto* g = ((RefFusion*)fp)->grid; *voxel_size = g->voxel_size_; *truncation = g->truncation_; *integration_weight_sample = g->integration_weight_sample_;
+}
+int32_t ref_grid_save(void* gp, const char* path) { return ((SparseVoxelGrid<VoxelSBR>*)gp)->save(path) ? 1 : 0; }
+void* ref_grid_load(const char* path) {
+    auto* g = SparseVoxelGrid<VoxelSBR>::create(0.004f, 0.1f, 5.0f);
+    if (!g->load(path)) { delete g; return nullptr; }
+    return g;
+}
+int32_t ref_camera_save(const char* path, int32_t w, int32_t h, const float* k4, const float* dist5) {
+    Mat3f K = Mat3f::Identity(); K(0, 0) = k4[0]; K(1, 1) = k4[1]; K(0, 2) = k4[2]; K(1, 2) = k4[3];
+    Camera cam(K, w, h); Vec5f d; for (int i = 0; i < 5; ++i) d[i] = dist5[i]; cam.setDistortion(d);
+    return cam.save(path) ? 1 : 0;
+}
+int32_t ref_camera_load(const char* path, int32_t* w, int32_t* h, float* k4, float* dist5) {
+    Camera cam; const bool ok = cam.load(path);
+    *w = cam.width(); *h = cam.height(); const Mat3f K = cam.intrinsics(); k4[0] = K(0, 0); k4[1] = K(1, 1); k4[2] = K(0, 2); k4[3] = K(1, 2);
+    const Vec5f d = cam.distortion(); for (int i = 0; i < 5; ++i) dist5[i] = d[i];
+    return ok ? 1 : 0;
 }
 void ref_fusion_free(void* fp) { auto* f = (RefFusion*)fp; delete f->grid; delete f; }
 void ref_erode_discontinuities(int32_t w, int32_t h, const float* in, int32_t window, float max_diff, float* out) {

@@ -260,3 +260,99 @@ def test_small_helpers_equal_the_reference_code(oracle, R):
     assert np.array_equal(oracle.depth_down(d), R.depth_down(d))
     out_cam = np.array([130.0, 131.0, 63.5, 47.5], np.float32)
     assert np.array_equal(oracle.resize_depth(d, cam, 128, 96, out_cam), R.resize_depth(d, cam, 128, 96, out_cam))
+
+
+def _by_key(d):
+    o = np.lexsort((d["keys"][:, 2], d["keys"][:, 1], d["keys"][:, 0]))
+    return {k: (v[o] if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == len(o) else v) for k, v in d.items()}
+
+
+def test_tsdf_files_equal_the_reference_writer_and_reader(R, tmp_path):
+    """SparseVoxelGrid<Voxel>::save / load (sparse_voxel_grid.cpp:484-569) of the reference on a fused grid vs the product's host/io.cpp: the product
+    reads the reference's file record for record in file order; the product's file of the same records equals the reference's byte for byte outside the
+    struct's pad byte (record offset 23, indeterminate in the reference); the reference's load() reads the product's file."""
+    from intrinsic3d_amd import binding
+    from oracle import ref_py
+    sc, frames = _fusion_frames(11, True)
+    intr = sc["intr"].astype(np.float32)
+    f = R.Fusion(sc["voxel_size"], 0.1, 10.0)
+    for d, bgr, T in frames[:2]:
+        f.integrate(d, intr, bgr, intr, T, 2)
+    f.finish(3); rec = f.export(); n = len(rec["sdf"]); assert n > 2000
+    ref_path = tmp_path / "ref.tsdf"; ref_py.tsdf_save(f, ref_path)
+    got = binding.tsdf_read(ref_path)
+    for k in ("keys", "sdf", "weight", "color"):
+        assert np.array_equal(got[k], rec[k]), k
+    assert got["voxel_size"] == np.float32(sc["voxel_size"]) and got["truncation"] == np.float32(sc["voxel_size"]) * np.float32(5)
+    our_path = tmp_path / "ours.tsdf"
+    binding.tsdf_write(our_path, got["voxel_size"], got["keys"], got["sdf"], got["weight"], got["color"], truncation=got["truncation"],
+                       integration_weight_sample=got["integration_weight_sample"], max_load_factor=got["max_load_factor"])
+    a = np.frombuffer(open(ref_path, "rb").read(), np.uint8); b = np.frombuffer(open(our_path, "rb").read(), np.uint8)
+    assert a.size == b.size == 24 + 24 * n and np.array_equal(a[:24], b[:24])
+    ra = a[24:].reshape(n, 24); rb = b[24:].reshape(n, 24)
+    assert np.array_equal(ra[:, :23], rb[:, :23])
+    back = ref_py.tsdf_load(our_path)
+    assert back["voxel_size"] == got["voxel_size"] and back["truncation"] == got["truncation"] and back["integration_weight_sample"] == got["integration_weight_sample"]
+    x, y = _by_key(back), _by_key(rec)                                      # a re-filled hash map iterates in its own order
+    for k in ("keys", "sdf", "weight", "color"):
+        assert np.array_equal(x[k], y[k]), k
+    assert ref_py.tsdf_load(tmp_path / "missing.tsdf") is None
+    with pytest.raises(binding.I3DError):
+        binding.tsdf_read(tmp_path / "missing.tsdf")
+
+
+def test_voxel_sbr_files_equal_the_reference_writer_and_reader(R, tmp_path):
+    """SparseVoxelGrid<VoxelSBR>::save / load of the reference (the per-level dumps Intrinsic3D writes) vs i3d_sbr_write / i3d_sbr_read."""
+    from intrinsic3d_amd import binding
+    from oracle import ref_py
+    sc = _mangled_scene(6)
+    g = R.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+    e = g.export(); n = len(e["sdf"]); rng = np.random.default_rng(0)
+    g.import_fields(e["sdf"] + rng.normal(0, 1e-4, n), rng.uniform(0.1, 0.9, n), None); e = g.export()
+    ref_path = tmp_path / "ref.sbr"; ref_py.sbr_save(g, ref_path)
+    got = binding.sbr_read(ref_path)
+    for k in ("keys", "sdf", "sdf_refined", "albedo", "weight", "color"):
+        assert np.array_equal(got[k], e[k]), k
+    our_path = tmp_path / "ours.sbr"
+    hdr = binding.tsdf_read.__globals__["C"]                                # header floats come back through the generic header reader
+    vs, tr, iw, ml = hdr.c_float(), hdr.c_float(), hdr.c_float(), hdr.c_float(); cnt = hdr.c_uint64()
+    assert binding.load().i3d_tsdf_read_header(str(ref_path).encode(), hdr.byref(vs), hdr.byref(tr), hdr.byref(iw), hdr.byref(cnt), hdr.byref(ml)) == 0
+    binding.sbr_write(our_path, vs.value, got, truncation=tr.value, integration_weight_sample=iw.value, max_load_factor=ml.value)
+    a = np.frombuffer(open(ref_path, "rb").read(), np.uint8); b = np.frombuffer(open(our_path, "rb").read(), np.uint8)
+    assert a.size == b.size == 24 + 44 * n and np.array_equal(a[:24], b[:24])
+    ra = a[24:].reshape(n, 44); rb = b[24:].reshape(n, 44)
+    named = np.r_[0:12, 12:20, 20:24, 24:27, 28:36, 36:44]                  # key | sdf | weight | colour | albedo | sdf_refined; byte 27 is padding
+    assert np.array_equal(ra[:, named], rb[:, named])
+    back = ref_py.sbr_load(our_path); x, y = _by_key(back.export()), _by_key(e)
+    for k in ("keys", "sdf", "sdf_refined", "albedo", "weight", "color"):
+        assert np.array_equal(x[k], y[k]), k
+    assert x["voxel_size"] == y["voxel_size"]
+
+
+def test_intrinsics_files_equal_the_reference_writer_and_reader(R, tmp_path):
+    """Camera::save / Camera::load (camera.cpp:202-274) of the reference vs i3d_write_intrinsics / i3d_read_intrinsics: same text, same parsed floats,
+    same defaults when the file is missing."""
+    from intrinsic3d_amd import binding
+    from oracle import ref_py
+    rng = np.random.default_rng(4)
+    cases = [(640, 480, [525.0, 525.0, 319.5, 239.5], [0, 0, 0, 0, 0]),
+             (1296, 968, [1170.187988, 1170.187988, 647.75, 483.75], [0.01, -0.0234567891, 0.0, 1e-5, -3.3e-7]),
+             (320, 240, [1e6 + 0.5, 123456.789, 0.000123456, 1e-7], [1e10, -1e-10, 123456789.0, 0.1, 100000.0])]
+    for _ in range(20):
+        cases.append((int(rng.integers(1, 4000)), int(rng.integers(1, 4000)), (rng.uniform(50, 3000, 4) * rng.choice([1, 1e-3, 1e3], 4)).tolist(),
+                      (rng.normal(0, 0.1, 5) * rng.choice([1, 1e-5, 1e4], 5)).tolist()))
+    for i, (w, h, k, d) in enumerate(cases):
+        a = tmp_path / f"ref_{i}.txt"; b = tmp_path / f"ours_{i}.txt"
+        assert ref_py.camera_save(a, w, h, k, d)
+        binding.write_intrinsics(b, w, h, k, d)
+        assert open(a).read() == open(b).read(), (i, open(a).read(), open(b).read())
+        ok_r, wr, hr, kr, dr = ref_py.camera_load(b); ok_o, wo, ho, ko, do = binding.read_intrinsics(a)
+        assert ok_r and ok_o and (wr, hr) == (wo, ho) == (w, h)
+        assert np.array_equal(kr, np.float32(ko)) and np.array_equal(dr, np.float32(do))
+    ok_r, wr, hr, kr, dr = ref_py.camera_load(tmp_path / "nope.txt"); ok_o, wo, ho, ko, do = binding.read_intrinsics(tmp_path / "nope.txt")
+    assert not ok_r and not ok_o and np.array_equal(kr, np.float32(ko)) and np.array_equal(dr, np.float32(do)) and (wr, hr) == (wo, ho) == (640, 480)
+    # the one deliberate difference: a file that ends early.  The reference's stream reads are unchecked (it reports success, the last value read repeated in the missing entries);
+    # the product reports I3D_ERR_IO and hands back the defaults
+    open(tmp_path / "short.txt", "w").write("640 480\n525 0 319.5\n0 525")
+    ok_r, _, _, kr, _ = ref_py.camera_load(tmp_path / "short.txt"); ok_o, _, _, ko, _ = binding.read_intrinsics(tmp_path / "short.txt")
+    assert ok_r and kr[3] == 525.0 and not ok_o and list(ko) == [525.0, 525.0, 319.5, 239.5]
