@@ -25,6 +25,8 @@ namespace i3d {
 // The row set (1.46 GB on the bench workload) is written once per outer iteration and read much later: non-temporal stores, so that it does not
 // displace the keyframe images (245 MB, re-read by every wave) and the voxel state from the last-level cache.
 typedef float v4f_row __attribute__((ext_vector_type(4)));
+typedef float v2f_row __attribute__((ext_vector_type(2)));
+static __device__ inline void st_row2(float2* p, float a, float b) { v2f_row v; v.x = a; v.y = b; __builtin_nontemporal_store(v, reinterpret_cast<v2f_row*>(p)); }
 static __device__ inline void st_row(float4* p, float a, float b, float c, float d) { v4f_row v; v.x = a; v.y = b; v.z = c; v.w = d; __builtin_nontemporal_store(v, reinterpret_cast<v4f_row*>(p)); }
 
 // 4 consecutive taps of one image row as ONE 16-byte load from a 4-byte aligned address.  The pointer is re-typed to the global
@@ -204,7 +206,6 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowVi
             if (WITH_J) {
                 r.regflags[a] = 0; r.ea_free[a] = 0; r.nrows[a] = 0;
                 for (int d = 0; d < 6; ++d) r.ea_w[(size_t)d * Acap + a] = 0.0f;
-                for (int k = 0; k < r.slots; ++k) r.rows[row_index(a, k, 7, r.slots)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
         } else {
         int idx[P_VOX];
@@ -308,7 +309,7 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowVi
                 const size_t ka = (size_t)k * Acap + a;
                 float roww; int f;
                 if (WITH_J) { const float ow = r.obs_w[ka]; f = r.obs_frame[ka]; roww = (ow > 0.0f) ? (float)((double)ow * weight_sdf) : 0.0f; }
-                else { const float4 m = r.rows[row_index(a, k, 7, r.slots)]; const int fb = __float_as_int(m.z); roww = (fb & ROW_FREE_BIT) ? m.x : 0.0f; f = fb & ~ROW_FREE_BIT; }
+                else { const size_t ro = row_scalar_index(a, k, r.slots); const int fb = __float_as_int(r.row_jt()[row_jt_index(a, k, r.slots)].y); roww = (fb & ROW_FREE_BIT) ? r.row_wr[ro].x : 0.0f; f = fb & ~ROW_FREE_BIT; }
                 if (roww == 0.0f) continue;
                 const FrameHot& fc = FR_LDS ? flds[f] : frames[f].hot;
                 // ---- phase 1: values (fp64) ----
@@ -337,6 +338,9 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowVi
                 }
                 if (!WITH_J) { if (ok) cost += 0.5 * (double)roww * p.type_w[0] * res * res; continue; }
                 if (!ok) continue;                                                 // dropped at creation (shading_cost.cpp:136-145)
+                // rows are stored with the row weight folded in (Js = sqrt(w) J, common.hpp RowView).  Every partial below is linear in the four
+                // coefficients c_j, so the fold costs 4 multiplications here instead of 29 at the store
+                { const float sw = sqrtf(roww); cj[0] *= sw; cj[1] *= sw; cj[2] *= sw; cj[3] *= sw; }
                 // ---- phase 2: partials (fp32), accumulated point by point ----
                 float J[P_TOTAL];
 #pragma unroll
@@ -392,13 +396,14 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowVi
 #pragma unroll
                 for (int gq = 0; gq < 7; ++gq)
                     st_row(&r.rows[row_index(a, nout, gq, r.slots)], J[4 * gq], J[4 * gq + 1], J[4 * gq + 2], J[4 * gq + 3]);
-                st_row(&r.rows[row_index(a, nout, 7, r.slots)], roww, (float)res, __int_as_float(f | (vox_free ? ROW_FREE_BIT : 0)), J[28]);
+                const size_t ro = row_scalar_index(a, nout, r.slots);
+                st_row2(&r.row_jt()[row_jt_index(a, nout, r.slots)], J[28], __int_as_float(f | (vox_free ? ROW_FREE_BIT : 0)));
+                st_row2(&r.row_wr[ro], roww, (float)res);
                 ++nout;
             }
         }
         if (WITH_J) {
             r.nrows[a] = (uint8_t)nout;
-            for (int k = nout; k < r.slots; ++k) r.rows[row_index(a, k, 7, r.slots)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         }
     }
@@ -427,7 +432,7 @@ __global__ void __launch_bounds__(256) k_weight_sums(RowView r, double* partials
         if (!(r.aflags[a] & F_ACTIVE)) continue;
         na += 1.0;
         const int nr = r.nrows[a];
-        for (int k = 0; k < nr; ++k) { const float w = r.rows[row_index(a, k, 7, r.slots)].x; s0 += (double)w; if (w != 0.0f) n0 += 1.0; }
+        for (int k = 0; k < nr; ++k) { const float w = r.row_wr[row_scalar_index(a, k, r.slots)].x; s0 += (double)w; if (w != 0.0f) n0 += 1.0; }
         const uint8_t rf = r.regflags[a];
         if (rf & 1) s1 += 1.0;
         if (rf & 2) s2 += 1.0;

@@ -36,9 +36,14 @@ __host__ __device__ inline int slot_rev_nbr(int c) {
 enum : uint8_t { F_VALID = 1, F_ACTIVE = 2, F_RING = 4, F_FREE_SDF = 8, F_FREE_ALB = 16 };
 
 constexpr int MAX_SLOTS = 8;
-constexpr int ROW_PLANES = 8;
-constexpr int ROW_FREE_BIT = 1 << 30;     // set in plane 7 .z when the row has at least one free column
-__host__ __device__ inline size_t row_index(size_t a, int k, int plane, int slots) { return ((((a >> 6) * (size_t)slots + (size_t)k) * ROW_PLANES + (size_t)plane) << 6) + (a & 63); }       // Eg rows kept per voxel (reference default num_observations = 5)
+constexpr int ROW_PLANES = 7;
+constexpr int ROW_FREE_BIT = 1 << 30;     // set in a row's keyframe tag when the row has at least one free column
+// One (64-entry group, slot) block of the row buffer = 7680 B: seven 1 KB planes of float4 (partials 0..27), then one 512 B plane of float2
+// (partial 28, keyframe tag) — see RowView.  row_index: float4 units;  row_jt_index: float2 units of the same buffer
+constexpr int ROW_BLOCK_F4 = 64 * ROW_PLANES + 32;        // 480 float4
+__host__ __device__ inline size_t row_index(size_t a, int k, int plane, int slots) { return ((a >> 6) * (size_t)slots + (size_t)k) * ROW_BLOCK_F4 + ((size_t)plane << 6) + (a & 63); }
+__host__ __device__ inline size_t row_jt_index(size_t a, int k, int slots) { return (((a >> 6) * (size_t)slots + (size_t)k) * ROW_BLOCK_F4 + 64 * ROW_PLANES) * 2 + (a & 63); }
+__host__ __device__ inline size_t row_scalar_index(size_t a, int k, int slots) { return (((a >> 6) * (size_t)slots + (size_t)k) << 6) + (a & 63); }    // one value per row, same wave tiling
 
 // ---- per-keyframe constants, rebuilt on the host (fp64) once per outer iteration ----------------------------
 struct FrameHot {                  // what the build / cost kernels read per row: 144 B, staged in LDS for all keyframes
@@ -116,11 +121,15 @@ struct RowView {                    // per work-list entry a in [0, A): voxels t
     const uint8_t* aflags;          // voxel flags of the entry
     const int* anbr;                // [NUM_NBR][Acap] neighbour table in LIST space (-1 = neighbour not in the list => fixed, contributes 0)
     int* obs_frame; float* obs_w;   // [slots][Acap] observation pass output (ascending weight, 0 = none)
-    // Eg rows of an entry are compacted into its first nrows slots.  A row is 8 float4 = 128 B; rows are stored wave-tiled
-    // (AoSoA): [tile = a/64][slot][plane 0..7][lane = a%64], i.e. one wave reads ONE contiguous 8 KB block per slot.
-    //   planes 0..6: raw partials, columns 0..27 (sdf 0-9, albedo 10-13, pose 14-19, intrinsics 20-23, distortion 24-27)
-    //   plane 7    : x = row weight obs.w*weight_sdf (0 = no row), y = raw residual, z = keyframe | ROW_FREE_BIT (int bits), w = column 28 (p2)
-    float4* rows;
+    // Eg rows of an entry are compacted into its first nrows slots.  What the operator streams per row is 120 B — the 29 partials (SURVEY.md 8(d)'s
+    // 4 B per non-zero) + the row's keyframe id: the row weight is FOLDED into the partials (Js = sqrt(w) J, so J^T W J u = Js^T (Js u) and the
+    // weight is never read); weight and residual sit in a side array only the once-per-iteration kernels read.
+    //   rows   : wave-tiled (AoSoA) [group = a/64][slot] blocks of 7680 B, ONE contiguous block per wave and slot:
+    //              [plane 0..6][lane = a%64] float4: sqrt(w) x columns 0..27 (sdf 0-9, albedo 10-13, pose 14-19, intrinsics 20-23, distortion 24-27), then
+    //              [lane] float2: x = sqrt(w) x column 28 (p2), y = keyframe | ROW_FREE_BIT (int bits)
+    //   row_wr : [group][slot][lane] float2: x = row weight obs.w*weight_sdf (> 0 for every stored row), y = raw residual
+    float4* rows; float2* row_wr;
+    __host__ __device__ float2* row_jt() const { return reinterpret_cast<float2*>(rows); }       // index with row_jt_index
     uint8_t* nrows;                 // [Acap]
     uint8_t* regflags;              // [Acap] bit0 Er row, bit1 Es row, bit2 Es Jacobian is 1 (else 0), bit3 Er row has a free column, bit4 Es free
     float* ea_w;                    // [6][Acap] chroma weight of the Ea row towards 1-ring neighbour d, 0 = none

@@ -109,22 +109,23 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
         }
         const size_t ac = in ? (size_t)a : 0;
         for (int k = 0; k < nr_max; ++k) {
-            const float4* __restrict__ row = r.rows + row_index(ac, k, 0, r.slots);     // 8 planes, 64 float4 apart: one contiguous 8 KB block per wave
+            const float4* __restrict__ row = r.rows + row_index(ac, k, 0, r.slots);     // 7 planes, 64 float4 apart: one contiguous 7 KB block per wave
             float4 j4[7];
 #pragma unroll
             for (int q = 0; q < 7; ++q) j4[q] = ld_row(row + q * 64);
-            const float4 m = ld_row(row + 7 * 64);
+            const size_t ro = row_scalar_index(ac, k, r.slots);
+            const float2 jt = r.row_jt()[row_jt_index(ac, k, r.slots)];
             constexpr int NPV = (MODE == PASS_COLNORM) ? 21 : 6;
             float pv[NPV]; int fsel = 0; bool pvalid = false;
 #pragma unroll
             for (int i = 0; i < NPV; ++i) pv[i] = 0.0f;
-            if (k < nr && m.x != 0.0f) {
-                const float rho = m.x * tw0;
-                const int f = __float_as_int(m.z) & ~ROW_FREE_BIT;
+            if (k < nr) {
+                const float rho = tw0;                       // the row weight is folded into the stored partials (Js = sqrt(w) J)
+                const int f = __float_as_int(jt.y) & ~ROW_FREE_BIT;
                 float J[P_TOTAL];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { J[4 * q] = j4[q].x; J[4 * q + 1] = j4[q].y; J[4 * q + 2] = j4[q].z; J[4 * q + 3] = j4[q].w; }
-                J[28] = m.w;
+                J[28] = jt.x;
                 if (MODE == PASS_COLNORM) {
 #pragma unroll
                     for (int c = 0; c < P_VOX; ++c) acc[c] += rho * J[c] * J[c];
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                   }
                 } else {
                     float t;
-                    if (MODE == PASS_GRAD) t = rho * m.y;
+                    if (MODE == PASS_GRAD) { const float2 wr = r.row_wr[ro]; t = rho * (sqrtf(wr.x) * wr.y); }      // Js^T (tw sqrt(w) r) = J^T W r
                     else {
                         float d = 0.0f;
 #pragma unroll
@@ -303,10 +304,14 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
         for (int o = 32; o > 0; o >>= 1) nr_max = max(nr_max, __shfl_xor(nr_max, o, 64));
         const size_t ac = in ? (size_t)a : 0;
         // first row block on its way before anything else of the tile is touched
-        float4 rwA[8], rwB[8];
-        if (nr_max > 0) { const float4* __restrict__ row = r.rows + row_index(ac, 0, 0, r.slots);
+        float4 rwA[8], rwB[8];                          // planes 0..6 + (column 28, keyframe tag) in [7].xy
+        auto load_block = [&](float4 (&rw)[8], int k) {
+            const float4* __restrict__ row = r.rows + row_index(ac, k, 0, r.slots);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
+            for (int q = 0; q < 7; ++q) rw[q] = ld_row(row + q * 64);
+            { const float2 jt = r.row_jt()[row_jt_index(ac, k, r.slots)]; rw[7].x = jt.x; rw[7].y = jt.y; }
+        };
+        if (nr_max > 0) load_block(rwA, 0);
         // operator input at the 14 stencil unknowns of the voxel -> LDS (0 where the neighbour is not in the list = fixed parameter)
         if (in) {
 #pragma unroll
@@ -316,9 +321,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
                 uvl[c * EG_THREADS] = la >= 0 ? u[c < 10 ? vec_sdf(la, chunk) : vec_alb(la, chunk)] : 0.0f;
             }
         }
-        if (nr_max > 1) { const float4* __restrict__ row = r.rows + row_index(ac, 1, 0, r.slots);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
+        if (nr_max > 1) load_block(rwB, 1);
         // ---- regulariser rows: tr (Er), ts (Es, Jacobian folded in), ta[6] (Ea).  They do not depend on the Eg rows: computed HERE, while
         //      the first two row blocks are in flight, so their index / vector gathers cost no round trip of their own ----
         if (in) {
@@ -348,17 +351,16 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
         for (int c = 0; c < P_VOX; ++c) acc[c] = 0.0f;
 
         auto consume = [&](const float4 (&rw)[8], int k) {
-            const float4 m = rw[7];
             float pv[6]; int fsel = 0; bool pvalid = false;
 #pragma unroll
             for (int i = 0; i < 6; ++i) pv[i] = 0.0f;
-            if (k < nr && m.x != 0.0f) {
-                const float rho = m.x * tw0;
-                const int f = __float_as_int(m.z) & ~ROW_FREE_BIT;
+            if (k < nr) {
+                const float rho = tw0;                       // the row weight is folded into the stored partials
+                const int f = __float_as_int(rw[7].y) & ~ROW_FREE_BIT;
                 float J[P_TOTAL];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { J[4 * q] = rw[q].x; J[4 * q + 1] = rw[q].y; J[4 * q + 2] = rw[q].z; J[4 * q + 3] = rw[q].w; }
-                J[28] = m.w;
+                J[28] = rw[7].x;
                 float d = 0.0f;
 #pragma unroll
                 for (int c = 0; c < P_VOX; ++c) d += J[c] * uvl[c * EG_THREADS];
@@ -384,14 +386,10 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
         };
         for (int k = 0; k < nr_max; k += 2) {                 // slot k is in rwA, slot k+1 (if any) in rwB; a buffer is refilled as soon as it is consumed
             consume(rwA, k);
-            if (k + 2 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 2, 0, r.slots);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
+            if (k + 2 < nr_max) load_block(rwA, k + 2);
             if (k + 1 < nr_max) {
                 consume(rwB, k + 1);
-                if (k + 3 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 3, 0, r.slots);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
+                if (k + 3 < nr_max) load_block(rwB, k + 3);
             }
         }
         if (in) {

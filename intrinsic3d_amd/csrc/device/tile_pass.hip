@@ -116,6 +116,9 @@ __global__ void __launch_bounds__(256) k_eaw_sym(RowView r, const int* __restric
 
 // ---- the pass ---------------------------------------------------------------------------------------------------------------------
 static __device__ inline void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+struct RowBlock { float4 p[7]; float j28; int tag; };  // one stored Eg row in registers: planes 0..6 + column 28 + keyframe tag
+typedef unsigned v4u_b __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_b __attribute__((ext_vector_type(2)));
 template <int NW> static __device__ inline int unpack16(const unsigned (&w)[NW], int j) { return (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu); }
 
 // T lanes = T entries per tile.  SLOTS > 0: the row loop is unrolled for exactly that many observation slots and EVERY slot is requested
@@ -200,19 +203,25 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     // the tile in flight (mutable: with PIPE the loads of the next tile overwrite them while the current one is still being pulled)
     constexpr int NQH = (HMAX + T - 1) / T;
     int tile = 0, base = 0, a = 0, H = 0, nr_ld = 0; bool in = false, owned = false; size_t ac = 0;
-    float us = 0.0f, ua = 0.0f; uint8_t fl = 0, rf_ld = 0; unsigned ln[6]; float hs[NQH], ha[NQH]; float4 rwA[8], rwB[8];
+    float us = 0.0f, ua = 0.0f; uint8_t fl = 0, rf_ld = 0; unsigned ln[6]; float hs[NQH], ha[NQH]; RowBlock rwA, rwB;
     const int tk_end = min(tile0 + tiles_per_block, ntl);
     // everything a tile needs besides its later rows is requested first (older than the row loads: waiting for it does not drain them)
-    auto issue_A = [&]() {
-        const float4* __restrict__ row = r.rows + row_index(ac, 0, 0, r.slots);
+    // one row = 120 B per lane: seven 16-byte planes + (column 28, keyframe id).  The 29 partials and the id, nothing else (the weight is folded in, RowView)
+    // Addressing: the 64 entries of a wave share one 7680 B block per slot, so the rows are read through a BUFFER RESOURCE whose base is the wave's
+    // slot-0 block (wave-uniform: scalar registers): a lane contributes one 32-bit offset register, the slot / plane offsets are scalar or immediate —
+    // instead of a 64-bit per-lane pointer per stream (the row loop has no register to spare; a spilled pointer there is reloaded per row block, and
+    // every reload is an s_waitcnt vmcnt(0) that drains the stream).  num_records bounds the wave to its own blocks.
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)r.rows, 0, 0, 0x00020000);
+    const unsigned lane16 = (threadIdx.x & 63u) * 16u;
+    auto load_block = [&](RowBlock& rw, int k, int slots) {
+        (void)slots;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64);
+        for (int q = 0; q < 7; ++q) { const v4u_b v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, k * (ROW_BLOCK_F4 * 16) + q * 1024, 2 /* nt */);
+                                      rw.p[q] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+        { const v2u_b t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane16 >> 1, k * (ROW_BLOCK_F4 * 16) + 64 * ROW_PLANES * 16, 2); rw.j28 = __uint_as_float(t.x); rw.tag = (int)t.y; }
     };
-    auto issue_B = [&]() {
-        if (SLOTS > 1 || (SLOTS == 0 && r.slots > 1)) { const float4* __restrict__ row = r.rows + row_index(ac, 1, 0, r.slots);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
-    };
+    auto issue_A = [&]() { load_block(rwA, 0, r.slots); };
+    auto issue_B = [&]() { if (SLOTS > 1 || (SLOTS == 0 && r.slots > 1)) load_block(rwB, 1, r.slots); };
     // part 1: the operator input of the tile and of its halo — the only DEPENDENT loads of a tile (halo index -> gather); with PIPE these cross the
     // pull phase of the previous tile (8 registers).  part 2: flags, local slots (coalesced, issued with the row blocks).
     auto issue_in = [&](int tk) {
@@ -222,6 +231,9 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         in = a < A;
         owned = a >= r.own0 && a < r.own1;          // p.q and the camera block count a row once: on the rank that owns its voxel
         ac = in ? (size_t)a : 0;
+        { const int wa0 = base + (int)(threadIdx.x & ~63u);                                  // first entry of this wave: wave-uniform
+          const unsigned grp = (unsigned)__builtin_amdgcn_readfirstlane(wa0 < A ? (wa0 >> 6) : 0);
+          rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(r.rows + (size_t)grp * (size_t)(r.slots * ROW_BLOCK_F4)), 0, r.slots * (ROW_BLOCK_F4 * 16), 0x00020000); }
         H = halo_cnt[tile];
         us = in ? u[a] : 0.0f; ua = in ? u[chunk + a] : 0.0f;
         // branch-free (unconditional loads, padding slots gather entry 0 and are zeroed when staged): loads under divergent branches are waited for at
@@ -281,20 +293,19 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         int nr_max = nr;
         if (SLOTS == 0) { for (int o = 32; o > 0; o >>= 1) nr_max = max(nr_max, __shfl_xor(nr_max, o, 64)); }
         // one row: t = W (J u), J^T t added to the lane's own column sums in LDS (plain read-modify-write: the slots are private to the lane)
-        auto consume = [&](const float4 (&rw)[8], int k) {
-            // plane 7 carries the row's residual in .y, which this pass never reads: without a use the register allocator hands that VGPR to another value
-            // WHILE THE LOAD IS IN FLIGHT, and the write-after-write hazard costs an s_waitcnt vmcnt(0) right behind every refill — the row stream
-            // was never double-buffered (found in the ISA; round 2 measured 0.32 ms against 0.235 ms for the bare stream)
-            asm volatile("" :: "v"(rw[7].y));
-            const float4 m = rw[7];
+        // (every register of a block is read below.  A loaded register that is never read gets handed to another value WHILE THE LOAD IS IN FLIGHT, and
+        // the write-after-write hazard costs an s_waitcnt vmcnt(0) behind every refill: found in the ISA of the round-2 format, whose plane 7 carried the
+        // residual the operator does not use)
+        auto consume = [&](const RowBlock& rb, int k) {
+            const float4 (&rw)[7] = rb.p;
             int fsel = 0; bool pvalid = false; float tsel = 0.0f;
-            if (k < nr && m.x != 0.0f) {
-                const float rho = m.x * tw0;
-                const int f = __float_as_int(m.z) & ~ROW_FREE_BIT;
+            if (k < nr) {
+                const float rho = tw0;                                 // the row weight is folded into the stored partials (Js = sqrt(w) J)
+                const int f = rb.tag & ~ROW_FREE_BIT;
                 float J[P_TOTAL];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { J[4 * q] = rw[q].x; J[4 * q + 1] = rw[q].y; J[4 * q + 2] = rw[q].z; J[4 * q + 3] = rw[q].w; }
-                J[28] = m.w;
+                J[28] = rb.j28;
                 float d = J[0] * us + J[10] * ua;
 #pragma unroll
                 for (int c = 1; c < 10; ++c) d += J[c] * u_s[unpack16(ln, c - 1)];
@@ -326,27 +337,19 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
 #pragma unroll
             for (int k = 0; k < SLOTS; k += 2) {               // slot k is in rwA, slot k+1 (if any) in rwB; a buffer is refilled as soon as it is consumed
                 consume(rwA, k);
-                if (k + 2 < SLOTS) { const float4* __restrict__ row = r.rows + row_index(ac, k + 2, 0, SLOTS);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
+                if (k + 2 < SLOTS) load_block(rwA, k + 2, SLOTS);
                 if (k + 1 < SLOTS) {
                     consume(rwB, k + 1);
-                    if (k + 3 < SLOTS) { const float4* __restrict__ row = r.rows + row_index(ac, k + 3, 0, SLOTS);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
+                    if (k + 3 < SLOTS) load_block(rwB, k + 3, SLOTS);
                 }
             }
         } else {
             for (int k = 0; k < nr_max; k += 2) {
                 consume(rwA, k);
-                if (k + 2 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 2, 0, r.slots);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) rwA[q] = ld_row(row + q * 64); }
+                if (k + 2 < nr_max) load_block(rwA, k + 2, r.slots);
                 if (k + 1 < nr_max) {
                     consume(rwB, k + 1);
-                    if (k + 3 < nr_max) { const float4* __restrict__ row = r.rows + row_index(ac, k + 3, 0, r.slots);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) rwB[q] = ld_row(row + q * 64); }
+                    if (k + 3 < nr_max) load_block(rwB, k + 3, r.slots);
                 }
             }
         }

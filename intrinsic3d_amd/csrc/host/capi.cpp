@@ -115,11 +115,13 @@ int i3d_debug_flags(i3d_context* c, uint8_t* flags) {
 int i3d_debug_eg_rows(i3d_context* c, int32_t* frame, float* weight, float* residual, float* jac) {
     if (!c || !c->assembled) return ctx_fail(c, I3D_ERR_STATE, "i3d_debug_eg_rows: not assembled");
     const int N = c->N, A = c->A, S = c->slots; const size_t Acap = c->Acap;
-    const size_t nrow4 = ((Acap + 63) / 64) * 64 * (size_t)S * ROW_PLANES;
-    std::vector<int> rank(N), alist(A > 0 ? A : 1); std::vector<float4> rows(nrow4); std::vector<uint8_t> nr(Acap);
+    const size_t nrow = ((Acap + 63) / 64) * 64 * (size_t)S;
+    std::vector<int> rank(N), alist(A > 0 ? A : 1); std::vector<float4> rows(nrow / 64 * ROW_BLOCK_F4); std::vector<float2> wr(nrow); std::vector<uint8_t> nr(Acap);
     CTX_HIP(c, hipMemcpy(rank.data(), c->rank.p, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
     if (A > 0) CTX_HIP(c, hipMemcpy(alist.data(), c->alist.p, sizeof(int) * (size_t)A, hipMemcpyDeviceToHost));
-    CTX_HIP(c, hipMemcpy(rows.data(), c->rows.p, sizeof(float4) * nrow4, hipMemcpyDeviceToHost));
+    CTX_HIP(c, hipMemcpy(rows.data(), c->rows.p, sizeof(float4) * rows.size(), hipMemcpyDeviceToHost));
+    const float2* const jt = reinterpret_cast<const float2*>(rows.data());
+    CTX_HIP(c, hipMemcpy(wr.data(), c->row_wr.p, sizeof(float2) * nrow, hipMemcpyDeviceToHost));
     CTX_HIP(c, hipMemcpy(nr.data(), c->nrows.p, Acap, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < (size_t)N * S; ++i) { if (frame) frame[i] = -1; if (weight) weight[i] = 0.0f; if (residual) residual[i] = 0.0f; }
     if (jac) std::memset(jac, 0, sizeof(float) * (size_t)N * S * P_TOTAL);
@@ -129,15 +131,17 @@ int i3d_debug_eg_rows(i3d_context* c, int32_t* frame, float* weight, float* resi
         if (!(afl[a] & F_ACTIVE)) continue;
         const int v = rank[alist[a]];
         for (int k = 0; k < (int)nr[a]; ++k) {
-            const float4 m = rows[row_index(a, k, 7, S)];
+            const float2 m = wr[row_scalar_index(a, k, S)];
             if (m.x == 0.0f) continue;
             const size_t o = (size_t)v * S + k;
-            int f; std::memcpy(&f, &m.z, sizeof(int)); f &= ~ROW_FREE_BIT;
-            if (frame) frame[o] = f;
+            if (frame) { int f; std::memcpy(&f, &jt[row_jt_index(a, k, S)].y, sizeof(int)); frame[o] = f & ~ROW_FREE_BIT; }
             if (weight) weight[o] = m.x * tw;
             if (residual) residual[o] = m.y;
-            if (jac) { for (int q = 0; q < 7; ++q) { const float4 t = rows[row_index(a, k, q, S)]; jac[o * P_TOTAL + 4 * q] = t.x; jac[o * P_TOTAL + 4 * q + 1] = t.y; jac[o * P_TOTAL + 4 * q + 2] = t.z; jac[o * P_TOTAL + 4 * q + 3] = t.w; }
-                       jac[o * P_TOTAL + 28] = m.w; }
+            if (jac) {      // stored with the row weight folded in (Js = sqrt(w) J): handed out as the raw partials
+                const float isw = 1.0f / std::sqrt(m.x);
+                for (int q = 0; q < 7; ++q) { const float4 t = rows[row_index(a, k, q, S)]; jac[o * P_TOTAL + 4 * q] = t.x * isw; jac[o * P_TOTAL + 4 * q + 1] = t.y * isw; jac[o * P_TOTAL + 4 * q + 2] = t.z * isw; jac[o * P_TOTAL + 4 * q + 3] = t.w * isw; }
+                jac[o * P_TOTAL + 28] = jt[row_jt_index(a, k, S)].x * isw;
+            }
         }
     }
     return I3D_OK;

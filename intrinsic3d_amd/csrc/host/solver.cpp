@@ -40,7 +40,8 @@ static int alloc_rows(i3d_context* c, int slots) {
     const size_t Acap = (size_t)c->N;
     c->Acap = (int)Acap; c->slots = slots;
     CTX_HIP(c, c->obs_frame.alloc(Acap * slots)); CTX_HIP(c, c->obs_w.alloc(Acap * slots));
-    CTX_HIP(c, c->rows.alloc(((Acap + 63) / 64) * 64 * (size_t)slots * ROW_PLANES));
+    { const size_t nrow = ((Acap + 63) / 64) * 64 * (size_t)slots;
+      CTX_HIP(c, c->rows.alloc(nrow / 64 * ROW_BLOCK_F4)); CTX_HIP(c, c->row_wr.alloc(nrow)); }
     CTX_HIP(c, c->aflags.alloc(Acap)); CTX_HIP(c, c->nrows.alloc(Acap)); CTX_HIP(c, c->anbr.alloc(Acap * NUM_NBR));
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8));
