@@ -334,7 +334,7 @@ def _main():
     # operator (K6):   4 nnz, nnz = 29 Rg + 7 Rr + Rs + 2 Ra  — §8(d)'s fused single-pass J^T J p ("4 nnz + 12*4 n" is the whole PCG iteration;
     #                  the 48 n of vector passes belong to the vector kernels, not to this one)
     # `design_GB` beside it is what THIS implementation must move per launch by construction: 120 B per stored Eg row (the 29 partials with the row
-    # weight folded in + the keyframe id; round 2: 128) + per work-list entry the operator input 8, flags 6, local stencil slots 36, symmetric Ea weights 24, accumulators out 8
+    # weight folded in + the keyframe id; round 2: 128) + per work-list entry the operator input 8, flags 6, local stencil slots 28 (18 x 12 bits), symmetric Ea weights 24, accumulators out 8
     # + ~20 B per tile-halo slot (~1 per entry); Er / Es rows are not stored (constant coefficients), so their 4 nnz bytes are never read.
     A, Rg, Rr, Rs, Ra = sizes["active"], sizes["eg"], sizes["er"], sizes["es"], sizes["ea"]
     nnz = 29.0 * Rg + 7.0 * Rr + Rs + 2.0 * Ra
@@ -342,7 +342,7 @@ def _main():
     b_build = 68.0 * A + 132.0 * Rg + 36.0 * Rr + 12.0 * Rs + 16.0 * Ra + img_bytes
     b_egpass = 4.0 * nnz
     d_build = b_build
-    d_egpass = 120.0 * Rg + (8 + 6 + 36 + 24 + 8 + 20) * float(A)
+    d_egpass = 120.0 * Rg + (8 + 6 + 28 + 24 + 8 + 20) * float(A)
     if world > 1:                                           # a rank streams its own share of the rows (its ghost rows are not counted: conservative)
         b_build /= world; b_egpass /= world; d_build /= world; d_egpass /= world
     kernels = {}

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libintrinsic3d_hip.so")
+# I3D_LIB: load another build of the SAME C ABI instead (same-box A/B of kernel variants in one GPU session; never a CPU substitute)
+LIB_PATH = os.environ.get("I3D_LIB") or os.path.join(_HERE, "libintrinsic3d_hip.so")
 
 K_NAMES = ["classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh", "eg_aux", "comm"]
 

@@ -36,6 +36,7 @@ __host__ __device__ inline int slot_rev_nbr(int c) {
 enum : uint8_t { F_VALID = 1, F_ACTIVE = 2, F_RING = 4, F_FREE_SDF = 8, F_FREE_ALB = 16 };
 
 constexpr int MAX_SLOTS = 8;
+constexpr int LNBR_WORDS = 7;             // tile plan: 18 local stencil slots x 12 bits per entry
 constexpr int ROW_PLANES = 7;
 constexpr int ROW_FREE_BIT = 1 << 30;     // set in a row's keyframe tag when the row has at least one free column
 // One (64-entry group, slot) block of the row buffer = 7680 B: seven 1 KB planes of float4 (partials 0..27), then one 512 B plane of float2
@@ -135,6 +136,20 @@ struct RowView {                    // per work-list entry a in [0, A): voxels t
     float* ea_w;                    // [6][Acap] chroma weight of the Ea row towards 1-ring neighbour d, 0 = none
     uint8_t* ea_free;               // [Acap] bit d: Ea row d has a free column
 };
+
+// Jacobi scale S = 1 / (1 + |column|), LM diagonal D^2 = clamp(|column|^2 S^2) / radius and the 1x1 block-Jacobi inverse 1 / (|column|^2 S^2 + D^2) of a
+// voxel unknown from its masked squared column norm cm (-1 = fixed parameter: everything 0).  ONE definition for the kernels that store them as vectors
+// (k_scale, k_lm_diag: camera tail, sharded / untiled solve, candidate point) and for the fused PCG kernels, which recompute them from cm instead of
+// reading three vectors (24 B less per entry and pass): both see the same values.  v_sqrt_f32 / v_rcp_f32 (1 ulp): what is rounded here is a
+// preconditioner and a column scaling, and the correctly rounded forms cost ~40 instructions per unknown, which the vector kernels feel.
+#ifdef __HIPCC__
+static __device__ inline float lm_scale(float cm) { return cm >= 0.0f ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(cm)) : 0.0f; }
+static __device__ inline void lm_diag(float cm, float s, float inv_radius, float& d2, float& minv) {
+    if (s == 0.0f) { d2 = 0.0f; minv = 0.0f; return; }
+    const float cs = (cm * s) * s;
+    d2 = fminf(fmaxf(cs, 1e-6f), 1e32f) * inv_radius; minv = __builtin_amdgcn_rcpf(cs + d2);
+}
+#endif
 
 // device-resident scalar state of one PCG solve (ConjugateGradientsSolver) — no host round trip inside an iteration
 struct PcgState {

@@ -56,7 +56,7 @@ void launch_fill(hipStream_t st, int n, float* x, float v);
 void launch_fill_d(hipStream_t st, int n, double* x, double v);
 void launch_int_to_double(hipStream_t st, const int* src, double* dst);      // a device flag joins an fp64 all-reduce
 void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* out);                 // out = a*b
-void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* freemask, float* S);          // S = free ? 1/(1+sqrt(c)) : 0
+void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* freemask, float* S, float* cm);   // S = free ? 1/(1+sqrt(c)) : 0;  cm = free ? c : -1
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float inv_radius, float* D2, float* Minv_diag);  // D2 = clamp(c S^2)/radius, Minv = 1/(c S^2 + D2) (free) else 0
 void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out /* accumulated */, double* scratch);
 void launch_dot2(hipStream_t st, Seg2 sg, const float* a, const float* b, double* out /* accumulated */, double* scratch);
@@ -109,7 +109,8 @@ void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext
 // ---- pcg_fused.hip: the PCG iteration in three launches (single rank): k_pcg_dir3 | k_eg_tile | k_pcg_step3 -----------------------
 struct Step3Args {
     int nq; int chunk4;
-    const float4* p; const float4* qacc; float4* x; float4* r; const float4* b; const float4* D2; const float4* Minv; float4* z; const float4* S;
+    const float4* p; const float4* qacc; float4* x; float4* r; const float4* b; float4* z;
+    const float4* cm; float inv_radius;       // masked squared column norms (-1 = fixed) + 1 / trust-region radius: S, D^2 and M^-1 of a voxel unknown are recomputed from them (lm_from_colnorm)
     const int* ext_off; const int* ext_pos; const float2* qh; int e0;
     const double* pq_partials; int n_pq; const double* d2_partials; int n_d2;
     int n_slice_wg;
@@ -120,7 +121,7 @@ struct Step3Args {
     PcgState* cur;
 };
 void launch_pcg_init3(hipStream_t st, PcgState* st2 /* [2] */, int fixed_iterations, int max_iterations);
-int  launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2,
+int  launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, float inv_radius,
                      const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq);   // returns #d2 partials
 int  pcg_step3_slice_wgs(int n_entries);
 int  pcg_step3_tail_wgs(int K);

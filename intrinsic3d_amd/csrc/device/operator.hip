@@ -548,15 +548,9 @@ __global__ void k_fill(int n, float* x, float v) { GRID_STRIDE(n) x[i] = v; }
 __global__ void k_fill_d(int n, double* x, double v) { GRID_STRIDE(n) x[i] = v; }
 __global__ void k_mul(int n, const float* a, const float* b, float* o) { GRID_STRIDE(n) o[i] = a[i] * b[i]; }
 __global__ void k_mul2(int n, size_t seg, const float* a, const float* b, float* o) { GRID_STRIDE(2 * n) { const size_t j = i < n ? (size_t)i : (size_t)(i - n) + seg; o[j] = a[j] * b[j]; } }
-__global__ void k_scale(int n, const float* c, const float* m, float* S) { GRID_STRIDE(n) S[i] = m[i] != 0.0f ? 1.0f / (1.0f + sqrtf(c[i])) : 0.0f; }
+__global__ void k_scale(int n, const float* c, const float* m, float* S, float* cm) { GRID_STRIDE(n) { const float v = m[i] != 0.0f ? c[i] : -1.0f; cm[i] = v; S[i] = lm_scale(v); } }
 __global__ void k_lm_diag(int n, const float* c, const float* S, float inv_radius, float* D2, float* Minv) {
-    GRID_STRIDE(n) {
-        const float s = S[i];
-        if (s == 0.0f) { D2[i] = 0.0f; Minv[i] = 0.0f; continue; }
-        const float cs = c[i] * s * s;
-        const float d2 = fminf(fmaxf(cs, 1e-6f), 1e32f) * inv_radius;
-        D2[i] = d2; Minv[i] = 1.0f / (cs + d2);
-    }
+    GRID_STRIDE(n) { float d2, mi; lm_diag(c[i], S[i], inv_radius, d2, mi); D2[i] = d2; Minv[i] = mi; }
 }
 __global__ void __launch_bounds__(256) k_dot(int n, const float* a, const float* b, double* out) {
     double s = 0.0; GRID_STRIDE(n) s += (double)a[i] * (double)b[i];
@@ -574,7 +568,7 @@ void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* o)
 void launch_mul2(hipStream_t st, Seg2 sg, const float* a, const float* b, float* o) {
     if (sg.n > 0) k_mul2<<<vblocks(2 * sg.n), 256, 0, st>>>(sg.n, sg.off1 - sg.off0, a + sg.off0, b + sg.off0, o + sg.off0);
 }
-void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* m, float* S) { if (n > 0) k_scale<<<vblocks(n), 256, 0, st>>>(n, c, m, S); }
+void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* m, float* S, float* cm) { if (n > 0) k_scale<<<vblocks(n), 256, 0, st>>>(n, c, m, S, cm); }
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float ir, float* D2, float* Minv) { if (n > 0) k_lm_diag<<<vblocks(n), 256, 0, st>>>(n, c, S, ir, D2, Minv); }
 void launch_dot2(hipStream_t st, Seg2 sg, const float* a, const float* b, double* out, double* scratch) {      // out += a.b over both segments
     if (sg.n <= 0) return;

@@ -21,18 +21,23 @@
 namespace i3d {
 
 constexpr int PF_THREADS = 512;
-constexpr int PF_MAX_WG = 1024;            // slice workgroups of dir3 / step3 (grid-stride beyond)
+constexpr int PF_MAX_WG = 512;            // slice workgroups of dir3 / step3 (grid-stride beyond)
 constexpr int PF_POSES_PER_WG = 10;        // camera tail: poses handled by one tail workgroup of k_pcg_step3
 
 // sum of nblk partial [NC]-tuples, identical (bit for bit) in every workgroup of PF_THREADS threads that calls it
 template <int NC>
-static __device__ inline void reduce_partials_all(const double* __restrict__ P, int nblk, double (&tot)[NC], double* sm /* [NC * 8] */) {
+static __device__ inline void reduce_partials_all(const double* __restrict__ P, int nblk, double (&tot)[NC], double* sm /* [NC * 8] */,
+                                                  const double* __restrict__ P2 = nullptr, int nblk2 = 0 /* a second list added to the same totals */) {
     double v[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) v[k] = 0.0;
     for (int i = threadIdx.x; i < nblk; i += PF_THREADS) {
 #pragma unroll
         for (int k = 0; k < NC; ++k) v[k] += P[(size_t)i * NC + k];
+    }
+    for (int i = threadIdx.x; i < nblk2; i += PF_THREADS) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) v[k] += P2[(size_t)i * NC + k];
     }
 #pragma unroll
     for (int k = 0; k < NC; ++k) for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
@@ -56,16 +61,22 @@ __global__ void k_pcg_init3(PcgState* st2, int fixed_iterations, int max_iterati
 }
 void launch_pcg_init3(hipStream_t st, PcgState* st2, int fixed_iterations, int max_iterations) { k_pcg_init3<<<1, 1, 0, st>>>(st2, fixed_iterations, max_iterations); }
 
+// Jacobi scale S, LM diagonal D^2 and 1x1 block-Jacobi inverse M^-1 of a voxel unknown from its masked squared column norm (k_scale + k_lm_diag,
+// operator.hip, expression for expression): the two vector kernels of a pass read ONE array instead of S, D^2 and M^-1 (24 B less per entry and pass)
+static __device__ inline void lm_from_colnorm(float cm, float inv_radius, float& s, float& d2, float& minv) { s = lm_scale(cm); lm_diag(cm, s, inv_radius, d2, minv); }
+
 // iteration boundary + direction.  `prev` was written by the previous boundary, `next` is read by the operator / step kernels of this pass
 __global__ void __launch_bounds__(PF_THREADS) k_pcg_dir3(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
-                                                        const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ D2,
-                                                        const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
+                                                        const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ D2 /* S, D2: the camera tail */,
+                                                        const float* __restrict__ cm, float inv_radius, const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
                                                         const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq) {
     __shared__ double sm[4 * 8];
     // (seq, done) goes to a 2-slot ring in pinned host memory: the host polls it one pass behind
     auto publish = [&](int done) { if (host_flags) { __hip_atomic_store(&host_flags[2 * (seq & 1) + 1], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                                      __hip_atomic_store(&host_flags[2 * (seq & 1)], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); } };
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* C4 = reinterpret_cast<const float4*>(cm); float4* u4 = reinterpret_cast<float4*>(u);
     if (prev->done) { if (writer) { *next = *prev; publish(prev->done); } return; }
     double tot[4];
     reduce_partials_all<4>(step_partials, n_step, tot, sm);
@@ -100,18 +111,16 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_dir3(int init, int n4, int s
     }
     if (stop) return;
     const float betaf = (float)beta; const bool first = it == 0;
-    const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
-    const float4* S4 = reinterpret_cast<const float4*>(S); float4* u4 = reinterpret_cast<float4*>(u);
-    const float4* D4 = reinterpret_cast<const float4*>(D2);
     double d2 = 0.0;
     for (int j = blockIdx.x * PF_THREADS + threadIdx.x; j < 2 * n4; j += gridDim.x * PF_THREADS) {
         const int i = j < n4 ? j : j - n4 + seg4;
-        float4 pi = z4[i];
+        float4 pi = z4[i]; const float4 cv = C4[i];
         if (!first) { const float4 po = p4[i]; pi.x += betaf * po.x; pi.y += betaf * po.y; pi.z += betaf * po.z; pi.w += betaf * po.w; }
         p4[i] = pi;
-        const float4 sv = S4[i];
+        float4 sv, dd; float mi;
+        lm_from_colnorm(cv.x, inv_radius, sv.x, dd.x, mi); lm_from_colnorm(cv.y, inv_radius, sv.y, dd.y, mi);
+        lm_from_colnorm(cv.z, inv_radius, sv.z, dd.z, mi); lm_from_colnorm(cv.w, inv_radius, sv.w, dd.w, mi);
         u4[i] = make_float4(sv.x * pi.x, sv.y * pi.y, sv.z * pi.z, sv.w * pi.w);
-        const float4 dd = D4[i];
         d2 += (double)dd.x * (double)pi.x * (double)pi.x + (double)dd.y * (double)pi.y * (double)pi.y + (double)dd.z * (double)pi.z * (double)pi.z + (double)dd.w * (double)pi.w * (double)pi.w;
     }
     if (blockIdx.x == gridDim.x - 1) {                               // the camera tail (6K+9 unknowns) rides with the last workgroup
@@ -124,17 +133,41 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_dir3(int init, int n4, int s
     block_partial_d(d2, d2_partials, 1, 0);
 }
 
-int launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2,
+int launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, float inv_radius,
                     const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq) {
     const int n4 = sg.n >> 2, seg4 = (int)((sg.off1 - sg.off0) >> 2);
     int blocks = (2 * n4 + PF_THREADS - 1) / PF_THREADS; blocks = blocks < 1 ? 1 : (blocks > PF_MAX_WG ? PF_MAX_WG : blocks);
     const size_t o = sg.off0;
-    k_pcg_dir3<<<blocks, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, step_partials, n_step, d2_partials, prev, next, host_flags, seq);
+    k_pcg_dir3<<<blocks, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, inv_radius, step_partials, n_step, d2_partials, prev, next, host_flags, seq);
     return blocks;
 }
 
 enum { S3_INIT = 0, S3_NORMAL = 1, S3_XONLY = 2, S3_RESET = 3 };
 
+
+// what one thread of k_pcg_step3 reads for its 4 entries (sdf + albedo segment): every load of a batch is issued before the first use.
+// (Requesting the first batch BEFORE the prologue's reductions was tried: the registers it holds across them cost an occupancy step — 144 VGPRs —
+// and the kernel got slower, 91 against 80 ms of vector kernels per 10 iterations; profiles/r03_ab_variants.json.)
+struct S3In { float4 as, aa; int4 o; int o4; float4 x[2], p[2], b[2], cm[2], r[2]; };
+template <int MODE> static __device__ inline void s3_load(const Step3Args& a, int q, S3In& v) {
+    if (MODE == S3_NORMAL || MODE == S3_RESET) {
+        v.as = a.qacc[q]; v.aa = a.qacc[q + a.chunk4];
+        const int e = a.e0 + 4 * q;
+        v.o = *reinterpret_cast<const int4*>(a.ext_off + e);                 // (e is a multiple of 4: slices start at multiples of 1024)
+        v.o4 = a.ext_off[e + 4];
+    }
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        const int i = q + seg * a.chunk4;
+        v.cm[seg] = a.cm[i];
+        if (MODE == S3_INIT) v.r[seg] = a.r[i];
+        else {
+            v.x[seg] = a.x[i];
+            if (MODE != S3_RESET) v.p[seg] = a.p[i];
+            if (MODE != S3_XONLY) { v.b[seg] = a.b[i]; if (MODE == S3_NORMAL) v.r[seg] = a.r[i]; }
+        }
+    }
+}
 
 template <int MODE>
 __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
@@ -143,13 +176,15 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
     __shared__ double camred[8][64];
     __shared__ float rs[64];
     PcgState* const cur = a.cur;
+    const bool slice_wg = (int)blockIdx.x < a.n_slice_wg;
+    const int q0 = blockIdx.x * PF_THREADS + threadIdx.x, qstride = a.n_slice_wg * PF_THREADS;
+    S3In in;
     if (cur->done) return;
     float alpha = 0.0f;
     if (MODE == S3_NORMAL || MODE == S3_XONLY) {                     // p.q = sum over rows of t (J u) + sum D^2 p^2  ->  alpha = rho / p.q
-        double t1[1], t2[1];
-        reduce_partials_all<1>(a.pq_partials, a.n_pq, t1, sm);
-        reduce_partials_all<1>(a.d2_partials, a.n_d2, t2, sm);
-        const double pq = t1[0] + t2[0];
+        double t1[1];
+        reduce_partials_all<1>(a.pq_partials, a.n_pq, t1, sm, a.d2_partials, a.n_d2);      // both lists in ONE reduction (one barrier pair instead of two)
+        const double pq = t1[0];
         const double al = cur->rho / pq;
         const bool bad = !(pq > 0.0) || isinf(pq) || isinf(al);
         if (blockIdx.x == 0 && threadIdx.x == 0) { cur->pq = pq; if (bad) cur->done = 2; else cur->alpha = al; }      // (no kernel reads pq / alpha from the state; done = 2 only makes everyone return)
@@ -157,48 +192,47 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
         alpha = (float)al;
     }
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if ((int)blockIdx.x < a.n_slice_wg) {
-        for (int q = blockIdx.x * PF_THREADS + threadIdx.x; q < a.nq; q += a.n_slice_wg * PF_THREADS) {
+    if (slice_wg) {
+        for (int q = q0; q < a.nq; q += qstride) {
+            s3_load<MODE>(a, q, in);
             float accv[2][4];
             if (MODE == S3_NORMAL || MODE == S3_RESET) {
-                const float4 as = a.qacc[q], aa = a.qacc[q + a.chunk4];
+                const float4 as = in.as, aa = in.aa;
                 accv[0][0] = as.x; accv[0][1] = as.y; accv[0][2] = as.z; accv[0][3] = as.w; accv[1][0] = aa.x; accv[1][1] = aa.y; accv[1][2] = aa.z; accv[1][3] = aa.w;
-                const int e = a.e0 + 4 * q;
-                const int4 o = *reinterpret_cast<const int4*>(a.ext_off + e);                 // (e is a multiple of 4: slices start at multiples of 1024)
-                const int o4 = a.ext_off[e + 4];
-                const int ob[5] = {o.x, o.y, o.z, o.w, o4};
+                const int ob[5] = {in.o.x, in.o.y, in.o.z, in.o.w, in.o4};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) for (int j = ob[k]; j < ob[k + 1]; ++j) { const float2 v = a.qh[a.ext_pos[j]]; accv[0][k] += v.x; accv[1][k] += v.y; }
             }
 #pragma unroll
             for (int seg = 0; seg < 2; ++seg) {
                 const int i = q + seg * a.chunk4;
-                float xv[4], rv[4];
-                if (MODE == S3_INIT) { const float4 t = a.r[i]; rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
+                float xv[4], rv[4], svv[4], dv[4], mv[4];
+                { const float4 cv = in.cm[seg]; lm_from_colnorm(cv.x, a.inv_radius, svv[0], dv[0], mv[0]); lm_from_colnorm(cv.y, a.inv_radius, svv[1], dv[1], mv[1]);
+                  lm_from_colnorm(cv.z, a.inv_radius, svv[2], dv[2], mv[2]); lm_from_colnorm(cv.w, a.inv_radius, svv[3], dv[3], mv[3]); }
+                if (MODE == S3_INIT) { const float4 t = in.r[seg]; rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
                 else {
-                    const float4 xo = a.x[i];
+                    const float4 xo = in.x[seg];
                     xv[0] = xo.x; xv[1] = xo.y; xv[2] = xo.z; xv[3] = xo.w;
                     float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (MODE != S3_RESET) {
-                        const float4 pp = a.p[i]; pv[0] = pp.x; pv[1] = pp.y; pv[2] = pp.z; pv[3] = pp.w;
+                        const float4 pp = in.p[seg]; pv[0] = pp.x; pv[1] = pp.y; pv[2] = pp.z; pv[3] = pp.w;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) xv[k] += alpha * pv[k];
                         a.x[i] = make_float4(xv[0], xv[1], xv[2], xv[3]);
                     }
                     if (MODE == S3_XONLY) continue;
-                    const float4 bb = a.b[i], dd = a.D2[i], sv = a.S[i];
-                    const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w}, svv[4] = {sv.x, sv.y, sv.z, sv.w};
+                    const float4 bb = in.b[seg];
+                    const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
                     float qq[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) qq[k] = svv[k] * accv[seg][k] + dv[k] * (MODE == S3_NORMAL ? pv[k] : xv[k]);      // q = S acc + D^2 v
-                    if (MODE == S3_NORMAL) { const float4 ro = a.r[i]; rv[0] = ro.x - alpha * qq[0]; rv[1] = ro.y - alpha * qq[1]; rv[2] = ro.z - alpha * qq[2]; rv[3] = ro.w - alpha * qq[3]; }
+                    if (MODE == S3_NORMAL) { const float4 ro = in.r[seg]; rv[0] = ro.x - alpha * qq[0]; rv[1] = ro.y - alpha * qq[1]; rv[2] = ro.z - alpha * qq[2]; rv[3] = ro.w - alpha * qq[3]; }
                     else { rv[0] = bv[0] - qq[0]; rv[1] = bv[1] - qq[1]; rv[2] = bv[2] - qq[2]; rv[3] = bv[3] - qq[3]; }           // RESET: r = b - A x
                     a.r[i] = make_float4(rv[0], rv[1], rv[2], rv[3]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { const double xd = xv[k]; s1 += xd * ((double)bv[k] + (double)rv[k]); s2 += xd * (double)rv[k]; s3 += (double)dv[k] * xd * xd; }
                 }
-                const float4 mm = a.Minv[i];
-                const float zv[4] = {mm.x * rv[0], mm.y * rv[1], mm.z * rv[2], mm.w * rv[3]};
+                const float zv[4] = {mv[0] * rv[0], mv[1] * rv[1], mv[2] * rv[2], mv[3] * rv[3]};
                 a.z[i] = make_float4(zv[0], zv[1], zv[2], zv[3]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s0 += (double)rv[k] * (double)zv[k];

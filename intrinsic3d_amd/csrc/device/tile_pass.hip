@@ -38,9 +38,9 @@ __device__ __host__ inline int tp_dir(int j) {
 // ---- plan (once per outer iteration) ----------------------------------------------------------------------------------------------
 // One workgroup per tile of T entries: hash set of the foreign entries its FORWARD stencils / rings reach -> compact -> bitonic sort
 // (deterministic slot numbers, coalescing-friendly staging) -> local slots by binary search.  Sharded: a rank plans the tiles it runs
-// (its own range + the foreign tiles that hold ghost entries); the others keep halo_cnt = 0 and padding.  lnbr[0..5]: the 12 read slots (uint16 pairs:
-// 0..T-1 own tile, T.. halo, zslot = not a list entry); lnbr[6..8]: the 6 extra reverse slots, own tile or zslot (foreign sources reach
-// the entry through THEIR tile's halo accumulators).  halo_idx is padded with TP_NONE (those keys sort behind every real pair).
+// (its own range + the foreign tiles that hold ghost entries); the others keep halo_cnt = 0 and padding.  lnbr: 18 local slots of 12 bits each, packed
+// LSB first into 7 words per entry (28 B; zslot <= 3072 fits 12 bits): slots 0..11 = the 12 read slots (0..T-1 own tile, T.. halo, zslot = not a list
+// entry), in words 0..4; slots 12..17 = the 6 extra reverse slots, own tile or zslot (foreign sources reach the entry through THEIR tile's halo accumulators).  halo_idx is padded with TP_NONE (those keys sort behind every real pair).
 __global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, int hlimit /* <= hmax: more halo entries than this = overflow */, int tile_first, const int* __restrict__ tile_list, unsigned* __restrict__ lnbr,
                                                     int* __restrict__ halo_idx, int* __restrict__ halo_cnt, int* __restrict__ overflow) {
     __shared__ int hkeys[4096];
@@ -94,8 +94,13 @@ __global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, 
         }
         ls[j] = (unsigned short)slot;
     }
+    unsigned pw[LNBR_WORDS];
 #pragma unroll
-    for (int w = 0; w < 9; ++w) lnbr[(size_t)w * r.Acap + a] = (unsigned)ls[2 * w] | ((unsigned)ls[2 * w + 1] << 16);
+    for (int w = 0; w < LNBR_WORDS; ++w) pw[w] = 0u;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) { const int bit = 12 * j, k = bit >> 5, sh = bit & 31; pw[k] |= (unsigned)ls[j] << sh; if (sh > 20) pw[k + 1] |= (unsigned)ls[j] >> (32 - sh); }
+#pragma unroll
+    for (int w = 0; w < LNBR_WORDS; ++w) lnbr[(size_t)w * r.Acap + a] = pw[w];
 }
 
 // symmetric albedo-edge weights: the Ea row of the edge (a, neighbour d) is created once, by whichever voxel is visited first
@@ -119,7 +124,14 @@ static __device__ inline void lds_add(float* p, float v) { __hip_atomic_fetch_ad
 struct RowBlock { float4 p[7]; float j28; int tag; };  // one stored Eg row in registers: planes 0..6 + column 28 + keyframe tag
 typedef unsigned v4u_b __attribute__((ext_vector_type(4)));
 typedef unsigned v2u_b __attribute__((ext_vector_type(2)));
-template <int NW> static __device__ inline int unpack16(const unsigned (&w)[NW], int j) { return (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu); }
+// local slot j of an entry's packed plan words (12 bits each, LSB first; j is a compile-time constant after unrolling: one v_bfe_u32, or v_alignbit + v_and
+// for the slots that straddle a word)
+template <int NW> static __device__ inline int unpack12(const unsigned (&w)[NW], int j) {
+    const int bit = 12 * j, k = bit >> 5, sh = bit & 31;
+    if (sh <= 20) return (int)((w[k] >> sh) & 0xFFFu);
+    return (int)(((w[k] >> sh) | (w[k + 1 < NW ? k + 1 : k] << (32 - sh))) & 0xFFFu);
+}
+template <int Z> struct AllZ { unsigned w[LNBR_WORDS]; constexpr AllZ() : w{} { for (int j = 0; j < 18; ++j) { const int bit = 12 * j, k = bit >> 5, sh = bit & 31; w[k] |= (unsigned)Z << sh; if (sh > 20) w[k + 1] |= (unsigned)Z >> (32 - sh); } } };
 
 // T lanes = T entries per tile.  SLOTS > 0: the row loop is unrolled for exactly that many observation slots and EVERY slot is requested
 // (unused slots of a voxel are skipped per lane): straight-line code whose s_waitcnt the compiler can count exactly — with a run-time
@@ -203,7 +215,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     // the tile in flight (mutable: with PIPE the loads of the next tile overwrite them while the current one is still being pulled)
     constexpr int NQH = (HMAX + T - 1) / T;
     int tile = 0, base = 0, a = 0, H = 0, nr_ld = 0; bool in = false, owned = false; size_t ac = 0;
-    float us = 0.0f, ua = 0.0f; uint8_t fl = 0, rf_ld = 0; unsigned ln[6]; float hs[NQH], ha[NQH]; RowBlock rwA, rwB;
+    float us = 0.0f, ua = 0.0f; uint8_t fl = 0, rf_ld = 0; unsigned ln[5]; float hs[NQH], ha[NQH]; RowBlock rwA, rwB;
     const int tk_end = min(tile0 + tiles_per_block, ntl);
     // everything a tile needs besides its later rows is requested first (older than the row loads: waiting for it does not drain them)
     // one row = 120 B per lane: seven 16-byte planes + (column 28, keyframe id).  The 29 partials and the id, nothing else (the weight is folded in, RowView)
@@ -250,7 +262,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         nr_ld = r.nrows[ac];
         rf_ld = r.regflags[ac];
 #pragma unroll
-        for (int w = 0; w < 6; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);      // per-entry plan data: read once per pass, like the rows
+        for (int w = 0; w < 5; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);      // per-entry plan data: read once per pass, like the rows
     };
     if (PIPE && tile0 < tk_end) issue_in(tile0);
     for (int tk = tile0; tk < tk_end; ++tk) {
@@ -269,10 +281,10 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         const bool active = in && (fl & F_ACTIVE);
         const int nr = active ? nr_ld : 0;
         const uint8_t rf = active ? rf_ld : 0;
-        if (!in) { for (int w = 0; w < 6; ++w) ln[w] = (unsigned)ZSLOT | ((unsigned)ZSLOT << 16); }
+        if (!in) { constexpr AllZ<ZSLOT> az; for (int w = 0; w < 5; ++w) ln[w] = az.w[w]; }
         __syncthreads();
-        // local slots: sdf stencil slot c (1..9) = unpack16(ln, c - 1); +x,+y,+z = 5,0,3; -x,-y,-z = 9,10,11
-        const int sx = unpack16(ln, 5), sy = unpack16(ln, 0), sz = unpack16(ln, 3), mx = unpack16(ln, 9), my = unpack16(ln, 10), mz = unpack16(ln, 11);
+        // local slots: sdf stencil slot c (1..9) = unpack12(ln, c - 1); +x,+y,+z = 5,0,3; -x,-y,-z = 9,10,11
+        const int sx = unpack12(ln, 5), sy = unpack12(ln, 0), sz = unpack12(ln, 3), mx = unpack12(ln, 9), my = unpack12(ln, 10), mz = unpack12(ln, 11);
         float self_s = 0.0f, self_a = 0.0f;
         // ---- regulariser rows (constant coefficients), while the first two row blocks are in flight ----
         {
@@ -308,7 +320,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 J[28] = rb.j28;
                 float d = J[0] * us + J[10] * ua;
 #pragma unroll
-                for (int c = 1; c < 10; ++c) d += J[c] * u_s[unpack16(ln, c - 1)];
+                for (int c = 1; c < 10; ++c) d += J[c] * u_s[unpack12(ln, c - 1)];
                 d += J[11] * u_a[sx] + J[12] * u_a[sy] + J[13] * u_a[sz];
                 const int o_up = o_upose + 6 * f;
 #pragma unroll
@@ -355,16 +367,16 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         }
         if (owned) pq += (double)pq_rows;
         // what the pull phase needs in addition (requested now, used behind the barrier): the 6 further reverse slots, the symmetric Ea weights
-        unsigned lr[3];
+        unsigned lr[2];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) lr[w] = __builtin_nontemporal_load(&lnbr[(size_t)(6 + w) * Acap + ac]);
+        for (int w = 0; w < 2; ++w) lr[w] = __builtin_nontemporal_load(&lnbr[(size_t)(5 + w) * Acap + ac]);
         float eaw[6];
 #pragma unroll
         for (int d = 0; d < 6; ++d) eaw[d] = __builtin_nontemporal_load(&eaw_sym[(size_t)d * Acap + ac]);
         // ---- what lands in the halo is pushed (few lanes: the tile's outer shell) ----
         if (nr > 0) {
 #pragma unroll
-            for (int c = 1; c < 10; ++c) { const int sl = unpack16(ln, c - 1); if (sl >= T && sl != ZSLOT) lds_add(&qh_s[sl - T], Cme[(c - 1) * T]); }
+            for (int c = 1; c < 10; ++c) { const int sl = unpack12(ln, c - 1); if (sl >= T && sl != ZSLOT) lds_add(&qh_s[sl - T], Cme[(c - 1) * T]); }
             if (sx >= T && sx != ZSLOT) lds_add(&qh_a[sx - T], Cme[9 * T]);
             if (sy >= T && sy != ZSLOT) lds_add(&qh_a[sy - T], Cme[10 * T]);
             if (sz >= T && sz != ZSLOT) lds_add(&qh_a[sz - T], Cme[11 * T]);
@@ -377,7 +389,8 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         if (in_c) {
             // reverse entries: slot c of entry e is this entry <=> e = this entry's neighbour in the mirrored direction
             // c: 1 -y, 2 -2y, 3 -y-z, 4 -z, 5 -2z, 6 -x, 7 -x-y, 8 -x-z, 9 -2x; albedo 11 -x, 12 -y, 13 -z
-            const int r2y = unpack16(lr, 0), ryz = unpack16(lr, 1), r2z = unpack16(lr, 2), rxy = unpack16(lr, 3), rxz = unpack16(lr, 4), r2x = unpack16(lr, 5);
+            const unsigned lall[LNBR_WORDS] = {0u, 0u, 0u, 0u, ln[4], lr[0], lr[1]};       // slots 12..17 live in words 4..6
+            const int r2y = unpack12(lall, 12), ryz = unpack12(lall, 13), r2z = unpack12(lall, 14), rxy = unpack12(lall, 15), rxz = unpack12(lall, 16), r2x = unpack12(lall, 17);
             auto pull = [&](int col, int slot) { return slot < T ? C_l[col * T + slot] : 0.0f; };
             float qs = self_s, qa = self_a;
             qs += pull(0, my) + pull(1, r2y) + pull(2, ryz) + pull(3, mz) + pull(4, r2z) + pull(5, mx) + pull(6, rxy) + pull(7, rxz) + pull(8, r2x);

@@ -97,7 +97,7 @@ struct i3d_context {
     }
 
     // ---- solver vectors (length NP = 2N + 6K + 9) ----
-    i3d::DevBuf<float> v_mask, v_c, v_S, v_D2, v_Minv, v_b, v_x, v_r, v_p, v_z, v_q, v_u, v_acc, v_tmp, v_qacc;
+    i3d::DevBuf<float> v_mask, v_c, v_S, v_cm, v_D2, v_Minv, v_b, v_x, v_r, v_p, v_z, v_q, v_u, v_acc, v_tmp, v_qacc;
     i3d::DevBuf<float> Minv_blocks;
     i3d::DevBuf<double> d_shared, d_blocks, d_scal, d_xshared, d_xcshared;
     i3d::DevBuf<i3d::PcgState> d_pcg, d_pcg2; i3d::DevBuf<double> d_partials; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};

@@ -46,14 +46,14 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8));
     { const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512), nh = nt * (size_t)tile_plan_hmax_of(512);        // the 512-entry geometry needs the most slots (3 per entry; 1024: 2)
-      CTX_HIP(c, c->tp_lnbr.alloc(Acap * 9)); CTX_HIP(c, c->tp_eaw.alloc(Acap * 6)); CTX_HIP(c, c->tp_halo_idx.alloc(nh)); CTX_HIP(c, c->tp_halo_cnt.alloc(nt)); CTX_HIP(c, c->tp_iota.alloc(nh));
+      CTX_HIP(c, c->tp_lnbr.alloc(Acap * LNBR_WORDS)); CTX_HIP(c, c->tp_eaw.alloc(Acap * 6)); CTX_HIP(c, c->tp_halo_idx.alloc(nh)); CTX_HIP(c, c->tp_halo_cnt.alloc(nt)); CTX_HIP(c, c->tp_iota.alloc(nh));
       CTX_HIP(c, c->tp_ext_e.alloc(nh)); CTX_HIP(c, c->tp_ext_pos.alloc(nh)); CTX_HIP(c, c->tp_qh.alloc(2 * nh)); CTX_HIP(c, c->tp_overflow.alloc(1));
       CTX_HIP(c, c->tp_ext_off.alloc(Acap + (size_t)SHARD_ALIGN * ((c->comm ? c->comm->world : 1) + 1) + 8));      // chunk + 1 offsets (chunk >= A, a multiple of the slice alignment)
       CTX_HIP(c, c->cam_part.alloc((size_t)2048 * (((size_t)6 * c->K + 9 + 3) & ~(size_t)3)));                     // one float row of the camera block per operator workgroup
       CTX_HIP(c, c->tp_temp.alloc(tile_plan_temp_bytes((int)nt))); }
     const int world_a = c->comm ? c->comm->world : 1;
     const size_t NP = 2 * ((size_t)c->N + (size_t)SHARD_ALIGN * (world_a + 1)) + 6 * (size_t)c->K + 9;      // chunk = world * slice >= A, slice a multiple of SHARD_ALIGN
-    for (DevBuf<float>* v : {&c->v_mask, &c->v_c, &c->v_S, &c->v_D2, &c->v_Minv, &c->v_b, &c->v_x, &c->v_r, &c->v_p, &c->v_z, &c->v_q, &c->v_u, &c->v_acc, &c->v_tmp, &c->v_qacc})
+    for (DevBuf<float>* v : {&c->v_mask, &c->v_c, &c->v_S, &c->v_cm, &c->v_D2, &c->v_Minv, &c->v_b, &c->v_x, &c->v_r, &c->v_p, &c->v_z, &c->v_q, &c->v_u, &c->v_acc, &c->v_tmp, &c->v_qacc})
         { const bool fresh = v->n < NP || !v->p; CTX_HIP(c, v->alloc(NP)); if (fresh) CTX_HIP(c, hipMemset(v->p, 0, sizeof(float) * v->n)); }   // padding entries stay finite
     CTX_HIP(c, c->Minv_blocks.alloc((size_t)36 * c->K + 16 + 25));
     CTX_HIP(c, c->d_shared.alloc((size_t)6 * c->K + 9 + 1)); CTX_HIP(c, c->d_blocks.alloc((size_t)21 * c->K + 25));      // +1: p.q partial rides with the camera block
@@ -442,7 +442,7 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
 
 // The same solve in THREE launches per pass (pcg_fused.hip): k_pcg_dir3 | k_eg_tile | k_pcg_step3.  Single rank, tiled operator.  The scalar state is
 // double-buffered by pass parity: boundary `it` reads st2[(it + 1) & 1] and writes st2[it & 1], which the operator and the step of pass `it` read.
-static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p) {
+static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, float inv_radius) {
     hipStream_t s = c->stream;
     const Layout L = layout_of(c);
     const int K = c->K; const size_t to = L.tail_off; const Seg2 own = L.own;
@@ -456,7 +456,7 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
     auto c4 = [&](const float* v) { return reinterpret_cast<const float4*>(v + own.off0); };
     auto m4 = [&](float* v) { return reinterpret_cast<float4*>(v + own.off0); };
     a.nq = own.n >> 2; a.chunk4 = (int)((own.off1 - own.off0) >> 2);
-    a.p = c4(c->v_p.p); a.qacc = c4(c->v_qacc.p); a.x = m4(c->v_x.p); a.r = m4(c->v_r.p); a.b = c4(c->v_b.p); a.D2 = c4(c->v_D2.p); a.Minv = c4(c->v_Minv.p); a.z = m4(c->v_z.p); a.S = c4(c->v_S.p);
+    a.p = c4(c->v_p.p); a.qacc = c4(c->v_qacc.p); a.x = m4(c->v_x.p); a.r = m4(c->v_r.p); a.b = c4(c->v_b.p); a.z = m4(c->v_z.p); a.cm = c4(c->v_cm.p); a.inv_radius = inv_radius;
     a.ext_off = tp.ext_off; a.ext_pos = tp.ext_pos; a.qh = reinterpret_cast<const float2*>(tp.qh); a.e0 = (int)own.off0;
     a.pq_partials = pq_part; a.d2_partials = d2_part; a.n_pq = 0; a.n_d2 = 0;
     a.n_slice_wg = pcg_step3_slice_wgs(own.n);
@@ -471,7 +471,7 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
     for (;; ++it) {
         PcgState* const prev = st2 + ((it + 1) & 1); PcgState* const cur = st2 + (it & 1);
         { TimedScope t(c, I3D_K_VECTOR);
-          a.n_d2 = launch_pcg_dir3(s, it == 1, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, step_part, n_step, d2_part, prev, cur, c->d_flags, seq0 + it); }
+          a.n_d2 = launch_pcg_dir3(s, it == 1, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, c->v_cm.p, inv_radius, step_part, n_step, d2_part, prev, cur, c->d_flags, seq0 + it); }
         { TimedScope t(c, I3D_K_EG_PASS); a.n_pq = launch_eg_tile(s, r, p, c->v_u.p, tp, nullptr, c->v_qacc.p, pq_part, cur, c->cam_part.p, NSP); a.n_cam = a.n_pq; }
         a.cur = cur;
         if (it % 10 != 0) { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3(s, 1, a); }
@@ -515,7 +515,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     rc = ensure_pinned(c, (size_t)21 * K + 25 + 64); if (rc) return rc;
     rc = read_doubles(c, c->d_blocks.p, (size_t)21 * K + 25, sb.H.data()); if (rc) return rc;
     { int rc2 = allgather(c, c->v_c.p); if (rc2) return rc2; }     // the candidate point needs S everywhere
-    { TimedScope t(c, I3D_K_VECTOR); launch_scale_from_colnorm(s, NP, c->v_c.p, c->v_mask.p, c->v_S.p); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_scale_from_colnorm(s, NP, c->v_c.p, c->v_mask.p, c->v_S.p, c->v_cm.p); }
     // gradient b = S J^T W r and initial cost
     rc = run_pass(c, PASS_GRAD, p, nullptr, c->v_acc.p); if (rc) return rc;
     { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, NP, c->v_S.p, c->v_acc.p, c->v_b.p); }
@@ -545,7 +545,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
         rc = upload_shared_precond(c); if (rc) return rc;
         {   // three launches per pass on one rank with the tiled operator; the six-launch sequence when sharded, untiled, or asked for (A/B runs)
             static const bool legacy = [] { const char* e = std::getenv("I3D_PCG_LEGACY"); return e && e[0] == '1'; }();
-            rc = (!sharded(c) && c->tile_ok && !legacy) ? pcg_solve_fused(c, cfg, p) : pcg_solve(c, cfg, p); if (rc) return rc;
+            rc = (!sharded(c) && c->tile_ok && !legacy) ? pcg_solve_fused(c, cfg, p, (float)(1.0 / radius)) : pcg_solve(c, cfg, p); if (rc) return rc;
         }
         // candidate point (replicated: every rank needs the whole step), queued behind the solve: ONE synchronisation returns the terminal PCG
         // state, the step / parameter norms and the candidate camera.  (A step the model rejects below costs one wasted candidate kernel.)
