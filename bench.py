@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNEL_TAG = "r03-slim-rows"     # bumped when k_build<true> / k_eg_tile change materially: PMC traffic / SQ counter files of older kernels are not attached
 # issue cost of a VALU wave-instruction on gfx950 measured with tools/experiments/valu_rate.hip (profiles/r02_valu_rate.txt): cycles per instruction on one SIMD
-VALU_CYCLES = {"f64": 5.4, "f32": 3.0}
+VALU_CYCLES = {"f64": 5.4, "f32": 3.0, "pk": 5.2}      # cycles per wave-instruction on one SIMD, measured (tools/experiments/valu_rate.hip); pk = packed fp32 (v_pk_*)
 GPU_CLOCK_HZ = 2.4e9; NUM_SIMD = 1024
 
 
@@ -365,7 +365,8 @@ def _main():
                "traffic_source": (f"committed PMC passes of this command, profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; not measured in this run)" if tr else None)}
         sq = sq_valu(name, Rg) if world == 1 else None
         if sq:      # what actually limits the kernel: issue time of its VALU instructions against the measured launch time
-            issue_ms = (sq["valu_f64"] * VALU_CYCLES["f64"] + (sq["valu"] - sq["valu_f64"]) * VALU_CYCLES["f32"]) / (NUM_SIMD * GPU_CLOCK_HZ) * 1e3
+            pk = sq.get("valu_pk", 0.0)
+            issue_ms = (sq["valu_f64"] * VALU_CYCLES["f64"] + pk * VALU_CYCLES["pk"] + (sq["valu"] - sq["valu_f64"] - pk) * VALU_CYCLES["f32"]) / (NUM_SIMD * GPU_CLOCK_HZ) * 1e3
             out.update(valu_instructions=sq["valu"], valu_issue_ms=issue_ms, valu_frac=issue_ms / k["avg_ms"], valu_source=f"profiles/{sq['source']} (SQ_INSTS_VALU; fp64 share from the ISA)")
             if out["valu_frac"] > out["frac"]:
                 out["bound"] = "valu-issue"

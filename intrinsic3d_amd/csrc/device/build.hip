@@ -26,6 +26,7 @@ namespace i3d {
 // displace the keyframe images (245 MB, re-read by every wave) and the voxel state from the last-level cache.
 typedef float v4f_row __attribute__((ext_vector_type(4)));
 typedef float v2f_row __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 static __device__ inline void st_row2(float2* p, float a, float b) { v2f_row v; v.x = a; v.y = b; __builtin_nontemporal_store(v, reinterpret_cast<v2f_row*>(p)); }
 static __device__ inline void st_row(float4* p, float a, float b, float c, float d) { v4f_row v; v.x = a; v.y = b; v.z = c; v.w = d; __builtin_nontemporal_store(v, reinterpret_cast<v4f_row*>(p)); }
 
@@ -52,7 +53,8 @@ static __device__ inline void shared_point(PointShared& q, double s, double sx, 
                                            int cx, int cy, int cz, double vs) {
     double g0 = sx - s, g1 = sy - s, g2 = sz - s;
     const double len = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
-    if (len > 0.0) { q.inv_len = (float)(1.0 / len); g0 /= len; g1 /= len; g2 /= len; } else q.inv_len = 0.0f;
+    // (one reciprocal instead of the reference's three divisions: 1e-16 relative on a value path held to 1e-4; an fp64 division is 67 cycles here)
+    if (len > 0.0) { const double il = 1.0 / len; q.inv_len = (float)il; g0 *= il; g1 *= il; g2 *= il; } else q.inv_len = 0.0f;
     q.s = (float)s; q.alb = (float)alb;
     q.P[0] = (double)cx * vs - g0 * s; q.P[1] = (double)cy * vs - g1 * s; q.P[2] = (double)cz * vs - g2 * s;
     const double nx = g0, ny = g1, nz = g2;
@@ -92,16 +94,18 @@ template <class T> static __device__ inline T hermite_der(T p0, T p1, T p2, T p3
 // four dependent ones: the kernel runs two waves per SIMD and is latency-bound, not issue-bound): bicubic_taps only issues the 4 x 16 B
 // loads, bicubic_eval consumes them.
 struct Taps { float4 t[4]; double xc, xr; };
+// min(max(x, 0), hi) in ONE instruction (the compiler forms v_med3_i32 only when it can prove 0 <= hi)
+static __device__ inline int clamp0(int x, int hi) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi)); return r; }
 static __device__ inline void bicubic_taps(const float* __restrict__ img, int w, int h, double r, double c, Taps& o) {
     const int row = (int)floor(r), col = (int)floor(c);
     o.xc = c - (double)col; o.xr = r - (double)row;
     const bool interior = col >= 1 && col + 2 <= w - 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int rr = min(max(row - 1 + i, 0), h - 1);
+        const int rr = clamp0(row - 1 + i, h - 1);
         const gf_ptr line = (gf_ptr)(img + (size_t)rr * w);
         if (interior) { const f4u v = *(gf4u_ptr)(line + (col - 1)); o.t[i] = make_float4(v.x, v.y, v.z, v.w); }
-        else o.t[i] = make_float4(line[min(max(col - 1, 0), w - 1)], line[min(max(col, 0), w - 1)], line[min(max(col + 1, 0), w - 1)], line[min(max(col + 2, 0), w - 1)]);
+        else o.t[i] = make_float4(line[clamp0(col - 1, w - 1)], line[clamp0(col, w - 1)], line[clamp0(col + 1, w - 1)], line[clamp0(col + 2, w - 1)]);
     }
 }
 // Catmull-Rom in WEIGHT form.  Ceres evaluates p1 + x (c + x (b + x a)) with a, b, c recombined from the taps for every spline (5 splines per
@@ -347,51 +351,63 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowVi
                 for (int i = 0; i < P_TOTAL; ++i) J[i] = 0.0f;
                 float Wx = 0.0f, Wy = 0.0f, Wz = 0.0f;                              // sum_j c_j (P_j x M_j): rotation part before Jr
                 const float R0 = (float)fc.R[0], R1 = (float)fc.R[1], R2 = (float)fc.R[2], R3 = (float)fc.R[3], R4 = (float)fc.R[4], R5 = (float)fc.R[5], R6 = (float)fc.R[6], R7 = (float)fc.R[7], R8 = (float)fc.R[8];
+                // Two stencil points per pass in PACKED fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes of arithmetic per instruction, the
+                // fp32 half of this kernel's issue time): the chain below is the same for every point, only the scatter into J is per point
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x0 = pv[j].x0, y0 = pv[j].y0, iz = pv[j].iz;
-                    const float r2 = x0 * x0 + y0 * y0, r4 = r2 * r2, r6 = r4 * r2;
-                    const float dc = 1.0f + k0 * r2 + k1 * r4 + k2 * r6;
-                    const float dcr = k0 + 2.0f * k1 * r2 + 3.0f * k2 * r4;          // d dc / d r2
-                    const float xd = x0 * dc + 2.0f * k3 * x0 * y0 + k4 * (r2 + 2.0f * x0 * x0);
-                    const float yd = y0 * dc + 2.0f * k4 * xd * y0 + k3 * (r2 + 2.0f * y0 * y0);
-                    const float dxd_dx0 = dc + 2.0f * x0 * x0 * dcr + 2.0f * k3 * y0 + 6.0f * k4 * x0;
-                    const float dxd_dy0 = 2.0f * x0 * y0 * dcr + 2.0f * k3 * x0 + 2.0f * k4 * y0;
-                    const float dyd_dx0 = 2.0f * x0 * y0 * dcr + 2.0f * k4 * y0 * dxd_dx0 + 2.0f * k3 * x0;
-                    const float dyd_dy0 = dc + 2.0f * y0 * y0 * dcr + 2.0f * k4 * (xd + y0 * dxd_dy0) + 6.0f * k3 * y0;
-                    const float au = pv[j].dfdc * fxs, av = pv[j].dfdr * fys;
-                    const float lx = au * dxd_dx0 + av * dyd_dx0, ly = au * dxd_dy0 + av * dyd_dy0;
-                    const float L0 = lx * iz, L1 = ly * iz, L2 = -(lx * x0 + ly * y0) * iz;      // d lum / d Q
-                    const float M0 = L0 * R0 + L1 * R3 + L2 * R6, M1 = L0 * R1 + L1 * R4 + L2 * R7, M2 = L0 * R2 + L1 * R5 + L2 * R8;   // d lum / d P
-                    const float c = cj[j];
+                for (int jp = 0; jp < 4; jp += 2) {
+                    const int ja = jp, jb = jp + 1;
+                    const f2 x0 = {pv[ja].x0, pv[jb].x0}, y0 = {pv[ja].y0, pv[jb].y0}, iz = {pv[ja].iz, pv[jb].iz};
+                    const f2 dfdc = {pv[ja].dfdc, pv[jb].dfdc}, dfdr = {pv[ja].dfdr, pv[jb].dfdr};
+                    const f2 r2 = x0 * x0 + y0 * y0, r4 = r2 * r2, r6 = r4 * r2;
+                    const f2 dc = 1.0f + k0 * r2 + k1 * r4 + k2 * r6;
+                    const f2 dcr = k0 + 2.0f * k1 * r2 + 3.0f * k2 * r4;          // d dc / d r2
+                    const f2 xd = x0 * dc + 2.0f * k3 * x0 * y0 + k4 * (r2 + 2.0f * x0 * x0);
+                    const f2 yd = y0 * dc + 2.0f * k4 * xd * y0 + k3 * (r2 + 2.0f * y0 * y0);
+                    const f2 dxd_dx0 = dc + 2.0f * x0 * x0 * dcr + 2.0f * k3 * y0 + 6.0f * k4 * x0;
+                    const f2 dxd_dy0 = 2.0f * x0 * y0 * dcr + 2.0f * k3 * x0 + 2.0f * k4 * y0;
+                    const f2 dyd_dx0 = 2.0f * x0 * y0 * dcr + 2.0f * k4 * y0 * dxd_dx0 + 2.0f * k3 * x0;
+                    const f2 dyd_dy0 = dc + 2.0f * y0 * y0 * dcr + 2.0f * k4 * (xd + y0 * dxd_dy0) + 6.0f * k3 * y0;
+                    const f2 au = dfdc * fxs, av = dfdr * fys;
+                    const f2 lx = au * dxd_dx0 + av * dyd_dx0, ly = au * dxd_dy0 + av * dyd_dy0;
+                    const f2 L0 = lx * iz, L1 = ly * iz, L2 = -(lx * x0 + ly * y0) * iz;      // d lum / d Q
+                    const f2 M0 = L0 * R0 + L1 * R3 + L2 * R6, M1 = L0 * R1 + L1 * R4 + L2 * R7, M2 = L0 * R2 + L1 * R5 + L2 * R8;   // d lum / d P
+                    const f2 c = {cj[ja], cj[jb]};
                     // E_j = B_j - lum_j;  dE/dg = alb * N dLs + s * N M,  dE/ds (direct) = M . n
-                    const float v[3] = {q[j].alb * q[j].dLs[0] + q[j].s * M0, q[j].alb * q[j].dLs[1] + q[j].s * M1, q[j].alb * q[j].dLs[2] + q[j].s * M2};
-                    float G[3]; apply_normal_jac(q[j], v, G);
-                    const float direct = M0 * q[j].n[0] + M1 * q[j].n[1] + M2 * q[j].n[2];
-                    J[PS[j][1]] += c * G[0]; J[PS[j][2]] += c * G[1]; J[PS[j][3]] += c * G[2];
-                    J[PS[j][0]] += c * (direct - (G[0] + G[1] + G[2]));
-                    J[P_ALB + j] = c * q[j].Ls;
+                    const f2 alb = {q[ja].alb, q[jb].alb}, sv = {q[ja].s, q[jb].s}, il = {q[ja].inv_len, q[jb].inv_len};
+                    const f2 n0 = {q[ja].n[0], q[jb].n[0]}, n1 = {q[ja].n[1], q[jb].n[1]}, n2 = {q[ja].n[2], q[jb].n[2]};
+                    const f2 v0 = alb * f2{q[ja].dLs[0], q[jb].dLs[0]} + sv * M0, v1 = alb * f2{q[ja].dLs[1], q[jb].dLs[1]} + sv * M1, v2 = alb * f2{q[ja].dLs[2], q[jb].dLs[2]} + sv * M2;
+                    // v -> (I - n n^T) v / |g|   (or v when |g| == 0: apply_normal_jac)
+                    const f2 d = n0 * v0 + n1 * v1 + n2 * v2;
+                    f2 G0 = (v0 - n0 * d) * il, G1 = (v1 - n1 * d) * il, G2 = (v2 - n2 * d) * il;
+                    if (il.x == 0.0f) { G0.x = v0.x; G1.x = v1.x; G2.x = v2.x; }
+                    if (il.y == 0.0f) { G0.y = v0.y; G1.y = v1.y; G2.y = v2.y; }
+                    const f2 direct = M0 * n0 + M1 * n1 + M2 * n2;
+                    const f2 cG0 = c * G0, cG1 = c * G1, cG2 = c * G2, cD = c * (direct - (G0 + G1 + G2)), cLs = c * f2{q[ja].Ls, q[jb].Ls};
+                    J[PS[ja][1]] += cG0.x; J[PS[ja][2]] += cG1.x; J[PS[ja][3]] += cG2.x; J[PS[ja][0]] += cD.x; J[P_ALB + ja] = cLs.x;
+                    J[PS[jb][1]] += cG0.y; J[PS[jb][2]] += cG1.y; J[PS[jb][3]] += cG2.y; J[PS[jb][0]] += cD.y; J[P_ALB + jb] = cLs.y;
                     // pose: d lum/d t = L ; d lum/d omega = (P x M)^T Jr
-                    J[P_POSE + 3] -= c * L0; J[P_POSE + 4] -= c * L1; J[P_POSE + 5] -= c * L2;
-                    const float Px = (float)q[j].P[0], Py = (float)q[j].P[1], Pz = (float)q[j].P[2];
-                    Wx += c * (Py * M2 - Pz * M1); Wy += c * (Pz * M0 - Px * M2); Wz += c * (Px * M1 - Py * M0);
-                    J[P_INTR + 0] -= c * pv[j].dfdc * psf * xd; J[P_INTR + 1] -= c * pv[j].dfdr * psf * yd;
-                    J[P_INTR + 2] -= c * pv[j].dfdc * psf;      J[P_INTR + 3] -= c * pv[j].dfdr * psf;
-                    const float dxk0 = x0 * r2, dxk1 = x0 * r4, dxk2 = x0 * r6, dxk3 = 2.0f * x0 * y0, dxk4 = r2 + 2.0f * x0 * x0;
-                    const float c2 = 2.0f * k4 * y0;
-                    J[P_DIST + 0] -= c * (au * dxk0 + av * (y0 * r2 + c2 * dxk0));
-                    J[P_DIST + 1] -= c * (au * dxk1 + av * (y0 * r4 + c2 * dxk1));
-                    J[P_DIST + 2] -= c * (au * dxk2 + av * (y0 * r6 + c2 * dxk2));
-                    J[P_DIST + 3] -= c * (au * dxk3 + av * (c2 * dxk3 + (r2 + 2.0f * y0 * y0)));
-                    J[P_DIST + 4] -= c * (au * dxk4 + av * (2.0f * xd * y0 + c2 * dxk4));
+                    const f2 cL0 = c * L0, cL1 = c * L1, cL2 = c * L2;
+                    J[P_POSE + 3] -= cL0.x + cL0.y; J[P_POSE + 4] -= cL1.x + cL1.y; J[P_POSE + 5] -= cL2.x + cL2.y;
+                    const f2 Px = {(float)q[ja].P[0], (float)q[jb].P[0]}, Py = {(float)q[ja].P[1], (float)q[jb].P[1]}, Pz = {(float)q[ja].P[2], (float)q[jb].P[2]};
+                    const f2 wx = c * (Py * M2 - Pz * M1), wy = c * (Pz * M0 - Px * M2), wz = c * (Px * M1 - Py * M0);
+                    Wx += wx.x + wx.y; Wy += wy.x + wy.y; Wz += wz.x + wz.y;
+                    const f2 cdc = c * dfdc * psf, cdr = c * dfdr * psf;
+                    const f2 i0 = cdc * xd, i1 = cdr * yd;
+                    J[P_INTR + 0] -= i0.x + i0.y; J[P_INTR + 1] -= i1.x + i1.y; J[P_INTR + 2] -= cdc.x + cdc.y; J[P_INTR + 3] -= cdr.x + cdr.y;
+                    const f2 dxk0 = x0 * r2, dxk1 = x0 * r4, dxk2 = x0 * r6, dxk3 = 2.0f * x0 * y0, dxk4 = r2 + 2.0f * x0 * x0;
+                    const f2 c2 = 2.0f * k4 * y0;
+                    const f2 e0 = c * (au * dxk0 + av * (y0 * r2 + c2 * dxk0)), e1 = c * (au * dxk1 + av * (y0 * r4 + c2 * dxk1)), e2 = c * (au * dxk2 + av * (y0 * r6 + c2 * dxk2));
+                    const f2 e3 = c * (au * dxk3 + av * (c2 * dxk3 + (r2 + 2.0f * y0 * y0))), e4 = c * (au * dxk4 + av * (2.0f * xd * y0 + c2 * dxk4));
+                    J[P_DIST + 0] -= e0.x + e0.y; J[P_DIST + 1] -= e1.x + e1.y; J[P_DIST + 2] -= e2.x + e2.y; J[P_DIST + 3] -= e3.x + e3.y; J[P_DIST + 4] -= e4.x + e4.y;
                 }
                 J[P_POSE + 0] = -(Wx * fc.Jr[0] + Wy * fc.Jr[3] + Wz * fc.Jr[6]);
                 J[P_POSE + 1] = -(Wx * fc.Jr[1] + Wy * fc.Jr[4] + Wz * fc.Jr[7]);
                 J[P_POSE + 2] = -(Wx * fc.Jr[2] + Wy * fc.Jr[5] + Wz * fc.Jr[8]);
-                bool fin = true;
+                // all 29 partials finite?  0 * x is 0 for a finite x and NaN for Inf / NaN: one fma per partial instead of a class test + mask merge each
+                float finz = 0.0f;
 #pragma unroll
-                for (int i = 0; i < P_TOTAL; ++i) fin = fin && !(isnan(J[i]) || isinf(J[i]));
-                if (!fin) continue;
+                for (int i = 0; i < P_TOTAL; ++i) finz = __builtin_fmaf(J[i], 0.0f, finz);
+                if (!(finz == 0.0f)) continue;
                 // rows of a voxel are compacted into its first slots (creation order = ascending observation weight)
 #pragma unroll
                 for (int gq = 0; gq < 7; ++gq)

@@ -62,3 +62,22 @@ def gpu_context(sc, arrays, vsh):
     ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
     ctx.set_voxel_sh(vsh)
     return ctx
+
+
+def align_by_key(out, ref, max_frac=2e-4):
+    """The level schedule re-sparsifies the grid from OPTIMISED values (|sdf_refined| > thres_shell and the sign tests of clearVoxelsOutsideThinShell,
+    algorithms.cpp:376-440): a voxel within round-off of such a threshold may be kept on one side and dropped on the other.  The visit ORDER of what both
+    keep must still be the reference's (erase keeps relative order; the children of an upsampling follow their parents), and only a handful of voxels may
+    differ at all.  Returns (out, ref) restricted to the common keys (unchanged when the key arrays are equal)."""
+    import numpy as np
+    if np.array_equal(out["keys"], ref["keys"]):
+        return out, ref
+    def as_set(k): return set(map(tuple, k.tolist()))
+    so, sr = as_set(out["keys"]), as_set(ref["keys"])
+    assert len(so ^ sr) <= max(16, int(max_frac * len(sr))), (len(so - sr), len(sr - so), len(sr))
+    common = so & sr
+    mo = np.fromiter((tuple(k) in common for k in out["keys"].tolist()), bool, len(out["keys"])); mr = np.fromiter((tuple(k) in common for k in ref["keys"].tolist()), bool, len(ref["keys"]))
+    out = {k: (v[mo] if getattr(v, "shape", ())[:1] == mo.shape else v) for k, v in out.items()}
+    ref = {k: (v[mr] if getattr(v, "shape", ())[:1] == mr.shape else v) for k, v in ref.items()}
+    assert np.array_equal(out["keys"], ref["keys"])                       # same relative visit order
+    return out, ref

@@ -32,19 +32,7 @@ def _oracle_refine(O, sc, frames, levels, ocfg, rc, intr, dist, poses, pose_eps=
 
 
 def _check_fields(out, ref, env):
-    if not np.array_equal(out["keys"], ref["keys"]):
-        # The schedule re-sparsifies the grid from OPTIMISED values (|sdf_refined| > thres_shell, sign tests of clearVoxelsOutsideThinShell,
-        # algorithms.cpp:376-440): a voxel within round-off of such a threshold may be kept on one side and dropped on the other.  The visit ORDER of what
-        # both keep must still be the reference's (erase keeps relative order; the children of an upsampling follow their parents), and only a handful of
-        # voxels may differ at all.
-        def as_set(k): return set(map(tuple, k.tolist()))
-        so, sr = as_set(out["keys"]), as_set(ref["keys"])
-        assert len(so ^ sr) <= max(16, int(2e-4 * len(sr))), (len(so - sr), len(sr - so), len(sr))
-        common = so & sr
-        mo = np.fromiter((tuple(k) in common for k in out["keys"].tolist()), bool, len(out["keys"])); mr = np.fromiter((tuple(k) in common for k in ref["keys"].tolist()), bool, len(ref["keys"]))
-        out = {k: (v[mo] if getattr(v, "shape", ())[:1] == mo.shape else v) for k, v in out.items()}
-        ref = {k: (v[mr] if getattr(v, "shape", ())[:1] == mr.shape else v) for k, v in ref.items()}
-        assert np.array_equal(out["keys"], ref["keys"])                       # same relative visit order
+    out, ref = helpers.align_by_key(out, ref)
     assert (out["weight"] != ref["weight"]).mean() <= 2e-4, int((out["weight"] != ref["weight"]).sum())      # (a child next to a differing voxel interpolates other corners)
     d_sdf = np.abs(out["sdf_refined"] - ref["sdf_refined"]); d_alb = np.abs(out["albedo"] - ref["albedo"])
     smax = float(np.abs(ref["sdf_refined"]).max()); amax = float(np.abs(ref["albedo"]).max())

@@ -7,8 +7,9 @@
 #include <vector>
 
 template <int KIND> __global__ void __launch_bounds__(256) k(double* out, int n, double seed) {
-    double a[8]; float b[8];
-    for (int i = 0; i < 8; ++i) { a[i] = seed + i + threadIdx.x * 1e-3; b[i] = (float)a[i]; }
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    double a[8]; float b[8]; f2 b2[8];
+    for (int i = 0; i < 8; ++i) { a[i] = seed + i + threadIdx.x * 1e-3; b[i] = (float)a[i]; b2[i] = f2{b[i], b[i] + 1.0f}; }
     const double m = 1.0000001, c = 1e-9; const float mf = 1.0000001f, cf = 1e-9f;
     for (int it = 0; it < n; ++it) {
 #pragma unroll
@@ -23,10 +24,11 @@ template <int KIND> __global__ void __launch_bounds__(256) k(double* out, int n,
             if (KIND == 7) { asm volatile("v_sqrt_f64 %0, %1" : "=v"(a[i]) : "v"(a[i])); }
             if (KIND == 8) a[i] = 1.0 / a[i];                                                                           // full IEEE division sequence
             if (KIND == 9) { int x = __double2loint(a[i]); asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(x)); a[i] = __hiloint2double(__double2hiint(a[i]), x); }
+            if (KIND == 11) { const f2 mm = {mf, mf}, cc = {cf, cf}; asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(b2[i]) : "v"(b2[i]), "v"(mm), "v"(cc)); }   // 2 fp32 fma per lane
             if (KIND == 10) { asm volatile("v_floor_f64 %0, %1" : "=v"(a[i]) : "v"(a[i])); }
         }
     }
-    double s = 0; for (int i = 0; i < 8; ++i) s += a[i] + b[i];
+    double s = 0; for (int i = 0; i < 8; ++i) s += a[i] + b[i] + b2[i].x + b2[i].y;
     if (s == 12345.678) out[0] = s;
 }
 
@@ -50,7 +52,7 @@ int main() {
         run<0>("v_fma_f64", w, clock, cus); run<1>("v_mul_f64", w, clock, cus); run<2>("v_add_f64", w, clock, cus);
         run<3>("v_fma_f32", w, clock, cus); run<4>("v_mul_f32", w, clock, cus); run<5>("v_cvt_f64_f32 + v_add_f32", w, clock, cus);
         run<6>("v_rcp_f64", w, clock, cus); run<7>("v_sqrt_f64", w, clock, cus); run<8>("1.0 / x (fp64 division)", w, clock, cus);
-        run<9>("v_mov_b32", w, clock, cus); run<10>("v_floor_f64", w, clock, cus);
+        run<9>("v_mov_b32", w, clock, cus); run<10>("v_floor_f64", w, clock, cus); run<11>("v_pk_fma_f32 (2 fma per lane)", w, clock, cus);
     }
     return 0;
 }
