@@ -199,9 +199,25 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
             if (MODE == S3_NORMAL || MODE == S3_RESET) {
                 const float4 as = in.as, aa = in.aa;
                 accv[0][0] = as.x; accv[0][1] = as.y; accv[0][2] = as.z; accv[0][3] = as.w; accv[1][0] = aa.x; accv[1][1] = aa.y; accv[1][2] = aa.z; accv[1][3] = aa.w;
+                // halo fold: the (entry, halo slot) pairs of the 4 entries are ONE contiguous run [o.x, o4) of the sorted pair list.  Batches of 8: all slot
+                // indices are requested together, then all halo sums — two memory round trips per batch instead of two per PAIR (the per-pair loop was a
+                // chain of ~9 dependent loads per thread; this kernel is latency-bound, not bandwidth-bound).  Sums are added in ascending pair order, as before.
                 const int ob[5] = {in.o.x, in.o.y, in.o.z, in.o.w, in.o4};
+                for (int j0 = ob[0]; j0 < ob[4]; j0 += 8) {
+                    int pos[8]; float2 hv[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) for (int j = ob[k]; j < ob[k + 1]; ++j) { const float2 v = a.qh[a.ext_pos[j]]; accv[0][k] += v.x; accv[1][k] += v.y; }
+                    for (int u = 0; u < 8; ++u) pos[u] = (j0 + u < ob[4]) ? a.ext_pos[j0 + u] : -1;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hv[u] = pos[u] >= 0 ? a.qh[pos[u]] : make_float2(0.0f, 0.0f);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u;
+                        if (j < ob[4]) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { const bool mine = j >= ob[k] && j < ob[k + 1]; accv[0][k] += mine ? hv[u].x : 0.0f; accv[1][k] += mine ? hv[u].y : 0.0f; }
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int seg = 0; seg < 2; ++seg) {
