@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                                                         int reps, int tiles_per_block, const PcgState* __restrict__ state) {
     if (state && state->done) return;
     extern __shared__ float lds[];        // [reps][rs] pose accumulators (6 per keyframe; COLNORM: the 21 block entries) + [NCAM] + JTJP: staged camera part of u [6K+9]
-    const int A = r.A, K = p.K; const size_t Acap = r.Acap;
+    const int K = p.K; const size_t Acap = r.Acap;
     const int nshared = 6 * K + 9;
     // replica stride: ODD, so that the replicas of one keyframe's accumulator fall into different LDS banks
     const int rs = ((MODE == PASS_COLNORM) ? 21 * K : 6 * K) | 1;

@@ -520,7 +520,8 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
                                                       t.ghost_tiles, ntl, state, cam_partials, cam_stride); } while (0)
             const bool gh = t.n_ghost > 0;
             static const int pipe = [] { const char* e = std::getenv("I3D_EGT_PIPE"); return e ? std::atoi(e) : 0; }();      // single rank; I3D_EGT_PIPE=0 / 1 / 2 for A/B runs (1, 2: the compiler spills what is carried across the pull phase)
-            if (r.slots == 5) { if (gh) I3D_EGT(5, true); else I3D_EGT(5, false); }      // the shipped num_observations (data/intrinsic3d.yml): unrolled row loop
+            static const int generic = [] { const char* e = std::getenv("I3D_EGT_GENERIC"); return e ? std::atoi(e) : 0; }();   // A/B: the run-time row loop (skips the slots no lane of the wave uses)
+            if (r.slots == 5 && !generic) { if (gh) I3D_EGT(5, true); else I3D_EGT(5, false); }      // the shipped num_observations (data/intrinsic3d.yml): unrolled row loop
             else { if (gh) I3D_EGT(0, true); else I3D_EGT(0, false); }
 #undef I3D_EGT
             written = blocks;
