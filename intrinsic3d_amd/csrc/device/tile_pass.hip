@@ -169,10 +169,10 @@ static __device__ inline void wave_accumulate_lds(bool valid, int f, F val, floa
 
 // GHOSTS: the tile list continues with foreign tiles that hold this rank's ghost entries (sharded runs).  A template parameter because the
 // extra wave-uniform test costs the unrolled row loop registers: 12 instead of 4 spilled, 363 instead of 344 us on the single-GPU bench.
-// PIPE: software pipelining across the tiles of a (persistent) workgroup — the loads of the NEXT tile (its operator input, flags, local slots, halo gathers
-// and its first two row blocks) are issued right after the last row of the current tile, BEFORE the barrier / pull / store phase, so the memory
-// pipe keeps streaming while the workgroup works in LDS (round 2: 0.324 ms against 0.235 ms for the bare row stream; the difference was this phase).
-template <int T, int HMAX, int SLOTS, bool GHOSTS, int PIPE /* 0 off | 1 operator input, flags, slots, halo gathers | 2 + the first row block */>
+// (Software pipelining across the tiles of a workgroup — the next tile's input gathers / first row block issued before the pull phase of the current
+// one — was built and measured in rounds 2 and 3, three sessions: never better than 1 %, slower whenever the values carried across the pull phase
+// spilled; removed.  DESIGN.md section 9.)
+template <int T, int HMAX, int SLOTS, bool GHOSTS>
 __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const float* __restrict__ u, const unsigned* __restrict__ lnbr,
                                                         const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx, const int* __restrict__ halo_cnt,
                                                         double* __restrict__ shared, float* __restrict__ qacc, float* __restrict__ qh, double* __restrict__ pq_partials,
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     const int i = threadIdx.x;
     double pq = 0.0;
 
-    // the tile in flight (mutable: with PIPE the loads of the next tile overwrite them while the current one is still being pulled)
+    // the tile in flight
     constexpr int NQH = (HMAX + T - 1) / T;
     int tile = 0, base = 0, a = 0, H = 0, nr_ld = 0; bool in = false, owned = false; size_t ac = 0;
     float us = 0.0f, ua = 0.0f; uint8_t fl = 0, rf_ld = 0; unsigned ln[5]; float hs[NQH], ha[NQH]; RowBlock rwA, rwB;
@@ -234,8 +234,8 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     };
     auto issue_A = [&]() { load_block(rwA, 0, r.slots); };
     auto issue_B = [&]() { if (SLOTS > 1 || (SLOTS == 0 && r.slots > 1)) load_block(rwB, 1, r.slots); };
-    // part 1: the operator input of the tile and of its halo — the only DEPENDENT loads of a tile (halo index -> gather); with PIPE these cross the
-    // pull phase of the previous tile (8 registers).  part 2: flags, local slots (coalesced, issued with the row blocks).
+    // part 1: the operator input of the tile and of its halo — the only DEPENDENT loads of a tile (halo index -> gather).
+    // part 2: flags, local slots (coalesced, issued with the row blocks).
     auto issue_in = [&](int tk) {
         const bool ghost = GHOSTS && tk >= n_own;
         tile = ghost ? ghost_list[tk - n_own] : tile_first + tk;
@@ -249,13 +249,12 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         H = halo_cnt[tile];
         us = in ? u[a] : 0.0f; ua = in ? u[chunk + a] : 0.0f;
         // branch-free (unconditional loads, padding slots gather entry 0 and are zeroed when staged): loads under divergent branches are waited for at
-        // every join, which would serialise exactly the dependent gathers this prefetch is meant to hide
+        // every join, which would serialise these dependent gathers
         int he[NQH];
 #pragma unroll
         for (int q = 0; q < NQH; ++q) he[q] = __builtin_nontemporal_load(&halo_idx[(size_t)tile * HMAX + (i + q * T < HMAX ? i + q * T : 0)]);
 #pragma unroll
         for (int q = 0; q < NQH; ++q) { const int e = (i + q * T < H) ? he[q] : 0; hs[q] = u[e]; ha[q] = u[chunk + e]; }
-        if (PIPE == 2) issue_A();
     };
     auto issue_meta = [&]() {
         fl = in ? r.aflags[ac] : 0;
@@ -264,12 +263,11 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
 #pragma unroll
         for (int w = 0; w < 5; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);      // per-entry plan data: read once per pass, like the rows
     };
-    if (PIPE && tile0 < tk_end) issue_in(tile0);
     for (int tk = tile0; tk < tk_end; ++tk) {
-        if (!PIPE) issue_in(tk);
+        issue_in(tk);
         issue_meta();
-        if (PIPE != 2) issue_A();
-        issue_B();                                         // (PIPE: only slot 0 travels across the pull phase — both blocks would not fit the 128 registers)
+        issue_A();
+        issue_B();
         const bool ghost_tile = GHOSTS && tk >= n_own;     // a few ghost rows on the rim of a neighbour's tile: most of its waves have nothing to stream
         // ---- stage the operator input of tile + halo, clear the accumulators ----
         u_s[i] = us; u_a[i] = ua;
@@ -381,9 +379,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
             if (sy >= T && sy != ZSLOT) lds_add(&qh_a[sy - T], Cme[10 * T]);
             if (sz >= T && sz != ZSLOT) lds_add(&qh_a[sz - T], Cme[11 * T]);
         }
-        // the pull below works on the CURRENT tile; with PIPE the next tile's loads go out first and overwrite the tile variables
         const int a_c = a, H_c = H, tile_c = tile; const bool in_c = in, owned_c = owned; const float ua_c = ua;
-        if (PIPE && tk + 1 < tk_end) issue_in(tk + 1);
         __syncthreads();
         // ---- pull: every entry collects the column sums of the tile entries whose stencil contains it ----
         if (in_c) {
@@ -511,17 +507,14 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
             // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
             // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
             if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
-#define I3D_EGT_ARGS r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, t.ghost_tiles, ntl, state, cam_partials, cam_stride
 #define I3D_EGT(SL, GH) do { \
-        if (pipe == 1 && !(GH)) { (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); k_eg_tile<T, HMAX, SL, false, 1><<<blocks, T, lds, st>>>(I3D_EGT_ARGS); break; } \
-        if (pipe == 2 && !(GH)) { (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); k_eg_tile<T, HMAX, SL, false, 2><<<blocks, T, lds, st>>>(I3D_EGT_ARGS); break; } \
-        (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, GH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        k_eg_tile<T, HMAX, SL, GH, 0><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
-                                                      t.ghost_tiles, ntl, state, cam_partials, cam_stride); } while (0)
+        (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, GH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        k_eg_tile<T, HMAX, SL, GH><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
+                                                   t.ghost_tiles, ntl, state, cam_partials, cam_stride); } while (0)
             const bool gh = t.n_ghost > 0;
-            static const int pipe = [] { const char* e = std::getenv("I3D_EGT_PIPE"); return e ? std::atoi(e) : 0; }();      // single rank; I3D_EGT_PIPE=0 / 1 / 2 for A/B runs (1, 2: the compiler spills what is carried across the pull phase)
-            static const int generic = [] { const char* e = std::getenv("I3D_EGT_GENERIC"); return e ? std::atoi(e) : 0; }();   // A/B: the run-time row loop (skips the slots no lane of the wave uses)
-            if (r.slots == 5 && !generic) { if (gh) I3D_EGT(5, true); else I3D_EGT(5, false); }      // the shipped num_observations (data/intrinsic3d.yml): unrolled row loop
+            // the shipped num_observations (data/intrinsic3d.yml): unrolled row loop.  (The run-time loop, which skips the slots no lane of a wave uses, is
+            // slower even where 36 % of the slots are empty: 0.577 vs 0.483 ms on --band 2, 0.336 vs 0.272 on the default workload.)
+            if (r.slots == 5) { if (gh) I3D_EGT(5, true); else I3D_EGT(5, false); }
             else { if (gh) I3D_EGT(0, true); else I3D_EGT(0, false); }
 #undef I3D_EGT
             written = blocks;
