@@ -49,12 +49,22 @@ struct PointShared {   // per stencil point j in {000,100,010,001}; value path f
     float alb;
 };
 
+// 1 / x on the fp64 VALUE path: v_rcp_f64 + two Newton steps (~40 cycles) instead of the correctly rounded division sequence (68 cycles, ten
+// instructions; tools/experiments/valu_rate.hip).  Within 1-2 ulp — the value path is held to 1e-4 of the reference, discrete decisions do not
+// go through here — and x = 0 / Inf / NaN still end in a NaN or out-of-range coordinate, i.e. in a dropped row, as with the division.
+static __device__ inline double rcp64(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 static __device__ inline void shared_point(PointShared& q, double s, double sx, double sy, double sz, double alb, const float sh[9],
                                            int cx, int cy, int cz, double vs) {
     double g0 = sx - s, g1 = sy - s, g2 = sz - s;
     const double len = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
     // (one reciprocal instead of the reference's three divisions: 1e-16 relative on a value path held to 1e-4; an fp64 division is 67 cycles here)
-    if (len > 0.0) { const double il = 1.0 / len; q.inv_len = (float)il; g0 *= il; g1 *= il; g2 *= il; } else q.inv_len = 0.0f;
+    if (len > 0.0) { const double il = rcp64(len); q.inv_len = (float)il; g0 *= il; g1 *= il; g2 *= il; } else q.inv_len = 0.0f;
     q.s = (float)s; q.alb = (float)alb;
     q.P[0] = (double)cx * vs - g0 * s; q.P[1] = (double)cy * vs - g1 * s; q.P[2] = (double)cz * vs - g2 * s;
     const double nx = g0, ny = g1, nz = g2;
@@ -115,8 +125,9 @@ static __device__ inline void bicubic_taps(const float* __restrict__ img, int w,
 //   w0' = (-1 + x(4 - 3x))/2  w1' = x(9x - 10)/2       w2' = (1 + x(8 - 9x))/2   w3' = x(3x - 2)/2
 template <class T> static __device__ inline void cr_weights(T x, T w[4]) {
     const T h = (T)0.5, x2 = x * x;
-    w[0] = h * x * ((T)-1.0 + x * ((T)2.0 - x)); w[1] = (T)1.0 + h * x2 * ((T)3.0 * x - (T)5.0);
+    w[0] = h * x * ((T)-1.0 + x * ((T)2.0 - x));
     w[2] = h * x * ((T)1.0 + x * ((T)4.0 - (T)3.0 * x)); w[3] = h * x2 * (x - (T)1.0);
+    w[1] = (T)1.0 - (w[0] + w[2] + w[3]);            // the four weights sum to 1 (= 1 + x^2 (3x - 5) / 2)
 }
 template <class T> static __device__ inline void cr_dweights(T x, T d[4]) {
     const T h = (T)0.5;
@@ -152,7 +163,7 @@ static __device__ inline bool project_point(const double P[3], const double R[9]
     const double Y = R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1];
     const double Z = R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2];
     const double ps = p.pyr_scale;
-    const double iz = 1.0 / Z;
+    const double iz = rcp64(Z);
     const double x0 = X * iz, y0 = Y * iz;
     const double r2 = x0 * x0 + y0 * y0, r4 = r2 * r2, r6 = r4 * r2;
     const double dc = 1.0 + p.dist[0] * r2 + p.dist[1] * r4 + p.dist[2] * r6;
@@ -160,9 +171,9 @@ static __device__ inline bool project_point(const double P[3], const double R[9]
     const double yd = y0 * dc + 2.0 * p.dist[4] * xd * y0 + p.dist[3] * (r2 + 2.0 * y0 * y0);
     u = (p.intr[0] * ps) * xd + p.intr[2] * ps; v = (p.intr[1] * ps) * yd + p.intr[3] * ps;
     if (WITH_J) { o.x0 = (float)x0; o.y0 = (float)y0; o.iz = (float)iz; }
-    if (u < 0.0 || u > (double)(p.w - 1) || v < 0.0 || v > (double)(p.h - 1)) return false;
-    if (!(u == u) || !(v == v)) return false;      // NaN coordinates: Ceres' comparisons are all false -> in-bounds -> NaN lum -> invalid row
-    return true;
+    // outside the image -> no row (cost.h:100-105).  NaN coordinates pass the reference's test (all its comparisons are false) and end in a NaN luminance,
+    // i.e. in an invalid row: the same outcome as failing here, so ONE test written to be false for NaN serves both
+    return u >= 0.0 && u <= (double)(p.w - 1) && v >= 0.0 && v <= (double)(p.h - 1);
 }
 
 // operators.cpp:142-147
@@ -338,7 +349,7 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowVi
                     const double d1 = (q[1].B - q[0].B) - (lum[1] - lum[0]), d2 = (q[2].B - q[0].B) - (lum[2] - lum[0]), d3 = (q[3].B - q[0].B) - (lum[3] - lum[0]);
                     res = sqrt(d1 * d1 + d2 * d2 + d3 * d3);
                     if (!(res > 0.0) || isinf(res)) { ok = false; res = 0.0; }    // 0, NaN, inf -> NV_INVALID_RESIDUAL (shading_cost.h:186-195)
-                    else { const double ir = 1.0 / res; cj[1] = (float)(d1 * ir); cj[2] = (float)(d2 * ir); cj[3] = (float)(d3 * ir); cj[0] = -(float)((d1 + d2 + d3) * ir); }
+                    else { const double ir = rcp64(res); cj[1] = (float)(d1 * ir); cj[2] = (float)(d2 * ir); cj[3] = (float)(d3 * ir); cj[0] = -(float)((d1 + d2 + d3) * ir); }
                 }
                 if (!WITH_J) { if (ok) cost += 0.5 * (double)roww * p.type_w[0] * res * res; continue; }
                 if (!ok) continue;                                                 // dropped at creation (shading_cost.cpp:136-145)

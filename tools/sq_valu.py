@@ -5,12 +5,12 @@
 
 SQ_INSTS_VALU is the mean over the dispatches that did work.  The fp64 share cannot be counted by a PMC counter on gfx950; it is the STATIC share of
 fp64 VALU instructions in the kernel's ISA (hipcc -S of device/build.hip and device/tile_pass.hip for gfx950, counted by mnemonic), which for these
-straight-line row loops is what the dynamic mix converges to: k_build<true> 936 fp64 and 429 packed-fp32 (v_pk_*) of 2879 VALU instructions, k_eg_tile 0
+straight-line row loops is what the dynamic mix converges to: k_build<true> 885 fp64 and 421 packed-fp32 (v_pk_*) of 2804 VALU instructions, k_eg_tile 0
 (fp32 only, a handful of fp64 conversions per tile).  Packed fp32 instructions are priced apart: 5.2 cycles per wave-instruction, like fp64
 (tools/experiments/valu_rate.hip)."""
 import json, re, sys
-F64_SHARE = {"build": 936.0 / 2879.0, "cost": 843.0 / 1420.0, "eg_pass": 0.0}
-PK_SHARE = {"build": 429.0 / 2879.0}
+F64_SHARE = {"build": 885.0 / 2804.0, "cost": 799.0 / 1362.0, "eg_pass": 0.0}
+PK_SHARE = {"build": 421.0 / 2804.0}
 PAT = {"build": r"k_build<true", "cost": r"k_build<false", "eg_pass": r"k_eg_tile", "observe": r"k_observe", "pcg_step": r"k_pcg_step3<1>", "pcg_dir": r"k_pcg_dir3"}
 sq = json.load(open(sys.argv[1])); bench = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
 out = {"source": "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY over "
