@@ -325,8 +325,9 @@ int launch_pcg_step3(hipStream_t st, int mode, Step3Args a) {
 __global__ void k_ext_offsets(int n, const int* __restrict__ ext_e, int A, int* __restrict__ ext_off) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > n) return;
-    const int cur = j < n ? min(ext_e[j], A) : A;
-    const int prev = j > 0 ? min(ext_e[j - 1], A) : -1;
+    // (clamped on both sides: the keys of a plan that overflowed are not entries, and nothing here may write outside [0, A])
+    const int cur = j < n ? min(max(ext_e[j], -1), A) : A;
+    const int prev = j > 0 ? min(max(ext_e[j - 1], -1), A) : -1;
     for (int e = prev + 1; e <= cur; ++e) ext_off[e] = j;
 }
 void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext_off) { k_ext_offsets<<<(n + 1 + 255) / 256, 256, 0, st>>>(n, ext_e, A, ext_off); }

@@ -70,7 +70,11 @@ __global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, 
     for (int i = threadIdx.x; i < 4096; i += 1024) if (hkeys[i] >= 0) { const int pos = atomicAdd(&cnt, 1); if (pos < TP_PLAN_LIST) hlist[pos] = hkeys[i]; }
     __syncthreads();
     const int H = cnt;
-    if (H > hlimit) { if (threadIdx.x == 0) { *overflow = 1; halo_cnt[tile] = 0; } return; }      // the caller falls back to the untiled pass
+    if (H > hlimit) {                                                                             // the caller plans again with the other geometry / falls back to the untiled pass
+        for (int i = threadIdx.x; i < hmax; i += 1024) halo_idx[(size_t)tile * hmax + i] = TP_NONE;    // (nothing stale or uninitialised reaches the sort of the pairs)
+        if (threadIdx.x == 0) { *overflow = 1; halo_cnt[tile] = 0; }
+        return;
+    }
     for (int k = 2; k <= TP_PLAN_LIST; k <<= 1)                                     // bitonic sort, ascending (the padding ends up last)
         for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
@@ -150,7 +154,11 @@ static __device__ inline void wave_accumulate_lds(bool valid, int f, F val, floa
     for (int round = 0; todo != 0ull; ++round) {
         if (round == 3) {                                   // > 3 distinct keyframes in this slot of the wave
             if (pending) {
-                const int lane_off = (threadIdx.x & (reps - 1)) * rs;
+                // (recomputed HERE on purpose: hoisted out of the row loop as a loop invariant it costs a register pair the loop does not have — in the
+                // 1024-entry geometry the compiler spilled it and reloaded it behind every row block, each reload an s_waitcnt vmcnt(0))
+                int lane_rep = (int)(threadIdx.x & (unsigned)(reps - 1));
+                asm volatile("" : "+v"(lane_rep));
+                const int lane_off = lane_rep * rs;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) lds_add(&lds[lane_off + stride * f + i], val(i));
             }
@@ -181,7 +189,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                                                         float* __restrict__ cam_partials /* or null: [gridDim.x][cam_stride] camera block of this workgroup (no atomics) */, int cam_stride) {
     if (state && state->done) return;
     constexpr int ZSLOT = T + HMAX, NSLOT = ZSLOT + 1;
-    extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T]
+    extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T] | p.q [T] fp64
     const int K = p.K; const size_t Acap = r.Acap; const int A = r.A, chunk = r.chunk;
     const int nshared = 6 * K + 9;
     const int rs = (6 * K) | 1;
@@ -210,7 +218,10 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     const int tile0 = blockIdx.x * tiles_per_block;
 #define ui (lds + o_upose + 6 * K)
     const int i = threadIdx.x;
-    double pq = 0.0;
+    // the lane's running p.q (fp64) is parked in LDS: as a register pair it lived across the row loop, and in the 1024-entry geometry that pair was the
+    // value the compiler spilled and reloaded behind every row block (each reload an s_waitcnt vmcnt(0) that drains the row stream)
+#define pq_l reinterpret_cast<double*>(lds + o_u + 2 * NSLOT + 2 * HMAX + T + 4 + 12 * T)
+    pq_l[i] = 0.0;
 
     // the tile in flight
     constexpr int NQH = (HMAX + T - 1) / T;
@@ -287,16 +298,17 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         // ---- regulariser rows (constant coefficients), while the first two row blocks are in flight ----
         {
             const int rg[6] = {sx, mx, sy, my, sz, mz};                    // ring order +x,-x,+y,-y,+z,-z
-            float tr = 0.0f;
+            float tr = 0.0f; double pq_pre = 0.0;
             if (rf & 1) {
                 const float lap = ((((((-6.0f * us) + u_s[rg[0]]) + u_s[rg[1]]) + u_s[rg[2]]) + u_s[rg[3]]) + u_s[rg[4]]) + u_s[rg[5]];
-                tr = tw1 * lap; if (owned) pq += (double)(tr * lap);
+                tr = tw1 * lap; if (owned) pq_pre += (double)(tr * lap);
                 self_s += -6.0f * tr;
 #pragma unroll
                 for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles
             }
             tr_l[i] = tr;
-            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * us; if (owned) pq += (double)(ts * us); self_s += ts; }
+            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * us; if (owned) pq_pre += (double)(ts * us); self_s += ts; }
+            if (rf & 7) pq_l[i] += pq_pre;
         }
 #define Cme (C_l + i)
         float pq_rows = 0.0f;
@@ -363,7 +375,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 }
             }
         }
-        if (owned) pq += (double)pq_rows;
+        if (owned) pq_l[i] += (double)pq_rows;
         // what the pull phase needs in addition (requested now, used behind the barrier): the 6 further reverse slots, the symmetric Ea weights
         unsigned lr[2];
 #pragma unroll
@@ -398,7 +410,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
             float ea = 0.0f, eq = 0.0f;
 #pragma unroll
             for (int d = 0; d < 6; ++d) { const float diff = ua_c - u_a[rg[d]]; const float t = eaw[d] * diff; ea += t; eq += (rg[d] == ZSLOT ? 1.0f : 0.5f) * t * diff; }
-            qa += tw3 * ea; if (owned_c) pq += (double)(tw3 * eq);      // an edge whose other voxel is a list entry is seen from both sides (by their owners)
+            qa += tw3 * ea; if (owned_c) pq_l[i] += (double)(tw3 * eq);      // an edge whose other voxel is a list entry is seen from both sides (by their owners)
             qacc[a_c] = qs; qacc[chunk + a_c] = qa;
         }
 #pragma unroll
@@ -419,7 +431,8 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         if (cam_partials) cam_partials[(size_t)blockIdx.x * cam_stride + q] = v;      // summed in a fixed order by k_pcg_step3's camera workgroups
         else if (v != 0.0f) atomicAdd(&shared[q], (double)v);
     }
-    if (pq_partials) block_partial_d(pq, pq_partials, 1, 0);
+    if (pq_partials) block_partial_d(pq_l[i], pq_partials, 1, 0);
+#undef pq_l
 #undef upose
 #undef u_s
 #undef u_a
@@ -447,8 +460,10 @@ __global__ void __launch_bounds__(256) k_halo_fold(int n, const int* __restrict_
 
 __global__ void k_iota(int n, int* __restrict__ x) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) x[i] = i; }
 
-// tile geometry: T entries per tile / workgroup, HMAX halo slots.  512 (two workgroups per CU, 57 KB of LDS each) unless the environment says 1024.
-static int tp_T() { static int t = 0; if (!t) { const char* e = std::getenv("I3D_EGT_TILE"); t = (e && std::atoi(e) == 1024) ? 1024 : 512; } return t; }
+// tile geometry: T entries per tile / workgroup, HMAX halo slots.  Default 1024 / 2048 (one workgroup of 16 waves per CU, 122 KB of LDS): a third fewer
+// tile boundaries than 512 / 1536 (two workgroups per CU) — same operator time once both row loops were spill-free, cheaper plan and halo fold: 40.1 vs
+// 41.1 ms per iteration in the same-box A/B (profiles/r03_ab_variants.json).  I3D_EGT_TILE=512 selects the other; a plan that overflows falls back to it.
+static int tp_T() { static int t = 0; if (!t) { const char* e = std::getenv("I3D_EGT_TILE"); t = (e && std::atoi(e) == 512) ? 512 : 1024; } return t; }
 static int tp_H() { return tp_T() == 1024 ? 2048 : 1536; }
 int tile_plan_tiles(int A) { return (A + tp_T() - 1) / tp_T(); }
 int tile_plan_hmax() { return tp_H(); }
@@ -467,7 +482,9 @@ hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, s
     const int n = ntiles * t.hmax;
     // tests of the overflow handling: pretend the 512-entry geometry has fewer halo slots than it has (the 1024-entry fallback is not limited)
     const int limit512 = [] { const char* s = std::getenv("I3D_EGT_HMAX_LIMIT"); return s ? std::atoi(s) : 0; }();      // (read per plan: tests set it for one run)
-    const int hlimit = (t.T == 512 && limit512 > 0 && limit512 < t.hmax) ? limit512 : t.hmax;
+    const int limit1024 = [] { const char* s = std::getenv("I3D_EGT_HMAX_LIMIT_1024"); return s ? std::atoi(s) : 0; }();
+    const int lim = t.T == 512 ? limit512 : limit1024;
+    const int hlimit = (lim > 0 && lim < t.hmax) ? lim : t.hmax;
     const bool all = t.tile_first == 0 && t.ntiles_own >= ntiles;
     if (!all) { e = hipMemsetAsync(t.halo_idx, 0x7f, sizeof(int) * (size_t)n, st); if (e != hipSuccess) return e;
                 e = hipMemsetAsync(t.halo_cnt, 0, sizeof(int) * (size_t)ntiles, st); if (e != hipSuccess) return e; }
@@ -488,7 +505,7 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
                             float* cam_partials, int cam_stride) {
     const int nshared = 6 * p.K + 9, rs = (6 * p.K) | 1;
     auto lds_bytes = [&](int reps) { const int nacc = reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
-                                     return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T) * sizeof(float); };
+                                     return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T + 2 * T /* p.q per lane, fp64 */) * sizeof(float); };
     const size_t budget = (T == 512 ? 79 : 158) * 1024;
     int reps = 4;                                            // replicas only serve the rare > 3-keyframe fallback of wave_accumulate
     while (reps > 1 && lds_bytes(reps) > budget) reps >>= 1;

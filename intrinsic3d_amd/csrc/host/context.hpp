@@ -86,7 +86,7 @@ struct i3d_context {
     i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_ext_off, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw, cam_part;
     i3d::DevBuf<unsigned char> tp_temp; bool tile_ok = false;
     double t_add_end = 0.0;         // host clock at the end of the residual collection of the current outer iteration (time_add | time_build)
-    int tile_T = 0;                 // geometry of the current plan (0 = the default); a sharded run moves to 1024-entry tiles when a 512-entry tile's halo does not fit
+    int tile_T = 0;                 // geometry of the current plan (0 = the default, 1024); single rank: 512 when a 1024-entry tile's halo does not fit; sharded: 512 first, then 1024
     int plan_T() const { return tile_T > 0 ? tile_T : i3d::tile_plan_T(); }
     i3d::TilePlan tile_plan() const {
         const int T = plan_T();

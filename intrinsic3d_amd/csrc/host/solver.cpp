@@ -199,6 +199,8 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         // owned range + compute list + halo lists + ghost tiles (every rank derives them from the replicated work list: no communication), then the tile plan.
         // A sharded run has no untiled operator: when the halo of a 512-entry tile does not fit anywhere (the ranks agree: max over ranks), all of them plan
         // again with 1024-entry tiles and 2048 halo slots (a third fewer tile boundaries; one workgroup per CU) before anything is built on the plan.
+        // (Sharded runs start from 512-entry tiles: a rank's share is small, and twice the tiles balance better over its CUs.)
+        c->tile_T = 512;
         for (int attempt = 0; attempt < 2; ++attempt) {
             int rc = shard_plan(c); if (rc) return rc;
             { RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
@@ -229,6 +231,15 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
     double sums[9]; { int rc = read_doubles(c, c->d_scal.p, 9, sums); if (rc) return rc; }
     if (sharded(c) && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "assemble: a peer-to-peer exchange timed out (a rank stopped taking part)");
+    if (!sharded(c) && tp_over != 0 && c->plan_T() == 1024) {
+        // single rank: the other geometry (three halo slots per entry instead of two) before giving up on the tiled pass
+        std::fprintf(stderr, "[i3d] operator pass: a 1024-entry tile's halo does not fit, planning again with 512-entry tiles\n");
+        c->tile_T = 512;
+        { RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
+          CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n)); }      // (the symmetric Ea weights do not depend on the geometry)
+        CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        CTX_HIP(c, hipStreamSynchronize(s));
+    }
     c->tile_ok = tp_over == 0;       // a halo that does not fit (pathological grids) -> the untiled operator pass (single rank only)
     if (!sharded(c) && !c->tile_ok) std::fprintf(stderr, "[i3d] operator pass: a tile's halo does not fit, using the untiled pass (k_eg_jtjp + k_gather)\n");
     if (sharded(c) && !c->tile_ok) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: the tile plan overflowed after it had been accepted");      // (cannot happen: agreed on above)

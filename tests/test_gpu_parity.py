@@ -219,6 +219,32 @@ def test_sharded_run_survives_a_tile_halo_that_does_not_fit(setup, monkeypatch, 
     L.i3d_comm_sim_destroy(shared)
 
 
+def test_single_rank_falls_back_to_the_other_tile_geometry(setup, monkeypatch, capfd):
+    """Single rank: the default plan has 1024-entry tiles with 2048 halo slots.  When such a tile's halo does not fit (forced here: the plan is told it has
+    48 slots) the run plans again with 512-entry tiles (three halo slots per entry instead of two) before it would give up on the tiled pass; with both
+    geometries refused it takes the untiled pass.  All three must give the same result."""
+    O = setup["O"]
+    cfg = helpers.gpu_cfg(helpers.oracle_cfg(O, setup["thres"], iterations=2, cg_fixed_iterations=12))
+
+    def run():
+        c = helpers.gpu_context(setup["sc"], setup["arrays"], setup["vsh"])
+        st = c.optimize(cfg); sdf, alb = c.get_grid(); c.close()
+        return st, sdf, alb
+    rst, rsdf, ralb = run()
+    assert "does not fit" not in capfd.readouterr().err
+    monkeypatch.setenv("I3D_EGT_HMAX_LIMIT_1024", "48")
+    st1, sdf1, alb1 = run()
+    err = capfd.readouterr().err
+    assert "planning again with 512-entry tiles" in err and "untiled" not in err
+    monkeypatch.setenv("I3D_EGT_HMAX_LIMIT", "48")
+    st2, sdf2, alb2 = run()
+    assert "using the untiled pass" in capfd.readouterr().err
+    for st, sdf, alb in ((st1, sdf1, alb1), (st2, sdf2, alb2)):
+        for s1, s2 in zip(rst, st):
+            assert list(s1.rows) == list(s2.rows) and list(s1.step_accepted[:s1.num_attempts]) == list(s2.step_accepted[:s2.num_attempts])
+        assert np.abs(sdf - rsdf).max() <= 1e-4 * np.abs(rsdf).max() and np.abs(alb - ralb).max() <= 1e-4 * np.abs(ralb).max()
+
+
 def test_sharded_ranks_match_single_rank(setup):
     """The SPMD path (tile-aligned owned ranges, compute lists with ghost entries, ghost tiles of the operator pass, rim exchange of the
     operator input, reduced PCG scalars / camera block) with W ranks simulated by W host threads on ONE GPU (i3d_comm_init_sim) must
