@@ -197,10 +197,12 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n));
     } else {
         // owned range + compute list + halo lists + ghost tiles (every rank derives them from the replicated work list: no communication), then the tile plan.
-        // A sharded run has no untiled operator: when the halo of a 512-entry tile does not fit anywhere (the ranks agree: max over ranks), all of them plan
-        // again with 1024-entry tiles and 2048 halo slots (a third fewer tile boundaries; one workgroup per CU) before anything is built on the plan.
-        // (Sharded runs start from 512-entry tiles: a rank's share is small, and twice the tiles balance better over its CUs.)
-        c->tile_T = 512;
+        // A sharded run has no untiled operator: when a tile's halo does not fit anywhere (the ranks agree: max over ranks), all of them plan again with the
+        // other geometry before anything is built on the plan.  First choice: 1024-entry tiles (2048 halo slots; a third fewer tile boundaries, one
+        // workgroup per CU) when a rank's share fills at least two rounds of them, else 512-entry tiles (1536 halo slots, two workgroups per CU): a small
+        // share balances better over twice the tiles.  Every rank derives the choice from the replicated work list.
+        const int first_T = (c->A / c->comm->world >= 2 * 256 * 1024) ? 1024 : 512;
+        c->tile_T = first_T;
         for (int attempt = 0; attempt < 2; ++attempt) {
             int rc = shard_plan(c); if (rc) return rc;
             { RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
@@ -209,9 +211,10 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
             rc = allreduce(c, c->d_scal.p + 20, 1); if (rc) return rc;
             double over = 0.0; rc = read_doubles(c, c->d_scal.p + 20, 1, &over); if (rc) return rc;
             if (over == 0.0) break;
-            if (c->plan_T() == 1024) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: a 1024-entry tile of the operator pass reaches more than 2048 foreign entries");
-            std::fprintf(stderr, "[i3d] sharded operator pass: a 512-entry tile's halo does not fit, planning again with 1024-entry tiles\n");
-            c->tile_T = 1024;
+            if (attempt == 1) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: a tile of the operator pass reaches more foreign entries than either tile geometry has halo slots");
+            const int other = c->plan_T() == 512 ? 1024 : 512;
+            std::fprintf(stderr, "[i3d] sharded operator pass: a %d-entry tile's halo does not fit, planning again with %d-entry tiles\n", c->plan_T(), other);
+            c->tile_T = other;
         }
         // rows are only built on the compute list: everything else on the tiles this rank runs must be inert
         CTX_HIP(c, hipMemsetAsync(c->nrows.p, 0, (size_t)c->A, s)); CTX_HIP(c, hipMemsetAsync(c->regflags.p, 0, (size_t)c->A, s));
