@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--subvolume", type=float, default=0.06, help="SH subvolume size in metres (chosen so that the shell of the 0.6 m object touches ~512 subvolumes, BASELINE.json configs[3])")
     ap.add_argument("--cpu-sample", type=float, default=1.0e6, help="stored voxels of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-ref-sample", type=float, default=2.5e5, help="stored voxels of the reference-code leg of the CPU baseline (0 = skip; skipped when oracle/_ref is not built)")
+    ap.add_argument("--spin-up", type=float, default=0.0, help="seconds of device copies before the warm-up steps (the device idles while the host generates the scene; 0 = none)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--carry-radius", action="store_true",
                     help="NOT the reference's behaviour (and not the headline): carry the trust-region radius across outer iterations, as nls_solver.cpp:322-323 intends")
@@ -337,6 +338,16 @@ def _main():
         for _ in range(3):
             b = a.clone()          # 16 B/lane vectorised copy: 2^30 B read + 2^30 B written per launch
         torch.cuda.synchronize(); del a, b
+    if args.spin_up > 0:
+        # optional (default off): seconds of device copies before the driver's own warm-up steps, untimed, reported as `spin_up_s`.  Tried against the
+        # suspicion that the first bench run on a fresh box is slow because the device idled during scene generation: no effect (26.59 with, 26.47
+        # without; the SAME box then ran the same command at 25.09 — the 5-9 % spread of the memory-bound kernels moves in time on one box).
+        t_spin = time.time(); a = torch.empty(1 << 26, dtype=torch.float32, device="cuda").normal_()
+        while time.time() - t_spin < args.spin_up:
+            for _ in range(20):
+                b = a.clone()
+            torch.cuda.synchronize()
+        del a, b
     if args.warmup > 0:
         ctx.optimize(make_cfg(binding, args, args.warmup, thres))
     ctx.timing_enable(not args.no_kernel_timing)
@@ -432,7 +443,7 @@ def _main():
         pcg = [int(s.pcg_iterations[i]) for s in stats for i in range(s.num_attempts)]
         out = {
             "metric": "Gauss-Newton iterations/s at the finest SDF level", "value": args.steps / dt, "unit": "GN iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spin_up_s": args.spin_up, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"parallelism": f"{world} rank(s), one per GPU: replicated voxel state; tile-aligned ownership of the brick-ordered work list, rim rows recomputed as ghosts; "
                                        f"per PCG pass one neighbour exchange of the operator input on the rim + one all-reduce [camera block | p.q] + one of 4 scalars"
