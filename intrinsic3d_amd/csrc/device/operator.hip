@@ -2,8 +2,8 @@
 //
 // Replaces Ceres' BlockSparseMatrix Jacobian + CgnrLinearOperator + BlockJacobiPreconditioner + ConjugateGradientsSolver
 // [Ceres 2.1.0, not in /root/reference; selected at nls_solver.cpp:307] for this problem's FIXED row structure:
-//   * Eg rows are stored wave-tiled (common.hpp row_index: [tile of 64 entries][slot][8 float4 planes][lane], 128 B per row), so a wave
-//     reads one contiguous 8 KB block per slot; Er / Es / Ea rows have constant coefficients (volumetric_regularizer.h:59-72,
+//   * Eg rows are stored wave-tiled (common.hpp RowView / row_index: one 7680 B block per [group of 64 entries][slot] = seven float4 planes + one
+//     float2 plane, 120 B per row, the row weight folded into the partials), so a wave reads one contiguous block per slot; Er / Es / Ea rows have constant coefficients (volumetric_regularizer.h:59-72,
 //     surface_stab_regularizer.h:59-66, albedo_regularizer.h:59-66) and are never stored;
 //   * column indices are implicit: a row's voxel columns are the centre voxel's neighbour-table entries;
 //   * all solver vectors live in WORK-LIST space (entries = voxels that own rows or unknowns): [sdf A | albedo A | poses 6K |

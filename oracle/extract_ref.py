@@ -62,6 +62,9 @@ CHUNKS = [
     ("camera_impl",          "src/camera.cpp", 41, 199, "Camera::Camera() :", "}"),
     ("camera_convert",       "src/camera.cpp", 277, 311, "void Camera::print", "}"),
     ("camera_load_save",     "src/camera.cpp", 202, 274, "bool Camera::load", "}"),
+    ("kfs_class",            "include/nv/keyframe_selection.h", 47, 75, "class KeyframeSelection", "};"),
+    ("kfs_impl_a",           "src/keyframe_selection.cpp", 46, 126, "KeyframeSelection::KeyframeSelection(int window_size)", "}"),
+    ("kfs_impl_b",           "src/keyframe_selection.cpp", 139, 310, "bool KeyframeSelection::load", "}"),
     ("math_decl",            "include/nv/math.h", 44, 65, "namespace math", "} // namespace math"),
     ("math_impl",            "src/math.cpp", 43, 163, "float robustKernel", "}"),
     ("operators_impl",       "src/sdf/operators.cpp", 45, 77, "Vec3f voxelCenterToIso(const SparseVoxelGrid", "}"),

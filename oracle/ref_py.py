@@ -160,3 +160,27 @@ def camera_load(path):
     w = C.c_int32(); h = C.c_int32(); k = np.zeros(4, np.float32); d = np.zeros(5, np.float32)
     ok = _raw().ref_camera_load(str(path).encode(), C.byref(w), C.byref(h), _p(k), _p(d)) == 1
     return ok, w.value, h.value, k, d
+
+
+# --- KeyframeSelection (keyframe_selection.cpp): the reference's class on caller data
+def blur_score(image):
+    a = np.ascontiguousarray(image, np.uint8); L = _raw(); L.ref_blur_score.restype = C.c_double
+    return float(L.ref_blur_score(_p(a), C.c_int32(a.shape[1]), C.c_int32(a.shape[0]), C.c_int32(1 if a.ndim == 2 else a.shape[2])))
+
+
+def keyframes_select(window, scores):
+    s = np.ascontiguousarray(scores, np.float64); out = np.zeros(len(s), np.uint8)
+    _raw().ref_keyframes_select(C.c_int32(window), C.c_int64(len(s)), _p(s), _p(out))
+    return out.astype(bool)
+
+
+def keyframes_save(path, window, scores, is_kf):
+    s = np.ascontiguousarray(scores, np.float64); k = np.ascontiguousarray(is_kf, np.uint8)
+    return _raw().ref_keyframes_save(str(path).encode(), C.c_int32(window), C.c_int64(len(s)), _p(s), _p(k)) == 1
+
+
+def keyframes_load(path, cap=1 << 16):
+    L = _raw(); L.ref_keyframes_load.restype = C.c_int64
+    w = C.c_int32(); s = np.zeros(cap); k = np.zeros(cap, np.uint8)
+    n = int(L.ref_keyframes_load(str(path).encode(), C.byref(w), C.c_int64(cap), _p(s), _p(k)))
+    return (None if n < 0 else (w.value, s[:n], k[:n].astype(bool)))

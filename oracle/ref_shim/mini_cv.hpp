@@ -3,7 +3,10 @@
 // Stand-in for the handful of OpenCV names [un-vendored dependency of /root/reference, absent from this image] the reference bodies
 // compiled into oracle/_ref touch: cv::Mat as a typed 2-D array (8-bit 3-channel, float 1- and 3-channel), cv::Vec3b / cv::Vec3f,
 // the tick counter of nv::Timer.  Images live in shared buffers (clone() copies, assignment aliases — as cv::Mat does).
-// No image processing (pyrDown, cvtColor, imread) is provided: pyramids are handed in from outside.  Nothing of this is reference code.
+// No pyramid / file image processing (pyrDown, imread) is provided: pyramids are handed in from outside.  For KeyframeSelection::estimateBlur the few
+// OpenCV calls it makes are restated at the bottom (cvtColor BGR2GRAY in 8-bit fixed point, convertTo with a scale, a float filter2D with the default
+// BORDER_REFLECT_101 border, transpose, sum) — OpenCV's published behaviour as we read it, NOT OpenCV: the product and this agree by construction there;
+// what the reference contributes is the class around them.  Nothing of this is reference code.
 #pragma once
 #include <chrono>
 #include <cstdint>
@@ -11,8 +14,10 @@
 #include <memory>
 #include <vector>
 
+#define CV_8UC1 0
 #define CV_8UC3 16
 #define CV_32FC1 5
+#define CV_32F 5
 #define CV_32FC3 21
 
 namespace cv {
@@ -36,7 +41,7 @@ struct Mat {
     std::shared_ptr<std::vector<unsigned char>> own;
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
-    static size_t elem(int type) { return type == CV_8UC3 ? 3 : type == CV_32FC3 ? 12 : 4; }
+    static size_t elem(int type) { return type == CV_8UC1 ? 1 : type == CV_8UC3 ? 3 : type == CV_32FC3 ? 12 : 4; }
     void create(int r, int c, int type) {
         rows = r; cols = c; type_ = type;
         own = std::make_shared<std::vector<unsigned char>>((size_t)r * c * elem(type), (unsigned char)0);
@@ -46,6 +51,12 @@ struct Mat {
     static Mat wrap(int r, int c, int type, const void* ptr) { Mat m; m.rows = r; m.cols = c; m.type_ = type; m.data = (unsigned char*)ptr; m.p = (const float*)ptr; return m; }
     static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
     static Mat zeros(Size s, int type) { return Mat(s.height, s.width, type); }
+    static Mat ones(int r, int c, int type) { Mat m(r, c, type); for (size_t i = 0; i < (size_t)r * c; ++i) reinterpret_cast<float*>(m.data)[i] = 1.0f; return m; }      // (CV_32F only)
+    // dst = saturate_cast<float>(src * alpha): 8-bit 1-channel -> float with the scale applied in float (cv::Mat::convertTo, the only conversion the reference bodies use)
+    void convertTo(Mat& dst, int type, double alpha = 1.0) const {
+        dst.create(rows, cols, type); const float a = (float)alpha;
+        for (size_t i = 0; i < (size_t)rows * cols; ++i) reinterpret_cast<float*>(dst.data)[i] = (float)data[i] * a;
+    }
     Size size() const { return Size(cols, rows); }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int type() const { return type_; }
@@ -54,6 +65,29 @@ struct Mat {
     template <class T> T& at(int y, int x) { return reinterpret_cast<T*>(data)[(size_t)y * cols + x]; }
     template <class T> const T& at(int y, int x) const { return reinterpret_cast<const T*>(data)[(size_t)y * cols + x]; }
 };
+
+struct Scalar { double val[4]; Scalar(double a = 0, double b = 0, double c = 0, double d = 0) : val{a, b, c, d} {} };
+inline Mat operator*(const Mat& m, double f) { Mat o = m.clone(); const float ff = (float)f; for (size_t i = 0; i < (size_t)o.rows * o.cols; ++i) reinterpret_cast<float*>(o.data)[i] *= ff; return o; }
+inline void transpose(const Mat& a, Mat& b) { Mat o(a.cols, a.rows, a.type()); for (int y = 0; y < a.rows; ++y) for (int x = 0; x < a.cols; ++x) o.at<float>(x, y) = a.at<float>(y, x); b = o; }
+enum { COLOR_BGR2GRAY = 6 };
+// 8-bit BGR -> grey in OpenCV's 14-bit fixed point: (B 1868 + G 9617 + R 4899 + 2^13) >> 14
+inline void cvtColor(const Mat& src, Mat& dst, int /*code*/) {
+    Mat o(src.rows, src.cols, CV_8UC1);
+    for (size_t i = 0; i < (size_t)src.rows * src.cols; ++i) o.data[i] = (unsigned char)((src.data[3 * i] * 1868 + src.data[3 * i + 1] * 9617 + src.data[3 * i + 2] * 4899 + (1 << 13)) >> 14);
+    dst = o;
+}
+// float correlation with the kernel anchored at its centre, BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba), products accumulated in float in kernel order
+inline void filter2D(const Mat& src, Mat& dst, int /*ddepth*/, const Mat& k) {
+    auto refl = [](int p, int len) { if (len == 1) return 0; while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p; return p; };
+    Mat o(src.rows, src.cols, CV_32FC1); const int ay = k.rows / 2, ax = k.cols / 2;
+    for (int y = 0; y < src.rows; ++y) for (int x = 0; x < src.cols; ++x) {
+        float s = 0.0f;
+        for (int j = 0; j < k.rows; ++j) for (int i = 0; i < k.cols; ++i) s += k.at<float>(j, i) * src.at<float>(refl(y + j - ay, src.rows), refl(x + i - ax, src.cols));
+        o.at<float>(y, x) = s;
+    }
+    dst = o;
+}
+inline Scalar sum(const Mat& m) { double s = 0.0; for (size_t i = 0; i < (size_t)m.rows * m.cols; ++i) s += (double)reinterpret_cast<const float*>(m.data)[i]; return Scalar(s); }
 
 inline int64_t getTickCount() { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline double getTickFrequency() { return 1e9; }

@@ -20,6 +20,7 @@
 #include <ctime>
 #include <limits>
 #include <sstream>
+#include <iomanip>
 #include <type_traits>
 #include <vector>
 #include <omp.h>
@@ -131,15 +132,17 @@ static double chroma_weight(const Vec3b& color, const Vec3b& color_nb) {     // 
 #include "gen/svsh_class.inc"
 #include "gen/svsh_impl.inc"
 
-// shim: the two collaborators Intrinsic3D holds.  The reference's Sensor reads a dataset folder through OpenCV and its
-// KeyframeSelection a text file; here the C ABI hands the keyframes in directly, so both are inert holders.
+// shim: the Sensor Intrinsic3D holds reads a dataset folder through OpenCV; here the C ABI hands the keyframes in directly, so it is an inert holder.
+// KeyframeSelection is the reference's own class (window selection, keyframes.txt, the Crete blur metric over the OpenCV stand-ins of mini_cv.hpp).
 class Sensor {
 public:
     Camera& colorCamera() { return color_cam_; }
     void setPose(int, const Mat4f&) {}
     Camera color_cam_;
 };
-class KeyframeSelection {};
+#include "gen/kfs_class.inc"
+#include "gen/kfs_impl_a.inc"
+#include "gen/kfs_impl_b.inc"
 #include "gen/i3d_class.inc"
 #include "gen/i3d_callback_dtor.inc"
 #include "gen/i3d_ctor.inc"
@@ -658,6 +661,24 @@ int32_t ref_camera_load(const char* path, int32_t* w, int32_t* h, float* k4, flo
     *w = cam.width(); *h = cam.height(); const Mat3f K = cam.intrinsics(); k4[0] = K(0, 0); k4[1] = K(1, 1); k4[2] = K(0, 2); k4[3] = K(1, 2);
     const Vec5f d = cam.distortion(); for (int i = 0; i < 5; ++i) dist5[i] = d[i];
     return ok ? 1 : 0;
+}
+/* KeyframeSelection (keyframe_selection.cpp:46-126, 139-310): the reference's class on caller data */
+double ref_blur_score(const uint8_t* image, int32_t w, int32_t h, int32_t channels) {
+    KeyframeSelection ks; return ks.estimateBlur(cv::Mat::wrap(h, w, channels == 3 ? CV_8UC3 : CV_8UC1, image));
+}
+void ref_keyframes_select(int32_t window, int64_t n, const double* scores, uint8_t* is_kf) {
+    KeyframeSelection ks(window); ks.frame_scores_.assign(scores, scores + n); ks.selectKeyframes();
+    for (int64_t i = 0; i < n; ++i) is_kf[i] = ks.isKeyframe((int)i) ? 1 : 0;
+}
+int32_t ref_keyframes_save(const char* path, int32_t window, int64_t n, const double* scores, const uint8_t* is_kf) {
+    KeyframeSelection ks(window); ks.frame_scores_.assign(scores, scores + n); ks.is_keyframe_.resize((size_t)n); for (int64_t i = 0; i < n; ++i) ks.is_keyframe_[(size_t)i] = is_kf[i] != 0;
+    return ks.save(path) ? 1 : 0;
+}
+int64_t ref_keyframes_load(const char* path, int32_t* window, int64_t cap, double* scores, uint8_t* is_kf) {
+    KeyframeSelection ks(0); if (!ks.load(path)) return -1;
+    *window = ks.window_size_; const int64_t n = (int64_t)ks.frame_scores_.size();
+    for (int64_t i = 0; i < n && i < cap; ++i) { scores[i] = ks.frame_scores_[(size_t)i]; is_kf[i] = ks.is_keyframe_[(size_t)i] ? 1 : 0; }
+    return n;
 }
 void ref_fusion_free(void* fp) { auto* f = (RefFusion*)fp; delete f->grid; delete f; }
 void ref_erode_discontinuities(int32_t w, int32_t h, const float* in, int32_t window, float max_diff, float* out) {

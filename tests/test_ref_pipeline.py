@@ -356,3 +356,35 @@ def test_intrinsics_files_equal_the_reference_writer_and_reader(R, tmp_path):
     open(tmp_path / "short.txt", "w").write("640 480\n525 0 319.5\n0 525")
     ok_r, _, _, kr, _ = ref_py.camera_load(tmp_path / "short.txt"); ok_o, _, _, ko, _ = binding.read_intrinsics(tmp_path / "short.txt")
     assert ok_r and kr[3] == 525.0 and not ok_o and list(ko) == [525.0, 525.0, 319.5, 239.5]
+
+
+def test_keyframe_selection_equals_the_reference_class(R, tmp_path):
+    """KeyframeSelection (keyframe_selection.cpp:46-126, 139-310) of the reference vs the product's host entry points: window selection incl. ties, all-zero
+    and ragged last windows; keyframes.txt written byte for byte and parsed the same; the Crete blur metric on colour and grey images (its OpenCV calls are
+    stand-ins on the reference side — what is pinned is the metric's own loops and normalisation)."""
+    from intrinsic3d_amd import binding as B
+    from oracle import ref_py
+    rng = np.random.default_rng(11)
+    for n, win in ((47, 10), (10, 10), (9, 10), (1, 3), (64, 7), (30, 1)):
+        scores = rng.uniform(0, 1, n)
+        if n > 20:
+            scores[5:9] = scores[5]                      # ties inside a window: the first maximum wins
+            scores[10:20] = 0.0                          # an all-zero window selects its first frame
+        a = B.keyframes_select(win, scores); b = ref_py.keyframes_select(win, scores)
+        assert np.array_equal(a, b), (n, win)
+        pa = str(tmp_path / f"ours_{n}_{win}.txt"); pb = str(tmp_path / f"ref_{n}_{win}.txt")
+        B.keyframes_save(pa, win, scores, a); assert ref_py.keyframes_save(pb, win, scores, b)
+        assert open(pa).read() == open(pb).read()
+        wa, sa, ka = B.keyframes_load(pb); wb, sb, kb = ref_py.keyframes_load(pa)
+        assert wa == wb == win and np.array_equal(sa, sb) and np.array_equal(ka, kb) and np.array_equal(ka, a)
+    assert ref_py.keyframes_load(str(tmp_path / "missing.txt")) is None
+    with pytest.raises(B.I3DError):
+        B.keyframes_load(str(tmp_path / "missing.txt"))
+    # blur metric: smooth, sharp, noisy, tiny and single-row images; colour and grey
+    yy, xx = np.mgrid[0:61, 0:83]
+    imgs = [(127 + 100 * np.sin(xx / 3.0) * np.cos(yy / 5.0)).astype(np.uint8), rng.integers(0, 256, (61, 83)).astype(np.uint8),
+            ((xx // 8 + yy // 8) % 2 * 255).astype(np.uint8), rng.integers(0, 256, (12, 7)).astype(np.uint8), rng.integers(0, 256, (1, 40)).astype(np.uint8)]
+    imgs += [np.stack([im, np.roll(im, 3, 1), 255 - im], -1) for im in imgs[:4]]
+    for im in imgs:
+        sa, sb = B.blur_score(im), ref_py.blur_score(im)
+        assert (np.isnan(sa) and np.isnan(sb)) or abs(sa - sb) <= 1e-12 * max(1.0, abs(sb)), (im.shape, sa, sb)
