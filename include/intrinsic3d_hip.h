@@ -197,6 +197,9 @@ int i3d_extract_mesh(i3d_context* ctx, int32_t use_refined_sdf, int32_t color_mo
 int i3d_get_mesh(i3d_context* ctx, float* vertices /*[nv][3]*/, uint8_t* colors /*[nv][3]*/, int32_t* faces /*[nf][3]*/);
 int i3d_export_mesh_ply(i3d_context* ctx, const char* path, int32_t use_refined_sdf, int32_t color_mode, int32_t largest_component_only);
 int i3d_write_ply(const char* path, int64_t num_vertices, const float* vertices, const uint8_t* colors /* may be NULL */, int64_t num_faces, const int32_t* faces);
+/* MeshUtil::removeLooseComponents + removeUnusedVertices (mesh/util.cpp:47-171) on caller arrays, in place (what largest_component_only applies): keeps the
+ * largest connected component (first one among equals, components numbered by their first face), drops the vertices no face uses; counts updated.  Host only. */
+int i3d_mesh_remove_loose_components(int64_t* num_vertices, float* vertices, uint8_t* colors /* may be NULL */, int64_t* num_faces, int32_t* faces);
 int i3d_mc_tables(uint8_t* ntri /*[256]*/, int8_t* tri /*[256][16]*/);      /* the triangulation table (Bourke's, as in marching_cubes.cpp:330-623); returns max triangles per cell */
 
 /* ---- dataset loader in front of the path.  Host code except i3d_init_frames_from_sensor.

@@ -70,7 +70,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_extract_mesh", "i3d_get_mesh", "i3d_export_mesh_ply", "i3d_write_ply", "i3d_mc_tables",
            "i3d_png_info", "i3d_png_decode", "i3d_pose_mat_to_vec6", "i3d_sensor_open", "i3d_sensor_close", "i3d_sensor_info", "i3d_sensor_color",
            "i3d_sensor_depth", "i3d_sensor_pose", "i3d_sensor_set_pose", "i3d_sensor_set_pose_vec6", "i3d_sensor_save_poses",
-           "i3d_keyframes_load", "i3d_keyframes_save", "i3d_keyframes_select", "i3d_blur_score", "i3d_init_frames_from_sensor",
+           "i3d_mesh_remove_loose_components", "i3d_keyframes_load", "i3d_keyframes_save", "i3d_keyframes_select", "i3d_blur_score", "i3d_init_frames_from_sensor",
            "i3d_fusion_create", "i3d_fusion_destroy", "i3d_fusion_last_error", "i3d_fusion_integrate", "i3d_fusion_finish", "i3d_fusion_info", "i3d_fusion_get",
            "i3d_fusion_save", "i3d_shard_need", "i3d_comm_stats",
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
@@ -156,6 +156,7 @@ def load():
     L.i3d_get_mesh.restype = i32; L.i3d_get_mesh.argtypes = [vp, vp, vp, vp]
     L.i3d_export_mesh_ply.restype = i32; L.i3d_export_mesh_ply.argtypes = [vp, cp, i32, i32, i32]
     L.i3d_write_ply.restype = i32; L.i3d_write_ply.argtypes = [cp, i64, vp, vp, i64, vp]
+    L.i3d_mesh_remove_loose_components.restype = i32; L.i3d_mesh_remove_loose_components.argtypes = [vp, vp, vp, vp, vp]
     L.i3d_mc_tables.restype = i32; L.i3d_mc_tables.argtypes = [vp, vp]
     L.i3d_config_load_yaml.restype = i32; L.i3d_config_load_yaml.argtypes = [cp, C.POINTER(RefineConfig), C.POINTER(OptimizerConfig)]
     u64 = C.c_uint64; f32 = C.c_float
@@ -560,6 +561,15 @@ def yaml_get(path, key, default=None):
         return default
     _io_check(rc, f"i3d_yaml_get({key})")
     return buf.value.decode()
+
+
+def mesh_remove_loose_components(vertices, colors, faces):
+    """MeshUtil::removeLooseComponents on arrays -> (vertices, colors or None, faces) of the largest connected component"""
+    v = np.array(vertices, np.float32, copy=True).reshape(-1, 3); f = np.array(faces, np.int32, copy=True).reshape(-1, 3)
+    c = None if colors is None else np.array(colors, np.uint8, copy=True).reshape(-1, 3)
+    nv, nf = C.c_int64(len(v)), C.c_int64(len(f))
+    _io_check(load().i3d_mesh_remove_loose_components(C.byref(nv), _p(v), None if c is None else _p(c), C.byref(nf), _p(f)), "i3d_mesh_remove_loose_components")
+    return v[:nv.value].copy(), (None if c is None else c[:nv.value].copy()), f[:nf.value].copy()
 
 
 def write_ply(path, vertices, colors, faces):

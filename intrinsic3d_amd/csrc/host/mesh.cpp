@@ -41,6 +41,46 @@ struct F3Hash { size_t operator()(const F3& v) const {
 struct MeshData { std::vector<float> vertices; std::vector<uint8_t> colors; std::vector<int32_t> faces; };
 static thread_local MeshData g_mesh;       // the last extracted mesh of this host thread (i3d_get_mesh)
 
+// MeshUtil::removeLooseComponents + removeUnusedVertices (mesh/util.cpp:47-171): faces that share a vertex position are connected; only the largest
+// connected component is kept — boost numbers components in the order of their first face and std::max_element keeps the first maximum — then the
+// vertices no face uses are dropped and the indices renumbered in vertex order.  (Vertices are unique per position after merge(), so sharing an index is
+// sharing a position.)
+static void remove_loose_components(MeshData& M) {
+    std::vector<int32_t>& faces = M.faces;
+    if (faces.empty()) return;
+    const size_t nf = faces.size() / 3, nv = M.vertices.size() / 3;
+    std::vector<int> parent(nf); std::iota(parent.begin(), parent.end(), 0);
+    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    std::vector<int> first_face(nv, -1);
+    for (size_t f = 0; f < nf; ++f) for (int k = 0; k < 3; ++k) {
+        const int v = faces[3 * f + k];
+        if (first_face[v] < 0) first_face[v] = (int)f;
+        else { int a = find(first_face[v]), b = find((int)f); if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; } }      // root = smallest face index
+    }
+    std::vector<int> size(nf, 0);
+    for (size_t f = 0; f < nf; ++f) size[find((int)f)]++;
+    int best = -1;
+    for (size_t f = 0; f < nf; ++f) if (parent[f] == (int)f && (best < 0 || size[f] > size[best])) best = (int)f;
+    std::vector<int32_t> out; out.reserve(3 * (size_t)size[best]);
+    for (size_t f = 0; f < nf; ++f) if (find((int)f) == best) { out.push_back(faces[3 * f]); out.push_back(faces[3 * f + 1]); out.push_back(faces[3 * f + 2]); }
+    faces.swap(out);
+    // removeUnusedVertices
+    std::vector<char> used(nv, 0);
+    for (int32_t v : faces) used[(size_t)v] = 1;
+    size_t kept = 0; for (size_t v = 0; v < nv; ++v) kept += used[v] ? 1 : 0;
+    if (kept == nv) return;
+    const bool has_colors = !M.colors.empty();
+    std::vector<int32_t> remap(nv, 0); std::vector<float> verts; std::vector<uint8_t> cols; verts.reserve(3 * kept); if (has_colors) cols.reserve(3 * kept);
+    int32_t idx = 0;
+    for (size_t v = 0; v < nv; ++v) if (used[v]) {
+        verts.push_back(M.vertices[3 * v]); verts.push_back(M.vertices[3 * v + 1]); verts.push_back(M.vertices[3 * v + 2]);
+        if (has_colors) { cols.push_back(M.colors[3 * v]); cols.push_back(M.colors[3 * v + 1]); cols.push_back(M.colors[3 * v + 2]); }
+        remap[v] = idx++;
+    }
+    M.vertices.swap(verts); M.colors.swap(cols);
+    for (int32_t& v : faces) v = remap[(size_t)v];
+}
+
 int extract_mesh(i3d_context* c, int use_refined, int color_mode, int largest_only, MeshData& M, int64_t* raw_triangles) {
     if (!c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "extract_mesh: no grid");
     CTX_HIP(c, hipSetDevice(c->device));
@@ -95,26 +135,8 @@ int extract_mesh(i3d_context* c, int use_refined, int color_mode, int largest_on
         kept.push_back(v0); kept.push_back(v1); kept.push_back(v2);
     }
     faces.swap(kept);
-    if (largest_only && !faces.empty()) {       // removeLooseComponents (mesh/util.cpp:47-98): faces sharing a vertex position are connected
-        const size_t nf = faces.size() / 3;
-        std::vector<int> parent(nf); std::iota(parent.begin(), parent.end(), 0);
-        auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
-        std::vector<int> first_face(M.vertices.size() / 3, -1);
-        for (size_t f = 0; f < nf; ++f) for (int k = 0; k < 3; ++k) {
-            const int v = faces[3 * f + k];
-            if (first_face[v] < 0) first_face[v] = (int)f;
-            else { int a = find(first_face[v]), b = find((int)f); if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; } }      // root = smallest face index
-        }
-        std::vector<int> size(nf, 0);
-        for (size_t f = 0; f < nf; ++f) size[find((int)f)]++;
-        // boost numbers components in order of their first face, std::max_element keeps the first maximum
-        int best = -1;
-        for (size_t f = 0; f < nf; ++f) if (parent[f] == (int)f && (best < 0 || size[f] > size[best])) best = (int)f;
-        std::vector<int32_t> out; out.reserve(3 * (size_t)size[best]);
-        for (size_t f = 0; f < nf; ++f) if (find((int)f) == best) { out.push_back(faces[3 * f]); out.push_back(faces[3 * f + 1]); out.push_back(faces[3 * f + 2]); }
-        faces.swap(out);
-    }
     M.faces.swap(faces);
+    if (largest_only) remove_loose_components(M);
     return I3D_OK;
 }
 
@@ -123,6 +145,18 @@ int extract_mesh(i3d_context* c, int use_refined, int color_mode, int largest_on
 using namespace i3d;
 
 extern "C" {
+
+// MeshUtil::removeLooseComponents (mesh/util.cpp:47-101) on caller arrays, in place: the largest connected component, unused vertices dropped.
+// colors may be NULL.  Host only.
+int i3d_mesh_remove_loose_components(int64_t* num_vertices, float* vertices, uint8_t* colors, int64_t* num_faces, int32_t* faces) {
+    if (!num_vertices || !num_faces || *num_vertices < 0 || *num_faces < 0 || (*num_vertices > 0 && !vertices) || (*num_faces > 0 && !faces)) return I3D_ERR_INVALID_ARGUMENT;
+    for (int64_t i = 0; i < 3 * *num_faces; ++i) if (faces[i] < 0 || faces[i] >= *num_vertices) return I3D_ERR_INVALID_ARGUMENT;
+    MeshData M; M.vertices.assign(vertices, vertices + 3 * *num_vertices); if (colors) M.colors.assign(colors, colors + 3 * *num_vertices); M.faces.assign(faces, faces + 3 * *num_faces);
+    remove_loose_components(M);
+    *num_vertices = (int64_t)(M.vertices.size() / 3); *num_faces = (int64_t)(M.faces.size() / 3);
+    std::copy(M.vertices.begin(), M.vertices.end(), vertices); if (colors) std::copy(M.colors.begin(), M.colors.end(), colors); std::copy(M.faces.begin(), M.faces.end(), faces);
+    return I3D_OK;
+}
 
 // Mesh::save (mesh/mesh.cpp:41-100): binary little-endian PLY, float positions, optional uchar colours, "uchar int" face lists
 int i3d_write_ply(const char* path, int64_t num_vertices, const float* vertices, const uint8_t* colors, int64_t num_faces, const int32_t* faces) {

@@ -47,6 +47,8 @@ CHUNKS = [
     ("mesh_struct",          "include/nv/mesh.h", 45, 59, "struct Mesh", "};"),
     ("mesh_save",            "src/mesh.cpp", 41, 100, "bool Mesh::save", "}"),
     ("mesh_degenerate",      "src/mesh/util.cpp", 174, 200, "bool removeDegenerateFaces", "}"),
+    ("mesh_loose",           "src/mesh/util.cpp", 47, 101, "void removeLooseComponents", "}"),
+    ("mesh_unused",          "src/mesh/util.cpp", 104, 171, "void removeUnusedVertices", "}"),
     ("mc_class",             "include/nv/mesh/marching_cubes.h", 50, 85, "template <class T>", "};"),
     ("mc_extract_mesh",      "src/mesh/marching_cubes.cpp", 43, 94, "template <class T>", "}"),
     ("mc_body",              "src/mesh/marching_cubes.cpp", 97, 317, "template <class T>", "}"),

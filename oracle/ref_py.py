@@ -184,3 +184,17 @@ def keyframes_load(path, cap=1 << 16):
     w = C.c_int32(); s = np.zeros(cap); k = np.zeros(cap, np.uint8)
     n = int(L.ref_keyframes_load(str(path).encode(), C.byref(w), C.c_int64(cap), _p(s), _p(k)))
     return (None if n < 0 else (w.value, s[:n], k[:n].astype(bool)))
+
+
+def mesh_remove_loose_components(vertices, colors, faces):
+    """MeshUtil::removeLooseComponents (+ removeUnusedVertices) of the reference on arrays -> (vertices, colors or None, faces)"""
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3); f = np.ascontiguousarray(faces, np.int32).reshape(-1, 3)
+    c = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 3)
+    L = _raw(); L.ref_mesh_from_arrays.restype = C.c_void_p
+    m = C.c_void_p(L.ref_mesh_from_arrays(C.c_int64(len(v)), _p(v), None if c is None else _p(c), C.c_int64(len(f)), _p(f)))
+    L.ref_mesh_remove_loose.argtypes = [C.c_void_p]; L.ref_mesh_counts.argtypes = [C.c_void_p] * 3; L.ref_mesh_get.argtypes = [C.c_void_p] * 4; L.ref_mesh_free.argtypes = [C.c_void_p]
+    L.ref_mesh_remove_loose(m)
+    nv = C.c_int64(); nf = C.c_int64(); L.ref_mesh_counts(m, C.byref(nv), C.byref(nf))
+    vo = np.zeros((nv.value, 3), np.float32); co = None if c is None else np.zeros((nv.value, 3), np.uint8); fo = np.zeros((nf.value, 3), np.int32)
+    L.ref_mesh_get(m, _p(vo), None if co is None else _p(co), _p(fo)); L.ref_mesh_free(m)
+    return vo, co, fo

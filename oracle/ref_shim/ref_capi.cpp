@@ -26,6 +26,7 @@
 #include <omp.h>
 #include "mini_eigen.hpp"
 #include "mini_cv.hpp"
+#include "mini_boost.hpp"
 #include "mini_ceres.hpp"
 
 #include "gen/invalid_residual.inc"
@@ -161,7 +162,10 @@ bool Intrinsic3D::init() {
 #include "gen/mesh_struct.inc"
 #include "gen/mesh_save.inc"
 namespace MeshUtil {
+void removeUnusedVertices(Mesh* mesh);               // (declared in the reference's mesh/util.h, defined below its first use)
 #include "gen/mesh_degenerate.inc"
+#include "gen/mesh_loose.inc"
+#include "gen/mesh_unused.inc"
 }  // namespace MeshUtil
 #include "gen/mc_class.inc"
 #include "gen/mc_extract_mesh.inc"
@@ -303,9 +307,18 @@ void* ref_mc_extract(float voxel_size, int64_t n, const int32_t* keys, const dou
 void ref_mesh_counts(void* mesh, int64_t* nv, int64_t* nf) { Mesh* m = (Mesh*)mesh; *nv = m ? (int64_t)m->vertices.size() : 0; *nf = m ? (int64_t)m->face_vertices.size() : 0; }
 void ref_mesh_get(void* mesh, float* verts, uint8_t* colors, int32_t* faces) {
     Mesh* m = (Mesh*)mesh; if (!m) return;
-    for (size_t i = 0; i < m->vertices.size(); ++i) for (int k = 0; k < 3; ++k) { verts[3 * i + k] = m->vertices[i][k]; colors[3 * i + k] = m->colors[i][k]; }
+    for (size_t i = 0; i < m->vertices.size(); ++i) for (int k = 0; k < 3; ++k) { verts[3 * i + k] = m->vertices[i][k]; if (colors && i < m->colors.size()) colors[3 * i + k] = m->colors[i][k]; }
     for (size_t i = 0; i < m->face_vertices.size(); ++i) for (int k = 0; k < 3; ++k) faces[3 * i + k] = m->face_vertices[i][k];
 }
+// MeshUtil::removeLooseComponents (mesh/util.cpp:47-171) on a mesh built from caller arrays (colors may be NULL) / on an extracted mesh, in place
+void* ref_mesh_from_arrays(int64_t nv, const float* verts, const uint8_t* colors, int64_t nf, const int32_t* faces) {
+    Mesh* m = new Mesh;
+    for (int64_t i = 0; i < nv; ++i) { m->vertices.push_back(Vec3f(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2])); if (colors) m->colors.push_back(Vec3b(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2])); }
+    for (int64_t i = 0; i < nf; ++i) m->face_vertices.push_back(Vec3i(faces[3 * i], faces[3 * i + 1], faces[3 * i + 2]));
+    return m;
+}
+void ref_mesh_remove_loose(void* mesh) { if (mesh) MeshUtil::removeLooseComponents((Mesh*)mesh); }
+int32_t ref_mesh_has_colors(void* mesh) { return (mesh && !((Mesh*)mesh)->colors.empty()) ? 1 : 0; }
 int32_t ref_mesh_save(void* mesh, const char* path) { Mesh* m = (Mesh*)mesh; return (m && m->save(path)) ? 1 : 0; }
 void ref_mesh_free(void* mesh) { delete (Mesh*)mesh; }
 // the two tables, for the case-by-case check of the product's packed copy

@@ -176,3 +176,11 @@ def test_mesh_identical_to_the_oracle_and_the_reference_code(oracle, tmp_path):
             ctx.export_mesh_ply(tmp_path / "dev2.ply", False, 0, False)
         assert v.tobytes() == rv.tobytes() and cc.tobytes() == rc.tobytes() and f.tobytes() == rf.tobytes()
         assert open(tmp_path / "dev2.ply", "rb").read() == open(tmp_path / "ref.ply", "rb").read()
+        # largest_component_only = MeshUtil::removeLooseComponents (+ removeUnusedVertices) on that mesh — this ragged grid (3 % of its voxels invalid)
+        # falls into several pieces
+        lv, lc, lf = ref_py.mesh_remove_loose_components(rv, rc, rf)
+        with binding.Context(0) as ctx:
+            ctx.set_grid(vs, a["keys"], a["sdf"], a["sdf"], a["albedo"], a["weight"], a["color"])
+            v2, c2, f2 = ctx.extract_mesh(use_refined_sdf=False, color_mode=0, largest_component_only=True)
+        assert len(lf) < len(rf) and len(lv) < len(rv)
+        assert v2.tobytes() == lv.tobytes() and c2.tobytes() == lc.tobytes() and f2.tobytes() == lf.tobytes()

@@ -388,3 +388,33 @@ def test_keyframe_selection_equals_the_reference_class(R, tmp_path):
     for im in imgs:
         sa, sb = B.blur_score(im), ref_py.blur_score(im)
         assert (np.isnan(sa) and np.isnan(sb)) or abs(sa - sb) <= 1e-12 * max(1.0, abs(sb)), (im.shape, sa, sb)
+
+
+def test_loose_component_removal_equals_the_reference_code(R):
+    """MeshUtil::removeLooseComponents + removeUnusedVertices (mesh/util.cpp:47-171, Boost's graph pieces as stand-ins) vs i3d_mesh_remove_loose_components —
+    what `largest_component_only` applies to an extracted mesh: several components of different and of EQUAL size (the first one wins), components that
+    touch in a single vertex, vertices no face uses, with and without colours."""
+    from intrinsic3d_amd import binding as B
+    from oracle import ref_py
+    rng = np.random.default_rng(3)
+
+    def blob(n_faces, v0, chain=True):
+        """n_faces triangles, consecutive ones sharing an edge (one component), on fresh vertices starting at index v0"""
+        nv = n_faces + 2; f = np.array([[v0 + i, v0 + i + 1, v0 + i + 2] for i in range(n_faces)], np.int32)
+        return nv, f
+    for trial, sizes in enumerate(([5, 9, 3], [4, 7, 7, 2], [6], [3, 3, 3], [1, 12, 12, 5, 12])):
+        faces = []; nv = 0
+        for s in sizes:
+            n, f = blob(s, nv); faces.append(f); nv += n
+            nv += int(rng.integers(0, 3))                                  # vertices no face uses, between the components
+        faces = np.concatenate(faces)
+        if trial == 1:                                                      # two components touching in ONE vertex become one
+            faces[faces == faces[4][0]] = faces[0][0]
+        order = rng.permutation(len(faces)) if trial in (0, 3, 4) else np.arange(len(faces))      # interleave the components' faces in the file order
+        faces = faces[order]
+        verts = rng.normal(0, 1, (nv, 3)).astype(np.float32); cols = rng.integers(0, 256, (nv, 3)).astype(np.uint8)
+        for c in (cols, None):
+            vo, co, fo = B.mesh_remove_loose_components(verts, c, faces)
+            vr, cr, fr = ref_py.mesh_remove_loose_components(verts, c, faces)
+            assert np.array_equal(vo, vr) and np.array_equal(fo, fr) and (c is None or np.array_equal(co, cr)), (trial, len(vo), len(vr), len(fo), len(fr))
+            assert len(fo) >= max(sizes) and fo.max() == len(vo) - 1
