@@ -64,6 +64,11 @@ CHUNKS = [
     ("camera_impl",          "src/camera.cpp", 41, 199, "Camera::Camera() :", "}"),
     ("camera_convert",       "src/camera.cpp", 277, 311, "void Camera::print", "}"),
     ("camera_load_save",     "src/camera.cpp", 202, 274, "bool Camera::load", "}"),
+    ("sensor_class",         "include/nv/rgbd/sensor.h", 49, 112, "class Sensor", "};"),
+    ("sensor_ctor",          "src/rgbd/sensor.cpp", 50, 63, "Sensor::Sensor() :", "}"),
+    ("sensor_access",        "src/rgbd/sensor.cpp", 121, 220, "const Camera& Sensor::depthCamera() const", "}"),
+    ("sensor_i3d_class",     "include/nv/rgbd/sensor_i3d.h", 50, 88, "class SensorI3d : public Sensor", "};"),
+    ("sensor_i3d_impl",      "src/rgbd/sensor_i3d.cpp", 48, 345, "SensorI3d::SensorI3d() :", "}"),
     ("kfs_class",            "include/nv/keyframe_selection.h", 47, 75, "class KeyframeSelection", "};"),
     ("kfs_impl_a",           "src/keyframe_selection.cpp", 46, 126, "KeyframeSelection::KeyframeSelection(int window_size)", "}"),
     ("kfs_impl_b",           "src/keyframe_selection.cpp", 139, 310, "bool KeyframeSelection::load", "}"),

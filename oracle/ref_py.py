@@ -198,3 +198,68 @@ def mesh_remove_loose_components(vertices, colors, faces):
     vo = np.zeros((nv.value, 3), np.float32); co = None if c is None else np.zeros((nv.value, 3), np.uint8); fo = np.zeros((nf.value, 3), np.int32)
     L.ref_mesh_get(m, _p(vo), None if co is None else _p(co), _p(fo)); L.ref_mesh_free(m)
     return vo, co, fo
+
+
+# --- SensorI3d (rgbd/sensor_i3d.cpp, rgbd/sensor.cpp): the reference's dataset-folder sensor; PNG decoding supplied by Pillow through cv::imdecode's hook
+_HOOK_T = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_ubyte), C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ubyte))
+_hook_keep = None
+
+
+def _install_pillow_decoder(L):
+    global _hook_keep
+    if _hook_keep is not None:
+        return
+    import io
+    from PIL import Image
+
+    def decode(buf, size, rows, cols, typ, out):
+        try:
+            im = Image.open(io.BytesIO(bytes(bytearray(buf[:size])))); im.load()
+        except Exception:
+            return 0
+        a = np.asarray(im)
+        if a.ndim == 3:
+            a = np.ascontiguousarray(a[:, :, 2::-1][:, :, :3], np.uint8); t = 16           # cv::imdecode hands out B, G, R
+        elif a.dtype == np.uint8:
+            a = np.ascontiguousarray(a, np.uint8); t = 0
+        else:
+            a = np.ascontiguousarray(a, np.uint16); t = 2
+        rows[0], cols[0], typ[0] = a.shape[0], a.shape[1], t
+        if out:
+            C.memmove(out, a.ctypes.data, a.nbytes)
+        return 1
+    _hook_keep = _HOOK_T(decode)
+    L.ref_set_imdecode_hook(_hook_keep)
+
+
+class Sensor:
+    """SensorI3d::init on a dataset folder + Sensor::depth / color / pose"""
+
+    def __init__(self, folder, max_frames=0, min_depth=0.0, max_depth=0.0):
+        self.L = C.CDLL(LIB_PATH); _install_pillow_decoder(self.L)
+        self.L.ref_sensor_open.restype = C.c_void_p; self.L.ref_sensor_depth.restype = C.c_int64; self.L.ref_sensor_color.restype = C.c_int64
+        for f in ("ref_sensor_info", "ref_sensor_pose", "ref_sensor_depth", "ref_sensor_color", "ref_sensor_free"):
+            getattr(self.L, f).argtypes = None
+        h = self.L.ref_sensor_open(str(folder).encode(), C.c_int32(max_frames), C.c_float(min_depth), C.c_float(max_depth))
+        self.h = C.c_void_p(h) if h else None
+        if self.h is None:
+            raise RuntimeError("SensorI3d::init failed")
+        nf = C.c_int32(); ns = C.c_int32(); cwh = np.zeros(2, np.int32); dwh = np.zeros(2, np.int32); ci = np.zeros(4, np.float32); di = np.zeros(4, np.float32)
+        self.L.ref_sensor_info(self.h, C.byref(nf), C.byref(ns), _p(cwh), _p(dwh), _p(ci), _p(di))
+        self.num_frames, self.num_stored = nf.value, ns.value
+        self.color_size, self.depth_size, self.color_intrinsics, self.depth_intrinsics = tuple(int(x) for x in cwh), tuple(int(x) for x in dwh), ci, di
+
+    def pose(self, i):
+        m = np.zeros((4, 4), np.float32); self.L.ref_sensor_pose(self.h, C.c_int32(i), _p(m)); return m
+
+    def depth(self, i):
+        out = np.zeros((self.depth_size[1], self.depth_size[0]), np.float32)
+        return out if self.L.ref_sensor_depth(self.h, C.c_int32(i), _p(out)) else None
+
+    def color(self, i):
+        out = np.zeros((self.color_size[1], self.color_size[0], 3), np.uint8)
+        return out if self.L.ref_sensor_color(self.h, C.c_int32(i), _p(out)) else None
+
+    def close(self):
+        if self.h:
+            self.L.ref_sensor_free(self.h); self.h = None

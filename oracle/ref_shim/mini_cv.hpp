@@ -15,6 +15,7 @@
 #include <vector>
 
 #define CV_8UC1 0
+#define CV_16UC1 2
 #define CV_8UC3 16
 #define CV_32FC1 5
 #define CV_32F 5
@@ -41,7 +42,8 @@ struct Mat {
     std::shared_ptr<std::vector<unsigned char>> own;
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
-    static size_t elem(int type) { return type == CV_8UC1 ? 1 : type == CV_8UC3 ? 3 : type == CV_32FC3 ? 12 : 4; }
+    static size_t elem(int type) { return type == CV_8UC1 ? 1 : type == CV_16UC1 ? 2 : type == CV_8UC3 ? 3 : type == CV_32FC3 ? 12 : 4; }
+    explicit Mat(const std::vector<unsigned char>& buf) { create(1, (int)buf.size(), CV_8UC1); if (!buf.empty()) std::memcpy(data, buf.data(), buf.size()); }      // an encoded file handed to imdecode
     void create(int r, int c, int type) {
         rows = r; cols = c; type_ = type;
         own = std::make_shared<std::vector<unsigned char>>((size_t)r * c * elem(type), (unsigned char)0);
@@ -52,10 +54,12 @@ struct Mat {
     static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
     static Mat zeros(Size s, int type) { return Mat(s.height, s.width, type); }
     static Mat ones(int r, int c, int type) { Mat m(r, c, type); for (size_t i = 0; i < (size_t)r * c; ++i) reinterpret_cast<float*>(m.data)[i] = 1.0f; return m; }      // (CV_32F only)
-    // dst = saturate_cast<float>(src * alpha): 8-bit 1-channel -> float with the scale applied in float (cv::Mat::convertTo, the only conversion the reference bodies use)
+    // dst = saturate_cast<float>(src * alpha): 8- / 16-bit 1-channel -> float with the scale applied in float (cv::Mat::convertTo, the only conversions the reference bodies use)
     void convertTo(Mat& dst, int type, double alpha = 1.0) const {
-        dst.create(rows, cols, type); const float a = (float)alpha;
-        for (size_t i = 0; i < (size_t)rows * cols; ++i) reinterpret_cast<float*>(dst.data)[i] = (float)data[i] * a;
+        if (empty()) { dst = Mat(); return; }
+        Mat o(rows, cols, type); const float a = (float)alpha;
+        for (size_t i = 0; i < (size_t)rows * cols; ++i) reinterpret_cast<float*>(o.data)[i] = (type_ == CV_16UC1 ? (float)reinterpret_cast<const uint16_t*>(data)[i] : (float)data[i]) * a;
+        dst = o;
     }
     Size size() const { return Size(cols, rows); }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
@@ -86,6 +90,23 @@ inline void filter2D(const Mat& src, Mat& dst, int /*ddepth*/, const Mat& k) {
         o.at<float>(y, x) = s;
     }
     dst = o;
+}
+// cv::threshold on float images: THRESH_TOZERO keeps src where src > thresh, THRESH_TOZERO_INV where src <= thresh (the comparison in float)
+enum { THRESH_TOZERO = 3, THRESH_TOZERO_INV = 4 };
+inline double threshold(const Mat& src, Mat& dst, double thresh, double /*maxval*/, int type) {
+    Mat o = src.clone(); const float t = (float)thresh; float* p = reinterpret_cast<float*>(o.data);
+    for (size_t i = 0; i < (size_t)o.rows * o.cols; ++i) { const bool above = p[i] > t; if (type == THRESH_TOZERO ? !above : above) p[i] = 0.0f; }
+    dst = o; return thresh;
+}
+// cv::imdecode: decoding is NOT restated here — the harness installs a decoder (tests: Pillow through a ctypes callback); without one images are empty
+enum { IMREAD_UNCHANGED = -1 };
+typedef int (*imdecode_hook_t)(const unsigned char* buf, size_t size, int* rows, int* cols, int* type, unsigned char* out /* NULL: sizes only */);
+inline imdecode_hook_t& imdecode_hook() { static imdecode_hook_t h = nullptr; return h; }
+inline Mat imdecode(const Mat& buf, int /*flags*/) {
+    Mat m; if (!imdecode_hook() || buf.empty()) return m;
+    int r = 0, c = 0, t = 0;
+    if (!imdecode_hook()(buf.data, (size_t)buf.cols, &r, &c, &t, nullptr) || r <= 0 || c <= 0) return m;
+    m.create(r, c, t); imdecode_hook()(buf.data, (size_t)buf.cols, &r, &c, &t, m.data); return m;
 }
 inline Scalar sum(const Mat& m) { double s = 0.0; for (size_t i = 0; i < (size_t)m.rows * m.cols; ++i) s += (double)reinterpret_cast<const float*>(m.data)[i]; return Scalar(s); }
 

@@ -133,14 +133,25 @@ static double chroma_weight(const Vec3b& color, const Vec3b& color_nb) {     // 
 #include "gen/svsh_class.inc"
 #include "gen/svsh_impl.inc"
 
-// shim: the Sensor Intrinsic3D holds reads a dataset folder through OpenCV; here the C ABI hands the keyframes in directly, so it is an inert holder.
-// KeyframeSelection is the reference's own class (window selection, keyframes.txt, the Crete blur metric over the OpenCV stand-ins of mini_cv.hpp).
-class Sensor {
+// Sensor / SensorI3d are the reference's own classes (folder conventions, pose / intrinsics text, depth scaling and thresholding); PNG decoding comes from
+// the harness (cv::imdecode hook).  Intrinsic3D only needs a Sensor to hold the colour camera and take poses: HolderSensor below.
+#include "gen/sensor_class.inc"
+#include "gen/sensor_ctor.inc"
+#include "gen/sensor_access.inc"
+#include "gen/sensor_i3d_class.inc"
+#include "gen/sensor_i3d_impl.inc"
+class HolderSensor : public Sensor {
 public:
-    Camera& colorCamera() { return color_cam_; }
-    void setPose(int, const Mat4f&) {}
-    Camera color_cam_;
+    void setPose(int, const Mat4f&) override {}
+    Mat4f pose(int) override { return Mat4f::Identity(); }
+    double timePose(int) override { return 0.0; }
+    double timeDepth(int) override { return 0.0; }
+    double timeColor(int) override { return 0.0; }
+    bool init(const std::string&) override { return false; }
+    cv::Mat loadDepth(int) override { return cv::Mat(); }
+    cv::Mat loadColor(int) override { return cv::Mat(); }
 };
+// KeyframeSelection is the reference's own class (window selection, keyframes.txt, the Crete blur metric over the OpenCV stand-ins of mini_cv.hpp).
 #include "gen/kfs_class.inc"
 #include "gen/kfs_impl_a.inc"
 #include "gen/kfs_impl_b.inc"
@@ -578,7 +589,7 @@ int32_t ref_estimate_sh(void* g, float subvolume_size, double lambda_reg, double
 int32_t ref_recompute_colors(void* g, void* fr, const double* intr, const double* dist, const double* poses, float occlusion_distance, int32_t num_observations) {
     CoutSilencer quiet;
     auto* G = (SparseVoxelGrid<VoxelSBR>*)g; auto* F = (RefFrames*)fr;
-    Sensor sensor; KeyframeSelection ks;
+    HolderSensor sensor; KeyframeSelection ks;
     Intrinsic3D::Config cfg; cfg.occlusions_distance = occlusion_distance; cfg.num_observations = (size_t)num_observations; cfg.num_rgbd_levels = F->levels;
     Intrinsic3D i3d(cfg, Optimizer::Config(), &sensor, &ks);
     i3d.opt_data_.grid = G; i3d.image_model_.rgbd_pyr = F->pyr; i3d.image_model_.poses.resize((size_t)F->K);
@@ -596,11 +607,11 @@ int32_t ref_refine(void** grid_io, void* fr, const ref_opt_config* c, int32_t nu
     auto* G = (SparseVoxelGrid<VoxelSBR>*)*grid_io; auto* F = (RefFrames*)fr;
     auto tw = twins().find(G); if (tw == twins().end()) return 3;          // refine() takes the Voxel grid the VoxelSBR grid was converted from
     SparseVoxelGrid<Voxel>* twin = tw->second;
-    Sensor sensor; KeyframeSelection ks;
+    HolderSensor sensor; KeyframeSelection ks;
     Intrinsic3D::Config cfg; cfg.num_grid_levels = num_grid_levels; cfg.num_rgbd_levels = num_rgbd_levels; cfg.thres_shell_factor = thres_shell_factor; cfg.thres_shell_factor_final = thres_shell_factor_final;
     cfg.clear_distant_voxels = clear_distant_voxels != 0; cfg.occlusions_distance = c->occlusion_distance; cfg.num_observations = (size_t)c->num_observations;
     cfg.subvolume_size_sh = subvolume_size_sh; cfg.sh_est_lambda_reg = sh_lambda_reg;
-    { Vec4 k; for (int i = 0; i < 4; ++i) k[i] = intr[i]; sensor.color_cam_.setIntrinsics(k); cv::Mat l0 = F->pyr[0].intensity(0); sensor.color_cam_.setWidth(l0.cols); sensor.color_cam_.setHeight(l0.rows); }
+    { Vec4 k; for (int i = 0; i < 4; ++i) k[i] = intr[i]; sensor.cam_color_.setIntrinsics(k); cv::Mat l0 = F->pyr[0].intensity(0); sensor.cam_color_.setWidth(l0.cols); sensor.cam_color_.setHeight(l0.rows); }
     Intrinsic3D i3d(cfg, to_opt_cfg(c), &sensor, &ks);
     i3d.image_model_.rgbd_pyr = F->pyr; i3d.image_model_.poses.resize((size_t)F->K);
     for (int i = 0; i < 4; ++i) i3d.image_model_.intrinsics[i] = intr[i];
@@ -675,6 +686,29 @@ int32_t ref_camera_load(const char* path, int32_t* w, int32_t* h, float* k4, flo
     const Vec5f d = cam.distortion(); for (int i = 0; i < 5; ++i) dist5[i] = d[i];
     return ok ? 1 : 0;
 }
+/* SensorI3d on a dataset folder (rgbd/sensor_i3d.cpp:48-345, rgbd/sensor.cpp:50-63,121-220) */
+void ref_set_imdecode_hook(cv::imdecode_hook_t h) { cv::imdecode_hook() = h; }
+void* ref_sensor_open(const char* folder, int32_t max_frames, float depth_min, float depth_max) {
+    SensorI3d* s = new SensorI3d; s->setNumFramesMax(max_frames); s->setDepthMin(depth_min); s->setDepthMax(depth_max);
+    std::streambuf* o1 = std::cout.rdbuf(nullptr); std::streambuf* o2 = std::cerr.rdbuf(nullptr);
+    const bool ok = s->init(folder);
+    std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
+    if (!ok) { delete s; return nullptr; }
+    return s;
+}
+void ref_sensor_info(void* h, int32_t* num_frames, int32_t* num_stored, int32_t* cwh, int32_t* dwh, float* ci4, float* di4) {
+    SensorI3d* s = (SensorI3d*)h; *num_frames = s->numFrames(); *num_stored = (int32_t)s->depth_images_.size();
+    cwh[0] = s->colorCamera().width(); cwh[1] = s->colorCamera().height(); dwh[0] = s->depthCamera().width(); dwh[1] = s->depthCamera().height();
+    const Mat3f Kc = s->colorCamera().intrinsics(), Kd = s->depthCamera().intrinsics();
+    ci4[0] = Kc(0, 0); ci4[1] = Kc(1, 1); ci4[2] = Kc(0, 2); ci4[3] = Kc(1, 2); di4[0] = Kd(0, 0); di4[1] = Kd(1, 1); di4[2] = Kd(0, 2); di4[3] = Kd(1, 2);
+}
+void ref_sensor_pose(void* h, int32_t id, float* m16) { const Mat4f p = ((SensorI3d*)h)->pose(id); for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m16[4 * r + c] = p(r, c); }
+double ref_sensor_time(void* h, int32_t id) { return ((SensorI3d*)h)->timeDepth(id); }
+/* returns rows * cols (0 = empty image); out may be NULL */
+int64_t ref_sensor_depth(void* h, int32_t id, float* out) { const cv::Mat d = ((SensorI3d*)h)->depth(id); if (d.empty()) return 0; if (out) std::memcpy(out, d.data, (size_t)d.rows * d.cols * 4); return (int64_t)d.rows * d.cols; }
+int64_t ref_sensor_color(void* h, int32_t id, uint8_t* out) { const cv::Mat c = ((SensorI3d*)h)->color(id); if (c.empty()) return 0; if (out) std::memcpy(out, c.data, (size_t)c.rows * c.cols * 3); return (int64_t)c.rows * c.cols; }
+void ref_sensor_free(void* h) { delete (SensorI3d*)h; }
+
 /* KeyframeSelection (keyframe_selection.cpp:46-126, 139-310): the reference's class on caller data */
 double ref_blur_score(const uint8_t* image, int32_t w, int32_t h, int32_t channels) {
     KeyframeSelection ks; return ks.estimateBlur(cv::Mat::wrap(h, w, channels == 3 ? CV_8UC3 : CV_8UC1, image));
