@@ -67,6 +67,7 @@ CHUNKS = [
     ("sensor_class",         "include/nv/rgbd/sensor.h", 49, 112, "class Sensor", "};"),
     ("sensor_ctor",          "src/rgbd/sensor.cpp", 50, 63, "Sensor::Sensor() :", "}"),
     ("sensor_access",        "src/rgbd/sensor.cpp", 121, 220, "const Camera& Sensor::depthCamera() const", "}"),
+    ("sensor_poses",         "src/rgbd/sensor.cpp", 235, 347, "bool Sensor::loadPoses", "}"),
     ("sensor_i3d_class",     "include/nv/rgbd/sensor_i3d.h", 50, 88, "class SensorI3d : public Sensor", "};"),
     ("sensor_i3d_impl",      "src/rgbd/sensor_i3d.cpp", 48, 345, "SensorI3d::SensorI3d() :", "}"),
     ("kfs_class",            "include/nv/keyframe_selection.h", 47, 75, "class KeyframeSelection", "};"),

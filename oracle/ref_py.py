@@ -260,6 +260,20 @@ class Sensor:
         out = np.zeros((self.color_size[1], self.color_size[0], 3), np.uint8)
         return out if self.L.ref_sensor_color(self.h, C.c_int32(i), _p(out)) else None
 
+    def set_pose(self, i, cam_to_world):
+        m = np.ascontiguousarray(cam_to_world, np.float32); self.L.ref_sensor_set_pose(self.h, C.c_int32(i), _p(m))
+
+    def save_poses(self, path):
+        return self.L.ref_sensor_save_poses(self.h, str(path).encode()) == 1
+
     def close(self):
         if self.h:
             self.L.ref_sensor_free(self.h); self.h = None
+
+
+def load_poses(path, first_is_identity=False, cap=4096):
+    """Sensor::loadPoses (static): TUM trajectory lines -> (timestamps, camera-to-world 4x4 float matrices); None if the file does not open"""
+    L = _raw(); L.ref_load_poses.restype = C.c_int64
+    ts = np.zeros(cap); m = np.zeros((cap, 4, 4), np.float32)
+    n = int(L.ref_load_poses(str(path).encode(), C.c_int32(1 if first_is_identity else 0), C.c_int64(cap), _p(ts), _p(m)))
+    return None if n < 0 else (ts[:n], m[:n])

@@ -37,6 +37,7 @@ struct BlockRef {
     Matrix<T, R, C>& m; int r0, c0;
     BlockRef& operator=(const Matrix<T, BR, BC>& v) { for (int c = 0; c < BC; ++c) for (int r = 0; r < BR; ++r) m(r0 + r, c0 + c) = v(r, c); return *this; }
     operator Matrix<T, BR, BC>() const { Matrix<T, BR, BC> o; for (int c = 0; c < BC; ++c) for (int r = 0; r < BR; ++r) o(r, c) = m(r0 + r, c0 + c); return o; }
+    T operator()(int r, int c) const { return m(r0 + r, c0 + c); }
 };
 
 template <class T, int R, int C>
@@ -150,6 +151,36 @@ struct AngleAxisd {
         tmp = cos1_axis[0] * axis[2]; res(0, 2) = tmp + sin_axis[1]; res(2, 0) = tmp - sin_axis[1];
         tmp = cos1_axis[1] * axis[2]; res(1, 2) = tmp - sin_axis[0]; res(2, 1) = tmp + sin_axis[0];
         for (int i = 0; i < 3; ++i) res(i, i) = cos1_axis[i] * axis[i] + c;
+        return res;
+    }
+};
+
+// Eigen::Quaternionf as Sensor::loadPoses / savePoses use it: from a rotation matrix (Geometry/Quaternion.h, quaternionbase_assign_impl<Other,3,3>: the
+// trace branch, else the largest diagonal element), from (w, x, y, z), and toRotationMatrix (the tx = 2x ... products of QuaternionBase::toRotationMatrix)
+struct Quaternionf {
+    float c[4];                                                    // x y z w (Eigen's coefficient order)
+    Quaternionf(float w, float x, float y, float z) { c[0] = x; c[1] = y; c[2] = z; c[3] = w; }
+    template <class M3> explicit Quaternionf(const M3& mm) {
+        Matrix3f m; for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) m(r, k) = mm(r, k);
+        float t = m(0, 0) + m(1, 1) + m(2, 2);
+        if (t > 0.0f) {
+            t = std::sqrt(t + 1.0f); c[3] = 0.5f * t; t = 0.5f / t;
+            c[0] = (m(2, 1) - m(1, 2)) * t; c[1] = (m(0, 2) - m(2, 0)) * t; c[2] = (m(1, 0) - m(0, 1)) * t;
+        } else {
+            int i = 0; if (m(1, 1) > m(0, 0)) i = 1; if (m(2, 2) > m(i, i)) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0f); c[i] = 0.5f * t; t = 0.5f / t;
+            c[3] = (m(k, j) - m(j, k)) * t; c[j] = (m(j, i) + m(i, j)) * t; c[k] = (m(k, i) + m(i, k)) * t;
+        }
+    }
+    float x() const { return c[0]; } float y() const { return c[1]; } float z() const { return c[2]; } float w() const { return c[3]; }
+    Matrix3f toRotationMatrix() const {
+        Matrix3f res;
+        const float tx = 2.0f * c[0], ty = 2.0f * c[1], tz = 2.0f * c[2];
+        const float twx = tx * c[3], twy = ty * c[3], twz = tz * c[3], txx = tx * c[0], txy = ty * c[0], txz = tz * c[0], tyy = ty * c[1], tyz = tz * c[1], tzz = tz * c[2];
+        res(0, 0) = 1.0f - (tyy + tzz); res(0, 1) = txy - twz; res(0, 2) = txz + twy;
+        res(1, 0) = txy + twz; res(1, 1) = 1.0f - (txx + tzz); res(1, 2) = tyz - twx;
+        res(2, 0) = txz - twy; res(2, 1) = tyz + twx; res(2, 2) = 1.0f - (txx + tyy);
         return res;
     }
 };

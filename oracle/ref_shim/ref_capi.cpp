@@ -138,6 +138,7 @@ static double chroma_weight(const Vec3b& color, const Vec3b& color_nb) {     // 
 #include "gen/sensor_class.inc"
 #include "gen/sensor_ctor.inc"
 #include "gen/sensor_access.inc"
+#include "gen/sensor_poses.inc"
 #include "gen/sensor_i3d_class.inc"
 #include "gen/sensor_i3d_impl.inc"
 class HolderSensor : public Sensor {
@@ -707,6 +708,15 @@ double ref_sensor_time(void* h, int32_t id) { return ((SensorI3d*)h)->timeDepth(
 /* returns rows * cols (0 = empty image); out may be NULL */
 int64_t ref_sensor_depth(void* h, int32_t id, float* out) { const cv::Mat d = ((SensorI3d*)h)->depth(id); if (d.empty()) return 0; if (out) std::memcpy(out, d.data, (size_t)d.rows * d.cols * 4); return (int64_t)d.rows * d.cols; }
 int64_t ref_sensor_color(void* h, int32_t id, uint8_t* out) { const cv::Mat c = ((SensorI3d*)h)->color(id); if (c.empty()) return 0; if (out) std::memcpy(out, c.data, (size_t)c.rows * c.cols * 3); return (int64_t)c.rows * c.cols; }
+void ref_sensor_set_pose(void* h, int32_t id, const float* m16) { Mat4f p; for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) p(r, c) = m16[4 * r + c]; ((SensorI3d*)h)->setPose(id, p); }
+int32_t ref_sensor_save_poses(void* h, const char* path) { return ((SensorI3d*)h)->savePoses(path) ? 1 : 0; }
+/* Sensor::loadPoses (static): TUM trajectory file -> timestamps + camera-to-world matrices; returns the count (-1: file not opened) */
+int64_t ref_load_poses(const char* path, int32_t first_is_identity, int64_t cap, double* timestamps, float* m16) {
+    std::vector<Mat4f> poses; std::vector<double> ts;
+    if (!Sensor::loadPoses(path, poses, ts, first_is_identity != 0)) return -1;
+    for (size_t i = 0; i < poses.size() && (int64_t)i < cap; ++i) { timestamps[i] = ts[i]; for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m16[16 * i + 4 * r + c] = poses[i](r, c); }
+    return (int64_t)poses.size();
+}
 void ref_sensor_free(void* h) { delete (SensorI3d*)h; }
 
 /* KeyframeSelection (keyframe_selection.cpp:46-126, 139-310): the reference's class on caller data */

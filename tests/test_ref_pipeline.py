@@ -458,5 +458,14 @@ def test_dataset_folder_sensor_equals_the_reference_classes(R, tmp_path):
     assert compare(f3) == (6, 3)                                        # a missing pose file ends the loading loop, the listing keeps its count
     f4 = tmp_path / "nocolor"; shutil.copytree(folder, f4); (f4 / "frame-000002.color.png").unlink()
     assert compare(f4) == (6, 2)                                        # a missing colour image as well
+    # Sensor::savePoses: TUM trajectory lines (timestamp, camera-to-world translation, Eigen::Quaternionf(R) as x y z w, 6 decimals) — the same text from both,
+    # incl. a rotation close to 180 degrees (negative-trace branch of the conversion); and the reference's loadPoses reads the product's file back
+    a = B.Sensor(folder); b = ref_py.Sensor(folder)
+    T = a.pose(1).copy(); T[:3, :3] = Rotation.from_rotvec([3.1, 0.02, -0.01]).as_matrix().astype(np.float32); a.set_pose(1, T); b.set_pose(1, T)
+    a.save_poses(tmp_path / "poses_ours.txt"); assert b.save_poses(tmp_path / "poses_ref.txt")
+    assert open(tmp_path / "poses_ours.txt").read() == open(tmp_path / "poses_ref.txt").read()
+    ts, mats = ref_py.load_poses(tmp_path / "poses_ours.txt")
+    assert np.array_equal(ts, np.arange(6.0)) and all(np.abs(mats[i] - a.pose(i)).max() < 5e-6 for i in range(6))
+    a.close(); b.close()
     f5 = tmp_path / "empty"; shutil.copytree(folder, f5); open(f5 / "frame-000001.color.png", "wb").close()
     assert compare(f5) == (6, 1)                                        # so does an EMPTY file (loadFile reports size 0 as failure: the `continue` for empty buffers is never reached)
