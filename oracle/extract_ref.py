@@ -58,12 +58,18 @@ CHUNKS = [
     ("grid_class",           "include/nv/sparse_voxel_grid.h", 84, 161, "template <class T>", "};"),
     ("grid_impl",            "src/sparse_voxel_grid.cpp", 43, 467, "template <class T>", "}"),
     ("grid_frustum",         "src/sparse_voxel_grid.cpp", 572, 602, "template <class T>", "}"),
+    ("grid_print_info",      "src/sparse_voxel_grid.cpp", 470, 480, "template <class T>", "}"),
     ("grid_save",            "src/sparse_voxel_grid.cpp", 483, 516, "template <class T>", "}"),
     ("grid_load",            "src/sparse_voxel_grid.cpp", 531, 569, "template <class T>", "}"),
     ("camera_class",         "include/nv/camera.h", 47, 89, "class Camera", "};"),
     ("camera_impl",          "src/camera.cpp", 41, 199, "Camera::Camera() :", "}"),
     ("camera_convert",       "src/camera.cpp", 277, 311, "void Camera::print", "}"),
     ("camera_load_save",     "src/camera.cpp", 202, 274, "bool Camera::load", "}"),
+    ("settings_class",       "include/nv/settings.h", 48, 74, "class Settings", "};"),
+    ("settings_impl",        "src/settings.cpp", 41, 138, "Settings::Settings()", "}"),
+    ("app_fusion_class",     "../apps/include/nv/app_fusion.h", 46, 58, "class AppFusion", "};"),
+    ("app_fusion_ctor",      "../apps/src/app_fusion.cpp", 52, 61, "AppFusion::AppFusion() :", "}"),
+    ("app_fusion_fuse",      "../apps/src/app_fusion.cpp", 107, 200, "bool AppFusion::fuseSDF", "}"),
     ("sensor_class",         "include/nv/rgbd/sensor.h", 49, 112, "class Sensor", "};"),
     ("sensor_ctor",          "src/rgbd/sensor.cpp", 50, 63, "Sensor::Sensor() :", "}"),
     ("sensor_access",        "src/rgbd/sensor.cpp", 121, 220, "const Camera& Sensor::depthCamera() const", "}"),

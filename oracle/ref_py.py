@@ -277,3 +277,12 @@ def load_poses(path, first_is_identity=False, cap=4096):
     ts = np.zeros(cap); m = np.zeros((cap, 4, 4), np.float32)
     n = int(L.ref_load_poses(str(path).encode(), C.c_int32(1 if first_is_identity else 0), C.c_int64(cap), _p(ts), _p(m)))
     return None if n < 0 else (ts[:n], m[:n])
+
+
+def app_fusion(folder, cfg, max_frames=0, min_depth=0.0, max_depth=0.0):
+    """AppFusion::fuseSDF of the reference on a dataset folder (its own SensorI3d, KeyframeSelection, grid, marching cubes); cfg: dict for nv::Settings
+    (keyframes, voxel_size, clip_x0..clip_z1, discont_window_size, output_sdf, output_mesh)."""
+    L = C.CDLL(LIB_PATH); _install_pillow_decoder(L)
+    ks = [str(k).encode() for k in cfg]; vs = [str(v).encode() for v in cfg.values()]
+    K = (C.c_char_p * len(ks))(*ks); V = (C.c_char_p * len(vs))(*vs)
+    return L.ref_app_fusion(str(folder).encode(), C.c_int32(max_frames), C.c_float(min_depth), C.c_float(max_depth), C.c_int32(len(ks)), K, V) == 1

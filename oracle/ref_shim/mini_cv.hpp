@@ -70,6 +70,7 @@ struct Mat {
     template <class T> const T& at(int y, int x) const { return reinterpret_cast<const T*>(data)[(size_t)y * cols + x]; }
 };
 
+class FileNode; class FileStorage;                  // only named in private declarations of nv::Settings that are never defined here
 struct Scalar { double val[4]; Scalar(double a = 0, double b = 0, double c = 0, double d = 0) : val{a, b, c, d} {} };
 inline Mat operator*(const Mat& m, double f) { Mat o = m.clone(); const float ff = (float)f; for (size_t i = 0; i < (size_t)o.rows * o.cols; ++i) reinterpret_cast<float*>(o.data)[i] *= ff; return o; }
 inline void transpose(const Mat& a, Mat& b) { Mat o(a.cols, a.rows, a.type()); for (int y = 0; y < a.rows; ++y) for (int x = 0; x < a.cols; ++x) o.at<float>(x, y) = a.at<float>(y, x); b = o; }

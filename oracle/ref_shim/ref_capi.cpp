@@ -52,7 +52,9 @@ namespace std {
 #define protected public
 namespace nv {
 
-class Settings;                                      // shim: only named by Config::load declarations that are never defined or called
+#include "gen/settings_class.inc"                    // the reference's Settings (string map, stream conversions); reading a yml needs cv::FileStorage:
+#include "gen/settings_impl.inc"                     // our load() below refuses, the C ABI fills the map through set()
+bool Settings::load(const std::string&) { return false; }
 
 #include "gen/grid_voxels.inc"
 #include "gen/camera_class.inc"
@@ -74,6 +76,7 @@ namespace math {
 }  // namespace math
 #include "gen/grid_impl.inc"
 #include "gen/grid_frustum.inc"
+#include "gen/grid_print_info.inc"
 #include "gen/grid_save.inc"
 #include "gen/grid_load.inc"
 namespace SDFOperators {
@@ -183,6 +186,9 @@ void removeUnusedVertices(Mesh* mesh);               // (declared in the referen
 #include "gen/mc_extract_mesh.inc"
 #include "gen/mc_body.inc"
 #include "gen/mc_tables.inc"
+#include "gen/app_fusion_class.inc"
+#include "gen/app_fusion_ctor.inc"
+#include "gen/app_fusion_fuse.inc"
 
 }  // namespace nv
 #undef private
@@ -718,6 +724,23 @@ int64_t ref_load_poses(const char* path, int32_t first_is_identity, int64_t cap,
     return (int64_t)poses.size();
 }
 void ref_sensor_free(void* h) { delete (SensorI3d*)h; }
+
+/* AppFusion::fuseSDF (apps/src/app_fusion.cpp:107-200) on a dataset folder: the reference's own fusion application loop — keyframe filter, erosion, normals,
+ * integrate, correctSDF, clearInvalidVoxels, .tsdf and mesh output — over its own SensorI3d.  cfg: n (key, value) string pairs for nv::Settings. */
+int32_t ref_app_fusion(const char* folder, int32_t max_frames, float depth_min, float depth_max, int32_t n, const char* const* keys, const char* const* values) {
+    SensorI3d* s = new SensorI3d; s->setNumFramesMax(max_frames); s->setDepthMin(depth_min); s->setDepthMax(depth_max);
+    const bool quiet = std::getenv("I3D_REF_VERBOSE") == nullptr;
+    std::streambuf* o1 = std::cout.rdbuf(); std::streambuf* o2 = std::cerr.rdbuf();
+    if (quiet) { std::cout.rdbuf(nullptr); std::cerr.rdbuf(nullptr); }
+    bool ok = s->init(folder);
+    if (ok) {
+        Settings cfg; for (int i = 0; i < n; ++i) cfg.set<std::string>(keys[i], values[i]);
+        AppFusion app; app.sensor_ = s;              // (the destructor deletes the sensor)
+        ok = app.fuseSDF(cfg);
+    } else delete s;
+    std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
+    return ok ? 1 : 0;
+}
 
 /* KeyframeSelection (keyframe_selection.cpp:46-126, 139-310): the reference's class on caller data */
 double ref_blur_score(const uint8_t* image, int32_t w, int32_t h, int32_t channels) {

@@ -81,3 +81,28 @@ def align_by_key(out, ref, max_frac=2e-4):
     ref = {k: (v[mr] if getattr(v, "shape", ())[:1] == mr.shape else v) for k, v in ref.items()}
     assert np.array_equal(out["keys"], ref["keys"])                       # same relative visit order
     return out, ref
+
+
+def axis_camera_dataset(root, seed=12, radius_vox=10, width=96, height=72):
+    """A dataset folder in the reference's layout (rgbd/frame-XXXXXX.{color.png,depth.png,pose.txt} + the two intrinsics files) of the synthetic sphere seen by
+    six cameras ON THE COORDINATE AXES: their rotations are signed permutations, so a 4x4 pose inverse is exact whatever its operation order (Eigen's
+    is unpinned) and fusion results can be compared bit for bit between implementations.  Returns (folder, voxel_size, number of frames)."""
+    import os
+    import numpy as np
+    from PIL import Image
+    sc = synthetic.make_scene(radius_vox=radius_vox, K=1, width=width, height=height, levels=1, seed=seed)
+    scene, center, intr = sc["scene"], sc["center"], sc["intr"]
+    folder = os.path.join(str(root), "rgbd"); os.makedirs(folder); os.makedirs(os.path.join(str(root), "fusion"), exist_ok=True)
+    K4 = np.eye(4); K4[0, 0], K4[1, 1], K4[0, 2], K4[1, 2] = intr
+    np.savetxt(os.path.join(folder, "colorIntrinsics.txt"), K4); np.savetxt(os.path.join(folder, "depthIntrinsics.txt"), K4)
+    rng = np.random.default_rng(seed); dist = 4.0 * radius_vox * float(sc["voxel_size"]); n = 0
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            d = np.zeros(3); d[axis] = sign; eye = center + dist * d
+            Rwc = np.round(synthetic.aa_to_rotmat(synthetic.look_at_pose(eye, center)[:3]))                       # signed permutation
+            lum, depth, bgr = synthetic.render_frame(scene, np.concatenate([synthetic.rotmat_to_aa(Rwc), -Rwc @ eye]), intr, width, height, 0.0, rng)
+            T = np.eye(4); T[:3, :3] = Rwc.T; T[:3, 3] = eye
+            Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(os.path.join(folder, f"frame-{n:06d}.color.png"))
+            Image.fromarray(np.round(depth * 1000.0).astype(np.uint16)).save(os.path.join(folder, f"frame-{n:06d}.depth.png"))
+            np.savetxt(os.path.join(folder, f"frame-{n:06d}.pose.txt"), T); n += 1
+    return folder, float(sc["voxel_size"]), n

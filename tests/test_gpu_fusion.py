@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import helpers  # noqa: E402
 
 
 def _frames(seed=9, K=6, radius=14, w=128, h=96, noise=0.0):
@@ -132,6 +134,33 @@ def test_app_fusion_then_app_intrinsic3d(oracle, tmp_path):
     r = subprocess.run([os.path.join(ROOT, "apps", "app_intrinsic3d"), "-s", s_yml, "-i", i_yml], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "intrinsic3d" / "mesh_g0_p0_albedo.ply").stat().st_size > 10000 and (tmp_path / "intrinsic3d" / "poses_g0_p0.txt").exists()
+
+
+def test_app_fusion_equals_the_reference_application(tmp_path):
+    """apps/app_fusion on a dataset folder against the reference's own AppFusion::fuseSDF (apps/src/app_fusion.cpp:107-200, compiled into oracle/_ref over its
+    own SensorI3d / KeyframeSelection / SparseVoxelGrid / MarchingCubes; PNG decoding by Pillow): the .tsdf — header and every record, in file order — and
+    the mesh file, byte for byte.  Cameras on the coordinate axes (exact pose inverses), with a keyframe file that drops two of the six frames."""
+    import subprocess
+    from intrinsic3d_amd import binding as B
+    from oracle import ref_py
+    if not ref_py.available():
+        pytest.skip("oracle/_ref/libref_i3d.so not built")
+    folder, vs, n = helpers.axis_camera_dataset(tmp_path)
+    keep = [True, False, True, True, False, True]
+    B.keyframes_save(str(tmp_path / "fusion" / "keyframes.txt"), 1, np.ones(n), keep)
+    (tmp_path / "sensor.yml").write_text('%YAML:1.0\n\n# rgbd sensor config\ndataset: "./rgbd/"\nmax_frames: "0"\nmin_depth: "0.05"\nmax_depth: "10.0"\n')
+    (tmp_path / "fusion.yml").write_text('%YAML:1.0\n\n# sdf fusion config\nkeyframes: "./fusion/keyframes.txt"\n' + f'voxel_size: "{vs:g}"\ndiscont_window_size: "2"\n'
+                                         + "".join(f'clip_{a}: "0.0"\n' for a in ("x0", "x1", "y0", "y1", "z0", "z1")) + 'output_mesh: "./fusion/mesh.ply"\noutput_sdf: "./fusion/volume.tsdf"\n')
+    r = subprocess.run([os.path.join(ROOT, "apps", "app_fusion"), "-s", str(tmp_path / "sensor.yml"), "-f", str(tmp_path / "fusion.yml")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cfg = {"keyframes": str(tmp_path / "fusion" / "keyframes.txt"), "voxel_size": f"{vs:g}", "clip_x0": 0, "clip_x1": 0, "clip_y0": 0, "clip_y1": 0, "clip_z0": 0, "clip_z1": 0,
+           "discont_window_size": 2, "output_sdf": str(tmp_path / "fusion" / "ref.tsdf"), "output_mesh": str(tmp_path / "fusion" / "ref.ply")}
+    assert ref_py.app_fusion(folder, cfg, 0, 0.05, 10.0)
+    a = np.frombuffer(open(tmp_path / "fusion" / "volume.tsdf", "rb").read(), np.uint8); b = np.frombuffer(open(tmp_path / "fusion" / "ref.tsdf", "rb").read(), np.uint8)
+    nrec = (b.size - 24) // 24
+    assert a.size == b.size and nrec > 2000 and np.array_equal(a[:24], b[:24])
+    assert np.array_equal(a[24:].reshape(nrec, 24)[:, :23], b[24:].reshape(nrec, 24)[:, :23])          # byte 23 of a record is the struct's padding
+    assert open(tmp_path / "fusion" / "mesh.ply", "rb").read() == open(tmp_path / "fusion" / "ref.ply", "rb").read()
 
 
 def test_device_fusion_matches_committed_golden():

@@ -469,3 +469,36 @@ def test_dataset_folder_sensor_equals_the_reference_classes(R, tmp_path):
     a.close(); b.close()
     f5 = tmp_path / "empty"; shutil.copytree(folder, f5); open(f5 / "frame-000001.color.png", "wb").close()
     assert compare(f5) == (6, 1)                                        # so does an EMPTY file (loadFile reports size 0 as failure: the `continue` for empty buffers is never reached)
+
+
+def test_fusion_application_equals_the_reference_code(oracle, R, tmp_path):
+    """AppFusion::fuseSDF (apps/src/app_fusion.cpp:107-200) of the reference — keyframe filter, erosion, normals, integrate, correctSDF, clearInvalidVoxels,
+    the .tsdf and the mesh — run on a dataset folder through its own SensorI3d, against the oracle's fusion of the same decoded frames (which the GPU
+    suite holds apps/app_fusion to, byte for byte): records in file order bit-exact, with and without a keyframe file that drops frames.  Six cameras on
+    the coordinate axes: their rotations are signed permutations, so the 4x4 pose inverse is exact whatever its operation order (Eigen's is unpinned)."""
+    import pathlib
+    from intrinsic3d_amd import binding as B
+    from oracle import ref_py
+    folder, vs, n = helpers.axis_camera_dataset(tmp_path); folder = pathlib.Path(folder)
+    counts = []
+    for use_kf in (False, True):
+        kf_file = ""; keep = [True] * n
+        if use_kf:
+            keep = [True, False, True, True, False, True]; kf_file = str(tmp_path / "fusion" / "keyframes.txt")
+            assert ref_py.keyframes_save(kf_file, 1, np.ones(n), keep)
+        out_sdf = tmp_path / "fusion" / f"ref_{int(use_kf)}.tsdf"; out_ply = tmp_path / "fusion" / f"ref_{int(use_kf)}.ply"
+        cfg = {"keyframes": kf_file, "voxel_size": repr(vs), "clip_x0": 0, "clip_x1": 0, "clip_y0": 0, "clip_y1": 0, "clip_z0": 0, "clip_z1": 0,
+               "discont_window_size": 2, "output_sdf": str(out_sdf), "output_mesh": str(out_ply)}
+        assert ref_py.app_fusion(folder, cfg, 0, 0.05, 10.0)
+        vol = B.tsdf_read(out_sdf)
+        s = B.Sensor(folder, 0, 0.05, 10.0)                             # (held to the reference's SensorI3d by test_dataset_folder_sensor_...)
+        o = oracle.Fusion(np.float32(vs), 0.05, 10.0, np.zeros(6, np.float32))
+        for i in range(s.num_frames):
+            if keep[i]:
+                o.integrate(s.depth(i), s.depth_intrinsics, s.color(i), s.color_intrinsics, s.pose(i), 2)
+        o.finish(10); ref = o.export(); s.close()
+        for k in ("keys", "sdf", "weight", "color"):
+            assert np.array_equal(vol[k], ref[k]), (use_kf, k)
+        counts.append(len(ref["sdf"]))
+        assert open(out_ply, "rb").read(3) == b"ply" and out_ply.stat().st_size > 10000
+    assert counts[0] > 3000 and counts[1] > 2000 and counts[0] != counts[1]
