@@ -90,8 +90,13 @@ int main(int argc, char* argv[]) {
     if (!mesh_file.empty() && count > 0) {
         std::vector<int32_t> keys(3 * count); std::vector<float> sdf(count), weight(count); std::vector<uint8_t> color(3 * count);
         i3d_fusion_get(vol, keys.data(), sdf.data(), weight.data(), color.data());
+        // MarchingCubes<Voxel>::extractSurface(*grid) walks the FUSION grid itself (app_fusion.cpp:186-193): its visit order is the record order of the
+        // volume — not the order a load + convert of the saved file would give (what i3d_set_grid_from_tsdf_records restates for the refinement app)
+        std::vector<double> sdf_d(sdf.begin(), sdf.end()), albedo(count, 0.0);
+        i3d_grid_view gv; gv.num_voxels = (int64_t)count; gv.voxel_size = voxel_size; gv.truncation = voxel_size * 5.0f; gv.keys = keys.data();
+        gv.sdf = sdf_d.data(); gv.sdf_refined = sdf_d.data(); gv.albedo = albedo.data(); gv.weight = weight.data(); gv.color = color.data();
         i3d_context* ctx = nullptr;
-        if (i3d_create(device, &ctx) != I3D_OK || i3d_set_grid_from_tsdf_records(ctx, voxel_size, (int64_t)count, keys.data(), sdf.data(), weight.data(), color.data()) != I3D_OK)
+        if (i3d_create(device, &ctx) != I3D_OK || i3d_set_grid(ctx, &gv) != I3D_OK)
             std::fprintf(stderr, "Mesh could not be generated!\n");
         else if (i3d_export_mesh_ply(ctx, mesh_file.c_str(), 0, 0, 0) != I3D_OK) std::fprintf(stderr, "Mesh could not be saved!\n");
         if (ctx) i3d_destroy(ctx);
