@@ -67,6 +67,10 @@ CHUNKS = [
     ("camera_load_save",     "src/camera.cpp", 202, 274, "bool Camera::load", "}"),
     ("settings_class",       "include/nv/settings.h", 48, 74, "class Settings", "};"),
     ("settings_impl",        "src/settings.cpp", 41, 138, "Settings::Settings()", "}"),
+    ("kfs_draw",             "src/keyframe_selection.cpp", 129, 136, "void KeyframeSelection::drawScore", "}"),
+    ("app_keyframes_class",  "../apps/include/nv/app_keyframes.h", 46, 58, "class AppKeyframes", "};"),
+    ("app_keyframes_ctor",   "../apps/src/app_keyframes.cpp", 46, 55, "AppKeyframes::AppKeyframes() :", "}"),
+    ("app_keyframes_select", "../apps/src/app_keyframes.cpp", 101, 144, "bool AppKeyframes::selectKeyframes", "}"),
     ("app_fusion_class",     "../apps/include/nv/app_fusion.h", 46, 58, "class AppFusion", "};"),
     ("app_fusion_ctor",      "../apps/src/app_fusion.cpp", 52, 61, "AppFusion::AppFusion() :", "}"),
     ("app_fusion_fuse",      "../apps/src/app_fusion.cpp", 107, 200, "bool AppFusion::fuseSDF", "}"),

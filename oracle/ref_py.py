@@ -286,3 +286,11 @@ def app_fusion(folder, cfg, max_frames=0, min_depth=0.0, max_depth=0.0):
     ks = [str(k).encode() for k in cfg]; vs = [str(v).encode() for v in cfg.values()]
     K = (C.c_char_p * len(ks))(*ks); V = (C.c_char_p * len(vs))(*vs)
     return L.ref_app_fusion(str(folder).encode(), C.c_int32(max_frames), C.c_float(min_depth), C.c_float(max_depth), C.c_int32(len(ks)), K, V) == 1
+
+
+def app_keyframes(folder, cfg, max_frames=0, min_depth=0.0, max_depth=0.0):
+    """AppKeyframes::selectKeyframes of the reference on a dataset folder; cfg: dict for nv::Settings (filename, window_size, show_keyframes)"""
+    L = C.CDLL(LIB_PATH); _install_pillow_decoder(L)
+    ks = [str(k).encode() for k in cfg]; vs = [str(v).encode() for v in cfg.values()]
+    K = (C.c_char_p * len(ks))(*ks); V = (C.c_char_p * len(vs))(*vs)
+    return L.ref_app_keyframes(str(folder).encode(), C.c_int32(max_frames), C.c_float(min_depth), C.c_float(max_depth), C.c_int32(len(ks)), K, V) == 1

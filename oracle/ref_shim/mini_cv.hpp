@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #define CV_8UC1 0
@@ -109,6 +110,14 @@ inline Mat imdecode(const Mat& buf, int /*flags*/) {
     if (!imdecode_hook()(buf.data, (size_t)buf.cols, &r, &c, &t, nullptr) || r <= 0 || c <= 0) return m;
     m.create(r, c, t); imdecode_hook()(buf.data, (size_t)buf.cols, &r, &c, &t, m.data); return m;
 }
+// interactive display / drawing of AppKeyframes' `show_keyframes` branch and KeyframeSelection::drawScore: never run by the harness, present so that the
+// reference bodies compile unchanged
+struct Point { int x, y; Point(int a = 0, int b = 0) : x(a), y(b) {} };
+enum { FONT_HERSHEY_COMPLEX = 3 };
+inline void putText(Mat&, const std::string&, Point, int, double, Scalar, int = 1) {}
+inline void imshow(const std::string&, const Mat&) {}
+inline int waitKey(int = 0) { return -1; }
+inline void destroyWindow(const std::string&) {}
 inline Scalar sum(const Mat& m) { double s = 0.0; for (size_t i = 0; i < (size_t)m.rows * m.cols; ++i) s += (double)reinterpret_cast<const float*>(m.data)[i]; return Scalar(s); }
 
 inline int64_t getTickCount() { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

@@ -159,6 +159,7 @@ public:
 #include "gen/kfs_class.inc"
 #include "gen/kfs_impl_a.inc"
 #include "gen/kfs_impl_b.inc"
+#include "gen/kfs_draw.inc"
 #include "gen/i3d_class.inc"
 #include "gen/i3d_callback_dtor.inc"
 #include "gen/i3d_ctor.inc"
@@ -189,6 +190,9 @@ void removeUnusedVertices(Mesh* mesh);               // (declared in the referen
 #include "gen/app_fusion_class.inc"
 #include "gen/app_fusion_ctor.inc"
 #include "gen/app_fusion_fuse.inc"
+#include "gen/app_keyframes_class.inc"
+#include "gen/app_keyframes_ctor.inc"
+#include "gen/app_keyframes_select.inc"
 
 }  // namespace nv
 #undef private
@@ -738,6 +742,18 @@ int32_t ref_app_fusion(const char* folder, int32_t max_frames, float depth_min, 
         AppFusion app; app.sensor_ = s;              // (the destructor deletes the sensor)
         ok = app.fuseSDF(cfg);
     } else delete s;
+    std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
+    return ok ? 1 : 0;
+}
+
+/* AppKeyframes::selectKeyframes (apps/src/app_keyframes.cpp:101-144) on a dataset folder: blur score of every frame, window selection, keyframes.txt */
+int32_t ref_app_keyframes(const char* folder, int32_t max_frames, float depth_min, float depth_max, int32_t n, const char* const* keys, const char* const* values) {
+    SensorI3d* s = new SensorI3d; s->setNumFramesMax(max_frames); s->setDepthMin(depth_min); s->setDepthMax(depth_max);
+    const bool quiet = std::getenv("I3D_REF_VERBOSE") == nullptr;
+    std::streambuf* o1 = std::cout.rdbuf(); std::streambuf* o2 = std::cerr.rdbuf();
+    if (quiet) { std::cout.rdbuf(nullptr); std::cerr.rdbuf(nullptr); }
+    bool ok = s->init(folder);
+    if (ok) { Settings cfg; for (int i = 0; i < n; ++i) cfg.set<std::string>(keys[i], values[i]); AppKeyframes app; app.sensor_ = s; ok = app.selectKeyframes(cfg); } else delete s;
     std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
     return ok ? 1 : 0;
 }

@@ -502,3 +502,34 @@ def test_fusion_application_equals_the_reference_code(oracle, R, tmp_path):
         counts.append(len(ref["sdf"]))
         assert open(out_ply, "rb").read(3) == b"ply" and out_ply.stat().st_size > 10000
     assert counts[0] > 3000 and counts[1] > 2000 and counts[0] != counts[1]
+
+
+def test_keyframe_application_equals_the_reference_code(R, tmp_path):
+    """apps/app_keyframes (host only) against the reference's AppKeyframes::selectKeyframes (apps/src/app_keyframes.cpp:101-144: the blur score of EVERY frame
+    of the sensor, window selection, keyframes.txt) on the same dataset folder: the file, byte for byte."""
+    import subprocess
+    from PIL import Image, ImageFilter
+    from oracle import ref_py
+    exe = os.path.join(ROOT, "apps", "app_keyframes")
+    if not os.path.exists(exe):
+        pytest.skip("apps/app_keyframes has not been built")
+    rng = np.random.default_rng(21); folder = tmp_path / "rgbd"; folder.mkdir(); (tmp_path / "fusion").mkdir()
+    np.savetxt(folder / "colorIntrinsics.txt", np.eye(4)); np.savetxt(folder / "depthIntrinsics.txt", np.eye(4))
+    yy, xx = np.mgrid[0:60, 0:80]
+    for i in range(13):
+        base = (127 + 90 * np.sin(xx / (2.0 + 0.3 * i)) * np.cos(yy / 3.0))[..., None] + rng.normal(0, 12, (60, 80, 3))
+        im = Image.fromarray(np.clip(base, 0, 255).astype(np.uint8))
+        if i % 3 == 1:
+            im = im.filter(ImageFilter.GaussianBlur(1.0 + 0.2 * i))                 # some frames blurred: they must lose their window
+        im.save(folder / f"frame-{i:06d}.color.png")
+        Image.fromarray(rng.integers(500, 3000, (30, 40)).astype(np.uint16)).save(folder / f"frame-{i:06d}.depth.png")
+        np.savetxt(folder / f"frame-{i:06d}.pose.txt", np.eye(4))
+    (tmp_path / "sensor.yml").write_text('%YAML:1.0\n\ndataset: "./rgbd/"\nmax_frames: "0"\nmin_depth: "0.1"\nmax_depth: "10.0"\n')
+    for win in (5, 1, 13):
+        (tmp_path / "keyframes.yml").write_text(f'%YAML:1.0\n\nwindow_size: "{win}"\nfilename: "./fusion/keyframes.txt"\nshow_keyframes: "0"\n')
+        r = subprocess.run([exe, "-s", str(tmp_path / "sensor.yml"), "-k", str(tmp_path / "keyframes.yml")], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        ours = open(tmp_path / "fusion" / "keyframes.txt").read()
+        assert ref_py.app_keyframes(folder, {"filename": str(tmp_path / "fusion" / "ref.txt"), "window_size": win, "show_keyframes": 0}, 0, 0.1, 10.0)
+        assert ours == open(tmp_path / "fusion" / "ref.txt").read(), win
+        assert len(ours.splitlines()) == 14 and ours.splitlines()[0] == str(win)
