@@ -84,3 +84,20 @@ def test_bench_never_runs_fewer_ranks_than_asked_for():
         pytest.skip("this box can run two ranks")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--voxels", "1e5"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2 and "refusing to run fewer ranks" in r.stderr and r.stdout.strip() == ""
+
+
+def test_committed_counter_files_attach_to_the_bench_line():
+    """bench.py takes roofline.traffic and roofline_build.valu_frac from the committed PMC / SQ passes when their kernel tag and workload match the run's:
+    the files under profiles/ must match the current tag and the default workload, or the driver's bench line silently carries nulls."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
+    assert d["kernel_tag"] == bench.KERNEL_TAG
+    rows, active = d["config"]["rows"]["Eg"], d["config"]["active_voxels"]
+    for kernel in ("eg_pass", "build"):
+        t = bench.pmc_traffic(kernel, rows, active)
+        assert t is not None and t[0] > 1e9 and t[1].startswith("r03_"), kernel
+        s = bench.sq_valu(kernel, rows)
+        assert s is not None and s["valu"] > 1e7 and s["source"].startswith("r03_"), kernel
+    assert abs(bench.pmc_traffic("eg_pass", rows, active)[0] / (4.0 * (29 * rows + 7 * d["config"]["rows"]["Er"] + d["config"]["rows"]["Es"] + 2 * d["config"]["rows"]["Ea"])) - 1.09) < 0.03
