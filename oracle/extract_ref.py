@@ -124,6 +124,8 @@ CHUNKS = [
     # --- the level schedule itself: Intrinsic3D::refine / prepare* / finish* / recomputeColors (init() is ours: it needs Sensor + OpenCV)
     ("i3d_class",            "include/nv/refinement/intrinsic3d.h", 59, 155, "class Intrinsic3D", "};"),
     ("i3d_callback_dtor",    "src/refinement/intrinsic3d.cpp", 53, 55, "Intrinsic3D::RefinementCallback::~RefinementCallback", "}"),
+    ("i3d_cfg_load",         "src/refinement/intrinsic3d.cpp", 58, 80, "void Intrinsic3D::Config::load", "}"),
+    ("opt_cfg_load",         "src/refinement/optimizer.cpp", 52, 72, "void Optimizer::Config::load", "}"),
     ("i3d_ctor",             "src/refinement/intrinsic3d.cpp", 98, 148, "Intrinsic3D::Intrinsic3D(Config cfg", "}"),
     ("i3d_refine",           "src/refinement/intrinsic3d.cpp", 206, 409, "bool Intrinsic3D::refine", "}"),
 ]

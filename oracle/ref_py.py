@@ -294,3 +294,14 @@ def app_keyframes(folder, cfg, max_frames=0, min_depth=0.0, max_depth=0.0):
     ks = [str(k).encode() for k in cfg]; vs = [str(v).encode() for v in cfg.values()]
     K = (C.c_char_p * len(ks))(*ks); V = (C.c_char_p * len(vs))(*vs)
     return L.ref_app_keyframes(str(folder).encode(), C.c_int32(max_frames), C.c_float(min_depth), C.c_float(max_depth), C.c_int32(len(ks)), K, V) == 1
+
+
+def config_load(cfg):
+    """Intrinsic3D::Config::load + Optimizer::Config::load of the reference from a dict of strings -> dict of the 20 loaded values"""
+    L = _raw(); ks = [str(k).encode() for k in cfg]; vs = [str(v).encode() for v in cfg.values()]
+    K = (C.c_char_p * len(ks))(*ks); V = (C.c_char_p * len(vs))(*vs); out = np.zeros(20)
+    L.ref_config_load(C.c_int32(len(ks)), K, V, _p(out))
+    names = ["num_grid_levels", "num_rgbd_levels", "thin_shell_factor", "thin_shell_factor_final", "clear_distant_voxels", "occlusion_distance", "num_observations",
+             "subvolume_size_sh", "sh_lambda_reg", "iterations", "lm_steps", "lambda_g", "lambda_r0", "lambda_r1", "lambda_s0", "lambda_s1", "lambda_a",
+             "fix_poses", "fix_intrinsics", "fix_distortion"]
+    return dict(zip(names, out.tolist()))

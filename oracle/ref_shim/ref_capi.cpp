@@ -162,6 +162,8 @@ public:
 #include "gen/kfs_draw.inc"
 #include "gen/i3d_class.inc"
 #include "gen/i3d_callback_dtor.inc"
+#include "gen/i3d_cfg_load.inc"
+#include "gen/opt_cfg_load.inc"
 #include "gen/i3d_ctor.inc"
 #include "gen/i3d_refine.inc"
 // shim for Intrinsic3D::init (intrinsic3d.cpp:151-203): its keyframe loop needs Sensor + cv::pyrDown / cvtColor; image_model_ is
@@ -744,6 +746,20 @@ int32_t ref_app_fusion(const char* folder, int32_t max_frames, float depth_min, 
     } else delete s;
     std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
     return ok ? 1 : 0;
+}
+
+/* Intrinsic3D::Config::load + Optimizer::Config::load (intrinsic3d.cpp:58-80, optimizer.cpp:52-72) from (key, value) strings.
+ * out[20]: num_grid_levels, num_rgbd_levels, thres_shell_factor, thres_shell_factor_final, clear_distant_voxels, occlusions_distance, num_observations,
+ * subvolume_size_sh, sh_est_lambda_reg | iterations, lm_steps, lambda_g, lambda_r0, lambda_r1, lambda_s0, lambda_s1, lambda_a, fix_poses, fix_intrinsics, fix_distortion */
+void ref_config_load(int32_t n, const char* const* keys, const char* const* values, double* out) {
+    Settings cfg; for (int i = 0; i < n; ++i) cfg.set<std::string>(keys[i], values[i]);
+    std::streambuf* o2 = std::cerr.rdbuf(nullptr);                  // (missing keys warn on stderr)
+    Intrinsic3D::Config a; a.load(cfg); Optimizer::Config b; b.load(cfg);
+    std::cerr.rdbuf(o2);
+    const double v[20] = {(double)a.num_grid_levels, (double)a.num_rgbd_levels, a.thres_shell_factor, a.thres_shell_factor_final, (double)a.clear_distant_voxels, (double)a.occlusions_distance,
+                          (double)a.num_observations, (double)a.subvolume_size_sh, a.sh_est_lambda_reg,
+                          (double)b.iterations, (double)b.lm_steps, b.lambda_g, b.lambda_r0, b.lambda_r1, b.lambda_s0, b.lambda_s1, b.lambda_a, (double)b.fix_poses, (double)b.fix_intrinsics, (double)b.fix_distortion};
+    for (int i = 0; i < 20; ++i) out[i] = v[i];
 }
 
 /* AppKeyframes::selectKeyframes (apps/src/app_keyframes.cpp:101-144) on a dataset folder: blur score of every frame, window selection, keyframes.txt */

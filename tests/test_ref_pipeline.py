@@ -533,3 +533,28 @@ def test_keyframe_application_equals_the_reference_code(R, tmp_path):
         assert ref_py.app_keyframes(folder, {"filename": str(tmp_path / "fusion" / "ref.txt"), "window_size": win, "show_keyframes": 0}, 0, 0.1, 10.0)
         assert ours == open(tmp_path / "fusion" / "ref.txt").read(), win
         assert len(ours.splitlines()) == 14 and ours.splitlines()[0] == str(win)
+
+
+def test_yaml_configuration_equals_the_reference_loaders(R, tmp_path):
+    """Intrinsic3D::Config::load + Optimizer::Config::load (intrinsic3d.cpp:58-80, optimizer.cpp:52-72, over the reference's Settings) vs i3d_config_load_yaml:
+    every key of the shipped data/intrinsic3d.yml (incl. its `subvolume_sh_lamda_reg` spelling) lands in the same field with the same value, for the shipped
+    values and for a second set that exercises fractions, exponents, negative and boolean entries."""
+    from intrinsic3d_amd import binding as B
+    from oracle import ref_py
+    shipped = {"num_grid_levels": "3", "num_rgbd_levels": "3", "thin_shell_factor": "2.0", "thin_shell_factor_final": "1.0", "clear_distant_voxels": "1",
+               "occlusion_distance": "0.02", "num_observations": "5", "subvolume_size_sh": "0.2", "subvolume_sh_lamda_reg": "10.0",
+               "iterations": "10", "lm_steps": "50", "lambda_g": "0.2", "lambda_r0": "80.0", "lambda_r1": "10.0", "lambda_s0": "120.0", "lambda_s1": "10.0", "lambda_a": "0.1",
+               "fix_poses": "0", "fix_intrinsics": "0", "fix_distortion": "0"}
+    other = dict(shipped, num_grid_levels="1", num_rgbd_levels="2", thin_shell_factor="2.5", thin_shell_factor_final="0.75", clear_distant_voxels="0", occlusion_distance="1e-2",
+                 num_observations="0", subvolume_size_sh="0.035", subvolume_sh_lamda_reg="1.5e1", iterations="3", lm_steps="7", lambda_g="1.25", lambda_r0="2e1", lambda_r1="160", lambda_a="-1.0",
+                 fix_poses="1", fix_intrinsics="1", fix_distortion="1")
+    for i, cfg in enumerate((shipped, other)):
+        yml = tmp_path / f"intrinsic3d_{i}.yml"
+        yml.write_text("%YAML:1.0\n\n# Intrinsic3D config\n" + "".join(f'# comment for {k}\n{k}: "{v}"\n' for k, v in cfg.items()) + 'keyframes: "./fusion/keyframes.txt"\noutput_mesh_prefix: "./intrinsic3d/mesh"\n')
+        rc, oc = B.load_yaml_config(yml)
+        ref = ref_py.config_load(cfg)
+        ours = {k: float(getattr(rc, k)) for k, _ in B.RefineConfig._fields_}
+        ours.update({k: float(getattr(oc, k)) for k in ("iterations", "lm_steps", "lambda_g", "lambda_r0", "lambda_r1", "lambda_s0", "lambda_s1", "lambda_a", "fix_poses", "fix_intrinsics", "fix_distortion")})
+        for k, v in ref.items():
+            assert ours[k] == v, (i, k, ours[k], v)
+        assert float(oc.occlusion_distance) == ref["occlusion_distance"] and float(oc.num_observations) == ref["num_observations"]
