@@ -90,6 +90,7 @@ CHUNKS = [
     ("algorithms_impl",      "src/sdf/algorithms.cpp", 47, 458, "SparseVoxelGrid<VoxelSBR>* convert", "}"),
     ("color_util_decl",      "include/nv/color_util.h", 46, 57, "float intensity(unsigned char r", "Vec3b randomColor();"),
     ("color_intensity",      "src/color_util.cpp", 41, 58, "float intensity(unsigned char r", "}"),
+    ("color_scalar",         "src/color_util.cpp", 70, 80, "template <typename T>", "template Vec3b scalarToColor(const double val, const double scale);"),
     ("color_random",         "src/color_util.cpp", 83, 114, "Vec3f checkRange", "}"),
     ("processing_decl",      "include/nv/rgbd/processing.h", 50, 62, "cv::Mat computeVertexMap", "Vec3b interpolateRGB"),
     ("processing_impl",      "src/rgbd/processing.cpp", 49, 301, "cv::Mat computeVertexMap", "}"),

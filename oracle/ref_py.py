@@ -305,3 +305,9 @@ def config_load(cfg):
              "subvolume_size_sh", "sh_lambda_reg", "iterations", "lm_steps", "lambda_g", "lambda_r0", "lambda_r1", "lambda_s0", "lambda_s1", "lambda_a",
              "fix_poses", "fix_intrinsics", "fix_distortion"]
     return dict(zip(names, out.tolist()))
+
+
+def albedo_colors(albedo):
+    """scalarToColor(albedo, 255.0) per voxel: the grey SDFVisualization::applyColorAlbedo paints before the "albedo" mesh is extracted"""
+    a = np.ascontiguousarray(albedo, np.float64); out = np.zeros((len(a), 3), np.uint8)
+    _raw().ref_albedo_colors(C.c_int64(len(a)), _p(a), _p(out)); return out

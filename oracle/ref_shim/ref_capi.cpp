@@ -84,6 +84,7 @@ namespace SDFOperators {
 #include "gen/operators_sdf_weight.inc"
 }  // namespace SDFOperators
 #include "gen/color_intensity.inc"
+#include "gen/color_scalar.inc"
 #include "gen/color_random.inc"
 #include "gen/processing_impl.inc"
 #include "gen/pyramid_class.inc"
@@ -343,6 +344,8 @@ void* ref_mesh_from_arrays(int64_t nv, const float* verts, const uint8_t* colors
 }
 void ref_mesh_remove_loose(void* mesh) { if (mesh) MeshUtil::removeLooseComponents((Mesh*)mesh); }
 int32_t ref_mesh_has_colors(void* mesh) { return (mesh && !((Mesh*)mesh)->colors.empty()) ? 1 : 0; }
+/* SDFVisualization::applyColorAlbedo's colour of a voxel: scalarToColor(albedo, 255.0) (color_util.cpp:70-80) */
+void ref_albedo_colors(int64_t n, const double* albedo, uint8_t* rgb) { for (int64_t i = 0; i < n; ++i) { const Vec3b c = scalarToColor(albedo[i], 255.0); rgb[3 * i] = c[0]; rgb[3 * i + 1] = c[1]; rgb[3 * i + 2] = c[2]; } }
 int32_t ref_mesh_save(void* mesh, const char* path) { Mesh* m = (Mesh*)mesh; return (m && m->save(path)) ? 1 : 0; }
 void ref_mesh_free(void* mesh) { delete (Mesh*)mesh; }
 // the two tables, for the case-by-case check of the product's packed copy

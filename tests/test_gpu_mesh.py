@@ -184,3 +184,12 @@ def test_mesh_identical_to_the_oracle_and_the_reference_code(oracle, tmp_path):
             v2, c2, f2 = ctx.extract_mesh(use_refined_sdf=False, color_mode=0, largest_component_only=True)
         assert len(lf) < len(rf) and len(lv) < len(rv)
         assert v2.tobytes() == lv.tobytes() and c2.tobytes() == lc.tobytes() and f2.tobytes() == lf.tobytes()
+        # the "albedo" colour mode: SDFVisualization::applyColorAlbedo paints every voxel scalarToColor(albedo, 255) before the mesh is extracted
+        alb_of = lambda k: ((k[:, 0] * 7 + k[:, 1] * 13 + k[:, 2] * 29) % 131) / 100.0 - 0.1      # a function of the voxel; beyond [0, 1] on both sides: the clamp
+        acol = ref_py.albedo_colors(alb_of(g))
+        av, ac, af = ref_py.marching_cubes(vs, g[o1], sdf[o1].astype(np.float64), w[o1], acol[o1])
+        with binding.Context(0) as ctx:
+            ctx.set_grid(vs, a["keys"], a["sdf"], a["sdf"], alb_of(a["keys"]), a["weight"], a["color"])
+            v3, c3, f3 = ctx.extract_mesh(use_refined_sdf=False, color_mode=1, largest_component_only=False)
+        assert v3.tobytes() == av.tobytes() and f3.tobytes() == af.tobytes(), (len(v3), len(av), len(f3), len(af))
+        assert c3.tobytes() == ac.tobytes(), (int((c3 != ac).sum()), c3[(c3 != ac).any(1)][:4], ac[(c3 != ac).any(1)][:4])
