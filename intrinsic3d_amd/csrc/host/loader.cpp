@@ -220,7 +220,7 @@ void rot_to_angle_axis(const double* R /*row-major 3x3*/, double aa[3]) {
         t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t;
         q[3] = (R[3 * k + j] - R[3 * j + k]) * t; q[j] = (R[3 * j + i] + R[3 * i + j]) * t; q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
     }
-    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    double n = std::sqrt(q[0] * q[0] + (q[1] * q[1] + q[2] * q[2]));          // q.vec().norm(): Eigen's fixed-size reduction a0 + (a1 + a2)
     if (n < 2.220446049250313e-16) {                        // stableNorm of a tiny vector
         const double mx = std::fmax(std::fabs(q[0]), std::fmax(std::fabs(q[1]), std::fabs(q[2])));
         n = mx > 0.0 ? mx * std::sqrt((q[0] / mx) * (q[0] / mx) + (q[1] / mx) * (q[1] / mx) + (q[2] / mx) * (q[2] / mx)) : 0.0;

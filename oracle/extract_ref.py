@@ -96,7 +96,11 @@ CHUNKS = [
     ("processing_impl",      "src/rgbd/processing.cpp", 49, 301, "cv::Mat computeVertexMap", "}"),
     ("pyramid_class",        "include/nv/rgbd/pyramid.h", 47, 69, "class Pyramid", "};"),
     ("pyramid_ctor",         "src/rgbd/pyramid.cpp", 43, 45, "Pyramid::Pyramid()", "}"),
+    ("pyramid_ctor2",        "src/rgbd/pyramid.cpp", 48, 51, "Pyramid::Pyramid(int num_levels", "}"),
     ("pyramid_dtor",         "src/rgbd/pyramid.cpp", 54, 56, "Pyramid::~Pyramid()", "}"),
+    ("pyramid_create",       "src/rgbd/pyramid.cpp", 59, 79, "bool Pyramid::create", "}"),
+    ("pyramid_downsample",   "src/rgbd/pyramid.cpp", 108, 113, "cv::Mat Pyramid::downsample(const cv::Mat &img)", "}"),
+    ("pyramid_create_pyr",   "src/rgbd/pyramid.cpp", 144, 152, "std::vector<cv::Mat> Pyramid::createPyramid", "}"),
     ("pyramid_access",       "src/rgbd/pyramid.cpp", 81, 105, "cv::Mat Pyramid::color", "}"),
     ("pyramid_depth_down",   "src/rgbd/pyramid.cpp", 116, 141, "cv::Mat Pyramid::downsampleDepth", "}"),
     ("pyramid_depth_pyr",    "src/rgbd/pyramid.cpp", 155, 166, "std::vector<cv::Mat> Pyramid::createDepthPyramid", "}"),
@@ -127,6 +131,8 @@ CHUNKS = [
     ("i3d_callback_dtor",    "src/refinement/intrinsic3d.cpp", 53, 55, "Intrinsic3D::RefinementCallback::~RefinementCallback", "}"),
     ("i3d_cfg_load",         "src/refinement/intrinsic3d.cpp", 58, 80, "void Intrinsic3D::Config::load", "}"),
     ("opt_cfg_load",         "src/refinement/optimizer.cpp", 52, 72, "void Optimizer::Config::load", "}"),
+    ("math_pose_mat_to_vec", "src/math.cpp", 166, 179, "Vec6 poseMatToVecAA", "}"),
+    ("i3d_init",             "src/refinement/intrinsic3d.cpp", 151, 203, "bool Intrinsic3D::init()", "}"),
     ("i3d_ctor",             "src/refinement/intrinsic3d.cpp", 98, 148, "Intrinsic3D::Intrinsic3D(Config cfg", "}"),
     ("i3d_refine",           "src/refinement/intrinsic3d.cpp", 206, 409, "bool Intrinsic3D::refine", "}"),
 ]

@@ -311,3 +311,31 @@ def albedo_colors(albedo):
     """scalarToColor(albedo, 255.0) per voxel: the grey SDFVisualization::applyColorAlbedo paints before the "albedo" mesh is extracted"""
     a = np.ascontiguousarray(albedo, np.float64); out = np.zeros((len(a), 3), np.uint8)
     _raw().ref_albedo_colors(C.c_int64(len(a)), _p(a), _p(out)); return out
+
+
+class InitModel:
+    """Intrinsic3D::init of the reference on a dataset folder: keyframe ids, world-to-camera pose vectors, intrinsics, and the keyframe pyramids"""
+
+    def __init__(self, folder, is_keyframe, num_rgbd_levels, max_frames=0, min_depth=0.0, max_depth=0.0):
+        self.L = C.CDLL(LIB_PATH); _install_pillow_decoder(self.L)
+        self.L.ref_i3d_init.restype = C.c_void_p; self.L.ref_i3d_init_image.restype = C.c_int64
+        kf = np.ascontiguousarray(is_keyframe, np.uint8)
+        h = self.L.ref_i3d_init(str(folder).encode(), C.c_int32(max_frames), C.c_float(min_depth), C.c_float(max_depth), C.c_int64(len(kf)), _p(kf), C.c_int32(num_rgbd_levels))
+        if not h:
+            raise RuntimeError("SensorI3d::init failed")
+        self.h = C.c_void_p(h)
+        n = int(self.L.ref_i3d_init_count(self.h))
+        self.frame_ids = np.zeros(n, np.int32); self.poses = np.zeros((n, 6)); self.intrinsics = np.zeros(4); self.distortion = np.zeros(5)
+        self.L.ref_i3d_init_model(self.h, _p(self.frame_ids), _p(self.poses), _p(self.intrinsics), _p(self.distortion))
+
+    def image(self, k, level, kind):
+        """kind: 'lum' | 'depth' | 'bgr'"""
+        code = {"lum": 0, "depth": 1, "bgr": 2}[kind]; wh = np.zeros(2, np.int32)
+        if not self.L.ref_i3d_init_image(self.h, C.c_int32(k), C.c_int32(level), C.c_int32(code), _p(wh), None):
+            return None
+        out = np.zeros((wh[1], wh[0], 3), np.uint8) if code == 2 else np.zeros((wh[1], wh[0]), np.float32)
+        self.L.ref_i3d_init_image(self.h, C.c_int32(k), C.c_int32(level), C.c_int32(code), _p(wh), _p(out)); return out
+
+    def close(self):
+        if self.h:
+            self.L.ref_i3d_init_free(self.h); self.h = None

@@ -58,6 +58,11 @@ struct Mat {
     // dst = saturate_cast<float>(src * alpha): 8- / 16-bit 1-channel -> float with the scale applied in float (cv::Mat::convertTo, the only conversions the reference bodies use)
     void convertTo(Mat& dst, int type, double alpha = 1.0) const {
         if (empty()) { dst = Mat(); return; }
+        if (type_ == CV_8UC3 && type == CV_32FC3) {                  // colour image to float, channel by channel
+            Mat o3(rows, cols, CV_32FC3); const float a3 = (float)alpha;
+            for (size_t i = 0; i < (size_t)rows * cols * 3; ++i) reinterpret_cast<float*>(o3.data)[i] = (float)data[i] * a3;
+            dst = o3; return;
+        }
         Mat o(rows, cols, type); const float a = (float)alpha;
         for (size_t i = 0; i < (size_t)rows * cols; ++i) reinterpret_cast<float*>(o.data)[i] = (type_ == CV_16UC1 ? (float)reinterpret_cast<const uint16_t*>(data)[i] : (float)data[i]) * a;
         dst = o;
@@ -78,6 +83,11 @@ inline void transpose(const Mat& a, Mat& b) { Mat o(a.cols, a.rows, a.type()); f
 enum { COLOR_BGR2GRAY = 6 };
 // 8-bit BGR -> grey in OpenCV's 14-bit fixed point: (B 1868 + G 9617 + R 4899 + 2^13) >> 14
 inline void cvtColor(const Mat& src, Mat& dst, int /*code*/) {
+    if (src.type() == CV_32FC3) {                                    // float images: gray = 0.114 b + 0.587 g + 0.299 r in float
+        Mat of(src.rows, src.cols, CV_32FC1); const float* p = reinterpret_cast<const float*>(src.data);
+        for (size_t i = 0; i < (size_t)src.rows * src.cols; ++i) reinterpret_cast<float*>(of.data)[i] = (p[3 * i] * 0.114f + p[3 * i + 1] * 0.587f) + p[3 * i + 2] * 0.299f;
+        dst = of; return;
+    }
     Mat o(src.rows, src.cols, CV_8UC1);
     for (size_t i = 0; i < (size_t)src.rows * src.cols; ++i) o.data[i] = (unsigned char)((src.data[3 * i] * 1868 + src.data[3 * i + 1] * 9617 + src.data[3 * i + 2] * 4899 + (1 << 13)) >> 14);
     dst = o;
@@ -90,6 +100,32 @@ inline void filter2D(const Mat& src, Mat& dst, int /*ddepth*/, const Mat& k) {
         float s = 0.0f;
         for (int j = 0; j < k.rows; ++j) for (int i = 0; i < k.cols; ++i) s += k.at<float>(j, i) * src.at<float>(refl(y + j - ay, src.rows), refl(x + i - ax, src.cols));
         o.at<float>(y, x) = s;
+    }
+    dst = o;
+}
+// cv::pyrDown to (cols/2, rows/2): [1 4 6 4 1] x [1 4 6 4 1] / 256, BORDER_REFLECT_101, horizontal pass first.  Float images in float; 8-bit images in
+// integers with (sum + 128) >> 8.
+inline void pyrDown(const Mat& src, Mat& dst, Size sz) {
+    auto refl = [](int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i; return i; };
+    const int ow = sz.width, oh = sz.height, w = src.cols, h = src.rows;
+    if (src.type() == CV_32FC1) {
+        Mat o(oh, ow, CV_32FC1); const float* s = reinterpret_cast<const float*>(src.data);
+        for (int y = 0; y < oh; ++y) for (int x = 0; x < ow; ++x) {
+            float row[5];
+            for (int j = 0; j < 5; ++j) {
+                const float* line = s + (size_t)refl(2 * y - 2 + j, h) * w;
+                const float m2 = line[refl(2 * x - 2, w)], m1 = line[refl(2 * x - 1, w)], c0 = line[refl(2 * x, w)], p1 = line[refl(2 * x + 1, w)], p2 = line[refl(2 * x + 2, w)];
+                row[j] = ((c0 * 6.0f + (m1 + p1) * 4.0f) + m2) + p2;
+            }
+            o.at<float>(y, x) = (((row[2] * 6.0f + (row[1] + row[3]) * 4.0f) + row[0]) + row[4]) * (1.0f / 256.0f);
+        }
+        dst = o; return;
+    }
+    const int ch = src.channels(); Mat o(oh, ow, src.type());
+    for (int y = 0; y < oh; ++y) for (int x = 0; x < ow; ++x) for (int c = 0; c < ch; ++c) {
+        int acc = 0; const int wt[5] = {1, 4, 6, 4, 1};
+        for (int j = 0; j < 5; ++j) { const unsigned char* line = src.data + (size_t)refl(2 * y - 2 + j, h) * w * ch; int r = 0; for (int i = 0; i < 5; ++i) r += wt[i] * line[refl(2 * x - 2 + i, w) * ch + c]; acc += wt[j] * r; }
+        o.data[((size_t)y * ow + x) * ch + c] = (unsigned char)((acc + 128) >> 8);
     }
     dst = o;
 }

@@ -60,6 +60,7 @@ struct Matrix {
     static Matrix Ones() { return Constant(T(1)); }
     static Matrix Identity() { Matrix m = Zero(); for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
     void setZero() { for (int i = 0; i < R * C; ++i) d[i] = T(0); }
+    void setZero(int) { setZero(); }                    // (fixed-size: Eigen asserts the size matches)
     T& operator[](size_t i) { return d[i]; }
     const T& operator[](size_t i) const { return d[i]; }
     T& operator()(int r, int c) { return d[c * R + r]; }
@@ -106,6 +107,8 @@ struct Matrix {
     template <int BR, int BC> BlockRef<T, R, C, BR, BC> topLeftCorner() { return BlockRef<T, R, C, BR, BC>{*this, 0, 0}; }
     template <int BR, int BC> BlockRef<T, R, C, BR, BC> topRightCorner() { return BlockRef<T, R, C, BR, BC>{*this, 0, C - BC}; }
     template <int BR> Matrix<T, BR, C> topRows() const { Matrix<T, BR, C> o; for (int c = 0; c < C; ++c) for (int r = 0; r < BR; ++r) o(r, c) = (*this)(r, c); return o; }
+    template <int BR> BlockRef<T, R, C, BR, C> topRows() { return BlockRef<T, R, C, BR, C>{*this, 0, 0}; }
+    template <int BR> BlockRef<T, R, C, BR, C> bottomRows() { return BlockRef<T, R, C, BR, C>{*this, R - BR, 0}; }
     template <int BR> Matrix<T, BR, C> bottomRows() const { Matrix<T, BR, C> o; for (int c = 0; c < C; ++c) for (int r = 0; r < BR; ++r) o(r, c) = (*this)(R - BR + r, c); return o; }
     // run-time sized corners: the reference only asks for (3,3) and (3,1) of a 4x4
     // (a run-time sized block times a vector is Eigen's GEMV: every row accumulates its columns left to right)
@@ -139,51 +142,69 @@ typedef Matrix<float, 2, 2> Matrix2f;  typedef Matrix<float, 3, 3> Matrix3f;  ty
 typedef Matrix<int, 2, 2> Matrix2i;    typedef Matrix<int, 3, 3> Matrix3i;    typedef Matrix<int, 4, 4> Matrix4i;
 
 struct AngleAxisd {
-    double angle; Vector3d axis;
-    AngleAxisd(double a, const Vector3d& ax) : angle(a), axis(ax) {}
+    double angle_; Vector3d axis_;
+    AngleAxisd(double a, const Vector3d& ax) : angle_(a), axis_(ax) {}
+    // AngleAxis(rotation matrix) = AngleAxis(Quaternion(matrix)) (Geometry/AngleAxis.h: fromRotationMatrix, operator=(QuaternionBase))
+    template <class M3> explicit AngleAxisd(const M3& m);
+    double angle() const { return angle_; }
+    const Vector3d& axis() const { return axis_; }
     Matrix3d matrix() const {
         Matrix3d res;
-        const Vector3d sin_axis = std::sin(angle) * axis;
-        const double c = std::cos(angle);
-        const Vector3d cos1_axis = (1.0 - c) * axis;
+        const Vector3d sin_axis = std::sin(angle_) * axis_;
+        const double c = std::cos(angle_);
+        const Vector3d cos1_axis = (1.0 - c) * axis_;
         double tmp;
-        tmp = cos1_axis[0] * axis[1]; res(0, 1) = tmp - sin_axis[2]; res(1, 0) = tmp + sin_axis[2];
-        tmp = cos1_axis[0] * axis[2]; res(0, 2) = tmp + sin_axis[1]; res(2, 0) = tmp - sin_axis[1];
-        tmp = cos1_axis[1] * axis[2]; res(1, 2) = tmp - sin_axis[0]; res(2, 1) = tmp + sin_axis[0];
-        for (int i = 0; i < 3; ++i) res(i, i) = cos1_axis[i] * axis[i] + c;
+        tmp = cos1_axis[0] * axis_[1]; res(0, 1) = tmp - sin_axis[2]; res(1, 0) = tmp + sin_axis[2];
+        tmp = cos1_axis[0] * axis_[2]; res(0, 2) = tmp + sin_axis[1]; res(2, 0) = tmp - sin_axis[1];
+        tmp = cos1_axis[1] * axis_[2]; res(1, 2) = tmp - sin_axis[0]; res(2, 1) = tmp + sin_axis[0];
+        for (int i = 0; i < 3; ++i) res(i, i) = cos1_axis[i] * axis_[i] + c;
         return res;
     }
 };
 
 // Eigen::Quaternionf as Sensor::loadPoses / savePoses use it: from a rotation matrix (Geometry/Quaternion.h, quaternionbase_assign_impl<Other,3,3>: the
 // trace branch, else the largest diagonal element), from (w, x, y, z), and toRotationMatrix (the tx = 2x ... products of QuaternionBase::toRotationMatrix)
-struct Quaternionf {
-    float c[4];                                                    // x y z w (Eigen's coefficient order)
-    Quaternionf(float w, float x, float y, float z) { c[0] = x; c[1] = y; c[2] = z; c[3] = w; }
-    template <class M3> explicit Quaternionf(const M3& mm) {
-        Matrix3f m; for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) m(r, k) = mm(r, k);
-        float t = m(0, 0) + m(1, 1) + m(2, 2);
-        if (t > 0.0f) {
-            t = std::sqrt(t + 1.0f); c[3] = 0.5f * t; t = 0.5f / t;
+template <class S>
+struct QuaternionT {
+    S c[4];                                                        // x y z w (Eigen's coefficient order)
+    QuaternionT(S w, S x, S y, S z) { c[0] = x; c[1] = y; c[2] = z; c[3] = w; }
+    template <class M3> explicit QuaternionT(const M3& mm) {
+        Matrix<S, 3, 3> m; for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) m(r, k) = mm(r, k);
+        S t = m(0, 0) + m(1, 1) + m(2, 2);
+        if (t > S(0)) {
+            t = std::sqrt(t + S(1)); c[3] = S(0.5) * t; t = S(0.5) / t;
             c[0] = (m(2, 1) - m(1, 2)) * t; c[1] = (m(0, 2) - m(2, 0)) * t; c[2] = (m(1, 0) - m(0, 1)) * t;
         } else {
             int i = 0; if (m(1, 1) > m(0, 0)) i = 1; if (m(2, 2) > m(i, i)) i = 2;
             const int j = (i + 1) % 3, k = (j + 1) % 3;
-            t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0f); c[i] = 0.5f * t; t = 0.5f / t;
+            t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + S(1)); c[i] = S(0.5) * t; t = S(0.5) / t;
             c[3] = (m(k, j) - m(j, k)) * t; c[j] = (m(j, i) + m(i, j)) * t; c[k] = (m(k, i) + m(i, k)) * t;
         }
     }
-    float x() const { return c[0]; } float y() const { return c[1]; } float z() const { return c[2]; } float w() const { return c[3]; }
-    Matrix3f toRotationMatrix() const {
-        Matrix3f res;
-        const float tx = 2.0f * c[0], ty = 2.0f * c[1], tz = 2.0f * c[2];
-        const float twx = tx * c[3], twy = ty * c[3], twz = tz * c[3], txx = tx * c[0], txy = ty * c[0], txz = tz * c[0], tyy = ty * c[1], tyz = tz * c[1], tzz = tz * c[2];
-        res(0, 0) = 1.0f - (tyy + tzz); res(0, 1) = txy - twz; res(0, 2) = txz + twy;
-        res(1, 0) = txy + twz; res(1, 1) = 1.0f - (txx + tzz); res(1, 2) = tyz - twx;
-        res(2, 0) = txz - twy; res(2, 1) = tyz + twx; res(2, 2) = 1.0f - (txx + tyy);
+    S x() const { return c[0]; } S y() const { return c[1]; } S z() const { return c[2]; } S w() const { return c[3]; }
+    Matrix<S, 3, 3> toRotationMatrix() const {
+        Matrix<S, 3, 3> res;
+        const S tx = S(2) * c[0], ty = S(2) * c[1], tz = S(2) * c[2];
+        const S twx = tx * c[3], twy = ty * c[3], twz = tz * c[3], txx = tx * c[0], txy = ty * c[0], txz = tz * c[0], tyy = ty * c[1], tyz = tz * c[1], tzz = tz * c[2];
+        res(0, 0) = S(1) - (tyy + tzz); res(0, 1) = txy - twz; res(0, 2) = txz + twy;
+        res(1, 0) = txy + twz; res(1, 1) = S(1) - (txx + tzz); res(1, 2) = tyz - twx;
+        res(2, 0) = txz - twy; res(2, 1) = tyz + twx; res(2, 2) = S(1) - (txx + tyy);
         return res;
     }
 };
+typedef QuaternionT<float> Quaternionf;
+typedef QuaternionT<double> Quaterniond;
+
+template <class M3> AngleAxisd::AngleAxisd(const M3& m) {
+    const Quaterniond q(m);
+    double n = std::sqrt(q.x() * q.x() + (q.y() * q.y() + q.z() * q.z()));          // q.vec().norm(): fixed-size reduction a0 + (a1 + a2)
+    // (below epsilon Eigen recomputes with stableNorm(): the same value up to scaling against overflow, which cannot occur for a unit quaternion)
+    if (n != 0.0) {
+        angle_ = 2.0 * std::atan2(n, std::abs(q.w()));
+        if (q.w() < 0.0) n = -n;
+        axis_[0] = q.x() / n; axis_[1] = q.y() / n; axis_[2] = q.z() / n;
+    } else { angle_ = 0.0; axis_[0] = 1.0; axis_[1] = 0.0; axis_[2] = 0.0; }
+}
 
 template <class S>
 struct VectorX {                                    // dynamic column vector (VectorXd / VectorXf)

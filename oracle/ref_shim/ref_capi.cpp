@@ -73,6 +73,7 @@ namespace SDFOperators {
 #include "gen/camera_load_save.inc"
 namespace math {
 #include "gen/math_impl.inc"
+#include "gen/math_pose_mat_to_vec.inc"
 }  // namespace math
 #include "gen/grid_impl.inc"
 #include "gen/grid_frustum.inc"
@@ -89,7 +90,11 @@ namespace SDFOperators {
 #include "gen/processing_impl.inc"
 #include "gen/pyramid_class.inc"
 #include "gen/pyramid_ctor.inc"
+#include "gen/pyramid_ctor2.inc"
 #include "gen/pyramid_dtor.inc"
+#include "gen/pyramid_create.inc"
+#include "gen/pyramid_downsample.inc"
+#include "gen/pyramid_create_pyr.inc"
 #include "gen/pyramid_access.inc"
 #include "gen/pyramid_depth_down.inc"
 #include "gen/pyramid_depth_pyr.inc"
@@ -177,6 +182,19 @@ bool Intrinsic3D::init() {
     sdf_colorization_.setConfig(colorizeCfg);
     return recomputeColors();
 }
+// ... and the reference's OWN init (intrinsic3d.cpp:151-203) under another name, as a member of a derived class: the keyframe loop over its Sensor /
+// KeyframeSelection, resizeDepth, Pyramid(num_levels, colour, depth), the pose inverse and math::poseMatToVecAA.  (The wrappers above keep the shim: they
+// are handed pyramids, not a sensor.)
+class Intrinsic3DInit : public Intrinsic3D {
+public:
+    using Intrinsic3D::Intrinsic3D;
+    bool init_reference();
+};
+#define Intrinsic3D Intrinsic3DInit
+#define init init_reference
+#include "gen/i3d_init.inc"
+#undef init
+#undef Intrinsic3D
 
 #include "gen/mesh_struct.inc"
 #include "gen/mesh_save.inc"
@@ -750,6 +768,49 @@ int32_t ref_app_fusion(const char* folder, int32_t max_frames, float depth_min, 
     std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
     return ok ? 1 : 0;
 }
+
+/* Intrinsic3D::init (intrinsic3d.cpp:151-203) on a dataset folder: SensorI3d + keyframe flags -> the image formation model the optimisation starts from.
+ * Returns a handle (NULL: the sensor could not be initialised); the getters hand out keyframe ids, world-to-camera pose vectors, intrinsics and the
+ * pyramid images.  init's own return value (the initial recolouring of a one-voxel stand-in grid) is not what is inspected here. */
+struct RefInit { SensorI3d* sensor; KeyframeSelection* ks; Intrinsic3DInit* app; SparseVoxelGrid<VoxelSBR>* grid; };
+void* ref_i3d_init(const char* folder, int32_t max_frames, float depth_min, float depth_max, int64_t n_flags, const uint8_t* is_kf, int32_t num_rgbd_levels) {
+    const bool quiet = std::getenv("I3D_REF_VERBOSE") == nullptr;
+    std::streambuf* o1 = std::cout.rdbuf(); std::streambuf* o2 = std::cerr.rdbuf();
+    if (quiet) { std::cout.rdbuf(nullptr); std::cerr.rdbuf(nullptr); }
+    SensorI3d* s = new SensorI3d; s->setNumFramesMax(max_frames); s->setDepthMin(depth_min); s->setDepthMax(depth_max);
+    RefInit* R = nullptr;
+    if (s->init(folder)) {
+        KeyframeSelection* ks = new KeyframeSelection(1); ks->frame_scores_.assign((size_t)n_flags, 1.0); ks->is_keyframe_.resize((size_t)n_flags);
+        for (int64_t i = 0; i < n_flags; ++i) ks->is_keyframe_[(size_t)i] = is_kf[i] != 0;
+        Intrinsic3D::Config cfg; cfg.num_grid_levels = 1; cfg.num_rgbd_levels = num_rgbd_levels; cfg.thres_shell_factor = 2.0; cfg.thres_shell_factor_final = 1.0; cfg.clear_distant_voxels = false;
+        cfg.occlusions_distance = 0.02f; cfg.num_observations = 5; cfg.subvolume_size_sh = 0.2f; cfg.sh_est_lambda_reg = 10.0;
+        Optimizer::Config oc; oc.iterations = 1; oc.lm_steps = 1; oc.lambda_g = 0.2; oc.lambda_r0 = oc.lambda_r1 = oc.lambda_s0 = oc.lambda_s1 = 1.0; oc.lambda_a = 0.1; oc.fix_poses = oc.fix_intrinsics = oc.fix_distortion = false;
+        R = new RefInit; R->sensor = s; R->ks = ks; R->app = new Intrinsic3DInit(cfg, oc, s, ks);
+        R->grid = new SparseVoxelGrid<VoxelSBR>(0.004f, depth_min, depth_max);
+        { VoxelSBR v; v.sdf = 0.0; v.sdf_refined = 0.0; v.albedo = 0.6; v.weight = 1.0f; v.color = Vec3b(128, 128, 128); R->grid->setVoxel(Vec3i(0, 0, 0), v); }
+        R->app->opt_data_.grid = R->grid;
+        (void)R->app->init_reference();
+    } else delete s;
+    std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
+    return R;
+}
+int32_t ref_i3d_init_count(void* h) { return (int32_t)((RefInit*)h)->app->image_model_.frame_ids.size(); }
+void ref_i3d_init_model(void* h, int32_t* frame_ids, double* poses6, double* intr4, double* dist5) {
+    auto& m = ((RefInit*)h)->app->image_model_;
+    for (size_t i = 0; i < m.frame_ids.size(); ++i) { frame_ids[i] = m.frame_ids[i]; for (int k = 0; k < 6; ++k) poses6[6 * i + k] = m.poses[i][k]; }
+    for (int k = 0; k < 4; ++k) intr4[k] = m.intrinsics[k];
+    for (int k = 0; k < 5; ++k) dist5[k] = m.distortion_coeffs[(size_t)k];
+}
+/* image of keyframe k at pyramid level lvl: kind 0 intensity (float), 1 depth (float), 2 colour (3 x u8); returns rows * cols, dims in wh */
+int64_t ref_i3d_init_image(void* h, int32_t k, int32_t lvl, int32_t kind, int32_t* wh, void* out) {
+    Pyramid& p = ((RefInit*)h)->app->image_model_.rgbd_pyr[(size_t)k];
+    const cv::Mat m = kind == 0 ? p.intensity(lvl) : kind == 1 ? p.depth(lvl) : p.color(lvl);
+    if (m.empty()) return 0;
+    wh[0] = m.cols; wh[1] = m.rows;
+    if (out) std::memcpy(out, m.data, (size_t)m.rows * m.cols * cv::Mat::elem(m.type()));
+    return (int64_t)m.rows * m.cols;
+}
+void ref_i3d_init_free(void* h) { RefInit* R = (RefInit*)h; if (!R) return; R->app->opt_data_.grid = nullptr; delete R->app; delete R->grid; delete R->ks; delete R->sensor; delete R; }
 
 /* Intrinsic3D::Config::load + Optimizer::Config::load (intrinsic3d.cpp:58-80, optimizer.cpp:52-72) from (key, value) strings.
  * out[20]: num_grid_levels, num_rgbd_levels, thres_shell_factor, thres_shell_factor_final, clear_distant_voxels, occlusions_distance, num_observations,

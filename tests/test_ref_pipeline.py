@@ -558,3 +558,42 @@ def test_yaml_configuration_equals_the_reference_loaders(R, tmp_path):
         for k, v in ref.items():
             assert ours[k] == v, (i, k, ours[k], v)
         assert float(oc.occlusion_distance) == ref["occlusion_distance"] and float(oc.num_observations) == ref["num_observations"]
+
+
+def test_refinement_initialisation_equals_the_reference_code(oracle, R, tmp_path):
+    """Intrinsic3D::init (intrinsic3d.cpp:151-203) of the reference on a dataset folder — the keyframe loop over its own SensorI3d / KeyframeSelection, resizeDepth
+    into the colour camera, Pyramid(num_levels, colour, depth) and the pose inverse + math::poseMatToVecAA — against what the product's
+    i3d_init_frames_from_sensor is built from and held to on the device: the oracle's pyramid primitives composed in the same order, and the host-side
+    i3d_pose_mat_to_vec6.  Depth camera at half the colour resolution; three pyramid levels; a keyframe list that skips frames."""
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+    from intrinsic3d_amd import binding as B
+    from oracle import ref_py
+    rng = np.random.default_rng(31); folder = tmp_path / "rgbd"; folder.mkdir()
+    Kc = np.eye(4); Kc[0, 0] = 105.0; Kc[1, 1] = 104.0; Kc[0, 2] = 47.5; Kc[1, 2] = 35.5
+    Kd = np.eye(4); Kd[0, 0] = 52.5; Kd[1, 1] = 52.0; Kd[0, 2] = 23.5; Kd[1, 2] = 17.5
+    np.savetxt(folder / "colorIntrinsics.txt", Kc); np.savetxt(folder / "depthIntrinsics.txt", Kd)
+    n = 5
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, (72, 96, 3), np.uint8)).save(folder / f"frame-{i:06d}.color.png")
+        d = rng.integers(300, 3500, (36, 48)).astype(np.uint16); d[rng.random(d.shape) < 0.2] = 0
+        Image.fromarray(d).save(folder / f"frame-{i:06d}.depth.png")
+        T = np.eye(4); T[:3, :3] = Rotation.from_rotvec(rng.normal(size=3) * (3.0 if i == 3 else 0.5)).as_matrix(); T[:3, 3] = rng.normal(size=3)
+        np.savetxt(folder / f"frame-{i:06d}.pose.txt", T)
+    keep = [True, False, True, True, False]; levels = 3
+    m = ref_py.InitModel(folder, keep, levels, 0, 0.4, 3.0)
+    s = B.Sensor(folder, 0, 0.4, 3.0)
+    assert list(m.frame_ids) == [i for i in range(n) if keep[i]]
+    assert np.array_equal(m.intrinsics, np.float32(s.color_intrinsics).astype(np.float64)) and not m.distortion.any()
+    for k, f in enumerate(m.frame_ids):
+        # (to round-off, not bit for bit: the 4x4 inverse in front of the conversion is Eigen's, whose operation order neither side reproduces)
+        assert np.abs(m.poses[k] - B.pose_mat_to_vec6(s.pose(int(f)))).max() <= 1e-13, (k, m.poses[k] - B.pose_mat_to_vec6(s.pose(int(f))))
+        bgr = s.color(int(f)); assert np.array_equal(m.image(k, 0, "bgr"), bgr)
+        lum = oracle.lum_from_bgr(bgr)
+        dep = oracle.resize_depth(s.depth(int(f)), s.depth_intrinsics, s.color_size[0], s.color_size[1], s.color_intrinsics)
+        for l in range(levels):
+            assert np.array_equal(m.image(k, l, "lum"), lum), (k, l)
+            assert np.array_equal(m.image(k, l, "depth"), dep), (k, l)
+            lum = oracle.pyr_down(lum); dep = oracle.depth_down(dep)
+        assert m.image(k, levels, "lum") is None
+    m.close(); s.close()
