@@ -60,6 +60,7 @@ CHUNKS = [
     ("grid_frustum",         "src/sparse_voxel_grid.cpp", 572, 602, "template <class T>", "}"),
     ("grid_print_info",      "src/sparse_voxel_grid.cpp", 470, 480, "template <class T>", "}"),
     ("grid_save",            "src/sparse_voxel_grid.cpp", 483, 516, "template <class T>", "}"),
+    ("grid_clone",           "src/sparse_voxel_grid.cpp", 519, 528, "template <class T>", "}"),
     ("grid_load",            "src/sparse_voxel_grid.cpp", 531, 569, "template <class T>", "}"),
     ("camera_class",         "include/nv/camera.h", 47, 89, "class Camera", "};"),
     ("camera_impl",          "src/camera.cpp", 41, 199, "Camera::Camera() :", "}"),
@@ -71,7 +72,12 @@ CHUNKS = [
     ("app_keyframes_class",  "../apps/include/nv/app_keyframes.h", 46, 58, "class AppKeyframes", "};"),
     ("app_keyframes_ctor",   "../apps/src/app_keyframes.cpp", 46, 55, "AppKeyframes::AppKeyframes() :", "}"),
     ("app_keyframes_select", "../apps/src/app_keyframes.cpp", 101, 144, "bool AppKeyframes::selectKeyframes", "}"),
+    ("vis_class",            "include/nv/sdf/visualization.h", 56, 101, "class SDFVisualization", "};"),
+    ("vis_impl",             "src/sdf/visualization.cpp", 60, 416, "SDFVisualization::SDFVisualization(SparseVoxelGrid<VoxelSBR>* grid", "}"),
     ("app_fusion_class",     "../apps/include/nv/app_fusion.h", 46, 58, "class AppFusion", "};"),
+    ("app_i3d_class",        "../apps/include/nv/app_intrinsic3d.h", 53, 68, "class AppIntrinsic3D : public Intrinsic3D::RefinementCallback", "};"),
+    ("app_i3d_ctor",         "../apps/src/app_intrinsic3d.cpp", 56, 69, "AppIntrinsic3D::AppIntrinsic3D() :", "}"),
+    ("app_i3d_on_refined",   "../apps/src/app_intrinsic3d.cpp", 159, 210, "void AppIntrinsic3D::onSDFRefined", "}"),
     ("app_fusion_ctor",      "../apps/src/app_fusion.cpp", 52, 61, "AppFusion::AppFusion() :", "}"),
     ("app_fusion_fuse",      "../apps/src/app_fusion.cpp", 107, 200, "bool AppFusion::fuseSDF", "}"),
     ("sensor_class",         "include/nv/rgbd/sensor.h", 49, 112, "class Sensor", "};"),
@@ -86,10 +92,12 @@ CHUNKS = [
     ("math_decl",            "include/nv/math.h", 44, 65, "namespace math", "} // namespace math"),
     ("math_impl",            "src/math.cpp", 43, 163, "float robustKernel", "}"),
     ("operators_impl",       "src/sdf/operators.cpp", 45, 77, "Vec3f voxelCenterToIso(const SparseVoxelGrid", "}"),
+    ("operators_lap_grad",   "src/sdf/operators.cpp", 80, 139, "float laplacian(const SparseVoxelGrid<VoxelSBR>* grid", "}"),
     ("algorithms_decl",      "include/nv/sdf/algorithms.h", 44, 69, "namespace SDFAlgorithms", "} // namespace SDFAlgorithms"),
     ("algorithms_impl",      "src/sdf/algorithms.cpp", 47, 458, "SparseVoxelGrid<VoxelSBR>* convert", "}"),
     ("color_util_decl",      "include/nv/color_util.h", 46, 57, "float intensity(unsigned char r", "Vec3b randomColor();"),
     ("color_intensity",      "src/color_util.cpp", 41, 58, "float intensity(unsigned char r", "}"),
+    ("color_chroma",         "src/color_util.cpp", 61, 67, "Vec3f chromacity(const Vec3b &color)", "}"),
     ("color_scalar",         "src/color_util.cpp", 70, 80, "template <typename T>", "template Vec3b scalarToColor(const double val, const double scale);"),
     ("color_random",         "src/color_util.cpp", 83, 114, "Vec3f checkRange", "}"),
     ("processing_decl",      "include/nv/rgbd/processing.h", 50, 62, "cv::Mat computeVertexMap", "Vec3b interpolateRGB"),
@@ -108,6 +116,7 @@ CHUNKS = [
     ("colorization_impl",    "src/sdf/colorization.cpp", 52, 370, "SDFColorization::SDFColorization(const Camera", "}"),
     ("shading_decl",         "include/nv/shading.h", 49, 51, "static const int NUM_SPHERICAL_HARMONICS", "Eigen::VectorXf shBasisFunctions"),
     ("shading_basis_f",      "src/shading.cpp", 43, 58, "Eigen::VectorXf shBasisFunctions", "}"),
+    ("shading_compute_f",    "src/shading.cpp", 61, 73, "float computeShading(const Vec3f &normal", "}"),
     ("voxel_residual",       "include/nv/refinement/cost.h", 59, 70, "struct VoxelResidual", "};"),
     ("shading_cost_class",   "include/nv/refinement/shading_cost.h", 76, 204, "class ShadingCost", "};"),
     ("shading_cost_impl",    "src/refinement/shading_cost.cpp", 46, 150, "ShadingCost::ShadingCost(const Vec3i", "}"),

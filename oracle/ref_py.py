@@ -339,3 +339,12 @@ class InitModel:
     def close(self):
         if self.h:
             self.L.ref_i3d_init_free(self.h); self.h = None
+
+
+def app_intrinsic3d(folder, cfg, max_frames=0, min_depth=0.0, max_depth=0.0):
+    """AppIntrinsic3D::run of the reference without its command line / yml reading (see ref_app_intrinsic3d); cfg: dict of intrinsic3d.yml.  Paths in cfg are
+    used as given (the reference changes into the sensor config's directory first: hand in absolute paths or chdir)."""
+    L = C.CDLL(LIB_PATH); _install_pillow_decoder(L)
+    ks = [str(k).encode() for k in cfg]; vs = [str(v).encode() for v in cfg.values()]
+    K = (C.c_char_p * len(ks))(*ks); V = (C.c_char_p * len(vs))(*vs)
+    return L.ref_app_intrinsic3d(str(folder).encode(), C.c_int32(max_frames), C.c_float(min_depth), C.c_float(max_depth), C.c_int32(len(ks)), K, V) == 1

@@ -79,12 +79,17 @@ namespace math {
 #include "gen/grid_frustum.inc"
 #include "gen/grid_print_info.inc"
 #include "gen/grid_save.inc"
+#include "gen/grid_clone.inc"
 #include "gen/grid_load.inc"
 namespace SDFOperators {
+float laplacian(const SparseVoxelGrid<VoxelSBR>* grid, const Vec3i& v_pos);            // (operators.h:88,111: declared in the header, used by SDFVisualization)
+Vec3f intensityGradient(const SparseVoxelGrid<VoxelSBR>* grid, const Vec3i& v_pos);
 #include "gen/operators_impl.inc"
+#include "gen/operators_lap_grad.inc"
 #include "gen/operators_sdf_weight.inc"
 }  // namespace SDFOperators
 #include "gen/color_intensity.inc"
+#include "gen/color_chroma.inc"
 #include "gen/color_scalar.inc"
 #include "gen/color_random.inc"
 #include "gen/processing_impl.inc"
@@ -108,6 +113,8 @@ namespace Shading {
 #include "gen/shading_compute.inc"
 #include "gen/shading_graddiff.inc"
 #include "gen/shading_basis_f.inc"
+float computeShading(const Vec3f &normal, const Eigen::VectorXf &sh_coeffs, float albedo);
+#include "gen/shading_compute_f.inc"
 }  // namespace Shading
 
 #include "gen/vertex_observation.inc"
@@ -189,10 +196,14 @@ class Intrinsic3DInit : public Intrinsic3D {
 public:
     using Intrinsic3D::Intrinsic3D;
     bool init_reference();
+    // the schedule once more as members of this class, so that refine() runs the reference's own init (the same text, intrinsic3d.cpp:206-409)
+    bool refine(SparseVoxelGrid<Voxel>* grid);
+    bool prepareGridLevel(int grid_lvl_coarsest); bool finishGridLevel(); bool prepareRgbdLevel(); bool finishRgbdLevel(); bool recomputeColors();
 };
 #define Intrinsic3D Intrinsic3DInit
 #define init init_reference
 #include "gen/i3d_init.inc"
+#include "gen/i3d_refine.inc"
 #undef init
 #undef Intrinsic3D
 
@@ -208,12 +219,17 @@ void removeUnusedVertices(Mesh* mesh);               // (declared in the referen
 #include "gen/mc_extract_mesh.inc"
 #include "gen/mc_body.inc"
 #include "gen/mc_tables.inc"
+#include "gen/vis_class.inc"
+#include "gen/vis_impl.inc"
 #include "gen/app_fusion_class.inc"
 #include "gen/app_fusion_ctor.inc"
 #include "gen/app_fusion_fuse.inc"
 #include "gen/app_keyframes_class.inc"
 #include "gen/app_keyframes_ctor.inc"
 #include "gen/app_keyframes_select.inc"
+#include "gen/app_i3d_class.inc"
+#include "gen/app_i3d_ctor.inc"
+#include "gen/app_i3d_on_refined.inc"
 
 }  // namespace nv
 #undef private
@@ -765,6 +781,36 @@ int32_t ref_app_fusion(const char* folder, int32_t max_frames, float depth_min, 
         AppFusion app; app.sensor_ = s;              // (the destructor deletes the sensor)
         ok = app.fuseSDF(cfg);
     } else delete s;
+    std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
+    return ok ? 1 : 0;
+}
+
+/* AppIntrinsic3D::run (apps/src/app_intrinsic3d.cpp:72-155) without its command line and yml reading, on a dataset folder: its own SensorI3d, KeyframeSelection
+ * ::load, SparseVoxelGrid<Voxel>::create(input_sdf), the two Config::load, Intrinsic3D (with its own init), refine, and onSDFRefined per level — the meshes of
+ * the enabled colour modes, the pose and the intrinsics files.  cfg: (key, value) strings of intrinsic3d.yml. */
+int32_t ref_app_intrinsic3d(const char* folder, int32_t max_frames, float depth_min, float depth_max, int32_t n, const char* const* keys, const char* const* values) {
+    const bool quiet = std::getenv("I3D_REF_VERBOSE") == nullptr;
+    std::streambuf* o1 = std::cout.rdbuf(); std::streambuf* o2 = std::cerr.rdbuf();
+    if (quiet) { std::cout.rdbuf(nullptr); std::cerr.rdbuf(nullptr); }
+    SensorI3d* s = new SensorI3d; s->setNumFramesMax(max_frames); s->setDepthMin(depth_min); s->setDepthMax(depth_max);
+    bool ok = s->init(folder);
+    if (!ok) delete s;
+    else {
+        AppIntrinsic3D app;                                              // (its destructor deletes sensor, keyframe selection and Intrinsic3D)
+        for (int i = 0; i < n; ++i) app.i3d_cfg_.set<std::string>(keys[i], values[i]);
+        app.sensor_ = s;
+        app.keyframe_selection_ = new KeyframeSelection();
+        (void)app.keyframe_selection_->load(app.i3d_cfg_.get<std::string>("keyframes"));
+        SparseVoxelGrid<Voxel>* grid = SparseVoxelGrid<Voxel>::create(app.i3d_cfg_.get<std::string>("input_sdf"), s->depthMin(), s->depthMax());
+        ok = grid != nullptr;
+        if (ok) {
+            Intrinsic3D::Config a; a.load(app.i3d_cfg_); Optimizer::Config b; b.load(app.i3d_cfg_);
+            Intrinsic3DInit* i3d = new Intrinsic3DInit(a, b, s, app.keyframe_selection_);
+            app.intrinsic3d_ = i3d; i3d->addRefinementCallback(&app);
+            ok = i3d->refine(grid);
+            delete grid;
+        }
+    }
     std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
     return ok ? 1 : 0;
 }

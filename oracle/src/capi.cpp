@@ -224,6 +224,7 @@ void orc_depth_down(int32_t w, int32_t h, const float* src, float* dst) {       
 
 // rgbd/processing.cpp:129-181 + interpolate<float> :236-283
 void orc_resize_depth(int32_t iw, int32_t ih, const float* din, const float* in_intr, int32_t ow, int32_t oh, const float* out_intr, float* dout) {
+    if (iw == ow && ih == oh) { std::memcpy(dout, din, sizeof(float) * (size_t)iw * ih); return; }      // :135-139: same size -> a clone, whatever the intrinsics
     const float in_fx = in_intr[0], in_fy = in_intr[1], in_cx = in_intr[2], in_cy = in_intr[3];
     const float out_cx = out_intr[2], out_cy = out_intr[3], out_fx_inv = 1.0f / out_intr[0], out_fy_inv = 1.0f / out_intr[1];
     for (int y = 0; y < oh; ++y) for (int x = 0; x < ow; ++x) {

@@ -198,3 +198,41 @@ def test_fusion_degenerate_frames(oracle):
             o.finish(2); f.finish(2); ref = o.export(); got = f.export()
         _same(got, ref)
         assert (len(ref["sdf"]) > 1000) == (clip is None)                  # the frustum bounds are rounded to whole METRES (sparse_voxel_grid.cpp:587-588): dmax 0.2 cuts nothing here
+
+
+def test_app_intrinsic3d_equals_the_reference_application(tmp_path):
+    """apps/app_intrinsic3d on a dataset folder against the reference's own AppIntrinsic3D flow (apps/src/app_intrinsic3d.cpp:71-210: SensorI3d, KeyframeSelection::load,
+    SparseVoxelGrid::create(tsdf), Intrinsic3D::init / refine, onSDFRefined -> SDFVisualization::colorize, savePoses, Camera::save — all compiled into oracle/_ref) with
+    `iterations: "0"`: the optimiser declines (optimizer.cpp:113-114) and both sides go on, so every stage's files depend only on loading, initialisation, thin
+    shell, lighting, recolouring, upsampling and export — and must agree byte for byte: three stages x (mesh, albedo mesh, poses, intrinsics)."""
+    import shutil
+    import subprocess
+    from intrinsic3d_amd import synthetic
+    from oracle import ref_py
+    import make_dataset
+    if not ref_py.available():
+        pytest.skip("oracle/_ref/libref_i3d.so not built")
+    sc = synthetic.make_scene(radius_vox=10, K=4, width=96, height=72, levels=1, seed=9, pose_noise=(0.0005, 0.001), lum_noise=0.003)
+    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=2, rgbd_levels=2, iterations=0)
+    import re
+    cfg = dict(re.findall(r'^(\w+): "(.*)"$', open(i_yml).read(), re.M))
+    out = tmp_path / "intrinsic3d"; out.mkdir(exist_ok=True)
+    r = subprocess.run([os.path.join(ROOT, "apps", "app_intrinsic3d"), "-s", s_yml, "-i", i_yml], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ours = tmp_path / "ours"; shutil.move(str(out), str(ours)); out.mkdir()
+    cwd = os.getcwd(); os.chdir(tmp_path)
+    try:
+        assert ref_py.app_intrinsic3d("./rgbd/", cfg, 0, 0.1, 10.0)
+    finally:
+        os.chdir(cwd)
+    names = sorted(os.listdir(out))
+    assert names == sorted(f"{p}_{s}{e}" for s in ("g1_p1", "g1_p0", "g0_p0") for p, e in (("intrinsics", ".txt"), ("poses", ".txt"), ("mesh", ".ply"), ("mesh", "_albedo.ply")))
+    report = {n: (os.path.exists(ours / n) and open(ours / n, "rb").read() == open(out / n, "rb").read()) for n in names}
+    if not all(report.values()) or sorted(os.listdir(ours)) != names:
+        keep = os.path.join(ROOT, "gpurun_out", "app_i3d_mismatch")                        # (for a look afterwards)
+        shutil.rmtree(keep, ignore_errors=True); os.makedirs(keep)
+        shutil.copytree(ours, os.path.join(keep, "ours")); shutil.copytree(out, os.path.join(keep, "ref"))
+        open(os.path.join(keep, "app.log"), "w").write(r.stdout + r.stderr)
+    assert sorted(os.listdir(ours)) == names, sorted(os.listdir(ours))
+    assert all(report.values()), report
+    assert (out / "mesh_g0_p0.ply").stat().st_size > 100000

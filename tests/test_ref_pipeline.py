@@ -17,6 +17,7 @@ fields, subvolume ids + interpolated SH, recolourisation, fusion alloc / integra
 What stays unpinned: Ceres itself (two restatements agree), Eigen's 4x4 inverse and OpenCV's pyrDown / cvtColor.
 """
 import os
+import re
 import sys
 
 import numpy as np
@@ -260,6 +261,8 @@ def test_small_helpers_equal_the_reference_code(oracle, R):
     assert np.array_equal(oracle.depth_down(d), R.depth_down(d))
     out_cam = np.array([130.0, 131.0, 63.5, 47.5], np.float32)
     assert np.array_equal(oracle.resize_depth(d, cam, 128, 96, out_cam), R.resize_depth(d, cam, 128, 96, out_cam))
+    same = R.resize_depth(d, cam, 80, 60, out_cam)                                       # same size: a clone, whatever the two cameras are (processing.cpp:135-139)
+    assert np.array_equal(same, d) and np.array_equal(oracle.resize_depth(d, cam, 80, 60, out_cam), d)
 
 
 def _by_key(d):
@@ -597,3 +600,72 @@ def test_refinement_initialisation_equals_the_reference_code(oracle, R, tmp_path
             lum = oracle.pyr_down(lum); dep = oracle.depth_down(dep)
         assert m.image(k, levels, "lum") is None
     m.close(); s.close()
+
+
+def _read_ply(path):
+    raw = open(path, "rb").read(); end = raw.index(b"end_header\n") + 11
+    head = raw[:end].decode().split("\n"); nv = int(head[2].split()[2]); nf = int([l for l in head if l.startswith("element face")][0].split()[2])
+    vt = np.frombuffer(raw, np.dtype([("p", "<f4", 3), ("c", "u1", 3)]), nv, end)
+    ft = np.frombuffer(raw, np.dtype([("n", "u1"), ("i", "<i4", 3)]), nf, end + nv * 15)
+    assert end + nv * 15 + nf * 13 == len(raw) and (ft["n"] == 3).all()
+    return vt["p"].copy(), vt["c"].copy(), ft["i"].copy()
+
+
+def test_refinement_application_equals_the_oracle_pipeline(oracle, R, tmp_path):
+    """AppIntrinsic3D::run + onSDFRefined (apps/src/app_intrinsic3d.cpp:71-210) of the reference, compiled into oracle/_ref over its own SensorI3d, KeyframeSelection,
+    SparseVoxelGrid::load / create(tsdf -> sbr), Intrinsic3D::init / refine, SDFVisualization and MarchingCubes, on a dataset folder in the reference's layout
+    (2 grid levels x (2, 1) pyramid levels, one iteration each) — against the oracle's pieces composed from the SAME files: which output files appear under which
+    names, the final poses / intrinsics text, and the last level's mesh in both colour modes."""
+    from intrinsic3d_amd import binding as B, synthetic
+    from oracle import ref_py
+    import make_dataset
+    sc = synthetic.make_scene(radius_vox=10, K=4, width=96, height=72, levels=1, seed=9, pose_noise=(0.0005, 0.001), lum_noise=0.003)
+    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=2, rgbd_levels=2, iterations=1)
+    cfg = dict(re.findall(r'^(\w+): "(.*)"$', open(i_yml).read(), re.M))
+    (tmp_path / "intrinsic3d").mkdir(exist_ok=True)
+    cwd = os.getcwd(); os.chdir(tmp_path)                                              # (the reference application changes into the sensor config's directory)
+    try:
+        assert ref_py.app_intrinsic3d("./rgbd/", cfg, 0, 0.1, 10.0)
+    finally:
+        os.chdir(cwd)
+    out = tmp_path / "intrinsic3d"
+    stages = ("g1_p1", "g1_p0", "g0_p0")                                                # grid level 1 is the coarse one: it runs both pyramid levels, level 0 only the finest
+    assert sorted(os.listdir(out)) == sorted(f"{p}_{s}{e}" for s in stages for p, e in (("intrinsics", ".txt"), ("poses", ".txt"), ("mesh", ".ply"), ("mesh", "_albedo.ply")))
+
+    # the same run on the oracle, from the same files
+    s = B.Sensor(tmp_path / "rgbd", 0, 0.1, 10.0)
+    kf = B.keyframes_load(str(tmp_path / "fusion" / "keyframes.txt"))[2]; assert kf.all()
+    vol = B.tsdf_read(str(tmp_path / "fusion" / os.path.basename(cfg["input_sdf"])))
+    # (the start poses are taken from the reference's own init: this little scene leaves poses and distortion weakly determined, and the 1e-13 by which Eigen's 4x4
+    #  inverse differs from the product's — test_refinement_initialisation — grows to 1e-2 through three optimisations)
+    m = ref_py.InitModel(tmp_path / "rgbd", kf, 2, 0, 0.1, 10.0); poses = np.array(m.poses); m.close()
+    frames = []
+    for f in range(s.num_frames):
+        bgr = s.color(f); lum = oracle.lum_from_bgr(bgr)
+        dep = oracle.resize_depth(s.depth(f), s.depth_intrinsics, s.color_size[0], s.color_size[1], s.color_intrinsics)
+        frames.append({"lum": [lum, oracle.pyr_down(lum)], "depth": [dep, oracle.depth_down(dep)], "bgr": [bgr, bgr[::2, ::2]]})
+    ci = np.float64(s.color_intrinsics); w, h = s.color_size; n = s.num_frames; s.close()
+    g = oracle.Grid.from_voxels(vol["voxel_size"], vol["keys"], vol["sdf"], vol["weight"], vol["color"]); fr = oracle.Frames(frames, 2)
+    ocfg = helpers.oracle_cfg(oracle, 0.0, iterations=1, **{k: float(cfg[k]) for k in ("lambda_g", "lambda_r0", "lambda_r1", "lambda_s0", "lambda_s1", "lambda_a")}, occlusion_distance=float(np.float32(cfg["occlusion_distance"])),
+                              lm_steps=int(cfg["lm_steps"]), num_observations=int(cfg["num_observations"]))
+    rc, intr, dist, pose6, done = oracle.refine(g, fr, ocfg, 2, 2, float(cfg["thin_shell_factor"]), float(cfg["thin_shell_factor_final"]), int(cfg["clear_distant_voxels"]),
+                                                float(np.float32(cfg["subvolume_size_sh"])), float(cfg["subvolume_sh_lamda_reg"]), ci, np.zeros(5), np.array(poses))
+    assert rc == 0 and done == 3
+    # poses / intrinsics files of the last stage (6 / default-precision decimals in the text)
+    B.write_poses(str(tmp_path / "ours_poses.txt"), np.arange(n, dtype=np.float64), pose6)
+    a = np.loadtxt(out / "poses_g0_p0.txt"); b = np.loadtxt(tmp_path / "ours_poses.txt")
+    assert a.shape == b.shape == (n, 8) and np.abs(a - b).max() <= 2e-6, np.abs(a - b).max()
+    assert np.abs(a - np.loadtxt(out / "poses_g1_p1.txt")).max() > 1e-5                     # ... and the poses did move between the stages
+    cam = ref_py.camera_load(str(out / "intrinsics_g0_p0.txt"))
+    assert cam[0] and (cam[1], cam[2]) == (w, h) and np.allclose(cam[3], intr, rtol=1e-5, atol=0) and np.allclose(cam[4], dist, rtol=1e-5, atol=1e-9)   # (six significant digits in the file)
+    # the last level's meshes: MarchingCubes over the refined distances, largest component, voxel colours / albedo colours
+    rv, rcol, rf = _read_ply(out / "mesh_g0_p0.ply"); av, acol, af = _read_ply(out / "mesh_g0_p0_albedo.ply")
+    ov, ocol, of = oracle.marching_cubes(g, True)
+    ov2, ocol2, of2 = B.mesh_remove_loose_components(ov, ocol, of)
+    assert rv.shape == ov2.shape and np.array_equal(rf, of2) and np.array_equal(af, of2)
+    assert np.abs(rv - ov2).max() <= 1e-6 and np.array_equal(av, rv)
+    assert (np.abs(rcol.astype(int) - ocol2.astype(int)) > 1).mean() < 1e-3                 # colours interpolate between voxels whose order of first use may differ in the last bit
+    e = g.export(); g.import_fields(color=ref_py.albedo_colors(e["albedo"]))
+    _, ac2, _ = B.mesh_remove_loose_components(*oracle.marching_cubes(g, True))
+    assert (np.abs(acol.astype(int) - ac2.astype(int)) > 1).mean() < 1e-3 and acol.std() > 0
+    g.free(); fr.free()
