@@ -5,7 +5,7 @@
 //
 // sensor.yml / intrinsic3d.yml are the reference's files (data/*.yml).  As in the reference the working directory becomes the directory of
 // sensor.yml, ./intrinsic3d is created, and after every (grid level, rgbd level) the meshes, poses and intrinsics are written with the
-// `_g{L}_p{P}` postfix.  Mesh colour modes: voxel colours and "albedo"; the reference's other debug visualisations are not produced.
+// `_g{L}_p{P}` postfix.  Mesh colour modes: every `output_mesh_*` switch of intrinsic3d.yml except the two subvolume views (random colours in the reference).
 #include "../include/intrinsic3d_hip.h"
 #include <climits>
 #include <cstdio>
@@ -39,12 +39,20 @@ void on_refined(void* user, int32_t grid_level, int32_t, int32_t pyramid_level, 
     const std::string mesh_prefix = yaml(a.cfg_file, "output_mesh_prefix");
     if (!mesh_prefix.empty()) {
         const int largest = std::atoi(yaml(a.cfg_file, "output_mesh_largest_comp_only", "0").c_str());
-        std::printf("SDF visualization and export: \n");
-        if (i3d_export_mesh_ply(a.ctx, (mesh_prefix + post + ".ply").c_str(), 1, 0, largest) != I3D_OK) std::fprintf(stderr, "Could not save mesh: %s\n", i3d_last_error(a.ctx));
-        if (std::atoi(yaml(a.cfg_file, "output_mesh_albedo", "0").c_str())) {
-            std::printf("SDF visualization and export: albedo\n");
-            if (i3d_export_mesh_ply(a.ctx, (mesh_prefix + post + "_albedo.ply").c_str(), 1, 1, largest) != I3D_OK) std::fprintf(stderr, "Could not save mesh: %s\n", i3d_last_error(a.ctx));
+        // SDFVisualization::getOutputModes(settings, true) (sdf/visualization.cpp:71-89): the voxel colours, then every enabled mode in this order
+        static const struct { const char* key; const char* name; int mode; } MODES[] = {
+            {nullptr, "", I3D_COLOR_VOXEL}, {"output_mesh_normals", "normals", I3D_COLOR_NORMALS}, {"output_mesh_laplacian", "lap", I3D_COLOR_LAPLACIAN},
+            {"output_mesh_intensity", "lum", I3D_COLOR_INTENSITY}, {"output_mesh_intensity_grad", "lum_grad", I3D_COLOR_INTENSITY_GRAD}, {"output_mesh_albedo", "albedo", I3D_COLOR_ALBEDO},
+            {"output_mesh_shading_sv", "shading_sv", I3D_COLOR_SHADING}, {"output_mesh_shading_sv_const", "shading_sv_const", I3D_COLOR_SHADING_CONST_ALBEDO},
+            {"output_mesh_chromacity", "chroma", I3D_COLOR_CHROMACITY}};
+        for (const auto& m : MODES) {
+            if (m.key && !std::atoi(yaml(a.cfg_file, m.key, "0").c_str())) continue;
+            std::printf("SDF visualization and export: %s\n", m.name);
+            const std::string file = mesh_prefix + post + (m.name[0] ? "_" + std::string(m.name) : std::string()) + ".ply";
+            if (i3d_export_mesh_ply(a.ctx, file.c_str(), 1, m.mode, largest) != I3D_OK) std::fprintf(stderr, "Could not save mesh: %s\n", i3d_last_error(a.ctx));
         }
+        for (const char* key : {"output_mesh_subvolumes", "output_mesh_subvolumes_interpolated"})           // painted with rand() colours in the reference: nothing to reproduce
+            if (std::atoi(yaml(a.cfg_file, key, "0").c_str())) std::fprintf(stderr, "%s: this view shows random subvolume colours in the reference and is not produced here\n", key);
     }
     double intr[4], dist[5]; std::vector<double> poses(6 * a.frame_ids.size());
     if (i3d_get_camera(a.ctx, intr, dist, poses.data()) != I3D_OK) { std::fprintf(stderr, "Could not read the camera: %s\n", i3d_last_error(a.ctx)); return; }

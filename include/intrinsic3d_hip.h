@@ -190,9 +190,22 @@ int i3d_config_load_yaml(const char* path, i3d_refine_config* rcfg, i3d_optimize
 int i3d_yaml_get(const char* path, const char* key, char* value, uint64_t capacity);     /* Settings::get<std::string>: any key of a flat yml */
 
 /* ---- mesh export of the resident grid (MarchingCubes<VoxelSBR>::extractSurface, MeshUtil, Mesh::save; SDFVisualization::exportMesh) -----
- * use_refined_sdf: SDFAlgorithms::applyRefinedSdf before extraction (app_intrinsic3d.cpp:170-172).  color_mode: 0 voxel colour, 1 "albedo"
- * (visualization.cpp:308-315).  largest_component_only: MeshUtil::removeLooseComponents.  PLY: binary_little_endian, float xyz, uchar rgb,
+ * use_refined_sdf: SDFAlgorithms::applyRefinedSdf before extraction (app_intrinsic3d.cpp:170-172).  color_mode: I3D_COLOR_* below — what
+ * SDFVisualization::colorize paints on the voxels before the mesh of a mode is extracted (visualization.cpp:101-164, 228-373); the shading modes need the
+ * lighting estimate of i3d_estimate_sh / i3d_refine.  largest_component_only: MeshUtil::removeLooseComponents.  PLY: binary_little_endian, float xyz, uchar rgb,
  * "uchar int" face lists (mesh.cpp:41-100). */
+enum {
+    I3D_COLOR_VOXEL = 0,                 /* ""                 the voxel colours */
+    I3D_COLOR_ALBEDO = 1,                /* "albedo"           output_mesh_albedo            applyColorAlbedo            :308-315 */
+    I3D_COLOR_NORMALS = 2,               /* "normals"          output_mesh_normals           applyColorNormals           :228-240 */
+    I3D_COLOR_LAPLACIAN = 3,             /* "lap"              output_mesh_laplacian         applyColorLaplacian         :243-259 */
+    I3D_COLOR_INTENSITY = 4,             /* "lum"              output_mesh_intensity         applyColorIntensity         :262-270 */
+    I3D_COLOR_INTENSITY_GRAD = 5,        /* "lum_grad"         output_mesh_intensity_grad    applyColorIntensityGradient :273-305 */
+    I3D_COLOR_SHADING = 6,               /* "shading_sv"       output_mesh_shading_sv        applyColorShading(false)    :318-359 */
+    I3D_COLOR_SHADING_CONST_ALBEDO = 7,  /* "shading_sv_const" output_mesh_shading_sv_const  applyColorShading(true) */
+    I3D_COLOR_CHROMACITY = 8             /* "chroma"           output_mesh_chromacity        applyColorChromacity        :362-373 */
+    /* "subvol" / "subvol_interp" paint Subvolumes::color(), drawn from rand() in the reference (subvolumes.cpp:87-91): nothing to reproduce, not offered */
+};
 int i3d_extract_mesh(i3d_context* ctx, int32_t use_refined_sdf, int32_t color_mode, int32_t largest_component_only, int64_t* num_vertices, int64_t* num_faces);
 int i3d_get_mesh(i3d_context* ctx, float* vertices /*[nv][3]*/, uint8_t* colors /*[nv][3]*/, int32_t* faces /*[nf][3]*/);
 int i3d_export_mesh_ply(i3d_context* ctx, const char* path, int32_t use_refined_sdf, int32_t color_mode, int32_t largest_component_only);
@@ -200,6 +213,13 @@ int i3d_write_ply(const char* path, int64_t num_vertices, const float* vertices,
 /* MeshUtil::removeLooseComponents + removeUnusedVertices (mesh/util.cpp:47-171) on caller arrays, in place (what largest_component_only applies): keeps the
  * largest connected component (first one among equals, components numbered by their first face), drops the vertices no face uses; counts updated.  Host only. */
 int i3d_mesh_remove_loose_components(int64_t* num_vertices, float* vertices, uint8_t* colors /* may be NULL */, int64_t* num_faces, int32_t* faces);
+/* SDFVisualization::applyColor* on caller arrays (voxels in any order; subvolumes as i3d_estimate_sh returns them, only read by the shading modes): the colour
+ * every voxel gets in a colour mode.  The same function the export kernel runs, instantiated for the host.  visit_rank: the position of every voxel in the
+ * reference's walk over its grid (NULL: the array order) — "lum_grad" is painted in place there, a voxel reads its +x neighbour repainted if the walk passed
+ * it earlier (visualization.cpp:273-305), and the export reproduces that from the resident grid's visit order.  Host only. */
+int i3d_visualization_colors(int32_t color_mode, float voxel_size, int64_t num_voxels, const int32_t* keys, const double* sdf_refined, const double* albedo, const float* weight,
+                             const uint8_t* color, const int64_t* visit_rank /* or NULL */, float subvolume_size, int32_t num_subvolumes, const int32_t* subvolume_index /* [S][3] or NULL */,
+                             const double* subvolume_sh /* [S][9] or NULL */, uint8_t* color_out /* [n][3] */);
 int i3d_mc_tables(uint8_t* ntri /*[256]*/, int8_t* tri /*[256][16]*/);      /* the triangulation table (Bourke's, as in marching_cubes.cpp:330-623); returns max triangles per cell */
 
 /* ---- dataset loader in front of the path.  Host code except i3d_init_frames_from_sensor.

@@ -67,7 +67,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_export_grid", "i3d_refine",
            "i3d_tsdf_read_header", "i3d_tsdf_read_records", "i3d_tsdf_write", "i3d_sbr_write", "i3d_sbr_read", "i3d_write_poses",
            "i3d_write_intrinsics", "i3d_read_intrinsics", "i3d_config_load_yaml", "i3d_yaml_get",
-           "i3d_extract_mesh", "i3d_get_mesh", "i3d_export_mesh_ply", "i3d_write_ply", "i3d_mc_tables",
+           "i3d_extract_mesh", "i3d_get_mesh", "i3d_export_mesh_ply", "i3d_write_ply", "i3d_mc_tables", "i3d_visualization_colors",
            "i3d_png_info", "i3d_png_decode", "i3d_pose_mat_to_vec6", "i3d_sensor_open", "i3d_sensor_close", "i3d_sensor_info", "i3d_sensor_color",
            "i3d_sensor_depth", "i3d_sensor_pose", "i3d_sensor_set_pose", "i3d_sensor_set_pose_vec6", "i3d_sensor_save_poses",
            "i3d_mesh_remove_loose_components", "i3d_keyframes_load", "i3d_keyframes_save", "i3d_keyframes_select", "i3d_blur_score", "i3d_init_frames_from_sensor",
@@ -570,6 +570,22 @@ def mesh_remove_loose_components(vertices, colors, faces):
     nv, nf = C.c_int64(len(v)), C.c_int64(len(f))
     _io_check(load().i3d_mesh_remove_loose_components(C.byref(nv), _p(v), None if c is None else _p(c), C.byref(nf), _p(f)), "i3d_mesh_remove_loose_components")
     return v[:nv.value].copy(), (None if c is None else c[:nv.value].copy()), f[:nf.value].copy()
+
+
+COLOR_MODES = {"": 0, "albedo": 1, "normals": 2, "lap": 3, "lum": 4, "lum_grad": 5, "shading_sv": 6, "shading_sv_const": 7, "chroma": 8}   # SDFVisualization::getOutputModes' names
+
+
+def visualization_colors(mode, voxel_size, keys, sdf_refined, albedo, weight, color, subvolume_size=0.0, sub_index=None, sub_sh=None, visit_rank=None):
+    """SDFVisualization::applyColor<mode> on arrays (host instantiation of the export kernel's function) -> colours [n, 3]"""
+    k = np.ascontiguousarray(keys, np.int32); n = len(k); out = np.zeros((n, 3), np.uint8)
+    s = np.ascontiguousarray(sdf_refined, np.float64); a = np.ascontiguousarray(albedo, np.float64); w = np.ascontiguousarray(weight, np.float32); c = np.ascontiguousarray(color, np.uint8)
+    si = None if sub_index is None else np.ascontiguousarray(sub_index, np.int32); ss = None if sub_sh is None else np.ascontiguousarray(sub_sh, np.float64)
+    L = load(); L.i3d_visualization_colors.restype = C.c_int32
+    L.i3d_visualization_colors.argtypes = [C.c_int32, C.c_float, C.c_int64] + [C.c_void_p] * 6 + [C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    vr = None if visit_rank is None else np.ascontiguousarray(visit_rank, np.int64)
+    _io_check(L.i3d_visualization_colors(COLOR_MODES[mode] if isinstance(mode, str) else int(mode), float(voxel_size), n, _p(k), _p(s), _p(a), _p(w), _p(c), _p(vr), float(subvolume_size),
+                                         0 if si is None else len(si), _p(si), _p(ss), _p(out)), "i3d_visualization_colors")
+    return out
 
 
 def write_ply(path, vertices, colors, faces):

@@ -19,7 +19,9 @@ namespace i3d {
 // mesh_kernels.hip — marching cubes on the resident grid (one lane per voxel in visit order)
 void launch_mc_count(hipStream_t st, GridView g, HashTable t, const int* inv_rank, int refined, const unsigned char* ntri, int* counts);
 void launch_mc_emit(hipStream_t st, GridView g, HashTable t, const int* inv_rank, int refined, int color_mode, const unsigned char* ntri, const signed char* tri,
-                    int tri_stride, const int* offsets, float* pos, unsigned char* col);
+                    int tri_stride, const int* offsets, float* pos, unsigned char* col, const uchar4* mode_color /* or null */);
+// debug colour modes of SDFVisualization (vis_colors.hpp) painted per stored voxel, by device index
+void launch_vis_colors(hipStream_t st, GridView g, int mode, float subvolume_size, const unsigned long long* sub_keys, int S, const double* sub_sh, uchar4* out);
 }  // namespace i3d
 
 namespace i3d {

@@ -5,6 +5,7 @@
 // The triangulation table is Bourke's (host/mc_table.hpp, unpacked by host/mesh.cpp): the triangle sequence of a cell equals the reference's.
 #include "kernels.hpp"
 #include "level_kernels.hpp"
+#include "vis_colors.hpp"
 
 namespace i3d {
 
@@ -65,7 +66,8 @@ static __device__ inline float mc_lerp(float t0, float t1, float v0, float v1) {
 
 __global__ void __launch_bounds__(256) k_mc_emit(GridView g, HashTable t, const int* __restrict__ inv_rank, int refined, int color_mode,
                                                  const unsigned char* __restrict__ ntri, const signed char* __restrict__ tri, int tri_stride,
-                                                 const int* __restrict__ offsets, float* __restrict__ pos, unsigned char* __restrict__ col) {
+                                                 const int* __restrict__ offsets, float* __restrict__ pos, unsigned char* __restrict__ col,
+                                                 const uchar4* __restrict__ mode_color /* colour modes >= 2: what k_vis_colors painted, by device index */) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= g.N) return;
     int corner[8];
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(256) k_mc_emit(GridView g, HashTable t, const 
         pos[3 * o + 0] = mc_lerp(s1, s2, (float)g.cx[a] * g.voxel_size, (float)g.cx[b] * g.voxel_size);
         pos[3 * o + 1] = mc_lerp(s1, s2, (float)g.cy[a] * g.voxel_size, (float)g.cy[b] * g.voxel_size);
         pos[3 * o + 2] = mc_lerp(s1, s2, (float)g.cz[a] * g.voxel_size, (float)g.cz[b] * g.voxel_size);
-        uchar4 ca = g.color[a], cb = g.color[b];
+        uchar4 ca = mode_color ? mode_color[a] : g.color[a], cb = mode_color ? mode_color[b] : g.color[b];
         if (color_mode == 1) {                     // SDFVisualization::applyColorAlbedo: scalarToColor(albedo, 255) (visualization.cpp:308-315, color_util.cpp:70-78)
             const unsigned char ga = (unsigned char)fmin(fmax(g.x_alb[a] * 255.0, 0.0), 255.0), gb = (unsigned char)fmin(fmax(g.x_alb[b] * 255.0, 0.0), 255.0);
             ca = make_uchar4(ga, ga, ga, 0); cb = make_uchar4(gb, gb, gb, 0);
@@ -99,8 +101,53 @@ void launch_mc_count(hipStream_t st, GridView g, HashTable t, const int* inv_ran
     if (g.N > 0) k_mc_count<<<(g.N + 255) / 256, 256, 0, st>>>(g, t, inv_rank, refined, ntri, counts);
 }
 void launch_mc_emit(hipStream_t st, GridView g, HashTable t, const int* inv_rank, int refined, int color_mode, const unsigned char* ntri, const signed char* tri,
-                    int tri_stride, const int* offsets, float* pos, unsigned char* col) {
-    if (g.N > 0) k_mc_emit<<<(g.N + 255) / 256, 256, 0, st>>>(g, t, inv_rank, refined, color_mode, ntri, tri, tri_stride, offsets, pos, col);
+                    int tri_stride, const int* offsets, float* pos, unsigned char* col, const uchar4* mode_color) {
+    if (g.N > 0) k_mc_emit<<<(g.N + 255) / 256, 256, 0, st>>>(g, t, inv_rank, refined, mode_color ? 0 : color_mode, ntri, tri, tri_stride, offsets, pos, col, mode_color);
+}
+
+// SDFVisualization::applyColor* (sdf/visualization.cpp:228-416) for the debug colour modes: one lane per stored voxel, its 6-ring through the stencil table.
+// The arithmetic is vis_color() of vis_colors.hpp — the function the host entry point i3d_visualization_colors instantiates for the CPU tests.
+struct VisGridDev {                              // the accessors vis_lum_grad_px walks the resident grid with
+    const GridView& g;
+    __device__ long long px(long long i) const { return g.nbr[(size_t)NB_PX * g.N + i]; }
+    __device__ int rank(long long i) const { return g.rank[i]; }
+    __device__ bool ring(long long i) const {
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) { const int nb = g.nbr[(size_t)d * g.N + i]; ok = ok && nb >= 0 && g.weight[nb] > 0.0f; }      // NB_PX .. NB_MZ are 0..5
+        return ok;
+    }
+    __device__ void color(long long i, unsigned char c[3]) const { const uchar4 q = g.color[i]; c[0] = q.x; c[1] = q.y; c[2] = q.z; }
+};
+__global__ void __launch_bounds__(256) k_vis_colors(GridView g, int mode, float subvolume_size, const unsigned long long* __restrict__ sub_keys, int S,
+                                                    const double* __restrict__ sub_sh, uchar4* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= g.N) return;
+    const size_t N = g.N;
+    constexpr int RING[6] = {NB_PX, NB_MX, NB_PY, NB_MY, NB_PZ, NB_MZ};
+    VisStencil v;
+    v.valid[0] = g.weight[s] > 0.0f; v.sdf[0] = (float)g.x_sdf[s];
+    const uchar4 c = g.color[s]; v.color[0] = c.x; v.color[1] = c.y; v.color[2] = c.z;
+    v.color_px[0] = v.color_px[1] = v.color_px[2] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int nb = g.nbr[(size_t)RING[i] * N + s];
+        v.valid[i + 1] = nb >= 0 && g.weight[nb] > 0.0f;
+        v.sdf[i + 1] = nb >= 0 ? (float)g.x_sdf[nb] : 0.0f;
+        if (i == 0 && nb >= 0) { const uchar4 cn = g.color[nb]; v.color_px[0] = cn.x; v.color_px[1] = cn.y; v.color_px[2] = cn.z; }
+    }
+    v.albedo = g.x_alb[s];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v.sh[j] = 0.0f;
+    if (vis_mode_needs_sh(mode) && S > 0)              // voxelToWorld = float(i) * voxel_size (sparse_voxel_grid.cpp:224-228)
+        vis_interpolate_sh((float)g.cx[s] * g.voxel_size, (float)g.cy[s] * g.voxel_size, (float)g.cz[s] * g.voxel_size, subvolume_size, sub_keys, S, sub_sh, v.sh);
+    if (mode == VIS_INTENSITY_GRAD && v.valid[1] && v.valid[2] && v.valid[3] && v.valid[4] && v.valid[5] && v.valid[6]) vis_lum_grad_px(VisGridDev{g}, (long long)s, v.color_px);
+    unsigned char o[3];
+    vis_color(mode, v, g.truncation, o);
+    out[s] = make_uchar4(o[0], o[1], o[2], 0);
+}
+void launch_vis_colors(hipStream_t st, GridView g, int mode, float subvolume_size, const unsigned long long* sub_keys, int S, const double* sub_sh, uchar4* out) {
+    if (g.N > 0) k_vis_colors<<<(g.N + 255) / 256, 256, 0, st>>>(g, mode, subvolume_size, sub_keys, S, sub_sh, out);
 }
 
 }  // namespace i3d

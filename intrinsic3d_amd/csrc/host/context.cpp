@@ -198,7 +198,7 @@ int i3d_set_grid(i3d_context* c, const i3d_grid_view* gv) {
 
 namespace i3d {
 int set_grid_device(i3d_context* c, int N, float voxel_size, float truncation, GridStaging& g) {
-    c->N = N; c->voxel_size = voxel_size; c->truncation = truncation; c->have_grid = false; c->have_sh = false; c->assembled = false;
+    c->N = N; c->voxel_size = voxel_size; c->truncation = truncation; c->have_grid = false; c->have_sh = false; c->have_subvolumes = false; c->assembled = false;
     c->slots = 0;      // row storage is sized by N: force a re-allocation for the new grid
     hipStream_t st = c->stream;
     DevBuf<int> perm, iota; DevBuf<unsigned long long> skeys, skeys2;

@@ -57,6 +57,9 @@ struct i3d_context {
     i3d::DevBuf<unsigned char> scan_tmp; size_t scan_tmp_bytes = 0;
     i3d::DevBuf<unsigned long long> hkeys; i3d::DevBuf<int> hvals; unsigned int hmask = 0;     // device hash of the resident grid (kept for the level kernels)
     bool have_grid = false, have_sh = false;
+    // the lighting estimate behind `sh` (LightingSVSH::subvolumes() / shCoeffs()): packed subvolume indices (ascending), nine coefficients each, the subvolume size —
+    // what the "shading" colour modes of the mesh export interpolate at every voxel (SDFVisualization::applyColorShading)
+    std::vector<unsigned long long> sv_keys; std::vector<double> sv_sh; float sv_size = 0.0f; bool have_subvolumes = false;
 
     // ---- keyframes ----
     int K = 0, levels = 0;

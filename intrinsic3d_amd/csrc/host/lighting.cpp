@@ -264,6 +264,7 @@ int estimate_sh(i3d_context* c, float subvolume_size, double lambda_reg, double 
     CTX_HIP(c, hipStreamSynchronize(st));
     CTX_HIP(c, hipGetLastError());
     c->have_sh = true;
+    c->sv_keys = sub_keys; c->sv_sh = sh; c->sv_size = subvolume_size; c->have_subvolumes = true;
     if (num_subvolumes) *num_subvolumes = S;
     if (sh_out) std::memcpy(sh_out, sh.data(), sizeof(double) * (size_t)S * 9);
     if (sub_index) for (int i = 0; i < S; ++i) { int x2, y2, z2; unpack(sub_keys[i], x2, y2, z2); sub_index[3 * i] = x2; sub_index[3 * i + 1] = y2; sub_index[3 * i + 2] = z2; }

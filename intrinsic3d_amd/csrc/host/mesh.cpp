@@ -7,6 +7,7 @@
 // mc_table.hpp, so cells, triangles, faces and therefore the PLY stream are identical to the reference's, not just the vertex set.
 #include "context.hpp"
 #include "../device/level_kernels.hpp"
+#include "../device/vis_colors.hpp"
 #include "mc_table.hpp"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
@@ -83,6 +84,7 @@ static void remove_loose_components(MeshData& M) {
 
 int extract_mesh(i3d_context* c, int use_refined, int color_mode, int largest_only, MeshData& M, int64_t* raw_triangles) {
     if (!c->have_grid) return ctx_fail(c, I3D_ERR_STATE, "extract_mesh: no grid");
+    if (color_mode < 0 || color_mode >= VIS_NUM_MODES) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "extract_mesh: unknown colour mode");
     CTX_HIP(c, hipSetDevice(c->device));
     hipStream_t st = c->stream; const int N = c->N;
     const McTables& T = tables();
@@ -104,7 +106,21 @@ int extract_mesh(i3d_context* c, int use_refined, int color_mode, int largest_on
     if (nt == 0) return I3D_OK;                                      // extractMesh returns nullptr
     DevBuf<float> d_pos; DevBuf<unsigned char> d_col;
     CTX_HIP(c, d_pos.alloc(nt * 9)); CTX_HIP(c, d_col.alloc(nt * 9));
-    launch_mc_emit(st, g, ht, inv.p, use_refined, color_mode, d_ntri.p, d_tri.p, MC_STRIDE, offs.p, d_pos.p, d_col.p);
+    // colour modes >= 2 (SDFVisualization::colorize's debug views): paint every voxel first, the emit kernel interpolates what was painted
+    DevBuf<uchar4> d_mode; DevBuf<unsigned long long> d_svk; DevBuf<double> d_svs;
+    if (color_mode >= 2) {
+        int S = 0;
+        if (vis_mode_needs_sh(color_mode)) {                                              // applyColorShading without subvolumes paints nothing (:322-323): refuse instead
+            if (!c->have_subvolumes || c->sv_keys.empty()) return ctx_fail(c, I3D_ERR_STATE, "extract_mesh: the shading colour modes need a lighting estimate (i3d_estimate_sh / i3d_refine)");
+            S = (int)c->sv_keys.size();
+            CTX_HIP(c, d_svk.alloc(S)); CTX_HIP(c, d_svs.alloc((size_t)S * 9));
+            CTX_HIP(c, hipMemcpyAsync(d_svk.p, c->sv_keys.data(), sizeof(unsigned long long) * S, hipMemcpyHostToDevice, st));
+            CTX_HIP(c, hipMemcpyAsync(d_svs.p, c->sv_sh.data(), sizeof(double) * (size_t)S * 9, hipMemcpyHostToDevice, st));
+        }
+        CTX_HIP(c, d_mode.alloc(N));
+        launch_vis_colors(st, g, color_mode, c->sv_size, d_svk.p, S, d_svs.p, d_mode.p);
+    }
+    launch_mc_emit(st, g, ht, inv.p, use_refined, color_mode, d_ntri.p, d_tri.p, MC_STRIDE, offs.p, d_pos.p, d_col.p, d_mode.p);
     std::vector<float> pos(nt * 9); std::vector<uint8_t> col(nt * 9);
     CTX_HIP(c, hipMemcpyAsync(pos.data(), d_pos.p, sizeof(float) * nt * 9, hipMemcpyDeviceToHost, st));
     CTX_HIP(c, hipMemcpyAsync(col.data(), d_col.p, nt * 9, hipMemcpyDeviceToHost, st));
@@ -195,6 +211,55 @@ int i3d_export_mesh_ply(i3d_context* c, const char* path, int32_t use_refined_sd
     if (rc) return rc;
     if (M.vertices.empty()) return ctx_fail(c, I3D_ERR_STATE, "i3d_export_mesh_ply: mesh could not be generated (no iso-surface)");
     return i3d_write_ply(path, (int64_t)(M.vertices.size() / 3), M.vertices.data(), M.colors.data(), (int64_t)(M.faces.size() / 3), M.faces.data());
+}
+// SDFVisualization::applyColor* (sdf/visualization.cpp:228-416) on caller arrays: the colour every voxel gets in a colour mode (I3D_COLOR_*).  The voxels may come
+// in any order; visit_rank (or NULL: the array order) is the position of every voxel in the reference's walk over the grid, which only "lum_grad" depends on.
+// Host instantiation of the function the export kernel runs (device/vis_colors.hpp); neighbours through a map over the keys.
+int i3d_visualization_colors(int32_t color_mode, float voxel_size, int64_t n, const int32_t* keys, const double* sdf_refined, const double* albedo, const float* weight,
+                             const uint8_t* color, const int64_t* visit_rank, float subvolume_size, int32_t num_subvolumes, const int32_t* subvolume_index, const double* subvolume_sh,
+                             uint8_t* color_out) {
+    if (color_mode < 0 || color_mode >= VIS_NUM_MODES || n < 0 || !keys || !sdf_refined || !albedo || !weight || !color || !color_out) return I3D_ERR_INVALID_ARGUMENT;
+    if (vis_mode_needs_sh(color_mode) && (num_subvolumes <= 0 || !subvolume_index || !subvolume_sh)) return I3D_ERR_INVALID_ARGUMENT;
+    std::unordered_map<unsigned long long, int64_t> at; at.reserve((size_t)n * 2);
+    for (int64_t i = 0; i < n; ++i) at.emplace(vis_pack3(keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]), i);
+    std::vector<unsigned long long> sk; std::vector<double> ss;
+    if (vis_mode_needs_sh(color_mode)) {                                   // the interpolation looks subvolumes up by packed index: sort them
+        std::vector<int> order((size_t)num_subvolumes); std::iota(order.begin(), order.end(), 0);
+        std::vector<unsigned long long> raw((size_t)num_subvolumes);
+        for (int i = 0; i < num_subvolumes; ++i) raw[(size_t)i] = vis_pack3(subvolume_index[3 * i], subvolume_index[3 * i + 1], subvolume_index[3 * i + 2]);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return raw[(size_t)a] < raw[(size_t)b]; });
+        sk.resize((size_t)num_subvolumes); ss.resize((size_t)num_subvolumes * 9);
+        for (int i = 0; i < num_subvolumes; ++i) { sk[(size_t)i] = raw[(size_t)order[(size_t)i]]; std::memcpy(&ss[(size_t)i * 9], subvolume_sh + (size_t)order[(size_t)i] * 9, 9 * sizeof(double)); }
+    }
+    const float truncation = voxel_size * 5.0f;                            // sparse_voxel_grid.cpp:48
+    const int off[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    auto find = [&](int x, int y, int z) -> int64_t { const auto it = at.find(vis_pack3(x, y, z)); return it == at.end() ? -1 : it->second; };
+    struct HostGrid {                                                      // the accessors vis_lum_grad_px walks the arrays with
+        const int32_t* keys; const float* weight; const uint8_t* col; const int64_t* visit_rank; const decltype(find)& f; const int (*off)[3];
+        long long px(long long i) const { return f(keys[3 * i] + 1, keys[3 * i + 1], keys[3 * i + 2]); }
+        long long rank(long long i) const { return visit_rank ? visit_rank[i] : i; }
+        bool ring(long long i) const { bool ok = true; for (int d = 0; d < 6; ++d) { const int64_t nb = f(keys[3 * i] + off[d][0], keys[3 * i + 1] + off[d][1], keys[3 * i + 2] + off[d][2]); ok = ok && nb >= 0 && weight[nb] > 0.0f; } return ok; }
+        void color(long long i, unsigned char c[3]) const { for (int k = 0; k < 3; ++k) c[k] = col[3 * i + k]; }
+    } hg{keys, weight, color, visit_rank, find, off};
+    for (int64_t i = 0; i < n; ++i) {
+        const int x = keys[3 * i], y = keys[3 * i + 1], z = keys[3 * i + 2];
+        VisStencil v;
+        v.valid[0] = weight[i] > 0.0f; v.sdf[0] = (float)sdf_refined[i];
+        for (int k = 0; k < 3; ++k) { v.color[k] = color[3 * i + k]; v.color_px[k] = 0; }
+        for (int d = 0; d < 6; ++d) {
+            const int64_t nb = find(x + off[d][0], y + off[d][1], z + off[d][2]);
+            v.valid[d + 1] = nb >= 0 && weight[nb] > 0.0f;
+            v.sdf[d + 1] = nb >= 0 ? (float)sdf_refined[nb] : 0.0f;
+            if (d == 0 && nb >= 0) for (int k = 0; k < 3; ++k) v.color_px[k] = color[3 * nb + k];
+        }
+        v.albedo = albedo[i];
+        if (color_mode == VIS_INTENSITY_GRAD && v.valid[1] && v.valid[2] && v.valid[3] && v.valid[4] && v.valid[5] && v.valid[6]) vis_lum_grad_px(hg, (long long)i, v.color_px);
+        for (int j = 0; j < 9; ++j) v.sh[j] = 0.0f;
+        if (vis_mode_needs_sh(color_mode))
+            vis_interpolate_sh((float)x * voxel_size, (float)y * voxel_size, (float)z * voxel_size, subvolume_size, sk.data(), num_subvolumes, ss.data(), v.sh);
+        vis_color(color_mode, v, truncation, color_out + 3 * i);
+    }
+    return I3D_OK;
 }
 // the triangulation table the kernels use, for inspection / tests: ntri[256], tri[256][16] (edge ids, -1 padded); returns max triangles per cell
 int i3d_mc_tables(uint8_t* ntri, int8_t* tri) {

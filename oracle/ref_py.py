@@ -313,6 +313,20 @@ def albedo_colors(albedo):
     _raw().ref_albedo_colors(C.c_int64(len(a)), _p(a), _p(out)); return out
 
 
+def visualization_colors(mode, voxel_size, keys, sdf_refined, albedo, weight, color, subvolume_size=0.0, sub_index=None, sub_sh=None):
+    """SDFVisualization::applyColor<mode> of the reference on caller arrays -> (colours [n, 3], position of every voxel in the reference's walk over its grid)"""
+    k = np.ascontiguousarray(keys, np.int32); n = len(k); out = np.zeros((n, 3), np.uint8)
+    s = np.ascontiguousarray(sdf_refined, np.float64); a = np.ascontiguousarray(albedo, np.float64); w = np.ascontiguousarray(weight, np.float32); c = np.ascontiguousarray(color, np.uint8)
+    si = np.ascontiguousarray(sub_index if sub_index is not None else np.zeros((0, 3)), np.int32); ss = np.ascontiguousarray(sub_sh if sub_sh is not None else np.zeros((0, 9)), np.float64)
+    L = _raw(); L.ref_visualization_colors.restype = C.c_int32
+    L.ref_visualization_colors.argtypes = [C.c_char_p, C.c_float, C.c_int64] + [C.c_void_p] * 5 + [C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rank = np.zeros(n, np.int64)
+    rc = L.ref_visualization_colors(mode.encode(), float(voxel_size), n, _p(k), _p(s), _p(a), _p(w), _p(c), float(subvolume_size), len(si), _p(si), _p(ss), _p(out), _p(rank))
+    if rc < 0:
+        raise ValueError(mode)
+    return out, rank
+
+
 class InitModel:
     """Intrinsic3D::init of the reference on a dataset folder: keyframe ids, world-to-camera pose vectors, intrinsics, and the keyframe pyramids"""
 

@@ -380,6 +380,42 @@ void ref_mesh_remove_loose(void* mesh) { if (mesh) MeshUtil::removeLooseComponen
 int32_t ref_mesh_has_colors(void* mesh) { return (mesh && !((Mesh*)mesh)->colors.empty()) ? 1 : 0; }
 /* SDFVisualization::applyColorAlbedo's colour of a voxel: scalarToColor(albedo, 255.0) (color_util.cpp:70-80) */
 void ref_albedo_colors(int64_t n, const double* albedo, uint8_t* rgb) { for (int64_t i = 0; i < n; ++i) { const Vec3b c = scalarToColor(albedo[i], 255.0); rgb[3 * i] = c[0]; rgb[3 * i + 1] = c[1]; rgb[3 * i + 2] = c[2]; } }
+/* SDFVisualization::applyColor* (visualization.cpp:228-416) of the reference on a grid built from caller arrays (voxels inserted in the given order): the colour every
+ * voxel carries after the mode's method ran.  mode: "normals" | "lap" | "lum" | "lum_grad" | "albedo" | "shading_sv" | "shading_sv_const" | "chroma".  The shading
+ * modes run over the reference's own Subvolumes of the grid (compute()), whose coefficients are looked up by subvolume index in (sub_index, sub_sh); a subvolume
+ * that is not listed gets zeros.  Returns the number of subvolumes (0: not a shading mode), -1 for an unknown mode. */
+int32_t ref_visualization_colors(const char* mode, float voxel_size, int64_t n, const int32_t* keys, const double* sdf_refined, const double* albedo, const float* weight, const uint8_t* color,
+                                 float subvolume_size, int32_t n_sub, const int32_t* sub_index, const double* sub_sh, uint8_t* out, int64_t* visit_rank /* or NULL: position of voxel i in the grid's walk */) {
+    SparseVoxelGrid<VoxelSBR>* g = SparseVoxelGrid<VoxelSBR>::create(voxel_size);
+    for (int64_t i = 0; i < n; ++i) { VoxelSBR v; v.sdf = sdf_refined[i]; v.sdf_refined = sdf_refined[i]; v.albedo = albedo[i]; v.weight = weight[i];
+        v.color = Vec3b(color[3 * i], color[3 * i + 1], color[3 * i + 2]); g->setVoxel(Vec3i(keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]), v); }
+    if (visit_rank) {
+        std::unordered_map<Vec3i, int64_t, std::hash<Vec3i>> pos; int64_t r = 0;
+        for (auto it = g->begin(); it != g->end(); ++it, ++r) pos[it->first] = r;
+        for (int64_t i = 0; i < n; ++i) visit_rank[i] = pos[Vec3i(keys[3 * i], keys[3 * i + 1], keys[3 * i + 2])];
+    }
+    SDFVisualization vis(g, "unused");
+    const std::string m = mode; int32_t rc = 0;
+    if (m == "normals") vis.applyColorNormals();
+    else if (m == "lap") vis.applyColorLaplacian();
+    else if (m == "lum") vis.applyColorIntensity();
+    else if (m == "lum_grad") vis.applyColorIntensityGradient();
+    else if (m == "albedo") vis.applyColorAlbedo();
+    else if (m == "chroma") vis.applyColorChromacity();
+    else if (m == "shading_sv" || m == "shading_sv_const") {
+        Subvolumes sv(subvolume_size); sv.compute(g);
+        std::vector<Eigen::VectorXd> coeffs((size_t)sv.count());
+        for (int i = 0; i < (int)sv.count(); ++i) {
+            Eigen::VectorXd c = Eigen::VectorXd::Zero(9); const Vec3i idx = sv.index(i);
+            for (int k = 0; k < n_sub; ++k) if (sub_index[3 * k] == idx[0] && sub_index[3 * k + 1] == idx[1] && sub_index[3 * k + 2] == idx[2]) { for (int j = 0; j < 9; ++j) c[j] = sub_sh[9 * k + j]; break; }
+            coeffs[(size_t)i] = c;
+        }
+        vis.applyColorShading(&sv, coeffs, m == "shading_sv_const"); rc = (int32_t)sv.count();
+    } else rc = -1;
+    for (int64_t i = 0; i < n; ++i) { const Vec3b c = g->voxel(Vec3i(keys[3 * i], keys[3 * i + 1], keys[3 * i + 2])).color; out[3 * i] = c[0]; out[3 * i + 1] = c[1]; out[3 * i + 2] = c[2]; }
+    delete g;
+    return rc;
+}
 int32_t ref_mesh_save(void* mesh, const char* path) { Mesh* m = (Mesh*)mesh; return (m && m->save(path)) ? 1 : 0; }
 void ref_mesh_free(void* mesh) { delete (Mesh*)mesh; }
 // the two tables, for the case-by-case check of the product's packed copy

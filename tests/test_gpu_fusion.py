@@ -204,7 +204,9 @@ def test_app_intrinsic3d_equals_the_reference_application(tmp_path):
     """apps/app_intrinsic3d on a dataset folder against the reference's own AppIntrinsic3D flow (apps/src/app_intrinsic3d.cpp:71-210: SensorI3d, KeyframeSelection::load,
     SparseVoxelGrid::create(tsdf), Intrinsic3D::init / refine, onSDFRefined -> SDFVisualization::colorize, savePoses, Camera::save — all compiled into oracle/_ref) with
     `iterations: "0"`: the optimiser declines (optimizer.cpp:113-114) and both sides go on, so every stage's files depend only on loading, initialisation, thin
-    shell, lighting, recolouring, upsampling and export — and must agree byte for byte: three stages x (mesh, albedo mesh, poses, intrinsics)."""
+    shell, lighting, recolouring, upsampling and export — and must agree byte for byte: three stages x (the mesh in nine colour modes — voxel colours, normals, Laplacian,
+    intensity, intensity gradient (painted in place in the reference: depends on the walk over the grid), albedo, shading with the estimated / a constant albedo, chromacity —
+    poses, intrinsics) = 33 files."""
     import shutil
     import subprocess
     from intrinsic3d_amd import synthetic
@@ -215,6 +217,10 @@ def test_app_intrinsic3d_equals_the_reference_application(tmp_path):
     sc = synthetic.make_scene(radius_vox=10, K=4, width=96, height=72, levels=1, seed=9, pose_noise=(0.0005, 0.001), lum_noise=0.003)
     s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=2, rgbd_levels=2, iterations=0)
     import re
+    txt = open(i_yml).read(); assert 'subvolume_size_sh: "0.2"' in txt
+    open(i_yml, "w").write(txt.replace('subvolume_size_sh: "0.2"', 'subvolume_size_sh: "0.03"'))     # 3 cm subvolumes: the 8 cm object spans several (interpolated shading)
+    with open(i_yml, "a") as f:                                                        # every debug view of SDFVisualization::getOutputModes that can be reproduced
+        f.write("".join(f'output_mesh_{k}: "1"\n' for k in ("normals", "laplacian", "intensity", "intensity_grad", "shading_sv", "shading_sv_const", "chromacity")))
     cfg = dict(re.findall(r'^(\w+): "(.*)"$', open(i_yml).read(), re.M))
     out = tmp_path / "intrinsic3d"; out.mkdir(exist_ok=True)
     r = subprocess.run([os.path.join(ROOT, "apps", "app_intrinsic3d"), "-s", s_yml, "-i", i_yml], capture_output=True, text=True, timeout=600)
@@ -226,7 +232,8 @@ def test_app_intrinsic3d_equals_the_reference_application(tmp_path):
     finally:
         os.chdir(cwd)
     names = sorted(os.listdir(out))
-    assert names == sorted(f"{p}_{s}{e}" for s in ("g1_p1", "g1_p0", "g0_p0") for p, e in (("intrinsics", ".txt"), ("poses", ".txt"), ("mesh", ".ply"), ("mesh", "_albedo.ply")))
+    views = ("", "_normals", "_lap", "_lum", "_lum_grad", "_albedo", "_shading_sv", "_shading_sv_const", "_chroma")
+    assert names == sorted(f"{p}_{s}{e}" for s in ("g1_p1", "g1_p0", "g0_p0") for p, e in [("intrinsics", ".txt"), ("poses", ".txt")] + [("mesh", v + ".ply") for v in views])
     report = {n: (os.path.exists(ours / n) and open(ours / n, "rb").read() == open(out / n, "rb").read()) for n in names}
     if not all(report.values()) or sorted(os.listdir(ours)) != names:
         keep = os.path.join(ROOT, "gpurun_out", "app_i3d_mismatch")                        # (for a look afterwards)

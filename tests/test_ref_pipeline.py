@@ -669,3 +669,40 @@ def test_refinement_application_equals_the_oracle_pipeline(oracle, R, tmp_path):
     _, ac2, _ = B.mesh_remove_loose_components(*oracle.marching_cubes(g, True))
     assert (np.abs(acol.astype(int) - ac2.astype(int)) > 1).mean() < 1e-3 and acol.std() > 0
     g.free(); fr.free()
+
+
+@pytest.mark.parametrize("seed", [1, 7])
+def test_debug_colour_modes_equal_the_reference_visualization(R, seed):
+    """SDFVisualization::applyColorNormals / Laplacian / Intensity / IntensityGradient / Albedo / Shading (both) / Chromacity (sdf/visualization.cpp:228-373, compiled into
+    oracle/_ref with SDFOperators, Shading::computeShading and the reference's own Subvolumes) against i3d_visualization_colors — the host instantiation of the very
+    function the export kernel runs (device/vis_colors.hpp) — on a blob with holes, zero-weight voxels, black / saturated colours, albedos outside [0, 1] and
+    several subvolumes with missing neighbours: every voxel's colour, byte for byte."""
+    from intrinsic3d_amd import binding as B
+    from oracle import ref_py
+    rng = np.random.default_rng(seed)
+    vs = 0.004; r = 9
+    g = np.stack(np.meshgrid(*[np.arange(-r, r + 1)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    d = np.linalg.norm(g + 0.3, axis=1) - 6.2
+    keep = (np.abs(d) < 2.6) & (rng.random(len(g)) > 0.04)                              # a shell with holes
+    keys = (g[keep] + np.array([40, -3, 7])).astype(np.int32); n = len(keys)
+    keys = keys[rng.permutation(n)]
+    sdf = (np.linalg.norm(keys - np.array([40, -3, 7]) + 0.3, axis=1) - 6.2) * vs + rng.normal(0, 0.15 * vs, n)
+    w = rng.uniform(0.5, 30, n).astype(np.float32); w[rng.random(n) < 0.05] = 0.0       # invalid voxels
+    alb = rng.uniform(-0.1, 1.2, n); alb[rng.random(n) < 0.02] = 0.0
+    col = rng.integers(0, 256, (n, 3)).astype(np.uint8); col[rng.random(n) < 0.03] = 0; col[rng.random(n) < 0.03] = 255
+    size = 0.0131                                                                        # subvolumes of 3.3 voxels
+    sub = np.unique(np.floor((keys.astype(np.float32) * np.float32(vs)) * (np.float32(1.0) / np.float32(size))).astype(np.int32), axis=0)
+    sub = sub[rng.permutation(len(sub))]
+    sh = np.concatenate([rng.uniform(0.4, 1.1, (len(sub), 1)), rng.normal(0, 0.35, (len(sub), 8))], 1)
+    for mode in ("normals", "lap", "lum", "lum_grad", "albedo", "chroma", "shading_sv", "shading_sv_const"):
+        ref, rank = ref_py.visualization_colors(mode, vs, keys, sdf, alb, w, col, size, sub, sh)
+        got = B.visualization_colors(mode, vs, keys, sdf, alb, w, col, size, sub, sh, visit_rank=rank)
+        assert np.array_equal(got, ref), (mode, int((got != ref).any(1).sum()), n)
+        if mode == "lum_grad":      # painted in place while the grid is walked: a voxel reads its +x neighbour REPAINTED if the walk passed that one earlier — the walk's order matters
+            assert not np.array_equal(B.visualization_colors(mode, vs, keys, sdf, alb, w, col, size, sub, sh), ref) and sorted(rank) == list(range(n))
+        assert len(np.unique(ref)) > (2 if mode == "lum_grad" else 20), mode             # the mode painted something
+    assert len(sub) > 20
+    k2 = keys + np.array([0, 30, 10], np.int32)                                          # all coordinates positive: ONE subvolume of 10 m, whose coefficients are used as they are
+    one, _ = ref_py.visualization_colors("shading_sv", vs, k2, sdf, alb, w, col, 10.0, np.zeros((1, 3), np.int32), sh[:1])
+    assert np.array_equal(B.visualization_colors("shading_sv", vs, k2, sdf, alb, w, col, 10.0, np.zeros((1, 3), np.int32), sh[:1]), one) and one.any()
+    assert np.array_equal(B.visualization_colors("", vs, keys, sdf, alb, w, col), col)
