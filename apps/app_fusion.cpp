@@ -41,8 +41,8 @@ int main(int argc, char* argv[]) {
     mkdir("./fusion", 0755);
 
     i3d_sensor* sensor = nullptr;
-    const float depth_min = yamlf(sensor_cfg, "min_depth"), depth_max = yamlf(sensor_cfg, "max_depth");
-    int rc = i3d_sensor_open(yaml(sensor_cfg, "dataset").c_str(), std::atoi(yaml(sensor_cfg, "max_frames", "0").c_str()), depth_min, depth_max, &sensor);
+    float depth_min = 0.0f, depth_max = 0.0f;
+    int rc = i3d_sensor_open_yaml(sensor_cfg.c_str(), &sensor, &depth_min, &depth_max);                    // Sensor::create(sensor_cfg)
     int32_t num_frames = 0, num_loaded = 0, cwh[2] = {0, 0}, dwh[2] = {0, 0}; float ci[4], di[4];
     if (rc == I3D_OK) i3d_sensor_info(sensor, &num_frames, &num_loaded, cwh, dwh, ci, di);
     if (rc != I3D_OK || num_loaded == 0) { std::fprintf(stderr, "RGB-D sensor could not be initialized!\n"); return 1; }

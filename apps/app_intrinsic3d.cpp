@@ -91,9 +91,7 @@ int main(int argc, char* argv[]) {
     mkdir("./intrinsic3d", 0755);
 
     App app; app.cfg_file = i3d_cfg;
-    const std::string dataset = yaml(sensor_cfg, "dataset");
-    int rc = i3d_sensor_open(dataset.c_str(), std::atoi(yaml(sensor_cfg, "max_frames", "0").c_str()), (float)std::atof(yaml(sensor_cfg, "min_depth", "0").c_str()),
-                             (float)std::atof(yaml(sensor_cfg, "max_depth", "0").c_str()), &app.sensor);
+    int rc = i3d_sensor_open_yaml(sensor_cfg.c_str(), &app.sensor, nullptr, nullptr);                      // Sensor::create(sensor_cfg)
     int32_t num_frames = 0, num_loaded = 0, cwh[2] = {0, 0};
     if (rc == I3D_OK) i3d_sensor_info(app.sensor, &num_frames, &num_loaded, cwh, nullptr, nullptr, nullptr);
     if (rc != I3D_OK || num_loaded == 0) { std::fprintf(stderr, "RGB-D sensor could not be initialized!\n"); return 1; }

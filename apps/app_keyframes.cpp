@@ -35,8 +35,7 @@ int main(int argc, char* argv[]) {
     mkdir("./fusion", 0755);
 
     i3d_sensor* sensor = nullptr;
-    int rc = i3d_sensor_open(yaml(sensor_cfg, "dataset").c_str(), std::atoi(yaml(sensor_cfg, "max_frames", "0").c_str()), (float)std::atof(yaml(sensor_cfg, "min_depth", "0").c_str()),
-                             (float)std::atof(yaml(sensor_cfg, "max_depth", "0").c_str()), &sensor);
+    int rc = i3d_sensor_open_yaml(sensor_cfg.c_str(), &sensor, nullptr, nullptr);                          // Sensor::create(sensor_cfg)
     int32_t num_frames = 0, num_loaded = 0, cwh[2] = {0, 0};
     if (rc == I3D_OK) i3d_sensor_info(sensor, &num_frames, &num_loaded, cwh, nullptr, nullptr, nullptr);
     if (rc != I3D_OK || num_loaded == 0) { std::fprintf(stderr, "RGB-D sensor could not be initialized!\n"); return 1; }

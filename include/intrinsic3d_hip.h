@@ -233,6 +233,9 @@ int i3d_pose_mat_to_vec6(const float* cam_to_world16, double* pose6);
  * `{depth,color}Intrinsics.txt` of `folder`; max_frames / min_depth / max_depth as in sensor.yml (0 = off) */
 typedef struct i3d_sensor i3d_sensor;
 int  i3d_sensor_open(const char* folder, int32_t max_frames, float min_depth, float max_depth, i3d_sensor** out);
+/* Sensor::create(Settings&) (rgbd/sensor.cpp:64-118) over a sensor.yml: keys dataset, max_frames, min_depth, max_depth, converted like Settings::get<T> (settings.cpp:86-109);
+ * the depth range read from the file is handed back (AppFusion sizes its volume with it, app_fusion.cpp:131-133). */
+int  i3d_sensor_open_yaml(const char* sensor_yml, i3d_sensor** out, float* min_depth /* may be NULL */, float* max_depth /* may be NULL */);
 void i3d_sensor_close(i3d_sensor* s);
 int  i3d_sensor_info(const i3d_sensor* s, int32_t* num_frames, int32_t* num_loaded, int32_t* color_wh /*[2]*/, int32_t* depth_wh /*[2]*/,
                      float* color_intr4 /* fx fy cx cy */, float* depth_intr4);

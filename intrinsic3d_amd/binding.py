@@ -68,7 +68,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_tsdf_read_header", "i3d_tsdf_read_records", "i3d_tsdf_write", "i3d_sbr_write", "i3d_sbr_read", "i3d_write_poses",
            "i3d_write_intrinsics", "i3d_read_intrinsics", "i3d_config_load_yaml", "i3d_yaml_get",
            "i3d_extract_mesh", "i3d_get_mesh", "i3d_export_mesh_ply", "i3d_write_ply", "i3d_mc_tables", "i3d_visualization_colors",
-           "i3d_png_info", "i3d_png_decode", "i3d_pose_mat_to_vec6", "i3d_sensor_open", "i3d_sensor_close", "i3d_sensor_info", "i3d_sensor_color",
+           "i3d_png_info", "i3d_png_decode", "i3d_pose_mat_to_vec6", "i3d_sensor_open", "i3d_sensor_open_yaml", "i3d_sensor_close", "i3d_sensor_info", "i3d_sensor_color",
            "i3d_sensor_depth", "i3d_sensor_pose", "i3d_sensor_set_pose", "i3d_sensor_set_pose_vec6", "i3d_sensor_save_poses",
            "i3d_mesh_remove_loose_components", "i3d_keyframes_load", "i3d_keyframes_save", "i3d_keyframes_select", "i3d_blur_score", "i3d_init_frames_from_sensor",
            "i3d_fusion_create", "i3d_fusion_destroy", "i3d_fusion_last_error", "i3d_fusion_integrate", "i3d_fusion_finish", "i3d_fusion_info", "i3d_fusion_get",
@@ -670,9 +670,15 @@ def keyframes_select(window_size, scores):
 class Sensor:
     """Sensor::create on an Intrinsic3D dataset folder (rgbd/sensor_i3d.cpp); decoding happens on demand, like the reference"""
 
-    def __init__(self, folder, max_frames=0, min_depth=0.0, max_depth=0.0):
-        self.L = load(); self.h = C.c_void_p()
-        _io_check(self.L.i3d_sensor_open(str(folder).encode(), int(max_frames), float(min_depth), float(max_depth), C.byref(self.h)), "i3d_sensor_open")
+    def __init__(self, folder=None, max_frames=0, min_depth=0.0, max_depth=0.0, yml=None):
+        self.L = load(); self.h = C.c_void_p(); self.depth_range = (float(min_depth), float(max_depth))
+        if yml is not None:                                           # Sensor::create(Settings(sensor.yml))
+            lo = C.c_float(); hi = C.c_float()
+            self.L.i3d_sensor_open_yaml.restype = C.c_int32; self.L.i3d_sensor_open_yaml.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+            _io_check(self.L.i3d_sensor_open_yaml(str(yml).encode(), C.byref(self.h), C.byref(lo), C.byref(hi)), "i3d_sensor_open_yaml")
+            self.depth_range = (lo.value, hi.value)
+        else:
+            _io_check(self.L.i3d_sensor_open(str(folder).encode(), int(max_frames), float(min_depth), float(max_depth), C.byref(self.h)), "i3d_sensor_open")
         nf = C.c_int32(); nl = C.c_int32(); cwh = np.zeros(2, np.int32); dwh = np.zeros(2, np.int32); ci = np.zeros(4, np.float32); di = np.zeros(4, np.float32)
         _io_check(self.L.i3d_sensor_info(self.h, C.byref(nf), C.byref(nl), _p(cwh), _p(dwh), _p(ci), _p(di)), "i3d_sensor_info")
         self.num_frames, self.num_loaded = nf.value, nl.value

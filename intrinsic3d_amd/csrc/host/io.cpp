@@ -207,6 +207,23 @@ int i3d_config_load_yaml(const char* path, i3d_refine_config* rc, i3d_optimizer_
 }
 
 
+// Sensor::create(Settings&) (rgbd/sensor.cpp:64-118) over a sensor.yml: `dataset` names the folder, `max_frames` / `min_depth` / `max_depth` configure the sensor before
+// it is initialised.  Values are converted the way Settings::get<T> does it (settings.cpp:86-109): a missing key reads as "0" ("" for the folder), numbers through the
+// stream extraction rules (leading number, direct rounding to float), the folder up to its first white space.
+int i3d_sensor_open_yaml(const char* sensor_yml, i3d_sensor** out, float* min_depth, float* max_depth) {
+    if (!sensor_yml || !out) return I3D_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    std::map<std::string, std::string> kv;
+    if (!read_flat_yaml(sensor_yml, kv) || kv.empty()) return I3D_ERR_IO;                 // Settings::empty(): no sensor
+    auto text = [&](const char* key, const char* missing) { const auto it = kv.find(key); return it == kv.end() ? std::string(missing) : it->second; };
+    std::string folder; { std::stringstream ss(text("dataset", "")); ss >> folder; }
+    int max_frames = 0; { std::stringstream ss(text("max_frames", "0")); ss >> max_frames; }
+    float dmin = 0.0f, dmax = 0.0f; { std::stringstream ss(text("min_depth", "0")); ss >> dmin; } { std::stringstream ss(text("max_depth", "0")); ss >> dmax; }
+    if (min_depth) *min_depth = dmin;
+    if (max_depth) *max_depth = dmax;
+    return i3d_sensor_open(folder.c_str(), max_frames, dmin, dmax, out);
+}
+
 // Settings::get<std::string>(key) (the apps' accessor over cv::FileStorage): the value as text; I3D_ERR_INVALID_ARGUMENT when the key is absent
 int i3d_yaml_get(const char* path, const char* key, char* value, uint64_t capacity) {
     if (!path || !key || !value || capacity == 0) return I3D_ERR_INVALID_ARGUMENT;

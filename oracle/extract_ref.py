@@ -82,6 +82,7 @@ CHUNKS = [
     ("app_fusion_fuse",      "../apps/src/app_fusion.cpp", 107, 200, "bool AppFusion::fuseSDF", "}"),
     ("sensor_class",         "include/nv/rgbd/sensor.h", 49, 112, "class Sensor", "};"),
     ("sensor_ctor",          "src/rgbd/sensor.cpp", 50, 63, "Sensor::Sensor() :", "}"),
+    ("sensor_create",        "src/rgbd/sensor.cpp", 66, 118, "Sensor* Sensor::create(const std::string &dataset, Settings &cfg)", "}"),
     ("sensor_access",        "src/rgbd/sensor.cpp", 121, 220, "const Camera& Sensor::depthCamera() const", "}"),
     ("sensor_poses",         "src/rgbd/sensor.cpp", 235, 347, "bool Sensor::loadPoses", "}"),
     ("sensor_i3d_class",     "include/nv/rgbd/sensor_i3d.h", 50, 88, "class SensorI3d : public Sensor", "};"),

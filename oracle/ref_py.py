@@ -235,12 +235,19 @@ def _install_pillow_decoder(L):
 class Sensor:
     """SensorI3d::init on a dataset folder + Sensor::depth / color / pose"""
 
-    def __init__(self, folder, max_frames=0, min_depth=0.0, max_depth=0.0):
+    def __init__(self, folder=None, max_frames=0, min_depth=0.0, max_depth=0.0, cfg=None):
         self.L = C.CDLL(LIB_PATH); _install_pillow_decoder(self.L)
-        self.L.ref_sensor_open.restype = C.c_void_p; self.L.ref_sensor_depth.restype = C.c_int64; self.L.ref_sensor_color.restype = C.c_int64
+        self.L.ref_sensor_open.restype = C.c_void_p; self.L.ref_sensor_create.restype = C.c_void_p; self.L.ref_sensor_depth.restype = C.c_int64; self.L.ref_sensor_color.restype = C.c_int64
         for f in ("ref_sensor_info", "ref_sensor_pose", "ref_sensor_depth", "ref_sensor_color", "ref_sensor_free"):
             getattr(self.L, f).argtypes = None
-        h = self.L.ref_sensor_open(str(folder).encode(), C.c_int32(max_frames), C.c_float(min_depth), C.c_float(max_depth))
+        self.depth_range = (float(min_depth), float(max_depth)); self.max_frames = max_frames
+        if cfg is not None:                                           # Sensor::create(Settings&) with the strings of a sensor.yml
+            ks = [str(k).encode() for k in cfg]; vs = [str(v).encode() for v in cfg.values()]
+            r2 = np.zeros(2, np.float32); mf = C.c_int32()
+            h = self.L.ref_sensor_create(C.c_int32(len(ks)), (C.c_char_p * len(ks))(*ks), (C.c_char_p * len(vs))(*vs), _p(r2), C.byref(mf))
+            self.depth_range = (float(r2[0]), float(r2[1])); self.max_frames = mf.value
+        else:
+            h = self.L.ref_sensor_open(str(folder).encode(), C.c_int32(max_frames), C.c_float(min_depth), C.c_float(max_depth))
         self.h = C.c_void_p(h) if h else None
         if self.h is None:
             raise RuntimeError("SensorI3d::init failed")

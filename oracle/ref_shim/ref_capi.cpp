@@ -157,6 +157,7 @@ static double chroma_weight(const Vec3b& color, const Vec3b& color_nb) {     // 
 #include "gen/sensor_poses.inc"
 #include "gen/sensor_i3d_class.inc"
 #include "gen/sensor_i3d_impl.inc"
+#include "gen/sensor_create.inc"
 class HolderSensor : public Sensor {
 public:
     void setPose(int, const Mat4f&) override {}
@@ -780,6 +781,14 @@ void* ref_sensor_open(const char* folder, int32_t max_frames, float depth_min, f
     const bool ok = s->init(folder);
     std::cout.rdbuf(o1); std::cerr.rdbuf(o2);
     if (!ok) { delete s; return nullptr; }
+    return s;
+}
+/* Sensor::create(Settings&) (rgbd/sensor.cpp:64-118) with the (key, value) strings of a sensor.yml; range2 = depthMin(), depthMax() of what it built */
+void* ref_sensor_create(int32_t n, const char* const* keys, const char* const* values, float* range2, int32_t* max_frames) {
+    CoutSilencer quiet;
+    Settings cfg; for (int i = 0; i < n; ++i) cfg.set<std::string>(keys[i], values[i]);
+    Sensor* s = Sensor::create(cfg);
+    if (s) { range2[0] = s->depthMin(); range2[1] = s->depthMax(); *max_frames = s->numFramesMax(); }
     return s;
 }
 void ref_sensor_info(void* h, int32_t* num_frames, int32_t* num_stored, int32_t* cwh, int32_t* dwh, float* ci4, float* di4) {

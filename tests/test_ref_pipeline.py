@@ -706,3 +706,32 @@ def test_debug_colour_modes_equal_the_reference_visualization(R, seed):
     one, _ = ref_py.visualization_colors("shading_sv", vs, k2, sdf, alb, w, col, 10.0, np.zeros((1, 3), np.int32), sh[:1])
     assert np.array_equal(B.visualization_colors("shading_sv", vs, k2, sdf, alb, w, col, 10.0, np.zeros((1, 3), np.int32), sh[:1]), one) and one.any()
     assert np.array_equal(B.visualization_colors("", vs, keys, sdf, alb, w, col), col)
+
+
+def test_sensor_yml_equals_the_reference_factory(R, tmp_path):
+    """Sensor::create(Settings&) (rgbd/sensor.cpp:64-118 over Settings::get<T>, settings.cpp:86-109) against i3d_sensor_open_yaml — what the three applications open
+    their sensor.yml with: key names, missing keys, the stream conversions (leading number of "2abc", exponent notation, a folder name cut at its first blank)."""
+    from intrinsic3d_amd import binding as B
+    from oracle import ref_py
+    folder, vs, n = helpers.axis_camera_dataset(tmp_path)
+    cases = [{"dataset": str(folder), "max_frames": "3", "min_depth": "0.45", "max_depth": "2.5"},
+             {"dataset": str(folder) + "/"},                                              # nothing else: no frame limit, no depth range
+             {"dataset": str(folder), "max_frames": "2abc", "min_depth": "1e-1", "max_depth": "0.7000001", "unrelated": "x"},
+             {"dataset": str(folder), "max_frames": "0", "min_depth": ".3", "max_depth": "10"}]
+    for i, cfg in enumerate(cases):
+        yml = tmp_path / f"sensor{i}.yml"
+        yml.write_text("%YAML:1.0\n\n# rgbd sensor config\n" + "".join(f'{k}: "{v}"\n' for k, v in cfg.items()))
+        r = ref_py.Sensor(cfg=cfg); s = B.Sensor(yml=yml)
+        assert (s.num_frames, s.num_loaded) == (r.num_frames, r.num_stored), (i, s.num_frames, r.num_frames)
+        assert s.depth_range == r.depth_range, (i, s.depth_range, r.depth_range)
+        assert np.array_equal(s.depth(0), r.depth(0)) and np.array_equal(s.color(s.num_loaded - 1), r.color(r.num_stored - 1))
+        s.close(); r.close()
+    assert ref_py.Sensor(cfg=cases[2]).num_stored == 2 and ref_py.Sensor(cfg=cases[1]).num_stored == n
+    spaced = tmp_path / "with blank"; os.symlink(folder, spaced)
+    bad = {"dataset": str(spaced), "max_frames": "0"}                                    # Settings::get<std::string> stops at the blank: a folder that does not exist
+    (tmp_path / "bad.yml").write_text("%YAML:1.0\n" + "".join(f'{k}: "{v}"\n' for k, v in bad.items()))
+    r = ref_py.Sensor(cfg=bad); s = B.Sensor(yml=tmp_path / "bad.yml")                    # ... which both sides open as a sensor without frames (the applications stop there)
+    assert (r.num_frames, r.num_stored) == (0, 0) == (s.num_frames, s.num_loaded)
+    (tmp_path / "empty.yml").write_text("%YAML:1.0\n")                                    # Settings::empty(): no sensor
+    with pytest.raises(B.I3DError):
+        B.Sensor(yml=tmp_path / "empty.yml")
