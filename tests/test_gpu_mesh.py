@@ -193,3 +193,37 @@ def test_mesh_identical_to_the_oracle_and_the_reference_code(oracle, tmp_path):
             v3, c3, f3 = ctx.extract_mesh(use_refined_sdf=False, color_mode=1, largest_component_only=False)
         assert v3.tobytes() == av.tobytes() and f3.tobytes() == af.tobytes(), (len(v3), len(av), len(f3), len(af))
         assert c3.tobytes() == ac.tobytes(), (int((c3 != ac).sum()), c3[(c3 != ac).any(1)][:4], ac[(c3 != ac).any(1)][:4])
+
+
+def test_export_colour_modes_device_equals_host_instantiation(tmp_path):
+    """the debug colour modes of the export (k_vis_colors: the device instantiation of vis_colors.hpp) against i3d_visualization_colors (the host instantiation the CPU
+    suite holds to the reference's SDFVisualization) on a grid with holes, zero-weight voxels, random colours and several lighting subvolumes: a mesh exported in mode
+    X must equal, byte for byte, the plain export of the same grid repainted with the host's colours for X.  Plus the two refusals."""
+    from intrinsic3d_amd import binding
+    rng = np.random.default_rng(5)
+    vs = 0.004; r = 11
+    g = np.stack(np.meshgrid(*[np.arange(-r, r + 1)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    d = np.linalg.norm(g + 0.3, axis=1) - 7.3
+    keep = (np.abs(d) < 2.6) & (rng.random(len(g)) > 0.03)
+    keys = (g[keep] + np.array([31, -4, 12])).astype(np.int32); n = len(keys); keys = keys[rng.permutation(n)]
+    sdf = (np.linalg.norm(keys - np.array([31, -4, 12]) + 0.3, axis=1) - 7.3) * vs + rng.normal(0, 0.1 * vs, n)
+    w = rng.uniform(0.5, 30, n).astype(np.float32); w[rng.random(n) < 0.04] = 0.0
+    alb = rng.uniform(0.05, 1.1, n); col = rng.integers(0, 256, (n, 3)).astype(np.uint8); col[rng.random(n) < 0.03] = 0
+    size = 0.02
+    with binding.Context(0) as ctx:
+        ctx.set_grid(vs, keys, sdf, sdf, alb, w, col)
+        with pytest.raises(binding.I3DError):
+            ctx.export_mesh_ply(tmp_path / "x.ply", True, 6, False)                      # a shading view before any lighting estimate
+        with pytest.raises(binding.I3DError):
+            ctx.export_mesh_ply(tmp_path / "x.ply", True, 9, False)                      # no such mode
+        sh, idx, _ = ctx.estimate_sh(size, 10.0, 2.0 * vs)
+        assert len(sh) > 8
+        for mode, mid in binding.COLOR_MODES.items():
+            if mid == 0:
+                continue
+            ctx.export_mesh_ply(tmp_path / "dev.ply", True, mid, False)
+            host = binding.visualization_colors(mode, vs, keys, sdf, alb, w, col, size, idx, sh, visit_rank=np.arange(n))      # the visit order is the order the grid was handed over in
+            ctx.update_grid(color=host); ctx.export_mesh_ply(tmp_path / "host.ply", True, 0, False); ctx.update_grid(color=col)
+            a = open(tmp_path / "dev.ply", "rb").read(); b = open(tmp_path / "host.ply", "rb").read()
+            assert a == b and len(a) > 10000, (mode, len(a), len(b))
+            assert len(np.unique(host)) > 3, mode
