@@ -611,16 +611,33 @@ def _read_ply(path):
     return vt["p"].copy(), vt["c"].copy(), ft["i"].copy()
 
 
-def test_refinement_application_equals_the_oracle_pipeline(oracle, R, tmp_path):
+APP_CASES = {
+    # grid levels, pyramid levels, iterations, non-keyframes appended, half-resolution depth camera, intrinsic3d.yml overrides
+    "two_levels": (2, 2, 1, 0, False, {}),
+    "three_levels_fixed_distortion_skipped_frames": (3, 3, 2, 2, False, {"fix_distortion": 1}),
+    "constant_albedo_no_clearing_half_res_depth": (2, 1, 1, 0, True, {"lambda_a": -1.0, "clear_distant_voxels": 0, "thin_shell_factor_final": 0.0, "num_observations": 3,
+                                                                      "occlusion_distance": 0.01, "subvolume_size_sh": 0.03, "fix_poses": 1}),
+}
+
+
+@pytest.mark.parametrize("case", list(APP_CASES))
+def test_refinement_application_equals_the_oracle_pipeline(oracle, R, tmp_path, case):
     """AppIntrinsic3D::run + onSDFRefined (apps/src/app_intrinsic3d.cpp:71-210) of the reference, compiled into oracle/_ref over its own SensorI3d, KeyframeSelection,
-    SparseVoxelGrid::load / create(tsdf -> sbr), Intrinsic3D::init / refine, SDFVisualization and MarchingCubes, on a dataset folder in the reference's layout
-    (2 grid levels x (2, 1) pyramid levels, one iteration each) — against the oracle's pieces composed from the SAME files: which output files appear under which
-    names, the final poses / intrinsics text, and the last level's mesh in both colour modes."""
+    SparseVoxelGrid::load / create(tsdf -> sbr), Intrinsic3D::init / refine, SDFVisualization and MarchingCubes, on a dataset folder in the reference's layout —
+    against the oracle's pieces composed from the SAME files: which output files appear under which names, the final poses / intrinsics text, and the last level's
+    mesh in both colour modes.  Cases: the level schedule (2 x (2, 1) and 3 x (3, 2, 1) stages), frames that are not keyframes, a depth camera at half the colour
+    resolution (resizeDepth proper), fixed parameter groups, constant albedo, no voxel clearing with a constant shell factor, 3 observations, small subvolumes."""
+    from PIL import Image
     from intrinsic3d_amd import binding as B, synthetic
     from oracle import ref_py
     import make_dataset
+    GL, PL, iters, extra, half_depth, over = APP_CASES[case]
     sc = synthetic.make_scene(radius_vox=10, K=4, width=96, height=72, levels=1, seed=9, pose_noise=(0.0005, 0.001), lum_noise=0.003)
-    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=2, rgbd_levels=2, iterations=1)
+    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=GL, rgbd_levels=PL, iterations=iters, extra_frames=extra, **over)
+    if half_depth:                                                                      # depth maps at 48 x 36 with their own intrinsics
+        K = np.loadtxt(tmp_path / "rgbd" / "depthIntrinsics.txt"); K[:2, :3] *= 0.5; np.savetxt(tmp_path / "rgbd" / "depthIntrinsics.txt", K, fmt="%.9g")
+        for f in sorted((tmp_path / "rgbd").glob("*.depth.png")):
+            Image.fromarray(np.asarray(Image.open(f))[::2, ::2].copy()).save(f)
     cfg = dict(re.findall(r'^(\w+): "(.*)"$', open(i_yml).read(), re.M))
     (tmp_path / "intrinsic3d").mkdir(exist_ok=True)
     cwd = os.getcwd(); os.chdir(tmp_path)                                              # (the reference application changes into the sensor config's directory)
@@ -629,45 +646,65 @@ def test_refinement_application_equals_the_oracle_pipeline(oracle, R, tmp_path):
     finally:
         os.chdir(cwd)
     out = tmp_path / "intrinsic3d"
-    stages = ("g1_p1", "g1_p0", "g0_p0")                                                # grid level 1 is the coarse one: it runs both pyramid levels, level 0 only the finest
+    # the coarsest grid level runs every pyramid level, the finer ones only the finest (intrinsic3d.cpp:243-246); level numbers count down to 0
+    stages = [f"g{GL - 1}_p{p}" for p in range(PL - 1, -1, -1)] + [f"g{g}_p0" for g in range(GL - 2, -1, -1)]
     assert sorted(os.listdir(out)) == sorted(f"{p}_{s}{e}" for s in stages for p, e in (("intrinsics", ".txt"), ("poses", ".txt"), ("mesh", ".ply"), ("mesh", "_albedo.ply")))
 
     # the same run on the oracle, from the same files
     s = B.Sensor(tmp_path / "rgbd", 0, 0.1, 10.0)
-    kf = B.keyframes_load(str(tmp_path / "fusion" / "keyframes.txt"))[2]; assert kf.all()
+    kf = B.keyframes_load(str(tmp_path / "fusion" / "keyframes.txt"))[2]; assert kf.sum() == 4 and len(kf) == 4 + extra
     vol = B.tsdf_read(str(tmp_path / "fusion" / os.path.basename(cfg["input_sdf"])))
     # (the start poses are taken from the reference's own init: this little scene leaves poses and distortion weakly determined, and the 1e-13 by which Eigen's 4x4
     #  inverse differs from the product's — test_refinement_initialisation — grows to 1e-2 through three optimisations)
-    m = ref_py.InitModel(tmp_path / "rgbd", kf, 2, 0, 0.1, 10.0); poses = np.array(m.poses); m.close()
+    m = ref_py.InitModel(tmp_path / "rgbd", kf, PL, 0, 0.1, 10.0); poses = np.array(m.poses); m.close()
     frames = []
     for f in range(s.num_frames):
-        bgr = s.color(f); lum = oracle.lum_from_bgr(bgr)
-        dep = oracle.resize_depth(s.depth(f), s.depth_intrinsics, s.color_size[0], s.color_size[1], s.color_intrinsics)
-        frames.append({"lum": [lum, oracle.pyr_down(lum)], "depth": [dep, oracle.depth_down(dep)], "bgr": [bgr, bgr[::2, ::2]]})
+        if not kf[f]:
+            continue
+        bgr = s.color(f); lum = [oracle.lum_from_bgr(bgr)]
+        dep = [oracle.resize_depth(s.depth(f), s.depth_intrinsics, s.color_size[0], s.color_size[1], s.color_intrinsics)]
+        for _ in range(1, PL):
+            lum.append(oracle.pyr_down(lum[-1])); dep.append(oracle.depth_down(dep[-1]))
+        frames.append({"lum": lum, "depth": dep, "bgr": [bgr] + [bgr[::2 ** l, ::2 ** l] for l in range(1, PL)]})
     ci = np.float64(s.color_intrinsics); w, h = s.color_size; n = s.num_frames; s.close()
-    g = oracle.Grid.from_voxels(vol["voxel_size"], vol["keys"], vol["sdf"], vol["weight"], vol["color"]); fr = oracle.Frames(frames, 2)
-    ocfg = helpers.oracle_cfg(oracle, 0.0, iterations=1, **{k: float(cfg[k]) for k in ("lambda_g", "lambda_r0", "lambda_r1", "lambda_s0", "lambda_s1", "lambda_a")}, occlusion_distance=float(np.float32(cfg["occlusion_distance"])),
-                              lm_steps=int(cfg["lm_steps"]), num_observations=int(cfg["num_observations"]))
-    rc, intr, dist, pose6, done = oracle.refine(g, fr, ocfg, 2, 2, float(cfg["thin_shell_factor"]), float(cfg["thin_shell_factor_final"]), int(cfg["clear_distant_voxels"]),
+    g = oracle.Grid.from_voxels(vol["voxel_size"], vol["keys"], vol["sdf"], vol["weight"], vol["color"]); fr = oracle.Frames(frames, PL)
+    ocfg = helpers.oracle_cfg(oracle, 0.0, iterations=iters, **{k: float(cfg[k]) for k in ("lambda_g", "lambda_r0", "lambda_r1", "lambda_s0", "lambda_s1", "lambda_a")}, occlusion_distance=float(np.float32(cfg["occlusion_distance"])),
+                              lm_steps=int(cfg["lm_steps"]), num_observations=int(cfg["num_observations"]), **{k: int(cfg[k]) for k in ("fix_poses", "fix_intrinsics", "fix_distortion")})
+    rc, intr, dist, pose6, done = oracle.refine(g, fr, ocfg, GL, PL, float(cfg["thin_shell_factor"]), float(cfg["thin_shell_factor_final"]), int(cfg["clear_distant_voxels"]),
                                                 float(np.float32(cfg["subvolume_size_sh"])), float(cfg["subvolume_sh_lamda_reg"]), ci, np.zeros(5), np.array(poses))
-    assert rc == 0 and done == 3
-    # poses / intrinsics files of the last stage (6 / default-precision decimals in the text)
-    B.write_poses(str(tmp_path / "ours_poses.txt"), np.arange(n, dtype=np.float64), pose6)
-    a = np.loadtxt(out / "poses_g0_p0.txt"); b = np.loadtxt(tmp_path / "ours_poses.txt")
-    assert a.shape == b.shape == (n, 8) and np.abs(a - b).max() <= 2e-6, np.abs(a - b).max()
-    assert np.abs(a - np.loadtxt(out / "poses_g1_p1.txt")).max() > 1e-5                     # ... and the poses did move between the stages
+    assert rc == 0 and done == len(stages)
+    # poses / intrinsics files of the last stage (6 / default-precision decimals in the text); frames that are not keyframes keep the pose they were loaded with
+    a = np.loadtxt(out / "poses_g0_p0.txt"); assert a.shape == (n, 8)
+    ids = np.flatnonzero(kf)
+    B.write_poses(str(tmp_path / "ours_poses.txt"), ids.astype(np.float64), pose6)
+    b = np.loadtxt(tmp_path / "ours_poses.txt").reshape(len(ids), 8)
+    assert np.abs(a[ids] - b).max() <= 2e-6, np.abs(a[ids] - b).max()
+    first = np.loadtxt(out / f"poses_{stages[0]}.txt")
+    assert (np.abs(a - first).max() > 1e-5) == (int(cfg["fix_poses"]) == 0)                 # ... and the poses did move between the stages, unless they are fixed
+    if extra:
+        assert np.array_equal(a[~kf.astype(bool)], first[~kf.astype(bool)])
     cam = ref_py.camera_load(str(out / "intrinsics_g0_p0.txt"))
     assert cam[0] and (cam[1], cam[2]) == (w, h) and np.allclose(cam[3], intr, rtol=1e-5, atol=0) and np.allclose(cam[4], dist, rtol=1e-5, atol=1e-9)   # (six significant digits in the file)
+    assert (np.abs(dist).max() == 0.0) == (int(cfg["fix_distortion"]) == 1)
     # the last level's meshes: MarchingCubes over the refined distances, largest component, voxel colours / albedo colours
     rv, rcol, rf = _read_ply(out / "mesh_g0_p0.ply"); av, acol, af = _read_ply(out / "mesh_g0_p0_albedo.ply")
     ov, ocol, of = oracle.marching_cubes(g, True)
     ov2, ocol2, of2 = B.mesh_remove_loose_components(ov, ocol, of)
-    assert rv.shape == ov2.shape and np.array_equal(rf, of2) and np.array_equal(af, of2)
-    assert np.abs(rv - ov2).max() <= 1e-6 and np.array_equal(av, rv)
-    assert (np.abs(rcol.astype(int) - ocol2.astype(int)) > 1).mean() < 1e-3                 # colours interpolate between voxels whose order of first use may differ in the last bit
+    assert np.array_equal(av, rv) and np.array_equal(af, rf)
     e = g.export(); g.import_fields(color=ref_py.albedo_colors(e["albedo"]))
     _, ac2, _ = B.mesh_remove_loose_components(*oracle.marching_cubes(g, True))
-    assert (np.abs(acol.astype(int) - ac2.astype(int)) > 1).mean() < 1e-3 and acol.std() > 0
+    if rv.shape == ov2.shape:
+        assert np.array_equal(rf, of2) and np.abs(rv - ov2).max() <= 1e-6
+        assert (np.abs(rcol.astype(int) - ocol2.astype(int)) > 1).mean() < 1e-3             # colours interpolate between voxels whose order of first use may differ in the last bit
+        assert (np.abs(acol.astype(int) - ac2.astype(int)) > 1).mean() < 1e-3
+    else:
+        # five optimisations by two LM implementations (1e-10 apart) later, a voxel or two fall on the other side of a threshold (thin shell / sign of the distance):
+        # a handful of vertices exist on one side only; everything else is the same surface
+        from scipy.spatial import cKDTree
+        assert abs(len(rv) - len(ov2)) <= 1e-3 * len(rv) and abs(len(rf) - len(of2)) <= 1e-3 * len(rf)
+        d, j = cKDTree(ov2).query(rv)
+        assert (d <= 1e-6).mean() > 0.999 and (np.abs(rcol.astype(int) - ocol2[j].astype(int)).max(1)[d <= 1e-6] > 1).mean() < 1e-3
+    assert (np.ptp(acol) > 1) == (float(cfg["lambda_a"]) >= 0)                              # constant albedo: one grey (152 / 153 after the float interpolation along the edges)
     g.free(); fr.free()
 
 
