@@ -200,7 +200,8 @@ def test_fusion_degenerate_frames(oracle):
         assert (len(ref["sdf"]) > 1000) == (clip is None)                  # the frustum bounds are rounded to whole METRES (sparse_voxel_grid.cpp:587-588): dmax 0.2 cuts nothing here
 
 
-def test_app_intrinsic3d_equals_the_reference_application(tmp_path):
+@pytest.mark.parametrize("case", ["two_levels", "three_levels_half_res_depth_skipped_frames"])
+def test_app_intrinsic3d_equals_the_reference_application(tmp_path, case):
     """apps/app_intrinsic3d on a dataset folder against the reference's own AppIntrinsic3D flow (apps/src/app_intrinsic3d.cpp:71-210: SensorI3d, KeyframeSelection::load,
     SparseVoxelGrid::create(tsdf), Intrinsic3D::init / refine, onSDFRefined -> SDFVisualization::colorize, savePoses, Camera::save — all compiled into oracle/_ref) with
     `iterations: "0"`: the optimiser declines (optimizer.cpp:113-114) and both sides go on, so every stage's files depend only on loading, initialisation, thin
@@ -215,7 +216,13 @@ def test_app_intrinsic3d_equals_the_reference_application(tmp_path):
     if not ref_py.available():
         pytest.skip("oracle/_ref/libref_i3d.so not built")
     sc = synthetic.make_scene(radius_vox=10, K=4, width=96, height=72, levels=1, seed=9, pose_noise=(0.0005, 0.001), lum_noise=0.003)
-    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=2, rgbd_levels=2, iterations=0)
+    GL, PL, extra = (2, 2, 0) if case == "two_levels" else (3, 3, 2)
+    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=GL, rgbd_levels=PL, iterations=0, extra_frames=extra)
+    if case != "two_levels":                                                           # depth maps at half the colour resolution with their own intrinsics: resizeDepth proper
+        from PIL import Image
+        K = np.loadtxt(tmp_path / "rgbd" / "depthIntrinsics.txt"); K[:2, :3] *= 0.5; np.savetxt(tmp_path / "rgbd" / "depthIntrinsics.txt", K, fmt="%.9g")
+        for f in sorted((tmp_path / "rgbd").glob("*.depth.png")):
+            Image.fromarray(np.asarray(Image.open(f))[::2, ::2].copy()).save(f)
     import re
     txt = open(i_yml).read(); assert 'subvolume_size_sh: "0.2"' in txt
     open(i_yml, "w").write(txt.replace('subvolume_size_sh: "0.2"', 'subvolume_size_sh: "0.03"'))     # 3 cm subvolumes: the 8 cm object spans several (interpolated shading)
@@ -233,7 +240,8 @@ def test_app_intrinsic3d_equals_the_reference_application(tmp_path):
         os.chdir(cwd)
     names = sorted(os.listdir(out))
     views = ("", "_normals", "_lap", "_lum", "_lum_grad", "_albedo", "_shading_sv", "_shading_sv_const", "_chroma")
-    assert names == sorted(f"{p}_{s}{e}" for s in ("g1_p1", "g1_p0", "g0_p0") for p, e in [("intrinsics", ".txt"), ("poses", ".txt")] + [("mesh", v + ".ply") for v in views])
+    stages = [f"g{GL - 1}_p{p}" for p in range(PL - 1, -1, -1)] + [f"g{g}_p0" for g in range(GL - 2, -1, -1)]
+    assert names == sorted(f"{p}_{s}{e}" for s in stages for p, e in [("intrinsics", ".txt"), ("poses", ".txt")] + [("mesh", v + ".ply") for v in views])
     report = {n: (os.path.exists(ours / n) and open(ours / n, "rb").read() == open(out / n, "rb").read()) for n in names}
     if not all(report.values()) or sorted(os.listdir(ours)) != names:
         keep = os.path.join(ROOT, "gpurun_out", "app_i3d_mismatch")                        # (for a look afterwards)
