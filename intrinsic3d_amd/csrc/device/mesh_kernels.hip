@@ -110,6 +110,7 @@ void launch_mc_emit(hipStream_t st, GridView g, HashTable t, const int* inv_rank
 struct VisGridDev {                              // the accessors vis_lum_grad_px walks the resident grid with
     const GridView& g;
     __device__ long long px(long long i) const { return g.nbr[(size_t)NB_PX * g.N + i]; }
+    __device__ long long mx(long long i) const { return g.nbr[(size_t)NB_MX * g.N + i]; }
     __device__ int rank(long long i) const { return g.rank[i]; }
     __device__ bool ring(long long i) const {
         bool ok = true;

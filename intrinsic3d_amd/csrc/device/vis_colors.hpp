@@ -54,24 +54,25 @@ I3D_VIS_HD inline unsigned char vis_lum_grad_byte(const unsigned char c0[3], con
 }
 // The reference paints "lum_grad" IN PLACE while it walks the grid: the +x neighbour whose colour a voxel reads has already been repainted when the walk came
 // past it earlier — and what it was repainted with depended on ITS +x neighbour in the same way.  So the colour a voxel sees there is defined along the chain of
-// +x neighbours with falling visit rank.  G: px(i) -> index of the +x neighbour, rank(i) -> position in the reference's walk (its unordered_map order),
+// +x neighbours with falling visit rank (linear in its length: out along +x, back along -x).  G: px(i) / mx(i) -> index of the +x / -x neighbour, rank(i) -> position
+// in the reference's walk (its unordered_map order),
 // ring(i) -> all six neighbours valid, color(i, c[3]).  Call with ring(s) true; e = the colour of s's +x neighbour at the moment s is visited.
 template <class G>
 I3D_VIS_HD inline void vis_lum_grad_px(const G& g, long long s, unsigned char e[3]) {
     const long long t1 = g.px(s);
     g.color(t1, e);
     if (!(g.rank(t1) < g.rank(s))) return;                                    // not visited before s: still its own colour
-    int len = 0; long long cur = t1;
-    while (g.ring(cur)) { const long long nx = g.px(cur); if (!(g.rank(nx) < g.rank(cur))) break; cur = nx; ++len; }
-    bool have = false; unsigned char carry = 0;
-    for (int k = len; k >= 0; --k) {                                          // from the far end of the chain back to t1 (chains are short: visit ranks are hash ordered)
-        long long node = t1;
-        for (int j = 0; j < k; ++j) node = g.px(node);
+    long long cur = t1;                                                       // the far end of the chain of +x neighbours visited ever earlier ...
+    while (g.ring(cur)) { const long long nx = g.px(cur); if (!(g.rank(nx) < g.rank(cur))) break; cur = nx; }
+    unsigned char carry = 0; bool have = false;
+    for (;;) {                                                                // ... and back along -x to t1: what each one was repainted with, given what ITS +x neighbour showed then
         unsigned char c0[3], cx[3] = {carry, carry, carry};
-        g.color(node, c0);
-        const bool ring = g.ring(node);
-        if (!have && ring) g.color(g.px(node), cx);
+        g.color(cur, c0);
+        const bool ring = g.ring(cur);
+        if (!have && ring) g.color(g.px(cur), cx);
         carry = vis_lum_grad_byte(c0, cx, ring); have = true;
+        if (cur == t1) break;
+        cur = g.mx(cur);
     }
     e[0] = e[1] = e[2] = carry;
 }

@@ -237,6 +237,7 @@ int i3d_visualization_colors(int32_t color_mode, float voxel_size, int64_t n, co
     struct HostGrid {                                                      // the accessors vis_lum_grad_px walks the arrays with
         const int32_t* keys; const float* weight; const uint8_t* col; const int64_t* visit_rank; const decltype(find)& f; const int (*off)[3];
         long long px(long long i) const { return f(keys[3 * i] + 1, keys[3 * i + 1], keys[3 * i + 2]); }
+        long long mx(long long i) const { return f(keys[3 * i] - 1, keys[3 * i + 1], keys[3 * i + 2]); }
         long long rank(long long i) const { return visit_rank ? visit_rank[i] : i; }
         bool ring(long long i) const { bool ok = true; for (int d = 0; d < 6; ++d) { const int64_t nb = f(keys[3 * i] + off[d][0], keys[3 * i + 1] + off[d][1], keys[3 * i + 2] + off[d][2]); ok = ok && nb >= 0 && weight[nb] > 0.0f; } return ok; }
         void color(long long i, unsigned char c[3]) const { for (int k = 0; k < 3; ++k) c[k] = col[3 * i + k]; }

@@ -772,3 +772,29 @@ def test_sensor_yml_equals_the_reference_factory(R, tmp_path):
     (tmp_path / "empty.yml").write_text("%YAML:1.0\n")                                    # Settings::empty(): no sensor
     with pytest.raises(B.I3DError):
         B.Sensor(yml=tmp_path / "empty.yml")
+
+
+def test_intensity_gradient_view_with_long_repaint_chains():
+    """"lum_grad" is painted in place in the reference (visualization.cpp:273-305): with a walk that runs against +x every voxel of a row reads a neighbour that was repainted
+    just before — chains as long as the rows.  i3d_visualization_colors (out along +x, back along -x) against a literal in-place loop over the same walk."""
+    from intrinsic3d_amd import binding as B
+    rng = np.random.default_rng(3)
+    g = np.stack(np.meshgrid(np.arange(40), np.arange(5), np.arange(5), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    keys = g[rng.random(len(g)) > 0.02]; n = len(keys)
+    w = np.ones(n, np.float32); w[rng.random(n) < 0.02] = 0.0
+    col = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+    order = np.lexsort((keys[:, 2], keys[:, 1], -keys[:, 0]))                            # the walk: x descending
+    rank = np.empty(n, np.int64); rank[order] = np.arange(n)
+    got = B.visualization_colors("lum_grad", 0.004, keys, np.zeros(n), np.full(n, 0.6), w, col, visit_rank=rank)
+    at = {tuple(k): i for i, k in enumerate(keys)}; cur = col.copy()
+    f = np.float32
+    lum = lambda c: f(f(f(0.299) * f(c[0]) + f(0.587) * f(c[1])) + f(0.114) * f(c[2]))
+    for i in order:                                                                      # the reference's loop, literally
+        x, y, z = keys[i]
+        nb = [at.get((x + 1, y, z)), at.get((x - 1, y, z)), at.get((x, y + 1, z)), at.get((x, y - 1, z)), at.get((x, y, z + 1)), at.get((x, y, z - 1))]
+        dx = f(0)
+        if all(j is not None and w[j] > 0 for j in nb):
+            dx = f(lum(cur[nb[0]]) - lum(cur[i]))
+        cur[i] = np.uint8(min(max(f(dx * f(0.5) + f(127.0)), f(0)), f(255)))
+    assert np.array_equal(got, cur)
+    assert (np.abs(got[:, 0].astype(int) - 127) > 20).sum() > 20 and not np.array_equal(got, B.visualization_colors("lum_grad", 0.004, keys, np.zeros(n), np.full(n, 0.6), w, col))
