@@ -798,3 +798,30 @@ def test_intensity_gradient_view_with_long_repaint_chains():
         cur[i] = np.uint8(min(max(f(dx * f(0.5) + f(127.0)), f(0)), f(255)))
     assert np.array_equal(got, cur)
     assert (np.abs(got[:, 0].astype(int) - 127) > 20).sum() > 20 and not np.array_equal(got, B.visualization_colors("lum_grad", 0.004, keys, np.zeros(n), np.full(n, 0.6), w, col))
+
+
+def test_pose_vectors_of_special_rotations_equal_the_reference_initialisation(R, tmp_path):
+    """pose file -> SensorI3d::loadPose -> inverse -> math::poseMatToVecAA (intrinsic3d.cpp:186-190, math.cpp:166-179) in the reference's own init against
+    i3d_pose_mat_to_vec6 for the rotations where an angle-axis conversion has its corners: identity, half turns about each axis and about a diagonal, angles of
+    1e-9 and 1e-5, a hair below pi, and diagonal sign matrices."""
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+    from intrinsic3d_amd import binding as B
+    from oracle import ref_py
+    folder = tmp_path / "rgbd"; folder.mkdir()
+    K = np.eye(4); K[0, 0] = K[1, 1] = 50; K[0, 2] = 15.5; K[1, 2] = 11.5
+    np.savetxt(folder / "colorIntrinsics.txt", K); np.savetxt(folder / "depthIntrinsics.txt", K)
+    rots = [np.eye(3)] + [Rotation.from_rotvec(v).as_matrix() for v in ([np.pi, 0, 0], [0, np.pi, 0], [0, 0, np.pi], [1e-9, 0, 0], [1e-5, 2e-5, -1e-5],
+                                                                          np.array([1, 1, 1]) / np.sqrt(3) * np.pi, np.array([1, 2, 3]) / np.sqrt(14) * (np.pi - 1e-4))]
+    rots += [np.diag([1, -1, -1.0]), np.diag([-1, -1, 1.0])]
+    rng = np.random.default_rng(0)
+    for i, Rm in enumerate(rots):
+        Image.fromarray(rng.integers(0, 256, (24, 32, 3), np.uint8)).save(folder / f"frame-{i:06d}.color.png")
+        Image.fromarray(rng.integers(500, 900, (24, 32)).astype(np.uint16)).save(folder / f"frame-{i:06d}.depth.png")
+        T = np.eye(4); T[:3, :3] = Rm; T[:3, 3] = rng.normal(size=3); np.savetxt(folder / f"frame-{i:06d}.pose.txt", T, fmt="%.17g")
+    m = ref_py.InitModel(folder, [True] * len(rots), 1, 0, 0.1, 10.0); s = B.Sensor(folder, 0, 0.1, 10.0)
+    for k in range(len(rots)):
+        a = np.asarray(m.poses[k]); b = B.pose_mat_to_vec6(s.pose(k))
+        assert np.abs(a - b).max() <= 1e-15 * max(1.0, np.abs(a).max()) * 4, (k, a, b)
+    assert abs(np.linalg.norm(m.poses[1][:3]) - np.pi) < 1e-7 and not np.asarray(m.poses[0][:3]).any()
+    m.close(); s.close()
