@@ -207,6 +207,16 @@ class Frames:
             lib().orc_frames_free(self.h); self.h = None
 
 
+def set_collect_threads(n):
+    """threads of the residual collection of optimize (1 = the reference's behaviour; same rows in the same order either way)"""
+    lib().orc_set_collect_threads(C.c_int32(int(n)))
+
+
+def phase_seconds(reset=True):
+    """seconds spent collecting residuals / (unused) / building + solving since the last reset"""
+    out = np.zeros(3); lib().orc_phase_seconds(_p(out), C.c_int32(1 if reset else 0)); return out
+
+
 def lum_from_bgr(bgr):
     b = np.ascontiguousarray(bgr, np.uint8); out = np.zeros(b.shape[:2], np.float32)
     lib().orc_lum_from_bgr(C.c_int32(out.size), _p(b), _p(out)); return out

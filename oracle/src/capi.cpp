@@ -62,6 +62,11 @@ void orc_frames_set(void* fr, int32_t f, int32_t lvl, int32_t w, int32_t h, cons
 }
 void orc_frames_free(void* fr) { delete (Frames*)fr; }
 
+// measurement aids of bench.py's CPU baseline: threads of the residual collection (<= 1: one thread, as in the reference; the rows and their order do not
+// depend on it) and the seconds spent collecting residuals [0] / building + solving [2] since the last reset
+void orc_set_collect_threads(int32_t n) { collect_threads_ref() = n; }
+void orc_phase_seconds(double* out3, int32_t reset) { for (int i = 0; i < 3; ++i) { out3[i] = phase_seconds()[i]; if (reset) phase_seconds()[i] = 0.0; } }
+
 int32_t orc_optimize(void* g, void* fr, const orc_opt_config* c, double* intr, double* dist, double* poses,
                      const double* voxel_sh, orc_iter_stats* stats) {
     auto* G = (Grid<VoxelSBR>*)g; auto* F = (Frames*)fr; OptConfig cfg = to_cfg(c);

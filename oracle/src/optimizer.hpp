@@ -10,6 +10,7 @@
 // PARITY UNPINNED: the reference has no tests/golden vectors and cannot be built here
 // (needs Ceres, Eigen, OpenCV, Boost — none present); see DESIGN.md.
 #pragma once
+#include <chrono>
 #include <cstring>
 #include <map>
 #include "grid.hpp"
@@ -41,6 +42,13 @@ struct IterStats {
 
 struct Observation { uint8_t color[3] = {0, 0, 0}; float weight = 0.0f; int frame = -1;
     bool operator<(const Observation& o) const { return weight < o.weight; } };
+
+// measurement aids of the CPU baseline (bench.py): threads of the residual collection (default 1 = the reference's behaviour) and the seconds the last
+// optimize spent collecting residuals / building + normalising / solving (the reference's time_add / time_build / time_solve, nls_solver.cpp:66-67,101)
+inline int& collect_threads_ref() { static int n = 1; return n; }
+inline int collect_threads() { return collect_threads_ref(); }
+inline double* phase_seconds() { static double t[3] = {0, 0, 0}; return t; }
+inline double wall_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 inline double varying_lambda(int it, int n, double l0, double l1) {            // cost.h:130-143
     if (n <= 1) return l0;
@@ -213,17 +221,18 @@ inline void gather_row_params(const Problem& P, const Row& r, const std::vector<
     for (int i = 0; i < r.ncols; ++i) prm[i] = xg[r.cols[i]];
 }
 
-// optimizer.cpp:176-282 (one voxel).  xg = flat global parameter vector mirroring the grid / camera state.
-inline bool add_voxel_residuals(Problem& P, const OptConfig& cfg, const Colorizer& col, const Frames& fr,
-                                const CameraIO& cam, const std::vector<double>& voxel_sh, int vi,
-                                std::unordered_set<V3i, V3iHash>& voxels_added, const std::vector<double>& xg) {
-    Grid<VoxelSBR>& g = *P.grid; const V3i p = P.keys[vi];
+// optimizer.cpp:176-282 (one voxel), in two halves.  xg = flat global parameter vector mirroring the grid / camera state.
+// First half (:176-241): is the voxel taken, and its Eg rows — reads the grid, the frames and the camera, writes nothing shared: the half that
+// collect_rows may run on several threads (orc_set_collect_threads; the reference runs it on one).
+inline bool voxel_eg_rows(const Problem& P, const OptConfig& cfg, const Colorizer& col, const Frames& fr,
+                          const CameraIO& cam, const std::vector<double>& voxel_sh, int vi, const std::vector<double>& xg, std::vector<Row>& eg_out) {
+    const Grid<VoxelSBR>& g = *P.grid; const V3i p = P.keys[vi];
+    eg_out.clear();
     if (!g.valid(p)) return false;
     const VoxelSBR& v = *P.vox[vi];
     if (std::abs(v.sdf_refined) > cfg.thres_shell) return false;
     float n[3]; surface_normal(g, p, n);
     if (is_zero3(n)) return false;
-    P.active[vi] = 1;
     const double weight_sdf = sdf_to_weight(v.sdf_refined, (double)g.truncation);
     std::vector<Observation> obs;
     col.collect(g, cam.poses, fr, p, n, cfg.rgbd_level, obs);
@@ -254,7 +263,14 @@ inline bool add_voxel_residuals(Problem& P, const OptConfig& cfg, const Colorize
         r.weight = (double)obs[i].weight;
         eg.push_back(r);
     }
-    for (auto& r : eg) { r.weight *= weight_sdf; if (r.weight != 0.0) P.rows[0].push_back(r); }
+    for (auto& r : eg) { r.weight *= weight_sdf; if (r.weight != 0.0) eg_out.push_back(r); }
+    return true;
+}
+// Second half (:243-282), in visit order: the rows into the problem, the regularisers, the visit-order dependent Ea edge rule.
+inline void add_voxel_rows(Problem& P, const OptConfig& cfg, int vi, const std::vector<Row>& eg, std::unordered_set<V3i, V3iHash>& voxels_added) {
+    Grid<VoxelSBR>& g = *P.grid; const V3i p = P.keys[vi]; const VoxelSBR& v = *P.vox[vi];
+    P.active[vi] = 1;
+    for (const auto& r : eg) P.rows[0].push_back(r);
 
     V3i nb[6]; ring6(p, nb);
     const bool ring_ok = ring_valid(g, p);
@@ -281,7 +297,6 @@ inline bool add_voxel_residuals(Problem& P, const OptConfig& cfg, const Colorize
         }
     }
     voxels_added.insert(p);
-    return true;
 }
 
 // optimizer.cpp:312-361
@@ -321,9 +336,24 @@ inline void collect_rows(Problem& P, const OptConfig& cfg, const Frames& fr, con
     P.active.assign(P.N, 0); P.ringok.assign(P.N, 0); P.fix_sdf.assign(P.N, 0); P.fix_alb.assign(P.N, 0);
     std::unordered_set<V3i, V3iHash> voxels_added;
     P.valid_voxels = 0;
-    for (int vi = 0; vi < P.N; ++vi)
-        if (add_voxel_residuals(P, cfg, col, fr, cam, voxel_sh, vi, voxels_added, xg)) ++P.valid_voxels;
+    const double t0 = wall_seconds();
+    const int threads = collect_threads();
+    if (threads <= 1) {                                                  // as in the reference: one thread walks the grid
+        std::vector<Row> eg;
+        for (int vi = 0; vi < P.N; ++vi)
+            if (voxel_eg_rows(P, cfg, col, fr, cam, voxel_sh, vi, xg, eg)) { add_voxel_rows(P, cfg, vi, eg, voxels_added); ++P.valid_voxels; }
+    } else {                                                             // the same rows in the same order: first halves of a block of voxels in parallel, second halves in visit order
+        const int BLOCK = 1 << 15;
+        std::vector<std::vector<Row>> egs(BLOCK); std::vector<uint8_t> taken(BLOCK);
+        for (int b0 = 0; b0 < P.N; b0 += BLOCK) {
+            const int nb = std::min(BLOCK, P.N - b0);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads)
+            for (int i = 0; i < nb; ++i) taken[i] = voxel_eg_rows(P, cfg, col, fr, cam, voxel_sh, b0 + i, xg, egs[i]) ? 1 : 0;
+            for (int i = 0; i < nb; ++i) if (taken[i]) { add_voxel_rows(P, cfg, b0 + i, egs[i], voxels_added); ++P.valid_voxels; }
+        }
+    }
     compute_fixed_flags(P, cfg);
+    phase_seconds()[0] += wall_seconds() - t0;
     (void)g;
 }
 
@@ -464,8 +494,10 @@ inline bool optimize(Grid<VoxelSBR>& g, const Frames& fr, CameraIO& cam, const O
         IterStats st; std::memset(&st, 0, sizeof(st));
         st.valid_voxels = P.valid_voxels;
         if (P.valid_voxels > 0) {
+            const double t1 = wall_seconds();
             normalize_weights(P, lambda);
             LMSummary s = solve_problem(P, cfg, xg, &st, cfg.carry_trust_radius ? carried_radius : 1e4);
+            phase_seconds()[2] += wall_seconds() - t1;               // (problem reduction + weight normalisation + LM: time_build + time_solve of the reference)
             if (s.final_radius > 0.0) carried_radius = s.final_radius;
             write_back(P, cam, xg);
             st.cost_initial = s.initial_cost; st.cost_final = s.final_cost; st.lm_iterations = s.iterations;

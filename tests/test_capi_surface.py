@@ -101,3 +101,21 @@ def test_committed_counter_files_attach_to_the_bench_line():
         s = bench.sq_valu(kernel, rows)
         assert s is not None and s["valu"] > 1e7 and s["source"].startswith("r03_"), kernel
     assert abs(bench.pmc_traffic("eg_pass", rows, active)[0] / (4.0 * (29 * rows + 7 * d["config"]["rows"]["Er"] + d["config"]["rows"]["Es"] + 2 * d["config"]["rows"]["Ea"])) - 1.09) < 0.03
+
+
+def test_cpu_baseline_leg_times_the_collection_single_threaded_and_threaded():
+    """bench.py's cpu_baseline leg (the oracle as the CHECKER / baseline, never the product) on a small scene: SURVEY section 8(d) asks for the residual collection
+    timed on one thread, as the reference runs it, and threaded — the threaded walk must assemble the same rows.  (The device-parity part of the leg needs a GPU and
+    reports None here.)"""
+    import argparse
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    sc = helpers.small_scene(seed=4, radius_vox=12, K=6, width=96, height=72)
+    sc = dict(sc); sc.setdefault("scene", None)
+    args = argparse.Namespace(cpu_sample=4000, cpu_ref_sample=0, subvolume=0.05)
+    out = bench.cpu_baseline(args, sc, 2.0 * float(sc["voxel_size"]), lambda m: None, device=0)
+    assert out is not None and out["kind"] == "port" and out["value"] > 0
+    ph = out["phases_s_per_iteration_sample"]; th = out["threaded_collection"]
+    assert ph["collect_single_thread"] > 0 and ph["build_and_solve"] > 0
+    assert th is not None and th["rows_equal_single_thread"] and th["collect_s"] > 0 and th["value"] > 0
