@@ -445,7 +445,7 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
     if (with_jacobian) {
         // point records in LDS (74 KB per workgroup), per-keyframe constants from global memory: 247 VGPRs, no spills, TWO workgroups per CU.
         // (Measured: 2.13 -> 1.45 ms; with the keyframe constants staged in LDS as well only one workgroup fits and nothing is gained.)
-        (void)hipFuncSetAttribute((const void*)k_build<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
+        if (!set_dynamic_lds((const void*)k_build<true, false, 2>, "k_build<true>", qlds, p.K)) return;
         k_build<true, false, 2><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out);
     } else if (lds <= 48 * 1024) k_build<false, true, 2><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);       // (tap loads of 2 points in flight: 1 -> +3 %, 4 spills at 128 registers -> +87 %)
     else k_build<false, false, 2><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);

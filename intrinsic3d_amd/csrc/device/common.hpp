@@ -178,4 +178,11 @@ struct OptParams {                  // scalar state of one outer iteration
 constexpr int I3D_ERR_HIP_ = 3;
 extern thread_local char g_errbuf[512];
 
+// Launch wrappers return counts, not status codes.  A launch CONFIGURATION that cannot work — a dynamic-LDS request over the device limit, which grows with the
+// keyframe count K — is latched per thread with a message that names the kernel, the request and K; the host control picks it up where it checks
+// hipGetLastError() (ctx_launch_check, context.cpp) and returns I3D_ERR_CAPACITY instead of a generic HIP launch failure.
+constexpr size_t I3D_LDS_LIMIT = 160 * 1024;
+bool set_dynamic_lds(const void* kernel, const char* name, size_t bytes, int K);       // false: latched, do not launch
+bool take_launch_error(char* msg, size_t n);                                            // true: there was one (cleared)
+
 }  // namespace i3d

@@ -9,6 +9,19 @@
 namespace i3d {
 
 thread_local char g_errbuf[512] = {0};
+static thread_local char g_launch_err[256] = {0};
+bool set_dynamic_lds(const void* kernel, const char* name, size_t bytes, int K) {
+    hipError_t e = bytes <= I3D_LDS_LIMIT ? hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipErrorInvalidValue;
+    if (e == hipSuccess) return true;
+    (void)hipGetLastError();
+    if (!g_launch_err[0]) std::snprintf(g_launch_err, sizeof(g_launch_err), "%s needs %zu bytes of LDS per workgroup with K = %d keyframes (limit %zu): %s", name, bytes, K, I3D_LDS_LIMIT, hipGetErrorString(e));
+    return false;
+}
+bool take_launch_error(char* msg, size_t n) {
+    if (!g_launch_err[0]) return false;
+    std::snprintf(msg, n, "%s", g_launch_err); g_launch_err[0] = 0;
+    return true;
+}
 
 static __device__ __host__ inline unsigned long long pack_key(int x, int y, int z) {
     const unsigned long long B = 1ull << 20;

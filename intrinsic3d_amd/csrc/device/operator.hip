@@ -427,20 +427,20 @@ void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptPar
     while (reps > 1 && (size_t)(reps * rs + 9 + nshared) * sizeof(float) > 150 * 1024) reps >>= 1;
     const size_t lds_rep = (size_t)(reps * rs + 9 + nshared) * sizeof(float);
     if (mode == PASS_GRAD) {
-        (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_GRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rep);
+        if (!set_dynamic_lds((const void*)k_eg_pass<PASS_GRAD>, "k_eg_pass<GRAD>", lds_rep, p.K)) return;
         k_eg_pass<PASS_GRAD><<<blocks, EG_THREADS, lds_rep, st>>>(g, r, p, u, b, reps, tiles_per_block, state);
     } else if (mode == PASS_JTJP) {
         int rj = 8;                                        // replicas only serve the rare > 3-keyframe fallback; LDS goes to the uv staging
         while (rj > 1 && (size_t)(rj * rs + 9 + nshared + P_VOX * EG_THREADS) * sizeof(float) > 150 * 1024) rj >>= 1;
         const size_t lds_j = (size_t)(rj * rs + 9 + nshared + P_VOX * EG_THREADS) * sizeof(float);
-        (void)hipFuncSetAttribute((const void*)k_eg_jtjp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_j);
+        if (!set_dynamic_lds((const void*)k_eg_jtjp, "k_eg_jtjp", lds_j, p.K)) return;
         k_eg_jtjp<<<blocks, EG_THREADS, lds_j, st>>>(g, r, p, u, b, rj, tiles_per_block, state);
     } else {
         int reps2 = 32;
         const int rs2 = (21 * p.K) | 1;
         while (reps2 > 1 && (size_t)(reps2 * rs2 + 34) * sizeof(float) > 150 * 1024) reps2 >>= 1;
         const size_t n = (size_t)(reps2 * rs2 + 34) * sizeof(float);
-        (void)hipFuncSetAttribute((const void*)k_eg_pass<PASS_COLNORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n);
+        if (!set_dynamic_lds((const void*)k_eg_pass<PASS_COLNORM>, "k_eg_pass<COLNORM>", n, p.K)) return;
         k_eg_pass<PASS_COLNORM><<<blocks, EG_THREADS, n, st>>>(g, r, p, u, b, reps2, tiles_per_block, state);
     }
 }

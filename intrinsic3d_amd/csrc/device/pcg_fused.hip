@@ -179,7 +179,13 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
     const bool slice_wg = (int)blockIdx.x < a.n_slice_wg;
     const int q0 = blockIdx.x * PF_THREADS + threadIdx.x, qstride = a.n_slice_wg * PF_THREADS;
     S3In in;
-    if (cur->done) return;
+    // ONE read of the flag per workgroup: workgroup 0 may store done = 2 (breakdown) below while later workgroups of the same launch start, and waves of
+    // one workgroup that saw different values would leave the prologue reduction with unwritten slots.  Whatever a workgroup reads, it acts on as a whole:
+    // done != 0 -> nothing is touched; done == 0 -> it finds the same breakdown itself (every workgroup adds the same partials in the same order) and returns.
+    __shared__ int done_s;
+    if (threadIdx.x == 0) done_s = cur->done;
+    __syncthreads();
+    if (done_s) return;
     float alpha = 0.0f;
     if (MODE == S3_NORMAL || MODE == S3_XONLY) {                     // p.q = sum over rows of t (J u) + sum D^2 p^2  ->  alpha = rho / p.q
         double t1[1];
@@ -321,15 +327,15 @@ int launch_pcg_step3(hipStream_t st, int mode, Step3Args a) {
     return mode == S3_XONLY ? 0 : blocks;
 }
 
-// plan side of the fold: ext_off[e] = index of the first (entry, halo slot) pair whose entry is >= e, e in [0, A]
+// plan side of the fold: ext_off[e] = index of the first (entry, halo slot) pair whose entry is >= e, e in [0, A]: one lower-bound search per entry over the
+// sorted keys (the keys of a plan that overflowed are not entries: they compare like any other integer and nothing is written outside [0, A])
 __global__ void k_ext_offsets(int n, const int* __restrict__ ext_e, int A, int* __restrict__ ext_off) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > n) return;
-    // (clamped on both sides: the keys of a plan that overflowed are not entries, and nothing here may write outside [0, A])
-    const int cur = j < n ? min(max(ext_e[j], -1), A) : A;
-    const int prev = j > 0 ? min(max(ext_e[j - 1], -1), A) : -1;
-    for (int e = prev + 1; e <= cur; ++e) ext_off[e] = j;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > A) return;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ext_e[mid] < e) lo = mid + 1; else hi = mid; }
+    ext_off[e] = lo;
 }
-void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext_off) { k_ext_offsets<<<(n + 1 + 255) / 256, 256, 0, st>>>(n, ext_e, A, ext_off); }
+void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext_off) { k_ext_offsets<<<(A + 1 + 255) / 256, 256, 0, st>>>(n, ext_e, A, ext_off); }
 
 }  // namespace i3d

@@ -525,7 +525,7 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
             // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
             if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
 #define I3D_EGT(SL, GH) do { \
-        (void)hipFuncSetAttribute((const void*)k_eg_tile<T, HMAX, SL, GH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (!set_dynamic_lds((const void*)k_eg_tile<T, HMAX, SL, GH>, "k_eg_tile", lds, p.K)) break; \
         k_eg_tile<T, HMAX, SL, GH><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
                                                    t.ghost_tiles, ntl, state, cam_partials, cam_stride); } while (0)
             const bool gh = t.n_ghost > 0;

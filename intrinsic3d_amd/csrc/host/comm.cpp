@@ -23,11 +23,15 @@ struct RcclComm : Comm {
     // this iteration's rim pushes (HALO_CAP entries instead of P2P_HALO_CAP)
     int plan_changed(const HaloPlan& h, hipStream_t st) override {
         if (!use_p2p) return 0;
-        double bad = p2p.set_halo_lists(h, st) != 0 ? 1.0 : 0.0;
+        // 0 ok | 2 the rim of a pair exceeds a mailbox (re-routed through RCCL, agreed below) | anything else: a HIP / copy error, which must surface —
+        // but only AFTER the agreement all-reduce, so that the collectives of the ranks stay matched (max over ranks: 1 = re-route, 2 = somebody failed)
+        const int rc = p2p.set_halo_lists(h, st);
+        double bad = rc == 0 ? 0.0 : (rc == 2 ? 1.0 : 2.0);
         if (!d_agree && hipMalloc((void**)&d_agree, sizeof(double)) != hipSuccess) return 1;
         if (hipMemcpyAsync(d_agree, &bad, sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
         if (ncclAllReduce(d_agree, d_agree, 1, ncclDouble, ncclMax, comm, st) != ncclSuccess) return 1;
         if (hipMemcpyAsync(&bad, d_agree, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+        if (bad >= 2.0) return 3;                  // a rank could not install its lists (HIP error): every rank reports it
         halo_rccl = bad != 0.0;
         return 0;
     }

@@ -14,6 +14,13 @@ int ctx_hip(i3d_context* c, hipError_t e, const char* what) {
     return ctx_fail(c, I3D_ERR_HIP, std::string(what) + " -> " + hipGetErrorString(e));
 }
 
+int ctx_launch_check(i3d_context* c) {
+    char msg[256];
+    if (take_launch_error(msg, sizeof(msg))) return ctx_fail(c, I3D_ERR_CAPACITY, msg);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? I3D_OK : ctx_hip(c, e, "kernel launch");
+}
+
 int ensure_pinned(i3d_context* c, size_t n) {
     if (n <= c->h_pinned_n) return I3D_OK;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);

@@ -121,6 +121,7 @@ namespace i3d {
 // helpers implemented in context.cpp
 int ctx_fail(i3d_context* c, int code, const std::string& msg);
 int ctx_hip(i3d_context* c, hipError_t e, const char* what);
+int ctx_launch_check(i3d_context* c);      // hipGetLastError + the latched launch-configuration error (common.hpp: set_dynamic_lds) -> I3D_ERR_HIP / I3D_ERR_CAPACITY
 #define CTX_HIP(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return i3d::ctx_hip((c), _e, #expr); } while (0)
 void build_frame_consts(const i3d_context* c, int level, const double* poses, std::vector<FrameConst>& out);
 int ensure_pinned(i3d_context* c, size_t n);

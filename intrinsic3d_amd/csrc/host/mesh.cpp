@@ -46,7 +46,9 @@ static thread_local MeshData g_mesh;       // the last extracted mesh of this ho
 // connected component is kept — boost numbers components in the order of their first face and std::max_element keeps the first maximum — then the
 // vertices no face uses are dropped and the indices renumbered in vertex order.  (Vertices are unique per position after merge(), so sharing an index is
 // sharing a position.)
-static void remove_loose_components(MeshData& M) {
+// canon (optional): canonical vertex of every vertex — the first vertex at the same POSITION.  The reference connects faces through a position-keyed
+// vertex map (mesh/util.cpp:52-62); the internal path has unique positions after merge(), caller-supplied meshes (a triangle soup) may not.
+static void remove_loose_components(MeshData& M, const std::vector<int32_t>* canon = nullptr) {
     std::vector<int32_t>& faces = M.faces;
     if (faces.empty()) return;
     const size_t nf = faces.size() / 3, nv = M.vertices.size() / 3;
@@ -54,7 +56,7 @@ static void remove_loose_components(MeshData& M) {
     auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
     std::vector<int> first_face(nv, -1);
     for (size_t f = 0; f < nf; ++f) for (int k = 0; k < 3; ++k) {
-        const int v = faces[3 * f + k];
+        const int v = canon ? (*canon)[(size_t)faces[3 * f + k]] : faces[3 * f + k];
         if (first_face[v] < 0) first_face[v] = (int)f;
         else { int a = find(first_face[v]), b = find((int)f); if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; } }      // root = smallest face index
     }
@@ -168,7 +170,10 @@ int i3d_mesh_remove_loose_components(int64_t* num_vertices, float* vertices, uin
     if (!num_vertices || !num_faces || *num_vertices < 0 || *num_faces < 0 || (*num_vertices > 0 && !vertices) || (*num_faces > 0 && !faces)) return I3D_ERR_INVALID_ARGUMENT;
     for (int64_t i = 0; i < 3 * *num_faces; ++i) if (faces[i] < 0 || faces[i] >= *num_vertices) return I3D_ERR_INVALID_ARGUMENT;
     MeshData M; M.vertices.assign(vertices, vertices + 3 * *num_vertices); if (colors) M.colors.assign(colors, colors + 3 * *num_vertices); M.faces.assign(faces, faces + 3 * *num_faces);
-    remove_loose_components(M);
+    std::vector<int32_t> canon((size_t)*num_vertices);
+    { std::unordered_map<F3, int, F3Hash> first; first.reserve((size_t)*num_vertices * 2);
+      for (int64_t v = 0; v < *num_vertices; ++v) canon[(size_t)v] = first.emplace(F3{vertices[3 * v], vertices[3 * v + 1], vertices[3 * v + 2]}, (int)v).first->second; }
+    remove_loose_components(M, &canon);
     *num_vertices = (int64_t)(M.vertices.size() / 3); *num_faces = (int64_t)(M.faces.size() / 3);
     std::copy(M.vertices.begin(), M.vertices.end(), vertices); if (colors) std::copy(M.colors.begin(), M.colors.end(), colors); std::copy(M.faces.begin(), M.faces.end(), faces);
     return I3D_OK;

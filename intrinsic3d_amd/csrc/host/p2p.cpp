@@ -106,7 +106,7 @@ int P2PEngine::allreduce(double* dev, size_t n, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int P2PEngine::set_halo_lists(const HaloPlan& h, hipStream_t st) {      // once per outer iteration
-    if (h.n_send > 0 || h.n_recv > 0) for (int k = 0; k < world; ++k) if (h.send_cnt[k] > L.halo_cap || h.recv_cnt[k] > L.halo_cap) return 1;
+    if (h.n_send > 0 || h.n_recv > 0) for (int k = 0; k < world; ++k) if (h.send_cnt[k] > L.halo_cap || h.recv_cnt[k] > L.halo_cap) return 2;      // 2 = the rim does not fit a mailbox (not an error: the caller re-routes it)
     int host[4 * P2P_MAX_RANKS]; std::memset(host, 0, sizeof(host));
     for (int k = 0; k < world; ++k) { host[k] = h.send_off[k]; host[P2P_MAX_RANKS + k] = h.send_cnt[k]; host[2 * P2P_MAX_RANKS + k] = h.recv_off[k]; host[3 * P2P_MAX_RANKS + k] = h.recv_cnt[k]; }
     if (hipMemcpyAsync(d_lists, host, sizeof(host), hipMemcpyHostToDevice, st) != hipSuccess) return 1;

@@ -27,7 +27,7 @@ struct P2PEngine {
     void destroy();
     P2PDev device() const;                            // handle for kernels that reduce in place (p2p_allreduce_wg)
     int  allreduce(double* dev, size_t n, hipStream_t st);
-    int  set_halo_lists(const HaloPlan& h, hipStream_t st);
+    int  set_halo_lists(const HaloPlan& h, hipStream_t st);      // 0 ok, 2 = a pair's rim exceeds the mailbox, 1 = HIP error
     int  push_halo(float* vec, const HaloPlan& h, hipStream_t st);
     int  check(hipStream_t st);                       // 1 if a spin timed out
 };

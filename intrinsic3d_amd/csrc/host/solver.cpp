@@ -9,6 +9,7 @@
 #include <rocprim/rocprim.hpp>
 #include <chrono>
 #include <limits>
+#include <algorithm>
 
 namespace i3d {
 
@@ -45,7 +46,10 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->aflags.alloc(Acap)); CTX_HIP(c, c->nrows.alloc(Acap)); CTX_HIP(c, c->anbr.alloc(Acap * NUM_NBR));
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8));
-    { const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512), nh = nt * (size_t)tile_plan_hmax_of(512);        // the 512-entry geometry needs the most slots (3 per entry; 1024: 2)
+    { // sized for BOTH tile geometries: the 512-entry one needs the most slots on large grids (3 per entry; 1024: 2), but a grid of <= 512 entries is ONE
+      // 1024-entry tile with 2048 halo slots against one 512-entry tile with 1536
+      const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512);
+      const size_t nh = std::max(nt * (size_t)tile_plan_hmax_of(512), (size_t)tile_plan_tiles_of((int)Acap, 1024) * (size_t)tile_plan_hmax_of(1024));
       CTX_HIP(c, c->tp_lnbr.alloc(Acap * LNBR_WORDS)); CTX_HIP(c, c->tp_eaw.alloc(Acap * 6)); CTX_HIP(c, c->tp_halo_idx.alloc(nh)); CTX_HIP(c, c->tp_halo_cnt.alloc(nt)); CTX_HIP(c, c->tp_iota.alloc(nh));
       CTX_HIP(c, c->tp_ext_e.alloc(nh)); CTX_HIP(c, c->tp_ext_pos.alloc(nh)); CTX_HIP(c, c->tp_qh.alloc(2 * nh)); CTX_HIP(c, c->tp_overflow.alloc(1));
       CTX_HIP(c, c->tp_ext_off.alloc(Acap + (size_t)SHARD_ALIGN * ((c->comm ? c->comm->world : 1) + 1) + 8));      // chunk + 1 offsets (chunk >= A, a multiple of the slice alignment)
@@ -156,7 +160,9 @@ static int shard_plan(i3d_context* c) {
     if (h.n_recv) CTX_HIP(c, hipMemcpyAsync(c->halo_recv_idx.p, ridx.data(), sizeof(int) * ridx.size(), hipMemcpyHostToDevice, s));
     CTX_HIP(c, hipStreamSynchronize(s));                  // (the host vectors above go out of scope)
     h.d_send_idx = c->halo_send_idx.p; h.d_recv_idx = c->halo_recv_idx.p; h.d_send_buf = c->halo_send_buf.p; h.d_recv_buf = c->halo_recv_buf.p;
-    if (c->comm->plan_changed(h, s)) return ctx_fail(c, I3D_ERR_CAPACITY, "sharding: the rim of a rank pair exceeds the peer-to-peer mailbox");
+    { const int prc = c->comm->plan_changed(h, s);
+      if (prc == 2) return ctx_fail(c, I3D_ERR_CAPACITY, "sharding: the rim of a rank pair exceeds the peer-to-peer mailbox");
+      if (prc) return ctx_fail(c, I3D_ERR_COMM, "sharding: installing the halo lists of the peer-to-peer transport failed on a rank (HIP / copy error)"); }
     return I3D_OK;
 }
 
@@ -255,7 +261,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     if (st) { for (int t = 0; t < 4; ++t) { st->rows[t] = (int64_t)(sums[4 + t] + 0.5); st->weight_sum[t] = sums[t]; st->type_weight[t] = p.type_w[t]; } st->valid_voxels = c->n_active; }
     c->last_sizes[0] = c->n_active; for (int t = 0; t < 4; ++t) c->last_sizes[1 + t] = (long long)(sums[4 + t] + 0.5);
     c->last_params = p; c->assembled = true;
-    CTX_HIP(c, hipGetLastError());
+    { const int lrc = ctx_launch_check(c); if (lrc) return lrc; }
     return I3D_OK;
 }
 
@@ -508,7 +514,7 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
     c->pcg_seq = seq0 + it + 1;
     // boundary `it` copied the terminal state forward (kernels after `done` are no-ops), so st2[it & 1] is final
     CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[0], st2 + (it & 1), sizeof(PcgState), hipMemcpyDeviceToHost, s));
-    CTX_HIP(c, hipGetLastError());
+    { const int lrc = ctx_launch_check(c); if (lrc) return lrc; }
     return I3D_OK;
 }
 

@@ -421,6 +421,14 @@ def test_loose_component_removal_equals_the_reference_code(R):
             vr, cr, fr = ref_py.mesh_remove_loose_components(verts, c, faces)
             assert np.array_equal(vo, vr) and np.array_equal(fo, fr) and (c is None or np.array_equal(co, cr)), (trial, len(vo), len(vr), len(fo), len(fr))
             assert len(fo) >= max(sizes) and fo.max() == len(vo) - 1
+    # an unmerged triangle soup: every face owns three vertices, neighbouring faces share POSITIONS only.  The reference connects faces through its
+    # position-keyed vertex map (mesh/util.cpp:52-62), so the soup's components are those of the merged mesh
+    n0, f0 = blob(9, 0); n1, f1 = blob(4, n0)
+    merged = np.concatenate([f0, f1]); pos = rng.normal(0, 1, (n0 + n1, 3)).astype(np.float32)
+    soup_v = pos[merged.reshape(-1)]; soup_f = np.arange(3 * len(merged), dtype=np.int32).reshape(-1, 3)
+    vo, _, fo = B.mesh_remove_loose_components(soup_v, None, soup_f)
+    vr, _, fr = ref_py.mesh_remove_loose_components(soup_v, None, soup_f)
+    assert len(fo) == 9 and np.array_equal(vo, vr) and np.array_equal(fo, fr)
 
 
 def test_dataset_folder_sensor_equals_the_reference_classes(R, tmp_path):
