@@ -377,6 +377,7 @@ def _main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    syncs0 = ctx.debug_counters()["stream_syncs"]
     t0 = time.perf_counter()
     stats = []
     while len(stats) < args.steps:          # the reference's call shape: 10 iterations per Optimizer::optimize, lambda schedule per call
@@ -385,6 +386,7 @@ def _main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    stream_syncs = ctx.debug_counters()["stream_syncs"] - syncs0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     t0 = time.time(); _ = ctx.get_grid(); _ = ctx.get_camera(); t_download = time.time() - t0          # what a host-buffer caller reads back
@@ -484,6 +486,8 @@ def _main():
             "time_split_ms_per_step": {"time_add": float(np.mean([s.time_add for s in stats]) * 1e3), "time_build": float(np.mean([s.time_build for s in stats]) * 1e3),
                                        "time_solve": float(np.mean([s.time_solve for s in stats]) * 1e3)},      # nls_solver.cpp:66-67,101
             "cost": [float(stats[0].cost_initial), float(stats[-1].cost_final)],
+            # host <-> device round trips: the trust-region loop runs on the device (lm_kernels.hip), the host polls mapped memory instead of draining the stream
+            "stream_syncs_per_step": stream_syncs / float(args.steps),
             # the boundary also accepts host buffers (i3d_set_grid / i3d_set_frames / i3d_optimize_host): the same run with the one-off upload
             # (voxels + keyframe pyramids over PCIe, hash / neighbour-table build) and the read-back of the refined fields counted in.  Never `value`.
             "host_buffers_inclusive": {"upload_and_grid_build_s": t_upload, "download_s": t_download,

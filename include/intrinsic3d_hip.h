@@ -334,6 +334,9 @@ int i3d_debug_neighbors(i3d_context* ctx, int32_t* nbr /*[N][18] visit indices, 
 /* gradient S^-1-free: g = J^T W r, diag(J^T W J) and y = J^T W J x over parameter ids [sdf N | albedo N | poses 6K | intr 4 | dist 5], visit order */
 int i3d_debug_normal_eq(i3d_context* ctx, double* gradient, double* jtj_diag, double* cost);
 int i3d_debug_jtj_apply(i3d_context* ctx, const double* x, double* y);
+/* counters of the context since its creation: stream synchronisations of the solver path (assemble + the LM loop).  The trust-region loop of
+ * NLSSolver::solve (nls_solver.cpp:296-337) runs on the device; a Gauss-Newton iteration costs a handful of them, not two per LM attempt. */
+int i3d_debug_counters(i3d_context* ctx, int64_t* stream_syncs);
 
 #ifdef __cplusplus
 }

@@ -198,8 +198,14 @@ static __device__ inline float chroma_weight(uchar4 c, uchar4 cn) {
 // FR_LDS: the per-keyframe constants (144 B each) of ALL keyframes are staged in LDS once per workgroup — every row reads
 // R, t (and Jr) of its keyframe, and with them in global memory those wave-divergent gathers keep the texture-address unit busy.
 template <bool WITH_J, bool FR_LDS, int BATCH>
-__global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out) {
+__global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out,
+                                                               const double* __restrict__ cam9, const LmState* __restrict__ lm) {
     extern __shared__ double frame_lds_raw[];
+    if (!WITH_J) {
+        if (lm && lm->done) return;               // cost of a candidate nobody will look at (the attempt was queued before the host knew that the solve had ended)
+        // camera of the evaluated point from device memory (uniform address: scalar loads into the registers the by-value copy would occupy)
+        if (cam9) { for (int i = 0; i < 4; ++i) p.intr[i] = cam9[i]; for (int i = 0; i < 5; ++i) p.dist[i] = cam9[4 + i]; }
+    }
     FrameHot* const flds = reinterpret_cast<FrameHot*>(frame_lds_raw);
     if (FR_LDS) {
         constexpr int WORDS = sizeof(FrameHot) / 8;
@@ -437,7 +443,8 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowVi
     if (!WITH_J) block_partial_d(cost, cost_out, 1, 0);          // per-workgroup partial (no same-address atomics), summed by k_reduce_partials
 }
 
-void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out, double* scratch) {
+void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out, double* scratch,
+                  const double* cam9, const LmState* lm) {
     if (r.nC <= 0) return;
     const int blocks = (r.nC + 255) / 256;
     double* const cost_dst = cost_out; cost_out = scratch;       // the kernels write per-workgroup partials
@@ -446,9 +453,9 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
         // point records in LDS (74 KB per workgroup), per-keyframe constants from global memory: 247 VGPRs, no spills, TWO workgroups per CU.
         // (Measured: 2.13 -> 1.45 ms; with the keyframe constants staged in LDS as well only one workgroup fits and nothing is gained.)
         if (!set_dynamic_lds((const void*)k_build<true, false, 2>, "k_build<true>", qlds, p.K)) return;
-        k_build<true, false, 2><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out);
-    } else if (lds <= 48 * 1024) k_build<false, true, 2><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out);       // (tap loads of 2 points in flight: 1 -> +3 %, 4 spills at 128 registers -> +87 %)
-    else k_build<false, false, 2><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out);
+        k_build<true, false, 2><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out, nullptr, nullptr);
+    } else if (lds <= 48 * 1024) k_build<false, true, 2><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out, cam9, lm);       // (tap loads of 2 points in flight: 1 -> +3 %, 4 spills at 128 registers -> +87 %)
+    else k_build<false, false, 2><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out, cam9, lm);
     if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr);      // cost_dst += sum
 }
 

@@ -163,6 +163,26 @@ struct PcgState {
     int max_iterations;
 };
 
+// Device-resident state of one NLSSolver::solve (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy as configured by nls_solver.cpp:296-337):
+// the trust-region bookkeeping runs in one-thread kernels (lm_kernels.hip), the host only queues launches and polls one record per attempt.
+struct LmState {
+    double cost;                    // cost at the current point
+    double radius, decrease_factor; // trust-region radius, its reduction factor after a rejected step (doubles every time)
+    double grad2, nfree;            // |J^T W r|^2 and the number of free parameters at the start (gradient test, statistics)
+    float  inv_radius; int pad0;    // (float)(1 / radius) of the attempt in flight: what the vector kernels read
+    int done;                       // 0 running | 1 the solve is over: every later kernel of it returns at once
+    int termination;                // i3d_iteration_stats::termination: 0 step limit | 1 converged (tolerances, radius) | 2 successful step (the callback) | 3 invalid steps
+    int accepted;                   // the deciding attempt accepted its candidate (k_accept applies it)
+    int invalid;                    // consecutive invalid steps (max_num_consecutive_invalid_steps = 5)
+    int attempts;                   // attempts decided
+    int successful;
+};
+struct LmRecord {                   // one per attempt (index 0: the initial tests), in mapped host memory; `seq` is stored last with release semantics
+    int seq; int final_;            // final_: the solve ended here
+    int accepted; int pcg_it; int termination; int kind;      // kind: 0 init | 1 decided attempt | 2 ended before the attempt (radius underflow)
+    double cost, cand_cost, model_change, rel, radius_after, grad2, nfree;
+};
+
 struct OptParams {                  // scalar state of one outer iteration
     double thres_shell; double lambda_a;
     double type_w[4];               // lambda_t / sum_t * 1000

@@ -28,7 +28,10 @@ void launch_observe(hipStream_t st, GridView g, RowView r, OptParams p, const Fr
 // ---- build.hip --------------------------------------------------------------------------------------------
 // with_jacobian: fills res/J/roww/rowfree + regulariser flags (assembly).  Otherwise evaluates the cost of the rows
 // already assembled at the state (g.x_sdf, g.x_alb, frames, p) into cost_out (double, accumulated).
-void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out /* accumulated */, double* scratch);
+// cam9 (cost evaluation only, or null): intrinsics (4) + distortion (5) of the evaluated point in DEVICE memory, overriding p.intr / p.dist — the candidate
+// camera of an LM attempt never visits the host (lm_kernels.hip).  lm (or null): skip the launch's work when the solve is already over.
+void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out /* accumulated */, double* scratch,
+                  const double* cam9 = nullptr, const LmState* lm = nullptr);
 void launch_weight_sums(hipStream_t st, RowView r, double* sums9 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels */,
                         double* scratch);
 
@@ -64,7 +67,7 @@ void launch_mul2(hipStream_t st, Seg2 sg, const float* a, const float* b, float*
 void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask /*[NP]*/);
 
 // fused PCG iteration, scalars resident in PcgState
-void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations);
+void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations, const LmState* lm = nullptr);      // lm->done: the solve starts finished
 // mode: 0 init (z, r.z) | 1 x += a p, r -= a q, z, sums | 2 x only | 3 r = b - q(=A x), z, sums      (a rank's slice; off, n multiples of 4)
 // S_for_inline_q != nullptr: `q` holds the raw accumulators of the tiled operator pass and q = S acc + D2 v is formed inside the kernel
 int  launch_pcg_step(hipStream_t st, int mode, Seg2 sg, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
@@ -110,7 +113,7 @@ void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext
 struct Step3Args {
     int nq; int chunk4;
     const float4* p; const float4* qacc; float4* x; float4* r; const float4* b; float4* z;
-    const float4* cm; float inv_radius;       // masked squared column norms (-1 = fixed) + 1 / trust-region radius: S, D^2 and M^-1 of a voxel unknown are recomputed from them (lm_from_colnorm)
+    const float4* cm; const LmState* lm;       // masked squared column norms (-1 = fixed) + the LM state holding 1 / trust-region radius of the attempt in flight: S, D^2 and M^-1 of a voxel unknown are recomputed from them (lm_from_colnorm)
     const int* ext_off; const int* ext_pos; const float2* qh; int e0;
     const double* pq_partials; int n_pq; const double* d2_partials; int n_d2;
     int n_slice_wg;
@@ -120,8 +123,8 @@ struct Step3Args {
     double* step_partials;
     PcgState* cur;
 };
-void launch_pcg_init3(hipStream_t st, PcgState* st2 /* [2] */, int fixed_iterations, int max_iterations);
-int  launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, float inv_radius,
+void launch_pcg_init3(hipStream_t st, PcgState* st2 /* [2] */, int fixed_iterations, int max_iterations, const LmState* lm = nullptr);
+int  launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, const LmState* lm,
                      const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq);   // returns #d2 partials
 int  pcg_step3_slice_wgs(int n_entries);
 int  pcg_step3_tail_wgs(int K);
@@ -136,8 +139,15 @@ size_t halo_sort_temp_bytes(int cap);
 hipError_t launch_halo_sort(hipStream_t st, void* temp, size_t temp_bytes, const unsigned long long* in, unsigned long long* out, int n);
 
 void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* x_shared, double* xc_sdf, double* xc_alb,
-                      double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask, double* scratch);
-void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb);           // x <- candidate, refresh fp32 shadows
+                      double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask, double* scratch, const LmState* lm = nullptr);
+void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb, const LmState* lm = nullptr);           // x <- candidate, refresh fp32 shadows (lm: only if it accepted)
+// ---- lm_kernels.hip: the trust-region loop on the device -------------------------------------------------------------------------
+void launch_lm_init(hipStream_t st, LmState* lm, const double* cost, const double* grad2, const double* nfree, double radius0, LmRecord* rec, int seq);
+void launch_lm_begin(hipStream_t st, LmState* lm, int K, int fix_poses, int fix_intr, int fix_dist, const double* cdiag, const double* tri, float* Mblk,
+                     const float* tc, const float* tS, float* tD2, float* tMinv, LmRecord* rec, int seq);
+void launch_lm_diag_dev(hipStream_t st, int n, const float* c, const float* S, const LmState* lm, float* D2, float* Minv);
+void launch_cand_frames(hipStream_t st, int K, const double* xc, const FrameConst* base, FrameConst* out, const LmState* lm);
+void launch_lm_decide(hipStream_t st, LmState* lm, const PcgState* ps, const double* norms2, const double* cand_cost, int attempt, int lm_steps, LmRecord* rec, int seq);
 void launch_mark_compute(hipStream_t st, RowView r, int* flag);
 void launch_compact_list(hipStream_t st, int A, const int* flag, const int* scan, int* list);
 

@@ -815,13 +815,14 @@ __global__ void __launch_bounds__(1024) k_pcg_tail_b(size_t to, int K, OptParams
     st->alpha = alpha;
 }
 
-__global__ void k_pcg_init(PcgState* st, int fixed_iterations, int max_iterations) {
+__global__ void k_pcg_init(PcgState* st, int fixed_iterations, int max_iterations, const LmState* lm) {
+    const bool over = lm && lm->done;
     for (int k = 0; k < 4; ++k) st->acc[k] = 0.0;
     st->rho = 0.0; st->last_rho = 1.0; st->pq = 0.0; st->alpha = 0.0; st->beta = 0.0; st->xbr = 0.0; st->xr = 0.0; st->d2xx = 0.0;
-    st->Q0 = 0.0; st->Q1 = 0.0; st->it = 0; st->done = (fixed_iterations == 0) ? 1 : 0; st->fixed_iterations = fixed_iterations; st->max_iterations = max_iterations;
+    st->Q0 = 0.0; st->Q1 = 0.0; st->it = 0; st->done = (fixed_iterations == 0 || over) ? 1 : 0; st->fixed_iterations = fixed_iterations; st->max_iterations = max_iterations;
 }
 
-void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations) { k_pcg_init<<<1, 1, 0, st>>>(state, fixed_iterations, max_iterations); }
+void launch_pcg_init(hipStream_t st, PcgState* state, int fixed_iterations, int max_iterations, const LmState* lm) { k_pcg_init<<<1, 1, 0, st>>>(state, fixed_iterations, max_iterations, lm); }
 static inline int step_blocks(int n4) { int b = (n4 + 255) / 256; return b < 1 ? 1 : (b > 2048 ? 2048 : b); }      // 64 VGPRs: 8 waves per SIMD = 2048 workgroups of 256 in flight
 // off and n must be multiples of 4 (the rank-major layout pads every slice to a multiple of 8 floats)
 int launch_pcg_step(hipStream_t st, int mode, Seg2 sg, const float* p, const float* q, float* x, float* r, const float* b, const float* D2, const float* Minv,
@@ -867,7 +868,8 @@ void launch_pcg_tail_b(hipStream_t st, size_t tail_off, int K, OptParams p, doub
 // parameters.  Replicated: every rank holds the full step and S vectors (all-gathered) and updates the whole list.
 __global__ void __launch_bounds__(256) k_candidate(GridView g, RowView r, int K, float sign, const float* __restrict__ step, const float* __restrict__ S,
                                                    const double* __restrict__ xsh, double* xc_sdf, double* xc_alb, double* xc_sh,
-                                                   double* norms2, const float* __restrict__ mask) {
+                                                   double* norms2, const float* __restrict__ mask, const LmState* __restrict__ lm) {
+    if (lm && lm->done) return;           // (a later attempt queued before the host knew that the solve had ended: the accepted candidate must survive)
     const int A = r.A, NS = 6 * K + 9, chunk = r.chunk;
     const size_t tail = 2 * (size_t)chunk;
     double d2 = 0.0, x2 = 0.0;
@@ -889,16 +891,17 @@ __global__ void __launch_bounds__(256) k_candidate(GridView g, RowView r, int K,
     block_partial_d(d2, norms2, 2, 0); block_partial_d(x2, norms2, 2, 1);
 }
 void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, const float* step, const float* S, const double* xsh, double* xc_sdf, double* xc_alb,
-                      double* xc_sh, double* norms2, const float* mask, double* scratch) {
+                      double* xc_sh, double* norms2, const float* mask, double* scratch, const LmState* lm) {
     int b = vblocks(r.A + 6 * K + 9); if (b > 1024) b = 1024;
-    k_candidate<<<b, 256, 0, st>>>(g, r, K, sign, step, S, xsh, xc_sdf, xc_alb, xc_sh, scratch, mask);
-    launch_reduce_partials(st, scratch, b, 2, norms2, nullptr);
+    k_candidate<<<b, 256, 0, st>>>(g, r, K, sign, step, S, xsh, xc_sdf, xc_alb, xc_sh, scratch, mask, lm);
+    launch_reduce_partials(st, scratch, b, 2, norms2, nullptr);      // (after a finished solve: stale partials into a slot nobody reads)
 }
 // x <- candidate on the work list (everything else never moves), refresh the fp32 shadows
-__global__ void k_accept(GridView g, RowView r, const double* __restrict__ xc_sdf, const double* __restrict__ xc_alb) {
+__global__ void k_accept(GridView g, RowView r, const double* __restrict__ xc_sdf, const double* __restrict__ xc_alb, const LmState* __restrict__ lm) {
+    if (lm && !lm->accepted) return;
     GRID_STRIDE(r.A) { const int s = r.alist[i]; const double a = xc_sdf[s], b = xc_alb[s]; g.x_sdf[s] = a; g.x_alb[s] = b; g.f_sdf[s] = (float)a; g.f_alb[s] = (float)b; }
 }
-void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb) { if (r.A > 0) k_accept<<<vblocks(r.A), 256, 0, st>>>(g, r, xc_sdf, xc_alb); }
+void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb, const LmState* lm) { if (r.A > 0) k_accept<<<vblocks(r.A), 256, 0, st>>>(g, r, xc_sdf, xc_alb, lm); }
 
 // halo exchange of the operator input (Comm::push_halo): gather the rim values a peer needs / scatter what the peers sent
 __global__ void k_halo_pack(int n, const int* __restrict__ idx, const float* __restrict__ vec, int chunk, float* __restrict__ buf) {

@@ -51,15 +51,16 @@ static __device__ inline void reduce_partials_all(const double* __restrict__ P, 
     __syncthreads();
 }
 
-__global__ void k_pcg_init3(PcgState* st2, int fixed_iterations, int max_iterations) {
+__global__ void k_pcg_init3(PcgState* st2, int fixed_iterations, int max_iterations, const LmState* lm) {
+    const bool over = lm && lm->done;           // the LM loop ended before this (speculatively queued) solve: every kernel of it returns at once
     for (int b = 0; b < 2; ++b) {
         PcgState* st = st2 + b;
         for (int k = 0; k < 4; ++k) st->acc[k] = 0.0;
         st->rho = 0.0; st->last_rho = 1.0; st->pq = 0.0; st->alpha = 0.0; st->beta = 0.0; st->xbr = 0.0; st->xr = 0.0; st->d2xx = 0.0;
-        st->Q0 = 0.0; st->Q1 = 0.0; st->it = 0; st->done = (fixed_iterations == 0) ? 1 : 0; st->fixed_iterations = fixed_iterations; st->max_iterations = max_iterations;
+        st->Q0 = 0.0; st->Q1 = 0.0; st->it = 0; st->done = (fixed_iterations == 0 || over) ? 1 : 0; st->fixed_iterations = fixed_iterations; st->max_iterations = max_iterations;
     }
 }
-void launch_pcg_init3(hipStream_t st, PcgState* st2, int fixed_iterations, int max_iterations) { k_pcg_init3<<<1, 1, 0, st>>>(st2, fixed_iterations, max_iterations); }
+void launch_pcg_init3(hipStream_t st, PcgState* st2, int fixed_iterations, int max_iterations, const LmState* lm) { k_pcg_init3<<<1, 1, 0, st>>>(st2, fixed_iterations, max_iterations, lm); }
 
 // Jacobi scale S, LM diagonal D^2 and 1x1 block-Jacobi inverse M^-1 of a voxel unknown from its masked squared column norm (k_scale + k_lm_diag,
 // operator.hip, expression for expression): the two vector kernels of a pass read ONE array instead of S, D^2 and M^-1 (24 B less per entry and pass)
@@ -68,7 +69,7 @@ static __device__ inline void lm_from_colnorm(float cm, float inv_radius, float&
 // iteration boundary + direction.  `prev` was written by the previous boundary, `next` is read by the operator / step kernels of this pass
 __global__ void __launch_bounds__(PF_THREADS) k_pcg_dir3(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
                                                         const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ D2 /* S, D2: the camera tail */,
-                                                        const float* __restrict__ cm, float inv_radius, const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
+                                                        const float* __restrict__ cm, const LmState* __restrict__ lm, const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
                                                         const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq) {
     __shared__ double sm[4 * 8];
     // (seq, done) goes to a 2-slot ring in pinned host memory: the host polls it one pass behind
@@ -78,6 +79,7 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_dir3(int init, int n4, int s
     const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
     const float4* C4 = reinterpret_cast<const float4*>(cm); float4* u4 = reinterpret_cast<float4*>(u);
     if (prev->done) { if (writer) { *next = *prev; publish(prev->done); } return; }
+    const float inv_radius = lm->inv_radius;                         // (uniform: a scalar load)
     double tot[4];
     reduce_partials_all<4>(step_partials, n_step, tot, sm);
     int it = prev->it, done = 0; bool stop = false;
@@ -133,12 +135,12 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_dir3(int init, int n4, int s
     block_partial_d(d2, d2_partials, 1, 0);
 }
 
-int launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, float inv_radius,
+int launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, const LmState* lm,
                     const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq) {
     const int n4 = sg.n >> 2, seg4 = (int)((sg.off1 - sg.off0) >> 2);
     int blocks = (2 * n4 + PF_THREADS - 1) / PF_THREADS; blocks = blocks < 1 ? 1 : (blocks > PF_MAX_WG ? PF_MAX_WG : blocks);
     const size_t o = sg.off0;
-    k_pcg_dir3<<<blocks, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, inv_radius, step_partials, n_step, d2_partials, prev, next, host_flags, seq);
+    k_pcg_dir3<<<blocks, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, lm, step_partials, n_step, d2_partials, prev, next, host_flags, seq);
     return blocks;
 }
 
@@ -186,6 +188,7 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
     if (threadIdx.x == 0) done_s = cur->done;
     __syncthreads();
     if (done_s) return;
+    const float inv_radius = a.lm->inv_radius;                       // (uniform: a scalar load)
     float alpha = 0.0f;
     if (MODE == S3_NORMAL || MODE == S3_XONLY) {                     // p.q = sum over rows of t (J u) + sum D^2 p^2  ->  alpha = rho / p.q
         double t1[1];
@@ -229,8 +232,8 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
             for (int seg = 0; seg < 2; ++seg) {
                 const int i = q + seg * a.chunk4;
                 float xv[4], rv[4], svv[4], dv[4], mv[4];
-                { const float4 cv = in.cm[seg]; lm_from_colnorm(cv.x, a.inv_radius, svv[0], dv[0], mv[0]); lm_from_colnorm(cv.y, a.inv_radius, svv[1], dv[1], mv[1]);
-                  lm_from_colnorm(cv.z, a.inv_radius, svv[2], dv[2], mv[2]); lm_from_colnorm(cv.w, a.inv_radius, svv[3], dv[3], mv[3]); }
+                { const float4 cv = in.cm[seg]; lm_from_colnorm(cv.x, inv_radius, svv[0], dv[0], mv[0]); lm_from_colnorm(cv.y, inv_radius, svv[1], dv[1], mv[1]);
+                  lm_from_colnorm(cv.z, inv_radius, svv[2], dv[2], mv[2]); lm_from_colnorm(cv.w, inv_radius, svv[3], dv[3], mv[3]); }
                 if (MODE == S3_INIT) { const float4 t = in.r[seg]; rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
                 else {
                     const float4 xo = in.x[seg];

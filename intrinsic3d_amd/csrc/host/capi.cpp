@@ -185,5 +185,10 @@ int i3d_debug_jtj_apply(i3d_context* c, const double* x, double* y) {
     if (!c || !x || !y) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_debug_jtj_apply: null pointer");
     return jtj_apply_debug(c, x, y);
 }
+int i3d_debug_counters(i3d_context* c, int64_t* stream_syncs) {
+    if (!c) return I3D_ERR_INVALID_ARGUMENT;
+    if (stream_syncs) *stream_syncs = (int64_t)c->n_syncs;
+    return I3D_OK;
+}
 
 }  // extern "C"

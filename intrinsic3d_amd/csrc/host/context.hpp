@@ -105,6 +105,11 @@ struct i3d_context {
     i3d::DevBuf<double> d_shared, d_blocks, d_scal, d_xshared, d_xcshared;
     i3d::DevBuf<i3d::PcgState> d_pcg, d_pcg2; i3d::DevBuf<double> d_partials; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};
     int* h_flags = nullptr; int* d_flags = nullptr; int pcg_seq = 0;      // pinned (seq, done) ring written by k_pcg_tail_a, polled by the host
+    // the trust-region loop on the device (lm_kernels.hip): its state, one record per attempt in mapped host memory, the camera blocks of J^T W J it damps
+    i3d::DevBuf<i3d::LmState> d_lm; i3d::LmRecord* h_lmrec = nullptr; i3d::LmRecord* d_lmrec = nullptr; int lm_seq = 1;
+    i3d::DevBuf<double> d_cam_c, d_cam_H;
+    hipEvent_t ev_asm[2] = {nullptr, nullptr};      // start of an outer iteration's assembly | end of its residual collection (time_add / time_build without a synchronisation)
+    long long n_syncs = 0;                          // hipStreamSynchronize calls of the solver path (i3d_debug_sync_count)
     double* h_pinned = nullptr; size_t h_pinned_n = 0;
 
     i3d::OptParams last_params; bool assembled = false;

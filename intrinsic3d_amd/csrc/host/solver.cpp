@@ -36,6 +36,10 @@ static double varying_lambda(int it, int n, double l0, double l1) {        // co
 }
 
 constexpr int HALO_CAP = 1 << 20;      // (direction, peer, entry) items of a rank's halo plan
+constexpr int LM_REC_SLOTS = 64;       // LmRecord ring: the initial tests + one record per LM attempt (lm_steps <= LM_REC_SLOTS - 2)
+
+// every stream synchronisation of the solver path goes through here (counted: i3d_debug_counters; the review bar is <= 8 per Gauss-Newton iteration)
+static hipError_t sync_stream(i3d_context* c) { ++c->n_syncs; return hipStreamSynchronize(c->stream); }
 
 static int alloc_rows(i3d_context* c, int slots) {
     const size_t Acap = (size_t)c->N;
@@ -77,7 +81,12 @@ static int alloc_rows(i3d_context* c, int slots) {
     if (!c->h_flags) { CTX_HIP(c, hipHostMalloc((void**)&c->h_flags, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
                        for (int i = 0; i < 16; ++i) c->h_flags[i] = -1;
                        CTX_HIP(c, hipHostGetDevicePointer((void**)&c->d_flags, c->h_flags, 0)); }
-    return ensure_pinned(c, 64 + (size_t)27 * c->K + 64 + (size_t)18 * c->K + 64);      // + staging of the block preconditioner (36K + 41 floats), see lm_solve
+    CTX_HIP(c, c->d_lm.alloc(1)); CTX_HIP(c, c->d_cam_c.alloc((size_t)6 * c->K + 9)); CTX_HIP(c, c->d_cam_H.alloc((size_t)21 * c->K + 25));
+    if (!c->h_lmrec) { CTX_HIP(c, hipHostMalloc((void**)&c->h_lmrec, LM_REC_SLOTS * sizeof(LmRecord), hipHostMallocMapped | hipHostMallocCoherent));
+                       std::memset(c->h_lmrec, 0, LM_REC_SLOTS * sizeof(LmRecord));
+                       CTX_HIP(c, hipHostGetDevicePointer((void**)&c->d_lmrec, c->h_lmrec, 0)); }
+    for (auto& e : c->ev_asm) if (!e) CTX_HIP(c, hipEventCreate(&e));
+    return ensure_pinned(c, 64 + (size_t)27 * c->K + 64);
 }
 
 // vector layout (common.hpp): [sdf chunk | albedo chunk | camera tail]; a rank's slice = the same segment of both parts
@@ -132,7 +141,7 @@ static int shard_plan(i3d_context* c) {
     CTX_HIP(c, hipMemcpyAsync(&nitems, c->halo_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
     std::vector<int> tf((size_t)ntiles + 1, 0);
     CTX_HIP(c, hipMemcpyAsync(tf.data(), c->tile_flag.p, sizeof(int) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
-    CTX_HIP(c, hipStreamSynchronize(s));
+    CTX_HIP(c, sync_stream(c));
     c->nC = tl[0] + tl[1];
     if (nitems > HALO_CAP) return ctx_fail(c, I3D_ERR_CAPACITY, "sharding: the halo plan does not fit its buffers");
     // ghost tiles: foreign tiles that hold compute-list entries
@@ -147,7 +156,7 @@ static int shard_plan(i3d_context* c) {
     if (nitems > 0) {
         CTX_HIP(c, launch_halo_sort(s, c->halo_temp.p, c->halo_temp.n, c->halo_items.p, c->halo_sorted.p, nitems));
         CTX_HIP(c, hipMemcpyAsync(items.data(), c->halo_sorted.p, sizeof(unsigned long long) * (size_t)nitems, hipMemcpyDeviceToHost, s));
-        CTX_HIP(c, hipStreamSynchronize(s));
+        CTX_HIP(c, sync_stream(c));
     }
     std::vector<int> sidx, ridx;
     for (unsigned long long it : items) {
@@ -158,7 +167,7 @@ static int shard_plan(i3d_context* c) {
     h.n_send = (int)sidx.size(); h.n_recv = (int)ridx.size();
     if (h.n_send) CTX_HIP(c, hipMemcpyAsync(c->halo_send_idx.p, sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice, s));
     if (h.n_recv) CTX_HIP(c, hipMemcpyAsync(c->halo_recv_idx.p, ridx.data(), sizeof(int) * ridx.size(), hipMemcpyHostToDevice, s));
-    CTX_HIP(c, hipStreamSynchronize(s));                  // (the host vectors above go out of scope)
+    CTX_HIP(c, sync_stream(c));                  // (the host vectors above go out of scope)
     h.d_send_idx = c->halo_send_idx.p; h.d_recv_idx = c->halo_recv_idx.p; h.d_send_buf = c->halo_send_buf.p; h.d_recv_buf = c->halo_recv_buf.p;
     { const int prc = c->comm->plan_changed(h, s);
       if (prc == 2) return ctx_fail(c, I3D_ERR_CAPACITY, "sharding: the rim of a rank pair exceeds the peer-to-peer mailbox");
@@ -169,7 +178,7 @@ static int shard_plan(i3d_context* c) {
 // read `n` doubles from device memory (after everything queued on the stream)
 static int read_doubles(i3d_context* c, const double* dptr, size_t n, double* out) {
     CTX_HIP(c, hipMemcpyAsync(c->h_pinned, dptr, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    CTX_HIP(c, sync_stream(c));
     std::memcpy(out, c->h_pinned, n * sizeof(double));
     return I3D_OK;
 }
@@ -182,6 +191,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     if (c->K > 2000) return ctx_fail(c, I3D_ERR_CAPACITY, "optimize: more than 2000 keyframes (the camera accumulators of the operator pass live in 160 KB of LDS)");
     if (c->slots != slots || c->Acap != c->N || !c->rows.p) { int rc = alloc_rows(c, slots); if (rc) return rc; }
     hipStream_t s = c->stream;
+    CTX_HIP(c, hipEventRecord(c->ev_asm[0], s));
     p = make_params(c, cfg, c->intr, c->dist);
     std::vector<FrameConst> fc; build_frame_consts(c, cfg.rgbd_level, c->poses.data(), fc);
     CTX_HIP(c, hipMemcpyAsync(c->d_frames.p, fc.data(), sizeof(FrameConst) * fc.size(), hipMemcpyHostToDevice, s));
@@ -193,7 +203,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     int tail[2];
     CTX_HIP(c, hipMemcpyAsync(&tail[0], c->ascan.p + (c->N - 1), sizeof(int), hipMemcpyDeviceToHost, s));
     CTX_HIP(c, hipMemcpyAsync(&tail[1], c->aflag.p + (c->N - 1), sizeof(int), hipMemcpyDeviceToHost, s));
-    CTX_HIP(c, hipStreamSynchronize(s));
+    CTX_HIP(c, sync_stream(c));
     c->A = tail[0] + tail[1];
     { TimedScope t(c, I3D_K_CLASSIFY); launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
     c->tile_ok = false; c->tile_T = 0;
@@ -228,9 +238,8 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     RowView r = c->row_view();
     { TimedScope t(c, I3D_K_OBSERVE); launch_observe(s, g, r, p, c->d_frames.p); }
     // the reference's three-way split (nls_solver.cpp:66-67,101): time_add = collecting the residuals (addVoxelResiduals: classification, observations),
-    // time_build = buildProblem (cost functions, weight normalisation), time_solve.  One extra synchronisation per outer iteration marks the boundary.
-    CTX_HIP(c, hipStreamSynchronize(s));
-    c->t_add_end = now_s();
+    // time_build = buildProblem (cost functions, weight normalisation), time_solve.  The boundary is an event on the stream (round 3: a synchronisation).
+    CTX_HIP(c, hipEventRecord(c->ev_asm[1], s));
     { TimedScope t(c, I3D_K_BUILD); launch_build(s, g, r, p, c->d_frames.p, true, nullptr, c->d_partials.p); }
     { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan(), sharded(c) ? c->cflag.p : nullptr); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
@@ -247,7 +256,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         { RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
           CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n)); }      // (the symmetric Ea weights do not depend on the geometry)
         CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        CTX_HIP(c, hipStreamSynchronize(s));
+        CTX_HIP(c, sync_stream(c));
     }
     c->tile_ok = tp_over == 0;       // a halo that does not fit (pathological grids) -> the untiled operator pass (single rank only)
     if (!sharded(c) && !c->tile_ok) std::fprintf(stderr, "[i3d] operator pass: a tile's halo does not fit, using the untiled pass (k_eg_jtjp + k_gather)\n");
@@ -261,6 +270,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     if (st) { for (int t = 0; t < 4; ++t) { st->rows[t] = (int64_t)(sums[4 + t] + 0.5); st->weight_sum[t] = sums[t]; st->type_weight[t] = p.type_w[t]; } st->valid_voxels = c->n_active; }
     c->last_sizes[0] = c->n_active; for (int t = 0; t < 4; ++t) c->last_sizes[1 + t] = (long long)(sums[4 + t] + 0.5);
     c->last_params = p; c->assembled = true;
+    { float ms = 0.0f; c->t_add_end = (hipEventElapsedTime(&ms, c->ev_asm[0], c->ev_asm[1]) == hipSuccess) ? (double)ms * 1e-3 : -1.0; }      // (both events lie before the read-back above)
     { const int lrc = ctx_launch_check(c); if (lrc) return lrc; }
     return I3D_OK;
 }
@@ -285,68 +295,21 @@ static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const flo
     return I3D_OK;
 }
 
-// a.b over the distributed vector: own slice -> all-reduce -> + the replicated camera tail
-static int dot(i3d_context* c, const float* a, const float* b, double* out) {
+// a.b over the distributed vector: own slice -> all-reduce -> + the replicated camera tail; the result stays on the device (*slot, one of d_scal's doubles)
+static int dot_dev(i3d_context* c, const float* a, const float* b, double* slot) {
     const Layout L = layout_of(c);
-    CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 4, c->stream));
-    { TimedScope t(c, I3D_K_VECTOR); launch_dot2(c->stream, L.own, a, b, c->d_scal.p, c->d_partials.p); }
-    { int rc = allreduce(c, c->d_scal.p, 1); if (rc) return rc; }
-    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, L.NS, a + L.tail_off, b + L.tail_off, c->d_scal.p, c->d_partials.p); }
-    return read_doubles(c, c->d_scal.p, 1, out);
-}
-
-static bool spd_invert(int n, const double* m, double* inv) {            // Cholesky (Ceres: BlockRandomAccessDiagonalMatrix::Invert)
-    double L[36];
-    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) {
-        double s = m[i * n + j];
-        for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
-        if (i == j) { if (!(s > 0.0)) return false; L[i * n + i] = std::sqrt(s); } else L[i * n + j] = s / L[j * n + j];
-    }
-    for (int col = 0; col < n; ++col) {
-        double y[6], x[6];
-        for (int i = 0; i < n; ++i) { double s = (i == col) ? 1.0 : 0.0; for (int k = 0; k < i; ++k) s -= L[i * n + k] * y[k]; y[i] = s / L[i * n + i]; }
-        for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
-        for (int i = 0; i < n; ++i) inv[i * n + col] = x[i];
-    }
-    return true;
-}
-
-struct SharedBlocks { std::vector<double> c, H; };     // diag (6K+9) and upper triangles (21K+25) of J^T W J on the camera unknowns
-
-// block-Jacobi inverse of the pose (6x6), intrinsics (4x4) and distortion (5x5) blocks of  S H S + D^2
-// host part: the damped camera blocks of trust-region radius `radius`, inverted in fp64, into the pinned staging area
-static void prepare_shared_precond(i3d_context* c, const OptParams& p, const SharedBlocks& sb, double radius) {
-    const int K = c->K;
-    // staged in pinned memory behind the read-back area: the copy is asynchronous, the next writer of this area is the next LM attempt (two
-    // stream synchronisations later)
-    float* const Minv = reinterpret_cast<float*>(c->h_pinned + 64 + (size_t)27 * K + 64);
-    const size_t nM = (size_t)36 * K + 41;
-    std::fill(Minv, Minv + nM, 0.0f);
-    auto do_block = [&](int n, const double* cdiag, const double* tri, bool fixed, float* out) {
-        if (fixed) return;
-        double S[6], M[36], inv[36];
-        for (int i = 0; i < n; ++i) S[i] = 1.0 / (1.0 + std::sqrt(cdiag[i]));
-        int o = 0;
-        for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) { const double v = S[i] * S[j] * tri[o++]; M[i * n + j] = v; M[j * n + i] = v; }
-        for (int i = 0; i < n; ++i) { const double cs = cdiag[i] * S[i] * S[i]; M[i * n + i] += std::min(std::max(cs, 1e-6), 1e32) / radius; }
-        if (!spd_invert(n, M, inv)) { for (int i = 0; i < n * n; ++i) inv[i] = 0.0; for (int i = 0; i < n; ++i) inv[i * n + i] = 1.0 / M[i * n + i]; }
-        for (int i = 0; i < n * n; ++i) out[i] = (float)inv[i];
-    };
-    for (int f = 0; f < K; ++f) do_block(6, &sb.c[6 * f], &sb.H[21 * f], p.fix_poses, &Minv[36 * (size_t)f]);
-    do_block(4, &sb.c[6 * K], &sb.H[21 * K], p.fix_intr, &Minv[36 * (size_t)K]);
-    do_block(5, &sb.c[6 * K + 4], &sb.H[21 * K + 10], p.fix_dist, &Minv[36 * (size_t)K + 16]);
-}
-static int upload_shared_precond(i3d_context* c) {
-    const size_t nM = (size_t)36 * c->K + 41;
-    CTX_HIP(c, hipMemcpyAsync(c->Minv_blocks.p, reinterpret_cast<float*>(c->h_pinned + 64 + (size_t)27 * c->K + 64), sizeof(float) * nM, hipMemcpyHostToDevice, c->stream));
+    CTX_HIP(c, hipMemsetAsync(slot, 0, sizeof(double), c->stream));
+    { TimedScope t(c, I3D_K_VECTOR); launch_dot2(c->stream, L.own, a, b, slot, c->d_partials.p); }
+    { int rc = allreduce(c, slot, 1); if (rc) return rc; }
+    { TimedScope t(c, I3D_K_VECTOR); launch_dot(c->stream, L.NS, a + L.tail_off, b + L.tail_off, slot, c->d_partials.p); }
     return I3D_OK;
 }
 
-static int eval_cost_launch(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames) {
+static int eval_cost_launch(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames, const double* cam9 = nullptr, const LmState* lm = nullptr) {
     GridView g = c->grid_view();
     if (candidate) { g.x_sdf = c->xc_sdf.p; g.x_alb = c->xc_alb.p; }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 16, 0, sizeof(double), c->stream));
-    { TimedScope t(c, I3D_K_COST); launch_build(c->stream, g, c->row_view(), p, frames, false, c->d_scal.p + 16, c->d_partials.p); }
+    { TimedScope t(c, I3D_K_COST); launch_build(c->stream, g, c->row_view(), p, frames, false, c->d_scal.p + 16, c->d_partials.p, cam9, lm); }
     return allreduce(c, c->d_scal.p + 16, 1);
 }
 static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames, double* cost) {
@@ -362,9 +325,8 @@ static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const F
 //   * ONE small all-reduce after the operator: [camera block 6K+9 | p.q] (fp64);
 //   * ONE all-reduce of the 4 iteration scalars (r.z, x.(b+r), x.r, sum D^2 x^2) at the iteration boundary.
 // No vector is gathered: everything that lands on an owned unknown is computed from rows the rank holds itself (owned + ghost entries).
-// The terminal state is copied to c->h_pcg[0] on the stream WITHOUT a synchronisation: the caller reads it after its next one (lm_solve queues
-// the candidate point behind the solve and synchronises once for both).
-static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p) {
+// The terminal state stays on the device: k_lm_decide reads it on the stream.
+static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, const PcgState** final_state) {
     hipStream_t s = c->stream;
     const Layout L = layout_of(c);
     const int K = c->K; const bool multi = sharded(c), tiled = c->tile_ok;
@@ -373,7 +335,7 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     PcgState* st = c->d_pcg.p;
     double* pq_slot = c->d_shared.p + L.NS;
     const size_t to = L.tail_off; const Seg2 own = L.own;
-    { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, (int)L.NP, c->v_x.p, 0.0f); launch_pcg_init(s, st, cfg.pcg_fixed_iterations, 500); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, (int)L.NP, c->v_x.p, 0.0f); launch_pcg_init(s, st, cfg.pcg_fixed_iterations, 500, c->d_lm.p); }
     CTX_HIP(c, hipMemcpyAsync(c->v_r.p, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s));
     // fp64 partial sums: [0, 4*2048) slice sums of k_pcg_step, then the p.q partials of the operator pass, then the D^2 p^2 partials of k_pcg_direction
     double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048; double* const d2_part = pq_part + 1024;
@@ -449,20 +411,20 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
             const int want = seq0 + it - 1; volatile int* ring = c->h_flags + 2 * (want & 1);
             const double t_wait = now_s();
             while (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) {
-                if (now_s() - t_wait > 30.0) { CTX_HIP(c, hipStreamSynchronize(s)); if (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) return ctx_fail(c, I3D_ERR_HIP, "pcg_solve: the device stopped publishing its state"); }
+                if (now_s() - t_wait > 30.0) { CTX_HIP(c, sync_stream(c)); if (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) return ctx_fail(c, I3D_ERR_HIP, "pcg_solve: the device stopped publishing its state"); }
             }
             if (__atomic_load_n((int*)&ring[1], __ATOMIC_ACQUIRE)) break;
         }
         if (it > 520) break;
     }
     c->pcg_seq = seq0 + it + 1;
-    CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[0], st, sizeof(PcgState), hipMemcpyDeviceToHost, s));      // kernels after `done` were no-ops, so this is the terminal state
+    *final_state = st;                   // kernels after `done` were no-ops, so this is the terminal state (read by k_lm_decide on the stream)
     return I3D_OK;
 }
 
 // The same solve in THREE launches per pass (pcg_fused.hip): k_pcg_dir3 | k_eg_tile | k_pcg_step3.  Single rank, tiled operator.  The scalar state is
 // double-buffered by pass parity: boundary `it` reads st2[(it + 1) & 1] and writes st2[it & 1], which the operator and the step of pass `it` read.
-static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, float inv_radius) {
+static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, const PcgState** final_state) {
     hipStream_t s = c->stream;
     const Layout L = layout_of(c);
     const int K = c->K; const size_t to = L.tail_off; const Seg2 own = L.own;
@@ -470,13 +432,13 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
     PcgState* const st2 = c->d_pcg2.p;
     const int NSP = (L.NS + 3) & ~3;
     double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048; double* const d2_part = pq_part + 2048;
-    { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, (int)L.NP, c->v_x.p, 0.0f); launch_pcg_init3(s, st2, cfg.pcg_fixed_iterations, 500); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_fill(s, (int)L.NP, c->v_x.p, 0.0f); launch_pcg_init3(s, st2, cfg.pcg_fixed_iterations, 500, c->d_lm.p); }
     CTX_HIP(c, hipMemcpyAsync(c->v_r.p, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s));
     Step3Args a; std::memset(&a, 0, sizeof(a));
     auto c4 = [&](const float* v) { return reinterpret_cast<const float4*>(v + own.off0); };
     auto m4 = [&](float* v) { return reinterpret_cast<float4*>(v + own.off0); };
     a.nq = own.n >> 2; a.chunk4 = (int)((own.off1 - own.off0) >> 2);
-    a.p = c4(c->v_p.p); a.qacc = c4(c->v_qacc.p); a.x = m4(c->v_x.p); a.r = m4(c->v_r.p); a.b = c4(c->v_b.p); a.z = m4(c->v_z.p); a.cm = c4(c->v_cm.p); a.inv_radius = inv_radius;
+    a.p = c4(c->v_p.p); a.qacc = c4(c->v_qacc.p); a.x = m4(c->v_x.p); a.r = m4(c->v_r.p); a.b = c4(c->v_b.p); a.z = m4(c->v_z.p); a.cm = c4(c->v_cm.p); a.lm = c->d_lm.p;
     a.ext_off = tp.ext_off; a.ext_pos = tp.ext_pos; a.qh = reinterpret_cast<const float2*>(tp.qh); a.e0 = (int)own.off0;
     a.pq_partials = pq_part; a.d2_partials = d2_part; a.n_pq = 0; a.n_d2 = 0;
     a.n_slice_wg = pcg_step3_slice_wgs(own.n);
@@ -491,7 +453,7 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
     for (;; ++it) {
         PcgState* const prev = st2 + ((it + 1) & 1); PcgState* const cur = st2 + (it & 1);
         { TimedScope t(c, I3D_K_VECTOR);
-          a.n_d2 = launch_pcg_dir3(s, it == 1, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, c->v_cm.p, inv_radius, step_part, n_step, d2_part, prev, cur, c->d_flags, seq0 + it); }
+          a.n_d2 = launch_pcg_dir3(s, it == 1, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, c->v_cm.p, c->d_lm.p, step_part, n_step, d2_part, prev, cur, c->d_flags, seq0 + it); }
         { TimedScope t(c, I3D_K_EG_PASS); a.n_pq = launch_eg_tile(s, r, p, c->v_u.p, tp, nullptr, c->v_qacc.p, pq_part, cur, c->cam_part.p, NSP); a.n_cam = a.n_pq; }
         a.cur = cur;
         if (it % 10 != 0) { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3(s, 1, a); }
@@ -505,124 +467,131 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
             const int want = seq0 + it - 1; volatile int* ring = c->h_flags + 2 * (want & 1);
             const double t_wait = now_s();
             while (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) {
-                if (now_s() - t_wait > 30.0) { CTX_HIP(c, hipStreamSynchronize(s)); if (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) return ctx_fail(c, I3D_ERR_HIP, "pcg_solve: the device stopped publishing its state"); }
+                if (now_s() - t_wait > 30.0) { CTX_HIP(c, sync_stream(c)); if (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) return ctx_fail(c, I3D_ERR_HIP, "pcg_solve: the device stopped publishing its state"); }
             }
             if (__atomic_load_n((int*)&ring[1], __ATOMIC_ACQUIRE)) break;
         }
         if (it > 520) break;
     }
     c->pcg_seq = seq0 + it + 1;
-    // boundary `it` copied the terminal state forward (kernels after `done` are no-ops), so st2[it & 1] is final
-    CTX_HIP(c, hipMemcpyAsync(&c->h_pcg[0], st2 + (it & 1), sizeof(PcgState), hipMemcpyDeviceToHost, s));
+    // boundary `it` copied the terminal state forward (kernels after `done` are no-ops), so st2[it & 1] is final (read by k_lm_decide on the stream)
+    *final_state = st2 + (it & 1);
     { const int lrc = ctx_launch_check(c); if (lrc) return lrc; }
     return I3D_OK;
 }
 
+// wait for record `idx` of the current solve (mapped host memory, written by the LM kernels with a release store of its sequence number)
+static int wait_record(i3d_context* c, int idx, int seq, LmRecord& out) {
+    LmRecord* const r = c->h_lmrec + idx;
+    const double t0 = now_s();
+    while (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) != seq) {
+        if (now_s() - t0 > 60.0) {
+            CTX_HIP(c, sync_stream(c));
+            if (__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) != seq) return ctx_fail(c, I3D_ERR_HIP, "lm_solve: the device stopped publishing the state of the trust-region loop");
+        }
+    }
+    out = *r;
+    return I3D_OK;
+}
+
 // NLSSolver::solve on the assembled rows.  Updates the device unknowns and the host camera when a step is accepted.
+// The trust-region loop itself runs on the device (lm_kernels.hip); the host queues, per attempt,
+//     k_lm_begin | PCG passes (polling the pass flags) | k_candidate | k_cand_frames | k_build<false> | k_lm_decide | k_accept
+// and reads ONE record per attempt from mapped host memory — the record of attempt k-1 while the solve of attempt k is already queued (its kernels
+// return at once when the loop has ended).  No stream synchronisation inside the loop; one at the end (accepted camera back to the host).
 static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& p, i3d_iteration_stats* st, double initial_radius) {
     hipStream_t s = c->stream;
     const Layout L = layout_of(c);
     const int N = c->N, K = c->K, NP = (int)L.NP, NS = L.NS;
     GridView g = c->grid_view(); RowView r = c->row_view();
+    if (cfg.lm_steps > LM_REC_SLOTS - 2) return ctx_fail(c, I3D_ERR_CAPACITY, "optimize: more than 62 LM steps per outer iteration");
     { TimedScope t(c, I3D_K_VECTOR); launch_freemask(s, r, p, c->v_mask.p); }
     // candidate arrays mirror x outside the work list (fixed parameters are read through them by the cost kernel)
     CTX_HIP(c, hipMemcpyAsync(c->xc_sdf.p, c->x_sdf.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, s));
     CTX_HIP(c, hipMemcpyAsync(c->xc_alb.p, c->x_alb.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, s));
-    // column norms -> Jacobi scaling (computed once, TrustRegionMinimizer::Init)
+    // column norms -> Jacobi scaling (computed once, TrustRegionMinimizer::Init); the camera blocks stay on the device for k_lm_begin
     int rc = run_pass(c, PASS_COLNORM, p, nullptr, c->v_c.p); if (rc) return rc;
-    SharedBlocks sb; sb.c.resize(NS); sb.H.resize((size_t)21 * K + 25);
-    rc = read_doubles(c, c->d_shared.p, NS, sb.c.data()); if (rc) return rc;
-    rc = ensure_pinned(c, (size_t)21 * K + 25 + 64); if (rc) return rc;
-    rc = read_doubles(c, c->d_blocks.p, (size_t)21 * K + 25, sb.H.data()); if (rc) return rc;
+    CTX_HIP(c, hipMemcpyAsync(c->d_cam_c.p, c->d_shared.p, sizeof(double) * (size_t)NS, hipMemcpyDeviceToDevice, s));
+    CTX_HIP(c, hipMemcpyAsync(c->d_cam_H.p, c->d_blocks.p, sizeof(double) * ((size_t)21 * K + 25), hipMemcpyDeviceToDevice, s));
     { int rc2 = allgather(c, c->v_c.p); if (rc2) return rc2; }     // the candidate point needs S everywhere
     { TimedScope t(c, I3D_K_VECTOR); launch_scale_from_colnorm(s, NP, c->v_c.p, c->v_mask.p, c->v_S.p, c->v_cm.p); }
     // gradient b = S J^T W r and initial cost
     rc = run_pass(c, PASS_GRAD, p, nullptr, c->v_acc.p); if (rc) return rc;
     { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, NP, c->v_S.p, c->v_acc.p, c->v_b.p); }
-    double cost = 0.0; rc = eval_cost(c, p, false, c->d_frames.p, &cost); if (rc) return rc;
-    double gmax2 = 0.0; rc = dot(c, c->v_acc.p, c->v_acc.p, &gmax2); if (rc) return rc;
-    double nfree = 0.0; rc = dot(c, c->v_mask.p, c->v_mask.p, &nfree); if (rc) return rc;
-    if (st) { st->cost_initial = cost; st->cost_final = cost; st->free_parameters = (int64_t)(nfree + 0.5); }
-    c->last_sizes[5] = (long long)(nfree + 0.5);
-    if (c->n_active == 0 || nfree == 0.0) { if (st) st->termination = 1; return I3D_OK; }
-    if (gmax2 == 0.0) { if (st) st->termination = 1; return I3D_OK; }            // gradient_tolerance (max-norm <= 1e-10)
+    rc = eval_cost_launch(c, p, false, c->d_frames.p); if (rc) return rc;                    // -> d_scal[16]
+    rc = dot_dev(c, c->v_acc.p, c->v_acc.p, c->d_scal.p + 8); if (rc) return rc;             // |g|^2
+    rc = dot_dev(c, c->v_mask.p, c->v_mask.p, c->d_scal.p + 9); if (rc) return rc;           // free parameters
+    {   // camera unknowns of the current point for the candidate kernel (staged in pinned memory: the copy is asynchronous)
+        double* xs = c->h_pinned;
+        for (int i = 0; i < 6 * K; ++i) xs[i] = c->poses[i];
+        for (int i = 0; i < 4; ++i) xs[6 * K + i] = c->intr[i];
+        for (int i = 0; i < 5; ++i) xs[6 * K + 4 + i] = c->dist[i];
+        CTX_HIP(c, hipMemcpyAsync(c->d_xshared.p, xs, sizeof(double) * NS, hipMemcpyHostToDevice, s));
+    }
+    const int seq0 = c->lm_seq; c->lm_seq += LM_REC_SLOTS;
+    LmState* const lm = c->d_lm.p;
+    launch_lm_init(s, lm, c->d_scal.p + 16, c->d_scal.p + 8, c->d_scal.p + 9, initial_radius, c->d_lmrec, seq0);
 
-    std::vector<double> xshared(NS), xcshared(NS);
-    for (int i = 0; i < 6 * K; ++i) xshared[i] = c->poses[i];
-    for (int i = 0; i < 4; ++i) xshared[6 * K + i] = c->intr[i];
-    for (int i = 0; i < 5; ++i) xshared[6 * K + 4 + i] = c->dist[i];
-    CTX_HIP(c, hipMemcpyAsync(c->d_xshared.p, xshared.data(), sizeof(double) * NS, hipMemcpyHostToDevice, s));
-
-    double radius = initial_radius, decrease_factor = 2.0;          // Ceres default 1e4 (initial_trust_region_radius)
-    double prepared_radius = -1.0;                                  // radius the staged block preconditioner was computed for
-    int invalid = 0, attempts = 0;
-    if (st) { st->termination = 0; st->final_radius = radius; }
-    for (int iter = 1; iter <= cfg.lm_steps; ++iter) {
-        if (radius < 1e-32) { if (st) st->termination = 1; break; }
-        if (st) st->lm_iterations = iter;
-        { TimedScope t(c, I3D_K_VECTOR); launch_lm_diag(s, NP, c->v_c.p, c->v_S.p, (float)(1.0 / radius), c->v_D2.p, c->v_Minv.p); }
-        if (prepared_radius != radius) { prepare_shared_precond(c, p, sb, radius); prepared_radius = radius; }
-        rc = upload_shared_precond(c); if (rc) return rc;
-        {   // three launches per pass on one rank with the tiled operator; the six-launch sequence when sharded, untiled, or asked for (A/B runs)
-            static const bool legacy = [] { const char* e = std::getenv("I3D_PCG_LEGACY"); return e && e[0] == '1'; }();
-            rc = (!sharded(c) && c->tile_ok && !legacy) ? pcg_solve_fused(c, cfg, p, (float)(1.0 / radius)) : pcg_solve(c, cfg, p); if (rc) return rc;
+    static const bool legacy = [] { const char* e = std::getenv("I3D_PCG_LEGACY"); return e && e[0] == '1'; }();
+    // three launches per pass on one rank with the tiled operator; the six-launch sequence when sharded, untiled, or asked for (A/B runs)
+    const bool fused = !sharded(c) && c->tile_ok && !legacy;
+    int attempts = 0; bool ended = false, accepted = false;
+    // one record consumed: statistics + whether the solve is over
+    auto consume = [&](const LmRecord& rec) {
+        if (rec.kind == 0) {
+            if (st) { st->cost_initial = rec.cost; st->cost_final = rec.cost; st->free_parameters = (int64_t)(rec.nfree + 0.5); st->termination = rec.final_ ? 1 : 0; st->final_radius = initial_radius; }
+            c->last_sizes[5] = (long long)(rec.nfree + 0.5);
+        } else if (rec.kind == 2) { if (st) st->termination = 1; }                            // the radius ran out before the attempt (LevenbergMarquardtStrategy)
+        else {
+            if (st) {
+                st->lm_iterations = attempts + 1;
+                if (attempts < 50) { st->pcg_iterations[attempts] = rec.pcg_it; st->step_accepted[attempts] = rec.accepted; }
+                st->final_radius = rec.radius_after; st->termination = rec.termination;
+                if (rec.accepted) { st->cost_final = rec.cost; st->successful_steps += 1; }
+            }
+            if (cfg.verbose) std::printf("  [i3d LM] it %d cand %.9e model %.3e rho %.4f radius -> %.3e cg %d%s\n", attempts + 1, rec.cand_cost, rec.model_change, rec.rel, rec.radius_after, rec.pcg_it,
+                                         rec.accepted ? " accepted" : "");
+            accepted = rec.accepted != 0;
+            ++attempts;
         }
-        // candidate point (replicated: every rank needs the whole step), queued behind the solve: ONE synchronisation returns the terminal PCG
-        // state, the step / parameter norms and the candidate camera.  (A step the model rejects below costs one wasted candidate kernel.)
+        if (rec.final_) ended = true;
+    };
+    int k = 0;
+    for (; k < cfg.lm_steps; ++k) {
+        // attempt k, queued behind whatever attempt k-1 still has in flight.  k_lm_begin: radius test, 1/radius, LM diagonal of the camera tail, block-Jacobi
+        // inverses of the damped camera blocks
+        { TimedScope t(c, I3D_K_VECTOR);
+          launch_lm_begin(s, lm, K, p.fix_poses, p.fix_intr, p.fix_dist, c->d_cam_c.p, c->d_cam_H.p, c->Minv_blocks.p, c->v_c.p + L.tail_off, c->v_S.p + L.tail_off, c->v_D2.p + L.tail_off, c->v_Minv.p + L.tail_off,
+                          c->d_lmrec + 1 + k, seq0 + 1 + k);
+          if (!fused) launch_lm_diag_dev(s, (int)L.tail_off, c->v_c.p, c->v_S.p, lm, c->v_D2.p, c->v_Minv.p); }      // (the three-launch pass recomputes S, D^2, M^-1 of the voxel unknowns from the column norms)
+        const PcgState* ps = nullptr;
+        rc = fused ? pcg_solve_fused(c, cfg, p, &ps) : pcg_solve(c, cfg, p, &ps); if (rc) return rc;
+        // the pass flags this solve waited for were written after everything queued before it: record k (initial tests for k = 0, else attempt k-1) is there
+        { LmRecord rec; rc = wait_record(c, k, seq0 + k, rec); if (rc) return rc; consume(rec); }
+        if (ended) break;
+        // candidate point (replicated: every rank needs the whole step), its keyframe constants and its cost, then the decision — all on the stream
         { int rc2 = allgather(c, c->v_x.p); if (rc2) return rc2; }
         CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 4, 0, sizeof(double) * 2, s));
-        { TimedScope t(c, I3D_K_VECTOR); launch_candidate(s, g, r, K, -1.0f, c->v_x.p, c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p, c->d_partials.p); }
-        CTX_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_xcshared.p, sizeof(double) * NS, hipMemcpyDeviceToHost, s));
-        CTX_HIP(c, hipMemcpyAsync(c->h_pinned + NS, c->d_scal.p + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
-        CTX_HIP(c, hipStreamSynchronize(s));
-        if (sharded(c) && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "pcg_solve: a peer-to-peer exchange timed out (a rank stopped taking part)");
-        const PcgState ps = c->h_pcg[0];
-        const double norms[2] = {c->h_pinned[NS], c->h_pinned[NS + 1]};
-        std::memcpy(xcshared.data(), c->h_pinned, sizeof(double) * NS);
-        if (st && attempts < 50) st->pcg_iterations[attempts] = ps.done == 2 ? ps.it + 1 : ps.it;     // Ceres counts the iteration it broke in
-        // model_cost_change = -(J s)^T (r + J s / 2) with s = -x  ==  x.(b + r_cg)/2 + sum D^2 x^2 / 2
-        const double model_change = 0.5 * ps.xbr + 0.5 * ps.d2xx;
-        const bool finite = std::isfinite(ps.xbr) && std::isfinite(ps.d2xx);
-        if (!finite || !(model_change > 0.0)) {                  // invalid step (max_num_consecutive_invalid_steps = 5)
-            if (st && attempts < 50) st->step_accepted[attempts] = 0;
-            ++attempts;
-            if (++invalid > 5) { if (st) st->termination = 3; break; }
-            radius *= 0.5; if (st) st->final_radius = radius; continue;
-        }
-        invalid = 0;
-        OptParams pc = p;
-        for (int i = 0; i < 4; ++i) pc.intr[i] = xcshared[6 * K + i];
-        for (int i = 0; i < 5; ++i) pc.dist[i] = xcshared[6 * K + 4 + i];
-        std::vector<FrameConst> fcc; build_frame_consts(c, cfg.rgbd_level, xcshared.data(), fcc);
-        CTX_HIP(c, hipMemcpyAsync(c->d_frames_cand.p, fcc.data(), sizeof(FrameConst) * fcc.size(), hipMemcpyHostToDevice, s));
-        rc = eval_cost_launch(c, pc, true, c->d_frames_cand.p); if (rc) return rc;
-        // while the cost kernel runs: the block preconditioner of the NEXT attempt, should this one be rejected (K Cholesky inversions on the host)
-        { const double next_radius = radius / decrease_factor; prepare_shared_precond(c, p, sb, next_radius); prepared_radius = next_radius; }
-        double cand_cost = 0.0; rc = read_doubles(c, c->d_scal.p + 16, 1, &cand_cost); if (rc) return rc;
-        const double step_norm = std::sqrt(norms[0]), x_norm = std::sqrt(norms[1]);
-        if (step_norm <= 1e-8 * (x_norm + 1e-8)) { if (st) { if (attempts < 50) st->step_accepted[attempts] = 0; st->termination = 1; } ++attempts; break; }
-        const double cost_change = cost - cand_cost;
-        if (std::fabs(cost_change) <= 1e-6 * cost) { if (st) { if (attempts < 50) st->step_accepted[attempts] = 0; st->termination = 1; } ++attempts; break; }
-        const double rel = cost_change / model_change;
-        if (cfg.verbose) std::printf("  [i3d LM] it %d cost %.9e cand %.9e model %.3e rho %.4f radius %.3e cg %d\n", iter, cost, cand_cost, model_change, rel, radius, ps.it);
-        if (rel > 1e-3) {                                        // min_relative_decrease
-            { TimedScope t(c, I3D_K_VECTOR); launch_accept(s, g, r, c->xc_sdf.p, c->xc_alb.p); }
-            for (int i = 0; i < 6 * K; ++i) c->poses[i] = xcshared[i];
-            for (int i = 0; i < 4; ++i) c->intr[i] = xcshared[6 * K + i];
-            for (int i = 0; i < 5; ++i) c->dist[i] = xcshared[6 * K + 4 + i];
-            cost = cand_cost;
-            radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
-            if (st) { st->cost_final = cost; st->successful_steps += 1; if (attempts < 50) st->step_accepted[attempts] = 1; st->final_radius = radius; st->termination = 2; }
-            ++attempts;
-            break;                                               // SuccessfulStepCallback: stop after the first successful step
-        }
-        if (st && attempts < 50) st->step_accepted[attempts] = 0;
-        ++attempts;
-        radius = radius / decrease_factor; decrease_factor *= 2.0;
-        if (st) st->final_radius = radius;
+        { TimedScope t(c, I3D_K_VECTOR);
+          launch_candidate(s, g, r, K, -1.0f, c->v_x.p, c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p, c->d_partials.p, lm);
+          launch_cand_frames(s, K, c->d_xcshared.p, c->d_frames.p, c->d_frames_cand.p, lm); }
+        rc = eval_cost_launch(c, p, true, c->d_frames_cand.p, c->d_xcshared.p + 6 * K, lm); if (rc) return rc;
+        { TimedScope t(c, I3D_K_VECTOR);
+          launch_lm_decide(s, lm, ps, c->d_scal.p + 4, c->d_scal.p + 16, k, cfg.lm_steps, c->d_lmrec + 1 + k, seq0 + 1 + k);
+          launch_accept(s, g, r, c->xc_sdf.p, c->xc_alb.p, lm); }
     }
+    if (!ended) { LmRecord rec; rc = wait_record(c, k, seq0 + k, rec); if (rc) return rc; consume(rec); }      // the last attempt's record (step limit)
     if (st) st->num_attempts = std::min(attempts, 50);
-    CTX_HIP(c, hipStreamSynchronize(s));
+    // the accepted camera back to the host (the next outer iteration rebuilds its keyframe constants from it)
+    CTX_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_xcshared.p, sizeof(double) * NS, hipMemcpyDeviceToHost, s));
+    CTX_HIP(c, sync_stream(c));
+    if (sharded(c) && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "lm_solve: a peer-to-peer exchange timed out (a rank stopped taking part)");
+    if (accepted) {
+        for (int i = 0; i < 6 * K; ++i) c->poses[i] = c->h_pinned[i];
+        for (int i = 0; i < 4; ++i) c->intr[i] = c->h_pinned[6 * K + i];
+        for (int i = 0; i < 5; ++i) c->dist[i] = c->h_pinned[6 * K + 4 + i];
+    }
+    { const int lrc = ctx_launch_check(c); if (lrc) return lrc; }
     return I3D_OK;
 }
 
@@ -638,7 +607,8 @@ int optimize(i3d_context* c, const i3d_optimizer_config& cfg, i3d_iteration_stat
         const double t0 = now_s();
         int rc = assemble(c, cfg, itr, p, st); if (rc) return rc;
         const double t1 = now_s();
-        st->time_add = (c->t_add_end > t0 ? c->t_add_end : t1) - t0; st->time_build = t1 - (c->t_add_end > t0 ? c->t_add_end : t1);
+        // t_add_end: device time from the start of the assembly to the end of the residual collection (events on the stream)
+        st->time_add = (c->t_add_end >= 0.0 && c->t_add_end <= t1 - t0) ? c->t_add_end : t1 - t0; st->time_build = (t1 - t0) - st->time_add;
         if (c->n_active > 0) { rc = lm_solve(c, cfg, p, st, cfg.carry_trust_radius ? carried_radius : 1e4); if (rc) return rc;
                                if (st->final_radius > 0.0) carried_radius = st->final_radius; }
         const double t2 = now_s();
@@ -676,8 +646,8 @@ int normal_eq_debug(i3d_context* c, double* gradient, double* jtj_diag, double* 
     OptParams p = c->last_params;
     launch_freemask(c->stream, c->row_view(), p, c->v_mask.p);
     int rc;
-    if (jtj_diag) { rc = run_pass(c, PASS_COLNORM, p, nullptr, c->v_c.p); if (rc) return rc; CTX_HIP(c, hipStreamSynchronize(c->stream)); rc = to_visit_order(c, c->v_c.p, jtj_diag); if (rc) return rc; }
-    if (gradient) { rc = run_pass(c, PASS_GRAD, p, nullptr, c->v_acc.p); if (rc) return rc; CTX_HIP(c, hipStreamSynchronize(c->stream)); rc = to_visit_order(c, c->v_acc.p, gradient); if (rc) return rc; }
+    if (jtj_diag) { rc = run_pass(c, PASS_COLNORM, p, nullptr, c->v_c.p); if (rc) return rc; CTX_HIP(c, sync_stream(c)); rc = to_visit_order(c, c->v_c.p, jtj_diag); if (rc) return rc; }
+    if (gradient) { rc = run_pass(c, PASS_GRAD, p, nullptr, c->v_acc.p); if (rc) return rc; CTX_HIP(c, sync_stream(c)); rc = to_visit_order(c, c->v_acc.p, gradient); if (rc) return rc; }
     if (cost) { rc = eval_cost(c, p, false, c->d_frames.p, cost); if (rc) return rc; }
     return I3D_OK;
 }
@@ -690,13 +660,13 @@ int jtj_apply_debug(i3d_context* c, const double* x, double* y) {
     std::vector<int> rank, alist; std::vector<float> h(NP, 0.0f), m(NP);
     int rc = list_maps(c, rank, alist); if (rc) return rc;
     launch_freemask(c->stream, c->row_view(), p, c->v_mask.p);
-    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    CTX_HIP(c, sync_stream(c));
     CTX_HIP(c, hipMemcpy(m.data(), c->v_mask.p, sizeof(float) * (size_t)NP, hipMemcpyDeviceToHost));
     for (int a = 0; a < A; ++a) { const int v = rank[alist[a]]; h[a] = (float)x[v] * m[a]; h[ch + a] = (float)x[N + v] * m[ch + a]; }
     for (int i = 0; i < NS; ++i) h[2 * ch + i] = (float)x[2 * N + i] * m[2 * ch + i];
     CTX_HIP(c, hipMemcpy(c->v_u.p, h.data(), sizeof(float) * (size_t)NP, hipMemcpyHostToDevice));
     rc = run_pass(c, PASS_JTJP, p, c->v_u.p, c->v_acc.p); if (rc) return rc;
-    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    CTX_HIP(c, sync_stream(c));
     return to_visit_order(c, c->v_acc.p, y);
 }
 
