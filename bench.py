@@ -32,7 +32,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNEL_TAG = "r03-slim-rows"     # bumped when k_build<true> / k_eg_tile change materially: PMC traffic / SQ counter files of older kernels are not attached
 # issue cost of a VALU wave-instruction on gfx950 measured with tools/experiments/valu_rate.hip (profiles/r02_valu_rate.txt): cycles per instruction on one SIMD
-VALU_CYCLES = {"f64": 5.4, "f32": 3.0, "pk": 5.2}      # cycles per wave-instruction on one SIMD, measured (tools/experiments/valu_rate.hip); pk = packed fp32 (v_pk_*)
+# cycles per wave-instruction on one SIMD BY OCCUPANCY (waves per SIMD), measured (tools/experiments/valu_rate.hip, profiles/r03_valu_rate.txt); pk = packed fp32 (v_pk_*).
+# A kernel is priced at the occupancy it actually runs at (k_build<true>: 247 VGPRs = 2 waves per SIMD), not at the 4-wave rates.
+VALU_CYCLES_BY_OCC = {1: {"f64": 9.8, "f32": 7.3, "pk": 8.6}, 2: {"f64": 6.45, "f32": 4.27, "pk": 6.30}, 4: {"f64": 5.24, "f32": 3.21, "pk": 5.20}}
+KERNEL_OCCUPANCY = {"build": 2, "cost": 4, "eg_pass": 4, "observe": 4}      # waves per SIMD from the register counts (tools/kernel_resources.sh)
 GPU_CLOCK_HZ = 2.4e9; NUM_SIMD = 1024
 
 
@@ -60,6 +63,9 @@ def parse_args():
     ap.add_argument("--all-kernel-timing", action="store_true", help="HIP events around every launch (kernel_ms_total for all categories; ~8 % slower)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="experiments only: no per-launch HIP events (no roofline in the output)")
     ap.add_argument("--pcg-fixed", type=int, default=-1, help="experiments only: pin the PCG iterations per LM attempt (-1 = Ceres' stopping rule)")
+    ap.add_argument("--band2-steps", type=int, default=4,
+                    help="timed steps of the second leg on SURVEY.md 8(d)'s own C4 shape (the 4-voxel stored shell, --band 2: 3.2 Eg rows per voxel) whose numbers ride in the "
+                         "same JSON line as value_band2 / roofline_band2 (0 = skip; skipped when --band is 2 already, when sharded, and in experiment modes)")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="also launch a known-size device copy (1 GiB read + 1 GiB write) so that a rocprofv3 --pmc pass over this command "
                          "can calibrate FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section); see tools/pmc_traffic.py")
@@ -222,6 +228,101 @@ def reference_code_leg(args, sc, thres, cfg, log):
     except Exception as e:                                    # the leg is a report, never a reason to fail the bench
         log(f"reference-code leg skipped: {e}")
         return None
+
+
+def kernel_table(args, sizes, world, timing_work, timing):
+    """Average launch time of the two roofline kernels against SURVEY.md section 8(d)'s byte model.
+       build (K2+K3):   68 A + 132 Rg + 36 Rr + 12 Rs + 16 Ra + B_img
+       operator (K6):   4 nnz, nnz = 29 Rg + 7 Rr + Rs + 2 Ra  -- 8(d)'s fused single-pass J^T J p ("4 nnz + 12*4 n" is the whole PCG iteration; the 48 n of
+                        vector passes belong to the vector kernels, not to this one)
+       `design_GB` beside it is what THIS implementation must move per launch by construction: 120 B per stored Eg row (the 29 partials with the row weight folded in
+       + the keyframe id) + per work-list entry the operator input 8, flags 6, local stencil slots 28 (18 x 12 bits), symmetric Ea weights 24, accumulators out 8
+       + ~20 B per tile-halo slot (~1 per entry); Er / Es rows are not stored (constant coefficients), so their 4 nnz bytes are never read."""
+    A, Rg, Rr, Rs, Ra = sizes["active"], sizes["eg"], sizes["er"], sizes["es"], sizes["ea"]
+    nnz = 29.0 * Rg + 7.0 * Rr + Rs + 2.0 * Ra
+    img_bytes = min(4.0 * args.frames * args.width * args.height, 256.0 * Rg)
+    b_build = 68.0 * A + 132.0 * Rg + 36.0 * Rr + 12.0 * Rs + 16.0 * Ra + img_bytes
+    b_egpass = 4.0 * nnz
+    d_build = b_build
+    d_egpass = 120.0 * Rg + (8 + 6 + 28 + 24 + 8 + 20) * float(A)
+    if world > 1:                                           # a rank streams its own share of the rows (its ghost rows are not counted: conservative)
+        b_build /= world; b_egpass /= world; d_build /= world; d_egpass /= world
+    kernels = {}
+    for name, bytes_per_launch, design in (("build", b_build, d_build), ("eg_pass", b_egpass, d_egpass)):
+        ms, n, slow_ms, slow_n = timing_work[name]
+        if n > 0:
+            avg = ms / n                     # HIP events around each launch on the library's stream, no-op launches excluded
+            kernels[name] = {"launches": n, "launches_incl_noop": timing[name][1], "avg_ms": avg, "algorithmic_GB": bytes_per_launch / 1e9,
+                             "design_GB": design / 1e9, "achieved_GBs": bytes_per_launch / 1e9 / (avg * 1e-3),
+                             # launches slower than 4x the 90th percentile are not in avg_ms (a launch that straddles a device hiccup); reported, not hidden:
+                             "excluded_slow_launches": slow_n, "excluded_slow_ms": slow_ms, "avg_ms_incl_slow": (ms + slow_ms) / (n + slow_n)}
+    return kernels
+
+
+def roofline_of(name, kernels, Rg, A, world, attach_counters=True):
+    """The `roofline` object of one kernel.  `bound` comes from COUNTERS when a committed SQ pass of the same kernel tag and workload exists:
+         wait_share          = SQ_WAIT_ANY / SQ_WAVE_CYCLES         (share of resident wave-cycles spent in s_waitcnt)
+         valu_issue_share    = VALU instructions x measured cycles per instruction AT THE KERNEL'S OCCUPANCY / launch time
+       "latency" when the waves mostly wait and neither the memory system nor the VALU is saturated, "valu-issue" when the issue time fills the launch,
+       "hbm" otherwise (the byte model against the 8 TB/s peak is the figure of merit either way)."""
+    if name not in kernels:
+        return None
+    k = kernels[name]
+    tr = pmc_traffic(name, Rg, A) if (world == 1 and attach_counters) else None
+    out = {"kernel": {"build": "k_build<true>", "eg_pass": "k_eg_tile"}[name], "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+           "traffic_source": (f"committed PMC passes of this command, profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; not measured in this run)" if tr else None)}
+    sq = sq_valu(name, Rg) if (world == 1 and attach_counters) else None
+    if sq:
+        occ = KERNEL_OCCUPANCY.get(name, 4); cyc = VALU_CYCLES_BY_OCC[occ]
+        pk = sq.get("valu_pk", 0.0)
+        issue_ms = (sq["valu_f64"] * cyc["f64"] + pk * cyc["pk"] + (sq["valu"] - sq["valu_f64"] - pk) * cyc["f32"]) / (NUM_SIMD * GPU_CLOCK_HZ) * 1e3
+        cn = sq.get("counters", {})
+        wait_share = cn["SQ_WAIT_ANY"] / cn["SQ_WAVE_CYCLES"] if cn.get("SQ_WAVE_CYCLES") else None
+        out.update(valu_instructions=sq["valu"], valu_issue_ms=issue_ms, valu_frac=issue_ms / k["avg_ms"], occupancy_waves_per_simd=occ,
+                   wait_share=wait_share, valu_active_per_busy_cycle=(cn["SQ_ACTIVE_INST_VALU"] / cn["SQ_BUSY_CYCLES"] if cn.get("SQ_BUSY_CYCLES") else None),
+                   valu_source=f"profiles/{sq['source']} (SQ_INSTS_VALU, SQ_WAIT_ANY / SQ_WAVE_CYCLES, SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES; fp64 share from the ISA; cycles per instruction at {occ} waves per SIMD)")
+        if out["valu_frac"] >= 0.8:
+            out["bound"] = "valu-issue"
+        elif wait_share is not None and wait_share >= 0.5 and out["frac"] < 0.5:
+            out["bound"] = f"latency (s_waitcnt {100 * wait_share:.0f} % of the wave-cycles at {occ} waves per SIMD; VALU issue {100 * out['valu_frac']:.0f} % of the launch)"
+    return out
+
+
+def band2_leg(args, binding, log, device):
+    """SURVEY.md section 8(d)'s own C4 shape on the driver's record: the 4-voxel stored shell (--band 2).  The voxels on the rim of the stored band cannot own Eg
+    rows (their forward stencil leaves the band), so the work list averages ~3.2 rows per entry instead of 5.0 — the case the operator pass must be robust to
+    (per-group row counts bound a wave's row stream, tile_pass.hip).  Same voxel count / keyframes / configuration as the headline leg, fewer steps."""
+    import copy
+    a2 = copy.copy(args); a2.band = 2.0
+    sc = build_workload(a2, log)
+    thres = a2.shell * float(sc["voxel_size"])
+    arrays = grid_arrays(sc)
+    ctx = binding.Context(device)
+    try:
+        ctx.set_grid(sc["voxel_size"], arrays["keys"], arrays["sdf"], arrays["sdf_refined"], arrays["albedo"], arrays["weight"], arrays["color"])
+        ctx.set_frames(sc["frames"], 1)
+        ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
+        ctx.estimate_sh(a2.subvolume, 10.0, thres)
+        ctx.optimize(make_cfg(binding, a2, 1, thres))                 # warm-up
+        ctx.timing_enable(True); ctx.timing_select(["eg_pass", "build"]); ctx.timing_get(reset=True)
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = ctx.optimize(make_cfg(binding, a2, a2.band2_steps, thres))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timing_work = ctx.timing_get_work_ex(); timing = ctx.timing_get(reset=True); sizes = ctx.problem_sizes()
+        kernels = kernel_table(a2, sizes, 1, timing_work, timing)
+        A, Rg = sizes["active"], sizes["eg"]
+        return {"value": a2.band2_steps / dt, "unit": "GN iterations/s", "steps": a2.band2_steps, "warmup": 1, "ms_per_step": dt / a2.band2_steps * 1e3,
+                "workload": f"as config.workload with the 4-voxel stored shell of SURVEY.md 8(d) (--band 2): {arrays['keys'].shape[0]} stored voxels, {A} active, "
+                            f"{Rg} Eg rows = {Rg / max(1, A):.2f} per active voxel",
+                "stored_voxels": int(arrays["keys"].shape[0]), "active_voxels": A, "rows": {"Eg": Rg, "Er": sizes["er"], "Es": sizes["es"], "Ea": sizes["ea"]},
+                "lm_attempts": [int(s.num_attempts) for s in stats],
+                "roofline": roofline_of("eg_pass", kernels, Rg, A, 1, attach_counters=False), "roofline_build": roofline_of("build", kernels, Rg, A, 1, attach_counters=False), "kernels": kernels}
+    finally:
+        ctx.close()
 
 
 def sq_valu(kernel, eg_rows):
@@ -398,48 +499,10 @@ def _main():
     comm_stats = ctx.comm_stats() if sharded_run else None
     transport = ctx.comm_transport() if sharded_run else ""
 
-    # ---- roofline of the residual/Jacobian kernel and of the PCG operator kernel, both on SURVEY.md §8(d)'s byte model ----
-    # build (K2+K3):   68 A + 132 Rg + 36 Rr + 12 Rs + 16 Ra + B_img
-    # operator (K6):   4 nnz, nnz = 29 Rg + 7 Rr + Rs + 2 Ra  — §8(d)'s fused single-pass J^T J p ("4 nnz + 12*4 n" is the whole PCG iteration;
-    #                  the 48 n of vector passes belong to the vector kernels, not to this one)
-    # `design_GB` beside it is what THIS implementation must move per launch by construction: 120 B per stored Eg row (the 29 partials with the row
-    # weight folded in + the keyframe id; round 2: 128) + per work-list entry the operator input 8, flags 6, local stencil slots 28 (18 x 12 bits), symmetric Ea weights 24, accumulators out 8
-    # + ~20 B per tile-halo slot (~1 per entry); Er / Es rows are not stored (constant coefficients), so their 4 nnz bytes are never read.
     A, Rg, Rr, Rs, Ra = sizes["active"], sizes["eg"], sizes["er"], sizes["es"], sizes["ea"]
-    nnz = 29.0 * Rg + 7.0 * Rr + Rs + 2.0 * Ra
-    img_bytes = min(4.0 * args.frames * args.width * args.height, 256.0 * Rg)
-    b_build = 68.0 * A + 132.0 * Rg + 36.0 * Rr + 12.0 * Rs + 16.0 * Ra + img_bytes
-    b_egpass = 4.0 * nnz
-    d_build = b_build
-    d_egpass = 120.0 * Rg + (8 + 6 + 28 + 24 + 8 + 20) * float(A)
-    if world > 1:                                           # a rank streams its own share of the rows (its ghost rows are not counted: conservative)
-        b_build /= world; b_egpass /= world; d_build /= world; d_egpass /= world
-    kernels = {}
-    for name, bytes_per_launch, design in (("build", b_build, d_build), ("eg_pass", b_egpass, d_egpass)):
-        ms, n, slow_ms, slow_n = timing_work[name]
-        if n > 0:
-            avg = ms / n                     # HIP events around each launch on the library's stream, no-op launches excluded
-            kernels[name] = {"launches": n, "launches_incl_noop": timing[name][1], "avg_ms": avg, "algorithmic_GB": bytes_per_launch / 1e9,
-                             "design_GB": design / 1e9, "achieved_GBs": bytes_per_launch / 1e9 / (avg * 1e-3),
-                             # launches slower than 4x the 90th percentile are not in avg_ms (a launch that straddles a device hiccup); reported, not hidden:
-                             "excluded_slow_launches": slow_n, "excluded_slow_ms": slow_ms, "avg_ms_incl_slow": (ms + slow_ms) / (n + slow_n)}
-
+    kernels = kernel_table(args, sizes, world, timing_work, timing)
     def roof(name):
-        if name not in kernels:
-            return None
-        k = kernels[name]
-        tr = pmc_traffic(name, Rg, A) if world == 1 else None
-        out = {"kernel": {"build": "k_build<true>", "eg_pass": "k_eg_tile"}[name], "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
-               "traffic_source": (f"committed PMC passes of this command, profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; not measured in this run)" if tr else None)}
-        sq = sq_valu(name, Rg) if world == 1 else None
-        if sq:      # what actually limits the kernel: issue time of its VALU instructions against the measured launch time
-            pk = sq.get("valu_pk", 0.0)
-            issue_ms = (sq["valu_f64"] * VALU_CYCLES["f64"] + pk * VALU_CYCLES["pk"] + (sq["valu"] - sq["valu_f64"] - pk) * VALU_CYCLES["f32"]) / (NUM_SIMD * GPU_CLOCK_HZ) * 1e3
-            out.update(valu_instructions=sq["valu"], valu_issue_ms=issue_ms, valu_frac=issue_ms / k["avg_ms"], valu_source=f"profiles/{sq['source']} (SQ_INSTS_VALU; fp64 share from the ISA)")
-            if out["valu_frac"] > out["frac"]:
-                out["bound"] = "valu-issue"
-        return out
+        return roofline_of(name, kernels, Rg, A, world)
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
     roofline = roof(dominant) if dominant else None
     roofline_build = roof("build")           # the kernel the north star names, whichever one dominates
@@ -452,6 +515,12 @@ def _main():
         comm = {"transport": transport, "separate_launch_ms_total": ms, "separate_launches": n, "operator_passes": passes,
                 "separate_launch_us_per_pass": 1e3 * ms / passes, "stats_rank0": comm_stats}
 
+    band2 = None
+    if rank == 0 and world == 1 and args.band2_steps > 0 and abs(args.band - 2.0) > 1e-6 and not (args.force_collectives or args.pmc_calibrate or args.no_kernel_timing or args.all_kernel_timing or args.carry_radius):
+        try:
+            band2 = band2_leg(args, binding, log, local_rank)
+        except Exception as e:      # reported beside the headline; never lets it down
+            log(f"band-2 leg failed: {e}")
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         try:
@@ -482,6 +551,8 @@ def _main():
             "carry_trust_radius": bool(args.carry_radius), "kernel_tag": KERNEL_TAG,
             "optimize_calls": (args.steps + CALL_ITERATIONS - 1) // CALL_ITERATIONS, "iterations_per_call": min(CALL_ITERATIONS, args.steps),
             "roofline": roofline, "roofline_build": roofline_build, "kernels": kernels, "comm": comm,
+            # SURVEY.md 8(d)'s own C4 shape (4-voxel stored shell, ~3.2 Eg rows per voxel) beside the headline workload (7-voxel band, 5.0 rows per voxel)
+            "value_band2": band2["value"] if band2 else None, "roofline_band2": band2["roofline"] if band2 else None, "band2": band2,
             "kernel_ms_total": {k: v[0] for k, v in timing.items()}, "kernel_launches": {k: v[1] for k, v in timing.items()},
             "time_split_ms_per_step": {"time_add": float(np.mean([s.time_add for s in stats]) * 1e3), "time_build": float(np.mean([s.time_build for s in stats]) * 1e3),
                                        "time_solve": float(np.mean([s.time_solve for s in stats]) * 1e3)},      # nls_solver.cpp:66-67,101

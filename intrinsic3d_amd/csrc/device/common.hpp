@@ -132,6 +132,8 @@ struct RowView {                    // per work-list entry a in [0, A): voxels t
     float4* rows; float2* row_wr;
     __host__ __device__ float2* row_jt() const { return reinterpret_cast<float2*>(rows); }       // index with row_jt_index
     uint8_t* nrows;                 // [Acap]
+    int* gmax;                      // [ceil(Acap / 64)] largest nrows of every group of 64 entries (k_group_rows, after the build): the operator pass bounds a wave's row
+                                    // stream to the slots its group uses (buffer range check: the empty slots cost no memory traffic)
     uint8_t* regflags;              // [Acap] bit0 Er row, bit1 Es row, bit2 Es Jacobian is 1 (else 0), bit3 Er row has a free column, bit4 Es free
     float* ea_w;                    // [6][Acap] chroma weight of the Ea row towards 1-ring neighbour d, 0 = none
     uint8_t* ea_free;               // [Acap] bit d: Ea row d has a free column

@@ -154,6 +154,44 @@ void launch_compact(hipStream_t st, int N, const int* flag, const int* scan, con
     if (N > 0) k_compact<<<(N + 255) / 256, 256, 0, st>>>(N, flag, scan, flags, aidx, alist, aflags);
 }
 
+// Stable partition inside every block of 512 consecutive work-list entries (one workgroup per block): first the entries that can own Eg rows — active, with the
+// whole forward stencil of the shading term stored (shading_cost.cpp:65-70; what k_build calls `eligible`) — then the rest (free-only entries, active voxels on
+// the rim of the stored band).  The brick-Morton order inside both halves is kept; tile and slice membership (multiples of 512 entries) does not change.  Where a
+// band of the stored shell cannot own rows (SURVEY.md 8(d)'s 4-voxel shell: 36 % of the active voxels) the row-less entries now fill whole waves instead of
+// being sprinkled over all of them.
+__global__ void __launch_bounds__(512) k_partition_blocks(GridView g, int A, int* __restrict__ alist, uint8_t* __restrict__ aflags, int* __restrict__ aidx) {
+    __shared__ int wcount[8];
+    const int base = blockIdx.x * 512, a = base + (int)threadIdx.x;
+    const bool in = a < A;
+    const int s = in ? alist[a] : -1;
+    const uint8_t fl = in ? aflags[a] : 0;
+    bool rows = in && (fl & F_ACTIVE);
+    if (rows) {
+#pragma unroll
+        for (int c = 1; c < 10; ++c) rows &= g.nbr[(size_t)slot_fwd_nbr(c) * g.N + s] >= 0;
+    }
+    const unsigned long long m = __ballot(rows);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wcount[w] = __popcll(m);
+    __syncthreads();                                                 // (also: every entry of the block is read before any is rewritten)
+    int before = 0, total = 0;
+    for (int i = 0; i < 8; ++i) { const int cnt = wcount[i]; if (i < w) before += cnt; total += cnt; }
+    const int rank_rows = before + __popcll(m & ((1ull << lane) - 1ull));             // entries with rows in front of this one
+    const int pos = rows ? rank_rows : total + ((int)threadIdx.x - rank_rows);         // stable on both sides
+    if (in) { const int na = base + pos; alist[na] = s; aflags[na] = fl; aidx[s] = na; }
+}
+void launch_partition_blocks(hipStream_t st, GridView g, int A, int* alist, uint8_t* aflags, int* aidx) {
+    if (A > 0) k_partition_blocks<<<(A + 511) / 512, 512, 0, st>>>(g, A, alist, aflags, aidx);
+}
+__global__ void k_group_rows(int A, const uint8_t* __restrict__ nrows, int* __restrict__ gmax) {
+    const int gq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (64 * gq >= A) return;
+    int m = 0;
+    for (int i = 0; i < 64 && 64 * gq + i < A; ++i) m = max(m, (int)nrows[64 * (size_t)gq + i]);
+    gmax[gq] = m;
+}
+void launch_group_rows(hipStream_t st, int A, const uint8_t* nrows, int* gmax) { if (A > 0) k_group_rows<<<((A + 63) / 64 + 255) / 256, 256, 0, st>>>(A, nrows, gmax); }
+
 // neighbour table of the work list in LIST space: the solver's vectors live there (2A + 6K + 9 entries instead of 2N + ...)
 __global__ void k_anbr(int N, int A, int Acap, const int* __restrict__ alist, const int* __restrict__ nbr, const int* __restrict__ aidx, int* __restrict__ anbr) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;

@@ -16,6 +16,10 @@ void launch_hash_build(hipStream_t st, int N, const int* cx, const int* cy, cons
 void launch_nbr_build(hipStream_t st, int N, const int* cx, const int* cy, const int* cz, HashTable t, int* nbr);
 void launch_classify(hipStream_t st, GridView g, OptParams p, int* active_flag);
 void launch_compact(hipStream_t st, int N, const int* active_flag, const int* active_scan, const uint8_t* flags, int* aidx, int* alist, uint8_t* aflags);
+// stable partition of every 512-entry block of the work list: entries that can own Eg rows (active, whole forward stencil stored) first.  Entries without rows then
+// fill whole waves of the operator pass, which skip their row stream (k_group_rows); tiles (512 / 1024 entries) and rank slices keep their members
+void launch_partition_blocks(hipStream_t st, GridView g, int A, int* alist, uint8_t* aflags, int* aidx);
+void launch_group_rows(hipStream_t st, int A, const uint8_t* nrows, int* gmax);       // gmax[g] = max nrows over entries [64 g, 64 g + 64)
 void launch_anbr(hipStream_t st, int N, int A, int Acap, const int* alist, const int* nbr, const int* aidx, int* anbr);
 void launch_scatter_sh(hipStream_t st, int N, const int* rank, const double* sh_visit /*[N][9]*/, float* sh /*[9][N]*/);
 void launch_gather_visit(hipStream_t st, int N, const int* rank, const double* x_sdf, const double* x_alb, double* out_sdf, double* out_alb);

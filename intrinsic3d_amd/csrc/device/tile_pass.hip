@@ -186,7 +186,9 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                                                         double* __restrict__ shared, float* __restrict__ qacc, float* __restrict__ qh, double* __restrict__ pq_partials,
                                                         int reps, int tiles_per_block, int tile_first, int n_own /* tiles [tile_first, +n_own): this rank's own */,
                                                         const int* __restrict__ ghost_list /* then ntl - n_own foreign tiles holding ghost entries */, int ntl, const PcgState* __restrict__ state,
-                                                        float* __restrict__ cam_partials /* or null: [gridDim.x][cam_stride] camera block of this workgroup (no atomics) */, int cam_stride) {
+                                                        float* __restrict__ cam_partials /* or null: [gridDim.x][cam_stride] camera block of this workgroup (no atomics) */, int cam_stride,
+                                                        const int* __restrict__ gmaxv /* = r.gmax as a restrict-qualified kernel argument: its wave-uniform loads become scalar loads (lgkmcnt), a
+                                                                                         vector load here would put an s_waitcnt vmcnt(0) behind the row blocks just requested */) {
     if (state && state->done) return;
     constexpr int ZSLOT = T + HMAX, NSLOT = ZSLOT + 1;
     extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T] | p.q [T] fp64
@@ -234,14 +236,27 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     // slot-0 block (wave-uniform: scalar registers): a lane contributes one 32-bit offset register, the slot / plane offsets are scalar or immediate —
     // instead of a 64-bit per-lane pointer per stream (the row loop has no register to spare; a spilled pointer there is reloaded per row block, and
     // every reload is an s_waitcnt vmcnt(0) that drains the stream).  num_records bounds the wave to its own blocks.
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)r.rows, 0, 0, 0x00020000);
+    // The descriptor of slot k covers exactly the wave's block of that slot — or NOTHING when no entry of the wave's group has more than k rows (gm = r.gmax of
+    // the group, k_group_rows): a buffer load outside its descriptor's range returns zeros without touching memory, so the unrolled, branch-free row loop below
+    // keeps its exactly counted s_waitcnt while the empty slots of a group cost no bandwidth (round 3 streamed all five slots of every group: 36 % padding on
+    // SURVEY.md 8(d)'s 4-voxel shell).  (One descriptor per slot, not one descriptor + a slot offset: the range check sees only voffset + the immediate.)
+    const char* wave_rows = reinterpret_cast<const char*>(r.rows);      // the wave's slot-0 block (wave-uniform, set per tile)
+    int gm = 0;                                                          // slots in use in the wave's group
     const unsigned lane16 = (threadIdx.x & 63u) * 16u;
     auto load_block = [&](RowBlock& rw, int k, int slots) {
         (void)slots;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wave_rows, 0, k < gm ? MAX_SLOTS * ROW_BLOCK_F4 * 16 : 0, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 7; ++q) { const v4u_b v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, k * (ROW_BLOCK_F4 * 16) + q * 1024, 2 /* nt */);
                                       rw.p[q] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
         { const v2u_b t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane16 >> 1, k * (ROW_BLOCK_F4 * 16) + 64 * ROW_PLANES * 16, 2); rw.j28 = __uint_as_float(t.x); rw.tag = (int)t.y; }
+    };
+    // group row count of the wave in tile `tk` (scalar load); requested one tile ahead so that the descriptors of a tile never wait for it
+    auto tile_of = [&](int tk) { return (GHOSTS && tk >= n_own) ? ghost_list[tk - n_own] : tile_first + tk; };
+    auto group_rows = [&](int tk) -> int {
+        const int wa0 = tile_of(tk) * T + (int)(threadIdx.x & ~63u);
+        const int grp = __builtin_amdgcn_readfirstlane(wa0 < A ? (wa0 >> 6) : -1);
+        return grp >= 0 ? gmaxv[grp] : 0;
     };
     auto issue_A = [&]() { load_block(rwA, 0, r.slots); };
     auto issue_B = [&]() { if (SLOTS > 1 || (SLOTS == 0 && r.slots > 1)) load_block(rwB, 1, r.slots); };
@@ -256,7 +271,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         ac = in ? (size_t)a : 0;
         { const int wa0 = base + (int)(threadIdx.x & ~63u);                                  // first entry of this wave: wave-uniform
           const unsigned grp = (unsigned)__builtin_amdgcn_readfirstlane(wa0 < A ? (wa0 >> 6) : 0);
-          rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(r.rows + (size_t)grp * (size_t)(r.slots * ROW_BLOCK_F4)), 0, r.slots * (ROW_BLOCK_F4 * 16), 0x00020000); }
+          wave_rows = reinterpret_cast<const char*>(r.rows + (size_t)grp * (size_t)(r.slots * ROW_BLOCK_F4)); }
         H = halo_cnt[tile];
         us = in ? u[a] : 0.0f; ua = in ? u[chunk + a] : 0.0f;
         // branch-free (unconditional loads, padding slots gather entry 0 and are zeroed when staged): loads under divergent branches are waited for at
@@ -274,11 +289,14 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
 #pragma unroll
         for (int w = 0; w < 5; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);      // per-entry plan data: read once per pass, like the rows
     };
+    int gm_next = tile0 < tk_end ? group_rows(tile0) : 0;
     for (int tk = tile0; tk < tk_end; ++tk) {
+        gm = gm_next;
         issue_in(tk);
         issue_meta();
         issue_A();
         issue_B();
+        gm_next = tk + 1 < tk_end ? group_rows(tk + 1) : 0;
         const bool ghost_tile = GHOSTS && tk >= n_own;     // a few ghost rows on the rim of a neighbour's tile: most of its waves have nothing to stream
         // ---- stage the operator input of tile + halo, clear the accumulators ----
         u_s[i] = us; u_a[i] = ua;
@@ -527,7 +545,7 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
 #define I3D_EGT(SL, GH) do { \
         if (!set_dynamic_lds((const void*)k_eg_tile<T, HMAX, SL, GH>, "k_eg_tile", lds, p.K)) break; \
         k_eg_tile<T, HMAX, SL, GH><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
-                                                   t.ghost_tiles, ntl, state, cam_partials, cam_stride); } while (0)
+                                                   t.ghost_tiles, ntl, state, cam_partials, cam_stride, r.gmax); } while (0)
             const bool gh = t.n_ghost > 0;
             // the shipped num_observations (data/intrinsic3d.yml): unrolled row loop.  (The run-time loop, which skips the slots no lane of a wave uses, is
             // slower even where 36 % of the slots are empty: 0.577 vs 0.483 ms on --band 2, 0.336 vs 0.272 on the default workload.)

@@ -83,7 +83,7 @@ i3d::RowView i3d_context::row_view() const {
     RowView r;
     r.A = A; r.Acap = Acap; r.slots = slots; r.chunk = chunk; r.world = comm ? comm->world : 1; r.own0 = own0; r.own1 = own1;
     r.clist = (comm && (comm->world > 1 || comm->force)) ? clist.p : nullptr; r.nC = nC; r.alist = alist.p; r.aflags = aflags.p; r.anbr = anbr.p; r.obs_frame = obs_frame.p; r.obs_w = obs_w.p;
-    r.rows = rows.p; r.row_wr = row_wr.p; r.nrows = nrows.p; r.regflags = regflags.p; r.ea_w = ea_w.p; r.ea_free = ea_free.p;
+    r.rows = rows.p; r.row_wr = row_wr.p; r.nrows = nrows.p; r.gmax = gmax.p; r.regflags = regflags.p; r.ea_w = ea_w.p; r.ea_free = ea_free.p;
     return r;
 }
 

@@ -84,7 +84,7 @@ struct i3d_context {
     i3d::DevBuf<float> halo_send_buf, halo_recv_buf; i3d::DevBuf<unsigned char> halo_temp; int n_ghost_tiles = 0, slice = 0;
     i3d::DevBuf<int> obs_frame, anbr; i3d::DevBuf<float> obs_w, ea_w, C, treg;
     i3d::DevBuf<float4> rows; i3d::DevBuf<float2> row_wr;
-    i3d::DevBuf<uint8_t> aflags, nrows, regflags, ea_free;
+    i3d::DevBuf<uint8_t> aflags, nrows, regflags, ea_free; i3d::DevBuf<int> gmax;
     // tiled operator pass (tile_pass.hip): plan of the current work list
     i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_ext_off, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw, cam_part;
     i3d::DevBuf<unsigned char> tp_temp; bool tile_ok = false;

@@ -47,7 +47,7 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->obs_frame.alloc(Acap * slots)); CTX_HIP(c, c->obs_w.alloc(Acap * slots));
     { const size_t nrow = ((Acap + 63) / 64) * 64 * (size_t)slots;
       CTX_HIP(c, c->rows.alloc(nrow / 64 * ROW_BLOCK_F4)); CTX_HIP(c, c->row_wr.alloc(nrow)); }
-    CTX_HIP(c, c->aflags.alloc(Acap)); CTX_HIP(c, c->nrows.alloc(Acap)); CTX_HIP(c, c->anbr.alloc(Acap * NUM_NBR));
+    CTX_HIP(c, c->aflags.alloc(Acap)); CTX_HIP(c, c->nrows.alloc(Acap)); CTX_HIP(c, c->gmax.alloc(Acap / 64 + 2)); CTX_HIP(c, c->anbr.alloc(Acap * NUM_NBR));
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8));
     { // sized for BOTH tile geometries: the 512-entry one needs the most slots on large grids (3 per entry; 1024: 2), but a grid of <= 512 entries is ONE
@@ -205,7 +205,10 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     CTX_HIP(c, hipMemcpyAsync(&tail[1], c->aflag.p + (c->N - 1), sizeof(int), hipMemcpyDeviceToHost, s));
     CTX_HIP(c, sync_stream(c));
     c->A = tail[0] + tail[1];
-    { TimedScope t(c, I3D_K_CLASSIFY); launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
+    { TimedScope t(c, I3D_K_CLASSIFY);
+      static const bool no_partition = [] { const char* e = std::getenv("I3D_NO_PARTITION"); return e && e[0] == '1'; }();      // A/B runs
+      if (!no_partition) launch_partition_blocks(s, g, c->A, c->alist.p, c->aflags.p, c->aidx.p);
+      launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
     c->tile_ok = false; c->tile_T = 0;
     if (!sharded(c)) {
         shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; c->slice = c->chunk;
@@ -241,6 +244,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     // time_build = buildProblem (cost functions, weight normalisation), time_solve.  The boundary is an event on the stream (round 3: a synchronisation).
     CTX_HIP(c, hipEventRecord(c->ev_asm[1], s));
     { TimedScope t(c, I3D_K_BUILD); launch_build(s, g, r, p, c->d_frames.p, true, nullptr, c->d_partials.p); }
+    { TimedScope t(c, I3D_K_CLASSIFY); launch_group_rows(s, c->A, c->nrows.p, c->gmax.p); }
     { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan(), sharded(c) ? c->cflag.p : nullptr); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
     { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, c->d_scal.p, c->d_partials.p); }
