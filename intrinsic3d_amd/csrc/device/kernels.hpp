@@ -114,6 +114,13 @@ int  launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, Tile
 void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext_off);
 
 // ---- pcg_fused.hip: the PCG iteration in three launches (single rank): k_pcg_dir3 | k_eg_tile | k_pcg_step3 -----------------------
+// sharded three-launch pass over the peer-to-peer mailboxes: what k_pcg_dir3 / k_pcg_step3 need besides their single-rank arguments (the exchanges run INSIDE them)
+struct ShardArgs {
+    P2PDev pd; RimLists rim; int seq;      // seq: pass number of the host, identical on all ranks -> the epochs of the pass's exchanges (p2p_device.hpp)
+    int n_slice_partials;                   // k_pcg_dir3: step partials [0, n) are sums over this rank's slice, the rest the (replicated) camera tail's
+    int n_rim_wg;                           // k_pcg_dir3: workgroups that exchange the rim
+    const float* zb; float* pb; float* ub; const float* cmb; int chunk;      // whole vectors (rim entries are addressed absolutely)
+};
 struct Step3Args {
     int nq; int chunk4;
     const float4* p; const float4* qacc; float4* x; float4* r; const float4* b; float4* z;
@@ -126,11 +133,14 @@ struct Step3Args {
     const float* tp; float* tx; float* tr; const float* tb; const float* tD2; float* tz; const float* tS;
     double* step_partials;
     PcgState* cur;
+    int sharded; ShardArgs sh;              // sharded: p.q and the camera block are summed over the ranks inside the kernel; d2_partials[n_d2] = the camera tail's D^2 p^2 (replicated, counted once)
 };
 void launch_pcg_init3(hipStream_t st, PcgState* st2 /* [2] */, int fixed_iterations, int max_iterations, const LmState* lm = nullptr);
 int  launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, const LmState* lm,
-                     const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq);   // returns #d2 partials
-int  pcg_step3_slice_wgs(int n_entries);
+                     const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq,
+                     const ShardArgs* sa = nullptr);   // returns #d2 partials of the slice (sharded: the tail's follows at that index)
+void launch_rim_u(hipStream_t st, const ShardArgs& sa, const PcgState* state);      // sharded residual-reset pass: the rim of u = S x
+int  pcg_step3_slice_wgs(int n_entries, int cap = 0);      // cap > 0: at most this many (rank simulation on one device)
 int  pcg_step3_tail_wgs(int K);
 int  launch_pcg_step3(hipStream_t st, int mode /* 0 init | 1 normal | 2 x only | 3 reset */, Step3Args a);                                          // returns #[4]-partials
 void launch_halo_fold(hipStream_t st, RowView r, TilePlan t, float* qacc, const PcgState* state);

@@ -17,6 +17,7 @@
 // Everything here is deterministic: no floating-point atomics, fixed summation orders.
 #include "kernels.hpp"
 #include "reduce_device.hpp"
+#include <cstring>
 
 namespace i3d {
 
@@ -66,22 +67,54 @@ void launch_pcg_init3(hipStream_t st, PcgState* st2, int fixed_iterations, int m
 // operator.hip, expression for expression): the two vector kernels of a pass read ONE array instead of S, D^2 and M^-1 (24 B less per entry and pass)
 static __device__ inline void lm_from_colnorm(float cm, float inv_radius, float& s, float& d2, float& minv) { s = lm_scale(cm); lm_diag(cm, s, inv_radius, d2, minv); }
 
-// iteration boundary + direction.  `prev` was written by the previous boundary, `next` is read by the operator / step kernels of this pass
-__global__ void __launch_bounds__(PF_THREADS) k_pcg_dir3(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
+// iteration boundary + direction.  `prev` was written by the previous boundary, `next` is read by the operator / step kernels of this pass.
+// SH (sharded run over the peer-to-peer mailboxes, p2p_device.hpp): the ONE exchange of the boundary happens in here —
+//   * workgroup 0 stores this rank's four slice sums into every rank's mailbox, every workgroup of every rank reads all contributions and adds them in rank
+//     order (bit-identical scalars everywhere, no launch, no grid barrier); the sums of the replicated camera tail are added once, locally;
+//   * the rim rides with it: a few extra workgroups store z on the owned entries the peers' rows read straight into the peers' mailboxes BEFORE they wait for
+//     anything, and — once beta is known — rebuild p = z + beta p and u = S p on the foreign entries this rank's rows read (every rank holds the column norms of
+//     all entries, so S is local).  Round 3 pushed u = S p with a launch of its own after the direction kernel, between two all-reduce launches.
+// Workgroup roles (SH), by blockIdx: [0, n_rim) rim | n_rim .. n_rim + n_main - 1 the slice | the last one the camera tail.  Their partial sums of D^2 p^2 land
+// at [0, n_main) (slice) and [n_main] (tail, counted once by k_pcg_step3 after ITS exchange).
+template <bool SH>
+__global__ void __launch_bounds__(PF_THREADS, SH ? 4 : 1) k_pcg_dir3(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
                                                         const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ D2 /* S, D2: the camera tail */,
                                                         const float* __restrict__ cm, const LmState* __restrict__ lm, const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
-                                                        const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq) {
+                                                        const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq, ShardArgs sa) {
     __shared__ double sm[4 * 8];
+    __shared__ double smx[SH ? 4 * P2P_MAX_RANKS : 1];
     // (seq, done) goes to a 2-slot ring in pinned host memory: the host polls it one pass behind
     auto publish = [&](int done) { if (host_flags) { __hip_atomic_store(&host_flags[2 * (seq & 1) + 1], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                                      __hip_atomic_store(&host_flags[2 * (seq & 1)], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); } };
-    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    // logical workgroup: 0 .. n_main - 1 slice, n_main the camera tail (SH only), beyond: rim
+    const int n_rim = SH ? sa.n_rim_wg : 0, n_main = SH ? (int)gridDim.x - n_rim - 1 : (int)gridDim.x;
+    const int lid = SH ? ((int)blockIdx.x < n_rim ? n_main + 1 + (int)blockIdx.x : (int)blockIdx.x - n_rim) : (int)blockIdx.x;
+    const bool rim_wg = SH && lid > n_main, tail_wg = SH ? lid == n_main : lid == n_main - 1;
+    const bool writer = lid == 0 && threadIdx.x == 0;
     const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
     const float4* C4 = reinterpret_cast<const float4*>(cm); float4* u4 = reinterpret_cast<float4*>(u);
-    if (prev->done) { if (writer) { *next = *prev; publish(prev->done); } return; }
+    if (prev->done) { if (writer) { *next = *prev; publish(prev->done); } return; }      // (the same decision on every rank: the state is replicated bit for bit)
     const float inv_radius = lm->inv_radius;                         // (uniform: a scalar load)
     double tot[4];
-    reduce_partials_all<4>(step_partials, n_step, tot, sm);
+    if (!SH) reduce_partials_all<4>(step_partials, n_step, tot, sm);
+    else {
+        const unsigned e32 = p2p_pass_epoch(seq, P2P_X_DIR);
+        if (rim_wg) {                                                // z on the owned rim -> the peers' mailboxes, before any wait
+            const RimLists& rl = sa.rim;
+            for (int j = (lid - n_main - 1) * PF_THREADS + threadIdx.x; j < rl.n_send; j += n_rim * PF_THREADS) {
+                const int e = rl.send_idx[j], k = rl.send_peer[j];
+                p2p_put_rim(sa.pd, 0, e32, k, j - rl.send_off[k], sa.zb[e], sa.zb[(size_t)sa.chunk + e]);
+            }
+        }
+        {   double loc[4];
+            reduce_partials_all<4>(step_partials, sa.n_slice_partials, loc, sm);                                               // this rank's slice
+            if (lid == 0 && threadIdx.x < 4) p2p_put_double_all(sa.pd, 0, e32, threadIdx.x, threadIdx.x == 0 ? loc[0] : threadIdx.x == 1 ? loc[1] : threadIdx.x == 2 ? loc[2] : loc[3]); }
+        double tl[4];
+        reduce_partials_all<4>(step_partials + 4 * (size_t)sa.n_slice_partials, n_step - sa.n_slice_partials, tl, sm);         // the camera tail (replicated)
+        p2p_sum_all<4>(sa.pd, 0, e32, tot, smx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot[k] += tl[k];
+    }
     int it = prev->it, done = 0; bool stop = false;
     double Q0 = prev->Q0, Q1 = prev->Q1, xbr = prev->xbr, xr = prev->xr, d2xx = prev->d2xx;
     if (!init) {                                                     // end of iteration it: quadratic-model termination (eta = 0.1)
@@ -111,38 +144,78 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_dir3(int init, int n4, int s
         *next = s;
         publish(done);
     }
-    if (stop) return;
+    if (stop) return;                                                // (rim words already sent stay unread: their epoch is never asked for again)
     const float betaf = (float)beta; const bool first = it == 0;
-    double d2 = 0.0;
-    for (int j = blockIdx.x * PF_THREADS + threadIdx.x; j < 2 * n4; j += gridDim.x * PF_THREADS) {
-        const int i = j < n4 ? j : j - n4 + seg4;
-        float4 pi = z4[i]; const float4 cv = C4[i];
-        if (!first) { const float4 po = p4[i]; pi.x += betaf * po.x; pi.y += betaf * po.y; pi.z += betaf * po.z; pi.w += betaf * po.w; }
-        p4[i] = pi;
-        float4 sv, dd; float mi;
-        lm_from_colnorm(cv.x, inv_radius, sv.x, dd.x, mi); lm_from_colnorm(cv.y, inv_radius, sv.y, dd.y, mi);
-        lm_from_colnorm(cv.z, inv_radius, sv.z, dd.z, mi); lm_from_colnorm(cv.w, inv_radius, sv.w, dd.w, mi);
-        u4[i] = make_float4(sv.x * pi.x, sv.y * pi.y, sv.z * pi.z, sv.w * pi.w);
-        d2 += (double)dd.x * (double)pi.x * (double)pi.x + (double)dd.y * (double)pi.y * (double)pi.y + (double)dd.z * (double)pi.z * (double)pi.z + (double)dd.w * (double)pi.w * (double)pi.w;
+    if (rim_wg) {                                                    // p = z + beta p, u = S p on the foreign entries this rank's rows read
+        const RimLists& rl = sa.rim; const unsigned e32 = p2p_pass_epoch(seq, P2P_X_DIR);
+        for (int j = (lid - n_main - 1) * PF_THREADS + threadIdx.x; j < rl.n_recv; j += n_rim * PF_THREADS) {
+            const int e = rl.recv_idx[j], k = rl.recv_peer[j];
+            float zs, za; p2p_get_rim(sa.pd, 0, e32, k, j - rl.recv_off[k], zs, za);
+            const size_t ea = (size_t)sa.chunk + e;
+            const float ps = first ? zs : zs + betaf * sa.pb[e], pa = first ? za : za + betaf * sa.pb[ea];
+            sa.pb[e] = ps; sa.pb[ea] = pa;
+            sa.ub[e] = lm_scale(sa.cmb[e]) * ps; sa.ub[ea] = lm_scale(sa.cmb[ea]) * pa;
+        }
+        return;
     }
-    if (blockIdx.x == gridDim.x - 1) {                               // the camera tail (6K+9 unknowns) rides with the last workgroup
+    double d2 = 0.0;
+    if (!SH || !tail_wg) {
+        for (int j = lid * PF_THREADS + threadIdx.x; j < 2 * n4; j += n_main * PF_THREADS) {
+            const int i = j < n4 ? j : j - n4 + seg4;
+            float4 pi = z4[i]; const float4 cv = C4[i];
+            if (!first) { const float4 po = p4[i]; pi.x += betaf * po.x; pi.y += betaf * po.y; pi.z += betaf * po.z; pi.w += betaf * po.w; }
+            p4[i] = pi;
+            float4 sv, dd; float mi;
+            lm_from_colnorm(cv.x, inv_radius, sv.x, dd.x, mi); lm_from_colnorm(cv.y, inv_radius, sv.y, dd.y, mi);
+            lm_from_colnorm(cv.z, inv_radius, sv.z, dd.z, mi); lm_from_colnorm(cv.w, inv_radius, sv.w, dd.w, mi);
+            u4[i] = make_float4(sv.x * pi.x, sv.y * pi.y, sv.z * pi.z, sv.w * pi.w);
+            d2 += (double)dd.x * (double)pi.x * (double)pi.x + (double)dd.y * (double)pi.y * (double)pi.y + (double)dd.z * (double)pi.z * (double)pi.z + (double)dd.w * (double)pi.w * (double)pi.w;
+        }
+    }
+    if (tail_wg) {                                                   // the camera tail (6K+9 unknowns): with the last slice workgroup, or (SH) a workgroup of its own
         for (int t = threadIdx.x; t < ntail; t += PF_THREADS) {
             const size_t i = tail_rel + t;
             const float pi = first ? z[i] : z[i] + betaf * p[i]; p[i] = pi; u[i] = S[i] * pi;
             d2 += (double)D2[i] * (double)pi * (double)pi;
         }
     }
-    block_partial_d(d2, d2_partials, 1, 0);
+    { const double t = block_sum_d(d2); if (threadIdx.x == 0) d2_partials[lid] = t; }
 }
 
+static int dir3_main_wgs(int n_entries, int cap) { int b = (n_entries / 2 + PF_THREADS - 1) / PF_THREADS; b = b < 1 ? 1 : b; return b > cap ? cap : b; }      // 2 * (n / 4) float4 items
+// returns the number of D^2 p^2 partials of the SLICE (sharded: the tail's own partial follows at that index)
 int launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, const LmState* lm,
-                    const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq) {
+                    const double* step_partials, int n_step, double* d2_partials, const PcgState* prev, PcgState* next, int* host_flags, int seq, const ShardArgs* sa) {
     const int n4 = sg.n >> 2, seg4 = (int)((sg.off1 - sg.off0) >> 2);
-    int blocks = (2 * n4 + PF_THREADS - 1) / PF_THREADS; blocks = blocks < 1 ? 1 : (blocks > PF_MAX_WG ? PF_MAX_WG : blocks);
     const size_t o = sg.off0;
-    k_pcg_dir3<<<blocks, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, lm, step_partials, n_step, d2_partials, prev, next, host_flags, seq);
-    return blocks;
+    if (!sa) {
+        const int blocks = dir3_main_wgs(sg.n, PF_MAX_WG);
+        ShardArgs none; std::memset(&none, 0, sizeof(none));
+        k_pcg_dir3<false><<<blocks, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, lm, step_partials, n_step, d2_partials, prev, next, host_flags, seq, none);
+        return blocks;
+    }
+    const int cap = sa->pd.wg_cap > 0 ? sa->pd.wg_cap : PF_MAX_WG;
+    const int n_main = dir3_main_wgs(sg.n, cap);
+    k_pcg_dir3<true><<<sa->n_rim_wg + n_main + 1, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, lm, step_partials, n_step, d2_partials, prev, next,
+                                                                       host_flags, seq, *sa);
+    return n_main;
 }
+
+// residual-reset passes of a sharded run: the rim of the operator input u = S x (k_pcg_dir3's rim workgroups move z, not u).  Once per ten passes.
+__global__ void __launch_bounds__(PF_THREADS) k_rim_u(ShardArgs sa, const PcgState* __restrict__ state) {
+    if (state->done) return;
+    const RimLists& rl = sa.rim; const unsigned e32 = p2p_pass_epoch(sa.seq, P2P_X_RESET_RIM);
+    for (int j = blockIdx.x * PF_THREADS + threadIdx.x; j < rl.n_send; j += gridDim.x * PF_THREADS) {
+        const int e = rl.send_idx[j], k = rl.send_peer[j];
+        p2p_put_rim(sa.pd, 0, e32, k, j - rl.send_off[k], sa.ub[e], sa.ub[(size_t)sa.chunk + e]);
+    }
+    for (int j = blockIdx.x * PF_THREADS + threadIdx.x; j < rl.n_recv; j += gridDim.x * PF_THREADS) {
+        const int e = rl.recv_idx[j], k = rl.recv_peer[j];
+        float us, ua; p2p_get_rim(sa.pd, 0, e32, k, j - rl.recv_off[k], us, ua);
+        sa.ub[e] = us; sa.ub[(size_t)sa.chunk + e] = ua;
+    }
+}
+void launch_rim_u(hipStream_t st, const ShardArgs& sa, const PcgState* state) { if (sa.rim.n_send > 0 || sa.rim.n_recv > 0) k_rim_u<<<sa.n_rim_wg > 0 ? sa.n_rim_wg : 1, PF_THREADS, 0, st>>>(sa, state); }
 
 enum { S3_INIT = 0, S3_NORMAL = 1, S3_XONLY = 2, S3_RESET = 3 };
 
@@ -171,9 +244,13 @@ template <int MODE> static __device__ inline void s3_load(const Step3Args& a, in
     }
 }
 
-template <int MODE>
+// SH (sharded run over the mailboxes): the second exchange of a pass happens in here — this rank's p.q (rows it owns + D^2 p^2 of its slice) is summed over the
+// ranks in the prologue of EVERY workgroup (workgroup 0 stores it into all mailboxes), and the camera workgroups sum their columns of the operator's camera
+// block over the ranks before they update the (replicated) camera tail.  No launch of its own, no vector leaves a rank.
+template <int MODE, bool SH>
 __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
     __shared__ double sm[4 * 8];
+    __shared__ double smx[SH ? P2P_MAX_RANKS : 1];
     __shared__ double camv[64];
     __shared__ double camred[8][64];
     __shared__ float rs[64];
@@ -193,6 +270,12 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
     if (MODE == S3_NORMAL || MODE == S3_XONLY) {                     // p.q = sum over rows of t (J u) + sum D^2 p^2  ->  alpha = rho / p.q
         double t1[1];
         reduce_partials_all<1>(a.pq_partials, a.n_pq, t1, sm, a.d2_partials, a.n_d2);      // both lists in ONE reduction (one barrier pair instead of two)
+        if (SH) {
+            const unsigned e32 = p2p_pass_epoch(a.sh.seq, P2P_X_STEP);
+            if (blockIdx.x == 0 && threadIdx.x == 0) p2p_put_double_all(a.sh.pd, 1, e32, 0, t1[0]);
+            p2p_sum_all<1>(a.sh.pd, 1, e32, t1, smx);
+            t1[0] += a.d2_partials[a.n_d2];                                                // the camera tail's D^2 p^2: replicated, counted once
+        }
         const double pq = t1[0];
         const double al = cur->rho / pq;
         const bool bad = !(pq > 0.0) || isinf(pq) || isinf(al);
@@ -276,7 +359,15 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
             if (c < ncol) for (int w = g; w < a.n_cam; w += 8) v += (double)a.cam_partials[(size_t)w * a.cam_stride + col0 + c];
             camred[g][c] = v;
             __syncthreads();
-            if (t < ncol) { double s = 0.0; for (int gg = 0; gg < 8; ++gg) s += camred[gg][t]; camv[t] = s; }
+            if (t < ncol) {
+                double s = 0.0; for (int gg = 0; gg < 8; ++gg) s += camred[gg][t];
+                if (SH) {       // this rank's column sums (rows it owns) -> all ranks; the total in rank order
+                    const unsigned e32 = p2p_pass_epoch(a.sh.seq, MODE == S3_RESET ? P2P_X_RESET_STEP : P2P_X_STEP);
+                    p2p_put_double_all(a.sh.pd, 1, e32, 1 + col0 + t, s);
+                    s = 0.0; for (int j = 0; j < a.sh.pd.L.world; ++j) s += p2p_get_double(a.sh.pd, 1, e32, j, 1 + col0 + t);
+                }
+                camv[t] = s;
+            }
             __syncthreads();
         }
         if (t < ncol) {
@@ -315,18 +406,20 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
     block_partial_d(s0, a.step_partials, 4, 0); block_partial_d(s1, a.step_partials, 4, 1); block_partial_d(s2, a.step_partials, 4, 2); block_partial_d(s3, a.step_partials, 4, 3);
 }
 
-int pcg_step3_slice_wgs(int n_entries) { int b = (n_entries / 4 + PF_THREADS - 1) / PF_THREADS; return b < 1 ? 1 : (b > PF_MAX_WG ? PF_MAX_WG : b); }
+int pcg_step3_slice_wgs(int n_entries, int cap) { if (cap <= 0 || cap > PF_MAX_WG) cap = PF_MAX_WG; int b = (n_entries / 4 + PF_THREADS - 1) / PF_THREADS; return b < 1 ? 1 : (b > cap ? cap : b); }
 int pcg_step3_tail_wgs(int K) { return (K + PF_POSES_PER_WG - 1) / PF_POSES_PER_WG + 1; }
 
 // returns the number of [4]-partials written (0 in XONLY mode)
 int launch_pcg_step3(hipStream_t st, int mode, Step3Args a) {
     const int blocks = a.n_slice_wg + pcg_step3_tail_wgs(a.K);
+#define I3D_S3(M) do { if (a.sharded) k_pcg_step3<M, true><<<blocks, PF_THREADS, 0, st>>>(a); else k_pcg_step3<M, false><<<blocks, PF_THREADS, 0, st>>>(a); } while (0)
     switch (mode) {
-        case S3_INIT:   k_pcg_step3<S3_INIT><<<blocks, PF_THREADS, 0, st>>>(a); break;
-        case S3_NORMAL: k_pcg_step3<S3_NORMAL><<<blocks, PF_THREADS, 0, st>>>(a); break;
-        case S3_XONLY:  k_pcg_step3<S3_XONLY><<<blocks, PF_THREADS, 0, st>>>(a); break;
-        default:        k_pcg_step3<S3_RESET><<<blocks, PF_THREADS, 0, st>>>(a); break;
+        case S3_INIT:   I3D_S3(S3_INIT); break;
+        case S3_NORMAL: I3D_S3(S3_NORMAL); break;
+        case S3_XONLY:  I3D_S3(S3_XONLY); break;
+        default:        I3D_S3(S3_RESET); break;
     }
+#undef I3D_S3
     return mode == S3_XONLY ? 0 : blocks;
 }
 

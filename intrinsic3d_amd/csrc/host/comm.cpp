@@ -37,6 +37,7 @@ struct RcclComm : Comm {
     }
     int health(hipStream_t st) override { return use_p2p ? p2p.check(st) : 0; }
     bool device_reduce(P2PDev* dev) override { if (!use_p2p) return false; *dev = p2p.device(); return true; }
+    bool fused_exchange(P2PDev* dev) override { if (!use_p2p || halo_rccl) return false; *dev = p2p.device(); return true; }
     int allreduce_sum(double* dev, size_t n, hipStream_t st) override {
         ++reduce_calls; reduce_bytes += 8ll * (long long)n;
         if (use_p2p && (int)n <= p2p.L.red_cap) return p2p.allreduce(dev, n, st);
@@ -73,13 +74,15 @@ int rccl_unique_id(void* out, size_t* bytes) {
 
 // Mailboxes for the per-pass exchanges: created on every rank, IPC handles all-gathered through RCCL, then verified with real exchanges
 // (known sums, bounded waits).  All ranks take the same decision (all-reduced); anything short of a clean pass leaves RCCL in charge.
-// The mailbox transport is OPT-IN (I3D_TRANSPORT=p2p): it has only ever run with all ranks on one device (same-process simulation, 2-8 processes on
-// one GPU, a forced 1-rank communicator) — until a multi-GPU run of the suite has passed, RCCL carries every exchange by default.
+// The mailbox transport carries the per-pass exchanges whenever this start-up test passes on every rank (I3D_TRANSPORT=rccl keeps RCCL for everything): with it
+// the sharded PCG pass is the three launches of the single-rank pass, its two exchanges running INSIDE k_pcg_dir3 / k_pcg_step3 (pcg_fused.hip) — the test below
+// therefore also runs that multi-workgroup exchange pattern (P2PEngine::selftest_fused).  It has run between processes on ONE device and between the ranks of the
+// same-process simulation; the first start on a multi-GPU node is decided by this test, with bounded waits, and anything short of a clean pass leaves RCCL in charge.
 // *fatal is set when this rank could not even take part in the agreement collectives (scratch allocation): the caller aborts the init instead of
 // letting the ranks issue mismatched collectives.
 static bool bootstrap_p2p(RcclComm* c, hipStream_t st, bool* fatal) {
     *fatal = false;
-    { const char* e = std::getenv("I3D_TRANSPORT"); if (!e || std::strcmp(e, "p2p") != 0) return false; }      // every rank reads the same environment: no collective is skipped one-sidedly
+    { const char* e = std::getenv("I3D_TRANSPORT"); if (e && std::strcmp(e, "rccl") == 0) return false; }      // every rank reads the same environment: no collective is skipped one-sidedly
     // the scratch of the agreement collectives comes first and unconditionally: every rank issues the all-gather and both min-reductions whatever happens to it locally
     unsigned char* d_handles = nullptr; double* d_test = nullptr;
     if (hipMalloc((void**)&d_handles, 64 * (size_t)c->world) != hipSuccess || hipMalloc((void**)&d_test, sizeof(double) * 64) != hipSuccess) {
@@ -146,6 +149,8 @@ static bool bootstrap_p2p(RcclComm* c, hipStream_t st, bool* fatal) {
             }
         }
         if (d_idx) (void)hipFree(d_idx); if (d_vec) (void)hipFree(d_vec);
+        // the exchange pattern of the three-launch sharded pass: many workgroups, one writer, everybody reads; rim words pushed and consumed in the same launch
+        if (ok) ok = c->p2p.selftest_fused(st) == 0;
         flag = ok ? 1.0 : 0.0;
         (void)hipMemcpy(d_test, &flag, sizeof(double), hipMemcpyHostToDevice); (void)ncclAllReduce(d_test, d_test, 1, ncclDouble, ncclMin, c->comm, st); (void)hipStreamSynchronize(st);
         (void)hipMemcpy(&flag, d_test, sizeof(double), hipMemcpyDeviceToHost);
@@ -199,9 +204,11 @@ struct SimComm : Comm {
         if (all) { for (int k = 0; k < world; ++k) p2p.attach_pointer(k, sh->mailbox[k]); p2p.ready = true; use_p2p = true; transport = "p2p-mailbox (rank simulation)"; }
         sh->barrier();
     }
-    int plan_changed(const HaloPlan& h, hipStream_t st) override { attach(); return use_p2p ? p2p.set_halo_lists(h, st) : 0; }
+    bool halo_too_big = false;
+    int plan_changed(const HaloPlan& h, hipStream_t st) override { attach(); if (!use_p2p) return 0; const int rc = p2p.set_halo_lists(h, st); halo_too_big = rc == 2; return rc; }
     int health(hipStream_t st) override { return use_p2p ? p2p.check(st) : 0; }
     bool device_reduce(P2PDev* dev) override { attach(); if (!use_p2p) return false; *dev = p2p.device(); return true; }
+    bool fused_exchange(P2PDev* dev) override { attach(); if (!use_p2p || halo_too_big) return false; *dev = p2p.device(); return true; }
     int allreduce_sum(double* dev, size_t n, hipStream_t st) override {
         ++reduce_calls; reduce_bytes += 8ll * (long long)n;
         attach();
@@ -256,6 +263,7 @@ Comm* make_sim_comm(SimShared* s, int rank) {
     const char* e = std::getenv("I3D_SIM_P2P");
     if (e && e[0] == '1' && s->world <= 4) {      // mailboxes are registered here; the peers are attached at the first collective (all ranks are running by then)
         c->want_p2p = c->p2p.create(rank, s->world, P2P_RED_CAP, P2P_HALO_CAP) == 0;
+        c->p2p.wg_cap = 256 / s->world;      // the multi-workgroup exchange kernels of ALL ranks must be resident on this one device together
         std::lock_guard<std::mutex> lk(s->m); s->mailbox[rank] = c->want_p2p ? c->p2p.mailbox : nullptr;
     }
     return c;

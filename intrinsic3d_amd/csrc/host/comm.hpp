@@ -35,7 +35,11 @@ struct Comm {
     virtual int push_halo(float* vec, const HaloPlan& h, hipStream_t st) = 0;
     // true: all-reduces of a few doubles can run INSIDE single-workgroup kernels (p2p_allreduce_wg with *dev); the caller logs them with count_reduce
     virtual bool device_reduce(P2PDev* dev) { (void)dev; return false; }
+    // true: this outer iteration's per-pass exchanges may run inside the MULTI-workgroup PCG kernels (pcg_fused.hip: the three-launch sharded pass) — the
+    // mailbox transport is up and every rank pair's rim fits its mailbox
+    virtual bool fused_exchange(P2PDev* dev) { (void)dev; return false; }
     void count_reduce(size_t n) { ++reduce_calls; reduce_bytes += 8ll * (long long)n; }
+    void count_halo(long long entries) { ++halo_calls; halo_bytes_sent += 8ll * entries; }
     // called once per outer iteration after the halo plan changed; 0 = ok
     virtual int plan_changed(const HaloPlan&, hipStream_t) { return 0; }
     // 0 = healthy; non-zero after a peer-to-peer wait timed out (synchronises the stream)

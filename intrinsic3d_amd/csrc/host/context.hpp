@@ -80,7 +80,7 @@ struct i3d_context {
     i3d::Comm* comm = nullptr; int chunk = 1, own0 = 0, own1 = 0, nC = 0;
     i3d::DevBuf<int> clist, cflag, cscan;
     // halo exchange plan of the current work list (shard_kernels.hip) and the foreign tiles with ghost entries
-    i3d::HaloPlan halo; i3d::DevBuf<unsigned long long> need_mask, halo_items, halo_sorted; i3d::DevBuf<int> halo_count, halo_send_idx, halo_recv_idx, tile_flag, ghost_tiles;
+    i3d::HaloPlan halo; i3d::DevBuf<unsigned long long> need_mask, halo_items, halo_sorted; i3d::DevBuf<int> halo_count, halo_send_idx, halo_recv_idx, halo_send_peer, halo_recv_peer, halo_offs, tile_flag, ghost_tiles;
     i3d::DevBuf<float> halo_send_buf, halo_recv_buf; i3d::DevBuf<unsigned char> halo_temp; int n_ghost_tiles = 0, slice = 0;
     i3d::DevBuf<int> obs_frame, anbr; i3d::DevBuf<float> obs_w, ea_w, C, treg;
     i3d::DevBuf<float4> rows; i3d::DevBuf<float2> row_wr;
@@ -104,7 +104,7 @@ struct i3d_context {
     i3d::DevBuf<float> Minv_blocks;
     i3d::DevBuf<double> d_shared, d_blocks, d_scal, d_xshared, d_xcshared;
     i3d::DevBuf<i3d::PcgState> d_pcg, d_pcg2; i3d::DevBuf<double> d_partials; i3d::PcgState* h_pcg = nullptr; hipEvent_t pcg_ev[2] = {nullptr, nullptr};
-    int* h_flags = nullptr; int* d_flags = nullptr; int pcg_seq = 0;      // pinned (seq, done) ring written by k_pcg_tail_a, polled by the host
+    int* h_flags = nullptr; int* d_flags = nullptr; int pcg_seq = 1024;      // pinned (seq, done) ring written by k_pcg_tail_a, polled by the host
     // the trust-region loop on the device (lm_kernels.hip): its state, one record per attempt in mapped host memory, the camera blocks of J^T W J it damps
     i3d::DevBuf<i3d::LmState> d_lm; i3d::LmRecord* h_lmrec = nullptr; i3d::LmRecord* d_lmrec = nullptr; int lm_seq = 1;
     i3d::DevBuf<double> d_cam_c, d_cam_H;

@@ -98,7 +98,7 @@ void P2PEngine::destroy() {
 
 static PeerPtrs ptrs_of(const P2PEngine& e) { PeerPtrs p; for (int k = 0; k < P2P_MAX_RANKS; ++k) p.m[k] = e.peer[k]; return p; }
 
-P2PDev P2PEngine::device() const { P2PDev d; d.on = ready ? 1 : 0; d.me = rank; d.L = L; d.err = d_err; d.epoch_red = d_epoch_red; d.spin_limit = spin_limit; d.peers = ptrs_of(*this); return d; }
+P2PDev P2PEngine::device() const { P2PDev d; d.on = ready ? 1 : 0; d.me = rank; d.L = L; d.err = d_err; d.epoch_red = d_epoch_red; d.spin_limit = spin_limit; d.peers = ptrs_of(*this); d.wg_cap = wg_cap; return d; }
 
 int P2PEngine::allreduce(double* dev, size_t n, hipStream_t st) {
     if ((int)n > L.red_cap) return 1;
@@ -118,6 +118,41 @@ int P2PEngine::push_halo(float* vec, const HaloPlan& h, hipStream_t st) {
                                    d_lists + 3 * P2P_MAX_RANKS, d_err, spin_limit);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+// Start-up test of the exchanges that run inside the multi-workgroup PCG kernels (p2p_device.hpp: p2p_put_double_all / p2p_sum_all / p2p_put_rim / p2p_get_rim):
+// per round, in ONE launch of several workgroups — the first two push B rim items to every peer before waiting for anything, workgroup 2 stores this rank's four
+// doubles into all mailboxes, every workgroup reads and checks the rank-ordered sums, the first two then consume and check the peers' rim items.  Rounds use the
+// pass numbers 1..8 (real solves start far above), alternating the two buffers like a pass does (dir | step).
+__global__ void __launch_bounds__(256) k_p2p_selftest_fused(P2PDev d, int seq, int B, int* bad) {
+    __shared__ double smx[4 * P2P_MAX_RANKS];
+    const int W = d.L.world, me = d.me;
+    for (int which = 0; which < 2; ++which) {
+        const unsigned e32 = p2p_pass_epoch(seq, which == 0 ? P2P_X_DIR : P2P_X_STEP); const int par = which;
+        if (which == 0 && blockIdx.x < 2)
+            for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < B * W; j += 2 * blockDim.x) { const int k = j / B, i = j % B; if (k != me) p2p_put_rim(d, par, e32, k, i, (float)(1000 * me + i + seq), -(float)(7 * k + i)); }
+        if (blockIdx.x == 2 && threadIdx.x < 4) p2p_put_double_all(d, par, e32, threadIdx.x, (double)(me + 1) * (threadIdx.x + 1) + 0.25 * seq + which);
+        double tot[4]; p2p_sum_all<4>(d, par, e32, tot, smx);
+        const double tri = 0.5 * W * (W + 1);
+        for (int k = 0; k < 4; ++k) if (tot[k] != tri * (k + 1) + W * (0.25 * seq + which)) atomicExch(bad, 1);
+        if (which == 0 && blockIdx.x < 2)
+            for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < B * W; j += 2 * blockDim.x) {
+                const int k = j / B, i = j % B; if (k == me) continue;
+                float a, b; p2p_get_rim(d, par, e32, k, i, a, b);
+                if (a != (float)(1000 * k + i + seq) || b != -(float)(7 * me + i)) atomicExch(bad, 2);
+            }
+    }
+}
+int P2PEngine::selftest_fused(hipStream_t st) {
+    int* d_bad = nullptr;
+    if (hipMalloc((void**)&d_bad, sizeof(int)) != hipSuccess || hipMemset(d_bad, 0, sizeof(int)) != hipSuccess) return 1;
+    int bad = 0; bool ok = true;
+    for (int seq = 1; seq <= 8 && ok; ++seq) {
+        k_p2p_selftest_fused<<<24, 256, 0, st>>>(device(), seq, 96, d_bad);
+        ok = hipGetLastError() == hipSuccess && check(st) == 0 && hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
+    }
+    (void)hipFree(d_bad);
+    return ok ? 0 : 1;
+}
+
 int P2PEngine::check(hipStream_t st) {      // has any spin timed out?  (synchronises the stream)
     int e = 0;
     if (hipMemcpyAsync(&e, d_err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;

@@ -19,6 +19,7 @@ struct P2PEngine {
     unsigned long long* d_epoch_red = nullptr;        // all-reduces performed so far (device counter, see p2p_device.hpp)
     unsigned long long epoch_halo = 0;
     unsigned long long spin_limit = P2P_SPIN_LIMIT;   // bound of every wait (shader-clock ticks)
+    int wg_cap = 0;                                   // > 0: cap on the workgroups of the multi-workgroup exchange kernels (rank simulation on one device)
 
     int  create(int rank, int world, int red_cap, int halo_cap);
     int  export_handle(void* out64);                  // hipIpcMemHandle_t of the mailbox
@@ -30,6 +31,7 @@ struct P2PEngine {
     int  set_halo_lists(const HaloPlan& h, hipStream_t st);      // 0 ok, 2 = a pair's rim exceeds the mailbox, 1 = HIP error
     int  push_halo(float* vec, const HaloPlan& h, hipStream_t st);
     int  check(hipStream_t st);                       // 1 if a spin timed out
+    int  selftest_fused(hipStream_t st);              // the in-kernel, multi-workgroup exchanges of pcg_fused.hip with known values (all ranks call it together); 0 = ok
 };
 
 }  // namespace i3d

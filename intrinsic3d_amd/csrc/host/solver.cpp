@@ -36,6 +36,7 @@ static double varying_lambda(int it, int n, double l0, double l1) {        // co
 }
 
 constexpr int HALO_CAP = 1 << 20;      // (direction, peer, entry) items of a rank's halo plan
+constexpr int PCG_SEQ_STRIDE = 1024;   // pass numbers a PCG solve may use (<= 521 passes): the numbering of the next solve does not depend on how many passes a host queued
 constexpr int LM_REC_SLOTS = 64;       // LmRecord ring: the initial tests + one record per LM attempt (lm_steps <= LM_REC_SLOTS - 2)
 
 // every stream synchronisation of the solver path goes through here (counted: i3d_debug_counters; the review bar is <= 8 per Gauss-Newton iteration)
@@ -69,7 +70,7 @@ static int alloc_rows(i3d_context* c, int slots) {
     if (c->comm) {      // sharding plan storage (small: the rim of a rank is a few percent of what it owns)
         const size_t cap = HALO_CAP;
         CTX_HIP(c, c->need_mask.alloc(Acap)); CTX_HIP(c, c->halo_items.alloc(cap)); CTX_HIP(c, c->halo_sorted.alloc(cap)); CTX_HIP(c, c->halo_count.alloc(1));
-        CTX_HIP(c, c->halo_send_idx.alloc(cap)); CTX_HIP(c, c->halo_recv_idx.alloc(cap)); CTX_HIP(c, c->halo_send_buf.alloc(2 * cap)); CTX_HIP(c, c->halo_recv_buf.alloc(2 * cap));
+        CTX_HIP(c, c->halo_send_idx.alloc(cap)); CTX_HIP(c, c->halo_recv_idx.alloc(cap)); CTX_HIP(c, c->halo_send_peer.alloc(cap)); CTX_HIP(c, c->halo_recv_peer.alloc(cap)); CTX_HIP(c, c->halo_offs.alloc(2 * P2P_MAX_RANKS)); CTX_HIP(c, c->halo_send_buf.alloc(2 * cap)); CTX_HIP(c, c->halo_recv_buf.alloc(2 * cap));
         CTX_HIP(c, c->halo_temp.alloc(halo_sort_temp_bytes((int)cap)));
         const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512) + 1; CTX_HIP(c, c->tile_flag.alloc(nt)); CTX_HIP(c, c->ghost_tiles.alloc(nt));
     }
@@ -158,15 +159,20 @@ static int shard_plan(i3d_context* c) {
         CTX_HIP(c, hipMemcpyAsync(items.data(), c->halo_sorted.p, sizeof(unsigned long long) * (size_t)nitems, hipMemcpyDeviceToHost, s));
         CTX_HIP(c, sync_stream(c));
     }
-    std::vector<int> sidx, ridx;
+    std::vector<int> sidx, ridx, speer, rpeer;       // + the peer of every item: the flat lists the in-kernel exchanges of the three-launch pass walk (RimLists)
     for (unsigned long long it : items) {
         const int dir = (int)(it >> 40) & 1, peer = (int)((it >> 32) & 0xFF), e = (int)(it & 0xFFFFFFFFull);
-        if (dir == 0) { if (h.send_cnt[peer]++ == 0) h.send_off[peer] = (int)sidx.size(); sidx.push_back(e); }
-        else          { if (h.recv_cnt[peer]++ == 0) h.recv_off[peer] = (int)ridx.size(); ridx.push_back(e); }
+        if (dir == 0) { if (h.send_cnt[peer]++ == 0) h.send_off[peer] = (int)sidx.size(); sidx.push_back(e); speer.push_back(peer); }
+        else          { if (h.recv_cnt[peer]++ == 0) h.recv_off[peer] = (int)ridx.size(); ridx.push_back(e); rpeer.push_back(peer); }
     }
     h.n_send = (int)sidx.size(); h.n_recv = (int)ridx.size();
-    if (h.n_send) CTX_HIP(c, hipMemcpyAsync(c->halo_send_idx.p, sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice, s));
-    if (h.n_recv) CTX_HIP(c, hipMemcpyAsync(c->halo_recv_idx.p, ridx.data(), sizeof(int) * ridx.size(), hipMemcpyHostToDevice, s));
+    if (h.n_send) { CTX_HIP(c, hipMemcpyAsync(c->halo_send_idx.p, sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice, s));
+                    CTX_HIP(c, hipMemcpyAsync(c->halo_send_peer.p, speer.data(), sizeof(int) * speer.size(), hipMemcpyHostToDevice, s)); }
+    if (h.n_recv) { CTX_HIP(c, hipMemcpyAsync(c->halo_recv_idx.p, ridx.data(), sizeof(int) * ridx.size(), hipMemcpyHostToDevice, s));
+                    CTX_HIP(c, hipMemcpyAsync(c->halo_recv_peer.p, rpeer.data(), sizeof(int) * rpeer.size(), hipMemcpyHostToDevice, s)); }
+    int offs[2 * P2P_MAX_RANKS] = {0};
+    for (int k = 0; k < world; ++k) { offs[k] = h.send_off[k]; offs[P2P_MAX_RANKS + k] = h.recv_off[k]; }
+    CTX_HIP(c, hipMemcpyAsync(c->halo_offs.p, offs, sizeof(offs), hipMemcpyHostToDevice, s));
     CTX_HIP(c, sync_stream(c));                  // (the host vectors above go out of scope)
     h.d_send_idx = c->halo_send_idx.p; h.d_recv_idx = c->halo_recv_idx.p; h.d_send_buf = c->halo_send_buf.p; h.d_recv_buf = c->halo_recv_buf.p;
     { const int prc = c->comm->plan_changed(h, s);
@@ -421,18 +427,30 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
         }
         if (it > 520) break;
     }
-    c->pcg_seq = seq0 + it + 1;
+    c->pcg_seq = seq0 + PCG_SEQ_STRIDE;
     *final_state = st;                   // kernels after `done` were no-ops, so this is the terminal state (read by k_lm_decide on the stream)
     return I3D_OK;
 }
 
 // The same solve in THREE launches per pass (pcg_fused.hip): k_pcg_dir3 | k_eg_tile | k_pcg_step3.  Single rank, tiled operator.  The scalar state is
 // double-buffered by pass parity: boundary `it` reads st2[(it + 1) & 1] and writes st2[it & 1], which the operator and the step of pass `it` read.
+// Sharded (one process per GPU, mailbox transport): the SAME three launches — the boundary's exchange ([4 slice sums] + the rim of z) runs inside k_pcg_dir3, the
+// operator's ([p.q | camera block]) inside k_pcg_step3; the residual-reset passes (one in ten) push the rim of u = S x with a launch of their own (k_rim_u).
 static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, const PcgState** final_state) {
     hipStream_t s = c->stream;
     const Layout L = layout_of(c);
     const int K = c->K; const size_t to = L.tail_off; const Seg2 own = L.own;
     RowView r = c->row_view(); TilePlan tp = c->tile_plan();
+    const bool sh = sharded(c);
+    ShardArgs sa; std::memset(&sa, 0, sizeof(sa));
+    if (sh) {
+        if (!c->comm->fused_exchange(&sa.pd) || L.NS + 2 > sa.pd.L.red_cap) return ctx_fail(c, I3D_ERR_STATE, "pcg_solve_fused: the in-kernel exchanges are not available");
+        const HaloPlan& h = c->halo;
+        sa.rim = RimLists{h.n_send, h.n_recv, c->halo_send_idx.p, c->halo_send_peer.p, c->halo_recv_idx.p, c->halo_recv_peer.p, c->halo_offs.p, c->halo_offs.p + P2P_MAX_RANKS};
+        sa.n_rim_wg = (h.n_send + h.n_recv) > 0 ? std::max(1, std::min(4, (std::max(h.n_send, h.n_recv) + 1023) / 1024)) : 1;
+        sa.zb = c->v_z.p; sa.pb = c->v_p.p; sa.ub = c->v_u.p; sa.cmb = c->v_cm.p; sa.chunk = c->chunk;
+    }
+    const int wg_cap = sh ? sa.pd.wg_cap : 0;
     PcgState* const st2 = c->d_pcg2.p;
     const int NSP = (L.NS + 3) & ~3;
     double* const step_part = c->d_partials.p; double* const pq_part = c->d_partials.p + 4 * 2048; double* const d2_part = pq_part + 2048;
@@ -445,25 +463,32 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
     a.p = c4(c->v_p.p); a.qacc = c4(c->v_qacc.p); a.x = m4(c->v_x.p); a.r = m4(c->v_r.p); a.b = c4(c->v_b.p); a.z = m4(c->v_z.p); a.cm = c4(c->v_cm.p); a.lm = c->d_lm.p;
     a.ext_off = tp.ext_off; a.ext_pos = tp.ext_pos; a.qh = reinterpret_cast<const float2*>(tp.qh); a.e0 = (int)own.off0;
     a.pq_partials = pq_part; a.d2_partials = d2_part; a.n_pq = 0; a.n_d2 = 0;
-    a.n_slice_wg = pcg_step3_slice_wgs(own.n);
+    a.n_slice_wg = pcg_step3_slice_wgs(own.n, wg_cap);
+    a.sharded = sh ? 1 : 0;
     a.K = K; a.fix_poses = p.fix_poses; a.fix_intr = p.fix_intr; a.fix_dist = p.fix_dist;
     a.cam_partials = c->cam_part.p; a.n_cam = 0; a.cam_stride = NSP; a.Mblk = c->Minv_blocks.p;
     a.tp = c->v_p.p + to; a.tx = c->v_x.p + to; a.tr = c->v_r.p + to; a.tb = c->v_b.p + to; a.tD2 = c->v_D2.p + to; a.tz = c->v_z.p + to; a.tS = c->v_S.p + to;
     a.step_partials = step_part;
     int n_step = 0;
     { TimedScope t(c, I3D_K_VECTOR); a.cur = st2; n_step = launch_pcg_step3(s, 0 /*init*/, a); }
+    // pass numbers are the epochs of the in-kernel exchanges: identical on all ranks (every rank queues the same solves; how many passes a rank's HOST queued
+    // behind the convergence flag may differ, so every solve takes a fixed block of numbers)
     const int seq0 = c->pcg_seq;
     int it = 1;
     for (;; ++it) {
         PcgState* const prev = st2 + ((it + 1) & 1); PcgState* const cur = st2 + (it & 1);
+        sa.seq = seq0 + it; sa.n_slice_partials = a.n_slice_wg; a.sh = sa;
         { TimedScope t(c, I3D_K_VECTOR);
-          a.n_d2 = launch_pcg_dir3(s, it == 1, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, c->v_cm.p, c->d_lm.p, step_part, n_step, d2_part, prev, cur, c->d_flags, seq0 + it); }
+          a.n_d2 = launch_pcg_dir3(s, it == 1, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, c->v_cm.p, c->d_lm.p, step_part, n_step, d2_part, prev, cur, c->d_flags, seq0 + it,
+                                   sh ? &sa : nullptr); }
+        if (sh) { c->comm->count_reduce(4); c->comm->count_halo(c->halo.n_send); c->comm->count_reduce((size_t)L.NS + 1); }      // (logged as exchanges of this pass: they have no launches of their own)
         { TimedScope t(c, I3D_K_EG_PASS); a.n_pq = launch_eg_tile(s, r, p, c->v_u.p, tp, nullptr, c->v_qacc.p, pq_part, cur, c->cam_part.p, NSP); a.n_cam = a.n_pq; }
         a.cur = cur;
         if (it % 10 != 0) { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3(s, 1, a); }
         else {                                                                   // residual_reset_period: r = b - A x instead of r -= alpha q
             { TimedScope t(c, I3D_K_VECTOR); launch_pcg_step3(s, 2, a);
               launch_mul2(s, own, c->v_S.p, c->v_x.p, c->v_u.p); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
+            if (sh) { TimedScope t(c, I3D_K_COMM); launch_rim_u(s, sa, cur); c->comm->count_halo(c->halo.n_send); }
             { TimedScope t(c, I3D_K_EG_PASS); a.n_cam = launch_eg_tile(s, r, p, c->v_u.p, tp, nullptr, c->v_qacc.p, nullptr, cur, c->cam_part.p, NSP); }
             { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3(s, 3, a); }
         }
@@ -477,7 +502,7 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
         }
         if (it > 520) break;
     }
-    c->pcg_seq = seq0 + it + 1;
+    c->pcg_seq = seq0 + PCG_SEQ_STRIDE;
     // boundary `it` copied the terminal state forward (kernels after `done` are no-ops), so st2[it & 1] is final (read by k_lm_decide on the stream)
     *final_state = st2 + (it & 1);
     { const int lrc = ctx_launch_check(c); if (lrc) return lrc; }
@@ -538,7 +563,8 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
 
     static const bool legacy = [] { const char* e = std::getenv("I3D_PCG_LEGACY"); return e && e[0] == '1'; }();
     // three launches per pass on one rank with the tiled operator; the six-launch sequence when sharded, untiled, or asked for (A/B runs)
-    const bool fused = !sharded(c) && c->tile_ok && !legacy;
+    bool fused = c->tile_ok && !legacy;
+    if (fused && sharded(c)) { P2PDev probe; fused = c->comm->fused_exchange(&probe) && L.NS + 2 <= probe.L.red_cap; }      // else: the six-launch pass with separate exchange launches (RCCL, or a rim that exceeds a mailbox)
     int attempts = 0; bool ended = false, accepted = false;
     // one record consumed: statistics + whether the solve is over
     auto consume = [&](const LmRecord& rec) {

@@ -145,13 +145,17 @@ def test_many_keyframes(oracle):
     np.testing.assert_allclose(cam[2], ocam[2], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("transport", ["p2p", "rccl"])
+@pytest.mark.parametrize("transport", ["p2p", "rccl", "default"])
 def test_real_rccl_collectives_with_one_rank(oracle, monkeypatch, transport):
     """the sharded code path driven through a REAL 1-rank RCCL communicator (I3D_FORCE_COLLECTIVES=1) — same answer as the plain path —
-    with the mailbox transport (bootstrap over RCCL, start-up self-test, reductions inside the boundary kernels) and with the RCCL fallback
-    (I3D_TRANSPORT=rccl: grouped send / receive for the rim, ncclAllReduce for the blocks, separate reduction launches)"""
+    with the mailbox transport (bootstrap over RCCL, start-up self-test incl. the in-kernel multi-workgroup exchanges; the pass is the three launches of the
+    single-rank pass, both exchanges inside k_pcg_dir3 / k_pcg_step3) — which is also what an unset I3D_TRANSPORT selects — and with the RCCL fallback
+    (I3D_TRANSPORT=rccl: grouped send / receive for the rim, ncclAllReduce for the blocks, the six-launch pass with separate reduction launches)"""
     from intrinsic3d_amd import binding
-    monkeypatch.setenv("I3D_TRANSPORT", transport)
+    if transport == "default":
+        monkeypatch.delenv("I3D_TRANSPORT", raising=False); transport = "p2p"
+    else:
+        monkeypatch.setenv("I3D_TRANSPORT", transport)
     sc = helpers.small_scene(seed=14, radius_vox=9, K=4, width=96, height=72)
     g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc)
     cfg = helpers.gpu_cfg(helpers.oracle_cfg(oracle, thres, iterations=2, cg_fixed_iterations=12))

@@ -67,6 +67,9 @@ static int child(int rank, int world, int rounds, int to_parent, int from_parent
         if (e.check(st)) bad = 15;
         if (bad) std::fprintf(stderr, "rank %d: failure %d in round %d\n", rank, bad, rep);
     }
+    // the exchanges that run INSIDE the multi-workgroup PCG kernels of the three-launch sharded pass (one writer workgroup, every workgroup reads; rim items pushed and
+    // consumed in the same launch), across processes
+    if (!bad && e.selftest_fused(st)) { bad = 16; std::fprintf(stderr, "rank %d: the in-kernel multi-workgroup exchange failed\n", rank); }
     // nobody unmaps while a peer may still be storing into it
     tok = bad ? 0 : 1; (void)write_all(to_parent, &tok, 1); (void)read_all(from_parent, &tok, 1);
     e.destroy();
