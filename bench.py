@@ -422,7 +422,9 @@ def _main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # ONE device communicator per job: the library's own (RCCL, bootstrapped below from a unique id).  The launcher-side group only carries that id, the
+        # barriers around the timed region and the max over the ranks' clocks — host-side traffic, so gloo (round 3 opened a second NCCL communicator for it).
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     from intrinsic3d_amd import binding
     sc = build_workload(args, log)
@@ -435,13 +437,9 @@ def _main():
         ctx.comm_init(0, 1, binding.Context.comm_unique_id())
     if world > 1:
         # one process per GPU: RCCL communicator of the library, bootstrapped through torch.distributed (unique id from rank 0)
-        uid = torch.zeros(256, dtype=torch.uint8, device="cuda")
-        n = torch.zeros(1, dtype=torch.int32, device="cuda")
-        if rank == 0:
-            b = binding.Context.comm_unique_id()
-            uid[:len(b)] = torch.tensor(list(b), dtype=torch.uint8, device="cuda"); n[0] = len(b)
-        dist.broadcast(uid, 0); dist.broadcast(n, 0)
-        ctx.comm_init(rank, world, bytes(uid[:int(n.item())].cpu().tolist()))
+        box = [binding.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(rank, world, box[0])
     t0 = time.time()
     ctx.set_grid(sc["voxel_size"], arrays["keys"], arrays["sdf"], arrays["sdf_refined"], arrays["albedo"], arrays["weight"], arrays["color"])
     ctx.set_frames(sc["frames"], 1)
@@ -489,7 +487,7 @@ def _main():
     dt = time.perf_counter() - t0
     stream_syncs = ctx.debug_counters()["stream_syncs"] - syncs0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     t0 = time.time(); _ = ctx.get_grid(); _ = ctx.get_camera(); t_download = time.time() - t0          # what a host-buffer caller reads back
     timing_work = ctx.timing_get_work_ex()   # launches that did work (PCG launches queued behind the convergence flag return at once); + what the upper cut-off removed
     timing = ctx.timing_get(reset=True)
@@ -535,8 +533,9 @@ def _main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spin_up_s": args.spin_up, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"parallelism": f"{world} rank(s), one per GPU: replicated voxel state; tile-aligned ownership of the brick-ordered work list, rim rows recomputed as ghosts; "
-                                       f"per PCG pass one neighbour exchange of the operator input on the rim + one all-reduce [camera block | p.q] + one of 4 scalars"
-                                       + (f" over {transport}" if transport else ""),
+                                       f"per PCG pass three launches and two exchanges that run inside them over the peer-to-peer mailboxes ([4 slice sums + the rim of z] in k_pcg_dir3, "
+                                       f"[p.q | camera block] in k_pcg_step3); over RCCL the six-launch pass with one neighbour exchange + two all-reduce launches"
+                                       + (f"; this run: {transport}" if transport else ""),
                        "workload": f"synthetic hashed SDF grid, {arrays['keys'].shape[0]} stored voxels @ {args.voxel_size * 1e3:g} mm "
                                    f"({A} in the thin shell), {args.frames} keyframes {args.width}x{args.height}, {sh_sub.shape[0]} SH subvolumes of {args.subvolume} m (estimated on the device, untimed), "
                                    f"joint SDF+albedo+pose+intrinsics+distortion, 5 observations/voxel (BASELINE.json configs[3] on one node)",
