@@ -49,8 +49,10 @@ struct PassBuffers {
     float* treg;         // [8][Acap]  tr, ts, ta[6]
     double* shared;      // [6K+9] pose/intr/dist accumulators (zeroed by the caller)
     double* blocks;      // COLNORM only: [21K + 10 + 15] upper triangles of the pose/intr/dist J^T W J blocks
+    float* part; int part_stride;      // GRAD / COLNORM: one float row of camera totals per workgroup (summed in a fixed order by launch_sum_rows: no global atomics)
 };
-void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u /*[NP] or null*/, PassBuffers b, const PcgState* state);
+int  launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u /*[NP] or null*/, PassBuffers b, const PcgState* state);   // returns the rows written to b.part
+void launch_sum_rows(hipStream_t st, PassMode mode, int K, const float* part, int nrows, int stride, double* shared, double* blocks);
 void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out /*[2A]*/);
 int  launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_partials /* or, dot_atomic: the sum itself */,
                         bool dot_atomic, const PcgState* state);   // returns #partials

@@ -55,22 +55,29 @@ template <int MODE>
 __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, OptParams p, const float* __restrict__ u, PassBuffers b,
                                                         int reps, int tiles_per_block, const PcgState* __restrict__ state) {
     if (state && state->done) return;
-    extern __shared__ float lds[];        // [reps][rs] pose accumulators (6 per keyframe; COLNORM: the 21 block entries) + [NCAM] + JTJP: staged camera part of u [6K+9]
+    // Fixed-order sums (round 4): the pose columns of a wave's rows go into a table private to the wave (wave_ops.hpp: wave_table_add), merged into the workgroup's
+    // dense accumulator in wave order at the end of every tile; the intrinsics / distortion sums leave through per-wave slots; the workgroup's totals leave as ONE
+    // float row (b.part), summed over the workgroups in a fixed order by k_sum_rows — no LDS accumulator shared by waves, no global atomics: the gradient and the
+    // column norms of an outer iteration are bit-reproducible.
+    extern __shared__ float lds[];        // [ticket | 3] [NW][NCAM] | [NW][TC] tags | [NW][TC][NPV] | dense [rs] | [NCAM] | JTJP: staged camera part of u [6K+9]
     const int K = p.K; const size_t Acap = r.Acap;
     const int nshared = 6 * K + 9;
-    // replica stride: ODD, so that the replicas of one keyframe's accumulator fall into different LDS banks
+    constexpr int NPVT = (MODE == PASS_COLNORM) ? 21 : 6, TCT = (MODE == PASS_COLNORM) ? 16 : 32, NWT = EG_THREADS / 64;
     const int rs = ((MODE == PASS_COLNORM) ? 21 * K : 6 * K) | 1;
     constexpr int NCAM = (MODE == PASS_COLNORM) ? 34 : 9;       // COLNORM: 9 squared columns + 10 + 15 block entries of intrinsics / distortion
-    const int nacc = reps * rs + NCAM;
-    for (int i = threadIdx.x; i < nacc; i += EG_THREADS) lds[i] = 0.0f;
+    constexpr int D_CAMW = 4, D_TAG = D_CAMW + ((NWT * NCAM + 3) & ~3), D_VAL = D_TAG + NWT * TCT, D0 = D_VAL + NWT * TCT * NPVT;
+    const int nacc = D0 + rs + NCAM;
+    for (int i = threadIdx.x; i < nacc; i += EG_THREADS) lds[i] = (i >= D_TAG && i < D_VAL) ? __int_as_float(-1) : 0.0f;
     float* upose = lds + nacc;            // JTJP: the 6K+9 camera entries of u (every row reads 6+9 of them)
     const size_t tail = 2 * (size_t)r.chunk;          // camera part of every solver vector
     const int chunk = r.chunk;
     if (MODE == PASS_JTJP) for (int i = threadIdx.x; i < nshared; i += EG_THREADS) upose[i] = u[tail + i];
     __syncthreads();
-    float* const cam_acc = lds + reps * rs;
-    float* const pose_acc = lds + (threadIdx.x & (reps - 1)) * rs;            // per-lane replica (fallback path)
-    float* const wave_acc = lds + ((threadIdx.x >> 6) & (reps - 1)) * rs;     // per-wave replica (aggregated path)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int o_tag = D_TAG + wave * TCT, o_val = D_VAL + wave * (TCT * NPVT);
+    int tcount = 0;
+    float* const cam_acc = lds + D0 + rs;
+    (void)reps;
     float cam9[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
@@ -181,8 +188,11 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                 }
             }
             // pose columns of this slot: every lane of the wave takes part (the loop bound nr_max is wave-uniform)
-            wave_accumulate<NPV>(pvalid, fsel, pv, pose_acc, wave_acc, NPV);
+            wave_table_add<NPV, TCT>(pvalid, fsel, [&](int q) { return pv[q]; }, lds, o_tag, o_val, tcount, D0, NPV);
         }
+        // the waves' tables -> the dense accumulator, in wave order (once per tile of 1024 entries: this kernel runs once per outer iteration)
+        __syncthreads();
+        for (int w = 0; w < NWT; ++w) { if (wave == w) wave_table_merge<NPVT, TCT>(lds, o_tag, o_val, tcount, D0, NPVT); __syncthreads(); }
         if (in) {
 #pragma unroll
             for (int c = 0; c < P_VOX; ++c) b.C[(size_t)c * Acap + a] = acc[c];
@@ -229,36 +239,41 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
             }
         }
     }
-    // columns shared by every row: wave-shuffle reduction, one LDS atomic per wave and column
+    // columns shared by every row: wave-shuffle reduction into the wave's slot, the slots added in wave order
 #pragma unroll
     for (int i = 0; i < NCAM; ++i) {
         float v = (MODE == PASS_COLNORM) ? camb[i] : cam9[i];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0 && v != 0.0f) atomicAdd(&cam_acc[i], v);
+        if ((threadIdx.x & 63) == 0) lds[D_CAMW + wave * NCAM + i] = v;
     }
     __syncthreads();
-    if (MODE == PASS_COLNORM) {
-        for (int i = threadIdx.x; i < 21 * K; i += EG_THREADS) {
-            float v = 0.0f; for (int q = 0; q < reps; ++q) v += lds[q * rs + i];
-            if (v != 0.0f) {
-                atomicAdd(&b.blocks[i], (double)v);
-                const int f = i / 21, o = i - 21 * f;            // diagonal entries of the block are the squared column norms
-                const int di = o == 0 ? 0 : o == 6 ? 1 : o == 11 ? 2 : o == 15 ? 3 : o == 18 ? 4 : o == 20 ? 5 : -1;
-                if (di >= 0) atomicAdd(&b.shared[6 * f + di], (double)v);
-            }
-        }
-        for (int i = threadIdx.x; i < NCAM; i += EG_THREADS) {
-            const float v = cam_acc[i];
-            if (v != 0.0f) atomicAdd(i < 9 ? &b.shared[6 * K + i] : &b.blocks[21 * K + (i - 9)], (double)v);
-        }
-    } else {
-        for (int i = threadIdx.x; i < nshared; i += EG_THREADS) {
-            float v;
-            if (i < 6 * K) { v = 0.0f; for (int q = 0; q < reps; ++q) v += lds[q * rs + i]; }
-            else v = cam_acc[i - 6 * K];
-            if (v != 0.0f) atomicAdd(&b.shared[i], (double)v);
-        }
-    }
+    if (threadIdx.x < NCAM) { float v = 0.0f; for (int w = 0; w < NWT; ++w) v += lds[D_CAMW + w * NCAM + threadIdx.x]; cam_acc[threadIdx.x] = v; }
+    __syncthreads();
+    // this workgroup's totals as one float row: [pose part (6K | 21K) | NCAM]; k_sum_rows adds the rows of all workgroups in a fixed order
+    const int npose = (MODE == PASS_COLNORM) ? 21 * K : 6 * K;
+    float* const row = b.part + (size_t)blockIdx.x * b.part_stride;
+    for (int i = threadIdx.x; i < npose + NCAM; i += EG_THREADS) row[i] = i < npose ? lds[D0 + i] : cam_acc[i - npose];
+}
+
+// shared / blocks <- the workgroups' rows of a k_eg_pass launch (or of k_eg_tile's cam_part), added in workgroup order (fp64).  mode: PASS_COLNORM distributes the
+// upper triangles into `blocks` and their diagonals into `shared`; otherwise the row is the camera block itself.
+__global__ void __launch_bounds__(256) k_sum_rows(int mode, int K, const float* __restrict__ part, int nrows, int stride, double* __restrict__ shared, double* __restrict__ blocks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncol = mode == PASS_COLNORM ? 21 * K + 34 : 6 * K + 9;
+    if (i >= ncol) return;
+    double v = 0.0;
+    for (int w = 0; w < nrows; ++w) v += (double)part[(size_t)w * stride + i];
+    if (mode != PASS_COLNORM) { shared[i] = v; return; }
+    if (i < 21 * K) {
+        blocks[i] = v;
+        const int f = i / 21, o = i - 21 * f;            // diagonal entries of the block are the squared column norms
+        const int di = o == 0 ? 0 : o == 6 ? 1 : o == 11 ? 2 : o == 15 ? 3 : o == 18 ? 4 : o == 20 ? 5 : -1;
+        if (di >= 0) shared[6 * f + di] = v;
+    } else { const int c = i - 21 * K; if (c < 9) shared[6 * K + c] = v; else blocks[21 * K + (c - 9)] = v; }
+}
+void launch_sum_rows(hipStream_t st, PassMode mode, int K, const float* part, int nrows, int stride, double* shared, double* blocks) {
+    const int ncol = mode == PASS_COLNORM ? 21 * K + 34 : 6 * K + 9;
+    k_sum_rows<<<(ncol + 255) / 256, 256, 0, st>>>((int)mode, K, part, nrows, stride, shared, blocks);
 }
 
 // ---- the PCG operator pass: k_eg_pass<PASS_JTJP> specialised for memory-level parallelism --------------------------------------
@@ -413,36 +428,36 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_jtjp(GridView g, RowView r, O
 }
 
 
-void launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u, PassBuffers b, const PcgState* state) {
-    if (r.nC <= 0) return;
+// returns the number of workgroups = rows written to b.part (GRAD / COLNORM; 0 for the untiled operator, which adds its camera block into b.shared)
+int launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u, PassBuffers b, const PcgState* state) {
+    if (r.nC <= 0) return 0;
     static int num_cu = 0;
     if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     const int ntiles = (r.nC + EG_THREADS - 1) / EG_THREADS;
     const int blocks = ntiles < num_cu ? ntiles : num_cu;                 // one persistent workgroup per CU
     const int tiles_per_block = (ntiles + blocks - 1) / blocks;
     const int nshared = 6 * p.K + 9;
-    // replicas of the pose accumulator: the largest power of two that fits ~150 KB of LDS
-    int reps = 32;
     const int rs = (6 * p.K) | 1;
-    while (reps > 1 && (size_t)(reps * rs + 9 + nshared) * sizeof(float) > 150 * 1024) reps >>= 1;
-    const size_t lds_rep = (size_t)(reps * rs + 9 + nshared) * sizeof(float);
+    constexpr int NW = EG_THREADS / 64;
+    auto det_words = [](int ncam, int tc, int npv) { return 4 + ((NW * ncam + 3) & ~3) + NW * tc + NW * tc * npv; };
     if (mode == PASS_GRAD) {
-        if (!set_dynamic_lds((const void*)k_eg_pass<PASS_GRAD>, "k_eg_pass<GRAD>", lds_rep, p.K)) return;
-        k_eg_pass<PASS_GRAD><<<blocks, EG_THREADS, lds_rep, st>>>(g, r, p, u, b, reps, tiles_per_block, state);
+        const size_t lds_g = (size_t)(det_words(9, 32, 6) + rs + 9) * sizeof(float);
+        if (!set_dynamic_lds((const void*)k_eg_pass<PASS_GRAD>, "k_eg_pass<GRAD>", lds_g, p.K)) return 0;
+        k_eg_pass<PASS_GRAD><<<blocks, EG_THREADS, lds_g, st>>>(g, r, p, u, b, 1, tiles_per_block, state);
+        return blocks;
     } else if (mode == PASS_JTJP) {
         int rj = 8;                                        // replicas only serve the rare > 3-keyframe fallback; LDS goes to the uv staging
         while (rj > 1 && (size_t)(rj * rs + 9 + nshared + P_VOX * EG_THREADS) * sizeof(float) > 150 * 1024) rj >>= 1;
         const size_t lds_j = (size_t)(rj * rs + 9 + nshared + P_VOX * EG_THREADS) * sizeof(float);
-        if (!set_dynamic_lds((const void*)k_eg_jtjp, "k_eg_jtjp", lds_j, p.K)) return;
+        if (!set_dynamic_lds((const void*)k_eg_jtjp, "k_eg_jtjp", lds_j, p.K)) return 0;
         k_eg_jtjp<<<blocks, EG_THREADS, lds_j, st>>>(g, r, p, u, b, rj, tiles_per_block, state);
-    } else {
-        int reps2 = 32;
-        const int rs2 = (21 * p.K) | 1;
-        while (reps2 > 1 && (size_t)(reps2 * rs2 + 34) * sizeof(float) > 150 * 1024) reps2 >>= 1;
-        const size_t n = (size_t)(reps2 * rs2 + 34) * sizeof(float);
-        if (!set_dynamic_lds((const void*)k_eg_pass<PASS_COLNORM>, "k_eg_pass<COLNORM>", n, p.K)) return;
-        k_eg_pass<PASS_COLNORM><<<blocks, EG_THREADS, n, st>>>(g, r, p, u, b, reps2, tiles_per_block, state);
+        return 0;
     }
+    const int rs2 = (21 * p.K) | 1;
+    const size_t n = (size_t)(det_words(34, 16, 21) + rs2 + 34) * sizeof(float);
+    if (!set_dynamic_lds((const void*)k_eg_pass<PASS_COLNORM>, "k_eg_pass<COLNORM>", n, p.K)) return 0;
+    k_eg_pass<PASS_COLNORM><<<blocks, EG_THREADS, n, st>>>(g, r, p, u, b, 1, tiles_per_block, state);
+    return blocks;
 }
 
 // ---- pass 2: one lane per work-list entry pulls what the rows contribute to its two unknowns ------------------------------

@@ -83,57 +83,53 @@ static __device__ inline void sh_features(const GridView& g, int s, double f[10]
     w = fmin(fmax(1.0 - fmin(fabs(xs), tr) / tr, 0.01), 1.0);                                       // sdfToWeight (operators.cpp:142-147)
 }
 
-// Gram accumulation over the subvolume-sorted list of eligible voxels.  One wave owns `tiles_per_wave` consecutive 64-voxel tiles.
-__global__ void __launch_bounds__(256) k_sh_gram(GridView g, int M, const int* __restrict__ sorted_vox, const int* __restrict__ sorted_sub,
-                                                 int tiles_per_wave, double* __restrict__ gram /*[S][100]*/, double* __restrict__ wsum) {
+// Gram accumulation over the subvolume-sorted list of eligible voxels [m0, m1) (a rank's slice): ONE WAVE PER SUBVOLUME walks the subvolume's run of the list in
+// 64-voxel tiles and writes its 10 x 10 block and weight sum itself — no block is shared by waves, nothing is added atomically, the sums of an estimate are
+// bit-reproducible (round 3: fixed 8-tile chunks per wave, fp64 atomics wherever a chunk ended inside a subvolume).  A subvolume holds a few thousand voxels of
+// the shell: a few dozen tiles per wave, once per level.
+__global__ void __launch_bounds__(256) k_sh_gram(GridView g, int m0, int m1, int S, const int* __restrict__ sorted_vox, const int* __restrict__ sorted_sub,
+                                                 double* __restrict__ gram /*[S][100]*/, double* __restrict__ wsub /*[S]*/) {
     __shared__ double feat[4][64][17];     // +1 padding: the MFMA operand read walks a column of 4 voxels x 16 features
     __shared__ double wl[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wave_global = blockIdx.x * 4 + wv;
-    const long long first = (long long)wave_global * tiles_per_wave * 64;
+    const int sub = blockIdx.x * 4 + wv;
+    if (sub >= S) return;
+    // the subvolume's run of the (sorted) list, cut to the slice
+    int lo = m0, hi = m1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_sub[mid] < sub) lo = mid + 1; else hi = mid; }
+    const int first = lo;
+    hi = m1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_sub[mid] <= sub) lo = mid + 1; else hi = mid; }
+    const int last = lo;
+    if (last <= first) return;                                       // (gram / wsub are zeroed by the caller)
     v4d acc = {0.0, 0.0, 0.0, 0.0};
-    int cur = -1;
     double wtot = 0.0;
-    auto flush = [&](int sub) {
-        if (sub < 0) return;
-        const int col = lane & 15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = (lane >> 4) + 4 * r; if (row < 10 && col < 10 && acc[r] != 0.0) atomicAdd(&gram[(size_t)sub * 100 + row * 10 + col], acc[r]); }
-        acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    };
-    for (int t = 0; t < tiles_per_wave; ++t) {
-        const long long i = first + (long long)t * 64 + lane;
-        if (first + (long long)t * 64 >= M) break;
-        int sub = -1; double f[10], w = 0.0;
-        if (i < M) { sub = sorted_sub[i]; sh_features(g, sorted_vox[i], f, w); wtot += w; }
+    for (int t0 = first; t0 < last; t0 += 64) {
+        const int i = t0 + lane;
+        double f[10], w = 0.0;
+        if (i < last) { sh_features(g, sorted_vox[i], f, w); wtot += w; }
         else { for (int j = 0; j < 10; ++j) f[j] = 0.0; }
-        const int sub0 = __shfl(sub, 0, 64);
-        const bool uniform = __all(sub == sub0 || sub < 0);
-        if (uniform) {
-            if (sub0 != cur) { flush(cur); cur = sub0; }
 #pragma unroll
-            for (int j = 0; j < 10; ++j) feat[wv][lane][j] = f[j];
+        for (int j = 0; j < 10; ++j) feat[wv][lane][j] = f[j];
 #pragma unroll
-            for (int j = 10; j < 16; ++j) feat[wv][lane][j] = 0.0;
-            wl[wv][lane] = w;
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): LDS writes of this wave are visible to its own reads
+        for (int j = 10; j < 16; ++j) feat[wv][lane][j] = 0.0;
+        wl[wv][lane] = w;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): LDS writes of this wave are visible to its own reads
 #pragma unroll
-            for (int grp = 0; grp < 16; ++grp) {
-                const int vox = 4 * grp + (lane >> 4);
-                const double b = feat[wv][vox][lane & 15];
-                const double a = b * wl[wv][vox];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else if (sub >= 0) {
-            // tile straddles a subvolume boundary: scalar rank-1 update straight into memory (rare)
-            for (int r = 0; r < 10; ++r) for (int c2 = 0; c2 < 10; ++c2) atomicAdd(&gram[(size_t)sub * 100 + r * 10 + c2], w * f[r] * f[c2]);
+        for (int grp = 0; grp < 16; ++grp) {
+            const int vox = 4 * grp + (lane >> 4);
+            const double bq = feat[wv][vox][lane & 15];
+            const double aq = bq * wl[wv][vox];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, acc, 0, 0, 0);
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    flush(cur);
+    const int col = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int row = (lane >> 4) + 4 * r; if (row < 10 && col < 10) gram[(size_t)sub * 100 + row * 10 + col] = acc[r]; }
     for (int o = 32; o > 0; o >>= 1) wtot += __shfl_down(wtot, o, 64);
-    if (lane == 0 && wtot != 0.0) atomicAdd(wsum, wtot);
+    if (lane == 0) wsub[sub] = wtot;
 }
 
 __global__ void __launch_bounds__(256) k_sh_assign(int M, const unsigned long long* __restrict__ sorted_keys, const unsigned long long* __restrict__ uniq, int S, int* __restrict__ sorted_sub) {
@@ -182,12 +178,9 @@ __global__ void __launch_bounds__(256) k_sh_interpolate(GridView g, ShParams sp,
 void launch_sh_keys(hipStream_t st, GridView g, ShParams sp, unsigned long long* keys, int* iota) { if (g.N > 0) k_sh_keys<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, keys, iota); }
 void launch_sh_all_keys(hipStream_t st, GridView g, ShParams sp, unsigned long long* keys) { if (g.N > 0) k_sh_all_keys<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, keys); }
 void launch_sh_assign(hipStream_t st, int M, const unsigned long long* sorted_keys, const unsigned long long* uniq, int S, int* sorted_sub) { if (M > 0) k_sh_assign<<<(M + 255) / 256, 256, 0, st>>>(M, sorted_keys, uniq, S, sorted_sub); }
-void launch_sh_gram(hipStream_t st, GridView g, int M, const int* sorted_vox, const int* sorted_sub, double* gram, double* wsum) {
-    if (M <= 0) return;
-    const int tiles = (M + 63) / 64;
-    int tiles_per_wave = 8;
-    const int waves = (tiles + tiles_per_wave - 1) / tiles_per_wave;
-    k_sh_gram<<<(waves + 3) / 4, 256, 0, st>>>(g, M, sorted_vox, sorted_sub, tiles_per_wave, gram, wsum);
+void launch_sh_gram(hipStream_t st, GridView g, int m0, int m1, int S, const int* sorted_vox, const int* sorted_sub, double* gram, double* wsub) {
+    if (m1 <= m0 || S <= 0) return;
+    k_sh_gram<<<(S + 3) / 4, 256, 0, st>>>(g, m0, m1, S, sorted_vox, sorted_sub, gram, wsub);
 }
 void launch_sh_interpolate(hipStream_t st, GridView g, ShParams sp, const unsigned long long* uniq, int S, const double* sh, float* out) {
     if (g.N > 0) k_sh_interpolate<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, uniq, S, sh, out);

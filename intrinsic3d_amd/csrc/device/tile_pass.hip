@@ -124,7 +124,6 @@ __global__ void __launch_bounds__(256) k_eaw_sym(RowView r, const int* __restric
 }
 
 // ---- the pass ---------------------------------------------------------------------------------------------------------------------
-static __device__ inline void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 struct RowBlock { float4 p[7]; float j28; int tag; };  // one stored Eg row in registers: planes 0..6 + column 28 + keyframe tag
 typedef unsigned v4u_b __attribute__((ext_vector_type(4)));
 typedef unsigned v2u_b __attribute__((ext_vector_type(2)));
@@ -148,7 +147,7 @@ template <int Z> struct AllZ { unsigned w[LNBR_WORDS]; constexpr AllZ() : w{} { 
 // `val(i)` yields component i of this lane's contribution ON DEMAND and every wave sum is added to LDS at once: neither the NV values nor the
 // NV sums are live together (the row loop has no register to spare: 128 per lane, and a spill reload there is a vmcnt(0) that drains the row stream)
 template <int NV, class F>
-static __device__ inline void wave_accumulate_lds(bool valid, int f, F val, float* lds, int reps, int rs, int wave_off, int stride) {
+static __device__ inline void wave_accumulate_lds(bool valid, int f, F val, float* lds, int reps, int rs, int wave_off, int stride, int base_off = 0) {
     bool pending = valid;
     unsigned long long todo = __ballot(pending);
     for (int round = 0; todo != 0ull; ++round) {
@@ -158,7 +157,7 @@ static __device__ inline void wave_accumulate_lds(bool valid, int f, F val, floa
                 // 1024-entry geometry the compiler spilled it and reloaded it behind every row block, each reload an s_waitcnt vmcnt(0))
                 int lane_rep = (int)(threadIdx.x & (unsigned)(reps - 1));
                 asm volatile("" : "+v"(lane_rep));
-                const int lane_off = lane_rep * rs;
+                const int lane_off = base_off + lane_rep * rs;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) lds_add(&lds[lane_off + stride * f + i], val(i));
             }
@@ -180,7 +179,10 @@ static __device__ inline void wave_accumulate_lds(bool valid, int f, F val, floa
 // (Software pipelining across the tiles of a workgroup — the next tile's input gathers / first row block issued before the pull phase of the current
 // one — was built and measured in rounds 2 and 3, three sessions: never better than 1 %, slower whenever the values carried across the pull phase
 // spilled; removed.  DESIGN.md section 9.)
-template <int T, int HMAX, int SLOTS, bool GHOSTS>
+// DET: fixed-order sums everywhere inside the workgroup — the halo pushes of a tile happen in an ORDERED SECTION (the waves take turns in wave order: a ticket in
+// LDS; the LDS atomic unit serialises them anyway), the pose block goes through per-wave tables (above), the intrinsics / distortion sums through per-wave slots.
+// With the fixed-order sums across workgroups (cam_part, p.q partials, the halo fold of k_pcg_step3) a PCG pass is then bit-reproducible from run to run.
+template <int T, int HMAX, int SLOTS, bool GHOSTS, bool DET>
 __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const float* __restrict__ u, const unsigned* __restrict__ lnbr,
                                                         const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx, const int* __restrict__ halo_cnt,
                                                         double* __restrict__ shared, float* __restrict__ qacc, float* __restrict__ qh, double* __restrict__ pq_partials,
@@ -195,9 +197,13 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     const int K = p.K; const size_t Acap = r.Acap; const int A = r.A, chunk = r.chunk;
     const int nshared = 6 * K + 9;
     const int rs = (6 * K) | 1;
-    const int nacc = reps * rs + 9;
+    // DET: the ticket, the per-wave intrinsics / distortion sums and the per-wave keyframe tables come FIRST, at compile-time offsets (everything behind them
+    // depends on K; offsets that are constants or functions of the wave number cost no scalar register across the row loop)
+    constexpr int NW = T / 64, TC = T == 1024 ? 64 : 32;
+    constexpr int D_CAM9W = 4, D_TAG = D_CAM9W + ((NW * 9 + 3) & ~3), D_VAL = D_TAG + NW * TC, D0 = DET ? D_VAL + NW * TC * 6 : 0;
+    const int nacc = D0 + reps * rs + 9;                             // end of the dense camera accumulators [D0, nacc)
     const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
-    for (int i = threadIdx.x; i < nacc; i += T) lds[i] = 0.0f;
+    for (int i = D0 + threadIdx.x; i < nacc; i += T) lds[i] = 0.0f;
     // every LDS access below is lds[<integer offset>]: pointers derived from `lds` and handed to helpers degrade to 64-bit generic pointers
     // (flat instructions, two registers each — they were what spilled inside the row loop)
 #define upose (lds + o_upose)
@@ -209,8 +215,8 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
 #define C_l (lds + o_u + 2 * NSLOT + 2 * HMAX + T + 4)                         /* [12][T] column sums of the tile's Eg rows (slots 1..9, 11..13), lane-private until the pull */
     const size_t tail = 2 * (size_t)chunk;
     for (int i = threadIdx.x; i < nshared; i += T) upose[i] = u[tail + i];
-    const int o_cam = reps * rs;
-    const int o_wave_acc = __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) & (reps - 1)) * rs);       // wave-uniform: a scalar
+    const int o_cam = D0 + reps * rs;
+    const int o_wave_acc = __builtin_amdgcn_readfirstlane(D0 + ((threadIdx.x >> 6) & (reps - 1)) * rs);       // wave-uniform: a scalar
     float cam9[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) cam9[i] = 0.0f;
@@ -224,6 +230,16 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     // value the compiler spilled and reloaded behind every row block (each reload an s_waitcnt vmcnt(0) that drains the row stream)
 #define pq_l reinterpret_cast<double*>(lds + o_u + 2 * NSLOT + 2 * HMAX + T + 4 + 12 * T)
     pq_l[i] = 0.0;
+    // DET: [ticket | 3 pad] [NW][9] per-wave intrinsics / distortion sums | [NW][TC] keyframe tags | [NW][TC][6] sums (at the front of the LDS, see above)
+    constexpr int o_det = 0, o_cam9w = D_CAM9W;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#define o_tag (D_TAG + wave * TC)
+#define o_val (D_VAL + wave * (TC * 6))
+    int tcount = 0;                                                  // entries of this wave's table (wave-uniform)
+    if (DET) {
+        if ((threadIdx.x & 63u) < (unsigned)TC) lds[o_tag + (threadIdx.x & 63u)] = __int_as_float(-1);
+        for (int e = threadIdx.x & 63u; e < TC * 6; e += 64) lds[o_val + e] = 0.0f;
+    }
 
     // the tile in flight
     constexpr int NQH = (HMAX + T - 1) / T;
@@ -302,7 +318,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         u_s[i] = us; u_a[i] = ua;
 #pragma unroll
         for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; if (hq < HMAX) { const bool hv = hq < H; u_s[T + hq] = hv ? hs[q] : 0.0f; u_a[T + hq] = hv ? ha[q] : 0.0f; qh_s[hq] = 0.0f; qh_a[hq] = 0.0f; } }
-        if (i == 0) { u_s[ZSLOT] = 0.0f; u_a[ZSLOT] = 0.0f; tr_l[T] = 0.0f; }
+        if (i == 0) { u_s[ZSLOT] = 0.0f; u_a[ZSLOT] = 0.0f; tr_l[T] = 0.0f; if (DET) lds[o_det] = __int_as_float(0); }      // (DET: the ordered section of this tile starts at wave 0)
 #pragma unroll
         for (int c = 0; c < 12; ++c) C_l[c * T + i] = 0.0f;
         const bool active = in && (fl & F_ACTIVE);
@@ -321,8 +337,10 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 const float lap = ((((((-6.0f * us) + u_s[rg[0]]) + u_s[rg[1]]) + u_s[rg[2]]) + u_s[rg[3]]) + u_s[rg[4]]) + u_s[rg[5]];
                 tr = tw1 * lap; if (owned) pq_pre += (double)(tr * lap);
                 self_s += -6.0f * tr;
+                if (!DET) {
 #pragma unroll
-                for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles
+                    for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles (DET: in the ordered section)
+                }
             }
             tr_l[i] = tr;
             if ((rf & 2) && (rf & 4)) { const float ts = tw2 * us; if (owned) pq_pre += (double)(ts * us); self_s += ts; }
@@ -368,8 +386,10 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 }
             }
             // pose columns 14..19 of the row: plane 3 (.z, .w) and plane 4
-            wave_accumulate_lds<6>(pvalid, fsel, [&](int q) { const float j = q == 0 ? rw[3].z : q == 1 ? rw[3].w : q == 2 ? rw[4].x : q == 3 ? rw[4].y : q == 4 ? rw[4].z : rw[4].w; return j * tsel; },
-                                   lds, reps, rs, o_wave_acc, 6);
+            if (DET) wave_table_add<6, TC>(pvalid, fsel, [&](int q) { const float j = q == 0 ? rw[3].z : q == 1 ? rw[3].w : q == 2 ? rw[4].x : q == 3 ? rw[4].y : q == 4 ? rw[4].z : rw[4].w; return j * tsel; },
+                                           lds, o_tag, o_val, tcount, D0, 6);
+            else wave_accumulate_lds<6>(pvalid, fsel, [&](int q) { const float j = q == 0 ? rw[3].z : q == 1 ? rw[3].w : q == 2 ? rw[4].x : q == 3 ? rw[4].y : q == 4 ? rw[4].z : rw[4].w; return j * tsel; },
+                                        lds, reps, rs, o_wave_acc, 6);
         };
         if (SLOTS > 0 && ghost_tile && __ballot(nr > 0) == 0ull) {
             // (wave-uniform, a scalar compare) no row in this wave of a ghost tile: nothing to stream
@@ -402,12 +422,24 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
 #pragma unroll
         for (int d = 0; d < 6; ++d) eaw[d] = __builtin_nontemporal_load(&eaw_sym[(size_t)d * Acap + ac]);
         // ---- what lands in the halo is pushed (few lanes: the tile's outer shell) ----
+        if (DET) {       // ordered section: wave w enters when waves 0 .. w-1 have left (their LDS operations are older than the ticket they wrote)
+            ordered_enter(&lds[o_det], wave);
+            if (rf & 1) {
+                const float tr = tr_l[i]; const int rg[6] = {sx, mx, sy, my, sz, mz};
+#pragma unroll
+                for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles
+            }
+        }
         if (nr > 0) {
 #pragma unroll
             for (int c = 1; c < 10; ++c) { const int sl = unpack12(ln, c - 1); if (sl >= T && sl != ZSLOT) lds_add(&qh_s[sl - T], Cme[(c - 1) * T]); }
             if (sx >= T && sx != ZSLOT) lds_add(&qh_a[sx - T], Cme[9 * T]);
             if (sy >= T && sy != ZSLOT) lds_add(&qh_a[sy - T], Cme[10 * T]);
             if (sz >= T && sz != ZSLOT) lds_add(&qh_a[sz - T], Cme[11 * T]);
+        }
+        if (DET) {
+            if (tcount > TC - 16) wave_table_merge<6, TC>(lds, o_tag, o_val, tcount, D0, 6);      // (wave-uniform) room for the next tile's keyframes
+            ordered_leave(&lds[o_det], wave);
         }
         const int a_c = a, H_c = H, tile_c = tile; const bool in_c = in, owned_c = owned; const float ua_c = ua;
         __syncthreads();
@@ -439,18 +471,25 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     for (int q = 0; q < 9; ++q) {
         float v = cam9[q];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0 && v != 0.0f) lds_add(&lds[o_cam + q], v);
+        if ((threadIdx.x & 63) == 0) { if (DET) lds[o_cam9w + wave * 9 + q] = v; else if (v != 0.0f) lds_add(&lds[o_cam + q], v); }
     }
     __syncthreads();
+    if (DET) {           // the waves' tables -> the dense accumulator, and their intrinsics / distortion sums, both in wave order
+        for (int w = 0; w < NW; ++w) { if (wave == w) wave_table_merge<6, TC>(lds, o_tag, o_val, tcount, D0, 6); __syncthreads(); }
+        if (threadIdx.x < 9) { float v = 0.0f; for (int w = 0; w < NW; ++w) v += lds[o_cam9w + w * 9 + threadIdx.x]; lds[o_cam + threadIdx.x] = v; }
+        __syncthreads();
+    }
     for (int q = threadIdx.x; q < nshared; q += T) {
         float v;
-        if (q < 6 * K) { v = 0.0f; for (int rp = 0; rp < reps; ++rp) v += lds[rp * rs + q]; }
+        if (q < 6 * K) { v = 0.0f; for (int rp = 0; rp < reps; ++rp) v += lds[D0 + rp * rs + q]; }
         else v = lds[o_cam + q - 6 * K];
         if (cam_partials) cam_partials[(size_t)blockIdx.x * cam_stride + q] = v;      // summed in a fixed order by k_pcg_step3's camera workgroups
         else if (v != 0.0f) atomicAdd(&shared[q], (double)v);
     }
     if (pq_partials) block_partial_d(pq_l[i], pq_partials, 1, 0);
 #undef pq_l
+#undef o_tag
+#undef o_val
 #undef upose
 #undef u_s
 #undef u_a
@@ -522,10 +561,14 @@ template <int T, int HMAX>
 static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state, int num_cu,
                             float* cam_partials, int cam_stride) {
     const int nshared = 6 * p.K + 9, rs = (6 * p.K) | 1;
-    auto lds_bytes = [&](int reps) { const int nacc = reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
+    // fixed-order sums inside the workgroup (DET) by default; I3D_EGT_DET=0 selects the round-3 accumulation (LDS atomics shared by the waves) for A/B runs
+    static const bool det = [] { const char* e = std::getenv("I3D_EGT_DET"); return !(e && e[0] == '0'); }();
+    constexpr int NW = T / 64, TC = T == 1024 ? 64 : 32;
+    const int det_words = det ? 4 + ((NW * 9 + 3) & ~3) + NW * TC * 7 : 0;      // ticket, per-wave camera sums, per-wave keyframe tables (at the front of the LDS)
+    auto lds_bytes = [&](int reps) { const int nacc = det_words + reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
                                      return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T + 2 * T /* p.q per lane, fp64 */) * sizeof(float); };
     const size_t budget = (T == 512 ? 79 : 158) * 1024;
-    int reps = 4;                                            // replicas only serve the rare > 3-keyframe fallback of wave_accumulate
+    int reps = det ? 1 : 4;                                  // replicas only serve the rare > 3-keyframe fallback of wave_accumulate (DET: one dense accumulator, the waves own tables)
     while (reps > 1 && lds_bytes(reps) > budget) reps >>= 1;
     const size_t lds = lds_bytes(reps);
     int per_cu = (T == 512 && lds <= budget) ? 2 : 1;
@@ -542,9 +585,10 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
             // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
             // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
             if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
-#define I3D_EGT(SL, GH) do { \
-        if (!set_dynamic_lds((const void*)k_eg_tile<T, HMAX, SL, GH>, "k_eg_tile", lds, p.K)) break; \
-        k_eg_tile<T, HMAX, SL, GH><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
+#define I3D_EGT(SL, GH) do { if (det) I3D_EGT2(SL, GH, true); else I3D_EGT2(SL, GH, false); } while (0)
+#define I3D_EGT2(SL, GH, DT) do { \
+        if (!set_dynamic_lds((const void*)k_eg_tile<T, HMAX, SL, GH, DT>, "k_eg_tile", lds, p.K)) break; \
+        k_eg_tile<T, HMAX, SL, GH, DT><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
                                                    t.ghost_tiles, ntl, state, cam_partials, cam_stride, r.gmax); } while (0)
             const bool gh = t.n_ghost > 0;
             // the shipped num_observations (data/intrinsic3d.yml): unrolled row loop.  (The run-time loop, which skips the slots no lane of a wave uses, is
@@ -552,6 +596,7 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
             if (r.slots == 5) { if (gh) I3D_EGT(5, true); else I3D_EGT(5, false); }
             else { if (gh) I3D_EGT(0, true); else I3D_EGT(0, false); }
 #undef I3D_EGT
+#undef I3D_EGT2
             written = blocks;
         }
     }

@@ -54,4 +54,62 @@ static __device__ inline void wave_accumulate(bool valid, int f, const float (&v
 }
 
 
+static __device__ inline void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// DETERMINISTIC camera block (DET): the pose columns of a wave's rows go into a table PRIVATE to the wave — one (keyframe tag, NV sums) entry per distinct keyframe
+// the wave has met, found with one LDS read of the tags (lane = table slot) and a ballot — instead of LDS accumulators that several waves add to in whatever
+// order they arrive.  The tables are merged into the workgroup's dense accumulator in wave order (inside the ordered section of a tile when a table fills up, and
+// once at the end of the workgroup), so the fp32 sums of a pass do not depend on timing.  TC entries per wave (<= 64: one lane per slot); a wave that meets more
+// distinct keyframes between two merges falls back to atomics on the dense accumulator (order-dependent; not seen on the bench scenes: slots are keyframe-ordered
+// and neighbouring voxels choose the same keyframes).
+template <int NV, int TC, class F>
+static __device__ inline void wave_table_add(bool valid, int f, F val, float* lds, int o_tag, int o_val, int& count /* wave-uniform */, int o_dense, int dense_stride) {
+    bool pending = valid;
+    unsigned long long todo = __ballot(pending);
+    const int lane = (int)(threadIdx.x & 63u);
+    while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int f0 = __builtin_amdgcn_readlane(f, leader);
+        const bool mine = pending && f == f0;
+        const int tg = __float_as_int(lds[o_tag + (lane & (TC - 1))]);                 // tags of unused slots are -1
+        const unsigned long long hit = __ballot(tg == f0);
+        int slot;
+        if (hit != 0ull) slot = (__ffsll((long long)hit) - 1) & (TC - 1);
+        else if (count < TC) { slot = count; if (lane == 0) lds[o_tag + slot] = __int_as_float(f0); count = count + 1; }
+        else slot = -1;
+        const bool lead = lane == leader;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float sum = wave_sum(mine ? val(i) : 0.0f);
+            if (lead) { if (slot >= 0) lds[o_val + slot * NV + i] += sum; else lds_add(&lds[o_dense + dense_stride * f0 + i], sum); }
+        }
+        pending = pending && !mine;
+        todo = __ballot(pending);
+    }
+}
+// one wave's table -> the dense accumulator (distinct keyframes per entry: no two lanes meet), table cleared.  Called in wave order.
+template <int NV, int TC>
+static __device__ inline void wave_table_merge(float* lds, int o_tag, int o_val, int& count, int o_dense, int dense_stride) {
+    const int lane = (int)(threadIdx.x & 63u);
+    for (int e = lane; e < count * NV; e += 64) {
+        const int sl = e / NV, i = e - sl * NV;
+        const int f = __float_as_int(lds[o_tag + sl]);
+        lds[o_dense + dense_stride * f + i] += lds[o_val + e];
+        lds[o_val + e] = 0.0f;
+    }
+    if (lane < TC) lds[o_tag + lane] = __int_as_float(-1);
+    count = 0;
+}
+
+// Ordered section of a workgroup: wave w enters when waves 0 .. w-1 have left (a ticket in LDS; the LDS operations of a wave are older than the ticket it wrote).
+// The ticket word must be 0 when the first wave arrives (reset it behind a barrier).
+static __device__ inline void ordered_enter(float* ticket, int wave) {
+    while (__float_as_int(__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != wave) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+static __device__ inline void ordered_leave(float* ticket, int wave) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63u) == 0) __hip_atomic_store(ticket, __int_as_float(wave + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 }  // namespace i3d

@@ -86,6 +86,7 @@ struct i3d_context {
     i3d::DevBuf<float4> rows; i3d::DevBuf<float2> row_wr;
     i3d::DevBuf<uint8_t> aflags, nrows, regflags, ea_free; i3d::DevBuf<int> gmax;
     // tiled operator pass (tile_pass.hip): plan of the current work list
+    i3d::DevBuf<float> aux_part;      // one float row of camera totals per workgroup of the gradient / column-norm passes (summed in a fixed order)
     i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_ext_off, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw, cam_part;
     i3d::DevBuf<unsigned char> tp_temp; bool tile_ok = false;
     double t_add_end = 0.0;         // host clock at the end of the residual collection of the current outer iteration (time_add | time_build)

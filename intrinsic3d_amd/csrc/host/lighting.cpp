@@ -209,23 +209,24 @@ int estimate_sh(i3d_context* c, float subvolume_size, double lambda_reg, double 
     std::vector<unsigned long long> el_keys; std::vector<int> el_cnt;
     { int rc = rle(el_keys, el_cnt); if (rc) return rc; }
     long long M = 0; for (size_t i = 0; i < el_keys.size(); ++i) if (el_keys[i] != ~0ull) M += el_cnt[i];
-    DevBuf<double> d_gram, d_wsum; CTX_HIP(c, d_gram.alloc((size_t)S * 100)); CTX_HIP(c, d_wsum.alloc(1));
-    CTX_HIP(c, hipMemsetAsync(d_gram.p, 0, sizeof(double) * (size_t)S * 100, st)); CTX_HIP(c, hipMemsetAsync(d_wsum.p, 0, sizeof(double), st));
+    DevBuf<double> d_gram, d_wsum; CTX_HIP(c, d_gram.alloc((size_t)S * 100)); CTX_HIP(c, d_wsum.alloc((size_t)S));      // per-subvolume weight sums (added up on the host in subvolume order)
+    CTX_HIP(c, hipMemsetAsync(d_gram.p, 0, sizeof(double) * (size_t)S * 100, st)); CTX_HIP(c, hipMemsetAsync(d_wsum.p, 0, sizeof(double) * (size_t)S, st));
     launch_sh_assign(st, (int)M, k1.p, d_sub.p, S, ssub.p);
     // Sharded (lighting_svsh.cpp:196-253 is the data term): the subvolume-sorted list of eligible voxels is cut into `world` contiguous
     // slices, a rank accumulates the Gram blocks of ITS slice only, and one all-reduce (sum) of S x 100 doubles + the weight sum gives every rank the
     // same totals — the all-reduce hands out one result, so the lighting, and with it every replicated row, is bit-identical on all ranks.
     const int world = (c->comm && (c->comm->world > 1 || c->comm->force)) ? c->comm->world : 1, me = world > 1 ? c->comm->rank : 0;
     const long long m0 = (M * me) / world, m1 = (M * (me + 1)) / world;
-    if (m1 > m0) launch_sh_gram(st, g, (int)(m1 - m0), svox.p + m0, ssub.p + m0, d_gram.p, d_wsum.p);
+    if (m1 > m0) launch_sh_gram(st, g, (int)m0, (int)m1, S, svox.p, ssub.p, d_gram.p, d_wsum.p);
     if (c->comm && (c->comm->world > 1 || c->comm->force)) {
-        if (c->comm->allreduce_sum(d_gram.p, (size_t)S * 100, st) || c->comm->allreduce_sum(d_wsum.p, 1, st)) return ctx_fail(c, I3D_ERR_COMM, "i3d_estimate_sh: all-reduce failed");
+        if (c->comm->allreduce_sum(d_gram.p, (size_t)S * 100, st) || c->comm->allreduce_sum(d_wsum.p, (size_t)S, st)) return ctx_fail(c, I3D_ERR_COMM, "i3d_estimate_sh: all-reduce failed");
     }
     ShSystem sys; sys.S = S; sys.G.resize((size_t)S * 100);
-    double wsum = 0.0;
+    double wsum = 0.0; std::vector<double> wsub((size_t)S, 0.0);
     CTX_HIP(c, hipMemcpyAsync(sys.G.data(), d_gram.p, sizeof(double) * (size_t)S * 100, hipMemcpyDeviceToHost, st));
-    CTX_HIP(c, hipMemcpyAsync(&wsum, d_wsum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    CTX_HIP(c, hipMemcpyAsync(wsub.data(), d_wsum.p, sizeof(double) * (size_t)S, hipMemcpyDeviceToHost, st));
     CTX_HIP(c, hipStreamSynchronize(st));
+    for (int q = 0; q < S; ++q) wsum += wsub[(size_t)q];
 
     // ---- neighbour pairs between subvolumes (6-ring, both directions) ----
     auto unpack = [](unsigned long long k, int& x, int& y, int& z) { x = (int)(k & 0x1fffff) - (1 << 20); y = (int)((k >> 21) & 0x1fffff) - (1 << 20); z = (int)((k >> 42) & 0x1fffff) - (1 << 20); };

@@ -36,6 +36,8 @@ static double varying_lambda(int it, int n, double l0, double l1) {        // co
 }
 
 constexpr int HALO_CAP = 1 << 20;      // (direction, peer, entry) items of a rank's halo plan
+constexpr int AUX_PART_ROWS = 320;     // >= the workgroups of a gradient / column-norm pass (one per CU)
+static size_t aux_part_stride(int K) { return ((size_t)21 * K + 34 + 3) & ~(size_t)3; }
 constexpr int PCG_SEQ_STRIDE = 1024;   // pass numbers a PCG solve may use (<= 521 passes): the numbering of the next solve does not depend on how many passes a host queued
 constexpr int LM_REC_SLOTS = 64;       // LmRecord ring: the initial tests + one record per LM attempt (lm_steps <= LM_REC_SLOTS - 2)
 
@@ -50,7 +52,7 @@ static int alloc_rows(i3d_context* c, int slots) {
       CTX_HIP(c, c->rows.alloc(nrow / 64 * ROW_BLOCK_F4)); CTX_HIP(c, c->row_wr.alloc(nrow)); }
     CTX_HIP(c, c->aflags.alloc(Acap)); CTX_HIP(c, c->nrows.alloc(Acap)); CTX_HIP(c, c->gmax.alloc(Acap / 64 + 2)); CTX_HIP(c, c->anbr.alloc(Acap * NUM_NBR));
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
-    CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8));
+    CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8)); CTX_HIP(c, c->aux_part.alloc((size_t)AUX_PART_ROWS * aux_part_stride(c->K)));
     { // sized for BOTH tile geometries: the 512-entry one needs the most slots on large grids (3 per entry; 1024: 2), but a grid of <= 512 entries is ONE
       // 1024-entry tile with 2048 halo slots against one 512-entry tile with 1536
       const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512);
@@ -288,15 +290,22 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
 // ---- normal-equation pieces (GRAD / COLNORM; the PCG operator is inlined in pcg_solve) ----------------------------------------
 static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const float* u, float* out /*[NP]*/) {
     hipStream_t s = c->stream; GridView g = c->grid_view(); RowView r = c->row_view(); const Layout L = layout_of(c);
-    PassBuffers b{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
+    const int stride = (int)aux_part_stride(c->K);
+    PassBuffers b{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p, c->aux_part.p, stride};
     CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
     if (mode == PASS_COLNORM) CTX_HIP(c, hipMemsetAsync(c->d_blocks.p, 0, sizeof(double) * (21 * (size_t)c->K + 25), s));
+    // the camera block leaves every launch as one float row per workgroup, added up in workgroup order (launch_sum_rows): no global atomics, bit-reproducible
     if (mode == PASS_JTJP && c->tile_ok && !sharded(c)) {        // the PCG's tiled operator pass (raw accumulators straight into `out`)
-        { TimedScope t(c, I3D_K_EG_PASS); launch_eg_tile(s, r, p, u, c->tile_plan(), c->d_shared.p, out, nullptr, nullptr); }
+        const int NSP = (L.NS + 3) & ~3; int rows = 0;
+        { TimedScope t(c, I3D_K_EG_PASS); rows = launch_eg_tile(s, r, p, u, c->tile_plan(), nullptr, out, nullptr, nullptr, c->cam_part.p, NSP); }
         { TimedScope t(c, I3D_K_GATHER); launch_halo_fold(s, r, c->tile_plan(), out, nullptr); }
-        { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, 2 * c->chunk, c->v_mask.p, out, out); }      // the raw accumulators also cover fixed unknowns (the PCG multiplies them by S = 0)
+        { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, 2 * c->chunk, c->v_mask.p, out, out);       // the raw accumulators also cover fixed unknowns (the PCG multiplies them by S = 0)
+          if (rows > 0) launch_sum_rows(s, PASS_JTJP, c->K, c->cam_part.p, rows, NSP, c->d_shared.p, c->d_blocks.p); }
     } else {
-        { TimedScope t(c, mode == PASS_JTJP ? I3D_K_EG_PASS : I3D_K_EG_AUX); launch_eg_pass(s, mode, g, r, p, u, b, nullptr); }
+        int rows = 0;
+        { TimedScope t(c, mode == PASS_JTJP ? I3D_K_EG_PASS : I3D_K_EG_AUX); rows = launch_eg_pass(s, mode, g, r, p, u, b, nullptr);
+          if (rows > AUX_PART_ROWS) return ctx_fail(c, I3D_ERR_CAPACITY, "run_pass: more workgroups than rows of the camera partial buffer");
+          if (rows > 0) launch_sum_rows(s, mode, c->K, c->aux_part.p, rows, stride, c->d_shared.p, c->d_blocks.p); }
         { TimedScope t(c, I3D_K_GATHER); launch_gather(s, mode, r, b, out); }
     }
     { int rc = allreduce(c, c->d_shared.p, (size_t)L.NS); if (rc) return rc; }
@@ -341,7 +350,7 @@ static int pcg_solve(i3d_context* c, const i3d_optimizer_config& cfg, const OptP
     const Layout L = layout_of(c);
     const int K = c->K; const bool multi = sharded(c), tiled = c->tile_ok;
     GridView g = c->grid_view(); RowView r = c->row_view();
-    PassBuffers pb{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p};
+    PassBuffers pb{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p, c->aux_part.p, (int)aux_part_stride(c->K)};
     PcgState* st = c->d_pcg.p;
     double* pq_slot = c->d_shared.p + L.NS;
     const size_t to = L.tail_off; const Seg2 own = L.own;
