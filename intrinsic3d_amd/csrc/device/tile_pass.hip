@@ -182,7 +182,8 @@ static __device__ inline void wave_accumulate_lds(bool valid, int f, F val, floa
 // DET: fixed-order sums everywhere inside the workgroup — the halo pushes of a tile happen in an ORDERED SECTION (the waves take turns in wave order: a ticket in
 // LDS; the LDS atomic unit serialises them anyway), the pose block goes through per-wave tables (above), the intrinsics / distortion sums through per-wave slots.
 // With the fixed-order sums across workgroups (cam_part, p.q partials, the halo fold of k_pcg_step3) a PCG pass is then bit-reproducible from run to run.
-template <int T, int HMAX, int SLOTS, bool GHOSTS, bool DET>
+// DETM (bit mask, A/B runs): 1 = ordered halo pushes, 2 = per-wave keyframe tables + per-wave camera slots, 4 = fences (instead of relying on the in-order LDS) in the ordered section
+template <int T, int HMAX, int SLOTS, bool GHOSTS, int DETM>
 __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const float* __restrict__ u, const unsigned* __restrict__ lnbr,
                                                         const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx, const int* __restrict__ halo_cnt,
                                                         double* __restrict__ shared, float* __restrict__ qacc, float* __restrict__ qh, double* __restrict__ pq_partials,
@@ -192,6 +193,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                                                         const int* __restrict__ gmaxv /* = r.gmax as a restrict-qualified kernel argument: its wave-uniform loads become scalar loads (lgkmcnt), a
                                                                                          vector load here would put an s_waitcnt vmcnt(0) behind the row blocks just requested */) {
     if (state && state->done) return;
+    constexpr bool DET = DETM != 0, DORD = (DETM & 1) != 0, DTAB = (DETM & 2) != 0, DFEN = (DETM & 4) != 0;
     constexpr int ZSLOT = T + HMAX, NSLOT = ZSLOT + 1;
     extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T] | p.q [T] fp64
     const int K = p.K; const size_t Acap = r.Acap; const int A = r.A, chunk = r.chunk;
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     // DET: the ticket, the per-wave intrinsics / distortion sums and the per-wave keyframe tables come FIRST, at compile-time offsets (everything behind them
     // depends on K; offsets that are constants or functions of the wave number cost no scalar register across the row loop)
     constexpr int NW = T / 64, TC = T == 1024 ? 64 : 32;
-    constexpr int D_CAM9W = 4, D_TAG = D_CAM9W + ((NW * 9 + 3) & ~3), D_VAL = D_TAG + NW * TC, D0 = DET ? D_VAL + NW * TC * 6 : 0;
+    constexpr int D_CAM9W = 4, D_TAG = D_CAM9W + ((NW * 9 + 3) & ~3), D_VAL = D_TAG + NW * TC, D0 = DET ? D_VAL + NW * TC * 6 : 0;      // (the region is laid out whenever any DETM bit is set)
     const int nacc = D0 + reps * rs + 9;                             // end of the dense camera accumulators [D0, nacc)
     const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
     for (int i = D0 + threadIdx.x; i < nacc; i += T) lds[i] = 0.0f;
@@ -228,7 +230,9 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     const int i = threadIdx.x;
     // the lane's running p.q (fp64) is parked in LDS: as a register pair it lived across the row loop, and in the 1024-entry geometry that pair was the
     // value the compiler spilled and reloaded behind every row block (each reload an s_waitcnt vmcnt(0) that drains the row stream)
-#define pq_l reinterpret_cast<double*>(lds + o_u + 2 * NSLOT + 2 * HMAX + T + 4 + 12 * T)
+    // with the per-wave tables the row loop has no register for the lane's own sdf / albedo sums (column 0 / 10 of its rows): two more lane-private LDS columns
+    constexpr int NCOL = DTAB ? 14 : 12;
+#define pq_l reinterpret_cast<double*>(lds + o_u + 2 * NSLOT + 2 * HMAX + T + 4 + NCOL * T)
     pq_l[i] = 0.0;
     // DET: [ticket | 3 pad] [NW][9] per-wave intrinsics / distortion sums | [NW][TC] keyframe tags | [NW][TC][6] sums (at the front of the LDS, see above)
     constexpr int o_det = 0, o_cam9w = D_CAM9W;
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
 #define o_tag (D_TAG + wave * TC)
 #define o_val (D_VAL + wave * (TC * 6))
     int tcount = 0;                                                  // entries of this wave's table (wave-uniform)
-    if (DET) {
+    if (DTAB) {
         if ((threadIdx.x & 63u) < (unsigned)TC) lds[o_tag + (threadIdx.x & 63u)] = __int_as_float(-1);
         for (int e = threadIdx.x & 63u; e < TC * 6; e += 64) lds[o_val + e] = 0.0f;
     }
@@ -318,9 +322,9 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         u_s[i] = us; u_a[i] = ua;
 #pragma unroll
         for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; if (hq < HMAX) { const bool hv = hq < H; u_s[T + hq] = hv ? hs[q] : 0.0f; u_a[T + hq] = hv ? ha[q] : 0.0f; qh_s[hq] = 0.0f; qh_a[hq] = 0.0f; } }
-        if (i == 0) { u_s[ZSLOT] = 0.0f; u_a[ZSLOT] = 0.0f; tr_l[T] = 0.0f; if (DET) lds[o_det] = __int_as_float(0); }      // (DET: the ordered section of this tile starts at wave 0)
+        if (i == 0) { u_s[ZSLOT] = 0.0f; u_a[ZSLOT] = 0.0f; tr_l[T] = 0.0f; if (DORD) lds[o_det] = __int_as_float(0); }      // (the ordered section of this tile starts at wave 0)
 #pragma unroll
-        for (int c = 0; c < 12; ++c) C_l[c * T + i] = 0.0f;
+        for (int c = 0; c < NCOL; ++c) C_l[c * T + i] = 0.0f;
         const bool active = in && (fl & F_ACTIVE);
         const int nr = active ? nr_ld : 0;
         const uint8_t rf = active ? rf_ld : 0;
@@ -337,9 +341,9 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 const float lap = ((((((-6.0f * us) + u_s[rg[0]]) + u_s[rg[1]]) + u_s[rg[2]]) + u_s[rg[3]]) + u_s[rg[4]]) + u_s[rg[5]];
                 tr = tw1 * lap; if (owned) pq_pre += (double)(tr * lap);
                 self_s += -6.0f * tr;
-                if (!DET) {
+                if (!DORD) {
 #pragma unroll
-                    for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles (DET: in the ordered section)
+                    for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles (ordered: in the ordered section)
                 }
             }
             tr_l[i] = tr;
@@ -375,7 +379,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 for (int q = 0; q < 9; ++q) d += J[P_INTR + q] * ui[q];
                 const float t = rho * d;
                 pq_rows += t * d;
-                self_s += J[0] * t; self_a += J[10] * t;
+                if (DTAB) { Cme[12 * T] += J[0] * t; Cme[13 * T] += J[10] * t; } else { self_s += J[0] * t; self_a += J[10] * t; }
 #pragma unroll
                 for (int c = 1; c < 10; ++c) Cme[(c - 1) * T] += J[c] * t;
                 Cme[9 * T] += J[11] * t; Cme[10 * T] += J[12] * t; Cme[11 * T] += J[13] * t;
@@ -386,10 +390,10 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 }
             }
             // pose columns 14..19 of the row: plane 3 (.z, .w) and plane 4
-            if (DET) wave_table_add<6, TC>(pvalid, fsel, [&](int q) { const float j = q == 0 ? rw[3].z : q == 1 ? rw[3].w : q == 2 ? rw[4].x : q == 3 ? rw[4].y : q == 4 ? rw[4].z : rw[4].w; return j * tsel; },
+            if (DTAB) wave_table_add<6, TC>(pvalid, fsel, [&](int q) { const float j = q == 0 ? rw[3].z : q == 1 ? rw[3].w : q == 2 ? rw[4].x : q == 3 ? rw[4].y : q == 4 ? rw[4].z : rw[4].w; return j * tsel; },
                                            lds, o_tag, o_val, tcount, D0, 6);
             else wave_accumulate_lds<6>(pvalid, fsel, [&](int q) { const float j = q == 0 ? rw[3].z : q == 1 ? rw[3].w : q == 2 ? rw[4].x : q == 3 ? rw[4].y : q == 4 ? rw[4].z : rw[4].w; return j * tsel; },
-                                        lds, reps, rs, o_wave_acc, 6);
+                                        lds, reps, rs, o_wave_acc, 6, D0);
         };
         if (SLOTS > 0 && ghost_tile && __ballot(nr > 0) == 0ull) {
             // (wave-uniform, a scalar compare) no row in this wave of a ghost tile: nothing to stream
@@ -422,8 +426,8 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
 #pragma unroll
         for (int d = 0; d < 6; ++d) eaw[d] = __builtin_nontemporal_load(&eaw_sym[(size_t)d * Acap + ac]);
         // ---- what lands in the halo is pushed (few lanes: the tile's outer shell) ----
-        if (DET) {       // ordered section: wave w enters when waves 0 .. w-1 have left (their LDS operations are older than the ticket they wrote)
-            ordered_enter(&lds[o_det], wave);
+        if (DORD) {      // ordered section: wave w enters when waves 0 .. w-1 have left (their LDS operations are older than the ticket they wrote)
+            ordered_enter<DFEN>(&lds[o_det], wave);
             if (rf & 1) {
                 const float tr = tr_l[i]; const int rg[6] = {sx, mx, sy, my, sz, mz};
 #pragma unroll
@@ -437,10 +441,8 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
             if (sy >= T && sy != ZSLOT) lds_add(&qh_a[sy - T], Cme[10 * T]);
             if (sz >= T && sz != ZSLOT) lds_add(&qh_a[sz - T], Cme[11 * T]);
         }
-        if (DET) {
-            if (tcount > TC - 16) wave_table_merge<6, TC>(lds, o_tag, o_val, tcount, D0, 6);      // (wave-uniform) room for the next tile's keyframes
-            ordered_leave(&lds[o_det], wave);
-        }
+        if (DTAB && DORD) { if (tcount > TC - 16) wave_table_merge<6, TC>(lds, o_tag, o_val, tcount, D0, 6); }      // (wave-uniform) room for the next tile's keyframes
+        if (DORD) ordered_leave<DFEN>(&lds[o_det], wave);
         const int a_c = a, H_c = H, tile_c = tile; const bool in_c = in, owned_c = owned; const float ua_c = ua;
         __syncthreads();
         // ---- pull: every entry collects the column sums of the tile entries whose stencil contains it ----
@@ -451,6 +453,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
             const int r2y = unpack12(lall, 12), ryz = unpack12(lall, 13), r2z = unpack12(lall, 14), rxy = unpack12(lall, 15), rxz = unpack12(lall, 16), r2x = unpack12(lall, 17);
             auto pull = [&](int col, int slot) { return slot < T ? C_l[col * T + slot] : 0.0f; };
             float qs = self_s, qa = self_a;
+            if (DTAB) { qs += C_l[12 * T + i]; qa += C_l[13 * T + i]; }
             qs += pull(0, my) + pull(1, r2y) + pull(2, ryz) + pull(3, mz) + pull(4, r2z) + pull(5, mx) + pull(6, rxy) + pull(7, rxz) + pull(8, r2x);
             qa += pull(9, mx) + pull(10, my) + pull(11, mz);
             const int rg[6] = {sx, mx, sy, my, sz, mz};
@@ -471,10 +474,10 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     for (int q = 0; q < 9; ++q) {
         float v = cam9[q];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0) { if (DET) lds[o_cam9w + wave * 9 + q] = v; else if (v != 0.0f) lds_add(&lds[o_cam + q], v); }
+        if ((threadIdx.x & 63) == 0) { if (DTAB) lds[o_cam9w + wave * 9 + q] = v; else if (v != 0.0f) lds_add(&lds[o_cam + q], v); }
     }
     __syncthreads();
-    if (DET) {           // the waves' tables -> the dense accumulator, and their intrinsics / distortion sums, both in wave order
+    if (DTAB) {          // the waves' tables -> the dense accumulator, and their intrinsics / distortion sums, both in wave order
         for (int w = 0; w < NW; ++w) { if (wave == w) wave_table_merge<6, TC>(lds, o_tag, o_val, tcount, D0, 6); __syncthreads(); }
         if (threadIdx.x < 9) { float v = 0.0f; for (int w = 0; w < NW; ++w) v += lds[o_cam9w + w * 9 + threadIdx.x]; lds[o_cam + threadIdx.x] = v; }
         __syncthreads();
@@ -562,13 +565,14 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
                             float* cam_partials, int cam_stride) {
     const int nshared = 6 * p.K + 9, rs = (6 * p.K) | 1;
     // fixed-order sums inside the workgroup (DET) by default; I3D_EGT_DET=0 selects the round-3 accumulation (LDS atomics shared by the waves) for A/B runs
-    static const bool det = [] { const char* e = std::getenv("I3D_EGT_DET"); return !(e && e[0] == '0'); }();
+    static const int detm = [] { const char* e = std::getenv("I3D_EGT_DET"); const int m = e ? std::atoi(e) : 3; return (m == 0 || m == 1 || m == 2 || m == 3 || m == 7) ? m : 3; }();
+    const bool det = detm != 0;
     constexpr int NW = T / 64, TC = T == 1024 ? 64 : 32;
     const int det_words = det ? 4 + ((NW * 9 + 3) & ~3) + NW * TC * 7 : 0;      // ticket, per-wave camera sums, per-wave keyframe tables (at the front of the LDS)
     auto lds_bytes = [&](int reps) { const int nacc = det_words + reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
-                                     return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T + 2 * T /* p.q per lane, fp64 */) * sizeof(float); };
+                                     return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + ((detm & 2) ? 14 : 12) * T + 2 * T /* p.q per lane, fp64 */) * sizeof(float); };
     const size_t budget = (T == 512 ? 79 : 158) * 1024;
-    int reps = det ? 1 : 4;                                  // replicas only serve the rare > 3-keyframe fallback of wave_accumulate (DET: one dense accumulator, the waves own tables)
+    int reps = (detm & 2) ? 1 : 4;                                  // replicas only serve the rare > 3-keyframe fallback of wave_accumulate (DET: one dense accumulator, the waves own tables)
     while (reps > 1 && lds_bytes(reps) > budget) reps >>= 1;
     const size_t lds = lds_bytes(reps);
     int per_cu = (T == 512 && lds <= budget) ? 2 : 1;
@@ -585,7 +589,7 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
             // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
             // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
             if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
-#define I3D_EGT(SL, GH) do { if (det) I3D_EGT2(SL, GH, true); else I3D_EGT2(SL, GH, false); } while (0)
+#define I3D_EGT(SL, GH) do { switch (detm) { case 0: I3D_EGT2(SL, GH, 0); break; case 1: I3D_EGT2(SL, GH, 1); break; case 2: I3D_EGT2(SL, GH, 2); break; case 7: I3D_EGT2(SL, GH, 7); break; default: I3D_EGT2(SL, GH, 3); break; } } while (0)
 #define I3D_EGT2(SL, GH, DT) do { \
         if (!set_dynamic_lds((const void*)k_eg_tile<T, HMAX, SL, GH, DT>, "k_eg_tile", lds, p.K)) break; \
         k_eg_tile<T, HMAX, SL, GH, DT><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \

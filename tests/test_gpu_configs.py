@@ -33,8 +33,10 @@ def _oracle_refine(O, sc, frames, levels, ocfg, rc, intr, dist, poses, pose_eps=
 
 
 def _check_fields(out, ref, env):
-    out, ref = helpers.align_by_key(out, ref)
-    assert (out["weight"] != ref["weight"]).mean() <= 2e-4, int((out["weight"] != ref["weight"]).sum())      # (a child next to a differing voxel interpolates other corners)
+    # voxels on one side only (a re-sparsification threshold within the two computations' difference): as many as the reference computation itself flips under
+    # 1e-7 input perturbations allow, times the one envelope factor — 2e-4 of the voxels at least
+    out, ref = helpers.align_by_key(out, ref, max_frac=max(2e-4, helpers.ENVELOPE_FACTOR * env.get("key_frac", 0.0)))
+    assert (out["weight"] != ref["weight"]).mean() <= max(2e-4, helpers.ENVELOPE_FACTOR * env.get("key_frac", 0.0)), int((out["weight"] != ref["weight"]).sum())      # (a child next to a differing voxel interpolates other corners)
     d_sdf = np.abs(out["sdf_refined"] - ref["sdf_refined"]); d_alb = np.abs(out["albedo"] - ref["albedo"])
     smax = float(np.abs(ref["sdf_refined"]).max()); amax = float(np.abs(ref["albedo"]).max())
     assert np.quantile(d_sdf, 0.999) <= 1e-4 * smax, (np.quantile(d_sdf, 0.999), smax)
@@ -46,12 +48,20 @@ def _check_fields(out, ref, env):
 
 
 def _envelope(O, sc, frames, levels, ocfg, rc, intr, dist, poses, ref, eps_list):
-    env = dict(sdf_refined=0.0, albedo=0.0)
+    env = dict(sdf_refined=0.0, albedo=0.0, key_frac=0.0, poses=0.0, intr=0.0)
     for eps in eps_list:
-        per, _, _, _ = _oracle_refine(O, sc, frames, levels, ocfg, rc, intr, dist, poses, pose_eps=eps)
+        per, pintr, pposes, _ = _oracle_refine(O, sc, frames, levels, ocfg, rc, intr, dist, poses, pose_eps=eps)
+        env["poses"] = max(env["poses"], float(np.abs(pposes - ref["_poses"]).max())) if "_poses" in ref else env["poses"]
+        env["intr"] = max(env["intr"], float(np.abs(pintr - ref["_intr"]).max() / np.abs(ref["_intr"]).max())) if "_intr" in ref else env["intr"]
         if per["keys"].shape == ref["keys"].shape and np.array_equal(per["keys"], ref["keys"]):
-            for k in env:
+            for k in ("sdf_refined", "albedo"):
                 env[k] = max(env[k], float(np.abs(per[k] - ref[k]).max()))
+        else:       # the perturbed reference keeps / drops other voxels at a re-sparsification threshold: how many, and the fields on the common ones
+            so, sr = set(map(tuple, per["keys"].tolist())), set(map(tuple, ref["keys"].tolist()))
+            env["key_frac"] = max(env["key_frac"], len(so ^ sr) / float(len(sr)))
+            a, b = helpers.align_by_key({k: v for k, v in per.items()}, {k: v for k, v in ref.items() if not k.startswith("_")}, max_frac=1.0)
+            for k in ("sdf_refined", "albedo"):
+                env[k] = max(env[k], float(np.abs(a[k] - b[k]).max()))
     return env
 
 
@@ -129,7 +139,9 @@ def _three_level_schedule(oracle, tmp_path, *, seed, fix_poses, fix_distortion, 
     vsc = dict(voxel_size=vol["voxel_size"], keys=vol["keys"], sdf=vol["sdf"], weight=vol["weight"], color=vol["color"])
     ref, ointr, oposes, done = _oracle_refine(oracle, vsc, frames, levels, ocfg, rc, intr0, dist0, poses0)
     assert done == 5
+    ref["_poses"] = oposes; ref["_intr"] = ointr
     env = _envelope(oracle, vsc, frames, levels, ocfg, rc, intr0, dist0, poses0, ref, (1e-7, -1e-7))
+    del ref["_poses"], ref["_intr"]
     assert float(vol["voxel_size"]) / 4.0 == pytest.approx(0.001)            # 4 mm -> 1 mm
     return dict(out=out, ref=ref, env=env, intr=intr, ointr=ointr, poses=poses, oposes=oposes, poses0=poses0, dist=dist, intr0=intr0,
                 oracle_args=(vsc, frames, levels, ocfg, rc, intr0, dist0, poses0))
@@ -156,14 +168,10 @@ def test_config_c5_full_joint_refinement_with_free_camera(oracle, tmp_path, caps
     assert np.abs(r["poses"] - r["poses0"]).max() > 1e-5 and np.abs(r["intr"] - r["intr0"]).max() > 1e-4      # the camera did move
     _check_fields(r["out"], r["ref"], r["env"])
     # the camera against the oracle's: its own sensitivity to 1e-7 input perturbations (two perturbed re-runs) bounds what can be asked of poses on this object
-    vsc, frames, levels, ocfg, rc, intr0, dist0, poses0 = r["oracle_args"]
-    spread_p = spread_i = 0.0
-    for eps in (1e-7, -1e-7):
-        _, pi, pp, _ = _oracle_refine(oracle, vsc, frames, levels, ocfg, rc, intr0, dist0, poses0, pose_eps=eps)
-        spread_p = max(spread_p, float(np.abs(pp - r["oposes"]).max())); spread_i = max(spread_i, float(np.abs(pi - r["ointr"]).max() / np.abs(r["ointr"]).max()))
+    spread_p, spread_i = r["env"]["poses"], r["env"]["intr"]
     d_pose = float(np.abs(r["poses"] - r["oposes"]).max()); d_intr = float(np.abs(r["intr"] - r["ointr"]).max() / np.abs(r["ointr"]).max())
     with capsys.disabled():
-        print(f"\n[C5] poses: device vs oracle {d_pose:.3e} (oracle's own spread under 1e-7 input perturbations {spread_p:.3e}); intrinsics {d_intr:.3e} relative (spread {spread_i:.3e}); "
+        print(f"\n[C5] voxels on one side only under 1e-7 perturbations of the ORACLE's input: {r['env']['key_frac']:.2e} of the grid; poses: device vs oracle {d_pose:.3e} (oracle's own spread under 1e-7 input perturbations {spread_p:.3e}); intrinsics {d_intr:.3e} relative (spread {spread_i:.3e}); "
               f"pose update {np.abs(r['poses'] - r['poses0']).max():.3e}")
     assert d_intr <= max(1e-4, helpers.ENVELOPE_FACTOR * spread_i), (d_intr, spread_i)
     assert d_pose <= max(1e-4 * max(1.0, float(np.abs(r["oposes"]).max())), helpers.ENVELOPE_FACTOR * spread_p), (d_pose, spread_p)
