@@ -100,6 +100,7 @@ struct TilePlan {                   // built once per outer iteration by launch_
     int T, hmax;                    // geometry of THIS plan: 512 / 1536 (two workgroups per CU) or 1024 / 2048 (the fallback when a tile's halo does not fit)
     int tile_first, ntiles_own;     // tiles this rank owns (all of them when not sharded)
     const int* ghost_tiles; int n_ghost;   // sharded: foreign tiles that hold ghost entries of this rank's compute list
+    int det;                               // 1: fixed-order sums inside the workgroups of the operator pass as well (I3D_DETERMINISTIC=1, read per outer iteration)
 };
 int    tile_plan_T();                      // default geometry (I3D_EGT_TILE): entries per tile
 int    tile_plan_tiles(int A);             // ... tiles of A entries, halo slots per tile

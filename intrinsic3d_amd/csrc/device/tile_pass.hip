@@ -182,7 +182,9 @@ static __device__ inline void wave_accumulate_lds(bool valid, int f, F val, floa
 // DET: fixed-order sums everywhere inside the workgroup — the halo pushes of a tile happen in an ORDERED SECTION (the waves take turns in wave order: a ticket in
 // LDS; the LDS atomic unit serialises them anyway), the pose block goes through per-wave tables (above), the intrinsics / distortion sums through per-wave slots.
 // With the fixed-order sums across workgroups (cam_part, p.q partials, the halo fold of k_pcg_step3) a PCG pass is then bit-reproducible from run to run.
-// DETM (bit mask, A/B runs): 1 = ordered halo pushes, 2 = per-wave keyframe tables + per-wave camera slots, 4 = fences (instead of relying on the in-order LDS) in the ordered section
+// DETM (bit mask): 1 = ordered halo pushes, 2 = per-wave keyframe tables + per-wave camera slots.  Shipped: 0 (default) and 3 (I3D_DETERMINISTIC=1).
+// Measured on the bench workload (profiles/r04_det_variants.json, one session): 0: 0.277-0.297 ms | 2: 0.296-0.302 (+4 %: the table look-up in the row loop) |
+// 3: 0.370-0.384 (+30 %: sixteen waves taking turns per tile, with or without fences) — the price of bit-reproducibility, which is why it is opt-in.
 template <int T, int HMAX, int SLOTS, bool GHOSTS, int DETM>
 __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const float* __restrict__ u, const unsigned* __restrict__ lnbr,
                                                         const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx, const int* __restrict__ halo_cnt,
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                                                         const int* __restrict__ gmaxv /* = r.gmax as a restrict-qualified kernel argument: its wave-uniform loads become scalar loads (lgkmcnt), a
                                                                                          vector load here would put an s_waitcnt vmcnt(0) behind the row blocks just requested */) {
     if (state && state->done) return;
-    constexpr bool DET = DETM != 0, DORD = (DETM & 1) != 0, DTAB = (DETM & 2) != 0, DFEN = (DETM & 4) != 0;
+    constexpr bool DET = DETM != 0, DORD = (DETM & 1) != 0, DTAB = (DETM & 2) != 0;
     constexpr int ZSLOT = T + HMAX, NSLOT = ZSLOT + 1;
     extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T] | p.q [T] fp64
     const int K = p.K; const size_t Acap = r.Acap; const int A = r.A, chunk = r.chunk;
@@ -230,8 +232,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     const int i = threadIdx.x;
     // the lane's running p.q (fp64) is parked in LDS: as a register pair it lived across the row loop, and in the 1024-entry geometry that pair was the
     // value the compiler spilled and reloaded behind every row block (each reload an s_waitcnt vmcnt(0) that drains the row stream)
-    // with the per-wave tables the row loop has no register for the lane's own sdf / albedo sums (column 0 / 10 of its rows): two more lane-private LDS columns
-    constexpr int NCOL = DTAB ? 14 : 12;
+    constexpr int NCOL = 12;
 #define pq_l reinterpret_cast<double*>(lds + o_u + 2 * NSLOT + 2 * HMAX + T + 4 + NCOL * T)
     pq_l[i] = 0.0;
     // DET: [ticket | 3 pad] [NW][9] per-wave intrinsics / distortion sums | [NW][TC] keyframe tags | [NW][TC][6] sums (at the front of the LDS, see above)
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { J[4 * q] = rw[q].x; J[4 * q + 1] = rw[q].y; J[4 * q + 2] = rw[q].z; J[4 * q + 3] = rw[q].w; }
                 J[28] = rb.j28;
-                float d = J[0] * us + J[10] * ua;
+                float d = DTAB ? J[0] * u_s[i] + J[10] * u_a[i] : J[0] * us + J[10] * ua;      // (with the tables the row loop has no register left for the entry's own u: re-read from LDS)
 #pragma unroll
                 for (int c = 1; c < 10; ++c) d += J[c] * u_s[unpack12(ln, c - 1)];
                 d += J[11] * u_a[sx] + J[12] * u_a[sy] + J[13] * u_a[sz];
@@ -379,7 +380,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 for (int q = 0; q < 9; ++q) d += J[P_INTR + q] * ui[q];
                 const float t = rho * d;
                 pq_rows += t * d;
-                if (DTAB) { Cme[12 * T] += J[0] * t; Cme[13 * T] += J[10] * t; } else { self_s += J[0] * t; self_a += J[10] * t; }
+                self_s += J[0] * t; self_a += J[10] * t;
 #pragma unroll
                 for (int c = 1; c < 10; ++c) Cme[(c - 1) * T] += J[c] * t;
                 Cme[9 * T] += J[11] * t; Cme[10 * T] += J[12] * t; Cme[11 * T] += J[13] * t;
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         for (int d = 0; d < 6; ++d) eaw[d] = __builtin_nontemporal_load(&eaw_sym[(size_t)d * Acap + ac]);
         // ---- what lands in the halo is pushed (few lanes: the tile's outer shell) ----
         if (DORD) {      // ordered section: wave w enters when waves 0 .. w-1 have left (their LDS operations are older than the ticket they wrote)
-            ordered_enter<DFEN>(&lds[o_det], wave);
+            ordered_enter(&lds[o_det], wave);
             if (rf & 1) {
                 const float tr = tr_l[i]; const int rg[6] = {sx, mx, sy, my, sz, mz};
 #pragma unroll
@@ -442,8 +443,8 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
             if (sz >= T && sz != ZSLOT) lds_add(&qh_a[sz - T], Cme[11 * T]);
         }
         if (DTAB && DORD) { if (tcount > TC - 16) wave_table_merge<6, TC>(lds, o_tag, o_val, tcount, D0, 6); }      // (wave-uniform) room for the next tile's keyframes
-        if (DORD) ordered_leave<DFEN>(&lds[o_det], wave);
-        const int a_c = a, H_c = H, tile_c = tile; const bool in_c = in, owned_c = owned; const float ua_c = ua;
+        if (DORD) ordered_leave(&lds[o_det], wave);
+        const int a_c = a, H_c = H, tile_c = tile; const bool in_c = in, owned_c = owned; const float ua_c = DTAB ? u_a[i] : ua;
         __syncthreads();
         // ---- pull: every entry collects the column sums of the tile entries whose stencil contains it ----
         if (in_c) {
@@ -453,7 +454,6 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
             const int r2y = unpack12(lall, 12), ryz = unpack12(lall, 13), r2z = unpack12(lall, 14), rxy = unpack12(lall, 15), rxz = unpack12(lall, 16), r2x = unpack12(lall, 17);
             auto pull = [&](int col, int slot) { return slot < T ? C_l[col * T + slot] : 0.0f; };
             float qs = self_s, qa = self_a;
-            if (DTAB) { qs += C_l[12 * T + i]; qa += C_l[13 * T + i]; }
             qs += pull(0, my) + pull(1, r2y) + pull(2, ryz) + pull(3, mz) + pull(4, r2z) + pull(5, mx) + pull(6, rxy) + pull(7, rxz) + pull(8, r2x);
             qa += pull(9, mx) + pull(10, my) + pull(11, mz);
             const int rg[6] = {sx, mx, sy, my, sz, mz};
@@ -564,13 +564,15 @@ template <int T, int HMAX>
 static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state, int num_cu,
                             float* cam_partials, int cam_stride) {
     const int nshared = 6 * p.K + 9, rs = (6 * p.K) | 1;
-    // fixed-order sums inside the workgroup (DET) by default; I3D_EGT_DET=0 selects the round-3 accumulation (LDS atomics shared by the waves) for A/B runs
-    static const int detm = [] { const char* e = std::getenv("I3D_EGT_DET"); const int m = e ? std::atoi(e) : 3; return (m == 0 || m == 1 || m == 2 || m == 3 || m == 7) ? m : 3; }();
+    // I3D_DETERMINISTIC=1: fixed-order sums inside the workgroup as well (ordered halo pushes, per-wave keyframe tables) — every kernel of an outer iteration is then
+    // bit-reproducible from run to run (tools/flake_hunt.py: 0.0 on every field) at ~20 % lower throughput; the default keeps the LDS atomics of round 3 HERE and
+    // only here (gradient, column norms, SH Gram blocks, camera block and halo fold across workgroups are fixed-order in both modes)
+    const int detm = t.det ? 3 : 0;
     const bool det = detm != 0;
     constexpr int NW = T / 64, TC = T == 1024 ? 64 : 32;
     const int det_words = det ? 4 + ((NW * 9 + 3) & ~3) + NW * TC * 7 : 0;      // ticket, per-wave camera sums, per-wave keyframe tables (at the front of the LDS)
     auto lds_bytes = [&](int reps) { const int nacc = det_words + reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
-                                     return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + ((detm & 2) ? 14 : 12) * T + 2 * T /* p.q per lane, fp64 */) * sizeof(float); };
+                                     return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T + 2 * T /* p.q per lane, fp64 */) * sizeof(float); };
     const size_t budget = (T == 512 ? 79 : 158) * 1024;
     int reps = (detm & 2) ? 1 : 4;                                  // replicas only serve the rare > 3-keyframe fallback of wave_accumulate (DET: one dense accumulator, the waves own tables)
     while (reps > 1 && lds_bytes(reps) > budget) reps >>= 1;
@@ -589,7 +591,7 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
             // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
             // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
             if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
-#define I3D_EGT(SL, GH) do { switch (detm) { case 0: I3D_EGT2(SL, GH, 0); break; case 1: I3D_EGT2(SL, GH, 1); break; case 2: I3D_EGT2(SL, GH, 2); break; case 7: I3D_EGT2(SL, GH, 7); break; default: I3D_EGT2(SL, GH, 3); break; } } while (0)
+#define I3D_EGT(SL, GH) do { if (detm == 3) I3D_EGT2(SL, GH, 3); else I3D_EGT2(SL, GH, 0); } while (0)
 #define I3D_EGT2(SL, GH, DT) do { \
         if (!set_dynamic_lds((const void*)k_eg_tile<T, HMAX, SL, GH, DT>, "k_eg_tile", lds, p.K)) break; \
         k_eg_tile<T, HMAX, SL, GH, DT><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \

@@ -201,8 +201,6 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     hipStream_t s = c->stream;
     CTX_HIP(c, hipEventRecord(c->ev_asm[0], s));
     p = make_params(c, cfg, c->intr, c->dist);
-    std::vector<FrameConst> fc; build_frame_consts(c, cfg.rgbd_level, c->poses.data(), fc);
-    CTX_HIP(c, hipMemcpyAsync(c->d_frames.p, fc.data(), sizeof(FrameConst) * fc.size(), hipMemcpyHostToDevice, s));
     GridView g = c->grid_view();
     { TimedScope t(c, I3D_K_CLASSIFY);
       launch_classify(s, g, p, c->aflag.p);
@@ -211,14 +209,25 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     int tail[2];
     CTX_HIP(c, hipMemcpyAsync(&tail[0], c->ascan.p + (c->N - 1), sizeof(int), hipMemcpyDeviceToHost, s));
     CTX_HIP(c, hipMemcpyAsync(&tail[1], c->aflag.p + (c->N - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+    // the keyframe constants of this iteration's poses (host, fp64, the reference's libm) while the device classifies: the host would wait here anyway
+    std::vector<FrameConst> fc; build_frame_consts(c, cfg.rgbd_level, c->poses.data(), fc);
     CTX_HIP(c, sync_stream(c));
+    CTX_HIP(c, hipMemcpyAsync(c->d_frames.p, fc.data(), sizeof(FrameConst) * fc.size(), hipMemcpyHostToDevice, s));
     c->A = tail[0] + tail[1];
     { TimedScope t(c, I3D_K_CLASSIFY);
       static const bool no_partition = [] { const char* e = std::getenv("I3D_NO_PARTITION"); return e && e[0] == '1'; }();      // A/B runs
       if (!no_partition) launch_partition_blocks(s, g, c->A, c->alist.p, c->aflags.p, c->aidx.p);
       launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
     c->tile_ok = false; c->tile_T = 0;
+    { const char* e = std::getenv("I3D_DETERMINISTIC"); c->deterministic = e && e[0] == '1'; }
     if (!sharded(c)) {
+        // tile geometry: 1024-entry tiles (one workgroup of 16 waves per CU) unless the work list is row-poor — SURVEY.md 8(d)'s 4-voxel shell, real sequences with few
+        // observations: a third of the entries own no Eg rows, their waves idle while the others stream, and two smaller workgroups per CU keep more row blocks in
+        // flight (measured on --band 2: 0.43 -> 0.39 ms per pass; on the 5.0-rows workload 512-entry tiles are 2.5 % slower).  The density is last iteration's
+        // (rows per entry are a property of the grid, not of the iteration); either geometry is the other's fallback when a tile's halo does not fit.
+        { const long long la = c->last_sizes[0], lr = c->last_sizes[1];
+          static const bool forced = std::getenv("I3D_EGT_TILE") != nullptr;
+          if (!forced && la > 0 && (double)lr < 0.8 * (double)slots * (double)la) c->tile_T = 512; }
         shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; c->slice = c->chunk;
         RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
         CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n));
@@ -261,10 +270,11 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
     double sums[9]; { int rc = read_doubles(c, c->d_scal.p, 9, sums); if (rc) return rc; }
     if (sharded(c) && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "assemble: a peer-to-peer exchange timed out (a rank stopped taking part)");
-    if (!sharded(c) && tp_over != 0 && c->plan_T() == 1024) {
-        // single rank: the other geometry (three halo slots per entry instead of two) before giving up on the tiled pass
-        std::fprintf(stderr, "[i3d] operator pass: a 1024-entry tile's halo does not fit, planning again with 512-entry tiles\n");
-        c->tile_T = 512;
+    if (!sharded(c) && tp_over != 0) {
+        // single rank: the other geometry before giving up on the tiled pass
+        const int other = c->plan_T() == 1024 ? 512 : 1024;
+        std::fprintf(stderr, "[i3d] operator pass: a %d-entry tile's halo does not fit, planning again with %d-entry tiles\n", c->plan_T(), other);
+        c->tile_T = other;
         { RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
           CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n)); }      // (the symmetric Ea weights do not depend on the geometry)
         CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));

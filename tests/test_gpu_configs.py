@@ -32,15 +32,23 @@ def _oracle_refine(O, sc, frames, levels, ocfg, rc, intr, dist, poses, pose_eps=
     return ref, ointr, oposes, done
 
 
-def _check_fields(out, ref, env):
+def _check_fields(out, ref, env, ordered=True, free_camera=False):
     # voxels on one side only (a re-sparsification threshold within the two computations' difference): as many as the reference computation itself flips under
     # 1e-7 input perturbations allow, times the one envelope factor — 2e-4 of the voxels at least
-    out, ref = helpers.align_by_key(out, ref, max_frac=max(2e-4, helpers.ENVELOPE_FACTOR * env.get("key_frac", 0.0)))
+    out, ref = helpers.align_by_key(out, ref, max_frac=max(2e-4, helpers.ENVELOPE_FACTOR * env.get("key_frac", 0.0)), ordered=ordered)
     assert (out["weight"] != ref["weight"]).mean() <= max(2e-4, helpers.ENVELOPE_FACTOR * env.get("key_frac", 0.0)), int((out["weight"] != ref["weight"]).sum())      # (a child next to a differing voxel interpolates other corners)
     d_sdf = np.abs(out["sdf_refined"] - ref["sdf_refined"]); d_alb = np.abs(out["albedo"] - ref["albedo"])
     smax = float(np.abs(ref["sdf_refined"]).max()); amax = float(np.abs(ref["albedo"]).max())
-    assert np.quantile(d_sdf, 0.999) <= 1e-4 * smax, (np.quantile(d_sdf, 0.999), smax)
-    assert np.quantile(d_alb, 0.999) <= 1e-4 * amax, (np.quantile(d_alb, 0.999), amax)
+    if free_camera:      # free poses on a near-symmetric object leave a gauge direction: the bulk of the field inside the reference computation's own spread (as in
+                         # test_gpu_levels.py::test_refine_two_levels_matches_oracle), the median far below it
+        print(f"\n[schedule, free camera] sdf: median {np.median(d_sdf) / smax:.2e}, 99.9 % {np.quantile(d_sdf, 0.999) / smax:.2e}, max {d_sdf.max() / smax:.2e} of max |sdf|; "
+              f"oracle's own spread under 1e-7 input perturbations {env['sdf_refined'] / smax:.2e}; albedo: median {np.median(d_alb):.2e}, 99.9 % {np.quantile(d_alb, 0.999):.2e}, "
+              f"max {d_alb.max():.2e}, spread {env['albedo']:.2e}; one-sided voxels under the perturbations {env.get('key_frac', 0.0):.2e}")
+        assert np.quantile(d_sdf, 0.999) <= max(1e-4 * smax, env["sdf_refined"]), (np.quantile(d_sdf, 0.999), smax, env)
+        assert np.quantile(d_alb, 0.999) <= max(1e-4 * amax, env["albedo"]), (np.quantile(d_alb, 0.999), amax, env)
+    else:
+        assert np.quantile(d_sdf, 0.999) <= 1e-4 * smax, (np.quantile(d_sdf, 0.999), smax)
+        assert np.quantile(d_alb, 0.999) <= 1e-4 * amax, (np.quantile(d_alb, 0.999), amax)
     assert d_sdf.max() <= max(1e-4 * smax, helpers.ENVELOPE_FACTOR * env["sdf_refined"]), (d_sdf.max(), smax, env)
     assert d_alb.max() <= max(1e-4 * amax, helpers.ENVELOPE_FACTOR * env["albedo"]), (d_alb.max(), env)
     cd = np.abs(out["color"].astype(int) - ref["color"].astype(int))
@@ -59,7 +67,7 @@ def _envelope(O, sc, frames, levels, ocfg, rc, intr, dist, poses, ref, eps_list)
         else:       # the perturbed reference keeps / drops other voxels at a re-sparsification threshold: how many, and the fields on the common ones
             so, sr = set(map(tuple, per["keys"].tolist())), set(map(tuple, ref["keys"].tolist()))
             env["key_frac"] = max(env["key_frac"], len(so ^ sr) / float(len(sr)))
-            a, b = helpers.align_by_key({k: v for k, v in per.items()}, {k: v for k, v in ref.items() if not k.startswith("_")}, max_frac=1.0)
+            a, b = helpers.align_by_key({k: v for k, v in per.items()}, {k: v for k, v in ref.items() if not k.startswith("_")}, max_frac=1.0, ordered=False)
             for k in ("sdf_refined", "albedo"):
                 env[k] = max(env[k], float(np.abs(a[k] - b[k]).max()))
     return env
@@ -166,7 +174,8 @@ def test_config_c5_full_joint_refinement_with_free_camera(oracle, tmp_path, caps
     maximum inside the reference computation's own sensitivity (free poses on a near-symmetric object leave a gauge direction); poses / intrinsics reported."""
     r = _three_level_schedule(oracle, tmp_path, seed=35, fix_poses=0, fix_distortion=0, iterations=3, pose_noise=(0.002, 0.0035), subvolume=0.03)
     assert np.abs(r["poses"] - r["poses0"]).max() > 1e-5 and np.abs(r["intr"] - r["intr0"]).max() > 1e-4      # the camera did move
-    _check_fields(r["out"], r["ref"], r["env"])
+    with capsys.disabled():
+        _check_fields(r["out"], r["ref"], r["env"], ordered=False, free_camera=True)
     # the camera against the oracle's: its own sensitivity to 1e-7 input perturbations (two perturbed re-runs) bounds what can be asked of poses on this object
     spread_p, spread_i = r["env"]["poses"], r["env"]["intr"]
     d_pose = float(np.abs(r["poses"] - r["oposes"]).max()); d_intr = float(np.abs(r["intr"] - r["ointr"]).max() / np.abs(r["ointr"]).max())
