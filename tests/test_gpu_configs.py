@@ -166,12 +166,16 @@ def test_config_c3_three_level_schedule_through_the_app(oracle, tmp_path):
     assert np.abs(r["intr"] - r["ointr"]).max() <= 1e-4 * np.abs(r["ointr"]).max(), (r["intr"], r["ointr"])
 
 
-def test_config_c5_full_joint_refinement_with_free_camera(oracle, tmp_path, capsys):
+def test_config_c5_full_joint_refinement_with_free_camera(oracle, tmp_path, capsys, monkeypatch):
     """BASELINE.json configs[4] at test size: the FULL joint problem — SDF + albedo + spatially varying SH + poses + intrinsics + distortion, every switch of the
     shipped data/intrinsic3d.yml (fix_poses 0, fix_intrinsics 0, fix_distortion 0; 3 grid levels x (3, 1, 1) pyramid levels; subvolume_size_sh 0.2 m scaled to the
     8 cm object: 0.03 m) — from a dataset folder with noisy input poses (2 mm / 0.2 deg) through apps/app_intrinsic3d, against oracle.refine (Intrinsic3D::refine,
     refinement/intrinsic3d.cpp:229-290; Optimizer::optimize with the camera blocks free, optimizer.cpp:296-306).  Fields by key: 99.9 % quantile <= 1e-4, the
     maximum inside the reference computation's own sensitivity (free poses on a near-symmetric object leave a gauge direction); poses / intrinsics reported."""
+    # Run in the bit-reproducible mode (I3D_DETERMINISTIC=1, inherited by the application's process): on this ill-conditioned problem two runs of the DEFAULT mode
+    # (fp32 LDS atomics inside the operator pass) end 1e-4 apart in the intrinsics — measured — which is the comparison between the application and the in-process
+    # flow below, not the parity with the oracle
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1")
     r = _three_level_schedule(oracle, tmp_path, seed=35, fix_poses=0, fix_distortion=0, iterations=3, pose_noise=(0.002, 0.0035), subvolume=0.03)
     assert np.abs(r["poses"] - r["poses0"]).max() > 1e-5 and np.abs(r["intr"] - r["intr0"]).max() > 1e-4      # the camera did move
     with capsys.disabled():
