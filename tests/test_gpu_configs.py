@@ -52,11 +52,13 @@ def _check_fields(out, ref, env, ordered=True, free_camera=False):
     assert d_sdf.max() <= max(1e-4 * smax, helpers.ENVELOPE_FACTOR * env["sdf_refined"]), (d_sdf.max(), smax, env)
     assert d_alb.max() <= max(1e-4 * amax, helpers.ENVELOPE_FACTOR * env["albedo"]), (d_alb.max(), env)
     cd = np.abs(out["color"].astype(int) - ref["color"].astype(int))
-    assert (cd > 1).mean() < 1e-3                                             # 8-bit truncation of colours computed from ~1e-7-different geometry
+    # 8-bit truncation of colours computed from ~1e-7-different geometry; with a free camera the keyframe poses themselves differ inside the envelope and
+    # the recolourisation samples the images elsewhere: as many components as the oracle's own perturbed runs change, times the one factor
+    assert (cd > 1).mean() < max(1e-3, helpers.ENVELOPE_FACTOR * env.get("color_frac", 0.0)), ((cd > 1).mean(), env.get("color_frac"))
 
 
 def _envelope(O, sc, frames, levels, ocfg, rc, intr, dist, poses, ref, eps_list):
-    env = dict(sdf_refined=0.0, albedo=0.0, key_frac=0.0, poses=0.0, intr=0.0)
+    env = dict(sdf_refined=0.0, albedo=0.0, key_frac=0.0, poses=0.0, intr=0.0, color_frac=0.0)
     for eps in eps_list:
         per, pintr, pposes, _ = _oracle_refine(O, sc, frames, levels, ocfg, rc, intr, dist, poses, pose_eps=eps)
         env["poses"] = max(env["poses"], float(np.abs(pposes - ref["_poses"]).max())) if "_poses" in ref else env["poses"]
@@ -64,12 +66,14 @@ def _envelope(O, sc, frames, levels, ocfg, rc, intr, dist, poses, ref, eps_list)
         if per["keys"].shape == ref["keys"].shape and np.array_equal(per["keys"], ref["keys"]):
             for k in ("sdf_refined", "albedo"):
                 env[k] = max(env[k], float(np.abs(per[k] - ref[k]).max()))
+            env["color_frac"] = max(env["color_frac"], float((np.abs(per["color"].astype(int) - ref["color"].astype(int)) > 1).mean()))
         else:       # the perturbed reference keeps / drops other voxels at a re-sparsification threshold: how many, and the fields on the common ones
             so, sr = set(map(tuple, per["keys"].tolist())), set(map(tuple, ref["keys"].tolist()))
             env["key_frac"] = max(env["key_frac"], len(so ^ sr) / float(len(sr)))
             a, b = helpers.align_by_key({k: v for k, v in per.items()}, {k: v for k, v in ref.items() if not k.startswith("_")}, max_frac=1.0, ordered=False)
             for k in ("sdf_refined", "albedo"):
                 env[k] = max(env[k], float(np.abs(a[k] - b[k]).max()))
+            env["color_frac"] = max(env["color_frac"], float((np.abs(a["color"].astype(int) - b["color"].astype(int)) > 1).mean()))
     return env
 
 
@@ -171,7 +175,10 @@ def test_config_c5_full_joint_refinement_with_free_camera(oracle, tmp_path, caps
     shipped data/intrinsic3d.yml (fix_poses 0, fix_intrinsics 0, fix_distortion 0; 3 grid levels x (3, 1, 1) pyramid levels; subvolume_size_sh 0.2 m scaled to the
     8 cm object: 0.03 m) — from a dataset folder with noisy input poses (2 mm / 0.2 deg) through apps/app_intrinsic3d, against oracle.refine (Intrinsic3D::refine,
     refinement/intrinsic3d.cpp:229-290; Optimizer::optimize with the camera blocks free, optimizer.cpp:296-306).  Fields by key: 99.9 % quantile <= 1e-4, the
-    maximum inside the reference computation's own sensitivity (free poses on a near-symmetric object leave a gauge direction); poses / intrinsics reported."""
+    maximum inside the reference computation's own sensitivity (free poses on a near-symmetric object leave a gauge direction); poses / intrinsics reported.
+    Measured: on this 4 cm synthetic sphere the free-camera schedule WANDERS — the oracle's own poses move 5e-2 and its fields 4e-2 of max |sdf| when its input poses
+    are perturbed by 1e-7 (every scene variant tried: more bumps, more keyframes, no pose noise) — so this test shows that the whole pipeline agrees with the oracle
+    as far as the oracle agrees with itself (median 2e-4, 99.9 % 8e-3 of max |sdf|); the 1e-4 statements with free poses are the single-level tests."""
     # Run in the bit-reproducible mode (I3D_DETERMINISTIC=1, inherited by the application's process): on this ill-conditioned problem two runs of the DEFAULT mode
     # (fp32 LDS atomics inside the operator pass) end 1e-4 apart in the intrinsics — measured — which is the comparison between the application and the in-process
     # flow below, not the parity with the oracle
