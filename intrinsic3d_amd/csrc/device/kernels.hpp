@@ -105,7 +105,7 @@ struct TilePlan {                   // built once per outer iteration by launch_
 int    tile_plan_T();                      // default geometry (I3D_EGT_TILE): entries per tile
 int    tile_plan_tiles(int A);             // ... tiles of A entries, halo slots per tile
 int    tile_plan_hmax();
-inline int tile_plan_hmax_of(int T) { return T == 1024 ? 2048 : (T == 512 ? 1536 : 768); }      // 1024: 2 halo slots per entry (one workgroup per CU) | 512: 3 (two per CU) | 256: 3 (four per CU; small rank shares)
+inline int tile_plan_hmax_of(int T) { return T == 1024 ? 2048 : 1536; }
 inline int tile_plan_tiles_of(int A, int T) { return (A + T - 1) / T; }
 size_t tile_plan_temp_bytes(int ntiles);
 hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, size_t temp_bytes);

@@ -543,7 +543,7 @@ hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, s
     // tests of the overflow handling: pretend the 512-entry geometry has fewer halo slots than it has (the 1024-entry fallback is not limited)
     const int limit512 = [] { const char* s = std::getenv("I3D_EGT_HMAX_LIMIT"); return s ? std::atoi(s) : 0; }();      // (read per plan: tests set it for one run)
     const int limit1024 = [] { const char* s = std::getenv("I3D_EGT_HMAX_LIMIT_1024"); return s ? std::atoi(s) : 0; }();
-    const int lim = t.T <= 512 ? limit512 : limit1024;      // (the small-tile knob covers both small geometries: 256 -> 512 -> 1024 is the sharded fallback chain)
+    const int lim = t.T == 512 ? limit512 : limit1024;
     const int hlimit = (lim > 0 && lim < t.hmax) ? lim : t.hmax;
     const bool all = t.tile_first == 0 && t.ntiles_own >= ntiles;
     if (!all) { e = hipMemsetAsync(t.halo_idx, 0x7f, sizeof(int) * (size_t)n, st); if (e != hipSuccess) return e;
@@ -573,11 +573,11 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
     const int det_words = det ? 4 + ((NW * 9 + 3) & ~3) + NW * TC * 7 : 0;      // ticket, per-wave camera sums, per-wave keyframe tables (at the front of the LDS)
     auto lds_bytes = [&](int reps) { const int nacc = det_words + reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
                                      return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T + 2 * T /* p.q per lane, fp64 */) * sizeof(float); };
-    const size_t budget = (T == 1024 ? 158 : (T == 512 ? 79 : 39)) * 1024;      // one / two / four workgroups per CU
+    const size_t budget = (T == 512 ? 79 : 158) * 1024;
     int reps = (detm & 2) ? 1 : 4;                                  // replicas only serve the rare > 3-keyframe fallback of wave_accumulate (DET: one dense accumulator, the waves own tables)
     while (reps > 1 && lds_bytes(reps) > budget) reps >>= 1;
     const size_t lds = lds_bytes(reps);
-    int per_cu = lds <= budget ? (T == 1024 ? 1 : (T == 512 ? 2 : 4)) : 1;
+    int per_cu = (T == 512 && lds <= budget) ? 2 : 1;
     { static int knob = -1; if (knob < 0) { const char* e = std::getenv("I3D_EGT_WG_PER_CU"); knob = e ? std::atoi(e) : 0; } if (knob > 0) per_cu = knob; }
     // tiles in units of T: the plan counts tiles of tp_T() == T
     int written = 0;
@@ -615,8 +615,7 @@ int launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TileP
     static int num_cu = 0;
     if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     if (t.T == 1024) return launch_eg_tile_t<1024, 2048>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
-    if (t.T == 512) return launch_eg_tile_t<512, 1536>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
-    return launch_eg_tile_t<256, 768>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
+    return launch_eg_tile_t<512, 1536>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
 }
 // halo accumulators of all tiles -> the per-entry accumulators (sorted by target entry at plan time; timed as its own category)
 void launch_halo_fold(hipStream_t st, RowView r, TilePlan t, float* qacc, const PcgState* state) {

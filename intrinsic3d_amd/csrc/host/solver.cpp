@@ -55,8 +55,8 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8)); CTX_HIP(c, c->aux_part.alloc((size_t)AUX_PART_ROWS * aux_part_stride(c->K)));
     { // sized for BOTH tile geometries: the 512-entry one needs the most slots on large grids (3 per entry; 1024: 2), but a grid of <= 512 entries is ONE
       // 1024-entry tile with 2048 halo slots against one 512-entry tile with 1536
-      const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 256);
-      size_t nh = 0; for (int T : {256, 512, 1024}) nh = std::max(nh, (size_t)tile_plan_tiles_of((int)Acap, T) * (size_t)tile_plan_hmax_of(T));
+      const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512);
+      const size_t nh = std::max(nt * (size_t)tile_plan_hmax_of(512), (size_t)tile_plan_tiles_of((int)Acap, 1024) * (size_t)tile_plan_hmax_of(1024));
       CTX_HIP(c, c->tp_lnbr.alloc(Acap * LNBR_WORDS)); CTX_HIP(c, c->tp_eaw.alloc(Acap * 6)); CTX_HIP(c, c->tp_halo_idx.alloc(nh)); CTX_HIP(c, c->tp_halo_cnt.alloc(nt)); CTX_HIP(c, c->tp_iota.alloc(nh));
       CTX_HIP(c, c->tp_ext_e.alloc(nh)); CTX_HIP(c, c->tp_ext_pos.alloc(nh)); CTX_HIP(c, c->tp_qh.alloc(2 * nh)); CTX_HIP(c, c->tp_overflow.alloc(1));
       CTX_HIP(c, c->tp_ext_off.alloc(Acap + (size_t)SHARD_ALIGN * ((c->comm ? c->comm->world : 1) + 1) + 8));      // chunk + 1 offsets (chunk >= A, a multiple of the slice alignment)
@@ -74,7 +74,7 @@ static int alloc_rows(i3d_context* c, int slots) {
         CTX_HIP(c, c->need_mask.alloc(Acap)); CTX_HIP(c, c->halo_items.alloc(cap)); CTX_HIP(c, c->halo_sorted.alloc(cap)); CTX_HIP(c, c->halo_count.alloc(1));
         CTX_HIP(c, c->halo_send_idx.alloc(cap)); CTX_HIP(c, c->halo_recv_idx.alloc(cap)); CTX_HIP(c, c->halo_send_peer.alloc(cap)); CTX_HIP(c, c->halo_recv_peer.alloc(cap)); CTX_HIP(c, c->halo_offs.alloc(2 * P2P_MAX_RANKS)); CTX_HIP(c, c->halo_send_buf.alloc(2 * cap)); CTX_HIP(c, c->halo_recv_buf.alloc(2 * cap));
         CTX_HIP(c, c->halo_temp.alloc(halo_sort_temp_bytes((int)cap)));
-        const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 256) + 1; CTX_HIP(c, c->tile_flag.alloc(nt)); CTX_HIP(c, c->ghost_tiles.alloc(nt));
+        const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512) + 1; CTX_HIP(c, c->tile_flag.alloc(nt)); CTX_HIP(c, c->ghost_tiles.alloc(nt));
     }
     CTX_HIP(c, c->d_scal.alloc(32)); CTX_HIP(c, c->d_xshared.alloc((size_t)6 * c->K + 9)); CTX_HIP(c, c->d_xcshared.alloc((size_t)6 * c->K + 9));
     CTX_HIP(c, c->d_pcg.alloc(1)); CTX_HIP(c, c->d_pcg2.alloc(2));
@@ -237,13 +237,9 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         // other geometry before anything is built on the plan.  First choice: 1024-entry tiles (2048 halo slots; a third fewer tile boundaries, one
         // workgroup per CU) when a rank's share fills at least two rounds of them, else 512-entry tiles (1536 halo slots, two workgroups per CU): a small
         // share balances better over twice the tiles.  Every rank derives the choice from the replicated work list.
-        // One round of resident workgroups holds 256 x 1024 = 512 x 512 = 1024 x 256 entries whatever the geometry; what differs is the price of the LAST, partly
-        // filled round — one tile time, i.e. proportional to the tile size: a share of 1.09 rounds (8 ranks on the 8 M-voxel bench) pays 2 x 32 us with 1024-entry
-        // tiles, ~2 x 16 with 512, ~32 + 8 with 256.  So: 256-entry tiles (four workgroups per CU) for shares below two rounds, 512 below four, else 1024.
-        const long long share = c->A / c->comm->world, round_entries = 256ll * 1024;
-        const int first_T = share >= 4 * round_entries ? 1024 : (share >= 2 * round_entries ? 512 : 256);
+        const int first_T = (c->A / c->comm->world >= 2 * 256 * 1024) ? 1024 : 512;
         c->tile_T = first_T;
-        for (int attempt = 0; attempt < 3; ++attempt) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
             int rc = shard_plan(c); if (rc) return rc;
             { RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
               CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n)); }
@@ -251,8 +247,8 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
             rc = allreduce(c, c->d_scal.p + 20, 1); if (rc) return rc;
             double over = 0.0; rc = read_doubles(c, c->d_scal.p + 20, 1, &over); if (rc) return rc;
             if (over == 0.0) break;
-            if (attempt == 2 || (attempt == 1 && first_T != 256)) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: a tile of the operator pass reaches more foreign entries than any tile geometry has halo slots");
-            const int other = c->plan_T() == 256 ? 512 : (c->plan_T() == 512 ? 1024 : 512);
+            if (attempt == 1) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: a tile of the operator pass reaches more foreign entries than either tile geometry has halo slots");
+            const int other = c->plan_T() == 512 ? 1024 : 512;
             std::fprintf(stderr, "[i3d] sharded operator pass: a %d-entry tile's halo does not fit, planning again with %d-entry tiles\n", c->plan_T(), other);
             c->tile_T = other;
         }
