@@ -237,6 +237,8 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         // other geometry before anything is built on the plan.  First choice: 1024-entry tiles (2048 halo slots; a third fewer tile boundaries, one
         // workgroup per CU) when a rank's share fills at least two rounds of them, else 512-entry tiles (1536 halo slots, two workgroups per CU): a small
         // share balances better over twice the tiles.  Every rank derives the choice from the replicated work list.
+        // (256-entry tiles for shares below two rounds were built and measured in round 4: the operator gains 2 us per pass, the halo fold loses more —
+        // profiles/r04_share_tile_ab.json — removed.)
         const int first_T = (c->A / c->comm->world >= 2 * 256 * 1024) ? 1024 : 512;
         c->tile_T = first_T;
         for (int attempt = 0; attempt < 2; ++attempt) {
