@@ -486,6 +486,7 @@ def _main():
         dist.barrier()
     dt = time.perf_counter() - t0
     stream_syncs = ctx.debug_counters()["stream_syncs"] - syncs0
+    cull_pairs, cull_skipped = ctx.debug_cull_stats()       # observation pass: (64-voxel group, keyframe) pairs of the last iteration, and how many were culled
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     t0 = time.time(); _ = ctx.get_grid(); _ = ctx.get_camera(); t_download = time.time() - t0          # what a host-buffer caller reads back
@@ -558,6 +559,7 @@ def _main():
             "cost": [float(stats[0].cost_initial), float(stats[-1].cost_final)],
             # host <-> device round trips: the trust-region loop runs on the device (lm_kernels.hip), the host polls mapped memory instead of draining the stream
             "stream_syncs_per_step": stream_syncs / float(args.steps),
+            "observe_culling": {"group_keyframe_pairs": cull_pairs, "culled": cull_skipped, "fraction": (cull_skipped / float(cull_pairs)) if cull_skipped >= 0 and cull_pairs else None},
             # the boundary also accepts host buffers (i3d_set_grid / i3d_set_frames / i3d_optimize_host): the same run with the one-off upload
             # (voxels + keyframe pyramids over PCIe, hash / neighbour-table build) and the read-back of the refined fields counted in.  Never `value`.
             "host_buffers_inclusive": {"upload_and_grid_build_s": t_upload, "download_s": t_download,

@@ -337,6 +337,10 @@ int i3d_debug_jtj_apply(i3d_context* ctx, const double* x, double* y);
 /* counters of the context since its creation: stream synchronisations of the solver path (assemble + the LM loop).  The trust-region loop of
  * NLSSolver::solve (nls_solver.cpp:296-337) runs on the device; a Gauss-Newton iteration costs a handful of them, not two per LM attempt. */
 int i3d_debug_counters(i3d_context* ctx, int64_t* stream_syncs);
+/* the conservative culling in front of the observation pass (SDFColorization::computeObservation is evaluated per (voxel, keyframe), colorization.cpp:215-315;
+ * the device skips (group of 64 voxels, keyframe) pairs no voxel of which can be observed): pairs of the last assemble and how many were skipped.  culled = -1 when
+ * culling is off (I3D_NO_CULL=1). */
+int i3d_debug_cull_stats(i3d_context* ctx, int64_t* pairs, int64_t* culled);
 
 #ifdef __cplusplus
 }

@@ -76,7 +76,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_comm_transport", "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_timing_get_work_ex", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_map_order", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
-           "i3d_debug_normal_eq", "i3d_debug_jtj_apply", "i3d_debug_counters"]
+           "i3d_debug_normal_eq", "i3d_debug_jtj_apply", "i3d_debug_counters", "i3d_debug_cull_stats"]
 
 _lib = None
 
@@ -137,6 +137,7 @@ def load():
     L.i3d_debug_normal_eq.restype = i32; L.i3d_debug_normal_eq.argtypes = [vp, vp, vp, C.POINTER(f64)]
     L.i3d_debug_jtj_apply.restype = i32; L.i3d_debug_jtj_apply.argtypes = [vp, vp, vp]
     L.i3d_debug_counters.restype = i32; L.i3d_debug_counters.argtypes = [vp, vp]
+    L.i3d_debug_cull_stats.restype = i32; L.i3d_debug_cull_stats.argtypes = [vp, vp, vp]
     L.i3d_set_grid_from_tsdf_records.restype = i32; L.i3d_set_grid_from_tsdf_records.argtypes = [vp, f32, i64, vp, vp, vp, vp]
     L.i3d_recompute_colors.restype = i32; L.i3d_recompute_colors.argtypes = [vp, f32, i32]
     L.i3d_clear_outside_thin_shell.restype = i32; L.i3d_clear_outside_thin_shell.argtypes = [vp, f64, C.POINTER(i64)]
@@ -467,6 +468,12 @@ class Context:
         n = C.c_int64(0)
         self._check(self.L.i3d_debug_counters(self.h, C.byref(n)), "i3d_debug_counters")
         return {"stream_syncs": int(n.value)}
+
+    def debug_cull_stats(self):
+        """(group, keyframe) pairs of the last assemble and how many the observation pass skipped (-1: culling off)."""
+        a = C.c_int64(0); b = C.c_int64(0)
+        self._check(self.L.i3d_debug_cull_stats(self.h, C.byref(a), C.byref(b)), "i3d_debug_cull_stats")
+        return int(a.value), int(b.value)
 
     def debug_jtj_apply(self, x):
         x = np.ascontiguousarray(x, np.float64); y = np.zeros_like(x)

@@ -27,7 +27,13 @@ void launch_update_fields(hipStream_t st, int N, const int* rank, const double* 
                           double* x_sdf, double* x_alb, float* f_sdf, float* f_alb, uchar4* color);
 
 // ---- observe.hip ------------------------------------------------------------------------------------------
-void launch_observe(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames);
+void launch_observe(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, const unsigned* cull_mask = nullptr, bool prefilter = false);
+// cull_kernels.hip: per-keyframe 8x8-block depth ranges; bounding spheres of the 64-entry groups of the compute list and their keyframe cull masks ([group][ceil(K/32)])
+constexpr int CULL_BLOCK = 8, CULL_MAX_LEVELS = 12;          // depth-range pyramid: 8 x 8 pixel blocks at level 0, 2 x 2 reductions above
+struct CullPyramid { int levels, cells; int bw[CULL_MAX_LEVELS], bh[CULL_MAX_LEVELS], off[CULL_MAX_LEVELS]; };     // cells = float2 entries per keyframe (all levels)
+CullPyramid cull_pyramid(int w, int h);
+void launch_depth_blocks(hipStream_t st, const FrameConst* frames, int K, int w, int h, float2* out);
+void launch_group_cull(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, const float2* dblocks, float4* bounds, unsigned* mask);
 
 // ---- build.hip --------------------------------------------------------------------------------------------
 // with_jacobian: fills res/J/roww/rowfree + regulariser flags (assembly).  Otherwise evaluates the cost of the rows

@@ -191,4 +191,18 @@ int i3d_debug_counters(i3d_context* c, int64_t* stream_syncs) {
     return I3D_OK;
 }
 
+int i3d_debug_cull_stats(i3d_context* c, int64_t* pairs, int64_t* culled) {
+    if (!c || !pairs || !culled) return I3D_ERR_INVALID_ARGUMENT;
+    if (!c->cull_mask.p || c->nC <= 0) return ctx_fail(c, I3D_ERR_STATE, "i3d_debug_cull_stats: nothing assembled");
+    const size_t ngroups = ((size_t)c->nC + 63) / 64, ncw = ((size_t)c->K + 31) / 32;
+    *pairs = (int64_t)(ngroups * (size_t)c->K);
+    if (!c->cull_on) { *culled = -1; return I3D_OK; }
+    std::vector<unsigned> m(ngroups * ncw);
+    CTX_HIP(c, hipSetDevice(c->device));
+    CTX_HIP(c, hipMemcpy(m.data(), c->cull_mask.p, m.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    int64_t n = 0; for (unsigned w : m) n += __builtin_popcount(w);
+    *culled = n;
+    return I3D_OK;
+}
+
 }  // extern "C"

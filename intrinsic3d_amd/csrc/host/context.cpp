@@ -220,7 +220,7 @@ int i3d_set_frames(i3d_context* c, int32_t K, int32_t levels, const int32_t* wid
                    const float* const* lum, const float* const* depth, const uint8_t* const* bgr) {
     if (!c || K <= 0 || levels <= 0 || !widths || !heights || !lum || !depth) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_frames: bad arguments");
     CTX_HIP(c, hipSetDevice(c->device));
-    c->have_frames = false; c->K = K; c->levels = levels;
+    c->have_frames = false; c->K = K; c->levels = levels; c->cull_level = -1;
     c->slots = 0; c->assembled = false;            // K sizes the camera blocks and solver vectors: force alloc_rows() to run again
     c->fw.assign(widths, widths + levels); c->fh.assign(heights, heights + levels);
     c->lum.clear(); c->depth.clear(); c->bgr.clear();

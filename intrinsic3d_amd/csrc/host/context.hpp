@@ -85,6 +85,9 @@ struct i3d_context {
     i3d::DevBuf<int> obs_frame, anbr; i3d::DevBuf<float> obs_w, ea_w, C, treg;
     i3d::DevBuf<float4> rows; i3d::DevBuf<float2> row_wr;
     i3d::DevBuf<uint8_t> aflags, nrows, regflags, ea_free; i3d::DevBuf<int> gmax;
+    // culling in front of the observation pass (cull_kernels.hip): 8x8-block depth ranges of every keyframe at level cull_level (-1: not built), bounding spheres and
+    // keyframe masks of the 64-entry groups of the compute list
+    i3d::DevBuf<float2> cull_blocks; i3d::DevBuf<float4> cull_bounds; i3d::DevBuf<unsigned> cull_mask; int cull_level = -1; bool cull_on = false;
     // tiled operator pass (tile_pass.hip): plan of the current work list
     i3d::DevBuf<float> aux_part;      // one float row of camera totals per workgroup of the gradient / column-norm passes (summed in a fixed order)
     i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_ext_off, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw, cam_part;

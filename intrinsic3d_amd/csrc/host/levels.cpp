@@ -138,7 +138,7 @@ int i3d_set_frames_rgbd(i3d_context* c, int32_t K, int32_t levels, int32_t width
     if ((width >> (levels - 1)) < 1 || (height >> (levels - 1)) < 1) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_frames_rgbd: more levels than the image size allows");
     CTX_HIP(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    c->have_frames = false; c->K = K; c->levels = levels;
+    c->have_frames = false; c->K = K; c->levels = levels; c->cull_level = -1;
     c->slots = 0; c->assembled = false;            // K sizes the camera blocks and solver vectors: force alloc_rows() to run again
     c->fw.resize(levels); c->fh.resize(levels);
     for (int l = 0; l < levels; ++l) { c->fw[l] = l ? c->fw[l - 1] / 2 : width; c->fh[l] = l ? c->fh[l - 1] / 2 : height; }

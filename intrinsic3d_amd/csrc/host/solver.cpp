@@ -51,6 +51,7 @@ static int alloc_rows(i3d_context* c, int slots) {
     { const size_t nrow = ((Acap + 63) / 64) * 64 * (size_t)slots;
       CTX_HIP(c, c->rows.alloc(nrow / 64 * ROW_BLOCK_F4)); CTX_HIP(c, c->row_wr.alloc(nrow)); }
     CTX_HIP(c, c->aflags.alloc(Acap)); CTX_HIP(c, c->nrows.alloc(Acap)); CTX_HIP(c, c->gmax.alloc(Acap / 64 + 2)); CTX_HIP(c, c->anbr.alloc(Acap * NUM_NBR));
+    CTX_HIP(c, c->cull_bounds.alloc(Acap / 64 + 2)); CTX_HIP(c, c->cull_mask.alloc((Acap / 64 + 2) * (size_t)((c->K + 31) / 32)));
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8)); CTX_HIP(c, c->aux_part.alloc((size_t)AUX_PART_ROWS * aux_part_stride(c->K)));
     { // sized for BOTH tile geometries: the 512-entry one needs the most slots on large grids (3 per entry; 1024: 2), but a grid of <= 512 entries is ONE
@@ -258,7 +259,17 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         CTX_HIP(c, hipMemsetAsync(c->nrows.p, 0, (size_t)c->A, s)); CTX_HIP(c, hipMemsetAsync(c->regflags.p, 0, (size_t)c->A, s));
     }
     RowView r = c->row_view();
-    { TimedScope t(c, I3D_K_OBSERVE); launch_observe(s, g, r, p, c->d_frames.p); }
+    { TimedScope t(c, I3D_K_OBSERVE);
+      // conservative (group of 64 entries, keyframe) culling: the depth-range pyramid once per keyframe set and level, spheres and masks per iteration
+      // I3D_NO_CULL (A/B runs and the with / without test; read at every assemble): 1 = neither, 2 = no group masks, 3 = no weight-bound prefilter
+      const char* e = std::getenv("I3D_NO_CULL"); const char mode = e ? e[0] : '0';
+      const unsigned* mask = nullptr; c->cull_on = !(mode == '1' || mode == '2'); const bool prefilter = !(mode == '1' || mode == '3');
+      if (c->cull_on) {
+          if (c->cull_level != cfg.rgbd_level || !c->cull_blocks.p) {
+              CTX_HIP(c, c->cull_blocks.alloc((size_t)c->K * cull_pyramid(p.w, p.h).cells));
+              launch_depth_blocks(s, c->d_frames.p, c->K, p.w, p.h, c->cull_blocks.p); c->cull_level = cfg.rgbd_level; }
+          launch_group_cull(s, g, r, p, c->d_frames.p, c->cull_blocks.p, c->cull_bounds.p, c->cull_mask.p); mask = c->cull_mask.p; }
+      launch_observe(s, g, r, p, c->d_frames.p, mask, prefilter); }
     // the reference's three-way split (nls_solver.cpp:66-67,101): time_add = collecting the residuals (addVoxelResiduals: classification, observations),
     // time_build = buildProblem (cost functions, weight normalisation), time_solve.  The boundary is an event on the stream (round 3: a synchronisation).
     CTX_HIP(c, hipEventRecord(c->ev_asm[1], s));
