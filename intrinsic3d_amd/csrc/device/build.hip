@@ -17,6 +17,8 @@
 //            accumulated point by point; the rotation columns use  d(RP)/d omega = -R [P]x Jr  (Jr per keyframe), so the
 //            per-point work is one cross product instead of three 3x3 products.
 // The 16 bicubic taps of a point are 4 unaligned float4 loads (interior) instead of 16 scalar gathers.
+#include <cstdlib>
+#include <type_traits>
 #include "kernels.hpp"
 #include "reduce_device.hpp"
 
@@ -103,20 +105,43 @@ template <class T> static __device__ inline T hermite_der(T p0, T p1, T p2, T p3
 // Split in two so that the tap loads of ALL four stencil points of a row are in flight together (one memory round trip per row instead of
 // four dependent ones: the kernel runs two waves per SIMD and is latency-bound, not issue-bound): bicubic_taps only issues the 4 x 16 B
 // loads, bicubic_eval consumes them.
-struct Taps { float4 t[4]; double xc, xr; };
+struct Taps { float4 t[4]; double xc, xr; unsigned map; };
 // min(max(x, 0), hi) in ONE instruction (the compiler forms v_med3_i32 only when it can prove 0 <= hi)
 static __device__ inline int clamp0(int x, int hi) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi)); return r; }
+// BRANCH-FREE since round 4: always ONE 16-byte load per image row, from a start column clamped so that the four floats lie inside the row; where the 4 x 4 window
+// crosses the left / right border (Grid2D clamps the column, cost.h:108-127), `map` records which loaded float each tap is (byte j = index of tap j) and
+// bicubic_eval folds the spline weights accordingly.  The two-path form it replaces (x4 load in the interior, four clamped scalar loads at the border, merged into the
+// same registers) made the compiler put `s_waitcnt vmcnt(2)` in front of every load — a load may not be issued into registers an older load is still writing — so the
+// taps of several points were never really in flight together.  Images narrower than 4 pixels: the load runs into the next row / the 16 bytes of padding every
+// luminance image is allocated with (context.cpp), and `map` only points at columns of this row.
+constexpr unsigned TAPS_IDENTITY = 0x03020100u;
 static __device__ inline void bicubic_taps(const float* __restrict__ img, int w, int h, double r, double c, Taps& o) {
     const int row = (int)floor(r), col = (int)floor(c);
     o.xc = c - (double)col; o.xr = r - (double)row;
-    const bool interior = col >= 1 && col + 2 <= w - 1;
+    const int col0 = clamp0(col - 1, max(w - 4, 0));
+    unsigned map = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) map |= (unsigned)(clamp0(col - 1 + j, w - 1) - col0) << (8 * j);
+    o.map = map;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rr = clamp0(row - 1 + i, h - 1);
-        const gf_ptr line = (gf_ptr)(img + (size_t)rr * w);
-        if (interior) { const f4u v = *(gf4u_ptr)(line + (col - 1)); o.t[i] = make_float4(v.x, v.y, v.z, v.w); }
-        else o.t[i] = make_float4(line[clamp0(col - 1, w - 1)], line[clamp0(col, w - 1)], line[clamp0(col + 1, w - 1)], line[clamp0(col + 2, w - 1)]);
+        const f4u v = *(gf4u_ptr)((gf_ptr)(img + (size_t)rr * w) + col0);
+        o.t[i] = make_float4(v.x, v.y, v.z, v.w);
     }
+}
+// spline weights of the four taps -> weights of the four LOADED floats (border columns are clamped onto the same float: their weights add up)
+template <class T> static __device__ inline void fold_weights(unsigned map, T w[4]) {
+    if (map == TAPS_IDENTITY) return;
+    T m[4] = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned idx = (map >> (8 * j)) & 0xffu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] += (idx == (unsigned)k) ? w[j] : (T)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = m[k];
 }
 // Catmull-Rom in WEIGHT form.  Ceres evaluates p1 + x (c + x (b + x a)) with a, b, c recombined from the taps for every spline (5 splines per
 // point, ~15 operations each); the same cubic as a weighted sum of the taps shares ONE weight vector per axis between the four row splines and
@@ -138,12 +163,14 @@ template <bool WITH_J>
 static __device__ inline void bicubic_eval(const Taps& k, double& f, float& dfdr, float& dfdc) {
     const float4* t = k.t;
     double wc[4], wr[4]; cr_weights<double>(k.xc, wc); cr_weights<double>(k.xr, wr);
+    fold_weights<double>(k.map, wc);
     double fr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fr[i] = wc[0] * (double)t[i].x + wc[1] * (double)t[i].y + wc[2] * (double)t[i].z + wc[3] * (double)t[i].w;
     f = wr[0] * fr[0] + wr[1] * fr[1] + wr[2] * fr[2] + wr[3] * fr[3];
     if (WITH_J) {
         float dwc[4], dwr[4]; cr_dweights<float>((float)k.xc, dwc); cr_dweights<float>((float)k.xr, dwr);
+        fold_weights<float>(k.map, dwc);
         dfdr = dwr[0] * (float)fr[0] + dwr[1] * (float)fr[1] + dwr[2] * (float)fr[2] + dwr[3] * (float)fr[3];
         float acc = 0.0f;
 #pragma unroll
@@ -197,8 +224,8 @@ static __device__ inline float chroma_weight(uchar4 c, uchar4 cn) {
 
 // FR_LDS: the per-keyframe constants (144 B each) of ALL keyframes are staged in LDS once per workgroup — every row reads
 // R, t (and Jr) of its keyframe, and with them in global memory those wave-divergent gathers keep the texture-address unit busy.
-template <bool WITH_J, bool FR_LDS, int BATCH>
-__global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out,
+template <bool WITH_J, bool FR_LDS, int BATCH, bool PIPE = false>
+__global__ void __launch_bounds__(256, WITH_J ? 2 : (PIPE ? 3 : 4)) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out,
                                                                const double* __restrict__ cam9, const LmState* __restrict__ lm) {
     extern __shared__ double frame_lds_raw[];
     if (!WITH_J) {
@@ -326,6 +353,62 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : 4) k_build(GridView g, RowVi
             const float fxs = (float)(p.intr[0] * p.pyr_scale), fys = (float)(p.intr[1] * p.pyr_scale);
             const float k0 = (float)p.dist[0], k1 = (float)p.dist[1], k2 = (float)p.dist[2], k3 = (float)p.dist[3], k4 = (float)p.dist[4];
 
+            if (!WITH_J && PIPE) {
+                // ---- candidate cost, software-pipelined (round 4) --------------------------------------------------------------------------------------------
+                // The row loop below exposes three dependent memory round trips per row to its wave (keyframe tag -> taps of points 0,1 -> taps of points 2,3); at four
+                // waves per SIMD two thirds of the resident wave-cycles sat in s_waitcnt (profiles/r04_sq_counters.json).  Here the keyframe tags of ALL rows of the voxel
+                // are requested a row ahead, and the projection + tap loads of one stencil point are always issued TWO points ahead of the
+                // evaluation that consumes them — across the row boundary too — so a wave has the taps of two points in flight while it evaluates.  Same arithmetic per
+                // point; a point that leaves the image still has its (sanitised) taps loaded and its row dropped as before.
+                auto tag_of = [&](int k) -> unsigned { return (unsigned)__float_as_int(r.row_jt()[row_jt_index(a, k, r.slots)].y); };
+                // `after`: a value the projection must wait for (an empty asm ties the point's x to it) — without it the compiler starts the next point's projection before the
+                // evaluation that frees its tap registers, and keeps three sets of taps alive
+                auto issue = [&](const FrameHot& fc, const PointShared& pt, Taps& t, double after) -> bool {
+                    double u, v; PointVal unused;
+                    double Pt[3] = {pt.P[0], pt.P[1], pt.P[2]};
+                    asm volatile("" : "+v"(Pt[0]) : "v"(after));
+                    const bool in = project_point<false>(Pt, fc.R, fc.t, p, u, v, unused);
+                    if (!in) { u = 0.0; v = 0.0; }                // (NaN / far outside: keep the tap addresses inside the image; the row is dropped)
+                    bicubic_taps(fc.lum, p.w, p.h, v, u, t);
+                    return in;
+                };
+                // the free bit is a property of the voxel (vox_free at assembly): either every row of it is part of the reduced program or none
+                const unsigned tag0 = tag_of(0);
+                if (tag0 & (unsigned)ROW_FREE_BIT) {
+                    Taps T0, T1;
+                    int fcur = (int)(tag0 & ~(unsigned)ROW_FREE_BIT);
+                    const double dB1 = q[1].B - q[0].B, dB2 = q[2].B - q[0].B, dB3 = q[3].B - q[0].B;
+                    bool ok = issue(FR_LDS ? flds[fcur] : frames[fcur].hot, q[0], T0, 0.0);
+                    ok = issue(FR_LDS ? flds[fcur] : frames[fcur].hot, q[1], T1, 0.0) && ok;
+                    // one row: evaluate its four points while the next two are requested.  MORE (compile time) = another row follows: its first two points are requested
+                    // during this row's last two evaluations.  The last row is peeled off instead of testing `k + 1 < nin` inside: after a conditional load the compiler
+                    // cannot count what is in flight and falls back to draining everything.
+                    auto row = [&](int k, auto more_tag) {
+                        constexpr bool MORE = decltype(more_tag)::value;
+                        // requested now, needed after the second / fourth evaluation (loads complete in order: they are there when the taps issued after them are)
+                        const float roww = r.row_wr[row_scalar_index(a, k, r.slots)].x;
+                        const unsigned tagn = MORE ? tag_of(k + 1) : 0u;
+                        const FrameHot& fc = FR_LDS ? flds[fcur] : frames[fcur].hot;
+                        double l0, l1, l2, l3; float u0, u1;
+                        bicubic_eval<false>(T0, l0, u0, u1); ok = issue(fc, q[2], T0, l0) && ok;
+                        bicubic_eval<false>(T1, l1, u0, u1); ok = issue(fc, q[3], T1, l1) && ok;
+                        const int fnext = MORE ? (int)(tagn & ~(unsigned)ROW_FREE_BIT) : fcur;
+                        const FrameHot& fn = FR_LDS ? flds[fnext] : frames[fnext].hot;
+                        bool okn = true;
+                        bicubic_eval<false>(T0, l2, u0, u1); if (MORE) okn = issue(fn, q[0], T0, l2);
+                        bicubic_eval<false>(T1, l3, u0, u1); if (MORE) okn = issue(fn, q[1], T1, l3) && okn;
+                        if (ok) {
+                            const double d1 = dB1 - (l1 - l0), d2 = dB2 - (l2 - l0), d3 = dB3 - (l3 - l0);
+                            const double res = sqrt(d1 * d1 + d2 * d2 + d3 * d3);
+                            if (res > 0.0 && !isinf(res)) cost += 0.5 * (double)roww * p.type_w[0] * res * res;      // 0, NaN, inf -> NV_INVALID_RESIDUAL (shading_cost.h:186-195)
+                        }
+                        ok = okn; fcur = fnext;
+                    };
+#pragma unroll 1
+                    for (int k = 0; k + 1 < nin; ++k) row(k, std::true_type{});
+                    row(nin - 1, std::false_type{});
+                }
+            } else
             for (int k = 0; k < nin; ++k) {
                 const size_t ka = (size_t)k * Acap + a;
                 float roww; int f;
@@ -454,8 +537,14 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
         // (Measured: 2.13 -> 1.45 ms; with the keyframe constants staged in LDS as well only one workgroup fits and nothing is gained.)
         if (!set_dynamic_lds((const void*)k_build<true, false, 2>, "k_build<true>", qlds, p.K)) return;
         k_build<true, false, 2><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out, nullptr, nullptr);
-    } else if (lds <= 48 * 1024) k_build<false, true, 2><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out, cam9, lm);       // (tap loads of 2 points in flight: 1 -> +3 %, 4 spills at 128 registers -> +87 %)
-    else k_build<false, false, 2><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out, cam9, lm);
+    } else {
+        static const bool no_pipe = [] { const char* e = std::getenv("I3D_COST_NOPIPE"); return e && e[0] == '1'; }();      // A/B runs
+        if (lds <= 48 * 1024) {
+            if (no_pipe) k_build<false, true, 2><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out, cam9, lm);       // (tap loads of 2 points in flight: 1 -> +3 %, 4 spills at 128 registers -> +87 %)
+            else k_build<false, true, 2, true><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out, cam9, lm);
+        } else if (no_pipe) k_build<false, false, 2><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out, cam9, lm);
+        else k_build<false, false, 2, true><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out, cam9, lm);
+    }
     if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr);      // cost_dst += sum
 }
 

@@ -228,7 +228,7 @@ int i3d_set_frames(i3d_context* c, int32_t K, int32_t levels, const int32_t* wid
     for (int f = 0; f < K; ++f) for (int l = 0; l < levels; ++l) {
         const size_t k = (size_t)f * levels + l, px = (size_t)widths[l] * heights[l];
         if (!lum[k] || !depth[k]) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_frames: null image");
-        CTX_HIP(c, c->lum[k].alloc(px)); CTX_HIP(c, c->depth[k].alloc(px));
+        CTX_HIP(c, c->lum[k].alloc(px + 4));       /* + 16 B: the 16-byte tap loads of the cost kernels may run past the last row of an image narrower than 4 pixels (build.hip) */ CTX_HIP(c, c->depth[k].alloc(px));
         CTX_HIP(c, hipMemcpyAsync(c->lum[k].p, lum[k], px * sizeof(float), hipMemcpyHostToDevice, c->stream));
         CTX_HIP(c, hipMemcpyAsync(c->depth[k].p, depth[k], px * sizeof(float), hipMemcpyHostToDevice, c->stream));
         if (bgr && bgr[k]) { CTX_HIP(c, c->bgr[k].alloc(px * 3)); CTX_HIP(c, hipMemcpyAsync(c->bgr[k].p, bgr[k], px * 3, hipMemcpyHostToDevice, c->stream)); }

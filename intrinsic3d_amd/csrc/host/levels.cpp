@@ -147,13 +147,13 @@ int i3d_set_frames_rgbd(i3d_context* c, int32_t K, int32_t levels, int32_t width
     for (int f = 0; f < K; ++f) {
         if (!bgr[f] || !depth[f]) return ctx_fail(c, I3D_ERR_INVALID_ARGUMENT, "i3d_set_frames_rgbd: null image");
         const size_t k0 = (size_t)f * levels, px = (size_t)width * height;
-        CTX_HIP(c, c->bgr[k0].alloc(px * 3)); CTX_HIP(c, c->lum[k0].alloc(px)); CTX_HIP(c, c->depth[k0].alloc(px));
+        CTX_HIP(c, c->bgr[k0].alloc(px * 3)); CTX_HIP(c, c->lum[k0].alloc(px + 4)); CTX_HIP(c, c->depth[k0].alloc(px));
         CTX_HIP(c, hipMemcpyAsync(c->bgr[k0].p, bgr[f], px * 3, hipMemcpyHostToDevice, st));
         CTX_HIP(c, hipMemcpyAsync(c->depth[k0].p, depth[f], px * sizeof(float), hipMemcpyHostToDevice, st));
         launch_lum_from_bgr(st, (int)px, c->bgr[k0].p, c->lum[k0].p);
         for (int l = 1; l < levels; ++l) {
             const size_t k = k0 + l, n = (size_t)c->fw[l] * c->fh[l];
-            CTX_HIP(c, c->lum[k].alloc(n)); CTX_HIP(c, c->depth[k].alloc(n));
+            CTX_HIP(c, c->lum[k].alloc(n + 4)); CTX_HIP(c, c->depth[k].alloc(n));
             launch_pyr_down(st, c->fw[l - 1], c->fh[l - 1], c->lum[k - 1].p, c->fw[l], c->fh[l], c->lum[k].p);
             launch_depth_down(st, c->fw[l - 1], c->depth[k - 1].p, c->fw[l], c->fh[l], c->depth[k].p);
         }

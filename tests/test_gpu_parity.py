@@ -132,6 +132,53 @@ def test_optimize_matches_oracle(setup):
     ctx.close(); g2.free()
 
 
+def test_rows_whose_spline_window_crosses_the_image_border(oracle):
+    """The bicubic window of a projected point near the image border is clamped column by column (Grid2D, cost.h:108-127).  The device loads ONE 16-byte tap row
+    from a clamped start column and folds the spline weights of the clamped taps (build.hip, bicubic_taps / fold_weights): residuals, Jacobians and the
+    candidate cost of a scene that is larger than every image must still match the oracle."""
+    from intrinsic3d_amd import synthetic
+    sc = helpers.small_scene(seed=7, fx=300.0, cam_dist=0.17)
+    g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc)
+    ocfg = helpers.oracle_cfg(oracle, thres, cg_fixed_iterations=5, iterations=1)
+    pv = oracle.ProblemView(g, fr, ocfg, sc["intr"], sc["dist"], sc["poses"], vsh, 0)
+    ctx = helpers.gpu_context(sc, arrays, vsh)
+    try:
+        ctx.debug_assemble(helpers.gpu_cfg(ocfg), 0)
+        v, f, w, r, J = pv.eg(with_jacobian=True)
+        gfr, gw, gr, gJ = ctx.debug_eg_rows(jac=True)
+        assert set(zip(v.tolist(), f.tolist())) == set((int(i), int(gfr[i, k])) for i, k in zip(*np.nonzero(gfr >= 0)))
+        # how many of these rows sit within two pixels of the border (voxel centre through the keyframe's pose; the iso-point is a fraction of a voxel away)
+        P = arrays["keys"][v].astype(np.float64) * float(sc["voxel_size"])
+        poses = np.asarray(sc["poses"], np.float64).reshape(-1, 6)
+        R = np.stack([synthetic.aa_to_rotmat(p6[:3]) for p6 in poses]); t = poses[:, 3:]
+        q = np.einsum("nij,nj->ni", R[f], P) + t[f]
+        u = sc["intr"][0] * q[:, 0] / q[:, 2] + sc["intr"][2]; vv = sc["intr"][1] * q[:, 1] / q[:, 2] + sc["intr"][3]
+        W, H = sc["width"], sc["height"]
+        near = (u < 2.0) | (u > W - 3.0) | (vv < 2.0) | (vv > H - 3.0)
+        assert near.sum() >= 20, int(near.sum())
+        slot = np.array([int(np.nonzero(gfr[vi] == fi)[0][0]) for vi, fi in zip(v, f)])
+        np.testing.assert_allclose(gr[v, slot], r, rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(gr[v, slot][near], r[near], rtol=1e-4, atol=1e-9)
+        colmax = np.abs(J).max(axis=0, keepdims=True)
+        bad = np.abs(gJ[v, slot] - J) > 1e-4 * np.abs(J) + 2e-6 * colmax
+        assert not bad.any(), (np.argwhere(bad)[:5], near[np.argwhere(bad)[:5, 0]])
+        pv.free()
+        # one iteration through the trust-region loop: the candidate-cost kernel (software-pipelined variant) sees the same border rows
+        g2 = oracle.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+        g2.clear_outside_shell(thres); g2.import_fields(sdf_refined=arrays["sdf_refined"], albedo=arrays["albedo"])
+        rc, intr, dist, poses_o, stats = oracle.optimize(g2, fr, ocfg, sc["intr"], sc["dist"], sc["poses"], vsh)
+        assert rc == 0
+        gst = ctx.optimize(helpers.gpu_cfg(ocfg))
+        for so, sg in zip(stats, gst):
+            assert list(so.rows) == list(sg.rows)
+            assert abs(so.cost_initial - sg.cost_initial) <= 1e-4 * so.cost_initial
+            assert abs(so.cost_final - sg.cost_final) <= 1e-4 * so.cost_final
+            assert list(so.accepted[:so.n_attempts]) == list(sg.step_accepted[:sg.num_attempts])
+        g2.free()
+    finally:
+        ctx.close()
+
+
 def test_estimate_sh_matches_oracle(setup):
     """LightingSVSH::estimate + computeVoxelShCoeffs: fp64 MFMA Gram blocks + host LM vs the oracle's Ceres-equivalent solve."""
     O = setup["O"]; sc = setup["sc"]; thres = setup["thres"]
