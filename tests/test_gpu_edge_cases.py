@@ -240,7 +240,7 @@ def test_mailbox_transport_across_processes(world):
     """tools/p2p_ipc_selftest: the mailbox transport between PROCESSES — IPC handles of the fine-grained mailboxes exchanged over pipes, no
     RCCL — all-reduces of 4 and 1210 doubles and rim pushes between every pair, 100 rounds, every value checked.  (One device here, so the
     ranks share it; on a multi-GPU node the same binary puts every rank on its own device.)"""
-    import os, subprocess
+    import os, re, subprocess
     import torch
     if world == 8 and torch.cuda.device_count() < 8:
         # measured on a 1-GPU box: eight PROCESSES whose kernels poll each other are not co-scheduled on one device (ranks time out in round 0 / 1 after their
@@ -249,5 +249,15 @@ def test_mailbox_transport_across_processes(world):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "p2p_ipc_selftest")
     assert os.path.exists(exe), "tools/p2p_ipc_selftest has not been built (run __graft_entry__.build())"
     # 8 ranks = a node's worth of processes (here sharing one device: their polling kernels time-slice, so fewer rounds; every wait is bounded)
-    r = subprocess.run([exe, str(world), "100" if world < 8 else "30"], capture_output=True, text=True, timeout=300)
+    # Ranks that SHARE a device depend on the driver co-scheduling the polling kernels of several processes: measured 1 run in 12 at world 4 in which they
+    # were not and every rank left through its bounded wait (exit code 15, rounds 0 / 1).  That is the environment, not the protocol: such a run is repeated
+    # (at most twice); a wrong VALUE (any other failure code) fails at once, and with a device per rank there is no retry.
+    shared = torch.cuda.device_count() < world
+    for attempt in range(3 if shared else 1):
+        r = subprocess.run([exe, str(world), "100" if world < 8 else "30"], capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            break
+        codes = set(re.findall(r"failure (\d+) in round", r.stdout + r.stderr))
+        if not (shared and codes == {"15"}):
+            break
     assert r.returncode == 0, r.stdout + r.stderr
