@@ -30,12 +30,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_TAG = "r04-range-checked-slots"     # bumped when k_build<true> / k_eg_tile change materially: PMC traffic / SQ counter files of older kernels are not attached
+KERNEL_TAG = "r04-branch-free-taps"     # bumped when k_build<true> / k_eg_tile change materially: PMC traffic / SQ counter files of older kernels are not attached
 # issue cost of a VALU wave-instruction on gfx950 measured with tools/experiments/valu_rate.hip (profiles/r02_valu_rate.txt): cycles per instruction on one SIMD
 # cycles per wave-instruction on one SIMD BY OCCUPANCY (waves per SIMD), measured (tools/experiments/valu_rate.hip, profiles/r03_valu_rate.txt); pk = packed fp32 (v_pk_*).
 # A kernel is priced at the occupancy it actually runs at (k_build<true>: 247 VGPRs = 2 waves per SIMD), not at the 4-wave rates.
-VALU_CYCLES_BY_OCC = {1: {"f64": 9.8, "f32": 7.3, "pk": 8.6}, 2: {"f64": 6.45, "f32": 4.27, "pk": 6.30}, 4: {"f64": 5.24, "f32": 3.21, "pk": 5.20}}
-KERNEL_OCCUPANCY = {"build": 2, "cost": 4, "eg_pass": 4, "observe": 4}      # waves per SIMD from the register counts (tools/kernel_resources.sh)
+VALU_CYCLES_BY_OCC = {1: {"f64": 9.8, "f32": 7.3, "pk": 8.6}, 2: {"f64": 6.45, "f32": 4.27, "pk": 6.30}, 3: {"f64": 5.85, "f32": 3.74, "pk": 5.75}, 4: {"f64": 5.24, "f32": 3.21, "pk": 5.20}}      # (3: mean of the measured 2- and 4-wave rates)
+KERNEL_OCCUPANCY = {"build": 2, "cost": 3, "eg_pass": 4, "observe": 4}      # waves per SIMD from the register counts (tools/kernel_resources.sh)
 GPU_CLOCK_HZ = 2.4e9; NUM_SIMD = 1024
 
 
