@@ -170,7 +170,7 @@ struct PcgState {
 struct LmState {
     double cost;                    // cost at the current point
     double radius, decrease_factor; // trust-region radius, its reduction factor after a rejected step (doubles every time)
-    double grad2, nfree;            // |J^T W r|^2 and the number of free parameters at the start (gradient test, statistics)
+    double ngrad, nfree;            // free parameters whose gradient entry exceeds Ceres' gradient_tolerance (max-norm test: 0 = converged), free parameters at the start
     float  inv_radius; int pad0;    // (float)(1 / radius) of the attempt in flight: what the vector kernels read
     int done;                       // 0 running | 1 the solve is over: every later kernel of it returns at once
     int termination;                // i3d_iteration_stats::termination: 0 step limit | 1 converged (tolerances, radius) | 2 successful step (the callback) | 3 invalid steps
@@ -182,7 +182,7 @@ struct LmState {
 struct LmRecord {                   // one per attempt (index 0: the initial tests), in mapped host memory; `seq` is stored last with release semantics
     int seq; int final_;            // final_: the solve ended here
     int accepted; int pcg_it; int termination; int kind;      // kind: 0 init | 1 decided attempt | 2 ended before the attempt (radius underflow)
-    double cost, cand_cost, model_change, rel, radius_after, grad2, nfree;
+    double cost, cand_cost, model_change, rel, radius_after, ngrad, nfree;
 };
 
 struct OptParams {                  // scalar state of one outer iteration

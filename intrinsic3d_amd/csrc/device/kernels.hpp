@@ -74,6 +74,8 @@ void launch_mul(hipStream_t st, int n, const float* a, const float* b, float* ou
 void launch_scale_from_colnorm(hipStream_t st, int n, const float* c, const float* freemask, float* S, float* cm);   // S = free ? 1/(1+sqrt(c)) : 0;  cm = free ? c : -1
 void launch_lm_diag(hipStream_t st, int n, const float* c, const float* S, float inv_radius, float* D2, float* Minv_diag);  // D2 = clamp(c S^2)/radius, Minv = 1/(c S^2 + D2) (free) else 0
 void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out /* accumulated */, double* scratch);
+void launch_count_above2(hipStream_t st, Seg2 sg, const float* a, const float* m, float tol, double* out, double* scratch);
+void launch_count_above(hipStream_t st, int n, const float* a, const float* m, float tol, double* out, double* scratch);
 void launch_dot2(hipStream_t st, Seg2 sg, const float* a, const float* b, double* out /* accumulated */, double* scratch);
 void launch_mul2(hipStream_t st, Seg2 sg, const float* a, const float* b, float* out);
 void launch_freemask(hipStream_t st, RowView r, OptParams p, float* mask /*[NP]*/);
@@ -165,7 +167,7 @@ void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, 
                       double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask, double* scratch, const LmState* lm = nullptr);
 void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb, const LmState* lm = nullptr);           // x <- candidate, refresh fp32 shadows (lm: only if it accepted)
 // ---- lm_kernels.hip: the trust-region loop on the device -------------------------------------------------------------------------
-void launch_lm_init(hipStream_t st, LmState* lm, const double* cost, const double* grad2, const double* nfree, double radius0, LmRecord* rec, int seq);
+void launch_lm_init(hipStream_t st, LmState* lm, const double* cost, const double* ngrad, const double* nfree, double radius0, LmRecord* rec, int seq);
 void launch_lm_begin(hipStream_t st, LmState* lm, int K, int fix_poses, int fix_intr, int fix_dist, const double* cdiag, const double* tri, float* Mblk,
                      const float* tc, const float* tS, float* tD2, float* tMinv, LmRecord* rec, int seq);
 void launch_lm_diag_dev(hipStream_t st, int n, const float* c, const float* S, const LmState* lm, float* D2, float* Minv);

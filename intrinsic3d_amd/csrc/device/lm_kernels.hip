@@ -17,22 +17,22 @@ static __device__ inline void lm_publish(LmRecord* rec, int seq) {
     if (rec) __hip_atomic_store(&rec->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void k_lm_init(LmState* lm, const double* __restrict__ cost, const double* __restrict__ grad2, const double* __restrict__ nfree, double radius0, LmRecord* rec, int seq) {
+__global__ void k_lm_init(LmState* lm, const double* __restrict__ cost, const double* __restrict__ ngrad, const double* __restrict__ nfree, double radius0, LmRecord* rec, int seq) {
     LmState s;
-    s.cost = *cost; s.radius = radius0; s.decrease_factor = 2.0; s.grad2 = *grad2; s.nfree = *nfree;
+    s.cost = *cost; s.radius = radius0; s.decrease_factor = 2.0; s.ngrad = *ngrad; s.nfree = *nfree;
     s.inv_radius = (float)(1.0 / radius0); s.pad0 = 0;
     s.done = 0; s.termination = 0; s.accepted = 0; s.invalid = 0; s.attempts = 0; s.successful = 0;
-    // no free parameter, or gradient_tolerance (Ceres: max-norm <= 1e-10; here |g|_2 == 0)
-    if (s.nfree == 0.0 || s.grad2 == 0.0) { s.done = 1; s.termination = 1; }
+    // no free parameter, or gradient_tolerance: max-norm of the gradient over the free parameters <= 1e-10 (trust_region_minimizer.cc, Ceres 2.1.0), i.e. no entry above it
+    if (s.nfree == 0.0 || s.ngrad == 0.0) { s.done = 1; s.termination = 1; }
     *lm = s;
     if (rec) {
         rec->final_ = s.done; rec->accepted = 0; rec->pcg_it = 0; rec->termination = s.termination; rec->kind = 0;
-        rec->cost = s.cost; rec->cand_cost = 0.0; rec->model_change = 0.0; rec->rel = 0.0; rec->radius_after = s.radius; rec->grad2 = s.grad2; rec->nfree = s.nfree;
+        rec->cost = s.cost; rec->cand_cost = 0.0; rec->model_change = 0.0; rec->rel = 0.0; rec->radius_after = s.radius; rec->ngrad = s.ngrad; rec->nfree = s.nfree;
         lm_publish(rec, seq);
     }
 }
-void launch_lm_init(hipStream_t st, LmState* lm, const double* cost, const double* grad2, const double* nfree, double radius0, LmRecord* rec, int seq) {
-    k_lm_init<<<1, 1, 0, st>>>(lm, cost, grad2, nfree, radius0, rec, seq);
+void launch_lm_init(hipStream_t st, LmState* lm, const double* cost, const double* ngrad, const double* nfree, double radius0, LmRecord* rec, int seq) {
+    k_lm_init<<<1, 1, 0, st>>>(lm, cost, ngrad, nfree, radius0, rec, seq);
 }
 
 // Cholesky inverse of an SPD n x n block, n <= 6 (Ceres: BlockRandomAccessDiagonalMatrix::Invert)
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(64) k_lm_begin(LmState* lm, int K, int fix_pos
         if (gid == 0) {
             lm->termination = 1; lm->done = 1;
             if (rec) { rec->final_ = 1; rec->accepted = 0; rec->pcg_it = 0; rec->termination = 1; rec->kind = 2; rec->cost = lm->cost; rec->cand_cost = 0.0; rec->model_change = 0.0; rec->rel = 0.0;
-                       rec->radius_after = radius; rec->grad2 = lm->grad2; rec->nfree = lm->nfree; lm_publish(rec, seq); }
+                       rec->radius_after = radius; rec->ngrad = lm->ngrad; rec->nfree = lm->nfree; lm_publish(rec, seq); }
         }
         return;
     }
@@ -155,7 +155,7 @@ __global__ void k_lm_decide(LmState* lm, const PcgState* __restrict__ ps, const 
     lm->attempts = lm->attempts + 1; lm->accepted = accepted; lm->done = final_;
     if (rec) {
         rec->final_ = final_; rec->accepted = accepted; rec->pcg_it = pcg_it; rec->termination = termination; rec->kind = 1;
-        rec->cost = cost; rec->cand_cost = cand; rec->model_change = model_change; rec->rel = rel; rec->radius_after = radius; rec->grad2 = lm->grad2; rec->nfree = lm->nfree;
+        rec->cost = cost; rec->cand_cost = cand; rec->model_change = model_change; rec->rel = rel; rec->radius_after = radius; rec->ngrad = lm->ngrad; rec->nfree = lm->nfree;
         lm_publish(rec, seq);
     }
 }

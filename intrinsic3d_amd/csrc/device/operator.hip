@@ -575,6 +575,16 @@ __global__ void __launch_bounds__(256) k_dot2(int n, size_t seg, const float* a,
     double s = 0.0; GRID_STRIDE(2 * n) { const size_t j = i < n ? (size_t)i : (size_t)(i - n) + seg; s += (double)a[j] * (double)b[j]; }
     block_partial_d(s, out, 1, 0);
 }
+// number of entries with |a_i m_i| > tol (as a double: it travels through the same sum reductions / all-reduces as the dot products).  Ceres' gradient test is a
+// max-norm test, max_i |g_i| <= gradient_tolerance over the free parameters: true exactly when this count is 0 — and a count, unlike a maximum, is sum-reducible.
+__global__ void __launch_bounds__(256) k_count_above(int n, const float* a, const float* m, float tol, double* out) {
+    double s = 0.0; GRID_STRIDE(n) s += (fabsf(a[i] * m[i]) > tol) ? 1.0 : 0.0;
+    block_partial_d(s, out, 1, 0);
+}
+__global__ void __launch_bounds__(256) k_count_above2(int n, size_t seg, const float* a, const float* m, float tol, double* out) {
+    double s = 0.0; GRID_STRIDE(2 * n) { const size_t j = i < n ? (size_t)i : (size_t)(i - n) + seg; s += (fabsf(a[j] * m[j]) > tol) ? 1.0 : 0.0; }
+    block_partial_d(s, out, 1, 0);
+}
 void launch_fill(hipStream_t st, int n, float* x, float v) { if (n > 0) k_fill<<<vblocks(n), 256, 0, st>>>(n, x, v); }
 void launch_fill_d(hipStream_t st, int n, double* x, double v) { if (n > 0) k_fill_d<<<vblocks(n), 256, 0, st>>>(n, x, v); }
 __global__ void k_int_to_double(const int* src, double* dst) { *dst = (double)*src; }
@@ -589,6 +599,18 @@ void launch_dot2(hipStream_t st, Seg2 sg, const float* a, const float* b, double
     if (sg.n <= 0) return;
     const int blocks = vblocks(2 * sg.n) > 1024 ? 1024 : vblocks(2 * sg.n);
     k_dot2<<<blocks, 256, 0, st>>>(sg.n, sg.off1 - sg.off0, a + sg.off0, b + sg.off0, scratch);
+    launch_reduce_partials(st, scratch, blocks, 1, out, nullptr);
+}
+void launch_count_above2(hipStream_t st, Seg2 sg, const float* a, const float* m, float tol, double* out, double* scratch) {      // out += #{|a m| > tol} over both segments
+    if (sg.n <= 0) return;
+    const int blocks = vblocks(2 * sg.n) > 1024 ? 1024 : vblocks(2 * sg.n);
+    k_count_above2<<<blocks, 256, 0, st>>>(sg.n, sg.off1 - sg.off0, a + sg.off0, m + sg.off0, tol, scratch);
+    launch_reduce_partials(st, scratch, blocks, 1, out, nullptr);
+}
+void launch_count_above(hipStream_t st, int n, const float* a, const float* m, float tol, double* out, double* scratch) {
+    if (n <= 0) return;
+    const int blocks = vblocks(n) > 1024 ? 1024 : vblocks(n);
+    k_count_above<<<blocks, 256, 0, st>>>(n, a, m, tol, scratch);
     launch_reduce_partials(st, scratch, blocks, 1, out, nullptr);
 }
 void launch_dot(hipStream_t st, int n, const float* a, const float* b, double* out, double* scratch) {      // out += a.b

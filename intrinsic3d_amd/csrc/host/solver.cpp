@@ -347,6 +347,16 @@ static int dot_dev(i3d_context* c, const float* a, const float* b, double* slot)
     return I3D_OK;
 }
 
+// slot = number of owned entries (+ the replicated camera tail, counted once) with |a m| > tol
+static int count_above_dev(i3d_context* c, const float* a, const float* m, float tol, double* slot) {
+    const Layout L = layout_of(c);
+    CTX_HIP(c, hipMemsetAsync(slot, 0, sizeof(double), c->stream));
+    { TimedScope t(c, I3D_K_VECTOR); launch_count_above2(c->stream, L.own, a, m, tol, slot, c->d_partials.p); }
+    { int rc = allreduce(c, slot, 1); if (rc) return rc; }
+    { TimedScope t(c, I3D_K_VECTOR); launch_count_above(c->stream, L.NS, a + L.tail_off, m + L.tail_off, tol, slot, c->d_partials.p); }
+    return I3D_OK;
+}
+
 static int eval_cost_launch(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames, const double* cam9 = nullptr, const LmState* lm = nullptr) {
     GridView g = c->grid_view();
     if (candidate) { g.x_sdf = c->xc_sdf.p; g.x_alb = c->xc_alb.p; }
@@ -580,7 +590,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     rc = run_pass(c, PASS_GRAD, p, nullptr, c->v_acc.p); if (rc) return rc;
     { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, NP, c->v_S.p, c->v_acc.p, c->v_b.p); }
     rc = eval_cost_launch(c, p, false, c->d_frames.p); if (rc) return rc;                    // -> d_scal[16]
-    rc = dot_dev(c, c->v_acc.p, c->v_acc.p, c->d_scal.p + 8); if (rc) return rc;             // |g|^2
+    rc = count_above_dev(c, c->v_acc.p, c->v_mask.p, 1e-10f, c->d_scal.p + 8); if (rc) return rc;   // gradient_tolerance: free entries of g = J^T W r above 1e-10 (max-norm test)
     rc = dot_dev(c, c->v_mask.p, c->v_mask.p, c->d_scal.p + 9); if (rc) return rc;           // free parameters
     {   // camera unknowns of the current point for the candidate kernel (staged in pinned memory: the copy is asynchronous)
         double* xs = c->h_pinned;

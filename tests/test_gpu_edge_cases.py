@@ -235,6 +235,25 @@ def test_carry_trust_radius_extension(oracle):
     assert gstats[1].num_attempts <= gstats0[1].num_attempts and gstats[0].num_attempts == gstats0[0].num_attempts
 
 
+def test_gradient_tolerance_is_a_max_norm_test(oracle):
+    """Ceres ends a solve before the first step when the max-norm of the gradient over the free parameters is <= gradient_tolerance = 1e-10
+    (trust_region_minimizer.cc; the call site nls_solver.cpp:296-337 keeps the default).  With every term switched off except a data term weighted 1e-13 the
+    gradient is ~1e-12: the oracle takes no LM attempt and leaves the fields alone, and so must the device (until round 4 it tested |g|_2 == 0 and stepped)."""
+    sc = helpers.small_scene(seed=21, radius_vox=9, K=4, width=96, height=72)
+    thres = 2.0 * float(sc["voxel_size"])
+    rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres, lambda_g=1e-13, lambda_r0=0.0, lambda_r1=0.0, lambda_s0=0.0, lambda_s1=0.0, lambda_a=0.0)
+    assert rc == 0
+    assert [s.n_attempts for s in ostats] == [0, 0] and [s.num_attempts for s in gstats] == [0, 0]
+    for so, sg in zip(ostats, gstats):
+        assert list(so.rows) == list(sg.rows)
+        assert abs(so.cost_initial - sg.cost_initial) <= 1e-4 * so.cost_initial and abs(so.cost_final - sg.cost_final) <= 1e-4 * so.cost_final
+    assert np.array_equal(out["sdf_refined"], ref["sdf_refined"]) and np.array_equal(out["albedo"], ref["albedo"])
+    np.testing.assert_array_equal(np.asarray(cam[2]).ravel(), np.asarray(ocam[2]).ravel())
+    # ... and a gradient of ~1e-8 (data term weighted 1e-9) is NOT converged: both step
+    rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres, lambda_g=1e-9, lambda_r0=0.0, lambda_r1=0.0, lambda_s0=0.0, lambda_s1=0.0, lambda_a=0.0)
+    assert rc == 0 and ostats[0].n_attempts >= 1 and gstats[0].num_attempts >= 1
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_mailbox_transport_across_processes(world):
     """tools/p2p_ipc_selftest: the mailbox transport between PROCESSES — IPC handles of the fine-grained mailboxes exchanged over pipes, no
