@@ -42,6 +42,7 @@ GPU_CLOCK_HZ = 2.4e9; NUM_SIMD = 1024
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--verbose", action="store_true", help="print every trust-region attempt (candidate cost, model change, rho, radius) on stderr")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--voxels", type=float, default=8.0e6, help="stored voxels of the synthetic grid")
@@ -97,7 +98,7 @@ def make_cfg(binding, args, iterations, thres):
     return binding.default_config(iterations=iterations, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0,
                                   lambda_s1=10.0, lambda_a=0.1, fix_poses=0, fix_intrinsics=0, fix_distortion=0,
                                   occlusion_distance=0.02, num_observations=5, thres_shell=thres, grid_level=0, rgbd_level=0,
-                                  pcg_fixed_iterations=args.pcg_fixed, verbose=0, carry_trust_radius=1 if args.carry_radius else 0)
+                                  pcg_fixed_iterations=args.pcg_fixed, verbose=1 if getattr(args, 'verbose', False) else 0, carry_trust_radius=1 if args.carry_radius else 0)
 
 
 def cpu_baseline(args, sc, thres, log, device=0):
