@@ -109,7 +109,12 @@ struct TilePlan {                   // built once per outer iteration by launch_
     int tile_first, ntiles_own;     // tiles this rank owns (all of them when not sharded)
     const int* ghost_tiles; int n_ghost;   // sharded: foreign tiles that hold ghost entries of this rank's compute list
     int det;                               // 1: fixed-order sums inside the workgroups of the operator pass as well (I3D_DETERMINISTIC=1, read per outer iteration)
+    // halo PULL lists (k_tile_pull_plan; null = the halo sums of a tile are pushed with LDS atomics): for every halo slot of a tile the (column, lane) pairs of the tile
+    // that contribute to it, CSR by halo slot, each segment sorted — the slot's owner thread adds them in that fixed order
+    const unsigned short* hp_off;   // [tiles][hmax + 1]
+    const unsigned short* hp_src;   // [tiles][4 * hmax]: (column << 10) | lane; column 0..8 sdf, 9..11 albedo, 12 the Er row value
 };
+inline int tile_plan_pull_cap(int hmax) { return 4 * hmax; }      // list entries per tile (= the LDS the pushed halo accumulators occupied)
 int    tile_plan_T();                      // default geometry (I3D_EGT_TILE): entries per tile
 int    tile_plan_tiles(int A);             // ... tiles of A entries, halo slots per tile
 int    tile_plan_hmax();

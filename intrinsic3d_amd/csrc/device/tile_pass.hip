@@ -136,6 +136,69 @@ template <int NW> static __device__ inline int unpack12(const unsigned (&w)[NW],
 }
 template <int Z> struct AllZ { unsigned w[LNBR_WORDS]; constexpr AllZ() : w{} { for (int j = 0; j < 18; ++j) { const int bit = 12 * j, k = bit >> 5, sh = bit & 31; w[k] |= (unsigned)Z << sh; if (sh > 20) w[k + 1] |= (unsigned)Z >> (32 - sh); } } };
 
+// Halo PULL lists (round 4, I3D_HALO_PULL=1 / the bit-reproducible mode).  What a tile's rows add to entries OUTSIDE the tile went through LDS float atomics into
+// per-tile halo accumulators — in whatever order the waves arrive, the one order-dependent sum of the default operator pass besides the pose block, and ~70 cycles per
+// wave-instruction.  The targets are known at plan time: lane L's stencil slot j points at local slot ls (>= T: halo slot ls - T).  This kernel inverts that map per
+// tile: for every halo slot the (column, lane) pairs that feed it (CSR by halo slot; 9 sdf columns + 3 albedo columns of the lane's Eg rows, + the lane's Er row value
+// towards its six ring neighbours = column 12), every segment sorted.  In the pass the halo slot's owner thread then adds C[column][lane] over its segment, after the
+// barrier that completes the lane-private column sums: a pull like the in-tile one, fixed order, no atomics.
+template <int T, int HMAX>
+__global__ void __launch_bounds__(T) k_tile_pull_plan(RowView r, int tile_first, const int* __restrict__ tile_list, const unsigned* __restrict__ lnbr, const int* __restrict__ halo_cnt,
+                                                      unsigned short* __restrict__ hp_off, unsigned short* __restrict__ hp_src, int* __restrict__ overflow) {
+    constexpr int CAP = 4 * HMAX, ZSLOT = T + HMAX, PER = HMAX / T, NWV = T / 64;
+    static_assert(HMAX % T == 0, "slots per thread");
+    __shared__ int cnt[HMAX];
+    __shared__ int off[HMAX + 1];
+    __shared__ unsigned short list[CAP];
+    __shared__ int wsum[NWV];
+    const int tile = tile_list ? tile_list[blockIdx.x] : tile_first + (int)blockIdx.x, a = tile * T + (int)threadIdx.x;
+    const bool in = a < r.A;
+    for (int s2 = threadIdx.x; s2 < HMAX; s2 += T) cnt[s2] = 0;
+    __syncthreads();
+    unsigned ln[5];
+#pragma unroll
+    for (int w = 0; w < 5; ++w) ln[w] = in ? lnbr[(size_t)w * r.Acap + a] : 0u;
+    // the lane's 18 outside references: (stencil slot j, column)
+    constexpr int RJ[18] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 5, 0, 3, 5, 9, 0, 10, 3, 11};
+    constexpr int RC[18] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 12, 12, 12};
+    int hs[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) { const int sl = in ? unpack12(ln, RJ[k]) : ZSLOT; hs[k] = (sl >= T && sl != ZSLOT) ? sl - T : -1; if (hs[k] >= 0) atomicAdd(&cnt[hs[k]], 1); }
+    __syncthreads();
+    // exclusive scan of cnt -> off (PER consecutive slots per thread, wave scan, wave totals)
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { loc[q] = cnt[threadIdx.x * PER + q]; sum += loc[q]; }
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((int)(threadIdx.x & 63) >= o) inc += v; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < NWV; ++w) { if (w < (int)(threadIdx.x >> 6)) base += wsum[w]; total += wsum[w]; }
+    int run = base + inc - sum;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { off[threadIdx.x * PER + q] = run; run += loc[q]; }
+    if (threadIdx.x == T - 1) off[HMAX] = run;
+    for (int s2 = threadIdx.x; s2 < HMAX; s2 += T) cnt[s2] = 0;
+    __syncthreads();
+    if (total > CAP) {                               // (wave-uniform) the caller plans again with the other geometry / falls back to the untiled pass, like a halo that does not fit
+        if (threadIdx.x == 0) *overflow = 1;
+        for (int s2 = threadIdx.x; s2 <= HMAX; s2 += T) hp_off[(size_t)tile * (HMAX + 1) + s2] = 0;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 18; ++k) if (hs[k] >= 0) { const int pos = off[hs[k]] + atomicAdd(&cnt[hs[k]], 1); list[pos] = (unsigned short)((RC[k] << 10) | (int)threadIdx.x); }
+    __syncthreads();
+    const int H = halo_cnt[tile];
+    for (int s2 = threadIdx.x; s2 < H; s2 += T) {    // every segment ascending: the order the pass adds in
+        const int j0 = off[s2], j1 = off[s2 + 1];
+        for (int i2 = j0 + 1; i2 < j1; ++i2) { const unsigned short v = list[i2]; int j = i2 - 1; while (j >= j0 && list[j] > v) { list[j + 1] = list[j]; --j; } list[j + 1] = v; }
+    }
+    __syncthreads();
+    for (int s2 = threadIdx.x; s2 <= HMAX; s2 += T) hp_off[(size_t)tile * (HMAX + 1) + s2] = (unsigned short)off[s2];
+    for (int p2 = threadIdx.x; p2 < total; p2 += T) hp_src[(size_t)tile * CAP + p2] = list[p2];
+}
+
 // T lanes = T entries per tile.  SLOTS > 0: the row loop is unrolled for exactly that many observation slots and EVERY slot is requested
 // (unused slots of a voxel are skipped per lane): straight-line code whose s_waitcnt the compiler can count exactly — with a run-time
 // trip count and conditional refills it falls back to vmcnt(0) at the loop header, which drains the block meant to stay in flight.
@@ -193,9 +256,11 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                                                         const int* __restrict__ ghost_list /* then ntl - n_own foreign tiles holding ghost entries */, int ntl, const PcgState* __restrict__ state,
                                                         float* __restrict__ cam_partials /* or null: [gridDim.x][cam_stride] camera block of this workgroup (no atomics) */, int cam_stride,
                                                         const int* __restrict__ gmaxv /* = r.gmax as a restrict-qualified kernel argument: its wave-uniform loads become scalar loads (lgkmcnt), a
-                                                                                         vector load here would put an s_waitcnt vmcnt(0) behind the row blocks just requested */) {
+                                                                                         vector load here would put an s_waitcnt vmcnt(0) behind the row blocks just requested */,
+                                                        const unsigned short* __restrict__ hp_off, const unsigned short* __restrict__ hp_src /* DETM & 4: the halo pull lists (k_tile_pull_plan) */) {
     if (state && state->done) return;
-    constexpr bool DET = DETM != 0, DORD = (DETM & 1) != 0, DTAB = (DETM & 2) != 0;
+    constexpr bool DET = (DETM & 3) != 0, DORD = (DETM & 1) != 0, DTAB = (DETM & 2) != 0, HP = (DETM & 4) != 0;
+    static_assert(!(DORD && HP), "a pulled halo needs no ordered pushes");
     constexpr int ZSLOT = T + HMAX, NSLOT = ZSLOT + 1;
     extern __shared__ float lds[];        // [reps][rs] pose acc | [9] | pad | camera part of u [6K+9] | pad | u_s,u_a [NSLOT] | qh_s,qh_a [HMAX] | tr [T+1] | C [12][T] | p.q [T] fp64
     const int K = p.K; const size_t Acap = r.Acap; const int A = r.A, chunk = r.chunk;
@@ -235,6 +300,11 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     constexpr int NCOL = 12;
 #define pq_l reinterpret_cast<double*>(lds + o_u + 2 * NSLOT + 2 * HMAX + T + 4 + NCOL * T)
     pq_l[i] = 0.0;
+    // HP: the (column, lane) pull list of the tile in flight lives where the pushed halo accumulators were (2 HMAX floats = 4 HMAX list entries), its CSR offsets
+    // behind the per-lane p.q
+    constexpr int HPCAP = 4 * HMAX;
+#define hp_list reinterpret_cast<unsigned short*>(lds + o_u + 2 * NSLOT)
+#define hp_offs reinterpret_cast<unsigned short*>(lds + o_u + 2 * NSLOT + 2 * HMAX + T + 4 + NCOL * T + 2 * T)
     // DET: [ticket | 3 pad] [NW][9] per-wave intrinsics / distortion sums | [NW][TC] keyframe tags | [NW][TC][6] sums (at the front of the LDS, see above)
     constexpr int o_det = 0, o_cam9w = D_CAM9W;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -250,6 +320,8 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     constexpr int NQH = (HMAX + T - 1) / T;
     int tile = 0, base = 0, a = 0, H = 0, nr_ld = 0; bool in = false, owned = false; size_t ac = 0;
     float us = 0.0f, ua = 0.0f; uint8_t fl = 0, rf_ld = 0; unsigned ln[5]; float hs[NQH], ha[NQH]; RowBlock rwA, rwB;
+    constexpr int NQL = HP ? (HPCAP / 8 + T - 1) / T : 1, NQO = HP ? (HMAX + 1 + T - 1) / T : 1;      // 16-byte list chunks / offsets per thread
+    uint4 hpl[NQL]; unsigned short hpo[NQO];
     const int tk_end = min(tile0 + tiles_per_block, ntl);
     // everything a tile needs besides its later rows is requested first (older than the row loads: waiting for it does not drain them)
     // one row = 120 B per lane: seven 16-byte planes + (column 28, keyframe id).  The 29 partials and the id, nothing else (the weight is folded in, RowView)
@@ -302,6 +374,12 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         for (int q = 0; q < NQH; ++q) he[q] = __builtin_nontemporal_load(&halo_idx[(size_t)tile * HMAX + (i + q * T < HMAX ? i + q * T : 0)]);
 #pragma unroll
         for (int q = 0; q < NQH; ++q) { const int e = (i + q * T < H) ? he[q] : 0; hs[q] = u[e]; ha[q] = u[chunk + e]; }
+        if (HP) {          // the tile's pull list (one or two 16-byte chunks per thread) and its offsets: consumed by the staging below, long before the row loop
+#pragma unroll
+            for (int q = 0; q < NQL; ++q) { const int ch = i + q * T; hpl[q] = reinterpret_cast<const uint4*>(hp_src + (size_t)tile * HPCAP)[ch < HPCAP / 8 ? ch : 0]; }
+#pragma unroll
+            for (int q = 0; q < NQO; ++q) { const int o = i + q * T; hpo[q] = hp_off[(size_t)tile * (HMAX + 1) + (o <= HMAX ? o : HMAX)]; }
+        }
     };
     auto issue_meta = [&]() {
         fl = in ? r.aflags[ac] : 0;
@@ -322,8 +400,14 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         // ---- stage the operator input of tile + halo, clear the accumulators ----
         u_s[i] = us; u_a[i] = ua;
 #pragma unroll
-        for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; if (hq < HMAX) { const bool hv = hq < H; u_s[T + hq] = hv ? hs[q] : 0.0f; u_a[T + hq] = hv ? ha[q] : 0.0f; qh_s[hq] = 0.0f; qh_a[hq] = 0.0f; } }
-        if (i == 0) { u_s[ZSLOT] = 0.0f; u_a[ZSLOT] = 0.0f; tr_l[T] = 0.0f; if (DORD) lds[o_det] = __int_as_float(0); }      // (the ordered section of this tile starts at wave 0)
+        for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; if (hq < HMAX) { const bool hv = hq < H; u_s[T + hq] = hv ? hs[q] : 0.0f; u_a[T + hq] = hv ? ha[q] : 0.0f; if (!HP) { qh_s[hq] = 0.0f; qh_a[hq] = 0.0f; } } }
+        if (HP) {
+#pragma unroll
+            for (int q = 0; q < NQL; ++q) { const int ch = i + q * T; if (ch < HPCAP / 8) { reinterpret_cast<uint2*>(hp_list)[2 * ch] = make_uint2(hpl[q].x, hpl[q].y); reinterpret_cast<uint2*>(hp_list)[2 * ch + 1] = make_uint2(hpl[q].z, hpl[q].w); } }      // (the list area is 8-byte aligned, not 16)
+#pragma unroll
+            for (int q = 0; q < NQO; ++q) { const int o = i + q * T; if (o <= HMAX) hp_offs[o] = hpo[q]; }
+        }
+        if (i == 0) { u_s[ZSLOT] = 0.0f; u_a[ZSLOT] = 0.0f; tr_l[T] = 0.0f; if (DET) lds[o_det] = __int_as_float(0); }      // (the ordered section of this tile starts at wave 0)
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) C_l[c * T + i] = 0.0f;
         const bool active = in && (fl & F_ACTIVE);
@@ -342,9 +426,9 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 const float lap = ((((((-6.0f * us) + u_s[rg[0]]) + u_s[rg[1]]) + u_s[rg[2]]) + u_s[rg[3]]) + u_s[rg[4]]) + u_s[rg[5]];
                 tr = tw1 * lap; if (owned) pq_pre += (double)(tr * lap);
                 self_s += -6.0f * tr;
-                if (!DORD) {
+                if (!DORD && !HP) {
 #pragma unroll
-                    for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles (ordered: in the ordered section)
+                    for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles (ordered: in the ordered section; HP: pulled)
                 }
             }
             tr_l[i] = tr;
@@ -435,7 +519,7 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
                 for (int d = 0; d < 6; ++d) if (rg[d] >= T && rg[d] != ZSLOT) lds_add(&qh_s[rg[d] - T], tr);      // ring neighbours of other tiles
             }
         }
-        if (nr > 0) {
+        if (!HP && nr > 0) {
 #pragma unroll
             for (int c = 1; c < 10; ++c) { const int sl = unpack12(ln, c - 1); if (sl >= T && sl != ZSLOT) lds_add(&qh_s[sl - T], Cme[(c - 1) * T]); }
             if (sx >= T && sx != ZSLOT) lds_add(&qh_a[sx - T], Cme[9 * T]);
@@ -444,8 +528,15 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
         }
         if (DTAB && DORD) { if (tcount > TC - 16) wave_table_merge<6, TC>(lds, o_tag, o_val, tcount, D0, 6); }      // (wave-uniform) room for the next tile's keyframes
         if (DORD) ordered_leave(&lds[o_det], wave);
+        // tables without an ordered section (pulled halo): a wave whose table is nearly full raises a flag, and behind the barrier ALL tables are merged in wave order
+        if (DTAB && !DORD) { if (tcount > TC - 16 && (threadIdx.x & 63u) == 0u) lds[o_det] = __int_as_float(1); }
         const int a_c = a, H_c = H, tile_c = tile; const bool in_c = in, owned_c = owned; const float ua_c = DTAB ? u_a[i] : ua;
         __syncthreads();
+        if (DTAB && !DORD) {
+            if (__float_as_int(lds[o_det]) != 0) {                  // (workgroup-uniform: written before the barrier, cleared by the next tile's staging behind the next one)
+                for (int w = 0; w < NW; ++w) { if (wave == w) wave_table_merge<6, TC>(lds, o_tag, o_val, tcount, D0, 6); __syncthreads(); }
+            }
+        }
         // ---- pull: every entry collects the column sums of the tile entries whose stencil contains it ----
         if (in_c) {
             // reverse entries: slot c of entry e is this entry <=> e = this entry's neighbour in the mirrored direction
@@ -467,7 +558,22 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
             qacc[a_c] = qs; qacc[chunk + a_c] = qa;
         }
 #pragma unroll
-        for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; if (hq < H_c) { const size_t o = (size_t)tile_c * HMAX + hq; qh[2 * o] = qh_s[hq]; qh[2 * o + 1] = qh_a[hq]; } }
+        for (int q = 0; q < NQH; ++q) {
+            const int hq = i + q * T;
+            if (hq < H_c) {
+                const size_t o = (size_t)tile_c * HMAX + hq;
+                if (HP) {        // this halo slot's sums: its (column, lane) segment, in list order
+                    float hsum = 0.0f, hal = 0.0f;
+                    const int j1 = hp_offs[hq + 1];
+                    for (int j = hp_offs[hq]; j < j1; ++j) {
+                        const int e = hp_list[j], col = e >> 10, lane = e & 1023;
+                        const float v = col == 12 ? tr_l[lane] : C_l[col * T + lane];
+                        if (col >= 9 && col != 12) hal += v; else hsum += v;
+                    }
+                    qh[2 * o] = hsum; qh[2 * o + 1] = hal;
+                } else { qh[2 * o] = qh_s[hq]; qh[2 * o + 1] = qh_a[hq]; }
+            }
+        }
         __syncthreads();       // the staging of the next tile rewrites u / C / tr slots other lanes are still pulling from
     }
 #pragma unroll
@@ -491,6 +597,8 @@ __global__ void __launch_bounds__(T, 4) k_eg_tile(RowView r, OptParams p, const 
     }
     if (pq_partials) block_partial_d(pq_l[i], pq_partials, 1, 0);
 #undef pq_l
+#undef hp_list
+#undef hp_offs
 #undef o_tag
 #undef o_val
 #undef upose
@@ -550,6 +658,13 @@ hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, s
                 e = hipMemsetAsync(t.halo_cnt, 0, sizeof(int) * (size_t)ntiles, st); if (e != hipSuccess) return e; }
     if (t.ntiles_own > 0) k_tile_plan<<<t.ntiles_own, 1024, 0, st>>>(r, t.T, t.hmax, hlimit, t.tile_first, nullptr, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
     if (t.n_ghost > 0) k_tile_plan<<<t.n_ghost, 1024, 0, st>>>(r, t.T, t.hmax, hlimit, 0, t.ghost_tiles, t.lnbr, t.halo_idx, t.halo_cnt, t.overflow);
+    if (t.hp_off) {          // the halo pull lists of the tiles just planned (needs their lnbr words and halo counts)
+        unsigned short* off = const_cast<unsigned short*>(t.hp_off); unsigned short* src = const_cast<unsigned short*>(t.hp_src);
+        if (t.T == 1024) { if (t.ntiles_own > 0) k_tile_pull_plan<1024, 2048><<<t.ntiles_own, 1024, 0, st>>>(r, t.tile_first, nullptr, t.lnbr, t.halo_cnt, off, src, t.overflow);
+                           if (t.n_ghost > 0) k_tile_pull_plan<1024, 2048><<<t.n_ghost, 1024, 0, st>>>(r, 0, t.ghost_tiles, t.lnbr, t.halo_cnt, off, src, t.overflow); }
+        else { if (t.ntiles_own > 0) k_tile_pull_plan<512, 1536><<<t.ntiles_own, 512, 0, st>>>(r, t.tile_first, nullptr, t.lnbr, t.halo_cnt, off, src, t.overflow);
+               if (t.n_ghost > 0) k_tile_pull_plan<512, 1536><<<t.n_ghost, 512, 0, st>>>(r, 0, t.ghost_tiles, t.lnbr, t.halo_cnt, off, src, t.overflow); }
+    }
     k_iota<<<(n + 255) / 256, 256, 0, st>>>(n, t.iota);
     e = rocprim::radix_sort_pairs(temp, temp_bytes, (const int*)t.halo_idx, t.ext_e, (const int*)t.iota, t.ext_pos, (size_t)n, 0, 32, st);
     if (e != hipSuccess) return e;
@@ -567,12 +682,16 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
     // I3D_DETERMINISTIC=1: fixed-order sums inside the workgroup as well (ordered halo pushes, per-wave keyframe tables) — every kernel of an outer iteration is then
     // bit-reproducible from run to run (tools/flake_hunt.py: 0.0 on every field) at ~20 % lower throughput; the default keeps the LDS atomics of round 3 HERE and
     // only here (gradient, column norms, SH Gram blocks, camera block and halo fold across workgroups are fixed-order in both modes)
-    const int detm = t.det ? 3 : 0;
-    const bool det = detm != 0;
+    // halo sums: pushed with LDS atomics (default), or PULLED over the plan's lists (t.hp_off: I3D_HALO_PULL=1, and always in the bit-reproducible mode, where the pull
+    // replaces the ordered pushes of the first version — I3D_EGT_ORDERED=1 brings those back for A/B runs)
+    static const bool ordered = [] { const char* e = std::getenv("I3D_EGT_ORDERED"); return e && e[0] == '1'; }();
+    const bool pull = t.hp_off != nullptr && !(t.det && ordered);
+    const int detm = t.det ? (pull ? 6 : 3) : (pull ? 4 : 0);
+    const bool det = (detm & 3) != 0;
     constexpr int NW = T / 64, TC = T == 1024 ? 64 : 32;
     const int det_words = det ? 4 + ((NW * 9 + 3) & ~3) + NW * TC * 7 : 0;      // ticket, per-wave camera sums, per-wave keyframe tables (at the front of the LDS)
     auto lds_bytes = [&](int reps) { const int nacc = det_words + reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
-                                     return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T + 2 * T /* p.q per lane, fp64 */) * sizeof(float); };
+                                     return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T + 2 * T /* p.q per lane, fp64 */ + (pull ? (HMAX + 4) / 2 : 0) /* pull-list offsets */) * sizeof(float); };
     const size_t budget = (T == 512 ? 79 : 158) * 1024;
     int reps = (detm & 2) ? 1 : 4;                                  // replicas only serve the rare > 3-keyframe fallback of wave_accumulate (DET: one dense accumulator, the waves own tables)
     while (reps > 1 && lds_bytes(reps) > budget) reps >>= 1;
@@ -591,11 +710,11 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
             // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
             // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
             if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
-#define I3D_EGT(SL, GH) do { if (detm == 3) I3D_EGT2(SL, GH, 3); else I3D_EGT2(SL, GH, 0); } while (0)
+#define I3D_EGT(SL, GH) do { if (detm == 3) I3D_EGT2(SL, GH, 3); else if (detm == 6) I3D_EGT2(SL, GH, 6); else if (detm == 4) I3D_EGT2(SL, GH, 4); else I3D_EGT2(SL, GH, 0); } while (0)
 #define I3D_EGT2(SL, GH, DT) do { \
         if (!set_dynamic_lds((const void*)k_eg_tile<T, HMAX, SL, GH, DT>, "k_eg_tile", lds, p.K)) break; \
         k_eg_tile<T, HMAX, SL, GH, DT><<<blocks, T, lds, st>>>(r, p, u, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, shared, qacc, t.qh, pq_partials, reps, tiles_per_block, t.tile_first, t.ntiles_own, \
-                                                   t.ghost_tiles, ntl, state, cam_partials, cam_stride, r.gmax); } while (0)
+                                                   t.ghost_tiles, ntl, state, cam_partials, cam_stride, r.gmax, pull ? t.hp_off : nullptr, pull ? t.hp_src : nullptr); } while (0)
             const bool gh = t.n_ghost > 0;
             // the shipped num_observations (data/intrinsic3d.yml): unrolled row loop.  (The run-time loop, which skips the slots no lane of a wave uses, is
             // slower even where 36 % of the slots are empty: 0.577 vs 0.483 ms on --band 2, 0.336 vs 0.272 on the default workload.)

@@ -92,6 +92,7 @@ struct i3d_context {
     i3d::DevBuf<float> aux_part;      // one float row of camera totals per workgroup of the gradient / column-norm passes (summed in a fixed order)
     i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_ext_off, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw, cam_part;
     i3d::DevBuf<unsigned char> tp_temp; bool tile_ok = false;
+    i3d::DevBuf<unsigned short> tp_hp_off, tp_hp_src; bool halo_pull = false;      // halo pull lists of the plan (tile_pass.hip k_tile_pull_plan): I3D_HALO_PULL=1 and the bit-reproducible mode
     double t_add_end = 0.0;         // host clock at the end of the residual collection of the current outer iteration (time_add | time_build)
     bool deterministic = false;     // I3D_DETERMINISTIC=1 (read at every assemble): bit-reproducible operator pass, ~20 % slower
     int tile_T = 0;                 // geometry of the current plan (0 = the default, 1024); single rank: 512 when a 1024-entry tile's halo does not fit; sharded: 512 first, then 1024
@@ -101,7 +102,7 @@ struct i3d_context {
         const bool sh = comm && (comm->world > 1 || comm->force);
         const int t0 = sh ? own0 / T : 0, t1 = sh ? (own1 + T - 1) / T : i3d::tile_plan_tiles_of(A, T);
         return i3d::TilePlan{tp_lnbr.p, tp_eaw.p, tp_halo_idx.p, tp_halo_cnt.p, tp_iota.p, tp_ext_e.p, tp_ext_pos.p, tp_qh.p, tp_ext_off.p, tp_overflow.p, T, i3d::tile_plan_hmax_of(T), t0, t1 > t0 ? t1 - t0 : 0,
-                             ghost_tiles.p, sh ? n_ghost_tiles : 0, deterministic ? 1 : 0};
+                             ghost_tiles.p, sh ? n_ghost_tiles : 0, deterministic ? 1 : 0, halo_pull ? tp_hp_off.p : nullptr, halo_pull ? tp_hp_src.p : nullptr};
     }
 
     // ---- solver vectors (length NP = 2N + 6K + 9) ----

@@ -221,6 +221,15 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
       launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
     c->tile_ok = false; c->tile_T = 0;
     { const char* e = std::getenv("I3D_DETERMINISTIC"); c->deterministic = e && e[0] == '1'; }
+    {   // halo sums of the operator pass pulled over plan lists instead of pushed with LDS atomics: always in the bit-reproducible mode, else on request
+        const char* e = std::getenv("I3D_HALO_PULL");
+        c->halo_pull = c->deterministic || (e && e[0] == '1');
+        if (c->halo_pull) {      // sized for both tile geometries (Acap entries)
+            const size_t n512 = (size_t)tile_plan_tiles_of(c->Acap, 512), n1024 = (size_t)tile_plan_tiles_of(c->Acap, 1024);
+            CTX_HIP(c, c->tp_hp_off.alloc(std::max(n512 * (size_t)(1536 + 1), n1024 * (size_t)(2048 + 1)) + 8));
+            CTX_HIP(c, c->tp_hp_src.alloc(std::max(n512 * (size_t)tile_plan_pull_cap(1536), n1024 * (size_t)tile_plan_pull_cap(2048)) + 8));
+        }
+    }
     if (!sharded(c)) {
         // tile geometry: 1024-entry tiles (one workgroup of 16 waves per CU) unless the work list is row-poor — SURVEY.md 8(d)'s 4-voxel shell, real sequences with few
         // observations: a third of the entries own no Eg rows, their waves idle while the others stream, and two smaller workgroups per CU keep more row blocks in
