@@ -188,8 +188,8 @@ def test_chained_ten_iterations_without_reseeding(slice_setup):
 
 def test_deterministic_mode_is_bit_reproducible(slice_setup, monkeypatch):
     """I3D_DETERMINISTIC=1: every sum of an outer iteration is taken in a fixed order — the gradient, the column norms, the SH Gram blocks, the camera block and the
-    halo fold across workgroups in both modes; with the switch also the halo pushes and the pose block INSIDE the operator pass's workgroups (ordered section,
-    per-wave keyframe tables, tile_pass.hip).  Two runs of two chained iterations (Ceres' own PCG stop, every group free) from identical inputs must then agree
+    halo fold across workgroups in both modes; with the switch also the halo sums and the pose block INSIDE the operator pass's workgroups (halo pulled over the
+    plan's lists, per-wave keyframe tables, tile_pass.hip).  Two runs of two chained iterations (Ceres' own PCG stop, every group free) from identical inputs must then agree
     bit for bit in every field — and still agree with the default mode to round-off."""
     S = slice_setup; O = S["O"]; sc = S["sc"]; a0 = S["arrays"]
     cfg = helpers.gpu_cfg(_bench_cfg(O, S["thres"], -1)); cfg.iterations = 2
@@ -207,3 +207,8 @@ def test_deterministic_mode_is_bit_reproducible(slice_setup, monkeypatch):
     st0, s0, a0_, c0 = run()
     assert [list(s.step_accepted[:s.num_attempts]) for s in st0] == [list(s.step_accepted[:s.num_attempts]) for s in st1]
     assert np.abs(s0 - s1).max() <= 1e-5 * np.abs(s1).max() and np.abs(a0_ - a1).max() <= 1e-5 * np.abs(a1).max()
+    # the pulled halo on its own (I3D_HALO_PULL=1: the pose block still through LDS atomics): the same operator up to summation order
+    monkeypatch.setenv("I3D_HALO_PULL", "1")
+    st3, s3, a3, c3 = run()
+    assert [list(s.step_accepted[:s.num_attempts]) for s in st3] == [list(s.step_accepted[:s.num_attempts]) for s in st1]
+    assert np.abs(s3 - s1).max() <= 1e-5 * np.abs(s1).max() and np.abs(a3 - a1).max() <= 1e-5 * np.abs(a1).max()
