@@ -303,7 +303,8 @@ const char* i3d_comm_transport(i3d_context* ctx);
  * since the last reset.  names: see i3d_kernel_name(). */
 enum { I3D_K_CLASSIFY = 0, I3D_K_OBSERVE, I3D_K_BUILD, I3D_K_EG_PASS /* J^T W J p passes of the PCG */, I3D_K_GATHER, I3D_K_COST, I3D_K_VECTOR, I3D_K_SH,
        I3D_K_EG_AUX /* gradient and column-norm passes over the rows */,
-       I3D_K_COMM /* sharded runs: halo push, all-reduce, all-gather launches (GPU time incl. waiting for the peers) */, I3D_K_COUNT };
+       I3D_K_COMM /* sharded runs: halo push, all-reduce, all-gather launches (GPU time incl. waiting for the peers) */,
+       I3D_K_EG_MR2, I3D_K_EG_MR3 /* operator passes of a ladder batch that serve 2 / 3 systems with one stream of the rows (I3D_K_EG_PASS: one system) */, I3D_K_COUNT };
 int i3d_timing_enable(i3d_context* ctx, int32_t on);
 /* restrict the per-launch HIP events to the categories of the mask (bit = 1 << I3D_K_*; default: all).  An event pair around EVERY launch of a
  * Gauss-Newton iteration (~900 launches) costs ~8 % of its wall clock; bench.py times only what its roofline needs. */
@@ -337,6 +338,11 @@ int i3d_debug_jtj_apply(i3d_context* ctx, const double* x, double* y);
 /* counters of the context since its creation: stream synchronisations of the solver path (assemble + the LM loop).  The trust-region loop of
  * NLSSolver::solve (nls_solver.cpp:296-337) runs on the device; a Gauss-Newton iteration costs a handful of them, not two per LM attempt. */
 int i3d_debug_counters(i3d_context* ctx, int64_t* stream_syncs);
+/* the damping ladder of the trust-region loop (consecutive LM attempts of NLSSolver::solve, nls_solver.cpp:296-337, whose radii are known in advance are solved
+ * together, I3D_LADDER): since the context was created — [0] batches, [1] streams of the stored rows (operator launches of ladder solves), [2] system passes (what
+ * the serial loop would have streamed), [3] batches that went out of step (invalid step) and were re-solved, [4] systems solved but never decided (an earlier
+ * attempt of their batch was accepted), [5] the batch depth in force (1 = serial loop). */
+int i3d_debug_ladder_stats(i3d_context* ctx, int64_t* out6);
 /* the conservative culling in front of the observation pass (SDFColorization::computeObservation is evaluated per (voxel, keyframe), colorization.cpp:215-315;
  * the device skips (group of 64 voxels, keyframe) pairs no voxel of which can be observed): pairs of the last assemble and how many were skipped.  culled = -1 when
  * culling is off (I3D_NO_CULL=1). */

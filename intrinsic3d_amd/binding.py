@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # I3D_LIB: load another build of the SAME C ABI instead (same-box A/B of kernel variants in one GPU session; never a CPU substitute)
 LIB_PATH = os.environ.get("I3D_LIB") or os.path.join(_HERE, "libintrinsic3d_hip.so")
 
-K_NAMES = ["classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh", "eg_aux", "comm"]
+K_NAMES = ["classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh", "eg_aux", "comm", "eg_mr2", "eg_mr3"]
 
 
 class OptimizerConfig(C.Structure):
@@ -76,7 +76,7 @@ EXPORTS = ["i3d_create", "i3d_destroy", "i3d_last_error", "i3d_version", "i3d_se
            "i3d_comm_unique_id", "i3d_comm_init", "i3d_comm_sim_create", "i3d_comm_sim_destroy", "i3d_comm_init_sim", "i3d_shard_plan", "i3d_shard_vec_index",
            "i3d_comm_transport", "i3d_timing_enable", "i3d_timing_select", "i3d_timing_get", "i3d_timing_get_work", "i3d_timing_get_work_ex", "i3d_kernel_name", "i3d_problem_sizes",
            "i3d_debug_assemble", "i3d_debug_map_order", "i3d_debug_flags", "i3d_debug_eg_rows", "i3d_debug_reg_rows", "i3d_debug_neighbors",
-           "i3d_debug_normal_eq", "i3d_debug_jtj_apply", "i3d_debug_counters", "i3d_debug_cull_stats"]
+           "i3d_debug_normal_eq", "i3d_debug_jtj_apply", "i3d_debug_counters", "i3d_debug_cull_stats", "i3d_debug_ladder_stats"]
 
 _lib = None
 
@@ -137,6 +137,7 @@ def load():
     L.i3d_debug_normal_eq.restype = i32; L.i3d_debug_normal_eq.argtypes = [vp, vp, vp, C.POINTER(f64)]
     L.i3d_debug_jtj_apply.restype = i32; L.i3d_debug_jtj_apply.argtypes = [vp, vp, vp]
     L.i3d_debug_counters.restype = i32; L.i3d_debug_counters.argtypes = [vp, vp]
+    L.i3d_debug_ladder_stats.restype = i32; L.i3d_debug_ladder_stats.argtypes = [vp, vp]
     L.i3d_debug_cull_stats.restype = i32; L.i3d_debug_cull_stats.argtypes = [vp, vp, vp]
     L.i3d_set_grid_from_tsdf_records.restype = i32; L.i3d_set_grid_from_tsdf_records.argtypes = [vp, f32, i64, vp, vp, vp, vp]
     L.i3d_recompute_colors.restype = i32; L.i3d_recompute_colors.argtypes = [vp, f32, i32]
@@ -468,6 +469,12 @@ class Context:
         n = C.c_int64(0)
         self._check(self.L.i3d_debug_counters(self.h, C.byref(n)), "i3d_debug_counters")
         return {"stream_syncs": int(n.value)}
+
+    def debug_ladder_stats(self):
+        """the damping ladder since the context was created: batches, row streams, system passes (= the streams of the serial loop), re-solved batches, unused systems, depth"""
+        a = (C.c_int64 * 6)()
+        self._check(self.L.i3d_debug_ladder_stats(self.h, a), "i3d_debug_ladder_stats")
+        return {"batches": int(a[0]), "row_streams": int(a[1]), "system_passes": int(a[2]), "resyncs": int(a[3]), "unused_systems": int(a[4]), "depth": int(a[5])}
 
     def debug_cull_stats(self):
         """(group, keyframe) pairs of the last assemble and how many the observation pass skipped (-1: culling off)."""

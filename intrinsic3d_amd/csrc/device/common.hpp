@@ -167,21 +167,29 @@ struct PcgState {
 
 // Device-resident state of one NLSSolver::solve (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy as configured by nls_solver.cpp:296-337):
 // the trust-region bookkeeping runs in one-thread kernels (lm_kernels.hip), the host only queues launches and polls one record per attempt.
+// The damping ladder (solver.cpp lm_solve): the reference restarts the trust region at 1e4 in every outer iteration (optimizer.cpp:138), so most LM attempts are
+// rejected, and after a rejection the next radius is known in advance (radius /= decrease_factor, decrease_factor *= 2: LevenbergMarquardtStrategy::StepRejected).
+// Up to LADDER_MAX consecutive attempts are therefore SOLVED together — PCG systems that differ only in the LM diagonal, iterated in lock step so that one stream of
+// J serves several of them (tile_pass_mr.hip) — and then DECIDED one after the other exactly as the serial loop would.
+constexpr int LADDER_MAX = 6;
 struct LmState {
     double cost;                    // cost at the current point
     double radius, decrease_factor; // trust-region radius, its reduction factor after a rejected step (doubles every time)
     double ngrad, nfree;            // free parameters whose gradient entry exceeds Ceres' gradient_tolerance (max-norm test: 0 = converged), free parameters at the start
     float  inv_radius; int pad0;    // (float)(1 / radius) of the attempt in flight: what the vector kernels read
-    int done;                       // 0 running | 1 the solve is over: every later kernel of it returns at once
+    int done;                       // 0 running | 1 the solve is over: every later kernel of it returns at once | 2 the ladder is out of step (an invalid step halved the
+                                    // radius instead): the rest of the batch is skipped and the host starts a new batch at the current radius (k_lm_begin_lad clears it)
     int termination;                // i3d_iteration_stats::termination: 0 step limit | 1 converged (tolerances, radius) | 2 successful step (the callback) | 3 invalid steps
     int accepted;                   // the deciding attempt accepted its candidate (k_accept applies it)
     int invalid;                    // consecutive invalid steps (max_num_consecutive_invalid_steps = 5)
     int attempts;                   // attempts decided
     int successful;
+    // ladder batch in flight: the radius each of its systems was solved with (system j = the attempt after j rejections), what the vector kernels read of it
+    double lad_radius[LADDER_MAX]; float lad_inv_radius[LADDER_MAX]; int lad_n; int pad1;
 };
 struct LmRecord {                   // one per attempt (index 0: the initial tests), in mapped host memory; `seq` is stored last with release semantics
     int seq; int final_;            // final_: the solve ended here
-    int accepted; int pcg_it; int termination; int kind;      // kind: 0 init | 1 decided attempt | 2 ended before the attempt (radius underflow)
+    int accepted; int pcg_it; int termination; int kind;      // kind: 0 init | 1 decided attempt | 2 ended before the attempt (radius underflow) | 3 ladder out of step: attempt NOT decided, solve it again
     double cost, cand_cost, model_change, rel, radius_after, ngrad, nfree;
 };
 

@@ -113,6 +113,7 @@ struct TilePlan {                   // built once per outer iteration by launch_
     // that contribute to it, CSR by halo slot, each segment sorted — the slot's owner thread adds them in that fixed order
     const unsigned short* hp_off;   // [tiles][hmax + 1]
     const unsigned short* hp_src;   // [tiles][4 * hmax]: (column << 10) | lane; column 0..8 sdf, 9..11 albedo, 12 the Er row value
+    int pull;                       // 1: the single-system pass pulls its halo over the lists too (I3D_HALO_PULL=1 / the bit-reproducible mode); 0: the lists (if any) only serve the multi-system pass
 };
 inline int tile_plan_pull_cap(int hmax) { return 4 * hmax; }      // list entries per tile (= the LDS the pushed halo accumulators occupied)
 int    tile_plan_T();                      // default geometry (I3D_EGT_TILE): entries per tile
@@ -128,6 +129,13 @@ void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t, const int* cflag /* s
 int  launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials /* or null */,
                     const PcgState* state, float* cam_partials = nullptr, int cam_stride = 0);
 void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext_off);
+void eg_tile_launch_shape(const TilePlan& t, int K, int& blocks, int& tiles_per_block);      // workgroups / tiles per workgroup launch_eg_tile uses for this plan
+
+// ---- tile_pass_mr.hip: the operator pass for up to 3 systems of a ladder batch in ONE stream of the rows (512-entry geometry with pull lists, 5 observation slots, single rank) ----
+struct LadVec;
+int  eg_tile_mr_max_systems(int K);        // systems one launch can take at K keyframes (LDS): 3 at K = 200, 0 = the pass cannot run
+int  launch_eg_tile_mr(hipStream_t st, RowView r, OptParams p, TilePlan t, int nsys, const int* sys, const float* u0, float* qacc0, float* qh0, double* pq0 /* or null */, float* cam0, int cam_stride,
+                       const PcgState* st0 /* system 0's state of this pass's parity */, const LadVec& lv);      // returns the workgroups (= p.q partials / camera rows per system), 0 = not launched
 
 // ---- pcg_fused.hip: the PCG iteration in three launches (single rank): k_pcg_dir3 | k_eg_tile | k_pcg_step3 -----------------------
 // sharded three-launch pass over the peer-to-peer mailboxes: what k_pcg_dir3 / k_pcg_step3 need besides their single-rank arguments (the exchanges run INSIDE them)
@@ -136,6 +144,16 @@ struct ShardArgs {
     int n_slice_partials;                   // k_pcg_dir3: step partials [0, n) are sums over this rank's slice, the rest the (replicated) camera tail's
     int n_rim_wg;                           // k_pcg_dir3: workgroups that exchange the rim
     const float* zb; float* pb; float* ub; const float* cmb; int chunk;      // whole vectors (rim entries are addressed absolutely)
+};
+// ladder batch (common.hpp LADDER_MAX): system j's copy of every per-system array starts j * stride elements behind system 0's
+struct LadVec {
+    size_t vec;                             // solver vectors x, r, p, z, u, qacc (floats; a multiple of 4)
+    size_t qh;                              // halo sums of the operator pass (floats; even)
+    size_t cam;                             // camera partial rows of the operator pass (floats)
+    size_t part;                            // fp64 partial sums: the step / p.q / D^2 p^2 regions of a system (doubles)
+    size_t mblk;                            // block-Jacobi inverses of the camera blocks (floats)
+    size_t tail;                            // LM diagonal of the camera tail (floats)
+    int sysid[LADDER_MAX];                  // launch slot (blockIdx.y, or the slot of a multi-system operator pass) -> system
 };
 struct Step3Args {
     int nq; int chunk4;
@@ -150,6 +168,7 @@ struct Step3Args {
     double* step_partials;
     PcgState* cur;
     int sharded; ShardArgs sh;              // sharded: p.q and the camera block are summed over the ranks inside the kernel; d2_partials[n_d2] = the camera tail's D^2 p^2 (replicated, counted once)
+    int lad_sys;                            // -1: 1 / radius from lm->inv_radius; >= 0: system of a ladder batch, lm->lad_inv_radius[lad_sys]
 };
 void launch_pcg_init3(hipStream_t st, PcgState* st2 /* [2] */, int fixed_iterations, int max_iterations, const LmState* lm = nullptr);
 int  launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, const LmState* lm,
@@ -160,6 +179,11 @@ int  pcg_step3_slice_wgs(int n_entries, int cap = 0);      // cap > 0: at most t
 int  pcg_step3_tail_wgs(int K);
 int  launch_pcg_step3(hipStream_t st, int mode /* 0 init | 1 normal | 2 x only | 3 reset */, Step3Args a);                                          // returns #[4]-partials
 void launch_halo_fold(hipStream_t st, RowView r, TilePlan t, float* qacc, const PcgState* state);
+// ladder batch: the same kernels over several systems at once (blockIdx.y; the arithmetic of a system does not change)
+void launch_pcg_init_lad(hipStream_t st, PcgState* st2_all /* [LADDER_MAX][2] */, int B, int fixed_iterations, int max_iterations, const LmState* lm);
+int  launch_pcg_dir3_lad(hipStream_t st, bool init, int nsys, Seg2 sg, size_t tail_off, int ntail, const float* z0, float* p0, const float* S, float* u0, const float* tD2_0, const float* cm, const LmState* lm,
+                         const double* step_partials0, int n_step, double* d2_partials0, PcgState* st2_0, int prev_parity, int* host_flags0, int seq, const LadVec& lv);
+int  launch_pcg_step3_lad(hipStream_t st, int mode, int nsys, Step3Args a, const LadVec& lv);
 
 // ---- shard_kernels.hip: the sharding plan of one outer iteration ----------------------------------------------------------------
 void launch_need_mask(hipStream_t st, RowView r, int slice, unsigned long long* need /* [A], zeroed */);
@@ -177,7 +201,10 @@ void launch_lm_begin(hipStream_t st, LmState* lm, int K, int fix_poses, int fix_
                      const float* tc, const float* tS, float* tD2, float* tMinv, LmRecord* rec, int seq);
 void launch_lm_diag_dev(hipStream_t st, int n, const float* c, const float* S, const LmState* lm, float* D2, float* Minv);
 void launch_cand_frames(hipStream_t st, int K, const double* xc, const FrameConst* base, FrameConst* out, const LmState* lm);
-void launch_lm_decide(hipStream_t st, LmState* lm, const PcgState* ps, const double* norms2, const double* cand_cost, int attempt, int lm_steps, LmRecord* rec, int seq);
+void launch_lm_decide(hipStream_t st, LmState* lm, const PcgState* ps, const double* norms2, const double* cand_cost, int attempt, int lm_steps, LmRecord* rec, int seq,
+                      int lad_next = -1 /* ladder batch: index of the next system (look-ahead), -1 = serial loop */, int debug_invalid = 0);
+void launch_lm_begin_lad(hipStream_t st, LmState* lm, int B, int K, int fix_poses, int fix_intr, int fix_dist, const double* cdiag, const double* tri, float* Mblk, size_t mblk_stride,
+                         const float* tc, const float* tS, float* tD2, size_t tail_stride, LmRecord* rec, int seq);
 void launch_mark_compute(hipStream_t st, RowView r, int* flag);
 void launch_compact_list(hipStream_t st, int A, const int* flag, const int* scan, int* list);
 

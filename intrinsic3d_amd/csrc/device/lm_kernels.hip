@@ -90,6 +90,42 @@ void launch_lm_begin(hipStream_t st, LmState* lm, int K, int fix_poses, int fix_
     k_lm_begin<<<(K + 2 + 63) / 64, 64, 0, st>>>(lm, K, fix_poses, fix_intr, fix_dist, cdiag, tri, Mblk, tc, tS, tD2, tMinv, rec, seq);
 }
 
+// The same for a LADDER batch of B consecutive attempts (common.hpp: LADDER_MAX): system j (blockIdx.y) gets the radius the trust region will have after j
+// rejections from its current state — radius / decrease_factor, decrease_factor * 2, replayed in the strategy's own arithmetic (k_lm_decide), so system j is solved
+// with bit for bit the radius the serial loop would reach — its 1/radius for the vector kernels, its damped block-Jacobi inverses and the LM diagonal of its camera
+// tail.  A system whose radius has run out (< 1e-32) gets inv_radius 0 and no work: its PCG starts finished (k_pcg_init_lad), the decision chain ends the solve
+// where the serial loop would (k_lm_decide's look-ahead).  Clears the out-of-step state of the previous batch.
+__global__ void __launch_bounds__(64) k_lm_begin_lad(LmState* lm, int B, int K, int fix_poses, int fix_intr, int fix_dist, const double* __restrict__ cdiag, const double* __restrict__ tri,
+                                                     float* __restrict__ Mblk, size_t mblk_stride, const float* __restrict__ tc, const float* __restrict__ tS, float* __restrict__ tD2, size_t tail_stride,
+                                                     LmRecord* rec, int seq) {
+    if (lm->done == 1) return;
+    const int j = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x;
+    double radius = lm->radius, dec = lm->decrease_factor;
+    if (j == 0 && radius < 1e-32) {      // the first attempt of the batch: exactly k_lm_begin's test
+        if (gid == 0) {
+            lm->termination = 1; lm->done = 1; lm->lad_n = 0;
+            if (rec) { rec->final_ = 1; rec->accepted = 0; rec->pcg_it = 0; rec->termination = 1; rec->kind = 2; rec->cost = lm->cost; rec->cand_cost = 0.0; rec->model_change = 0.0; rec->rel = 0.0;
+                       rec->radius_after = radius; rec->ngrad = lm->ngrad; rec->nfree = lm->nfree; lm_publish(rec, seq); }
+        }
+        return;
+    }
+    for (int s = 0; s < j; ++s) { radius = radius / dec; dec *= 2.0; }
+    const bool dead = radius < 1e-32;
+    const float inv_radius = dead ? 0.0f : (float)(1.0 / radius);
+    if (gid == 0) { lm->lad_radius[j] = radius; lm->lad_inv_radius[j] = inv_radius; if (j == 0) { lm->lad_n = B; lm->inv_radius = inv_radius; lm->done = 0; } }
+    if (dead) return;
+    float* const Mb = Mblk + (size_t)j * mblk_stride;
+    if (gid < K) cam_block_inverse(6, cdiag + 6 * gid, tri + 21 * gid, fix_poses != 0, radius, Mb + 36 * (size_t)gid);
+    else if (gid == K) cam_block_inverse(4, cdiag + 6 * K, tri + 21 * K, fix_intr != 0, radius, Mb + 36 * (size_t)K);
+    else if (gid == K + 1) cam_block_inverse(5, cdiag + 6 * K + 4, tri + 21 * K + 10, fix_dist != 0, radius, Mb + 36 * (size_t)K + 16);
+    const int NS = 6 * K + 9;
+    for (int i = gid; i < NS; i += gridDim.x * blockDim.x) { float d2, mi; lm_diag(tc[i], tS[i], inv_radius, d2, mi); tD2[(size_t)j * tail_stride + i] = d2; }
+}
+void launch_lm_begin_lad(hipStream_t st, LmState* lm, int B, int K, int fix_poses, int fix_intr, int fix_dist, const double* cdiag, const double* tri, float* Mblk, size_t mblk_stride,
+                         const float* tc, const float* tS, float* tD2, size_t tail_stride, LmRecord* rec, int seq) {
+    k_lm_begin_lad<<<dim3((K + 2 + 63) / 64, B), 64, 0, st>>>(lm, B, K, fix_poses, fix_intr, fix_dist, cdiag, tri, Mblk, mblk_stride, tc, tS, tD2, tail_stride, rec, seq);
+}
+
 // LM diagonal + 1x1 block-Jacobi inverses of the whole vector at the radius of the attempt in flight (sharded / untiled solve: the three-launch pass recomputes
 // them from the column norms instead)
 __global__ void k_lm_diag_dev(int n, const float* __restrict__ c, const float* __restrict__ S, const LmState* __restrict__ lm, float* __restrict__ D2, float* __restrict__ Minv) {
@@ -121,8 +157,12 @@ void launch_cand_frames(hipStream_t st, int K, const double* xc, const FrameCons
 // One attempt decided (TrustRegionMinimizer::Minimize after the linear solve; the reference stops after the first successful step, nls_solver.cpp:279-293).
 //   ps      terminal state of the PCG solve (x.(b+r), sum D^2 x^2 -> model_cost_change = -(J s)^T (r + J s / 2), s = -x)
 //   norms2  |delta|^2, |x|^2 over the free parameters (k_candidate);  cand_cost: cost at the candidate (k_build<false>, all-reduced when sharded)
+//   lad_next >= 0: this attempt is system lad_next - 1 of a ladder batch.  A rejection must leave the radius system lad_next was solved with; anything else (an invalid
+//           step halves the radius) puts the batch out of step: done = 2, the NEXT attempt's record says "not decided" (kind 3) and the host solves it again alone.
+//           The radius-underflow test k_lm_begin makes at the start of an attempt is made here for the next system of the batch, into the same record.
+//   debug_invalid: tests only — treat this attempt's step as invalid (model_cost_change <= 0)
 __global__ void k_lm_decide(LmState* lm, const PcgState* __restrict__ ps, const double* __restrict__ norms2, const double* __restrict__ cand_cost_p, int attempt /* 0-based */, int lm_steps,
-                            LmRecord* rec, int seq) {
+                            LmRecord* rec, int seq, int lad_next, int debug_invalid) {
     if (lm->done) return;
     const int pcg_it = ps->done == 2 ? ps->it + 1 : ps->it;          // Ceres counts the iteration it broke in
     const double xbr = ps->xbr, d2xx = ps->d2xx;
@@ -132,8 +172,8 @@ __global__ void k_lm_decide(LmState* lm, const PcgState* __restrict__ ps, const 
     const double cand = *cand_cost_p;
     int final_ = 0, accepted = 0, termination = lm->termination, invalid = lm->invalid, successful = lm->successful;
     double rel = 0.0;
-    if (!finite || !(model_change > 0.0)) {                          // invalid step (max_num_consecutive_invalid_steps = 5)
-        if (++invalid > 5) { termination = 3; final_ = 1; }
+    if (!finite || !(model_change > 0.0) || debug_invalid) {         // invalid step; TrustRegionMinimizer::HandleInvalidStep fails on the 5th in a row (++n >= max_num_consecutive_invalid_steps = 5)
+        if (++invalid >= 5) { termination = 3; final_ = 1; }
         else radius *= 0.5;
     } else {
         invalid = 0;
@@ -158,9 +198,21 @@ __global__ void k_lm_decide(LmState* lm, const PcgState* __restrict__ ps, const 
         rec->cost = cost; rec->cand_cost = cand; rec->model_change = model_change; rec->rel = rel; rec->radius_after = radius; rec->ngrad = lm->ngrad; rec->nfree = lm->nfree;
         lm_publish(rec, seq);
     }
+    if (!final_ && lad_next >= 0 && lad_next < lm->lad_n) {          // the next system of the batch
+        LmRecord* const nrec = rec ? rec + 1 : nullptr;
+        if (radius != lm->lad_radius[lad_next]) {
+            lm->done = 2;
+            if (nrec) { nrec->final_ = 0; nrec->accepted = 0; nrec->pcg_it = 0; nrec->termination = termination; nrec->kind = 3; nrec->cost = cost; nrec->cand_cost = 0.0; nrec->model_change = 0.0;
+                        nrec->rel = 0.0; nrec->radius_after = radius; nrec->ngrad = lm->ngrad; nrec->nfree = lm->nfree; lm_publish(nrec, seq + 1); }
+        } else if (radius < 1e-32) {                                 // LevenbergMarquardtStrategy: the radius cannot shrink further (k_lm_begin's test, for the attempt that would start now)
+            lm->termination = 1; lm->done = 1;
+            if (nrec) { nrec->final_ = 1; nrec->accepted = 0; nrec->pcg_it = 0; nrec->termination = 1; nrec->kind = 2; nrec->cost = cost; nrec->cand_cost = 0.0; nrec->model_change = 0.0;
+                        nrec->rel = 0.0; nrec->radius_after = radius; nrec->ngrad = lm->ngrad; nrec->nfree = lm->nfree; lm_publish(nrec, seq + 1); }
+        }
+    }
 }
-void launch_lm_decide(hipStream_t st, LmState* lm, const PcgState* ps, const double* norms2, const double* cand_cost, int attempt, int lm_steps, LmRecord* rec, int seq) {
-    k_lm_decide<<<1, 1, 0, st>>>(lm, ps, norms2, cand_cost, attempt, lm_steps, rec, seq);
+void launch_lm_decide(hipStream_t st, LmState* lm, const PcgState* ps, const double* norms2, const double* cand_cost, int attempt, int lm_steps, LmRecord* rec, int seq, int lad_next, int debug_invalid) {
+    k_lm_decide<<<1, 1, 0, st>>>(lm, ps, norms2, cand_cost, attempt, lm_steps, rec, seq, lad_next, debug_invalid);
 }
 
 }  // namespace i3d

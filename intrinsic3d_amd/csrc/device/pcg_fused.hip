@@ -76,11 +76,13 @@ static __device__ inline void lm_from_colnorm(float cm, float inv_radius, float&
 //     all entries, so S is local).  Round 3 pushed u = S p with a launch of its own after the direction kernel, between two all-reduce launches.
 // Workgroup roles (SH), by blockIdx: [0, n_rim) rim | n_rim .. n_rim + n_main - 1 the slice | the last one the camera tail.  Their partial sums of D^2 p^2 land
 // at [0, n_main) (slice) and [n_main] (tail, counted once by k_pcg_step3 after ITS exchange).
+// (the body of the kernel: shared by the single-system launch and the ladder launch, whose workgroups pick their system by blockIdx.y — the SAME arithmetic in the
+// same order, so a system iterated in a ladder batch goes through bit for bit the states it goes through alone)
 template <bool SH>
-__global__ void __launch_bounds__(PF_THREADS, SH ? 4 : 1) k_pcg_dir3(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
-                                                        const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ D2 /* S, D2: the camera tail */,
-                                                        const float* __restrict__ cm, const LmState* __restrict__ lm, const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
-                                                        const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq, ShardArgs sa) {
+static __device__ __forceinline__ void pcg_dir3_body(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
+                                                        const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ tD2 /* LM diagonal of the camera tail, [ntail] */,
+                                                        const float* __restrict__ cm, const float inv_radius, const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
+                                                        const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq, const ShardArgs& sa) {
     __shared__ double sm[4 * 8];
     __shared__ double smx[SH ? 4 * P2P_MAX_RANKS : 1];
     // (seq, done) goes to a 2-slot ring in pinned host memory: the host polls it one pass behind
@@ -94,7 +96,6 @@ __global__ void __launch_bounds__(PF_THREADS, SH ? 4 : 1) k_pcg_dir3(int init, i
     const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
     const float4* C4 = reinterpret_cast<const float4*>(cm); float4* u4 = reinterpret_cast<float4*>(u);
     if (prev->done) { if (writer) { *next = *prev; publish(prev->done); } return; }      // (the same decision on every rank: the state is replicated bit for bit)
-    const float inv_radius = lm->inv_radius;                         // (uniform: a scalar load)
     double tot[4];
     if (!SH) reduce_partials_all<4>(step_partials, n_step, tot, sm);
     else {
@@ -176,10 +177,28 @@ __global__ void __launch_bounds__(PF_THREADS, SH ? 4 : 1) k_pcg_dir3(int init, i
         for (int t = threadIdx.x; t < ntail; t += PF_THREADS) {
             const size_t i = tail_rel + t;
             const float pi = first ? z[i] : z[i] + betaf * p[i]; p[i] = pi; u[i] = S[i] * pi;
-            d2 += (double)D2[i] * (double)pi * (double)pi;
+            d2 += (double)tD2[t] * (double)pi * (double)pi;
         }
     }
     { const double t = block_sum_d(d2); if (threadIdx.x == 0) d2_partials[lid] = t; }
+}
+template <bool SH>
+__global__ void __launch_bounds__(PF_THREADS, SH ? 4 : 1) k_pcg_dir3(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
+                                                        const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ D2 /* S, D2: the camera tail */,
+                                                        const float* __restrict__ cm, const LmState* __restrict__ lm, const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
+                                                        const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq, ShardArgs sa) {
+    pcg_dir3_body<SH>(init, n4, seg4, tail_rel, ntail, z, p, S, u, D2 + tail_rel, cm, lm->inv_radius /* (uniform: a scalar load) */, step_partials, n_step, d2_partials, prev, next, host_flags, seq, sa);
+}
+// ladder batch (single rank): blockIdx.y picks the system; its vectors, partial sums, scalar states and host ring lie at fixed strides behind system 0's
+__global__ void __launch_bounds__(PF_THREADS, 1) k_pcg_dir3_lad(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z0, float* __restrict__ p0,
+                                                        const float* __restrict__ S, float* __restrict__ u0, const float* __restrict__ tD2_0, const float* __restrict__ cm, const LmState* __restrict__ lm,
+                                                        const double* __restrict__ step_partials0, int n_step, double* __restrict__ d2_partials0, PcgState* __restrict__ st2_0 /* [system][2] */, int prev_parity,
+                                                        int* host_flags0, int seq, LadVec lv) {
+    const int j = lv.sysid[blockIdx.y];
+    ShardArgs none; none.n_rim_wg = 0;
+    const size_t vo = (size_t)j * lv.vec;
+    pcg_dir3_body<false>(init, n4, seg4, tail_rel, ntail, z0 + vo, p0 + vo, S, u0 + vo, tD2_0 + (size_t)j * lv.tail, cm, lm->lad_inv_radius[j], step_partials0 + (size_t)j * lv.part, n_step,
+                         d2_partials0 + (size_t)j * lv.part, st2_0 + 2 * j + prev_parity, st2_0 + 2 * j + (prev_parity ^ 1), host_flags0 + 4 * j, seq, none);
 }
 
 static int dir3_main_wgs(int n_entries, int cap) { int b = (n_entries / 2 + PF_THREADS - 1) / PF_THREADS; b = b < 1 ? 1 : b; return b > cap ? cap : b; }      // 2 * (n / 4) float4 items
@@ -199,6 +218,17 @@ int launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int nta
     k_pcg_dir3<true><<<sa->n_rim_wg + n_main + 1, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, lm, step_partials, n_step, d2_partials, prev, next,
                                                                        host_flags, seq, *sa);
     return n_main;
+}
+
+// all systems of `lv` in one launch; returns the number of D^2 p^2 partials per system
+int launch_pcg_dir3_lad(hipStream_t st, bool init, int nsys, Seg2 sg, size_t tail_off, int ntail, const float* z0, float* p0, const float* S, float* u0, const float* tD2_0, const float* cm, const LmState* lm,
+                        const double* step_partials0, int n_step, double* d2_partials0, PcgState* st2_0, int prev_parity, int* host_flags0, int seq, const LadVec& lv) {
+    const int n4 = sg.n >> 2, seg4 = (int)((sg.off1 - sg.off0) >> 2);
+    const size_t o = sg.off0;
+    const int blocks = dir3_main_wgs(sg.n, PF_MAX_WG);
+    k_pcg_dir3_lad<<<dim3(blocks, nsys), PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z0 + o, p0 + o, S + o, u0 + o, tD2_0, cm + o, lm, step_partials0, n_step, d2_partials0,
+                                                              st2_0, prev_parity, host_flags0, seq, lv);
+    return blocks;
 }
 
 // residual-reset passes of a sharded run: the rim of the operator input u = S x (k_pcg_dir3's rim workgroups move z, not u).  Once per ten passes.
@@ -248,7 +278,7 @@ template <int MODE> static __device__ inline void s3_load(const Step3Args& a, in
 // ranks in the prologue of EVERY workgroup (workgroup 0 stores it into all mailboxes), and the camera workgroups sum their columns of the operator's camera
 // block over the ranks before they update the (replicated) camera tail.  No launch of its own, no vector leaves a rank.
 template <int MODE, bool SH>
-__global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
+static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
     __shared__ double sm[4 * 8];
     __shared__ double smx[SH ? P2P_MAX_RANKS : 1];
     __shared__ double camv[64];
@@ -265,7 +295,7 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
     if (threadIdx.x == 0) done_s = cur->done;
     __syncthreads();
     if (done_s) return;
-    const float inv_radius = a.lm->inv_radius;                       // (uniform: a scalar load)
+    const float inv_radius = a.lad_sys >= 0 ? a.lm->lad_inv_radius[a.lad_sys] : a.lm->inv_radius;      // (uniform: a scalar load)
     float alpha = 0.0f;
     if (MODE == S3_NORMAL || MODE == S3_XONLY) {                     // p.q = sum over rows of t (J u) + sum D^2 p^2  ->  alpha = rho / p.q
         double t1[1];
@@ -405,6 +435,22 @@ __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) {
     if (MODE == S3_XONLY) return;
     block_partial_d(s0, a.step_partials, 4, 0); block_partial_d(s1, a.step_partials, 4, 1); block_partial_d(s2, a.step_partials, 4, 2); block_partial_d(s3, a.step_partials, 4, 3);
 }
+template <int MODE, bool SH>
+__global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) { pcg_step3_body<MODE, SH>(a); }
+// ladder batch (single rank): blockIdx.y picks the system (see k_pcg_dir3_lad); `a0` holds system 0's pointers
+template <int MODE>
+__global__ void __launch_bounds__(PF_THREADS) k_pcg_step3_lad(Step3Args a0, LadVec lv) {
+    const int j = lv.sysid[blockIdx.y];
+    Step3Args a = a0;
+    const size_t v4 = ((size_t)j * lv.vec) >> 2, vo = (size_t)j * lv.vec, po = (size_t)j * lv.part;
+    a.p += v4; a.qacc += v4; a.x += v4; a.r += v4; a.z += v4;
+    a.qh += ((size_t)j * lv.qh) >> 1;
+    a.pq_partials += po; a.d2_partials += po; a.step_partials += po;
+    a.cam_partials += (size_t)j * lv.cam; a.Mblk += (size_t)j * lv.mblk;
+    a.tp += vo; a.tx += vo; a.tr += vo; a.tz += vo; a.tD2 += (size_t)j * lv.tail;
+    a.cur += 2 * j; a.lad_sys = j;
+    pcg_step3_body<MODE, false>(a);
+}
 
 int pcg_step3_slice_wgs(int n_entries, int cap) { if (cap <= 0 || cap > PF_MAX_WG) cap = PF_MAX_WG; int b = (n_entries / 4 + PF_THREADS - 1) / PF_THREADS; return b < 1 ? 1 : (b > cap ? cap : b); }
 int pcg_step3_tail_wgs(int K) { return (K + PF_POSES_PER_WG - 1) / PF_POSES_PER_WG + 1; }
@@ -422,6 +468,33 @@ int launch_pcg_step3(hipStream_t st, int mode, Step3Args a) {
 #undef I3D_S3
     return mode == S3_XONLY ? 0 : blocks;
 }
+
+// all systems of `lv` in one launch (a.cur = system 0's state of this pass's parity); returns the number of [4]-partials per system (0 in XONLY mode)
+int launch_pcg_step3_lad(hipStream_t st, int mode, int nsys, Step3Args a, const LadVec& lv) {
+    const int blocks = a.n_slice_wg + pcg_step3_tail_wgs(a.K);
+    const dim3 grid(blocks, nsys);
+    switch (mode) {
+        case S3_INIT:   k_pcg_step3_lad<S3_INIT><<<grid, PF_THREADS, 0, st>>>(a, lv); break;
+        case S3_NORMAL: k_pcg_step3_lad<S3_NORMAL><<<grid, PF_THREADS, 0, st>>>(a, lv); break;
+        case S3_XONLY:  k_pcg_step3_lad<S3_XONLY><<<grid, PF_THREADS, 0, st>>>(a, lv); break;
+        default:        k_pcg_step3_lad<S3_RESET><<<grid, PF_THREADS, 0, st>>>(a, lv); break;
+    }
+    return mode == S3_XONLY ? 0 : blocks;
+}
+
+// ladder batch: both states of every system; a system whose radius has run out (k_lm_begin_lad) starts finished
+__global__ void k_pcg_init_lad(PcgState* st2_all, int B, int fixed_iterations, int max_iterations, const LmState* lm) {
+    const int j = threadIdx.x;
+    if (j >= B) return;
+    const bool over = lm->done != 0 || lm->lad_radius[j] < 1e-32;
+    for (int b = 0; b < 2; ++b) {
+        PcgState* st = st2_all + 2 * j + b;
+        for (int k = 0; k < 4; ++k) st->acc[k] = 0.0;
+        st->rho = 0.0; st->last_rho = 1.0; st->pq = 0.0; st->alpha = 0.0; st->beta = 0.0; st->xbr = 0.0; st->xr = 0.0; st->d2xx = 0.0;
+        st->Q0 = 0.0; st->Q1 = 0.0; st->it = 0; st->done = (fixed_iterations == 0 || over) ? 1 : 0; st->fixed_iterations = fixed_iterations; st->max_iterations = max_iterations;
+    }
+}
+void launch_pcg_init_lad(hipStream_t st, PcgState* st2_all, int B, int fixed_iterations, int max_iterations, const LmState* lm) { k_pcg_init_lad<<<1, LADDER_MAX, 0, st>>>(st2_all, B, fixed_iterations, max_iterations, lm); }
 
 // plan side of the fold: ext_off[e] = index of the first (entry, halo slot) pair whose entry is >= e, e in [0, A]: one lower-bound search per entry over the
 // sorted keys (the keys of a plan that overflowed are not entries: they compare like any other integer and nothing is written outside [0, A])

@@ -21,6 +21,7 @@
 #include "kernels.hpp"
 #include "reduce_device.hpp"
 #include "wave_ops.hpp"
+#include "tile_device.hpp"
 #include <rocprim/rocprim.hpp>
 
 namespace i3d {
@@ -124,18 +125,6 @@ __global__ void __launch_bounds__(256) k_eaw_sym(RowView r, const int* __restric
 }
 
 // ---- the pass ---------------------------------------------------------------------------------------------------------------------
-struct RowBlock { float4 p[7]; float j28; int tag; };  // one stored Eg row in registers: planes 0..6 + column 28 + keyframe tag
-typedef unsigned v4u_b __attribute__((ext_vector_type(4)));
-typedef unsigned v2u_b __attribute__((ext_vector_type(2)));
-// local slot j of an entry's packed plan words (12 bits each, LSB first; j is a compile-time constant after unrolling: one v_bfe_u32, or v_alignbit + v_and
-// for the slots that straddle a word)
-template <int NW> static __device__ inline int unpack12(const unsigned (&w)[NW], int j) {
-    const int bit = 12 * j, k = bit >> 5, sh = bit & 31;
-    if (sh <= 20) return (int)((w[k] >> sh) & 0xFFFu);
-    return (int)(((w[k] >> sh) | (w[k + 1 < NW ? k + 1 : k] << (32 - sh))) & 0xFFFu);
-}
-template <int Z> struct AllZ { unsigned w[LNBR_WORDS]; constexpr AllZ() : w{} { for (int j = 0; j < 18; ++j) { const int bit = 12 * j, k = bit >> 5, sh = bit & 31; w[k] |= (unsigned)Z << sh; if (sh > 20) w[k + 1] |= (unsigned)Z >> (32 - sh); } } };
-
 // Halo PULL lists (round 4, I3D_HALO_PULL=1 / the bit-reproducible mode).  What a tile's rows add to entries OUTSIDE the tile went through LDS float atomics into
 // per-tile halo accumulators — in whatever order the waves arrive, the one order-dependent sum of the default operator pass besides the pose block, and ~70 cycles per
 // wave-instruction.  The targets are known at plan time: lane L's stencil slot j points at local slot ls (>= T: halo slot ls - T).  This kernel inverts that map per
@@ -675,29 +664,59 @@ hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, s
 // after the build kernel has written the Ea weights of this outer iteration
 void launch_eaw_sym(hipStream_t st, RowView r, TilePlan t, const int* cflag) { if (r.A > 0) k_eaw_sym<<<(r.A + 255) / 256, 256, 0, st>>>(r, cflag, t.eaw_sym); }
 
+// LDS request and launch shape of the pass for a plan: shared with the multi-system pass (tile_pass_mr.hip), whose per-workgroup partial rows must be the ones a
+// system gets from this kernel
+struct EgtShape { int detm, reps, per_cu, blocks, tiles_per_block; size_t lds; };
 template <int T, int HMAX>
-static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state, int num_cu,
-                            float* cam_partials, int cam_stride) {
-    const int nshared = 6 * p.K + 9, rs = (6 * p.K) | 1;
-    // I3D_DETERMINISTIC=1: fixed-order sums inside the workgroup as well (ordered halo pushes, per-wave keyframe tables) — every kernel of an outer iteration is then
-    // bit-reproducible from run to run (tools/flake_hunt.py: 0.0 on every field) at ~20 % lower throughput; the default keeps the LDS atomics of round 3 HERE and
-    // only here (gradient, column norms, SH Gram blocks, camera block and halo fold across workgroups are fixed-order in both modes)
-    // halo sums: pushed with LDS atomics (default), or PULLED over the plan's lists (t.hp_off: I3D_HALO_PULL=1, and always in the bit-reproducible mode, where the pull
-    // replaces the ordered pushes of the first version — I3D_EGT_ORDERED=1 brings those back for A/B runs)
+static EgtShape egt_shape(const TilePlan& t, int K, int num_cu) {
+    const int nshared = 6 * K + 9, rs = (6 * K) | 1;
     static const bool ordered = [] { const char* e = std::getenv("I3D_EGT_ORDERED"); return e && e[0] == '1'; }();
-    const bool pull = t.hp_off != nullptr && !(t.det && ordered);
-    const int detm = t.det ? (pull ? 6 : 3) : (pull ? 4 : 0);
-    const bool det = (detm & 3) != 0;
+    const bool pull = t.pull && t.hp_off != nullptr && !(t.det && ordered);
+    EgtShape s; s.detm = t.det ? (pull ? 6 : 3) : (pull ? 4 : 0);
+    const bool det = (s.detm & 3) != 0;
     constexpr int NW = T / 64, TC = T == 1024 ? 64 : 32;
     const int det_words = det ? 4 + ((NW * 9 + 3) & ~3) + NW * TC * 7 : 0;      // ticket, per-wave camera sums, per-wave keyframe tables (at the front of the LDS)
     auto lds_bytes = [&](int reps) { const int nacc = det_words + reps * rs + 9; const int o_upose = (nacc + 3) & ~3, o_u = (o_upose + nshared + 3) & ~3;
                                      return (size_t)(o_u + 2 * (T + HMAX + 1) + 2 * HMAX + T + 4 + 12 * T + 2 * T /* p.q per lane, fp64 */ + (pull ? (HMAX + 4) / 2 : 0) /* pull-list offsets */) * sizeof(float); };
     const size_t budget = (T == 512 ? 79 : 158) * 1024;
-    int reps = (detm & 2) ? 1 : 4;                                  // replicas only serve the rare > 3-keyframe fallback of wave_accumulate (DET: one dense accumulator, the waves own tables)
-    while (reps > 1 && lds_bytes(reps) > budget) reps >>= 1;
-    const size_t lds = lds_bytes(reps);
-    int per_cu = (T == 512 && lds <= budget) ? 2 : 1;
-    { static int knob = -1; if (knob < 0) { const char* e = std::getenv("I3D_EGT_WG_PER_CU"); knob = e ? std::atoi(e) : 0; } if (knob > 0) per_cu = knob; }
+    s.reps = (s.detm & 2) ? 1 : 4;                                  // replicas only serve the rare > 3-keyframe fallback of wave_accumulate (DET: one dense accumulator, the waves own tables)
+    while (s.reps > 1 && lds_bytes(s.reps) > budget) s.reps >>= 1;
+    s.lds = lds_bytes(s.reps);
+    s.per_cu = (T == 512 && s.lds <= budget) ? 2 : 1;
+    { static int knob = -1; if (knob < 0) { const char* e = std::getenv("I3D_EGT_WG_PER_CU"); knob = e ? std::atoi(e) : 0; } if (knob > 0) s.per_cu = knob; }
+    // ONE launch over the rank's own tiles followed by the foreign tiles that hold its ghost entries (the short ghost tiles fill the idle tail of
+    // the last round of own tiles instead of paying a launch and a round of their own)
+    const int ntl = t.ntiles_own + t.n_ghost;
+    s.blocks = 0; s.tiles_per_block = 0;
+    if (ntl > 0) {
+        s.blocks = ntl < s.per_cu * num_cu ? ntl : s.per_cu * num_cu;
+        s.tiles_per_block = (ntl + s.blocks - 1) / s.blocks;
+        // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
+        // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
+        if (ntl > s.blocks && ntl < 2 * s.blocks) { s.tiles_per_block = 1; s.blocks = ntl; }
+    }
+    return s;
+}
+static int egt_num_cu() {
+    static int num_cu = 0;
+    if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    return num_cu;
+}
+void eg_tile_launch_shape(const TilePlan& t, int K, int& blocks, int& tiles_per_block) {
+    const EgtShape s = t.T == 1024 ? egt_shape<1024, 2048>(t, K, egt_num_cu()) : egt_shape<512, 1536>(t, K, egt_num_cu());
+    blocks = s.blocks; tiles_per_block = s.tiles_per_block;
+}
+
+template <int T, int HMAX>
+static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state, int num_cu,
+                            float* cam_partials, int cam_stride) {
+    // I3D_DETERMINISTIC=1: fixed-order sums inside the workgroup as well (ordered halo pushes, per-wave keyframe tables) — every kernel of an outer iteration is then
+    // bit-reproducible from run to run (tools/flake_hunt.py: 0.0 on every field) at ~20 % lower throughput; the default keeps the LDS atomics of round 3 HERE and
+    // only here (gradient, column norms, SH Gram blocks, camera block and halo fold across workgroups are fixed-order in both modes)
+    // halo sums: pushed with LDS atomics (default), or PULLED over the plan's lists (t.pull: I3D_HALO_PULL=1, and always in the bit-reproducible mode, where the pull
+    // replaces the ordered pushes of the first version — I3D_EGT_ORDERED=1 brings those back for A/B runs)
+    const EgtShape sh = egt_shape<T, HMAX>(t, p.K, num_cu);
+    const int detm = sh.detm, reps = sh.reps; const size_t lds = sh.lds; const bool pull = (detm & 4) != 0;
     // tiles in units of T: the plan counts tiles of tp_T() == T
     int written = 0;
     // ONE launch over the rank's own tiles followed by the foreign tiles that hold its ghost entries (the short ghost tiles fill the idle tail of
@@ -705,11 +724,7 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
     {
         const int ntl = t.ntiles_own + t.n_ghost;
         if (ntl > 0) {
-            int blocks = ntl < per_cu * num_cu ? ntl : per_cu * num_cu;
-            int tiles_per_block = (ntl + blocks - 1) / blocks;
-            // between one and two rounds of resident workgroups (a rank's share at 8 GPUs): one tile per workgroup — the short second round runs
-            // on a nearly empty chip (measured at 557 tiles: 61.4 vs 64.0 us for 279 workgroups of two tiles)
-            if (ntl > blocks && ntl < 2 * blocks) { tiles_per_block = 1; blocks = ntl; }
+            const int blocks = sh.blocks, tiles_per_block = sh.tiles_per_block;
 #define I3D_EGT(SL, GH) do { if (detm == 3) I3D_EGT2(SL, GH, 3); else if (detm == 6) I3D_EGT2(SL, GH, 6); else if (detm == 4) I3D_EGT2(SL, GH, 4); else I3D_EGT2(SL, GH, 0); } while (0)
 #define I3D_EGT2(SL, GH, DT) do { \
         if (!set_dynamic_lds((const void*)k_eg_tile<T, HMAX, SL, GH, DT>, "k_eg_tile", lds, p.K)) break; \
@@ -731,8 +746,7 @@ static int launch_eg_tile_t(hipStream_t st, RowView r, OptParams p, const float*
 int launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, TilePlan t, double* shared, float* qacc, double* pq_partials, const PcgState* state,
                    float* cam_partials, int cam_stride) {
     if (r.A <= 0) return 0;
-    static int num_cu = 0;
-    if (!num_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    const int num_cu = egt_num_cu();
     if (t.T == 1024) return launch_eg_tile_t<1024, 2048>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
     return launch_eg_tile_t<512, 1536>(st, r, p, u, t, shared, qacc, pq_partials, state, num_cu, cam_partials, cam_stride);
 }

@@ -1,0 +1,415 @@
+// K6, ladder form — the PCG operator pass q_b = J^T W J u_b for NB systems b at once: ONE stream of the stored rows serves NB right-hand sides.
+//
+// Why: the reference restarts its trust region at 1e4 in every outer iteration (optimizer.cpp:138 constructs a fresh NLSSolver, nls_solver.cpp:322-323 never
+// takes effect), so 5 of 6 LM attempts are rejected, and the rejected attempts solve systems (J^T W J + D_k^2) y = b that share J, b and the Jacobi scaling and
+// differ only in the damping D_k^2 = clamp(diag) / radius_k — whose radii are known in advance (common.hpp: LADDER_MAX).  The serial loop streams the same
+// 1.46 GB of rows ~130 times per Gauss-Newton iteration on the bench workload; iterated in lock step the systems share each stream (solver.cpp pcg_solve_ladder).
+//
+// What is shared per row: the 120 B of the row, its unpacked plan slots, the keyframe grouping of the wave (which lanes hold which keyframe).  What is per system:
+// the operator input u_b (staged in LDS per system), t_b = W (J u_b), the column sums.  Unlike k_eg_tile (4 waves per SIMD, 128 registers, column sums in LDS)
+// this kernel runs 8 waves of 512 lanes per CU at 2 waves per SIMD: the 12 column sums of every system live in REGISTERS during the row loop and go through ONE
+// LDS buffer system by system in the pull phase.  With NB systems the pass is VALU-bound from NB = 3 on (each row costs ~NB x the arithmetic for one load),
+// which is why a batch of more than 3 systems is split into groups of <= 3 rather than widened (and why LDS holds 3 staged inputs and no more at K = 200).
+//
+// Every sum is taken in a fixed order: the halo is PULLED over the plan's lists (k_tile_pull_plan) and the pose block goes through per-wave keyframe tables — the
+// arithmetic of system b is, operation for operation, that of k_eg_tile<512, 1536, 5, false, 6> (the bit-reproducible variant) on u_b, so a system iterated in a
+// batch goes through bit-identical states to the same system iterated alone in I3D_DETERMINISTIC=1 (tests/test_gpu_ladder.py).
+#include <cstring>
+#include <cstdlib>
+#include "kernels.hpp"
+#include "reduce_device.hpp"
+#include "wave_ops.hpp"
+#include "tile_device.hpp"
+
+namespace i3d {
+
+constexpr int MR_T = 512, MR_HMAX = 1536, MR_NWV = MR_T / 64, MR_TC = 32;
+
+// LDS layout in floats.  Everything whose size does not depend on K sits at COMPILE-TIME offsets (an offset that is a constant costs no scalar register across the
+// row loop; the first version of this kernel derived every system block from K and spilled 40-56 scalar registers into vector lanes):
+//   [flag | 3 pad] [NB][72] per-wave intrinsics / distortion sums | [NWV][TC] keyframe tags (shared by the systems: the rows are) | [NB][NWV][TC][6] table sums |
+//   [NB] x { u_s, u_a [2 NSLOT] | Er row values [T + 4] } | the tile's pull list [2 HMAX] | column sums of ONE system [12][T] | pull-list offsets [(HMAX + 4) / 2, rounded]
+// then, per system and K-dependent: dense camera accumulator [rs + 9] | camera part of u_b [6K + 9].
+template <int NB> struct MrConst {
+    static constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, NSLOT = T + HMAX + 1;
+    static constexpr int CAMW = (NW * 9 + 3) & ~3, VSTR = NW * TC * 6;
+    static constexpr int D_FLAG = 0, D_CAM9W = 4, D_TAG = D_CAM9W + NB * CAMW, D_VAL = D_TAG + NW * TC;
+    static constexpr int O_U = D_VAL + NB * VSTR, UB = (2 * NSLOT + T + 4 + 3) & ~3;          // system b: u_s at O_U + b UB, u_a behind it, then the Er row values
+    static constexpr int O_LIST = O_U + NB * UB, O_C = O_LIST + 2 * HMAX, O_OFFS = O_C + 12 * T, D0 = O_OFFS + (((HMAX + 4) / 2 + 3) & ~3);
+};
+struct MrLayout { int o_upose, SK; size_t bytes; };          // the K-dependent tail: system b at D0 + b SK: accumulator, then (at o_upose) the camera part of u_b
+static __host__ __device__ inline MrLayout mr_layout(int D0, int NB, int K) {
+    const int nshared = 6 * K + 9, rs = (6 * K) | 1;
+    MrLayout L;
+    L.o_upose = (rs + 9 + 3) & ~3; L.SK = (L.o_upose + nshared + 3) & ~3;
+    L.bytes = (size_t)(D0 + NB * L.SK) * sizeof(float);
+    return L;
+}
+static size_t mr_lds_bytes(int NB, int K) { return NB == 1 ? mr_layout(MrConst<1>::D0, 1, K).bytes : (NB == 2 ? mr_layout(MrConst<2>::D0, 2, K).bytes : mr_layout(MrConst<3>::D0, 3, K).bytes); }
+
+// the pose columns of one row slot across the wave for NB systems: wave_table_add (wave_ops.hpp) with the table look-up done once
+template <int NB>
+static __device__ inline void mr_table_add(bool valid, int f, const float (&jp)[6], const float (&ts)[NB], float* lds, int o_tag, int o_val, int val_stride, int& count, int o_dense, int dense_stride) {
+    bool pending = valid;
+    unsigned long long todo = __ballot(pending);
+    const int lane = (int)(threadIdx.x & 63u);
+    while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int f0 = __builtin_amdgcn_readlane(f, leader);
+        const bool mine = pending && f == f0;
+        const int tg = __float_as_int(lds[o_tag + (lane & (MR_TC - 1))]);
+        const unsigned long long hit = __ballot(tg == f0);
+        int slot;
+        if (hit != 0ull) slot = (__ffsll((long long)hit) - 1) & (MR_TC - 1);
+        else if (count < MR_TC) { slot = count; if (lane == 0) lds[o_tag + slot] = __int_as_float(f0); count = count + 1; }
+        else slot = -1;
+        const bool lead = lane == leader;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float sum = wave_sum(mine ? jp[i] * ts[b] : 0.0f);
+                if (lead) lds_add(slot >= 0 ? &lds[o_val + b * val_stride + slot * 6 + i] : &lds[o_dense + b * dense_stride + 6 * f0 + i], sum);
+            }
+        }
+        pending = pending && !mine;
+        todo = __ballot(pending);
+    }
+}
+template <int NB>
+static __device__ inline void mr_table_merge(float* lds, int o_tag, int o_val, int val_stride, int& count, int o_dense, int dense_stride) {
+    const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        for (int e = lane; e < count * 6; e += 64) {
+            const int sl = e / 6, i = e - sl * 6;
+            const int f = __float_as_int(lds[o_tag + sl]);
+            lds[o_dense + b * dense_stride + 6 * f + i] += lds[o_val + b * val_stride + e];
+            lds[o_val + b * val_stride + e] = 0.0f;
+        }
+    }
+    if (lane < MR_TC) lds[o_tag + lane] = __int_as_float(-1);
+    count = 0;
+}
+
+struct MrArgs {
+    const float* u0; float* qacc0; float* qh0; double* pq0 /* or null: no p.q (residual-reset pass) */; float* cam0;
+    const PcgState* st0;                   // system 0's state of this pass's parity; system j's is st0 + 2 j
+    size_t vec, qh, cam, part;             // LadVec strides
+    int sys[3];                            // the systems of this launch
+};
+
+template <int NB>
+__global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, MrArgs m, const unsigned* __restrict__ lnbr, const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx,
+                                                        const int* __restrict__ halo_cnt, int tiles_per_block, int ntl, int cam_stride, const int* __restrict__ gmaxv,
+                                                        const unsigned short* __restrict__ hp_off, const unsigned short* __restrict__ hp_src) {
+    constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, ZSLOT = T + HMAX, NSLOT = ZSLOT + 1, NCOL = 12, HPCAP = 4 * HMAX, NQH = HMAX / T;
+    {   // every system of the launch has stopped: nothing to do (launches queued behind the convergence flags)
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) any = any || (m.st0[2 * m.sys[b]].done == 0);
+        if (!any) return;
+    }
+    extern __shared__ float lds[];
+    const int K = p.K; const size_t Acap = r.Acap; const int A = r.A, chunk = r.chunk;
+    const int nshared = 6 * K + 9, rs = (6 * K) | 1;
+    using MC = MrConst<NB>;
+    constexpr int D_FLAG = MC::D_FLAG, D_CAM9W = MC::D_CAM9W, CAMW = MC::CAMW, D_TAG = MC::D_TAG, D_VAL = MC::D_VAL, VSTR = MC::VSTR, D0 = MC::D0;
+    const MrLayout L = mr_layout(D0, NB, K);
+    const int SB = L.SK, o_upose = L.o_upose;
+#define SYS(b) (D0 + (b) * SB)                                   /* K-dependent block of system b: dense pose accumulator [0, 6K), intrinsics / distortion totals [rs, rs + 9), camera part of u_b at o_upose */
+#define U_S(b) (MC::O_U + (b) * MC::UB)
+#define U_A(b) (MC::O_U + (b) * MC::UB + NSLOT)
+#define TR_L(b) (MC::O_U + (b) * MC::UB + 2 * NSLOT)
+#define C_L (MC::O_C)
+#define hp_list reinterpret_cast<unsigned short*>(lds + MC::O_LIST)
+#define hp_offs reinterpret_cast<unsigned short*>(lds + MC::O_OFFS)
+    const int i = threadIdx.x, lane = (int)(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t tail = 2 * (size_t)chunk;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float* ub = m.u0 + (size_t)m.sys[b] * m.vec;
+        for (int e = i; e < rs + 9; e += T) lds[SYS(b) + e] = 0.0f;
+        for (int e = i; e < nshared; e += T) lds[SYS(b) + o_upose + e] = ub[tail + e];
+        for (int e = lane; e < TC * 6; e += 64) lds[D_VAL + b * VSTR + wave * (TC * 6) + e] = 0.0f;
+    }
+    if (lane < TC) lds[D_TAG + wave * TC + lane] = __int_as_float(-1);
+    const int o_tag = D_TAG + wave * TC, o_val = D_VAL + wave * (TC * 6);
+    int tcount = 0;
+    float cam9[NB][9];
+    double pq[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { pq[b] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cam9[b][q] = 0.0f; }
+    const float tw0 = p.type_wf[0], tw1 = p.type_wf[1], tw2 = p.type_wf[2], tw3 = p.type_wf[3];
+    const int tile0 = blockIdx.x * tiles_per_block;
+    const int tk_end = min(tile0 + tiles_per_block, ntl);
+
+    // the tile in flight (names as in k_eg_tile)
+    int tile = 0, base = 0, a = 0, H = 0, nr_ld = 0; bool in = false; size_t ac = 0;
+    uint8_t fl = 0, rf_ld = 0; unsigned ln[5]; RowBlock rwA, rwB;
+    float us[NB], ua[NB], hs[NB][NQH], ha[NB][NQH];
+    constexpr int NQL = (HPCAP / 8 + T - 1) / T, NQO = (HMAX + 1 + T - 1) / T;
+    uint4 hpl[NQL]; unsigned short hpo[NQO];
+    const char* wave_rows = reinterpret_cast<const char*>(r.rows);
+    int gm = 0;
+    const unsigned lane16 = (threadIdx.x & 63u) * 16u;
+    auto load_block = [&](RowBlock& rw, int k) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wave_rows, 0, k < gm ? MAX_SLOTS * ROW_BLOCK_F4 * 16 : 0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { const v4u_b v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, k * (ROW_BLOCK_F4 * 16) + q * 1024, 2 /* nt */);
+                                      rw.p[q] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+        { const v2u_b t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane16 >> 1, k * (ROW_BLOCK_F4 * 16) + 64 * ROW_PLANES * 16, 2); rw.j28 = __uint_as_float(t.x); rw.tag = (int)t.y; }
+    };
+    auto group_rows = [&](int tk) -> int {
+        const int wa0 = tk * T + (int)(threadIdx.x & ~63u);
+        const int grp = __builtin_amdgcn_readfirstlane(wa0 < A ? (wa0 >> 6) : -1);
+        return grp >= 0 ? gmaxv[grp] : 0;
+    };
+    auto issue_in = [&](int tk) {
+        tile = tk; base = tile * T; a = base + i; in = a < A; ac = in ? (size_t)a : 0;
+        { const int wa0 = base + (int)(threadIdx.x & ~63u);
+          const unsigned grp = (unsigned)__builtin_amdgcn_readfirstlane(wa0 < A ? (wa0 >> 6) : 0);
+          wave_rows = reinterpret_cast<const char*>(r.rows + (size_t)grp * (size_t)(r.slots * ROW_BLOCK_F4)); }
+        H = halo_cnt[tile];
+        int he[NQH];
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) he[q] = __builtin_nontemporal_load(&halo_idx[(size_t)tile * HMAX + (i + q * T < HMAX ? i + q * T : 0)]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float* ub = m.u0 + (size_t)m.sys[b] * m.vec;
+            us[b] = in ? ub[a] : 0.0f; ua[b] = in ? ub[chunk + a] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) { const int e = (i + q * T < H) ? he[q] : 0; hs[b][q] = ub[e]; ha[b][q] = ub[chunk + e]; }
+        }
+#pragma unroll
+        for (int q = 0; q < NQL; ++q) { const int ch = i + q * T; hpl[q] = reinterpret_cast<const uint4*>(hp_src + (size_t)tile * HPCAP)[ch < HPCAP / 8 ? ch : 0]; }
+#pragma unroll
+        for (int q = 0; q < NQO; ++q) { const int o = i + q * T; hpo[q] = hp_off[(size_t)tile * (HMAX + 1) + (o <= HMAX ? o : HMAX)]; }
+    };
+    auto issue_meta = [&]() {
+        fl = in ? r.aflags[ac] : 0;
+        nr_ld = r.nrows[ac];
+        rf_ld = r.regflags[ac];
+#pragma unroll
+        for (int w = 0; w < 5; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);
+    };
+    int gm_next = tile0 < tk_end ? group_rows(tile0) : 0;
+    for (int tk = tile0; tk < tk_end; ++tk) {
+        gm = gm_next;
+        issue_in(tk);
+        issue_meta();
+        load_block(rwA, 0);
+        load_block(rwB, 1);
+        gm_next = tk + 1 < tk_end ? group_rows(tk + 1) : 0;
+        // ---- stage the operator inputs of tile + halo ----
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            lds[U_S(b) + i] = us[b]; lds[U_A(b) + i] = ua[b];
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; if (hq < HMAX) { const bool hv = hq < H; lds[U_S(b) + T + hq] = hv ? hs[b][q] : 0.0f; lds[U_A(b) + T + hq] = hv ? ha[b][q] : 0.0f; } }
+            if (i == 0) { lds[U_S(b) + ZSLOT] = 0.0f; lds[U_A(b) + ZSLOT] = 0.0f; lds[TR_L(b) + T] = 0.0f; }
+        }
+#pragma unroll
+        for (int q = 0; q < NQL; ++q) { const int ch = i + q * T; if (ch < HPCAP / 8) { reinterpret_cast<uint2*>(hp_list)[2 * ch] = make_uint2(hpl[q].x, hpl[q].y); reinterpret_cast<uint2*>(hp_list)[2 * ch + 1] = make_uint2(hpl[q].z, hpl[q].w); } }
+#pragma unroll
+        for (int q = 0; q < NQO; ++q) { const int o = i + q * T; if (o <= HMAX) hp_offs[o] = hpo[q]; }
+        if (i == 0) lds[D_FLAG] = __int_as_float(0);
+        const bool active = in && (fl & F_ACTIVE);
+        const int nr = active ? nr_ld : 0;
+        const uint8_t rf = active ? rf_ld : 0;
+        if (!in) { constexpr AllZ<ZSLOT> az; for (int w = 0; w < 5; ++w) ln[w] = az.w[w]; }
+        __syncthreads();
+        const int sx = unpack12(ln, 5), sy = unpack12(ln, 0), sz = unpack12(ln, 3), mx = unpack12(ln, 9), my = unpack12(ln, 10), mz = unpack12(ln, 11);
+        float self_s[NB], self_a[NB], pq_rows[NB], C[NB][NCOL];
+        // ---- regulariser rows (constant coefficients), while the first two row blocks are in flight ----
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            self_s[b] = 0.0f; self_a[b] = 0.0f; pq_rows[b] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) C[b][c] = 0.0f;
+            const int rg[6] = {sx, mx, sy, my, sz, mz};
+            float tr = 0.0f; double pq_pre = 0.0;
+            if (rf & 1) {
+                const float lap = ((((((-6.0f * us[b]) + lds[U_S(b) + rg[0]]) + lds[U_S(b) + rg[1]]) + lds[U_S(b) + rg[2]]) + lds[U_S(b) + rg[3]]) + lds[U_S(b) + rg[4]]) + lds[U_S(b) + rg[5]];
+                tr = tw1 * lap; if (in) pq_pre += (double)(tr * lap);
+                self_s[b] += -6.0f * tr;
+            }
+            lds[TR_L(b) + i] = tr;
+            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * us[b]; if (in) pq_pre += (double)(ts * us[b]); self_s[b] += ts; }
+            if (rf & 7) pq[b] += pq_pre;
+        }
+        // one row: t_b = W (J u_b) for every system, J^T t_b into the lane's column sums (registers)
+        auto consume = [&](const RowBlock& rb, int k) {
+            const float4 (&rw)[7] = rb.p;
+            int fsel = 0; bool pvalid = false; float tsel[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) tsel[b] = 0.0f;
+            if (k < nr) {
+                const float rho = tw0;
+                const int f = rb.tag & ~ROW_FREE_BIT;
+                float J[P_TOTAL];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { J[4 * q] = rw[q].x; J[4 * q + 1] = rw[q].y; J[4 * q + 2] = rw[q].z; J[4 * q + 3] = rw[q].w; }
+                J[28] = rb.j28;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    float d = J[0] * lds[U_S(b) + i] + J[10] * lds[U_A(b) + i];
+#pragma unroll
+                    for (int c = 1; c < 10; ++c) d += J[c] * lds[U_S(b) + unpack12(ln, c - 1)];
+                    d += J[11] * lds[U_A(b) + sx] + J[12] * lds[U_A(b) + sy] + J[13] * lds[U_A(b) + sz];
+                    const int o_up = SYS(b) + o_upose + 6 * f;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) d += J[P_POSE + q] * lds[o_up + q];
+                    const int o_ui = SYS(b) + o_upose + 6 * K;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) d += J[P_INTR + q] * lds[o_ui + q];
+                    const float t = rho * d;
+                    pq_rows[b] += t * d;
+                    self_s[b] += J[0] * t; self_a[b] += J[10] * t;
+#pragma unroll
+                    for (int c = 1; c < 10; ++c) C[b][c - 1] += J[c] * t;
+                    C[b][9] += J[11] * t; C[b][10] += J[12] * t; C[b][11] += J[13] * t;
+                    if (in) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) cam9[b][q] += J[P_INTR + q] * t;
+                    }
+                    tsel[b] = t;
+                }
+                if (!p.fix_poses && in) { fsel = f; pvalid = true; }
+            }
+            const float jp[6] = {rw[3].z, rw[3].w, rw[4].x, rw[4].y, rw[4].z, rw[4].w};      // pose columns 14..19 of the row
+            mr_table_add<NB>(pvalid, fsel, jp, tsel, lds, o_tag, o_val, VSTR, tcount, D0, SB);
+        };
+        consume(rwA, 0); load_block(rwA, 2);
+        consume(rwB, 1); load_block(rwB, 3);
+        consume(rwA, 2); load_block(rwA, 4);
+        consume(rwB, 3);
+        consume(rwA, 4);
+        if (in) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) pq[b] += (double)pq_rows[b];
+        }
+        unsigned lr[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) lr[w] = __builtin_nontemporal_load(&lnbr[(size_t)(5 + w) * Acap + ac]);
+        float eaw[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) eaw[d] = __builtin_nontemporal_load(&eaw_sym[(size_t)d * Acap + ac]);
+        if (tcount > TC - 16 && lane == 0) lds[D_FLAG] = __int_as_float(1);      // a table is nearly full: behind the barrier ALL tables are merged, in wave order
+        const unsigned lall[LNBR_WORDS] = {0u, 0u, 0u, 0u, ln[4], lr[0], lr[1]};
+        const int r2y = unpack12(lall, 12), ryz = unpack12(lall, 13), r2z = unpack12(lall, 14), rxy = unpack12(lall, 15), rxz = unpack12(lall, 16), r2x = unpack12(lall, 17);
+        // ---- pull, system by system through the one column-sum buffer ----
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) lds[C_L + c * T + i] = C[b][c];
+            const float ua_c = lds[U_A(b) + i];
+            __syncthreads();
+            if (b == 0 && __float_as_int(lds[D_FLAG]) != 0) {                      // (workgroup-uniform: written before the barrier, cleared by the next tile's staging behind the next one)
+                for (int w = 0; w < NW; ++w) { if (wave == w) mr_table_merge<NB>(lds, o_tag, o_val, VSTR, tcount, D0, SB); __syncthreads(); }
+            }
+            float* const qacc = m.qacc0 + (size_t)m.sys[b] * m.vec;
+            float* const qh = m.qh0 + (size_t)m.sys[b] * m.qh;
+            if (in) {
+                auto pull = [&](int col, int slot) { return slot < T ? lds[C_L + col * T + slot] : 0.0f; };
+                float qs = self_s[b], qa = self_a[b];
+                qs += pull(0, my) + pull(1, r2y) + pull(2, ryz) + pull(3, mz) + pull(4, r2z) + pull(5, mx) + pull(6, rxy) + pull(7, rxz) + pull(8, r2x);
+                qa += pull(9, mx) + pull(10, my) + pull(11, mz);
+                const int rg[6] = {sx, mx, sy, my, sz, mz};
+#pragma unroll
+                for (int d = 0; d < 6; ++d) qs += lds[TR_L(b) + (rg[d] < T ? rg[d] : T)];
+                float ea = 0.0f, eq = 0.0f;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) { const float diff = ua_c - lds[U_A(b) + rg[d]]; const float t = eaw[d] * diff; ea += t; eq += (rg[d] == ZSLOT ? 1.0f : 0.5f) * t * diff; }
+                qa += tw3 * ea; pq[b] += (double)(tw3 * eq);
+                qacc[a] = qs; qacc[chunk + a] = qa;
+            }
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) {
+                const int hq = i + q * T;
+                if (hq < H) {
+                    const size_t o = (size_t)tile * HMAX + hq;
+                    float hsum = 0.0f, hal = 0.0f;
+                    const int j1 = hp_offs[hq + 1];
+                    for (int j = hp_offs[hq]; j < j1; ++j) {
+                        const int e = hp_list[j], col = e >> 10, ln2 = e & 1023;
+                        const float v = col == 12 ? lds[TR_L(b) + ln2] : lds[C_L + col * T + ln2];
+                        if (col >= 9 && col != 12) hal += v; else hsum += v;
+                    }
+                    qh[2 * o] = hsum; qh[2 * o + 1] = hal;
+                }
+            }
+            __syncthreads();       // the next system's column sums / the next tile's staging overwrite what other lanes are still pulling from
+        }
+    }
+    // ---- the camera block of every system: per-wave sums and tables -> the dense accumulator, in wave order -> one float row per workgroup ----
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            float v = cam9[b][q];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) lds[D_CAM9W + b * CAMW + wave * 9 + q] = v;
+        }
+    }
+    __syncthreads();
+    for (int w = 0; w < NW; ++w) { if (wave == w) mr_table_merge<NB>(lds, o_tag, o_val, VSTR, tcount, D0, SB); __syncthreads(); }
+    if (threadIdx.x < 9) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { float v = 0.0f; for (int w = 0; w < NW; ++w) v += lds[D_CAM9W + b * CAMW + w * 9 + threadIdx.x]; lds[SYS(b) + rs + threadIdx.x] = v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float* const cam = m.cam0 + (size_t)m.sys[b] * m.cam;
+        for (int q = threadIdx.x; q < nshared; q += T) {
+            float v;
+            if (q < 6 * K) { v = 0.0f; v += lds[SYS(b) + q]; }
+            else v = lds[SYS(b) + rs + q - 6 * K];
+            cam[(size_t)blockIdx.x * cam_stride + q] = v;
+        }
+    }
+    if (m.pq0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) block_partial_d(pq[b], m.pq0 + (size_t)m.sys[b] * m.part, 1, 0);
+    }
+#undef SYS
+#undef U_S
+#undef U_A
+#undef TR_L
+#undef C_L
+#undef hp_list
+#undef hp_offs
+}
+
+// the largest number of systems one launch can take at K keyframes (the staged inputs of every system must fit the 160 KB of LDS): 3 at the bench's K = 200, 0 = never
+int eg_tile_mr_max_systems(int K) {
+    for (int nb = 3; nb >= 1; --nb) if (mr_lds_bytes(nb, K) <= I3D_LDS_LIMIT) return nb;
+    return 0;
+}
+
+// One stream of the rows for the nsys (<= 3) systems sys[0..nsys) of a ladder batch.  The plan must be the 512-entry geometry with its pull lists (t.hp_off); the launch
+// shape (workgroups, tiles per workgroup) is the single-system pass's, so that the per-workgroup partial rows of a system are the ones it gets alone.
+// Returns the number of workgroups = p.q partials / camera rows per system (0: not launched).
+int launch_eg_tile_mr(hipStream_t st, RowView r, OptParams p, TilePlan t, int nsys, const int* sys, const float* u0, float* qacc0, float* qh0, double* pq0, float* cam0, int cam_stride,
+                      const PcgState* st0, const LadVec& lv) {
+    if (r.A <= 0 || nsys < 1 || nsys > 3 || t.T != MR_T || !t.hp_off || r.slots != 5) return 0;
+    int blocks = 0, tiles_per_block = 0;
+    eg_tile_launch_shape(t, p.K, blocks, tiles_per_block);
+    if (blocks <= 0) return 0;
+    const int ntl = t.ntiles_own;
+    MrArgs m; m.u0 = u0; m.qacc0 = qacc0; m.qh0 = qh0; m.pq0 = pq0; m.cam0 = cam0; m.st0 = st0; m.vec = lv.vec; m.qh = lv.qh; m.cam = lv.cam; m.part = lv.part;
+    for (int b = 0; b < 3; ++b) m.sys[b] = sys[b < nsys ? b : nsys - 1];
+    const size_t lds = mr_lds_bytes(nsys, p.K);
+#define I3D_MR(NB) do { \
+        if (!set_dynamic_lds((const void*)k_eg_tile_mr<NB>, "k_eg_tile_mr", lds, p.K)) return 0; \
+        k_eg_tile_mr<NB><<<blocks, MR_T, lds, st>>>(r, p, m, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, tiles_per_block, ntl, cam_stride, r.gmax, t.hp_off, t.hp_src); } while (0)
+    if (nsys == 1) I3D_MR(1); else if (nsys == 2) I3D_MR(2); else I3D_MR(3);
+#undef I3D_MR
+    return blocks;
+}
+
+}  // namespace i3d

@@ -191,6 +191,12 @@ int i3d_debug_counters(i3d_context* c, int64_t* stream_syncs) {
     return I3D_OK;
 }
 
+int i3d_debug_ladder_stats(i3d_context* c, int64_t* out6) {
+    if (!c || !out6) return I3D_ERR_INVALID_ARGUMENT;
+    out6[0] = c->lad_batches; out6[1] = c->lad_streams; out6[2] = c->lad_system_passes; out6[3] = c->lad_resyncs; out6[4] = c->lad_wasted; out6[5] = c->ladder_max;
+    return I3D_OK;
+}
+
 int i3d_debug_cull_stats(i3d_context* c, int64_t* pairs, int64_t* culled) {
     if (!c || !pairs || !culled) return I3D_ERR_INVALID_ARGUMENT;
     if (!c->cull_mask.p || c->nC <= 0) return ctx_fail(c, I3D_ERR_STATE, "i3d_debug_cull_stats: nothing assembled");

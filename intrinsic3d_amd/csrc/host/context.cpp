@@ -310,7 +310,7 @@ int i3d_timing_get_work_ex(i3d_context* c, double* ms, int64_t* launches, double
     return I3D_OK;
 }
 const char* i3d_kernel_name(int32_t k) {
-    static const char* names[I3D_K_COUNT] = {"classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh", "eg_aux", "comm"};
+    static const char* names[I3D_K_COUNT] = {"classify", "observe", "build", "eg_pass", "gather", "cost", "vector", "sh", "eg_aux", "comm", "eg_mr2", "eg_mr3"};
     return (k >= 0 && k < I3D_K_COUNT) ? names[k] : "?";
 }
 int i3d_problem_sizes(i3d_context* c, int64_t out[6]) { if (!c || !out) return I3D_ERR_INVALID_ARGUMENT; for (int i = 0; i < 6; ++i) out[i] = c->last_sizes[i]; return I3D_OK; }

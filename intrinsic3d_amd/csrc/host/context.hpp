@@ -93,6 +93,16 @@ struct i3d_context {
     i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_ext_off, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw, cam_part;
     i3d::DevBuf<unsigned char> tp_temp; bool tile_ok = false;
     i3d::DevBuf<unsigned short> tp_hp_off, tp_hp_src; bool halo_pull = false;      // halo pull lists of the plan (tile_pass.hip k_tile_pull_plan): I3D_HALO_PULL=1 and the bit-reproducible mode
+    bool ladder_lists = false;      // the lists are built for the multi-system operator pass of the ladder (tile_pass_mr.hip) although the single-system pass pushes its halo
+    // ---- the damping ladder (solver.cpp lm_solve / pcg_solve_ladder): per-system slabs of the PCG vectors and partial sums ----
+    int ladder_max = 1;             // I3D_LADDER (read at every assemble): attempts solved together, 1 = the serial loop
+    int ladder_hint = 0;            // LM attempts of the previous outer iteration (the first batch speculates that deep)
+    i3d::LadVec lad{};              // strides of the slabs below
+    i3d::DevBuf<float> lad_vec;     // [LADDER_MAX][6][lad.vec]: x, r, p, z, u, qacc of every system
+    i3d::DevBuf<float> lad_qh, lad_cam, lad_mblk, lad_tail;
+    i3d::DevBuf<double> lad_part;   // [LADDER_MAX][lad.part]: step partials [4 * 1024] | p.q partials [1024] | D^2 p^2 partials [1024]
+    i3d::DevBuf<i3d::PcgState> lad_st;      // [LADDER_MAX][2]
+    long long lad_batches = 0, lad_streams = 0, lad_system_passes = 0, lad_resyncs = 0, lad_wasted = 0;      // counters (i3d_debug_ladder_stats)
     double t_add_end = 0.0;         // host clock at the end of the residual collection of the current outer iteration (time_add | time_build)
     bool deterministic = false;     // I3D_DETERMINISTIC=1 (read at every assemble): bit-reproducible operator pass, ~20 % slower
     int tile_T = 0;                 // geometry of the current plan (0 = the default, 1024); single rank: 512 when a 1024-entry tile's halo does not fit; sharded: 512 first, then 1024
@@ -102,7 +112,7 @@ struct i3d_context {
         const bool sh = comm && (comm->world > 1 || comm->force);
         const int t0 = sh ? own0 / T : 0, t1 = sh ? (own1 + T - 1) / T : i3d::tile_plan_tiles_of(A, T);
         return i3d::TilePlan{tp_lnbr.p, tp_eaw.p, tp_halo_idx.p, tp_halo_cnt.p, tp_iota.p, tp_ext_e.p, tp_ext_pos.p, tp_qh.p, tp_ext_off.p, tp_overflow.p, T, i3d::tile_plan_hmax_of(T), t0, t1 > t0 ? t1 - t0 : 0,
-                             ghost_tiles.p, sh ? n_ghost_tiles : 0, deterministic ? 1 : 0, halo_pull ? tp_hp_off.p : nullptr, halo_pull ? tp_hp_src.p : nullptr};
+                             ghost_tiles.p, sh ? n_ghost_tiles : 0, deterministic ? 1 : 0, (halo_pull || ladder_lists) ? tp_hp_off.p : nullptr, (halo_pull || ladder_lists) ? tp_hp_src.p : nullptr, halo_pull ? 1 : 0};
     }
 
     // ---- solver vectors (length NP = 2N + 6K + 9) ----

@@ -82,8 +82,8 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->d_partials.alloc((Acap / 256 + 2048) * 9));       // per-workgroup partial sums of the fp64 reductions
     if (!c->h_pcg) CTX_HIP(c, hipHostMalloc((void**)&c->h_pcg, 2 * sizeof(PcgState), hipHostMallocDefault));
     for (auto& e : c->pcg_ev) if (!e) CTX_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (!c->h_flags) { CTX_HIP(c, hipHostMalloc((void**)&c->h_flags, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
-                       for (int i = 0; i < 16; ++i) c->h_flags[i] = -1;
+    if (!c->h_flags) { CTX_HIP(c, hipHostMalloc((void**)&c->h_flags, 32 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));      // (pass, done) rings: 4 ints per system of a ladder batch
+                       for (int i = 0; i < 32; ++i) c->h_flags[i] = -1;
                        CTX_HIP(c, hipHostGetDevicePointer((void**)&c->d_flags, c->h_flags, 0)); }
     CTX_HIP(c, c->d_lm.alloc(1)); CTX_HIP(c, c->d_cam_c.alloc((size_t)6 * c->K + 9)); CTX_HIP(c, c->d_cam_H.alloc((size_t)21 * c->K + 25));
     if (!c->h_lmrec) { CTX_HIP(c, hipHostMalloc((void**)&c->h_lmrec, LM_REC_SLOTS * sizeof(LmRecord), hipHostMallocMapped | hipHostMallocCoherent));
@@ -221,10 +221,18 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
       launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
     c->tile_ok = false; c->tile_T = 0;
     { const char* e = std::getenv("I3D_DETERMINISTIC"); c->deterministic = e && e[0] == '1'; }
+    {   // the damping ladder (lm_solve): up to I3D_LADDER consecutive LM attempts solved together, one stream of the rows per group of <= 3 of them (tile_pass_mr.hip);
+        // 1 = the serial trust-region loop.  Needs the single-rank tiled pass in its 512-entry geometry with pull lists and the shipped 5 observation slots.
+        const char* e = std::getenv("I3D_LADDER"); const int v = e ? std::atoi(e) : LADDER_MAX;
+        c->ladder_max = v < 1 ? 1 : (v > LADDER_MAX ? LADDER_MAX : v);
+        if (sharded(c) || slots != 5 || eg_tile_mr_max_systems(c->K) < 2) c->ladder_max = 1;
+        { const char* l = std::getenv("I3D_PCG_LEGACY"); if (l && l[0] == '1') c->ladder_max = 1; }
+        c->ladder_lists = c->ladder_max > 1;
+    }
     {   // halo sums of the operator pass pulled over plan lists instead of pushed with LDS atomics: always in the bit-reproducible mode, else on request
         const char* e = std::getenv("I3D_HALO_PULL");
         c->halo_pull = c->deterministic || (e && e[0] == '1');
-        if (c->halo_pull) {      // sized for both tile geometries (Acap entries)
+        if (c->halo_pull || c->ladder_lists) {      // sized for both tile geometries (Acap entries)
             const size_t n512 = (size_t)tile_plan_tiles_of(c->Acap, 512), n1024 = (size_t)tile_plan_tiles_of(c->Acap, 1024);
             CTX_HIP(c, c->tp_hp_off.alloc(std::max(n512 * (size_t)(1536 + 1), n1024 * (size_t)(2048 + 1)) + 8));
             CTX_HIP(c, c->tp_hp_src.alloc(std::max(n512 * (size_t)tile_plan_pull_cap(1536), n1024 * (size_t)tile_plan_pull_cap(2048)) + 8));
@@ -237,7 +245,8 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         // (rows per entry are a property of the grid, not of the iteration); either geometry is the other's fallback when a tile's halo does not fit.
         { const long long la = c->last_sizes[0], lr = c->last_sizes[1];
           static const bool forced = std::getenv("I3D_EGT_TILE") != nullptr;
-          if (!forced && la > 0 && (double)lr < 0.8 * (double)slots * (double)la) c->tile_T = 512; }
+          if (!forced && la > 0 && (double)lr < 0.8 * (double)slots * (double)la) c->tile_T = 512;
+          if (c->ladder_max > 1) c->tile_T = 512; }      // the multi-system pass exists in the 512-entry geometry (8 waves at 2 per SIMD: the column sums of 3 systems live in registers)
         shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; c->slice = c->chunk;
         RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
         CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n));
@@ -516,7 +525,7 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
     a.pq_partials = pq_part; a.d2_partials = d2_part; a.n_pq = 0; a.n_d2 = 0;
     a.n_slice_wg = pcg_step3_slice_wgs(own.n, wg_cap);
     a.sharded = sh ? 1 : 0;
-    a.K = K; a.fix_poses = p.fix_poses; a.fix_intr = p.fix_intr; a.fix_dist = p.fix_dist;
+    a.K = K; a.fix_poses = p.fix_poses; a.fix_intr = p.fix_intr; a.fix_dist = p.fix_dist; a.lad_sys = -1;
     a.cam_partials = c->cam_part.p; a.n_cam = 0; a.cam_stride = NSP; a.Mblk = c->Minv_blocks.p;
     a.tp = c->v_p.p + to; a.tx = c->v_x.p + to; a.tr = c->v_r.p + to; a.tb = c->v_b.p + to; a.tD2 = c->v_D2.p + to; a.tz = c->v_z.p + to; a.tS = c->v_S.p + to;
     a.step_partials = step_part;
@@ -556,6 +565,138 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
     c->pcg_seq = seq0 + PCG_SEQ_STRIDE;
     // boundary `it` copied the terminal state forward (kernels after `done` are no-ops), so st2[it & 1] is final (read by k_lm_decide on the stream)
     *final_state = st2 + (it & 1);
+    { const int lrc = ctx_launch_check(c); if (lrc) return lrc; }
+    return I3D_OK;
+}
+
+// ---- the damping ladder ------------------------------------------------------------------------------------------------------------------------------
+// Slabs of the per-system arrays of a batch (LadVec): every system has its own x, r, p, z, u, operator accumulators, halo sums, camera partial rows, partial
+// sums, block-Jacobi inverses, camera-tail diagonal and scalar states; b, the column norms and S are shared.
+constexpr int LAD_PART_STEP = 4 * 2048, LAD_PART_PQ = 2048, LAD_PART_D2 = 2048;
+static int alloc_ladder(i3d_context* c) {
+    const Layout L = layout_of(c);
+    const int nsys = c->ladder_max;
+    LadVec& lv = c->lad;
+    const size_t vec = ((size_t)c->v_x.n + 3) & ~(size_t)3;                                  // as long as the solver vectors of the context
+    const size_t qh = 2 * (size_t)tile_plan_tiles_of(c->Acap, 512) * (size_t)tile_plan_hmax_of(512);
+    const size_t cam = (size_t)2048 * (((size_t)L.NS + 3) & ~(size_t)3);
+    lv.vec = vec; lv.qh = qh; lv.cam = cam; lv.part = LAD_PART_STEP + LAD_PART_PQ + LAD_PART_D2; lv.mblk = ((size_t)36 * c->K + 41 + 3) & ~(size_t)3; lv.tail = ((size_t)L.NS + 3) & ~(size_t)3;
+    const bool fresh = c->lad_vec.n < (size_t)6 * nsys * vec || !c->lad_vec.p;
+    CTX_HIP(c, c->lad_vec.alloc((size_t)6 * nsys * vec));
+    if (fresh) CTX_HIP(c, hipMemsetAsync(c->lad_vec.p, 0, sizeof(float) * c->lad_vec.n, c->stream));      // padding entries stay finite
+    CTX_HIP(c, c->lad_qh.alloc((size_t)nsys * qh)); CTX_HIP(c, c->lad_cam.alloc((size_t)nsys * cam)); CTX_HIP(c, c->lad_part.alloc((size_t)nsys * lv.part));
+    CTX_HIP(c, c->lad_mblk.alloc((size_t)nsys * lv.mblk)); CTX_HIP(c, c->lad_tail.alloc((size_t)nsys * lv.tail)); CTX_HIP(c, c->lad_st.alloc((size_t)2 * LADDER_MAX));
+    return I3D_OK;
+}
+// the six vector kinds of the slab: kind * ladder_max * vec + system * vec
+enum { LV_X = 0, LV_R, LV_P, LV_Z, LV_U, LV_Q };
+static float* lad_vecp(const i3d_context* c, int kind, int sys = 0) { return c->lad_vec.p + ((size_t)kind * c->ladder_max + sys) * c->lad.vec; }
+
+// B systems (J^T W J + D_j^2) y = b, j = 0 .. B-1 (the LM diagonals of a ladder batch, k_lm_begin_lad), iterated in LOCK STEP: pass `it` of the loop is iteration `it` of
+// every system still running.  Per pass: ONE k_pcg_dir3 launch and ONE k_pcg_step3 launch over the live systems (blockIdx.y), and the operator — the rows are streamed
+// once per GROUP of up to 3 live systems (k_eg_tile_mr) instead of once per system.  Every system keeps its own scalar state, stopping rule and host ring; a system
+// that has stopped is dropped from the launches one pass after the host saw its flag.  The arithmetic of a system is that of pcg_solve_fused on it alone.
+static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, const OptParams& p, int B, const PcgState** finals, int* passes_out) {
+    hipStream_t s = c->stream;
+    const Layout L = layout_of(c);
+    const int K = c->K; const size_t to = L.tail_off; const Seg2 own = L.own;
+    RowView r = c->row_view(); TilePlan tp = c->tile_plan();
+    LadVec lv = c->lad;
+    float* const X0 = lad_vecp(c, LV_X); float* const R0 = lad_vecp(c, LV_R); float* const P0 = lad_vecp(c, LV_P); float* const Z0 = lad_vecp(c, LV_Z);
+    float* const U0 = lad_vecp(c, LV_U); float* const Q0 = lad_vecp(c, LV_Q);
+    PcgState* const st2 = c->lad_st.p;
+    const int NSP = (L.NS + 3) & ~3;
+    double* const step_part0 = c->lad_part.p; double* const pq_part0 = step_part0 + LAD_PART_STEP; double* const d2_part0 = pq_part0 + LAD_PART_PQ;
+    static const bool use_mr = [] { const char* e = std::getenv("I3D_LADDER_MR"); return !(e && e[0] == '0'); }();       // 0: the single-system operator once per system (A/B and parity runs)
+    static const bool mr1 = [] { const char* e = std::getenv("I3D_LADDER_MR1"); return e && e[0] == '1'; }();            // 1: a lone live system goes through k_eg_tile_mr<1> as well
+    static const int group_cap = [] { const char* e = std::getenv("I3D_LADDER_GROUP"); const int v = e ? std::atoi(e) : 3; return v < 1 ? 1 : (v > 3 ? 3 : v); }();
+    const int mr_cap = std::min(group_cap, eg_tile_mr_max_systems(K));
+    const bool mr_ok = use_mr && mr_cap >= 1 && tp.T == 512 && tp.hp_off != nullptr && r.slots == 5;
+    { TimedScope t(c, I3D_K_VECTOR);
+      CTX_HIP(c, hipMemsetAsync(X0, 0, sizeof(float) * (size_t)B * lv.vec, s));
+      for (int j = 0; j < B; ++j) CTX_HIP(c, hipMemcpyAsync(R0 + (size_t)j * lv.vec, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s));
+      launch_pcg_init_lad(s, st2, B, cfg.pcg_fixed_iterations, 500, c->d_lm.p); }
+    Step3Args a; std::memset(&a, 0, sizeof(a));
+    auto c4 = [&](const float* v) { return reinterpret_cast<const float4*>(v + own.off0); };
+    auto m4 = [&](float* v) { return reinterpret_cast<float4*>(v + own.off0); };
+    a.nq = own.n >> 2; a.chunk4 = (int)((own.off1 - own.off0) >> 2);
+    a.p = c4(P0); a.qacc = c4(Q0); a.x = m4(X0); a.r = m4(R0); a.b = c4(c->v_b.p); a.z = m4(Z0); a.cm = c4(c->v_cm.p); a.lm = c->d_lm.p;
+    a.ext_off = tp.ext_off; a.ext_pos = tp.ext_pos; a.qh = reinterpret_cast<const float2*>(c->lad_qh.p); a.e0 = (int)own.off0;
+    a.pq_partials = pq_part0; a.d2_partials = d2_part0; a.n_pq = 0; a.n_d2 = 0;
+    a.n_slice_wg = pcg_step3_slice_wgs(own.n, 0);
+    a.sharded = 0; a.lad_sys = 0;
+    a.K = K; a.fix_poses = p.fix_poses; a.fix_intr = p.fix_intr; a.fix_dist = p.fix_dist;
+    a.cam_partials = c->lad_cam.p; a.n_cam = 0; a.cam_stride = NSP; a.Mblk = c->lad_mblk.p;
+    a.tp = P0 + to; a.tx = X0 + to; a.tr = R0 + to; a.tb = c->v_b.p + to; a.tD2 = c->lad_tail.p; a.tz = Z0 + to; a.tS = c->v_S.p + to;
+    a.step_partials = step_part0;
+    std::vector<int> live(B); for (int j = 0; j < B; ++j) live[j] = j;
+    auto set_slots = [&]() { for (int q = 0; q < LADDER_MAX; ++q) lv.sysid[q] = live[q < (int)live.size() ? q : (int)live.size() - 1]; };
+    // the operator on the live systems: groups of <= mr_cap systems share one stream of the rows; returns the workgroups per system (p.q partials / camera rows)
+    auto rows_apply = [&](int parity, bool with_dot) -> int {
+        int n = 0; const int nl = (int)live.size();
+        if (mr_ok && (nl > 1 || mr1)) {
+            const int groups = (nl + mr_cap - 1) / mr_cap;
+            int at = 0;
+            for (int g = 0; g < groups; ++g) {
+                const int ng = (nl - at + (groups - g) - 1) / (groups - g);        // balanced: 4 -> 2 + 2, 5 -> 3 + 2
+                TimedScope t(c, ng == 1 ? I3D_K_EG_PASS : (ng == 2 ? I3D_K_EG_MR2 : I3D_K_EG_MR3));
+                n = launch_eg_tile_mr(s, r, p, tp, ng, live.data() + at, U0, Q0, c->lad_qh.p, with_dot ? pq_part0 : nullptr, c->lad_cam.p, NSP, st2 + parity, lv);
+                if (n <= 0) return -1;
+                at += ng; ++c->lad_streams;
+            }
+        } else {
+            for (int j : live) {
+                TilePlan tj = tp; tj.qh = c->lad_qh.p + (size_t)j * lv.qh;
+                TimedScope t(c, I3D_K_EG_PASS);
+                n = launch_eg_tile(s, r, p, U0 + (size_t)j * lv.vec, tj, nullptr, Q0 + (size_t)j * lv.vec, with_dot ? pq_part0 + (size_t)j * lv.part : nullptr, st2 + 2 * j + parity,
+                                   c->lad_cam.p + (size_t)j * lv.cam, NSP);
+                ++c->lad_streams;
+            }
+        }
+        c->lad_system_passes += nl;
+        return n;
+    };
+    int n_step = 0;
+    set_slots();
+    { TimedScope t(c, I3D_K_VECTOR); a.cur = st2; n_step = launch_pcg_step3_lad(s, 0 /*init*/, B, a, lv); }
+    const int seq0 = c->pcg_seq;
+    for (int j = 0; j < B; ++j) finals[j] = st2 + 2 * j;
+    int it = 1;
+    for (;; ++it) {
+        set_slots();
+        const int nl = (int)live.size();
+        { TimedScope t(c, I3D_K_VECTOR);
+          a.n_d2 = launch_pcg_dir3_lad(s, it == 1, nl, own, to, L.NS, Z0, P0, c->v_S.p, U0, c->lad_tail.p, c->v_cm.p, c->d_lm.p, step_part0, n_step, d2_part0, st2, (it + 1) & 1, c->d_flags, seq0 + it, lv); }
+        { const int n = rows_apply(it & 1, true); if (n < 0) return ctx_fail(c, I3D_ERR_STATE, "pcg_solve_ladder: the multi-system operator pass could not be launched"); a.n_pq = n; a.n_cam = n; }
+        a.cur = st2 + (it & 1);
+        if (it % 10 != 0) { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3_lad(s, 1, nl, a, lv); }
+        else {                                                                   // residual_reset_period: r = b - A x instead of r -= alpha q
+            { TimedScope t(c, I3D_K_VECTOR); launch_pcg_step3_lad(s, 2, nl, a, lv);
+              for (int j : live) { float* xj = X0 + (size_t)j * lv.vec; float* uj = U0 + (size_t)j * lv.vec;
+                                   launch_mul2(s, own, c->v_S.p, xj, uj); launch_mul(s, L.NS, c->v_S.p + to, xj + to, uj + to); } }
+            { const int n = rows_apply(it & 1, false); if (n < 0) return ctx_fail(c, I3D_ERR_STATE, "pcg_solve_ladder: the multi-system operator pass could not be launched"); a.n_cam = n; }
+            { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3_lad(s, 3, nl, a, lv); }
+        }
+        if (it >= 2) {                                                           // the boundaries of pass it-1, system by system, while pass it runs
+            const int want = seq0 + it - 1;
+            std::vector<int> still;
+            for (int j : live) {
+                volatile int* ring = c->h_flags + 4 * j + 2 * (want & 1);
+                const double t_wait = now_s();
+                while (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) {
+                    if (now_s() - t_wait > 30.0) { CTX_HIP(c, sync_stream(c)); if (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) return ctx_fail(c, I3D_ERR_HIP, "pcg_solve_ladder: the device stopped publishing its state"); }
+                }
+                if (!__atomic_load_n((int*)&ring[1], __ATOMIC_ACQUIRE)) still.push_back(j);
+                // (a stopped system: boundary it-1 left its terminal state in one buffer and pass it's boundary copied it into the other — either is final)
+            }
+            live.swap(still);
+            if (live.empty()) break;
+        }
+        if (it > 520) break;
+    }
+    if (passes_out) *passes_out = it;
+    c->pcg_seq = seq0 + PCG_SEQ_STRIDE;
+    for (int j : live) finals[j] = st2 + 2 * j + (it & 1);       // (only after the pass limit: the state of the last pass queued)
     { const int lrc = ctx_launch_check(c); if (lrc) return lrc; }
     return I3D_OK;
 }
@@ -637,8 +778,55 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
         }
         if (rec.final_) ended = true;
     };
+    static const int dbg_invalid = [] { const char* e = std::getenv("I3D_DEBUG_INVALID_ATTEMPT"); return e ? std::atoi(e) : -1; }();      // tests: this attempt's step counts as invalid
+    // The damping ladder: batches of consecutive attempts are SOLVED together (k_lm_begin_lad: the radii a run of rejections leads to; pcg_solve_ladder: lock step, the
+    // rows streamed once per group of systems) and then DECIDED one after the other by the same k_lm_decide — results, attempts, accept sequence and PCG counts are
+    // those of the serial loop (bit for bit in the bit-reproducible mode).  Batch depth: what the previous outer iteration needed (the reference restarts at radius 1e4
+    // every time, optimizer.cpp:138, so the count barely moves), doubling while everything is rejected.  An invalid step (radius halved instead of divided) puts a
+    // batch out of step: the attempt behind it is solved again on its own (LmRecord kind 3).
+    const bool ladder = c->ladder_max > 1 && fused && !sharded(c) && c->plan_T() == 512 && c->tile_plan().hp_off != nullptr && c->slots == 5;
+    if (ladder) {
+        rc = alloc_ladder(c); if (rc) return rc;
+        const LadVec& lv = c->lad;
+        { LmRecord rec; rc = wait_record(c, 0, seq0, rec); if (rc) return rc; consume(rec); }      // the initial tests
+        int k = 0, prevB = 0; bool after_resync = false;
+        while (k < cfg.lm_steps && !ended) {
+            int B = after_resync ? 1 : (prevB == 0 ? (c->ladder_hint > 0 ? c->ladder_hint : 2) : 2 * prevB);
+            B = std::max(1, std::min(B, std::min(c->ladder_max, cfg.lm_steps - k)));
+            after_resync = false; prevB = B;
+            { TimedScope t(c, I3D_K_VECTOR);
+              launch_lm_begin_lad(s, lm, B, K, p.fix_poses, p.fix_intr, p.fix_dist, c->d_cam_c.p, c->d_cam_H.p, c->lad_mblk.p, lv.mblk, c->v_c.p + L.tail_off, c->v_S.p + L.tail_off, c->lad_tail.p, lv.tail,
+                                  c->d_lmrec + 1 + k, seq0 + 1 + k); }
+            const PcgState* fin[LADDER_MAX] = {nullptr};
+            rc = pcg_solve_ladder(c, cfg, p, B, fin, nullptr); if (rc) return rc;
+            ++c->lad_batches;
+            for (int j = 0; j < B; ++j) {      // the decision chain of every system, in ladder order; everything behind the deciding attempt returns at once
+                CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 4, 0, sizeof(double) * 2, s));
+                { TimedScope t(c, I3D_K_VECTOR);
+                  launch_candidate(s, g, r, K, -1.0f, lad_vecp(c, LV_X, j), c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p, c->d_partials.p, lm);
+                  launch_cand_frames(s, K, c->d_xcshared.p, c->d_frames.p, c->d_frames_cand.p, lm); }
+                rc = eval_cost_launch(c, p, true, c->d_frames_cand.p, c->d_xcshared.p + 6 * K, lm); if (rc) return rc;
+                { TimedScope t(c, I3D_K_VECTOR);
+                  launch_lm_decide(s, lm, fin[j], c->d_scal.p + 4, c->d_scal.p + 16, k + j, cfg.lm_steps, c->d_lmrec + 1 + k + j, seq0 + 1 + k + j, j + 1, dbg_invalid == k + j ? 1 : 0);
+                  launch_accept(s, g, r, c->xc_sdf.p, c->xc_alb.p, lm); }
+            }
+            int decided = 0;
+            for (int j = 0; j < B && !ended; ++j) {
+                LmRecord rec; rc = wait_record(c, 1 + k + j, seq0 + 1 + k + j, rec); if (rc) return rc;
+                if (rec.kind == 3) {            // out of step: attempt k + j was solved with a radius the trust region did not reach — solve it again, alone
+                    __atomic_store_n(&c->h_lmrec[1 + k + j].seq, 0, __ATOMIC_RELEASE);
+                    ++c->lad_resyncs; after_resync = true; break;
+                }
+                consume(rec); ++decided;
+            }
+            if (ended && decided < B) c->lad_wasted += B - decided;
+            k += decided;
+        }
+        if (attempts > 0) c->ladder_hint = attempts;
+        ended = true;        // (every record of the solve has been consumed)
+    }
     int k = 0;
-    for (; k < cfg.lm_steps; ++k) {
+    for (; !ladder && k < cfg.lm_steps; ++k) {
         // attempt k, queued behind whatever attempt k-1 still has in flight.  k_lm_begin: radius test, 1/radius, LM diagonal of the camera tail, block-Jacobi
         // inverses of the damped camera blocks
         { TimedScope t(c, I3D_K_VECTOR);
@@ -658,7 +846,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
           launch_cand_frames(s, K, c->d_xcshared.p, c->d_frames.p, c->d_frames_cand.p, lm); }
         rc = eval_cost_launch(c, p, true, c->d_frames_cand.p, c->d_xcshared.p + 6 * K, lm); if (rc) return rc;
         { TimedScope t(c, I3D_K_VECTOR);
-          launch_lm_decide(s, lm, ps, c->d_scal.p + 4, c->d_scal.p + 16, k, cfg.lm_steps, c->d_lmrec + 1 + k, seq0 + 1 + k);
+          launch_lm_decide(s, lm, ps, c->d_scal.p + 4, c->d_scal.p + 16, k, cfg.lm_steps, c->d_lmrec + 1 + k, seq0 + 1 + k, -1, dbg_invalid == k ? 1 : 0);
           launch_accept(s, g, r, c->xc_sdf.p, c->xc_alb.p, lm); }
     }
     if (!ended) { LmRecord rec; rc = wait_record(c, k, seq0 + k, rec); if (rc) return rc; consume(rec); }      // the last attempt's record (step limit)

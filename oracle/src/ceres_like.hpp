@@ -199,7 +199,7 @@ inline LMSummary lm_minimize(const EvalFn& evaluate, CRS& J, const std::vector<i
         }
         if (!finite || !(model_change > 0.0)) {            // invalid step
             sum.step_accepted.push_back(0);
-            if (++invalid > opt.max_consecutive_invalid_steps) { sum.termination = 3; break; }
+            if (++invalid >= opt.max_consecutive_invalid_steps) { sum.termination = 3; break; }      // TrustRegionMinimizer::HandleInvalidStep: fails ON the 5th consecutive invalid step
             radius *= 0.5; reuse_diag = false; continue;
         }
         invalid = 0;
