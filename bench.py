@@ -249,7 +249,11 @@ def kernel_table(args, sizes, world, timing_work, timing):
     if world > 1:                                           # a rank streams its own share of the rows (its ghost rows are not counted: conservative)
         b_build /= world; b_egpass /= world; d_build /= world; d_egpass /= world
     kernels = {}
-    for name, bytes_per_launch, design in (("build", b_build, d_build), ("eg_pass", b_egpass, d_egpass)):
+    # ladder batches: one launch of k_eg_tile_mr<NB> streams the rows ONCE for NB systems (strict bytes: still 4 nnz); per system it stages one more input and writes one more output
+    per_sys = (8 + 8) * float(A) / world
+    for name, bytes_per_launch, design in (("build", b_build, d_build), ("eg_pass", b_egpass, d_egpass), ("eg_mr2", b_egpass, d_egpass + per_sys), ("eg_mr3", b_egpass, d_egpass + 2 * per_sys)):
+        if name not in timing_work:
+            continue
         ms, n, slow_ms, slow_n = timing_work[name]
         if n > 0:
             avg = ms / n                     # HIP events around each launch on the library's stream, no-op launches excluded
@@ -270,7 +274,7 @@ def roofline_of(name, kernels, Rg, A, world, attach_counters=True):
         return None
     k = kernels[name]
     tr = pmc_traffic(name, Rg, A) if (world == 1 and attach_counters) else None
-    out = {"kernel": {"build": "k_build<true>", "eg_pass": "k_eg_tile"}[name], "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    out = {"kernel": {"build": "k_build<true>", "eg_pass": "k_eg_tile", "eg_mr2": "k_eg_tile_mr<2>", "eg_mr3": "k_eg_tile_mr<3>"}[name], "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
            "traffic_source": (f"committed PMC passes of this command, profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; not measured in this run)" if tr else None)}
     sq = sq_valu(name, Rg) if (world == 1 and attach_counters) else None
@@ -306,7 +310,7 @@ def band2_leg(args, binding, log, device):
         ctx.set_camera(sc["intr"], sc["dist"], sc["poses"])
         ctx.estimate_sh(a2.subvolume, 10.0, thres)
         ctx.optimize(make_cfg(binding, a2, 1, thres))                 # warm-up
-        ctx.timing_enable(True); ctx.timing_select(["eg_pass", "build"]); ctx.timing_get(reset=True)
+        ctx.timing_enable(True); ctx.timing_select(["eg_pass", "eg_mr2", "eg_mr3", "build"]); ctx.timing_get(reset=True)
         import torch
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -472,7 +476,7 @@ def _main():
     sharded_run = world > 1 or args.force_collectives
     if not args.all_kernel_timing:
         # the roofline kernels only: an event pair around EVERY launch costs ~8 % of the wall clock (+ the exchange launches when sharded)
-        ctx.timing_select(["eg_pass", "build"] + (["comm"] if sharded_run else []))
+        ctx.timing_select(["eg_pass", "eg_mr2", "eg_mr3", "build"] + (["comm"] if sharded_run else []))
     ctx.timing_get(reset=True)
     torch.cuda.synchronize()
     if dist is not None:
@@ -487,6 +491,7 @@ def _main():
         dist.barrier()
     dt = time.perf_counter() - t0
     stream_syncs = ctx.debug_counters()["stream_syncs"] - syncs0
+    ladder = ctx.debug_ladder_stats()
     cull_pairs, cull_skipped = ctx.debug_cull_stats()       # observation pass: (64-voxel group, keyframe) pairs of the last iteration, and how many were culled
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
@@ -560,6 +565,8 @@ def _main():
             "cost": [float(stats[0].cost_initial), float(stats[-1].cost_final)],
             # host <-> device round trips: the trust-region loop runs on the device (lm_kernels.hip), the host polls mapped memory instead of draining the stream
             "stream_syncs_per_step": stream_syncs / float(args.steps),
+            # the damping ladder (whole context, warm-up included): LM attempts solved together share the streams of the stored rows
+            "ladder": ladder,
             "observe_culling": {"group_keyframe_pairs": cull_pairs, "culled": cull_skipped, "fraction": (cull_skipped / float(cull_pairs)) if cull_skipped >= 0 and cull_pairs else None},
             # the boundary also accepts host buffers (i3d_set_grid / i3d_set_frames / i3d_optimize_host): the same run with the one-off upload
             # (voxels + keyframe pyramids over PCIe, hash / neighbour-table build) and the read-back of the refined fields counted in.  Never `value`.

@@ -620,7 +620,7 @@ __global__ void k_iota(int n, int* __restrict__ x) { const int i = blockIdx.x * 
 // tile geometry: T entries per tile / workgroup, HMAX halo slots.  Default 1024 / 2048 (one workgroup of 16 waves per CU, 122 KB of LDS): a third fewer
 // tile boundaries than 512 / 1536 (two workgroups per CU) — same operator time once both row loops were spill-free, cheaper plan and halo fold: 40.1 vs
 // 41.1 ms per iteration in the same-box A/B (profiles/r03_ab_variants.json).  I3D_EGT_TILE=512 selects the other; a plan that overflows falls back to it.
-static int tp_T() { static int t = 0; if (!t) { const char* e = std::getenv("I3D_EGT_TILE"); t = (e && std::atoi(e) == 512) ? 512 : 1024; } return t; }
+static int tp_T() { const char* e = std::getenv("I3D_EGT_TILE"); return (e && std::atoi(e) == 512) ? 512 : 1024; }      // (read per call: tests switch it inside one process)
 static int tp_H() { return tp_T() == 1024 ? 2048 : 1536; }
 int tile_plan_tiles(int A) { return (A + tp_T() - 1) / tp_T(); }
 int tile_plan_hmax() { return tp_H(); }

@@ -244,7 +244,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         // flight (measured on --band 2: 0.43 -> 0.39 ms per pass; on the 5.0-rows workload 512-entry tiles are 2.5 % slower).  The density is last iteration's
         // (rows per entry are a property of the grid, not of the iteration); either geometry is the other's fallback when a tile's halo does not fit.
         { const long long la = c->last_sizes[0], lr = c->last_sizes[1];
-          static const bool forced = std::getenv("I3D_EGT_TILE") != nullptr;
+          const bool forced = std::getenv("I3D_EGT_TILE") != nullptr;
           if (!forced && la > 0 && (double)lr < 0.8 * (double)slots * (double)la) c->tile_T = 512;
           if (c->ladder_max > 1) c->tile_T = 512; }      // the multi-system pass exists in the 512-entry geometry (8 waves at 2 per SIMD: the column sums of 3 systems live in registers)
         shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; c->slice = c->chunk;
@@ -607,9 +607,10 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
     PcgState* const st2 = c->lad_st.p;
     const int NSP = (L.NS + 3) & ~3;
     double* const step_part0 = c->lad_part.p; double* const pq_part0 = step_part0 + LAD_PART_STEP; double* const d2_part0 = pq_part0 + LAD_PART_PQ;
-    static const bool use_mr = [] { const char* e = std::getenv("I3D_LADDER_MR"); return !(e && e[0] == '0'); }();       // 0: the single-system operator once per system (A/B and parity runs)
-    static const bool mr1 = [] { const char* e = std::getenv("I3D_LADDER_MR1"); return e && e[0] == '1'; }();            // 1: a lone live system goes through k_eg_tile_mr<1> as well
-    static const int group_cap = [] { const char* e = std::getenv("I3D_LADDER_GROUP"); const int v = e ? std::atoi(e) : 3; return v < 1 ? 1 : (v > 3 ? 3 : v); }();
+    // (read per solve: tests and A/B runs switch them inside one process)
+    const bool use_mr = [] { const char* e = std::getenv("I3D_LADDER_MR"); return !(e && e[0] == '0'); }();       // 0: the single-system operator once per system (A/B and parity runs)
+    const bool mr1 = [] { const char* e = std::getenv("I3D_LADDER_MR1"); return e && e[0] == '1'; }();            // 1: a lone live system goes through k_eg_tile_mr<1> as well
+    const int group_cap = [] { const char* e = std::getenv("I3D_LADDER_GROUP"); const int v = e ? std::atoi(e) : 3; return v < 1 ? 1 : (v > 3 ? 3 : v); }();
     const int mr_cap = std::min(group_cap, eg_tile_mr_max_systems(K));
     const bool mr_ok = use_mr && mr_cap >= 1 && tp.T == 512 && tp.hp_off != nullptr && r.slots == 5;
     { TimedScope t(c, I3D_K_VECTOR);
@@ -778,7 +779,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
         }
         if (rec.final_) ended = true;
     };
-    static const int dbg_invalid = [] { const char* e = std::getenv("I3D_DEBUG_INVALID_ATTEMPT"); return e ? std::atoi(e) : -1; }();      // tests: this attempt's step counts as invalid
+    const int dbg_invalid = [] { const char* e = std::getenv("I3D_DEBUG_INVALID_ATTEMPT"); return e ? std::atoi(e) : -1; }();      // tests: this attempt's step counts as invalid (read per solve)
     // The damping ladder: batches of consecutive attempts are SOLVED together (k_lm_begin_lad: the radii a run of rejections leads to; pcg_solve_ladder: lock step, the
     // rows streamed once per group of systems) and then DECIDED one after the other by the same k_lm_decide — results, attempts, accept sequence and PCG counts are
     // those of the serial loop (bit for bit in the bit-reproducible mode).  Batch depth: what the previous outer iteration needed (the reference restarts at radius 1e4

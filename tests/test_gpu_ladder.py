@@ -1,0 +1,120 @@
+"""-m gpu: the damping ladder of the trust-region loop (solver.cpp lm_solve, tile_pass_mr.hip).
+
+The reference restarts its trust region at 1e4 in every outer iteration (optimizer.cpp:138 builds a fresh NLSSolver; nls_solver.cpp:322-323 never takes effect), so
+most LM attempts are rejected, and after a rejection the next radius is known in advance (LevenbergMarquardtStrategy::StepRejected).  The library therefore SOLVES up to
+I3D_LADDER consecutive attempts together — PCG systems that differ only in the LM diagonal, iterated in lock step, one stream of the stored rows for up to three of
+them — and then DECIDES them one after the other with the same kernel as the serial loop.  Nothing about the result may change:
+
+  * in the bit-reproducible mode (I3D_DETERMINISTIC=1) the ladder, at every depth and grouping, must return bit for bit what the serial loop (I3D_LADDER=1) returns:
+    fields, camera, costs, attempts, accept / reject sequence, PCG iteration counts, final radius;
+  * in the default mode (fp32 LDS atomics inside the single-system pass) to round-off, with the same attempts and accept sequence;
+  * an invalid step (radius halved instead of divided) puts a batch out of step: the attempt behind it must be solved again, alone, with the radius the trust region
+    really reached — again bit for bit the serial loop's answer.
+Oracle parity of the ladder itself is what the rest of the suite checks: the ladder is the default, every other GPU test runs through it."""
+import numpy as np
+import pytest
+
+import helpers
+from test_gpu_bench_parity import build_slice, _bench_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def slice_setup(oracle):
+    return build_slice(oracle)
+
+
+@pytest.fixture(autouse=True)
+def same_tile_geometry(monkeypatch):
+    """The multi-system pass exists in the 512-entry tile geometry; the serial loop it is compared with must tile the same way (the halo sums of a tile are partial
+    sums: another tiling is another summation order)."""
+    monkeypatch.setenv("I3D_EGT_TILE", "512")
+
+
+def _run(S, iterations=2, cg_fixed=-1):
+    O = S["O"]; sc = S["sc"]; a0 = S["arrays"]
+    cfg = helpers.gpu_cfg(_bench_cfg(O, S["thres"], cg_fixed)); cfg.iterations = iterations
+    ctx = helpers.gpu_context(sc, a0, S["vsh"])
+    st = ctx.optimize(cfg); sdf, alb = ctx.get_grid(); cam = ctx.get_camera(); lad = ctx.debug_ladder_stats(); ctx.close()
+    return st, sdf, alb, cam, lad
+
+
+def _stats(st):
+    return [(s.num_attempts, list(s.step_accepted[:s.num_attempts]), list(s.pcg_iterations[:s.num_attempts]), s.cost_initial, s.cost_final, s.final_radius, s.termination,
+             list(s.rows)) for s in st]
+
+
+def _same(a, b):
+    st1, s1, a1, c1, _ = a; st2, s2, a2, c2, _ = b
+    assert _stats(st1) == _stats(st2), (_stats(st1), _stats(st2))
+    diffs = {"sdf": float(np.abs(s1 - s2).max()), "albedo": float(np.abs(a1 - a2).max()), "intr": float(np.abs(c1[0] - c2[0]).max()), "dist": float(np.abs(c1[1] - c2[1]).max()),
+             "poses": float(np.abs(c1[2] - c2[2]).max())}
+    assert np.array_equal(s1, s2) and np.array_equal(a1, a2) and all(np.array_equal(x, y) for x, y in zip(c1, c2)), diffs
+
+
+_serial = {}
+
+
+def _serial_det(S, monkeypatch):
+    """two chained iterations of the serial loop in the bit-reproducible mode (computed once per module)"""
+    if "run" not in _serial:
+        monkeypatch.setenv("I3D_DETERMINISTIC", "1"); monkeypatch.setenv("I3D_LADDER", "1")
+        _serial["run"] = _run(S)
+        assert _serial["run"][4]["batches"] == 0 and _serial["run"][4]["depth"] == 1
+        assert sum(s.num_attempts for s in _serial["run"][0]) >= 6          # rejected attempts are what the ladder is about
+    return _serial["run"]
+
+
+# (depth, systems per row stream, multi-system kernel, lone systems through it too)
+@pytest.mark.parametrize("depth,group,mr,mr1", [("6", "3", "0", "0"), ("6", "3", "1", "0"), ("6", "2", "1", "0"), ("3", "3", "1", "0"), ("2", "3", "1", "0"), ("6", "3", "1", "1")])
+def test_ladder_is_the_serial_loop_bit_for_bit(slice_setup, monkeypatch, depth, group, mr, mr1):
+    serial = _serial_det(slice_setup, monkeypatch)
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1")
+    monkeypatch.setenv("I3D_LADDER", depth); monkeypatch.setenv("I3D_LADDER_GROUP", group); monkeypatch.setenv("I3D_LADDER_MR", mr); monkeypatch.setenv("I3D_LADDER_MR1", mr1)
+    lad = _run(slice_setup)
+    st = lad[4]
+    assert st["batches"] >= 2 and st["depth"] == int(depth) and st["resyncs"] == 0, st
+    if mr == "1":
+        assert st["row_streams"] < st["system_passes"], st          # rows were shared
+    else:
+        assert st["row_streams"] == st["system_passes"], st
+    _same(serial, lad)
+
+
+def test_ladder_with_fixed_pcg_depth_and_residual_resets(slice_setup, monkeypatch):
+    """30 PCG iterations per attempt: every system of a batch goes through the residual reset (r = b - A x) at iterations 10, 20, 30 in lock step."""
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1")
+    monkeypatch.setenv("I3D_LADDER", "1")
+    serial = _run(slice_setup, iterations=1, cg_fixed=30)
+    monkeypatch.setenv("I3D_LADDER", "6")
+    _same(serial, _run(slice_setup, iterations=1, cg_fixed=30))
+
+
+def test_ladder_in_the_default_mode_agrees_to_round_off(slice_setup, monkeypatch):
+    monkeypatch.setenv("I3D_LADDER", "1")
+    st1, s1, a1, c1, _ = _run(slice_setup)
+    monkeypatch.setenv("I3D_LADDER", "6")
+    st2, s2, a2, c2, lad = _run(slice_setup)
+    assert lad["row_streams"] < lad["system_passes"]
+    assert [(s.num_attempts, list(s.step_accepted[:s.num_attempts])) for s in st1] == [(s.num_attempts, list(s.step_accepted[:s.num_attempts])) for s in st2]
+    for x, y in zip(st1, st2):       # Ceres' stop test compares i (Q1 - Q0) / Q1 with 0.1: summation-order noise may move a count by one
+        assert all(abs(int(p) - int(q)) <= 1 for p, q in zip(x.pcg_iterations[:x.num_attempts], y.pcg_iterations[:y.num_attempts]))
+        assert abs(x.cost_final - y.cost_final) <= 1e-6 * abs(x.cost_final)
+    assert np.abs(s1 - s2).max() <= 1e-5 * np.abs(s1).max() and np.abs(a1 - a2).max() <= 1e-5 * np.abs(a1).max()
+    np.testing.assert_allclose(c2[2], c1[2], rtol=1e-5, atol=1e-7)
+
+
+def test_an_invalid_step_puts_the_batch_out_of_step_and_it_is_solved_again(slice_setup, monkeypatch):
+    """TrustRegionMinimizer::HandleInvalidStep halves the radius and leaves the reduction factor alone: the systems behind the invalid attempt were solved for radii the
+    trust region never reaches.  (The step of attempt 0 — the first of a batch — is DECLARED invalid by a test switch; on real data model_cost_change <= 0 does not
+    occur.)"""
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1")
+    monkeypatch.setenv("I3D_DEBUG_INVALID_ATTEMPT", "0")
+    monkeypatch.setenv("I3D_LADDER", "1")
+    serial = _run(slice_setup, iterations=1)
+    assert serial[0][0].num_attempts >= 3 and serial[0][0].step_accepted[0] == 0
+    monkeypatch.setenv("I3D_LADDER", "6")
+    lad = _run(slice_setup, iterations=1)
+    _same(serial, lad)
+    assert lad[4]["resyncs"] >= 1, lad[4]
