@@ -101,7 +101,7 @@ def make_cfg(binding, args, iterations, thres):
                                   pcg_fixed_iterations=args.pcg_fixed, verbose=1 if getattr(args, 'verbose', False) else 0, carry_trust_radius=1 if args.carry_radius else 0)
 
 
-def cpu_baseline(args, sc, thres, log, device=0):
+def cpu_baseline(args, sc, thres, log, device=0, threaded_leg=True, reference_leg=True):
     """The restated CPU reference (oracle, fp64, 8 OpenMP threads in the solve like options.num_threads = 8) on a bounded
     spatial sample of the SAME workload: the voxels of a cap of the sphere, same keyframes, same configuration."""
     from oracle import oracle_py as O
@@ -134,7 +134,7 @@ def cpu_baseline(args, sc, thres, log, device=0):
     after = g.export() if rc == 0 else None
     # ... and once more with the collection threaded (section 8(d) asks for both): ONE iteration from the same start, same rows in the same order
     threaded = None
-    if rc == 0:
+    if rc == 0 and threaded_leg:
         g.import_fields(sdf_refined=before["sdf_refined"], albedo=before["albedo"], color=before["color"])
         cfg1 = O.OptConfig(iterations=1, lm_steps=50, lambda_g=0.2, lambda_r0=80.0, lambda_r1=10.0, lambda_s0=120.0, lambda_s1=10.0, lambda_a=0.1,
                            fix_poses=0, fix_intrinsics=0, fix_distortion=0, occlusion_distance=0.02, num_observations=5, thres_shell=thres,
@@ -184,8 +184,10 @@ def cpu_baseline(args, sc, thres, log, device=0):
     scale = keys.shape[0] / float(n)
     value = 1.0 / (sec_per_iter_sample * scale)
     log(f"cpu baseline: {n} voxels, {iters} iterations in {dt:.1f}s -> {sec_per_iter_sample:.2f} s/iter on the sample, x{scale:.1f} voxels")
-    ref_code = reference_code_leg(args, sc, thres, cfg, log)
+    ref_code = reference_code_leg(args, sc, thres, cfg, log) if reference_leg else None
     return {"value": value, "reference_code": ref_code, "unit": "GN iterations/s", "cores": os.cpu_count(), "threads": threads, "kind": "port",
+            # `value` is measured on the sample and scaled linearly by the voxel ratio unless the sample IS the workload (tools/c4_full_parity.py: profiles/r05_c4_full_parity.json)
+            "extrapolated": bool(scale > 1.001), "voxel_ratio": scale, "sample_voxels": int(n),
             "sample": f"restated CPU reference (Ceres-2.1.0-equivalent, fp64) on a {n}-voxel cap of the same grid with all {sc['K']} keyframes, "
                       f"{iters} GN iterations in {dt:.1f}s; per-iteration time scaled linearly by the voxel ratio {scale:.1f} to the full workload "
                       f"(residual collection single-threaded as in the reference, solve on {threads} threads like options.num_threads = 8; the host has {os.cpu_count()} cores)",

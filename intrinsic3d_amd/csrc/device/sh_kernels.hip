@@ -8,8 +8,10 @@
 // so everything Ceres needs from these rows is the 10x10 Gram block  G_s = sum_v w_v [phi_v; I_v][phi_v; I_v]^T
 // (9x9 normal matrix, 9-vector right-hand side, scalar).  That rank-k update is the one GEMM-shaped piece of the whole
 // path and runs on the matrix cores in fp64:  v_mfma_f64_16x16x4_f64, A = w*[phi;I] padded 10->16, B = [phi;I], 4 voxels
-// per instruction, 16 instructions per 64-voxel wave tile, accumulated in registers across a wave's chunk and flushed with
-// one fp64 atomic per used entry when the subvolume changes.  fp64 because the SH coefficients must match the reference's
+// per instruction, 16 instructions per 64-voxel wave tile, accumulated in registers.  One wave owns one CHUNK (SH_CHUNK_TILES tiles) of one subvolume's run of
+// the sorted voxel list and stores its block; the chunks of a subvolume are added in chunk order by k_sh_gram_sum — no atomics, fixed summation order, and a single
+// large subvolume (subvolume_size_sh: 0 = one global volume) is spread over as many waves as it has chunks instead of being walked by one.
+// fp64 because the SH coefficients must match the reference's
 // fp64 solve to 1e-4 and the 9x9 blocks are ill-conditioned when a subvolume sees a narrow range of normals.
 #include "kernels.hpp"
 #include "sh_kernels.hpp"
@@ -83,25 +85,28 @@ static __device__ inline void sh_features(const GridView& g, int s, double f[10]
     w = fmin(fmax(1.0 - fmin(fabs(xs), tr) / tr, 0.01), 1.0);                                       // sdfToWeight (operators.cpp:142-147)
 }
 
-// Gram accumulation over the subvolume-sorted list of eligible voxels [m0, m1) (a rank's slice): ONE WAVE PER SUBVOLUME walks the subvolume's run of the list in
-// 64-voxel tiles and writes its 10 x 10 block and weight sum itself — no block is shared by waves, nothing is added atomically, the sums of an estimate are
-// bit-reproducible (round 3: fixed 8-tile chunks per wave, fp64 atomics wherever a chunk ended inside a subvolume).  A subvolume holds a few thousand voxels of
-// the shell: a few dozen tiles per wave, once per level.
-__global__ void __launch_bounds__(256) k_sh_gram(GridView g, int m0, int m1, int S, const int* __restrict__ sorted_vox, const int* __restrict__ sorted_sub,
-                                                 double* __restrict__ gram /*[S][100]*/, double* __restrict__ wsub /*[S]*/) {
+// Gram accumulation over the subvolume-sorted list of eligible voxels [m0, m1) (a rank's slice).  Wave (sub, chunk) walks tiles [chunk * CT, (chunk + 1) * CT) of the
+// subvolume's run in 64-voxel tiles and writes ITS 10 x 10 block and weight sum (part / wpart, zeroed by the caller: a wave without voxels writes nothing) — no block is
+// shared by waves, nothing is added atomically, the sums of an estimate are bit-reproducible.  Round 4 gave a subvolume ONE wave (a single global volume of 2 M voxels
+// = one wave walking 36 k tiles); round 3 used fp64 atomics wherever a chunk ended inside a subvolume.
+constexpr int SH_CHUNK_TILES = 32;
+__global__ void __launch_bounds__(256) k_sh_gram(GridView g, int m0, int m1, int S, int nchunk, const int* __restrict__ sorted_vox, const int* __restrict__ sorted_sub,
+                                                 double* __restrict__ part /*[S][nchunk][100]*/, double* __restrict__ wpart /*[S][nchunk]*/) {
     __shared__ double feat[4][64][17];     // +1 padding: the MFMA operand read walks a column of 4 voxels x 16 features
     __shared__ double wl[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int sub = blockIdx.x * 4 + wv;
+    const int sub = blockIdx.x * 4 + wv, chunk = blockIdx.y;
     if (sub >= S) return;
     // the subvolume's run of the (sorted) list, cut to the slice
     int lo = m0, hi = m1;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_sub[mid] < sub) lo = mid + 1; else hi = mid; }
-    const int first = lo;
+    const int run0 = lo;
     hi = m1;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_sub[mid] <= sub) lo = mid + 1; else hi = mid; }
-    const int last = lo;
-    if (last <= first) return;                                       // (gram / wsub are zeroed by the caller)
+    const int run1 = lo;
+    const long long c0 = (long long)run0 + (long long)chunk * (SH_CHUNK_TILES * 64);
+    if (c0 >= run1) return;
+    const int first = (int)c0, last = (int)((c0 + SH_CHUNK_TILES * 64 < run1) ? c0 + SH_CHUNK_TILES * 64 : run1);
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     double wtot = 0.0;
     for (int t0 = first; t0 < last; t0 += 64) {
@@ -126,10 +131,19 @@ __global__ void __launch_bounds__(256) k_sh_gram(GridView g, int m0, int m1, int
         __builtin_amdgcn_wave_barrier();
     }
     const int col = lane & 15;
+    double* const out = part + ((size_t)sub * nchunk + chunk) * 100;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int row = (lane >> 4) + 4 * r; if (row < 10 && col < 10) gram[(size_t)sub * 100 + row * 10 + col] = acc[r]; }
+    for (int r = 0; r < 4; ++r) { const int row = (lane >> 4) + 4 * r; if (row < 10 && col < 10) out[row * 10 + col] = acc[r]; }
     for (int o = 32; o > 0; o >>= 1) wtot += __shfl_down(wtot, o, 64);
-    if (lane == 0) wsub[sub] = wtot;
+    if (lane == 0) wpart[(size_t)sub * nchunk + chunk] = wtot;
+}
+// the chunks of every subvolume, added in chunk order (one thread per entry of a block; entry 100 = the weight sum)
+__global__ void __launch_bounds__(128) k_sh_gram_sum(int S, int nchunk, const double* __restrict__ part, const double* __restrict__ wpart, double* __restrict__ gram, double* __restrict__ wsub) {
+    const int sub = blockIdx.x, e = threadIdx.x;
+    if (sub >= S || e > 100) return;
+    double s = 0.0;
+    if (e < 100) { for (int c = 0; c < nchunk; ++c) s += part[((size_t)sub * nchunk + c) * 100 + e]; gram[(size_t)sub * 100 + e] = s; }
+    else { for (int c = 0; c < nchunk; ++c) s += wpart[(size_t)sub * nchunk + c]; wsub[sub] = s; }
 }
 
 __global__ void __launch_bounds__(256) k_sh_assign(int M, const unsigned long long* __restrict__ sorted_keys, const unsigned long long* __restrict__ uniq, int S, int* __restrict__ sorted_sub) {
@@ -178,9 +192,13 @@ __global__ void __launch_bounds__(256) k_sh_interpolate(GridView g, ShParams sp,
 void launch_sh_keys(hipStream_t st, GridView g, ShParams sp, unsigned long long* keys, int* iota) { if (g.N > 0) k_sh_keys<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, keys, iota); }
 void launch_sh_all_keys(hipStream_t st, GridView g, ShParams sp, unsigned long long* keys) { if (g.N > 0) k_sh_all_keys<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, keys); }
 void launch_sh_assign(hipStream_t st, int M, const unsigned long long* sorted_keys, const unsigned long long* uniq, int S, int* sorted_sub) { if (M > 0) k_sh_assign<<<(M + 255) / 256, 256, 0, st>>>(M, sorted_keys, uniq, S, sorted_sub); }
-void launch_sh_gram(hipStream_t st, GridView g, int m0, int m1, int S, const int* sorted_vox, const int* sorted_sub, double* gram, double* wsub) {
+int sh_gram_chunks(long long longest_run) { const long long per = (long long)SH_CHUNK_TILES * 64; const long long n = (longest_run + per - 1) / per; return n < 1 ? 1 : (int)n; }
+// nchunk >= sh_gram_chunks(longest run of the slice); part [S * nchunk * 100] and wpart [S * nchunk] are scratch, zeroed here
+void launch_sh_gram(hipStream_t st, GridView g, int m0, int m1, int S, int nchunk, const int* sorted_vox, const int* sorted_sub, double* part, double* wpart, double* gram, double* wsub) {
     if (m1 <= m0 || S <= 0) return;
-    k_sh_gram<<<(S + 3) / 4, 256, 0, st>>>(g, m0, m1, S, sorted_vox, sorted_sub, gram, wsub);
+    (void)hipMemsetAsync(part, 0, sizeof(double) * (size_t)S * nchunk * 100, st); (void)hipMemsetAsync(wpart, 0, sizeof(double) * (size_t)S * nchunk, st);
+    k_sh_gram<<<dim3((S + 3) / 4, nchunk), 256, 0, st>>>(g, m0, m1, S, nchunk, sorted_vox, sorted_sub, part, wpart);
+    k_sh_gram_sum<<<S, 128, 0, st>>>(S, nchunk, part, wpart, gram, wsub);
 }
 void launch_sh_interpolate(hipStream_t st, GridView g, ShParams sp, const unsigned long long* uniq, int S, const double* sh, float* out) {
     if (g.N > 0) k_sh_interpolate<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, uniq, S, sh, out);

@@ -11,9 +11,17 @@
 // LDS buffer system by system in the pull phase.  With NB systems the pass is VALU-bound from NB = 3 on (each row costs ~NB x the arithmetic for one load),
 // which is why a batch of more than 3 systems is split into groups of <= 3 rather than widened (and why LDS holds 3 staged inputs and no more at K = 200).
 //
-// Every sum is taken in a fixed order: the halo is PULLED over the plan's lists (k_tile_pull_plan) and the pose block goes through per-wave keyframe tables — the
-// arithmetic of system b is, operation for operation, that of k_eg_tile<512, 1536, 5, false, 6> (the bit-reproducible variant) on u_b, so a system iterated in a
-// batch goes through bit-identical states to the same system iterated alone in I3D_DETERMINISTIC=1 (tests/test_gpu_ladder.py).
+// Every sum is taken in a fixed order: the halo is PULLED over the plan's lists (k_tile_pull_plan), the pose block goes through per-wave keyframe tables, the wave
+// sums are DPP trees — a launch is bit-reproducible, and the result of a system does not depend on which other systems share its launch (NB is only a loop
+// bound around per-system arithmetic): a system iterated in a batch goes through bit-identical states to the same system iterated alone through k_eg_tile_mr<1>
+// (tests/test_gpu_ladder.py).  Against k_eg_tile the pose sums are associated differently (see mr_table_add), i.e. equal to fp32 round-off, not bit for bit.
+//
+// What the first version of this kernel taught (profiles/r05_ladder_mr_v1.json: 0.73 ms for 3 systems against 3 x 0.275 ms serial — no gain): the pass is bound by
+// INSTRUCTION ISSUE, not by bandwidth, as soon as more than one system shares a row.  (a) The compiler does not batch LDS reads that feed one FMA chain: every
+// ds_read was followed by its own s_waitcnt, 27 exposed LDS latencies per row and system at 2 waves per SIMD.  Here the inputs of all systems sit side by side in
+// LDS (one 16-byte read per stencil slot serves every system) and a row's reads are issued together in front of a scheduling barrier.  (b) The wave sums of the pose
+// block were readlane trees with an exec-masked LDS add each (25 instructions and 6 hazard stalls per value): here 4 + 2 DPP adds per value, all values of a round
+// interleaved, ONE exec-masked block of LDS adds.
 #include <cstring>
 #include <cstdlib>
 #include "kernels.hpp"
@@ -26,28 +34,38 @@ namespace i3d {
 constexpr int MR_T = 512, MR_HMAX = 1536, MR_NWV = MR_T / 64, MR_TC = 32;
 
 // LDS layout in floats.  Everything whose size does not depend on K sits at COMPILE-TIME offsets (an offset that is a constant costs no scalar register across the
-// row loop; the first version of this kernel derived every system block from K and spilled 40-56 scalar registers into vector lanes):
+// row loop):
 //   [flag | 3 pad] [NB][72] per-wave intrinsics / distortion sums | [NWV][TC] keyframe tags (shared by the systems: the rows are) | [NB][NWV][TC][6] table sums |
 //   [NB] x { u_s, u_a [2 NSLOT] | Er row values [T + 4] } | the tile's pull list [2 HMAX] | column sums of ONE system [12][T] | pull-list offsets [(HMAX + 4) / 2, rounded]
-// then, per system and K-dependent: dense camera accumulator [rs + 9] | camera part of u_b [6K + 9].
+//   | the lanes' running p.q [NB][T] fp64 (parked here: as register pairs they are live across the whole row loop)
+// then, per system and K-dependent: dense camera accumulator [rs + 9] | pose part of u_b [6K] | its intrinsics / distortion part [9, padded to 12, 16-byte aligned].
+// (Inputs of the systems interleaved per slot — one 16-byte read serving three systems — were built and dropped: the 40 registers one row's reads then occupy
+// spilled the 3-system kernel; what matters is that a system's reads are issued TOGETHER, not that they are few.)
 template <int NB> struct MrConst {
     static constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, NSLOT = T + HMAX + 1;
     static constexpr int CAMW = (NW * 9 + 3) & ~3, VSTR = NW * TC * 6;
     static constexpr int D_FLAG = 0, D_CAM9W = 4, D_TAG = D_CAM9W + NB * CAMW, D_VAL = D_TAG + NW * TC;
     static constexpr int O_U = D_VAL + NB * VSTR, UB = (2 * NSLOT + T + 4 + 3) & ~3;          // system b: u_s at O_U + b UB, u_a behind it, then the Er row values
-    static constexpr int O_LIST = O_U + NB * UB, O_C = O_LIST + 2 * HMAX, O_OFFS = O_C + 12 * T, D0 = O_OFFS + (((HMAX + 4) / 2 + 3) & ~3);
+    static constexpr int O_LIST = O_U + NB * UB, O_C = O_LIST + 2 * HMAX, O_OFFS = O_C + 12 * T, O_PQ = O_OFFS + (((HMAX + 4) / 2 + 3) & ~3), D0 = O_PQ + NB * 2 * T;      // O_PQ: the lanes' running p.q, fp64, [NB][T]
 };
-struct MrLayout { int o_upose, SK; size_t bytes; };          // the K-dependent tail: system b at D0 + b SK: accumulator, then (at o_upose) the camera part of u_b
+struct MrLayout { int o_upose, o_ui, SK; size_t bytes; };          // the K-dependent tail: system b at D0 + b SK: accumulator, then (at o_upose) the pose part of u_b, then (at o_ui, 16-byte aligned) its 9 intrinsics / distortion entries
 static __host__ __device__ inline MrLayout mr_layout(int D0, int NB, int K) {
-    const int nshared = 6 * K + 9, rs = (6 * K) | 1;
+    const int rs = (6 * K) | 1;
     MrLayout L;
-    L.o_upose = (rs + 9 + 3) & ~3; L.SK = (L.o_upose + nshared + 3) & ~3;
+    L.o_upose = (rs + 9 + 3) & ~3; L.o_ui = (L.o_upose + 6 * K + 3) & ~3; L.SK = L.o_ui + 12;
     L.bytes = (size_t)(D0 + NB * L.SK) * sizeof(float);
     return L;
 }
 static size_t mr_lds_bytes(int NB, int K) { return NB == 1 ? mr_layout(MrConst<1>::D0, 1, K).bytes : (NB == 2 ? mr_layout(MrConst<2>::D0, 2, K).bytes : mr_layout(MrConst<3>::D0, 3, K).bytes); }
 
-// the pose columns of one row slot across the wave for NB systems: wave_table_add (wave_ops.hpp) with the table look-up done once
+// one step of a wave sum: v += v of the lane the DPP control selects (a lane without a source — row_bcast15 into row 0, row_bcast31 into rows 0 and 1 — adds 0: bound_ctrl)
+template <int CTRL> static __device__ inline float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// The pose columns of one row slot across the wave for NB systems: wave_table_add (wave_ops.hpp) with the table look-up done once per round and the 6 NB wave sums of a
+// round taken TOGETHER — xor butterfly inside every row of 16 lanes (4 DPP adds), every row into the next (row_bcast15), row 1 into 2 and 3 (row_bcast31): lane 63
+// holds (r3 + r2) + (r1 + r0) and adds all of them to the wave's table in one exec-masked block.  No readlane, no scalar round trip, the chains of the different values
+// interleave (a DPP read needs two idle slots behind the write of its source: with 6 NB independent chains they are never idle).
 template <int NB>
 static __device__ inline void mr_table_add(bool valid, int f, const float (&jp)[6], const float (&ts)[NB], float* lds, int o_tag, int o_val, int val_stride, int& count, int o_dense, int dense_stride) {
     bool pending = valid;
@@ -63,13 +81,31 @@ static __device__ inline void mr_table_add(bool valid, int f, const float (&jp)[
         if (hit != 0ull) slot = (__ffsll((long long)hit) - 1) & (MR_TC - 1);
         else if (count < MR_TC) { slot = count; if (lane == 0) lds[o_tag + slot] = __int_as_float(f0); count = count + 1; }
         else slot = -1;
-        const bool lead = lane == leader;
+        float v[NB * 6];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
+            const float tm = mine ? ts[b] : 0.0f;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const float sum = wave_sum(mine ? jp[i] * ts[b] : 0.0f);
-                if (lead) lds_add(slot >= 0 ? &lds[o_val + b * val_stride + slot * 6 + i] : &lds[o_dense + b * dense_stride + 6 * f0 + i], sum);
+            for (int i = 0; i < 6; ++i) v[b * 6 + i] = jp[i] * tm;
+        }
+#pragma unroll
+        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0xB1>(v[j]);        // quad_perm [1,0,3,2]
+#pragma unroll
+        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x4E>(v[j]);        // quad_perm [2,3,0,1]
+#pragma unroll
+        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x141>(v[j]);       // row_half_mirror
+#pragma unroll
+        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x140>(v[j]);       // row_mirror: every lane of a row holds the row's sum
+#pragma unroll
+        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x142>(v[j]);             // row_bcast15: lane 15 of every row into the next row (row 3 = r3 + r2, row 1 = r1 + r0)
+#pragma unroll
+        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x143>(v[j]);             // row_bcast31: lane 31 into rows 2 and 3 -> lane 63 = (r3 + r2) + (r1 + r0)
+        if (lane == 63) {
+            const int base = slot >= 0 ? o_val + slot * 6 : o_dense + 6 * f0, stride = slot >= 0 ? val_stride : dense_stride;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) lds_add(&lds[base + b * stride + i], v[b * 6 + i]);      // (no return value; the table is this wave's alone, its LDS operations execute in program order)
             }
         }
         pending = pending && !mine;
@@ -103,7 +139,7 @@ template <int NB>
 __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, MrArgs m, const unsigned* __restrict__ lnbr, const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx,
                                                         const int* __restrict__ halo_cnt, int tiles_per_block, int ntl, int cam_stride, const int* __restrict__ gmaxv,
                                                         const unsigned short* __restrict__ hp_off, const unsigned short* __restrict__ hp_src) {
-    constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, ZSLOT = T + HMAX, NSLOT = ZSLOT + 1, NCOL = 12, HPCAP = 4 * HMAX, NQH = HMAX / T;
+    constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, ZSLOT = T + HMAX, NCOL = 12, HPCAP = 4 * HMAX, NQH = HMAX / T;
     {   // every system of the launch has stopped: nothing to do (launches queued behind the convergence flags)
         bool any = false;
 #pragma unroll
@@ -116,11 +152,11 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
     using MC = MrConst<NB>;
     constexpr int D_FLAG = MC::D_FLAG, D_CAM9W = MC::D_CAM9W, CAMW = MC::CAMW, D_TAG = MC::D_TAG, D_VAL = MC::D_VAL, VSTR = MC::VSTR, D0 = MC::D0;
     const MrLayout L = mr_layout(D0, NB, K);
-    const int SB = L.SK, o_upose = L.o_upose;
+    const int SB = L.SK, o_upose = L.o_upose, o_ui = L.o_ui;
 #define SYS(b) (D0 + (b) * SB)                                   /* K-dependent block of system b: dense pose accumulator [0, 6K), intrinsics / distortion totals [rs, rs + 9), camera part of u_b at o_upose */
 #define U_S(b) (MC::O_U + (b) * MC::UB)
-#define U_A(b) (MC::O_U + (b) * MC::UB + NSLOT)
-#define TR_L(b) (MC::O_U + (b) * MC::UB + 2 * NSLOT)
+#define U_A(b) (MC::O_U + (b) * MC::UB + MC::NSLOT)
+#define TR_L(b) (MC::O_U + (b) * MC::UB + 2 * MC::NSLOT)
 #define C_L (MC::O_C)
 #define hp_list reinterpret_cast<unsigned short*>(lds + MC::O_LIST)
 #define hp_offs reinterpret_cast<unsigned short*>(lds + MC::O_OFFS)
@@ -131,16 +167,17 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
     for (int b = 0; b < NB; ++b) {
         const float* ub = m.u0 + (size_t)m.sys[b] * m.vec;
         for (int e = i; e < rs + 9; e += T) lds[SYS(b) + e] = 0.0f;
-        for (int e = i; e < nshared; e += T) lds[SYS(b) + o_upose + e] = ub[tail + e];
+        for (int e = i; e < 6 * K; e += T) lds[SYS(b) + o_upose + e] = ub[tail + e];
+        if (i < 12) lds[SYS(b) + o_ui + i] = i < 9 ? ub[tail + 6 * K + i] : 0.0f;
         for (int e = lane; e < TC * 6; e += 64) lds[D_VAL + b * VSTR + wave * (TC * 6) + e] = 0.0f;
     }
     if (lane < TC) lds[D_TAG + wave * TC + lane] = __int_as_float(-1);
     const int o_tag = D_TAG + wave * TC, o_val = D_VAL + wave * (TC * 6);
     int tcount = 0;
     float cam9[NB][9];
-    double pq[NB];
+#define PQ_L(b) reinterpret_cast<double*>(lds + MC::O_PQ + (b) * 2 * T)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { pq[b] = 0.0;
+    for (int b = 0; b < NB; ++b) { PQ_L(b)[i] = 0.0;
 #pragma unroll
         for (int q = 0; q < 9; ++q) cam9[b][q] = 0.0f; }
     const float tw0 = p.type_wf[0], tw1 = p.type_wf[1], tw2 = p.type_wf[2], tw3 = p.type_wf[3];
@@ -209,7 +246,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
         for (int b = 0; b < NB; ++b) {
             lds[U_S(b) + i] = us[b]; lds[U_A(b) + i] = ua[b];
 #pragma unroll
-            for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; if (hq < HMAX) { const bool hv = hq < H; lds[U_S(b) + T + hq] = hv ? hs[b][q] : 0.0f; lds[U_A(b) + T + hq] = hv ? ha[b][q] : 0.0f; } }
+            for (int q = 0; q < NQH; ++q) { const int hq = i + q * T; const bool hv = hq < H; lds[U_S(b) + T + hq] = hv ? hs[b][q] : 0.0f; lds[U_A(b) + T + hq] = hv ? ha[b][q] : 0.0f; }
             if (i == 0) { lds[U_S(b) + ZSLOT] = 0.0f; lds[U_A(b) + ZSLOT] = 0.0f; lds[TR_L(b) + T] = 0.0f; }
         }
 #pragma unroll
@@ -232,15 +269,20 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
             for (int c = 0; c < NCOL; ++c) C[b][c] = 0.0f;
             const int rg[6] = {sx, mx, sy, my, sz, mz};
             float tr = 0.0f; double pq_pre = 0.0;
+            const float usb = lds[U_S(b) + i];
             if (rf & 1) {
-                const float lap = ((((((-6.0f * us[b]) + lds[U_S(b) + rg[0]]) + lds[U_S(b) + rg[1]]) + lds[U_S(b) + rg[2]]) + lds[U_S(b) + rg[3]]) + lds[U_S(b) + rg[4]]) + lds[U_S(b) + rg[5]];
+                const float lap = ((((((-6.0f * usb) + lds[U_S(b) + rg[0]]) + lds[U_S(b) + rg[1]]) + lds[U_S(b) + rg[2]]) + lds[U_S(b) + rg[3]]) + lds[U_S(b) + rg[4]]) + lds[U_S(b) + rg[5]];
                 tr = tw1 * lap; if (in) pq_pre += (double)(tr * lap);
                 self_s[b] += -6.0f * tr;
             }
             lds[TR_L(b) + i] = tr;
-            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * us[b]; if (in) pq_pre += (double)(ts * us[b]); self_s[b] += ts; }
-            if (rf & 7) pq[b] += pq_pre;
+            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * usb; if (in) pq_pre += (double)(ts * usb); self_s[b] += ts; }
+            if (rf & 7) PQ_L(b)[i] += pq_pre;
         }
+        // the lane's 9 forward stencil slots (sdf slots 1..9 of a row): the same for every row of the entry and for every system
+        int so[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) so[c] = unpack12(ln, c);
         // one row: t_b = W (J u_b) for every system, J^T t_b into the lane's column sums (registers)
         auto consume = [&](const RowBlock& rb, int k) {
             const float4 (&rw)[7] = rb.p;
@@ -256,16 +298,26 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                 J[28] = rb.j28;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    float d = J[0] * lds[U_S(b) + i] + J[10] * lds[U_A(b) + i];
+                    // every LDS read of (row, system) first, behind one another: left to itself the compiler puts an s_waitcnt behind each of the 29
+                    float sv[10], av[4], pu[6];
+                    sv[0] = lds[U_S(b) + i];
 #pragma unroll
-                    for (int c = 1; c < 10; ++c) d += J[c] * lds[U_S(b) + unpack12(ln, c - 1)];
-                    d += J[11] * lds[U_A(b) + sx] + J[12] * lds[U_A(b) + sy] + J[13] * lds[U_A(b) + sz];
+                    for (int c = 1; c < 10; ++c) sv[c] = lds[U_S(b) + so[c - 1]];
+                    av[0] = lds[U_A(b) + i]; av[1] = lds[U_A(b) + sx]; av[2] = lds[U_A(b) + sy]; av[3] = lds[U_A(b) + sz];
                     const int o_up = SYS(b) + o_upose + 6 * f;
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) d += J[P_POSE + q] * lds[o_up + q];
-                    const int o_ui = SYS(b) + o_upose + 6 * K;
+                    for (int q = 0; q < 6; ++q) pu[q] = lds[o_up + q];
+                    const float4 u0 = *reinterpret_cast<const float4*>(lds + SYS(b) + o_ui), u1 = *reinterpret_cast<const float4*>(lds + SYS(b) + o_ui + 4), u2 = *reinterpret_cast<const float4*>(lds + SYS(b) + o_ui + 8);
+                    __builtin_amdgcn_sched_barrier(0);
+                    float d = J[0] * sv[0] + J[10] * av[0];
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) d += J[P_INTR + q] * lds[o_ui + q];
+                    for (int c = 1; c < 10; ++c) d += J[c] * sv[c];
+                    d += J[11] * av[1] + J[12] * av[2] + J[13] * av[3];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) d += J[P_POSE + q] * pu[q];
+                    d += J[P_INTR] * u0.x; d += J[P_INTR + 1] * u0.y; d += J[P_INTR + 2] * u0.z; d += J[P_INTR + 3] * u0.w;
+                    d += J[P_INTR + 4] * u1.x; d += J[P_INTR + 5] * u1.y; d += J[P_INTR + 6] * u1.z; d += J[P_INTR + 7] * u1.w;
+                    d += J[P_INTR + 8] * u2.x;
                     const float t = rho * d;
                     pq_rows[b] += t * d;
                     self_s[b] += J[0] * t; self_a[b] += J[10] * t;
@@ -277,6 +329,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                         for (int q = 0; q < 9; ++q) cam9[b][q] += J[P_INTR + q] * t;
                     }
                     tsel[b] = t;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!p.fix_poses && in) { fsel = f; pvalid = true; }
             }
@@ -290,7 +343,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
         consume(rwA, 4);
         if (in) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) pq[b] += (double)pq_rows[b];
+            for (int b = 0; b < NB; ++b) PQ_L(b)[i] += (double)pq_rows[b];
         }
         unsigned lr[2];
 #pragma unroll
@@ -324,7 +377,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                 float ea = 0.0f, eq = 0.0f;
 #pragma unroll
                 for (int d = 0; d < 6; ++d) { const float diff = ua_c - lds[U_A(b) + rg[d]]; const float t = eaw[d] * diff; ea += t; eq += (rg[d] == ZSLOT ? 1.0f : 0.5f) * t * diff; }
-                qa += tw3 * ea; pq[b] += (double)(tw3 * eq);
+                qa += tw3 * ea; PQ_L(b)[i] += (double)(tw3 * eq);
                 qacc[a] = qs; qacc[chunk + a] = qa;
             }
 #pragma unroll
@@ -374,7 +427,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
     }
     if (m.pq0) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) block_partial_d(pq[b], m.pq0 + (size_t)m.sys[b] * m.part, 1, 0);
+        for (int b = 0; b < NB; ++b) block_partial_d(PQ_L(b)[i], m.pq0 + (size_t)m.sys[b] * m.part, 1, 0);
     }
 #undef SYS
 #undef U_S
@@ -383,6 +436,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #undef C_L
 #undef hp_list
 #undef hp_offs
+#undef PQ_L
 }
 
 // the largest number of systems one launch can take at K keyframes (the staged inputs of every system must fit the 160 KB of LDS): 3 at the bench's K = 200, 0 = never

@@ -95,6 +95,7 @@ struct i3d_context {
     i3d::DevBuf<unsigned short> tp_hp_off, tp_hp_src; bool halo_pull = false;      // halo pull lists of the plan (tile_pass.hip k_tile_pull_plan): I3D_HALO_PULL=1 and the bit-reproducible mode
     bool ladder_lists = false;      // the lists are built for the multi-system operator pass of the ladder (tile_pass_mr.hip) although the single-system pass pushes its halo
     // ---- the damping ladder (solver.cpp lm_solve / pcg_solve_ladder): per-system slabs of the PCG vectors and partial sums ----
+    bool mr1_serial = false;        // I3D_EGT_MR1=1: the serial loop's operator pass is k_eg_tile_mr<1> (A/B runs, the control of the ladder tests)
     int ladder_max = 1;             // I3D_LADDER (read at every assemble): attempts solved together, 1 = the serial loop
     int ladder_hint = 0;            // LM attempts of the previous outer iteration (the first batch speculates that deep)
     i3d::LadVec lad{};              // strides of the slabs below

@@ -227,7 +227,10 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         c->ladder_max = v < 1 ? 1 : (v > LADDER_MAX ? LADDER_MAX : v);
         if (sharded(c) || slots != 5 || eg_tile_mr_max_systems(c->K) < 2) c->ladder_max = 1;
         { const char* l = std::getenv("I3D_PCG_LEGACY"); if (l && l[0] == '1') c->ladder_max = 1; }
-        c->ladder_lists = c->ladder_max > 1;
+        // I3D_EGT_MR1=1: the SERIAL loop streams its rows through k_eg_tile_mr<1> (the multi-system kernel with one system) instead of k_eg_tile — the control of the
+        // ladder tests (same kernel family: a system solved alone vs in a batch, bit for bit) and an A/B switch
+        { const char* m1 = std::getenv("I3D_EGT_MR1"); c->mr1_serial = m1 && m1[0] == '1' && !sharded(c) && slots == 5 && eg_tile_mr_max_systems(c->K) >= 1; }
+        c->ladder_lists = c->ladder_max > 1 || c->mr1_serial;
     }
     {   // halo sums of the operator pass pulled over plan lists instead of pushed with LDS atomics: always in the bit-reproducible mode, else on request
         const char* e = std::getenv("I3D_HALO_PULL");
@@ -246,7 +249,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         { const long long la = c->last_sizes[0], lr = c->last_sizes[1];
           const bool forced = std::getenv("I3D_EGT_TILE") != nullptr;
           if (!forced && la > 0 && (double)lr < 0.8 * (double)slots * (double)la) c->tile_T = 512;
-          if (c->ladder_max > 1) c->tile_T = 512; }      // the multi-system pass exists in the 512-entry geometry (8 waves at 2 per SIMD: the column sums of 3 systems live in registers)
+          if (c->ladder_max > 1 || c->mr1_serial) c->tile_T = 512; }      // the multi-system pass exists in the 512-entry geometry (8 waves at 2 per SIMD: the column sums of 3 systems live in registers)
         shard_range(c->A, 1, 0, c->chunk, c->own0, c->own1); c->nC = c->A; c->slice = c->chunk;
         RowView r0 = c->row_view(); TimedScope t(c, I3D_K_CLASSIFY);
         CTX_HIP(c, launch_tile_plan(s, r0, c->tile_plan(), c->tp_temp.p, c->tp_temp.n));
@@ -533,6 +536,12 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
     { TimedScope t(c, I3D_K_VECTOR); a.cur = st2; n_step = launch_pcg_step3(s, 0 /*init*/, a); }
     // pass numbers are the epochs of the in-kernel exchanges: identical on all ranks (every rank queues the same solves; how many passes a rank's HOST queued
     // behind the convergence flag may differ, so every solve takes a fixed block of numbers)
+    const bool mr1 = c->mr1_serial && !sh && tp.T == 512 && tp.hp_off != nullptr && r.slots == 5;
+    auto op = [&](double* pq, const PcgState* cur) -> int {      // q_acc = J^T W J u on the rows of this rank
+        if (mr1) { const int sys0[3] = {0, 0, 0}; LadVec z; std::memset(&z, 0, sizeof(z));
+                   return launch_eg_tile_mr(s, r, p, tp, 1, sys0, c->v_u.p, c->v_qacc.p, tp.qh, pq, c->cam_part.p, NSP, cur, z); }
+        return launch_eg_tile(s, r, p, c->v_u.p, tp, nullptr, c->v_qacc.p, pq, cur, c->cam_part.p, NSP);
+    };
     const int seq0 = c->pcg_seq;
     int it = 1;
     for (;; ++it) {
@@ -542,14 +551,14 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
           a.n_d2 = launch_pcg_dir3(s, it == 1, own, to, L.NS, c->v_z.p, c->v_p.p, c->v_S.p, c->v_u.p, c->v_D2.p, c->v_cm.p, c->d_lm.p, step_part, n_step, d2_part, prev, cur, c->d_flags, seq0 + it,
                                    sh ? &sa : nullptr); }
         if (sh) { c->comm->count_reduce(4); c->comm->count_halo(c->halo.n_send); c->comm->count_reduce((size_t)L.NS + 1); }      // (logged as exchanges of this pass: they have no launches of their own)
-        { TimedScope t(c, I3D_K_EG_PASS); a.n_pq = launch_eg_tile(s, r, p, c->v_u.p, tp, nullptr, c->v_qacc.p, pq_part, cur, c->cam_part.p, NSP); a.n_cam = a.n_pq; }
+        { TimedScope t(c, I3D_K_EG_PASS); a.n_pq = op(pq_part, cur); a.n_cam = a.n_pq; }
         a.cur = cur;
         if (it % 10 != 0) { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3(s, 1, a); }
         else {                                                                   // residual_reset_period: r = b - A x instead of r -= alpha q
             { TimedScope t(c, I3D_K_VECTOR); launch_pcg_step3(s, 2, a);
               launch_mul2(s, own, c->v_S.p, c->v_x.p, c->v_u.p); launch_mul(s, L.NS, c->v_S.p + to, c->v_x.p + to, c->v_u.p + to); }
             if (sh) { TimedScope t(c, I3D_K_COMM); launch_rim_u(s, sa, cur); c->comm->count_halo(c->halo.n_send); }
-            { TimedScope t(c, I3D_K_EG_PASS); a.n_cam = launch_eg_tile(s, r, p, c->v_u.p, tp, nullptr, c->v_qacc.p, nullptr, cur, c->cam_part.p, NSP); }
+            { TimedScope t(c, I3D_K_EG_PASS); a.n_cam = op(nullptr, cur); }
             { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3(s, 3, a); }
         }
         if (it >= 2) {                                                           // look at the boundary of pass it-1 while pass it runs

@@ -3,13 +3,16 @@
 The reference restarts its trust region at 1e4 in every outer iteration (optimizer.cpp:138 builds a fresh NLSSolver; nls_solver.cpp:322-323 never takes effect), so
 most LM attempts are rejected, and after a rejection the next radius is known in advance (LevenbergMarquardtStrategy::StepRejected).  The library therefore SOLVES up to
 I3D_LADDER consecutive attempts together — PCG systems that differ only in the LM diagonal, iterated in lock step, one stream of the stored rows for up to three of
-them — and then DECIDES them one after the other with the same kernel as the serial loop.  Nothing about the result may change:
+them (k_eg_tile_mr) — and then DECIDES them one after the other with the same kernel as the serial loop.  Nothing about the result may change.  In the bit-reproducible
+mode (I3D_DETERMINISTIC=1), fields, camera, costs, attempts, accept / reject sequence, PCG iteration counts and final radius must be equal BIT FOR BIT between
 
-  * in the bit-reproducible mode (I3D_DETERMINISTIC=1) the ladder, at every depth and grouping, must return bit for bit what the serial loop (I3D_LADDER=1) returns:
-    fields, camera, costs, attempts, accept / reject sequence, PCG iteration counts, final radius;
-  * in the default mode (fp32 LDS atomics inside the single-system pass) to round-off, with the same attempts and accept sequence;
-  * an invalid step (radius halved instead of divided) puts a batch out of step: the attempt behind it must be solved again, alone, with the radius the trust region
-    really reached — again bit for bit the serial loop's answer.
+  (A) the serial loop of round 4 (I3D_LADDER=1, k_eg_tile) and the ladder driving that same kernel once per system (I3D_LADDER_MR=0): the lock-step solve, the
+      speculation and the decision chain change nothing;
+  (B) the serial loop streaming its rows through k_eg_tile_mr<1> (I3D_EGT_MR1=1) and the ladder at every depth and grouping (k_eg_tile_mr<1,2,3>): a system's result
+      does not depend on which other systems share its stream of the rows.
+k_eg_tile_mr against k_eg_tile itself is equality to fp32 round-off (its wave sums are DPP trees with another association): checked as such.  In the default mode
+(fp32 LDS atomics inside k_eg_tile) everything agrees to round-off with the same attempts and accept sequence.  An invalid step (radius halved instead of divided)
+puts a batch out of step: the attempt behind it must be solved again, alone, with the radius the trust region really reached — bit for bit the serial answer.
 Oracle parity of the ladder itself is what the rest of the suite checks: the ladder is the default, every other GPU test runs through it."""
 import numpy as np
 import pytest
@@ -56,38 +59,61 @@ def _same(a, b):
 _serial = {}
 
 
-def _serial_det(S, monkeypatch):
-    """two chained iterations of the serial loop in the bit-reproducible mode (computed once per module)"""
-    if "run" not in _serial:
-        monkeypatch.setenv("I3D_DETERMINISTIC", "1"); monkeypatch.setenv("I3D_LADDER", "1")
-        _serial["run"] = _run(S)
-        assert _serial["run"][4]["batches"] == 0 and _serial["run"][4]["depth"] == 1
-        assert sum(s.num_attempts for s in _serial["run"][0]) >= 6          # rejected attempts are what the ladder is about
-    return _serial["run"]
+def _serial_det(S, monkeypatch, mr1):
+    """two chained iterations of the serial loop in the bit-reproducible mode (computed once per module): mr1 = its rows through k_eg_tile_mr<1> instead of k_eg_tile"""
+    key = "mr1" if mr1 else "egt"
+    if key not in _serial:
+        monkeypatch.setenv("I3D_DETERMINISTIC", "1"); monkeypatch.setenv("I3D_LADDER", "1"); monkeypatch.setenv("I3D_EGT_MR1", "1" if mr1 else "0")
+        _serial[key] = _run(S)
+        assert _serial[key][4]["batches"] == 0 and _serial[key][4]["depth"] == 1
+        assert sum(s.num_attempts for s in _serial[key][0]) >= 6          # rejected attempts are what the ladder is about
+    return _serial[key]
 
 
-# (depth, systems per row stream, multi-system kernel, lone systems through it too)
-@pytest.mark.parametrize("depth,group,mr,mr1", [("6", "3", "0", "0"), ("6", "3", "1", "0"), ("6", "2", "1", "0"), ("3", "3", "1", "0"), ("2", "3", "1", "0"), ("6", "3", "1", "1")])
-def test_ladder_is_the_serial_loop_bit_for_bit(slice_setup, monkeypatch, depth, group, mr, mr1):
-    serial = _serial_det(slice_setup, monkeypatch)
-    monkeypatch.setenv("I3D_DETERMINISTIC", "1")
-    monkeypatch.setenv("I3D_LADDER", depth); monkeypatch.setenv("I3D_LADDER_GROUP", group); monkeypatch.setenv("I3D_LADDER_MR", mr); monkeypatch.setenv("I3D_LADDER_MR1", mr1)
+@pytest.mark.parametrize("depth", ["6", "2"])
+def test_ladder_control_flow_is_the_serial_loop_bit_for_bit(slice_setup, monkeypatch, depth):
+    """(A): the round-4 operator kernel once per system inside the lock-step solve"""
+    serial = _serial_det(slice_setup, monkeypatch, mr1=False)
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1"); monkeypatch.setenv("I3D_LADDER", depth); monkeypatch.setenv("I3D_LADDER_MR", "0"); monkeypatch.setenv("I3D_EGT_MR1", "0")
+    lad = _run(slice_setup)
+    st = lad[4]
+    assert st["batches"] >= 2 and st["depth"] == int(depth) and st["resyncs"] == 0 and st["row_streams"] == st["system_passes"], st
+    _same(serial, lad)
+
+
+# (depth, systems per row stream)
+@pytest.mark.parametrize("depth,group", [("6", "3"), ("6", "2"), ("3", "3"), ("2", "3"), ("6", "1")])
+def test_a_system_does_not_depend_on_the_systems_it_shares_the_rows_with(slice_setup, monkeypatch, depth, group):
+    """(B): k_eg_tile_mr<1> alone in the serial loop vs k_eg_tile_mr<NB> in batches"""
+    serial = _serial_det(slice_setup, monkeypatch, mr1=True)
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1"); monkeypatch.setenv("I3D_EGT_MR1", "0")
+    monkeypatch.setenv("I3D_LADDER", depth); monkeypatch.setenv("I3D_LADDER_GROUP", group); monkeypatch.setenv("I3D_LADDER_MR", "1"); monkeypatch.setenv("I3D_LADDER_MR1", "1")
     lad = _run(slice_setup)
     st = lad[4]
     assert st["batches"] >= 2 and st["depth"] == int(depth) and st["resyncs"] == 0, st
-    if mr == "1":
+    if group != "1":
         assert st["row_streams"] < st["system_passes"], st          # rows were shared
-    else:
-        assert st["row_streams"] == st["system_passes"], st
     _same(serial, lad)
+
+
+def test_multi_system_kernel_against_the_round_4_kernel(slice_setup, monkeypatch):
+    """k_eg_tile_mr<1> vs k_eg_tile in the serial loop: the same operator up to the association of its wave sums"""
+    a = _serial_det(slice_setup, monkeypatch, mr1=False); b = _serial_det(slice_setup, monkeypatch, mr1=True)
+    st1, s1, a1, c1, _ = a; st2, s2, a2, c2, _ = b
+    assert [(s.num_attempts, list(s.step_accepted[:s.num_attempts]), list(s.pcg_iterations[:s.num_attempts])) for s in st1] == \
+           [(s.num_attempts, list(s.step_accepted[:s.num_attempts]), list(s.pcg_iterations[:s.num_attempts])) for s in st2]
+    for x, y in zip(st1, st2):
+        assert abs(x.cost_final - y.cost_final) <= 1e-9 * abs(x.cost_final)
+    assert np.abs(s1 - s2).max() <= 1e-6 * np.abs(s1).max() and np.abs(a1 - a2).max() <= 1e-6 * np.abs(a1).max()
+    np.testing.assert_allclose(c2[2], c1[2], rtol=1e-6, atol=1e-8)
 
 
 def test_ladder_with_fixed_pcg_depth_and_residual_resets(slice_setup, monkeypatch):
     """30 PCG iterations per attempt: every system of a batch goes through the residual reset (r = b - A x) at iterations 10, 20, 30 in lock step."""
     monkeypatch.setenv("I3D_DETERMINISTIC", "1")
-    monkeypatch.setenv("I3D_LADDER", "1")
+    monkeypatch.setenv("I3D_LADDER", "1"); monkeypatch.setenv("I3D_EGT_MR1", "1")
     serial = _run(slice_setup, iterations=1, cg_fixed=30)
-    monkeypatch.setenv("I3D_LADDER", "6")
+    monkeypatch.setenv("I3D_LADDER", "6"); monkeypatch.setenv("I3D_EGT_MR1", "0"); monkeypatch.setenv("I3D_LADDER_MR1", "1")
     _same(serial, _run(slice_setup, iterations=1, cg_fixed=30))
 
 
@@ -111,10 +137,10 @@ def test_an_invalid_step_puts_the_batch_out_of_step_and_it_is_solved_again(slice
     occur.)"""
     monkeypatch.setenv("I3D_DETERMINISTIC", "1")
     monkeypatch.setenv("I3D_DEBUG_INVALID_ATTEMPT", "0")
-    monkeypatch.setenv("I3D_LADDER", "1")
+    monkeypatch.setenv("I3D_LADDER", "1"); monkeypatch.setenv("I3D_EGT_MR1", "1")
     serial = _run(slice_setup, iterations=1)
     assert serial[0][0].num_attempts >= 3 and serial[0][0].step_accepted[0] == 0
-    monkeypatch.setenv("I3D_LADDER", "6")
+    monkeypatch.setenv("I3D_LADDER", "6"); monkeypatch.setenv("I3D_EGT_MR1", "0"); monkeypatch.setenv("I3D_LADDER_MR1", "1")
     lad = _run(slice_setup, iterations=1)
     _same(serial, lad)
     assert lad[4]["resyncs"] >= 1, lad[4]

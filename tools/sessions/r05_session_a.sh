@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r05a
 export TMPDIR=/tmp
-python -m pytest tests/test_gpu_ladder.py -q -m gpu -p no:cacheprovider > gpurun_out/r05a/ladder_tests.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_ladder.py -q -m gpu -p no:cacheprovider > gpurun_out/r05a/ladder_tests.log 2>&1
 echo "ladder tests rc=$?" | tee -a gpurun_out/r05a/summary.txt
 tail -40 gpurun_out/r05a/ladder_tests.log
 B="python bench.py --steps 10 --warmup 2 --cpu-sample 0 --band2-steps 0"
@@ -19,8 +19,6 @@ run serial I3D_LADDER=1
 run ladder6 I3D_LADDER=6
 run ladder6_g2 I3D_LADDER=6 I3D_LADDER_GROUP=2
 run ladder6_mr1 I3D_LADDER=6 I3D_LADDER_MR1=1
-run ladder3 I3D_LADDER=3
-run serial512 I3D_LADDER=1 I3D_EGT_TILE=512
 timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider -x > gpurun_out/r05a/gpu_suite.log 2>&1
 echo "gpu suite rc=$?" | tee -a gpurun_out/r05a/summary.txt
 tail -15 gpurun_out/r05a/gpu_suite.log
