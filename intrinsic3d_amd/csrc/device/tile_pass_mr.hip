@@ -309,24 +309,26 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                     for (int q = 0; q < 6; ++q) pu[q] = lds[o_up + q];
                     const float4 u0 = *reinterpret_cast<const float4*>(lds + SYS(b) + o_ui), u1 = *reinterpret_cast<const float4*>(lds + SYS(b) + o_ui + 4), u2 = *reinterpret_cast<const float4*>(lds + SYS(b) + o_ui + 8);
                     __builtin_amdgcn_sched_barrier(0);
-                    float d = J[0] * sv[0] + J[10] * av[0];
+                    // (this file is compiled without FMA contraction and every multiply-add is spelled out: what a system's arithmetic is must not depend on how
+                    // the compiler packs the systems of a launch — the first version contracted differently for NB = 1 and NB = 3 and differed in the 11th digit)
+                    float d = fmaf(J[0], sv[0], J[10] * av[0]);
 #pragma unroll
-                    for (int c = 1; c < 10; ++c) d += J[c] * sv[c];
-                    d += J[11] * av[1] + J[12] * av[2] + J[13] * av[3];
+                    for (int c = 1; c < 10; ++c) d = fmaf(J[c], sv[c], d);
+                    d = fmaf(J[11], av[1], d); d = fmaf(J[12], av[2], d); d = fmaf(J[13], av[3], d);
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) d += J[P_POSE + q] * pu[q];
-                    d += J[P_INTR] * u0.x; d += J[P_INTR + 1] * u0.y; d += J[P_INTR + 2] * u0.z; d += J[P_INTR + 3] * u0.w;
-                    d += J[P_INTR + 4] * u1.x; d += J[P_INTR + 5] * u1.y; d += J[P_INTR + 6] * u1.z; d += J[P_INTR + 7] * u1.w;
-                    d += J[P_INTR + 8] * u2.x;
+                    for (int q = 0; q < 6; ++q) d = fmaf(J[P_POSE + q], pu[q], d);
+                    d = fmaf(J[P_INTR], u0.x, d); d = fmaf(J[P_INTR + 1], u0.y, d); d = fmaf(J[P_INTR + 2], u0.z, d); d = fmaf(J[P_INTR + 3], u0.w, d);
+                    d = fmaf(J[P_INTR + 4], u1.x, d); d = fmaf(J[P_INTR + 5], u1.y, d); d = fmaf(J[P_INTR + 6], u1.z, d); d = fmaf(J[P_INTR + 7], u1.w, d);
+                    d = fmaf(J[P_INTR + 8], u2.x, d);
                     const float t = rho * d;
-                    pq_rows[b] += t * d;
-                    self_s[b] += J[0] * t; self_a[b] += J[10] * t;
+                    pq_rows[b] = fmaf(t, d, pq_rows[b]);
+                    self_s[b] = fmaf(J[0], t, self_s[b]); self_a[b] = fmaf(J[10], t, self_a[b]);
 #pragma unroll
-                    for (int c = 1; c < 10; ++c) C[b][c - 1] += J[c] * t;
-                    C[b][9] += J[11] * t; C[b][10] += J[12] * t; C[b][11] += J[13] * t;
+                    for (int c = 1; c < 10; ++c) C[b][c - 1] = fmaf(J[c], t, C[b][c - 1]);
+                    C[b][9] = fmaf(J[11], t, C[b][9]); C[b][10] = fmaf(J[12], t, C[b][10]); C[b][11] = fmaf(J[13], t, C[b][11]);
                     if (in) {
 #pragma unroll
-                        for (int q = 0; q < 9; ++q) cam9[b][q] += J[P_INTR + q] * t;
+                        for (int q = 0; q < 9; ++q) cam9[b][q] = fmaf(J[P_INTR + q], t, cam9[b][q]);
                     }
                     tsel[b] = t;
                     __builtin_amdgcn_sched_barrier(0);

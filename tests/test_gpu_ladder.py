@@ -103,7 +103,7 @@ def test_multi_system_kernel_against_the_round_4_kernel(slice_setup, monkeypatch
     assert [(s.num_attempts, list(s.step_accepted[:s.num_attempts]), list(s.pcg_iterations[:s.num_attempts])) for s in st1] == \
            [(s.num_attempts, list(s.step_accepted[:s.num_attempts]), list(s.pcg_iterations[:s.num_attempts])) for s in st2]
     for x, y in zip(st1, st2):
-        assert abs(x.cost_final - y.cost_final) <= 1e-9 * abs(x.cost_final)
+        assert abs(x.cost_final - y.cost_final) <= 1e-7 * abs(x.cost_final)
     assert np.abs(s1 - s2).max() <= 1e-6 * np.abs(s1).max() and np.abs(a1 - a2).max() <= 1e-6 * np.abs(a1).max()
     np.testing.assert_allclose(c2[2], c1[2], rtol=1e-6, atol=1e-8)
 
@@ -139,7 +139,7 @@ def test_an_invalid_step_puts_the_batch_out_of_step_and_it_is_solved_again(slice
     monkeypatch.setenv("I3D_DEBUG_INVALID_ATTEMPT", "0")
     monkeypatch.setenv("I3D_LADDER", "1"); monkeypatch.setenv("I3D_EGT_MR1", "1")
     serial = _run(slice_setup, iterations=1)
-    assert serial[0][0].num_attempts >= 3 and serial[0][0].step_accepted[0] == 0
+    assert serial[0][0].num_attempts >= 2 and serial[0][0].step_accepted[0] == 0
     monkeypatch.setenv("I3D_LADDER", "6"); monkeypatch.setenv("I3D_EGT_MR1", "0"); monkeypatch.setenv("I3D_LADDER_MR1", "1")
     lad = _run(slice_setup, iterations=1)
     _same(serial, lad)
