@@ -253,10 +253,15 @@ enum { S3_INIT = 0, S3_NORMAL = 1, S3_XONLY = 2, S3_RESET = 3 };
 // what one thread of k_pcg_step3 reads for its 4 entries (sdf + albedo segment): every load of a batch is issued before the first use.
 // (Requesting the first batch BEFORE the prologue's reductions was tried: the registers it holds across them cost an occupancy step — 144 VGPRs —
 // and the kernel got slower, 91 against 80 ms of vector kernels per 10 iterations; profiles/r03_ab_variants.json.)
+// where system j of a ladder batch keeps its copy of the per-system arrays, relative to system 0's (all zero for the single-system launch).  Applied at the use
+// sites: a modified COPY of the argument struct went to scratch memory (976 bytes per lane, every pointer a scratch load: the vector kernels of a batch ran at half
+// the speed of the serial ones, profiles/r05_ladder_vector_scratch.json).
+struct S3Off { size_t v4, vo, qh2, part, cam, mblk, tail; int st, sys; };
 struct S3In { float4 as, aa; int4 o; int o4; float4 x[2], p[2], b[2], cm[2], r[2]; };
-template <int MODE> static __device__ inline void s3_load(const Step3Args& a, int q, S3In& v) {
+template <int MODE> static __device__ inline void s3_load(const Step3Args& a, const S3Off& o, int q, S3In& v) {
+    const float4* const qacc = a.qacc + o.v4; const float4* const x = a.x + o.v4; const float4* const p = a.p + o.v4; const float4* const r = a.r + o.v4;
     if (MODE == S3_NORMAL || MODE == S3_RESET) {
-        v.as = a.qacc[q]; v.aa = a.qacc[q + a.chunk4];
+        v.as = qacc[q]; v.aa = qacc[q + a.chunk4];
         const int e = a.e0 + 4 * q;
         v.o = *reinterpret_cast<const int4*>(a.ext_off + e);                 // (e is a multiple of 4: slices start at multiples of 1024)
         v.o4 = a.ext_off[e + 4];
@@ -265,11 +270,11 @@ template <int MODE> static __device__ inline void s3_load(const Step3Args& a, in
     for (int seg = 0; seg < 2; ++seg) {
         const int i = q + seg * a.chunk4;
         v.cm[seg] = a.cm[i];
-        if (MODE == S3_INIT) v.r[seg] = a.r[i];
+        if (MODE == S3_INIT) v.r[seg] = r[i];
         else {
-            v.x[seg] = a.x[i];
-            if (MODE != S3_RESET) v.p[seg] = a.p[i];
-            if (MODE != S3_XONLY) { v.b[seg] = a.b[i]; if (MODE == S3_NORMAL) v.r[seg] = a.r[i]; }
+            v.x[seg] = x[i];
+            if (MODE != S3_RESET) v.p[seg] = p[i];
+            if (MODE != S3_XONLY) { v.b[seg] = a.b[i]; if (MODE == S3_NORMAL) v.r[seg] = r[i]; }
         }
     }
 }
@@ -278,13 +283,17 @@ template <int MODE> static __device__ inline void s3_load(const Step3Args& a, in
 // ranks in the prologue of EVERY workgroup (workgroup 0 stores it into all mailboxes), and the camera workgroups sum their columns of the operator's camera
 // block over the ranks before they update the (replicated) camera tail.  No launch of its own, no vector leaves a rank.
 template <int MODE, bool SH>
-static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
+static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a, const S3Off& o) {
     __shared__ double sm[4 * 8];
     __shared__ double smx[SH ? P2P_MAX_RANKS : 1];
     __shared__ double camv[64];
     __shared__ double camred[8][64];
     __shared__ float rs[64];
-    PcgState* const cur = a.cur;
+    PcgState* const cur = a.cur + o.st;
+    float4* const X = a.x + o.v4; float4* const R = a.r + o.v4; float4* const Z = a.z + o.v4;
+    const double* const pq_partials = a.pq_partials + o.part; const double* const d2_partials = a.d2_partials + o.part; double* const step_partials = a.step_partials + o.part;
+    const float2* const qh = a.qh + o.qh2; const float* const cam_partials = a.cam_partials + o.cam; const float* const Mblk = a.Mblk + o.mblk;
+    const float* const tp = a.tp + o.vo; float* const tx = a.tx + o.vo; float* const tr = a.tr + o.vo; float* const tz = a.tz + o.vo; const float* const tD2 = a.tD2 + o.tail;
     const bool slice_wg = (int)blockIdx.x < a.n_slice_wg;
     const int q0 = blockIdx.x * PF_THREADS + threadIdx.x, qstride = a.n_slice_wg * PF_THREADS;
     S3In in;
@@ -295,16 +304,16 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
     if (threadIdx.x == 0) done_s = cur->done;
     __syncthreads();
     if (done_s) return;
-    const float inv_radius = a.lad_sys >= 0 ? a.lm->lad_inv_radius[a.lad_sys] : a.lm->inv_radius;      // (uniform: a scalar load)
+    const float inv_radius = o.sys >= 0 ? a.lm->lad_inv_radius[o.sys] : a.lm->inv_radius;      // (uniform: a scalar load)
     float alpha = 0.0f;
     if (MODE == S3_NORMAL || MODE == S3_XONLY) {                     // p.q = sum over rows of t (J u) + sum D^2 p^2  ->  alpha = rho / p.q
         double t1[1];
-        reduce_partials_all<1>(a.pq_partials, a.n_pq, t1, sm, a.d2_partials, a.n_d2);      // both lists in ONE reduction (one barrier pair instead of two)
+        reduce_partials_all<1>(pq_partials, a.n_pq, t1, sm, d2_partials, a.n_d2);      // both lists in ONE reduction (one barrier pair instead of two)
         if (SH) {
             const unsigned e32 = p2p_pass_epoch(a.sh.seq, P2P_X_STEP);
             if (blockIdx.x == 0 && threadIdx.x == 0) p2p_put_double_all(a.sh.pd, 1, e32, 0, t1[0]);
             p2p_sum_all<1>(a.sh.pd, 1, e32, t1, smx);
-            t1[0] += a.d2_partials[a.n_d2];                                                // the camera tail's D^2 p^2: replicated, counted once
+            t1[0] += d2_partials[a.n_d2];                                                // the camera tail's D^2 p^2: replicated, counted once
         }
         const double pq = t1[0];
         const double al = cur->rho / pq;
@@ -316,7 +325,7 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (slice_wg) {
         for (int q = q0; q < a.nq; q += qstride) {
-            s3_load<MODE>(a, q, in);
+            s3_load<MODE>(a, o, q, in);
             float accv[2][4];
             if (MODE == S3_NORMAL || MODE == S3_RESET) {
                 const float4 as = in.as, aa = in.aa;
@@ -330,7 +339,7 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) pos[u] = (j0 + u < ob[4]) ? a.ext_pos[j0 + u] : -1;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) hv[u] = pos[u] >= 0 ? a.qh[pos[u]] : make_float2(0.0f, 0.0f);
+                    for (int u = 0; u < 8; ++u) hv[u] = pos[u] >= 0 ? qh[pos[u]] : make_float2(0.0f, 0.0f);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int j = j0 + u;
@@ -356,7 +365,7 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
                         const float4 pp = in.p[seg]; pv[0] = pp.x; pv[1] = pp.y; pv[2] = pp.z; pv[3] = pp.w;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) xv[k] += alpha * pv[k];
-                        a.x[i] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+                        X[i] = make_float4(xv[0], xv[1], xv[2], xv[3]);
                     }
                     if (MODE == S3_XONLY) continue;
                     const float4 bb = in.b[seg];
@@ -366,12 +375,12 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
                     for (int k = 0; k < 4; ++k) qq[k] = svv[k] * accv[seg][k] + dv[k] * (MODE == S3_NORMAL ? pv[k] : xv[k]);      // q = S acc + D^2 v
                     if (MODE == S3_NORMAL) { const float4 ro = in.r[seg]; rv[0] = ro.x - alpha * qq[0]; rv[1] = ro.y - alpha * qq[1]; rv[2] = ro.z - alpha * qq[2]; rv[3] = ro.w - alpha * qq[3]; }
                     else { rv[0] = bv[0] - qq[0]; rv[1] = bv[1] - qq[1]; rv[2] = bv[2] - qq[2]; rv[3] = bv[3] - qq[3]; }           // RESET: r = b - A x
-                    a.r[i] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+                    R[i] = make_float4(rv[0], rv[1], rv[2], rv[3]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { const double xd = xv[k]; s1 += xd * ((double)bv[k] + (double)rv[k]); s2 += xd * (double)rv[k]; s3 += (double)dv[k] * xd * xd; }
                 }
                 const float zv[4] = {mv[0] * rv[0], mv[1] * rv[1], mv[2] * rv[2], mv[3] * rv[3]};
-                a.z[i] = make_float4(zv[0], zv[1], zv[2], zv[3]);
+                Z[i] = make_float4(zv[0], zv[1], zv[2], zv[3]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s0 += (double)rv[k] * (double)zv[k];
             }
@@ -386,7 +395,7 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
         if (MODE == S3_NORMAL || MODE == S3_RESET) {                 // column sums of the operator's camera partials (one float row per workgroup), fixed order
             const int g = t / 64, c = t % 64;                        // 8 row groups x 64 columns
             double v = 0.0;
-            if (c < ncol) for (int w = g; w < a.n_cam; w += 8) v += (double)a.cam_partials[(size_t)w * a.cam_stride + col0 + c];
+            if (c < ncol) for (int w = g; w < a.n_cam; w += 8) v += (double)cam_partials[(size_t)w * a.cam_stride + col0 + c];
             camred[g][c] = v;
             __syncthreads();
             if (t < ncol) {
@@ -404,17 +413,17 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
             const int i = col0 + t;
             const bool fixed = i < 6 * K ? a.fix_poses : (i < 6 * K + 4 ? a.fix_intr : a.fix_dist);
             float ri;
-            if (MODE == S3_INIT) ri = a.tr[i];
+            if (MODE == S3_INIT) ri = tr[i];
             else {
-                float xi = a.tx[i];
-                if (MODE != S3_RESET) { xi += alpha * a.tp[i]; a.tx[i] = xi; }
+                float xi = tx[i];
+                if (MODE != S3_RESET) { xi += alpha * tp[i]; tx[i] = xi; }
                 if (MODE == S3_XONLY) ri = 0.0f;
                 else {
-                    const float vv = MODE == S3_NORMAL ? a.tp[i] : xi;
-                    const float qi = a.tS[i] * (fixed ? 0.0f : (float)camv[t]) + a.tD2[i] * vv;
-                    ri = MODE == S3_NORMAL ? a.tr[i] - alpha * qi : a.tb[i] - qi;
-                    a.tr[i] = ri;
-                    const double xd = xi; s1 += xd * ((double)a.tb[i] + (double)ri); s2 += xd * (double)ri; s3 += (double)a.tD2[i] * xd * xd;
+                    const float vv = MODE == S3_NORMAL ? tp[i] : xi;
+                    const float qi = a.tS[i] * (fixed ? 0.0f : (float)camv[t]) + tD2[i] * vv;
+                    ri = MODE == S3_NORMAL ? tr[i] - alpha * qi : a.tb[i] - qi;
+                    tr[i] = ri;
+                    const double xd = xi; s1 += xd * ((double)a.tb[i] + (double)ri); s2 += xd * (double)ri; s3 += (double)tD2[i] * xd * xd;
                 }
             }
             rs[t] = ri;
@@ -424,32 +433,25 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a) {
         if (t < ncol) {
             const int i = col0 + t;
             int base, n, row; const float* M;
-            if (i < 6 * K) { const int f = i / 6; base = 6 * f; n = 6; row = i - base; M = a.Mblk + 36 * f; }
-            else if (i < 6 * K + 4) { base = 6 * K; n = 4; row = i - base; M = a.Mblk + 36 * K; }
-            else { base = 6 * K + 4; n = 5; row = i - base; M = a.Mblk + 36 * K + 16; }
+            if (i < 6 * K) { const int f = i / 6; base = 6 * f; n = 6; row = i - base; M = Mblk + 36 * f; }
+            else if (i < 6 * K + 4) { base = 6 * K; n = 4; row = i - base; M = Mblk + 36 * K; }
+            else { base = 6 * K + 4; n = 5; row = i - base; M = Mblk + 36 * K + 16; }
             float s = 0.0f;
             for (int j = 0; j < n; ++j) s += M[row * n + j] * rs[base - col0 + j];
-            a.tz[i] = s; s0 += (double)rs[t] * (double)s;
+            tz[i] = s; s0 += (double)rs[t] * (double)s;
         }
     }
     if (MODE == S3_XONLY) return;
-    block_partial_d(s0, a.step_partials, 4, 0); block_partial_d(s1, a.step_partials, 4, 1); block_partial_d(s2, a.step_partials, 4, 2); block_partial_d(s3, a.step_partials, 4, 3);
+    block_partial_d(s0, step_partials, 4, 0); block_partial_d(s1, step_partials, 4, 1); block_partial_d(s2, step_partials, 4, 2); block_partial_d(s3, step_partials, 4, 3);
 }
 template <int MODE, bool SH>
-__global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) { pcg_step3_body<MODE, SH>(a); }
-// ladder batch (single rank): blockIdx.y picks the system (see k_pcg_dir3_lad); `a0` holds system 0's pointers
+__global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) { const S3Off o{0, 0, 0, 0, 0, 0, 0, 0, -1}; pcg_step3_body<MODE, SH>(a, o); }
+// ladder batch (single rank): blockIdx.y picks the system (see k_pcg_dir3_lad); `a` holds system 0's pointers
 template <int MODE>
-__global__ void __launch_bounds__(PF_THREADS) k_pcg_step3_lad(Step3Args a0, LadVec lv) {
+__global__ void __launch_bounds__(PF_THREADS) k_pcg_step3_lad(Step3Args a, LadVec lv) {
     const int j = lv.sysid[blockIdx.y];
-    Step3Args a = a0;
-    const size_t v4 = ((size_t)j * lv.vec) >> 2, vo = (size_t)j * lv.vec, po = (size_t)j * lv.part;
-    a.p += v4; a.qacc += v4; a.x += v4; a.r += v4; a.z += v4;
-    a.qh += ((size_t)j * lv.qh) >> 1;
-    a.pq_partials += po; a.d2_partials += po; a.step_partials += po;
-    a.cam_partials += (size_t)j * lv.cam; a.Mblk += (size_t)j * lv.mblk;
-    a.tp += vo; a.tx += vo; a.tr += vo; a.tz += vo; a.tD2 += (size_t)j * lv.tail;
-    a.cur += 2 * j; a.lad_sys = j;
-    pcg_step3_body<MODE, false>(a);
+    const S3Off o{((size_t)j * lv.vec) >> 2, (size_t)j * lv.vec, ((size_t)j * lv.qh) >> 1, (size_t)j * lv.part, (size_t)j * lv.cam, (size_t)j * lv.mblk, (size_t)j * lv.tail, 2 * j, j};
+    pcg_step3_body<MODE, false>(a, o);
 }
 
 int pcg_step3_slice_wgs(int n_entries, int cap) { if (cap <= 0 || cap > PF_MAX_WG) cap = PF_MAX_WG; int b = (n_entries / 4 + PF_THREADS - 1) / PF_THREADS; return b < 1 ? 1 : (b > cap ? cap : b); }

@@ -140,11 +140,14 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                                                         const int* __restrict__ halo_cnt, int tiles_per_block, int ntl, int cam_stride, const int* __restrict__ gmaxv,
                                                         const unsigned short* __restrict__ hp_off, const unsigned short* __restrict__ hp_src) {
     constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, ZSLOT = T + HMAX, NCOL = 12, HPCAP = 4 * HMAX, NQH = HMAX / T;
-    {   // every system of the launch has stopped: nothing to do (launches queued behind the convergence flags)
+    // A system that has stopped (the host drops it from the launches one pass after it saw the flag) is carried without arithmetic: its inputs are still staged — the
+    // loads of a tile are unconditional — but its rows, its pull phase and its outputs are skipped (workgroup-uniform branches: the state is read once per launch).
+    bool alive[NB];
+    {
         bool any = false;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) any = any || (m.st0[2 * m.sys[b]].done == 0);
-        if (!any) return;
+        for (int b = 0; b < NB; ++b) { alive[b] = m.st0[2 * m.sys[b]].done == 0; any = any || alive[b]; }
+        if (!any) return;      // every system of the launch has stopped: nothing to do (launches queued behind the convergence flags)
     }
     extern __shared__ float lds[];
     const int K = p.K; const size_t Acap = r.Acap; const int A = r.A, chunk = r.chunk;
@@ -298,6 +301,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                 J[28] = rb.j28;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
+                    if (!alive[b]) continue;
                     // every LDS read of (row, system) first, behind one another: left to itself the compiler puts an s_waitcnt behind each of the 29
                     float sv[10], av[4], pu[6];
                     sv[0] = lds[U_S(b) + i];
@@ -359,8 +363,10 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
         // ---- pull, system by system through the one column-sum buffer ----
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
+            if (alive[b]) {
 #pragma unroll
-            for (int c = 0; c < NCOL; ++c) lds[C_L + c * T + i] = C[b][c];
+                for (int c = 0; c < NCOL; ++c) lds[C_L + c * T + i] = C[b][c];
+            }
             const float ua_c = lds[U_A(b) + i];
             __syncthreads();
             if (b == 0 && __float_as_int(lds[D_FLAG]) != 0) {                      // (workgroup-uniform: written before the barrier, cleared by the next tile's staging behind the next one)
@@ -368,7 +374,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
             }
             float* const qacc = m.qacc0 + (size_t)m.sys[b] * m.vec;
             float* const qh = m.qh0 + (size_t)m.sys[b] * m.qh;
-            if (in) {
+            if (in && alive[b]) {
                 auto pull = [&](int col, int slot) { return slot < T ? lds[C_L + col * T + slot] : 0.0f; };
                 float qs = self_s[b], qa = self_a[b];
                 qs += pull(0, my) + pull(1, r2y) + pull(2, ryz) + pull(3, mz) + pull(4, r2z) + pull(5, mx) + pull(6, rxy) + pull(7, rxz) + pull(8, r2x);
@@ -385,7 +391,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #pragma unroll
             for (int q = 0; q < NQH; ++q) {
                 const int hq = i + q * T;
-                if (hq < H) {
+                if (hq < H && alive[b]) {
                     const size_t o = (size_t)tile * HMAX + hq;
                     float hsum = 0.0f, hal = 0.0f;
                     const int j1 = hp_offs[hq + 1];
@@ -419,6 +425,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+        if (!alive[b]) continue;
         float* const cam = m.cam0 + (size_t)m.sys[b] * m.cam;
         for (int q = threadIdx.x; q < nshared; q += T) {
             float v;
@@ -429,7 +436,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
     }
     if (m.pq0) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) block_partial_d(PQ_L(b)[i], m.pq0 + (size_t)m.sys[b] * m.part, 1, 0);
+        for (int b = 0; b < NB; ++b) { if (alive[b]) block_partial_d(PQ_L(b)[i], m.pq0 + (size_t)m.sys[b] * m.part, 1, 0); }
     }
 #undef SYS
 #undef U_S

@@ -623,8 +623,8 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
     const int mr_cap = std::min(group_cap, eg_tile_mr_max_systems(K));
     const bool mr_ok = use_mr && mr_cap >= 1 && tp.T == 512 && tp.hp_off != nullptr && r.slots == 5;
     { TimedScope t(c, I3D_K_VECTOR);
-      CTX_HIP(c, hipMemsetAsync(X0, 0, sizeof(float) * (size_t)B * lv.vec, s));
-      for (int j = 0; j < B; ++j) CTX_HIP(c, hipMemcpyAsync(R0 + (size_t)j * lv.vec, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s));
+      for (int j = 0; j < B; ++j) { CTX_HIP(c, hipMemsetAsync(X0 + (size_t)j * lv.vec, 0, sizeof(float) * L.NP, s));
+                                    CTX_HIP(c, hipMemcpyAsync(R0 + (size_t)j * lv.vec, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s)); }
       launch_pcg_init_lad(s, st2, B, cfg.pcg_fixed_iterations, 500, c->d_lm.p); }
     Step3Args a; std::memset(&a, 0, sizeof(a));
     auto c4 = [&](const float* v) { return reinterpret_cast<const float4*>(v + own.off0); };

@@ -105,7 +105,7 @@ def test_multi_system_kernel_against_the_round_4_kernel(slice_setup, monkeypatch
     for x, y in zip(st1, st2):
         assert abs(x.cost_final - y.cost_final) <= 1e-7 * abs(x.cost_final)
     assert np.abs(s1 - s2).max() <= 1e-6 * np.abs(s1).max() and np.abs(a1 - a2).max() <= 1e-6 * np.abs(a1).max()
-    np.testing.assert_allclose(c2[2], c1[2], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(c2[2], c1[2], rtol=1e-5, atol=1e-7)
 
 
 def test_ladder_with_fixed_pcg_depth_and_residual_resets(slice_setup, monkeypatch):
@@ -133,14 +133,14 @@ def test_ladder_in_the_default_mode_agrees_to_round_off(slice_setup, monkeypatch
 
 def test_an_invalid_step_puts_the_batch_out_of_step_and_it_is_solved_again(slice_setup, monkeypatch):
     """TrustRegionMinimizer::HandleInvalidStep halves the radius and leaves the reduction factor alone: the systems behind the invalid attempt were solved for radii the
-    trust region never reaches.  (The step of attempt 0 — the first of a batch — is DECLARED invalid by a test switch; on real data model_cost_change <= 0 does not
-    occur.)"""
+    trust region never reaches.  The step of attempt 1 is DECLARED invalid by a test switch (on real data model_cost_change <= 0 does not occur): in the second
+    iteration attempt 0 is rejected (radius 5000, factor 4), attempt 1 — the first of the batch {1, 2} — is invalid (radius 2500), and system 2 was solved for 1250."""
     monkeypatch.setenv("I3D_DETERMINISTIC", "1")
-    monkeypatch.setenv("I3D_DEBUG_INVALID_ATTEMPT", "0")
+    monkeypatch.setenv("I3D_DEBUG_INVALID_ATTEMPT", "1")
     monkeypatch.setenv("I3D_LADDER", "1"); monkeypatch.setenv("I3D_EGT_MR1", "1")
-    serial = _run(slice_setup, iterations=1)
-    assert serial[0][0].num_attempts >= 2 and serial[0][0].step_accepted[0] == 0
+    serial = _run(slice_setup, iterations=2)
+    assert serial[0][1].num_attempts >= 3 and serial[0][1].step_accepted[1] == 0
     monkeypatch.setenv("I3D_LADDER", "6"); monkeypatch.setenv("I3D_EGT_MR1", "0"); monkeypatch.setenv("I3D_LADDER_MR1", "1")
-    lad = _run(slice_setup, iterations=1)
+    lad = _run(slice_setup, iterations=2)
     _same(serial, lad)
     assert lad[4]["resyncs"] >= 1, lad[4]

@@ -266,12 +266,17 @@ def test_sharded_run_survives_a_tile_halo_that_does_not_fit(setup, monkeypatch, 
     L.i3d_comm_sim_destroy(shared)
 
 
-def test_single_rank_falls_back_to_the_other_tile_geometry(setup, monkeypatch, capfd):
-    """Single rank: the default plan has 1024-entry tiles with 2048 halo slots.  When such a tile's halo does not fit (forced here: the plan is told it has
-    48 slots) the run plans again with 512-entry tiles (three halo slots per entry instead of two) before it would give up on the tiled pass; with both
-    geometries refused it takes the untiled pass.  All three must give the same result."""
+@pytest.mark.parametrize("ladder", ["6", "1"])
+def test_single_rank_falls_back_to_the_other_tile_geometry(setup, monkeypatch, capfd, ladder):
+    """Single rank.  With the damping ladder (the default) the plan has 512-entry tiles with 1536 halo slots — the geometry of the multi-system operator pass —, the
+    serial loop (I3D_LADDER=1) plans 1024-entry tiles with 2048 halo slots.  When a tile's halo does not fit the first geometry (forced here: the plan is told it has
+    48 slots) the run plans again with the other one before it would give up on the tiled pass (the ladder then steps back to the serial loop: its kernel exists
+    for 512-entry tiles); with both geometries refused it takes the untiled pass.  All three must give the same result."""
     O = setup["O"]
     cfg = helpers.gpu_cfg(helpers.oracle_cfg(O, setup["thres"], iterations=2, cg_fixed_iterations=12))
+    monkeypatch.setenv("I3D_LADDER", ladder)
+    first, other = (("I3D_EGT_HMAX_LIMIT", "I3D_EGT_HMAX_LIMIT_1024") if ladder != "1" else ("I3D_EGT_HMAX_LIMIT_1024", "I3D_EGT_HMAX_LIMIT"))
+    other_tiles = "1024" if ladder != "1" else "512"
 
     def run():
         c = helpers.gpu_context(setup["sc"], setup["arrays"], setup["vsh"])
@@ -279,11 +284,11 @@ def test_single_rank_falls_back_to_the_other_tile_geometry(setup, monkeypatch, c
         return st, sdf, alb
     rst, rsdf, ralb = run()
     assert "does not fit" not in capfd.readouterr().err
-    monkeypatch.setenv("I3D_EGT_HMAX_LIMIT_1024", "48")
+    monkeypatch.setenv(first, "48")
     st1, sdf1, alb1 = run()
     err = capfd.readouterr().err
-    assert "planning again with 512-entry tiles" in err and "untiled" not in err
-    monkeypatch.setenv("I3D_EGT_HMAX_LIMIT", "48")
+    assert f"planning again with {other_tiles}-entry tiles" in err and "untiled" not in err
+    monkeypatch.setenv(other, "48")
     st2, sdf2, alb2 = run()
     assert "using the untiled pass" in capfd.readouterr().err
     for st, sdf, alb in ((st1, sdf1, alb1), (st2, sdf2, alb2)):
