@@ -97,7 +97,7 @@ struct i3d_context {
     // ---- the damping ladder (solver.cpp lm_solve / pcg_solve_ladder): per-system slabs of the PCG vectors and partial sums ----
     bool mr1_serial = false;        // I3D_EGT_MR1=1: the serial loop's operator pass is k_eg_tile_mr<1> (A/B runs, the control of the ladder tests)
     int ladder_max = 1;             // I3D_LADDER (read at every assemble): attempts solved together, 1 = the serial loop
-    int ladder_hint = 0;            // LM attempts of the previous outer iteration (the first batch speculates that deep)
+    int ladder_hint = 0, ladder_hint_prev = 0;      // LM attempts of the last two outer iterations (the first batch speculates as deep as the larger)
     i3d::LadVec lad{};              // strides of the slabs below
     i3d::DevBuf<float> lad_vec;     // [LADDER_MAX][6][lad.vec]: x, r, p, z, u, qacc of every system
     i3d::DevBuf<float> lad_qh, lad_cam, lad_mblk, lad_tail;

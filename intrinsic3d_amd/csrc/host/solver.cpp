@@ -799,9 +799,13 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
         rc = alloc_ladder(c); if (rc) return rc;
         const LadVec& lv = c->lad;
         { LmRecord rec; rc = wait_record(c, 0, seq0, rec); if (rc) return rc; consume(rec); }      // the initial tests
+        // Batch depth.  First batch: what the last two outer iterations needed (the larger: one system too many costs its few PCG passes at the marginal price of a
+        // shared stream, one too few costs a second batch); without history 2, doubling while everything is rejected.  With history, a batch that ends without an
+        // accepted step is followed by batches of 2: the accepting attempt is near (a second full-depth batch wasted 5 of its 6 systems, profiles/r05_ladder_policy.json).
+        const bool warm = c->ladder_hint > 0;
         int k = 0, prevB = 0; bool after_resync = false;
         while (k < cfg.lm_steps && !ended) {
-            int B = after_resync ? 1 : (prevB == 0 ? (c->ladder_hint > 0 ? c->ladder_hint : 2) : 2 * prevB);
+            int B = after_resync ? 1 : (prevB == 0 ? (warm ? std::max(c->ladder_hint, c->ladder_hint_prev) : 2) : (warm ? 2 : 2 * prevB));
             B = std::max(1, std::min(B, std::min(c->ladder_max, cfg.lm_steps - k)));
             after_resync = false; prevB = B;
             { TimedScope t(c, I3D_K_VECTOR);
@@ -832,7 +836,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
             if (ended && decided < B) c->lad_wasted += B - decided;
             k += decided;
         }
-        if (attempts > 0) c->ladder_hint = attempts;
+        if (attempts > 0) { c->ladder_hint_prev = c->ladder_hint; c->ladder_hint = attempts; }
         ended = true;        // (every record of the solve has been consumed)
     }
     int k = 0;
