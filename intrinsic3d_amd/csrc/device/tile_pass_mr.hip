@@ -35,7 +35,7 @@ constexpr int MR_T = 512, MR_HMAX = 1536, MR_NWV = MR_T / 64, MR_TC = 32;
 
 // LDS layout in floats.  Everything whose size does not depend on K sits at COMPILE-TIME offsets (an offset that is a constant costs no scalar register across the
 // row loop):
-//   [flag | 3 pad] [NB][72] per-wave intrinsics / distortion sums | [NWV][TC] keyframe tags (shared by the systems: the rows are) | [NB][NWV][TC][6] table sums |
+//   [flag | 3 pad] [NB][72] per-wave intrinsics / distortion sums | [NWV][TC] keyframe tags (shared by the systems: the rows are) | [NWV][TC][6 NB] table sums (the values of a slot side by side) |
 //   [NB] x { u_s, u_a [2 NSLOT] | Er row values [T + 4] } | the tile's pull list [2 HMAX] | column sums of ONE system [12][T] | pull-list offsets [(HMAX + 4) / 2, rounded]
 //   | the lanes' running p.q [NB][T] fp64 (parked here: as register pairs they are live across the whole row loop)
 // then, per system and K-dependent: dense camera accumulator [rs + 9] | pose part of u_b [6K] | its intrinsics / distortion part [9, padded to 12, 16-byte aligned].
@@ -43,7 +43,7 @@ constexpr int MR_T = 512, MR_HMAX = 1536, MR_NWV = MR_T / 64, MR_TC = 32;
 // spilled the 3-system kernel; what matters is that a system's reads are issued TOGETHER, not that they are few.)
 template <int NB> struct MrConst {
     static constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, NSLOT = T + HMAX + 1;
-    static constexpr int CAMW = (NW * 9 + 3) & ~3, VSTR = NW * TC * 6;
+    static constexpr int CAMW = (NW * 9 + 3) & ~3, VSTR = NW * TC * 6;          // (VSTR x NB floats of table sums: [NW][TC][6 NB])
     static constexpr int D_FLAG = 0, D_CAM9W = 4, D_TAG = D_CAM9W + NB * CAMW, D_VAL = D_TAG + NW * TC;
     static constexpr int O_U = D_VAL + NB * VSTR, UB = (2 * NSLOT + T + 4 + 3) & ~3;          // system b: u_s at O_U + b UB, u_a behind it, then the Er row values
     static constexpr int O_LIST = O_U + NB * UB, O_C = O_LIST + 2 * HMAX, O_OFFS = O_C + 12 * T, O_PQ = O_OFFS + (((HMAX + 4) / 2 + 3) & ~3), D0 = O_PQ + NB * 2 * T;      // O_PQ: the lanes' running p.q, fp64, [NB][T]
@@ -58,19 +58,17 @@ static __host__ __device__ inline MrLayout mr_layout(int D0, int NB, int K) {
 }
 static size_t mr_lds_bytes(int NB, int K) { return NB == 1 ? mr_layout(MrConst<1>::D0, 1, K).bytes : (NB == 2 ? mr_layout(MrConst<2>::D0, 2, K).bytes : mr_layout(MrConst<3>::D0, 3, K).bytes); }
 
-// one step of a wave sum: v += v of the lane the DPP control selects (a lane without a source — row_bcast15 into row 0, row_bcast31 into rows 0 and 1 — adds 0: bound_ctrl)
-template <int CTRL> static __device__ inline float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
 // The pose columns of one row slot across the wave for NB systems: wave_table_add (wave_ops.hpp) with the table look-up done once per round and the 6 NB wave sums of a
-// round taken TOGETHER — xor butterfly inside every row of 16 lanes (4 DPP adds), every row into the next (row_bcast15), row 1 into 2 and 3 (row_bcast31): lane 63
-// holds (r3 + r2) + (r1 + r0) and adds all of them to the wave's table in one exec-masked block.  No readlane, no scalar round trip, the chains of the different values
-// interleave (a DPP read needs two idle slots behind the write of its source: with 6 NB independent chains they are never idle).
+// round taken TOGETHER by wave_sum_quads (four values share one tree: 2.5 instructions per value instead of the 6 of a DPP tree, or the 25 of the first version's
+// readlane trees).  The sums of value vi = 6 b + i end up in the lanes of one row of 16; the first lane of every row adds them to the wave's table — [slot][6 NB],
+// the values of a slot side by side — in ONE exec-masked block of MQ LDS adds (4 lanes each, distinct addresses).
 template <int NB>
-static __device__ inline void mr_table_add(bool valid, int f, const float (&jp)[6], const float (&ts)[NB], float* lds, int o_tag, int o_val, int val_stride, int& count, int o_dense, int dense_stride) {
+static __device__ inline void mr_table_add(bool valid, int f, const float (&jp)[6], const float (&ts)[NB], float* lds, int o_tag, int o_val, int& count, int o_dense, int dense_stride) {
+    constexpr int M = 6 * NB, MQ = (M + 3) / 4;
     bool pending = valid;
     unsigned long long todo = __ballot(pending);
     const int lane = (int)(threadIdx.x & 63u);
+    const int qv = wave_quad_value(lane);                       // this lane's rows hold value 4 q + qv of quad q
     while (todo != 0ull) {
         const int leader = __ffsll((long long)todo) - 1;
         const int f0 = __builtin_amdgcn_readlane(f, leader);
@@ -81,7 +79,7 @@ static __device__ inline void mr_table_add(bool valid, int f, const float (&jp)[
         if (hit != 0ull) slot = (__ffsll((long long)hit) - 1) & (MR_TC - 1);
         else if (count < MR_TC) { slot = count; if (lane == 0) lds[o_tag + slot] = __int_as_float(f0); count = count + 1; }
         else slot = -1;
-        float v[NB * 6];
+        float v[4 * MQ], sum[MQ];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float tm = mine ? ts[b] : 0.0f;
@@ -89,23 +87,16 @@ static __device__ inline void mr_table_add(bool valid, int f, const float (&jp)[
             for (int i = 0; i < 6; ++i) v[b * 6 + i] = jp[i] * tm;
         }
 #pragma unroll
-        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0xB1>(v[j]);        // quad_perm [1,0,3,2]
+        for (int j = M; j < 4 * MQ; ++j) v[j] = 0.0f;
+        wave_sum_quads<MQ>(v, sum);
+        if ((lane & 15) == 0) {
+            if (slot >= 0) {
+                const int base = o_val + slot * M + qv;
 #pragma unroll
-        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x4E>(v[j]);        // quad_perm [2,3,0,1]
+                for (int q = 0; q < MQ; ++q) { if (4 * q + 3 < M || 4 * q + qv < M) lds_add(&lds[base + 4 * q], sum[q]); }      // (no return value; the table is this wave's alone, its LDS operations execute in program order)
+            } else {            // table full (not seen on the bench scenes): straight into the dense accumulators (order-dependent)
 #pragma unroll
-        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x141>(v[j]);       // row_half_mirror
-#pragma unroll
-        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x140>(v[j]);       // row_mirror: every lane of a row holds the row's sum
-#pragma unroll
-        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x142>(v[j]);             // row_bcast15: lane 15 of every row into the next row (row 3 = r3 + r2, row 1 = r1 + r0)
-#pragma unroll
-        for (int j = 0; j < NB * 6; ++j) v[j] = dpp_add<0x143>(v[j]);             // row_bcast31: lane 31 into rows 2 and 3 -> lane 63 = (r3 + r2) + (r1 + r0)
-        if (lane == 63) {
-            const int base = slot >= 0 ? o_val + slot * 6 : o_dense + 6 * f0, stride = slot >= 0 ? val_stride : dense_stride;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) lds_add(&lds[base + b * stride + i], v[b * 6 + i]);      // (no return value; the table is this wave's alone, its LDS operations execute in program order)
+                for (int q = 0; q < MQ; ++q) { const int vi = 4 * q + qv; if (vi < M) { const int b = vi / 6; lds_add(&lds[o_dense + b * dense_stride + 6 * f0 + (vi - 6 * b)], sum[q]); } }
             }
         }
         pending = pending && !mine;
@@ -113,16 +104,14 @@ static __device__ inline void mr_table_add(bool valid, int f, const float (&jp)[
     }
 }
 template <int NB>
-static __device__ inline void mr_table_merge(float* lds, int o_tag, int o_val, int val_stride, int& count, int o_dense, int dense_stride) {
+static __device__ inline void mr_table_merge(float* lds, int o_tag, int o_val, int& count, int o_dense, int dense_stride) {
+    constexpr int M = 6 * NB;
     const int lane = (int)(threadIdx.x & 63u);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        for (int e = lane; e < count * 6; e += 64) {
-            const int sl = e / 6, i = e - sl * 6;
-            const int f = __float_as_int(lds[o_tag + sl]);
-            lds[o_dense + b * dense_stride + 6 * f + i] += lds[o_val + b * val_stride + e];
-            lds[o_val + b * val_stride + e] = 0.0f;
-        }
+    for (int e = lane; e < count * M; e += 64) {
+        const int sl = e / M, vi = e - sl * M, b = vi / 6, i = vi - 6 * b;
+        const int f = __float_as_int(lds[o_tag + sl]);
+        lds[o_dense + b * dense_stride + 6 * f + i] += lds[o_val + e];
+        lds[o_val + e] = 0.0f;
     }
     if (lane < MR_TC) lds[o_tag + lane] = __int_as_float(-1);
     count = 0;
@@ -153,7 +142,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
     const int K = p.K; const size_t Acap = r.Acap; const int A = r.A, chunk = r.chunk;
     const int nshared = 6 * K + 9, rs = (6 * K) | 1;
     using MC = MrConst<NB>;
-    constexpr int D_FLAG = MC::D_FLAG, D_CAM9W = MC::D_CAM9W, CAMW = MC::CAMW, D_TAG = MC::D_TAG, D_VAL = MC::D_VAL, VSTR = MC::VSTR, D0 = MC::D0;
+    constexpr int D_FLAG = MC::D_FLAG, D_CAM9W = MC::D_CAM9W, CAMW = MC::CAMW, D_TAG = MC::D_TAG, D_VAL = MC::D_VAL, D0 = MC::D0;
     const MrLayout L = mr_layout(D0, NB, K);
     const int SB = L.SK, o_upose = L.o_upose, o_ui = L.o_ui;
 #define SYS(b) (D0 + (b) * SB)                                   /* K-dependent block of system b: dense pose accumulator [0, 6K), intrinsics / distortion totals [rs, rs + 9), camera part of u_b at o_upose */
@@ -172,10 +161,10 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
         for (int e = i; e < rs + 9; e += T) lds[SYS(b) + e] = 0.0f;
         for (int e = i; e < 6 * K; e += T) lds[SYS(b) + o_upose + e] = ub[tail + e];
         if (i < 12) lds[SYS(b) + o_ui + i] = i < 9 ? ub[tail + 6 * K + i] : 0.0f;
-        for (int e = lane; e < TC * 6; e += 64) lds[D_VAL + b * VSTR + wave * (TC * 6) + e] = 0.0f;
     }
     if (lane < TC) lds[D_TAG + wave * TC + lane] = __int_as_float(-1);
-    const int o_tag = D_TAG + wave * TC, o_val = D_VAL + wave * (TC * 6);
+    const int o_tag = D_TAG + wave * TC, o_val = D_VAL + wave * (TC * 6 * NB);
+    for (int e = lane; e < TC * 6 * NB; e += 64) lds[o_val + e] = 0.0f;
     int tcount = 0;
     float cam9[NB][9];
 #define PQ_L(b) reinterpret_cast<double*>(lds + MC::O_PQ + (b) * 2 * T)
@@ -340,7 +329,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                 if (!p.fix_poses && in) { fsel = f; pvalid = true; }
             }
             const float jp[6] = {rw[3].z, rw[3].w, rw[4].x, rw[4].y, rw[4].z, rw[4].w};      // pose columns 14..19 of the row
-            mr_table_add<NB>(pvalid, fsel, jp, tsel, lds, o_tag, o_val, VSTR, tcount, D0, SB);
+            mr_table_add<NB>(pvalid, fsel, jp, tsel, lds, o_tag, o_val, tcount, D0, SB);
         };
         consume(rwA, 0); load_block(rwA, 2);
         consume(rwB, 1); load_block(rwB, 3);
@@ -370,7 +359,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
             const float ua_c = lds[U_A(b) + i];
             __syncthreads();
             if (b == 0 && __float_as_int(lds[D_FLAG]) != 0) {                      // (workgroup-uniform: written before the barrier, cleared by the next tile's staging behind the next one)
-                for (int w = 0; w < NW; ++w) { if (wave == w) mr_table_merge<NB>(lds, o_tag, o_val, VSTR, tcount, D0, SB); __syncthreads(); }
+                for (int w = 0; w < NW; ++w) { if (wave == w) mr_table_merge<NB>(lds, o_tag, o_val, tcount, D0, SB); __syncthreads(); }
             }
             float* const qacc = m.qacc0 + (size_t)m.sys[b] * m.vec;
             float* const qh = m.qh0 + (size_t)m.sys[b] * m.qh;
@@ -417,7 +406,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
         }
     }
     __syncthreads();
-    for (int w = 0; w < NW; ++w) { if (wave == w) mr_table_merge<NB>(lds, o_tag, o_val, VSTR, tcount, D0, SB); __syncthreads(); }
+    for (int w = 0; w < NW; ++w) { if (wave == w) mr_table_merge<NB>(lds, o_tag, o_val, tcount, D0, SB); __syncthreads(); }
     if (threadIdx.x < 9) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) { float v = 0.0f; for (int w = 0; w < NW; ++w) v += lds[D_CAM9W + b * CAMW + w * 9 + threadIdx.x]; lds[SYS(b) + rs + threadIdx.x] = v; }

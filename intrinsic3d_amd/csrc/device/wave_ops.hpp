@@ -101,6 +101,35 @@ static __device__ inline void wave_table_merge(float* lds, int o_tag, int o_val,
     count = 0;
 }
 
+// Wave sums of MANY values at once (gfx950: v_permlane32_swap / v_permlane16_swap).  A DPP tree costs 6 instructions per value (4 inside the rows of 16 lanes, 2 across
+// them); here four values share the tree.  v[4q .. 4q+3] = A, B, C, D:
+//     permlane32_swap(A, B) + add:  rows 0,1 hold A[i] + A[i+32], rows 2,3 hold B[i] + B[i+32]          (same for C, D)
+//     permlane16_swap(AB, CD) + add: row 0 = A, row 1 = C, row 2 = B, row 3 = D, each lane (x[i] + x[i+32]) + (x[i+16] + x[i+48])
+//     xor butterfly inside the rows (4 DPP adds): every lane of a row holds the total of the row's value
+// = 10 instructions per four values.  out[q]: lane l holds the wave sum of value 4q + wave_quad_value(l).  The association is fixed and the same for every value
+// whatever shares its registers (what tile_pass_mr.hip needs: a system's sums must not depend on the systems it is batched with).
+typedef unsigned v2u_swap __attribute__((ext_vector_type(2)));
+static __device__ inline int wave_quad_value(int lane) { const int row = lane >> 4; return ((row & 1) << 1) | (row >> 1); }      // rows 0,1,2,3 -> 0,2,1,3
+template <int MQ>
+static __device__ inline void wave_sum_quads(const float (&v)[4 * MQ], float (&out)[MQ]) {
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+        const v2u_swap ab = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * q]), __float_as_uint(v[4 * q + 1]), false, false);
+        const v2u_swap cd = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * q + 2]), __float_as_uint(v[4 * q + 3]), false, false);
+        const float sab = __uint_as_float(ab.x) + __uint_as_float(ab.y), scd = __uint_as_float(cd.x) + __uint_as_float(cd.y);
+        const v2u_swap r = __builtin_amdgcn_permlane16_swap(__float_as_uint(sab), __float_as_uint(scd), false, false);
+        out[q] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) out[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out[q]), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) out[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out[q]), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) out[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out[q]), 0x141, 0xF, 0xF, true));    // row_half_mirror
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) out[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out[q]), 0x140, 0xF, 0xF, true));    // row_mirror
+}
+
 // Ordered section of a workgroup: wave w enters when waves 0 .. w-1 have left (a ticket in LDS; the LDS operations of a wave are older than the ticket it wrote).
 // The ticket word must be 0 when the first wave arrives (reset it behind a barrier).
 // No fence on either side: the LDS executes the DS instructions of a compute unit in the order they were issued, so the atomics a wave issued before its ticket
