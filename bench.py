@@ -30,12 +30,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_TAG = "r04-branch-free-taps"     # bumped when k_build<true> / k_eg_tile change materially: PMC traffic / SQ counter files of older kernels are not attached
+KERNEL_TAG = "r05-ladder"     # bumped when k_build<true> / k_eg_tile change materially: PMC traffic / SQ counter files of older kernels are not attached
 # issue cost of a VALU wave-instruction on gfx950 measured with tools/experiments/valu_rate.hip (profiles/r02_valu_rate.txt): cycles per instruction on one SIMD
 # cycles per wave-instruction on one SIMD BY OCCUPANCY (waves per SIMD), measured (tools/experiments/valu_rate.hip, profiles/r03_valu_rate.txt); pk = packed fp32 (v_pk_*).
 # A kernel is priced at the occupancy it actually runs at (k_build<true>: 247 VGPRs = 2 waves per SIMD), not at the 4-wave rates.
 VALU_CYCLES_BY_OCC = {1: {"f64": 9.8, "f32": 7.3, "pk": 8.6}, 2: {"f64": 6.45, "f32": 4.27, "pk": 6.30}, 3: {"f64": 5.85, "f32": 3.74, "pk": 5.75}, 4: {"f64": 5.24, "f32": 3.21, "pk": 5.20}}      # (3: mean of the measured 2- and 4-wave rates)
-KERNEL_OCCUPANCY = {"build": 2, "cost": 3, "eg_pass": 4, "observe": 4}      # waves per SIMD from the register counts (tools/kernel_resources.sh)
+KERNEL_OCCUPANCY = {"build": 2, "cost": 3, "eg_pass": 4, "eg_mr2": 2, "eg_mr3": 2, "observe": 4}      # waves per SIMD from the register counts (tools/kernel_resources.sh)
 GPU_CLOCK_HZ = 2.4e9; NUM_SIMD = 1024
 
 
@@ -276,9 +276,14 @@ def roofline_of(name, kernels, Rg, A, world, attach_counters=True):
         return None
     k = kernels[name]
     tr = pmc_traffic(name, Rg, A) if (world == 1 and attach_counters) else None
+    nsys = {"eg_mr2": 2, "eg_mr3": 3}.get(name, 1)
     out = {"kernel": {"build": "k_build<true>", "eg_pass": "k_eg_tile", "eg_mr2": "k_eg_tile_mr<2>", "eg_mr3": "k_eg_tile_mr<3>"}[name], "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
            "traffic_source": (f"committed PMC passes of this command, profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; not measured in this run)" if tr else None)}
+    if nsys > 1:
+        # one launch streams the rows ONCE (strict bytes: 4 nnz, what `achieved` / `frac` price) and applies them to `systems_per_launch` PCG systems of a ladder batch:
+        # `useful_*` = what the serial loop streams for the same work (4 nnz per system).  The pass is bound by instruction issue from two systems on, not by HBM.
+        out.update(systems_per_launch=nsys, useful_achieved=k["achieved_GBs"] * nsys, useful_frac=k["achieved_GBs"] * nsys / HBM_PEAK_GBS, bound="valu-issue (two or three systems share every byte of the rows)")
     sq = sq_valu(name, Rg) if (world == 1 and attach_counters) else None
     if sq:
         occ = KERNEL_OCCUPANCY.get(name, 4); cyc = VALU_CYCLES_BY_OCC[occ]
@@ -290,7 +295,7 @@ def roofline_of(name, kernels, Rg, A, world, attach_counters=True):
                    wait_share=wait_share, valu_active_per_busy_cycle=(cn["SQ_ACTIVE_INST_VALU"] / cn["SQ_BUSY_CYCLES"] if cn.get("SQ_BUSY_CYCLES") else None),
                    valu_source=f"profiles/{sq['source']} (SQ_INSTS_VALU, SQ_WAIT_ANY / SQ_WAVE_CYCLES, SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES; fp64 share from the ISA; cycles per instruction at {occ} waves per SIMD)")
         if out["valu_frac"] >= 0.8:
-            out["bound"] = "valu-issue"
+            out["bound"] = "valu-issue" + (f" ({nsys} systems share every byte of the rows)" if nsys > 1 else "")
         elif wait_share is not None and wait_share >= 0.5 and out["frac"] < 0.5:
             out["bound"] = f"latency (s_waitcnt {100 * wait_share:.0f} % of the wave-cycles at {occ} waves per SIMD; VALU issue {100 * out['valu_frac']:.0f} % of the launch)"
     return out
@@ -455,7 +460,9 @@ def _main():
     log(f"upload + hash/neighbour build: {t_upload:.2f}s")
     t0 = time.time()
     sh_sub, _, sh_stats = ctx.estimate_sh(args.subvolume, 10.0, thres)       # LightingSVSH::estimate + computeVoxelShCoeffs (intrinsic3d.cpp:255-264)
-    log(f"SH estimate: {sh_sub.shape[0]} subvolumes, {sh_stats.data_rows} data rows, {sh_stats.lm_iterations} LM iterations in {time.time() - t0:.2f}s")
+    torch.cuda.synchronize(); sh_first_s = time.time() - t0
+    t0 = time.time(); ctx.estimate_sh(args.subvolume, 10.0, thres); torch.cuda.synchronize(); sh_estimate_ms = (time.time() - t0) * 1e3      # once more, warm (buffers allocated): what a level pays
+    log(f"SH estimate: {sh_sub.shape[0]} subvolumes, {sh_stats.data_rows} data rows, {sh_stats.lm_iterations} LM iterations in {sh_first_s:.2f}s (warm: {sh_estimate_ms:.1f} ms)")
 
     if args.pmc_calibrate:
         a = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
@@ -483,7 +490,7 @@ def _main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    syncs0 = ctx.debug_counters()["stream_syncs"]
+    syncs0 = ctx.debug_counters()["stream_syncs"]; ladder0 = ctx.debug_ladder_stats()
     t0 = time.perf_counter()
     stats = []
     while len(stats) < args.steps:          # the reference's call shape: 10 iterations per Optimizer::optimize, lambda schedule per call
@@ -494,6 +501,7 @@ def _main():
     dt = time.perf_counter() - t0
     stream_syncs = ctx.debug_counters()["stream_syncs"] - syncs0
     ladder = ctx.debug_ladder_stats()
+    ladder_d = {k: ladder[k] - ladder0[k] for k in ("batches", "row_streams", "system_passes", "resyncs", "unused_systems")}
     cull_pairs, cull_skipped = ctx.debug_cull_stats()       # observation pass: (64-voxel group, keyframe) pairs of the last iteration, and how many were culled
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
@@ -513,6 +521,14 @@ def _main():
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
     roofline = roof(dominant) if dominant else None
     roofline_build = roof("build")           # the kernel the north star names, whichever one dominates
+    # all operator launches of the timed region together (one, two or three systems per stream of the rows): strict bytes (4 nnz per launch) and the bytes the serial
+    # loop streams for the same system passes, over the summed launch time
+    ops = [(kernels[k], n) for k, n in (("eg_pass", 1), ("eg_mr2", 2), ("eg_mr3", 3)) if k in kernels]
+    roofline_operator = None
+    if ops:
+        t_ms = sum(k["avg_ms"] * k["launches"] for k, _ in ops); gb = sum(k["algorithmic_GB"] * k["launches"] for k, _ in ops); ugb = sum(k["algorithmic_GB"] * k["launches"] * n for k, n in ops)
+        roofline_operator = {"kernels": "k_eg_tile + k_eg_tile_mr<2> + k_eg_tile_mr<3>", "launches": sum(k["launches"] for k, _ in ops), "ms_total": t_ms, "achieved": gb / (t_ms * 1e-3), "frac": gb / (t_ms * 1e-3) / HBM_PEAK_GBS,
+                             "useful_achieved": ugb / (t_ms * 1e-3), "useful_frac": ugb / (t_ms * 1e-3) / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s", "systems_per_launch": ugb / gb}
     comm = None
     if sharded_run:
         # HIP events around the exchange launches that still are launches of their own (the rim push; with RCCL also the all-reduces).  Over the
@@ -558,7 +574,7 @@ def _main():
                        "pcg_iterations_per_step": pcg, "lm_attempts": [int(s.num_attempts) for s in stats]},
             "carry_trust_radius": bool(args.carry_radius), "kernel_tag": KERNEL_TAG,
             "optimize_calls": (args.steps + CALL_ITERATIONS - 1) // CALL_ITERATIONS, "iterations_per_call": min(CALL_ITERATIONS, args.steps),
-            "roofline": roofline, "roofline_build": roofline_build, "kernels": kernels, "comm": comm,
+            "roofline": roofline, "roofline_build": roofline_build, "roofline_operator": roofline_operator, "kernels": kernels, "comm": comm,
             # SURVEY.md 8(d)'s own C4 shape (4-voxel stored shell, ~3.2 Eg rows per voxel) beside the headline workload (7-voxel band, 5.0 rows per voxel)
             "value_band2": band2["value"] if band2 else None, "roofline_band2": band2["roofline"] if band2 else None, "band2": band2,
             "kernel_ms_total": {k: v[0] for k, v in timing.items()}, "kernel_launches": {k: v[1] for k, v in timing.items()},
@@ -567,8 +583,15 @@ def _main():
             "cost": [float(stats[0].cost_initial), float(stats[-1].cost_final)],
             # host <-> device round trips: the trust-region loop runs on the device (lm_kernels.hip), the host polls mapped memory instead of draining the stream
             "stream_syncs_per_step": stream_syncs / float(args.steps),
+            # LightingSVSH::estimate + computeVoxelShCoeffs on the device (keys, sorts, MFMA Gram blocks, the 9 S-unknown LM on the host, interpolation): once per level, untimed above
+            "sh_estimate_ms": sh_estimate_ms,
             # the damping ladder (whole context, warm-up included): LM attempts solved together share the streams of the stored rows
-            "ladder": ladder,
+            "ladder": dict(ladder_d, depth=ladder["depth"]),
+            # streams of the stored rows per Gauss-Newton iteration (operator launches: every one reads 4 nnz bytes once) against the system passes they serve
+            # (= what the serial trust-region loop streams: one per PCG iteration of every LM attempt)
+            "operator_passes_per_step": (sum(kernels[k]["launches"] for k in ("eg_pass", "eg_mr2", "eg_mr3") if k in kernels)) / float(args.steps),
+            "system_passes_per_step": (ladder_d["system_passes"] / float(args.steps)) if ladder["depth"] > 1 else (kernels["eg_pass"]["launches"] / float(args.steps) if "eg_pass" in kernels else None),
+            "operator_bytes_per_pass_GB": kernels[dominant]["algorithmic_GB"] if dominant in ("eg_pass", "eg_mr2", "eg_mr3") else None,
             "observe_culling": {"group_keyframe_pairs": cull_pairs, "culled": cull_skipped, "fraction": (cull_skipped / float(cull_pairs)) if cull_skipped >= 0 and cull_pairs else None},
             # the boundary also accepts host buffers (i3d_set_grid / i3d_set_frames / i3d_optimize_host): the same run with the one-off upload
             # (voxels + keyframe pyramids over PCIe, hash / neighbour-table build) and the read-back of the refined fields counted in.  Never `value`.
