@@ -76,12 +76,15 @@ __global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, 
         if (threadIdx.x == 0) { *overflow = 1; halo_cnt[tile] = 0; }
         return;
     }
-    for (int k = 2; k <= TP_PLAN_LIST; k <<= 1)                                     // bitonic sort, ascending (the padding ends up last)
+    // bitonic sort, ascending, of the first NS >= H list entries (everything behind the H keys is padding, which sorts last anyway): a 512-entry tile reaches a few
+    // hundred foreign entries, not 2048 — sorting the whole list cost 0.55 ms per outer iteration on the bench workload (5.9 k tiles) against 0.29 ms for its 1024-entry tiles
+    int NS = 64; while (NS < H) NS <<= 1;
+    for (int k = 2; k <= NS; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int i = threadIdx.x + half * 1024, ixj = i ^ j;
-                if (ixj > i) { const int x = hlist[i], y = hlist[ixj]; const bool up = (i & k) == 0; if ((x > y) == up) { hlist[i] = y; hlist[ixj] = x; } }
+                if (i < NS && ixj > i) { const int x = hlist[i], y = hlist[ixj]; const bool up = (i & k) == 0; if ((x > y) == up) { hlist[i] = y; hlist[ixj] = x; } }
             }
             __syncthreads();
         }
