@@ -332,7 +332,9 @@ def band2_leg(args, binding, log, device):
                             f"{Rg} Eg rows = {Rg / max(1, A):.2f} per active voxel",
                 "stored_voxels": int(arrays["keys"].shape[0]), "active_voxels": A, "rows": {"Eg": Rg, "Er": sizes["er"], "Es": sizes["es"], "Ea": sizes["ea"]},
                 "lm_attempts": [int(s.num_attempts) for s in stats],
-                "roofline": roofline_of("eg_pass", kernels, Rg, A, 1, attach_counters=False), "roofline_build": roofline_of("build", kernels, Rg, A, 1, attach_counters=False), "kernels": kernels}
+                # the dominant operator kernel of this leg, with the PMC / SQ counters of a committed pass over THIS workload when there is one (matched by row count)
+                "roofline": roofline_of(max((k for k in kernels if k != "build"), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]), kernels, Rg, A, 1),
+                "roofline_build": roofline_of("build", kernels, Rg, A, 1), "kernels": kernels, "ladder": ctx.debug_ladder_stats()}
     finally:
         ctx.close()
 

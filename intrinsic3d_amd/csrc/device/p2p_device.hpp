@@ -83,7 +83,9 @@ static __device__ inline void p2p_allreduce_wg(const P2PDev& d, double* dev, int
 // The workgroups of one launch cannot agree on a device counter one of them advances, so the epoch of these exchanges is handed in by the host: the pass
 // number, identical on all ranks (every rank queues the same passes; a finished solve skips its exchanges on every rank alike).  Four epochs per pass:
 enum { P2P_X_DIR = 0, P2P_X_STEP = 1, P2P_X_RESET_RIM = 2, P2P_X_RESET_STEP = 3 };
-static __device__ inline unsigned p2p_pass_epoch(int seq, int which) { return 4u * (unsigned)seq + (unsigned)which; }      // never 0 (seq >= 1); parity buffer = which & 1
+// (top bit set: the epochs of the counter-driven all-reduce, p2p_allreduce_wg, count up from 1 in the SAME mailbox words and never reach 2^31 — a stale pass epoch
+// left in a word can therefore never equal a counter epoch after a switch from the fused pass to the legacy pass; advisor finding of round 4)
+static __device__ inline unsigned p2p_pass_epoch(int seq, int which) { return 0x80000000u | (4u * (unsigned)seq + (unsigned)which); }      // never 0; parity buffer = which & 1
 // A rank cannot overwrite words a peer still has to read: buffers alternate (dir: 0, step: 1, reset rim: 0, reset step: 1), and before a rank reaches the next
 // exchange on the same buffer it has completed one on the other buffer, which needed every peer's contribution — sent by a LATER kernel of that peer's
 // stream than the one that read the words in question.

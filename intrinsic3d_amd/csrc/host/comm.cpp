@@ -74,15 +74,18 @@ int rccl_unique_id(void* out, size_t* bytes) {
 
 // Mailboxes for the per-pass exchanges: created on every rank, IPC handles all-gathered through RCCL, then verified with real exchanges
 // (known sums, bounded waits).  All ranks take the same decision (all-reduced); anything short of a clean pass leaves RCCL in charge.
-// The mailbox transport carries the per-pass exchanges whenever this start-up test passes on every rank (I3D_TRANSPORT=rccl keeps RCCL for everything): with it
+// With I3D_TRANSPORT=p2p the mailbox transport carries the per-pass exchanges whenever this start-up test passes on every rank (default: RCCL for everything): with it
 // the sharded PCG pass is the three launches of the single-rank pass, its two exchanges running INSIDE k_pcg_dir3 / k_pcg_step3 (pcg_fused.hip) — the test below
 // therefore also runs that multi-workgroup exchange pattern (P2PEngine::selftest_fused).  It has run between processes on ONE device and between the ranks of the
-// same-process simulation; the first start on a multi-GPU node is decided by this test, with bounded waits, and anything short of a clean pass leaves RCCL in charge.
+// same-process simulation; on a multi-GPU node it is decided by this test, with bounded waits, and anything short of a clean pass leaves RCCL in charge.
 // *fatal is set when this rank could not even take part in the agreement collectives (scratch allocation): the caller aborts the init instead of
 // letting the ranks issue mismatched collectives.
 static bool bootstrap_p2p(RcclComm* c, hipStream_t st, bool* fatal) {
     *fatal = false;
-    { const char* e = std::getenv("I3D_TRANSPORT"); if (e && std::strcmp(e, "rccl") == 0) return false; }      // every rank reads the same environment: no collective is skipped one-sidedly
+    // RCCL carries everything unless the mailboxes are ASKED for (I3D_TRANSPORT=p2p): they have run between processes on one device and between the ranks of the
+    // same-process simulation, never between devices — until tests/test_gpu_multi_device.py and bench.py --gpus N have passed on a multi-GPU node the library does
+    // not start a production run on a transport whose failure mode is a bounded-wait time-out in the middle of a solve (advisor finding of round 4).
+    { const char* e = std::getenv("I3D_TRANSPORT"); if (!e || std::strcmp(e, "p2p") != 0) return false; }      // every rank reads the same environment: no collective is skipped one-sidedly
     // the scratch of the agreement collectives comes first and unconditionally: every rank issues the all-gather and both min-reductions whatever happens to it locally
     unsigned char* d_handles = nullptr; double* d_test = nullptr;
     if (hipMalloc((void**)&d_handles, 64 * (size_t)c->world) != hipSuccess || hipMalloc((void**)&d_test, sizeof(double) * 64) != hipSuccess) {

@@ -149,11 +149,11 @@ def test_many_keyframes(oracle):
 def test_real_rccl_collectives_with_one_rank(oracle, monkeypatch, transport):
     """the sharded code path driven through a REAL 1-rank RCCL communicator (I3D_FORCE_COLLECTIVES=1) — same answer as the plain path —
     with the mailbox transport (bootstrap over RCCL, start-up self-test incl. the in-kernel multi-workgroup exchanges; the pass is the three launches of the
-    single-rank pass, both exchanges inside k_pcg_dir3 / k_pcg_step3) — which is also what an unset I3D_TRANSPORT selects — and with the RCCL fallback
+    single-rank pass, both exchanges inside k_pcg_dir3 / k_pcg_step3; I3D_TRANSPORT=p2p) and with RCCL, which is also what an unset I3D_TRANSPORT selects
     (I3D_TRANSPORT=rccl: grouped send / receive for the rim, ncclAllReduce for the blocks, the six-launch pass with separate reduction launches)"""
     from intrinsic3d_amd import binding
     if transport == "default":
-        monkeypatch.delenv("I3D_TRANSPORT", raising=False); transport = "p2p"
+        monkeypatch.delenv("I3D_TRANSPORT", raising=False); transport = "rccl"      # the mailboxes are opt-in until a multi-GPU run has passed (comm.cpp bootstrap_p2p)
     else:
         monkeypatch.setenv("I3D_TRANSPORT", transport)
     sc = helpers.small_scene(seed=14, radius_vox=9, K=4, width=96, height=72)

@@ -27,11 +27,11 @@ def _launch(world, args, timeout=900, env_extra=None):
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
 
 
-@pytest.mark.parametrize("transport", ["default", "rccl"])
+@pytest.mark.parametrize("transport", ["p2p", "rccl"])
 def test_sharded_processes_match_single_rank(tmp_path, transport):
     """tests/multi_rank_worker.py on 1 device (plain path) and on every power-of-two device count the box offers: rows, accept / reject sequence, costs, fields and
-    camera of EVERY rank equal the single-rank run's to the sharded path's bar; over the mailboxes (the default when the start-up test passes between the
-    devices: three launches per PCG pass, the exchanges inside the kernels) and over RCCL (I3D_TRANSPORT=rccl: the six-launch pass)."""
+    camera of EVERY rank equal the single-rank run's to the sharded path's bar; over RCCL (the default: the six-launch pass) and over the mailboxes
+    (I3D_TRANSPORT=p2p, when their start-up test passes between the devices: three launches per PCG pass, the exchanges inside the kernels)."""
     nd = _devices()
     if nd < 2:
         pytest.skip("needs at least two devices")
@@ -43,11 +43,13 @@ def test_sharded_processes_match_single_rank(tmp_path, transport):
     worlds = [w for w in (2, 4, 8) if w <= nd]
     for W in worlds:
         out = str(tmp_path / f"w{W}")
-        r = _launch(W, [worker, out, "2", "12"], env_extra=({"I3D_TRANSPORT": "rccl"} if transport == "rccl" else {}))
+        r = _launch(W, [worker, out, "2", "12"], env_extra={"I3D_TRANSPORT": transport})
         assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
         for k in range(W):
             d = np.load(out + f".rank{k}.npz")
-            assert str(d["transport"]).startswith("rccl" if transport == "rccl" else "p2p-mailbox"), str(d["transport"])
+            # the mailboxes carry the exchanges only when their start-up test passed on every rank: on a node where it does not, RCCL stays in charge and the run must still match
+            assert str(d["transport"]).startswith("rccl") or (transport == "p2p" and str(d["transport"]).startswith("p2p-mailbox")), str(d["transport"])
+            print(f"[multi-device] W = {W}, asked for {transport}: {d['transport']}")
             assert np.array_equal(d["rows"], ref["rows"]) and np.array_equal(d["accepted"], ref["accepted"])
             assert np.all(np.abs(d["cost"] - ref["cost"]) <= 1e-4 * np.abs(ref["cost"]))
             assert np.abs(d["sdf"] - ref["sdf"]).max() <= 1e-4 * np.abs(ref["sdf"]).max() and np.abs(d["alb"] - ref["alb"]).max() <= 1e-4 * np.abs(ref["alb"]).max()

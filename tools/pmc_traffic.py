@@ -11,7 +11,8 @@ bytes-per-count for 16 B/lane streaming accesses, which is what the row streams 
 means and the factors are written out so the correction can be audited."""
 import collections, csv, glob, json, re, sys
 
-KERNELS = {"eg_pass": r"k_eg_tile", "halo_fold": r"k_halo_fold", "pcg_step": r"k_pcg_step3<1|k_pcg_step<1", "pcg_direction": r"k_pcg_dir3|k_pcg_direction",
+KERNELS = {"eg_pass": r"k_eg_tile<", "eg_mr2": r"k_eg_tile_mr<2>", "eg_mr3": r"k_eg_tile_mr<3>", "halo_fold": r"k_halo_fold", "pcg_step": r"k_pcg_step3<1|k_pcg_step<1", "pcg_direction": r"k_pcg_dir3<|k_pcg_direction",
+           "pcg_step_lad": r"k_pcg_step3_lad<1", "pcg_direction_lad": r"k_pcg_dir3_lad",
            "eg_pass_untiled": r"k_eg_jtjp|k_eg_pass<1>", "eg_pass_gradient": r"k_eg_pass<0>", "eg_pass_diag": r"k_eg_pass<2>", "gather": r"k_gather<false, true>",
            "build": r"k_build<true", "cost": r"k_build<false", "observe": r"k_observe", "copy_1GiB": r"(elementwise|vectorized|copy).*"}
 COPY_BYTES = float(1 << 30)
@@ -68,7 +69,7 @@ def main():
         res["kernels"][name] = {"FETCH_SIZE_raw_mean": a[0], "WRITE_SIZE_raw_mean": b[0], "launches_counted": [a[1], b[1]],
                                 "read_bytes_per_launch": a[0] * f_read, "write_bytes_per_launch": b[0] * f_write,
                                 "traffic_bytes_per_launch": a[0] * f_read + b[0] * f_write}
-    for k in ("eg_pass", "build"):
+    for k in ("eg_pass", "eg_mr2", "eg_mr3", "build"):
         if k in res["kernels"] and k in bench.get("kernels", {}):
             res["kernels"][k]["algorithmic_bytes_per_launch"] = bench["kernels"][k]["algorithmic_GB"] * 1e9
     json.dump(res, open(out, "w"), indent=1)
