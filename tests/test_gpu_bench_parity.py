@@ -127,6 +127,18 @@ def test_native_pcg_stop_matches_oracle(slice_setup):
         _check_fields(ref, ocam, dev, dcam, start)
 
 
+def test_native_pcg_stop_in_the_bit_reproducible_mode(slice_setup, monkeypatch):
+    """The same comparison with every device sum in a fixed order (I3D_DETERMINISTIC=1): no tolerance on the PCG iteration counts — every attempt, rejected or accepted,
+    stops at the iteration the fp64 oracle stops at on this slice (the +-1 of the test above covers run-to-run summation-order noise of the default mode, which this
+    mode does not have)."""
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1")
+    for ref, ocam, so, dev, dcam, sg, start in _run_both(slice_setup, -1):
+        assert list(so.rows) == list(sg.rows) and so.n_attempts == sg.num_attempts
+        assert list(so.accepted[:so.n_attempts]) == list(sg.step_accepted[:sg.num_attempts])
+        assert list(so.cg_iters[:so.n_attempts]) == list(sg.pcg_iterations[:sg.num_attempts]), (list(so.cg_iters[:so.n_attempts]), list(sg.pcg_iterations[:sg.num_attempts]))
+        _check_fields(ref, ocam, dev, dcam, start)
+
+
 def test_chained_ten_iterations_without_reseeding(slice_setup):
     """Ten CHAINED outer iterations (the shipped lambda schedule, Ceres' own PCG stop, every group free) on the bench-shaped slice: the device continues
     from ITS OWN result and the oracle from its own — no re-seeding.  The two states differ by fp32 round-off, which a handful of discrete decisions of

@@ -96,7 +96,9 @@ def test_normal_equations(setup):
     gg, gd, gcost = ctx.debug_normal_eq()
     assert abs(gcost - cost) <= 1e-5 * cost
     np.testing.assert_allclose(gd, dg, rtol=2e-4, atol=1e-6 * dg.max())
-    np.testing.assert_allclose(gg, g, rtol=2e-3, atol=2e-5 * np.abs(g).max())
+    np.testing.assert_allclose(gg, g, rtol=2e-3, atol=2e-5 * np.abs(g).max())      # entry by entry (small entries are sums with cancellation: fp32 row partials against the oracle's fp64 duals)
+    print(f"\n[normal equations] gradient: max-norm error {np.abs(gg - g).max() / np.abs(g).max():.2e} of max |g|; diagonal: {np.abs(gd - dg).max() / np.abs(dg).max():.2e}")
+    assert np.abs(gg - g).max() <= 1e-4 * np.abs(g).max()                          # and in the max-norm convention of the field checks
     rng = np.random.default_rng(0)
     x = rng.normal(0, 1, g.shape) * free
     y = pv.jtj_apply(x); gy = ctx.debug_jtj_apply(x)
@@ -128,7 +130,18 @@ def test_optimize_matches_oracle(setup):
     assert dalb <= 1e-4 * np.abs(ref["albedo"]).max(), dalb
     np.testing.assert_allclose(gi, intr, rtol=1e-4)
     np.testing.assert_allclose(gp, poses, rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(gd, dist, rtol=5e-3, atol=5e-4)   # k2,k3 are barely observable (r^4, r^6 with r < 0.5): ill-conditioned block
+    # Distortion: k2, k3 are barely observable (r^4, r^6 with r < 0.5 in normalised image coordinates), so the 5 x 5 distortion block is ill-conditioned and the
+    # bound cannot be a blanket number: it is the north star's 1e-4, or ENVELOPE_FACTOR x what the ORACLE's own answer moves when its input fields are perturbed by
+    # 1e-7 relative (measured here, printed), whichever is larger — component by component.
+    g3 = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"]); g3.clear_outside_shell(setup["thres"])
+    rng = np.random.default_rng(11)
+    g3.import_fields(sdf_refined=a0["sdf_refined"] * (1.0 + 1e-7 * rng.standard_normal(len(a0["sdf_refined"]))), albedo=a0["albedo"] * (1.0 + 1e-7 * rng.standard_normal(len(a0["albedo"]))))
+    rc3, _, dist3, _, _ = O.optimize(g3, setup["fr"], ocfg, sc["intr"], sc["dist"], sc["poses"], setup["vsh"]); g3.free()
+    assert rc3 == 0
+    spread = np.abs(np.asarray(dist3) - np.asarray(dist)); err = np.abs(np.asarray(gd) - np.asarray(dist))
+    tol = np.maximum(1e-4 * np.abs(np.asarray(dist)), helpers.ENVELOPE_FACTOR * spread) + 1e-12
+    print(f"\n[distortion] oracle {np.asarray(dist)}, device error {err}, oracle's own spread under 1e-7 input perturbations {spread}, bound {tol}")
+    assert np.all(err <= tol), (err, tol)
     ctx.close(); g2.free()
 
 

@@ -1,0 +1,49 @@
+"""Copies what tools/r05_profile.sh (+ tools/c4_full_parity.py) left under gpurun_out/<dir> into profiles/ under the round's names (the judged copies).
+usage: python tools/r05_collect.py gpurun_out/r05h"""
+import json, os, shutil, sys
+
+src = sys.argv[1]; dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+
+
+def cp(a, b):
+    p = os.path.join(src, a)
+    if os.path.exists(p): shutil.copyfile(p, os.path.join(dst, b)); print("->", b)
+    else: print("MISSING", a)
+
+
+for a, b in (("bench_default.json", "r05_bench_default.json"), ("bench_profiled.json", "r05_bench_profiled.json"), ("kernel_stats.csv", "r05_bench_profiled_kernel_stats.csv"),
+             ("kernel_avg_work_only.txt", "r05_bench_profiled_kernel_avg_work_only.txt"), ("pmc_traffic_default.json", "r05_pmc_traffic.json"), ("pmc_traffic_band2.json", "r05_band2_pmc_traffic.json"),
+             ("sq_counters_default.json", "r05_sq_counters.json"), ("sq_counters_band2.json", "r05_band2_sq_counters.json"), ("bench_serial.json", "r05_bench_serial_loop.json"),
+             ("bench_deterministic.json", "r05_bench_deterministic.json"), ("timeline_idle.txt", "r05_timeline_idle.txt"), ("c4_full_parity.json", "r05_c4_full_parity.json"),
+             ("sh_kernels.txt", "r05_sh_kernels.txt")):
+    cp(a, b)
+# MFMA evidence of the SH Gram kernel: raw counters + the derived figures
+p = os.path.join(src, "mfma_sh_gram_raw.json")
+if os.path.exists(p):
+    raw = json.load(open(p)); out = {"source": "rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU over "
+                                               "`python bench.py --steps 1 --warmup 0 --cpu-sample 0 --band2-steps 0 --no-kernel-timing` (the bench's SH estimate: 515 subvolumes, 2.28 M eligible voxels)",
+                                     "kernels": raw}
+    for k, v in raw.items():
+        m = v["mean"]
+        if "SQ_INSTS_VALU_MFMA_MOPS_F64" in m:
+            # one v_mfma_f64_16x16x4_f64 = 16 x 16 x 4 x 2 flop = 2048 flop; the counter counts MOPS in units of 512 flop (MI355X_MICROARCH.md) -> report both raw and derived
+            out.setdefault("derived", {})[k] = {"mfma_mops_f64": m["SQ_INSTS_VALU_MFMA_MOPS_F64"], "mfma_busy_cycles": m.get("SQ_VALU_MFMA_BUSY_CYCLES"), "busy_cycles": m.get("SQ_BUSY_CYCLES"),
+                                                  "mfma_busy_share_of_busy_cycles": (m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_BUSY_CYCLES"]) if m.get("SQ_BUSY_CYCLES") else None}
+    json.dump(out, open(os.path.join(dst, "r05_mfma_sh_gram.json"), "w"), indent=1); print("-> r05_mfma_sh_gram.json")
+runs = {}
+for name in ("share_plain", "share_fc"):
+    p = os.path.join(src, name + ".json")
+    if not os.path.exists(p): continue
+    d = json.loads(open(p).read().strip().splitlines()[-1]); c = d.get("comm")
+    runs[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "kernels": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"]} for k, v in d["kernels"].items()},
+                  "transport": (c or {}).get("transport"), "active_voxels": d["config"]["active_voxels"], "rows": d["config"]["rows"], "ladder": d.get("ladder"), "comm": c}
+if runs:
+    json.dump({"what": "a rank's share of the bench problem (8 ranks: 1/8 of the voxels) on ONE GPU: the single-rank path (damping ladder on) and the sharded path through a 1-rank communicator "
+                       "(RCCL, the default transport; the sharded path runs the serial trust-region loop); python bench.py --cpu-sample 0 --voxels 1e6 --band2-steps 0 [--force-collectives]; one session",
+               "runs": runs}, open(os.path.join(dst, "r05_rank_share.json"), "w"), indent=1)
+    print("-> r05_rank_share.json")
+with open(os.path.join(dst, "r05_run_to_run.txt"), "w") as f:
+    for title, name in (("# default mode (fp32 LDS atomics inside k_eg_tile; k_eg_tile_mr is fixed-order)", "run_to_run_default.txt"), ("# I3D_DETERMINISTIC=1", "run_to_run_deterministic.txt")):
+        p = os.path.join(src, name)
+        f.write(title + "\n" + ("".join(l for l in open(p) if l.startswith("rep ") or l.startswith("max")) if os.path.exists(p) else "MISSING\n"))
+print("-> r05_run_to_run.txt")
