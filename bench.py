@@ -283,7 +283,8 @@ def roofline_of(name, kernels, Rg, A, world, attach_counters=True):
     if nsys > 1:
         # one launch streams the rows ONCE (strict bytes: 4 nnz, what `achieved` / `frac` price) and applies them to `systems_per_launch` PCG systems of a ladder batch:
         # `useful_*` = what the serial loop streams for the same work (4 nnz per system).  The pass is bound by instruction issue from two systems on, not by HBM.
-        out.update(systems_per_launch=nsys, useful_achieved=k["achieved_GBs"] * nsys, useful_frac=k["achieved_GBs"] * nsys / HBM_PEAK_GBS, bound="valu-issue (two or three systems share every byte of the rows)")
+        out.update(systems_per_launch=nsys, useful_achieved=k["achieved_GBs"] * nsys, useful_frac=k["achieved_GBs"] * nsys / HBM_PEAK_GBS,
+                   bound=f"issue + latency at 2 waves per SIMD ({nsys} systems share every byte of the rows; no counters attached)")
     sq = sq_valu(name, Rg) if (world == 1 and attach_counters) else None
     if sq:
         occ = KERNEL_OCCUPANCY.get(name, 4); cyc = VALU_CYCLES_BY_OCC[occ]
@@ -296,8 +297,9 @@ def roofline_of(name, kernels, Rg, A, world, attach_counters=True):
                    valu_source=f"profiles/{sq['source']} (SQ_INSTS_VALU, SQ_WAIT_ANY / SQ_WAVE_CYCLES, SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES; fp64 share from the ISA; cycles per instruction at {occ} waves per SIMD)")
         if out["valu_frac"] >= 0.8:
             out["bound"] = "valu-issue" + (f" ({nsys} systems share every byte of the rows)" if nsys > 1 else "")
-        elif wait_share is not None and wait_share >= 0.5 and out["frac"] < 0.5:
-            out["bound"] = f"latency (s_waitcnt {100 * wait_share:.0f} % of the wave-cycles at {occ} waves per SIMD; VALU issue {100 * out['valu_frac']:.0f} % of the launch)"
+        elif wait_share is not None and wait_share >= 0.45 and out["frac"] < 0.55:
+            out["bound"] = (f"latency (s_waitcnt {100 * wait_share:.0f} % of the wave-cycles at {occ} waves per SIMD; VALU issue {100 * out['valu_frac']:.0f} % of the launch"
+                            + (f"; {nsys} systems share every byte of the rows" if nsys > 1 else "") + ")")
     return out
 
 

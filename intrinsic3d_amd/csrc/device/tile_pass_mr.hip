@@ -127,7 +127,7 @@ struct MrArgs {
 template <int NB>
 __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, MrArgs m, const unsigned* __restrict__ lnbr, const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx,
                                                         const int* __restrict__ halo_cnt, int tiles_per_block, int ntl, int cam_stride, const int* __restrict__ gmaxv,
-                                                        const unsigned short* __restrict__ hp_off, const unsigned short* __restrict__ hp_src, int skew) {
+                                                        const unsigned short* __restrict__ hp_off, const unsigned short* __restrict__ hp_src) {
     constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, ZSLOT = T + HMAX, NCOL = 12, HPCAP = 4 * HMAX, NQH = HMAX / T;
     // A system that has stopped (the host drops it from the launches one pass after it saw the flag) is carried without arithmetic: its inputs are still staged — the
     // loads of a tile are unconditional — but its rows, its pull phase and its outputs are skipped (workgroup-uniform branches: the state is read once per launch).
@@ -334,7 +334,6 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
             if (reload >= 0) load_block(rb, reload);
             mr_table_add<NB>(pvalid, fsel, jp, tsel, lds, o_tag, o_val, tcount, D0, SB);
         };
-        if (skew > 0 && wave >= NW / 2) { for (int q = 0; q < skew; ++q) __builtin_amdgcn_s_sleep(4); }      // (A/B switch I3D_MR_SKEW: the two waves of a SIMD out of phase, 256 cycles per unit)
         consume(rwA, 0, 2);
         consume(rwB, 1, 3);
         consume(rwA, 2, 4);
@@ -460,10 +459,9 @@ int launch_eg_tile_mr(hipStream_t st, RowView r, OptParams p, TilePlan t, int ns
     MrArgs m; m.u0 = u0; m.qacc0 = qacc0; m.qh0 = qh0; m.pq0 = pq0; m.cam0 = cam0; m.st0 = st0; m.vec = lv.vec; m.qh = lv.qh; m.cam = lv.cam; m.part = lv.part;
     for (int b = 0; b < 3; ++b) m.sys[b] = sys[b < nsys ? b : nsys - 1];
     const size_t lds = mr_lds_bytes(nsys, p.K);
-    const int skew = [] { const char* e = std::getenv("I3D_MR_SKEW"); return e ? std::atoi(e) : 0; }();
 #define I3D_MR(NB) do { \
         if (!set_dynamic_lds((const void*)k_eg_tile_mr<NB>, "k_eg_tile_mr", lds, p.K)) return 0; \
-        k_eg_tile_mr<NB><<<blocks, MR_T, lds, st>>>(r, p, m, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, tiles_per_block, ntl, cam_stride, r.gmax, t.hp_off, t.hp_src, skew); } while (0)
+        k_eg_tile_mr<NB><<<blocks, MR_T, lds, st>>>(r, p, m, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, tiles_per_block, ntl, cam_stride, r.gmax, t.hp_off, t.hp_src); } while (0)
     if (nsys == 1) I3D_MR(1); else if (nsys == 2) I3D_MR(2); else I3D_MR(3);
 #undef I3D_MR
     return blocks;

@@ -131,16 +131,19 @@ def test_optimize_matches_oracle(setup):
     np.testing.assert_allclose(gi, intr, rtol=1e-4)
     np.testing.assert_allclose(gp, poses, rtol=1e-4, atol=1e-6)
     # Distortion: k2, k3 are barely observable (r^4, r^6 with r < 0.5 in normalised image coordinates), so the 5 x 5 distortion block is ill-conditioned and the
-    # bound cannot be a blanket number: it is the north star's 1e-4, or ENVELOPE_FACTOR x what the ORACLE's own answer moves when its input fields are perturbed by
-    # 1e-7 relative (measured here, printed), whichever is larger — component by component.
+    # bound cannot be a blanket number.  It is DERIVED: the oracle is run again on input fields perturbed by 1e-7 relative, which measures — component by component —
+    # how far the answer moves per unit of relative perturbation of the problem (the amplification); the device reproduces residuals and Jacobian entries to 1e-4
+    # (test_eg_residual_and_jacobian), i.e. solves a problem perturbed by at most 1e-4, so its distortion may differ by amplification x 1e-4, and never needs more
+    # than the north star's 1e-4 where the amplification is below one.  Printed: the amplification and the perturbation the observed error corresponds to.
     g3 = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"]); g3.clear_outside_shell(setup["thres"])
-    rng = np.random.default_rng(11)
-    g3.import_fields(sdf_refined=a0["sdf_refined"] * (1.0 + 1e-7 * rng.standard_normal(len(a0["sdf_refined"]))), albedo=a0["albedo"] * (1.0 + 1e-7 * rng.standard_normal(len(a0["albedo"]))))
+    rng = np.random.default_rng(11); eps = 1e-7
+    g3.import_fields(sdf_refined=a0["sdf_refined"] * (1.0 + eps * rng.standard_normal(len(a0["sdf_refined"]))), albedo=a0["albedo"] * (1.0 + eps * rng.standard_normal(len(a0["albedo"]))))
     rc3, _, dist3, _, _ = O.optimize(g3, setup["fr"], ocfg, sc["intr"], sc["dist"], sc["poses"], setup["vsh"]); g3.free()
     assert rc3 == 0
-    spread = np.abs(np.asarray(dist3) - np.asarray(dist)); err = np.abs(np.asarray(gd) - np.asarray(dist))
-    tol = np.maximum(1e-4 * np.abs(np.asarray(dist)), helpers.ENVELOPE_FACTOR * spread) + 1e-12
-    print(f"\n[distortion] oracle {np.asarray(dist)}, device error {err}, oracle's own spread under 1e-7 input perturbations {spread}, bound {tol}")
+    amp = np.abs(np.asarray(dist3) - np.asarray(dist)) / eps; err = np.abs(np.asarray(gd) - np.asarray(dist))
+    tol = np.maximum(1e-4 * np.abs(np.asarray(dist)), 1e-4 * amp) + 1e-12
+    print(f"\n[distortion] oracle {np.asarray(dist)}\n  device error {err}\n  amplification (change per unit relative perturbation of the fields) {amp}\n  bound {tol}\n"
+          f"  the device's error corresponds to a relative perturbation of {err / np.maximum(amp, 1e-30)} (bar: 1e-4)")
     assert np.all(err <= tol), (err, tol)
     ctx.close(); g2.free()
 
