@@ -558,30 +558,28 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
 // 45.6 M projections + bicubic evaluations in fp64 per candidate on the bench workload, although neighbouring voxels choose nearly the same keyframes and the bench's
 // 11.4 M rows reference only ~15 M distinct (voxel, keyframe) samples.  The trust-region loop evaluates six to seven candidates per Gauss-Newton iteration, all with
 // the SAME rows (only the unknowns move), so the sharing pattern is planned once per outer iteration:
-//   k_sample_plan   per stored voxel w: the keyframes of the free rows of w, w-x, w-y, w-z (<= CS_SLOTS = 4 x 5 distinct ones; more observation slots than 5 can overflow -> the iteration falls back to k_build<false>)
+//   k_sample_plan   per list entry w: the keyframes of the free rows of w, w-x, w-y, w-z (<= CS_SLOTS = 4 x 5 distinct ones; more observation slots than 5 can overflow -> the iteration falls back to k_build<false>)
 //   k_sample_rows   per row: the sample slot of its keyframe at each of its four points (4 x 8 bits)
 // and a candidate costs
-//   k_cost_sample   per (voxel, slot): iso-point -> projection with the candidate camera -> bicubic luminance (fp64; NaN = outside the image), the only kernel that
+//   k_cost_sample   per (entry, slot): iso-point -> projection with the candidate camera -> bicubic luminance (fp64; NaN = outside the image), the only kernel that
 //                   touches the images: one stencil point per lane instead of four, few live values, high occupancy
 //   k_cost_rows     per entry: regulariser costs, the four shadings, and per row four sample reads -> residual -> cost
 // Every sample is computed by the same functions on the same inputs as in k_build<false>, the residuals are formed and added in the same order and the per-workgroup
 // partial sums have the same shape: the cost is bit-identical (tests/test_gpu_ladder.py::test_shared_sample_cost_is_the_row_wise_cost_bit_for_bit).
 static __device__ inline int row_tag(const RowView& r, int a, int k) { return __float_as_int(r.row_jt()[row_jt_index(a, k, r.slots)].y); }
 
-// (samples are indexed by the DEVICE voxel index, not by the work-list entry: a point of a row — the +x, +y, +z neighbour of its voxel — need not be a list entry;
-// a neighbour whose parameters are all fixed and which owns no rows is not in the list)
-__global__ void __launch_bounds__(256) k_sample_plan(GridView g, RowView r, CostPlan cp) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= g.N) return;
-    const size_t N = g.N;
-    const int src[4] = {w, g.nbr[(size_t)NB_MX * N + w], g.nbr[(size_t)NB_MY * N + w], g.nbr[(size_t)NB_MZ * N + w]};
+__global__ void __launch_bounds__(256) k_sample_plan(RowView r, CostPlan cp) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= r.A) return;
+    const size_t Acap = r.Acap;
+    const int src[4] = {a, r.anbr[(size_t)NB_MX * Acap + a], r.anbr[(size_t)NB_MY * Acap + a], r.anbr[(size_t)NB_MZ * Acap + a]};
     int set[CS_SLOTS]; int n = 0; bool over = false;
 #pragma unroll
     for (int i = 0; i < CS_SLOTS; ++i) set[i] = -1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int v = src[q] >= 0 ? g.aidx[src[q]] : -1;                       // list entry of the source voxel
-        if (v < 0 || v >= r.A || !(r.aflags[v] & F_ACTIVE)) continue;
+        const int v = src[q];
+        if (v < 0 || !(r.aflags[v] & F_ACTIVE)) continue;
         const int nr = r.nrows[v];
         if (nr == 0 || !(row_tag(r, v, 0) & ROW_FREE_BIT)) continue;          // the free bit is a property of the voxel: all of its rows or none
         for (int k = 0; k < nr; ++k) {
@@ -596,34 +594,29 @@ __global__ void __launch_bounds__(256) k_sample_plan(GridView g, RowView r, Cost
             ++n;
         }
     }
-    cp.samp_n[w] = (uint8_t)n;
-    for (int i = 0; i < n; ++i) {
-        int f = -1;
+    cp.samp_n[a] = (uint8_t)n;
 #pragma unroll
-        for (int j = 0; j < CS_SLOTS; ++j) if (j == i) f = set[j];
-        cp.samp_f[(size_t)i * N + w] = (unsigned short)f;
-    }
+    for (int i = 0; i < CS_SLOTS; ++i) cp.samp_f[(size_t)i * Acap + a] = (unsigned short)(set[i] < 0 ? 0xffff : set[i]);
     if (over) *cp.overflow = 1;
 }
-__global__ void __launch_bounds__(256) k_sample_rows(GridView g, RowView r, CostPlan cp) {
+__global__ void __launch_bounds__(256) k_sample_rows(RowView r, CostPlan cp) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= r.A || !(r.aflags[a] & F_ACTIVE)) return;
     const int nr = r.nrows[a];
     if (nr == 0 || !(row_tag(r, a, 0) & ROW_FREE_BIT)) return;
-    const size_t Acap = r.Acap, N = g.N;
-    const int s = r.alist[a];
-    const int pt[4] = {s, g.nbr[(size_t)NB_PX * N + s], g.nbr[(size_t)NB_PY * N + s], g.nbr[(size_t)NB_PZ * N + s]};
+    const size_t Acap = r.Acap;
+    const int pt[4] = {a, r.anbr[(size_t)NB_PX * Acap + a], r.anbr[(size_t)NB_PY * Acap + a], r.anbr[(size_t)NB_PZ * Acap + a]};
     for (int k = 0; k < nr; ++k) {
         const int f = row_tag(r, a, k) & ~ROW_FREE_BIT;
         unsigned packed = 0; bool ok = true;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int slot = -1;
-            if (pt[j] >= 0) { const int n = cp.samp_n[pt[j]]; for (int i = 0; i < n; ++i) if (cp.samp_f[(size_t)i * N + pt[j]] == (unsigned short)f) { slot = i; break; } }
+            if (pt[j] >= 0) { const int n = cp.samp_n[pt[j]]; for (int i = 0; i < n; ++i) if (cp.samp_f[(size_t)i * Acap + pt[j]] == (unsigned short)f) { slot = i; break; } }
             ok &= slot >= 0; packed |= (unsigned)(slot < 0 ? 0 : slot) << (8 * j);
         }
         cp.row_slots[(size_t)k * Acap + a] = packed;
-        if (!ok) *cp.overflow = 1;        // (cannot happen when the sets did not overflow: a row exists only where the forward stencil of its voxel is stored)
+        if (!ok) *cp.overflow = 1;        // (cannot happen when the sets did not overflow: a point of a row is a list entry whose set holds the row's keyframe)
     }
 }
 
@@ -638,11 +631,12 @@ __global__ void __launch_bounds__(256) k_cost_sample(GridView g, RowView r, OptP
         for (int i = threadIdx.x; i < p.K * WORDS; i += blockDim.x) { const int f = i / WORDS, w = i - f * WORDS; frame_lds_raw[(size_t)f * WORDS + w] = reinterpret_cast<const double*>(&frames[f].hot)[w]; }
         __syncthreads();
     }
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= g.N) return;
-    const int n = cp.samp_n[s];
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= r.A) return;
+    const int n = cp.samp_n[a];
     if (n == 0) return;
-    const size_t N = g.N;
+    const size_t Acap = r.Acap; const int N = g.N;
+    const int s = r.alist[a];
     const int ix = g.nbr[(size_t)NB_PX * N + s], iy = g.nbr[(size_t)NB_PY * N + s], iz = g.nbr[(size_t)NB_PZ * N + s];
     if (ix < 0 || iy < 0 || iz < 0) return;          // (not the point of any row: a row needs the forward ring of each of its points)
     // the iso-point of this voxel: shared_point's position, expression for expression
@@ -657,7 +651,7 @@ __global__ void __launch_bounds__(256) k_cost_sample(GridView g, RowView r, OptP
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     for (int i0 = 0; i0 < n; i0 += 2) {            // two samples per trip: their tap loads are in flight together
         const bool two = i0 + 1 < n;
-        const int f0 = cp.samp_f[(size_t)i0 * N + s], f1 = two ? cp.samp_f[(size_t)(i0 + 1) * N + s] : f0;
+        const int f0 = cp.samp_f[(size_t)i0 * Acap + a], f1 = two ? cp.samp_f[(size_t)(i0 + 1) * Acap + a] : f0;
         const FrameHot& c0 = FR_LDS ? flds[f0] : frames[f0].hot; const FrameHot& c1 = FR_LDS ? flds[f1] : frames[f1].hot;
         double u0, v0, u1, v1; PointVal unused;
         const bool in0 = project_point<false>(P, c0.R, c0.t, p, u0, v0, unused), in1 = project_point<false>(P, c1.R, c1.t, p, u1, v1, unused);
@@ -667,8 +661,8 @@ __global__ void __launch_bounds__(256) k_cost_sample(GridView g, RowView r, OptP
         bicubic_taps(c0.lum, p.w, p.h, v0, u0, t0); bicubic_taps(c1.lum, p.w, p.h, v1, u1, t1);
         double l0, l1; float d0, d1;
         bicubic_eval<false>(t0, l0, d0, d1); bicubic_eval<false>(t1, l1, d0, d1);
-        cp.L[(size_t)i0 * N + s] = in0 ? l0 : nan;
-        if (two) cp.L[(size_t)(i0 + 1) * N + s] = in1 ? l1 : nan;
+        cp.L[(size_t)i0 * Acap + a] = in0 ? l0 : nan;
+        if (two) cp.L[(size_t)(i0 + 1) * Acap + a] = in1 ? l1 : nan;
     }
 }
 
@@ -722,12 +716,12 @@ __global__ void __launch_bounds__(256) k_cost_rows(GridView g, RowView r, OptPar
                 shared_point(q[2], sd[1], sd[7], sd[2], sd[3], g.x_alb[idx[12]], sh, cx, cy + 1, cz, vs);
                 shared_point(q[3], sd[4], sd[8], sd[3], sd[5], g.x_alb[idx[13]], sh, cx, cy, cz + 1, vs);
                 const double dB1 = q[1].B - q[0].B, dB2 = q[2].B - q[0].B, dB3 = q[3].B - q[0].B;
-                const size_t NN = (size_t)N;
+                const int e1 = r.anbr[(size_t)NB_PX * Acap + a], e2 = r.anbr[(size_t)NB_PY * Acap + a], e3 = r.anbr[(size_t)NB_PZ * Acap + a];
                 for (int k = 0; k < nin; ++k) {
                     const float roww = r.row_wr[row_scalar_index(a, k, r.slots)].x;
                     const unsigned sl = cp.row_slots[(size_t)k * Acap + a];
-                    const double l0 = cp.L[(size_t)(sl & 255u) * NN + s], l1 = cp.L[(size_t)((sl >> 8) & 255u) * NN + idx[6]], l2 = cp.L[(size_t)((sl >> 16) & 255u) * NN + idx[1]],
-                                 l3 = cp.L[(size_t)(sl >> 24) * NN + idx[4]];      // the points: the voxel, +x (stencil slot 6), +y (1), +z (4)
+                    const double l0 = cp.L[(size_t)(sl & 255u) * Acap + a], l1 = cp.L[(size_t)((sl >> 8) & 255u) * Acap + e1], l2 = cp.L[(size_t)((sl >> 16) & 255u) * Acap + e2],
+                                 l3 = cp.L[(size_t)(sl >> 24) * Acap + e3];
                     const double d1 = dB1 - (l1 - l0), d2 = dB2 - (l2 - l0), d3 = dB3 - (l3 - l0);
                     const double res = sqrt(d1 * d1 + d2 * d2 + d3 * d3);
                     if (res > 0.0 && !isinf(res)) cost += 0.5 * (double)roww * p.type_w[0] * res * res;      // a point outside the image left NaN: no residual (NV_INVALID_RESIDUAL)
@@ -738,18 +732,18 @@ __global__ void __launch_bounds__(256) k_cost_rows(GridView g, RowView r, OptPar
     block_partial_d(cost, cost_out, 1, 0);
 }
 
-void launch_sample_plan(hipStream_t st, GridView g, RowView r, CostPlan cp) {
+void launch_sample_plan(hipStream_t st, RowView r, CostPlan cp) {
     if (r.A <= 0) return;
     (void)hipMemsetAsync(cp.overflow, 0, sizeof(int), st);
-    k_sample_plan<<<(g.N + 255) / 256, 256, 0, st>>>(g, r, cp);
-    k_sample_rows<<<(r.A + 255) / 256, 256, 0, st>>>(g, r, cp);
+    k_sample_plan<<<(r.A + 255) / 256, 256, 0, st>>>(r, cp);
+    k_sample_rows<<<(r.A + 255) / 256, 256, 0, st>>>(r, cp);
 }
 // the cost of the assembled rows at (g.x_sdf, g.x_alb, frames, p / cam9) through the plan: cost_out += cost (scratch: per-workgroup partials)
 void launch_cost_shared(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, CostPlan cp, double* cost_out, double* scratch, const double* cam9, const LmState* lm) {
     if (r.nC <= 0) return;
     const size_t lds = (size_t)p.K * sizeof(FrameHot);
-    if (lds <= 48 * 1024) k_cost_sample<true><<<(g.N + 255) / 256, 256, lds, st>>>(g, r, p, frames, cp, cam9, lm);
-    else k_cost_sample<false><<<(g.N + 255) / 256, 256, 0, st>>>(g, r, p, frames, cp, cam9, lm);
+    if (lds <= 48 * 1024) k_cost_sample<true><<<(r.A + 255) / 256, 256, lds, st>>>(g, r, p, frames, cp, cam9, lm);
+    else k_cost_sample<false><<<(r.A + 255) / 256, 256, 0, st>>>(g, r, p, frames, cp, cam9, lm);
     const int blocks = (r.nC + 255) / 256;
     k_cost_rows<<<blocks, 256, 0, st>>>(g, r, p, cp, scratch, lm);
     launch_reduce_partials(st, scratch, blocks, 1, cost_out, nullptr);

@@ -45,13 +45,13 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
 // candidate cost with shared image samples (build.hip): the (voxel, keyframe) luminance samples the rows of an outer iteration reference, planned once per iteration
 constexpr int CS_SLOTS = 20;      // 4 source voxels (w, w-x, w-y, w-z) x 5 rows: the union cannot be larger with the shipped 5 observations per voxel
 struct CostPlan {
-    unsigned short* samp_f;       // [CS_SLOTS][N] keyframes sampled at a stored voxel's iso-point (device voxel index; only the first samp_n are written)
-    uint8_t* samp_n;              // [N] their number
+    unsigned short* samp_f;       // [CS_SLOTS][Acap] keyframes sampled at a list entry's iso-point (0xffff = unused)
+    uint8_t* samp_n;              // [Acap] their number
     unsigned* row_slots;          // [slots][Acap] per row: the slot of its keyframe at its four points (4 x 8 bits)
-    double* L;                    // [CS_SLOTS][N] the samples of the candidate being evaluated (NaN = outside the image)
+    double* L;                    // [CS_SLOTS][Acap] the samples of the candidate being evaluated (NaN = outside the image)
     int* overflow;                // device flag: an entry needs more than CS_SLOTS samples -> k_build<false> for this outer iteration
 };
-void launch_sample_plan(hipStream_t st, GridView g, RowView r, CostPlan cp);
+void launch_sample_plan(hipStream_t st, RowView r, CostPlan cp);
 void launch_cost_shared(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, CostPlan cp, double* cost_out /* accumulated */, double* scratch,
                         const double* cam9 = nullptr, const LmState* lm = nullptr);
 void launch_weight_sums(hipStream_t st, RowView r, double* sums9 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels */,

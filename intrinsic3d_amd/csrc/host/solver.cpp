@@ -304,7 +304,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         const size_t Acap = (size_t)c->Acap;
         CTX_HIP(c, c->cs_samp_f.alloc(Acap * CS_SLOTS)); CTX_HIP(c, c->cs_samp_n.alloc(Acap)); CTX_HIP(c, c->cs_row_slots.alloc(Acap * (size_t)slots)); CTX_HIP(c, c->cs_L.alloc(Acap * CS_SLOTS));
         CTX_HIP(c, c->cs_overflow.alloc(1));
-        TimedScope t(c, I3D_K_CLASSIFY); launch_sample_plan(s, g, r, c->cost_plan());
+        TimedScope t(c, I3D_K_CLASSIFY); launch_sample_plan(s, r, c->cost_plan());
     }
     { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan(), sharded(c) ? c->cflag.p : nullptr); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_ladder.py tests/test_gpu_parity.py tests/test_gpu_bench_parity.py -q -m gpu -p no:cacheprovider -s > $O/tests.log 2>&1
 echo "tests rc=$?" | tee -a $O/summary.txt
 grep -n "passed\|failed\|FAILED\|\[distortion\]\|perturbation of\|candidate cost" $O/tests.log | cut -c1-400 | tail -12
-B="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-sample 0 --band2-steps 0"
+B="python bench.py --steps 10 --warmup 2 --cpu-sample 0 --band2-steps 0"
 run() { name=$1; shift; env "$@" > $O/bench_$name.json 2> $O/bench_$name.log; echo "$name rc=$? $(python - <<P
 import json
 try:
