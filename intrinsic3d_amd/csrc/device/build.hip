@@ -558,8 +558,8 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
 // 45.6 M projections + bicubic evaluations in fp64 per candidate on the bench workload, although neighbouring voxels choose nearly the same keyframes and the bench's
 // 11.4 M rows reference only ~15 M distinct (voxel, keyframe) samples.  The trust-region loop evaluates six to seven candidates per Gauss-Newton iteration, all with
 // the SAME rows (only the unknowns move), so the sharing pattern is planned once per outer iteration:
-//   k_sample_plan   per list entry w: the keyframes of the free rows of w, w-x, w-y, w-z (<= CS_SLOTS = 4 x 5 distinct ones; more observation slots than 5 can overflow -> the iteration falls back to k_build<false>)
-//   k_sample_rows   per row: the sample slot of its keyframe at each of its four points (4 x 8 bits)
+//   k_sample_plan   per list entry w: the keyframes of the free rows of w, w-x, w-y, w-z (<= CS_SLOTS distinct ones; more -> the whole iteration falls back to k_build<false>)
+//   k_sample_rows   per row: the sample slot of its keyframe at each of its four points (4 x 4 bits)
 // and a candidate costs
 //   k_cost_sample   per (entry, slot): iso-point -> projection with the candidate camera -> bicubic luminance (fp64; NaN = outside the image), the only kernel that
 //                   touches the images: one stencil point per lane instead of four, few live values, high occupancy
@@ -613,9 +613,9 @@ __global__ void __launch_bounds__(256) k_sample_rows(RowView r, CostPlan cp) {
         for (int j = 0; j < 4; ++j) {
             int slot = -1;
             if (pt[j] >= 0) { const int n = cp.samp_n[pt[j]]; for (int i = 0; i < n; ++i) if (cp.samp_f[(size_t)i * Acap + pt[j]] == (unsigned short)f) { slot = i; break; } }
-            ok &= slot >= 0; packed |= (unsigned)(slot < 0 ? 0 : slot) << (8 * j);
+            ok &= slot >= 0; packed |= (unsigned)(slot < 0 ? 0 : slot) << (4 * j);
         }
-        cp.row_slots[(size_t)k * Acap + a] = packed;
+        cp.row_slots[(size_t)k * Acap + a] = (unsigned short)packed;
         if (!ok) *cp.overflow = 1;        // (cannot happen when the sets did not overflow: a point of a row is a list entry whose set holds the row's keyframe)
     }
 }
@@ -720,8 +720,8 @@ __global__ void __launch_bounds__(256) k_cost_rows(GridView g, RowView r, OptPar
                 for (int k = 0; k < nin; ++k) {
                     const float roww = r.row_wr[row_scalar_index(a, k, r.slots)].x;
                     const unsigned sl = cp.row_slots[(size_t)k * Acap + a];
-                    const double l0 = cp.L[(size_t)(sl & 255u) * Acap + a], l1 = cp.L[(size_t)((sl >> 8) & 255u) * Acap + e1], l2 = cp.L[(size_t)((sl >> 16) & 255u) * Acap + e2],
-                                 l3 = cp.L[(size_t)(sl >> 24) * Acap + e3];
+                    const double l0 = cp.L[(size_t)(sl & 15u) * Acap + a], l1 = cp.L[(size_t)((sl >> 4) & 15u) * Acap + e1], l2 = cp.L[(size_t)((sl >> 8) & 15u) * Acap + e2],
+                                 l3 = cp.L[(size_t)((sl >> 12) & 15u) * Acap + e3];
                     const double d1 = dB1 - (l1 - l0), d2 = dB2 - (l2 - l0), d3 = dB3 - (l3 - l0);
                     const double res = sqrt(d1 * d1 + d2 * d2 + d3 * d3);
                     if (res > 0.0 && !isinf(res)) cost += 0.5 * (double)roww * p.type_w[0] * res * res;      // a point outside the image left NaN: no residual (NV_INVALID_RESIDUAL)

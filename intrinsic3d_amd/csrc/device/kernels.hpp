@@ -43,11 +43,11 @@ void launch_group_cull(hipStream_t st, GridView g, RowView r, OptParams p, const
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out /* accumulated */, double* scratch,
                   const double* cam9 = nullptr, const LmState* lm = nullptr);
 // candidate cost with shared image samples (build.hip): the (voxel, keyframe) luminance samples the rows of an outer iteration reference, planned once per iteration
-constexpr int CS_SLOTS = 20;      // 4 source voxels (w, w-x, w-y, w-z) x 5 rows: the union cannot be larger with the shipped 5 observations per voxel
+constexpr int CS_SLOTS = 12;
 struct CostPlan {
     unsigned short* samp_f;       // [CS_SLOTS][Acap] keyframes sampled at a list entry's iso-point (0xffff = unused)
     uint8_t* samp_n;              // [Acap] their number
-    unsigned* row_slots;          // [slots][Acap] per row: the slot of its keyframe at its four points (4 x 8 bits)
+    unsigned short* row_slots;    // [slots][Acap] per row: the slot of its keyframe at its four points (4 x 4 bits)
     double* L;                    // [CS_SLOTS][Acap] the samples of the candidate being evaluated (NaN = outside the image)
     int* overflow;                // device flag: an entry needs more than CS_SLOTS samples -> k_build<false> for this outer iteration
 };
