@@ -552,203 +552,6 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
     if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr);      // cost_dst += sum
 }
 
-// ---- candidate cost with SHARED image samples ------------------------------------------------------------------------------------------------------------------
-// A row (voxel v, keyframe f) of Eg compares shading differences with luminance differences between v and its +x, +y, +z neighbours, each luminance sampled at the
-// projection of the neighbour's OWN iso-point (shading_cost.h:139-167) — a function of (voxel w, keyframe f) alone.  k_build<false> evaluates four such samples per row:
-// 45.6 M projections + bicubic evaluations in fp64 per candidate on the bench workload, although neighbouring voxels choose nearly the same keyframes and the bench's
-// 11.4 M rows reference only ~15 M distinct (voxel, keyframe) samples.  The trust-region loop evaluates six to seven candidates per Gauss-Newton iteration, all with
-// the SAME rows (only the unknowns move), so the sharing pattern is planned once per outer iteration:
-//   k_sample_plan   per list entry w: the keyframes of the free rows of w, w-x, w-y, w-z (<= CS_SLOTS distinct ones; more -> the whole iteration falls back to k_build<false>)
-//   k_sample_rows   per row: the sample slot of its keyframe at each of its four points (4 x 4 bits)
-// and a candidate costs
-//   k_cost_sample   per (entry, slot): iso-point -> projection with the candidate camera -> bicubic luminance (fp64; NaN = outside the image), the only kernel that
-//                   touches the images: one stencil point per lane instead of four, few live values, high occupancy
-//   k_cost_rows     per entry: regulariser costs, the four shadings, and per row four sample reads -> residual -> cost
-// Every sample is computed by the same functions on the same inputs as in k_build<false>, the residuals are formed and added in the same order and the per-workgroup
-// partial sums have the same shape: the cost is bit-identical (tests/test_gpu_ladder.py::test_shared_sample_cost_is_the_row_wise_cost_bit_for_bit).
-static __device__ inline int row_tag(const RowView& r, int a, int k) { return __float_as_int(r.row_jt()[row_jt_index(a, k, r.slots)].y); }
-
-__global__ void __launch_bounds__(256) k_sample_plan(RowView r, CostPlan cp) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= r.A) return;
-    const size_t Acap = r.Acap;
-    const int src[4] = {a, r.anbr[(size_t)NB_MX * Acap + a], r.anbr[(size_t)NB_MY * Acap + a], r.anbr[(size_t)NB_MZ * Acap + a]};
-    int set[CS_SLOTS]; int n = 0; bool over = false;
-#pragma unroll
-    for (int i = 0; i < CS_SLOTS; ++i) set[i] = -1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int v = src[q];
-        if (v < 0 || !(r.aflags[v] & F_ACTIVE)) continue;
-        const int nr = r.nrows[v];
-        if (nr == 0 || !(row_tag(r, v, 0) & ROW_FREE_BIT)) continue;          // the free bit is a property of the voxel: all of its rows or none
-        for (int k = 0; k < nr; ++k) {
-            const int f = row_tag(r, v, k) & ~ROW_FREE_BIT;
-            bool found = false;
-#pragma unroll
-            for (int i = 0; i < CS_SLOTS; ++i) found |= set[i] == f;
-            if (found) continue;
-            if (n >= CS_SLOTS) { over = true; continue; }
-#pragma unroll
-            for (int i = 0; i < CS_SLOTS; ++i) if (i == n) set[i] = f;        // (compile-time indices: the set stays in registers)
-            ++n;
-        }
-    }
-    cp.samp_n[a] = (uint8_t)n;
-#pragma unroll
-    for (int i = 0; i < CS_SLOTS; ++i) cp.samp_f[(size_t)i * Acap + a] = (unsigned short)(set[i] < 0 ? 0xffff : set[i]);
-    if (over) *cp.overflow = 1;
-}
-__global__ void __launch_bounds__(256) k_sample_rows(RowView r, CostPlan cp) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= r.A || !(r.aflags[a] & F_ACTIVE)) return;
-    const int nr = r.nrows[a];
-    if (nr == 0 || !(row_tag(r, a, 0) & ROW_FREE_BIT)) return;
-    const size_t Acap = r.Acap;
-    const int pt[4] = {a, r.anbr[(size_t)NB_PX * Acap + a], r.anbr[(size_t)NB_PY * Acap + a], r.anbr[(size_t)NB_PZ * Acap + a]};
-    for (int k = 0; k < nr; ++k) {
-        const int f = row_tag(r, a, k) & ~ROW_FREE_BIT;
-        unsigned packed = 0; bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int slot = -1;
-            if (pt[j] >= 0) { const int n = cp.samp_n[pt[j]]; for (int i = 0; i < n; ++i) if (cp.samp_f[(size_t)i * Acap + pt[j]] == (unsigned short)f) { slot = i; break; } }
-            ok &= slot >= 0; packed |= (unsigned)(slot < 0 ? 0 : slot) << (4 * j);
-        }
-        cp.row_slots[(size_t)k * Acap + a] = (unsigned short)packed;
-        if (!ok) *cp.overflow = 1;        // (cannot happen when the sets did not overflow: a point of a row is a list entry whose set holds the row's keyframe)
-    }
-}
-
-template <bool FR_LDS>
-__global__ void __launch_bounds__(256) k_cost_sample(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, CostPlan cp, const double* __restrict__ cam9, const LmState* __restrict__ lm) {
-    extern __shared__ double frame_lds_raw[];
-    if (lm && lm->done) return;
-    if (cam9) { for (int i = 0; i < 4; ++i) p.intr[i] = cam9[i]; for (int i = 0; i < 5; ++i) p.dist[i] = cam9[4 + i]; }
-    FrameHot* const flds = reinterpret_cast<FrameHot*>(frame_lds_raw);
-    if (FR_LDS) {
-        constexpr int WORDS = sizeof(FrameHot) / 8;
-        for (int i = threadIdx.x; i < p.K * WORDS; i += blockDim.x) { const int f = i / WORDS, w = i - f * WORDS; frame_lds_raw[(size_t)f * WORDS + w] = reinterpret_cast<const double*>(&frames[f].hot)[w]; }
-        __syncthreads();
-    }
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= r.A) return;
-    const int n = cp.samp_n[a];
-    if (n == 0) return;
-    const size_t Acap = r.Acap; const int N = g.N;
-    const int s = r.alist[a];
-    const int ix = g.nbr[(size_t)NB_PX * N + s], iy = g.nbr[(size_t)NB_PY * N + s], iz = g.nbr[(size_t)NB_PZ * N + s];
-    if (ix < 0 || iy < 0 || iz < 0) return;          // (not the point of any row: a row needs the forward ring of each of its points)
-    // the iso-point of this voxel: shared_point's position, expression for expression
-    double P[3];
-    {
-        const double sv = g.x_sdf[s], vs = (double)g.voxel_size;
-        double g0 = g.x_sdf[ix] - sv, g1 = g.x_sdf[iy] - sv, g2 = g.x_sdf[iz] - sv;
-        const double len = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
-        if (len > 0.0) { const double il = rcp64(len); g0 *= il; g1 *= il; g2 *= il; }
-        P[0] = (double)g.cx[s] * vs - g0 * sv; P[1] = (double)g.cy[s] * vs - g1 * sv; P[2] = (double)g.cz[s] * vs - g2 * sv;
-    }
-    const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    for (int i0 = 0; i0 < n; i0 += 2) {            // two samples per trip: their tap loads are in flight together
-        const bool two = i0 + 1 < n;
-        const int f0 = cp.samp_f[(size_t)i0 * Acap + a], f1 = two ? cp.samp_f[(size_t)(i0 + 1) * Acap + a] : f0;
-        const FrameHot& c0 = FR_LDS ? flds[f0] : frames[f0].hot; const FrameHot& c1 = FR_LDS ? flds[f1] : frames[f1].hot;
-        double u0, v0, u1, v1; PointVal unused;
-        const bool in0 = project_point<false>(P, c0.R, c0.t, p, u0, v0, unused), in1 = project_point<false>(P, c1.R, c1.t, p, u1, v1, unused);
-        if (!in0) { u0 = 0.0; v0 = 0.0; }
-        if (!in1) { u1 = 0.0; v1 = 0.0; }
-        Taps t0, t1;
-        bicubic_taps(c0.lum, p.w, p.h, v0, u0, t0); bicubic_taps(c1.lum, p.w, p.h, v1, u1, t1);
-        double l0, l1; float d0, d1;
-        bicubic_eval<false>(t0, l0, d0, d1); bicubic_eval<false>(t1, l1, d0, d1);
-        cp.L[(size_t)i0 * Acap + a] = in0 ? l0 : nan;
-        if (two) cp.L[(size_t)(i0 + 1) * Acap + a] = in1 ? l1 : nan;
-    }
-}
-
-__global__ void __launch_bounds__(256) k_cost_rows(GridView g, RowView r, OptParams p, CostPlan cp, double* cost_out, const LmState* __restrict__ lm) {
-    if (lm && lm->done) return;
-    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-    const int a = ci < r.nC ? (r.clist ? r.clist[ci] : ci) : -1;
-    const bool owned = a >= r.own0 && a < r.own1;
-    double cost = 0.0;
-    if (a >= 0 && owned) {
-        const int N = g.N; const size_t Acap = r.Acap;
-        const int s = r.alist[a];
-        const uint8_t fl = r.aflags[a];
-        if (fl & F_ACTIVE) {
-            int idx[P_VOX];
-#pragma unroll
-            for (int c = 0; c < 10; ++c) { const int nb = slot_fwd_nbr(c); idx[c] = nb < 0 ? s : g.nbr[(size_t)nb * N + s]; }
-            idx[10] = idx[0]; idx[11] = idx[6]; idx[12] = idx[1]; idx[13] = idx[4];
-            int ring[6];
-#pragma unroll
-            for (int d = 0; d < 6; ++d) ring[d] = g.nbr[(size_t)d * N + s];
-            const double xs = g.x_sdf[s];
-            const uint8_t rf = r.regflags[a];
-            // cost of the regulariser rows at this state (k_build<false>, statement for statement)
-            if ((rf & 1) && (rf & 8)) {
-                const double dxx = g.x_sdf[ring[0]] + g.x_sdf[ring[1]] - 2.0 * xs, dyy = g.x_sdf[ring[2]] + g.x_sdf[ring[3]] - 2.0 * xs,
-                             dzz = g.x_sdf[ring[4]] + g.x_sdf[ring[5]] - 2.0 * xs;
-                const double lap = dxx + dyy + dzz; cost += 0.5 * p.type_w[1] * lap * lap;
-            }
-            if ((rf & 2) && (rf & 16)) { double e = xs - g.sdf0[s]; if (e == 0.0) e = 0.0000001; cost += 0.5 * p.type_w[2] * e * e; }
-            const uint8_t eafree = r.ea_free[a];
-            const double xa = g.x_alb[s];
-#pragma unroll
-            for (int d = 0; d < 6; ++d) if (eafree & (1 << d)) {
-                const double e = xa - g.x_alb[ring[d]];
-                cost += 0.5 * (double)r.ea_w[(size_t)d * Acap + a] * p.type_w[3] * e * e;
-            }
-            const int nin = (int)r.nrows[a];
-            if (nin > 0 && (row_tag(r, a, 0) & ROW_FREE_BIT)) {
-                double sd[10];
-#pragma unroll
-                for (int c = 0; c < 10; ++c) sd[c] = g.x_sdf[idx[c]];
-                float sh[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) sh[j] = g.sh[(size_t)j * N + s];
-                const int cx = g.cx[s], cy = g.cy[s], cz = g.cz[s];
-                const double vs = (double)g.voxel_size;
-                PointShared q[4];
-                shared_point(q[0], sd[0], sd[6], sd[1], sd[4], g.x_alb[idx[10]], sh, cx, cy, cz, vs);
-                shared_point(q[1], sd[6], sd[9], sd[7], sd[8], g.x_alb[idx[11]], sh, cx + 1, cy, cz, vs);
-                shared_point(q[2], sd[1], sd[7], sd[2], sd[3], g.x_alb[idx[12]], sh, cx, cy + 1, cz, vs);
-                shared_point(q[3], sd[4], sd[8], sd[3], sd[5], g.x_alb[idx[13]], sh, cx, cy, cz + 1, vs);
-                const double dB1 = q[1].B - q[0].B, dB2 = q[2].B - q[0].B, dB3 = q[3].B - q[0].B;
-                const int e1 = r.anbr[(size_t)NB_PX * Acap + a], e2 = r.anbr[(size_t)NB_PY * Acap + a], e3 = r.anbr[(size_t)NB_PZ * Acap + a];
-                for (int k = 0; k < nin; ++k) {
-                    const float roww = r.row_wr[row_scalar_index(a, k, r.slots)].x;
-                    const unsigned sl = cp.row_slots[(size_t)k * Acap + a];
-                    const double l0 = cp.L[(size_t)(sl & 15u) * Acap + a], l1 = cp.L[(size_t)((sl >> 4) & 15u) * Acap + e1], l2 = cp.L[(size_t)((sl >> 8) & 15u) * Acap + e2],
-                                 l3 = cp.L[(size_t)((sl >> 12) & 15u) * Acap + e3];
-                    const double d1 = dB1 - (l1 - l0), d2 = dB2 - (l2 - l0), d3 = dB3 - (l3 - l0);
-                    const double res = sqrt(d1 * d1 + d2 * d2 + d3 * d3);
-                    if (res > 0.0 && !isinf(res)) cost += 0.5 * (double)roww * p.type_w[0] * res * res;      // a point outside the image left NaN: no residual (NV_INVALID_RESIDUAL)
-                }
-            }
-        }
-    }
-    block_partial_d(cost, cost_out, 1, 0);
-}
-
-void launch_sample_plan(hipStream_t st, RowView r, CostPlan cp) {
-    if (r.A <= 0) return;
-    (void)hipMemsetAsync(cp.overflow, 0, sizeof(int), st);
-    k_sample_plan<<<(r.A + 255) / 256, 256, 0, st>>>(r, cp);
-    k_sample_rows<<<(r.A + 255) / 256, 256, 0, st>>>(r, cp);
-}
-// the cost of the assembled rows at (g.x_sdf, g.x_alb, frames, p / cam9) through the plan: cost_out += cost (scratch: per-workgroup partials)
-void launch_cost_shared(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, CostPlan cp, double* cost_out, double* scratch, const double* cam9, const LmState* lm) {
-    if (r.nC <= 0) return;
-    const size_t lds = (size_t)p.K * sizeof(FrameHot);
-    if (lds <= 48 * 1024) k_cost_sample<true><<<(r.A + 255) / 256, 256, lds, st>>>(g, r, p, frames, cp, cam9, lm);
-    else k_cost_sample<false><<<(r.A + 255) / 256, 256, 0, st>>>(g, r, p, frames, cp, cam9, lm);
-    const int blocks = (r.nC + 255) / 256;
-    k_cost_rows<<<blocks, 256, 0, st>>>(g, r, p, cp, scratch, lm);
-    launch_reduce_partials(st, scratch, blocks, 1, cost_out, nullptr);
-}
-
 // nls_solver.cpp:379-394 — per-type sums of the row weights (sums[0..3]) and row counts (sums[4..7])
 __global__ void __launch_bounds__(256) k_weight_sums(RowView r, double* partials) {
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0, n0 = 0, n3 = 0, na = 0;

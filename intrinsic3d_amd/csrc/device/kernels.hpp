@@ -42,18 +42,6 @@ void launch_group_cull(hipStream_t st, GridView g, RowView r, OptParams p, const
 // camera of an LM attempt never visits the host (lm_kernels.hip).  lm (or null): skip the launch's work when the solve is already over.
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out /* accumulated */, double* scratch,
                   const double* cam9 = nullptr, const LmState* lm = nullptr);
-// candidate cost with shared image samples (build.hip): the (voxel, keyframe) luminance samples the rows of an outer iteration reference, planned once per iteration
-constexpr int CS_SLOTS = 12;
-struct CostPlan {
-    unsigned short* samp_f;       // [CS_SLOTS][Acap] keyframes sampled at a list entry's iso-point (0xffff = unused)
-    uint8_t* samp_n;              // [Acap] their number
-    unsigned short* row_slots;    // [slots][Acap] per row: the slot of its keyframe at its four points (4 x 4 bits)
-    double* L;                    // [CS_SLOTS][Acap] the samples of the candidate being evaluated (NaN = outside the image)
-    int* overflow;                // device flag: an entry needs more than CS_SLOTS samples -> k_build<false> for this outer iteration
-};
-void launch_sample_plan(hipStream_t st, RowView r, CostPlan cp);
-void launch_cost_shared(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, CostPlan cp, double* cost_out /* accumulated */, double* scratch,
-                        const double* cam9 = nullptr, const LmState* lm = nullptr);
 void launch_weight_sums(hipStream_t st, RowView r, double* sums9 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels */,
                         double* scratch);
 

@@ -95,10 +95,6 @@ struct i3d_context {
     i3d::DevBuf<unsigned short> tp_hp_off, tp_hp_src; bool halo_pull = false;      // halo pull lists of the plan (tile_pass.hip k_tile_pull_plan): I3D_HALO_PULL=1 and the bit-reproducible mode
     bool ladder_lists = false;      // the lists are built for the multi-system operator pass of the ladder (tile_pass_mr.hip) although the single-system pass pushes its halo
     // ---- the damping ladder (solver.cpp lm_solve / pcg_solve_ladder): per-system slabs of the PCG vectors and partial sums ----
-    // candidate cost through shared (voxel, keyframe) image samples (build.hip k_sample_plan / k_cost_sample / k_cost_rows): planned per outer iteration
-    i3d::DevBuf<unsigned short> cs_samp_f, cs_row_slots; i3d::DevBuf<uint8_t> cs_samp_n; i3d::DevBuf<double> cs_L; i3d::DevBuf<int> cs_overflow;
-    bool cost_plan_ok = false;      // the plan of this outer iteration fits (no entry needs more than CS_SLOTS samples): eval_cost_launch goes through it
-    i3d::CostPlan cost_plan() const { return i3d::CostPlan{cs_samp_f.p, cs_samp_n.p, cs_row_slots.p, cs_L.p, cs_overflow.p}; }
     bool mr1_serial = false;        // I3D_EGT_MR1=1: the serial loop's operator pass is k_eg_tile_mr<1> (A/B runs, the control of the ladder tests)
     int ladder_max = 1;             // I3D_LADDER (read at every assemble): attempts solved together, 1 = the serial loop
     int ladder_hint = 0, ladder_hint_prev = 0;      // LM attempts of the last two outer iterations (the first batch speculates as deep as the larger)

@@ -296,23 +296,12 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     CTX_HIP(c, hipEventRecord(c->ev_asm[1], s));
     { TimedScope t(c, I3D_K_BUILD); launch_build(s, g, r, p, c->d_frames.p, true, nullptr, c->d_partials.p); }
     { TimedScope t(c, I3D_K_CLASSIFY); launch_group_rows(s, c->A, c->nrows.p, c->gmax.p); }
-    // the (voxel, keyframe) image samples the rows of this iteration share (build.hip): the six to seven candidate costs of the trust-region loop go through them
-    bool cost_shared = !sharded(c);
-    { const char* e = std::getenv("I3D_COST_SHARED"); if (e && e[0] == '0') cost_shared = false; }
-    c->cost_plan_ok = false;
-    if (cost_shared) {
-        const size_t Acap = (size_t)c->Acap;
-        CTX_HIP(c, c->cs_samp_f.alloc(Acap * CS_SLOTS)); CTX_HIP(c, c->cs_samp_n.alloc(Acap)); CTX_HIP(c, c->cs_row_slots.alloc(Acap * (size_t)slots)); CTX_HIP(c, c->cs_L.alloc(Acap * CS_SLOTS));
-        CTX_HIP(c, c->cs_overflow.alloc(1));
-        TimedScope t(c, I3D_K_CLASSIFY); launch_sample_plan(s, r, c->cost_plan());
-    }
     { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan(), sharded(c) ? c->cflag.p : nullptr); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
     { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, c->d_scal.p, c->d_partials.p); }
     { int rc = allreduce(c, c->d_scal.p, 9); if (rc) return rc; }
-    int tp_over = 1, cs_over = 1;
+    int tp_over = 1;
     CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    if (cost_shared) CTX_HIP(c, hipMemcpyAsync(&cs_over, c->cs_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
     double sums[9]; { int rc = read_doubles(c, c->d_scal.p, 9, sums); if (rc) return rc; }
     if (sharded(c) && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "assemble: a peer-to-peer exchange timed out (a rank stopped taking part)");
     if (!sharded(c) && tp_over != 0) {
@@ -325,8 +314,6 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
         CTX_HIP(c, sync_stream(c));
     }
-    c->cost_plan_ok = cost_shared && cs_over == 0;      // an entry with more than CS_SLOTS distinct keyframes around it: the row-wise cost kernel for this iteration
-    if (cost_shared && !c->cost_plan_ok) { static bool said = false; if (!said) { said = true; std::fprintf(stderr, "[i3d] candidate cost: a voxel is sampled in more than %d keyframes, using the row-wise kernel\n", CS_SLOTS); } }
     c->tile_ok = tp_over == 0;       // a halo that does not fit (pathological grids) -> the untiled operator pass (single rank only)
     if (!sharded(c) && !c->tile_ok) std::fprintf(stderr, "[i3d] operator pass: a tile's halo does not fit, using the untiled pass (k_eg_jtjp + k_gather)\n");
     if (sharded(c) && !c->tile_ok) return ctx_fail(c, I3D_ERR_CAPACITY, "sharded optimize: the tile plan overflowed after it had been accepted");      // (cannot happen: agreed on above)
@@ -395,9 +382,7 @@ static int eval_cost_launch(i3d_context* c, const OptParams& p, bool candidate, 
     GridView g = c->grid_view();
     if (candidate) { g.x_sdf = c->xc_sdf.p; g.x_alb = c->xc_alb.p; }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 16, 0, sizeof(double), c->stream));
-    { TimedScope t(c, I3D_K_COST);
-      if (c->cost_plan_ok) launch_cost_shared(c->stream, g, c->row_view(), p, frames, c->cost_plan(), c->d_scal.p + 16, c->d_partials.p, cam9, lm);
-      else launch_build(c->stream, g, c->row_view(), p, frames, false, c->d_scal.p + 16, c->d_partials.p, cam9, lm); }
+    { TimedScope t(c, I3D_K_COST); launch_build(c->stream, g, c->row_view(), p, frames, false, c->d_scal.p + 16, c->d_partials.p, cam9, lm); }
     return allreduce(c, c->d_scal.p + 16, 1);
 }
 static int eval_cost(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames, double* cost) {

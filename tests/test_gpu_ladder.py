@@ -144,15 +144,3 @@ def test_an_invalid_step_puts_the_batch_out_of_step_and_it_is_solved_again(slice
     lad = _run(slice_setup, iterations=2)
     _same(serial, lad)
     assert lad[4]["resyncs"] >= 1, lad[4]
-
-
-def test_shared_sample_cost_is_the_row_wise_cost_bit_for_bit(slice_setup, monkeypatch):
-    """The candidate cost through shared (voxel, keyframe) image samples (build.hip: k_sample_plan / k_cost_sample / k_cost_rows, the default) against the row-wise
-    kernel of round 4 (k_build<false>, I3D_COST_SHARED=0): the same samples by the same functions, the same residuals added in the same order — initial and final
-    costs, the accept / reject sequence, the radius after every attempt (rho = cost change / model change feeds it) and every field must be equal bit for bit."""
-    monkeypatch.setenv("I3D_DETERMINISTIC", "1"); monkeypatch.setenv("I3D_LADDER", "6")
-    monkeypatch.setenv("I3D_COST_SHARED", "0")
-    row_wise = _run(slice_setup)
-    monkeypatch.setenv("I3D_COST_SHARED", "1")
-    shared = _run(slice_setup)
-    _same(row_wise, shared)
