@@ -195,3 +195,39 @@ def test_config_c5_full_joint_refinement_with_free_camera(oracle, tmp_path, caps
               f"pose update {np.abs(r['poses'] - r['poses0']).max():.3e}")
     assert d_intr <= max(1e-4, helpers.ENVELOPE_FACTOR * spread_i), (d_intr, spread_i)
     assert d_pose <= max(1e-4 * max(1.0, float(np.abs(r["oposes"]).max())), helpers.ENVELOPE_FACTOR * spread_p), (d_pose, spread_p)
+
+
+def test_free_camera_schedule_in_the_default_mode_against_the_bit_reproducible_one(tmp_path, monkeypatch):
+    """The C5 schedule (every group free, 3 grid levels x (3, 1, 1) pyramid levels, dataset folder) in the DEFAULT mode — fp32 LDS atomics inside k_eg_tile, which
+    the lone systems of the damping ladder still go through — against the same schedule in the bit-reproducible mode, which the test above compares with the
+    oracle.  The two differ by summation-order noise only; on this gauge-free problem the schedule amplifies it (two default-mode runs of round 4 ended 1e-4 apart
+    in the intrinsics), so the tolerances are explicit and an order of magnitude above that: intrinsics 1e-3 relative, poses 1e-3, the 99.9 % quantile of the fields
+    1e-3 of their maximum, and at most 2e-3 of the voxels kept on one side only (advisor finding of round 4: no free-camera schedule test covered the default mode)."""
+    from intrinsic3d_amd import binding as B, synthetic
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_dataset
+    levels = 3
+    sc = synthetic.make_scene(radius_vox=10, K=6, width=192, height=144, levels=1, seed=35, pose_noise=(0.002, 0.0035), lum_noise=0.003, cam_dist=0.2)
+    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=3, rgbd_levels=levels, iterations=3, fix_poses=0, fix_distortion=0, subvolume_size_sh=0.03)
+    sensor = B.Sensor(tmp_path / "rgbd", 0, 0.1, 10.0)
+    _, _, is_kf = B.keyframes_load(str(tmp_path / "fusion" / "keyframes.txt"))
+    rc, oc = B.load_yaml_config(i_yml)
+    vol = B.tsdf_read(str(tmp_path / "fusion" / f"volume_{float(sc['voxel_size']):g}.tsdf"))
+
+    def run():
+        with B.Context(0) as ctx:
+            ctx.set_grid_from_tsdf_records(vol["voxel_size"], vol["keys"], vol["sdf"], vol["weight"], vol["color"])
+            B.init_frames_from_sensor(ctx, sensor, is_kf, levels)
+            ctx.refine(rc, oc)
+            return ctx.export_grid(), ctx.get_camera()
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1")
+    det, (di, dd, dp) = run()
+    monkeypatch.delenv("I3D_DETERMINISTIC")
+    dflt, (fi, fd, fp) = run()
+    a, b = helpers.align_by_key(dflt, det, max_frac=2e-3, ordered=False)
+    e_sdf = np.abs(a["sdf_refined"] - b["sdf_refined"]) / np.abs(b["sdf_refined"]).max(); e_alb = np.abs(a["albedo"] - b["albedo"]) / np.abs(b["albedo"]).max()
+    d_intr = float(np.abs(fi - di).max() / np.abs(di).max()); d_pose = float(np.abs(fp - dp).max())
+    print(f"\n[C5, default vs bit-reproducible mode] sdf: 99.9 % {np.quantile(e_sdf, 0.999):.2e}, max {e_sdf.max():.2e}; albedo: 99.9 % {np.quantile(e_alb, 0.999):.2e}, max {e_alb.max():.2e}; "
+          f"intrinsics {d_intr:.2e} relative, poses {d_pose:.2e}; voxels {len(dflt['keys'])} / {len(det['keys'])}")
+    assert np.quantile(e_sdf, 0.999) <= 1e-3 and np.quantile(e_alb, 0.999) <= 1e-3
+    assert d_intr <= 1e-3 and d_pose <= 1e-3
