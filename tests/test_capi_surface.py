@@ -92,15 +92,17 @@ def test_committed_counter_files_attach_to_the_bench_line():
     import json
     sys.path.insert(0, ROOT)
     import bench
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
     assert d["kernel_tag"] == bench.KERNEL_TAG
     rows, active = d["config"]["rows"]["Eg"], d["config"]["active_voxels"]
-    for kernel in ("eg_pass", "build"):
+    for kernel in ("eg_mr2", "eg_mr3", "build"):
         t = bench.pmc_traffic(kernel, rows, active)
-        assert t is not None and t[0] > 1e9 and t[1].startswith("r04_"), kernel
+        assert t is not None and t[0] > 1e9 and t[1].startswith("r05_"), kernel
         s = bench.sq_valu(kernel, rows)
-        assert s is not None and s["valu"] > 1e7 and s["source"].startswith("r04_"), kernel
-    assert abs(bench.pmc_traffic("eg_pass", rows, active)[0] / (4.0 * (29 * rows + 7 * d["config"]["rows"]["Er"] + d["config"]["rows"]["Es"] + 2 * d["config"]["rows"]["Ea"])) - 1.09) < 0.03
+        assert s is not None and s["valu"] > 1e7 and s["source"].startswith("r05_"), kernel
+    strict = 4.0 * (29 * rows + 7 * d["config"]["rows"]["Er"] + d["config"]["rows"]["Es"] + 2 * d["config"]["rows"]["Ea"])
+    # one stream of the rows serves two / three systems: the measured bytes stay within ~1.2x of ONE system's strict bytes
+    assert 1.05 < bench.pmc_traffic("eg_mr2", rows, active)[0] / strict < 1.25 and 1.05 < bench.pmc_traffic("eg_mr3", rows, active)[0] / strict < 1.30
 
 
 def test_cpu_baseline_leg_times_the_collection_single_threaded_and_threaded():
