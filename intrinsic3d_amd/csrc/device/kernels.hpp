@@ -57,6 +57,14 @@ struct PassBuffers {
     double* blocks;      // COLNORM only: [21K + 10 + 15] upper triangles of the pose/intr/dist J^T W J blocks
     float* part; int part_stride;      // GRAD / COLNORM: one float row of camera totals per workgroup (summed in a fixed order by launch_sum_rows: no global atomics)
 };
+// gradient + column norms from one row stream (gradcol.hip): the staging planes and camera rows of BOTH passes
+struct GradColBuffers {
+    float* Cg; float* Cc;           // [14][Acap] column sums: J^T W r | diag(J^T W J)
+    float* tregg; float* tregc;     // [8][Acap] regulariser terms of the two
+    float* part; int part_stride;   // per workgroup: gradient row [6K | 9] at part, column-norm row [21K | 34] at part + col_off
+    int col_off;
+};
+int  launch_eg_gradcol(hipStream_t st, GridView g, RowView r, OptParams p, GradColBuffers b);      // returns the rows written to b.part
 int  launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u /*[NP] or null*/, PassBuffers b, const PcgState* state);   // returns the rows written to b.part
 void launch_sum_rows(hipStream_t st, PassMode mode, int K, const float* part, int nrows, int stride, double* shared, double* blocks);
 void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, float* out /*[2A]*/);

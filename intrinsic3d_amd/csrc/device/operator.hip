@@ -257,12 +257,20 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
 
 // shared / blocks <- the workgroups' rows of a k_eg_pass launch (or of k_eg_tile's cam_part), added in workgroup order (fp64).  mode: PASS_COLNORM distributes the
 // upper triangles into `blocks` and their diagonals into `shared`; otherwise the row is the camera block itself.
+// 256 threads = 32 columns x 8 row groups: a thread adds every 8th row of its column (fp64), the 8 group sums are added in group order — a fixed association, and
+// 8 independent chains per column instead of one serial walk over up to 512 rows.
 __global__ void __launch_bounds__(256) k_sum_rows(int mode, int K, const float* __restrict__ part, int nrows, int stride, double* __restrict__ shared, double* __restrict__ blocks) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double grp[8][33];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
     const int ncol = mode == PASS_COLNORM ? 21 * K + 34 : 6 * K + 9;
-    if (i >= ncol) return;
     double v = 0.0;
-    for (int w = 0; w < nrows; ++w) v += (double)part[(size_t)w * stride + i];
+    if (i < ncol) for (int w = rg; w < nrows; w += 8) v += (double)part[(size_t)w * stride + i];
+    grp[rg][col] = v;
+    __syncthreads();
+    if (rg != 0 || i >= ncol) return;
+    v = grp[0][col];
+    for (int q = 1; q < 8; ++q) v += grp[q][col];
     if (mode != PASS_COLNORM) { shared[i] = v; return; }
     if (i < 21 * K) {
         blocks[i] = v;
@@ -273,7 +281,7 @@ __global__ void __launch_bounds__(256) k_sum_rows(int mode, int K, const float* 
 }
 void launch_sum_rows(hipStream_t st, PassMode mode, int K, const float* part, int nrows, int stride, double* shared, double* blocks) {
     const int ncol = mode == PASS_COLNORM ? 21 * K + 34 : 6 * K + 9;
-    k_sum_rows<<<(ncol + 255) / 256, 256, 0, st>>>((int)mode, K, part, nrows, stride, shared, blocks);
+    k_sum_rows<<<(ncol + 31) / 32, 256, 0, st>>>((int)mode, K, part, nrows, stride, shared, blocks);
 }
 
 // ---- the PCG operator pass: k_eg_pass<PASS_JTJP> specialised for memory-level parallelism --------------------------------------

@@ -38,6 +38,9 @@ static double varying_lambda(int it, int n, double l0, double l1) {        // co
 constexpr int HALO_CAP = 1 << 20;      // (direction, peer, entry) items of a rank's halo plan
 constexpr int AUX_PART_ROWS = 320;     // >= the workgroups of a gradient / column-norm pass (one per CU)
 static size_t aux_part_stride(int K) { return ((size_t)21 * K + 34 + 3) & ~(size_t)3; }
+constexpr int GC_PART_ROWS = 1024;     // >= the workgroups of the one-stream gradient + column-norm pass (two per CU)
+static size_t gc_col_off(int K) { return ((size_t)6 * K + 9 + 3) & ~(size_t)3; }
+static size_t gc_part_stride(int K) { return gc_col_off(K) + aux_part_stride(K); }
 constexpr int PCG_SEQ_STRIDE = 1024;   // pass numbers a PCG solve may use (<= 521 passes): the numbering of the next solve does not depend on how many passes a host queued
 constexpr int LM_REC_SLOTS = 64;       // LmRecord ring: the initial tests + one record per LM attempt (lm_steps <= LM_REC_SLOTS - 2)
 
@@ -54,6 +57,7 @@ static int alloc_rows(i3d_context* c, int slots) {
     CTX_HIP(c, c->cull_bounds.alloc(Acap / 64 + 2)); CTX_HIP(c, c->cull_mask.alloc((Acap / 64 + 2) * (size_t)((c->K + 31) / 32)));
     CTX_HIP(c, c->regflags.alloc(Acap)); CTX_HIP(c, c->ea_free.alloc(Acap)); CTX_HIP(c, c->ea_w.alloc(Acap * 6));
     CTX_HIP(c, c->C.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg.alloc(Acap * 8)); CTX_HIP(c, c->aux_part.alloc((size_t)AUX_PART_ROWS * aux_part_stride(c->K)));
+    CTX_HIP(c, c->C2.alloc(Acap * P_VOX)); CTX_HIP(c, c->treg2.alloc(Acap * 8)); CTX_HIP(c, c->gc_part.alloc((size_t)GC_PART_ROWS * gc_part_stride(c->K)));
     { // sized for BOTH tile geometries: the 512-entry one needs the most slots on large grids (3 per entry; 1024: 2), but a grid of <= 512 entries is ONE
       // 1024-entry tile with 2048 halo slots against one 512-entry tile with 1536
       const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512);
@@ -355,6 +359,31 @@ static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const flo
     { int rc = allreduce(c, c->d_shared.p, (size_t)L.NS); if (rc) return rc; }
     if (mode == PASS_COLNORM) { int rc = allreduce(c, c->d_blocks.p, 21 * (size_t)c->K + 25); if (rc) return rc; }
     { TimedScope t(c, I3D_K_VECTOR); launch_shared_finalize(s, L.tail_off, c->K, p, c->d_shared.p, out, false, nullptr, nullptr, nullptr, nullptr, nullptr); }
+    return I3D_OK;
+}
+
+// Column norms -> c->v_c (+ d_shared / d_blocks: the camera part and the camera blocks) and the raw gradient J^T W r -> c->v_acc from ONE stream of the rows
+// (gradcol.hip).  One rank only (a sharded run keeps the two passes: their all-reduces sit between the launches).  `between` runs after the column norms are
+// complete and before d_shared is reused for the gradient's camera part.
+template <class F> static int run_gradcol(i3d_context* c, const OptParams& p, F between) {
+    hipStream_t s = c->stream; GridView g = c->grid_view(); RowView r = c->row_view(); const Layout L = layout_of(c);
+    const int stride = (int)gc_part_stride(c->K), col_off = (int)gc_col_off(c->K);
+    GradColBuffers gb{c->C.p, c->C2.p, c->treg.p, c->treg2.p, c->gc_part.p, stride, col_off};
+    CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
+    CTX_HIP(c, hipMemsetAsync(c->d_blocks.p, 0, sizeof(double) * (21 * (size_t)c->K + 25), s));
+    int rows = 0;
+    { TimedScope t(c, I3D_K_EG_AUX); rows = launch_eg_gradcol(s, g, r, p, gb);
+      if (rows > GC_PART_ROWS) return ctx_fail(c, I3D_ERR_CAPACITY, "run_gradcol: more workgroups than rows of the camera partial buffer");
+      if (rows > 0) launch_sum_rows(s, PASS_COLNORM, c->K, c->gc_part.p + col_off, rows, stride, c->d_shared.p, c->d_blocks.p); }
+    { PassBuffers b{c->C2.p, c->treg2.p, c->d_shared.p, c->d_blocks.p, nullptr, 0};
+      TimedScope t(c, I3D_K_GATHER); launch_gather(s, PASS_COLNORM, r, b, c->v_c.p); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_shared_finalize(s, L.tail_off, c->K, p, c->d_shared.p, c->v_c.p, false, nullptr, nullptr, nullptr, nullptr, nullptr); }
+    { int rc = between(); if (rc) return rc; }
+    CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
+    { TimedScope t(c, I3D_K_EG_AUX); if (rows > 0) launch_sum_rows(s, PASS_GRAD, c->K, c->gc_part.p, rows, stride, c->d_shared.p, c->d_blocks.p); }
+    { PassBuffers b{c->C.p, c->treg.p, c->d_shared.p, c->d_blocks.p, nullptr, 0};
+      TimedScope t(c, I3D_K_GATHER); launch_gather(s, PASS_GRAD, r, b, c->v_acc.p); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_shared_finalize(s, L.tail_off, c->K, p, c->d_shared.p, c->v_acc.p, false, nullptr, nullptr, nullptr, nullptr, nullptr); }
     return I3D_OK;
 }
 
@@ -741,13 +770,23 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     CTX_HIP(c, hipMemcpyAsync(c->xc_sdf.p, c->x_sdf.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, s));
     CTX_HIP(c, hipMemcpyAsync(c->xc_alb.p, c->x_alb.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, s));
     // column norms -> Jacobi scaling (computed once, TrustRegionMinimizer::Init); the camera blocks stay on the device for k_lm_begin
-    int rc = run_pass(c, PASS_COLNORM, p, nullptr, c->v_c.p); if (rc) return rc;
-    CTX_HIP(c, hipMemcpyAsync(c->d_cam_c.p, c->d_shared.p, sizeof(double) * (size_t)NS, hipMemcpyDeviceToDevice, s));
-    CTX_HIP(c, hipMemcpyAsync(c->d_cam_H.p, c->d_blocks.p, sizeof(double) * ((size_t)21 * K + 25), hipMemcpyDeviceToDevice, s));
-    { int rc2 = allgather(c, c->v_c.p); if (rc2) return rc2; }     // the candidate point needs S everywhere
-    { TimedScope t(c, I3D_K_VECTOR); launch_scale_from_colnorm(s, NP, c->v_c.p, c->v_mask.p, c->v_S.p, c->v_cm.p); }
-    // gradient b = S J^T W r and initial cost
-    rc = run_pass(c, PASS_GRAD, p, nullptr, c->v_acc.p); if (rc) return rc;
+    // (one stream of the rows serves both on one rank: gradcol.hip; I3D_GRADCOL=0 keeps the two passes)
+    const bool one_stream = !sharded(c) && !([] { const char* e = std::getenv("I3D_GRADCOL"); return e && e[0] == '0'; }());
+    auto after_colnorm = [&]() -> int {
+        CTX_HIP(c, hipMemcpyAsync(c->d_cam_c.p, c->d_shared.p, sizeof(double) * (size_t)NS, hipMemcpyDeviceToDevice, s));
+        CTX_HIP(c, hipMemcpyAsync(c->d_cam_H.p, c->d_blocks.p, sizeof(double) * ((size_t)21 * K + 25), hipMemcpyDeviceToDevice, s));
+        { int rc2 = allgather(c, c->v_c.p); if (rc2) return rc2; }     // the candidate point needs S everywhere
+        { TimedScope t(c, I3D_K_VECTOR); launch_scale_from_colnorm(s, NP, c->v_c.p, c->v_mask.p, c->v_S.p, c->v_cm.p); }
+        return I3D_OK;
+    };
+    int rc = I3D_OK;
+    if (one_stream) { rc = run_gradcol(c, p, after_colnorm); if (rc) return rc; }
+    else {
+        rc = run_pass(c, PASS_COLNORM, p, nullptr, c->v_c.p); if (rc) return rc;
+        rc = after_colnorm(); if (rc) return rc;
+        // gradient b = S J^T W r and initial cost
+        rc = run_pass(c, PASS_GRAD, p, nullptr, c->v_acc.p); if (rc) return rc;
+    }
     { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, NP, c->v_S.p, c->v_acc.p, c->v_b.p); }
     rc = eval_cost_launch(c, p, false, c->d_frames.p); if (rc) return rc;                    // -> d_scal[16]
     rc = count_above_dev(c, c->v_acc.p, c->v_mask.p, 1e-10f, c->d_scal.p + 8); if (rc) return rc;   // gradient_tolerance: free entries of g = J^T W r above 1e-10 (max-norm test)
