@@ -552,29 +552,60 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
     if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr);      // cost_dst += sum
 }
 
-// nls_solver.cpp:379-394 — per-type sums of the row weights (sums[0..3]) and row counts (sums[4..7])
-__global__ void __launch_bounds__(256) k_weight_sums(RowView r, double* partials) {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, n0 = 0, n3 = 0, na = 0;
+// nls_solver.cpp:379-394 — per-type sums of the row weights (sums[0..3]) and row counts (sums[4..7]); [8] active voxels.
+// [9..12]: sum of w r^2 per row type at the state the rows were built at, over the rows of the reduced program (at least one free parameter) — the cost the trust-region
+// loop starts from is 0.5 sum_t type_w[t] sums[9 + t] (the type weights are only known once sums[0..3] are: nls_solver.cpp:379-394), which saves the residual-only pass
+// k_build<false> at the unchanged point.  Eg residuals are the stored ones (row_wr.y, fp32-rounded: 2e-11 of the cost on 1e7 rows); the regulariser residuals are
+// recomputed in fp64 exactly as k_build<false> does.
+__global__ void __launch_bounds__(256) k_weight_sums(RowView r, GridView g, double* partials) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, n0 = 0, n3 = 0, na = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    const int N = g.N;
     for (int a = r.own0 + blockIdx.x * blockDim.x + threadIdx.x; a < r.own1 && a < r.A; a += gridDim.x * blockDim.x) {      // owned range only
         if (!(r.aflags[a] & F_ACTIVE)) continue;
         na += 1.0;
         const int nr = r.nrows[a];
-        for (int k = 0; k < nr; ++k) { const float w = r.row_wr[row_scalar_index(a, k, r.slots)].x; s0 += (double)w; if (w != 0.0f) n0 += 1.0; }
+        for (int k = 0; k < nr; ++k) {
+            const float2 wr = r.row_wr[row_scalar_index(a, k, r.slots)]; const float w = wr.x;
+            s0 += (double)w; if (w != 0.0f) n0 += 1.0;
+            if (__float_as_int(r.row_jt()[row_jt_index(a, k, r.slots)].y) & ROW_FREE_BIT) c0 += (double)w * ((double)wr.y * (double)wr.y);
+        }
         const uint8_t rf = r.regflags[a];
         if (rf & 1) s1 += 1.0;
         if (rf & 2) s2 += 1.0;
-        for (int d = 0; d < 6; ++d) { const float w = r.ea_w[(size_t)d * r.Acap + a]; s3 += (double)w; if (w != 0.0f) n3 += 1.0; }
+        const int s = r.alist[a];
+        const uint8_t eafree = r.ea_free[a];
+        const bool er = (rf & 1) && (rf & 8), es = (rf & 2) && (rf & 16);
+        int ring[6];
+        if (er || eafree) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) ring[d] = g.nbr[(size_t)d * N + s];
+        }
+        if (er || es) {
+            const double xs = g.x_sdf[s];
+            if (er) {
+                const double dxx = g.x_sdf[ring[0]] + g.x_sdf[ring[1]] - 2.0 * xs, dyy = g.x_sdf[ring[2]] + g.x_sdf[ring[3]] - 2.0 * xs, dzz = g.x_sdf[ring[4]] + g.x_sdf[ring[5]] - 2.0 * xs;
+                const double lap = dxx + dyy + dzz; c1 += lap * lap;
+            }
+            if (es) { double e = xs - g.sdf0[s]; if (e == 0.0) e = 0.0000001; c2 += e * e; }      // surface_stab_regularizer.h:62-64
+        }
+        const double xa = eafree ? g.x_alb[s] : 0.0;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            const float w = r.ea_w[(size_t)d * r.Acap + a]; s3 += (double)w; if (w != 0.0f) n3 += 1.0;
+            if (eafree & (1 << d)) { const double e = xa - g.x_alb[ring[d]]; c3 += (double)w * (e * e); }
+        }
     }
-    block_partial_d(s0, partials, 9, 0); block_partial_d(s1, partials, 9, 1); block_partial_d(s2, partials, 9, 2); block_partial_d(s3, partials, 9, 3);
-    block_partial_d(n0, partials, 9, 4); block_partial_d(0.0, partials, 9, 5); block_partial_d(0.0, partials, 9, 6); block_partial_d(n3, partials, 9, 7);
-    block_partial_d(na, partials, 9, 8);
+    block_partial_d(s0, partials, 13, 0); block_partial_d(s1, partials, 13, 1); block_partial_d(s2, partials, 13, 2); block_partial_d(s3, partials, 13, 3);
+    block_partial_d(n0, partials, 13, 4); block_partial_d(0.0, partials, 13, 5); block_partial_d(0.0, partials, 13, 6); block_partial_d(n3, partials, 13, 7);
+    block_partial_d(na, partials, 13, 8);
+    block_partial_d(c0, partials, 13, 9); block_partial_d(c1, partials, 13, 10); block_partial_d(c2, partials, 13, 11); block_partial_d(c3, partials, 13, 12);
 }
-void launch_weight_sums(hipStream_t st, RowView r, double* sums9, double* scratch) {
+void launch_weight_sums(hipStream_t st, RowView r, GridView g, double* sums13, double* scratch) {
     const int n = r.own1 - r.own0;
     if (n <= 0) return;
     int blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
-    k_weight_sums<<<blocks, 256, 0, st>>>(r, scratch);
-    launch_reduce_partials(st, scratch, blocks, 9, sums9, nullptr);
+    k_weight_sums<<<blocks, 256, 0, st>>>(r, g, scratch);
+    launch_reduce_partials(st, scratch, blocks, 13, sums13, nullptr);
 }
 
 }  // namespace i3d

@@ -42,8 +42,8 @@ void launch_group_cull(hipStream_t st, GridView g, RowView r, OptParams p, const
 // camera of an LM attempt never visits the host (lm_kernels.hip).  lm (or null): skip the launch's work when the solve is already over.
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out /* accumulated */, double* scratch,
                   const double* cam9 = nullptr, const LmState* lm = nullptr);
-void launch_weight_sums(hipStream_t st, RowView r, double* sums9 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels */,
-                        double* scratch);
+void launch_weight_sums(hipStream_t st, RowView r, GridView g, double* sums13 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels,
+                        [9..12] sum of w r^2 per row type over the rows with a free parameter */, double* scratch);
 
 // ---- operator.hip -----------------------------------------------------------------------------------------
 // All vectors are in work-list space: NP = 2A + 6K + 9.
@@ -204,6 +204,7 @@ void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, 
                       double* xc_shared, double* norms2 /* [0] += |delta|^2, [1] += |x|^2 over free */, const float* mask, double* scratch, const LmState* lm = nullptr);
 void launch_accept(hipStream_t st, GridView g, RowView r, const double* xc_sdf, const double* xc_alb, const LmState* lm = nullptr);           // x <- candidate, refresh fp32 shadows (lm: only if it accepted)
 // ---- lm_kernels.hip: the trust-region loop on the device -------------------------------------------------------------------------
+void launch_set_double(hipStream_t st, double* dst, double v);
 void launch_lm_init(hipStream_t st, LmState* lm, const double* cost, const double* ngrad, const double* nfree, double radius0, LmRecord* rec, int seq);
 void launch_lm_begin(hipStream_t st, LmState* lm, int K, int fix_poses, int fix_intr, int fix_dist, const double* cdiag, const double* tri, float* Mblk,
                      const float* tc, const float* tS, float* tD2, float* tMinv, LmRecord* rec, int seq);

@@ -31,6 +31,8 @@ __global__ void k_lm_init(LmState* lm, const double* __restrict__ cost, const do
         lm_publish(rec, seq);
     }
 }
+__global__ void k_set_double(double* dst, double v) { *dst = v; }
+void launch_set_double(hipStream_t st, double* dst, double v) { k_set_double<<<1, 1, 0, st>>>(dst, v); }
 void launch_lm_init(hipStream_t st, LmState* lm, const double* cost, const double* ngrad, const double* nfree, double radius0, LmRecord* rec, int seq) {
     k_lm_init<<<1, 1, 0, st>>>(lm, cost, ngrad, nfree, radius0, rec, seq);
 }

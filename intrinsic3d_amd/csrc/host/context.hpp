@@ -89,6 +89,7 @@ struct i3d_context {
     // keyframe masks of the 64-entry groups of the compute list
     i3d::DevBuf<float2> cull_blocks; i3d::DevBuf<float4> cull_bounds; i3d::DevBuf<unsigned> cull_mask; int cull_level = -1; bool cull_on = false;
     // tiled operator pass (tile_pass.hip): plan of the current work list
+    double cost_at_build = 0.0;       // 0.5 sum_t type_w[t] sum(w r^2) at the point the rows were built at (assemble)
     i3d::DevBuf<float> C2, treg2, gc_part;      // the second set of staging planes + the camera rows of the one-stream gradient / column-norm pass (gradcol.hip)
     i3d::DevBuf<float> aux_part;      // one float row of camera totals per workgroup of the gradient / column-norm passes (summed in a fixed order)
     i3d::DevBuf<unsigned> tp_lnbr; i3d::DevBuf<int> tp_halo_idx, tp_halo_cnt, tp_iota, tp_ext_e, tp_ext_pos, tp_ext_off, tp_overflow; i3d::DevBuf<float> tp_qh, tp_eaw, cam_part;

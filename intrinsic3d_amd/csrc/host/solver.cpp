@@ -302,11 +302,11 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     { TimedScope t(c, I3D_K_CLASSIFY); launch_group_rows(s, c->A, c->nrows.p, c->gmax.p); }
     { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan(), sharded(c) ? c->cflag.p : nullptr); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
-    { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, c->d_scal.p, c->d_partials.p); }
-    { int rc = allreduce(c, c->d_scal.p, 9); if (rc) return rc; }
+    { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, g, c->d_scal.p, c->d_partials.p); }
+    { int rc = allreduce(c, c->d_scal.p, 13); if (rc) return rc; }
     int tp_over = 1;
     CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    double sums[9]; { int rc = read_doubles(c, c->d_scal.p, 9, sums); if (rc) return rc; }
+    double sums[13]; { int rc = read_doubles(c, c->d_scal.p, 13, sums); if (rc) return rc; }
     if (sharded(c) && c->comm->health(s)) return ctx_fail(c, I3D_ERR_COMM, "assemble: a peer-to-peer exchange timed out (a rank stopped taking part)");
     if (!sharded(c) && tp_over != 0) {
         // single rank: the other geometry before giving up on the tiled pass
@@ -327,6 +327,8 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
                               varying_lambda(iteration, cfg.iterations, cfg.lambda_s0, cfg.lambda_s1), cfg.lambda_a};
     for (int t = 0; t < 4; ++t) { p.type_w[t] = sums[t] != 0.0 ? (lambda[t] / sums[t]) * 1000.0 : 0.0; p.type_wf[t] = (float)p.type_w[t]; }     // nls_solver.cpp:379-394
     c->n_active = (long long)(sums[8] + 0.5);
+    // the cost at the point the rows were built at (k_weight_sums): what the trust-region loop starts from
+    c->cost_at_build = 0.5 * (p.type_w[0] * sums[9] + p.type_w[1] * sums[10] + p.type_w[2] * sums[11] + p.type_w[3] * sums[12]);
     if (st) { for (int t = 0; t < 4; ++t) { st->rows[t] = (int64_t)(sums[4 + t] + 0.5); st->weight_sum[t] = sums[t]; st->type_weight[t] = p.type_w[t]; } st->valid_voxels = c->n_active; }
     c->last_sizes[0] = c->n_active; for (int t = 0; t < 4; ++t) c->last_sizes[1 + t] = (long long)(sums[4 + t] + 0.5);
     c->last_params = p; c->assembled = true;
@@ -788,7 +790,9 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
         rc = run_pass(c, PASS_GRAD, p, nullptr, c->v_acc.p); if (rc) return rc;
     }
     { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, NP, c->v_S.p, c->v_acc.p, c->v_b.p); }
-    rc = eval_cost_launch(c, p, false, c->d_frames.p); if (rc) return rc;                    // -> d_scal[16]
+    // initial cost -> d_scal[16]: from the residuals the assembly already holds (I3D_COST0=0: the residual-only pass at the unchanged point, as up to round 4)
+    if ([] { const char* e = std::getenv("I3D_COST0"); return e && e[0] == '0'; }()) { rc = eval_cost_launch(c, p, false, c->d_frames.p); if (rc) return rc; }
+    else { TimedScope t(c, I3D_K_VECTOR); launch_set_double(s, c->d_scal.p + 16, c->cost_at_build); }
     rc = count_above_dev(c, c->v_acc.p, c->v_mask.p, 1e-10f, c->d_scal.p + 8); if (rc) return rc;   // gradient_tolerance: free entries of g = J^T W r above 1e-10 (max-norm test)
     rc = dot_dev(c, c->v_mask.p, c->v_mask.p, c->d_scal.p + 9); if (rc) return rc;           // free parameters
     {   // camera unknowns of the current point for the candidate kernel (staged in pinned memory: the copy is asynchronous)
