@@ -553,10 +553,11 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
 }
 
 // nls_solver.cpp:379-394 — per-type sums of the row weights (sums[0..3]) and row counts (sums[4..7]); [8] active voxels.
-// [9..12]: sum of w r^2 per row type at the state the rows were built at, over the rows of the reduced program (at least one free parameter) — the cost the trust-region
+// COST, [9..12]: sum of w r^2 per row type at the state the rows were built at, over the rows of the reduced program (at least one free parameter) — the cost the trust-region
 // loop starts from is 0.5 sum_t type_w[t] sums[9 + t] (the type weights are only known once sums[0..3] are: nls_solver.cpp:379-394), which saves the residual-only pass
-// k_build<false> at the unchanged point.  Eg residuals are the stored ones (row_wr.y, fp32-rounded: 2e-11 of the cost on 1e7 rows); the regulariser residuals are
+// k_build<false> at the unchanged point (a sharded run, and I3D_GRADCOL=0; on one rank the sums ride on the gradient pass, gradcol.hip).  Eg residuals are the stored ones (row_wr.y, fp32-rounded: 2e-11 of the cost on 1e7 rows); the regulariser residuals are
 // recomputed in fp64 exactly as k_build<false> does.
+template <bool COST>
 __global__ void __launch_bounds__(256) k_weight_sums(RowView r, GridView g, double* partials) {
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0, n0 = 0, n3 = 0, na = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     const int N = g.N;
@@ -567,14 +568,14 @@ __global__ void __launch_bounds__(256) k_weight_sums(RowView r, GridView g, doub
         for (int k = 0; k < nr; ++k) {
             const float2 wr = r.row_wr[row_scalar_index(a, k, r.slots)]; const float w = wr.x;
             s0 += (double)w; if (w != 0.0f) n0 += 1.0;
-            if (__float_as_int(r.row_jt()[row_jt_index(a, k, r.slots)].y) & ROW_FREE_BIT) c0 += (double)w * ((double)wr.y * (double)wr.y);
+            if (COST && (__float_as_int(r.row_jt()[row_jt_index(a, k, r.slots)].y) & ROW_FREE_BIT)) c0 += (double)w * ((double)wr.y * (double)wr.y);
         }
         const uint8_t rf = r.regflags[a];
         if (rf & 1) s1 += 1.0;
         if (rf & 2) s2 += 1.0;
-        const int s = r.alist[a];
-        const uint8_t eafree = r.ea_free[a];
-        const bool er = (rf & 1) && (rf & 8), es = (rf & 2) && (rf & 16);
+        const int s = COST ? r.alist[a] : 0;
+        const uint8_t eafree = COST ? r.ea_free[a] : 0;
+        const bool er = COST && (rf & 1) && (rf & 8), es = COST && (rf & 2) && (rf & 16);
         int ring[6];
         if (er || eafree) {
 #pragma unroll
@@ -600,11 +601,12 @@ __global__ void __launch_bounds__(256) k_weight_sums(RowView r, GridView g, doub
     block_partial_d(na, partials, 13, 8);
     block_partial_d(c0, partials, 13, 9); block_partial_d(c1, partials, 13, 10); block_partial_d(c2, partials, 13, 11); block_partial_d(c3, partials, 13, 12);
 }
-void launch_weight_sums(hipStream_t st, RowView r, GridView g, double* sums13, double* scratch) {
+void launch_weight_sums(hipStream_t st, RowView r, GridView g, bool with_cost, double* sums13, double* scratch) {
     const int n = r.own1 - r.own0;
     if (n <= 0) return;
     int blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
-    k_weight_sums<<<blocks, 256, 0, st>>>(r, g, scratch);
+    if (with_cost) k_weight_sums<true><<<blocks, 256, 0, st>>>(r, g, scratch);
+    else k_weight_sums<false><<<blocks, 256, 0, st>>>(r, g, scratch);
     launch_reduce_partials(st, scratch, blocks, 13, sums13, nullptr);
 }
 

@@ -9,6 +9,7 @@
 // 128 registers a 1024-thread workgroup leaves a lane.  Sums are fixed-order as in k_eg_pass (wave-private keyframe tables merged in wave order, per-wave slots
 // for the shared columns, one row per workgroup): bit-reproducible.
 #include "kernels.hpp"
+#include "reduce_device.hpp"
 #include "wave_ops.hpp"
 
 namespace i3d {
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(GC_THREADS, 3) k_eg_gradcol(GridView g, RowVie
     for (int i = 0; i < 25; ++i) camb[i] = 0.0f;
     const float tw0 = (float)p.type_w[0];
     const bool free_poses = !p.fix_poses;
+    double cost = 0.0;                    // 0.5 sum w r^2 over the rows of the reduced program (what k_build<false> returns at this point), on the rows' owner
     const int nC = r.nC;
     const int ntiles = (nC + GC_THREADS - 1) / GC_THREADS;
     const int tile0 = blockIdx.x * tiles_per_block;
@@ -76,6 +78,7 @@ __global__ void __launch_bounds__(GC_THREADS, 3) k_eg_gradcol(GridView g, RowVie
 #pragma unroll
                 for (int c = 0; c < P_VOX; ++c) { accg[c] += J[c] * t; accc[c] += tw0 * J[c] * J[c]; }
                 if (owned) {
+                    if (__float_as_int(jt.y) & ROW_FREE_BIT) cost += 0.5 * (double)wr.x * p.type_w[0] * ((double)wr.y * (double)wr.y);      // (the stored residual: fp32-rounded)
 #pragma unroll
                     for (int i = 0; i < 9; ++i) cam9[i] += J[P_INTR + i] * t;
                     int o = 0;
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(GC_THREADS, 3) k_eg_gradcol(GridView g, RowVie
                 }
             }
             // pose columns of this slot: 6 gradient entries + the upper triangle of the keyframe's 6 x 6 block
-            wave_table_add<GC_NPV, GC_TC>(live && owned, fsel, [&](int q) {
+            wave_table_add_quads<GC_NPV, GC_TC, 3>(live && owned, fsel, [&](int q) {
                 return q < 6 ? (free_poses ? J[P_POSE + (q < 6 ? q : 0)] * t : 0.0f) : tw0 * J[P_POSE + GC_TRI_I[q < 6 ? 0 : q - 6]] * J[P_POSE + GC_TRI_J[q < 6 ? 0 : q - 6]];
             }, lds, o_tag, o_val, tcount, GC_D0, GC_NPV);
         }
@@ -106,6 +109,7 @@ __global__ void __launch_bounds__(GC_THREADS, 3) k_eg_gradcol(GridView g, RowVie
             float trg = 0.0f, tsg = 0.0f, trc = 0.0f, tsc = 0.0f;
             const int s = r.alist[a];
             const int N = g.N;
+            const uint8_t eafree = (owned && (fl & F_ACTIVE)) ? r.ea_free[a] : 0;
             if (rf & 1) {
                 const float rho = (float)p.type_w[1];
                 const double xs = g.x_sdf[s];
@@ -113,19 +117,30 @@ __global__ void __launch_bounds__(GC_THREADS, 3) k_eg_gradcol(GridView g, RowVie
 #pragma unroll
                 for (int d = 0; d < 6; ++d) nbv[d] = g.x_sdf[g.nbr[(size_t)d * N + s]];
                 const double dxx = nbv[0] + nbv[1] - 2.0 * xs, dyy = nbv[2] + nbv[3] - 2.0 * xs, dzz = nbv[4] + nbv[5] - 2.0 * xs;
-                trg = rho * (float)(dxx + dyy + dzz); trc = rho;
+                const double lap = dxx + dyy + dzz;
+                trg = rho * (float)lap; trc = rho;
+                if (owned && (rf & 8)) cost += 0.5 * p.type_w[1] * lap * lap;
             }
-            if ((rf & 2) && (rf & 4)) { const float rho = (float)p.type_w[2]; tsg = rho * (float)(g.x_sdf[s] - g.sdf0[s]); tsc = rho; }
+            if (rf & 2) {
+                const double e0 = g.x_sdf[s] - g.sdf0[s];
+                if (rf & 4) { const float rho = (float)p.type_w[2]; tsg = rho * (float)e0; tsc = rho; }
+                if (owned && (rf & 16)) { const double e = e0 == 0.0 ? 0.0000001 : e0; cost += 0.5 * p.type_w[2] * e * e; }      // surface_stab_regularizer.h:62-64
+            }
             b.tregg[a] = trg; b.tregg[Acap + a] = tsg; b.tregc[a] = trc; b.tregc[Acap + a] = tsc;
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
                 const float w = (fl & F_ACTIVE) ? r.ea_w[(size_t)d * Acap + a] : 0.0f;
                 float tag = 0.0f, tac = 0.0f;
-                if (w != 0.0f) { const float rho = w * (float)p.type_w[3]; tag = rho * (float)(g.x_alb[s] - g.x_alb[g.nbr[(size_t)d * N + s]]); tac = rho; }
+                if (w != 0.0f) {
+                    const float rho = w * (float)p.type_w[3]; const double e = g.x_alb[s] - g.x_alb[g.nbr[(size_t)d * N + s]];
+                    tag = rho * (float)e; tac = rho;
+                    if (eafree & (1 << d)) cost += 0.5 * (double)w * p.type_w[3] * e * e;
+                }
                 b.tregg[(size_t)(2 + d) * Acap + a] = tag; b.tregc[(size_t)(2 + d) * Acap + a] = tac;
             }
         }
     }
+    block_partial_d(cost, b.cost_partials, 1, 0);          // per-workgroup partial, summed by k_reduce_partials
     // columns shared by every row: wave-shuffle reduction into the wave's slot, the slots added in wave order
 #pragma unroll
     for (int i = 0; i < GC_NCAM; ++i) {
@@ -163,6 +178,7 @@ int launch_eg_gradcol(hipStream_t st, GridView g, RowView r, OptParams p, GradCo
     if (!set_dynamic_lds((const void*)k_eg_gradcol, "k_eg_gradcol", n, p.K)) return 0;
     const int used = (ntiles + tiles_per_block - 1) / tiles_per_block;    // workgroups that own a tile (the others would write zero rows)
     k_eg_gradcol<<<used, GC_THREADS, n, st>>>(g, r, p, b, tiles_per_block);
+    launch_reduce_partials(st, b.cost_partials, used, 1, b.cost_out, nullptr);      // *cost_out += sum
     return used;
 }
 

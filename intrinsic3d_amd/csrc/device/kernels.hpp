@@ -42,7 +42,7 @@ void launch_group_cull(hipStream_t st, GridView g, RowView r, OptParams p, const
 // camera of an LM attempt never visits the host (lm_kernels.hip).  lm (or null): skip the launch's work when the solve is already over.
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out /* accumulated */, double* scratch,
                   const double* cam9 = nullptr, const LmState* lm = nullptr);
-void launch_weight_sums(hipStream_t st, RowView r, GridView g, double* sums13 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels,
+void launch_weight_sums(hipStream_t st, RowView r, GridView g, bool with_cost, double* sums13 /* accumulated: [0..3] weight sums, [4] Eg rows, [7] Ea rows ([5],[6] = [1],[2]), [8] active voxels,
                         [9..12] sum of w r^2 per row type over the rows with a free parameter */, double* scratch);
 
 // ---- operator.hip -----------------------------------------------------------------------------------------
@@ -63,6 +63,7 @@ struct GradColBuffers {
     float* tregg; float* tregc;     // [8][Acap] regulariser terms of the two
     float* part; int part_stride;   // per workgroup: gradient row [6K | 9] at part, column-norm row [21K | 34] at part + col_off
     int col_off;
+    double* cost_partials; double* cost_out;      // per-workgroup partials of the cost at this point (0.5 sum w r^2 over the rows with a free parameter); *cost_out += their sum
 };
 int  launch_eg_gradcol(hipStream_t st, GridView g, RowView r, OptParams p, GradColBuffers b);      // returns the rows written to b.part
 int  launch_eg_pass(hipStream_t st, PassMode mode, GridView g, RowView r, OptParams p, const float* u /*[NP] or null*/, PassBuffers b, const PcgState* state);   // returns the rows written to b.part

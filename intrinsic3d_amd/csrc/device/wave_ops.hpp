@@ -130,6 +130,48 @@ static __device__ inline void wave_sum_quads(const float (&v)[4 * MQ], float (&o
     for (int q = 0; q < MQ; ++q) out[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out[q]), 0x140, 0xF, 0xF, true));    // row_mirror
 }
 
+// wave_table_add with the NV wave sums of a round taken together by wave_sum_quads (2.5 instructions per value instead of the 15 of wave_sum: 4 DPP adds, 4 readlanes,
+// 3 adds) and ONE exec-masked block of LDS adds: the first lane of every row of 16 adds the values it holds (value 4 q + wave_quad_value(lane) of quad q).  Same table
+// layout ([slot][NV]) and merge as wave_table_add; a different — still fixed — association of the wave sums.
+template <int NV, int QC, int Q0, class F>
+static __device__ inline void wave_table_chunks(bool mine, F& val, float* dst, int lane, int qv) {
+    constexpr int MQ = (NV + 3) / 4, NQ = (MQ - Q0) < QC ? (MQ - Q0) : QC;
+    if constexpr (NQ > 0) {
+        float v[4 * NQ], sum[NQ];
+#pragma unroll
+        for (int i = 0; i < 4 * NQ; ++i) v[i] = (4 * Q0 + i < NV && mine) ? val(4 * Q0 + (4 * Q0 + i < NV ? i : 0)) : 0.0f;
+        wave_sum_quads<NQ>(v, sum);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { if (4 * (Q0 + q) + 3 < NV || 4 * (Q0 + q) + qv < NV) lds_add(dst + 4 * (Q0 + q), sum[q]); }
+        }
+        wave_table_chunks<NV, QC, Q0 + QC>(mine, val, dst, lane, qv);
+    }
+}
+template <int NV, int TC, int QC = 4, class F>
+static __device__ inline void wave_table_add_quads(bool valid, int f, F val, float* lds, int o_tag, int o_val, int& count /* wave-uniform */, int o_dense, int dense_stride) {
+    bool pending = valid;
+    unsigned long long todo = __ballot(pending);
+    const int lane = (int)(threadIdx.x & 63u);
+    const int qv = wave_quad_value(lane);
+    while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int f0 = __builtin_amdgcn_readlane(f, leader);
+        const bool mine = pending && f == f0;
+        const int tg = __float_as_int(lds[o_tag + (lane & (TC - 1))]);                 // tags of unused slots are -1
+        const unsigned long long hit = __ballot(tg == f0);
+        int slot;
+        if (hit != 0ull) slot = (__ffsll((long long)hit) - 1) & (TC - 1);
+        else if (count < TC) { slot = count; if (lane == 0) lds[o_tag + slot] = __int_as_float(f0); count = count + 1; }
+        else slot = -1;
+        // (in chunks of QC quads: the values of a chunk are live together, 4 QC + QC registers; a value's tree does not depend on what shares its chunk)
+        float* const dst = slot >= 0 ? &lds[o_val + slot * NV + qv] : &lds[o_dense + dense_stride * f0 + qv];      // (table full, not seen on the bench scenes: the dense accumulator, order-dependent)
+        wave_table_chunks<NV, QC, 0>(mine, val, dst, lane, qv);
+        pending = pending && !mine;
+        todo = __ballot(pending);
+    }
+}
+
 // Ordered section of a workgroup: wave w enters when waves 0 .. w-1 have left (a ticket in LDS; the LDS operations of a wave are older than the ticket it wrote).
 // The ticket word must be 0 when the first wave arrives (reset it behind a barrier).
 // No fence on either side: the LDS executes the DS instructions of a compute unit in the order they were issued, so the atomics a wave issued before its ticket

@@ -107,7 +107,7 @@ struct i3d_context {
     i3d::DevBuf<i3d::PcgState> lad_st;      // [LADDER_MAX][2]
     long long lad_batches = 0, lad_streams = 0, lad_system_passes = 0, lad_resyncs = 0, lad_wasted = 0;      // counters (i3d_debug_ladder_stats)
     double t_add_end = 0.0;         // host clock at the end of the residual collection of the current outer iteration (time_add | time_build)
-    bool deterministic = false;     // I3D_DETERMINISTIC=1 (read at every assemble): bit-reproducible operator pass, ~20 % slower
+    bool deterministic = false;     // read at every assemble: bit-reproducible operator pass (default on one rank, I3D_DETERMINISTIC=0 / =1 override)
     int tile_T = 0;                 // geometry of the current plan (0 = the default, 1024); single rank: 512 when a 1024-entry tile's halo does not fit; sharded: 512 first, then 1024
     int plan_T() const { return tile_T > 0 ? tile_T : i3d::tile_plan_T(); }
     i3d::TilePlan tile_plan() const {

@@ -107,6 +107,14 @@ static Layout layout_of(const i3d_context* c) {
     return L;
 }
 static bool sharded(const i3d_context* c) { return c->comm && (c->comm->world > 1 || c->comm->force); }
+// Where the cost the trust-region loop starts from comes from (it is the cost at the point the rows were built at; up to round 4: a residual-only pass k_build<false>):
+//   one rank           : the gradient pass (gradcol.hip) adds up 0.5 w r^2 of the rows it streams anyway;
+//   sharded / I3D_GRADCOL=0 : k_weight_sums adds the per-type sums while it walks the row weights (assemble);
+//   I3D_COST0=0        : the residual-only pass.
+static bool env_off(const char* name) { const char* e = std::getenv(name); return e && e[0] == '0'; }
+static bool one_stream_gradcol(const i3d_context* c) { return !sharded(c) && !env_off("I3D_GRADCOL"); }
+static bool cost_from_sums(const i3d_context* c) { return !env_off("I3D_COST0") && !one_stream_gradcol(c); }
+
 static int allreduce(i3d_context* c, double* dev, size_t n) {
     if (!sharded(c)) return I3D_OK;
     TimedScope t(c, I3D_K_COMM);
@@ -224,7 +232,10 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
       if (!no_partition) launch_partition_blocks(s, g, c->A, c->alist.p, c->aflags.p, c->aidx.p);
       launch_anbr(s, c->N, c->A, c->Acap, c->alist.p, c->nbr.p, c->aidx.p, c->anbr.p); }
     c->tile_ok = false; c->tile_T = 0;
-    { const char* e = std::getenv("I3D_DETERMINISTIC"); c->deterministic = e && e[0] == '1'; }
+    // Bit-reproducible operator pass (fixed-order sums inside the workgroups of k_eg_tile as well): the default on one rank, where the multi-system pass is fixed-order
+    // by construction and only the lone-system passes pay for it (0.7 % of an iteration, profiles/r05_bench_deterministic.json); I3D_DETERMINISTIC=0 selects the
+    // LDS-atomic pass.  A sharded run iterates serially through k_eg_tile (5 % there): opt-in with I3D_DETERMINISTIC=1.
+    { const char* e = std::getenv("I3D_DETERMINISTIC"); c->deterministic = e ? e[0] == '1' : !sharded(c); }
     {   // the damping ladder (lm_solve): up to I3D_LADDER consecutive LM attempts solved together, one stream of the rows per group of <= 3 of them (tile_pass_mr.hip);
         // 1 = the serial trust-region loop.  Needs the single-rank tiled pass in its 512-entry geometry with pull lists and the shipped 5 observation slots.
         const char* e = std::getenv("I3D_LADDER"); const int v = e ? std::atoi(e) : LADDER_MAX;
@@ -302,7 +313,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
     { TimedScope t(c, I3D_K_CLASSIFY); launch_group_rows(s, c->A, c->nrows.p, c->gmax.p); }
     { TimedScope t(c, I3D_K_CLASSIFY); launch_eaw_sym(s, r, c->tile_plan(), sharded(c) ? c->cflag.p : nullptr); }
     CTX_HIP(c, hipMemsetAsync(c->d_scal.p, 0, sizeof(double) * 32, s));
-    { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, g, c->d_scal.p, c->d_partials.p); }
+    { TimedScope t(c, I3D_K_VECTOR); launch_weight_sums(s, r, g, cost_from_sums(c), c->d_scal.p, c->d_partials.p); }
     { int rc = allreduce(c, c->d_scal.p, 13); if (rc) return rc; }
     int tp_over = 1;
     CTX_HIP(c, hipMemcpyAsync(&tp_over, c->tp_overflow.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -370,7 +381,8 @@ static int run_pass(i3d_context* c, PassMode mode, const OptParams& p, const flo
 template <class F> static int run_gradcol(i3d_context* c, const OptParams& p, F between) {
     hipStream_t s = c->stream; GridView g = c->grid_view(); RowView r = c->row_view(); const Layout L = layout_of(c);
     const int stride = (int)gc_part_stride(c->K), col_off = (int)gc_col_off(c->K);
-    GradColBuffers gb{c->C.p, c->C2.p, c->treg.p, c->treg2.p, c->gc_part.p, stride, col_off};
+    GradColBuffers gb{c->C.p, c->C2.p, c->treg.p, c->treg2.p, c->gc_part.p, stride, col_off, c->d_partials.p, c->d_scal.p + 16};
+    CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 16, 0, sizeof(double), s));
     CTX_HIP(c, hipMemsetAsync(c->d_shared.p, 0, sizeof(double) * ((size_t)L.NS + 1), s));
     CTX_HIP(c, hipMemsetAsync(c->d_blocks.p, 0, sizeof(double) * (21 * (size_t)c->K + 25), s));
     int rows = 0;
@@ -773,7 +785,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     CTX_HIP(c, hipMemcpyAsync(c->xc_alb.p, c->x_alb.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, s));
     // column norms -> Jacobi scaling (computed once, TrustRegionMinimizer::Init); the camera blocks stay on the device for k_lm_begin
     // (one stream of the rows serves both on one rank: gradcol.hip; I3D_GRADCOL=0 keeps the two passes)
-    const bool one_stream = !sharded(c) && !([] { const char* e = std::getenv("I3D_GRADCOL"); return e && e[0] == '0'; }());
+    const bool one_stream = one_stream_gradcol(c);
     auto after_colnorm = [&]() -> int {
         CTX_HIP(c, hipMemcpyAsync(c->d_cam_c.p, c->d_shared.p, sizeof(double) * (size_t)NS, hipMemcpyDeviceToDevice, s));
         CTX_HIP(c, hipMemcpyAsync(c->d_cam_H.p, c->d_blocks.p, sizeof(double) * ((size_t)21 * K + 25), hipMemcpyDeviceToDevice, s));
@@ -791,8 +803,8 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     }
     { TimedScope t(c, I3D_K_VECTOR); launch_mul(s, NP, c->v_S.p, c->v_acc.p, c->v_b.p); }
     // initial cost -> d_scal[16]: from the residuals the assembly already holds (I3D_COST0=0: the residual-only pass at the unchanged point, as up to round 4)
-    if ([] { const char* e = std::getenv("I3D_COST0"); return e && e[0] == '0'; }()) { rc = eval_cost_launch(c, p, false, c->d_frames.p); if (rc) return rc; }
-    else { TimedScope t(c, I3D_K_VECTOR); launch_set_double(s, c->d_scal.p + 16, c->cost_at_build); }
+    if (env_off("I3D_COST0")) { rc = eval_cost_launch(c, p, false, c->d_frames.p); if (rc) return rc; }
+    else if (!one_stream) { TimedScope t(c, I3D_K_VECTOR); launch_set_double(s, c->d_scal.p + 16, c->cost_at_build); }      // (one stream: k_eg_gradcol left it there)
     rc = count_above_dev(c, c->v_acc.p, c->v_mask.p, 1e-10f, c->d_scal.p + 8); if (rc) return rc;   // gradient_tolerance: free entries of g = J^T W r above 1e-10 (max-norm test)
     rc = dot_dev(c, c->v_mask.p, c->v_mask.p, c->d_scal.p + 9); if (rc) return rc;           // free parameters
     {   // camera unknowns of the current point for the candidate kernel (staged in pinned memory: the copy is asynchronous)
