@@ -218,7 +218,7 @@ struct SimComm : Comm {
         if (use_p2p && (int)n <= p2p.L.red_cap) return p2p.allreduce(dev, n, st);
         if (hipStreamSynchronize(st) != hipSuccess) return 1;
         std::vector<double> mine(n);
-        if (hipMemcpy(mine.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        if (hipMemcpyAsync(mine.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
         { std::lock_guard<std::mutex> lk(sh->m); if (sh->sum.size() != n) sh->sum.assign(n, 0.0); }
         sh->barrier();
         // fixed rank order -> every rank sees the same bits
@@ -227,7 +227,11 @@ struct SimComm : Comm {
         sh->barrier();
         if (rank == 0) { std::lock_guard<std::mutex> lk(sh->m); std::fill(sh->sum.begin(), sh->sum.end(), 0.0); }
         sh->barrier();
-        return hipMemcpy(dev, out.data(), n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+        // (every copy of the simulation goes through the rank's OWN stream and is waited for: the library's streams are non-blocking, so a null-stream
+        //  hipMemcpy is not ordered against them, and a device-to-device hipMemcpy need not have finished when it returns — a rim or a gathered slice
+        //  could be read before it had landed: one sharded run in a few dozen ended 6e-3 off in the cost, round 5)
+        if (hipMemcpyAsync(dev, out.data(), n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+        return hipStreamSynchronize(st) == hipSuccess ? 0 : 1;
     }
     int allgather(float* dev, size_t count, hipStream_t st) override {
         if (hipStreamSynchronize(st) != hipSuccess) return 1;
@@ -235,8 +239,9 @@ struct SimComm : Comm {
         sh->barrier();
         for (int k = 0; k < world; ++k) if (k != rank) {
             const float* src = (const float*)sh->ptr[k] + (size_t)k * count;       // same device: plain device-to-device copy
-            if (hipMemcpy(dev + (size_t)k * count, src, count * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) return 1;
+            if (hipMemcpyAsync(dev + (size_t)k * count, src, count * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
         }
+        if (hipStreamSynchronize(st) != hipSuccess) return 1;      // before the peers may go on and change their slices
         sh->barrier();
         return 0;
     }
@@ -253,9 +258,10 @@ struct SimComm : Comm {
             if (k == rank || h.recv_cnt[k] == 0) continue;
             const HaloPlan* pk = sh->halo[k];
             if (pk->send_cnt[rank] != h.recv_cnt[k]) return 1;                  // the two ends of a pair disagree about their list
-            if (hipMemcpy(h.d_recv_buf + 2 * (size_t)h.recv_off[k], pk->d_send_buf + 2 * (size_t)pk->send_off[rank], sizeof(float) * 2 * (size_t)h.recv_cnt[k],
-                          hipMemcpyDeviceToDevice) != hipSuccess) return 1;
+            if (hipMemcpyAsync(h.d_recv_buf + 2 * (size_t)h.recv_off[k], pk->d_send_buf + 2 * (size_t)pk->send_off[rank], sizeof(float) * 2 * (size_t)h.recv_cnt[k],
+                               hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
         }
+        if (hipStreamSynchronize(st) != hipSuccess) return 1;      // the peers' send buffers are read: they may pack the next pass after the barrier
         sh->barrier();
         launch_halo_unpack(st, h.n_recv, h.d_recv_idx, h.d_recv_buf, h.chunk, vec);
         return 0;

@@ -70,7 +70,7 @@ static int alloc_rows(i3d_context* c, int slots) {
     const int world_a = c->comm ? c->comm->world : 1;
     const size_t NP = 2 * ((size_t)c->N + (size_t)SHARD_ALIGN * (world_a + 1)) + 6 * (size_t)c->K + 9;      // chunk = world * slice >= A, slice a multiple of SHARD_ALIGN
     for (DevBuf<float>* v : {&c->v_mask, &c->v_c, &c->v_S, &c->v_cm, &c->v_D2, &c->v_Minv, &c->v_b, &c->v_x, &c->v_r, &c->v_p, &c->v_z, &c->v_q, &c->v_u, &c->v_acc, &c->v_tmp, &c->v_qacc})
-        { const bool fresh = v->n < NP || !v->p; CTX_HIP(c, v->alloc(NP)); if (fresh) CTX_HIP(c, hipMemset(v->p, 0, sizeof(float) * v->n)); }   // padding entries stay finite
+        { const bool fresh = v->n < NP || !v->p; CTX_HIP(c, v->alloc(NP)); if (fresh) CTX_HIP(c, hipMemsetAsync(v->p, 0, sizeof(float) * v->n, c->stream)); }   // padding entries stay finite (on the library's stream: it is non-blocking, a null-stream memset is not ordered against it)
     CTX_HIP(c, c->Minv_blocks.alloc((size_t)36 * c->K + 16 + 25));
     CTX_HIP(c, c->d_shared.alloc((size_t)6 * c->K + 9 + 1)); CTX_HIP(c, c->d_blocks.alloc((size_t)21 * c->K + 25));      // +1: p.q partial rides with the camera block
     CTX_HIP(c, c->clist.alloc(Acap)); CTX_HIP(c, c->cflag.alloc(Acap)); CTX_HIP(c, c->cscan.alloc(Acap));

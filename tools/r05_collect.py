@@ -14,7 +14,7 @@ def cp(a, b):
 for a, b in (("bench_default.json", "r05_bench_default.json"), ("bench_profiled.json", "r05_bench_profiled.json"), ("kernel_stats.csv", "r05_bench_profiled_kernel_stats.csv"),
              ("kernel_avg_work_only.txt", "r05_bench_profiled_kernel_avg_work_only.txt"), ("pmc_traffic_default.json", "r05_pmc_traffic.json"), ("pmc_traffic_band2.json", "r05_band2_pmc_traffic.json"),
              ("sq_counters_default.json", "r05_sq_counters.json"), ("sq_counters_band2.json", "r05_band2_sq_counters.json"), ("bench_serial.json", "r05_bench_serial_loop.json"),
-             ("bench_deterministic.json", "r05_bench_deterministic.json"), ("timeline_idle.txt", "r05_timeline_idle.txt"), ("c4_full_parity.json", "r05_c4_full_parity.json"),
+             ("bench_deterministic.json", "r05_bench_deterministic.json"), ("bench_atomics.json", "r05_bench_lds_atomic_mode.json"), ("timeline_idle.txt", "r05_timeline_idle.txt"), ("c4_full_parity.json", "r05_c4_full_parity.json"),
              ("sh_kernels.txt", "r05_sh_kernels.txt")):
     cp(a, b)
 # MFMA evidence of the SH Gram kernel: raw counters + the derived figures
@@ -43,7 +43,10 @@ if runs:
                "runs": runs}, open(os.path.join(dst, "r05_rank_share.json"), "w"), indent=1)
     print("-> r05_rank_share.json")
 with open(os.path.join(dst, "r05_run_to_run.txt"), "w") as f:
-    for title, name in (("# default mode (fp32 LDS atomics inside k_eg_tile; k_eg_tile_mr is fixed-order)", "run_to_run_default.txt"), ("# I3D_DETERMINISTIC=1", "run_to_run_deterministic.txt")):
+    names = (("# default mode (bit-reproducible operator pass)", "run_to_run_default.txt"), ("# I3D_DETERMINISTIC=0 (fp32 LDS atomics inside k_eg_tile; k_eg_tile_mr is fixed-order)", "run_to_run_atomics.txt"))
+    if os.path.exists(os.path.join(src, "run_to_run_deterministic.txt")):      # sessions before the default changed
+        names = (("# default mode (fp32 LDS atomics inside k_eg_tile; k_eg_tile_mr is fixed-order)", "run_to_run_default.txt"), ("# I3D_DETERMINISTIC=1", "run_to_run_deterministic.txt"))
+    for title, name in names:
         p = os.path.join(src, name)
         f.write(title + "\n" + ("".join(l for l in open(p) if l.startswith("rep ") or l.startswith("max")) if os.path.exists(p) else "MISSING\n"))
 print("-> r05_run_to_run.txt")
