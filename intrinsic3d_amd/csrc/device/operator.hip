@@ -55,7 +55,7 @@ template <int MODE>
 __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, OptParams p, const float* __restrict__ u, PassBuffers b,
                                                         int reps, int tiles_per_block, const PcgState* __restrict__ state) {
     if (state && state->done) return;
-    // Fixed-order sums (round 4): the pose columns of a wave's rows go into a table private to the wave (wave_ops.hpp: wave_table_add), merged into the workgroup's
+    // Fixed-order sums (round 4): the pose columns of a wave's rows go into a table private to the wave (wave_ops.hpp: wave_table_add_quads since round 5 — the wave sums of a round taken four to a tree), merged into the workgroup's
     // dense accumulator in wave order at the end of every tile; the intrinsics / distortion sums leave through per-wave slots; the workgroup's totals leave as ONE
     // float row (b.part), summed over the workgroups in a fixed order by k_sum_rows — no LDS accumulator shared by waves, no global atomics: the gradient and the
     // column norms of an outer iteration are bit-reproducible.
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(EG_THREADS) k_eg_pass(GridView g, RowView r, O
                 }
             }
             // pose columns of this slot: every lane of the wave takes part (the loop bound nr_max is wave-uniform)
-            wave_table_add<NPV, TCT>(pvalid, fsel, [&](int q) { return pv[q]; }, lds, o_tag, o_val, tcount, D0, NPV);
+            wave_table_add_quads<NPV, TCT, (MODE == PASS_COLNORM ? 2 : 3)>(pvalid, fsel, [&](int q) { return pv[q]; }, lds, o_tag, o_val, tcount, D0, NPV);
         }
         // the waves' tables -> the dense accumulator, in wave order (once per tile of 1024 entries: this kernel runs once per outer iteration)
         __syncthreads();
