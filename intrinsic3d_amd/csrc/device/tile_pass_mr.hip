@@ -275,6 +275,19 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
         int so[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) so[c] = unpack12(ln, c);
+        // The 14 voxel inputs of a row (10 sdf, 4 albedo) are the ENTRY's: the same for its <= 5 rows.  With one or two systems in the launch there are registers to hold them
+        // across the row loop (14 per system); the 3-system kernel (248 registers) reads them from LDS row by row.
+        constexpr bool HOIST = NB <= 2;
+        float hsv[HOIST ? NB : 1][10], hav[HOIST ? NB : 1][4];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                hsv[b][0] = lds[U_S(b) + i];
+#pragma unroll
+                for (int c = 1; c < 10; ++c) hsv[b][c] = lds[U_S(b) + so[c - 1]];
+                hav[b][0] = lds[U_A(b) + i]; hav[b][1] = lds[U_A(b) + sx]; hav[b][2] = lds[U_A(b) + sy]; hav[b][3] = lds[U_A(b) + sz];
+            }
+        }
         // one row: t_b = W (J u_b) for every system, J^T t_b into the lane's column sums (registers)
         // `reload` >= 0: the slot this buffer takes next, requested as soon as the row's partials have been used — BEFORE the wave sums of its pose block, which need
         // only the six pose partials (copied) and the t_b: the request is in flight for the whole of the reduction and of the next row
@@ -295,10 +308,17 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                     if (!alive[b]) continue;
                     // every LDS read of (row, system) first, behind one another: left to itself the compiler puts an s_waitcnt behind each of the 29
                     float sv[10], av[4], pu[6];
+                    if constexpr (HOIST) {      // (one or two systems: the 14 voxel inputs of the entry are held across its rows)
+#pragma unroll
+                        for (int c = 0; c < 10; ++c) sv[c] = hsv[b][c];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) av[c] = hav[b][c];
+                    } else {
                     sv[0] = lds[U_S(b) + i];
 #pragma unroll
                     for (int c = 1; c < 10; ++c) sv[c] = lds[U_S(b) + so[c - 1]];
                     av[0] = lds[U_A(b) + i]; av[1] = lds[U_A(b) + sx]; av[2] = lds[U_A(b) + sy]; av[3] = lds[U_A(b) + sz];
+                    }
                     const int o_up = SYS(b) + o_upose + 6 * f;
 #pragma unroll
                     for (int q = 0; q < 6; ++q) pu[q] = lds[o_up + q];
