@@ -22,6 +22,11 @@
 // LDS (one 16-byte read per stencil slot serves every system) and a row's reads are issued together in front of a scheduling barrier.  (b) The wave sums of the pose
 // block were readlane trees with an exec-masked LDS add each (25 instructions and 6 hazard stalls per value): here 4 + 2 DPP adds per value, all values of a round
 // interleaved, ONE exec-masked block of LDS adds.
+//
+// What later A/Bs added (same session, builds interleaved): the row loop is NOT where an added system's 0.08 ms go.  The 29-term dot product as two packed chains (-6 % VALU
+// instructions, profiles/r05_mr_packed_dot_ab.json) measures the same; an entry's 14 voxel inputs held in registers across its rows (-29 % LDS reads with two systems,
+// profiles/r05_mr_hoist_inputs_ab.json; kept for one and two systems, the 3-system kernel has no registers left) buys 0.7 %.  What remains per system is its staging (2048 gathered
+// inputs per tile) and its pull phase (column sums through LDS, two barriers, the halo list walk, the output stores) at ONE 512-thread workgroup per CU.
 #include <cstring>
 #include <cstdlib>
 #include "kernels.hpp"
