@@ -54,7 +54,6 @@ def parse_args():
     ap.add_argument("--shell", type=float, default=1.0, help="thin-shell factor (thin_shell_factor_final)")
     ap.add_argument("--subvolume", type=float, default=0.06, help="SH subvolume size in metres (chosen so that the shell of the 0.6 m object touches ~512 subvolumes, BASELINE.json configs[3])")
     ap.add_argument("--cpu-sample", type=float, default=1.0e6, help="stored voxels of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-ref-sample", type=float, default=2.5e5, help="stored voxels of the reference-code leg of the CPU baseline (0 = skip; skipped when oracle/_ref is not built)")
     ap.add_argument("--spin-up", type=float, default=0.0, help="seconds of device copies before the warm-up steps (the device idles while the host generates the scene; 0 = none)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--carry-radius", action="store_true",
@@ -101,7 +100,7 @@ def make_cfg(binding, args, iterations, thres):
                                   pcg_fixed_iterations=args.pcg_fixed, verbose=1 if getattr(args, 'verbose', False) else 0, carry_trust_radius=1 if args.carry_radius else 0)
 
 
-def cpu_baseline(args, sc, thres, log, device=0, threaded_leg=True, reference_leg=True):
+def cpu_baseline(args, sc, thres, log, device=0, threaded_leg=True):
     """The restated CPU reference (oracle, fp64, 8 OpenMP threads in the solve like options.num_threads = 8) on a bounded
     spatial sample of the SAME workload: the voxels of a cap of the sphere, same keyframes, same configuration."""
     from oracle import oracle_py as O
@@ -184,8 +183,7 @@ def cpu_baseline(args, sc, thres, log, device=0, threaded_leg=True, reference_le
     scale = keys.shape[0] / float(n)
     value = 1.0 / (sec_per_iter_sample * scale)
     log(f"cpu baseline: {n} voxels, {iters} iterations in {dt:.1f}s -> {sec_per_iter_sample:.2f} s/iter on the sample, x{scale:.1f} voxels")
-    ref_code = reference_code_leg(args, sc, thres, cfg, log) if reference_leg else None
-    return {"value": value, "reference_code": ref_code, "unit": "GN iterations/s", "cores": os.cpu_count(), "threads": threads, "kind": "port",
+    return {"value": value, "unit": "GN iterations/s", "cores": os.cpu_count(), "threads": threads, "kind": "port",
             # `value` is measured on the sample and scaled linearly by the voxel ratio unless the sample IS the workload (tools/c4_full_parity.py: profiles/r05_c4_full_parity.json)
             "extrapolated": bool(scale > 1.001), "voxel_ratio": scale, "sample_voxels": int(n),
             "sample": f"restated CPU reference (Ceres-2.1.0-equivalent, fp64) on a {n}-voxel cap of the same grid with all {sc['K']} keyframes, "
@@ -195,42 +193,6 @@ def cpu_baseline(args, sc, thres, log, device=0, threaded_leg=True, reference_le
             "phases_s_per_iteration_sample": {"collect_single_thread": float(phases[0]) / iters, "build_and_solve": float(phases[2]) / iters},
             "threaded_collection": None if threaded is None else dict(threaded, value=1.0 / (threaded["seconds_per_iteration_sample"] * scale)),
             "parity_on_sample": parity}
-
-
-def reference_code_leg(args, sc, thres, cfg, log):
-    """Beside the port: the reference's OWN classes (Optimizer / NLSSolver / SDFColorization / cost functors with ceres::Jet, compiled from the reference
-    sources into oracle/_ref over stand-ins for Eigen / OpenCV and a second Ceres-2.1.0 LM + CGNR, oracle/extract_ref.py) on a smaller cap of the same grid,
-    and the port on the SAME cap for the ratio.  Not the headline baseline: its linear solver is a stand-in, not Ceres."""
-    n_target = int(args.cpu_ref_sample)
-    if n_target <= 0:
-        return None
-    try:
-        from oracle import oracle_py as O, ref_py
-        if not ref_py.available():
-            return None
-        keys = sc["keys"]; x = keys[:, 0]; m = min(n_target, keys.shape[0])
-        cut = np.partition(x, keys.shape[0] - m)[keys.shape[0] - m]; sel = x >= cut
-        out = {}
-        vsh = None
-        for name, M in (("port", O), ("reference_code", ref_py.pipeline())):
-            g = M.Grid.from_voxels(sc["voxel_size"], keys[sel], sc["sdf"][sel], sc["weight"][sel], sc["color"][sel]); fr = M.Frames(sc["frames"], 1)
-            if vsh is None:                                   # one lighting estimate for both (two LM implementations may stop at different points of a flat valley)
-                rc_sh, _, _, vsh, _, _ = M.estimate_sh(g, args.subvolume, 10.0, thres)
-                if rc_sh != 0:
-                    vsh = np.tile(np.asarray(sc["scene"].sh), (len(g), 1))
-            c1 = M.OptConfig(**{k: getattr(cfg, k) for k, _ in cfg._fields_}); c1.iterations = 1
-            t0 = time.time(); rc, _, _, _, st = M.optimize(g, fr, c1, sc["intr"], sc["dist"], sc["poses"], vsh); dt = time.time() - t0
-            out[name] = {"seconds_per_iteration": dt, "voxels": len(g), "rows": [int(v) for v in st[0].rows], "lm_attempts": int(st[0].n_attempts),
-                         "cost": [float(st[0].cost_initial), float(st[0].cost_final)], "rc": int(rc)}
-            g.free(); fr.free()
-        out["reference_code_over_port"] = out["reference_code"]["seconds_per_iteration"] / out["port"]["seconds_per_iteration"]
-        out["note"] = ("the reference's own Optimizer::optimize (ceres::Jet autodiff through its functors, its NLSSolver / SDFColorization / SparseVoxelGrid) compiled from the "
-                       "reference sources, solved by a stand-in Ceres-2.1.0 LM + CGNR; same cap, same lighting, one GN iteration each")
-        log(f"reference-code leg: {out['port']['voxels']} voxels, port {out['port']['seconds_per_iteration']:.2f} s, reference code {out['reference_code']['seconds_per_iteration']:.2f} s per iteration")
-        return out
-    except Exception as e:                                    # the leg is a report, never a reason to fail the bench
-        log(f"reference-code leg skipped: {e}")
-        return None
 
 
 def kernel_table(args, sizes, world, timing_work, timing):

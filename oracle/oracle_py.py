@@ -52,8 +52,7 @@ _lib = None
 
 
 class _Prefixed:
-    """Attribute proxy over a CDLL: `orc_x` resolves to `<prefix>x`.  oracle/_ref exports the reference's own pipeline under the same shapes
-    with the prefix `ref_` (oracle/ref_py.py: pipeline()), so one harness drives both.  A symbol the library lacks yields a stub that raises."""
+    """Attribute proxy over a CDLL: `orc_x` resolves to `<prefix>x`.  A symbol the library lacks yields a stub that raises."""
 
     def __init__(self, cdll, prefix):
         self._cdll = cdll; self._prefix = prefix

@@ -9,7 +9,7 @@
 //   mesh/marching_cubes.cpp:278-317  interpolate / getVertex
 //   mesh/util.cpp:174-200            removeDegenerateFaces
 // The triangulation table is Bourke's (the product's packed copy, itself checked against the reference's table by
-// tests/test_oracle_vs_ref.py).
+// tests/test_io_cpu.py where /root/reference exists).
 #pragma once
 #include <cmath>
 #include <map>

@@ -73,8 +73,7 @@ inline double chroma_weight(const uint8_t ca[3], const uint8_t cb[3]) {
 
 // Eigen reduces a FIXED-SIZE 3-vector sum by halving (Core/Redux.h, redux_novec_unroller<0,3>): a0 + (a1 + a2).  Every dot / norm / fixed 3x3 * 3
 // product of the reference goes through it; run-time sized blocks (`topLeftCorner(3, 3) * p`) go through GEMV instead, which accumulates
-// left to right.  oracle/_ref runs the reference bodies on stand-ins with exactly these two orders and tests/test_ref_pipeline.py holds
-// this file to them bit for bit.
+// left to right.  (Eigen is absent from this image: the two orders are restated from its published source, unpinned.)
 template <class T> inline T esum3(T a0, T a1, T a2) { return a0 + (a1 + a2); }
 
 // operators.cpp:58-77 (float; Eigen normalize() divides by sqrt(squaredNorm))

@@ -244,8 +244,8 @@ def test_resize_depth_bit_exact(oracle):
 
 
 def test_device_level_operations_match_committed_golden():
-    """the device path alone against tests/golden/levels_small.json (CRCs of byte-exact stages, generated by make_golden.py from the REFERENCE'S OWN convert / recolour /
-    thin-shell / upsample / resizeDepth code in oracle/_ref; the OpenCV pyramid CRCs from the oracle): needs neither at run time"""
+    """the device path alone against tests/golden/levels_small.json (CRCs of byte-exact stages of the ORACLE's convert / recolour / thin-shell / upsample /
+    resizeDepth / pyramid restatements on seeded inputs, tests/golden/make_golden.py — regression vectors, not reference outputs): needs no oracle library at run time"""
     import json, os, zlib
     from intrinsic3d_amd import binding
     import golden.make_golden as mg

@@ -1,8 +1,7 @@
 """-m gpu: mesh export (marching cubes on the resident grid + PLY), SURVEY.md §8f rank 1.
 
 Triangle-for-triangle identity: vertices, colours and faces of i3d_get_mesh equal the oracle's restatement of
-MarchingCubes<VoxelSBR>::extractSurface bit for bit (and, when the prebuilt oracle/_ref travelled with the tree, the reference's own
-code); the oracle itself is held against that reference code on the CPU (tests/test_oracle_vs_ref.py).  Also held: the vertex arithmetic
+MarchingCubes<VoxelSBR>::extractSurface (mesh/marching_cubes.cpp:65-343) bit for bit.  Also held: the vertex arithmetic
 against a numpy restatement, crack-freeness on arbitrary sign patterns, outward orientation, and the byte layout of the PLY stream."""
 import collections
 import struct
@@ -165,39 +164,11 @@ def test_mesh_identical_to_the_oracle_and_the_reference_code(oracle, tmp_path):
         binding.write_ply(tmp_path / "orc.ply", ov, oc, of)
         assert open(tmp_path / "dev.ply", "rb").read() == open(tmp_path / "orc.ply", "rb").read()
     og.free()
-    from oracle import ref_py
-    if ref_py.available():                                   # the reference's own MarchingCubes + Mesh::save (prebuilt oracle/_ref)
-        import ctypes as C
-        o1 = np.zeros(len(g), np.int64); ref_py.lib().ref_grid_visit_order(float(vs), len(g), g.ctypes.data_as(C.c_void_p), o1.ctypes.data_as(C.c_void_p))
-        rv, rc, rf = ref_py.marching_cubes(vs, g[o1], sdf[o1].astype(np.float64), w[o1], col[o1], save_path=str(tmp_path / "ref.ply"))
-        with binding.Context(0) as ctx:
-            ctx.set_grid(vs, a["keys"], a["sdf"], a["sdf"], a["albedo"], a["weight"], a["color"])
-            v, cc, f = ctx.extract_mesh(use_refined_sdf=False, color_mode=0, largest_component_only=False)
-            ctx.export_mesh_ply(tmp_path / "dev2.ply", False, 0, False)
-        assert v.tobytes() == rv.tobytes() and cc.tobytes() == rc.tobytes() and f.tobytes() == rf.tobytes()
-        assert open(tmp_path / "dev2.ply", "rb").read() == open(tmp_path / "ref.ply", "rb").read()
-        # largest_component_only = MeshUtil::removeLooseComponents (+ removeUnusedVertices) on that mesh — this ragged grid (3 % of its voxels invalid)
-        # falls into several pieces
-        lv, lc, lf = ref_py.mesh_remove_loose_components(rv, rc, rf)
-        with binding.Context(0) as ctx:
-            ctx.set_grid(vs, a["keys"], a["sdf"], a["sdf"], a["albedo"], a["weight"], a["color"])
-            v2, c2, f2 = ctx.extract_mesh(use_refined_sdf=False, color_mode=0, largest_component_only=True)
-        assert len(lf) < len(rf) and len(lv) < len(rv)
-        assert v2.tobytes() == lv.tobytes() and c2.tobytes() == lc.tobytes() and f2.tobytes() == lf.tobytes()
-        # the "albedo" colour mode: SDFVisualization::applyColorAlbedo paints every voxel scalarToColor(albedo, 255) before the mesh is extracted
-        alb_of = lambda k: ((k[:, 0] * 7 + k[:, 1] * 13 + k[:, 2] * 29) % 131) / 100.0 - 0.1      # a function of the voxel; beyond [0, 1] on both sides: the clamp
-        acol = ref_py.albedo_colors(alb_of(g))
-        av, ac, af = ref_py.marching_cubes(vs, g[o1], sdf[o1].astype(np.float64), w[o1], acol[o1])
-        with binding.Context(0) as ctx:
-            ctx.set_grid(vs, a["keys"], a["sdf"], a["sdf"], alb_of(a["keys"]), a["weight"], a["color"])
-            v3, c3, f3 = ctx.extract_mesh(use_refined_sdf=False, color_mode=1, largest_component_only=False)
-        assert v3.tobytes() == av.tobytes() and f3.tobytes() == af.tobytes(), (len(v3), len(av), len(f3), len(af))
-        assert c3.tobytes() == ac.tobytes(), (int((c3 != ac).sum()), c3[(c3 != ac).any(1)][:4], ac[(c3 != ac).any(1)][:4])
 
 
 def test_export_colour_modes_device_equals_host_instantiation(tmp_path):
-    """the debug colour modes of the export (k_vis_colors: the device instantiation of vis_colors.hpp) against i3d_visualization_colors (the host instantiation the CPU
-    suite holds to the reference's SDFVisualization) on a grid with holes, zero-weight voxels, random colours and several lighting subvolumes: a mesh exported in mode
+    """the debug colour modes of the export (k_vis_colors: the device instantiation of vis_colors.hpp) against i3d_visualization_colors (the host instantiation
+    of the same header) on a grid with holes, zero-weight voxels, random colours and several lighting subvolumes: a mesh exported in mode
     X must equal, byte for byte, the plain export of the same grid repainted with the host's colours for X.  Plus the two refusals."""
     from intrinsic3d_amd import binding
     rng = np.random.default_rng(5)

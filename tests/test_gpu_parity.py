@@ -215,8 +215,8 @@ def test_estimate_sh_matches_oracle(setup):
 
 
 def test_gpu_matches_committed_golden(oracle):
-    """HIP path vs tests/golden/optimize_small.json: outputs of the REFERENCE'S OWN Optimizer / NLSSolver / LightingSVSH code (oracle/_ref over
-    mini-ceres), committed with their generating script (tests/golden/make_golden.py)."""
+    """HIP path vs tests/golden/optimize_small.json: the oracle's outputs on a seeded scene, committed with their generating script
+    (tests/golden/make_golden.py) — regression vectors of the restatement, not reference outputs (the reference cannot be built here)."""
     import json, os
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optimize_small.json")))
     sc = helpers.small_scene(seed=11, radius_vox=12, K=4, width=128, height=96)

@@ -134,7 +134,7 @@ output_mesh_prefix: "./intrinsic3d/mesh"
 
 
 def test_marching_cubes_table_properties():
-    """the triangulation table the kernels read (Bourke's, unpacked from host/mc_table.hpp; tests/test_oracle_vs_ref.py checks it against
+    """the triangulation table the kernels read (Bourke's, unpacked from host/mc_table.hpp; the test below checks it against
     the reference's literal table): every triangle uses cut edges only, every cut edge is used, closed loops, at most 5 triangles per cell"""
     ntri, tri, mx = binding.mc_tables()
     assert mx == 5 and ntri[0] == 0 and ntri[255] == 0
@@ -199,3 +199,19 @@ def test_map_order_replay_matches_the_standard_container():
     # negative coordinates hash through sign extension (mat.h:117-124): the order differs from the one of their absolute values
     neg = grid[:5000].copy(); neg[:, 0] -= 100
     assert np.array_equal(B.debug_map_order(neg, 0), B.debug_map_order(neg, 2))
+
+
+def test_marching_cubes_table_equals_the_reference_literal():
+    """host/mc_table.hpp case by case against the two integer literals in the reference's source text (mesh/marching_cubes.cpp:330-623,
+    read as data by tools/pack_mc_table.py: reference_tables); skipped where /root/reference does not exist"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import pack_mc_table
+    if not os.path.exists(pack_mc_table.REF_MC):
+        pytest.skip("/root/reference is not present")
+    edge, tri_ref = pack_mc_table.reference_tables()
+    ntri, tri, mx = binding.mc_tables()
+    for idx in range(256):
+        row = [int(v) for v in tri_ref[idx] if v >= 0]
+        assert 3 * int(ntri[idx]) == len(row) and tri[idx][:len(row)].tolist() == row, idx
+        assert sum(1 << e for e in set(row)) == int(edge[idx]), idx

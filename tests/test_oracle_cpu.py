@@ -167,8 +167,9 @@ def test_upsample_and_thin_shell_invariants(oracle):
 
 
 def test_golden_oracle_outputs(oracle):
-    """The oracle against numbers THE REFERENCE'S OWN CODE produced on a seeded scene (tests/golden/make_golden.py runs oracle/_ref: Optimizer, NLSSolver,
-    SDFColorization, LightingSVSH ... compiled from /root/reference); pins libstdc++'s visit order too."""
+    """The oracle against its own committed outputs on a seeded scene (tests/golden/make_golden.py): a regression guard for the checker — a change
+    of the restatement that moves a number shows up here before it shows up as a "device mismatch"; pins libstdc++'s visit order too.  NOT reference
+    outputs: the reference cannot be built in this image (oracle/i3d_oracle.h: parity unpinned)."""
     path = os.path.join(HERE, "golden", "optimize_small.json")
     if not os.path.exists(path):
         pytest.skip("golden file not generated")
@@ -185,14 +186,14 @@ def test_golden_oracle_outputs(oracle):
 
 
 def test_golden_level_operations(oracle):
-    """byte-exact stages of the level schedule (visit orders, 8-bit colours, upsampled fields, pyramids) vs the CRCs the reference's code produced"""
+    """byte-exact stages of the level schedule (visit orders, 8-bit colours, upsampled fields, pyramids) vs the committed CRCs of the oracle's own outputs (regression vectors)"""
     gold = json.load(open(os.path.join(HERE, "golden", "levels_small.json")))
     import golden.make_golden as mg
     assert mg.compute_levels(oracle) == mg.strip_tags(gold)
 
 
 def test_golden_fusion(oracle):
-    """the fused volume of five seeded frames (integrate, correctSDF, clearInvalidVoxels; record order) vs the CRCs the reference's code produced"""
+    """the fused volume of five seeded frames (integrate, correctSDF, clearInvalidVoxels; record order) vs the committed CRCs of the oracle's own outputs (regression vectors)"""
     gold = json.load(open(os.path.join(HERE, "golden", "fusion_small.json")))
     import golden.make_golden as mg
     assert mg.compute_fusion(oracle) == mg.strip_tags(gold)

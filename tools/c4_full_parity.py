@@ -38,7 +38,7 @@ def main():
     t0 = time.time()
     sc = bench.build_workload(args, log)
     thres = args.shell * float(sc["voxel_size"])
-    cpu = bench.cpu_baseline(args, sc, thres, log, device=0, threaded_leg=a.threaded_leg, reference_leg=False)
+    cpu = bench.cpu_baseline(args, sc, thres, log, device=0, threaded_leg=a.threaded_leg)
     if cpu is None:
         raise SystemExit("the CPU leg failed")
     out = {"what": "two Gauss-Newton iterations of the headline workload at FULL size, device vs CPU oracle, from identical inputs",
