@@ -25,7 +25,9 @@ def sh_basis(n: np.ndarray) -> np.ndarray:
 class Scene:
     """Bumpy sphere: sdf(p) = |p-c| - R + amp*sin(f x)sin(f y)sin(f z); albedo field; SH lighting."""
 
-    def __init__(self, center, radius, bump_amp, bump_freq, sh=SH_TRUE):
+    def __init__(self, center, radius, bump_amp, bump_freq, sh=SH_TRUE, albedo_freq=25.0, albedo_amp=0.2):
+        self.albedo_freq = float(albedo_freq)
+        self.albedo_amp = float(albedo_amp)
         self.c = np.asarray(center, dtype=np.float64)
         self.R = float(radius)
         self.amp = float(bump_amp)
@@ -49,7 +51,11 @@ class Scene:
         return g / np.sqrt((g * g).sum(-1, keepdims=True))
 
     def albedo(self, p):
-        return 0.6 + 0.2 * np.sin(25.0 * p[..., 0]) * np.cos(25.0 * p[..., 1])
+        f = self.albedo_freq
+        if f == 25.0:
+            return 0.6 + self.albedo_amp * np.sin(25.0 * p[..., 0]) * np.cos(25.0 * p[..., 1])
+        # a textured variant (three incommensurate directions, so that no rotation about the centre maps the pattern onto itself)
+        return 0.6 + self.albedo_amp * (np.sin(f * p[..., 0] + 0.3) * np.cos(0.83 * f * p[..., 1]) + 0.5 * np.sin(1.31 * f * p[..., 2] + 0.47 * f * p[..., 0])) / 1.5
 
     def shade(self, p):
         return self.albedo(p) * (sh_basis(self.normal(p)) @ self.sh)
@@ -189,7 +195,7 @@ def shell_voxels(scene: Scene, voxel_size, band_vox, lo, hi, truncation=None):
 
 def make_scene(radius_vox=24, voxel_size=0.004, K=4, width=160, height=120, levels=1, band_vox=3.2,
                dense_res=None, seed=0, cam_dist=None, bump_amp_vox=0.5, bump_freq=40.0, pose_noise=(0.0, 0.0),
-               lum_noise=0.0, fx=None, shuffle=True, tint=True):
+               lum_noise=0.0, fx=None, shuffle=True, tint=True, albedo_freq=25.0, albedo_amp=0.2):
     """Returns a dict with the voxel list (file order), frames, poses, intrinsics and ground truth.
 
     dense_res: if given, a dense res^3 grid is emitted (config C1) instead of a thin shell.
@@ -205,7 +211,7 @@ def make_scene(radius_vox=24, voxel_size=0.004, K=4, width=160, height=120, leve
         center = np.full(3, (margin + 2) * voxel_size)
         lo, hi = (0, 0, 0), (2 * margin + 4,) * 3
         band = band_vox
-    scene = Scene(center, R, bump_amp_vox * voxel_size, bump_freq)
+    scene = Scene(center, R, bump_amp_vox * voxel_size, bump_freq, albedo_freq=albedo_freq, albedo_amp=albedo_amp)
     keys, sdf = shell_voxels(scene, voxel_size, band, lo, hi)
     n = keys.shape[0]
     if shuffle:

@@ -101,7 +101,7 @@ def test_config_c2_single_level_fixed_camera_global_sh(oracle):
     assert np.abs(out["sdf_refined"] - out["sdf"]).max() > 1e-3 * float(sc["voxel_size"])             # the geometry did move
 
 
-def _three_level_schedule(oracle, tmp_path, *, seed, fix_poses, fix_distortion, iterations, pose_noise, subvolume):
+def _three_level_schedule(oracle, tmp_path, *, seed, fix_poses, fix_distortion, iterations, pose_noise, subvolume, **scene_kw):
     """The reference's coarse-to-fine schedule on a dataset folder, through apps/app_intrinsic3d and in-process, against oracle.refine on the same decoded
     keyframes.  Returns what the callers assert on."""
     from intrinsic3d_amd import binding as B, synthetic
@@ -110,7 +110,7 @@ def _three_level_schedule(oracle, tmp_path, *, seed, fix_poses, fix_distortion, 
     app = os.path.join(ROOT, "apps", "app_intrinsic3d")
     assert os.path.exists(app), "apps/app_intrinsic3d has not been built (run __graft_entry__.build())"
     levels = 3
-    sc = synthetic.make_scene(radius_vox=10, K=6, width=192, height=144, levels=1, seed=seed, pose_noise=pose_noise, lum_noise=0.003, cam_dist=0.2)      # surface beyond sensor.yml's min_depth 0.1 m
+    sc = synthetic.make_scene(radius_vox=10, K=6, width=192, height=144, levels=1, seed=seed, pose_noise=pose_noise, lum_noise=0.003, cam_dist=0.2, **scene_kw)      # surface beyond sensor.yml's min_depth 0.1 m
     s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=3, rgbd_levels=levels, iterations=iterations, fix_poses=fix_poses, fix_distortion=fix_distortion,
                                               subvolume_size_sh=subvolume)
     r = subprocess.run([app, "-s", s_yml, "-i", i_yml], capture_output=True, text=True, timeout=900)
@@ -183,7 +183,7 @@ def test_config_c5_full_joint_refinement_with_free_camera(oracle, tmp_path, caps
     # (fp32 LDS atomics inside the operator pass) end 1e-4 apart in the intrinsics — measured — which is the comparison between the application and the in-process
     # flow below, not the parity with the oracle
     monkeypatch.setenv("I3D_DETERMINISTIC", "1")
-    r = _three_level_schedule(oracle, tmp_path, seed=35, fix_poses=0, fix_distortion=0, iterations=3, pose_noise=(0.002, 0.0035), subvolume=0.03)
+    r = _three_level_schedule(oracle, tmp_path, seed=35, fix_poses=0, fix_distortion=0, iterations=3, pose_noise=(0.002, 0.0035), subvolume=0.03, **C5_TEXTURE)
     assert np.abs(r["poses"] - r["poses0"]).max() > 1e-5 and np.abs(r["intr"] - r["intr0"]).max() > 1e-4      # the camera did move
     with capsys.disabled():
         _check_fields(r["out"], r["ref"], r["env"], ordered=False, free_camera=True)
@@ -197,41 +197,119 @@ def test_config_c5_full_joint_refinement_with_free_camera(oracle, tmp_path, caps
     assert d_pose <= max(1e-4 * max(1.0, float(np.abs(r["oposes"]).max())), helpers.ENVELOPE_FACTOR * spread_p), (d_pose, spread_p)
 
 
-def test_free_camera_schedule_in_the_lds_atomic_mode_against_the_bit_reproducible_one(tmp_path, monkeypatch):
-    """The C5 schedule (every group free, 3 grid levels x (3, 1, 1) pyramid levels, dataset folder) in the LDS-ATOMIC mode (I3D_DETERMINISTIC=0: fp32 LDS atomics inside k_eg_tile,
-    which the lone systems of the damping ladder go through; the default up to round 4 and still the default of a sharded run) against the same schedule in the
-    bit-reproducible mode (the default on one rank), which the test above compares with the oracle.  The two differ by summation-order noise only, and this gauge-free schedule amplifies noise: the test above measures the ORACLE's own spread under 1e-7
-    perturbations of its input at 4.0e-2 (sdf) / 1.8e-2 (albedo) of the field maximum, 4.8e-2 in the poses, 5.7e-4 in the intrinsics, and the bit-reproducible run
-    against the oracle at 99.9 % 6.9e-3 / max 1.7e-2.  Measured here (MI355X, round 5): sdf 99.9 % 4.6e-3, max 1.7e-2; albedo 2.3e-3 / 1.1e-2; intrinsics 9.2e-5;
-    poses 6.5e-4; 6 of 121 167 voxels on one side only.  The bars are those spreads: median 1e-3, 99.9 % 1e-2, max 4e-2 of the field maximum; intrinsics 1e-3
-    relative, poses 5e-3; at most 2e-3 of the voxels kept on one side only (advisor finding of round 4: no free-camera schedule test covered the default mode)."""
-    from intrinsic3d_amd import binding as B, synthetic
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import make_dataset
-    levels = 3
-    sc = synthetic.make_scene(radius_vox=10, K=6, width=192, height=144, levels=1, seed=35, pose_noise=(0.002, 0.0035), lum_noise=0.003, cam_dist=0.2)
-    s_yml, i_yml = make_dataset.write_dataset(str(tmp_path), sc, grid_levels=3, rgbd_levels=levels, iterations=3, fix_poses=0, fix_distortion=0, subvolume_size_sh=0.03)
-    sensor = B.Sensor(tmp_path / "rgbd", 0, 0.1, 10.0)
-    _, _, is_kf = B.keyframes_load(str(tmp_path / "fusion" / "keyframes.txt"))
-    rc, oc = B.load_yaml_config(i_yml)
-    vol = B.tsdf_read(str(tmp_path / "fusion" / f"volume_{float(sc['voxel_size']):g}.tsdf"))
+# The C5 test object: the 4 cm sphere of the other schedule tests, but TEXTURED (albedo pattern of ~2.5 cm wavelength in three incommensurate directions, 1 cm bumps)
+# and seen through a longer lens (fx 300: 60 px radius at level 0, 15 px on the coarsest pyramid level).  On the untextured sphere at fx 157 (8 px on the coarsest
+# level) the free poses are all but unconstrained: the ORACLE moves them by 0.26 and 0.9 (rad / m) in the first two stages and its end result by 4e-2 of max |sdf|
+# under 1e-7 input perturbations; on this one the first stage moves them 0.046, the later ones ~5e-3, and the end result 3e-3 (tools/c5_conditioning.py).
+C5_TEXTURE = dict(albedo_freq=250.0, albedo_amp=0.3, bump_freq=120.0, fx=300.0)
+C5_SCENE = dict(radius_vox=10, K=6, width=192, height=144, seed=35, pose_noise=(0.002, 0.0035), lum_noise=0.003, cam_dist=0.2, **C5_TEXTURE)
 
-    def run():
-        with B.Context(0) as ctx:
-            ctx.set_grid_from_tsdf_records(vol["voxel_size"], vol["keys"], vol["sdf"], vol["weight"], vol["color"])
-            B.init_frames_from_sensor(ctx, sensor, is_kf, levels)
-            ctx.refine(rc, oc)
-            return ctx.export_grid(), ctx.get_camera()
-    monkeypatch.setenv("I3D_DETERMINISTIC", "1")
-    det, (di, dd, dp) = run()
-    monkeypatch.setenv("I3D_DETERMINISTIC", "0")
-    dflt, (fi, fd, fp) = run()
-    a, b = helpers.align_by_key(dflt, det, max_frac=2e-3, ordered=False)
-    e_sdf = np.abs(a["sdf_refined"] - b["sdf_refined"]) / np.abs(b["sdf_refined"]).max(); e_alb = np.abs(a["albedo"] - b["albedo"]) / np.abs(b["albedo"]).max()
-    d_intr = float(np.abs(fi - di).max() / np.abs(di).max()); d_pose = float(np.abs(fp - dp).max())
-    print(f"\n[C5, LDS-atomic vs bit-reproducible mode] sdf: median {np.median(e_sdf):.2e}, 99.9 % {np.quantile(e_sdf, 0.999):.2e}, max {e_sdf.max():.2e}; albedo: median {np.median(e_alb):.2e}, 99.9 % {np.quantile(e_alb, 0.999):.2e}, max {e_alb.max():.2e}; "
-          f"intrinsics {d_intr:.2e} relative, poses {d_pose:.2e}; voxels {len(dflt['keys'])} / {len(det['keys'])}")
-    assert np.median(e_sdf) <= 1e-3 and np.median(e_alb) <= 1e-3
-    assert np.quantile(e_sdf, 0.999) <= 1e-2 and np.quantile(e_alb, 0.999) <= 1e-2
-    assert e_sdf.max() <= 4e-2 and e_alb.max() <= 4e-2
-    assert d_intr <= 1e-3 and d_pose <= 5e-3
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
+
+
+def test_config_c5_every_stage_of_the_free_camera_schedule_at_1e_4(oracle, monkeypatch, capsys):
+    """BASELINE.json configs[4], the 1e-4 statement.  The free-camera schedule CHAINS 5 stages x 3 outer iterations, and the reference algorithm amplifies what it is
+    handed: the oracle's own end result moves 2e-3 ... 4e-2 of max |sdf| when its input poses are perturbed by 1e-7 (tools/c5_conditioning.py, every scene tried), so two
+    correct implementations cannot agree to 1e-4 at the END of the chain, and the end-to-end test above can only hold the device inside the oracle's own spread.  What
+    CAN be held to 1e-4 is every link of the chain: the reference's schedule (Intrinsic3D::refine, intrinsic3d.cpp:229-290; thin shell :298-316; all pyramid levels on
+    the coarsest grid only :236) is walked by the oracle, and every stage — (grid level, pyramid level) = (2,2) (2,1) (2,0) (1,0) (0,0), every group free
+    (optimizer.cpp:296-306 with no flag set) — is ALSO run on the device from the oracle's state at the start of that stage:
+      * thin shell on the device from the oracle's grid before it: keys in visit order and every field bit-exact;
+      * lighting estimate + 2 chained outer iterations (Ceres' own PCG stop) + recolourisation: rows of every type, LM attempts, accept / reject sequence equal; PCG
+        counts equal (+-1 on rejected attempts: fp32 vectors against the fp64 oracle at a stop threshold); sdf, albedo, poses, intrinsics <= 1e-4 in the max-norm
+        convention of DESIGN.md section 6; colours within one count on >= 99.9 % of the components;
+      * the first outer iteration of the stage again in the LDS-ATOMIC mode (I3D_DETERMINISTIC=0), with the damping ladder and through the serial loop (I3D_LADDER=1:
+        every pass through k_eg_tile's fp32 LDS atomics — the path a sharded run takes): each against the oracle at 1e-4 and against the bit-reproducible default
+        at <= 2e-6 (summation order only);
+      * x2 upsampling on the device from the oracle's grid at the end of the level: keys in visit order and every field bit-exact."""
+    from intrinsic3d_amd import binding as B, synthetic
+    O = oracle
+    GL = PL = 3
+    sc = synthetic.make_scene(levels=PL, **C5_SCENE)
+    G = O.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"]); Fr = O.Frames(sc["frames"], PL)
+    intr, dist, poses = np.array(sc["intr"], np.float64), np.array(sc["dist"], np.float64), np.array(sc["poses"], np.float64)
+    O.recompute_colors(G, Fr, intr, dist, poses, 0.02, 5)
+    sub, lam_reg, iters = 0.03, 10.0, 2
+    worst = dict(sdf=0.0, alb=0.0, pose=0.0, intr=0.0, mode=0.0); stages = []
+
+    def seed(ctx, a, cam):
+        ctx.set_grid(a["voxel_size"], a["keys"], a["sdf"], a["sdf_refined"], a["albedo"], a["weight"], a["color"]); ctx.set_camera(*cam)
+
+    def same_grid(dev, ref, what):
+        for k in ("keys", "weight", "color", "sdf", "sdf_refined", "albedo"):
+            assert np.array_equal(dev[k], ref[k]), (what, k)
+
+    with B.Context(0) as ctx:
+        ctx.set_frames(sc["frames"], PL)
+        for gl in range(GL - 1, -1, -1):
+            vs = float(G.voxel_size)
+            thres = float(O.lib().orc_varying_lambda(GL - 1 - gl, GL, 2.0, 1.0)) * vs
+            before = dict(G.export(), voxel_size=vs)
+            G.clear_outside_shell(thres)
+            seed(ctx, before, (intr, dist, poses)); ctx.clear_outside_thin_shell(thres)
+            same_grid(ctx.export_grid(), G.export(), f"thin shell at grid level {gl}")
+            for pl in range(PL - 1, -1, -1):
+                if pl > 0 and gl < GL - 1:
+                    continue
+                start = dict(G.export(), voxel_size=vs); cam0 = (intr.copy(), dist.copy(), poses.copy())
+                rc_sh, _, _, vsh, _, _ = O.estimate_sh(G, sub, lam_reg, thres)
+                assert rc_sh == 0
+                ocfg = helpers.oracle_cfg(O, thres, iterations=iters, lm_steps=50, grid_level=gl, rgbd_level=pl)
+                # the first outer iteration alone (for the mode comparison), then the stage proper
+                o1 = helpers.oracle_cfg(O, thres, iterations=1, lm_steps=50, grid_level=gl, rgbd_level=pl,
+                                        lambda_r0=ocfg.lambda_r0, lambda_s0=ocfg.lambda_s0, lambda_r1=ocfg.lambda_r0, lambda_s1=ocfg.lambda_s0)
+                rc1, i1, d1, p1, st1 = O.optimize(G, Fr, o1, cam0[0], cam0[1], cam0[2], vsh); ref1 = G.export()
+                assert rc1 == 0
+                G.import_fields(sdf_refined=start["sdf_refined"], albedo=start["albedo"])                          # back to the start of the stage (optimize touches nothing else)
+                first = {}
+                for name, env in (("default", {}), ("lds_atomic", {"I3D_DETERMINISTIC": "0"}), ("lds_atomic_serial_loop", {"I3D_DETERMINISTIC": "0", "I3D_LADDER": "1"})):
+                    with monkeypatch.context() as m:
+                        for k, v in env.items():
+                            m.setenv(k, v)
+                        seed(ctx, start, cam0); ctx.estimate_sh(sub, lam_reg, thres)
+                        g1 = ctx.optimize(helpers.gpu_cfg(o1))[0]
+                    sdf, alb = ctx.get_grid(); ci, cd, cp = ctx.get_camera(); first[name] = (sdf, alb, ci, cp)
+                    assert list(g1.rows) == list(st1[0].rows), (gl, pl, name)
+                    assert list(g1.step_accepted[:g1.num_attempts]) == list(st1[0].accepted[:st1[0].n_attempts]), (gl, pl, name)
+                    e = (_rel(sdf, ref1["sdf_refined"]), _rel(alb, ref1["albedo"]), _rel(ci, i1), float(np.abs(cp - p1).max() / max(1.0, np.abs(p1).max())))
+                    assert max(e) <= 1e-4, (gl, pl, name, e)
+                for name in ("lds_atomic", "lds_atomic_serial_loop"):
+                    dm = max(_rel(first[name][0], first["default"][0]), _rel(first[name][1], first["default"][1]), _rel(first[name][2], first["default"][2]),
+                             float(np.abs(first[name][3] - first["default"][3]).max()))
+                    worst["mode"] = max(worst["mode"], dm)
+                    assert dm <= 2e-6, (gl, pl, name, dm)
+                # the stage: lighting + `iters` chained outer iterations + recolourisation, on both sides from the same state
+                rc, intr, dist, poses, ost = O.optimize(G, Fr, ocfg, cam0[0], cam0[1], cam0[2], vsh)
+                assert rc == 0
+                O.recompute_colors(G, Fr, intr, dist, poses, 0.02, 5); ref = G.export()
+                seed(ctx, start, cam0); ctx.estimate_sh(sub, lam_reg, thres)
+                gst = ctx.optimize(helpers.gpu_cfg(ocfg)); ctx.recompute_colors(0.02, 5)
+                out = ctx.export_grid(); ci, cd, cp = ctx.get_camera()
+                for so, sg in zip(ost, gst):
+                    assert list(so.rows) == list(sg.rows) and so.rows[0] > 0, (gl, pl)
+                    assert list(so.accepted[:so.n_attempts]) == list(sg.step_accepted[:sg.num_attempts]), (gl, pl)
+                    oc = list(so.cg_iters[:so.n_attempts]); gc = list(sg.pcg_iterations[:sg.num_attempts])
+                    assert all(abs(x - y) <= 1 for x, y in zip(oc, gc)) and oc[-1] == gc[-1], (gl, pl, oc, gc)
+                    assert abs(so.cost_final - sg.cost_final) <= 1e-4 * so.cost_final
+                assert np.array_equal(out["keys"], ref["keys"])
+                e = dict(sdf=_rel(out["sdf_refined"], ref["sdf_refined"]), alb=_rel(out["albedo"], ref["albedo"]), intr=_rel(ci, intr),
+                         pose=float(np.abs(cp - poses).max() / max(1.0, np.abs(poses).max())))
+                stages.append((gl, pl, len(ref["keys"]), [int(s.n_attempts) for s in ost], e))
+                for k, v in e.items():
+                    worst[k] = max(worst[k], v)
+                assert max(e.values()) <= 1e-4, (gl, pl, e)
+                cdiff = np.abs(out["color"].astype(int) - ref["color"].astype(int))
+                assert (cdiff > 1).mean() <= 1e-3, (gl, pl, float((cdiff > 1).mean()))
+                assert float(np.abs(poses - cam0[2]).max()) > 1e-6                  # the camera is free, and moves
+            if gl > 0:
+                end = dict(G.export(), voxel_size=vs)
+                up = G.upsample(); G.free(); G = up
+                seed(ctx, end, (intr, dist, poses)); ctx.upsample()
+                same_grid(ctx.export_grid(), G.export(), f"upsampling from grid level {gl}")
+    G.free(); Fr.free()
+    with capsys.disabled():
+        print("\n[C5, stage by stage] " + "; ".join(f"g{gl}p{pl}: {n} voxels, attempts {att}, sdf {e['sdf']:.1e} albedo {e['alb']:.1e} intrinsics {e['intr']:.1e} poses {e['pose']:.1e}" for gl, pl, n, att, e in stages)
+              + f"; LDS-atomic modes against the default, one iteration: {worst['mode']:.1e}")
+    assert [(gl, pl) for gl, pl, *_ in stages] == [(2, 2), (2, 1), (2, 0), (1, 0), (0, 0)]

@@ -41,6 +41,7 @@ def test_sharded_processes_match_single_rank(tmp_path, transport):
     assert r.returncode == 0, r.stdout + r.stderr
     ref = np.load(base + ".rank0.npz")
     worlds = [w for w in (2, 4, 8) if w <= nd]
+    took_over = False
     for W in worlds:
         out = str(tmp_path / f"w{W}")
         r = _launch(W, [worker, out, "2", "12"], env_extra={"I3D_TRANSPORT": transport})
@@ -50,11 +51,14 @@ def test_sharded_processes_match_single_rank(tmp_path, transport):
             # the mailboxes carry the exchanges only when their start-up test passed on every rank: on a node where it does not, RCCL stays in charge and the run must still match
             assert str(d["transport"]).startswith("rccl") or (transport == "p2p" and str(d["transport"]).startswith("p2p-mailbox")), str(d["transport"])
             print(f"[multi-device] W = {W}, asked for {transport}: {d['transport']}")
+            took_over = took_over or (transport == "p2p" and str(d["transport"]).startswith("rccl"))
             assert np.array_equal(d["rows"], ref["rows"]) and np.array_equal(d["accepted"], ref["accepted"])
             assert np.all(np.abs(d["cost"] - ref["cost"]) <= 1e-4 * np.abs(ref["cost"]))
             assert np.abs(d["sdf"] - ref["sdf"]).max() <= 1e-4 * np.abs(ref["sdf"]).max() and np.abs(d["alb"] - ref["alb"]).max() <= 1e-4 * np.abs(ref["alb"]).max()
             np.testing.assert_allclose(d["intr"], ref["intr"], rtol=1e-4); np.testing.assert_allclose(d["poses"], ref["poses"], rtol=1e-4, atol=1e-6)
             assert int(d["halo_calls"]) > 0 and int(d["reduce_calls"]) > 0
+    if took_over:      # advisor finding of round 5: a mailbox bootstrap that fails must not read as "the p2p variant passed" — the run above re-tested RCCL
+        pytest.skip("I3D_TRANSPORT=p2p was asked for but the mailbox start-up test did not pass between these devices: RCCL carried the run (results matched); the mailbox transport stays unvalidated here")
 
 
 def test_bench_scales_over_the_devices_of_the_box(tmp_path):

@@ -141,7 +141,8 @@ def test_optimize_matches_oracle(setup):
     rc3, _, dist3, _, _ = O.optimize(g3, setup["fr"], ocfg, sc["intr"], sc["dist"], sc["poses"], setup["vsh"]); g3.free()
     assert rc3 == 0
     amp = np.abs(np.asarray(dist3) - np.asarray(dist)) / eps; err = np.abs(np.asarray(gd) - np.asarray(dist))
-    tol = np.maximum(1e-4 * np.abs(np.asarray(dist)), 1e-4 * amp) + 1e-12
+    # capped by the blanket bound of rounds 1-3 (advisor finding of round 5: one flipped discrete decision in the perturbed oracle run would inflate `amp` without limit)
+    tol = np.minimum(np.maximum(1e-4 * np.abs(np.asarray(dist)), 1e-4 * amp), 5e-3 * np.abs(np.asarray(dist)) + 5e-4) + 1e-12
     print(f"\n[distortion] oracle {np.asarray(dist)}\n  device error {err}\n  amplification (change per unit relative perturbation of the fields) {amp}\n  bound {tol}\n"
           f"  the device's error corresponds to a relative perturbation of {err / np.maximum(amp, 1e-30)} (bar: 1e-4)")
     assert np.all(err <= tol), (err, tol)
