@@ -4,10 +4,11 @@ oracle.refine (Intrinsic3D::refine, intrinsic3d.cpp:206-350).  configs[0] (C1) i
   C2  single level at 4 mm, fixed camera (poses, intrinsics, distortion), ONE global SH volume
   C3  3 grid levels (4 -> 2 -> 1 mm) x (3, 1, 1) pyramid levels, poses fixed, joint SDF + albedo + spatially varying SH, on a dataset folder
       in the reference's layout through apps/app_intrinsic3d and through the same flow in-process
-  C5  the same schedule with EVERY group free (poses, intrinsics, distortion: the shipped data/intrinsic3d.yml), noisy input poses
+  C5  the same schedule with EVERY group free (poses, intrinsics, distortion: the shipped data/intrinsic3d.yml), noisy input poses, on a textured object:
+      end to end (15 chained outer iterations) AND stage by stage from the oracle's state, both at 1e-4
 
-Structure (keys, visit order, weights) must be identical; fields are held to 1e-4 on the 99.9 % quantile and to
-max(1e-4, helpers.ENVELOPE_FACTOR x the oracle's own sensitivity to 1e-7 input perturbations) on the maximum."""
+Structure (keys, visit order, weights) must be identical; fields are held to 1e-4 on the 99.9 % quantile, and on the maximum to 1e-4 (C5) /
+max(1e-4, helpers.ENVELOPE_FACTOR x the oracle's own sensitivity to 1e-7 input perturbations) (C2, C3: never needed so far, the numbers are printed)."""
 import os
 import subprocess
 import sys
@@ -39,18 +40,18 @@ def _check_fields(out, ref, env, ordered=True, free_camera=False):
     assert (out["weight"] != ref["weight"]).mean() <= max(2e-4, helpers.ENVELOPE_FACTOR * env.get("key_frac", 0.0)), int((out["weight"] != ref["weight"]).sum())      # (a child next to a differing voxel interpolates other corners)
     d_sdf = np.abs(out["sdf_refined"] - ref["sdf_refined"]); d_alb = np.abs(out["albedo"] - ref["albedo"])
     smax = float(np.abs(ref["sdf_refined"]).max()); amax = float(np.abs(ref["albedo"]).max())
-    if free_camera:      # free poses on a near-symmetric object leave a gauge direction: the bulk of the field inside the reference computation's own spread (as in
-                         # test_gpu_levels.py::test_refine_two_levels_matches_oracle), the median far below it
-        print(f"\n[schedule, free camera] sdf: median {np.median(d_sdf) / smax:.2e}, 99.9 % {np.quantile(d_sdf, 0.999) / smax:.2e}, max {d_sdf.max() / smax:.2e} of max |sdf|; "
-              f"oracle's own spread under 1e-7 input perturbations {env['sdf_refined'] / smax:.2e}; albedo: median {np.median(d_alb):.2e}, 99.9 % {np.quantile(d_alb, 0.999):.2e}, "
-              f"max {d_alb.max():.2e}, spread {env['albedo']:.2e}; one-sided voxels under the perturbations {env.get('key_frac', 0.0):.2e}")
-        assert np.quantile(d_sdf, 0.999) <= max(1e-4 * smax, env["sdf_refined"]), (np.quantile(d_sdf, 0.999), smax, env)
-        assert np.quantile(d_alb, 0.999) <= max(1e-4 * amax, env["albedo"]), (np.quantile(d_alb, 0.999), amax, env)
+    print(f"\n[schedule{', free camera' if free_camera else ''}] sdf: median {np.median(d_sdf) / smax:.2e}, 99.9 % {np.quantile(d_sdf, 0.999) / smax:.2e}, max {d_sdf.max() / smax:.2e} of max |sdf|; "
+          f"oracle's own spread under 1e-7 input perturbations {env['sdf_refined'] / smax:.2e}; albedo: median {np.median(d_alb) / amax:.2e}, 99.9 % {np.quantile(d_alb, 0.999) / amax:.2e}, "
+          f"max {d_alb.max() / amax:.2e}, spread {env['albedo'] / amax:.2e}; one-sided voxels under the perturbations {env.get('key_frac', 0.0):.2e}")
+    assert np.quantile(d_sdf, 0.999) <= 1e-4 * smax, (np.quantile(d_sdf, 0.999), smax)
+    assert np.quantile(d_alb, 0.999) <= 1e-4 * amax, (np.quantile(d_alb, 0.999), amax)
+    if free_camera:      # C5 on the textured object: the plain bar on the maximum as well — no envelope (measured: sdf 5.3e-5, albedo 1.1e-5; the oracle's own spread
+                         # under 1e-7 perturbations of its input is 7e-3 / 1e-3, i.e. the device is two orders closer to the oracle than the oracle is to its perturbed self)
+        assert d_sdf.max() <= 1e-4 * smax, (d_sdf.max(), smax)
+        assert d_alb.max() <= 1e-4 * amax, (d_alb.max(), amax)
     else:
-        assert np.quantile(d_sdf, 0.999) <= 1e-4 * smax, (np.quantile(d_sdf, 0.999), smax)
-        assert np.quantile(d_alb, 0.999) <= 1e-4 * amax, (np.quantile(d_alb, 0.999), amax)
-    assert d_sdf.max() <= max(1e-4 * smax, helpers.ENVELOPE_FACTOR * env["sdf_refined"]), (d_sdf.max(), smax, env)
-    assert d_alb.max() <= max(1e-4 * amax, helpers.ENVELOPE_FACTOR * env["albedo"]), (d_alb.max(), env)
+        assert d_sdf.max() <= max(1e-4 * smax, helpers.ENVELOPE_FACTOR * env["sdf_refined"]), (d_sdf.max(), smax, env)
+        assert d_alb.max() <= max(1e-4 * amax, helpers.ENVELOPE_FACTOR * env["albedo"]), (d_alb.max(), env)
     cd = np.abs(out["color"].astype(int) - ref["color"].astype(int))
     # 8-bit truncation of colours computed from ~1e-7-different geometry; with a free camera the keyframe poses themselves differ inside the envelope and
     # the recolourisation samples the images elsewhere: as many components as the oracle's own perturbed runs change, times the one factor
@@ -171,30 +172,26 @@ def test_config_c3_three_level_schedule_through_the_app(oracle, tmp_path):
 
 
 def test_config_c5_full_joint_refinement_with_free_camera(oracle, tmp_path, capsys, monkeypatch):
-    """BASELINE.json configs[4] at test size: the FULL joint problem — SDF + albedo + spatially varying SH + poses + intrinsics + distortion, every switch of the
+    """BASELINE.json configs[4] at test size, END TO END: the FULL joint problem — SDF + albedo + spatially varying SH + poses + intrinsics + distortion, every switch of the
     shipped data/intrinsic3d.yml (fix_poses 0, fix_intrinsics 0, fix_distortion 0; 3 grid levels x (3, 1, 1) pyramid levels; subvolume_size_sh 0.2 m scaled to the
-    8 cm object: 0.03 m) — from a dataset folder with noisy input poses (2 mm / 0.2 deg) through apps/app_intrinsic3d, against oracle.refine (Intrinsic3D::refine,
-    refinement/intrinsic3d.cpp:229-290; Optimizer::optimize with the camera blocks free, optimizer.cpp:296-306).  Fields by key: 99.9 % quantile <= 1e-4, the
-    maximum inside the reference computation's own sensitivity (free poses on a near-symmetric object leave a gauge direction); poses / intrinsics reported.
-    Measured: on this 4 cm synthetic sphere the free-camera schedule WANDERS — the oracle's own poses move 5e-2 and its fields 4e-2 of max |sdf| when its input poses
-    are perturbed by 1e-7 (every scene variant tried: more bumps, more keyframes, no pose noise) — so this test shows that the whole pipeline agrees with the oracle
-    as far as the oracle agrees with itself (median 2e-4, 99.9 % 8e-3 of max |sdf|); the 1e-4 statements with free poses are the single-level tests."""
-    # Run in the bit-reproducible mode (I3D_DETERMINISTIC=1, inherited by the application's process): on this ill-conditioned problem two runs of the DEFAULT mode
-    # (fp32 LDS atomics inside the operator pass) end 1e-4 apart in the intrinsics — measured — which is the comparison between the application and the in-process
-    # flow below, not the parity with the oracle
-    monkeypatch.setenv("I3D_DETERMINISTIC", "1")
+    8 cm object: 0.03 m; 3 outer iterations per stage) — from a dataset folder with noisy input poses (2 mm / 0.2 deg) through apps/app_intrinsic3d and in-process, against
+    oracle.refine (Intrinsic3D::refine, refinement/intrinsic3d.cpp:229-290; Optimizer::optimize with the camera blocks free, optimizer.cpp:296-306), chained over all
+    15 outer iterations WITHOUT re-seeding.  Bars: keys and visit order identical; sdf and albedo <= 1e-4 of the field maximum on the 99.9 % quantile AND on the maximum;
+    poses <= 1e-4, intrinsics <= 1e-4 relative.  No envelope.  (Rounds 4-5 ran this on the untextured 4 cm sphere at fx 157, where the free poses are all but unconstrained and
+    the oracle's own result moves 4e-2 under 1e-7 perturbations: only an envelope test was possible there.  On the textured object — C5_TEXTURE below — the problem is still
+    sensitive (the oracle moves 7e-3 of max |sdf| under 1e-7 perturbations of its input poses, printed) but the device follows the oracle's trajectory: measured sdf
+    median 5e-7 / 99.9 % 7e-6 / max 5.3e-5, albedo max 1.1e-5, poses 2.5e-7, intrinsics 4.3e-7.)  The test below holds every stage on its own, from the oracle's state."""
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1")     # (the default on one rank; inherited by the application's process)
     r = _three_level_schedule(oracle, tmp_path, seed=35, fix_poses=0, fix_distortion=0, iterations=3, pose_noise=(0.002, 0.0035), subvolume=0.03, **C5_TEXTURE)
-    assert np.abs(r["poses"] - r["poses0"]).max() > 1e-5 and np.abs(r["intr"] - r["intr0"]).max() > 1e-4      # the camera did move
+    assert np.abs(r["poses"] - r["poses0"]).max() > 1e-3 and np.abs(r["intr"] - r["intr0"]).max() > 1e-2      # the camera did move
     with capsys.disabled():
-        _check_fields(r["out"], r["ref"], r["env"], ordered=False, free_camera=True)
-    # the camera against the oracle's: its own sensitivity to 1e-7 input perturbations (two perturbed re-runs) bounds what can be asked of poses on this object
-    spread_p, spread_i = r["env"]["poses"], r["env"]["intr"]
+        _check_fields(r["out"], r["ref"], r["env"], ordered=True, free_camera=True)
     d_pose = float(np.abs(r["poses"] - r["oposes"]).max()); d_intr = float(np.abs(r["intr"] - r["ointr"]).max() / np.abs(r["ointr"]).max())
     with capsys.disabled():
-        print(f"\n[C5] voxels on one side only under 1e-7 perturbations of the ORACLE's input: {r['env']['key_frac']:.2e} of the grid; poses: device vs oracle {d_pose:.3e} (oracle's own spread under 1e-7 input perturbations {spread_p:.3e}); intrinsics {d_intr:.3e} relative (spread {spread_i:.3e}); "
-              f"pose update {np.abs(r['poses'] - r['poses0']).max():.3e}")
-    assert d_intr <= max(1e-4, helpers.ENVELOPE_FACTOR * spread_i), (d_intr, spread_i)
-    assert d_pose <= max(1e-4 * max(1.0, float(np.abs(r["oposes"]).max())), helpers.ENVELOPE_FACTOR * spread_p), (d_pose, spread_p)
+        print(f"\n[C5] poses: device vs oracle {d_pose:.3e} (oracle's own spread under 1e-7 input perturbations {r['env']['poses']:.3e}); intrinsics {d_intr:.3e} relative "
+              f"(spread {r['env']['intr']:.3e}); pose update {np.abs(r['poses'] - r['poses0']).max():.3e}; one-sided voxels under the perturbations {r['env']['key_frac']:.2e}")
+    assert d_intr <= 1e-4, d_intr
+    assert d_pose <= 1e-4 * max(1.0, float(np.abs(r["oposes"]).max())), d_pose
 
 
 # The C5 test object: the 4 cm sphere of the other schedule tests, but TEXTURED (albedo pattern of ~2.5 cm wavelength in three incommensurate directions, 1 cm bumps)
