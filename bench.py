@@ -240,12 +240,13 @@ def roofline_of(name, kernels, Rg, A, world, attach_counters=True):
     tr = pmc_traffic(name, Rg, A) if (world == 1 and attach_counters) else None
     nsys = {"eg_mr2": 2, "eg_mr3": 3}.get(name, 1)
     out = {"kernel": {"build": "k_build<true>", "eg_pass": "k_eg_tile", "eg_mr2": "k_eg_tile_mr<2>", "eg_mr3": "k_eg_tile_mr<3>"}[name], "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+           "frac": k["achieved_GBs"] / HBM_PEAK_GBS, "traffic": tr[0] if tr else None, "traffic_measured_in_run": False,
            "traffic_source": (f"committed PMC passes of this command, profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated; not measured in this run)" if tr else None)}
     if nsys > 1:
         # one launch streams the rows ONCE (strict bytes: 4 nnz, what `achieved` / `frac` price) and applies them to `systems_per_launch` PCG systems of a ladder batch:
-        # `useful_*` = what the serial loop streams for the same work (4 nnz per system).  The pass is bound by instruction issue from two systems on, not by HBM.
-        out.update(systems_per_launch=nsys, useful_achieved=k["achieved_GBs"] * nsys, useful_frac=k["achieved_GBs"] * nsys / HBM_PEAK_GBS,
+        # `serial_equivalent_*` = what the serial loop would stream for the same work (4 nnz per system) per second of this launch, over the HBM peak: a RATIO that
+        # exceeds 1 by construction when systems share bytes — NOT a roofline fraction (round-5 review).  The roofline figure is `frac` (strict bytes).
+        out.update(systems_per_launch=nsys, serial_equivalent_GBs=k["achieved_GBs"] * nsys, serial_equivalent_bandwidth_ratio=k["achieved_GBs"] * nsys / HBM_PEAK_GBS,
                    bound=f"issue + latency at 2 waves per SIMD ({nsys} systems share every byte of the rows; no counters attached)")
     sq = sq_valu(name, Rg) if (world == 1 and attach_counters) else None
     if sq:
@@ -494,7 +495,7 @@ def _main():
     if ops:
         t_ms = sum(k["avg_ms"] * k["launches"] for k, _ in ops); gb = sum(k["algorithmic_GB"] * k["launches"] for k, _ in ops); ugb = sum(k["algorithmic_GB"] * k["launches"] * n for k, n in ops)
         roofline_operator = {"kernels": "k_eg_tile + k_eg_tile_mr<2> + k_eg_tile_mr<3>", "launches": sum(k["launches"] for k, _ in ops), "ms_total": t_ms, "achieved": gb / (t_ms * 1e-3), "frac": gb / (t_ms * 1e-3) / HBM_PEAK_GBS,
-                             "useful_achieved": ugb / (t_ms * 1e-3), "useful_frac": ugb / (t_ms * 1e-3) / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s", "systems_per_launch": ugb / gb}
+                             "serial_equivalent_GBs": ugb / (t_ms * 1e-3), "serial_equivalent_bandwidth_ratio": ugb / (t_ms * 1e-3) / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s", "systems_per_launch": ugb / gb}
     comm = None
     if sharded_run:
         # HIP events around the exchange launches that still are launches of their own (the rim push; with RCCL also the all-reduces).  Over the
@@ -521,6 +522,9 @@ def _main():
         pcg = [int(s.pcg_iterations[i]) for s in stats for i in range(s.num_attempts)]
         out = {
             "metric": "Gauss-Newton iterations/s at the finest SDF level", "value": args.steps / dt, "unit": "GN iterations/s",
+            # what the timed steps were (the schedule's iterations differ in weight: later ones take more PCG passes — the reason a 20-step run behind 5 warm-up steps
+            # reads lower than a 10-step run): LM attempts and PCG iterations of every attempt, per timed step
+            "lm_attempts": [int(s.num_attempts) for s in stats], "pcg_iterations": [[int(s.pcg_iterations[i]) for i in range(s.num_attempts)] for s in stats],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spin_up_s": args.spin_up, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"parallelism": f"{world} rank(s), one per GPU: replicated voxel state; tile-aligned ownership of the brick-ordered work list, rim rows recomputed as ghosts; "

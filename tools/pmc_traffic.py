@@ -42,23 +42,33 @@ def pick(rows, pattern, full_only=True):
 def main():
     fetch_dir, write_dir, bench_json, out = sys.argv[1:5]
     fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
-    # the calibration copy: the largest torch elementwise kernel
-    def copy_counter(rows):
-        best = None
-        for k, v in rows.items():
-            if "i3d::" in k or "rocprim" in k:
-                continue
-            m = max(v)
-            if best is None or m > best:
-                best = m
-        return best
-    cf, cw = copy_counter(fetch), copy_counter(write)
+    # The calibration copy: bench.py --pmc-calibrate clones a 2^28-float tensor three times (torch's copy kernel, 2^30 B read + 2^30 B written per launch).
+    # Round 5 took "the largest kernel that is neither the library's nor rocPRIM's" and got the HIP runtime's fill kernel instead (the 2.3 GB memset of the
+    # ladder slabs: WRITE_SIZE 2 257 042 instead of 1 048 576), which understated every write figure of that round by 2.15x.  Now: the copy is identified by NAME
+    # (a torch elementwise / copy kernel, never a runtime fill), must have been launched exactly as often as bench.py launches it, and the factors it yields must
+    # agree with what the guide prescribes for gfx950 (MI355X_MICROARCH.md, HBM: FETCH_SIZE counts a wide streaming read at half its bytes -> 2048 B per count;
+    # WRITE_SIZE in KiB -> 1024 B per count) to 5 % — or this tool fails.
+    CAL_LAUNCHES = 3
+    def copy_counter(rows, expect_raw):
+        cands = {k: v for k, v in rows.items() if not re.search(r"i3d::|rocprim|rocclr|fillBuffer|Memset|memset", k) and re.search(r"copy|elementwise|vectorized", k, re.I)}
+        audit = sorted(((k[:120], len(v), max(v)) for k, v in cands.items()), key=lambda t: -t[2])[:6]
+        exact = [(k, v) for k, v in cands.items() if len(v) == CAL_LAUNCHES]
+        if not exact:
+            raise SystemExit(f"pmc_traffic: no torch copy kernel with exactly {CAL_LAUNCHES} launches in the trace (was bench.py run with --pmc-calibrate?); candidates: {audit}")
+        k, v = min(exact, key=lambda kv: abs(max(kv[1]) / expect_raw - 1.0))
+        return max(v), k, audit
+    cf, name_f, audit_f = copy_counter(fetch, COPY_BYTES / 2048.0)
+    cw, name_w, audit_w = copy_counter(write, COPY_BYTES / 1024.0)
     f_read, f_write = COPY_BYTES / cf, COPY_BYTES / cw
+    if abs(f_read / 2048.0 - 1.0) > 0.05 or abs(f_write / 1024.0 - 1.0) > 0.05:
+        raise SystemExit(f"pmc_traffic: calibration off: {f_read:.1f} B per FETCH_SIZE count (expected 2048 +- 5 %), {f_write:.1f} B per WRITE_SIZE count (expected 1024 +- 5 %); "
+                         f"copy kernels picked: {name_f[:100]} / {name_w[:100]}; candidates {audit_f} / {audit_w}")
     bench = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 2 --warmup 1 --cpu-sample 0 --pmc-calibrate`",
            "calibration": {"copy_bytes": COPY_BYTES, "FETCH_SIZE_raw_of_copy": cf, "WRITE_SIZE_raw_of_copy": cw,
                            "bytes_per_FETCH_SIZE_count": f_read, "bytes_per_WRITE_SIZE_count": f_write,
-                           "note": "factor measured on a 16 B/lane streaming copy of 2^30 B; applied to every kernel below"},
+                           "copy_kernel": name_w[:160], "copy_launches": CAL_LAUNCHES,
+                           "note": "factor measured on a 16 B/lane streaming copy of 2^30 B (identified by name and launch count, asserted within 5 % of 2048 / 1024 B per count); applied to every kernel below"},
            "kernel_tag": bench.get("kernel_tag"), "eg_rows": bench["config"]["rows"]["Eg"], "active_voxels": bench["config"]["active_voxels"], "kernels": {}}
     for name, pat in KERNELS.items():
         if name == "copy_1GiB":
@@ -72,6 +82,9 @@ def main():
     for k in ("eg_pass", "eg_mr2", "eg_mr3", "build"):
         if k in res["kernels"] and k in bench.get("kernels", {}):
             res["kernels"][k]["algorithmic_bytes_per_launch"] = bench["kernels"][k]["algorithmic_GB"] * 1e9
+    # the build kernel stores 120 B per Eg row by construction: a write figure below that means the calibration (or the kernel match) is wrong
+    if "build" in res["kernels"] and res["kernels"]["build"]["write_bytes_per_launch"] < 120.0 * res["eg_rows"]:
+        raise SystemExit(f"pmc_traffic: k_build<true> write bytes {res['kernels']['build']['write_bytes_per_launch']:.3e} < 120 B x {res['eg_rows']} Eg rows — refusing to write {out}")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
