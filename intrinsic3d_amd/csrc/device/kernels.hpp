@@ -140,7 +140,7 @@ int  launch_eg_tile(hipStream_t st, RowView r, OptParams p, const float* u, Tile
 void launch_ext_offsets(hipStream_t st, int n, const int* ext_e, int A, int* ext_off);
 void eg_tile_launch_shape(const TilePlan& t, int K, int& blocks, int& tiles_per_block);      // workgroups / tiles per workgroup launch_eg_tile uses for this plan
 
-// ---- tile_pass_mr.hip: the operator pass for up to 3 systems of a ladder batch in ONE stream of the rows (512-entry geometry with pull lists, 5 observation slots, single rank) ----
+// ---- tile_pass_mr.hip: the operator pass for up to 3 systems of a ladder batch in ONE stream of the rows (512-entry geometry with pull lists, 5 observation slots; sharded: own + ghost tiles) ----
 struct LadVec;
 int  eg_tile_mr_max_systems(int K);        // systems one launch can take at K keyframes (LDS): 3 at K = 200, 0 = the pass cannot run
 int  launch_eg_tile_mr(hipStream_t st, RowView r, OptParams p, TilePlan t, int nsys, const int* sys, const float* u0, float* qacc0, float* qh0, double* pq0 /* or null */, float* cam0, int cam_stride,
@@ -178,6 +178,7 @@ struct Step3Args {
     PcgState* cur;
     int sharded; ShardArgs sh;              // sharded: p.q and the camera block are summed over the ranks inside the kernel; d2_partials[n_d2] = the camera tail's D^2 p^2 (replicated, counted once)
     int lad_sys;                            // -1: 1 / radius from lm->inv_radius; >= 0: system of a ladder batch, lm->lad_inv_radius[lad_sys]
+    const double* redop; int redop_stride;  // sharded ladder pass (exchanges as launches): [camera block 6K+9 | p.q] of system j, summed over the ranks, at redop + j * redop_stride; null otherwise
 };
 void launch_pcg_init3(hipStream_t st, PcgState* st2 /* [2] */, int fixed_iterations, int max_iterations, const LmState* lm = nullptr);
 int  launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int ntail, const float* z, float* p, const float* S, float* u, const float* D2, const float* cm, const LmState* lm,
@@ -191,8 +192,13 @@ void launch_halo_fold(hipStream_t st, RowView r, TilePlan t, float* qacc, const 
 // ladder batch: the same kernels over several systems at once (blockIdx.y; the arithmetic of a system does not change)
 void launch_pcg_init_lad(hipStream_t st, PcgState* st2_all /* [LADDER_MAX][2] */, int B, int fixed_iterations, int max_iterations, const LmState* lm);
 int  launch_pcg_dir3_lad(hipStream_t st, bool init, int nsys, Seg2 sg, size_t tail_off, int ntail, const float* z0, float* p0, const float* S, float* u0, const float* tD2_0, const float* cm, const LmState* lm,
-                         const double* step_partials0, int n_step, double* d2_partials0, PcgState* st2_0, int prev_parity, int* host_flags0, int seq, const LadVec& lv);
-int  launch_pcg_step3_lad(hipStream_t st, int mode, int nsys, Step3Args a, const LadVec& lv);
+                         const double* step_partials0, int n_step, double* d2_partials0, PcgState* st2_0, int prev_parity, int* host_flags0, int seq, const LadVec& lv,
+                         int n_slice_partials = 0, const double* red4_0 = nullptr /* sharded: [LADDER_MAX][4] slice sums over all ranks; the tail then has a workgroup of its own */);
+int  launch_pcg_step3_lad(hipStream_t st, int mode, int nsys, Step3Args a, const LadVec& lv);      // a.redop != null: sharded (see Step3Args)
+// sharded ladder pass: a rank's contributions to the two all-reduces of a pass, all live systems in one launch each
+void launch_lad_reduce_step(hipStream_t st, int nsys, const double* step_partials0, int n_slice, double* red4_0, const LadVec& lv);
+void launch_lad_reduce_op(hipStream_t st, int nsys, const float* cam_partials0, int n_cam, int cam_stride, int NS, const double* pq_partials0, int n_pq, const double* d2_partials0, int n_d2,
+                          double* redop0, int redop_stride, const LadVec& lv);
 
 // ---- shard_kernels.hip: the sharding plan of one outer iteration ----------------------------------------------------------------
 void launch_need_mask(hipStream_t st, RowView r, int slice, unsigned long long* need /* [A], zeroed */);

@@ -78,27 +78,34 @@ static __device__ inline void lm_from_colnorm(float cm, float inv_radius, float&
 // at [0, n_main) (slice) and [n_main] (tail, counted once by k_pcg_step3 after ITS exchange).
 // (the body of the kernel: shared by the single-system launch and the ladder launch, whose workgroups pick their system by blockIdx.y — the SAME arithmetic in the
 // same order, so a system iterated in a ladder batch goes through bit for bit the states it goes through alone)
-template <bool SH>
+// SH = 2 (round 6: sharded run whose exchanges are LAUNCHES of the transport — RCCL, the rank simulation): the workgroup roles of SH = 1 without rim workgroups; the four
+// slice sums arrive already summed over the ranks in sa_red4 (k_lad_reduce_step + one all-reduce in front of this kernel), the camera tail's partial rows are added locally.
+template <int SH>
 static __device__ __forceinline__ void pcg_dir3_body(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
                                                         const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ tD2 /* LM diagonal of the camera tail, [ntail] */,
                                                         const float* __restrict__ cm, const float inv_radius, const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
-                                                        const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq, const ShardArgs& sa) {
+                                                        const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq, const ShardArgs& sa,
+                                                        const double* __restrict__ red4 = nullptr /* SH = 2: [4] slice sums over all ranks */) {
     __shared__ double sm[4 * 8];
-    __shared__ double smx[SH ? 4 * P2P_MAX_RANKS : 1];
+    __shared__ double smx[SH == 1 ? 4 * P2P_MAX_RANKS : 1];
     // (seq, done) goes to a 2-slot ring in pinned host memory: the host polls it one pass behind
     auto publish = [&](int done) { if (host_flags) { __hip_atomic_store(&host_flags[2 * (seq & 1) + 1], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                                      __hip_atomic_store(&host_flags[2 * (seq & 1)], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); } };
     // logical workgroup: 0 .. n_main - 1 slice, n_main the camera tail (SH only), beyond: rim
-    const int n_rim = SH ? sa.n_rim_wg : 0, n_main = SH ? (int)gridDim.x - n_rim - 1 : (int)gridDim.x;
-    const int lid = SH ? ((int)blockIdx.x < n_rim ? n_main + 1 + (int)blockIdx.x : (int)blockIdx.x - n_rim) : (int)blockIdx.x;
-    const bool rim_wg = SH && lid > n_main, tail_wg = SH ? lid == n_main : lid == n_main - 1;
+    const int n_rim = SH == 1 ? sa.n_rim_wg : 0, n_main = SH ? (int)gridDim.x - n_rim - 1 : (int)gridDim.x;
+    const int lid = SH == 1 ? ((int)blockIdx.x < n_rim ? n_main + 1 + (int)blockIdx.x : (int)blockIdx.x - n_rim) : (int)blockIdx.x;
+    const bool rim_wg = SH == 1 && lid > n_main, tail_wg = SH ? lid == n_main : lid == n_main - 1;
     const bool writer = lid == 0 && threadIdx.x == 0;
     const float4* z4 = reinterpret_cast<const float4*>(z); float4* p4 = reinterpret_cast<float4*>(p);
     const float4* C4 = reinterpret_cast<const float4*>(cm); float4* u4 = reinterpret_cast<float4*>(u);
     if (prev->done) { if (writer) { *next = *prev; publish(prev->done); } return; }      // (the same decision on every rank: the state is replicated bit for bit)
     double tot[4];
     if (!SH) reduce_partials_all<4>(step_partials, n_step, tot, sm);
-    else {
+    else if (SH == 2) {
+        reduce_partials_all<4>(step_partials + 4 * (size_t)sa.n_slice_partials, n_step - sa.n_slice_partials, tot, sm);           // the camera tail (replicated)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot[k] += red4[k];
+    } else {
         const unsigned e32 = p2p_pass_epoch(seq, P2P_X_DIR);
         if (rim_wg) {                                                // z on the owned rim -> the peers' mailboxes, before any wait
             const RimLists& rl = sa.rim;
@@ -182,23 +189,25 @@ static __device__ __forceinline__ void pcg_dir3_body(int init, int n4, int seg4,
     }
     { const double t = block_sum_d(d2); if (threadIdx.x == 0) d2_partials[lid] = t; }
 }
-template <bool SH>
+template <int SH>
 __global__ void __launch_bounds__(PF_THREADS, SH ? 4 : 1) k_pcg_dir3(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z, float* __restrict__ p,
                                                         const float* __restrict__ S, float* __restrict__ u, const float* __restrict__ D2 /* S, D2: the camera tail */,
                                                         const float* __restrict__ cm, const LmState* __restrict__ lm, const double* __restrict__ step_partials, int n_step, double* __restrict__ d2_partials,
                                                         const PcgState* __restrict__ prev, PcgState* __restrict__ next, int* host_flags, int seq, ShardArgs sa) {
     pcg_dir3_body<SH>(init, n4, seg4, tail_rel, ntail, z, p, S, u, D2 + tail_rel, cm, lm->inv_radius /* (uniform: a scalar load) */, step_partials, n_step, d2_partials, prev, next, host_flags, seq, sa);
 }
-// ladder batch (single rank): blockIdx.y picks the system; its vectors, partial sums, scalar states and host ring lie at fixed strides behind system 0's
+// ladder batch: blockIdx.y picks the system; its vectors, partial sums, scalar states and host ring lie at fixed strides behind system 0's.  COLL: a sharded run
+// (SH = 2 of the body): the last workgroup is the camera tail's, the slice sums of system j come from red4_0 + 4 j.
+template <bool COLL>
 __global__ void __launch_bounds__(PF_THREADS, 1) k_pcg_dir3_lad(int init, int n4, int seg4, size_t tail_rel, int ntail, const float* __restrict__ z0, float* __restrict__ p0,
                                                         const float* __restrict__ S, float* __restrict__ u0, const float* __restrict__ tD2_0, const float* __restrict__ cm, const LmState* __restrict__ lm,
                                                         const double* __restrict__ step_partials0, int n_step, double* __restrict__ d2_partials0, PcgState* __restrict__ st2_0 /* [system][2] */, int prev_parity,
-                                                        int* host_flags0, int seq, LadVec lv) {
+                                                        int* host_flags0, int seq, LadVec lv, int n_slice_partials, const double* __restrict__ red4_0) {
     const int j = lv.sysid[blockIdx.y];
-    ShardArgs none; none.n_rim_wg = 0;
+    ShardArgs none; none.n_rim_wg = 0; none.n_slice_partials = n_slice_partials;
     const size_t vo = (size_t)j * lv.vec;
-    pcg_dir3_body<false>(init, n4, seg4, tail_rel, ntail, z0 + vo, p0 + vo, S, u0 + vo, tD2_0 + (size_t)j * lv.tail, cm, lm->lad_inv_radius[j], step_partials0 + (size_t)j * lv.part, n_step,
-                         d2_partials0 + (size_t)j * lv.part, st2_0 + 2 * j + prev_parity, st2_0 + 2 * j + (prev_parity ^ 1), host_flags0 + 4 * j, seq, none);
+    pcg_dir3_body<COLL ? 2 : 0>(init, n4, seg4, tail_rel, ntail, z0 + vo, p0 + vo, S, u0 + vo, tD2_0 + (size_t)j * lv.tail, cm, lm->lad_inv_radius[j], step_partials0 + (size_t)j * lv.part, n_step,
+                                d2_partials0 + (size_t)j * lv.part, st2_0 + 2 * j + prev_parity, st2_0 + 2 * j + (prev_parity ^ 1), host_flags0 + 4 * j, seq, none, COLL ? red4_0 + 4 * j : nullptr);
 }
 
 static int dir3_main_wgs(int n_entries, int cap) { int b = (n_entries / 2 + PF_THREADS - 1) / PF_THREADS; b = b < 1 ? 1 : b; return b > cap ? cap : b; }      // 2 * (n / 4) float4 items
@@ -210,24 +219,29 @@ int launch_pcg_dir3(hipStream_t st, bool init, Seg2 sg, size_t tail_off, int nta
     if (!sa) {
         const int blocks = dir3_main_wgs(sg.n, PF_MAX_WG);
         ShardArgs none; std::memset(&none, 0, sizeof(none));
-        k_pcg_dir3<false><<<blocks, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, lm, step_partials, n_step, d2_partials, prev, next, host_flags, seq, none);
+        k_pcg_dir3<0><<<blocks, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, lm, step_partials, n_step, d2_partials, prev, next, host_flags, seq, none);
         return blocks;
     }
     const int cap = sa->pd.wg_cap > 0 ? sa->pd.wg_cap : PF_MAX_WG;
     const int n_main = dir3_main_wgs(sg.n, cap);
-    k_pcg_dir3<true><<<sa->n_rim_wg + n_main + 1, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, lm, step_partials, n_step, d2_partials, prev, next,
+    k_pcg_dir3<1><<<sa->n_rim_wg + n_main + 1, PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z + o, p + o, S + o, u + o, D2 + o, cm + o, lm, step_partials, n_step, d2_partials, prev, next,
                                                                        host_flags, seq, *sa);
     return n_main;
 }
 
 // all systems of `lv` in one launch; returns the number of D^2 p^2 partials per system
 int launch_pcg_dir3_lad(hipStream_t st, bool init, int nsys, Seg2 sg, size_t tail_off, int ntail, const float* z0, float* p0, const float* S, float* u0, const float* tD2_0, const float* cm, const LmState* lm,
-                        const double* step_partials0, int n_step, double* d2_partials0, PcgState* st2_0, int prev_parity, int* host_flags0, int seq, const LadVec& lv) {
+                        const double* step_partials0, int n_step, double* d2_partials0, PcgState* st2_0, int prev_parity, int* host_flags0, int seq, const LadVec& lv,
+                        int n_slice_partials, const double* red4_0) {
     const int n4 = sg.n >> 2, seg4 = (int)((sg.off1 - sg.off0) >> 2);
     const size_t o = sg.off0;
     const int blocks = dir3_main_wgs(sg.n, PF_MAX_WG);
-    k_pcg_dir3_lad<<<dim3(blocks, nsys), PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z0 + o, p0 + o, S + o, u0 + o, tD2_0, cm + o, lm, step_partials0, n_step, d2_partials0,
-                                                              st2_0, prev_parity, host_flags0, seq, lv);
+    if (red4_0)         // sharded: the camera tail in a workgroup of its own (its D^2 p^2 partial follows the slice's at index `blocks`)
+        k_pcg_dir3_lad<true><<<dim3(blocks + 1, nsys), PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z0 + o, p0 + o, S + o, u0 + o, tD2_0, cm + o, lm, step_partials0, n_step, d2_partials0,
+                                                                            st2_0, prev_parity, host_flags0, seq, lv, n_slice_partials, red4_0);
+    else
+        k_pcg_dir3_lad<false><<<dim3(blocks, nsys), PF_THREADS, 0, st>>>(init ? 1 : 0, n4, seg4, tail_off - o, ntail, z0 + o, p0 + o, S + o, u0 + o, tD2_0, cm + o, lm, step_partials0, n_step, d2_partials0,
+                                                                         st2_0, prev_parity, host_flags0, seq, lv, 0, nullptr);
     return blocks;
 }
 
@@ -282,10 +296,12 @@ template <int MODE> static __device__ inline void s3_load(const Step3Args& a, co
 // SH (sharded run over the mailboxes): the second exchange of a pass happens in here — this rank's p.q (rows it owns + D^2 p^2 of its slice) is summed over the
 // ranks in the prologue of EVERY workgroup (workgroup 0 stores it into all mailboxes), and the camera workgroups sum their columns of the operator's camera
 // block over the ranks before they update the (replicated) camera tail.  No launch of its own, no vector leaves a rank.
-template <int MODE, bool SH>
+// SH = 2 (round 6): the sharded run whose exchanges are launches of the transport — [camera block | p.q] of this system arrive summed over the ranks in a.redop
+// (k_lad_reduce_op + one all-reduce in front of this kernel): p.q of the slices at [6K + 9], the camera tail's D^2 p^2 (replicated, counted once) added locally.
+template <int MODE, int SH>
 static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a, const S3Off& o) {
     __shared__ double sm[4 * 8];
-    __shared__ double smx[SH ? P2P_MAX_RANKS : 1];
+    __shared__ double smx[SH == 1 ? P2P_MAX_RANKS : 1];
     __shared__ double camv[64];
     __shared__ double camred[8][64];
     __shared__ float rs[64];
@@ -308,8 +324,9 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a, const 
     float alpha = 0.0f;
     if (MODE == S3_NORMAL || MODE == S3_XONLY) {                     // p.q = sum over rows of t (J u) + sum D^2 p^2  ->  alpha = rho / p.q
         double t1[1];
-        reduce_partials_all<1>(pq_partials, a.n_pq, t1, sm, d2_partials, a.n_d2);      // both lists in ONE reduction (one barrier pair instead of two)
-        if (SH) {
+        if (SH == 2) t1[0] = a.redop[(size_t)(o.sys < 0 ? 0 : o.sys) * a.redop_stride + 6 * a.K + 9] + d2_partials[a.n_d2];
+        else reduce_partials_all<1>(pq_partials, a.n_pq, t1, sm, d2_partials, a.n_d2);      // both lists in ONE reduction (one barrier pair instead of two)
+        if (SH == 1) {
             const unsigned e32 = p2p_pass_epoch(a.sh.seq, P2P_X_STEP);
             if (blockIdx.x == 0 && threadIdx.x == 0) p2p_put_double_all(a.sh.pd, 1, e32, 0, t1[0]);
             p2p_sum_all<1>(a.sh.pd, 1, e32, t1, smx);
@@ -395,12 +412,13 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a, const 
         if (MODE == S3_NORMAL || MODE == S3_RESET) {                 // column sums of the operator's camera partials (one float row per workgroup), fixed order
             const int g = t / 64, c = t % 64;                        // 8 row groups x 64 columns
             double v = 0.0;
-            if (c < ncol) for (int w = g; w < a.n_cam; w += 8) v += (double)cam_partials[(size_t)w * a.cam_stride + col0 + c];
+            if (SH != 2 && c < ncol) for (int w = g; w < a.n_cam; w += 8) v += (double)cam_partials[(size_t)w * a.cam_stride + col0 + c];
             camred[g][c] = v;
             __syncthreads();
             if (t < ncol) {
                 double s = 0.0; for (int gg = 0; gg < 8; ++gg) s += camred[gg][t];
-                if (SH) {       // this rank's column sums (rows it owns) -> all ranks; the total in rank order
+                if (SH == 2) s = a.redop[(size_t)(o.sys < 0 ? 0 : o.sys) * a.redop_stride + col0 + t];      // summed over the workgroups (k_lad_reduce_op) and the ranks (all-reduce)
+                if (SH == 1) {       // this rank's column sums (rows it owns) -> all ranks; the total in rank order
                     const unsigned e32 = p2p_pass_epoch(a.sh.seq, MODE == S3_RESET ? P2P_X_RESET_STEP : P2P_X_STEP);
                     p2p_put_double_all(a.sh.pd, 1, e32, 1 + col0 + t, s);
                     s = 0.0; for (int j = 0; j < a.sh.pd.L.world; ++j) s += p2p_get_double(a.sh.pd, 1, e32, j, 1 + col0 + t);
@@ -444,14 +462,14 @@ static __device__ __forceinline__ void pcg_step3_body(const Step3Args& a, const 
     if (MODE == S3_XONLY) return;
     block_partial_d(s0, step_partials, 4, 0); block_partial_d(s1, step_partials, 4, 1); block_partial_d(s2, step_partials, 4, 2); block_partial_d(s3, step_partials, 4, 3);
 }
-template <int MODE, bool SH>
+template <int MODE, int SH>
 __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3(Step3Args a) { const S3Off o{0, 0, 0, 0, 0, 0, 0, 0, -1}; pcg_step3_body<MODE, SH>(a, o); }
 // ladder batch (single rank): blockIdx.y picks the system (see k_pcg_dir3_lad); `a` holds system 0's pointers
-template <int MODE>
+template <int MODE, bool COLL>
 __global__ void __launch_bounds__(PF_THREADS) k_pcg_step3_lad(Step3Args a, LadVec lv) {
     const int j = lv.sysid[blockIdx.y];
     const S3Off o{((size_t)j * lv.vec) >> 2, (size_t)j * lv.vec, ((size_t)j * lv.qh) >> 1, (size_t)j * lv.part, (size_t)j * lv.cam, (size_t)j * lv.mblk, (size_t)j * lv.tail, 2 * j, j};
-    pcg_step3_body<MODE, false>(a, o);
+    pcg_step3_body<MODE, COLL ? 2 : 0>(a, o);
 }
 
 int pcg_step3_slice_wgs(int n_entries, int cap) { if (cap <= 0 || cap > PF_MAX_WG) cap = PF_MAX_WG; int b = (n_entries / 4 + PF_THREADS - 1) / PF_THREADS; return b < 1 ? 1 : (b > cap ? cap : b); }
@@ -460,7 +478,7 @@ int pcg_step3_tail_wgs(int K) { return (K + PF_POSES_PER_WG - 1) / PF_POSES_PER_
 // returns the number of [4]-partials written (0 in XONLY mode)
 int launch_pcg_step3(hipStream_t st, int mode, Step3Args a) {
     const int blocks = a.n_slice_wg + pcg_step3_tail_wgs(a.K);
-#define I3D_S3(M) do { if (a.sharded) k_pcg_step3<M, true><<<blocks, PF_THREADS, 0, st>>>(a); else k_pcg_step3<M, false><<<blocks, PF_THREADS, 0, st>>>(a); } while (0)
+#define I3D_S3(M) do { if (a.sharded) k_pcg_step3<M, 1><<<blocks, PF_THREADS, 0, st>>>(a); else k_pcg_step3<M, 0><<<blocks, PF_THREADS, 0, st>>>(a); } while (0)
     switch (mode) {
         case S3_INIT:   I3D_S3(S3_INIT); break;
         case S3_NORMAL: I3D_S3(S3_NORMAL); break;
@@ -475,13 +493,55 @@ int launch_pcg_step3(hipStream_t st, int mode, Step3Args a) {
 int launch_pcg_step3_lad(hipStream_t st, int mode, int nsys, Step3Args a, const LadVec& lv) {
     const int blocks = a.n_slice_wg + pcg_step3_tail_wgs(a.K);
     const dim3 grid(blocks, nsys);
+#define I3D_S3L(M) do { if (a.redop) k_pcg_step3_lad<M, true><<<grid, PF_THREADS, 0, st>>>(a, lv); else k_pcg_step3_lad<M, false><<<grid, PF_THREADS, 0, st>>>(a, lv); } while (0)
     switch (mode) {
-        case S3_INIT:   k_pcg_step3_lad<S3_INIT><<<grid, PF_THREADS, 0, st>>>(a, lv); break;
-        case S3_NORMAL: k_pcg_step3_lad<S3_NORMAL><<<grid, PF_THREADS, 0, st>>>(a, lv); break;
-        case S3_XONLY:  k_pcg_step3_lad<S3_XONLY><<<grid, PF_THREADS, 0, st>>>(a, lv); break;
-        default:        k_pcg_step3_lad<S3_RESET><<<grid, PF_THREADS, 0, st>>>(a, lv); break;
+        case S3_INIT:   I3D_S3L(S3_INIT); break;
+        case S3_NORMAL: I3D_S3L(S3_NORMAL); break;
+        case S3_XONLY:  I3D_S3L(S3_XONLY); break;
+        default:        I3D_S3L(S3_RESET); break;
     }
+#undef I3D_S3L
     return mode == S3_XONLY ? 0 : blocks;
+}
+
+// Sharded ladder pass (round 6), the exchanges as launches of the transport: what a rank contributes to the two all-reduces of a pass, for every live system at once.
+//   k_lad_reduce_step : red4[j][0..3]   = this rank's four slice sums of k_pcg_step3 (its first n_slice partial rows; the camera tail's rows stay local: replicated)
+//   k_lad_reduce_op   : redop[j][0..NS) = column sums of this rank's camera partial rows of the operator pass (the rows it owns), redop[j][NS] = its p.q (rows it owns + D^2 p^2 of its slice)
+// Fixed summation orders (the shapes of reduce_partials_all / of k_pcg_step3's camera workgroups): a rank's contribution is bit-reproducible; the all-reduce adds the ranks'.
+__global__ void __launch_bounds__(PF_THREADS) k_lad_reduce_step(const double* __restrict__ step_partials0, int n_slice, double* __restrict__ red4_0, LadVec lv) {
+    __shared__ double sm[4 * 8];
+    const int j = lv.sysid[blockIdx.x];
+    double tot[4];
+    reduce_partials_all<4>(step_partials0 + (size_t)j * lv.part, n_slice, tot, sm);
+    if (threadIdx.x < 4) red4_0[4 * j + threadIdx.x] = threadIdx.x == 0 ? tot[0] : threadIdx.x == 1 ? tot[1] : threadIdx.x == 2 ? tot[2] : tot[3];
+}
+void launch_lad_reduce_step(hipStream_t st, int nsys, const double* step_partials0, int n_slice, double* red4_0, const LadVec& lv) {
+    k_lad_reduce_step<<<nsys, PF_THREADS, 0, st>>>(step_partials0, n_slice, red4_0, lv);
+}
+__global__ void __launch_bounds__(PF_THREADS) k_lad_reduce_op(const float* __restrict__ cam_partials0, int n_cam, int cam_stride, int NS, const double* __restrict__ pq_partials0, int n_pq,
+                                                              const double* __restrict__ d2_partials0, int n_d2, double* __restrict__ redop0, int redop_stride, LadVec lv) {
+    __shared__ double sm[8];
+    __shared__ double camred[8][64];
+    const int j = lv.sysid[blockIdx.y];
+    double* const out = redop0 + (size_t)j * redop_stride;
+    const int ncw = (NS + 63) / 64;
+    if ((int)blockIdx.x < ncw) {                                     // 64 columns of the camera block: 8 row groups, then the groups in order
+        const int t = threadIdx.x, g = t / 64, c = t % 64, col = (int)blockIdx.x * 64 + c;
+        const float* cp = cam_partials0 + (size_t)j * lv.cam;
+        double v = 0.0;
+        if (col < NS) for (int w = g; w < n_cam; w += 8) v += (double)cp[(size_t)w * cam_stride + col];
+        camred[g][c] = v;
+        __syncthreads();
+        if (t < 64 && col < NS) { double s = 0.0; for (int gg = 0; gg < 8; ++gg) s += camred[gg][t]; out[col] = s; }
+    } else {
+        double t1[1];
+        reduce_partials_all<1>(pq_partials0 + (size_t)j * lv.part, n_pq, t1, sm, d2_partials0 + (size_t)j * lv.part, n_d2);
+        if (threadIdx.x == 0) out[NS] = t1[0];
+    }
+}
+void launch_lad_reduce_op(hipStream_t st, int nsys, const float* cam_partials0, int n_cam, int cam_stride, int NS, const double* pq_partials0, int n_pq, const double* d2_partials0, int n_d2,
+                          double* redop0, int redop_stride, const LadVec& lv) {
+    k_lad_reduce_op<<<dim3((NS + 63) / 64 + 1, nsys), PF_THREADS, 0, st>>>(cam_partials0, n_cam, cam_stride, NS, pq_partials0, n_pq, d2_partials0, n_d2, redop0, redop_stride, lv);
 }
 
 // ladder batch: both states of every system; a system whose radius has run out (k_lm_begin_lad) starts finished

@@ -129,10 +129,14 @@ struct MrArgs {
     int sys[3];                            // the systems of this launch
 };
 
-template <int NB>
+// GHOSTS (sharded runs, round 6): as in k_eg_tile — the tile list is this rank's own tiles [tile_first, tile_first + n_own) followed by the foreign tiles that hold its ghost
+// entries; p.q, the intrinsics / distortion sums and the pose block count a row ONCE, on the rank that owns its voxel (`owned`), while the voxel columns of every row this
+// rank streams (owned and ghost) land in its accumulators.  A template parameter: the single-rank kernel keeps its registers.
+template <int NB, bool GHOSTS>
 __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, MrArgs m, const unsigned* __restrict__ lnbr, const float* __restrict__ eaw_sym, const int* __restrict__ halo_idx,
                                                         const int* __restrict__ halo_cnt, int tiles_per_block, int ntl, int cam_stride, const int* __restrict__ gmaxv,
-                                                        const unsigned short* __restrict__ hp_off, const unsigned short* __restrict__ hp_src) {
+                                                        const unsigned short* __restrict__ hp_off, const unsigned short* __restrict__ hp_src,
+                                                        int tile_first, int n_own, const int* __restrict__ ghost_list) {
     constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, ZSLOT = T + HMAX, NCOL = 12, HPCAP = 4 * HMAX, NQH = HMAX / T;
     // A system that has stopped (the host drops it from the launches one pass after it saw the flag) is carried without arithmetic: its inputs are still staged — the
     // loads of a tile are unconditional — but its rows, its pull phase and its outputs are skipped (workgroup-uniform branches: the state is read once per launch).
@@ -182,9 +186,10 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
     const int tk_end = min(tile0 + tiles_per_block, ntl);
 
     // the tile in flight (names as in k_eg_tile)
-    int tile = 0, base = 0, a = 0, H = 0, nr_ld = 0; bool in = false; size_t ac = 0;
+    int tile = 0, base = 0, a = 0, H = 0, nr_ld = 0; bool in = false, owned = false; size_t ac = 0;
     uint8_t fl = 0, rf_ld = 0; unsigned ln[5]; RowBlock rwA, rwB;
     float us[NB], ua[NB], hs[NB][NQH], ha[NB][NQH];
+    auto tile_of = [&](int tk) { return (GHOSTS && tk >= n_own) ? ghost_list[tk - n_own] : (GHOSTS ? tile_first + tk : tk); };
     constexpr int NQL = (HPCAP / 8 + T - 1) / T, NQO = (HMAX + 1 + T - 1) / T;
     uint4 hpl[NQL]; unsigned short hpo[NQO];
     const char* wave_rows = reinterpret_cast<const char*>(r.rows);
@@ -198,12 +203,13 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
         { const v2u_b t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane16 >> 1, k * (ROW_BLOCK_F4 * 16) + 64 * ROW_PLANES * 16, 2); rw.j28 = __uint_as_float(t.x); rw.tag = (int)t.y; }
     };
     auto group_rows = [&](int tk) -> int {
-        const int wa0 = tk * T + (int)(threadIdx.x & ~63u);
+        const int wa0 = tile_of(tk) * T + (int)(threadIdx.x & ~63u);
         const int grp = __builtin_amdgcn_readfirstlane(wa0 < A ? (wa0 >> 6) : -1);
         return grp >= 0 ? gmaxv[grp] : 0;
     };
     auto issue_in = [&](int tk) {
-        tile = tk; base = tile * T; a = base + i; in = a < A; ac = in ? (size_t)a : 0;
+        tile = tile_of(tk); base = tile * T; a = base + i; in = a < A; ac = in ? (size_t)a : 0;
+        owned = GHOSTS ? (a >= r.own0 && a < r.own1) : in;          // p.q and the camera block count a row once: on the rank that owns its voxel
         { const int wa0 = base + (int)(threadIdx.x & ~63u);
           const unsigned grp = (unsigned)__builtin_amdgcn_readfirstlane(wa0 < A ? (wa0 >> 6) : 0);
           wave_rows = reinterpret_cast<const char*>(r.rows + (size_t)grp * (size_t)(r.slots * ROW_BLOCK_F4)); }
@@ -269,11 +275,11 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
             const float usb = lds[U_S(b) + i];
             if (rf & 1) {
                 const float lap = ((((((-6.0f * usb) + lds[U_S(b) + rg[0]]) + lds[U_S(b) + rg[1]]) + lds[U_S(b) + rg[2]]) + lds[U_S(b) + rg[3]]) + lds[U_S(b) + rg[4]]) + lds[U_S(b) + rg[5]];
-                tr = tw1 * lap; if (in) pq_pre += (double)(tr * lap);
+                tr = tw1 * lap; if (owned) pq_pre += (double)(tr * lap);
                 self_s[b] += -6.0f * tr;
             }
             lds[TR_L(b) + i] = tr;
-            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * usb; if (in) pq_pre += (double)(ts * usb); self_s[b] += ts; }
+            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * usb; if (owned) pq_pre += (double)(ts * usb); self_s[b] += ts; }
             if (rf & 7) PQ_L(b)[i] += pq_pre;
         }
         // the lane's 9 forward stencil slots (sdf slots 1..9 of a row): the same for every row of the entry and for every system
@@ -346,14 +352,14 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #pragma unroll
                     for (int c = 1; c < 10; ++c) C[b][c - 1] = fmaf(J[c], t, C[b][c - 1]);
                     C[b][9] = fmaf(J[11], t, C[b][9]); C[b][10] = fmaf(J[12], t, C[b][10]); C[b][11] = fmaf(J[13], t, C[b][11]);
-                    if (in) {
+                    if (owned) {
 #pragma unroll
                         for (int q = 0; q < 9; ++q) cam9[b][q] = fmaf(J[P_INTR + q], t, cam9[b][q]);
                     }
                     tsel[b] = t;
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (!p.fix_poses && in) { fsel = f; pvalid = true; }
+                if (!p.fix_poses && owned) { fsel = f; pvalid = true; }
             }
             const float jp[6] = {rw[3].z, rw[3].w, rw[4].x, rw[4].y, rw[4].z, rw[4].w};      // pose columns 14..19 of the row
             if (reload >= 0) load_block(rb, reload);
@@ -364,7 +370,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
         consume(rwA, 2, 4);
         consume(rwB, 3, -1);
         consume(rwA, 4, -1);
-        if (in) {
+        if (owned) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) PQ_L(b)[i] += (double)pq_rows[b];
         }
@@ -402,7 +408,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                 float ea = 0.0f, eq = 0.0f;
 #pragma unroll
                 for (int d = 0; d < 6; ++d) { const float diff = ua_c - lds[U_A(b) + rg[d]]; const float t = eaw[d] * diff; ea += t; eq += (rg[d] == ZSLOT ? 1.0f : 0.5f) * t * diff; }
-                qa += tw3 * ea; PQ_L(b)[i] += (double)(tw3 * eq);
+                qa += tw3 * ea; if (owned) PQ_L(b)[i] += (double)(tw3 * eq);      // an edge whose other voxel is a list entry is seen from both sides (by their owners)
                 qacc[a] = qs; qacc[chunk + a] = qa;
             }
 #pragma unroll
@@ -480,14 +486,17 @@ int launch_eg_tile_mr(hipStream_t st, RowView r, OptParams p, TilePlan t, int ns
     int blocks = 0, tiles_per_block = 0;
     eg_tile_launch_shape(t, p.K, blocks, tiles_per_block);
     if (blocks <= 0) return 0;
-    const int ntl = t.ntiles_own;
+    const int ntl = t.ntiles_own + t.n_ghost;          // sharded: the rank's own tiles, then the foreign tiles that hold its ghost entries (one launch, as k_eg_tile)
+    const bool gh = t.n_ghost > 0 || t.tile_first != 0 || r.own0 != 0 || r.own1 < r.A;
     MrArgs m; m.u0 = u0; m.qacc0 = qacc0; m.qh0 = qh0; m.pq0 = pq0; m.cam0 = cam0; m.st0 = st0; m.vec = lv.vec; m.qh = lv.qh; m.cam = lv.cam; m.part = lv.part;
     for (int b = 0; b < 3; ++b) m.sys[b] = sys[b < nsys ? b : nsys - 1];
     const size_t lds = mr_lds_bytes(nsys, p.K);
-#define I3D_MR(NB) do { \
-        if (!set_dynamic_lds((const void*)k_eg_tile_mr<NB>, "k_eg_tile_mr", lds, p.K)) return 0; \
-        k_eg_tile_mr<NB><<<blocks, MR_T, lds, st>>>(r, p, m, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, tiles_per_block, ntl, cam_stride, r.gmax, t.hp_off, t.hp_src); } while (0)
+#define I3D_MR2(NB, GH) do { \
+        if (!set_dynamic_lds((const void*)k_eg_tile_mr<NB, GH>, "k_eg_tile_mr", lds, p.K)) return 0; \
+        k_eg_tile_mr<NB, GH><<<blocks, MR_T, lds, st>>>(r, p, m, t.lnbr, t.eaw_sym, t.halo_idx, t.halo_cnt, tiles_per_block, ntl, cam_stride, r.gmax, t.hp_off, t.hp_src, t.tile_first, t.ntiles_own, t.ghost_tiles); } while (0)
+#define I3D_MR(NB) do { if (gh) I3D_MR2(NB, true); else I3D_MR2(NB, false); } while (0)
     if (nsys == 1) I3D_MR(1); else if (nsys == 2) I3D_MR(2); else I3D_MR(3);
+#undef I3D_MR2
 #undef I3D_MR
     return blocks;
 }

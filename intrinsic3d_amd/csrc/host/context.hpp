@@ -104,6 +104,7 @@ struct i3d_context {
     i3d::DevBuf<float> lad_vec;     // [LADDER_MAX][6][lad.vec]: x, r, p, z, u, qacc of every system
     i3d::DevBuf<float> lad_qh, lad_cam, lad_mblk, lad_tail;
     i3d::DevBuf<double> lad_part;   // [LADDER_MAX][lad.part]: step partials [4 * 1024] | p.q partials [1024] | D^2 p^2 partials [1024]
+    i3d::DevBuf<double> lad_red;    // sharded ladder: what a pass all-reduces — [LADDER_MAX][4] slice sums | [LADDER_MAX][6K + 10, padded] camera block + p.q
     i3d::DevBuf<i3d::PcgState> lad_st;      // [LADDER_MAX][2]
     long long lad_batches = 0, lad_streams = 0, lad_system_passes = 0, lad_resyncs = 0, lad_wasted = 0;      // counters (i3d_debug_ladder_stats)
     double t_add_end = 0.0;         // host clock at the end of the residual collection of the current outer iteration (time_add | time_build)

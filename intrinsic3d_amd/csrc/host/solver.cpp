@@ -240,7 +240,10 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         // 1 = the serial trust-region loop.  Needs the single-rank tiled pass in its 512-entry geometry with pull lists and the shipped 5 observation slots.
         const char* e = std::getenv("I3D_LADDER"); const int v = e ? std::atoi(e) : LADDER_MAX;
         c->ladder_max = v < 1 ? 1 : (v > LADDER_MAX ? LADDER_MAX : v);
-        if (sharded(c) || slots != 5 || eg_tile_mr_max_systems(c->K) < 2) c->ladder_max = 1;
+        if (slots != 5 || eg_tile_mr_max_systems(c->K) < 2) c->ladder_max = 1;
+        // sharded (round 6): the ladder runs with the exchanges as launches of the transport (RCCL, the rank simulation): pcg_solve_ladder all-reduces the batch's sums in
+        // one message per exchange.  Over the mailboxes (the in-kernel exchanges of the three-launch serial pass, I3D_TRANSPORT=p2p) the serial loop stays.
+        if (sharded(c)) { P2PDev probe; if (c->comm->fused_exchange(&probe)) c->ladder_max = 1; }
         { const char* l = std::getenv("I3D_PCG_LEGACY"); if (l && l[0] == '1') c->ladder_max = 1; }
         // I3D_EGT_MR1=1: the SERIAL loop streams its rows through k_eg_tile_mr<1> (the multi-system kernel with one system) instead of k_eg_tile — the control of the
         // ladder tests (same kernel family: a system solved alone vs in a batch, bit for bit) and an A/B switch
@@ -276,7 +279,7 @@ int assemble(i3d_context* c, const i3d_optimizer_config& cfg, int iteration, Opt
         // share balances better over twice the tiles.  Every rank derives the choice from the replicated work list.
         // (256-entry tiles for shares below two rounds were built and measured in round 4: the operator gains 2 us per pass, the halo fold loses more —
         // profiles/r04_share_tile_ab.json — removed.)
-        const int first_T = (c->A / c->comm->world >= 2 * 256 * 1024) ? 1024 : 512;
+        const int first_T = (c->ladder_max > 1) ? 512 : ((c->A / c->comm->world >= 2 * 256 * 1024) ? 1024 : 512);      // the multi-system pass exists in the 512-entry geometry
         c->tile_T = first_T;
         for (int attempt = 0; attempt < 2; ++attempt) {
             int rc = shard_plan(c); if (rc) return rc;
@@ -625,6 +628,7 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
 // Slabs of the per-system arrays of a batch (LadVec): every system has its own x, r, p, z, u, operator accumulators, halo sums, camera partial rows, partial
 // sums, block-Jacobi inverses, camera-tail diagonal and scalar states; b, the column norms and S are shared.
 constexpr int LAD_PART_STEP = 4 * 2048, LAD_PART_PQ = 2048, LAD_PART_D2 = 2048;
+static size_t lad_redop_stride(int NS) { return ((size_t)NS + 1 + 3) & ~(size_t)3; }
 static int alloc_ladder(i3d_context* c) {
     const Layout L = layout_of(c);
     const int nsys = c->ladder_max;
@@ -638,6 +642,12 @@ static int alloc_ladder(i3d_context* c) {
     if (fresh) CTX_HIP(c, hipMemsetAsync(c->lad_vec.p, 0, sizeof(float) * c->lad_vec.n, c->stream));      // padding entries stay finite
     CTX_HIP(c, c->lad_qh.alloc((size_t)nsys * qh)); CTX_HIP(c, c->lad_cam.alloc((size_t)nsys * cam)); CTX_HIP(c, c->lad_part.alloc((size_t)nsys * lv.part));
     CTX_HIP(c, c->lad_mblk.alloc((size_t)nsys * lv.mblk)); CTX_HIP(c, c->lad_tail.alloc((size_t)nsys * lv.tail)); CTX_HIP(c, c->lad_st.alloc((size_t)2 * LADDER_MAX));
+    if (sharded(c)) {      // what a pass all-reduces: [LADDER_MAX][4] slice sums of the step kernel, then [LADDER_MAX][NS + 1, padded] camera block + p.q of the operator pass
+        const size_t n = (size_t)LADDER_MAX * (4 + lad_redop_stride(L.NS));
+        const bool fresh_r = c->lad_red.n < n || !c->lad_red.p;
+        CTX_HIP(c, c->lad_red.alloc(n));
+        if (fresh_r) CTX_HIP(c, hipMemsetAsync(c->lad_red.p, 0, sizeof(double) * c->lad_red.n, c->stream));      // slots of systems that are not live are summed too: keep them finite
+    }
     return I3D_OK;
 }
 // the six vector kinds of the slab: kind * ladder_max * vec + system * vec
@@ -665,6 +675,16 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
     const int group_cap = [] { const char* e = std::getenv("I3D_LADDER_GROUP"); const int v = e ? std::atoi(e) : 3; return v < 1 ? 1 : (v > 3 ? 3 : v); }();
     const int mr_cap = std::min(group_cap, eg_tile_mr_max_systems(K));
     const bool mr_ok = use_mr && mr_cap >= 1 && tp.T == 512 && tp.hp_off != nullptr && r.slots == 5;
+    // Sharded (exchanges as launches of the transport: RCCL, the rank simulation).  Per pass and BATCH, not per system:
+    //   k_lad_reduce_step + ONE all-reduce of [LADDER_MAX][4] doubles (the slice sums of every live system) in front of k_pcg_dir3_lad,
+    //   the rim of u = S p of every live system pushed after it (one exchange per system: the transport's lists are per vector),
+    //   k_lad_reduce_op + ONE all-reduce of [LADDER_MAX][6K + 10] doubles (camera block + p.q of every live system) behind the operator.
+    // The slots of systems that have stopped ride along unused: the message size does not depend on which systems are live, so the ranks' collectives always match.
+    const bool sh = sharded(c);
+    if (sh && !mr_ok) return ctx_fail(c, I3D_ERR_STATE, "pcg_solve_ladder: a sharded batch needs the multi-system operator pass");
+    double* const red4 = sh ? c->lad_red.p : nullptr;
+    const int rstride = (int)lad_redop_stride(L.NS);
+    double* const redop = sh ? c->lad_red.p + (size_t)LADDER_MAX * 4 : nullptr;
     { TimedScope t(c, I3D_K_VECTOR);
       for (int j = 0; j < B; ++j) { CTX_HIP(c, hipMemsetAsync(X0 + (size_t)j * lv.vec, 0, sizeof(float) * L.NP, s));
                                     CTX_HIP(c, hipMemcpyAsync(R0 + (size_t)j * lv.vec, c->v_b.p, sizeof(float) * L.NP, hipMemcpyDeviceToDevice, s)); }
@@ -677,7 +697,7 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
     a.ext_off = tp.ext_off; a.ext_pos = tp.ext_pos; a.qh = reinterpret_cast<const float2*>(c->lad_qh.p); a.e0 = (int)own.off0;
     a.pq_partials = pq_part0; a.d2_partials = d2_part0; a.n_pq = 0; a.n_d2 = 0;
     a.n_slice_wg = pcg_step3_slice_wgs(own.n, 0);
-    a.sharded = 0; a.lad_sys = 0;
+    a.sharded = 0; a.lad_sys = 0; a.redop = redop; a.redop_stride = rstride;
     a.K = K; a.fix_poses = p.fix_poses; a.fix_intr = p.fix_intr; a.fix_dist = p.fix_dist;
     a.cam_partials = c->lad_cam.p; a.n_cam = 0; a.cam_stride = NSP; a.Mblk = c->lad_mblk.p;
     a.tp = P0 + to; a.tx = X0 + to; a.tr = R0 + to; a.tb = c->v_b.p + to; a.tD2 = c->lad_tail.p; a.tz = Z0 + to; a.tS = c->v_S.p + to;
@@ -687,7 +707,8 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
     // the operator on the live systems: groups of <= mr_cap systems share one stream of the rows; returns the workgroups per system (p.q partials / camera rows)
     auto rows_apply = [&](int parity, bool with_dot) -> int {
         int n = 0; const int nl = (int)live.size();
-        if (mr_ok && (nl > 1 || mr1)) {
+        if (sh) { for (int j : live) { const int rc = push_halo(c, U0 + (size_t)j * lv.vec); if (rc) return -1; } }      // the rim of every live system's operator input
+        if (mr_ok && (nl > 1 || mr1 || sh)) {
             const int groups = (nl + mr_cap - 1) / mr_cap;
             int at = 0;
             for (int g = 0; g < groups; ++g) {
@@ -707,7 +728,17 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
             }
         }
         c->lad_system_passes += nl;
+        if (sh) {          // this rank's [camera block | p.q (+ D^2 p^2 of its slice)] of every live system -> summed over the ranks, one message
+            { TimedScope t(c, I3D_K_VECTOR); launch_lad_reduce_op(s, nl, c->lad_cam.p, n, NSP, L.NS, pq_part0, with_dot ? n : 0, d2_part0, with_dot ? a.n_d2 : 0, redop, rstride, lv); }
+            if (allreduce(c, redop, (size_t)LADDER_MAX * rstride)) return -1;
+        }
         return n;
+    };
+    // sharded: the four slice sums of every live system, summed over the ranks in front of the boundary kernel
+    auto step_sums = [&](int nl, int n_slice) -> int {
+        if (!sh) return I3D_OK;
+        { TimedScope t(c, I3D_K_VECTOR); launch_lad_reduce_step(s, nl, step_part0, n_slice, red4, lv); }
+        return allreduce(c, red4, (size_t)LADDER_MAX * 4);
     };
     int n_step = 0;
     set_slots();
@@ -718,8 +749,10 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
     for (;; ++it) {
         set_slots();
         const int nl = (int)live.size();
+        { const int rc = step_sums(nl, a.n_slice_wg); if (rc) return rc; }
         { TimedScope t(c, I3D_K_VECTOR);
-          a.n_d2 = launch_pcg_dir3_lad(s, it == 1, nl, own, to, L.NS, Z0, P0, c->v_S.p, U0, c->lad_tail.p, c->v_cm.p, c->d_lm.p, step_part0, n_step, d2_part0, st2, (it + 1) & 1, c->d_flags, seq0 + it, lv); }
+          a.n_d2 = launch_pcg_dir3_lad(s, it == 1, nl, own, to, L.NS, Z0, P0, c->v_S.p, U0, c->lad_tail.p, c->v_cm.p, c->d_lm.p, step_part0, n_step, d2_part0, st2, (it + 1) & 1, c->d_flags, seq0 + it, lv,
+                                       a.n_slice_wg, red4); }
         { const int n = rows_apply(it & 1, true); if (n < 0) return ctx_fail(c, I3D_ERR_STATE, "pcg_solve_ladder: the multi-system operator pass could not be launched"); a.n_pq = n; a.n_cam = n; }
         a.cur = st2 + (it & 1);
         if (it % 10 != 0) { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3_lad(s, 1, nl, a, lv); }
@@ -849,7 +882,8 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     // those of the serial loop (bit for bit in the bit-reproducible mode).  Batch depth: what the previous outer iteration needed (the reference restarts at radius 1e4
     // every time, optimizer.cpp:138, so the count barely moves), doubling while everything is rejected.  An invalid step (radius halved instead of divided) puts a
     // batch out of step: the attempt behind it is solved again on its own (LmRecord kind 3).
-    const bool ladder = c->ladder_max > 1 && fused && !sharded(c) && c->plan_T() == 512 && c->tile_plan().hp_off != nullptr && c->slots == 5;
+    // (sharded: with the exchanges as launches of the transport — `fused` there means the in-kernel mailbox exchanges, which keep the serial loop)
+    const bool ladder = c->ladder_max > 1 && c->tile_ok && !legacy && (sharded(c) ? !fused : fused) && c->plan_T() == 512 && c->tile_plan().hp_off != nullptr && c->slots == 5;
     if (ladder) {
         rc = alloc_ladder(c); if (rc) return rc;
         const LadVec& lv = c->lad;
@@ -869,6 +903,7 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
             const PcgState* fin[LADDER_MAX] = {nullptr};
             rc = pcg_solve_ladder(c, cfg, p, B, fin, nullptr); if (rc) return rc;
             ++c->lad_batches;
+            for (int j = 0; j < B && sharded(c); ++j) { rc = allgather(c, lad_vecp(c, LV_X, j)); if (rc) return rc; }      // the candidate points are replicated: every rank needs the whole step of every system
             for (int j = 0; j < B; ++j) {      // the decision chain of every system, in ladder order; everything behind the deciding attempt returns at once
                 CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 4, 0, sizeof(double) * 2, s));
                 { TimedScope t(c, I3D_K_VECTOR);

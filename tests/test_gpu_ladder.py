@@ -144,3 +144,73 @@ def test_an_invalid_step_puts_the_batch_out_of_step_and_it_is_solved_again(slice
     lad = _run(slice_setup, iterations=2)
     _same(serial, lad)
     assert lad[4]["resyncs"] >= 1, lad[4]
+
+
+def _run_ranks(S, W, iterations=2, cg_fixed=-1):
+    """W simulated ranks (host threads on one GPU, i3d_comm_init_sim) through one optimize call on the bench slice: per rank (stats, sdf, albedo, camera, ladder stats)"""
+    import threading
+    from intrinsic3d_amd import binding
+    O = S["O"]; sc = S["sc"]; a0 = S["arrays"]
+    cfg = helpers.gpu_cfg(_bench_cfg(O, S["thres"], cg_fixed)); cfg.iterations = iterations
+    L = binding.load()
+    shared = L.i3d_comm_sim_create(W)
+    ctxs = [helpers.gpu_context(sc, a0, S["vsh"]) for _ in range(W)]
+    for r, c in enumerate(ctxs):
+        c.comm_init_sim(shared, r)
+    out = [None] * W; err = [None] * W
+
+    def run(r):
+        try:
+            out[r] = ctxs[r].optimize(cfg)
+        except Exception as e:      # surface failures instead of deadlocking the other ranks silently
+            err[r] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    [t.start() for t in th]; [t.join(timeout=300) for t in th]
+    assert not any(t.is_alive() for t in th), "sharded run hung"
+    assert all(e is None for e in err), err
+    res = []
+    for r, c in enumerate(ctxs):
+        sdf, alb = c.get_grid(); res.append((out[r], sdf, alb, c.get_camera(), c.debug_ladder_stats(), c.comm_stats())); c.close()
+    L.i3d_comm_sim_destroy(shared)
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ranks_run_the_ladder(slice_setup, world):
+    """Round 6: the damping ladder in the SHARDED path (the shard key of the reference is subvolumes.cpp:281-295, here tile ranges of the brick-ordered
+    work list).  W ranks — simulated by W host threads on one GPU, every exchange through the Comm interface the RCCL transport implements — solve the rejected attempts
+    of an outer iteration together: k_eg_tile_mr<NB, GHOSTS> over own + ghost tiles, ONE all-reduce of the batch's slice sums and ONE of its [camera block | p.q] per
+    pass.  Against the single-rank ladder on the bench slice (every group free, Ceres' own PCG stop, two chained outer iterations): same rows, same attempts, same
+    accept / reject sequence; PCG counts equal (+-1 on rejected attempts: the ranks' partial sums are associated differently, and a stop test may sit on its
+    threshold); costs, fields, intrinsics and poses to the sharded path's bar (1e-4, max-norm).  And the ladder did run on every rank (batches > 0, fewer row streams
+    than system passes), with the batch's exchanges in ONE message each: two all-reduces per pass whatever the number of live systems."""
+    ref = _run(slice_setup)
+    rst, rsdf, ralb, rcam, rlad = ref
+    assert rlad["batches"] > 0
+    for rank, (st, sdf, alb, cam, lad, comm) in enumerate(_run_ranks(slice_setup, world)):
+        assert lad["batches"] > 0 and lad["depth"] > 1 and lad["row_streams"] < lad["system_passes"], (rank, lad)
+        for k, (s1, s2) in enumerate(zip(rst, st)):
+            what = (world, rank, k, _stats([s1]), _stats([s2]))
+            assert list(s1.rows) == list(s2.rows) and s1.num_attempts == s2.num_attempts, what
+            assert list(s1.step_accepted[:s1.num_attempts]) == list(s2.step_accepted[:s2.num_attempts]), what
+            p1 = list(s1.pcg_iterations[:s1.num_attempts]); p2 = list(s2.pcg_iterations[:s2.num_attempts])
+            assert all(abs(x - y) <= 1 for x, y in zip(p1, p2)) and p1[-1] == p2[-1], what
+            assert abs(s1.cost_initial - s2.cost_initial) <= (1e-12 if k == 0 else 1e-4) * s1.cost_initial and abs(s1.cost_final - s2.cost_final) <= 1e-4 * s1.cost_final, what
+        assert np.abs(sdf - rsdf).max() <= 1e-4 * np.abs(rsdf).max() and np.abs(alb - ralb).max() <= 1e-4 * np.abs(ralb).max()
+        np.testing.assert_allclose(cam[0], rcam[0], rtol=1e-4); np.testing.assert_allclose(cam[2], rcam[2], rtol=1e-4, atol=1e-6)
+        # exchanges of the PCG passes: two all-reduces per pass of a BATCH (not per system): fewer reduce calls than twice the system passes
+        assert comm["reduce_calls"] < 2 * lad["system_passes"], (comm, lad)
+
+
+def test_sharded_ladder_with_fixed_pcg_depth_equals_the_sharded_serial_loop(slice_setup, monkeypatch):
+    """The sharded ladder against the sharded SERIAL loop (I3D_LADDER=1: k_eg_tile<GHOSTS>, the six-launch pass) at a fixed PCG depth of 12 (one residual reset): with no
+    stop test to sit on a threshold, attempts, accept sequence and PCG counts must be identical, and the fields agree to the round-off of two operator kernels whose wave
+    sums are associated differently (k_eg_tile_mr against k_eg_tile: as test_multi_system_kernel_against_the_round_4_kernel) — far below the parity bar."""
+    lad = _run_ranks(slice_setup, 2, cg_fixed=12)
+    monkeypatch.setenv("I3D_LADDER", "1")
+    ser = _run_ranks(slice_setup, 2, cg_fixed=12)
+    for (st1, s1, a1, c1, l1, _), (st2, s2, a2, c2, l2, _) in zip(lad, ser):
+        assert l1["batches"] > 0 and l2["batches"] == 0
+        assert [x[:3] for x in _stats(st1)] == [x[:3] for x in _stats(st2)], (_stats(st1), _stats(st2))
+        assert np.abs(s1 - s2).max() <= 1e-5 * np.abs(s2).max() and np.abs(a1 - a2).max() <= 1e-5 * np.abs(a2).max()
+        np.testing.assert_allclose(c1[0], c2[0], rtol=1e-5); np.testing.assert_allclose(c1[2], c2[2], rtol=1e-5, atol=1e-7)
