@@ -501,7 +501,7 @@ def _main():
         # HIP events around the exchange launches that still are launches of their own (the rim push; with RCCL also the all-reduces).  Over the
         # peer-to-peer transport the two reductions of a pass run INSIDE the PCG's boundary kernels, so the whole price of the sharded path on one
         # GPU is the difference of ms_per_step between a plain run and a --force-collectives run (profiles/README.md quotes both).
-        ms, n = timing["comm"]; passes = max(1, timing["eg_pass"][1])
+        ms, n = timing["comm"]; passes = max(1, sum(timing[k][1] for k in ("eg_pass", "eg_mr2", "eg_mr3") if k in timing))      # streams of the rows (a ladder batch shares the exchanges of a pass)
         comm = {"transport": transport, "separate_launch_ms_total": ms, "separate_launches": n, "operator_passes": passes,
                 "separate_launch_us_per_pass": 1e3 * ms / passes, "stats_rank0": comm_stats}
 
@@ -529,7 +529,8 @@ def _main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"parallelism": f"{world} rank(s), one per GPU: replicated voxel state; tile-aligned ownership of the brick-ordered work list, rim rows recomputed as ghosts; "
                                        f"per PCG pass three launches and two exchanges that run inside them over the peer-to-peer mailboxes ([4 slice sums + the rim of z] in k_pcg_dir3, "
-                                       f"[p.q | camera block] in k_pcg_step3); over RCCL the six-launch pass with one neighbour exchange + two all-reduce launches"
+                                       f"[p.q | camera block] in k_pcg_step3); over RCCL (the default) the damping ladder with ONE neighbour exchange + two all-reduce launches per pass of a BATCH "
+                                       f"(k_eg_tile_mr over own + ghost tiles)"
                                        + (f"; this run: {transport}" if transport else ""),
                        "workload": f"synthetic hashed SDF grid, {arrays['keys'].shape[0]} stored voxels @ {args.voxel_size * 1e3:g} mm "
                                    f"({A} in the thin shell), {args.frames} keyframes {args.width}x{args.height}, {sh_sub.shape[0]} SH subvolumes of {args.subvolume} m (estimated on the device, untimed), "

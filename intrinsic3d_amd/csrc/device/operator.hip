@@ -957,6 +957,27 @@ __global__ void k_halo_unpack(int n, const int* __restrict__ idx, const float* _
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const int e = idx[i]; vec[e] = buf[2 * (size_t)i]; vec[(size_t)chunk + e] = buf[2 * (size_t)i + 1]; }
 }
+// the rim of nsys vectors of a ladder batch in one buffer: entry j carries [system][sdf value, albedo value] side by side, so a peer's block stays contiguous
+__global__ void k_halo_pack_multi(int n, const int* __restrict__ idx, const float* __restrict__ vec0, size_t stride, HaloSys sys, int nsys, int chunk, float* __restrict__ buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * nsys) return;
+    const int j = i / nsys, s = i - j * nsys, e = idx[j];
+    const float* v = vec0 + (size_t)sys.id[s] * stride;
+    buf[2 * (size_t)i] = v[e]; buf[2 * (size_t)i + 1] = v[(size_t)chunk + e];
+}
+__global__ void k_halo_unpack_multi(int n, const int* __restrict__ idx, const float* __restrict__ buf, size_t stride, HaloSys sys, int nsys, int chunk, float* __restrict__ vec0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * nsys) return;
+    const int j = i / nsys, s = i - j * nsys, e = idx[j];
+    float* v = vec0 + (size_t)sys.id[s] * stride;
+    v[e] = buf[2 * (size_t)i]; v[(size_t)chunk + e] = buf[2 * (size_t)i + 1];
+}
+void launch_halo_pack_multi(hipStream_t st, int n, const int* idx, const float* vec0, size_t stride, HaloSys sys, int nsys, int chunk, float* buf) {
+    if (n > 0 && nsys > 0) k_halo_pack_multi<<<(n * nsys + 255) / 256, 256, 0, st>>>(n, idx, vec0, stride, sys, nsys, chunk, buf);
+}
+void launch_halo_unpack_multi(hipStream_t st, int n, const int* idx, const float* buf, size_t stride, HaloSys sys, int nsys, int chunk, float* vec0) {
+    if (n > 0 && nsys > 0) k_halo_unpack_multi<<<(n * nsys + 255) / 256, 256, 0, st>>>(n, idx, buf, stride, sys, nsys, chunk, vec0);
+}
 void launch_halo_pack(hipStream_t st, int n, const int* idx, const float* vec, int chunk, float* buf) { if (n > 0) k_halo_pack<<<(n + 255) / 256, 256, 0, st>>>(n, idx, vec, chunk, buf); }
 void launch_halo_unpack(hipStream_t st, int n, const int* idx, const float* buf, int chunk, float* vec) { if (n > 0) k_halo_unpack<<<(n + 255) / 256, 256, 0, st>>>(n, idx, buf, chunk, vec); }
 

@@ -7,6 +7,12 @@
 #include <cstddef>
 
 namespace i3d {
+constexpr int HALO_MULTI_MAX = 6;      // = LADDER_MAX (common.hpp): vectors one rim message of a ladder batch can carry (Comm::push_halo_multi)
+struct HaloSys { int id[HALO_MULTI_MAX]; };
+}
+
+
+namespace i3d {
 
 constexpr int P2P_MAX_RANKS = 64;
 constexpr unsigned long long P2P_SPIN_LIMIT = 60000000000ull;      // ~30 s of shader-clock ticks: a peer that is merely late (first launch in a fresh process loads the code object) is not a dead peer

@@ -63,6 +63,25 @@ struct RcclComm : Comm {
         launch_halo_unpack(st, h.n_recv, h.d_recv_idx, h.d_recv_buf, h.chunk, vec);
         return 0;
     }
+    // a ladder batch: ONE grouped launch of sends / receives, nsys values per rim entry
+    int push_halo_multi(float* vec0, size_t stride, const int* sys, int nsys, const HaloPlan& h, hipStream_t st) override {
+        if ((use_p2p && !halo_rccl) || nsys > HALO_MULTI_MAX) return Comm::push_halo_multi(vec0, stride, sys, nsys, h, st);
+        ++halo_calls; halo_bytes_sent += 8ll * h.n_send * nsys;
+        if ((h.n_send == 0 && h.n_recv == 0) || nsys <= 0) return 0;
+        HaloSys hs; for (int s = 0; s < HALO_MULTI_MAX; ++s) hs.id[s] = sys[s < nsys ? s : nsys - 1];
+        launch_halo_pack_multi(st, h.n_send, h.d_send_idx, vec0, stride, hs, nsys, h.chunk, h.d_send_buf);
+        if (ncclGroupStart() != ncclSuccess) return 1;
+        bool ok = true;
+        const size_t m = 2 * (size_t)nsys;
+        for (int k = 0; k < world; ++k) {
+            if (k == rank) continue;
+            if (h.send_cnt[k] > 0) ok &= ncclSend(h.d_send_buf + m * (size_t)h.send_off[k], m * (size_t)h.send_cnt[k], ncclFloat, k, comm, st) == ncclSuccess;
+            if (h.recv_cnt[k] > 0) ok &= ncclRecv(h.d_recv_buf + m * (size_t)h.recv_off[k], m * (size_t)h.recv_cnt[k], ncclFloat, k, comm, st) == ncclSuccess;
+        }
+        if (ncclGroupEnd() != ncclSuccess || !ok) return 1;
+        launch_halo_unpack_multi(st, h.n_recv, h.d_recv_idx, h.d_recv_buf, stride, hs, nsys, h.chunk, vec0);
+        return 0;
+    }
 };
 
 int rccl_unique_id(void* out, size_t* bytes) {
@@ -264,6 +283,28 @@ struct SimComm : Comm {
         if (hipStreamSynchronize(st) != hipSuccess) return 1;      // the peers' send buffers are read: they may pack the next pass after the barrier
         sh->barrier();
         launch_halo_unpack(st, h.n_recv, h.d_recv_idx, h.d_recv_buf, h.chunk, vec);
+        return 0;
+    }
+    int push_halo_multi(float* vec0, size_t stride, const int* sys, int nsys, const HaloPlan& h, hipStream_t st) override {
+        attach();
+        if (use_p2p || nsys > HALO_MULTI_MAX) return Comm::push_halo_multi(vec0, stride, sys, nsys, h, st);
+        ++halo_calls; halo_bytes_sent += 8ll * h.n_send * nsys;
+        HaloSys hs; for (int s = 0; s < HALO_MULTI_MAX; ++s) hs.id[s] = sys[s < nsys ? s : nsys - 1];
+        launch_halo_pack_multi(st, h.n_send, h.d_send_idx, vec0, stride, hs, nsys, h.chunk, h.d_send_buf);
+        if (hipStreamSynchronize(st) != hipSuccess) return 1;
+        sh->halo[rank] = &h;
+        sh->barrier();
+        const size_t m = 2 * (size_t)nsys;
+        for (int k = 0; k < world; ++k) {
+            if (k == rank || h.recv_cnt[k] == 0) continue;
+            const HaloPlan* pk = sh->halo[k];
+            if (pk->send_cnt[rank] != h.recv_cnt[k]) return 1;
+            if (hipMemcpyAsync(h.d_recv_buf + m * (size_t)h.recv_off[k], pk->d_send_buf + m * (size_t)pk->send_off[rank], sizeof(float) * m * (size_t)h.recv_cnt[k],
+                               hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return 1;
+        sh->barrier();
+        launch_halo_unpack_multi(st, h.n_recv, h.d_recv_idx, h.d_recv_buf, stride, hs, nsys, h.chunk, vec0);
         return 0;
     }
 };

@@ -33,6 +33,12 @@ struct Comm {
     virtual int allgather(float* dev, size_t count, hipStream_t st) = 0;
     // vec[e], vec[chunk + e] of the entries in the send lists -> the same positions of the peers' copies of vec (their recv lists)
     virtual int push_halo(float* vec, const HaloPlan& h, hipStream_t st) = 0;
+    // the same for the nsys (<= HALO_MULTI_MAX) vectors vec0 + sys[s] * stride of a ladder batch in ONE message per peer: every rim entry carries the values of all of them
+    // (the buffers of `h` hold HALO_MULTI_MAX values per entry).  Default: one exchange per vector.
+    virtual int push_halo_multi(float* vec0, size_t stride, const int* sys, int nsys, const HaloPlan& h, hipStream_t st) {
+        for (int s = 0; s < nsys; ++s) { const int rc = push_halo(vec0 + (size_t)sys[s] * stride, h, st); if (rc) return rc; }
+        return 0;
+    }
     // true: all-reduces of a few doubles can run INSIDE single-workgroup kernels (p2p_allreduce_wg with *dev); the caller logs them with count_reduce
     virtual bool device_reduce(P2PDev* dev) { (void)dev; return false; }
     // true: this outer iteration's per-pass exchanges may run inside the MULTI-workgroup PCG kernels (pcg_fused.hip: the three-launch sharded pass) — the
@@ -47,6 +53,8 @@ struct Comm {
     const char* transport = "";      // what carries the per-pass exchanges (for logs / bench)
 };
 
+void launch_halo_pack_multi(hipStream_t st, int n, const int* idx, const float* vec0, size_t stride, HaloSys sys, int nsys, int chunk, float* buf);
+void launch_halo_unpack_multi(hipStream_t st, int n, const int* idx, const float* buf, size_t stride, HaloSys sys, int nsys, int chunk, float* vec0);
 // pack / unpack kernels of the halo exchange (operator.hip)
 void launch_halo_pack(hipStream_t st, int n, const int* idx, const float* vec, int chunk, float* buf);
 void launch_halo_unpack(hipStream_t st, int n, const int* idx, const float* buf, int chunk, float* vec);

@@ -77,7 +77,7 @@ static int alloc_rows(i3d_context* c, int slots) {
     if (c->comm) {      // sharding plan storage (small: the rim of a rank is a few percent of what it owns)
         const size_t cap = HALO_CAP;
         CTX_HIP(c, c->need_mask.alloc(Acap)); CTX_HIP(c, c->halo_items.alloc(cap)); CTX_HIP(c, c->halo_sorted.alloc(cap)); CTX_HIP(c, c->halo_count.alloc(1));
-        CTX_HIP(c, c->halo_send_idx.alloc(cap)); CTX_HIP(c, c->halo_recv_idx.alloc(cap)); CTX_HIP(c, c->halo_send_peer.alloc(cap)); CTX_HIP(c, c->halo_recv_peer.alloc(cap)); CTX_HIP(c, c->halo_offs.alloc(2 * P2P_MAX_RANKS)); CTX_HIP(c, c->halo_send_buf.alloc(2 * cap)); CTX_HIP(c, c->halo_recv_buf.alloc(2 * cap));
+        CTX_HIP(c, c->halo_send_idx.alloc(cap)); CTX_HIP(c, c->halo_recv_idx.alloc(cap)); CTX_HIP(c, c->halo_send_peer.alloc(cap)); CTX_HIP(c, c->halo_recv_peer.alloc(cap)); CTX_HIP(c, c->halo_offs.alloc(2 * P2P_MAX_RANKS)); CTX_HIP(c, c->halo_send_buf.alloc((size_t)HALO_MULTI_MAX * (2 * cap))); CTX_HIP(c, c->halo_recv_buf.alloc((size_t)HALO_MULTI_MAX * (2 * cap)));      /* a ladder batch pushes HALO_MULTI_MAX values per rim entry in one message */
         CTX_HIP(c, c->halo_temp.alloc(halo_sort_temp_bytes((int)cap)));
         const size_t nt = (size_t)tile_plan_tiles_of((int)Acap, 512) + 1; CTX_HIP(c, c->tile_flag.alloc(nt)); CTX_HIP(c, c->ghost_tiles.alloc(nt));
     }
@@ -707,7 +707,8 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
     // the operator on the live systems: groups of <= mr_cap systems share one stream of the rows; returns the workgroups per system (p.q partials / camera rows)
     auto rows_apply = [&](int parity, bool with_dot) -> int {
         int n = 0; const int nl = (int)live.size();
-        if (sh) { for (int j : live) { const int rc = push_halo(c, U0 + (size_t)j * lv.vec); if (rc) return -1; } }      // the rim of every live system's operator input
+        if (sh) { TimedScope t(c, I3D_K_COMM);      // the rim of every live system's operator input: ONE message per peer, nl values per entry
+                  if (c->comm->push_halo_multi(U0, lv.vec, live.data(), nl, c->halo, s)) return -1; }
         if (mr_ok && (nl > 1 || mr1 || sh)) {
             const int groups = (nl + mr_cap - 1) / mr_cap;
             int at = 0;

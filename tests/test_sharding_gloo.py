@@ -9,7 +9,10 @@ Then one operator application exactly as host/solver.cpp + Comm run it:
   3. y = J^T W J u from the rows of the compute list (rows come from the CPU oracle), kept ONLY on owned unknowns; the camera columns and
      p.q counted ONLY on a row's owner;
   4. ONE all-reduce of [camera block | p.q]; nothing else is exchanged — no vector is gathered (the check below assembles the owned
-     segments only to compare with the oracle's global product)."""
+     segments only to compare with the oracle's global product).
+Round 6, the ladder batch (solver.cpp pcg_solve_ladder, sharded): B = 3 systems iterate in lock step and share the exchanges of a pass — the rim message carries B values
+per entry (Comm::push_halo_multi), the all-reduce carries [LADDER_MAX = 6][6K + 10] doubles whatever the number of live systems (the slots of stopped systems ride
+along unused, so the ranks' collectives always match): the same checks per system, with the same two collectives per pass."""
 import os
 import sys
 
@@ -26,7 +29,8 @@ ALB_OFF = [(0,0,0),(1,0,0),(0,1,0),(0,0,1)]
 RING = [(1,0,0),(-1,0,0),(0,1,0),(0,-1,0),(0,0,1),(0,0,-1)]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, B=1):
+    LADDER_MAX = 6
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     import torch
     import torch.distributed as dist
@@ -61,22 +65,22 @@ def _worker(rank, world, port, q):
         vs = lambda a: int(a)
         va = lambda a: chunk + int(a)
         rng = np.random.default_rng(7)
-        xg = rng.normal(0, 1, 2 * N + NS)
+        xg = rng.normal(0, 1, (B, 2 * N + NS))
         is_free = np.concatenate([free_s, free_a, np.full(6 * K, cfg.fix_poses == 0), np.full(4, cfg.fix_intrinsics == 0), np.full(5, cfg.fix_distortion == 0)])
         cost, grad, diag, touched = pv.normal_eq()
         xg = xg * is_free
         # 1. the operator input: owned segments + replicated camera tail; everything else is NaN
-        u = np.full(tail + NS, np.nan)
+        u = np.full((B, tail + NS), np.nan)
         for a in range(own0, own1):
-            u[vs(a)] = xg[wl[a]]; u[va(a)] = xg[N + wl[a]]
-        u[tail:] = xg[2 * N:]
+            u[:, vs(a)] = xg[:, wl[a]]; u[:, va(a)] = xg[:, N + wl[a]]
+        u[:, tail:] = xg[:, 2 * N:]
         # 2. the rim exchange: owner -> every rank whose rows read the entry
         send = [[] for _ in range(world)]
         for a in range(own0, own1):
             m = int(need[a])
             for k in range(world):
                 if k != rank and (m >> k) & 1:
-                    send[k].append((a, u[vs(a)], u[va(a)]))
+                    send[k].append((a, u[:, vs(a)].copy(), u[:, va(a)].copy()))       # ONE item per rim entry: the values of all B systems
         recv = [None] * world
         dist.all_to_all_single  # (gloo has no variable all_to_all for objects: use all_gather_object of the per-destination lists)
         allsend = [None] * world
@@ -86,27 +90,28 @@ def _worker(rank, world, port, q):
             if k == rank: continue
             for a, us_, ua_ in allsend[k][rank]:
                 assert (int(need[a]) >> rank) & 1 and not (own0 <= a < own1)
-                u[vs(a)] = us_; u[va(a)] = ua_; n_recv += 1
+                u[:, vs(a)] = us_; u[:, va(a)] = ua_; n_recv += 1
         n_send = sum(len(x) for x in send)
 
-        y_slice = np.zeros(tail + NS); cam = np.zeros(NS + 1)
+        y_slice = np.zeros((B, tail + NS)); cam = np.zeros((LADDER_MAX, NS + 1))       # the message has LADDER_MAX slots; B of them are live
         owned = lambda a: own0 <= a < own1
 
         def add_row(centre_a, cols, coefs, w, cam_cols=None, cam_coefs=None):
             # cols: vector positions (or None); t = w * (J . u); outputs only on owned unknowns; camera + p.q only on the owner of the row
-            d = sum(c * u[p] for p, c in zip(cols, coefs) if p is not None)
+            d = sum(c * u[:, p] for p, c in zip(cols, coefs) if p is not None)
             if cam_cols is not None:
-                d += sum(c * u[tail + p] for p, c in zip(cam_cols, cam_coefs))
-            assert d == d, "a row read an operator-input value that was neither owned nor pushed (need set too small)"
+                d = d + sum(c * u[:, tail + p] for p, c in zip(cam_cols, cam_coefs))
+            d = d + np.zeros(B)
+            assert np.all(d == d), "a row read an operator-input value that was neither owned nor pushed (need set too small)"
             t = w * d
             for p, c, a_of in zip(cols, coefs, row_entries):
                 if p is not None and owned(a_of):
-                    y_slice[p] += c * t
+                    y_slice[:, p] += c * t
             if owned(centre_a):
-                cam[NS] += t * d                                 # p.q row by row (tile_pass.hip)
+                cam[:B, NS] += t * d                             # p.q row by row (tile_pass.hip)
                 if cam_cols is not None:
                     for p, c in zip(cam_cols, cam_coefs):
-                        cam[p] += c * t
+                        cam[:B, p] += c * t
 
         v, f, w, r, J = pv.eg(True)
         for i in range(len(v)):
@@ -144,37 +149,40 @@ def _worker(rank, world, port, q):
             maskv[vs(a)] = free_s[wl[a]]; maskv[va(a)] = free_a[wl[a]]
         maskv[tail:] = is_free[2 * N:]
         # 4. the ONE collective of the pass: [camera block | p.q]
-        cam_t = torch.from_numpy(cam); dist.all_reduce(cam_t)
+        cam_t = torch.from_numpy(cam); dist.all_reduce(cam_t)      # [LADDER_MAX][NS + 1] in ONE message
+        assert np.all(cam_t.numpy()[B:] == 0.0)
         # (test only) assemble the owned segments to compare with the oracle's global product
-        seg = np.zeros(2 * slice_)
-        seg[:slice_] = y_slice[rank * slice_:(rank + 1) * slice_]; seg[slice_:] = y_slice[chunk + rank * slice_:chunk + (rank + 1) * slice_]
-        parts = [torch.zeros(2 * slice_, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(parts, torch.from_numpy(seg))
-        y = np.zeros(tail + NS)
-        for k2 in range(world):
-            pk = parts[k2].numpy(); y[k2 * slice_:(k2 + 1) * slice_] = pk[:slice_]; y[chunk + k2 * slice_:chunk + (k2 + 1) * slice_] = pk[slice_:]
-        y[tail:] = cam_t.numpy()[:NS]
-        y *= maskv
-        yref_g = pv.jtj_apply(xg)
-        yref = np.zeros(tail + NS)
-        for a in range(A):
-            yref[vs(a)] = yref_g[wl[a]]; yref[va(a)] = yref_g[N + wl[a]]
-        yref[tail:] = yref_g[2 * N:]
-        err = np.abs(y - yref).max() / (np.abs(yref).max() + 1e-30)
-        pq_ref = float(xg @ yref_g)
-        err_pq = abs(float(cam_t.numpy()[NS]) - pq_ref) / abs(pq_ref)
+        err = 0.0; err_pq = 0.0
+        for b in range(B):
+            seg = np.zeros(2 * slice_)
+            seg[:slice_] = y_slice[b, rank * slice_:(rank + 1) * slice_]; seg[slice_:] = y_slice[b, chunk + rank * slice_:chunk + (rank + 1) * slice_]
+            parts = [torch.zeros(2 * slice_, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(seg))
+            y = np.zeros(tail + NS)
+            for k2 in range(world):
+                pk = parts[k2].numpy(); y[k2 * slice_:(k2 + 1) * slice_] = pk[:slice_]; y[chunk + k2 * slice_:chunk + (k2 + 1) * slice_] = pk[slice_:]
+            y[tail:] = cam_t.numpy()[b, :NS]
+            y *= maskv
+            yref_g = pv.jtj_apply(xg[b])
+            yref = np.zeros(tail + NS)
+            for a in range(A):
+                yref[vs(a)] = yref_g[wl[a]]; yref[va(a)] = yref_g[N + wl[a]]
+            yref[tail:] = yref_g[2 * N:]
+            err = max(err, np.abs(y - yref).max() / (np.abs(yref).max() + 1e-30))
+            pq_ref = float(xg[b] @ yref_g)
+            err_pq = max(err_pq, abs(float(cam_t.numpy()[b, NS]) - pq_ref) / abs(pq_ref))
         q.put((rank, float(err), int(comp.sum()), int(own1 - own0), A, n_send, n_recv, float(err_pq)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_operator_protocol_gloo(world):
+@pytest.mark.parametrize("world,batch", [(2, 1), (3, 1), (2, 3)])
+def test_sharded_operator_protocol_gloo(world, batch):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 500) + world + 10 * batch
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, batch)) for r in range(world)]
     [p.start() for p in procs]
     [p.join(timeout=300) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
