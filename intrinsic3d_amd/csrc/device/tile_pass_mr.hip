@@ -40,8 +40,8 @@ constexpr int MR_T = 512, MR_HMAX = 1536, MR_NWV = MR_T / 64, MR_TC = 32;
 
 // LDS layout in floats.  Everything whose size does not depend on K sits at COMPILE-TIME offsets (an offset that is a constant costs no scalar register across the
 // row loop):
-//   [flag | 3 pad] [NB][72] per-wave intrinsics / distortion sums | [NWV][TC] keyframe tags (shared by the systems: the rows are) | [NWV][TC][6 NB] table sums (the values of a slot side by side) |
-//   [NB] x { u_s, u_a [2 NSLOT] | Er row values [T + 4] } | the tile's pull list [2 HMAX] | column sums of ONE system [12][T] | pull-list offsets [(HMAX + 4) / 2, rounded]
+//   [NB] x { u_s, u_a [2 NSLOT] } | [NB] x Er row values [T + 4] | [flag | 3 pad] [NB][72] per-wave intrinsics / distortion sums | [NWV][TC] keyframe tags (shared by the systems: the rows are) |
+//   [NWV][TC][6 NB] table sums (the values of a slot side by side) | the tile's pull list [2 HMAX] | column sums of ONE system [12][T] | pull-list offsets [(HMAX + 4) / 2, rounded]
 //   | the lanes' running p.q [NB][T] fp64 (parked here: as register pairs they are live across the whole row loop)
 // then, per system and K-dependent: dense camera accumulator [rs + 9] | pose part of u_b [6K] | its intrinsics / distortion part [9, padded to 12, 16-byte aligned].
 // (Inputs of the systems interleaved per slot — one 16-byte read serving three systems — were built and dropped: the 40 registers one row's reads then occupy
@@ -49,9 +49,13 @@ constexpr int MR_T = 512, MR_HMAX = 1536, MR_NWV = MR_T / 64, MR_TC = 32;
 template <int NB> struct MrConst {
     static constexpr int T = MR_T, HMAX = MR_HMAX, NW = MR_NWV, TC = MR_TC, NSLOT = T + HMAX + 1;
     static constexpr int CAMW = (NW * 9 + 3) & ~3, VSTR = NW * TC * 6;          // (VSTR x NB floats of table sums: [NW][TC][6 NB])
-    static constexpr int D_FLAG = 0, D_CAM9W = 4, D_TAG = D_CAM9W + NB * CAMW, D_VAL = D_TAG + NW * TC;
-    static constexpr int O_U = D_VAL + NB * VSTR, UB = (2 * NSLOT + T + 4 + 3) & ~3;          // system b: u_s at O_U + b UB, u_a behind it, then the Er row values
-    static constexpr int O_LIST = O_U + NB * UB, O_C = O_LIST + 2 * HMAX, O_OFFS = O_C + 12 * T, O_PQ = O_OFFS + (((HMAX + 4) / 2 + 3) & ~3), D0 = O_PQ + NB * 2 * T;      // O_PQ: the lanes' running p.q, fp64, [NB][T]
+    // The staged inputs come FIRST (round 6): the row loop reads them at lane-dependent slots, 14 reads per (row, system), and a ds_read takes an immediate offset of at most
+    // 64 KB - with the inputs of all three systems below that line one shifted slot register serves every system (before, system 2's albedo half lay at 65.4 KB and every
+    // read of it needed its own address register or add: the 3-system kernel sat at 248 registers).  The Er row values moved out of the per-system input blocks for the same reason.
+    static constexpr int O_U = 0, UB = (2 * NSLOT + 3) & ~3;                     // system b: u_s at O_U + b UB, u_a behind it
+    static constexpr int O_TR = O_U + NB * UB, TRB = (T + 4 + 3) & ~3;          // Er row values of system b at O_TR + b TRB
+    static constexpr int D_FLAG = O_TR + NB * TRB, D_CAM9W = D_FLAG + 4, D_TAG = D_CAM9W + NB * CAMW, D_VAL = D_TAG + NW * TC;
+    static constexpr int O_LIST = D_VAL + NB * VSTR, O_C = O_LIST + 2 * HMAX, O_OFFS = O_C + 12 * T, O_PQ = O_OFFS + (((HMAX + 4) / 2 + 3) & ~3), D0 = O_PQ + NB * 2 * T;      // O_PQ: the lanes' running p.q, fp64, [NB][T]
 };
 struct MrLayout { int o_upose, o_ui, SK; size_t bytes; };          // the K-dependent tail: system b at D0 + b SK: accumulator, then (at o_upose) the pose part of u_b, then (at o_ui, 16-byte aligned) its 9 intrinsics / distortion entries
 static __host__ __device__ inline MrLayout mr_layout(int D0, int NB, int K) {
@@ -122,6 +126,24 @@ static __device__ inline void mr_table_merge(float* lds, int o_tag, int o_val, i
     count = 0;
 }
 
+// Phase timing (variant build only: -DI3D_MR_PHASES, tools/build_variant.sh; never in the shipped library).  Every wave accumulates the s_memtime ticks it spends in
+// each phase of a tile in scalar registers and adds them to g_mr_phase[NB - 1][phase] at the end; mr_phase_report() (called by the variant's launch wrapper at
+// exit) prints wave-averaged shares.  Phases: 0 prologue | 1 issue the tile's loads | 2 staging writes (waits for the gathers) | 3 staging barrier | 4 regulariser rows + hoisted inputs |
+// 5 row loop | 6 reverse slots / Ea weights | 7 pull: column sums -> LDS | 8 pull: first barrier | 9 pull: sums, halo list walk, stores | 10 pull: second barrier | 11 epilogue
+#ifdef I3D_MR_PHASES
+constexpr int MR_NPH = 12;
+__device__ unsigned long long g_mr_phase[3][MR_NPH + 2];
+#define PH_DECL unsigned long long ph_[MR_NPH] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_t_ = __builtin_amdgcn_s_memtime(); unsigned ph_tiles_ = 0
+#define PH(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[k] += t_ - ph_t_; ph_t_ = t_; } while (0)
+#define PH_TILE ++ph_tiles_
+#define PH_FLUSH(NBv) do { if ((threadIdx.x & 63u) == 0u) { for (int k_ = 0; k_ < MR_NPH; ++k_) atomicAdd(&g_mr_phase[(NBv) - 1][k_], ph_[k_]); atomicAdd(&g_mr_phase[(NBv) - 1][MR_NPH], (unsigned long long)ph_tiles_); atomicAdd(&g_mr_phase[(NBv) - 1][MR_NPH + 1], 1ull); } } while (0)
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_TILE
+#define PH_FLUSH(NBv)
+#endif
+
 struct MrArgs {
     const float* u0; float* qacc0; float* qh0; double* pq0 /* or null: no p.q (residual-reset pass) */; float* cam0;
     const PcgState* st0;                   // system 0's state of this pass's parity; system j's is st0 + 2 j
@@ -157,7 +179,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #define SYS(b) (D0 + (b) * SB)                                   /* K-dependent block of system b: dense pose accumulator [0, 6K), intrinsics / distortion totals [rs, rs + 9), camera part of u_b at o_upose */
 #define U_S(b) (MC::O_U + (b) * MC::UB)
 #define U_A(b) (MC::O_U + (b) * MC::UB + MC::NSLOT)
-#define TR_L(b) (MC::O_U + (b) * MC::UB + 2 * MC::NSLOT)
+#define TR_L(b) (MC::O_TR + (b) * MC::TRB)
 #define C_L (MC::O_C)
 #define hp_list reinterpret_cast<unsigned short*>(lds + MC::O_LIST)
 #define hp_offs reinterpret_cast<unsigned short*>(lds + MC::O_OFFS)
@@ -207,16 +229,29 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
         const int grp = __builtin_amdgcn_readfirstlane(wa0 < A ? (wa0 >> 6) : -1);
         return grp >= 0 ? gmaxv[grp] : 0;
     };
-    auto issue_in = [&](int tk) {
+    // A tile's inputs arrive in TWO steps, both issued one tile ahead (round 6; s_memtime phase marks, profiles/r06_mr_phases_*.txt: with ONE workgroup per CU nothing hides
+    // a tile's start-up — issuing its loads and waiting for the dependent gathers was 31 % of a tile's time, the row loop 30 %):
+    //   issue_idx(tk)   : everything that depends on the tile number alone — halo indices, pull list and offsets, flags, plan slots — requested right behind the row loop of the
+    //                     tile before, in front of its pull phase;
+    //   issue_gather()  : the operator inputs of tile + halo (they need the halo indices) and the first two row blocks, requested behind the first barrier of that pull phase:
+    //                     the indices have arrived by then, and the values have the rest of the pull phase to arrive in.
+    // What the current tile still needs of its own (entry, flags, halo count, tile number) is copied out of the in-flight set at staging time (`_c`).
+    int he[NQH];
+    auto issue_idx = [&](int tk) {
         tile = tile_of(tk); base = tile * T; a = base + i; in = a < A; ac = in ? (size_t)a : 0;
         owned = GHOSTS ? (a >= r.own0 && a < r.own1) : in;          // p.q and the camera block count a row once: on the rank that owns its voxel
         { const int wa0 = base + (int)(threadIdx.x & ~63u);
           const unsigned grp = (unsigned)__builtin_amdgcn_readfirstlane(wa0 < A ? (wa0 >> 6) : 0);
           wave_rows = reinterpret_cast<const char*>(r.rows + (size_t)grp * (size_t)(r.slots * ROW_BLOCK_F4)); }
         H = halo_cnt[tile];
-        int he[NQH];
 #pragma unroll
         for (int q = 0; q < NQH; ++q) he[q] = __builtin_nontemporal_load(&halo_idx[(size_t)tile * HMAX + (i + q * T < HMAX ? i + q * T : 0)]);
+#pragma unroll
+        for (int q = 0; q < NQL; ++q) { const int ch = i + q * T; hpl[q] = reinterpret_cast<const uint4*>(hp_src + (size_t)tile * HPCAP)[ch < HPCAP / 8 ? ch : 0]; }
+#pragma unroll
+        for (int q = 0; q < NQO; ++q) { const int o = i + q * T; hpo[q] = hp_off[(size_t)tile * (HMAX + 1) + (o <= HMAX ? o : HMAX)]; }
+    };
+    auto issue_gather = [&]() {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float* ub = m.u0 + (size_t)m.sys[b] * m.vec;
@@ -224,10 +259,6 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #pragma unroll
             for (int q = 0; q < NQH; ++q) { const int e = (i + q * T < H) ? he[q] : 0; hs[b][q] = ub[e]; ha[b][q] = ub[chunk + e]; }
         }
-#pragma unroll
-        for (int q = 0; q < NQL; ++q) { const int ch = i + q * T; hpl[q] = reinterpret_cast<const uint4*>(hp_src + (size_t)tile * HPCAP)[ch < HPCAP / 8 ? ch : 0]; }
-#pragma unroll
-        for (int q = 0; q < NQO; ++q) { const int o = i + q * T; hpo[q] = hp_off[(size_t)tile * (HMAX + 1) + (o <= HMAX ? o : HMAX)]; }
     };
     auto issue_meta = [&]() {
         fl = in ? r.aflags[ac] : 0;
@@ -236,14 +267,20 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #pragma unroll
         for (int w = 0; w < 5; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);
     };
-    int gm_next = tile0 < tk_end ? group_rows(tile0) : 0;
-    for (int tk = tile0; tk < tk_end; ++tk) {
-        gm = gm_next;
-        issue_in(tk);
-        issue_meta();
+    PH_DECL;
+    int gm_next = 0;
+    if (tile0 < tk_end) {          // (workgroup-uniform) the first tile's inputs: the only ones nothing overlaps
+        gm = group_rows(tile0);
+        issue_idx(tile0); issue_meta(); issue_gather();
         load_block(rwA, 0);
         load_block(rwB, 1);
-        gm_next = tk + 1 < tk_end ? group_rows(tk + 1) : 0;
+        gm_next = tile0 + 1 < tk_end ? group_rows(tile0 + 1) : 0;
+    }
+    for (int tk = tile0; tk < tk_end; ++tk) {
+        PH(tk == tile0 ? 0 : 10); PH_TILE;
+        // the tile whose inputs are in flight becomes the current one
+        const int a_c = a, H_c = H, tile_c = tile; const bool in_c = in, owned_c = owned;
+        PH(1);
         // ---- stage the operator inputs of tile + halo ----
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -257,11 +294,14 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #pragma unroll
         for (int q = 0; q < NQO; ++q) { const int o = i + q * T; if (o <= HMAX) hp_offs[o] = hpo[q]; }
         if (i == 0) lds[D_FLAG] = __int_as_float(0);
-        const bool active = in && (fl & F_ACTIVE);
+        const bool active = in_c && (fl & F_ACTIVE);
         const int nr = active ? nr_ld : 0;
         const uint8_t rf = active ? rf_ld : 0;
-        if (!in) { constexpr AllZ<ZSLOT> az; for (int w = 0; w < 5; ++w) ln[w] = az.w[w]; }
+        if (!in_c) { constexpr AllZ<ZSLOT> az; for (int w = 0; w < 5; ++w) ln[w] = az.w[w]; }
+        const unsigned ln4_c = ln[4];
+        PH(2);
         __syncthreads();
+        PH(3);
         const int sx = unpack12(ln, 5), sy = unpack12(ln, 0), sz = unpack12(ln, 3), mx = unpack12(ln, 9), my = unpack12(ln, 10), mz = unpack12(ln, 11);
         float self_s[NB], self_a[NB], pq_rows[NB], C[NB][NCOL];
         // ---- regulariser rows (constant coefficients), while the first two row blocks are in flight ----
@@ -275,11 +315,11 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
             const float usb = lds[U_S(b) + i];
             if (rf & 1) {
                 const float lap = ((((((-6.0f * usb) + lds[U_S(b) + rg[0]]) + lds[U_S(b) + rg[1]]) + lds[U_S(b) + rg[2]]) + lds[U_S(b) + rg[3]]) + lds[U_S(b) + rg[4]]) + lds[U_S(b) + rg[5]];
-                tr = tw1 * lap; if (owned) pq_pre += (double)(tr * lap);
+                tr = tw1 * lap; if (owned_c) pq_pre += (double)(tr * lap);
                 self_s[b] += -6.0f * tr;
             }
             lds[TR_L(b) + i] = tr;
-            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * usb; if (owned) pq_pre += (double)(ts * usb); self_s[b] += ts; }
+            if ((rf & 2) && (rf & 4)) { const float ts = tw2 * usb; if (owned_c) pq_pre += (double)(ts * usb); self_s[b] += ts; }
             if (rf & 7) PQ_L(b)[i] += pq_pre;
         }
         // the lane's 9 forward stencil slots (sdf slots 1..9 of a row): the same for every row of the entry and for every system
@@ -352,52 +392,70 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #pragma unroll
                     for (int c = 1; c < 10; ++c) C[b][c - 1] = fmaf(J[c], t, C[b][c - 1]);
                     C[b][9] = fmaf(J[11], t, C[b][9]); C[b][10] = fmaf(J[12], t, C[b][10]); C[b][11] = fmaf(J[13], t, C[b][11]);
-                    if (owned) {
+                    if (owned_c) {
 #pragma unroll
                         for (int q = 0; q < 9; ++q) cam9[b][q] = fmaf(J[P_INTR + q], t, cam9[b][q]);
                     }
                     tsel[b] = t;
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (!p.fix_poses && owned) { fsel = f; pvalid = true; }
+                if (!p.fix_poses && owned_c) { fsel = f; pvalid = true; }
             }
             const float jp[6] = {rw[3].z, rw[3].w, rw[4].x, rw[4].y, rw[4].z, rw[4].w};      // pose columns 14..19 of the row
             if (reload >= 0) load_block(rb, reload);
             mr_table_add<NB>(pvalid, fsel, jp, tsel, lds, o_tag, o_val, tcount, D0, SB);
         };
+        PH(4);
         consume(rwA, 0, 2);
         consume(rwB, 1, 3);
         consume(rwA, 2, 4);
         consume(rwB, 3, -1);
         consume(rwA, 4, -1);
-        if (owned) {
+        PH(5);
+        if (owned_c) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) PQ_L(b)[i] += (double)pq_rows[b];
         }
+        const size_t ac_c = in_c ? (size_t)a_c : 0;          // (rebuilt here: as a 64-bit value it would be live across the row loop)
         unsigned lr[2];
 #pragma unroll
-        for (int w = 0; w < 2; ++w) lr[w] = __builtin_nontemporal_load(&lnbr[(size_t)(5 + w) * Acap + ac]);
+        for (int w = 0; w < 2; ++w) lr[w] = __builtin_nontemporal_load(&lnbr[(size_t)(5 + w) * Acap + ac_c]);
         float eaw[6];
 #pragma unroll
-        for (int d = 0; d < 6; ++d) eaw[d] = __builtin_nontemporal_load(&eaw_sym[(size_t)d * Acap + ac]);
+        for (int d = 0; d < 6; ++d) eaw[d] = __builtin_nontemporal_load(&eaw_sym[(size_t)d * Acap + ac_c]);
+        // the NEXT tile (the last tile of the workgroup asks for itself again: unconditional loads keep the compiler's wait counts exact; its row blocks are
+        // requested through zero-sized descriptors and move nothing): everything that depends on the tile number alone, now
+        const int tk_n = tk + 1 < tk_end ? tk + 1 : tk;
+        gm = gm_next;
+        issue_idx(tk_n);
         if (tcount > TC - 16 && lane == 0) lds[D_FLAG] = __int_as_float(1);      // a table is nearly full: behind the barrier ALL tables are merged, in wave order
-        const unsigned lall[LNBR_WORDS] = {0u, 0u, 0u, 0u, ln[4], lr[0], lr[1]};
+        const unsigned lall[LNBR_WORDS] = {0u, 0u, 0u, 0u, ln4_c, lr[0], lr[1]};
         const int r2y = unpack12(lall, 12), ryz = unpack12(lall, 13), r2z = unpack12(lall, 14), rxy = unpack12(lall, 15), rxz = unpack12(lall, 16), r2x = unpack12(lall, 17);
+        PH(6);
         // ---- pull, system by system through the one column-sum buffer ----
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
+            if (b > 0) PH(10);
             if (alive[b]) {
 #pragma unroll
                 for (int c = 0; c < NCOL; ++c) lds[C_L + c * T + i] = C[b][c];
             }
             const float ua_c = lds[U_A(b) + i];
+            PH(7);
             __syncthreads();
+            PH(8);
+            if (b == 0) {          // the next tile's operator inputs (its halo indices are here by now) and first two row blocks: in flight for the rest of the pull phase
+                issue_meta(); issue_gather();
+                load_block(rwA, 0);
+                load_block(rwB, 1);
+                gm_next = tk + 2 < tk_end ? group_rows(tk + 2) : 0;
+            }
             if (b == 0 && __float_as_int(lds[D_FLAG]) != 0) {                      // (workgroup-uniform: written before the barrier, cleared by the next tile's staging behind the next one)
                 for (int w = 0; w < NW; ++w) { if (wave == w) mr_table_merge<NB>(lds, o_tag, o_val, tcount, D0, SB); __syncthreads(); }
             }
             float* const qacc = m.qacc0 + (size_t)m.sys[b] * m.vec;
             float* const qh = m.qh0 + (size_t)m.sys[b] * m.qh;
-            if (in && alive[b]) {
+            if (in_c && alive[b]) {
                 auto pull = [&](int col, int slot) { return slot < T ? lds[C_L + col * T + slot] : 0.0f; };
                 float qs = self_s[b], qa = self_a[b];
                 qs += pull(0, my) + pull(1, r2y) + pull(2, ryz) + pull(3, mz) + pull(4, r2z) + pull(5, mx) + pull(6, rxy) + pull(7, rxz) + pull(8, r2x);
@@ -408,14 +466,14 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                 float ea = 0.0f, eq = 0.0f;
 #pragma unroll
                 for (int d = 0; d < 6; ++d) { const float diff = ua_c - lds[U_A(b) + rg[d]]; const float t = eaw[d] * diff; ea += t; eq += (rg[d] == ZSLOT ? 1.0f : 0.5f) * t * diff; }
-                qa += tw3 * ea; if (owned) PQ_L(b)[i] += (double)(tw3 * eq);      // an edge whose other voxel is a list entry is seen from both sides (by their owners)
-                qacc[a] = qs; qacc[chunk + a] = qa;
+                qa += tw3 * ea; if (owned_c) PQ_L(b)[i] += (double)(tw3 * eq);      // an edge whose other voxel is a list entry is seen from both sides (by their owners)
+                qacc[a_c] = qs; qacc[chunk + a_c] = qa;
             }
 #pragma unroll
             for (int q = 0; q < NQH; ++q) {
                 const int hq = i + q * T;
-                if (hq < H && alive[b]) {
-                    const size_t o = (size_t)tile * HMAX + hq;
+                if (hq < H_c && alive[b]) {
+                    const size_t o = (size_t)tile_c * HMAX + hq;
                     float hsum = 0.0f, hal = 0.0f;
                     const int j1 = hp_offs[hq + 1];
                     for (int j = hp_offs[hq]; j < j1; ++j) {
@@ -426,9 +484,11 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
                     qh[2 * o] = hsum; qh[2 * o + 1] = hal;
                 }
             }
+            PH(9);
             __syncthreads();       // the next system's column sums / the next tile's staging overwrite what other lanes are still pulling from
         }
     }
+    PH(10);
     // ---- the camera block of every system: per-wave sums and tables -> the dense accumulator, in wave order -> one float row per workgroup ----
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -461,6 +521,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #pragma unroll
         for (int b = 0; b < NB; ++b) { if (alive[b]) block_partial_d(PQ_L(b)[i], m.pq0 + (size_t)m.sys[b] * m.part, 1, 0); }
     }
+    PH(11); PH_FLUSH(NB);
 #undef SYS
 #undef U_S
 #undef U_A
@@ -470,6 +531,23 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #undef hp_offs
 #undef PQ_L
 }
+
+#ifdef I3D_MR_PHASES
+static void mr_phase_report() {
+    unsigned long long h[3][MR_NPH + 2];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mr_phase), sizeof(h)) != hipSuccess) return;
+    static const char* name[MR_NPH] = {"prologue", "issue loads", "staging writes (gather wait)", "staging barrier", "regulariser rows + hoist", "row loop", "reverse slots / Ea weights",
+                                       "pull: column sums -> LDS", "pull: barrier 1", "pull: sums + halo walk + stores", "pull: barrier 2", "epilogue"};
+    for (int nb = 0; nb < 3; ++nb) {
+        if (!h[nb][MR_NPH + 1]) continue;
+        double tot = 0.0; for (int k = 0; k < MR_NPH; ++k) tot += (double)h[nb][k];
+        std::fprintf(stderr, "[mr phases] k_eg_tile_mr<%d>: %llu waves, %.1f tiles per wave, %.0f ticks per wave (s_memtime), %.0f per tile\n", nb + 1, h[nb][MR_NPH + 1], (double)h[nb][MR_NPH] / (double)h[nb][MR_NPH + 1],
+                     tot / (double)h[nb][MR_NPH + 1], tot / (double)h[nb][MR_NPH]);
+        for (int k = 0; k < MR_NPH; ++k) std::fprintf(stderr, "[mr phases]   <%d> %-32s %6.2f %%  %9.0f ticks per tile\n", nb + 1, name[k], 100.0 * (double)h[nb][k] / tot, (double)h[nb][k] / (double)h[nb][MR_NPH]);
+    }
+}
+void mr_phase_report_now() { (void)hipDeviceSynchronize(); mr_phase_report(); }
+#endif
 
 // the largest number of systems one launch can take at K keyframes (the staged inputs of every system must fit the 160 KB of LDS): 3 at the bench's K = 200, 0 = never
 int eg_tile_mr_max_systems(int K) {

@@ -13,6 +13,10 @@
 
 namespace i3d {
 
+#ifdef I3D_MR_PHASES
+void mr_phase_report_now();     // tile_pass_mr.hip, variant build only
+#endif
+
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static OptParams make_params(const i3d_context* c, const i3d_optimizer_config& cfg, const double* intr, const double* dist) {
@@ -993,6 +997,9 @@ int optimize(i3d_context* c, const i3d_optimizer_config& cfg, i3d_iteration_stat
         timing_flush(c);
     }
     c->assembled = false;
+#ifdef I3D_MR_PHASES
+    mr_phase_report_now();      // (variant build only: tools/build_variant.sh)
+#endif
     return I3D_OK;
 }
 

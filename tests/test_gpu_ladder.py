@@ -97,9 +97,13 @@ def test_a_system_does_not_depend_on_the_systems_it_shares_the_rows_with(slice_s
 
 
 def test_multi_system_kernel_against_the_round_4_kernel(slice_setup, monkeypatch):
-    """k_eg_tile_mr<1> vs k_eg_tile in the serial loop: the same operator up to the association of its wave sums"""
-    a = _serial_det(slice_setup, monkeypatch, mr1=False); b = _serial_det(slice_setup, monkeypatch, mr1=True)
+    """k_eg_tile_mr<1> vs k_eg_tile in the serial loop: the same operator up to the association of its wave sums.  The outer iteration with the rejected attempts, from
+    identical inputs (_second_iteration_start: two CHAINED iterations compared across kernels are bistable at the parity bar's scale — a near-tie of the reference's top-5 cut)."""
+    monkeypatch.setenv("I3D_DETERMINISTIC", "1"); monkeypatch.setenv("I3D_LADDER", "1")
+    monkeypatch.setenv("I3D_EGT_MR1", "0"); a = _run_second(slice_setup)
+    monkeypatch.setenv("I3D_EGT_MR1", "1"); b = _run_second(slice_setup)
     st1, s1, a1, c1, _ = a; st2, s2, a2, c2, _ = b
+    assert st1[0].num_attempts >= 4
     assert [(s.num_attempts, list(s.step_accepted[:s.num_attempts]), list(s.pcg_iterations[:s.num_attempts])) for s in st1] == \
            [(s.num_attempts, list(s.step_accepted[:s.num_attempts]), list(s.pcg_iterations[:s.num_attempts])) for s in st2]
     for x, y in zip(st1, st2):
@@ -118,11 +122,12 @@ def test_ladder_with_fixed_pcg_depth_and_residual_resets(slice_setup, monkeypatc
 
 
 def test_ladder_in_the_default_mode_agrees_to_round_off(slice_setup, monkeypatch):
+    """the ladder (k_eg_tile_mr) against the serial loop (k_eg_tile) in the default mode, the outer iteration with the rejected attempts from identical inputs"""
     monkeypatch.setenv("I3D_LADDER", "1")
-    st1, s1, a1, c1, _ = _run(slice_setup)
+    st1, s1, a1, c1, _ = _run_second(slice_setup)
     monkeypatch.setenv("I3D_LADDER", "6")
-    st2, s2, a2, c2, lad = _run(slice_setup)
-    assert lad["row_streams"] < lad["system_passes"]
+    st2, s2, a2, c2, lad = _run_second(slice_setup)
+    assert lad["row_streams"] < lad["system_passes"] and st1[0].num_attempts >= 4
     assert [(s.num_attempts, list(s.step_accepted[:s.num_attempts])) for s in st1] == [(s.num_attempts, list(s.step_accepted[:s.num_attempts])) for s in st2]
     for x, y in zip(st1, st2):       # Ceres' stop test compares i (Q1 - Q0) / Q1 with 0.1: summation-order noise may move a count by one
         assert all(abs(int(p) - int(q)) <= 1 for p, q in zip(x.pcg_iterations[:x.num_attempts], y.pcg_iterations[:y.num_attempts]))
@@ -146,15 +151,45 @@ def test_an_invalid_step_puts_the_batch_out_of_step_and_it_is_solved_again(slice
     assert lad[4]["resyncs"] >= 1, lad[4]
 
 
-def _run_ranks(S, W, iterations=2, cg_fixed=-1):
-    """W simulated ranks (host threads on one GPU, i3d_comm_init_sim) through one optimize call on the bench slice: per rank (stats, sdf, albedo, camera, ladder stats)"""
+_second = {}
+
+
+def _second_iteration_start(S):
+    """The state the SECOND outer iteration of the bench slice starts from (the first one, one accepted attempt, run once on a single rank in the bit-reproducible default
+    mode): the iteration with the rejected attempts — the one the ladder is about — then starts from IDENTICAL inputs in every variant compared below.  (Chaining the two
+    iterations inside every variant instead makes the comparison bistable: the variants' first results differ by round-off, which is enough to swap two keyframes of
+    near-equal weight at the top-5 cut of one voxel, colorization.cpp:357-370 — a discrete decision of the reference algorithm — and the fields around it then end 5.3e-4
+    apart in about half of the runs, sharded or not: tools/experiments/sharded_ladder_diag.py, and _run_both of test_gpu_bench_parity.py for the same voxel in round 1.)"""
+    if "start" not in _second:
+        O = S["O"]; sc = S["sc"]
+        cfg = helpers.gpu_cfg(_bench_cfg(O, S["thres"], -1, second=False))
+        ctx = helpers.gpu_context(sc, S["arrays"], S["vsh"])
+        st = ctx.optimize(cfg); sdf, alb = ctx.get_grid(); cam = ctx.get_camera(); ctx.close()
+        assert st[0].successful_steps == 1
+        arrays = dict(S["arrays"]); arrays["sdf_refined"] = sdf; arrays["albedo"] = alb
+        sc2 = dict(sc); sc2["intr"], sc2["dist"], sc2["poses"] = cam
+        _second["start"] = (sc2, arrays)
+    return _second["start"]
+
+
+def _run_second(S, cg_fixed=-1):
+    """the second outer iteration alone, single rank"""
+    sc2, arrays = _second_iteration_start(S)
+    cfg = helpers.gpu_cfg(_bench_cfg(S["O"], S["thres"], cg_fixed, second=True))
+    ctx = helpers.gpu_context(sc2, arrays, S["vsh"])
+    st = ctx.optimize(cfg); sdf, alb = ctx.get_grid(); cam = ctx.get_camera(); lad = ctx.debug_ladder_stats(); ctx.close()
+    return st, sdf, alb, cam, lad
+
+
+def _run_ranks(S, W, cg_fixed=-1):
+    """W simulated ranks (host threads on one GPU, i3d_comm_init_sim) through the second outer iteration of the bench slice: per rank (stats, sdf, albedo, camera, ladder stats, comm stats)"""
     import threading
     from intrinsic3d_amd import binding
-    O = S["O"]; sc = S["sc"]; a0 = S["arrays"]
-    cfg = helpers.gpu_cfg(_bench_cfg(O, S["thres"], cg_fixed)); cfg.iterations = iterations
+    sc2, arrays = _second_iteration_start(S)
+    cfg = helpers.gpu_cfg(_bench_cfg(S["O"], S["thres"], cg_fixed, second=True))
     L = binding.load()
     shared = L.i3d_comm_sim_create(W)
-    ctxs = [helpers.gpu_context(sc, a0, S["vsh"]) for _ in range(W)]
+    ctxs = [helpers.gpu_context(sc2, arrays, S["vsh"]) for _ in range(W)]
     for r, c in enumerate(ctxs):
         c.comm_init_sim(shared, r)
     out = [None] * W; err = [None] * W
@@ -180,37 +215,40 @@ def test_sharded_ranks_run_the_ladder(slice_setup, world):
     """Round 6: the damping ladder in the SHARDED path (the shard key of the reference is subvolumes.cpp:281-295, here tile ranges of the brick-ordered
     work list).  W ranks — simulated by W host threads on one GPU, every exchange through the Comm interface the RCCL transport implements — solve the rejected attempts
     of an outer iteration together: k_eg_tile_mr<NB, GHOSTS> over own + ghost tiles, ONE all-reduce of the batch's slice sums and ONE of its [camera block | p.q] per
-    pass.  Against the single-rank ladder on the bench slice (every group free, Ceres' own PCG stop, two chained outer iterations): same rows, same attempts, same
-    accept / reject sequence; PCG counts equal (+-1 on rejected attempts: the ranks' partial sums are associated differently, and a stop test may sit on its
-    threshold); costs, fields, intrinsics and poses to the sharded path's bar (1e-4, max-norm).  And the ladder did run on every rank (batches > 0, fewer row streams
-    than system passes), with the batch's exchanges in ONE message each: two all-reduces per pass whatever the number of live systems."""
-    ref = _run(slice_setup)
-    rst, rsdf, ralb, rcam, rlad = ref
-    assert rlad["batches"] > 0
+    pass, ONE rim message of B values per entry.  Against the single-rank ladder on the bench slice (every group free, Ceres' own PCG stop; the outer iteration with the
+    rejected attempts, from identical inputs): same rows, same attempts, same accept / reject sequence; PCG counts equal (+-1 on rejected attempts: the ranks' partial
+    sums are associated differently, and a stop test may sit on its threshold); costs, fields, intrinsics and poses to 1e-5 in the max-norm (measured: 1e-7 ... 4e-7).
+    And the ladder did run on every rank (batches > 0, fewer row streams than system passes), with the batch's exchanges in ONE message each."""
+    rst, rsdf, ralb, rcam, rlad = _run_second(slice_setup)
+    assert rlad["batches"] > 0 and rst[0].num_attempts >= 4
     for rank, (st, sdf, alb, cam, lad, comm) in enumerate(_run_ranks(slice_setup, world)):
         assert lad["batches"] > 0 and lad["depth"] > 1 and lad["row_streams"] < lad["system_passes"], (rank, lad)
-        for k, (s1, s2) in enumerate(zip(rst, st)):
-            what = (world, rank, k, _stats([s1]), _stats([s2]))
-            assert list(s1.rows) == list(s2.rows) and s1.num_attempts == s2.num_attempts, what
-            assert list(s1.step_accepted[:s1.num_attempts]) == list(s2.step_accepted[:s2.num_attempts]), what
-            p1 = list(s1.pcg_iterations[:s1.num_attempts]); p2 = list(s2.pcg_iterations[:s2.num_attempts])
-            assert all(abs(x - y) <= 1 for x, y in zip(p1, p2)) and p1[-1] == p2[-1], what
-            assert abs(s1.cost_initial - s2.cost_initial) <= (1e-12 if k == 0 else 1e-4) * s1.cost_initial and abs(s1.cost_final - s2.cost_final) <= 1e-4 * s1.cost_final, what
-        assert np.abs(sdf - rsdf).max() <= 1e-4 * np.abs(rsdf).max() and np.abs(alb - ralb).max() <= 1e-4 * np.abs(ralb).max()
-        np.testing.assert_allclose(cam[0], rcam[0], rtol=1e-4); np.testing.assert_allclose(cam[2], rcam[2], rtol=1e-4, atol=1e-6)
-        # exchanges of the PCG passes: two all-reduces per pass of a BATCH (not per system): fewer reduce calls than twice the system passes
-        assert comm["reduce_calls"] < 2 * lad["system_passes"], (comm, lad)
+        s1, s2 = rst[0], st[0]
+        what = (world, rank, _stats([s1]), _stats([s2]))
+        assert list(s1.rows) == list(s2.rows) and s1.num_attempts == s2.num_attempts, what
+        assert list(s1.step_accepted[:s1.num_attempts]) == list(s2.step_accepted[:s2.num_attempts]), what
+        p1 = list(s1.pcg_iterations[:s1.num_attempts]); p2 = list(s2.pcg_iterations[:s2.num_attempts])
+        assert all(abs(x - y) <= 1 for x, y in zip(p1, p2)) and p1[-1] == p2[-1], what
+        assert abs(s1.cost_initial - s2.cost_initial) <= 1e-12 * s1.cost_initial and abs(s1.cost_final - s2.cost_final) <= 1e-5 * s1.cost_final, what
+        e = (float(np.abs(sdf - rsdf).max() / np.abs(rsdf).max()), float(np.abs(alb - ralb).max() / np.abs(ralb).max()))
+        print(f"\n[sharded ladder, {world} ranks, rank {rank}] sdf {e[0]:.1e} albedo {e[1]:.1e} of the field maximum against the single-rank ladder; exchanges {comm['reduce_calls']} all-reduces, {comm['halo_calls']} rim messages "
+              f"for {lad['system_passes']} system passes in {lad['row_streams']} streams")
+        assert max(e) <= 1e-5, e
+        np.testing.assert_allclose(cam[0], rcam[0], rtol=1e-5); np.testing.assert_allclose(cam[2], rcam[2], rtol=1e-5, atol=1e-7)
+        # exchanges of the PCG passes: two all-reduces and one rim message per pass of a BATCH, not per system
+        assert comm["reduce_calls"] < 2 * lad["system_passes"] and comm["halo_calls"] < lad["system_passes"], (comm, lad)
 
 
 def test_sharded_ladder_with_fixed_pcg_depth_equals_the_sharded_serial_loop(slice_setup, monkeypatch):
-    """The sharded ladder against the sharded SERIAL loop (I3D_LADDER=1: k_eg_tile<GHOSTS>, the six-launch pass) at a fixed PCG depth of 12 (one residual reset): with no
-    stop test to sit on a threshold, attempts, accept sequence and PCG counts must be identical, and the fields agree to the round-off of two operator kernels whose wave
-    sums are associated differently (k_eg_tile_mr against k_eg_tile: as test_multi_system_kernel_against_the_round_4_kernel) — far below the parity bar."""
+    """The sharded ladder against the sharded SERIAL loop (I3D_LADDER=1: k_eg_tile<GHOSTS>, the six-launch pass) at a fixed PCG depth of 12 (one residual reset), the outer
+    iteration with the rejected attempts from identical inputs: with no stop test to sit on a threshold, attempts, accept sequence and PCG counts must be identical, and
+    the fields agree to the round-off of two operator kernels whose wave sums are associated differently (k_eg_tile_mr against k_eg_tile: as
+    test_multi_system_kernel_against_the_round_4_kernel) — far below the parity bar."""
     lad = _run_ranks(slice_setup, 2, cg_fixed=12)
     monkeypatch.setenv("I3D_LADDER", "1")
     ser = _run_ranks(slice_setup, 2, cg_fixed=12)
     for (st1, s1, a1, c1, l1, _), (st2, s2, a2, c2, l2, _) in zip(lad, ser):
-        assert l1["batches"] > 0 and l2["batches"] == 0
+        assert l1["batches"] > 0 and l2["batches"] == 0 and st1[0].num_attempts >= 4
         assert [x[:3] for x in _stats(st1)] == [x[:3] for x in _stats(st2)], (_stats(st1), _stats(st2))
         assert np.abs(s1 - s2).max() <= 1e-5 * np.abs(s2).max() and np.abs(a1 - a2).max() <= 1e-5 * np.abs(a2).max()
         np.testing.assert_allclose(c1[0], c2[0], rtol=1e-5); np.testing.assert_allclose(c1[2], c2[2], rtol=1e-5, atol=1e-7)
