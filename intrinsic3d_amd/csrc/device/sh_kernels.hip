@@ -15,6 +15,7 @@
 // fp64 solve to 1e-4 and the 9x9 blocks are ill-conditioned when a subvolume sees a narrow range of normals.
 #include "kernels.hpp"
 #include "sh_kernels.hpp"
+#include <cstdlib>
 
 namespace i3d {
 
@@ -90,12 +91,12 @@ static __device__ inline void sh_features(const GridView& g, int s, double f[10]
 // shared by waves, nothing is added atomically, the sums of an estimate are bit-reproducible.  Round 4 gave a subvolume ONE wave (a single global volume of 2 M voxels
 // = one wave walking 36 k tiles); round 3 used fp64 atomics wherever a chunk ended inside a subvolume.
 constexpr int SH_CHUNK_TILES = 32;
-__global__ void __launch_bounds__(256) k_sh_gram(GridView g, int m0, int m1, int S, int nchunk, const int* __restrict__ sorted_vox, const int* __restrict__ sorted_sub,
+__global__ void __launch_bounds__(256) k_sh_gram(GridView g, int m0, int m1, int S, int nchunk, int chunk0 /* first chunk of this slab */, const int* __restrict__ sorted_vox, const int* __restrict__ sorted_sub,
                                                  double* __restrict__ part /*[S][nchunk][100]*/, double* __restrict__ wpart /*[S][nchunk]*/) {
     __shared__ double feat[4][64][17];     // +1 padding: the MFMA operand read walks a column of 4 voxels x 16 features
     __shared__ double wl[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int sub = blockIdx.x * 4 + wv, chunk = blockIdx.y;
+    const int sub = blockIdx.x * 4 + wv, chunk = blockIdx.y;          // (chunk: within the slab; chunk0 + chunk within the subvolume's run)
     if (sub >= S) return;
     // the subvolume's run of the (sorted) list, cut to the slice
     int lo = m0, hi = m1;
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) k_sh_gram(GridView g, int m0, int m1, int
     hi = m1;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_sub[mid] <= sub) lo = mid + 1; else hi = mid; }
     const int run1 = lo;
-    const long long c0 = (long long)run0 + (long long)chunk * (SH_CHUNK_TILES * 64);
+    const long long c0 = (long long)run0 + (long long)(chunk0 + chunk) * (SH_CHUNK_TILES * 64);
     if (c0 >= run1) return;
     const int first = (int)c0, last = (int)((c0 + SH_CHUNK_TILES * 64 < run1) ? c0 + SH_CHUNK_TILES * 64 : run1);
     v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -138,12 +139,12 @@ __global__ void __launch_bounds__(256) k_sh_gram(GridView g, int m0, int m1, int
     if (lane == 0) wpart[(size_t)sub * nchunk + chunk] = wtot;
 }
 // the chunks of every subvolume, added in chunk order (one thread per entry of a block; entry 100 = the weight sum)
-__global__ void __launch_bounds__(128) k_sh_gram_sum(int S, int nchunk, const double* __restrict__ part, const double* __restrict__ wpart, double* __restrict__ gram, double* __restrict__ wsub) {
+// (`first` = 0: a later slab of chunks continues the running sums — the order of the additions is the chunk order either way)
+__global__ void __launch_bounds__(128) k_sh_gram_sum(int S, int nchunk, int first, const double* __restrict__ part, const double* __restrict__ wpart, double* __restrict__ gram, double* __restrict__ wsub) {
     const int sub = blockIdx.x, e = threadIdx.x;
     if (sub >= S || e > 100) return;
-    double s = 0.0;
-    if (e < 100) { for (int c = 0; c < nchunk; ++c) s += part[((size_t)sub * nchunk + c) * 100 + e]; gram[(size_t)sub * 100 + e] = s; }
-    else { for (int c = 0; c < nchunk; ++c) s += wpart[(size_t)sub * nchunk + c]; wsub[sub] = s; }
+    if (e < 100) { double s = first ? 0.0 : gram[(size_t)sub * 100 + e]; for (int c = 0; c < nchunk; ++c) s += part[((size_t)sub * nchunk + c) * 100 + e]; gram[(size_t)sub * 100 + e] = s; }
+    else { double s = first ? 0.0 : wsub[sub]; for (int c = 0; c < nchunk; ++c) s += wpart[(size_t)sub * nchunk + c]; wsub[sub] = s; }
 }
 
 __global__ void __launch_bounds__(256) k_sh_assign(int M, const unsigned long long* __restrict__ sorted_keys, const unsigned long long* __restrict__ uniq, int S, int* __restrict__ sorted_sub) {
@@ -193,12 +194,29 @@ void launch_sh_keys(hipStream_t st, GridView g, ShParams sp, unsigned long long*
 void launch_sh_all_keys(hipStream_t st, GridView g, ShParams sp, unsigned long long* keys) { if (g.N > 0) k_sh_all_keys<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, keys); }
 void launch_sh_assign(hipStream_t st, int M, const unsigned long long* sorted_keys, const unsigned long long* uniq, int S, int* sorted_sub) { if (M > 0) k_sh_assign<<<(M + 255) / 256, 256, 0, st>>>(M, sorted_keys, uniq, S, sorted_sub); }
 int sh_gram_chunks(long long longest_run) { const long long per = (long long)SH_CHUNK_TILES * 64; const long long n = (longest_run + per - 1) / per; return n < 1 ? 1 : (int)n; }
-// nchunk >= sh_gram_chunks(longest run of the slice); part [S * nchunk * 100] and wpart [S * nchunk] are scratch, zeroed here
-void launch_sh_gram(hipStream_t st, GridView g, int m0, int m1, int S, int nchunk, const int* sorted_vox, const int* sorted_sub, double* part, double* wpart, double* gram, double* wsub) {
-    if (m1 <= m0 || S <= 0) return;
-    (void)hipMemsetAsync(part, 0, sizeof(double) * (size_t)S * nchunk * 100, st); (void)hipMemsetAsync(wpart, 0, sizeof(double) * (size_t)S * nchunk, st);
-    k_sh_gram<<<dim3((S + 3) / 4, nchunk), 256, 0, st>>>(g, m0, m1, S, nchunk, sorted_vox, sorted_sub, part, wpart);
-    k_sh_gram_sum<<<S, 128, 0, st>>>(S, nchunk, part, wpart, gram, wsub);
+// The chunk dimension runs in SLABS (round 6, advisor finding of round 5: the scratch was S x (chunks of the LONGEST subvolume) x 100 doubles — one large subvolume beside
+// thousands of small ones, or one global volume of > 134 M voxels past the 65535 limit of gridDim.y, and nothing checked the launches): a slab holds at most
+// sh_gram_slab_chunks(S) chunks of every subvolume (<= 128 MB of scratch, <= 32768 rows of the grid), its blocks are added to the running sums in chunk order, so the result
+// does not depend on the slab size.  Returns a HIP error code.
+int sh_gram_slab_chunks(int S, int nchunk) {
+    long long cap = (128ll << 20) / (100ll * 8ll * (long long)(S > 0 ? S : 1));
+    if (cap < 1) cap = 1; if (cap > 32768) cap = 32768;
+    { const char* e = std::getenv("I3D_SH_SLAB"); if (e && std::atoi(e) > 0) cap = std::atoi(e); }      // tests: force several slabs on a small scene (read per call)
+    return (int)(cap < nchunk ? cap : nchunk);
+}
+// nchunk >= sh_gram_chunks(longest run of the slice); part [S * slab * 100] and wpart [S * slab] are scratch (slab = sh_gram_slab_chunks(S, nchunk)), zeroed here
+hipError_t launch_sh_gram(hipStream_t st, GridView g, int m0, int m1, int S, int nchunk, const int* sorted_vox, const int* sorted_sub, double* part, double* wpart, double* gram, double* wsub) {
+    if (m1 <= m0 || S <= 0) return hipSuccess;
+    const int slab = sh_gram_slab_chunks(S, nchunk);
+    for (int c0 = 0; c0 < nchunk; c0 += slab) {
+        const int nc = nchunk - c0 < slab ? nchunk - c0 : slab;
+        hipError_t e = hipMemsetAsync(part, 0, sizeof(double) * (size_t)S * nc * 100, st); if (e != hipSuccess) return e;
+        e = hipMemsetAsync(wpart, 0, sizeof(double) * (size_t)S * nc, st); if (e != hipSuccess) return e;
+        k_sh_gram<<<dim3((S + 3) / 4, nc), 256, 0, st>>>(g, m0, m1, S, nc, c0, sorted_vox, sorted_sub, part, wpart);
+        k_sh_gram_sum<<<S, 128, 0, st>>>(S, nc, c0 == 0 ? 1 : 0, part, wpart, gram, wsub);
+        e = hipGetLastError(); if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 void launch_sh_interpolate(hipStream_t st, GridView g, ShParams sp, const unsigned long long* uniq, int S, const double* sh, float* out) {
     if (g.N > 0) k_sh_interpolate<<<(g.N + 255) / 256, 256, 0, st>>>(g, sp, uniq, S, sh, out);

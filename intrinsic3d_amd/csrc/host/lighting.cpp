@@ -219,8 +219,9 @@ int estimate_sh(i3d_context* c, float subvolume_size, double lambda_reg, double 
     const long long m0 = (M * me) / world, m1 = (M * (me + 1)) / world;
     long long longest = 0; for (size_t i = 0; i < el_keys.size(); ++i) if (el_keys[i] != ~0ull) longest = std::max(longest, (long long)el_cnt[i]);
     const int nchunk = sh_gram_chunks(longest);          // (a slice holds at most the whole run of a subvolume)
-    DevBuf<double> d_part, d_wpart; CTX_HIP(c, d_part.alloc((size_t)S * nchunk * 100)); CTX_HIP(c, d_wpart.alloc((size_t)S * nchunk));
-    if (m1 > m0) launch_sh_gram(st, g, (int)m0, (int)m1, S, nchunk, svox.p, ssub.p, d_part.p, d_wpart.p, d_gram.p, d_wsum.p);
+    const int slab = sh_gram_slab_chunks(S, nchunk);     // chunks per launch: bounds the scratch (<= 128 MB) and the grid
+    DevBuf<double> d_part, d_wpart; CTX_HIP(c, d_part.alloc((size_t)S * slab * 100)); CTX_HIP(c, d_wpart.alloc((size_t)S * slab));
+    if (m1 > m0) CTX_HIP(c, launch_sh_gram(st, g, (int)m0, (int)m1, S, nchunk, svox.p, ssub.p, d_part.p, d_wpart.p, d_gram.p, d_wsum.p));
     if (c->comm && (c->comm->world > 1 || c->comm->force)) {
         if (c->comm->allreduce_sum(d_gram.p, (size_t)S * 100, st) || c->comm->allreduce_sum(d_wsum.p, (size_t)S, st)) return ctx_fail(c, I3D_ERR_COMM, "i3d_estimate_sh: all-reduce failed");
     }

@@ -633,24 +633,35 @@ static int pcg_solve_fused(i3d_context* c, const i3d_optimizer_config& cfg, cons
 // sums, block-Jacobi inverses, camera-tail diagonal and scalar states; b, the column norms and S are shared.
 constexpr int LAD_PART_STEP = 4 * 2048, LAD_PART_PQ = 2048, LAD_PART_D2 = 2048;
 static size_t lad_redop_stride(int NS) { return ((size_t)NS + 1 + 3) & ~(size_t)3; }
+// Sized by what the CURRENT work list needs (round 6, advisor finding of round 5: the slabs were sized by the whole grid — 2.3 GB of vectors + 1.2 GB of halo sums at the bench
+// size, 290 bytes per stored voxel on top of the 16 solver vectors, whatever the active share): the vectors by the list's layout (2 chunk + 6K + 9, rounded up to 64 K entries so
+// that a list that grows a little does not reallocate), the halo sums by the list's tiles.  Grow-only.  Returns non-zero WITHOUT latching an error when the device cannot hold
+// them: the caller then solves this outer iteration with the serial trust-region loop.
 static int alloc_ladder(i3d_context* c) {
     const Layout L = layout_of(c);
     const int nsys = c->ladder_max;
     LadVec& lv = c->lad;
-    const size_t vec = ((size_t)c->v_x.n + 3) & ~(size_t)3;                                  // as long as the solver vectors of the context
-    const size_t qh = 2 * (size_t)tile_plan_tiles_of(c->Acap, 512) * (size_t)tile_plan_hmax_of(512);
+    const size_t vec = ((size_t)L.NP + 65535) & ~(size_t)65535;
+    const size_t qh = 2 * (size_t)tile_plan_tiles_of((int)std::min((size_t)c->Acap, ((size_t)c->chunk + 65535) & ~(size_t)65535), 512) * (size_t)tile_plan_hmax_of(512);
     const size_t cam = (size_t)2048 * (((size_t)L.NS + 3) & ~(size_t)3);
     lv.vec = vec; lv.qh = qh; lv.cam = cam; lv.part = LAD_PART_STEP + LAD_PART_PQ + LAD_PART_D2; lv.mblk = ((size_t)36 * c->K + 41 + 3) & ~(size_t)3; lv.tail = ((size_t)L.NS + 3) & ~(size_t)3;
     const bool fresh = c->lad_vec.n < (size_t)6 * nsys * vec || !c->lad_vec.p;
-    CTX_HIP(c, c->lad_vec.alloc((size_t)6 * nsys * vec));
-    if (fresh) CTX_HIP(c, hipMemsetAsync(c->lad_vec.p, 0, sizeof(float) * c->lad_vec.n, c->stream));      // padding entries stay finite
-    CTX_HIP(c, c->lad_qh.alloc((size_t)nsys * qh)); CTX_HIP(c, c->lad_cam.alloc((size_t)nsys * cam)); CTX_HIP(c, c->lad_part.alloc((size_t)nsys * lv.part));
-    CTX_HIP(c, c->lad_mblk.alloc((size_t)nsys * lv.mblk)); CTX_HIP(c, c->lad_tail.alloc((size_t)nsys * lv.tail)); CTX_HIP(c, c->lad_st.alloc((size_t)2 * LADDER_MAX));
-    if (sharded(c)) {      // what a pass all-reduces: [LADDER_MAX][4] slice sums of the step kernel, then [LADDER_MAX][NS + 1, padded] camera block + p.q of the operator pass
+    bool ok = c->lad_vec.alloc((size_t)6 * nsys * vec) == hipSuccess;
+    if (ok && fresh) ok = hipMemsetAsync(c->lad_vec.p, 0, sizeof(float) * c->lad_vec.n, c->stream) == hipSuccess;      // padding entries stay finite
+    ok = ok && c->lad_qh.alloc((size_t)nsys * qh) == hipSuccess && c->lad_cam.alloc((size_t)nsys * cam) == hipSuccess && c->lad_part.alloc((size_t)nsys * lv.part) == hipSuccess
+            && c->lad_mblk.alloc((size_t)nsys * lv.mblk) == hipSuccess && c->lad_tail.alloc((size_t)nsys * lv.tail) == hipSuccess && c->lad_st.alloc((size_t)2 * LADDER_MAX) == hipSuccess;
+    if (ok && sharded(c)) {      // what a pass all-reduces: [LADDER_MAX][4] slice sums of the step kernel, then [LADDER_MAX][NS + 1, padded] camera block + p.q of the operator pass
         const size_t n = (size_t)LADDER_MAX * (4 + lad_redop_stride(L.NS));
         const bool fresh_r = c->lad_red.n < n || !c->lad_red.p;
-        CTX_HIP(c, c->lad_red.alloc(n));
-        if (fresh_r) CTX_HIP(c, hipMemsetAsync(c->lad_red.p, 0, sizeof(double) * c->lad_red.n, c->stream));      // slots of systems that are not live are summed too: keep them finite
+        ok = c->lad_red.alloc(n) == hipSuccess;
+        if (ok && fresh_r) ok = hipMemsetAsync(c->lad_red.p, 0, sizeof(double) * c->lad_red.n, c->stream) == hipSuccess;      // slots of systems that are not live are summed too: keep them finite
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        c->lad_vec.release(); c->lad_qh.release(); c->lad_cam.release(); c->lad_part.release();
+        std::fprintf(stderr, "[i3d] the slabs of the damping ladder (%d systems x %.1f MB) do not fit the device: this outer iteration runs the serial trust-region loop\n", nsys,
+                     (double)(6 * vec + qh + cam) * 4.0 / 1e6);
+        return 1;
     }
     return I3D_OK;
 }
@@ -768,8 +779,12 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
             { const int n = rows_apply(it & 1, false); if (n < 0) return ctx_fail(c, I3D_ERR_STATE, "pcg_solve_ladder: the multi-system operator pass could not be launched"); a.n_cam = n; }
             { TimedScope t(c, I3D_K_VECTOR); n_step = launch_pcg_step3_lad(s, 3, nl, a, lv); }
         }
-        if (it >= 2) {                                                           // the boundaries of pass it-1, system by system, while pass it runs
-            const int want = seq0 + it - 1;
+        {   // The boundary of THIS pass (k_pcg_dir3_lad of pass `it`, queued above), system by system.  Round 5 looked one pass further back (the boundary of pass it-1, after
+            // queueing pass it): a system that had stopped was carried through TWO more passes — its slot in a stream of the rows (a dead system still stages its inputs, and
+            // keeps the launch at its wider variant) — 103.6 system passes per iteration on the driver's protocol against the 83.5 the PCG iteration counts add up to.  Waiting
+            // for this pass's own boundary costs nothing on the device: it is queued behind pass it-1, whose operator and step kernels are still running or queued when the host
+            // gets here, and pass it+1 is queued while the operator of pass `it` runs.  A stopped system is carried through ONE pass (the rest of this one).
+            const int want = seq0 + it;
             std::vector<int> still;
             for (int j : live) {
                 volatile int* ring = c->h_flags + 4 * j + 2 * (want & 1);
@@ -778,7 +793,7 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
                     if (now_s() - t_wait > 30.0) { CTX_HIP(c, sync_stream(c)); if (__atomic_load_n((int*)&ring[0], __ATOMIC_ACQUIRE) != want) return ctx_fail(c, I3D_ERR_HIP, "pcg_solve_ladder: the device stopped publishing its state"); }
                 }
                 if (!__atomic_load_n((int*)&ring[1], __ATOMIC_ACQUIRE)) still.push_back(j);
-                // (a stopped system: boundary it-1 left its terminal state in one buffer and pass it's boundary copied it into the other — either is final)
+                else finals[j] = st2 + 2 * j + (it & 1);       // boundary `it` wrote the terminal state into this pass's buffer; no later boundary copies it into the other
             }
             live.swap(still);
             if (live.empty()) break;
@@ -888,9 +903,11 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
     // every time, optimizer.cpp:138, so the count barely moves), doubling while everything is rejected.  An invalid step (radius halved instead of divided) puts a
     // batch out of step: the attempt behind it is solved again on its own (LmRecord kind 3).
     // (sharded: with the exchanges as launches of the transport — `fused` there means the in-kernel mailbox exchanges, which keep the serial loop)
-    const bool ladder = c->ladder_max > 1 && c->tile_ok && !legacy && (sharded(c) ? !fused : fused) && c->plan_T() == 512 && c->tile_plan().hp_off != nullptr && c->slots == 5;
+    bool ladder = c->ladder_max > 1 && c->tile_ok && !legacy && (sharded(c) ? !fused : fused) && c->plan_T() == 512 && c->tile_plan().hp_off != nullptr && c->slots == 5;
+    if (ladder && alloc_ladder(c) != I3D_OK) {      // (sharded: every rank holds the same list and takes the same decision unless its device alone is short of memory — then the collectives of the ranks no longer match and the run ends in the transport's time-out)
+        ladder = false;
+    }
     if (ladder) {
-        rc = alloc_ladder(c); if (rc) return rc;
         const LadVec& lv = c->lad;
         { LmRecord rec; rc = wait_record(c, 0, seq0, rec); if (rc) return rc; consume(rec); }      // the initial tests
         // Batch depth.  First batch: what the last two outer iterations needed (the larger: one system too many costs its few PCG passes at the marginal price of a

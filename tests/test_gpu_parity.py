@@ -215,6 +215,21 @@ def test_estimate_sh_matches_oracle(setup):
     ctx.set_voxel_sh(setup["vsh"])     # restore the state the other tests expect
 
 
+def test_estimate_sh_chunk_slabs_do_not_change_the_sums(setup, monkeypatch):
+    """The Gram blocks of the SH data term are accumulated chunk by chunk of a subvolume's voxel run (one wave per chunk, added in chunk order).  The chunk dimension runs
+    in slabs that bound the scratch and the grid (advisor finding of round 5: one large subvolume beside many small ones made the scratch S x longest-run, and a global
+    volume of > 134 M voxels passed the gridDim.y limit, unchecked): forced here to ONE chunk per launch on the single-volume estimate of the scene (several chunks of
+    2048 voxels), the coefficients must be bit for bit those of the default slab."""
+    ctx = setup["ctx"]; thres = setup["thres"]
+    a, ia, sa = ctx.estimate_sh(10.0, 10.0, thres)
+    assert a.shape[0] == 1 and sa.data_rows > 3 * 2048              # one volume, several chunks
+    monkeypatch.setenv("I3D_SH_SLAB", "1")
+    b, ib, sb = ctx.estimate_sh(10.0, 10.0, thres)
+    assert np.array_equal(a, b) and sa.cost_final == sb.cost_final
+    monkeypatch.delenv("I3D_SH_SLAB")
+    ctx.set_voxel_sh(setup["vsh"])
+
+
 def test_gpu_matches_committed_golden(oracle):
     """HIP path vs tests/golden/optimize_small.json: the oracle's outputs on a seeded scene, committed with their generating script
     (tests/golden/make_golden.py) — regression vectors of the restatement, not reference outputs (the reference cannot be built here)."""
@@ -453,7 +468,8 @@ def test_multi_tile_problem_matches_oracle(oracle):
             # ~125 x 125 voxels here: ~16 % of what a rank owns; ~5 % for the 1-mm bench shell at 8 ranks)
             assert 0 < cs["halo_send"] < 0.25 * A / W and 0 < cs["halo_recv"] < 0.25 * A / W, cs
             assert cs["compute_list"] < 1.25 * A / W + 2048, cs                     # owned + ghost entries
-            assert cs["halo_bytes_sent"] == 8 * cs["halo_send"] * cs["halo_calls"] and cs["halo_calls"] > 0
+            # a rim message carries 8 bytes per entry and SYSTEM: one system per message in the serial loop, the live systems of a ladder batch otherwise
+            assert cs["halo_calls"] > 0 and cs["halo_bytes_sent"] % (8 * cs["halo_send"]) == 0 and cs["halo_calls"] <= cs["halo_bytes_sent"] // (8 * cs["halo_send"]) <= 6 * cs["halo_calls"], cs
             if r == 0:
                 print(f"W={W}: rank 0 owns ~{A // W} entries, compute list {cs['compute_list']}, rim sent/received per pass {cs['halo_send']}/{cs['halo_recv']} entries "
                       f"({8 * cs['halo_send']} B), ghost tiles {cs['ghost_tiles']}, all-reduce bytes per call {cs['reduce_bytes'] // max(cs['reduce_calls'], 1)}")
