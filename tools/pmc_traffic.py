@@ -11,7 +11,7 @@ bytes-per-count for 16 B/lane streaming accesses, which is what the row streams 
 means and the factors are written out so the correction can be audited."""
 import collections, csv, glob, json, re, sys
 
-KERNELS = {"eg_pass": r"k_eg_tile<", "eg_mr2": r"k_eg_tile_mr<2>", "eg_mr3": r"k_eg_tile_mr<3>", "halo_fold": r"k_halo_fold", "pcg_step": r"k_pcg_step3<1|k_pcg_step<1", "pcg_direction": r"k_pcg_dir3<|k_pcg_direction",
+KERNELS = {"eg_pass": r"k_eg_tile<", "eg_mr2": r"k_eg_tile_mr<2[,>]", "eg_mr3": r"k_eg_tile_mr<3[,>]", "halo_fold": r"k_halo_fold", "pcg_step": r"k_pcg_step3<1|k_pcg_step<1", "pcg_direction": r"k_pcg_dir3<|k_pcg_direction",
            "pcg_step_lad": r"k_pcg_step3_lad<1", "pcg_direction_lad": r"k_pcg_dir3_lad",
            "eg_pass_untiled": r"k_eg_jtjp|k_eg_pass<1>", "eg_pass_gradient": r"k_eg_pass<0>", "eg_pass_diag": r"k_eg_pass<2>", "eg_gradcol": r"k_eg_gradcol", "gather": r"k_gather<false, true>",
            "build": r"k_build<true", "cost": r"k_build<false", "observe": r"k_observe", "copy_1GiB": r"(elementwise|vectorized|copy).*"}

@@ -11,7 +11,7 @@ straight-line row loops is what the dynamic mix converges to: k_build<true> 885 
 import json, re, sys
 F64_SHARE = {"build": 885.0 / 2804.0, "cost": 799.0 / 1362.0, "eg_pass": 0.0}
 PK_SHARE = {"build": 421.0 / 2804.0}
-PAT = {"build": r"k_build<true", "cost": r"k_build<false", "eg_pass": r"k_eg_tile<", "eg_mr2": r"k_eg_tile_mr<2>", "eg_mr3": r"k_eg_tile_mr<3>", "observe": r"k_observe", "pcg_step": r"k_pcg_step3(_lad)?<1",
+PAT = {"build": r"k_build<true", "cost": r"k_build<false", "eg_pass": r"k_eg_tile<", "eg_mr2": r"k_eg_tile_mr<2[,>]", "eg_mr3": r"k_eg_tile_mr<3[,>]", "observe": r"k_observe", "pcg_step": r"k_pcg_step3(_lad)?<1",
        "pcg_dir": r"k_pcg_dir3", "eg_gradcol": r"k_eg_gradcol"}
 sq = json.load(open(sys.argv[1])); bench = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
 out = {"source": "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY over "
