@@ -432,9 +432,11 @@ def _main():
     log(f"SH estimate: {sh_sub.shape[0]} subvolumes, {sh_stats.data_rows} data rows, {sh_stats.lm_iterations} LM iterations in {sh_first_s:.2f}s (warm: {sh_estimate_ms:.1f} ms)")
 
     if args.pmc_calibrate:
-        a = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+        # a KERNEL that reads 2^30 B and writes 2^30 B, three launches (tools/pmc_traffic.py identifies it by name and launch count).  Not a.clone(): a contiguous clone is a
+        # device-to-device memcpy of the runtime — no kernel, no counters (round 6: the tool found no copy kernel; rounds 3-4 had in fact calibrated on normal_()'s writes)
+        a = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_(); b = torch.empty_like(a)
         for _ in range(3):
-            b = a.clone()          # 16 B/lane vectorised copy: 2^30 B read + 2^30 B written per launch
+            torch.mul(a, 1.0, out=b)          # vectorized_elementwise_kernel: 16 B/lane streaming read + write
         torch.cuda.synchronize(); del a, b
     if args.spin_up > 0:
         # optional (default off): seconds of device copies before the driver's own warm-up steps, untimed, reported as `spin_up_s`.  Tried against the

@@ -92,14 +92,14 @@ def test_committed_counter_files_attach_to_the_bench_line():
     import json
     sys.path.insert(0, ROOT)
     import bench
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default.json")))
     assert d["kernel_tag"] == bench.KERNEL_TAG
     rows, active = d["config"]["rows"]["Eg"], d["config"]["active_voxels"]
     for kernel in ("eg_mr2", "eg_mr3", "build"):
         t = bench.pmc_traffic(kernel, rows, active)
-        assert t is not None and t[0] > 1e9 and t[1].startswith("r05_"), kernel
+        assert t is not None and t[0] > 1e9 and t[1].startswith("r06_"), kernel
         s = bench.sq_valu(kernel, rows)
-        assert s is not None and s["valu"] > 1e7 and s["source"].startswith("r05_"), kernel
+        assert s is not None and s["valu"] > 1e7 and s["source"].startswith("r06_"), kernel
     strict = 4.0 * (29 * rows + 7 * d["config"]["rows"]["Er"] + d["config"]["rows"]["Es"] + 2 * d["config"]["rows"]["Ea"])
     # one stream of the rows serves two / three systems: the measured bytes stay within ~1.2x of ONE system's strict bytes
     assert 1.05 < bench.pmc_traffic("eg_mr2", rows, active)[0] / strict < 1.25 and 1.05 < bench.pmc_traffic("eg_mr3", rows, active)[0] / strict < 1.30
