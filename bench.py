@@ -183,7 +183,8 @@ def cpu_baseline(args, sc, thres, log, device=0, threaded_leg=True):
     scale = keys.shape[0] / float(n)
     value = 1.0 / (sec_per_iter_sample * scale)
     log(f"cpu baseline: {n} voxels, {iters} iterations in {dt:.1f}s -> {sec_per_iter_sample:.2f} s/iter on the sample, x{scale:.1f} voxels")
-    return {"value": value, "unit": "GN iterations/s", "cores": os.cpu_count(), "threads": threads, "kind": "port",
+    return {"value": value, "unit": "GN iterations/s", "cores": threads, "host_cores": os.cpu_count(), "threads": threads, "kind": "port",      # cores = the threads actually used (the solve; the residual collection runs on one, as in the reference)
+           
             # `value` is measured on the sample and scaled linearly by the voxel ratio unless the sample IS the workload (tools/c4_full_parity.py: profiles/r05_c4_full_parity.json)
             "extrapolated": bool(scale > 1.001), "voxel_ratio": scale, "sample_voxels": int(n),
             "sample": f"restated CPU reference (Ceres-2.1.0-equivalent, fp64) on a {n}-voxel cap of the same grid with all {sc['K']} keyframes, "
