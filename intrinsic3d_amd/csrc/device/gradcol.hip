@@ -21,7 +21,10 @@ constexpr int GC_D_CAMW = 4, GC_D_TAG = GC_D_CAMW + ((GC_NW * (GC_NCAM + 0) + 3)
 __device__ constexpr int8_t GC_TRI_I[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
 __device__ constexpr int8_t GC_TRI_J[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
 
-__global__ void __launch_bounds__(GC_THREADS, 3) k_eg_gradcol(GridView g, RowView r, OptParams p, GradColBuffers b, int tiles_per_block) {
+#ifndef GC_OCC
+#define GC_OCC 2
+#endif
+__global__ void __launch_bounds__(GC_THREADS, GC_OCC) k_eg_gradcol(GridView g, RowView r, OptParams p, GradColBuffers b, int tiles_per_block) {
     extern __shared__ float lds[];        // [4] | [NW][NCAM] shared-column slots | [NW][TC] tags | [NW][TC][27] | dense [K][27] | [NCAM]
     const int K = p.K; const size_t Acap = r.Acap;
     const int rs = (GC_NPV * K) | 1;
@@ -58,13 +61,23 @@ __global__ void __launch_bounds__(GC_THREADS, 3) k_eg_gradcol(GridView g, RowVie
 #pragma unroll
         for (int c = 0; c < P_VOX; ++c) { accg[c] = 0.0f; accc[c] = 0.0f; }
         const size_t ac = in ? (size_t)a : 0;
-        for (int k = 0; k < nr_max; ++k) {
+        // the row behind the one being consumed is always in flight (round 6: the loop exposed one memory round trip per row slot — wait share 0.77 at 3 waves per SIMD): slot k + 1 is
+        // requested before slot k is used; the last slot asks for itself again (unconditional loads: the compiler's wait counts stay exact)
+        float4 n4[7]; float2 njt, nwr;
+        auto request = [&](int k) {
             const float4* __restrict__ row = r.rows + row_index(ac, k, 0, r.slots);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) n4[q] = ld_row(row + q * 64);
+            njt = r.row_jt()[row_jt_index(ac, k, r.slots)];
+            nwr = r.row_wr[row_scalar_index(ac, k, r.slots)];
+        };
+        if (nr_max > 0) request(0);
+        for (int k = 0; k < nr_max; ++k) {
             float4 j4[7];
 #pragma unroll
-            for (int q = 0; q < 7; ++q) j4[q] = ld_row(row + q * 64);
-            const size_t ro = row_scalar_index(ac, k, r.slots);
-            const float2 jt = r.row_jt()[row_jt_index(ac, k, r.slots)];
+            for (int q = 0; q < 7; ++q) j4[q] = n4[q];
+            const float2 jt = njt, wr_k = nwr;
+            request(k + 1 < nr_max ? k + 1 : k);
             const bool live = k < nr;
             float J[P_TOTAL];
 #pragma unroll
@@ -72,7 +85,7 @@ __global__ void __launch_bounds__(GC_THREADS, 3) k_eg_gradcol(GridView g, RowVie
             J[28] = jt.x;
             float t = 0.0f; int fsel = 0;
             if (live) {
-                const float2 wr = r.row_wr[ro];
+                const float2 wr = wr_k;
                 t = tw0 * (sqrtf(wr.x) * wr.y);               // Js^T (tw sqrt(w) r) = J^T W r  (the row weight is folded into the stored partials)
                 fsel = __float_as_int(jt.y) & ~ROW_FREE_BIT;
 #pragma unroll
