@@ -210,7 +210,7 @@ def _run_ranks(S, W, cg_fixed=-1):
     return res
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_ranks_run_the_ladder(slice_setup, world):
     """Round 6: the damping ladder in the SHARDED path (the shard key of the reference is subvolumes.cpp:281-295, here tile ranges of the brick-ordered
     work list).  W ranks — simulated by W host threads on one GPU, every exchange through the Comm interface the RCCL transport implements — solve the rejected attempts
@@ -218,7 +218,8 @@ def test_sharded_ranks_run_the_ladder(slice_setup, world):
     pass, ONE rim message of B values per entry.  Against the single-rank ladder on the bench slice (every group free, Ceres' own PCG stop; the outer iteration with the
     rejected attempts, from identical inputs): same rows, same attempts, same accept / reject sequence; PCG counts equal (+-1 on rejected attempts: the ranks' partial
     sums are associated differently, and a stop test may sit on its threshold); costs, fields, intrinsics and poses to 1e-5 in the max-norm (measured: 1e-7 ... 4e-7).
-    And the ladder did run on every rank (batches > 0, fewer row streams than system passes), with the batch's exchanges in ONE message each."""
+    And the ladder did run on every rank (batches > 0, fewer row streams than system passes), with the batch's exchanges in ONE message each.  (8 ranks: shares of a dozen
+    tiles, every tile next to a foreign one.)"""
     rst, rsdf, ralb, rcam, rlad = _run_second(slice_setup)
     assert rlad["batches"] > 0 and rst[0].num_attempts >= 4
     for rank, (st, sdf, alb, cam, lad, comm) in enumerate(_run_ranks(slice_setup, world)):
