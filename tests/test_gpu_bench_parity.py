@@ -111,9 +111,12 @@ def test_untiled_fallback_at_bench_depth(slice_setup, monkeypatch):
         _check_fields(ref, ocam, dev, dcam, start)
 
 
-def test_native_pcg_stop_matches_oracle(slice_setup):
+def test_native_pcg_stop_matches_oracle(slice_setup, monkeypatch):
     """Ceres' quadratic-model stop (eta = 0.1) decided on the device from fp32 vectors / fp64 reductions vs the fp64 oracle: the
-    iteration count of every LM attempt, the accept / reject sequence and the accepted step."""
+    iteration count of every LM attempt, the accept / reject sequence and the accepted step.  In the LDS-ATOMIC mode (I3D_DETERMINISTIC=0: the default of
+    rounds 1-4 and of a sharded run's lone-system passes), whose run-to-run summation-order noise is what the +-1 on rejected attempts below covers; the test
+    behind this one holds the bit-reproducible mode (the default on one rank) to the exact counts."""
+    monkeypatch.setenv("I3D_DETERMINISTIC", "0")
     for ref, ocam, so, dev, dcam, sg, start in _run_both(slice_setup, -1):
         assert list(so.rows) == list(sg.rows)
         assert so.n_attempts == sg.num_attempts
