@@ -38,11 +38,13 @@ def _check(ref, ostats, out, gstats, tol=1e-4):
     assert np.abs(out["albedo"] - ref["albedo"]).max() <= tol * np.abs(ref["albedo"]).max()
 
 
-def test_negative_coordinates(oracle):
+@pytest.mark.parametrize("where", ["negative_octant", "around_the_origin"])
+def test_negative_coordinates(oracle, where):
     """the same scene translated into the negative octant: keys < 0 exercise the sign-extending hash (mat.h:117-124) in the visit order
-    and the float voxel->world products; the surface must be found by the cameras all the same"""
+    and the float voxel->world products; the surface must be found by the cameras all the same.  Around the origin (round 6): keys of every sign in every coordinate, and
+    lighting subvolumes on both sides of every coordinate plane — their index is a FLOOR (subvolumes.cpp:281-295), unlike the truncating voxel index of row a2."""
     sc = dict(helpers.small_scene(seed=7, radius_vox=9, K=4, width=96, height=72))
-    shift = np.array([-40, -33, -51], np.int32)
+    shift = np.array([-40, -33, -51], np.int32) if where == "negative_octant" else -np.round(np.asarray(sc["center"], np.float64) / float(sc["voxel_size"])).astype(np.int32)
     sc["keys"] = sc["keys"] + shift[None, :]
     t = shift.astype(np.float64) * float(sc["voxel_size"])
     poses = np.array(sc["poses"], np.float64)
@@ -52,6 +54,8 @@ def test_negative_coordinates(oracle):
     thres = 2.0 * float(sc["voxel_size"])
     rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres)
     assert rc == 0 and ostats[0].rows[0] > 500 and (ref["keys"] < 0).all(axis=1).any()
+    if where == "around_the_origin":
+        assert all((ref["keys"][:, a] < 0).any() and (ref["keys"][:, a] > 0).any() for a in range(3))
     _check(ref, ostats, out, gstats)
 
 
