@@ -696,7 +696,7 @@ static int pcg_solve_ladder(i3d_context* c, const i3d_optimizer_config& cfg, con
     //   k_lad_reduce_op + ONE all-reduce of [LADDER_MAX][6K + 10] doubles (camera block + p.q of every live system) behind the operator.
     // The slots of systems that have stopped ride along unused: the message size does not depend on which systems are live, so the ranks' collectives always match.
     const bool sh = sharded(c);
-    if (sh && !mr_ok) return ctx_fail(c, I3D_ERR_STATE, "pcg_solve_ladder: a sharded batch needs the multi-system operator pass");
+    // (without the multi-system pass — I3D_LADDER_MR=0 — a sharded batch streams its rows once per system through k_eg_tile<..., GHOSTS>, like a single-rank one: the exchanges stay batched)
     double* const red4 = sh ? c->lad_red.p : nullptr;
     const int rstride = (int)lad_redop_stride(L.NS);
     double* const redop = sh ? c->lad_red.p + (size_t)LADDER_MAX * 4 : nullptr;
