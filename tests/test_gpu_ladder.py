@@ -253,3 +253,19 @@ def test_sharded_ladder_with_fixed_pcg_depth_equals_the_sharded_serial_loop(slic
         assert [x[:3] for x in _stats(st1)] == [x[:3] for x in _stats(st2)], (_stats(st1), _stats(st2))
         assert np.abs(s1 - s2).max() <= 1e-5 * np.abs(s2).max() and np.abs(a1 - a2).max() <= 1e-5 * np.abs(a2).max()
         np.testing.assert_allclose(c1[0], c2[0], rtol=1e-5); np.testing.assert_allclose(c1[2], c2[2], rtol=1e-5, atol=1e-7)
+
+
+def test_sharded_ladder_without_the_multi_system_pass(slice_setup, monkeypatch):
+    """I3D_LADDER_MR=0: the batch's exchanges stay one message each, the rows are streamed once per system through k_eg_tile<..., GHOSTS> (the control of round 5's ladder tests,
+    now sharded): against the same switch on one rank — same attempts, accept sequence, PCG counts (+-1 on rejected attempts), fields to 1e-5."""
+    monkeypatch.setenv("I3D_LADDER_MR", "0")
+    rst, rsdf, ralb, rcam, rlad = _run_second(slice_setup)
+    assert rlad["batches"] > 0 and rlad["row_streams"] == rlad["system_passes"]
+    for rank, (st, sdf, alb, cam, lad, comm) in enumerate(_run_ranks(slice_setup, 2)):
+        assert lad["batches"] > 0 and lad["row_streams"] == lad["system_passes"], (rank, lad)
+        s1, s2 = rst[0], st[0]
+        assert list(s1.rows) == list(s2.rows) and list(s1.step_accepted[:s1.num_attempts]) == list(s2.step_accepted[:s2.num_attempts]), (_stats([s1]), _stats([s2]))
+        p1 = list(s1.pcg_iterations[:s1.num_attempts]); p2 = list(s2.pcg_iterations[:s2.num_attempts])
+        assert all(abs(x - y) <= 1 for x, y in zip(p1, p2)) and p1[-1] == p2[-1], (p1, p2)
+        assert np.abs(sdf - rsdf).max() <= 1e-5 * np.abs(rsdf).max() and np.abs(alb - ralb).max() <= 1e-5 * np.abs(ralb).max()
+        assert comm["reduce_calls"] < 2 * lad["system_passes"]
