@@ -93,6 +93,175 @@ def test_shading_row_jacobian_vs_finite_differences(oracle):
             assert abs(fd - J[i]) <= 2e-5 * max(1.0, abs(J[i])), (i, fd, J[i])
 
 
+def _numpy_shading_residual(v, sh, pyr, vs, img, prm):
+    """A SECOND, literal transcription of the reference's Eg functor in numpy / fp64 — ShadingCost::operator() (refinement/shading_cost.h:85-198) with
+    SDFOperators::computeNormal / voxelToWorld / voxelCenterToIso (sdf/operators.h:49-86), transform (cost.h:80-90: ceres::AngleAxisRotatePoint + translation),
+    CameraT::project (camera.h:96-116: the distorted y uses the ALREADY distorted x), interpolate (cost.h:108-127: BiCubicInterpolator over a clamped Grid2D, Evaluate(row = p2d[1],
+    col = p2d[0])), Shading::computeShading / shBasisFunctions / computeShadingGradientDifference (shading.h:53-148) — written independently of oracle/src/residuals.hpp."""
+    s = dict(zip(["000", "010", "020", "011", "001", "002", "100", "110", "101", "200"], prm[:10]))                    # shading_cost.h:88-97
+    alb = dict(zip(["000", "100", "010", "001"], prm[10:14]))                                                          # :99-102
+    aa, t = np.asarray(prm[14:17], float), np.asarray(prm[17:20], float)
+    fx, fy, cx, cy = [x * pyr for x in prm[20:24]]                                                                     # :120-124
+    k = prm[24:29]
+    h, w = img.shape
+
+    def normal(s0, sx, sy, sz):                                                                                        # operators.h:70-86
+        n = np.array([sx - s0, sy - s0, sz - s0]); L = np.sqrt(n @ n)
+        return n / L if L > 0.0 else n
+
+    def rotate(p):                                                                                                     # ceres::AngleAxisRotatePoint (Ceres 2.1.0 rotation.h)
+        th2 = aa @ aa
+        if th2 > np.finfo(float).eps:
+            th = np.sqrt(th2); wv = aa / th
+            return p * np.cos(th) + np.cross(wv, p) * np.sin(th) + wv * (wv @ p) * (1.0 - np.cos(th))
+        return p + np.cross(aa, p)
+
+    def project(P):                                                                                                    # camera.h:96-116
+        x, y = P[0] / P[2], P[1] / P[2]
+        r2 = x * x + y * y; r4 = r2 * r2; r6 = r4 * r2
+        dc = 1.0 + k[0] * r2 + k[1] * r4 + k[2] * r6
+        x = x * dc + 2.0 * k[3] * x * y + k[4] * (r2 + 2.0 * x * x)
+        y = y * dc + 2.0 * k[4] * x * y + k[3] * (r2 + 2.0 * y * y)          # x is the distorted one here, as in the reference
+        u, vv = fx * x + cx, fy * y + cy
+        return (u, vv), not (u < 0.0 or u > w - 1 or vv < 0.0 or vv > h - 1)
+
+    def spline(p0, p1, p2, p3, x):                                                                                     # CubicHermiteSpline (Ceres 2.1.0 cubic_interpolation.h)
+        a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3); b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3); c = 0.5 * (-p0 + p2)
+        return p1 + x * (c + x * (b + x * a))
+
+    def bicubic(r, c):                                                                                                 # BiCubicInterpolator::Evaluate over Grid2D<float, 1, true, true>
+        row, col = int(np.floor(r)), int(np.floor(c))
+        px = lambda rr, cc: float(img[min(max(rr, 0), h - 1), min(max(cc, 0), w - 1)])
+        f = [spline(px(row - 1 + i, col - 1), px(row - 1 + i, col), px(row - 1 + i, col + 1), px(row - 1 + i, col + 2), c - col) for i in range(4)]
+        return spline(f[0], f[1], f[2], f[3], r - row)
+
+    pts = [("000", (0, 0, 0), normal(s["000"], s["100"], s["010"], s["001"])), ("100", (1, 0, 0), normal(s["100"], s["200"], s["110"], s["101"])),
+           ("010", (0, 1, 0), normal(s["010"], s["110"], s["020"], s["011"])), ("001", (0, 0, 1), normal(s["001"], s["101"], s["011"], s["002"]))]      # shading_cost.h:131-146
+    lum, shading = [], []
+    for name, off, n in pts:
+        pw = (np.asarray(v, float) + np.asarray(off, float)) * vs                                                      # voxelToWorld
+        piso = pw - n * s[name]                                                                                        # voxelCenterToIso
+        (u, vv), ok = project(rotate(piso) + t)
+        if not ok:
+            return 0.0                                                                                                 # NV_INVALID_RESIDUAL (cost.h:45)
+        lum.append(bicubic(vv, u))                                                                                     # Evaluate(p2d[1], p2d[0])
+        H = np.array([1.0, n[1], n[2], n[0], n[0] * n[1], n[1] * n[2], (-n[0] * n[0]) - (n[1] * n[1]) + 2.0 * (n[2] * n[2]), n[0] * n[2], (n[0] * n[0]) - (n[1] * n[1])])
+        shading.append(alb[name] * float(np.asarray(sh, float) @ H))
+    d = [(shading[i] - shading[0]) - (lum[i] - lum[0]) for i in (1, 2, 3)]                                             # shading.h:128-148
+    r = float(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))
+    return r if np.isfinite(r) else 0.0
+
+
+def test_shading_row_value_against_a_second_transcription(oracle):
+    """The VALUE path of an Eg row — the piece of the restatement nothing else in this image can check (the reference cannot be built: oracle/i3d_oracle.h) — against a
+    second, independently written transcription of the same reference lines in numpy: normals, iso-projection, Rodrigues, Brown distortion with its distorted-x quirk,
+    bicubic sampling of a general image with clamped borders, SH shading, the norm of the gradient difference.  Random parameter sets incl. large rotations, both pyramid
+    scales, points near the image border; the two must agree to fp64 round-off, and on which rows are invalid."""
+    v, sh, vs, lum, prm0 = _row_setup()
+    rng = np.random.default_rng(5)
+    checked = invalid = 0
+    for trial in range(60):
+        prm = prm0.copy()
+        prm[:10] += rng.normal(0, 2e-4, 10); prm[10:14] += rng.normal(0, 0.05, 4)
+        prm[14:17] = rng.normal(0, 0.05 if trial % 3 else 0.6, 3)                      # every third trial: a large rotation
+        prm[17:20] += rng.normal(0, 0.02 if trial % 4 else 0.15, 3)                    # every fourth: pushed towards / over the image border
+        prm[24:29] = rng.normal(0, 0.03, 5)
+        for pyr in (1.0, 0.5):
+            img = lum if pyr == 1.0 else lum[::2, ::2].copy()
+            r, _ = oracle.shading_row(v, sh, pyr, vs, img, prm, jac=False)
+            ref = _numpy_shading_residual(v, sh, pyr, vs, img, prm)
+            assert (r == 0.0) == (ref == 0.0), (trial, pyr, r, ref)
+            if ref == 0.0:
+                invalid += 1
+            else:
+                checked += 1
+                assert abs(r - ref) <= 1e-11 * max(1.0, abs(ref)), (trial, pyr, r, ref)
+    assert checked >= 40 and invalid >= 4, (checked, invalid)
+
+
+def test_observation_weights_against_a_second_transcription(oracle):
+    """The observation pass (a7: SDFColorization::collectObservations / computeObservation / isVoxelVisible / computeWeight / filter, sdf/colorization.cpp:192-370, with
+    SDFOperators::computeSurfaceNormal / voxelCenterToIso operators.cpp:44-77, Camera::project camera.cpp:124-154, math::robustKernel math.cpp:43-47 with its default threshold 2,
+    math::poseVecAAToMat math.cpp:151-163 and SDFOperators::sdfToWeight operators.cpp:142-147) transcribed a second time, in numpy float32, and held against the rows the
+    oracle creates on a small scene: for every Eg row (voxel, keyframe, row weight) the transcription must find the voxel visible in that keyframe, give the same weight (to
+    float round-off: Eigen's reduction orders are not transcribed) and rank the keyframe among the voxel's best five.  What the transcription does NOT cover is which voxels
+    get rows at all (eligibility is structural: tests below and the golden row counts)."""
+    import helpers
+    f32 = np.float32
+    sc = helpers.small_scene(seed=5, radius_vox=9, K=8, width=96, height=72)
+    g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc)
+    cfg = helpers.oracle_cfg(oracle, thres)
+    pv = oracle.ProblemView(g, fr, cfg, sc["intr"], sc["dist"], sc["poses"], vsh, 0)
+    v, f, w, r, _ = pv.eg(False)
+    assert len(v) > 500
+    keys = arrays["keys"]; sref = arrays["sdf_refined"]; vs = f32(sc["voxel_size"]); trunc = 5.0 * float(vs)
+    index = {tuple(k): i for i, k in enumerate(keys.tolist())}
+    K = sc["K"]; W, H = sc["width"], sc["height"]
+    fx, fy, cx, cy = [f32(x) for x in sc["intr"]]
+    dist = np.asarray(sc["dist"], np.float32)
+    Rs, ts = [], []
+    for pose in sc["poses"]:                                          # math.cpp:151-163: AngleAxisd(|w|, w / |w|).matrix(), then cast to float
+        aa = np.asarray(pose[:3], np.float64); th = np.linalg.norm(aa)
+        if th > 0:
+            a = aa / th; Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+            R = np.eye(3) + np.sin(th) * Kx + (1.0 - np.cos(th)) * (Kx @ Kx)
+        else:
+            R = np.eye(3)
+        Rs.append(R.astype(np.float32)); ts.append(np.asarray(pose[3:], np.float64).astype(np.float32))
+
+    def weight(i, k):
+        x, y, z = keys[i].tolist()
+        nb = [index.get((x + 1, y, z)), index.get((x, y + 1, z)), index.get((x, y, z + 1))]
+        if any(j is None for j in nb) or arrays["weight"][i] <= 0 or any(arrays["weight"][j] <= 0 for j in nb):
+            return None
+        s0 = f32(sref[i]); n = np.array([f32(sref[nb[0]]) - s0, f32(sref[nb[1]]) - s0, f32(sref[nb[2]]) - s0], np.float32)     # operators.cpp:58-77
+        L = f32(np.sqrt(f32(n[0] * n[0] + n[1] * n[1] + n[2] * n[2])))
+        if L != 0:
+            n = (n / L).astype(np.float32)
+        pt = (keys[i].astype(np.float32) * vs - n * s0).astype(np.float32)                                                         # voxelToWorld, voxelCenterToIso
+        q = (Rs[k] @ pt + ts[k]).astype(np.float32)
+        px, py = f32(q[0] / q[2]), f32(q[1] / q[2])
+        if np.any(np.abs(dist) > 1e-5):                                                                                            # camera.cpp:135 (Eigen isZero)
+            r2 = f32(px * px + py * py); r4 = f32(r2 * r2); r6 = f32(r4 * r2)
+            dc = f32(1.0) + dist[0] * r2 + dist[1] * r4 + dist[2] * r6
+            px = f32(px * dc + f32(2.0) * dist[3] * px * py + dist[4] * (r2 + f32(2.0) * px * px))
+            py = f32(py * dc + f32(2.0) * dist[4] * px * py + dist[3] * (r2 + f32(2.0) * py * py))
+        u, vv = f32(fx * px + cx), f32(fy * py + cy)
+        ui, vi = int(f32(u + f32(0.5))), int(f32(vv + f32(0.5)))                                                                   # truncating cast
+        if ui < 0 or ui >= W or vi < 0 or vi >= H:
+            return None
+        d = sc["frames"][k]["depth"][0][vi, ui]
+        if not (d > 0) or abs(f32(d - q[2])) > f32(cfg.occlusion_distance):                                                        # colorization.cpp:254-270
+            return None
+        nc = (Rs[k] @ n).astype(np.float32)
+        wn = f32(0.0)
+        if np.any(nc != 0):
+            qn = (q / f32(np.sqrt(f32(q @ q)))).astype(np.float32)
+            wn = f32(1.0) - f32(abs(f32(qn @ nc)))
+            wn = max(min(wn, f32(1.0)), f32(0.0))
+            div = f32(1.0) + f32(2.0) * wn; wn = max(f32(1.0) / f32(div * div * div), f32(0.001))                                # math.cpp:43-47
+        dw = max(min(f32(5.0), d), f32(0.01)); wd = max(f32(1.0) - (dw - f32(0.01)) / (f32(5.0) - f32(0.01)), f32(1.0)); wd = max(min(wd, f32(5.0)), f32(0.001))
+        return float(f32(wn * wd))
+
+    # the weight the oracle reports for a row is the one Ceres sees: rho = row weight x lambda_g / (sum of the row weights) x 1000 (nls_solver.cpp:379-394, ScaledLoss),
+    # row weight = observation weight x sdfToWeight(sdf_refined) (optimizer.cpp:227,235; operators.cpp:142-147)
+    raw = np.zeros(len(v))
+    for row in range(len(v)):
+        i, k = int(v[row]), int(f[row])
+        wk = weight(i, k)
+        assert wk is not None and wk > 0, (row, i, k)
+        raw[row] = wk * min(max(1.0 - min(abs(sref[i]), trunc) / trunc, 0.01), 1.0)
+    rho = raw * (cfg.lambda_g / raw.sum()) * 1000.0
+    worst = float(np.abs(w - rho).max() / np.abs(w).max()); rel = float((np.abs(w - rho) / w).max())
+    assert worst <= 2e-6 and rel <= 2e-5, (worst, rel)
+    for row in range(0, len(v), 11):                                  # the rank of the row's keyframe among all keyframes of its voxel
+        i, k = int(v[row]), int(f[row])
+        ws = [weight(i, kk) for kk in range(K)]
+        better = sum(1 for x in ws if x is not None and x > ws[k] * (1.0 + 1e-5))
+        assert better < cfg.num_observations, (row, i, k, ws)
+    pv.free(); g.free(); fr.free()
+
+
 def test_shading_row_invalid_cases(oracle):
     v, sh, vs, lum, prm = _row_setup()
     p = prm.copy(); p[19] = -0.5 - v[2] * vs          # behind / far off the image
