@@ -262,6 +262,45 @@ def test_observation_weights_against_a_second_transcription(oracle):
     pv.free(); g.free(); fr.free()
 
 
+def test_regulariser_rows_against_a_second_transcription(oracle):
+    """Er / Es / Ea rows of a small scene against numpy transcriptions of volumetric_regularizer.h:59-72 (r = sum of the six ring neighbours - 6 sdf_refined), surface_stab_regularizer.h:59-66
+    (r = sdf_refined - sdf, 1e-7 when exactly 0) and albedo_regularizer.cpp:50-84 with color_util.cpp:41-52 (weight = max(1 - ||c / lum - c_nb / lum_nb||, 0.01) on RGB / 255 and the 0-255
+    luminance; r = albedo - albedo_nb), each with the type normalisation lambda / (sum of the type's row weights) x 1000 (nls_solver.cpp:379-394; lambda_r / lambda_s at iteration 0 of the
+    schedule, cost.h:130-143)."""
+    import helpers
+    f32 = np.float32
+    sc = helpers.small_scene(seed=6, radius_vox=8, K=3, width=96, height=72)
+    g, fr, arrays, vsh, thres = helpers.oracle_setup(oracle, sc)
+    cfg = helpers.oracle_cfg(oracle, thres)
+    pv = oracle.ProblemView(g, fr, cfg, sc["intr"], sc["dist"], sc["poses"], vsh, 0)
+    keys = arrays["keys"]; index = {tuple(k): i for i, k in enumerate(keys.tolist())}
+    ring = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    nb = lambda i, d: index[tuple((keys[i] + np.asarray(ring[d])).tolist())]
+    # Er
+    v, d, w, r = pv.reg(1)
+    assert len(v) > 300
+    ref = np.array([sum(arrays["sdf_refined"][nb(i, dd)] for dd in range(6)) - 6.0 * arrays["sdf_refined"][i] for i in v.tolist()])
+    np.testing.assert_allclose(r, ref, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(w, np.full(len(v), cfg.lambda_r0 / len(v) * 1000.0), rtol=1e-12)
+    # Es
+    v, d, w, r = pv.reg(2)
+    ref = arrays["sdf_refined"][v] - arrays["sdf"][v]; ref = np.where(ref == 0.0, 1e-7, ref)
+    np.testing.assert_allclose(r, ref, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(w, np.full(len(v), cfg.lambda_s0 / len(v) * 1000.0), rtol=1e-12)
+    # Ea
+    v, d, w, r = pv.reg(3)
+    assert len(v) > 600
+    def chroma(i, j):
+        c = arrays["color"][i].astype(np.float32) * f32(1.0 / 255.0); cn = arrays["color"][j].astype(np.float32) * f32(1.0 / 255.0)
+        lum = lambda q: f32(0.299) * f32(q[0]) + f32(0.587) * f32(q[1]) + f32(0.114) * f32(q[2])
+        a = (c / lum(arrays["color"][i]) - cn / lum(arrays["color"][j])).astype(np.float32)
+        return max(f32(1.0) - f32(np.sqrt(f32(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]))), f32(0.01))
+    raw = np.array([float(chroma(i, nb(i, dd))) for i, dd in zip(v.tolist(), d.tolist())])
+    np.testing.assert_allclose(r, [arrays["albedo"][i] - arrays["albedo"][nb(i, dd)] for i, dd in zip(v.tolist(), d.tolist())], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(w, raw * (cfg.lambda_a / raw.sum()) * 1000.0, rtol=2e-6)
+    pv.free(); g.free(); fr.free()
+
+
 def test_shading_row_invalid_cases(oracle):
     v, sh, vs, lum, prm = _row_setup()
     p = prm.copy(); p[19] = -0.5 - v[2] * vs          # behind / far off the image
