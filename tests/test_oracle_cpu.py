@@ -301,6 +301,48 @@ def test_regulariser_rows_against_a_second_transcription(oracle):
     pv.free(); g.free(); fr.free()
 
 
+def test_voxel_sh_interpolation_against_a_second_transcription(oracle):
+    """LightingSVSH::computeVoxelShCoeffs / interpolate (lighting_svsh.cpp:83-110) -> Subvolumes::interpolate (subvolumes.cpp:164-205) with pointToIndexCoord (:298-304: world / size - 0.5,
+    float), math::interpolationWeights and math::average (math.cpp:74-128: float weights, missing subvolumes weight 0, first non-zero weight ASSIGNS, normalised by 1 / sum) transcribed in
+    numpy on the oracle's own per-subvolume coefficients: every in-shell voxel's nine coefficients to fp64 round-off, and the set of voxels that get coefficients."""
+    import helpers
+    f32 = np.float32
+    sc = helpers.small_scene(seed=8, radius_vox=10, K=3, width=96, height=72)
+    g = oracle.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], sc["weight"], sc["color"])
+    thres = 2.0 * float(sc["voxel_size"]); g.clear_outside_shell(thres)
+    size = f32(0.03)
+    rc, sh, idx, vsh, has, st = oracle.estimate_sh(g, float(size), 10.0, thres)
+    assert rc == 0 and sh.shape[0] >= 8
+    a = g.export(); vs = f32(sc["voxel_size"])
+    sub = {tuple(k): j for j, k in enumerate(idx.tolist())}
+    inv = f32(1.0) / size
+    n_has = 0
+    for i in range(len(a["keys"])):
+        in_shell = a["weight"][i] > 0 and abs(a["sdf_refined"][i]) <= thres
+        assert bool(has[i]) == bool(in_shell), i
+        if not in_shell:
+            continue
+        n_has += 1
+        pt = a["keys"][i].astype(np.float32) * vs
+        c = (pt * inv - f32(0.5)).astype(np.float32)
+        v0 = np.floor(c).astype(np.int64); wt = (c - v0.astype(np.float32)).astype(np.float32)
+        one = f32(1.0)
+        corners = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (0, 1, 1), (1, 0, 1), (1, 1, 1)]                   # math.cpp:109-116
+        wts = [f32((wt[0] if o[0] else one - wt[0]) * (wt[1] if o[1] else one - wt[1]) * (wt[2] if o[2] else one - wt[2])) for o in corners]
+        avg = np.zeros(9); sw = f32(0.0)
+        for o, w8 in zip(corners, wts):
+            j = sub.get(tuple((v0 + np.asarray(o)).tolist()))
+            if j is None or w8 == 0:
+                continue
+            avg = (float(w8) * sh[j]) if sw == 0 else avg + float(w8) * sh[j]
+            sw = f32(sw + w8)
+        if sw != 0:
+            avg = avg * float(f32(1.0) / sw)
+        np.testing.assert_allclose(vsh[i], avg, rtol=1e-12, atol=1e-14)
+    assert n_has > 1000
+    g.free()
+
+
 def test_shading_row_invalid_cases(oracle):
     v, sh, vs, lum, prm = _row_setup()
     p = prm.copy(); p[19] = -0.5 - v[2] * vs          # behind / far off the image
