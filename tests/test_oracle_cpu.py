@@ -343,6 +343,54 @@ def test_voxel_sh_interpolation_against_a_second_transcription(oracle):
     g.free()
 
 
+def test_upsampling_against_a_second_transcription(oracle):
+    """SDFAlgorithms::upsample + interpolate (sdf/algorithms.cpp:118-235) with math::interpolationWeights (math.cpp:103-128) transcribed in numpy float32: every child voxel 2 p + {0, 1}^3 of
+    every parent is the trilinear blend at p + {0, 1/2}^3 over the VALID corners (stored, weight > 0), renormalised by the sum of their weights; weight := 0 with four or fewer valid
+    corners; sdf / albedo / sdf_refined accumulate in float; the colour goes through nv::round (mat.h:88-93: + 0.5, truncating cast).  Field by field, bit for bit, by key."""
+    import helpers
+    f32 = np.float32
+    sc = helpers.small_scene(seed=9, radius_vox=7, K=2, width=64, height=48)
+    rng = np.random.default_rng(2)
+    w0 = sc["weight"].copy(); w0[rng.integers(0, len(w0), 40)] = 0.0                    # some invalid voxels: corners that do not count
+    g = oracle.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], w0, sc["color"])
+    a = g.export()
+    g.import_fields(sdf_refined=a["sdf"] + rng.normal(0, 1e-4, len(a["sdf"])), albedo=0.6 + rng.normal(0, 0.05, len(a["sdf"])))
+    a = g.export()
+    up = g.upsample(); b = up.export()
+    assert len(b["keys"]) == 8 * len(a["keys"]) and abs(float(up.voxel_size) - 0.5 * float(g.voxel_size)) < 1e-9
+    index = {tuple(k): i for i, k in enumerate(a["keys"].tolist())}
+    child = {tuple(k): i for i, k in enumerate(b["keys"].tolist())}
+    one = f32(1.0)
+    corners = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (0, 1, 1), (1, 0, 1), (1, 1, 1)]
+    checked = 0
+    for pi in range(0, len(a["keys"]), 3):
+        p = a["keys"][pi]
+        for o in corners:
+            wt = np.array([f32(0.5) * f32(x) for x in o], np.float32)                   # pos - floor(pos), pos = p + 0.5 o
+            sw = f32(0.0); cnt = 0
+            acc = dict(sdf=f32(0.0), weight=f32(0.0), albedo=f32(0.0), sdf_refined=f32(0.0)); col = np.zeros(3, np.float32)
+            for c in corners:
+                j = index.get(tuple((p + np.asarray(c)).tolist()))
+                if j is None or not (a["weight"][j] > 0):
+                    continue
+                w8 = f32((wt[0] if c[0] else one - wt[0]) * (wt[1] if c[1] else one - wt[1]) * (wt[2] if c[2] else one - wt[2]))
+                acc["sdf"] = f32(acc["sdf"] + w8 * f32(a["sdf"][j])); acc["weight"] = f32(acc["weight"] + w8 * a["weight"][j])
+                acc["albedo"] = f32(acc["albedo"] + w8 * f32(a["albedo"][j])); acc["sdf_refined"] = f32(acc["sdf_refined"] + w8 * f32(a["sdf_refined"][j]))
+                col = (col + w8 * a["color"][j].astype(np.float32)).astype(np.float32)
+                sw = f32(sw + w8); cnt += 1
+            if sw > 0:
+                acc = {k: f32(x / sw) for k, x in acc.items()}; col = (col / sw).astype(np.float32)
+            if cnt <= 4:
+                acc["weight"] = f32(0.0)
+            ci = child[tuple((2 * p + np.asarray(o)).tolist())]
+            assert b["sdf"][ci] == float(acc["sdf"]) and b["sdf_refined"][ci] == float(acc["sdf_refined"]) and b["albedo"][ci] == float(acc["albedo"]), (pi, o)
+            assert b["weight"][ci] == max(acc["weight"], f32(0.0)), (pi, o, b["weight"][ci], acc["weight"], cnt)
+            assert np.array_equal(b["color"][ci], (col + f32(0.5)).astype(np.int32).astype(np.uint8)), (pi, o)
+            checked += 1
+    assert checked > 3000 and (b["weight"] == 0).sum() > 50
+    g.free(); up.free()
+
+
 def test_shading_row_invalid_cases(oracle):
     v, sh, vs, lum, prm = _row_setup()
     p = prm.copy(); p[19] = -0.5 - v[2] * vs          # behind / far off the image
