@@ -391,6 +391,51 @@ def test_upsampling_against_a_second_transcription(oracle):
     g.free(); up.free()
 
 
+def test_thin_shell_against_a_second_transcription(oracle):
+    """SDFAlgorithms::clearVoxelsOutsideThinShell (sdf/algorithms.cpp:368-458) as set arithmetic in Python: kept = valid voxels within the shell, their stored 6-ring and stored (+2x, +2y, +2z)
+    neighbours, plus every other voxel with a stored voxel of the opposite sign (>= 0 against < 0) in its 5 x 5 x 5 block; everything else is removed, and the survivors keep the relative
+    order they had (erase from an unordered_map keeps the order of the rest)."""
+    import helpers
+    sc = helpers.small_scene(seed=10, radius_vox=9, K=2, width=64, height=48, band_vox=4.5)
+    rng = np.random.default_rng(4)
+    w0 = sc["weight"].copy(); w0[rng.integers(0, len(w0), 60)] = 0.0
+    g = oracle.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], w0, sc["color"])
+    a = g.export()
+    g.import_fields(sdf_refined=a["sdf"] + rng.normal(0, 2e-4, len(a["sdf"])))
+    a = g.export()
+    for factor in (2.0, 1.0):
+        thres = factor * float(sc["voxel_size"])
+        index = {tuple(k): i for i, k in enumerate(a["keys"].tolist())}
+        keep = set()
+        for i, k in enumerate(a["keys"].tolist()):
+            if not (a["weight"][i] > 0) or abs(a["sdf_refined"][i]) > thres:
+                continue
+            keep.add(tuple(k))
+            for o in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (2, 0, 0), (0, 2, 0), (0, 0, 2)):
+                q = (k[0] + o[0], k[1] + o[1], k[2] + o[2])
+                if q in index:
+                    keep.add(q)
+        for i, k in enumerate(a["keys"].tolist()):
+            if tuple(k) in keep:
+                continue
+            neg = a["sdf_refined"][i] < 0.0
+            crossing = False
+            for z in range(-2, 3):
+                for y in range(-2, 3):
+                    for x in range(-2, 3):
+                        j = index.get((k[0] + x, k[1] + y, k[2] + z)) if (x, y, z) != (0, 0, 0) else None
+                        if j is not None and ((a["sdf_refined"][j] >= 0.0) if neg else (a["sdf_refined"][j] < 0.0)):
+                            crossing = True
+            if crossing:
+                keep.add(tuple(k))
+        h = oracle.Grid.from_voxels(sc["voxel_size"], sc["keys"], sc["sdf"], w0, sc["color"]); h.import_fields(sdf_refined=a["sdf_refined"])
+        assert np.array_equal(h.export()["keys"], a["keys"])
+        h.clear_outside_shell(thres); b = h.export(); h.free()
+        want = np.array([k for k in a["keys"].tolist() if tuple(k) in keep], np.int32)
+        assert 0 < len(want) < len(a["keys"]) and np.array_equal(b["keys"], want), (factor, len(want), len(b["keys"]))
+    g.free()
+
+
 def test_shading_row_invalid_cases(oracle):
     v, sh, vs, lum, prm = _row_setup()
     p = prm.copy(); p[19] = -0.5 - v[2] * vs          # behind / far off the image
