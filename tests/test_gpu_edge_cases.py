@@ -301,3 +301,47 @@ def test_mailbox_transport_across_processes(world):
         if not (shared and codes == {"15"}):
             break
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_device_hash_table_under_collisions():
+    """The device's voxel table is open addressing with linear probing over a 64-bit finaliser of the packed key (grid_kernels.hip: pack_key, mix64); every neighbour of every stencil
+    goes through it once per grid.  The finaliser is a bijection, so keys can be CRAFTED to land on one slot: 2000 voxels whose home slot is the same (a probe chain 2000 long — the
+    table's worst case), each with its +x neighbour stored as well (ordinary slots), scattered over the whole +-2^20 coordinate range the packed key supports.  The neighbour table
+    must be exactly what a dictionary gives."""
+    from intrinsic3d_amd import binding
+    M = (1 << 64) - 1
+    C1, C2 = 0xff51afd7ed558ccd, 0xc4ceb9fe1a85ec53
+    I1, I2 = pow(C1, -1, 1 << 64), pow(C2, -1, 1 << 64)
+    def unmix(y):
+        y ^= y >> 33; y = (y * I2) & M; y ^= y >> 33; y = (y * I1) & M; y ^= y >> 33
+        return y
+    def mix(k):
+        k ^= k >> 33; k = (k * C1) & M; k ^= k >> 33; k = (k * C2) & M; k ^= k >> 33
+        return k
+    n_c = 2000; cap = 8192                                   # 2 x 4000 voxels -> 8192 slots
+    rng = np.random.default_rng(17)
+    keys = []
+    seen = set()
+    while len(keys) < n_c:
+        y = (int(rng.integers(0, 1 << 62)) << 13 | 5) & M   # low 13 bits = 5: home slot 5 of an 8192-slot table; the rest random
+        k = unmix(y)
+        if k >> 63:
+            continue
+        x, yy, z = (k & 0x1fffff) - (1 << 20), ((k >> 21) & 0x1fffff) - (1 << 20), ((k >> 42) & 0x1fffff) - (1 << 20)
+        if max(abs(x), abs(yy), abs(z)) > (1 << 20) - 8 or (x, yy, z) in seen or (x + 1, yy, z) in seen or (x - 1, yy, z) in seen:
+            continue
+        assert mix(k) & (cap - 1) == 5
+        seen.add((x, yy, z)); keys.append((x, yy, z))
+    allk = np.array(keys + [(x + 1, y, z) for x, y, z in keys], np.int32)
+    allk = allk[rng.permutation(len(allk))]
+    n = len(allk); assert n == 2 * n_c
+    with binding.Context(0) as ctx:
+        ctx.set_grid(0.004, allk, np.zeros(n), np.zeros(n), np.full(n, 0.6), np.ones(n, np.float32), np.full((n, 3), 128, np.uint8))
+        nb = ctx.debug_neighbors()
+    index = {tuple(k): i for i, k in enumerate(allk.tolist())}
+    offs = [(1,0,0),(-1,0,0),(0,1,0),(0,-1,0),(0,0,1),(0,0,-1),(2,0,0),(0,2,0),(0,0,2),(1,1,0),(1,0,1),(0,1,1),
+            (-2,0,0),(0,-2,0),(0,0,-2),(-1,-1,0),(-1,0,-1),(0,-1,-1)]
+    exp = np.full_like(nb, -1)
+    for j, o in enumerate(offs):
+        exp[:, j] = [index.get((k[0] + o[0], k[1] + o[1], k[2] + o[2]), -1) for k in allk.tolist()]
+    assert np.array_equal(nb, exp) and (exp[:, 0] >= 0).sum() == n_c and (exp[:, 1] >= 0).sum() == n_c
