@@ -60,9 +60,10 @@ def test_negative_coordinates(oracle, where):
 
 
 @pytest.mark.parametrize("kw", [dict(lambda_a=-1.0), dict(fix_poses=1, fix_intrinsics=1, fix_distortion=1), dict(num_observations=0),
-                                dict(fix_poses=1, fix_distortion=1, num_observations=2)])
+                                dict(fix_poses=1, fix_distortion=1, num_observations=2), dict(num_observations=8, K=12)])
 def test_parameter_group_switches(oracle, kw):
-    sc = helpers.small_scene(seed=8, radius_vox=9, K=4, width=96, height=72)
+    kw = dict(kw); K = kw.pop("K", 4)                 # (num_observations = 8 of 12 keyframes: the largest number of row slots per voxel the row layout holds)
+    sc = helpers.small_scene(seed=8, radius_vox=9, K=K, width=96, height=72)
     thres = 2.0 * float(sc["voxel_size"])
     rc, ref, ocam, ostats, out, cam, gstats = _run_both(oracle, sc, thres, **kw)
     assert rc == 0
@@ -74,6 +75,8 @@ def test_parameter_group_switches(oracle, kw):
         assert np.array_equal(cam[2], np.asarray(sc["poses"], np.float64))
     if kw.get("num_observations", 5) == 2:
         assert gstats[0].rows[0] <= 2 * ostats[0].valid_voxels                     # at most the 2 best observations per voxel
+    if kw.get("num_observations", 5) == 8:
+        assert 4.2 * ostats[0].valid_voxels < gstats[0].rows[0] <= 8 * ostats[0].valid_voxels    # (4.34 rows per voxel on this scene: a voxel is seen by 4-6 of the 12 keyframes; many voxels hold 6-8 rows)
 
 
 def test_capacity_and_state_errors(oracle):
