@@ -436,6 +436,123 @@ def test_thin_shell_against_a_second_transcription(oracle):
     g.free()
 
 
+def _np_erode(d, win, max_diff):
+    """rgbd/processing.cpp:184-232 as shifted-array comparisons: a pixel survives when every in-image pixel of its window is valid and within max_diff of it"""
+    h, w = d.shape
+    ok = d != 0
+    for dv in range(-win, win + 1):
+        for du in range(-win, win + 1):
+            ys = slice(max(0, -dv), min(h, h - dv)); xs = slice(max(0, -du), min(w, w - du))
+            yn = slice(max(0, dv), min(h, h + dv)); xn = slice(max(0, du), min(w, w + du))
+            nb = d[yn, xn]; me = d[ys, xs]
+            ok[ys, xs] &= (nb != 0) & ~(np.abs(nb - me) > np.float32(max_diff))
+    return np.where(ok, d, np.float32(0))
+
+
+def _np_normals(d, cam, thr):
+    """rgbd/processing.cpp:49-127: vertex map, central differences, cross(tangent_y, tangent_x) normalised; borders / invalid stars stay 0"""
+    f32 = np.float32
+    h, w = d.shape
+    fx, fy, cx, cy = (f32(v) for v in cam[:4])
+    xx = (np.arange(w, dtype=f32)[None, :] - cx) * (f32(1) / fx); yy = (np.arange(h, dtype=f32)[:, None] - cy) * (f32(1) / fy)
+    vm = np.stack([xx * d, yy * d, d], -1).astype(f32)
+    n = np.zeros_like(vm)
+    c = vm[1:-1, 1:-1]; x0 = vm[1:-1, :-2]; x1 = vm[1:-1, 2:]; y0 = vm[:-2, 1:-1]; y1 = vm[2:, 1:-1]
+    ok = (c[..., 2] != 0) & (x0[..., 2] != 0) & (x1[..., 2] != 0) & (y0[..., 2] != 0) & (y1[..., 2] != 0)
+    tx = x1 - x0; ty = y1 - y0
+    ok &= (np.linalg.norm(tx.astype(np.float64), axis=-1) < thr) & (np.linalg.norm(ty.astype(np.float64), axis=-1) < thr)
+    cr = np.cross(ty.astype(np.float64), tx.astype(np.float64)); ln = np.linalg.norm(cr, axis=-1, keepdims=True)
+    cr = np.where(ln > 0, cr / np.where(ln > 0, ln, 1), cr)
+    n[1:-1, 1:-1] = np.where(ok[..., None], cr, 0).astype(f32)
+    return n
+
+
+def test_fusion_update_against_a_second_transcription(oracle):
+    """SparseVoxelGrid::integrate's per-voxel update (sparse_voxel_grid.cpp:316-393), computeFrustumBounds (:573-602), erodeDiscontinuities and computeNormals (rgbd/processing.cpp)
+    written a second time, vectorised in numpy from the reference's text, vs orc::Fusion frame by frame on three rendered frames: every stored voxel's sdf / weight / colour after a
+    frame follows from its state before the frame. The two float32 evaluations order a few sums differently, so a voxel whose projection lands within 1e-3 px of a pixel boundary
+    (or whose distance sits within 1e-6 of the truncation test) may be set aside if the two disagree on whether the frame touches it (none does today); everything else must agree."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    from make_dataset import pose_vec_to_cam_to_world
+    from intrinsic3d_amd import synthetic
+    f32 = np.float32
+    sc = synthetic.make_scene(radius_vox=10, K=3, width=96, height=72, levels=1, seed=5)
+    vs = f32(sc["voxel_size"]); trunc = vs * f32(5.0); dmin, dmax, iws = f32(0.1), f32(10.0), f32(10.0)
+    cam = np.asarray(sc["intr"], np.float32); fx, fy, cx, cy = (f32(v) for v in cam[:4])
+    fus = oracle.Fusion(float(vs), float(dmin), float(dmax))
+    state = {}
+    compared = set_aside = 0
+    for fr, pose in zip(sc["frames"], sc["poses"]):
+        depth = np.ascontiguousarray(fr["depth"][0], np.float32); bgr = fr["bgr"][0]
+        h, w = depth.shape
+        T = pose_vec_to_cam_to_world(np.asarray(pose, np.float64)).astype(np.float32)
+        er = _np_erode(depth, 2, 0.5)
+        assert np.array_equal(er, oracle.erode_discontinuities(depth, 2))
+        nrm = _np_normals(er, cam, 0.3)
+        np.testing.assert_allclose(nrm, oracle.compute_normals(er, cam), rtol=0, atol=2e-6)
+        fus.integrate(depth, cam, bgr, cam, T, 2)
+        out = fus.export()
+        keys = out["keys"]
+        # state before the frame (a voxel allocated by this frame starts as Voxel(): sdf 0, weight 0, colour 0)
+        s_old = np.zeros(len(keys), f32); w_old = np.zeros(len(keys), f32); c_old = np.zeros((len(keys), 3), np.uint8)
+        for i, k in enumerate(map(tuple, keys.tolist())):
+            if k in state:
+                s_old[i], w_old[i], c_old[i] = state[k]
+        # frustum bounds: corners unprojected at depth_min / depth_max, floor / ceil in METRES, then worldToVoxel = trunc(p / vs + 0.5)
+        corners = np.array([[(f32(px) - cx) / fx * dd, (f32(py) - cy) / fy * dd, dd] for dd in (dmin, dmax) for px, py in ((0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1))], f32)
+        pts = (corners @ T[:3, :3].T + T[:3, 3]).astype(f32)
+        w2v = lambda p: (p.astype(f32) * (f32(1) / vs) + f32(0.5)).astype(np.int32)
+        cand = np.concatenate([w2v(np.floor(pts)), w2v(np.ceil(pts))])
+        lo, hi = cand.min(0), cand.max(0)
+        inb = ((keys >= lo) & (keys <= hi)).all(1)
+        # the update
+        W = np.linalg.inv(T.astype(np.float64))
+        pw = keys.astype(f32) * vs
+        p = (pw @ W[:3, :3].T.astype(f32) + W[:3, 3].astype(f32)).astype(f32)
+        p64 = keys.astype(np.float64) * float(vs) @ W[:3, :3].T + W[:3, 3]
+        z = np.where(p[:, 2] != 0, p[:, 2], f32(1))
+        u = (p[:, 0] * fx) / z + cx; v = (p[:, 1] * fy) / z + cy
+        pi = (u + f32(0.5)).astype(np.int32); pj = (v + f32(0.5)).astype(np.int32)      # round() = cast of (x + 0.5): truncation toward zero
+        on = inb & (p[:, 2] >= 0) & (u + f32(0.5) > -1) & (v + f32(0.5) > -1) & (pi >= 0) & (pj >= 0) & (pi < w) & (pj < h)
+        pic = np.clip(pi, 0, w - 1); pjc = np.clip(pj, 0, h - 1)
+        d = er[pjc, pic]
+        on &= d > 0
+        sdf = d - p[:, 2]
+        on &= ~(sdf <= -trunc)
+        tsdf = np.where(sdf >= 0, np.minimum(trunc, sdf), np.maximum(-trunc, sdf))
+        rk = lambda x: f32(1) / ((f32(1) + f32(2) * x) ** 3).astype(f32)
+        pn = p / np.maximum(np.linalg.norm(p.astype(np.float64), axis=1), 1e-30)[:, None].astype(f32)
+        wn = f32(1) - np.abs((pn * nrm[pjc, pic]).sum(1).astype(f32))
+        wn = np.maximum(iws * rk(np.clip(wn, f32(0), f32(1))), f32(1))
+        wd = np.maximum(iws * rk(f32(2) * np.abs(tsdf) / trunc), f32(1))
+        wz = np.maximum(iws * (f32(1) - (d - dmin) / (dmax - dmin)), f32(1))
+        wu = np.maximum((wn + wd + wz) / f32(3), f32(3)).astype(f32)
+        w_new = (w_old + wu).astype(f32)
+        s_new = ((s_old * w_old + sdf * wu) / w_new).astype(f32)
+        rgb = bgr[pjc, pic][:, ::-1].astype(f32)                                      # colour camera == depth camera here; voxel colour is R, G, B
+        c_new = ((c_old.astype(f32) * w_old[:, None] + rgb * wu[:, None]) / w_new[:, None]).astype(np.uint8)
+        want_s = np.where(on, s_new, s_old); want_w = np.where(on, w_new, w_old); want_c = np.where(on[:, None], c_new, c_old)
+        # fragile decisions (float64 view of the same projection)
+        z64 = np.where(np.abs(p64[:, 2]) > 1e-9, p64[:, 2], 1.0)
+        u64 = p64[:, 0] * float(fx) / z64 + float(cx) + 0.5; v64 = p64[:, 1] * float(fy) / z64 + float(cy) + 0.5
+        frac = lambda a: np.abs(a - np.round(a))
+        fragile = (frac(u64) < 1e-3) | (frac(v64) < 1e-3) | (np.abs(p64[:, 2]) < 1e-6) | (np.abs(d.astype(np.float64) - p64[:, 2] + float(trunc)) < 1e-6)
+        touched = out["weight"] != w_old
+        assert not ((on != touched) & ~fragile).any(), "which voxels the frame touched"  # (the frustum bounds are integer tests on exact inputs: nothing fragile there)
+        g = on == touched
+        np.testing.assert_allclose(out["weight"][g], want_w[g], rtol=1e-5, atol=0)               # the cubed kernel amplifies the last bit of the normalised ray
+        np.testing.assert_allclose(out["sdf"][g], want_s[g], rtol=0, atol=2e-6)
+        avg = (c_old.astype(np.float64) * w_old[:, None] + rgb.astype(np.float64) * wu[:, None]) / w_new[:, None]
+        got_c = out["color"].astype(int)
+        sel = on & g                                                                   # the 8-bit truncation of an average that sits on an integer (first frame: c * w / w)
+        assert (got_c[sel] >= np.floor(avg[sel] - 1e-3)).all() and (got_c[sel] <= np.floor(avg[sel] + 1e-3)).all()
+        assert np.array_equal(out["color"][~on & g], c_old[~on & g]) and (got_c[sel] == want_c[sel]).mean() > 0.9
+        compared += int((on & g).sum()); set_aside += int((~g).sum())
+        state = {k: (s, ww, c) for k, s, ww, c in zip(map(tuple, keys.tolist()), out["sdf"], out["weight"], out["color"])}
+    assert compared > 5000 and set_aside < 0.01 * compared, (compared, set_aside)
+
+
 def test_shading_row_invalid_cases(oracle):
     v, sh, vs, lum, prm = _row_setup()
     p = prm.copy(); p[19] = -0.5 - v[2] * vs          # behind / far off the image
