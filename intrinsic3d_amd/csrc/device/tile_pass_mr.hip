@@ -28,6 +28,8 @@
 // profiles/r05_mr_hoist_inputs_ab.json; kept for one and two systems, the 3-system kernel has no registers left) buys 0.7 %.  What remains per system is its staging (2048 gathered
 // inputs per tile) and its pull phase (column sums through LDS, two barriers, the halo list walk, the output stores) at ONE 512-thread workgroup per CU.
 #include <cstring>
+#include <algorithm>
+#include <vector>
 #include <cstdlib>
 #include "kernels.hpp"
 #include "reduce_device.hpp"
@@ -142,6 +144,16 @@ __device__ unsigned long long g_mr_phase[3][MR_NPH + 2];
 #define PH(k)
 #define PH_TILE
 #define PH_FLUSH(NBv)
+#endif
+// Workgroup balance (variant build only: -DI3D_MR_BLOCKTIME): two s_memtime reads per workgroup — start and end — summed per workgroup index over all launches; the report
+// gives mean / min / max over the workgroups.  A launch lasts as long as its slowest workgroup: max / mean is what a balanced tile assignment could win.
+#ifdef I3D_MR_BLOCKTIME
+__device__ unsigned long long g_mr_blk[3][1024], g_mr_blk_n[3][1024];
+#define BT_DECL const unsigned long long bt0_ = __builtin_amdgcn_s_memtime()
+#define BT_FLUSH(NBv) do { if (threadIdx.x == 0u && blockIdx.x < 1024u) { atomicAdd(&g_mr_blk[(NBv) - 1][blockIdx.x], __builtin_amdgcn_s_memtime() - bt0_); atomicAdd(&g_mr_blk_n[(NBv) - 1][blockIdx.x], 1ull); } } while (0)
+#else
+#define BT_DECL
+#define BT_FLUSH(NBv)
 #endif
 
 struct MrArgs {
@@ -267,7 +279,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #pragma unroll
         for (int w = 0; w < 5; ++w) ln[w] = __builtin_nontemporal_load(&lnbr[(size_t)w * Acap + ac]);
     };
-    PH_DECL;
+    PH_DECL; BT_DECL;
     int gm_next = 0;
     if (tile0 < tk_end) {          // (workgroup-uniform) the first tile's inputs: the only ones nothing overlaps
         gm = group_rows(tile0);
@@ -521,7 +533,7 @@ __global__ void __launch_bounds__(MR_T, 2) k_eg_tile_mr(RowView r, OptParams p, 
 #pragma unroll
         for (int b = 0; b < NB; ++b) { if (alive[b]) block_partial_d(PQ_L(b)[i], m.pq0 + (size_t)m.sys[b] * m.part, 1, 0); }
     }
-    PH(11); PH_FLUSH(NB);
+    PH(11); PH_FLUSH(NB); BT_FLUSH(NB);
 #undef SYS
 #undef U_S
 #undef U_A
@@ -547,6 +559,22 @@ static void mr_phase_report() {
     }
 }
 void mr_phase_report_now() { (void)hipDeviceSynchronize(); mr_phase_report(); }
+#endif
+#ifdef I3D_MR_BLOCKTIME
+void mr_blocktime_report_now() {
+    (void)hipDeviceSynchronize();
+    static unsigned long long h[3][1024], n[3][1024];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mr_blk), sizeof(h)) != hipSuccess || hipMemcpyFromSymbol(n, HIP_SYMBOL(g_mr_blk_n), sizeof(n)) != hipSuccess) return;
+    for (int nb = 0; nb < 3; ++nb) {
+        int cnt = 0; double sum = 0.0, mx = 0.0, mn = 1e300; int imx = -1;
+        std::vector<double> v;
+        for (int b = 0; b < 1024; ++b) if (n[nb][b]) { const double t = (double)h[nb][b] / (double)n[nb][b]; v.push_back(t); sum += t; if (t > mx) { mx = t; imx = b; } if (t < mn) mn = t; ++cnt; }
+        if (!cnt) continue;
+        std::sort(v.begin(), v.end());
+        std::fprintf(stderr, "[mr blocktime] k_eg_tile_mr<%d>: %d workgroups, %llu launches; ticks per launch: mean %.0f  min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f (workgroup %d)  max/mean %.3f\n",
+                     nb + 1, cnt, n[nb][0], sum / cnt, mn, v[cnt / 10], v[cnt / 2], v[(9 * cnt) / 10], mx, imx, mx / (sum / cnt));
+    }
+}
 #endif
 
 // the largest number of systems one launch can take at K keyframes (the staged inputs of every system must fit the 160 KB of LDS): 3 at the bench's K = 200, 0 = never

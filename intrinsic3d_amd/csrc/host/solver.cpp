@@ -16,6 +16,9 @@ namespace i3d {
 #ifdef I3D_MR_PHASES
 void mr_phase_report_now();     // tile_pass_mr.hip, variant build only
 #endif
+#ifdef I3D_MR_BLOCKTIME
+void mr_blocktime_report_now(); // tile_pass_mr.hip, variant build only
+#endif
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -1016,6 +1019,9 @@ int optimize(i3d_context* c, const i3d_optimizer_config& cfg, i3d_iteration_stat
     c->assembled = false;
 #ifdef I3D_MR_PHASES
     mr_phase_report_now();      // (variant build only: tools/build_variant.sh)
+#endif
+#ifdef I3D_MR_BLOCKTIME
+    mr_blocktime_report_now();
 #endif
     return I3D_OK;
 }
