@@ -228,8 +228,18 @@ static __device__ inline float chroma_weight(uchar4 c, uchar4 cn) {
 
 // FR_LDS: the per-keyframe constants (144 B each) of ALL keyframes are staged in LDS once per workgroup — every row reads
 // R, t (and Jr) of its keyframe, and with them in global memory those wave-divergent gathers keep the texture-address unit busy.
-template <bool WITH_J, bool FR_LDS, int BATCH, bool PIPE = false>
-__global__ void __launch_bounds__(256, WITH_J ? 2 : (PIPE ? 3 : 4)) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out,
+template <bool WITH_J, bool FR_LDS, int BATCH, bool PIPE = false> __global__ void k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out, const double* __restrict__ cam9, const LmState* __restrict__ lm);
+#ifdef I3D_BUILD_VALUE_PROBE
+// Timing probe (variant build only, never shipped): the VALUE half of a two-kernel split of k_build<true> — projection, taps, spline values AND derivatives, residual, the four
+// coefficients — storing what a derivative kernel would need (4 x {x0, y0, 1/z, dfdr, dfdc}, c_0..3, residual, weight, keyframe: 112 B per row, in the row buffer's own coalesced
+// planes) instead of assembling the 29 partials.  I3D_BUILD_VALUE_PROBE = waves per SIMD the compiler may aim for (2: point records in LDS as shipped; 3 / 4: in registers, keyframe
+// constants in LDS as in the cost kernel).  The rows it leaves are NOT rows: only the kernel's own duration means anything in such a run.
+constexpr int BUILD_PROBE_WAVES = I3D_BUILD_VALUE_PROBE;
+#else
+constexpr int BUILD_PROBE_WAVES = 0;
+#endif
+template <bool WITH_J, bool FR_LDS, int BATCH, bool PIPE>
+__global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE_WAVES : 2) : (PIPE ? 3 : 4)) k_build(GridView g, RowView r, OptParams p, const FrameConst* __restrict__ frames, double* cost_out,
                                                                const double* __restrict__ cam9, const LmState* __restrict__ lm) {
     extern __shared__ double frame_lds_raw[];
     if (!WITH_J) {
@@ -335,8 +345,9 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : (PIPE ? 3 : 4)) k_build(Grid
             const double vs = (double)g.voxel_size;
             // WITH_J: the 4 point records (72 B each) live in LDS (one 296-byte slot per lane), not in registers: the Jacobian variant is
             // register-bound (256 VGPR + AGPR spills = one wave per SIMD) and only reads them field by field
-            PointShared qreg[WITH_J ? 1 : 4];
-            PointShared* q = WITH_J ? reinterpret_cast<PointShared*>(reinterpret_cast<char*>(frame_lds_raw) + (FR_LDS ? (size_t)p.K * sizeof(FrameHot) : 0) + (size_t)threadIdx.x * Q_LDS_STRIDE) : qreg;
+            constexpr bool Q_LDS = WITH_J && BUILD_PROBE_WAVES <= 2;
+            PointShared qreg[Q_LDS ? 1 : 4];
+            PointShared* q = Q_LDS ? reinterpret_cast<PointShared*>(reinterpret_cast<char*>(frame_lds_raw) + (FR_LDS ? (size_t)p.K * sizeof(FrameHot) : 0) + (size_t)threadIdx.x * Q_LDS_STRIDE) : qreg;
             // sdf slots: 0:000 1:010 2:020 3:011 4:001 5:002 6:100 7:110 8:101 9:200 (shading_cost.h:88-97)
             shared_point(q[0], sd[0], sd[6], sd[1], sd[4], g.x_alb[idx[10]], sh, cx, cy, cz, vs);
             shared_point(q[1], sd[6], sd[9], sd[7], sd[8], g.x_alb[idx[11]], sh, cx + 1, cy, cz, vs);
@@ -449,6 +460,18 @@ __global__ void __launch_bounds__(256, WITH_J ? 2 : (PIPE ? 3 : 4)) k_build(Grid
                 // rows are stored with the row weight folded in (Js = sqrt(w) J, common.hpp RowView).  Every partial below is linear in the four
                 // coefficients c_j, so the fold costs 4 multiplications here instead of 29 at the store
                 { const float sw = sqrtf(roww); cj[0] *= sw; cj[1] *= sw; cj[2] *= sw; cj[3] *= sw; }
+#ifdef I3D_BUILD_VALUE_PROBE
+                {
+                    float I[28];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { I[5 * j] = pv[j].x0; I[5 * j + 1] = pv[j].y0; I[5 * j + 2] = pv[j].iz; I[5 * j + 3] = pv[j].dfdr; I[5 * j + 4] = pv[j].dfdc; }
+                    I[20] = cj[0]; I[21] = cj[1]; I[22] = cj[2]; I[23] = cj[3]; I[24] = (float)res; I[25] = roww; I[26] = __int_as_float(f | (vox_free ? ROW_FREE_BIT : 0)); I[27] = 0.0f;
+#pragma unroll
+                    for (int gq = 0; gq < 7; ++gq) st_row(&r.rows[row_index(a, nout, gq, r.slots)], I[4 * gq], I[4 * gq + 1], I[4 * gq + 2], I[4 * gq + 3]);
+                    ++nout;
+                    continue;
+                }
+#endif
                 // ---- phase 2: partials (fp32), accumulated point by point ----
                 float J[P_TOTAL];
 #pragma unroll
@@ -539,6 +562,13 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
     if (with_jacobian) {
         // point records in LDS (74 KB per workgroup), per-keyframe constants from global memory: 247 VGPRs, no spills, TWO workgroups per CU.
         // (Measured: 2.13 -> 1.45 ms; with the keyframe constants staged in LDS as well only one workgroup fits and nothing is gained.)
+#ifdef I3D_BUILD_VALUE_PROBE
+        if (BUILD_PROBE_WAVES > 2) {           // (variant build only) point records in registers, keyframe constants in LDS like the cost kernel
+            if (!set_dynamic_lds((const void*)k_build<true, true, 2>, "k_build<true> value probe", lds, p.K)) return;
+            k_build<true, true, 2><<<blocks, 256, lds, st>>>(g, r, p, frames, cost_out, nullptr, nullptr);
+            return;
+        }
+#endif
         if (!set_dynamic_lds((const void*)k_build<true, false, 2>, "k_build<true>", qlds, p.K)) return;
         k_build<true, false, 2><<<blocks, 256, qlds, st>>>(g, r, p, frames, cost_out, nullptr, nullptr);
     } else {
