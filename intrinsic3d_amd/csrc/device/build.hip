@@ -256,7 +256,21 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
         }
         __syncthreads();
     }
+#ifdef I3D_COST_MULTI_PROBE
+    // Timing probe (variant build only, never shipped): what ONE launch for the B candidates of a ladder batch could cost.  The cost kernel's grid is B times as large; the
+    // B workgroups of a voxel block evaluate the SAME candidate (a stand-in for B nearby candidate points: same voxel records, same observation lists, image taps within a pixel of
+    // each other), land on the same XCD (workgroup ids that agree modulo 8) within 8 B consecutive ids, and only the first of them contributes to the cost — the run itself stays the
+    // normal run, launch for launch, with a cost kernel that does B times the work.
+    int bx = blockIdx.x; bool probe_extra = false;
+#ifdef I3D_COST_MULTI_PROBE_FAR      // control: candidate-major ids — the B workgroups of a voxel block run a whole candidate apart, as B separate launches would
+    if (!WITH_J) { constexpr int PB = I3D_COST_MULTI_PROBE; const int per = (int)gridDim.x / PB; probe_extra = (int)blockIdx.x / per != 0; bx = (int)blockIdx.x % per; }
+#else
+    if (!WITH_J) { constexpr int PB = I3D_COST_MULTI_PROBE; const int grp = (int)blockIdx.x / (8 * PB), rr = (int)blockIdx.x % (8 * PB); probe_extra = rr / 8 != 0; bx = grp * 8 + (rr % 8); }
+#endif
+    const int ci = bx * blockDim.x + threadIdx.x;
+#else
     const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+#endif
     const int a = ci < r.nC ? (r.clist ? r.clist[ci] : ci) : -1;      // compute list of this rank (identity when not sharded)
     const bool owned = a >= r.own0 && a < r.own1;                     // cost / weight sums count every row once: on its owner
     double cost = 0.0;
@@ -550,13 +564,20 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
         }
         }
     }
+#ifdef I3D_COST_MULTI_PROBE
+    if (!WITH_J && probe_extra) cost = 0.0;
+#endif
     if (!WITH_J) block_partial_d(cost, cost_out, 1, 0);          // per-workgroup partial (no same-address atomics), summed by k_reduce_partials
 }
 
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out, double* scratch,
                   const double* cam9, const LmState* lm) {
     if (r.nC <= 0) return;
+#ifdef I3D_COST_MULTI_PROBE
+    const int blocks = with_jacobian ? (r.nC + 255) / 256 : (((r.nC + 255) / 256 + 7) / 8) * 8 * I3D_COST_MULTI_PROBE;
+#else
     const int blocks = (r.nC + 255) / 256;
+#endif
     double* const cost_dst = cost_out; cost_out = scratch;       // the kernels write per-workgroup partials
     const size_t lds = (size_t)p.K * sizeof(FrameHot), qlds = (size_t)256 * Q_LDS_STRIDE;
     if (with_jacobian) {
