@@ -298,27 +298,32 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
         const double xs = g.x_sdf[s];
         uint8_t rf = 0;
         if (WITH_J) {
+            // the ring's flags, visit ranks and colours: 18 gathers requested TOGETHER and unconditionally (an entry without a full ring reads its own voxel).  Six rounds of
+            // `flags -> rank -> colour` behind conditions were six to twelve exposed round trips per entry at two waves per SIMD.
+            uint8_t nfl[6]; int nrk[6]; uchar4 ncol[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) { const int nb = ring_ok ? ring[d] : s; nfl[d] = g.flags[nb]; nrk[d] = g.rank[nb]; ncol[d] = g.color[nb]; }
+            const uchar4 col = g.color[s];
+            const int myrank = g.rank[s];
+            const double sdf0s = g.sdf0[s];
             if (p.use_er && ring_ok) {
                 rf |= 1;
                 bool fr = (fl & F_FREE_SDF) != 0;
 #pragma unroll
-                for (int d = 0; d < 6; ++d) fr |= (g.flags[ring[d]] & F_FREE_SDF) != 0;
+                for (int d = 0; d < 6; ++d) fr |= (nfl[d] & F_FREE_SDF) != 0;
                 if (fr) rf |= 8;
             }
-            if (p.use_es) { rf |= 2; if ((xs - g.sdf0[s]) != 0.0) rf |= 4; if (fl & F_FREE_SDF) rf |= 16; }
+            if (p.use_es) { rf |= 2; if ((xs - sdf0s) != 0.0) rf |= 4; if (fl & F_FREE_SDF) rf |= 16; }
             uint8_t eafree = 0;
-            const uchar4 col = g.color[s];
-            const int myrank = g.rank[s];
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
                 float w = 0.0f;
                 if (p.use_ea && ring_ok) {
-                    const int nb = ring[d];
-                    const bool added_before = (g.flags[nb] & F_ACTIVE) && g.rank[nb] < myrank;     // voxels_added, optimizer.cpp:267-279
+                    const bool added_before = (nfl[d] & F_ACTIVE) && nrk[d] < myrank;     // voxels_added, optimizer.cpp:267-279
                     if (!added_before) {
-                        w = chroma_weight(col, g.color[nb]);
+                        w = chroma_weight(col, ncol[d]);
                         if (!(w == w) || isinf(w)) w = 0.0f;
-                        if (w != 0.0f && ((fl & F_FREE_ALB) || (g.flags[nb] & F_FREE_ALB))) eafree |= (uint8_t)(1 << d);
+                        if (w != 0.0f && ((fl & F_FREE_ALB) || (nfl[d] & F_FREE_ALB))) eafree |= (uint8_t)(1 << d);
                     }
                 }
                 r.ea_w[(size_t)d * Acap + a] = w;
@@ -363,16 +368,24 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
             PointShared qreg[Q_LDS ? 1 : 4];
             PointShared* q = Q_LDS ? reinterpret_cast<PointShared*>(reinterpret_cast<char*>(frame_lds_raw) + (FR_LDS ? (size_t)p.K * sizeof(FrameHot) : 0) + (size_t)threadIdx.x * Q_LDS_STRIDE) : qreg;
             // sdf slots: 0:000 1:010 2:020 3:011 4:001 5:002 6:100 7:110 8:101 9:200 (shading_cost.h:88-97)
-            shared_point(q[0], sd[0], sd[6], sd[1], sd[4], g.x_alb[idx[10]], sh, cx, cy, cz, vs);
-            shared_point(q[1], sd[6], sd[9], sd[7], sd[8], g.x_alb[idx[11]], sh, cx + 1, cy, cz, vs);
-            shared_point(q[2], sd[1], sd[7], sd[2], sd[3], g.x_alb[idx[12]], sh, cx, cy + 1, cz, vs);
-            shared_point(q[3], sd[4], sd[8], sd[3], sd[5], g.x_alb[idx[13]], sh, cx, cy, cz + 1, vs);
+            // (assembly) the four albedos and the 14 flag bytes of the stencil are requested with the sdf values, in front of the fp64 point records they would otherwise wait behind
+            double albv[4] = {0.0, 0.0, 0.0, 0.0}; uint8_t vfl[P_VOX];
+            if (WITH_J) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) albv[j] = g.x_alb[idx[10 + j]];
+#pragma unroll
+                for (int c = 0; c < P_VOX; ++c) vfl[c] = g.flags[idx[c]];
+            }
+            shared_point(q[0], sd[0], sd[6], sd[1], sd[4], WITH_J ? albv[0] : g.x_alb[idx[10]], sh, cx, cy, cz, vs);
+            shared_point(q[1], sd[6], sd[9], sd[7], sd[8], WITH_J ? albv[1] : g.x_alb[idx[11]], sh, cx + 1, cy, cz, vs);
+            shared_point(q[2], sd[1], sd[7], sd[2], sd[3], WITH_J ? albv[2] : g.x_alb[idx[12]], sh, cx, cy + 1, cz, vs);
+            shared_point(q[3], sd[4], sd[8], sd[3], sd[5], WITH_J ? albv[3] : g.x_alb[idx[13]], sh, cx, cy, cz + 1, vs);
             bool vox_free = false;
             if (WITH_J) {
 #pragma unroll
-                for (int c = 0; c < 10; ++c) vox_free |= (g.flags[idx[c]] & F_FREE_SDF) != 0;
+                for (int c = 0; c < 10; ++c) vox_free |= (vfl[c] & F_FREE_SDF) != 0;
 #pragma unroll
-                for (int c = 10; c < 14; ++c) vox_free |= (g.flags[idx[c]] & F_FREE_ALB) != 0;
+                for (int c = 10; c < 14; ++c) vox_free |= (vfl[c] & F_FREE_ALB) != 0;
                 vox_free |= !p.fix_poses || !p.fix_intr || !p.fix_dist;
             }
             const double weight_sdf = sdf_to_weight(xs, (double)g.truncation);
@@ -438,13 +451,32 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
                     row(nin - 1, std::false_type{});
                 }
             } else
+            {
+            // (assembly) the observation slot of row k + 1 is requested while row k is evaluated: its keyframe index is the first link of a row's chain of dependent loads
+            // (slot -> keyframe constants -> taps of points 0,1 -> taps of points 2,3).  Unconditional (the last row re-reads its own slot): a conditional load would make
+            // the compiler drain every load in flight at the join.
+            float ow_next = 0.0f; int f_next = 0;
+            if (WITH_J) { ow_next = r.obs_w[a]; f_next = r.obs_frame[a]; }
             for (int k = 0; k < nin; ++k) {
-                const size_t ka = (size_t)k * Acap + a;
                 float roww; int f;
-                if (WITH_J) { const float ow = r.obs_w[ka]; f = r.obs_frame[ka]; roww = (ow > 0.0f) ? (float)((double)ow * weight_sdf) : 0.0f; }
+                if (WITH_J) { const float ow = ow_next; f = f_next;
+                              { const size_t kn = (size_t)min(k + 1, nin - 1) * Acap + a; ow_next = r.obs_w[kn]; f_next = r.obs_frame[kn]; }
+                              roww = (ow > 0.0f) ? (float)((double)ow * weight_sdf) : 0.0f; }
                 else { const size_t ro = row_scalar_index(a, k, r.slots); const int fb = __float_as_int(r.row_jt()[row_jt_index(a, k, r.slots)].y); roww = (fb & ROW_FREE_BIT) ? r.row_wr[ro].x : 0.0f; f = fb & ~ROW_FREE_BIT; }
                 if (roww == 0.0f) continue;
                 const FrameHot& fc = FR_LDS ? flds[f] : frames[f].hot;
+                // (assembly: keyframe constants in global memory) the image pointer is requested HERE, in front of R and t: left to the scheduler it is requested where it is first
+                // used — behind the projections — and the taps wait a round trip of their own for it
+                const float* const lum_img = WITH_J ? fc.lum : nullptr;
+                // ... and R, t are read ONCE per row: left alone, the second pair of points and the fp32 copy of R for the partials each read them again — a round trip each
+                double Rl[WITH_J ? 9 : 1], tl[WITH_J ? 3 : 1];
+                if (WITH_J) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rl[i] = fc.R[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) tl[i] = fc.t[i];
+                }
+                if (WITH_J && !FR_LDS) __builtin_amdgcn_sched_barrier(0);
                 // ---- phase 1: values (fp64) ----
                 double lum[4]; PointVal pv[4];
                 bool ok = true;
@@ -453,11 +485,11 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
                     if (!ok) break;             // a row with a point outside the image is dropped (cost.h:100-105)
                     double pu[BATCH], pw[BATCH];
 #pragma unroll
-                    for (int j = 0; j < BATCH; ++j) ok = project_point<WITH_J>(q[j0 + j].P, fc.R, fc.t, p, pu[j], pw[j], pv[j0 + j]) && ok;
+                    for (int j = 0; j < BATCH; ++j) ok = project_point<WITH_J>(q[j0 + j].P, WITH_J ? Rl : fc.R, WITH_J ? tl : fc.t, p, pu[j], pw[j], pv[j0 + j]) && ok;
                     if (ok) {
                         Taps tp[BATCH];
 #pragma unroll
-                        for (int j = 0; j < BATCH; ++j) bicubic_taps(fc.lum, p.w, p.h, pw[j], pu[j], tp[j]);
+                        for (int j = 0; j < BATCH; ++j) bicubic_taps(WITH_J ? lum_img : fc.lum, p.w, p.h, pw[j], pu[j], tp[j]);
 #pragma unroll
                         for (int j = 0; j < BATCH; ++j) bicubic_eval<WITH_J>(tp[j], lum[j0 + j], pv[j0 + j].dfdr, pv[j0 + j].dfdc);
                     }
@@ -487,11 +519,17 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
                 }
 #endif
                 // ---- phase 2: partials (fp32), accumulated point by point ----
+                // (keyframe constants in global memory) the right Jacobian of the rotation is requested here and used at the end of the phase: requested where it is used it
+                // cost every row a round trip of its own
+                float jr[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) jr[i] = fc.Jr[i];
+                if (WITH_J && !FR_LDS) __builtin_amdgcn_sched_barrier(0);
                 float J[P_TOTAL];
 #pragma unroll
                 for (int i = 0; i < P_TOTAL; ++i) J[i] = 0.0f;
                 float Wx = 0.0f, Wy = 0.0f, Wz = 0.0f;                              // sum_j c_j (P_j x M_j): rotation part before Jr
-                const float R0 = (float)fc.R[0], R1 = (float)fc.R[1], R2 = (float)fc.R[2], R3 = (float)fc.R[3], R4 = (float)fc.R[4], R5 = (float)fc.R[5], R6 = (float)fc.R[6], R7 = (float)fc.R[7], R8 = (float)fc.R[8];
+                const float R0 = (float)Rl[0], R1 = (float)Rl[1], R2 = (float)Rl[2], R3 = (float)Rl[3], R4 = (float)Rl[4], R5 = (float)Rl[5], R6 = (float)Rl[6], R7 = (float)Rl[7], R8 = (float)Rl[8];
                 // Two stencil points per pass in PACKED fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes of arithmetic per instruction, the
                 // fp32 half of this kernel's issue time): the chain below is the same for every point, only the scatter into J is per point
 #pragma unroll
@@ -541,9 +579,9 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
                     const f2 e3 = c * (au * dxk3 + av * (c2 * dxk3 + (r2 + 2.0f * y0 * y0))), e4 = c * (au * dxk4 + av * (2.0f * xd * y0 + c2 * dxk4));
                     J[P_DIST + 0] -= e0.x + e0.y; J[P_DIST + 1] -= e1.x + e1.y; J[P_DIST + 2] -= e2.x + e2.y; J[P_DIST + 3] -= e3.x + e3.y; J[P_DIST + 4] -= e4.x + e4.y;
                 }
-                J[P_POSE + 0] = -(Wx * fc.Jr[0] + Wy * fc.Jr[3] + Wz * fc.Jr[6]);
-                J[P_POSE + 1] = -(Wx * fc.Jr[1] + Wy * fc.Jr[4] + Wz * fc.Jr[7]);
-                J[P_POSE + 2] = -(Wx * fc.Jr[2] + Wy * fc.Jr[5] + Wz * fc.Jr[8]);
+                J[P_POSE + 0] = -(Wx * jr[0] + Wy * jr[3] + Wz * jr[6]);
+                J[P_POSE + 1] = -(Wx * jr[1] + Wy * jr[4] + Wz * jr[7]);
+                J[P_POSE + 2] = -(Wx * jr[2] + Wy * jr[5] + Wz * jr[8]);
                 // all 29 partials finite?  0 * x is 0 for a finite x and NaN for Inf / NaN: one fma per partial instead of a class test + mask merge each
                 float finz = 0.0f;
 #pragma unroll
@@ -557,6 +595,7 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
                 st_row2(&r.row_jt()[row_jt_index(a, nout, r.slots)], J[28], __int_as_float(f | (vox_free ? ROW_FREE_BIT : 0)));
                 st_row2(&r.row_wr[ro], roww, (float)res);
                 ++nout;
+            }
             }
         }
         if (WITH_J) {
