@@ -278,6 +278,14 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
         const int N = g.N; const size_t Acap = r.Acap;
         const int s = r.alist[a];
         const uint8_t fl = r.aflags[a];
+        // (cost) what the entry stored at assembly — flags of its regulariser rows, row count, Ea weights — is indexed by the entry alone: requested with its list slot, not where used
+        uint8_t pre_rf = 0, pre_eafree = 0, pre_nrows = 0; float eaw[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (!WITH_J) {
+            pre_rf = r.regflags[a]; pre_eafree = r.ea_free[a]; pre_nrows = r.nrows[a];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) eaw[d] = r.ea_w[(size_t)d * Acap + a];
+        }
+        __builtin_amdgcn_sched_barrier(0);     // (every load above is requested before the first of them is waited for)
         if (!(fl & F_ACTIVE)) {                 // free-only entry: unknowns but no rows
             if (WITH_J) {
                 r.regflags[a] = 0; r.ea_free[a] = 0; r.nrows[a] = 0;
@@ -330,27 +338,34 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
             }
             r.regflags[a] = rf; r.ea_free[a] = eafree;
         } else {
-            rf = r.regflags[a];
-            // cost of the regulariser rows at this state (rows without a free parameter are not part of the reduced program)
+            // cost of the regulariser rows at this state (rows without a free parameter are not part of the reduced program).  Everything they read is requested TOGETHER and
+            // unconditionally (an entry without a full ring reads its own voxel): behind their conditions the seven gathers were seven exposed round trips per entry.
+            rf = pre_rf;
+            const uint8_t eafree = pre_eafree;
+            const double sdf0s = g.sdf0[s], xa = g.x_alb[s];
+            double xsr[6], xar[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) { const int nb = ring_ok ? ring[d] : s; xsr[d] = g.x_sdf[nb]; xar[d] = g.x_alb[nb]; }
             if ((rf & 1) && (rf & 8)) {
-                const double dxx = g.x_sdf[ring[0]] + g.x_sdf[ring[1]] - 2.0 * xs, dyy = g.x_sdf[ring[2]] + g.x_sdf[ring[3]] - 2.0 * xs,
-                             dzz = g.x_sdf[ring[4]] + g.x_sdf[ring[5]] - 2.0 * xs;
+                const double dxx = xsr[0] + xsr[1] - 2.0 * xs, dyy = xsr[2] + xsr[3] - 2.0 * xs, dzz = xsr[4] + xsr[5] - 2.0 * xs;
                 const double lap = dxx + dyy + dzz; cost += 0.5 * p.type_w[1] * lap * lap;
             }
-            if ((rf & 2) && (rf & 16)) { double e = xs - g.sdf0[s]; if (e == 0.0) e = 0.0000001; cost += 0.5 * p.type_w[2] * e * e; }
-            const uint8_t eafree = r.ea_free[a];
-            const double xa = g.x_alb[s];
+            if ((rf & 2) && (rf & 16)) { double e = xs - sdf0s; if (e == 0.0) e = 0.0000001; cost += 0.5 * p.type_w[2] * e * e; }
 #pragma unroll
             for (int d = 0; d < 6; ++d) if (eafree & (1 << d)) {
-                const double e = xa - g.x_alb[ring[d]];
-                cost += 0.5 * (double)r.ea_w[(size_t)d * Acap + a] * p.type_w[3] * e * e;
+                const double e = xa - xar[d];
+                cost += 0.5 * (double)eaw[d] * p.type_w[3] * e * e;
             }
         }
 
         // ---- Eg rows ---------------------------------------------------------------------------------------
-        const int nin = WITH_J ? r.slots : (int)r.nrows[a];       // candidates: observation slots (assembly) or stored rows (cost)
+        const int nin = WITH_J ? r.slots : (int)pre_nrows;        // candidates: observation slots (assembly) or stored rows (cost)
         bool any_row = false;
-        if (WITH_J) { for (int k = 0; k < r.slots; ++k) any_row |= r.obs_w[(size_t)k * Acap + a] > 0.0f; any_row &= eligible; }
+        if (WITH_J) {          // (unrolled, unconditional loads: as a run-time loop every slot was a load and a wait of its own)
+#pragma unroll
+            for (int k = 0; k < MAX_SLOTS; ++k) { const float w = r.obs_w[(size_t)min(k, r.slots - 1) * Acap + a]; any_row |= k < r.slots && w > 0.0f; }
+            any_row &= eligible;
+        }
         else any_row = nin > 0;
         int nout = 0;
         if (any_row) {
@@ -368,18 +383,18 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
             PointShared qreg[Q_LDS ? 1 : 4];
             PointShared* q = Q_LDS ? reinterpret_cast<PointShared*>(reinterpret_cast<char*>(frame_lds_raw) + (FR_LDS ? (size_t)p.K * sizeof(FrameHot) : 0) + (size_t)threadIdx.x * Q_LDS_STRIDE) : qreg;
             // sdf slots: 0:000 1:010 2:020 3:011 4:001 5:002 6:100 7:110 8:101 9:200 (shading_cost.h:88-97)
-            // (assembly) the four albedos and the 14 flag bytes of the stencil are requested with the sdf values, in front of the fp64 point records they would otherwise wait behind
+            // the four albedos (and, at assembly, the 14 flag bytes of the stencil) are requested with the sdf values, in front of the fp64 point records they would otherwise wait behind
             double albv[4] = {0.0, 0.0, 0.0, 0.0}; uint8_t vfl[P_VOX];
-            if (WITH_J) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) albv[j] = g.x_alb[idx[10 + j]];
+            for (int j = 0; j < 4; ++j) albv[j] = g.x_alb[idx[10 + j]];
+            if (WITH_J) {
 #pragma unroll
                 for (int c = 0; c < P_VOX; ++c) vfl[c] = g.flags[idx[c]];
             }
-            shared_point(q[0], sd[0], sd[6], sd[1], sd[4], WITH_J ? albv[0] : g.x_alb[idx[10]], sh, cx, cy, cz, vs);
-            shared_point(q[1], sd[6], sd[9], sd[7], sd[8], WITH_J ? albv[1] : g.x_alb[idx[11]], sh, cx + 1, cy, cz, vs);
-            shared_point(q[2], sd[1], sd[7], sd[2], sd[3], WITH_J ? albv[2] : g.x_alb[idx[12]], sh, cx, cy + 1, cz, vs);
-            shared_point(q[3], sd[4], sd[8], sd[3], sd[5], WITH_J ? albv[3] : g.x_alb[idx[13]], sh, cx, cy, cz + 1, vs);
+            shared_point(q[0], sd[0], sd[6], sd[1], sd[4], albv[0], sh, cx, cy, cz, vs);
+            shared_point(q[1], sd[6], sd[9], sd[7], sd[8], albv[1], sh, cx + 1, cy, cz, vs);
+            shared_point(q[2], sd[1], sd[7], sd[2], sd[3], albv[2], sh, cx, cy + 1, cz, vs);
+            shared_point(q[3], sd[4], sd[8], sd[3], sd[5], albv[3], sh, cx, cy, cz + 1, vs);
             bool vox_free = false;
             if (WITH_J) {
 #pragma unroll
