@@ -118,34 +118,42 @@ __global__ void __launch_bounds__(GC_THREADS, GC_OCC) k_eg_gradcol(GridView g, R
 #pragma unroll
             for (int c = 0; c < P_VOX; ++c) { b.Cg[(size_t)c * Acap + a] = accg[c]; b.Cc[(size_t)c * Acap + a] = accc[c]; }
             // ---- regulariser rows: tr (Er), ts (Es, Jacobian folded in), ta[6] (Ea): weighted residual (gradient) / weight (column norms) ----
-            const uint8_t rf = (fl & F_ACTIVE) ? r.regflags[a] : 0;
-            float trg = 0.0f, tsg = 0.0f, trc = 0.0f, tsc = 0.0f;
+            // Everything they read is requested in TWO batches, unconditionally (an entry without the row reads its own voxel; the flags select afterwards): the entry's bytes, Ea
+            // weights and ring, then the ring's sdf / albedo values.  Behind their conditions the Ea rows alone were a chain of weight -> neighbour -> albedo per direction: up to 18
+            // round trips per entry at ONE workgroup per CU.
             const int s = r.alist[a];
             const int N = g.N;
-            const uint8_t eafree = (owned && (fl & F_ACTIVE)) ? r.ea_free[a] : 0;
+            const bool act = (fl & F_ACTIVE) != 0;
+            const uint8_t rf_ld = r.regflags[a], eaf_ld = r.ea_free[a];
+            float eaw[6]; int rg[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) { eaw[d] = r.ea_w[(size_t)d * Acap + a]; rg[d] = g.nbr[(size_t)d * N + s]; }
+            const double xs = g.x_sdf[s], xa = g.x_alb[s], s0 = g.sdf0[s];
+            double xsn[6], xan[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) { const int nb = rg[d] >= 0 ? rg[d] : s; xsn[d] = g.x_sdf[nb]; xan[d] = g.x_alb[nb]; }
+            const uint8_t rf = act ? rf_ld : 0;
+            float trg = 0.0f, tsg = 0.0f, trc = 0.0f, tsc = 0.0f;
+            const uint8_t eafree = (owned && act) ? eaf_ld : 0;
             if (rf & 1) {
                 const float rho = (float)p.type_w[1];
-                const double xs = g.x_sdf[s];
-                double nbv[6];
-#pragma unroll
-                for (int d = 0; d < 6; ++d) nbv[d] = g.x_sdf[g.nbr[(size_t)d * N + s]];
-                const double dxx = nbv[0] + nbv[1] - 2.0 * xs, dyy = nbv[2] + nbv[3] - 2.0 * xs, dzz = nbv[4] + nbv[5] - 2.0 * xs;
+                const double dxx = xsn[0] + xsn[1] - 2.0 * xs, dyy = xsn[2] + xsn[3] - 2.0 * xs, dzz = xsn[4] + xsn[5] - 2.0 * xs;
                 const double lap = dxx + dyy + dzz;
                 trg = rho * (float)lap; trc = rho;
                 if (owned && (rf & 8)) cost += 0.5 * p.type_w[1] * lap * lap;
             }
             if (rf & 2) {
-                const double e0 = g.x_sdf[s] - g.sdf0[s];
+                const double e0 = xs - s0;
                 if (rf & 4) { const float rho = (float)p.type_w[2]; tsg = rho * (float)e0; tsc = rho; }
                 if (owned && (rf & 16)) { const double e = e0 == 0.0 ? 0.0000001 : e0; cost += 0.5 * p.type_w[2] * e * e; }      // surface_stab_regularizer.h:62-64
             }
             b.tregg[a] = trg; b.tregg[Acap + a] = tsg; b.tregc[a] = trc; b.tregc[Acap + a] = tsc;
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
-                const float w = (fl & F_ACTIVE) ? r.ea_w[(size_t)d * Acap + a] : 0.0f;
+                const float w = act ? eaw[d] : 0.0f;
                 float tag = 0.0f, tac = 0.0f;
                 if (w != 0.0f) {
-                    const float rho = w * (float)p.type_w[3]; const double e = g.x_alb[s] - g.x_alb[g.nbr[(size_t)d * N + s]];
+                    const float rho = w * (float)p.type_w[3]; const double e = xa - xan[d];
                     tag = rho * (float)e; tac = rho;
                     if (eafree & (1 << d)) cost += 0.5 * (double)w * p.type_w[3] * e * e;
                 }

@@ -485,34 +485,40 @@ __global__ void __launch_bounds__(256) k_gather(RowView r, PassBuffers b, float*
             int ringa[6];
 #pragma unroll
             for (int d = 0; d < 6; ++d) ringa[d] = r.anbr[(size_t)d * Acap + a];
+            // every gather below is UNCONDITIONAL (a missing neighbour reads this entry's own slot and contributes nothing): a load behind `if (av >= 0)` is a load the
+            // compiler cannot count — it drained everything in flight at each of them, one round trip per stencil slot (tools/isa_drains.py: 20 of the kernel's 23 waits)
             if (fl & F_FREE_SDF) {
                 float acc = 0.0f;
+                int avs[10];
 #pragma unroll
-                for (int c = 0; c < 10; ++c) {
-                    const int rn = slot_rev_nbr(c);
-                    const int av = rn < 0 ? a : (rn < 6 ? ringa[rn] : r.anbr[(size_t)rn * Acap + a]);
-                    if (av >= 0) acc += b.C[(size_t)c * Acap + av];
-                }
-                acc += b.treg[Acap + a] + (SQUARED ? 36.0f : -6.0f) * b.treg[a];
+                for (int c = 0; c < 10; ++c) { const int rn = slot_rev_nbr(c); avs[c] = rn < 0 ? a : (rn < 6 ? ringa[rn] : r.anbr[(size_t)rn * Acap + a]); }
+                float cv[10];
 #pragma unroll
-                for (int d = 0; d < 6; ++d) if (ringa[d] >= 0) acc += b.treg[ringa[d]];
+                for (int c = 0; c < 10; ++c) cv[c] = b.C[(size_t)c * Acap + (avs[c] >= 0 ? avs[c] : a)];
+                float tv[6];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) tv[d] = b.treg[ringa[d] >= 0 ? ringa[d] : a];
+                const float t1 = b.treg[Acap + a], t0 = b.treg[a];
+#pragma unroll
+                for (int c = 0; c < 10; ++c) if (avs[c] >= 0) acc += cv[c];
+                acc += t1 + (SQUARED ? 36.0f : -6.0f) * t0;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) if (ringa[d] >= 0) acc += tv[d];
                 osdf = acc;
             }
             if (fl & F_FREE_ALB) {
                 float acc = 0.0f;
+                float cv[4], te[6], tn[6];
 #pragma unroll
-                for (int c = 10; c < P_VOX; ++c) {
-                    const int rn = slot_rev_nbr(c);
-                    const int av = rn < 0 ? a : ringa[rn];
-                    if (av >= 0) acc += b.C[(size_t)c * Acap + av];
-                }
+                for (int c = 10; c < P_VOX; ++c) { const int rn = slot_rev_nbr(c); const int av = rn < 0 ? a : ringa[rn]; cv[c - 10] = b.C[(size_t)c * Acap + (av >= 0 ? av : a)]; }
 #pragma unroll
-                for (int d = 0; d < 6; ++d) acc += b.treg[(size_t)(2 + d) * Acap + a];
+                for (int d = 0; d < 6; ++d) { te[d] = b.treg[(size_t)(2 + d) * Acap + a]; tn[d] = b.treg[(size_t)(2 + (d ^ 1)) * Acap + (ringa[d] >= 0 ? ringa[d] : a)]; }     // tn: neighbour's edge pointing back at this entry
 #pragma unroll
-                for (int d = 0; d < 6; ++d) if (ringa[d] >= 0) {
-                    const float t = b.treg[(size_t)(2 + (d ^ 1)) * Acap + ringa[d]];     // neighbour's edge pointing back at this entry
-                    acc += SQUARED ? t : -t;
-                }
+                for (int c = 10; c < P_VOX; ++c) { const int rn = slot_rev_nbr(c); const int av = rn < 0 ? a : ringa[rn]; if (av >= 0) acc += cv[c - 10]; }
+#pragma unroll
+                for (int d = 0; d < 6; ++d) acc += te[d];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) if (ringa[d] >= 0) acc += SQUARED ? tn[d] : -tn[d];
                 oalb = acc;
             }
         }
