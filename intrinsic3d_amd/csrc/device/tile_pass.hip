@@ -55,9 +55,12 @@ __global__ void __launch_bounds__(1024) k_tile_plan(RowView r, int T, int hmax, 
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     int la[18];
+    // (all 18 neighbour slots requested before the first hash insert: interleaved with the insert loops every one of them was a round trip of its own)
+#pragma unroll
+    for (int j = 0; j < 18; ++j) la[j] = r.anbr[(size_t)tp_dir(j) * r.Acap + (in ? a : 0)];
 #pragma unroll
     for (int j = 0; j < 18; ++j) {
-        la[j] = in ? r.anbr[(size_t)tp_dir(j) * r.Acap + a] : -1;
+        if (!in) la[j] = -1;
         if (j < 12 && la[j] >= 0 && (unsigned)(la[j] - base) >= (unsigned)T) {
             unsigned h = ((unsigned)la[j] * 2654435761u) >> 20;                 // 12 bits
             for (int probes = 0; probes < 4096; ++probes) {
@@ -118,11 +121,17 @@ __global__ void __launch_bounds__(256) k_eaw_sym(RowView r, const int* __restric
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= r.A) return;
     const bool act = (r.aflags[a] & F_ACTIVE) != 0 && (!cflag || cflag[a]);
+    // three batches of unconditional loads (a missing neighbour reads this entry's own slots) instead of a weight -> neighbour -> flags -> weight chain per direction
+    float wo[6]; int nb[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) { wo[d] = r.ea_w[(size_t)d * r.Acap + a]; nb[d] = r.anbr[(size_t)d * r.Acap + a]; }
+    uint8_t nfl[6]; int ncf[6]; float wn[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) { const int n = nb[d] >= 0 ? nb[d] : a; nfl[d] = r.aflags[n]; ncf[d] = cflag ? cflag[n] : 1; wn[d] = r.ea_w[(size_t)(d ^ 1) * r.Acap + n]; }
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
-        float w = act ? r.ea_w[(size_t)d * r.Acap + a] : 0.0f;
-        const int nb = r.anbr[(size_t)d * r.Acap + a];
-        if (nb >= 0 && (r.aflags[nb] & F_ACTIVE) && (!cflag || cflag[nb])) w += r.ea_w[(size_t)(d ^ 1) * r.Acap + nb];
+        float w = act ? wo[d] : 0.0f;
+        if (nb[d] >= 0 && (nfl[d] & F_ACTIVE) && ncf[d]) w += wn[d];
         eaw_sym[(size_t)d * r.Acap + a] = w;
     }
 }

@@ -16,7 +16,7 @@ for ln in open(path):
         if 0 < s["since"] <= lim: s["lonely"] += 1
         s["since"] = 0
     elif re.search(r"s_waitcnt.*vmcnt\(\d+\)", ln): s["since"] = 0
-    if "s_endpgm" in ln: name = None
+    if ln.startswith(".Lfunc_end"): name = None          # (a kernel has several s_endpgm: early exits)
 import subprocess
 def demangle(n):
     try: return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip()[:90]
