@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_TAG = "r06-prefetch"     # bumped when k_build<true> / k_eg_tile change materially: PMC traffic / SQ counter files of older kernels are not attached
+KERNEL_TAG = "r06-batched"      # bumped when k_build<true> / k_eg_tile change materially: PMC traffic / SQ counter files of older kernels are not attached
 # issue cost of a VALU wave-instruction on gfx950 measured with tools/experiments/valu_rate.hip (profiles/r02_valu_rate.txt): cycles per instruction on one SIMD
 # cycles per wave-instruction on one SIMD BY OCCUPANCY (waves per SIMD), measured (tools/experiments/valu_rate.hip, profiles/r03_valu_rate.txt); pk = packed fp32 (v_pk_*).
 # A kernel is priced at the occupancy it actually runs at (k_build<true>: 247 VGPRs = 2 waves per SIMD), not at the 4-wave rates.
