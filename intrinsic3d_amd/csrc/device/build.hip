@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(256, WITH_J ? (BUILD_PROBE_WAVES ? BUILD_PROBE
 
 void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const FrameConst* frames, bool with_jacobian, double* cost_out, double* scratch,
                   const double* cam9, const LmState* lm) {
-    if (r.nC <= 0) return;
+    if (r.nC <= 0) { if (!with_jacobian && cost_out) (void)hipMemsetAsync(cost_out, 0, sizeof(double), st); return; }      // (a rank without rows contributes 0 to the all-reduced cost: the slot is ASSIGNED below, not zeroed by the caller)
 #ifdef I3D_COST_MULTI_PROBE
     const int blocks = with_jacobian ? (r.nC + 255) / 256 : (((r.nC + 255) / 256 + 7) / 8) * 8 * I3D_COST_MULTI_PROBE;
 #else
@@ -654,7 +654,7 @@ void launch_build(hipStream_t st, GridView g, RowView r, OptParams p, const Fram
         } else if (no_pipe) k_build<false, false, 2><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out, cam9, lm);
         else k_build<false, false, 2, true><<<blocks, 256, 0, st>>>(g, r, p, frames, cost_out, cam9, lm);
     }
-    if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr);      // cost_dst += sum
+    if (!with_jacobian) launch_reduce_partials(st, scratch, blocks, 1, cost_dst, nullptr, true);      // *cost_dst = sum (no memset in front of every candidate)
 }
 
 // nls_solver.cpp:379-394 — per-type sums of the row weights (sums[0..3]) and row counts (sums[4..7]); [8] active voxels.

@@ -72,7 +72,7 @@ void launch_gather(hipStream_t st, PassMode mode, RowView r, PassBuffers b, floa
 int  launch_gather_tail(hipStream_t st, RowView r, PassBuffers b, float* out, const float* S, const float* D2, const float* v, double* dot_partials /* or, dot_atomic: the sum itself */,
                         bool dot_atomic, const PcgState* state);   // returns #partials
 // dst[k] += sum_b partials[b*ncomp + k]: the second stage of every fp64 reduction (no same-address atomics from thousands of workgroups)
-void launch_reduce_partials(hipStream_t st, const double* partials, int nblk, int ncomp, double* dst, const PcgState* state);
+void launch_reduce_partials(hipStream_t st, const double* partials, int nblk, int ncomp, double* dst, const PcgState* state, bool assign = false);      // dst += sum (assign: dst = sum)
 void launch_shared_finalize(hipStream_t st, size_t tail_off, int K, OptParams p, const double* shared, float* out /*[NP]*/, bool tail, const float* S, const float* D2,
                             const float* v, double* dot_out, const PcgState* state);
 

@@ -31,18 +31,25 @@ namespace i3d {
 #define GRID_STRIDE(n) const int stride = gridDim.x * blockDim.x; for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += stride)
 static inline int vblocks(int n) { int b = (n + 255) / 256; return b < 1 ? 1 : (b > 2048 ? 2048 : b); }
 
-// dst[k] += sum over workgroups of partials[b * ncomp + k]   (one workgroup)
-__global__ void __launch_bounds__(1024) k_reduce_partials(const double* __restrict__ partials, int nblk, int ncomp, double* dst, const PcgState* __restrict__ state) {
+// dst[k] += (assign: =) sum over workgroups of partials[b * ncomp + k]   (one workgroup).  A thread's partials are requested eight at a time (clamped index) and added in the order
+// of the plain loop: one load and one wait per partial made this kernel nine round trips long on the cost kernel's 9 k partials.
+__global__ void __launch_bounds__(1024) k_reduce_partials(const double* __restrict__ partials, int nblk, int ncomp, double* dst, const PcgState* __restrict__ state, int assign) {
     if (state && state->done) return;
     for (int k = 0; k < ncomp; ++k) {
         double s = 0.0;
-        for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += partials[(size_t)i * ncomp + k];
+        for (int i0 = threadIdx.x; i0 < nblk; i0 += 8 * 1024) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = partials[(size_t)min(i0 + q * 1024, nblk - 1) * ncomp + k];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (i0 + q * 1024 < nblk) s += v[q];
+        }
         const double t = block_sum_d(s);
-        if (threadIdx.x == 0) dst[k] += t;
+        if (threadIdx.x == 0) dst[k] = assign ? t : dst[k] + t;
     }
 }
-void launch_reduce_partials(hipStream_t st, const double* partials, int nblk, int ncomp, double* dst, const PcgState* state) {
-    if (nblk > 0) k_reduce_partials<<<1, 1024, 0, st>>>(partials, nblk, ncomp, dst, state);
+void launch_reduce_partials(hipStream_t st, const double* partials, int nblk, int ncomp, double* dst, const PcgState* state, bool assign) {
+    if (nblk > 0) k_reduce_partials<<<1, 1024, 0, st>>>(partials, nblk, ncomp, dst, state, assign ? 1 : 0);
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------------
@@ -945,7 +952,7 @@ void launch_candidate(hipStream_t st, GridView g, RowView r, int K, float sign, 
                       double* xc_sh, double* norms2, const float* mask, double* scratch, const LmState* lm) {
     int b = vblocks(r.A + 6 * K + 9); if (b > 1024) b = 1024;
     k_candidate<<<b, 256, 0, st>>>(g, r, K, sign, step, S, xsh, xc_sdf, xc_alb, xc_sh, scratch, mask, lm);
-    launch_reduce_partials(st, scratch, b, 2, norms2, nullptr);      // (after a finished solve: stale partials into a slot nobody reads)
+    launch_reduce_partials(st, scratch, b, 2, norms2, nullptr, true);      // (after a finished solve: stale partials into a slot nobody reads)
 }
 // x <- candidate on the work list (everything else never moves), refresh the fp32 shadows
 __global__ void k_accept(GridView g, RowView r, const double* __restrict__ xc_sdf, const double* __restrict__ xc_alb, const LmState* __restrict__ lm) {

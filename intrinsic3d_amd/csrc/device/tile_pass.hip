@@ -667,7 +667,11 @@ hipError_t launch_tile_plan(hipStream_t st, RowView r, TilePlan t, void* temp, s
                if (t.n_ghost > 0) k_tile_pull_plan<512, 1536><<<t.n_ghost, 512, 0, st>>>(r, 0, t.ghost_tiles, t.lnbr, t.halo_cnt, off, src, t.overflow); }
     }
     k_iota<<<(n + 255) / 256, 256, 0, st>>>(n, t.iota);
-    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const int*)t.halo_idx, t.ext_e, (const int*)t.iota, t.ext_pos, (size_t)n, 0, 32, st);
+    // keys are list entries < A or the padding TP_NONE: sort on as many low bits as separate them (the padding must compare above every entry) — 22 or 23 bits on the bench
+    // workloads, three 8-bit passes instead of four; the stable sort leaves equal keys (and all padding) in slot order either way
+    int key_bits = 32;
+    for (int b = 1; b < 32; ++b) { const unsigned mask = (1u << b) - 1u; if ((1u << b) >= (unsigned)r.A && ((unsigned)TP_NONE & mask) >= (unsigned)r.A) { key_bits = b; break; } }
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const int*)t.halo_idx, t.ext_e, (const int*)t.iota, t.ext_pos, (size_t)n, 0, key_bits, st);
     if (e != hipSuccess) return e;
     if (t.ext_off) launch_ext_offsets(st, n, t.ext_e, r.chunk, t.ext_off);       // CSR offsets of the sorted pairs: k_pcg_step3 folds the halo sums itself (pcg_fused.hip)
     return hipGetLastError();

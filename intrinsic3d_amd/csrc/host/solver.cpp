@@ -434,7 +434,6 @@ static int count_above_dev(i3d_context* c, const float* a, const float* m, float
 static int eval_cost_launch(i3d_context* c, const OptParams& p, bool candidate, const FrameConst* frames, const double* cam9 = nullptr, const LmState* lm = nullptr) {
     GridView g = c->grid_view();
     if (candidate) { g.x_sdf = c->xc_sdf.p; g.x_alb = c->xc_alb.p; }
-    CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 16, 0, sizeof(double), c->stream));
     { TimedScope t(c, I3D_K_COST); launch_build(c->stream, g, c->row_view(), p, frames, false, c->d_scal.p + 16, c->d_partials.p, cam9, lm); }
     return allreduce(c, c->d_scal.p + 16, 1);
 }
@@ -930,7 +929,6 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
             ++c->lad_batches;
             for (int j = 0; j < B && sharded(c); ++j) { rc = allgather(c, lad_vecp(c, LV_X, j)); if (rc) return rc; }      // the candidate points are replicated: every rank needs the whole step of every system
             for (int j = 0; j < B; ++j) {      // the decision chain of every system, in ladder order; everything behind the deciding attempt returns at once
-                CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 4, 0, sizeof(double) * 2, s));
                 { TimedScope t(c, I3D_K_VECTOR);
                   launch_candidate(s, g, r, K, -1.0f, lad_vecp(c, LV_X, j), c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p, c->d_partials.p, lm);
                   launch_cand_frames(s, K, c->d_xcshared.p, c->d_frames.p, c->d_frames_cand.p, lm); }
@@ -969,7 +967,6 @@ static int lm_solve(i3d_context* c, const i3d_optimizer_config& cfg, OptParams& 
         if (ended) break;
         // candidate point (replicated: every rank needs the whole step), its keyframe constants and its cost, then the decision — all on the stream
         { int rc2 = allgather(c, c->v_x.p); if (rc2) return rc2; }
-        CTX_HIP(c, hipMemsetAsync(c->d_scal.p + 4, 0, sizeof(double) * 2, s));
         { TimedScope t(c, I3D_K_VECTOR);
           launch_candidate(s, g, r, K, -1.0f, c->v_x.p, c->v_S.p, c->d_xshared.p, c->xc_sdf.p, c->xc_alb.p, c->d_xcshared.p, c->d_scal.p + 4, c->v_mask.p, c->d_partials.p, lm);
           launch_cand_frames(s, K, c->d_xcshared.p, c->d_frames.p, c->d_frames_cand.p, lm); }
