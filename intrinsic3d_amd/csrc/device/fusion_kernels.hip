@@ -302,11 +302,29 @@ __global__ void k_correct(FusionTable t, long long m, float voxel_size, const un
     const float old_f = c_sdf[c];
     const double sdf = (double)old_f, sgn = sdf >= 0.0 ? 1.0 : -1.0;
     float res = old_f; bool updated = false; int n = 0;
-    for (int k = -1; k <= 1; ++k) for (int j = -1; j <= 1; ++j) for (int i = -1; i <= 1; ++i) {
+    // the 26 neighbours in THREE batches of unconditional loads (a missing neighbour reads this voxel's own slots): table entries, their visit positions, then the value each one
+    // contributes — current sweep for voxels visited earlier, previous sweep otherwise.  One neighbour at a time this was a chain of three dependent loads behind a condition, 78
+    // round trips per voxel and sweep (tools/isa_drains.py).  The compare-and-keep-the-last loop below is unchanged.
+    int nbv[26]; float val[26];
+#pragma unroll
+    for (int q = 0; q < 26; ++q) nbv[q] = nbr[(long long)q * m + c];
+    {
+        int pos[26];
+#pragma unroll
+        for (int q = 0; q < 26; ++q) pos[q] = c_pos[nbv[q] >= 0 ? nbv[q] : (int)c];
+#pragma unroll
+        for (int q = 0; q < 26; ++q) { const int e = nbv[q] >= 0 ? nbv[q] : (int)c; val[q] = (pos[q] < v ? (const float*)c_cur : c_sdf)[e]; }
+    }
+#pragma unroll
+    for (int k = -1; k <= 1; ++k)
+#pragma unroll
+    for (int j = -1; j <= 1; ++j)
+#pragma unroll
+    for (int i = -1; i <= 1; ++i) {
         if (k == 0 && j == 0 && i == 0) continue;
-        const int nb = nbr[(long long)n * m + c]; ++n;
+        const int nb = nbv[n]; const float vnb = val[n]; ++n;
         if (nb < 0) continue;
-        const double sdf_nb = (double)(c_pos[nb] < v ? c_cur[nb] : c_sdf[nb]), sgn_nb = sdf_nb >= 0.0 ? 1.0 : -1.0;
+        const double sdf_nb = (double)vnb, sgn_nb = sdf_nb >= 0.0 ? 1.0 : -1.0;
         const float dx = cx - (float)(gx + i) * voxel_size, dy = cy - (float)(gy + j) * voxel_size, dz = cz - (float)(gz + k) * voxel_size;
         const double dist_nb = sdf_nb + sgn_nb * (double)sqrtf(dx * dx + (dy * dy + dz * dz));
         if (fabs(dist_nb) < fabs(sdf) && sgn == sgn_nb) { res = (float)dist_nb; updated = true; }
